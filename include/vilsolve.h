@@ -1,0 +1,295 @@
+/*
+ * vilsolve.h -- C-ABI of the MI355X-native sliding-window factor-graph backend.
+ *
+ * This is the drop-in boundary for ONE hot path of mVIL-Fusion:
+ *     void Estimator::optimization()        vils_estimator/src/estimator.cpp:1124-1687
+ * and for the per-factor surface it is built on,
+ *     bool ceres::CostFunction::Evaluate(double const* const* parameters,
+ *                                        double* residuals, double** jacobians) const
+ *     (imu_factor.h:19, projection_td_factor.cpp:34, projection_factor.cpp:21,
+ *      marginalization_factor.cpp:352, lidar_backend.h:45/107, lidar_mapping/src/lidarFactor.hpp:12-138).
+ *
+ * Everything is plain-old-data, caller-owned, fp64 HOST pointers.  No pointer-identity semantics:
+ * the reference's "address -> parameter block" maps (marginalization_factor.cpp:100,106) are
+ * replaced by explicit (kind, index) block ids.
+ *
+ * Conventions (all from the reference):
+ *   pose block      = [px py pz qx qy qz qw]           estimator.cpp:920-927 (Hamilton, body->world)
+ *   speed-bias block= [vx vy vz bax bay baz bgx bgy bgz]  estimator.cpp:929-939
+ *   tangent update  = p += d[0:3]; q = normalize(q (x) [1, d[3:6]/2])   pose_local_parameterization.cpp:3-18
+ *   residual order of the IMU factor = [dp dtheta dv dba dbg]  parameters.h:80-87
+ *   all Jacobian blocks are ROW-MAJOR, num_residuals x GLOBAL block size (7 for poses: the 7th
+ *   column is 0 for analytic factors, raw d/dqw for the two AutoDiff factors).
+ */
+#ifndef VILSOLVE_H
+#define VILSOLVE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIL_ABI_VERSION 1
+
+/* ---- sizes (parameters.h:73-78) ------------------------------------------------------------ */
+#define VIL_SIZE_POSE      7
+#define VIL_SIZE_SPEEDBIAS 9
+#define VIL_IMU_CONST      287   /* doubles per IMU factor, layout below */
+#define VIL_VIS_CONST      14    /* doubles per visual factor, layout below */
+#define VIL_EDGE_CONST     9     /* cp(3) a(3) b(3)            lidarFactor.hpp:12-55  */
+#define VIL_PLANE_CONST    7     /* cp(3) n(3) d               lidarFactor.hpp:106-138 */
+#define VIL_ICP_CONST      10    /* ta tb tc td ti tj PIJ(3) s lidar_backend.h:97-184 */
+#define VIL_LPS_CONST      7     /* tl tr tk q(x y z w)        lidar_backend.h:35-95  */
+#define VIL_MAX_TRACE      64
+
+/* IMU constants, per factor (integration_base.h members consumed by imu_factor.h:19-181):
+ *   [0:3)   delta_p        [3:7) delta_q (x y z w)   [7:10) delta_v
+ *   [10:13) linearized_ba  [13:16) linearized_bg     [16]   sum_dt
+ *   [17:26) dp_dba  [26:35) dp_dbg  [35:44) dq_dbg  [44:53) dv_dba  [53:62) dv_dbg   (3x3 row-major)
+ *   [62:287) covariance 15x15 row-major (symmetric)
+ * Visual constants, per factor (projection_td_factor.cpp:6-19; row already has ROW/2 subtracted):
+ *   [0:3) pts_i (z=1)  [3:6) pts_j  [6:8) vel_i  [8:10) vel_j  [10] td_i  [11] td_j  [12] row_i  [13] row_j
+ */
+
+typedef enum {
+    VIL_OK = 0,
+    VIL_ERR_INVALID_ARGUMENT = -1,
+    VIL_ERR_DEVICE = -2,           /* HIP runtime error / no device / extension missing */
+    VIL_ERR_NON_FINITE = -3,       /* NaN/Inf in cost or step; state left unchanged      */
+    VIL_ERR_NOT_POSITIVE_DEFINITE = -4, /* reduced system not PD after max mu             */
+    VIL_ERR_COMM = -5,             /* RCCL failure                                        */
+    VIL_ERR_UNSUPPORTED = -6
+} vil_status;
+
+typedef enum {
+    VIL_FACTOR_IMU = 0,     /* A4  imu_factor.h:19                   r 15, J 15x7|15x9|15x7|15x9 */
+    VIL_FACTOR_VISUAL = 1,  /* A6/A7 projection(_td)_factor.cpp      r 2,  J 2x7|2x7|2x7|2x1|2x1 */
+    VIL_FACTOR_PRIOR = 2,   /* A8  marginalization_factor.cpp:352    r n,  J n x sum(global)     */
+    VIL_FACTOR_ICP = 3,     /* A11 lidar_backend.h:107               r 3,  J 3x7 x4              */
+    VIL_FACTOR_LPS = 4,     /* A12 lidar_backend.h:45                r 3,  J 3x7 x2              */
+    VIL_FACTOR_EDGE = 5,    /* A14 lidarFactor.hpp:12  (window form) r 3,  J 3x7                 */
+    VIL_FACTOR_PLANE = 6,   /* A14 lidarFactor.hpp:106 (window form) r 1,  J 1x7                 */
+    VIL_FACTOR_NCLASS = 7
+} vil_factor_class;
+
+/* doubles of residual / Jacobian written per factor by vil_eval_factors (prior: n, n*sum_global) */
+#define VIL_IMU_NR 15
+#define VIL_IMU_NJ (15 * (7 + 9 + 7 + 9))
+#define VIL_VIS_NR 2
+#define VIL_VIS_NJ (2 * (7 + 7 + 7 + 1 + 1))
+#define VIL_ICP_NR 3
+#define VIL_ICP_NJ (3 * 7 * 4)
+#define VIL_LPS_NR 3
+#define VIL_LPS_NJ (3 * 7 * 2)
+#define VIL_EDGE_NR 3
+#define VIL_EDGE_NJ (3 * 7)
+#define VIL_PLANE_NR 1
+#define VIL_PLANE_NJ 7
+
+typedef enum { VIL_BLK_POSE = 0, VIL_BLK_SPEEDBIAS = 1, VIL_BLK_EX = 2, VIL_BLK_TD = 3 } vil_block_kind;
+typedef enum { VIL_LOSS_NONE = 0, VIL_LOSS_CAUCHY = 1, VIL_LOSS_HUBER = 2 } vil_loss_kind;
+typedef enum { VIL_MARGIN_OLD = 0, VIL_MARGIN_SECOND_NEW = 1 } vil_marg_flag;
+
+typedef enum {
+    VIL_TERM_NONE = 0,
+    VIL_TERM_FUNCTION_TOLERANCE = 1,
+    VIL_TERM_GRADIENT_TOLERANCE = 2,
+    VIL_TERM_PARAMETER_TOLERANCE = 3,
+    VIL_TERM_MAX_ITERATIONS = 4,
+    VIL_TERM_MAX_TIME = 5,
+    VIL_TERM_FAILURE = 6
+} vil_termination;
+
+/* ---- state: the para_* arrays of estimator.h:110-116 ---------------------------------------- */
+typedef struct vil_state {
+    int32_t K;            /* frames in the window (reference: WINDOW_SIZE+1 = 7)  */
+    int32_t L;            /* landmarks (reference: f_manager.getFeatureCount())   */
+    double* pose;         /* K x 7   para_Pose                                    */
+    double* speedbias;    /* K x 9   para_SpeedBias                               */
+    double* ex_pose;      /* 7       para_Ex_Pose[0]  (tic, qic)                  */
+    double* td;           /* 1       para_Td[0]                                   */
+    double* inv_depth;    /* L       para_Feature                                 */
+} vil_state;
+
+/* ---- marginalisation prior: MarginalizationInfo's linearised output ------------------------- */
+typedef struct vil_prior {
+    int32_t n;                 /* residual count = sum of LOCAL sizes of kept blocks (marginalization_factor.cpp:199) */
+    int32_t nblk;              /* kept parameter blocks (keep_block_size.size())                */
+    const int32_t* blk_kind;   /* nblk  vil_block_kind                                          */
+    const int32_t* blk_index;  /* nblk  frame index for POSE / SPEEDBIAS (already shifted i->i-1)*/
+    const int32_t* blk_col;    /* nblk  first column of the block in J0 (keep_block_idx - m)    */
+    const double* x0;          /* concatenated GLOBAL-size linearisation points (keep_block_data)*/
+    const double* J0;          /* n x n COLUMN-major  linearized_jacobians                      */
+    const double* r0;          /* n                  linearized_residuals                       */
+} vil_prior;
+
+/* ---- one window's factor graph (everything estimator.cpp:1126-1398 hands to ceres::Problem) -- */
+typedef struct vil_problem {
+    int32_t K, L;
+    /* constancy (ceres SetParameterBlockConstant; estimator.cpp:1157,1220,1238,1369-1370) */
+    const uint8_t* pose_const;      /* K or NULL */
+    const uint8_t* sb_const;        /* K or NULL */
+    const uint8_t* lm_const;        /* L or NULL   (lidar_depth_flag) */
+    int32_t ex_const;               /* !ESTIMATE_EXTRINSIC */
+    int32_t td_const;               /* 1 => td not optimised */
+    int32_t use_td;                 /* 1: ProjectionTdFactor (A6), 0: ProjectionFactor (A7) */
+
+    /* IMU factors (estimator.cpp:1179-1186); factors with sum_dt > 10 are skipped by the library */
+    int32_t n_imu;
+    const int32_t* imu_i;           /* n_imu  frame i (j = imu_j) */
+    const int32_t* imu_j;           /* n_imu */
+    const double* imu_const;        /* n_imu x VIL_IMU_CONST */
+
+    /* visual factors, grouped by landmark in landmark order (estimator.cpp:1189-1242) */
+    int32_t n_vis;
+    const int32_t* vis_i;           /* n_vis  anchor frame (start_frame)   */
+    const int32_t* vis_j;           /* n_vis  observing frame              */
+    const int32_t* vis_l;           /* n_vis  landmark (feature_index), non-decreasing */
+    const double* vis_const;        /* n_vis x VIL_VIS_CONST */
+
+    /* prior (estimator.cpp:1171-1177); prior.n == 0 => none */
+    vil_prior prior;
+
+    /* LiDAR scan-to-scan relative constraints, constraint_mode==3 only (estimator.cpp:1371-1396) */
+    int32_t n_icp;
+    const int32_t* icp_ids;         /* n_icp x 4  (a,b,c,d) */
+    const double* icp_const;        /* n_icp x VIL_ICP_CONST */
+    /* LiDAR local-map rotation priors (estimator.cpp:1298-1324) */
+    int32_t n_lps;
+    const int32_t* lps_ids;         /* n_lps x 2  (l,r) */
+    const double* lps_const;        /* n_lps x VIL_LPS_CONST */
+
+    /* extended mode: point-level LiDAR factors attached to window poses */
+    int32_t n_edge;
+    const int32_t* edge_pose;       /* n_edge */
+    const double* edge_const;       /* n_edge x VIL_EDGE_CONST, cp in the LiDAR frame */
+    int32_t n_plane;
+    const int32_t* plane_pose;      /* n_plane */
+    const double* plane_const;      /* n_plane x VIL_PLANE_CONST */
+    double q_lb[4];                 /* RLB as quaternion (x y z w): p_l = RLB p_b + TLB (estimator.cpp:1289-1290) */
+    double t_lb[3];                 /* TLB */
+
+    /* constants from parameters.h / the yaml */
+    double G[3];                    /* gravity (0,0,g)   parameters.cpp:32,103            */
+    double sqrt_info_px;            /* FOCAL_LENGTH/2 = 230   estimator.cpp:18-19         */
+    double tr_over_row;             /* TR/ROW (0 when not rolling shutter)                */
+} vil_problem;
+
+/* ---- solver options: ceres::Solver::Options as used at estimator.cpp:1400-1411 --------------- */
+typedef struct vil_options {
+    int32_t max_iterations;         /* NUM_ITERATIONS (30)                                 */
+    double max_time_s;              /* SOLVER_TIME (0.05); <= 0 disables (parity runs)     */
+    double function_tolerance;      /* 1e-6  */
+    double gradient_tolerance;      /* 1e-10 */
+    double parameter_tolerance;     /* 1e-8  */
+    double initial_radius;          /* 1e4   */
+    double max_radius;              /* 1e16  */
+    double min_relative_decrease;   /* 1e-3  */
+    double min_mu, max_mu;          /* 1e-8, 1 */
+    int32_t jacobi_scaling;         /* 1     */
+    int32_t visual_loss;  double visual_loss_scale;   /* Cauchy 1.0  estimator.cpp:1129 */
+    int32_t lidar_loss;   double lidar_loss_scale;    /* Huber 0.1   localMapping.cpp:597 */
+    int32_t rel_loss;     double rel_loss_scale;      /* ICP/LPS: Cauchy 1.0              */
+    int32_t autodiff_quirk;         /* 1 (faithful): ICP/LPS pose Jacobian = raw d/d(qx,qy,qz) */
+    int32_t precision;              /* 0: fp64 everywhere; 1: fp32 factor evaluation, fp64 accumulation */
+} vil_options;
+
+typedef struct vil_summary {
+    int32_t iterations;             /* trust-region iterations executed (successful + unsuccessful) */
+    int32_t successful_steps;
+    int32_t termination;            /* vil_termination */
+    double initial_cost, final_cost;
+    double t_prepare_ms, t_solve_ms, t_readback_ms;   /* phase timings (estimator.cpp:1168,1412-1417) */
+    double cost_trace[VIL_MAX_TRACE];                 /* cost after each iteration   */
+    double radius_trace[VIL_MAX_TRACE];
+} vil_summary;
+
+/* ---- marginalisation request (estimator.cpp:1484-1683) --------------------------------------- */
+typedef struct vil_marg_spec {
+    int32_t flag;                   /* vil_marg_flag */
+    /* MARGIN_OLD only: the ICP / LPS constraint touching frame 0 (-1 = none; estimator.cpp:1311-1317,1381-1389) */
+    int32_t icp_marg;               /* index into problem.icp_* */
+    int32_t lps_marg;               /* index into problem.lps_* */
+    int32_t threads;                /* CPU oracle only: NUM_THREADS (4) */
+} vil_marg_spec;
+
+/* caller-provided storage for the new prior; sizes from vil_prior_capacity(K) */
+typedef struct vil_prior_out {
+    int32_t n, nblk, m;             /* m = marginalised dimension (diagnostic) */
+    int32_t* blk_kind;              /* capacity nblk_max */
+    int32_t* blk_index;
+    int32_t* blk_col;
+    double* x0;                     /* capacity 7*K + 9 + 7 + 1 ... see vil_prior_capacity */
+    double* J0;                     /* n_max x n_max, written n x n column-major */
+    double* r0;
+    double* A;                      /* optional n_max x n_max: reduced information matrix (J0^T J0 up to eps-truncation) */
+    double* b;                      /* optional n_max */
+} vil_prior_out;
+
+typedef struct vil_device_cfg {
+    int32_t device;                 /* HIP device ordinal                         */
+    int32_t rank, world;            /* data-parallel shard of the factor set      */
+    int32_t reserved;
+} vil_device_cfg;
+
+typedef struct vil_ctx vil_ctx;
+
+/* ---- entry points ----------------------------------------------------------------------------- */
+int vil_abi_version(void);
+const char* vil_strerror(int status);
+
+/* context: device buffers, stream, (optional) RCCL communicator. Non-reentrant per ctx
+ * (the reference never re-enters optimization(): estimator_node.cpp:388,352-355). */
+int vil_create(const vil_device_cfg* cfg, vil_ctx** out);
+void vil_destroy(vil_ctx* ctx);
+
+/* multi-GPU: rank 0 calls vil_comm_unique_id, the 128 bytes are broadcast by the host launcher
+ * (torch.distributed / MPI / anything), every rank calls vil_comm_init. */
+int vil_comm_unique_id(void* id128);
+int vil_comm_init(vil_ctx* ctx, const void* id128, int rank, int world);
+
+/* replaces estimator.cpp:1126-1419 (build ceres::Problem ... ceres::Solve): state is updated in
+ * place on success and left UNCHANGED on any error. */
+int vil_solve(vil_ctx* ctx, const vil_problem* problem, vil_state* state_inout,
+              const vil_options* options, vil_summary* summary);
+
+/* resident variant: upload once, solve many times without host<->device traffic of the factor tables */
+int vil_upload(vil_ctx* ctx, const vil_problem* problem, const vil_state* state);
+int vil_solve_resident(vil_ctx* ctx, const vil_options* options, vil_summary* summary);
+int vil_reset_state(vil_ctx* ctx);                       /* restore the uploaded state on device */
+int vil_download_state(vil_ctx* ctx, vil_state* state_out);
+
+/* replaces ceres::CostFunction::Evaluate for a whole factor class at once: raw (no loss) residuals
+ * and row-major global-size Jacobian blocks, factor-major, in the caller's factor order. */
+int vil_eval_factors(vil_ctx* ctx, const vil_problem* problem, const vil_state* state,
+                     int factor_class, double* residuals, double* jacobians);
+
+/* one linearisation of the whole window: robustified cost and the Schur-reduced normal equations
+ * S (D x D row-major, D = vil_reduced_dim(K)), g (D), at `state`, with trust-region damping mu = 0
+ * and no Jacobi scaling.  Diagnostic / parity surface of the hot loop's sweep + reduction. */
+int vil_linearize(vil_ctx* ctx, const vil_problem* problem, const vil_state* state,
+                  const vil_options* options, double* cost, double* S, double* g);
+
+/* replaces estimator.cpp:1486-1616 / 1624-1681 (MarginalizationInfo: preMarginalize + marginalize
+ * + getParameterBlocks with the i->i-1 address shift done as an index remap). */
+int vil_marginalize(vil_ctx* ctx, const vil_problem* problem, const vil_state* state,
+                    const vil_options* options, const vil_marg_spec* spec, vil_prior_out* out);
+
+/* host-side helpers of the boundary */
+int vil_reduced_dim(int K);                               /* 15K + 7 */
+void vil_prior_capacity(int K, int* n_max, int* nblk_max, int* x0_max);
+void vil_default_options(vil_options* o);
+/* estimator.cpp:960-1011: yaw/translation gauge fix of double2vector(), applied to a solved state
+ * given the pre-solve pose of frame 0 (Rs[0], Ps[0]). */
+int vil_gauge_fix(const double* pose0_before, vil_state* solved);
+/* partition of the factor set for rank r of w: visual by landmark owner, LiDAR points in
+ * contiguous pose-sorted chunks; fills [begin,end) ranges.  Pure host logic. */
+int vil_shard_ranges(const vil_problem* problem, int rank, int world,
+                     int32_t* lm_begin, int32_t* lm_end, int32_t* edge_begin, int32_t* edge_end,
+                     int32_t* plane_begin, int32_t* plane_end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VILSOLVE_H */

@@ -1,0 +1,140 @@
+"""Loader + thin Python calling layer over the C-ABI (include/vilsolve.h).
+
+`Backend` drives any shared library that exports the vilsolve entry points under a prefix:
+  * prefix "vil_"  -> csrc/libvilsolve.so, the HIP product (needs a GPU; fails loudly without one)
+  * prefix "orc_"  -> oracle/liboracle.so, the CPU restatement -- constructed ONLY by tests/,
+                      __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+There is no CPU fallback inside the product path: if libvilsolve.so is missing or no HIP device is
+present, `load_vilsolve()` / `Backend.create()` raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvilsolve.so")
+
+STATUS = {0: "ok", -1: "invalid argument", -2: "device error", -3: "non-finite", -4: "not positive definite", -5: "comm error", -6: "unsupported"}
+
+
+class VilError(RuntimeError):
+    def __init__(self, what, status):
+        super().__init__("%s failed: status %d (%s)" % (what, status, STATUS.get(status, "?")))
+        self.status = status
+
+
+def load_vilsolve(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise RuntimeError("HIP extension %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback" % path)
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+_dp = C.POINTER(C.c_double)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Backend:
+    def __init__(self, cdll, prefix, device=0, rank=0, world=1):
+        self.lib, self.prefix = cdll, prefix
+        self.ctx = None
+        self.has_ctx = prefix == "vil_"
+        if self.has_ctx:
+            cfg = abi.VilDeviceCfg(device, rank, world, 0)
+            ctx = C.c_void_p()
+            f = self.lib.vil_create
+            f.restype = C.c_int
+            st = f(C.byref(cfg), C.byref(ctx))
+            if st != 0:
+                raise VilError("vil_create", st)
+            self.ctx = ctx
+
+    def close(self):
+        if self.has_ctx and self.ctx is not None:
+            self.lib.vil_destroy.restype = None
+            self.lib.vil_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        f = getattr(self.lib, self.prefix + name)
+        f.restype = C.c_int
+        if self.has_ctx:
+            args = (self.ctx,) + args
+        st = f(*args)
+        if st != 0:
+            raise VilError(self.prefix + name, st)
+        return st
+
+    # -- Evaluate()-compatible per-class residuals and Jacobians
+    def eval_factors(self, w, cls, jac=True):
+        nr, nj = w.eval_sizes(cls)
+        r = np.zeros(max(nr, 1)); J = np.zeros(max(nj, 1))
+        p, s = w.c_problem(), w.c_state()
+        self._call("eval_factors", C.byref(p), C.byref(s), C.c_int(cls), _ptr(r), _ptr(J) if jac else C.cast(None, _dp))
+        return r[:nr], J[:nj]
+
+    def linearize(self, w, opts=None):
+        opts = opts or abi.default_options()
+        D = w.D
+        cost = C.c_double(0.0); S = np.zeros((D, D)); g = np.zeros(D)
+        p, s = w.c_problem(), w.c_state()
+        self._call("linearize", C.byref(p), C.byref(s), C.byref(opts), C.byref(cost), _ptr(S), _ptr(g))
+        return cost.value, S, g
+
+    def solve(self, w, opts=None):
+        """In place on w's state arrays (like Estimator::optimization() on para_*). Returns VilSummary."""
+        opts = opts or abi.default_options()
+        p, s = w.c_problem(), w.c_state()
+        summ = abi.VilSummary()
+        self._call("solve", C.byref(p), C.byref(s), C.byref(opts), C.byref(summ))
+        return summ
+
+    def marginalize(self, w, flag=abi.MARGIN_OLD, icp_marg=-1, lps_marg=-1, opts=None, threads=4):
+        opts = opts or abi.default_options()
+        p, s = w.c_problem(), w.c_state()
+        spec = abi.VilMargSpec(flag, icp_marg, lps_marg, threads)
+        out = abi.PriorOut(w.K)
+        self._call("marginalize", C.byref(p), C.byref(s), C.byref(opts), C.byref(spec), C.byref(out.c))
+        return out
+
+    def gauge_fix(self, pose0_before, w):
+        f = getattr(self.lib, self.prefix + "gauge_fix")
+        f.restype = C.c_int
+        s = w.c_state()
+        p0 = abi.f64(pose0_before)
+        st = f(_ptr(p0), C.byref(s))
+        if st != 0:
+            raise VilError("gauge_fix", st)
+
+    # -- resident API (HIP library only)
+    def upload(self, w):
+        p, s = w.c_problem(), w.c_state()
+        self._call("upload", C.byref(p), C.byref(s))
+
+    def solve_resident(self, opts=None):
+        opts = opts or abi.default_options()
+        summ = abi.VilSummary()
+        self._call("solve_resident", C.byref(opts), C.byref(summ))
+        return summ
+
+    def reset_state(self):
+        self._call("reset_state")
+
+    def download_state(self, w):
+        s = w.c_state()
+        self._call("download_state", C.byref(s))
+
+
+def open_vilsolve(device=0, rank=0, world=1):
+    return Backend(load_vilsolve(), "vil_", device, rank, world)
