@@ -1,0 +1,76 @@
+// Device-visible problem description shared by all kernels of libvilsolve (passed by value).
+// Reduced ("camera") ordering, identical to the oracle's:  pose k -> 6k ; ex -> 6K ; td -> 6K+6 ;
+// speed-bias k -> 6K+7+9k ;  D = 15K+7 ;  NV = 6K+7 is the sub-space visual factors touch.
+#pragma once
+#include <stdint.h>
+
+#define VIL_THREADS 256
+#define VIL_VCHUNK_LM 8       // landmarks per visual workgroup
+#define VIL_VCHUNK_F 128      // factors per visual workgroup (LDS staging bound)
+#define VIL_STEP_THREADS 1024
+
+struct SysBuf {       // one linearisation of the window (double-buffered: current / candidate)
+    double* S;        // D x D  Schur-reduced H (upper triangle accumulated by the sweep, mirrored by the step kernel)
+    double* gred;     // D      Schur-reduced gradient
+    double* bc;       // D      un-reduced gradient J_c^T r
+    double* diag;     // D      diagonal of the un-reduced H_cc
+    double* hll;      // L      J_l^T J_l
+    double* bl;       // L      J_l^T r
+    double* invp;     // L      1 / (hll + mu dl^2 / Sl^2), 0 for constant landmarks
+    double* eA;       // L x 13 e_l on [anchor pose(6) | ex(6) | td(1)]
+    double* eO;       // F x 6  e_l on the observing pose of each factor
+    double* cost;     // 1
+};
+
+struct Ctl {          // trust-region state, lives in device memory, owned by the step kernel
+    int cur, iter, done, term, first, resweep, reuse, nsucc, invalid_run, status, lin_mode, pad;
+    double radius, mu, cost_cur, model_change, alpha, dogleg_norm, initial_cost, cand_cost;
+    double cost_trace[64], radius_trace[64];
+};
+
+struct SolveOpts {
+    int max_iterations, jacobi_scaling, visual_loss, lidar_loss, rel_loss, autodiff_quirk;
+    double function_tolerance, gradient_tolerance, parameter_tolerance, max_radius, min_relative_decrease, min_mu, max_mu;
+    double visual_loss_scale, lidar_loss_scale, rel_loss_scale;
+};
+
+struct DevP {
+    int K, L, D, NV, NS;
+    // constancy
+    const uint8_t* pose_const; const uint8_t* sb_const; const uint8_t* lm_const;
+    int ex_const, td_free, use_td;
+    // state double buffer: [pose 7K | sb 9K | ex 7 | td 1 | lam L]
+    double* x[2];
+    // visual (SoA: component k of factor f at vis_c[k*vis_stride + f])
+    int n_vis, vis_stride, n_vchunk;
+    const double* vis_c; const int* vis_i; const int* vis_j; const int* vis_l;
+    const int* lm_start;      // L+1
+    const int* vchunk;        // n_vchunk x 2 landmark ranges
+    // LiDAR points, sorted by pose; chunk = (start, count, pose)
+    int n_plane, pl_stride, n_pchunk; const double* pl_c; const int* pchunk;
+    int n_edge, ed_stride, n_echunk; const double* ed_c; const int* echunk;
+    double Rbl[9], tbl[3];
+    // IMU
+    int n_imu; const double* imu_c; const double* imu_U; const int* imu_i; const int* imu_j;
+    // prior
+    int pn, pnblk; const int* pblk_kind; const int* pblk_index; const int* pblk_col; const int* pblk_xoff; const int* pmap;
+    const double* px0; const double* pJ0; const double* pr0; double* pH; double* pg0; double* pc0;
+    // ICP / LPS
+    int n_icp, n_lps; const int* icp_ids; const double* icp_c; const int* lps_ids; const double* lps_c;
+    double G[3], sqrt_info, k_tr;
+    // linear system + solver work space
+    SysBuf sys[2];
+    double* Sl; double* Sc; double* dc; double* dl; double* gradc; double* gradl; double* gnc; double* gnl;
+    double* M; double* stepc; double* stepl; double* tmpc; double* tmpl;
+    Ctl* ctl;
+};
+
+__host__ __device__ inline int xo_pose(const DevP& P, int k) { return 7 * k; }
+__host__ __device__ inline int xo_sb(const DevP& P, int k) { return 7 * P.K + 9 * k; }
+__host__ __device__ inline int xo_ex(const DevP& P) { return 16 * P.K; }
+__host__ __device__ inline int xo_td(const DevP& P) { return 16 * P.K + 7; }
+__host__ __device__ inline int xo_lam(const DevP& P) { return 16 * P.K + 8; }
+__host__ __device__ inline int col_pose(const DevP& P, int k) { return 6 * k; }
+__host__ __device__ inline int col_ex(const DevP& P) { return 6 * P.K; }
+__host__ __device__ inline int col_td(const DevP& P) { return 6 * P.K + 6; }
+__host__ __device__ inline int col_sb(const DevP& P, int k) { return 6 * P.K + 7 + 9 * k; }

@@ -1,0 +1,83 @@
+// Device-side small linear algebra for the gfx950 kernels (fp64, registers only).
+// Conventions follow the reference: Hamilton quaternions stored [x y z w] in parameter blocks
+// (estimator.cpp:920-927), R(q) rotates body->world, right-multiplicative tangent
+// (pose_local_parameterization.cpp:3-18).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace vd {
+
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// row-major 3x3 in registers
+struct M3 { double m[9]; };
+__device__ __forceinline__ V3 mul(const M3& A, V3 v) {
+    return {A.m[0] * v.x + A.m[1] * v.y + A.m[2] * v.z, A.m[3] * v.x + A.m[4] * v.y + A.m[5] * v.z, A.m[6] * v.x + A.m[7] * v.y + A.m[8] * v.z};
+}
+__device__ __forceinline__ V3 mulT(const M3& A, V3 v) {  // A^T v
+    return {A.m[0] * v.x + A.m[3] * v.y + A.m[6] * v.z, A.m[1] * v.x + A.m[4] * v.y + A.m[7] * v.z, A.m[2] * v.x + A.m[5] * v.y + A.m[8] * v.z};
+}
+// row vector times matrix: (v^T A)^T == A^T v
+__device__ __forceinline__ V3 rowmul(V3 v, const M3& A) { return mulT(A, v); }
+__device__ __forceinline__ V3 rowmulT(V3 v, const M3& A) { return mul(A, v); }  // v^T A^T
+
+// unit quaternion [x y z w] -> rotation matrix
+__device__ __forceinline__ M3 quatR(const double* q) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    M3 R;
+    R.m[0] = 1 - (tyy + tzz); R.m[1] = txy - twz; R.m[2] = txz + twy;
+    R.m[3] = txy + twz; R.m[4] = 1 - (txx + tzz); R.m[5] = tyz - twx;
+    R.m[6] = txz - twy; R.m[7] = tyz + twx; R.m[8] = 1 - (txx + tyy);
+    return R;
+}
+__device__ __forceinline__ M3 loadM3(const double* p) { M3 R; for (int i = 0; i < 9; ++i) R.m[i] = p[i]; return R; }
+
+// quaternions as (w, x, y, z) value structs for the IMU / prior algebra
+struct Q4 { double w, x, y, z; };
+__device__ __forceinline__ Q4 qload(const double* p /*x y z w*/) { return {p[3], p[0], p[1], p[2]}; }
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+    return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ Q4 qinv(Q4 q) {  // conjugate / squared norm (Eigen::Quaternion::inverse)
+    const double n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    const double s = 1.0 / n2;
+    return {q.w * s, -q.x * s, -q.y * s, -q.z * s};
+}
+__device__ __forceinline__ V3 qrot(Q4 q, V3 v) {
+    V3 u{q.x, q.y, q.z};
+    V3 uv = cross(u, v);
+    uv = uv + uv;
+    return v + q.w * uv + cross(u, uv);
+}
+
+// wave64 butterfly sum: every lane ends with the total
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// robust loss: rho(s), rho'(s) for ceres CauchyLoss(a)/HuberLoss(a). Both have rho'' <= 0, so the
+// corrector of marginalization_factor.cpp:37-67 reduces to r <- sqrt(rho') r, J <- sqrt(rho') J.
+__device__ __forceinline__ void loss_eval(int kind, double a, double s, double& rho, double& rho1) {
+    if (kind == 1) {
+        const double b = a * a, c = 1.0 / b, sum = 1.0 + s * c;
+        rho = b * log(sum); rho1 = 1.0 / sum;
+    } else if (kind == 2) {
+        const double b = a * a;
+        if (s > b) { const double r = sqrt(s); rho = 2.0 * a * r - b; rho1 = a / r; }
+        else { rho = s; rho1 = 1.0; }
+    } else { rho = s; rho1 = 1.0; }
+}
+
+}  // namespace vd

@@ -1,0 +1,555 @@
+// libvilsolve.so -- C-ABI (include/vilsolve.h) over the gfx950 kernels.
+// Replaces, for mVIL-Fusion's Estimator::optimization() (estimator.cpp:1124-1687), the ceres::Problem
+// construction + ceres::Solve + MarginalizationInfo machinery.  No CPU fallback: every compute entry
+// point needs a HIP device and returns VIL_ERR_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/vilsolve.h"
+#include "vil_dev.hpp"
+#include "vil_sweep.hpp"
+#include "vil_eval.hpp"
+#include "vil_step.hpp"
+#include "vil_marg.hpp"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[vilsolve] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return VIL_ERR_DEVICE; } } while (0)
+
+namespace {
+
+struct Arena {                     // one device allocation per uploaded window, mirrored by a host staging image
+    std::vector<char> h;
+    char* d = nullptr;
+    size_t cap = 0;
+    size_t take(size_t bytes) { size_t o = (h.size() + 255) & ~size_t(255); h.resize(o + bytes, 0); return o; }
+    template <class T> T* host(size_t off) { return reinterpret_cast<T*>(h.data() + off); }
+    template <class T> T* dev(size_t off) const { return reinterpret_cast<T*>(d + off); }
+};
+
+}  // namespace
+
+struct vil_ctx {
+    int device = 0, rank = 0, world = 1;
+    hipStream_t stream = nullptr;
+    Arena ar;
+    DevP P;                        // device pointers
+    bool uploaded = false;
+    int K = 0, L = 0, D = 0, NS = 0;
+    size_t off_x0 = 0;             // backup of the uploaded state (device)
+    double* d_x0 = nullptr;
+    std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
+    int n_blocks_sweep = 0;
+    size_t lds_sweep = 0;
+    int* d_status = nullptr;
+    Ctl* h_ctl = nullptr;          // pinned
+    double* h_pin = nullptr;       // pinned scratch
+    size_t h_pin_bytes = 0;
+    std::vector<int> prior_joff;
+    MargWork marg;
+};
+
+static SolveOpts to_dev_opts(const vil_options* o) {
+    SolveOpts s;
+    s.max_iterations = o->max_iterations; s.jacobi_scaling = o->jacobi_scaling;
+    s.visual_loss = o->visual_loss; s.lidar_loss = o->lidar_loss; s.rel_loss = o->rel_loss; s.autodiff_quirk = o->autodiff_quirk;
+    s.function_tolerance = o->function_tolerance; s.gradient_tolerance = o->gradient_tolerance; s.parameter_tolerance = o->parameter_tolerance;
+    s.max_radius = o->max_radius; s.min_relative_decrease = o->min_relative_decrease; s.min_mu = o->min_mu; s.max_mu = o->max_mu;
+    s.visual_loss_scale = o->visual_loss_scale; s.lidar_loss_scale = o->lidar_loss_scale; s.rel_loss_scale = o->rel_loss_scale;
+    return s;
+}
+
+static void quat_to_R_host(const double* q, double* R) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+extern "C" {
+
+int vil_abi_version(void) { return VIL_ABI_VERSION; }
+
+const char* vil_strerror(int st) {
+    switch (st) {
+        case VIL_OK: return "ok";
+        case VIL_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case VIL_ERR_DEVICE: return "HIP device error (no device / runtime failure)";
+        case VIL_ERR_NON_FINITE: return "non-finite cost or state";
+        case VIL_ERR_NOT_POSITIVE_DEFINITE: return "reduced system not positive definite";
+        case VIL_ERR_COMM: return "RCCL error";
+        case VIL_ERR_UNSUPPORTED: return "unsupported configuration";
+    }
+    return "unknown";
+}
+
+int vil_reduced_dim(int K) { return 15 * K + 7; }
+void vil_prior_capacity(int K, int* n_max, int* nblk_max, int* x0_max) {
+    if (n_max) *n_max = 6 * K + 16;
+    if (nblk_max) *nblk_max = K + 4;
+    if (x0_max) *x0_max = 7 * K + 9 + 7 + 1 + 16;
+}
+void vil_default_options(vil_options* o) {
+    o->max_iterations = 30; o->max_time_s = 0.05;
+    o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+    o->initial_radius = 1e4; o->max_radius = 1e16; o->min_relative_decrease = 1e-3;
+    o->min_mu = 1e-8; o->max_mu = 1.0; o->jacobi_scaling = 1;
+    o->visual_loss = VIL_LOSS_CAUCHY; o->visual_loss_scale = 1.0;
+    o->lidar_loss = VIL_LOSS_HUBER; o->lidar_loss_scale = 0.1;
+    o->rel_loss = VIL_LOSS_CAUCHY; o->rel_loss_scale = 1.0;
+    o->autodiff_quirk = 1; o->precision = 0;
+}
+
+int vil_create(const vil_device_cfg* cfg, vil_ctx** out) {
+    if (!cfg || !out) return VIL_ERR_INVALID_ARGUMENT;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fprintf(stderr, "[vilsolve] no HIP device: the hot path has no CPU fallback\n"); return VIL_ERR_DEVICE; }
+    if (cfg->device < 0 || cfg->device >= ndev) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(cfg->device));
+    vil_ctx* c = new vil_ctx();
+    c->device = cfg->device; c->rank = cfg->rank; c->world = cfg->world > 0 ? cfg->world : 1;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&c->d_status, sizeof(int)));
+    HIPCHK(hipHostMalloc(&c->h_ctl, sizeof(Ctl), hipHostMallocDefault));
+    memset(&c->P, 0, sizeof c->P);
+    *out = c;
+    return VIL_OK;
+}
+
+void vil_destroy(vil_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->ar.d) hipFree(c->ar.d);
+    if (c->d_status) hipFree(c->d_status);
+    if (c->h_ctl) hipHostFree(c->h_ctl);
+    if (c->h_pin) hipHostFree(c->h_pin);
+    marg_free(c->marg);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int validate(const vil_problem* p, const vil_state* s) {
+    if (!p || !s) return VIL_ERR_INVALID_ARGUMENT;
+    if (p->K < 2 || p->L < 0 || s->K != p->K || s->L != p->L) return VIL_ERR_INVALID_ARGUMENT;
+    if (15 * p->K + 7 > 512) return VIL_ERR_UNSUPPORTED;
+    if (p->n_icp + p->n_lps > 12 || p->n_icp < 0 || p->n_lps < 0) return VIL_ERR_UNSUPPORTED;   // reference trims to 5 + 7 (estimator.cpp:1283-1286,1345-1348)
+    if (p->prior.n > 512 || p->prior.nblk > 256) return VIL_ERR_UNSUPPORTED;
+    for (int f = 0; f < p->n_vis; ++f) {
+        if (p->vis_l[f] < 0 || p->vis_l[f] >= p->L || p->vis_i[f] < 0 || p->vis_i[f] >= p->K || p->vis_j[f] < 0 || p->vis_j[f] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
+        if (f && p->vis_l[f] < p->vis_l[f - 1]) return VIL_ERR_INVALID_ARGUMENT;
+        if (f && p->vis_l[f] == p->vis_l[f - 1] && p->vis_i[f] != p->vis_i[f - 1]) return VIL_ERR_INVALID_ARGUMENT;
+    }
+    for (int f = 0; f < p->n_plane; ++f) if (p->plane_pose[f] < 0 || p->plane_pose[f] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
+    for (int f = 0; f < p->n_edge; ++f) if (p->edge_pose[f] < 0 || p->edge_pose[f] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
+    for (int f = 0; f < p->n_imu; ++f) if (p->imu_i[f] < 0 || p->imu_i[f] >= p->K || p->imu_j[f] < 0 || p->imu_j[f] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
+    return VIL_OK;
+}
+
+// pose-sort LiDAR points, transpose to SoA, build (start,count,pose) chunks of <= 256 points
+static void pack_lidar(int n, int ncomp, const int* pose, const double* c, int K, std::vector<int>& perm, std::vector<double>& soa, int& stride, std::vector<int>& chunks) {
+    perm.resize(n);
+    std::vector<int> cnt(K + 1, 0);
+    for (int f = 0; f < n; ++f) cnt[pose[f] + 1]++;
+    for (int k = 0; k < K; ++k) cnt[k + 1] += cnt[k];
+    std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+    for (int f = 0; f < n; ++f) perm[pos[pose[f]]++] = f;
+    stride = (n + 31) & ~31;
+    soa.assign((size_t)ncomp * stride, 0.0);
+    for (int sidx = 0; sidx < n; ++sidx) for (int q = 0; q < ncomp; ++q) soa[(size_t)q * stride + sidx] = c[(size_t)perm[sidx] * ncomp + q];
+    chunks.clear();
+    for (int k = 0; k < K; ++k) for (int s = cnt[k]; s < cnt[k + 1]; s += VIL_THREADS) { chunks.push_back(s); chunks.push_back(std::min(VIL_THREADS, cnt[k + 1] - s)); chunks.push_back(k); }
+}
+
+int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
+    if (!c) return VIL_ERR_INVALID_ARGUMENT;
+    int st = validate(p, s);
+    if (st != VIL_OK) return st;
+    HIPCHK(hipSetDevice(c->device));
+    const int K = p->K, L = p->L, D = 15 * K + 7, NV = 6 * K + 7, NS = 16 * K + 8 + L;
+    Arena& ar = c->ar;
+    ar.h.clear();
+    DevP P; memset(&P, 0, sizeof P);
+    P.K = K; P.L = L; P.D = D; P.NV = NV; P.NS = NS;
+    P.ex_const = p->ex_const; P.use_td = p->use_td; P.td_free = (p->use_td && !p->td_const) ? 1 : 0;
+    memcpy(P.G, p->G, sizeof P.G); P.sqrt_info = p->sqrt_info_px; P.k_tr = p->tr_over_row;
+    { double R[9]; quat_to_R_host(p->q_lb, R); for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) P.Rbl[3 * i + j] = R[3 * j + i]; }
+      for (int i = 0; i < 3; ++i) P.tbl[i] = -(P.Rbl[3 * i] * p->t_lb[0] + P.Rbl[3 * i + 1] * p->t_lb[1] + P.Rbl[3 * i + 2] * p->t_lb[2]); }
+    struct Fix { size_t off; void** slot; };
+    std::vector<Fix> fix;
+    auto put = [&](const void* src, size_t bytes, void** slot) { size_t o = ar.take(bytes ? bytes : 8); if (src && bytes) memcpy(ar.h.data() + o, src, bytes); fix.push_back({o, slot}); return o; };
+    // constancy
+    if (p->pose_const) put(p->pose_const, K, (void**)&P.pose_const);
+    if (p->sb_const) put(p->sb_const, K, (void**)&P.sb_const);
+    if (p->lm_const && L) put(p->lm_const, L, (void**)&P.lm_const);
+    // state x[0], x[1], backup
+    std::vector<double> x(NS);
+    memcpy(&x[0], s->pose, sizeof(double) * 7 * K); memcpy(&x[7 * K], s->speedbias, sizeof(double) * 9 * K);
+    memcpy(&x[16 * K], s->ex_pose, sizeof(double) * 7); x[16 * K + 7] = s->td[0];
+    if (L) memcpy(&x[16 * K + 8], s->inv_depth, sizeof(double) * L);
+    put(x.data(), sizeof(double) * NS, (void**)&P.x[0]);
+    put(x.data(), sizeof(double) * NS, (void**)&P.x[1]);
+    put(x.data(), sizeof(double) * NS, (void**)&c->d_x0);
+    // visual
+    P.n_vis = p->n_vis; P.vis_stride = (p->n_vis + 31) & ~31;
+    {
+        std::vector<double> soa((size_t)14 * std::max(P.vis_stride, 1), 0.0);
+        for (int f = 0; f < p->n_vis; ++f) for (int q = 0; q < 14; ++q) soa[(size_t)q * P.vis_stride + f] = p->vis_const[(size_t)f * 14 + q];
+        put(soa.data(), soa.size() * 8, (void**)&P.vis_c);
+        put(p->vis_i, 4 * (size_t)p->n_vis, (void**)&P.vis_i); put(p->vis_j, 4 * (size_t)p->n_vis, (void**)&P.vis_j); put(p->vis_l, 4 * (size_t)p->n_vis, (void**)&P.vis_l);
+        std::vector<int> lms(L + 1, 0);
+        for (int f = 0; f < p->n_vis; ++f) lms[p->vis_l[f] + 1]++;
+        for (int l = 0; l < L; ++l) lms[l + 1] += lms[l];
+        put(lms.data(), 4 * (size_t)(L + 1), (void**)&P.lm_start);
+        std::vector<int> vch;
+        int l0 = 0;
+        while (l0 < L) {
+            int l1 = l0, nf = 0;
+            while (l1 < L && l1 - l0 < VIL_VCHUNK_LM && nf + (lms[l1 + 1] - lms[l1]) <= VIL_VCHUNK_F) { nf += lms[l1 + 1] - lms[l1]; ++l1; }
+            if (l1 == l0) return VIL_ERR_UNSUPPORTED;   // a single landmark with > VIL_VCHUNK_F observations
+            if (nf > 0) { vch.push_back(l0); vch.push_back(l1); }
+            l0 = l1;
+        }
+        P.n_vchunk = (int)vch.size() / 2;
+        put(vch.data(), 4 * vch.size(), (void**)&P.vchunk);
+    }
+    // LiDAR
+    {
+        std::vector<double> soa; std::vector<int> ch;
+        pack_lidar(p->n_plane, 7, p->plane_pose, p->plane_const, K, c->plane_perm, soa, P.pl_stride, ch);
+        P.n_plane = p->n_plane; P.n_pchunk = (int)ch.size() / 3;
+        put(soa.data(), soa.size() * 8, (void**)&P.pl_c); put(ch.data(), 4 * ch.size(), (void**)&P.pchunk);
+        pack_lidar(p->n_edge, 9, p->edge_pose, p->edge_const, K, c->edge_perm, soa, P.ed_stride, ch);
+        P.n_edge = p->n_edge; P.n_echunk = (int)ch.size() / 3;
+        put(soa.data(), soa.size() * 8, (void**)&P.ed_c); put(ch.data(), 4 * ch.size(), (void**)&P.echunk);
+    }
+    // IMU
+    P.n_imu = p->n_imu;
+    put(p->imu_const, 8 * (size_t)287 * p->n_imu, (void**)&P.imu_c);
+    put(nullptr, 8 * (size_t)225 * std::max(p->n_imu, 1), (void**)&P.imu_U);
+    put(p->imu_i, 4 * (size_t)p->n_imu, (void**)&P.imu_i); put(p->imu_j, 4 * (size_t)p->n_imu, (void**)&P.imu_j);
+    // prior
+    P.pn = p->prior.n > 0 ? p->prior.n : 0; P.pnblk = P.pn ? p->prior.nblk : 0;
+    c->prior_joff.clear();
+    if (P.pn) {
+        const vil_prior& pr = p->prior;
+        const int n = pr.n;
+        std::vector<int> xoff(pr.nblk), pmap(n, -1);
+        int xo = 0, jo = 0;
+        for (int b = 0; b < pr.nblk; ++b) {
+            const int kind = pr.blk_kind[b], gs = (kind == VIL_BLK_POSE || kind == VIL_BLK_EX) ? 7 : (kind == VIL_BLK_SPEEDBIAS ? 9 : 1), ls = gs == 7 ? 6 : gs;
+            xoff[b] = xo; xo += gs; c->prior_joff.push_back(jo); jo += n * gs;
+            int col = -1;
+            const int idx = pr.blk_index[b];
+            if (kind == VIL_BLK_POSE) { if (idx < 0 || idx >= K) return VIL_ERR_INVALID_ARGUMENT; col = (p->pose_const && p->pose_const[idx]) ? -1 : 6 * idx; }
+            else if (kind == VIL_BLK_SPEEDBIAS) { if (idx < 0 || idx >= K) return VIL_ERR_INVALID_ARGUMENT; col = (p->sb_const && p->sb_const[idx]) ? -1 : 6 * K + 7 + 9 * idx; }
+            else if (kind == VIL_BLK_EX) col = p->ex_const ? -1 : 6 * K;
+            else col = P.td_free ? 6 * K + 6 : -1;
+            if (pr.blk_col[b] < 0 || pr.blk_col[b] + ls > n) return VIL_ERR_INVALID_ARGUMENT;
+            for (int q = 0; q < ls; ++q) pmap[pr.blk_col[b] + q] = col < 0 ? -1 : col + q;
+        }
+        put(pr.blk_kind, 4 * (size_t)pr.nblk, (void**)&P.pblk_kind); put(pr.blk_index, 4 * (size_t)pr.nblk, (void**)&P.pblk_index);
+        put(pr.blk_col, 4 * (size_t)pr.nblk, (void**)&P.pblk_col); put(xoff.data(), 4 * (size_t)pr.nblk, (void**)&P.pblk_xoff);
+        put(pmap.data(), 4 * (size_t)n, (void**)&P.pmap);
+        put(pr.x0, 8 * (size_t)xo, (void**)&P.px0); put(pr.J0, 8 * (size_t)n * n, (void**)&P.pJ0); put(pr.r0, 8 * (size_t)n, (void**)&P.pr0);
+        put(nullptr, 8 * (size_t)n * n, (void**)&P.pH); put(nullptr, 8 * (size_t)n, (void**)&P.pg0); put(nullptr, 8, (void**)&P.pc0);
+    }
+    // ICP / LPS
+    P.n_icp = p->n_icp; P.n_lps = p->n_lps;
+    put(p->icp_ids, 16 * (size_t)p->n_icp, (void**)&P.icp_ids); put(p->icp_const, 80 * (size_t)p->n_icp, (void**)&P.icp_c);
+    put(p->lps_ids, 8 * (size_t)p->n_lps, (void**)&P.lps_ids); put(p->lps_const, 56 * (size_t)p->n_lps, (void**)&P.lps_c);
+    // systems + work space (zero-initialised)
+    for (int q = 0; q < 2; ++q) {
+        SysBuf& sb = P.sys[q];
+        put(nullptr, 8 * (size_t)D * D, (void**)&sb.S); put(nullptr, 8 * (size_t)D, (void**)&sb.gred); put(nullptr, 8 * (size_t)D, (void**)&sb.bc); put(nullptr, 8 * (size_t)D, (void**)&sb.diag);
+        put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&sb.hll); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&sb.bl); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&sb.invp);
+        put(nullptr, 8 * (size_t)13 * std::max(L, 1), (void**)&sb.eA); put(nullptr, 8 * (size_t)6 * std::max(p->n_vis, 1), (void**)&sb.eO); put(nullptr, 8, (void**)&sb.cost);
+    }
+    put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.Sl); put(nullptr, 8 * (size_t)D, (void**)&P.Sc); put(nullptr, 8 * (size_t)D, (void**)&P.dc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.dl);
+    put(nullptr, 8 * (size_t)D, (void**)&P.gradc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gradl); put(nullptr, 8 * (size_t)D, (void**)&P.gnc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gnl);
+    put(nullptr, 8 * (size_t)D * D, (void**)&P.M); put(nullptr, 8 * (size_t)D, (void**)&P.stepc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.stepl);
+    put(nullptr, 8 * (size_t)D, (void**)&P.tmpc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.tmpl);
+    put(nullptr, sizeof(Ctl), (void**)&P.ctl);
+    // device allocation + single H2D copy
+    const size_t total = (ar.h.size() + 255) & ~size_t(255);
+    if (total > ar.cap) { if (ar.d) HIPCHK(hipFree(ar.d)); ar.d = nullptr; HIPCHK(hipMalloc(&ar.d, total)); ar.cap = total; }
+    for (const Fix& f : fix) *f.slot = ar.d + f.off;
+    HIPCHK(hipMemcpyAsync(ar.d, ar.h.data(), ar.h.size(), hipMemcpyHostToDevice, c->stream));
+    c->P = P; c->K = K; c->L = L; c->D = D; c->NS = NS;
+    c->n_blocks_sweep = P.n_imu + P.n_vchunk + P.n_pchunk + P.n_echunk + 1;
+    c->lds_sweep = sizeof(double) * (VIL_VCHUNK_F * VF_STRIDE + VIL_VCHUNK_LM * 16 + 16);
+    // one-time set-up: IMU sqrt-information, prior contraction
+    HIPCHK(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
+    const int nb_setup = P.n_imu + (P.pn ? 64 : 0);
+    if (nb_setup > 0) hipLaunchKernelGGL(k_setup, dim3(nb_setup), dim3(VIL_THREADS), 0, c->stream, P, const_cast<double*>(P.imu_U), c->d_status);
+    int hstat = 0;
+    HIPCHK(hipMemcpyAsync(&hstat, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    c->uploaded = true;
+    return hstat == 0 ? VIL_OK : VIL_ERR_NOT_POSITIVE_DEFINITE;
+}
+
+static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
+    hipLaunchKernelGGL(k_sweep, dim3(c->n_blocks_sweep), dim3(VIL_THREADS), c->lds_sweep, c->stream, c->P, so);
+    return VIL_OK;
+}
+
+static int init_ctl(vil_ctx* c, const vil_options* o, int lin_mode) {
+    Ctl ctl; memset(&ctl, 0, sizeof ctl);
+    ctl.cur = 0; ctl.first = 1; ctl.radius = o->initial_radius; ctl.mu = o->min_mu; ctl.lin_mode = lin_mode;
+    *c->h_ctl = ctl;
+    HIPCHK(hipMemcpyAsync(c->P.ctl, c->h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
+    // both system buffers start zeroed; x[1] = x[0] = current state
+    for (int q = 0; q < 2; ++q) {
+        const SysBuf& sb = c->P.sys[q];
+        HIPCHK(hipMemsetAsync(sb.S, 0, 8 * (size_t)c->D * c->D, c->stream));
+        HIPCHK(hipMemsetAsync(sb.gred, 0, 8 * (size_t)c->D, c->stream)); HIPCHK(hipMemsetAsync(sb.bc, 0, 8 * (size_t)c->D, c->stream));
+        HIPCHK(hipMemsetAsync(sb.diag, 0, 8 * (size_t)c->D, c->stream)); HIPCHK(hipMemsetAsync(sb.cost, 0, 8, c->stream));
+    }
+    return VIL_OK;
+}
+
+int vil_reset_state(vil_ctx* c) {
+    if (!c || !c->uploaded) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->P.x[0], c->d_x0, 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->P.x[1], c->d_x0, 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
+    return VIL_OK;
+}
+
+int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
+    if (!c || !o || !sum || !c->uploaded) return VIL_ERR_INVALID_ARGUMENT;
+    if (o->precision != 0) return VIL_ERR_UNSUPPORTED;
+    HIPCHK(hipSetDevice(c->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    const SolveOpts so = to_dev_opts(o);
+    int st = init_ctl(c, o, 0);
+    if (st != VIL_OK) return st;
+    // every iteration = one sweep + one step kernel; `done` turns the tail into no-ops
+    bool finished = false;
+    const int chunk = 6;
+    for (int it = 0; it <= o->max_iterations + 8 && !finished; ) {
+        for (int q = 0; q < chunk && it <= o->max_iterations + 8; ++q, ++it) {
+            launch_sweep(c, so);
+            hipLaunchKernelGGL(k_step, dim3(1), dim3(VIL_STEP_THREADS), 0, c->stream, c->P, so);
+        }
+        HIPCHK(hipMemcpyAsync(c->h_ctl, c->P.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        finished = c->h_ctl->done != 0;
+        if (!finished && o->max_time_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= o->max_time_s) {
+            c->h_ctl->done = 1; c->h_ctl->term = VIL_TERM_MAX_TIME; finished = true;   // ceres max_solver_time_in_seconds (estimator.cpp:1411)
+        }
+    }
+    HIPCHK(hipGetLastError());
+    const Ctl& ctl = *c->h_ctl;
+    memset(sum, 0, sizeof *sum);
+    sum->iterations = ctl.iter; sum->successful_steps = ctl.nsucc; sum->termination = ctl.term;
+    sum->initial_cost = ctl.initial_cost; sum->final_cost = ctl.cost_cur;
+    for (int i = 0; i < VIL_MAX_TRACE; ++i) { sum->cost_trace[i] = ctl.cost_trace[i]; sum->radius_trace[i] = ctl.radius_trace[i]; }
+    sum->t_solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    // the accepted state is x[cur]; keep x[0] as "the" resident state
+    if (ctl.cur != 0) HIPCHK(hipMemcpyAsync(c->P.x[0], c->P.x[1], 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
+    else HIPCHK(hipMemcpyAsync(c->P.x[1], c->P.x[0], 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!finished) return VIL_ERR_DEVICE;
+    if (ctl.status != 0) return ctl.status;
+    if (!std::isfinite(ctl.cost_cur)) return VIL_ERR_NON_FINITE;
+    return VIL_OK;
+}
+
+int vil_download_state(vil_ctx* c, vil_state* s) {
+    if (!c || !s || !c->uploaded || s->K != c->K || s->L != c->L) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<double> x(c->NS);
+    HIPCHK(hipMemcpyAsync(x.data(), c->P.x[0], 8 * (size_t)c->NS, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (double v : x) if (!std::isfinite(v)) return VIL_ERR_NON_FINITE;
+    const int K = c->K, L = c->L;
+    memcpy(s->pose, &x[0], 8 * (size_t)7 * K); memcpy(s->speedbias, &x[7 * K], 8 * (size_t)9 * K);
+    memcpy(s->ex_pose, &x[16 * K], 56); s->td[0] = x[16 * K + 7];
+    if (L) memcpy(s->inv_depth, &x[16 * K + 8], 8 * (size_t)L);
+    return VIL_OK;
+}
+
+int vil_solve(vil_ctx* c, const vil_problem* p, vil_state* s, const vil_options* o, vil_summary* sum) {
+    if (!c || !p || !s || !o || !sum) return VIL_ERR_INVALID_ARGUMENT;
+    const auto t0 = std::chrono::steady_clock::now();
+    int st = vil_upload(c, p, s);
+    if (st != VIL_OK) return st;
+    const auto t1 = std::chrono::steady_clock::now();
+    st = vil_solve_resident(c, o, sum);
+    sum->t_prepare_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (st != VIL_OK) return st;                       // state left unchanged on any error
+    const auto t2 = std::chrono::steady_clock::now();
+    st = vil_download_state(c, s);
+    sum->t_readback_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
+    return st;
+}
+
+static int ensure_pin(vil_ctx* c, size_t bytes) {
+    if (bytes <= c->h_pin_bytes) return VIL_OK;
+    if (c->h_pin) hipHostFree(c->h_pin);
+    c->h_pin = nullptr; c->h_pin_bytes = 0;
+    HIPCHK(hipHostMalloc(&c->h_pin, bytes, hipHostMallocDefault));
+    c->h_pin_bytes = bytes;
+    return VIL_OK;
+}
+
+int vil_eval_factors(vil_ctx* c, const vil_problem* p, const vil_state* s, int cls, double* r, double* J) {
+    if (!c || !r) return VIL_ERR_INVALID_ARGUMENT;
+    int st = vil_upload(c, p, s);
+    if (st != VIL_OK) return st;
+    const DevP& P = c->P;
+    size_t nr = 0, nj = 0; int nfac = 0;
+    switch (cls) {
+        case VIL_FACTOR_IMU: nfac = P.n_imu; nr = 15; nj = 480; break;
+        case VIL_FACTOR_VISUAL: nfac = P.n_vis; nr = 2; nj = 46; break;
+        case VIL_FACTOR_ICP: nfac = P.n_icp; nr = 3; nj = 84; break;
+        case VIL_FACTOR_LPS: nfac = P.n_lps; nr = 3; nj = 42; break;
+        case VIL_FACTOR_EDGE: nfac = P.n_edge; nr = 3; nj = 21; break;
+        case VIL_FACTOR_PLANE: nfac = P.n_plane; nr = 1; nj = 7; break;
+        case VIL_FACTOR_PRIOR: nfac = P.pn ? 1 : 0; nr = P.pn; nj = 0; for (int b = 0; b < P.pnblk; ++b) { int k = p->prior.blk_kind[b]; nj += (size_t)P.pn * ((k == 0 || k == 2) ? 7 : (k == 1 ? 9 : 1)); } break;
+        default: return VIL_ERR_INVALID_ARGUMENT;
+    }
+    if (nfac == 0) return VIL_OK;
+    const size_t br = 8 * nr * nfac, bj = J ? 8 * nj * nfac : 0;
+    double *d_r = nullptr, *d_J = nullptr; int* d_joff = nullptr;
+    HIPCHK(hipMalloc(&d_r, br));
+    if (J) HIPCHK(hipMalloc(&d_J, bj));
+    const double* x = P.x[0];
+    const int nb = (nfac + VIL_THREADS - 1) / VIL_THREADS;
+    switch (cls) {
+        case VIL_FACTOR_IMU: hipLaunchKernelGGL(k_eval_imu, dim3(nfac), dim3(VIL_THREADS), 0, c->stream, P, x, d_r, d_J); break;
+        case VIL_FACTOR_VISUAL: hipLaunchKernelGGL(k_eval_visual, dim3(nb), dim3(VIL_THREADS), 0, c->stream, P, x, d_r, d_J); break;
+        case VIL_FACTOR_ICP: hipLaunchKernelGGL(k_eval_rel, dim3(1), dim3(64), 0, c->stream, P, x, 1, d_r, d_J); break;
+        case VIL_FACTOR_LPS: hipLaunchKernelGGL(k_eval_rel, dim3(1), dim3(64), 0, c->stream, P, x, 0, d_r, d_J); break;
+        case VIL_FACTOR_EDGE: hipLaunchKernelGGL(k_eval_lidar<3>, dim3(nb), dim3(VIL_THREADS), 0, c->stream, P, x, d_r, d_J); break;
+        case VIL_FACTOR_PLANE: hipLaunchKernelGGL(k_eval_lidar<1>, dim3(nb), dim3(VIL_THREADS), 0, c->stream, P, x, d_r, d_J); break;
+        case VIL_FACTOR_PRIOR:
+            HIPCHK(hipMalloc(&d_joff, 4 * c->prior_joff.size()));
+            HIPCHK(hipMemcpyAsync(d_joff, c->prior_joff.data(), 4 * c->prior_joff.size(), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_eval_prior, dim3(1), dim3(VIL_THREADS), 8 * (size_t)P.pn, c->stream, P, x, d_r, d_J, d_joff);
+            break;
+    }
+    st = ensure_pin(c, br + bj);
+    if (st != VIL_OK) return st;
+    HIPCHK(hipMemcpyAsync(c->h_pin, d_r, br, hipMemcpyDeviceToHost, c->stream));
+    if (J) HIPCHK(hipMemcpyAsync((char*)c->h_pin + br, d_J, bj, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    const double* hr = c->h_pin; const double* hj = (const double*)((char*)c->h_pin + br);
+    if (cls == VIL_FACTOR_EDGE || cls == VIL_FACTOR_PLANE) {   // undo the pose sort
+        const std::vector<int>& perm = cls == VIL_FACTOR_EDGE ? c->edge_perm : c->plane_perm;
+        for (int sidx = 0; sidx < nfac; ++sidx) {
+            const int f = perm[sidx];
+            memcpy(r + (size_t)f * nr, hr + (size_t)sidx * nr, 8 * nr);
+            if (J) memcpy(J + (size_t)f * nj, hj + (size_t)sidx * nj, 8 * nj);
+        }
+    } else { memcpy(r, hr, br); if (J) memcpy(J, hj, bj); }
+    hipFree(d_r); if (d_J) hipFree(d_J); if (d_joff) hipFree(d_joff);
+    return VIL_OK;
+}
+
+int vil_linearize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vil_options* o, double* cost, double* S, double* g) {
+    if (!c || !o || !cost || !S || !g) return VIL_ERR_INVALID_ARGUMENT;
+    int st = vil_upload(c, p, s);
+    if (st != VIL_OK) return st;
+    const SolveOpts so = to_dev_opts(o);
+    st = init_ctl(c, o, 1);
+    if (st != VIL_OK) return st;
+    launch_sweep(c, so);                                   // writes system set 1 (cand = 1 - cur)
+    hipLaunchKernelGGL(k_mirror, dim3(64), dim3(VIL_THREADS), 0, c->stream, c->P, 1);
+    const size_t D = c->D;
+    st = ensure_pin(c, 8 * (D * D + D + 1));
+    if (st != VIL_OK) return st;
+    HIPCHK(hipMemcpyAsync(c->h_pin, c->P.sys[1].S, 8 * D * D, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_pin + D * D, c->P.sys[1].gred, 8 * D, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_pin + D * D + D, c->P.sys[1].cost, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    memcpy(S, c->h_pin, 8 * D * D); memcpy(g, c->h_pin + D * D, 8 * D); *cost = c->h_pin[D * D + D];
+    return VIL_OK;
+}
+
+int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out) {
+    if (!c || !p || !s || !o || !spec || !out) return VIL_ERR_INVALID_ARGUMENT;
+    int st = vil_upload(c, p, s);
+    if (st != VIL_OK) return st;
+    return marg_run(c->device, c->stream, c->P, c->marg, p, s, to_dev_opts(o), spec, out);
+}
+
+// estimator.cpp:960-1011 double2vector(): yaw + translation gauge fix (host logic of the boundary)
+int vil_gauge_fix(const double* pose0_before, vil_state* s) {
+    if (!pose0_before || !s) return VIL_ERR_INVALID_ARGUMENT;
+    auto R2ypr = [](const double* R, double* ypr) {
+        const double y = atan2(R[3], R[0]);
+        const double pch = atan2(-R[6], R[0] * cos(y) + R[3] * sin(y));
+        const double rl = atan2(R[2] * sin(y) - R[5] * cos(y), -R[1] * sin(y) + R[4] * cos(y));
+        ypr[0] = y / M_PI * 180.0; ypr[1] = pch / M_PI * 180.0; ypr[2] = rl / M_PI * 180.0;
+    };
+    auto R2q = [](const double* R, double* q /*xyzw*/) {
+        double t = R[0] + R[4] + R[8];
+        if (t > 0) { t = sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t; }
+        else {
+            int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > R[4 * i]) i = 2;
+            const int j = (i + 1) % 3, k = (j + 1) % 3;
+            t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+            q[i] = 0.5 * t; t = 0.5 / t;
+            q[3] = (R[3 * k + j] - R[3 * j + k]) * t; q[j] = (R[3 * j + i] + R[3 * i + j]) * t; q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+        }
+    };
+    auto normq = [](const double* q, double* o) { const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]); for (int i = 0; i < 4; ++i) o[i] = q[i] / n; };
+    double R0[9], R00[9], a0[3], a00[3], rot[9];
+    quat_to_R_host(pose0_before + 3, R0); quat_to_R_host(s->pose + 3, R00);
+    R2ypr(R0, a0); R2ypr(R00, a00);
+    const double yd = (a0[0] - a00[0]) / 180.0 * M_PI;
+    rot[0] = cos(yd); rot[1] = -sin(yd); rot[2] = 0; rot[3] = sin(yd); rot[4] = cos(yd); rot[5] = 0; rot[6] = 0; rot[7] = 0; rot[8] = 1;
+    if (fabs(fabs(a0[1]) - 90) < 1.0 || fabs(fabs(a00[1]) - 90) < 1.0)
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double v = 0; for (int k = 0; k < 3; ++k) v += R0[3 * i + k] * R00[3 * j + k]; rot[3 * i + j] = v; }
+    const double p0[3] = {s->pose[0], s->pose[1], s->pose[2]};
+    for (int f = 0; f < s->K; ++f) {
+        double* pp = s->pose + 7 * f; double qn[4], Rf[9], Rn[9], d[3], P[3], V[3];
+        normq(pp + 3, qn); quat_to_R_host(qn, Rf);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double v = 0; for (int k = 0; k < 3; ++k) v += rot[3 * i + k] * Rf[3 * k + j]; Rn[3 * i + j] = v; }
+        for (int i = 0; i < 3; ++i) d[i] = pp[i] - p0[i];
+        for (int i = 0; i < 3; ++i) P[i] = rot[3 * i] * d[0] + rot[3 * i + 1] * d[1] + rot[3 * i + 2] * d[2] + pose0_before[i];
+        R2q(Rn, pp + 3); pp[0] = P[0]; pp[1] = P[1]; pp[2] = P[2];
+        double* sb = s->speedbias + 9 * f;
+        for (int i = 0; i < 3; ++i) V[i] = rot[3 * i] * sb[0] + rot[3 * i + 1] * sb[1] + rot[3 * i + 2] * sb[2];
+        sb[0] = V[0]; sb[1] = V[1]; sb[2] = V[2];
+    }
+    double qe[4], Re[9];
+    normq(s->ex_pose + 3, qe); quat_to_R_host(qe, Re); R2q(Re, s->ex_pose + 3);
+    return VIL_OK;
+}
+
+// visual factors by landmark owner (contiguous landmark ranges balanced by factor count),
+// LiDAR points in contiguous equal chunks.  Pure host logic, no device needed.
+int vil_shard_ranges(const vil_problem* p, int rank, int world, int32_t* lm_begin, int32_t* lm_end, int32_t* edge_begin, int32_t* edge_end, int32_t* plane_begin, int32_t* plane_end) {
+    if (!p || world <= 0 || rank < 0 || rank >= world) return VIL_ERR_INVALID_ARGUMENT;
+    std::vector<int> lms(p->L + 1, 0);
+    for (int f = 0; f < p->n_vis; ++f) lms[p->vis_l[f] + 1]++;
+    for (int l = 0; l < p->L; ++l) lms[l + 1] += lms[l];
+    auto cut = [&](int r) {   // first landmark whose factor prefix reaches r/world of the total
+        if (r <= 0) return 0; if (r >= world) return p->L;
+        const long long target = (long long)p->n_vis * r / world;
+        return (int)(std::lower_bound(lms.begin(), lms.end(), (int)target) - lms.begin());
+    };
+    if (lm_begin) *lm_begin = std::min(cut(rank), p->L);
+    if (lm_end) *lm_end = std::min(cut(rank + 1), p->L);
+    if (edge_begin) *edge_begin = (int)((long long)p->n_edge * rank / world);
+    if (edge_end) *edge_end = (int)((long long)p->n_edge * (rank + 1) / world);
+    if (plane_begin) *plane_begin = (int)((long long)p->n_plane * rank / world);
+    if (plane_end) *plane_end = (int)((long long)p->n_plane * (rank + 1) / world);
+    return VIL_OK;
+}
+
+int vil_comm_unique_id(void* id128) { (void)id128; return VIL_ERR_UNSUPPORTED; }
+int vil_comm_init(vil_ctx* ctx, const void* id128, int rank, int world) { (void)ctx; (void)id128; (void)rank; (void)world; return VIL_ERR_UNSUPPORTED; }
+
+}  // extern "C"
