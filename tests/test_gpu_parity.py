@@ -1,0 +1,123 @@
+"""GPU parity tests proper: HIP path (through the C-ABI) vs the CPU oracle on identical seeded inputs.
+
+fp64 tolerances: per-factor residual/Jacobian <= 1e-12 relative to the class scale;
+normal equations <= 1e-10 relative; window level: positions <= 1e-6 m, rotations <= 1e-7 rad after
+the double2vector gauge fix.
+"""
+import numpy as np
+import pytest
+
+from mvil_fusion_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+CLASSES = [abi.FACTOR_IMU, abi.FACTOR_VISUAL, abi.FACTOR_PRIOR, abi.FACTOR_ICP, abi.FACTOR_LPS, abi.FACTOR_EDGE, abi.FACTOR_PLANE]
+
+
+def rel_err(a, b):
+    scale = max(np.abs(b).max(), 1e-300)
+    return np.abs(a - b).max() / scale
+
+
+@pytest.fixture(scope="module")
+def wsmall(oracle):
+    return synth.make_config(2, L=150, n_plane=3000, n_edge=800, prior_fn=lambda pre: oracle.marginalize(pre).to_prior())
+
+
+@pytest.fixture(scope="module")
+def w1():
+    return synth.make_config(1)
+
+
+@pytest.mark.parametrize("cls", CLASSES)
+def test_eval_factors_parity(hip, oracle, wsmall, cls):
+    ro, Jo = oracle.eval_factors(wsmall, cls)
+    rg, Jg = hip.eval_factors(wsmall, cls)
+    assert ro.size > 0
+    assert rel_err(rg, ro) < 1e-12, rel_err(rg, ro)
+    assert rel_err(Jg, Jo) < 1e-12, rel_err(Jg, Jo)
+
+
+def test_eval_factors_no_td_variant(hip, oracle, w1):
+    w = synth.make_config(1)
+    w.use_td = 0
+    ro, Jo = oracle.eval_factors(w, abi.FACTOR_VISUAL)
+    rg, Jg = hip.eval_factors(w, abi.FACTOR_VISUAL)
+    assert rel_err(rg, ro) < 1e-12 and rel_err(Jg, Jo) < 1e-12
+
+
+def test_eval_residual_only(hip, oracle, wsmall):
+    ro, _ = oracle.eval_factors(wsmall, abi.FACTOR_VISUAL, jac=False)
+    rg, _ = hip.eval_factors(wsmall, abi.FACTOR_VISUAL, jac=False)
+    assert rel_err(rg, ro) < 1e-12
+
+
+@pytest.mark.parametrize("which", ["c1", "small", "small_quirk_off", "small_consts"])
+def test_linearize_parity(hip, oracle, w1, wsmall, which):
+    opts = abi.default_options()
+    w = w1 if which == "c1" else wsmall
+    if which == "small_quirk_off":
+        opts.autodiff_quirk = 0
+    if which == "small_consts":
+        w = synth.make_config(2, L=150, n_plane=3000, n_edge=800)
+        w.pose_const[w.K - 2] = 1; w.sb_const[w.K - 2] = 1; w.ex_const = 1; w.td_const = 1
+    co, So, go = oracle.linearize(w, opts)
+    cg, Sg, gg = hip.linearize(w, opts)
+    assert abs(cg - co) <= 1e-12 * abs(co)
+    assert rel_err(Sg, So) < 1e-10, rel_err(Sg, So)
+    assert rel_err(gg, go) < 1e-10, rel_err(gg, go)
+    assert np.allclose(Sg, Sg.T, rtol=0, atol=0)
+
+
+def rot_angle(qa, qb):
+    d = abs(float(np.dot(qa, qb)))
+    return 2 * np.arccos(min(1.0, d))
+
+
+def compare_states(wg, wo, pos_tol=1e-6, rot_tol=1e-7):
+    dp = np.abs(wg.pose[:, :3] - wo.pose[:, :3]).max()
+    dr = max(rot_angle(wg.pose[k, 3:], wo.pose[k, 3:]) for k in range(wg.K))
+    assert dp <= pos_tol, dp
+    assert dr <= rot_tol, dr
+    assert np.abs(wg.speedbias - wo.speedbias).max() <= 1e-5
+    return dp, dr
+
+
+@pytest.mark.parametrize("cid,kw", [(1, {}), (2, dict(L=150, n_plane=3000, n_edge=800)), (4, dict(L=300))])
+def test_solve_parity(hip, oracle, cid, kw):
+    pf = lambda pre: oracle.marginalize(pre).to_prior()
+    wg = synth.make_config(cid, prior_fn=pf, **kw)
+    wo = synth.make_config(cid, prior_fn=pf, **kw)
+    p0 = wg.pose[0].copy()
+    opts = abi.default_options()
+    sg = hip.solve(wg, opts)
+    so = oracle.solve(wo, opts)
+    assert abs(sg.initial_cost - so.initial_cost) <= 1e-11 * so.initial_cost
+    assert sg.iterations == so.iterations and sg.successful_steps == so.successful_steps and sg.termination == so.termination
+    n = min(sg.iterations, 64)
+    tg, to = np.array(sg.cost_trace[:n]), np.array(so.cost_trace[:n])
+    assert np.allclose(tg, to, rtol=1e-7), (tg, to)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    hip.gauge_fix(p0, wg); oracle.gauge_fix(p0, wo)
+    compare_states(wg, wo)
+
+
+def test_solve_leaves_state_unchanged_on_error(hip):
+    w = synth.make_config(1)
+    w.vis_const[5, 2] = np.nan  # poison one observation -> non-finite cost
+    before = w.state_copy()
+    with pytest.raises(Exception):
+        hip.solve(w)
+    after = w.state_copy()
+    for k in before:
+        assert np.array_equal(before[k], after[k], equal_nan=True)
+
+
+def test_resident_solve_repeatable(hip):
+    w = synth.make_config(2, L=150, n_plane=3000, n_edge=800)
+    hip.upload(w)
+    s1 = hip.solve_resident()
+    hip.reset_state()
+    s2 = hip.solve_resident()
+    assert s1.iterations == s2.iterations
+    assert abs(s1.final_cost - s2.final_cost) <= 1e-9 * s1.final_cost
