@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py -- sliding-window solve iterations/s on MI355X (BASELINE.json metric).
+
+A "step" is one full window solve (Estimator::optimization()'s ceres::Solve replacement) of the
+BASELINE.json configs[1] workload -- 10 keyframes, 1k landmarks, 30k LiDAR edge/plane points -- with
+the factor tables and the state already resident in HBM; value = trust-region iterations executed /
+wall time (whole job, all ranks).  One JSON line on rank 0 (contract in the task statement), carrying
+  roofline     : the factor-sweep kernel (dominant kernel), HIP-event timed on the library's stream
+  cpu_baseline : the CPU restatement of the reference algorithm (oracle/, kind "port"), single thread
+                 like the reference's ceres::Solve (no num_threads set, estimator.cpp:1400-1411)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+class VilProfile(C.Structure):
+    _fields_ = [("sweep_launches", C.c_int64), ("sweep_ms", C.c_double), ("step_launches", C.c_int64), ("step_ms", C.c_double)]
+
+
+def algorithmic_bytes(w):
+    """SURVEY.md 8(d), fused (read-only) variant of the sweep: bytes one launch must read."""
+    n = w.prior.n
+    return (132 * len(w.vis_i) + 60 * len(w.plane_pose) + 76 * len(w.edge_pose) + (2296 + 8) * len(w.imu_i)
+            + 8 * (n * n + n) + 8 * (16 * w.K + 8))
+
+
+def cpu_baseline(w, opts, budget_s=12.0):
+    """Oracle (CPU restatement, kind 'port') timed on this host: repeated full solves of the same window."""
+    from mvil_fusion_amd import lib
+    so_path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(so_path):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    orc = lib.Backend(C.CDLL(so_path), "orc_")
+    st0 = w.state_copy()
+    its, n, t0 = 0, 0, time.perf_counter()
+    while True:
+        w.set_state(st0)
+        s = orc.solve(w, opts)
+        its += s.iterations; n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 400:
+            break
+    w.set_state(st0)
+    return {"value": its / el, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": "%d full solves (%d trust-region iterations) of the same configs[1] window, %.1f s" % (n, its, el),
+            "note": "CPU restatement of the reference algorithm (Ceres unavailable); nproc=%d" % (os.cpu_count() or 0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--no-events", action="store_true", help="do not record HIP events around sweep launches in the timed region")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    graft.load_package()
+    from mvil_fusion_amd import abi, lib, synth
+
+    be = lib.open_vilsolve(device=local, rank=rank, world=world)
+    opts = abi.default_options()
+
+    def gpu_prior(pre):
+        try:
+            return be.marginalize(pre).to_prior()
+        except lib.VilError:
+            return None     # library marginalisation not available yet -> synthetic prior (stated in config)
+    w = synth.make_config(args.config, prior_fn=gpu_prior)
+    prior_kind = "vil_marginalize(previous synthetic window)" if getattr(w, "_prior_from_lib", False) else "synthetic dense prior"
+    be.upload(w)
+    if not args.no_events:
+        be.lib.vil_profile_enable(be.ctx, 1)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        be.reset_state(); be.solve_resident(opts)
+    prof = VilProfile()
+    be.lib.vil_profile_read(be.ctx, C.byref(prof), 1)
+    sync()
+    t0 = time.perf_counter()
+    iters, last = 0, None
+    for _ in range(args.steps):
+        be.reset_state()
+        last = be.solve_resident(opts)
+        iters += last.iterations
+    sync()
+    el = time.perf_counter() - t0
+    be.lib.vil_profile_read(be.ctx, C.byref(prof), 1)
+    tot_iters, max_el = iters, el
+    if dist is not None:
+        tt = torch.tensor([float(iters), el], device="cuda", dtype=torch.float64)
+        it_sum = tt.clone(); dist.all_reduce(it_sum, op=dist.ReduceOp.SUM)
+        el_max = tt.clone(); dist.all_reduce(el_max, op=dist.ReduceOp.MAX)
+        tot_iters, max_el = float(it_sum[0]), float(el_max[1])
+    if rank == 0:
+        out = {
+            "metric": "sliding-window solve iterations/sec (10 KF, 1k feat, 30k LiDAR pts)",
+            "value": tot_iters / max_el, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * max_el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[%d]: K=%d keyframes, L=%d landmarks, %d visual factors, %d plane + %d edge LiDAR points, %d IMU, %d ICP, %d LPS, prior n=%d (%s)"
+                       % (args.config - 1, w.K, w.L, len(w.vis_i), len(w.plane_pose), len(w.edge_pose), len(w.imu_i), len(w.icp_ids), len(w.lps_ids), w.prior.n, prior_kind),
+                       "iterations_per_solve": last.iterations, "termination": abi.TERM_NAMES[last.termination], "final_cost": last.final_cost,
+                       "parallelism": "1 GPU" if world == 1 else "%d independent replicas (factor sharding + RCCL all-reduce not enabled in this build)" % world,
+                       "step": "one full window solve, inputs resident in HBM"},
+        }
+        if prof.sweep_launches > 0:
+            ab = algorithmic_bytes(w)
+            us = 1e3 * prof.sweep_ms / prof.sweep_launches
+            ach = ab / (us * 1e-6) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "k_sweep", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "algorithmic_bytes_per_launch": ab, "avg_launch_us": us, "launches_timed": int(prof.sweep_launches),
+                               "step_kernel_avg_us": 1e3 * prof.step_ms / max(1, prof.step_launches),
+                               "variant": "fused sweep (no Jacobian materialisation): read-only bytes, SURVEY 8(d)"}
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(w, opts)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    be.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -260,6 +260,17 @@ int vil_solve_resident(vil_ctx* ctx, const vil_options* options, vil_summary* su
 int vil_reset_state(vil_ctx* ctx);                       /* restore the uploaded state on device */
 int vil_download_state(vil_ctx* ctx, vil_state* state_out);
 
+/* kernel timing with HIP events recorded on the library's own stream around every sweep launch
+ * (bench.py's roofline leg).  Off by default. */
+typedef struct vil_profile {
+    int64_t sweep_launches;        /* live (not early-exited) sweep launches timed              */
+    double sweep_ms;               /* sum of their durations                                    */
+    int64_t step_launches;
+    double step_ms;                /* sweep end -> next sweep start (step kernel + boundary)     */
+} vil_profile;
+int vil_profile_enable(vil_ctx* ctx, int on);
+int vil_profile_read(vil_ctx* ctx, vil_profile* out, int reset);
+
 /* replaces ceres::CostFunction::Evaluate for a whole factor class at once: raw (no loss) residuals
  * and row-major global-size Jacobian blocks, factor-major, in the caller's factor order. */
 int vil_eval_factors(vil_ctx* ctx, const vil_problem* problem, const vil_state* state,

@@ -4,10 +4,11 @@
 #pragma once
 #include <stdint.h>
 
-#define VIL_THREADS 256
-#define VIL_VCHUNK_LM 8       // landmarks per visual workgroup
+#define VIL_THREADS 256       // eval / reduce kernels, LiDAR chunk size
+#define VIL_SWEEP_THREADS 512 // sweep workgroups: 8 waves = 2 per SIMD for LDS-latency hiding
+#define VIL_VCHUNK_LM 16      // landmarks per visual sub-chunk
 #define VIL_VCHUNK_F 128      // factors per visual workgroup (LDS staging bound)
-#define VIL_STEP_THREADS 1024
+#define VIL_STEP_THREADS 512
 
 struct SysBuf {       // one linearisation of the window (double-buffered: current / candidate)
     double* S;        // D x D  Schur-reduced H (upper triangle accumulated by the sweep, mirrored by the step kernel)
@@ -23,8 +24,9 @@ struct SysBuf {       // one linearisation of the window (double-buffered: curre
 };
 
 struct Ctl {          // trust-region state, lives in device memory, owned by the step kernel
-    int cur, iter, done, term, first, resweep, reuse, nsucc, invalid_run, status, lin_mode, pad;
+    int cur, iter, done, term, first, resweep, reuse, nsucc, invalid_run, status, lin_mode, n_sweeps;
     double radius, mu, cost_cur, model_change, alpha, dogleg_norm, initial_cost, cand_cost;
+    double mu_used, gn2, g2, gg;   // dogleg scalars of the current linearisation (reused after a rejected step)
     double cost_trace[64], radius_trace[64];
 };
 
@@ -60,9 +62,20 @@ struct DevP {
     double G[3], sqrt_info, k_tr;
     // linear system + solver work space
     SysBuf sys[2];
+    // per-workgroup partial results of the sweep (no global atomics); gathered by k_reduce
+    int n_vwg, NVT, VP;           // visual workgroups; NV(NV+1)/2; doubles per visual partial = NVT + 3 NV + 1
+    const int* vwg;               // n_vwg x 2 sub-chunk ranges
+    double* vpart;                // n_vwg x VP  [tri(S') | bc | gred | diag | cost]
+    double* lpart;                // (n_pchunk + n_echunk) x 28  [21 upper 6x6 | 6 g | cost]
+    const int* lchunk_pose;       // 2 x (K+1): chunk ranges per pose (plane, edge)
+    double* ipart;                // n_imu x 931  [30x30 H | 30 g | cost]
+    double* mpart;                // prior: [pn g | cost] then n_rel x 601 [24x24 H | 24 g | cost]
+    const int* pinv;              // D: reduced column -> prior column or -1
     double* Sl; double* Sc; double* dc; double* dl; double* gradc; double* gradl; double* gnc; double* gnl;
     double* M; double* stepc; double* stepl; double* tmpc; double* tmpl;
     Ctl* ctl;
+    long long* dbg;               // 64 cycle stamps (debug/profiling aid)
+    int skip_mask;                // debug: bit0 visual, 1 imu, 2 plane, 3 edge, 4 misc roles skipped in the sweep
 };
 
 __host__ __device__ inline int xo_pose(const DevP& P, int k) { return 7 * k; }

@@ -84,18 +84,18 @@ __global__ void k_eval_imu(DevP P, const double* x, double* r, double* J) {
     }
 }
 
-// thread per (factor, pose block); ICP first, then LPS.  r: 3/factor, J: 84 (ICP) / 42 (LPS) raw AutoDiff blocks
+// thread per (factor, pose block, global coordinate).  r: 3/factor, J: 84 (ICP) / 42 (LPS) raw AutoDiff blocks
 __global__ void k_eval_rel(DevP P, const double* x, int icp, double* r, double* J) {
     using namespace vd;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int nb = icp ? 4 : 2, n = icp ? P.n_icp : P.n_lps;
-    if (t >= n * nb) return;
-    const int f = t / nb, b = t % nb;
-    double r3[3], J21[21];
-    if (icp) { const int* id = P.icp_ids + 4 * f; icp_eval(P.icp_c + (size_t)f * 10, x + xo_pose(P, id[0]), x + xo_pose(P, id[1]), x + xo_pose(P, id[2]), x + xo_pose(P, id[3]), b, r3, J21); }
-    else { const int* id = P.lps_ids + 2 * f; lps_eval(P.lps_c + (size_t)f * 7, x + xo_pose(P, id[0]), x + xo_pose(P, id[1]), b, r3, J21); }
-    if (b == 0) for (int k = 0; k < 3; ++k) r[3 * f + k] = r3[k];
-    if (J) for (int k = 0; k < 21; ++k) J[((size_t)f * nb + b) * 21 + k] = J21[k];
+    if (t >= n * nb * 7) return;
+    const int f = t / (nb * 7), rem = t - f * nb * 7, b = rem / 7, k = rem - 7 * b;
+    double r3[3], d3[3];
+    if (icp) { const int* id = P.icp_ids + 4 * f; icp_eval1(P.icp_c + (size_t)f * 10, x + xo_pose(P, id[0]), x + xo_pose(P, id[1]), x + xo_pose(P, id[2]), x + xo_pose(P, id[3]), b, k, r3, d3); }
+    else { const int* id = P.lps_ids + 2 * f; lps_eval1(P.lps_c + (size_t)f * 7, x + xo_pose(P, id[0]), x + xo_pose(P, id[1]), b, k, r3, d3); }
+    if (b == 0 && k == 0) for (int q = 0; q < 3; ++q) r[3 * f + q] = r3[q];
+    if (J) for (int q = 0; q < 3; ++q) J[((size_t)f * nb + b) * 21 + 7 * q + k] = d3[q];
 }
 
 // prior: r = r0 + J0 dx ; J blocks = J0 columns left-aligned in n x gsize row-major blocks

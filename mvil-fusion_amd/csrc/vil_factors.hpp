@@ -105,64 +105,84 @@ __device__ inline M3 mm(const M3& a, const M3& b) { M3 r; for (int i = 0; i < 3;
 __device__ inline M3 ql33(Q4 q) { M3 r = skewm({q.x, q.y, q.z}); r.m[0] += q.w; r.m[4] += q.w; r.m[8] += q.w; return r; }
 __device__ inline M3 qr33(Q4 q) { M3 r = skewm({-q.x, -q.y, -q.z}); r.m[0] += q.w; r.m[4] += q.w; r.m[8] += q.w; return r; }
 
-__device__ inline void imu_raw(const double* c, V3 G, const double* pi, const double* sbi, const double* pj, const double* sbj,
-                               double* r /*15*/, double* J /*15x30 row-major, or nullptr*/) {
+struct ImuCommon {
+    M3 RiT; V3 tp, tv; Q4 qt, qe, qji, dq; double dt;
+    V3 Bai, Baj, Bgi, Bgj, pt, vt;
+};
+__device__ inline void imu_common(const double* c, V3 G, const double* pi, const double* sbi, const double* pj, const double* sbj, ImuCommon& o) {
     const V3 Pi{pi[0], pi[1], pi[2]}, Pj{pj[0], pj[1], pj[2]};
     const Q4 Qi = qload(pi + 3), Qj = qload(pj + 3);
-    const V3 Vi{sbi[0], sbi[1], sbi[2]}, Bai{sbi[3], sbi[4], sbi[5]}, Bgi{sbi[6], sbi[7], sbi[8]};
-    const V3 Vj{sbj[0], sbj[1], sbj[2]}, Baj{sbj[3], sbj[4], sbj[5]}, Bgj{sbj[6], sbj[7], sbj[8]};
+    const V3 Vi{sbi[0], sbi[1], sbi[2]}, Vj{sbj[0], sbj[1], sbj[2]};
+    o.Bai = V3{sbi[3], sbi[4], sbi[5]}; o.Bgi = V3{sbi[6], sbi[7], sbi[8]};
+    o.Baj = V3{sbj[3], sbj[4], sbj[5]}; o.Bgj = V3{sbj[6], sbj[7], sbj[8]};
     const V3 dp{c[0], c[1], c[2]}, dv{c[7], c[8], c[9]};
-    const Q4 dq{c[6], c[3], c[4], c[5]};
-    const double dt = c[16];
+    o.dq = Q4{c[6], c[3], c[4], c[5]};
+    o.dt = c[16];
+    const double dt = o.dt;
     const M3 Jp_ba = loadM3(c + 17), Jp_bg = loadM3(c + 26), Jq_bg = loadM3(c + 35), Jv_ba = loadM3(c + 44), Jv_bg = loadM3(c + 53);
-    const V3 dba = Bai - V3{c[10], c[11], c[12]}, dbg = Bgi - V3{c[13], c[14], c[15]};
+    const V3 dba = o.Bai - V3{c[10], c[11], c[12]}, dbg = o.Bgi - V3{c[13], c[14], c[15]};
     const V3 th = mul(Jq_bg, dbg);
-    const Q4 qt = qmul(dq, Q4{1.0, 0.5 * th.x, 0.5 * th.y, 0.5 * th.z});    // corrected delta_q, not normalised
-    const V3 vt = dv + mul(Jv_ba, dba) + mul(Jv_bg, dbg);
-    const V3 pt = dp + mul(Jp_ba, dba) + mul(Jp_bg, dbg);
+    o.qt = qmul(o.dq, Q4{1.0, 0.5 * th.x, 0.5 * th.y, 0.5 * th.z});    // corrected delta_q, not normalised
+    o.vt = dv + mul(Jv_ba, dba) + mul(Jv_bg, dbg);
+    o.pt = dp + mul(Jp_ba, dba) + mul(Jp_bg, dbg);
     const Q4 Qi_inv = qinv(Qi);
-    const V3 tp = qrot(Qi_inv, (0.5 * dt * dt) * G + Pj - Pi - dt * Vi);
-    const V3 tv = qrot(Qi_inv, dt * G + Vj - Vi);
-    const Q4 qij = qmul(Qi_inv, Qj);
-    const Q4 qe = qmul(qinv(qt), qij);
-    r[0] = tp.x - pt.x; r[1] = tp.y - pt.y; r[2] = tp.z - pt.z;
-    r[3] = 2 * qe.x; r[4] = 2 * qe.y; r[5] = 2 * qe.z;
-    r[6] = tv.x - vt.x; r[7] = tv.y - vt.y; r[8] = tv.z - vt.z;
-    r[9] = Baj.x - Bai.x; r[10] = Baj.y - Bai.y; r[11] = Baj.z - Bai.z;
-    r[12] = Bgj.x - Bgi.x; r[13] = Bgj.y - Bgi.y; r[14] = Bgj.z - Bgi.z;
+    o.tp = qrot(Qi_inv, (0.5 * dt * dt) * G + Pj - Pi - dt * Vi);
+    o.tv = qrot(Qi_inv, dt * G + Vj - Vi);
+    o.qe = qmul(qinv(o.qt), qmul(Qi_inv, Qj));
+    o.qji = qmul(qinv(Qj), Qi);
+    const double qiv[4] = {Qi_inv.x, Qi_inv.y, Qi_inv.z, Qi_inv.w};
+    o.RiT = quatR(qiv);
+}
+__device__ inline void imu_resid(const ImuCommon& o, double* r) {
+    r[0] = o.tp.x - o.pt.x; r[1] = o.tp.y - o.pt.y; r[2] = o.tp.z - o.pt.z;
+    r[3] = 2 * o.qe.x; r[4] = 2 * o.qe.y; r[5] = 2 * o.qe.z;
+    r[6] = o.tv.x - o.vt.x; r[7] = o.tv.y - o.vt.y; r[8] = o.tv.z - o.vt.z;
+    r[9] = o.Baj.x - o.Bai.x; r[10] = o.Baj.y - o.Bai.y; r[11] = o.Baj.z - o.Bai.z;
+    r[12] = o.Bgj.x - o.Bgi.x; r[13] = o.Bgj.y - o.Bgi.y; r[14] = o.Bgj.z - o.Bgi.z;
+}
+#define IMU_NBLOCKS 17
+// block b of the raw 15x30 Jacobian: rows r0.., cols c0.. get s * m
+__device__ inline void imu_block(const ImuCommon& o, const double* c, int b, int& r0, int& c0, M3& m, double& s) {
+    M3 I3; for (int i = 0; i < 9; ++i) I3.m[i] = 0; I3.m[0] = I3.m[4] = I3.m[8] = 1;
+    s = 1.0;
+    switch (b) {
+        case 0: r0 = 0; c0 = 0; m = o.RiT; s = -1.0; break;                        // pose_i
+        case 1: r0 = 0; c0 = 3; m = skewm(o.tp); break;
+        case 2: {   // -(Qleft(Qj^-1 Qi) Qright(qt)) bottom-right: -v pv^T + (w I + [v]x)(pw I - [pv]x)
+            r0 = 3; c0 = 3; s = -1.0;
+            m = mm(ql33(o.qji), qr33(o.qt));
+            const double v[3] = {o.qji.x, o.qji.y, o.qji.z}, pv[3] = {o.qt.x, o.qt.y, o.qt.z};
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m.m[3 * i + j] -= v[i] * pv[j];
+            break; }
+        case 3: r0 = 6; c0 = 3; m = skewm(o.tv); break;
+        case 4: r0 = 0; c0 = 6; m = o.RiT; s = -o.dt; break;                       // speedbias_i
+        case 5: r0 = 0; c0 = 9; m = loadM3(c + 17); s = -1.0; break;
+        case 6: r0 = 0; c0 = 12; m = loadM3(c + 26); s = -1.0; break;
+        case 7: r0 = 3; c0 = 12; m = mm(ql33(qmul(o.qji, o.dq)), loadM3(c + 35)); s = -1.0; break;
+        case 8: r0 = 6; c0 = 6; m = o.RiT; s = -1.0; break;
+        case 9: r0 = 6; c0 = 9; m = loadM3(c + 44); s = -1.0; break;
+        case 10: r0 = 6; c0 = 12; m = loadM3(c + 53); s = -1.0; break;
+        case 11: r0 = 9; c0 = 9; m = I3; s = -1.0; break;
+        case 12: r0 = 12; c0 = 12; m = I3; s = -1.0; break;
+        case 13: r0 = 0; c0 = 15; m = o.RiT; break;                                  // pose_j
+        case 14: r0 = 3; c0 = 18; m = ql33(o.qe); break;
+        case 15: r0 = 6; c0 = 21; m = o.RiT; break;                                  // speedbias_j
+        default: r0 = 9; c0 = 24; m = I3; break;                                     // b == 16: also (12,27) = I, written by the caller
+    }
+}
+__device__ inline void imu_raw(const double* c, V3 G, const double* pi, const double* sbi, const double* pj, const double* sbj,
+                               double* r /*15*/, double* J /*15x30 row-major, or nullptr*/) {
+    ImuCommon o;
+    imu_common(c, G, pi, sbi, pj, sbj, o);
+    imu_resid(o, r);
     if (!J) return;
     for (int i = 0; i < 450; ++i) J[i] = 0.0;
-    const double qiv[4] = {Qi_inv.x, Qi_inv.y, Qi_inv.z, Qi_inv.w};
-    const M3 RiT = quatR(qiv);
-    M3 I3; for (int i = 0; i < 9; ++i) I3.m[i] = 0; I3.m[0] = I3.m[4] = I3.m[8] = 1;
-    // pose_i
-    put33(J, 30, 0, 0, RiT, -1.0);
-    put33(J, 30, 0, 3, skewm(tp), 1.0);
-    {   // -(Qleft(Qj^-1 Qi) Qright(qt)) bottom-right: -v pv^T + (w I + [v]x)(pw I - [pv]x)
-        const Q4 q = qmul(qinv(Qj), Qi);
-        M3 blk = mm(ql33(q), qr33(qt));
-        const double v[3] = {q.x, q.y, q.z}, pv[3] = {qt.x, qt.y, qt.z};
-        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) blk.m[3 * i + j] -= v[i] * pv[j];
-        put33(J, 30, 3, 3, blk, -1.0);
+    for (int b = 0; b < IMU_NBLOCKS; ++b) {
+        int r0, c0; M3 m; double s;
+        imu_block(o, c, b, r0, c0, m, s);
+        put33(J, 30, r0, c0, m, s);
+        if (b == 16) put33(J, 30, 12, 27, m, s);
     }
-    put33(J, 30, 6, 3, skewm(tv), 1.0);
-    // speedbias_i
-    put33(J, 30, 0, 6, RiT, -dt);
-    put33(J, 30, 0, 9, Jp_ba, -1.0);
-    put33(J, 30, 0, 12, Jp_bg, -1.0);
-    put33(J, 30, 3, 12, mm(ql33(qmul(qmul(qinv(Qj), Qi), dq)), Jq_bg), -1.0);
-    put33(J, 30, 6, 6, RiT, -1.0);
-    put33(J, 30, 6, 9, Jv_ba, -1.0);
-    put33(J, 30, 6, 12, Jv_bg, -1.0);
-    put33(J, 30, 9, 9, I3, -1.0);
-    put33(J, 30, 12, 12, I3, -1.0);
-    // pose_j
-    put33(J, 30, 0, 15, RiT, 1.0);
-    put33(J, 30, 3, 18, ql33(qe), 1.0);
-    // speedbias_j
-    put33(J, 30, 6, 21, RiT, 1.0);
-    put33(J, 30, 9, 24, I3, 1.0);
-    put33(J, 30, 12, 27, I3, 1.0);
 }
 
 // sqrt_info = LLT(cov^-1).matrixL()^T (imu_factor.h:64): upper-triangular U with U^T U = cov^-1.
@@ -197,88 +217,83 @@ __device__ inline bool imu_sqrt_info(const double* cov, double* U /*225 row-majo
 
 // ------------------------------------------------------------------------------------------------
 // forward-mode duals for the two AutoDiff factors (A11 ICP lidar_backend.h:107-169, A12 LPS :45-80).
-// One thread differentiates w.r.t. ONE 7-dof pose block (seeded), so N = 7.
+// One thread differentiates w.r.t. ONE global coordinate (seed = 7*block + k), so a dual carries a
+// single partial; 7 threads rebuild what a ceres::Jet<double,7> holds for one pose block.
 // ------------------------------------------------------------------------------------------------
-struct J7 {
-    double a, v[7];
-    __device__ J7() : a(0) { for (int i = 0; i < 7; ++i) v[i] = 0; }
-    __device__ J7(double s) : a(s) { for (int i = 0; i < 7; ++i) v[i] = 0; }
-};
-__device__ inline J7 operator+(const J7& x, const J7& y) { J7 r; r.a = x.a + y.a; for (int i = 0; i < 7; ++i) r.v[i] = x.v[i] + y.v[i]; return r; }
-__device__ inline J7 operator-(const J7& x, const J7& y) { J7 r; r.a = x.a - y.a; for (int i = 0; i < 7; ++i) r.v[i] = x.v[i] - y.v[i]; return r; }
-__device__ inline J7 operator-(const J7& x) { J7 r; r.a = -x.a; for (int i = 0; i < 7; ++i) r.v[i] = -x.v[i]; return r; }
-__device__ inline J7 operator*(const J7& x, const J7& y) { J7 r; r.a = x.a * y.a; for (int i = 0; i < 7; ++i) r.v[i] = x.a * y.v[i] + x.v[i] * y.a; return r; }
-__device__ inline J7 operator/(const J7& x, const J7& y) { J7 r; const double inv = 1.0 / y.a; r.a = x.a * inv; for (int i = 0; i < 7; ++i) r.v[i] = (x.v[i] - r.a * y.v[i]) * inv; return r; }
-__device__ inline J7 jsin(const J7& x) { J7 r; r.a = sin(x.a); const double c = cos(x.a); for (int i = 0; i < 7; ++i) r.v[i] = c * x.v[i]; return r; }
-__device__ inline J7 jacos(const J7& x) { J7 r; r.a = acos(x.a); const double d = -1.0 / sqrt(1.0 - x.a * x.a); for (int i = 0; i < 7; ++i) r.v[i] = d * x.v[i]; return r; }
-struct JQ { J7 w, x, y, z; };
-struct JV { J7 x, y, z; };
-__device__ inline JQ jq_load(const double* p, bool seed) {
-    JQ q; q.x = J7(p[3]); q.y = J7(p[4]); q.z = J7(p[5]); q.w = J7(p[6]);
-    if (seed) { q.x.v[3] = 1; q.y.v[4] = 1; q.z.v[5] = 1; q.w.v[6] = 1; }
-    return q;
+struct D1 { double a, d; };
+__device__ __forceinline__ D1 dc(double s) { return {s, 0.0}; }
+__device__ __forceinline__ D1 operator+(D1 x, D1 y) { return {x.a + y.a, x.d + y.d}; }
+__device__ __forceinline__ D1 operator-(D1 x, D1 y) { return {x.a - y.a, x.d - y.d}; }
+__device__ __forceinline__ D1 operator-(D1 x) { return {-x.a, -x.d}; }
+__device__ __forceinline__ D1 operator*(D1 x, D1 y) { return {x.a * y.a, x.a * y.d + x.d * y.a}; }
+__device__ __forceinline__ D1 operator/(D1 x, D1 y) { const double inv = 1.0 / y.a; const double q = x.a * inv; return {q, (x.d - q * y.d) * inv}; }
+__device__ __forceinline__ D1 dsin(D1 x) { return {sin(x.a), cos(x.a) * x.d}; }
+__device__ __forceinline__ D1 dacos(D1 x) { return {acos(x.a), -x.d / sqrt(1.0 - x.a * x.a)}; }
+struct DQ { D1 w, x, y, z; };
+struct DV { D1 x, y, z; };
+__device__ __forceinline__ DQ dq_load(const double* p, int k /*seeded coordinate 3..6 or -1*/) {
+    return {D1{p[6], k == 6 ? 1.0 : 0.0}, D1{p[3], k == 3 ? 1.0 : 0.0}, D1{p[4], k == 4 ? 1.0 : 0.0}, D1{p[5], k == 5 ? 1.0 : 0.0}};
 }
-__device__ inline JV jv_load(const double* p, bool seed) {
-    JV v; v.x = J7(p[0]); v.y = J7(p[1]); v.z = J7(p[2]);
-    if (seed) { v.x.v[0] = 1; v.y.v[1] = 1; v.z.v[2] = 1; }
-    return v;
+__device__ __forceinline__ DV dv_load(const double* p, int k /*0..2 or -1*/) {
+    return {D1{p[0], k == 0 ? 1.0 : 0.0}, D1{p[1], k == 1 ? 1.0 : 0.0}, D1{p[2], k == 2 ? 1.0 : 0.0}};
 }
-__device__ inline JQ jq_mul(const JQ& a, const JQ& b) {
+__device__ __forceinline__ DQ dq_mul(const DQ& a, const DQ& b) {
     return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
             a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
 }
-__device__ inline JQ jq_inv(const JQ& q) { J7 n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z; return {q.w / n2, -(q.x / n2), -(q.y / n2), -(q.z / n2)}; }
-__device__ inline JV jv_cross(const JV& a, const JV& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-__device__ inline JV jq_rot(const JQ& q, const JV& v) {   // Eigen _transformVector
-    JV u{q.x, q.y, q.z};
-    JV uv = jv_cross(u, v);
+__device__ __forceinline__ DQ dq_inv(const DQ& q) { const D1 n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z; return {q.w / n2, -(q.x / n2), -(q.y / n2), -(q.z / n2)}; }
+__device__ __forceinline__ DV dv_cross(const DV& a, const DV& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ DV dq_rot(const DQ& q, const DV& v) {   // Eigen _transformVector
+    const DV u{q.x, q.y, q.z};
+    DV uv = dv_cross(u, v);
     uv = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
-    JV w = jv_cross(u, uv);
+    const DV w = dv_cross(u, uv);
     return {v.x + q.w * uv.x + w.x, v.y + q.w * uv.y + w.y, v.z + q.w * uv.z + w.z};
 }
-__device__ inline JQ jq_slerp(const JQ& a, double t, const JQ& b) {   // Eigen::QuaternionBase::slerp
+__device__ __forceinline__ DQ dq_slerp(const DQ& a, double t, const DQ& b) {   // Eigen::QuaternionBase::slerp
     const double one = 1.0 - 2.220446049250313e-16;
-    J7 d = a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z;
-    J7 ad = d.a < 0.0 ? -d : d;
-    J7 s0, s1;
-    if (ad.a >= one) { s0 = J7(1.0 - t); s1 = J7(t); }
+    const D1 d = a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z;
+    const D1 ad = d.a < 0.0 ? -d : d;
+    D1 s0, s1;
+    if (ad.a >= one) { s0 = dc(1.0 - t); s1 = dc(t); }
     else {
-        J7 th = jacos(ad), st = jsin(th);
-        s0 = jsin(th * J7(1.0 - t)) / st;
-        s1 = jsin(th * J7(t)) / st;
+        const D1 th = dacos(ad), st = dsin(th);
+        s0 = dsin(th * dc(1.0 - t)) / st;
+        s1 = dsin(th * dc(t)) / st;
     }
     if (d.a < 0.0) s1 = -s1;
     return {s0 * a.w + s1 * b.w, s0 * a.x + s1 * b.x, s0 * a.y + s1 * b.y, s0 * a.z + s1 * b.z};
 }
 
-// ICP: c[10] = ta tb tc td ti tj PIJ(3) s ; poses a,b,c,d ; `seed` in 0..3 selects the differentiated block
-__device__ inline void icp_eval(const double* c, const double* pa, const double* pb, const double* pc, const double* pd, int seed, double* r3, double* J21 /*3x7*/) {
+// ICP: c[10] = ta tb tc td ti tj PIJ(3) s ; poses a,b,c,d ; differentiates w.r.t. coordinate k of block `blk`:
+// writes r3 (values) and dr3 = d r / d (block blk, coordinate k)
+__device__ inline void icp_eval1(const double* c, const double* pa, const double* pb, const double* pc, const double* pd, int blk, int k, double* r3, double* dr3) {
     const double ta = c[0], tb = c[1], tc = c[2], td = c[3], ti = c[4], tj = c[5];
-    JQ Qa = jq_load(pa, seed == 0), Qb = jq_load(pb, seed == 1), Qc = jq_load(pc, seed == 2), Qd = jq_load(pd, seed == 3);
-    JV Pa = jv_load(pa, seed == 0), Pb = jv_load(pb, seed == 1), Pc = jv_load(pc, seed == 2), Pd = jv_load(pd, seed == 3);
-    JQ Qi = jq_slerp(Qa, (ti - ta) / (tb - ta), Qb);
-    JQ Qj = jq_slerp(Qc, (tj - tc) / (td - tc), Qd);
-    const J7 wab(tb - ta), tia(ti - ta), wcd(td - tc), tjc(tj - tc);
-    JV Pi{Pa.x + (Pb.x - Pa.x) / wab * tia, Pa.y + (Pb.y - Pa.y) / wab * tia, Pa.z + (Pb.z - Pa.z) / wab * tia};
-    JV Pj{Pc.x + (Pd.x - Pc.x) / wcd * tjc, Pc.y + (Pd.y - Pc.y) / wcd * tjc, Pc.z + (Pd.z - Pc.z) / wcd * tjc};
-    JQ temQ = jq_mul(jq_inv(Qj), Qi);
-    JV dP{Pj.x - Pi.x, Pj.y - Pi.y, Pj.z - Pi.z};
-    JV tem = jq_rot(jq_inv(Qi), dP);
-    JV df{J7(c[6]) - tem.x, J7(c[7]) - tem.y, J7(c[8]) - tem.z};
-    JV RES = jq_rot(temQ, df);
-    J7 o0 = RES.x * J7(c[9]), o2 = RES.z * J7(c[9]);
+    const DQ Qa = dq_load(pa, blk == 0 ? k : -1), Qb = dq_load(pb, blk == 1 ? k : -1), Qc = dq_load(pc, blk == 2 ? k : -1), Qd = dq_load(pd, blk == 3 ? k : -1);
+    const DV Pa = dv_load(pa, blk == 0 ? k : -1), Pb = dv_load(pb, blk == 1 ? k : -1), Pc = dv_load(pc, blk == 2 ? k : -1), Pd = dv_load(pd, blk == 3 ? k : -1);
+    const DQ Qi = dq_slerp(Qa, (ti - ta) / (tb - ta), Qb);
+    const DQ Qj = dq_slerp(Qc, (tj - tc) / (td - tc), Qd);
+    const D1 wab = dc(tb - ta), tia = dc(ti - ta), wcd = dc(td - tc), tjc = dc(tj - tc);
+    const DV Pi{Pa.x + (Pb.x - Pa.x) / wab * tia, Pa.y + (Pb.y - Pa.y) / wab * tia, Pa.z + (Pb.z - Pa.z) / wab * tia};
+    const DV Pj{Pc.x + (Pd.x - Pc.x) / wcd * tjc, Pc.y + (Pd.y - Pc.y) / wcd * tjc, Pc.z + (Pd.z - Pc.z) / wcd * tjc};
+    const DQ temQ = dq_mul(dq_inv(Qj), Qi);
+    const DV dP{Pj.x - Pi.x, Pj.y - Pi.y, Pj.z - Pi.z};
+    const DV tem = dq_rot(dq_inv(Qi), dP);
+    const DV df{dc(c[6]) - tem.x, dc(c[7]) - tem.y, dc(c[8]) - tem.z};
+    const DV RES = dq_rot(temQ, df);
+    const D1 o0 = RES.x * dc(c[9]), o2 = RES.z * dc(c[9]);
     r3[0] = o0.a; r3[1] = 0.0; r3[2] = o2.a;
-    for (int k = 0; k < 7; ++k) { J21[k] = o0.v[k]; J21[7 + k] = 0.0; J21[14 + k] = o2.v[k]; }
+    dr3[0] = o0.d; dr3[1] = 0.0; dr3[2] = o2.d;
 }
-// LPS: c[7] = tl tr tk q(x y z w) ; poses a,b ; seed in 0..1
-__device__ inline void lps_eval(const double* c, const double* pa, const double* pb, int seed, double* r3, double* J21) {
-    JQ Qa = jq_load(pa, seed == 0), Qb = jq_load(pb, seed == 1);
-    JQ Qi = jq_slerp(Qa, (c[2] - c[0]) / (c[1] - c[0]), Qb);
-    JQ Q1{J7(c[6]), J7(c[3]), J7(c[4]), J7(c[5])};
-    JQ Q12 = jq_mul(jq_inv(Qi), Q1);
-    J7 o0 = J7(2.0) * Q12.x / J7(0.01), o1 = J7(2.0) * Q12.y / J7(0.01), o2 = J7(2.0) * Q12.z / J7(0.01);
+// LPS: c[7] = tl tr tk q(x y z w) ; poses a,b
+__device__ inline void lps_eval1(const double* c, const double* pa, const double* pb, int blk, int k, double* r3, double* dr3) {
+    const DQ Qa = dq_load(pa, blk == 0 ? k : -1), Qb = dq_load(pb, blk == 1 ? k : -1);
+    const DQ Qi = dq_slerp(Qa, (c[2] - c[0]) / (c[1] - c[0]), Qb);
+    const DQ Q1{dc(c[6]), dc(c[3]), dc(c[4]), dc(c[5])};
+    const DQ Q12 = dq_mul(dq_inv(Qi), Q1);
+    const D1 o0 = dc(2.0) * Q12.x / dc(0.01), o1 = dc(2.0) * Q12.y / dc(0.01), o2 = dc(2.0) * Q12.z / dc(0.01);
     r3[0] = o0.a; r3[1] = o1.a; r3[2] = o2.a;
-    for (int k = 0; k < 7; ++k) { J21[k] = o0.v[k]; J21[7 + k] = o1.v[k]; J21[14 + k] = o2.v[k]; }
+    dr3[0] = o0.d; dr3[1] = o1.d; dr3[2] = o2.d;
 }
 // mathematically-correct tangent option (vil_options.autodiff_quirk == 0): J[:,3:6] <- J[:,3:7] d(q (x) [1,dth/2])/d dth
 __device__ inline void tangent_fix(const double* pose, double* J21) {

@@ -5,20 +5,45 @@
 //   on a new linearisation: Jacobi/dogleg scaling, gradient, Cauchy point, reduced Cholesky solve,
 //   landmark back-substitution -> traditional dogleg blend -> model decrease -> candidate state.
 // All trust-region state lives in `Ctl` in device memory; `done` makes later launches no-ops.
+//
+// Dense solve: the scaled reduced matrix M = Sc S' Sc + mu dc^2 (D x D, D = 15K+7) plus the
+// right-hand side as an extra row is held PACKED-LOWER in LDS (100 KB at K = 10) and factored by a
+// right-looking blocked Cholesky, NB = 8: wave 0 factors and inverts the 8x8 diagonal block in
+// registers (wave shuffles), one thread per row applies the inverse to the panel, and the trailing
+// update -- the only dense contraction on this path -- runs on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64, one 16x16 tile per wave per step).  The forward substitution is the
+// factorisation of the extra row.  Windows whose packed matrix exceeds LDS (K >= 14) use the same
+// code on a packed global (L2-resident) buffer.
 #pragma once
 #include "vil_dev.hpp"
 #include "vil_factors.hpp"
 
 namespace vd {
 
+#define STEP_NB 8
+
 struct StepShared {
     Ctl c;
     double red[32];
+    double X[64 * 64];      // inverse of every 8x8 diagonal block of L (<= 64 blocks, D <= 512)
     double y[512];
-    double col[512];
-    double dg[512];
+    double sc[512], dcs[512], gr[512], gn[512];   // Sc, dogleg diagonal, gradient_, gauss_newton_step_ (camera part)
     int need, was_first, ok;
+    long long tacc[3];
 };
+
+// block-wide sum(a), sum(b) and sum-or-max(c) with one pair of barriers
+template <bool CMAX = false>
+__device__ __forceinline__ void bsum3(double& a, double& b, double& c, StepShared& s) {
+    a = wave_sum(a); b = wave_sum(b);
+    if (CMAX) { for (int o = 32; o > 0; o >>= 1) c = fmax(c, __shfl_xor(c, o, 64)); } else c = wave_sum(c);
+    __syncthreads();
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s.red[w] = a; s.red[8 + w] = b; s.red[16 + w] = c; }
+    __syncthreads();
+    a = 0; b = 0; c = 0;
+    for (int q = 0; q < nw; ++q) { a += s.red[q]; b += s.red[8 + q]; c = CMAX ? fmax(c, s.red[16 + q]) : c + s.red[16 + q]; }
+}
 
 __device__ __forceinline__ double bsum(double v, StepShared& s) {
     v = wave_sum(v);
@@ -62,14 +87,11 @@ __device__ __forceinline__ double lm_dot(const DevP& P, const SysBuf& sb, int l,
 
 // v^T H v over all free parameters, H = J^T J of the corrected Jacobian, from the reduced pieces:
 //   v_c^T H_cc v_c = v_c^T S' v_c + sum_l invp (e_l.v_c)^2     (S' = H_cc - sum_l invp e e^T)
-__device__ inline double quad_form(const DevP& P, const SysBuf& sb, const double* vc, const double* vl, StepShared& s) {
+// vc must be readable by every thread (LDS or global).
+__device__ __forceinline__ double quad_form(const DevP& P, const SysBuf& sb, const double* vc, const double* vl, StepShared& s) {
     const int D = P.D, L = P.L, t = threadIdx.x, NT = blockDim.x;
     double part = 0;
-    for (int i = t; i < D; i += NT) {
-        double row = 0;
-        for (int k = 0; k < D; ++k) row += sb.S[(size_t)k * D + i] * vc[k];   // symmetric: column read is coalesced
-        part += vc[i] * row;
-    }
+    for (int e = t; e < D * D; e += NT) { const int i = e / D, j = e - i * D; part += vc[i] * sb.S[e] * vc[j]; }
     for (int l = t; l < L; l += NT) {
         const double ip = sb.invp[l];
         if (ip == 0.0) continue;
@@ -79,23 +101,213 @@ __device__ inline double quad_form(const DevP& P, const SysBuf& sb, const double
     return bsum(part, s);
 }
 
-__device__ inline void pose_plus(const double* in, const double* d, double* o) {
+__device__ __forceinline__ void pose_plus(const double* in, const double* d, double* o) {
     for (int k = 0; k < 3; ++k) o[k] = in[k] + d[k];
     Q4 q = qmul(qload(in + 3), Q4{1.0, 0.5 * d[3], 0.5 * d[4], 0.5 * d[5]});
     const double n = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
     o[3] = q.x * n; o[4] = q.y * n; o[5] = q.z * n; o[6] = q.w * n;
 }
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// broadcast lane `L` (compile-time constant) of a double through SGPRs: v_readlane_b32 x2, no LDS round trip
+template <int L>
+__device__ __forceinline__ double bcast(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), L);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), L);
+    return __hiloint2double(hi, lo);
+}
+template <int J, int C>
+struct DiagUpd {   // trailing update inside the 8x8 diagonal block for column J, target columns C..7
+    static __device__ __forceinline__ void run(double (&a)[STEP_NB], int r) {
+        const double lcj = bcast<C>(a[J]);
+        if (r >= C) a[C] -= a[J] * lcj;
+        if constexpr (C + 1 < STEP_NB) DiagUpd<J, C + 1>::run(a, r);
+    }
+};
+// sqrt(x) and 1/sqrt(x) together: hardware rsq seed + two coupled Newton steps (no divide on the pivot chain)
+__device__ __forceinline__ void sqrt_rsqrt(double x, double& sq, double& rs) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g); h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g); h = fma(h, e, h);
+    sq = g; rs = h + h;
+}
+template <int J>
+struct DiagCol {
+    static __device__ __forceinline__ void run(double (&a)[STEP_NB], double (&dinv)[STEP_NB], int r, bool& ok) {
+        const double pj = bcast<J>(a[J]);
+        if (!(pj > 0.0) || !isfinite(pj)) ok = false;
+        double dj, inv;
+        sqrt_rsqrt(pj, dj, inv);
+        dinv[J] = inv;
+        if (r == J) a[J] = dj; else if (r > J) a[J] *= inv;
+        if constexpr (J + 1 < STEP_NB) { DiagUpd<J, J + 1>::run(a, r); DiagCol<J + 1>::run(a, dinv, r, ok); }
+    }
+};
+template <int RR, int K>
+struct InvDot {
+    static __device__ __forceinline__ void run(const double (&a)[STEP_NB], const double (&x)[STEP_NB], double& sum) {
+        if constexpr (K < RR) { sum += bcast<RR>(a[K]) * x[K]; InvDot<RR, K + 1>::run(a, x, sum); }
+    }
+};
+template <int RR>
+struct InvRow {
+    static __device__ __forceinline__ void run(const double (&a)[STEP_NB], const double (&dinv)[STEP_NB], double (&x)[STEP_NB], int cc) {
+        double sum = 0.0;
+        InvDot<RR, 0>::run(a, x, sum);
+        x[RR] = (RR == cc) ? dinv[RR] : (RR > cc ? -sum * dinv[RR] : 0.0);
+        if constexpr (RR + 1 < STEP_NB) InvRow<RR + 1>::run(a, dinv, x, cc);
+    }
+};
+
+__device__ __forceinline__ int tri_off(int i) { return (i * (i + 1)) >> 1; }
+
+// Blocked Cholesky of the packed-lower (D+1) x (D+1) array A whose last row is the right-hand side:
+// on return rows < D hold L, row D holds y = L^-1 rhs, s.X the inverses of the diagonal blocks.
+// Returns false (uniformly) if a pivot is not positive.
+template <class PTR>
+__device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
+    const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
+    const int R = D + 1;   // rows including the rhs row
+    long long tacc[3] = {0, 0, 0}, tprev = 0;
+    #define CSTAMP(k) do { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); if (k >= 0) tacc[k < 0 ? 0 : k] += tt_ - tprev; tprev = tt_; } while (0)
+    for (int kb = 0, blk = 0; kb < D; kb += STEP_NB, ++blk) {
+        const int nb = min(STEP_NB, D - kb);
+        CSTAMP(-1);
+        // ---- 1. diagonal block: factor + invert in registers of wave 0 --------------------------
+        if (wave == 0) {
+            const int r = lane & 7;
+            double a[STEP_NB];
+#pragma unroll
+            for (int c = 0; c < STEP_NB; ++c) a[c] = (r < nb && c <= r && c < nb) ? A[tri_off(kb + r) + kb + c] : (c == r ? 1.0 : 0.0);
+            bool ok = true;
+            double dinv[STEP_NB];
+            DiagCol<0>::run(a, dinv, r, ok);
+            // inverse: lane c computes column c of X = L^-1
+            double x[STEP_NB];
+#pragma unroll
+            for (int q = 0; q < STEP_NB; ++q) x[q] = 0.0;
+            const int cc = lane & 7;
+            InvRow<0>::run(a, dinv, x, cc);
+            if (lane < STEP_NB) {
+#pragma unroll
+                for (int c = 0; c < STEP_NB; ++c) {
+                    if (lane < nb && c <= lane && c < nb) A[tri_off(kb + lane) + kb + c] = a[c];
+                }
+#pragma unroll
+                for (int rr = 0; rr < STEP_NB; ++rr) s.X[blk * 64 + rr * 8 + lane] = x[rr];   // X[rr][cc]
+            }
+            if (lane == 0) s.ok = ok ? 1 : 0;
+        }
+        __syncthreads();
+        CSTAMP(0);
+        if (!s.ok) return false;
+        // ---- 2. panel: rows below the block (incl. rhs row), L_i = A_i X^T ------------------------
+        const int r0 = kb + nb;
+        for (int i = r0 + t; i < R; i += NT) {
+            double a[STEP_NB], o[STEP_NB];
+            const int base = tri_off(i) + kb;
+#pragma unroll
+            for (int c = 0; c < STEP_NB; ++c) a[c] = c < nb ? A[base + c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < STEP_NB; ++c) { double v = 0;
+#pragma unroll
+                for (int k = 0; k <= c; ++k) v += a[k] * s.X[blk * 64 + c * 8 + k]; o[c] = v; }
+#pragma unroll
+            for (int c = 0; c < STEP_NB; ++c) if (c < nb) A[base + c] = o[c];
+        }
+        __syncthreads();
+        CSTAMP(1);
+        // ---- 3. trailing update on the fp64 matrix cores: C[r][c] -= sum_k L[r][kb+k] L[c][kb+k] -----
+        const int rem = R - r0;                // rows r0 .. D (rhs row included)
+        if (rem > 0) {
+            const int nt = (rem + 15) >> 4;
+            const int ntile = nt * (nt + 1) / 2;
+            // software-pipelined over up to 8 tiles per wave: all operand loads, then the MFMAs, then the read-modify-writes
+            for (int t0 = 0; t0 < ntile; t0 += 8 * NW) {
+                d4 acc[8]; double av[8][2], bv[8][2]; int rowb[8], colb[8];
+                const int cnt = min(8, (ntile - t0 - wave + NW - 1) / NW);   // wave-uniform number of live slots
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (u < cnt) {
+                    const int tile = t0 + wave + u * NW;
+                    int I = (int)((sqrtf(8.f * (float)tile + 1.f) - 1.f) * 0.5f);
+                    if (((I + 1) * (I + 2)) / 2 <= tile) ++I;
+                    if ((I * (I + 1)) / 2 > tile) --I;
+                    const int J = tile - (I * (I + 1)) / 2;
+                    const bool valid = tile < ntile;
+                    rowb[u] = valid ? r0 + 16 * I : R; colb[u] = valid ? r0 + 16 * J : D;
+                    const int rr = rowb[u] + (lane & 15), cr = colb[u] + (lane & 15);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int k = 4 * h + (lane >> 4);
+                        av[u][h] = (rr < R && k < nb) ? A[tri_off(rr) + kb + k] : 0.0;
+                        bv[u][h] = (cr < D && k < nb) ? A[tri_off(cr) + kb + k] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (u < cnt) { d4 z = {0.0, 0.0, 0.0, 0.0}; acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][0], bv[u][0], z, 0, 0, 0); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (u < cnt) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][1], bv[u][1], acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (u < cnt) {
+                    const int col = colb[u] + (lane & 15);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = rowb[u] + (lane >> 4) + 4 * g;
+                        if (row < R && col < D && col <= row) A[tri_off(row) + col] -= acc[u][g];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        CSTAMP(2);
+    }
+    if (threadIdx.x == 0) { s.tacc[0] = tacc[0]; s.tacc[1] = tacc[1]; s.tacc[2] = tacc[2]; }
+    return true;
+}
+
+// back substitution L^T x = y (y = row D of A), blocked; result in s.y[0..D)
+template <class PTR>
+__device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
+    const int t = threadIdx.x, NT = blockDim.x;
+    for (int i = t; i < D; i += NT) s.y[i] = A[tri_off(D) + i];
+    __syncthreads();
+    const int nblk = (D + STEP_NB - 1) / STEP_NB;
+    for (int blk = nblk - 1; blk >= 0; --blk) {
+        const int kb = blk * STEP_NB, nb = min(STEP_NB, D - kb);
+        // x_blk = X^T y_blk
+        double xv = 0.0;
+        if (t < nb) { for (int k = t; k < nb; ++k) xv += s.X[blk * 64 + k * 8 + t] * s.y[kb + k]; }
+        __syncthreads();
+        if (t < nb) s.y[kb + t] = xv;
+        __syncthreads();
+        // y_c -= sum_r L[kb+r][c] x_r  for c < kb
+        for (int c = t; c < kb; c += NT) {
+            double v = s.y[c];
+            for (int r = 0; r < nb; ++r) v -= A[tri_off(kb + r) + c] * s.y[kb + r];
+            s.y[c] = v;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace vd
 
+template <bool LDSM>
 __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) {
     using namespace vd;
     __shared__ StepShared s;
+    extern __shared__ double Alds[];
     const int t = threadIdx.x, NT = blockDim.x;
     const int D = P.D, L = P.L;
     if (t == 0) { s.c = *P.ctl; s.need = 0; s.was_first = 0; s.ok = 1; }
     __syncthreads();
+    #define STAMP(k) do { __syncthreads(); if (t == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[k] = tt_; } } while (0)
     if (s.c.done) return;
+    STAMP(0);
     // ---------------- judge the candidate that the sweep just linearised -------------------------
     if (t == 0) {
         Ctl& c = s.c;
@@ -131,64 +343,79 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     const double* x = P.x[cur];
     double* xc = P.x[1 - cur];
     if (s.c.done) { if (t == 0) *P.ctl = s.c; return; }
-
+    STAMP(1);
+    double gn2 = 0, g2 = 0, gg = 0;
     if (s.need) {
-        // mirror the upper triangle written by the sweep
-        for (int e = t; e < D * D; e += NT) { const int i = e / D, j = e % D; if (i < j) sb.S[(size_t)j * D + i] = sb.S[e]; }
-        // gradient tolerance on the new linearisation
+        // ---- camera vectors: Jacobi scaling (first linearisation), dogleg diagonal, gradient_, u = Sc gradient_/d
         double gm = 0;
-        for (int i = t; i < D; i += NT) gm = fmax(gm, fabs(sb.bc[i]));
-        for (int l = t; l < L; l += NT) if (sb.invp[l] != 0.0) gm = fmax(gm, fabs(sb.bl[l]));
-        gm = bmax(gm, s);
-        if (gm <= O.gradient_tolerance) { if (t == 0) { s.c.done = 1; s.c.term = 2; *P.ctl = s.c; } return; }
-        // Jacobi scaling from the first Jacobian, dogleg diagonal, gradient in dogleg space
-        if (s.was_first) for (int i = t; i < D; i += NT) P.Sc[i] = O.jacobi_scaling ? 1.0 / (1.0 + sqrt(sb.diag[i])) : 1.0;
-        __syncthreads();
-        double g2 = 0;
         for (int i = t; i < D; i += NT) {
-            const double Sc = P.Sc[i];
-            const double d = sqrt(fmin(fmax(Sc * Sc * sb.diag[i], 1e-6), 1e32));
-            const double g = Sc * sb.bc[i] / d;
-            P.dc[i] = d; P.gradc[i] = g; P.tmpc[i] = Sc * g / d; g2 += g * g;
+            const double dg = sb.diag[i], b = sb.bc[i];
+            double Sc;
+            if (s.was_first) { Sc = O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0; P.Sc[i] = Sc; } else Sc = P.Sc[i];
+            const double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
+            const double g = Sc * b / d;
+            s.sc[i] = Sc; s.dcs[i] = d; s.gr[i] = g; s.y[i] = Sc * g / d;
+            P.dc[i] = d; P.gradc[i] = g;
+            g2 += g * g; gm = fmax(gm, fabs(b));
         }
-        for (int l = t; l < L; l += NT) {
-            const double Sl = P.Sl[l];
-            const double d = sqrt(fmin(fmax(Sl * Sl * sb.hll[l], 1e-6), 1e32));
-            const double g = sb.invp[l] != 0.0 ? Sl * sb.bl[l] / d : 0.0;
-            P.dl[l] = d; P.gradl[l] = g; P.tmpl[l] = Sl * g / d; g2 += g * g;
-        }
-        g2 = bsum(g2, s);
-        const double q = quad_form(P, sb, P.tmpc, P.tmpl, s);
-        // reduced system  M = Sc S' Sc + mu dc^2 ,  rhs = Sc gred   (M lower triangle used)
-        const double mu = s.c.mu;
-        for (int e = t; e < D * D; e += NT) {
-            const int i = e / D, j = e % D;
-            double v = P.Sc[i] * sb.S[e] * P.Sc[j];
-            if (i == j) v += mu * P.dc[i] * P.dc[i];
-            P.M[e] = v;
-        }
-        for (int i = t; i < D; i += NT) s.y[i] = P.Sc[i] * sb.gred[i];
         __syncthreads();
-        // ---- dense Cholesky (right-looking), forward substitution fused as an extra row -----------
-        bool fail = false;
-        for (int j = 0; j < D; ++j) {
-            const double piv = P.M[(size_t)j * D + j];
-            if (!(piv > 0.0) || !isfinite(piv)) { fail = true; break; }
-            const double inv = 1.0 / sqrt(piv);
-            __syncthreads();
-            for (int i = j + 1 + t; i < D; i += NT) { const double v = P.M[(size_t)i * D + j] * inv; P.M[(size_t)i * D + j] = v; s.col[i] = v; }
-            if (t == 0) { s.dg[j] = 1.0 / inv; s.y[j] *= inv; }
-            __syncthreads();
-            const int r = D - 1 - j;
-            const double yj = s.y[j];
-            for (int e = t; e < r * r; e += NT) {
-                const int i = j + 1 + e / r, k = j + 1 + e % r;
-                if (k <= i) P.M[(size_t)i * D + k] -= s.col[i] * s.col[k];
+        STAMP(9);
+        // ---- one pass over the landmarks: dl, gradient_, and their share of u^T H u --------------------------
+        double q = 0;
+        for (int l = t; l < L; l += NT) {
+            const double ip = sb.invp[l], Sl = P.Sl[l], h = sb.hll[l], b = sb.bl[l];
+            const double d = sqrt(fmin(fmax(Sl * Sl * h, 1e-6), 1e32));
+            const double g = ip != 0.0 ? Sl * b / d : 0.0;
+            P.dl[l] = d; P.gradl[l] = g;
+            if (ip != 0.0) {
+                const double ul = Sl * g / d;
+                const double ev = lm_dot(P, sb, l, s.y);
+                q += ip * ev * ev + 2.0 * ul * ev + h * ul * ul;
+                g2 += g * g; gm = fmax(gm, fabs(b));
             }
-            for (int k = j + 1 + t; k < D; k += NT) s.y[k] -= yj * s.col[k];
-            __syncthreads();
         }
-        if (fail) {
+        STAMP(10);
+        // ---- camera share of u^T H u, fused with packing M = Sc S' Sc + mu dc^2 (+ rhs row) into LDS ------------
+        const double mu = s.c.mu;
+        const int NL = tri_off(D);            // packed lower entries of rows 0..D-1 ; row D (rhs) follows
+        double* Ag = P.M;
+        for (int base = t; base < NL; base += 8 * NT) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * NT;
+                if (idx < NL) {
+                    int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+                    while (tri_off(i + 1) <= idx) ++i;
+                    while (tri_off(i) > idx) --i;
+                    v[u] = sb.S[(size_t)i * D + (idx - tri_off(i))];
+                } else v[u] = 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * NT;
+                if (idx < NL) {
+                    int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+                    while (tri_off(i + 1) <= idx) ++i;
+                    while (tri_off(i) > idx) --i;
+                    const int j = idx - tri_off(i);
+                    q += (i == j ? 1.0 : 2.0) * s.y[i] * v[u] * s.y[j];
+                    double m = s.sc[i] * v[u] * s.sc[j];
+                    if (i == j) m += mu * s.dcs[i] * s.dcs[i];
+                    if constexpr (LDSM) Alds[idx] = m; else Ag[idx] = m;
+                }
+            }
+        }
+        STAMP(11);
+        for (int j = t; j < D; j += NT) { const double m = s.sc[j] * sb.gred[j]; if constexpr (LDSM) Alds[NL + j] = m; else Ag[NL + j] = m; }
+        bsum3<true>(g2, q, gm, s);
+        STAMP(2);
+        if (gm <= O.gradient_tolerance) { if (t == 0) { s.c.done = 1; s.c.term = 2; *P.ctl = s.c; } return; }
+        bool ok;
+        if constexpr (LDSM) ok = chol_blocked(Alds, D, s); else ok = chol_blocked(Ag, D, s);
+        STAMP(3);
+        if (t == 0) { P.dbg[20] = s.tacc[0]; P.dbg[21] = s.tacc[1]; P.dbg[22] = s.tacc[2]; }
+        if (!ok) {
             // dogleg_strategy.cc: mu *= 10 and retry; the Schur pivots depend on mu, so re-sweep at x_cur
             if (t == 0) {
                 Ctl& c = s.c;
@@ -197,41 +424,47 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                 c.resweep = 1;
             }
             for (int i = t; i < P.NS; i += NT) xc[i] = x[i];
-            SysBuf z = P.sys[1 - cur];
-            for (int e = t; e < D * D; e += NT) z.S[e] = 0.0;
-            for (int i = t; i < D; i += NT) { z.gred[i] = 0; z.bc[i] = 0; z.diag[i] = 0; }
-            if (t == 0) z.cost[0] = 0.0;
             __syncthreads();
             if (t == 0) *P.ctl = s.c;
             return;
         }
-        // back substitution L^T x = y
-        for (int j = D - 1; j >= 0; --j) {
-            __syncthreads();
-            const double xj = s.y[j] / s.dg[j];
-            for (int k = t; k < j; k += NT) s.y[k] -= P.M[(size_t)j * D + k] * xj;
-            __syncthreads();
-            if (t == 0) s.y[j] = xj;
+        if constexpr (LDSM) back_subst(Alds, D, s); else back_subst(Ag, D, s);
+        STAMP(4);
+        // ---- gauss-newton step in dogleg space; landmark back-substitution fused with the dogleg sums ------------
+        for (int i = t; i < D; i += NT) {
+            const double xi = s.y[i];
+            const double gnv = -xi * s.dcs[i];
+            s.gn[i] = gnv; P.gnc[i] = gnv;
+            gn2 += gnv * gnv; gg += gnv * s.gr[i];
+            s.y[i] = s.sc[i] * xi;     // Sc x_c for the landmark back-substitution
         }
-        __syncthreads();
-        // gauss-newton step in dogleg space (camera part), landmark back-substitution
-        for (int i = t; i < D; i += NT) { const double xi = s.y[i]; P.gnc[i] = -xi * P.dc[i]; P.tmpc[i] = P.Sc[i] * xi; }
         __syncthreads();
         for (int l = t; l < L; l += NT) {
             const double ip = sb.invp[l];
-            double xl = 0.0;
-            if (ip != 0.0) xl = (sb.bl[l] - lm_dot(P, sb, l, P.tmpc)) * ip / P.Sl[l];
-            P.gnl[l] = -xl * P.dl[l];
+            double gnv = 0.0;
+            if (ip != 0.0) {
+                const double xl = (sb.bl[l] - lm_dot(P, sb, l, s.y)) * ip / P.Sl[l];
+                gnv = -xl * P.dl[l];
+                gn2 += gnv * gnv; gg += gnv * P.gradl[l];
+            }
+            P.gnl[l] = gnv;
         }
-        if (t == 0) { s.c.alpha = g2 / q; s.c.mu = fmax(O.min_mu, 2.0 * s.c.mu / 10.0); }
+        double dummy = 0;
+        bsum3(gn2, gg, dummy, s);
+        if (t == 0) {
+            Ctl& c = s.c;
+            c.alpha = g2 / q; c.mu_used = c.mu; c.gn2 = gn2; c.g2 = g2; c.gg = gg;
+            c.mu = fmax(O.min_mu, 2.0 * c.mu / 10.0);
+        }
+        __syncthreads();
+    } else {
+        for (int i = t; i < D; i += NT) { s.sc[i] = P.Sc[i]; s.dcs[i] = P.dc[i]; s.gr[i] = P.gradc[i]; s.gn[i] = P.gnc[i]; }
         __syncthreads();
     }
-    // ---------------- traditional dogleg in dogleg space -----------------------------------------
-    double gn2 = 0, g2 = 0, gg = 0;
-    for (int i = t; i < D; i += NT) { const double a = P.gnc[i], b = P.gradc[i]; gn2 += a * a; g2 += b * b; gg += a * b; }
-    for (int l = t; l < L; l += NT) { const double a = P.gnl[l], b = P.gradl[l]; gn2 += a * a; g2 += b * b; gg += a * b; }
-    gn2 = bsum(gn2, s); g2 = bsum(g2, s); gg = bsum(gg, s);
-    const double radius = s.c.radius, alpha = s.c.alpha;
+    STAMP(5);
+    // ---------------- traditional dogleg in dogleg space (scalars saved with the linearisation) ----------------
+    gn2 = s.c.gn2; g2 = s.c.g2; gg = s.c.gg;
+    const double radius = s.c.radius, alpha = s.c.alpha, mu_u = s.c.mu_used;
     const double gn_norm = sqrt(gn2), g_norm = sqrt(g2);
     double cg, cn, dnorm;
     if (gn_norm <= radius) { cg = 0; cn = 1; dnorm = gn_norm; }
@@ -245,55 +478,48 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         const double beta = (cc <= 0) ? (dd - cc) / bma2 : (radius * radius - a2) / (dd + cc);
         cg = -alpha * (1 - beta); cn = beta; dnorm = radius;
     }
-    double gd = 0;
-    for (int i = t; i < D; i += NT) { const double st = P.Sc[i] * (cg * P.gradc[i] + cn * P.gnc[i]) / P.dc[i]; P.stepc[i] = st; gd += sb.bc[i] * st; }
-    for (int l = t; l < L; l += NT) {
-        double st = 0.0;
-        if (sb.invp[l] != 0.0) { st = P.Sl[l] * (cg * P.gradl[l] + cn * P.gnl[l]) / P.dl[l]; gd += sb.bl[l] * st; }
-        P.stepl[l] = st;
-    }
-    gd = bsum(gd, s);
-    const double qd = quad_form(P, sb, P.stepc, P.stepl, s);
+    // model decrease from the linear-algebra identities of the solved system (u = Sc gradient_/d, w = GN step):
+    //   u^T H u = g2/alpha ; H w = -g - mu (d/S)^2 w  =>  u^T H w = -g2 - mu gg ,  w^T H w = -gg - mu gn2 ;  g^T u = g2 , g^T w = gg
+    const double qd = cg * cg * (g2 / alpha) + 2.0 * cg * cn * (-g2 - mu_u * gg) + cn * cn * (-gg - mu_u * gn2);
+    const double gd = cg * g2 + cn * gg;
     const double model_change = -(0.5 * qd + gd);
     // ---------------- candidate state x_cur (+) step, parameter tolerance ---------------------------
+    for (int i = t; i < D; i += NT) s.y[i] = s.sc[i] * (cg * s.gr[i] + cn * s.gn[i]) / s.dcs[i];
+    __syncthreads();
+    const double* stepc = s.y;
     double xn = 0, sn = 0;
     const int K = P.K;
     for (int k = t; k < 2 * K + 2; k += NT) {
         if (k < K) {
             const double* in = x + xo_pose(P, k); double* o = xc + xo_pose(P, k);
             if (P.pose_const && P.pose_const[k]) { for (int q = 0; q < 7; ++q) o[q] = in[q]; }
-            else { pose_plus(in, P.stepc + col_pose(P, k), o); for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
+            else { pose_plus(in, stepc + col_pose(P, k), o); for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
         } else if (k < 2 * K) {
             const int kk = k - K;
             const double* in = x + xo_sb(P, kk); double* o = xc + xo_sb(P, kk);
             const bool cst = P.sb_const && P.sb_const[kk];
-            for (int q = 0; q < 9; ++q) { const double d = cst ? 0.0 : P.stepc[col_sb(P, kk) + q]; o[q] = in[q] + d; if (!cst) { xn += in[q] * in[q]; sn += d * d; } }
+            for (int q = 0; q < 9; ++q) { const double d = cst ? 0.0 : stepc[col_sb(P, kk) + q]; o[q] = in[q] + d; if (!cst) { xn += in[q] * in[q]; sn += d * d; } }
         } else if (k == 2 * K) {
             const double* in = x + xo_ex(P); double* o = xc + xo_ex(P);
             if (P.ex_const) { for (int q = 0; q < 7; ++q) o[q] = in[q]; }
-            else { pose_plus(in, P.stepc + col_ex(P), o); for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
+            else { pose_plus(in, stepc + col_ex(P), o); for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
         } else {
             const double in = x[xo_td(P)];
-            const double d = P.td_free ? P.stepc[col_td(P)] : 0.0;
+            const double d = P.td_free ? stepc[col_td(P)] : 0.0;
             xc[xo_td(P)] = in + d;
             if (P.td_free) { xn += in * in; sn += d * d; }
         }
     }
     for (int l = t; l < L; l += NT) {
         const double in = x[xo_lam(P) + l];
-        const bool fr = !(P.lm_const && P.lm_const[l]);
-        const double d = fr ? P.stepl[l] : 0.0;
+        double d = 0.0;
+        if (sb.invp[l] != 0.0) d = P.Sl[l] * (cg * P.gradl[l] + cn * P.gnl[l]) / P.dl[l];
         xc[xo_lam(P) + l] = in + d;
-        if (fr) { xn += in * in; sn += d * d; }
+        if (!(P.lm_const && P.lm_const[l])) { xn += in * in; sn += d * d; }
     }
-    xn = bsum(xn, s); sn = bsum(sn, s);
-    // zero the candidate system for the next sweep
-    {
-        SysBuf z = P.sys[1 - cur];
-        for (int e = t; e < D * D; e += NT) z.S[e] = 0.0;
-        for (int i = t; i < D; i += NT) { z.gred[i] = 0; z.bc[i] = 0; z.diag[i] = 0; }
-        if (t == 0) z.cost[0] = 0.0;
-    }
+    double dummy2 = 0;
+    bsum3(xn, sn, dummy2, s);
+    STAMP(6);
     if (t == 0) {
         Ctl& c = s.c;
         c.iter++;
@@ -312,5 +538,6 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     }
     __syncthreads();
     if (s.c.resweep && !s.c.done) { for (int i = t; i < P.NS; i += NT) xc[i] = x[i]; }
+    STAMP(7);
     if (t == 0) *P.ctl = s.c;
 }

@@ -1,25 +1,23 @@
 // The factor sweep: ONE launch evaluates every residual block of the window at the candidate state
-// and reduces it into the Schur-complement normal equations of the candidate linearisation
+// and contracts it towards the Schur-complement normal equations of the candidate linearisation
 // (what ceres' Evaluate + SchurEliminator do per trust-region iteration behind estimator.cpp:1414).
+// No global atomics: every workgroup accumulates in registers / LDS and writes ONE partial record;
+// k_reduce then gathers the partials into the dense reduced system S', g (deterministic order).
 //
 // Work-group roles by blockIdx (all 256 threads):
 //   [imu]     one WG per IMU factor: lane 0 forms the raw 15x30 block, the WG whitens with the
 //             pre-factored sqrt-information and contracts to a 30x30 H block
-//   [visual]  one WG per chunk of <= 8 landmarks: thread-per-factor evaluation staged in LDS,
-//             thread-per-landmark Schur pivots, wave-per-landmark block outer products
+//   [visual]  one WG per group of landmark sub-chunks (<= 8 landmarks each): thread-per-factor
+//             evaluation staged in LDS, thread-per-landmark Schur pivots, wave-per-landmark block outer
+//             products accumulated into an LDS-resident packed triangle of the (6K+7)^2 visual sub-space
 //   [plane]/[edge] one WG per <=256 pose-uniform LiDAR points: thread-per-point evaluation,
-//             wave64 butterfly reduction of the 6x6 + 6 + cost, one atomic set per wave
+//             wave64 butterfly reduction of the 6x6 + 6 + cost
 //   [misc]    prior (n x n gemv on the pre-contracted J0^T J0), ICP and LPS AutoDiff factors
 #pragma once
 #include "vil_dev.hpp"
 #include "vil_factors.hpp"
 
 namespace vd {
-
-__device__ __forceinline__ void S_add(const DevP& P, double* S, int i, int j, double v) {
-    if (i > j) { int t = i; i = j; j = t; }
-    atomic_add_f64(S + (size_t)i * P.D + j, v);
-}
 
 __device__ __forceinline__ double block_sum(double v, double* red /*>= 4 doubles*/) {
     v = wave_sum(v);
@@ -30,18 +28,33 @@ __device__ __forceinline__ double block_sum(double v, double* red /*>= 4 doubles
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
     return t;
 }
+__device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }   // ds_add_f64
+__device__ __forceinline__ int tri_idx(int NV, int i, int j) { if (i > j) { const int t = i; i = j; j = t; } return i * NV - ((i * (i - 1)) >> 1) + (j - i); }
 
 // ---------------------------------------------------------------------------------------------
-__device__ inline void sweep_imu(const DevP& P, const SolveOpts& O, int f, const double* x, SysBuf& sb, double* sm) {
+__device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int f, const double* x, double* sm) {
     double* Jraw = sm;            // 450
     double* rr = sm + 450;        // 15
     double* UJ = sm + 480;        // 450
     double* Ur = sm + 930;        // 15
     const double* c = P.imu_c + (size_t)f * 287;
-    if (c[16] > 10.0) return;     // estimator.cpp:1182
-    const int i = P.imu_i[f], j = P.imu_j[f];
+    double* out = P.ipart + (size_t)f * 931;
     const int t = threadIdx.x;
-    if (t == 0) imu_raw(c, V3{P.G[0], P.G[1], P.G[2]}, x + xo_pose(P, i), x + xo_sb(P, i), x + xo_pose(P, j), x + xo_sb(P, j), rr, Jraw);
+    if (c[16] > 10.0) { for (int e = t; e < 931; e += blockDim.x) out[e] = 0.0; return; }   // estimator.cpp:1182
+    const int i = P.imu_i[f], j = P.imu_j[f];
+    for (int e = t; e < 450; e += blockDim.x) Jraw[e] = 0.0;
+    __syncthreads();
+    if (t <= IMU_NBLOCKS) {   // lanes 0..16: one 3x3 block each (common terms recomputed per lane); lane 17: residual
+        ImuCommon o;
+        imu_common(c, V3{P.G[0], P.G[1], P.G[2]}, x + xo_pose(P, i), x + xo_sb(P, i), x + xo_pose(P, j), x + xo_sb(P, j), o);
+        if (t == IMU_NBLOCKS) imu_resid(o, rr);
+        else {
+            int r0, c0; M3 m; double sc;
+            imu_block(o, c, t, r0, c0, m, sc);
+            put33(Jraw, 30, r0, c0, m, sc);
+            if (t == 16) put33(Jraw, 30, 12, 27, m, sc);
+        }
+    }
     __syncthreads();
     const double* U = P.imu_U + (size_t)f * 225;
     const bool ci = P.pose_const && P.pose_const[i], cj = P.pose_const && P.pose_const[j];
@@ -61,167 +74,192 @@ __device__ inline void sweep_imu(const DevP& P, const SolveOpts& O, int f, const
         }
     }
     __syncthreads();
-    auto gcol = [&](int a) { return a < 6 ? col_pose(P, i) + a : (a < 15 ? col_sb(P, i) + a - 6 : (a < 21 ? col_pose(P, j) + a - 15 : col_sb(P, j) + a - 21)); };
-    for (int e = t; e < 900 + 30; e += blockDim.x) {
-        if (e < 900) {
-            const int a = e / 30, b = e % 30;
-            if (a > b) continue;
-            double s = 0;
-            for (int k = 0; k < 15; ++k) s += UJ[k * 30 + a] * UJ[k * 30 + b];
-            if (s != 0.0) {
-                S_add(P, sb.S, gcol(a), gcol(b), s);
-                if (a == b) atomic_add_f64(sb.diag + gcol(a), s);
-            }
-        } else {
-            const int a = e - 900;
-            double s = 0;
-            for (int k = 0; k < 15; ++k) s += UJ[k * 30 + a] * Ur[k];
-            if (s != 0.0) { atomic_add_f64(sb.bc + gcol(a), s); atomic_add_f64(sb.gred + gcol(a), s); }
-        }
+    for (int e = t; e < 931; e += blockDim.x) {
+        double s = 0;
+        if (e < 900) { const int a = e / 30, b = e % 30; for (int k = 0; k < 15; ++k) s += UJ[k * 30 + a] * UJ[k * 30 + b]; }
+        else if (e < 930) { const int a = e - 900; for (int k = 0; k < 15; ++k) s += UJ[k * 30 + a] * Ur[k]; }
+        else { for (int k = 0; k < 15; ++k) s += Ur[k] * Ur[k]; s *= 0.5; }
+        out[e] = s;
     }
-    if (t == 0) { double s = 0; for (int k = 0; k < 15; ++k) s += Ur[k] * Ur[k]; atomic_add_f64(sb.cost, 0.5 * s); }
 }
 
 // ---------------------------------------------------------------------------------------------
 // LDS per factor: [Ji 12 | Jj 12 | Jex 12 | Jt 2 | Jl 2 | r 2 | eO 6] = 48 doubles
 #define VF_STRIDE 49   // odd stride: conflict-free column access
-__device__ inline void sweep_visual(const DevP& P, const SolveOpts& O, const Ctl& ctl, int chunk, const double* x, SysBuf& sb, double* sm) {
-    const int l0 = P.vchunk[2 * chunk], l1 = P.vchunk[2 * chunk + 1];
-    const int f0 = P.lm_start[l0], f1 = P.lm_start[l1];
-    const int nf = f1 - f0, nl = l1 - l0;
+__device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, const Ctl& ctl, int wg, const double* x, SysBuf& sb, double* sm) {
+    const int NV = P.NV, NVT = P.NVT;
     const int t = threadIdx.x;
-    double* Jf = sm;                                   // VIL_VCHUNK_F x VF_STRIDE
-    double* lmr = sm + VIL_VCHUNK_F * VF_STRIDE;       // VIL_VCHUNK_LM x 16: invp, eA[13]
+    double* tri = sm;                                  // NVT packed upper triangle of the visual sub-space
+    double* vbc = tri + NVT;                           // NV
+    double* vgr = vbc + NV;                            // NV
+    double* vdg = vgr + NV;                            // NV
+    double* Jf = vdg + NV;                             // VIL_VCHUNK_F x VF_STRIDE
+    double* lmr = Jf + VIL_VCHUNK_F * VF_STRIDE;       // VIL_VCHUNK_LM x 16: invp, eA[13]
     double* red = lmr + VIL_VCHUNK_LM * 16;
+    int* fj = (int*)(red + 8);                         // VIL_VCHUNK_F observer frames
+    int* lms = fj + VIL_VCHUNK_F;                      // VIL_VCHUNK_LM + 1 chunk-local factor offsets
+    int* lanc = lms + VIL_VCHUNK_LM + 1;               // VIL_VCHUNK_LM anchor frames
+    #define VSTAMP(k) do { __syncthreads(); if (t == 0 && wg == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[32 + k] = tt_; } } while (0)
+    VSTAMP(0);
+    for (int e = t; e < NVT + 3 * NV; e += blockDim.x) tri[e] = 0.0;
     const bool exc = P.ex_const != 0, tdc = !P.td_free;
     double cost = 0.0;
-    if (t < nf) {
-        const int f = f0 + t;
-        double c[14];
+    const int sc0 = P.vwg[2 * wg], sc1 = P.vwg[2 * wg + 1];
+    for (int chunk = sc0; chunk < sc1; ++chunk) {
+        const int l0 = P.vchunk[2 * chunk], l1 = P.vchunk[2 * chunk + 1];
+        const int f0 = P.lm_start[l0], f1 = P.lm_start[l1];
+        const int nf = f1 - f0, nl = l1 - l0;
+        __syncthreads();
+        VSTAMP(1);
+        if (t >= 256 && t <= 256 + nl) { const int q = t - 256; lms[q] = P.lm_start[l0 + q] - f0; if (q < nl) lanc[q] = P.vis_i[P.lm_start[l0 + q]]; }
+        if (t < nf) {
+            const int f = f0 + t;
+            double c[14];
 #pragma unroll
-        for (int k = 0; k < 14; ++k) c[k] = P.vis_c[(size_t)k * P.vis_stride + f];
-        const int i = P.vis_i[f], j = P.vis_j[f], l = P.vis_l[f];
-        const double* pi = x + xo_pose(P, i); const double* pj = x + xo_pose(P, j); const double* ex = x + xo_ex(P);
-        VisJ o;
-        visual_eval(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
-                    x[xo_lam(P) + l], x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
-        double rho, rho1;
-        loss_eval(O.visual_loss, O.visual_loss_scale, o.r[0] * o.r[0] + o.r[1] * o.r[1], rho, rho1);
-        cost = 0.5 * rho;
-        const double sr = sqrt(rho1);
-        const bool ci = P.pose_const && P.pose_const[i], cj = P.pose_const && P.pose_const[j], cl = P.lm_const && P.lm_const[l];
-        double* w = Jf + t * VF_STRIDE;
-        for (int k = 0; k < 12; ++k) { w[k] = ci ? 0.0 : sr * o.Ji[k]; w[12 + k] = cj ? 0.0 : sr * o.Jj[k]; w[24 + k] = exc ? 0.0 : sr * o.Jex[k]; }
-        w[36] = tdc ? 0.0 : sr * o.Jt[0]; w[37] = tdc ? 0.0 : sr * o.Jt[1];
-        w[38] = cl ? 0.0 : sr * o.Jl[0]; w[39] = cl ? 0.0 : sr * o.Jl[1];
-        w[40] = sr * o.r[0]; w[41] = sr * o.r[1];
-        // observer-pose pieces that need no landmark-level sum
-        for (int k = 0; k < 6; ++k) {
-            const double j0 = w[12 + k], j1 = w[18 + k];
-            const double eo = j0 * w[38] + j1 * w[39];
-            w[42 + k] = eo;
-            sb.eO[(size_t)f * 6 + k] = eo;
-            if (!cj) {
-                const double g = j0 * w[40] + j1 * w[41];
-                atomic_add_f64(sb.bc + col_pose(P, j) + k, g);
-                atomic_add_f64(sb.gred + col_pose(P, j) + k, g);
-                atomic_add_f64(sb.diag + col_pose(P, j) + k, j0 * j0 + j1 * j1);
-            }
-        }
-    }
-    cost = block_sum(cost, red);
-    if (t == 0) atomic_add_f64(sb.cost, cost);
-    __syncthreads();
-    // ---- per landmark: pivots, e on the shared groups, gradients ------------------------------
-    if (t < nl) {
-        const int l = l0 + t;
-        const int fs = P.lm_start[l] - f0, fe = P.lm_start[l + 1] - f0;
-        const int a = P.vis_i[P.lm_start[l]];
-        double h = 0, b = 0, e[13], g[13], dg[13];
-        for (int k = 0; k < 13; ++k) { e[k] = 0; g[k] = 0; dg[k] = 0; }
-        for (int q = fs; q < fe; ++q) {
-            const double* w = Jf + q * VF_STRIDE;
-            const double l0_ = w[38], l1_ = w[39], r0 = w[40], r1 = w[41];
-            h += l0_ * l0_ + l1_ * l1_; b += l0_ * r0 + l1_ * r1;
+            for (int k = 0; k < 14; ++k) c[k] = P.vis_c[(size_t)k * P.vis_stride + f];
+            const int i = P.vis_i[f], j = P.vis_j[f], l = P.vis_l[f];
+            const double* pi = x + xo_pose(P, i); const double* pj = x + xo_pose(P, j); const double* ex = x + xo_ex(P);
+            VisJ o;
+            visual_eval(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
+                        x[xo_lam(P) + l], x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
+            double rho, rho1;
+            loss_eval(O.visual_loss, O.visual_loss_scale, o.r[0] * o.r[0] + o.r[1] * o.r[1], rho, rho1);
+            cost += 0.5 * rho;
+            const double sr = sqrt(rho1);
+            const bool ci = P.pose_const && P.pose_const[i], cj = P.pose_const && P.pose_const[j], cl = P.lm_const && P.lm_const[l];
+            double* w = Jf + t * VF_STRIDE;
+            for (int k = 0; k < 12; ++k) { w[k] = ci ? 0.0 : sr * o.Ji[k]; w[12 + k] = cj ? 0.0 : sr * o.Jj[k]; w[24 + k] = exc ? 0.0 : sr * o.Jex[k]; }
+            w[36] = tdc ? 0.0 : sr * o.Jt[0]; w[37] = tdc ? 0.0 : sr * o.Jt[1];
+            w[38] = cl ? 0.0 : sr * o.Jl[0]; w[39] = cl ? 0.0 : sr * o.Jl[1];
+            w[40] = sr * o.r[0]; w[41] = sr * o.r[1];
+            fj[t] = j;
+            // observer-pose pieces that need no landmark-level sum
             for (int k = 0; k < 6; ++k) {
-                e[k] += w[k] * l0_ + w[6 + k] * l1_; g[k] += w[k] * r0 + w[6 + k] * r1; dg[k] += w[k] * w[k] + w[6 + k] * w[6 + k];
-                e[6 + k] += w[24 + k] * l0_ + w[30 + k] * l1_; g[6 + k] += w[24 + k] * r0 + w[30 + k] * r1; dg[6 + k] += w[24 + k] * w[24 + k] + w[30 + k] * w[30 + k];
-            }
-            e[12] += w[36] * l0_ + w[37] * l1_; g[12] += w[36] * r0 + w[37] * r1; dg[12] += w[36] * w[36] + w[37] * w[37];
-        }
-        const bool cl = P.lm_const && P.lm_const[l];
-        double Sl = 1.0;
-        if (ctl.first) { Sl = (O.jacobi_scaling && !ctl.lin_mode) ? 1.0 / (1.0 + sqrt(h)) : 1.0; P.Sl[l] = Sl; }
-        else Sl = P.Sl[l];
-        double dl2 = Sl * Sl * h; dl2 = fmin(fmax(dl2, 1e-6), 1e32);
-        const double p = ctl.lin_mode ? h : h + ctl.mu * dl2 / (Sl * Sl);
-        const double invp = (cl || !(p > 0.0)) ? 0.0 : 1.0 / p;
-        sb.hll[l] = h; sb.bl[l] = b; sb.invp[l] = invp;
-        double* lr = lmr + t * 16;
-        lr[0] = invp;
-        const double ib = invp * b;
-        for (int k = 0; k < 13; ++k) {
-            lr[1 + k] = e[k]; sb.eA[(size_t)l * 13 + k] = e[k];
-            const int col = k < 6 ? col_pose(P, a) + k : (k < 12 ? col_ex(P) + k - 6 : col_td(P));
-            if (g[k] != 0.0 || dg[k] != 0.0) {
-                atomic_add_f64(sb.bc + col, g[k]);
-                atomic_add_f64(sb.gred + col, g[k] - ib * e[k]);
-                atomic_add_f64(sb.diag + col, dg[k]);
+                const double j0 = w[12 + k], j1 = w[18 + k];
+                const double eo = j0 * w[38] + j1 * w[39];
+                w[42 + k] = eo;
+                sb.eO[(size_t)f * 6 + k] = eo;
+                if (!cj) {
+                    const double g = j0 * w[40] + j1 * w[41];
+                    lds_add(vbc + col_pose(P, j) + k, g);
+                    lds_add(vgr + col_pose(P, j) + k, g);
+                    lds_add(vdg + col_pose(P, j) + k, j0 * j0 + j1 * j1);
+                }
             }
         }
-        for (int q = fs; q < fe; ++q) {
-            const double* w = Jf + q * VF_STRIDE;
-            const int j = P.vis_j[f0 + q];
-            for (int k = 0; k < 6; ++k) if (w[42 + k] != 0.0) atomic_add_f64(sb.gred + col_pose(P, j) + k, -ib * w[42 + k]);
+        __syncthreads();
+        VSTAMP(2);
+        // ---- per landmark: pivots, e on the shared groups, gradients; 16 lanes per landmark ---------------
+        // lane component k: 0..5 anchor pose, 6..11 extrinsic, 12 td, 13 -> (h, b) pivot pieces
+        if (t < 16 * nl) {
+            const int tl = t >> 4, k = t & 15;
+            const int l = l0 + tl;
+            const int fs = lms[tl], fe = lms[tl + 1];
+            const int a = lanc[tl];
+            double e = 0, g = 0, dg = 0, h = 0, b = 0;
+            const int off = k < 6 ? k : (k < 12 ? 24 + (k - 6) : 36);
+            const int rs = k < 12 ? 6 : 1;      // row stride inside the 2 x n block
+            for (int q = fs; q < fe; ++q) {
+                const double* w = Jf + q * VF_STRIDE;
+                const double l0_ = w[38], l1_ = w[39], r0 = w[40], r1 = w[41];
+                if (k < 13) { const double j0 = w[off], j1 = w[off + rs]; e += j0 * l0_ + j1 * l1_; g += j0 * r0 + j1 * r1; dg += j0 * j0 + j1 * j1; }
+                else { h += l0_ * l0_ + l1_ * l1_; b += l0_ * r0 + l1_ * r1; }
+            }
+            // broadcast (h, b) of lane 13 to the 16-lane group
+            h = __shfl(h, (t & ~15) + 13, 64); b = __shfl(b, (t & ~15) + 13, 64);
+            const bool cl = P.lm_const && P.lm_const[l];
+            double Sl = 1.0;
+            if (ctl.first) { Sl = (O.jacobi_scaling && !ctl.lin_mode) ? 1.0 / (1.0 + sqrt(h)) : 1.0; if (k == 13) P.Sl[l] = Sl; }
+            else Sl = P.Sl[l];
+            double dl2 = Sl * Sl * h; dl2 = fmin(fmax(dl2, 1e-6), 1e32);
+            const double p = ctl.lin_mode ? h : h + ctl.mu * dl2 / (Sl * Sl);
+            const double invp = (cl || !(p > 0.0)) ? 0.0 : 1.0 / p;
+            const double ib = invp * b;
+            double* lr = lmr + tl * 16;
+            if (k == 13) { sb.hll[l] = h; sb.bl[l] = b; sb.invp[l] = invp; lr[0] = invp; lr[14] = (double)a; }
+            if (k < 13) {
+                lr[1 + k] = e; sb.eA[(size_t)l * 13 + k] = e;
+                const int col = k < 6 ? col_pose(P, a) + k : (k < 12 ? col_ex(P) + k - 6 : col_td(P));
+                if (g != 0.0 || dg != 0.0) { lds_add(vbc + col, g); lds_add(vgr + col, g - ib * e); lds_add(vdg + col, dg); }
+            }
+            // observer columns: gred -= invp b eO ; lanes 0..5 of the group walk the factors
+            if (k < 6) for (int q = fs; q < fe; ++q) { const double eo = Jf[q * VF_STRIDE + 42 + k]; if (eo != 0.0) lds_add(vgr + col_pose(P, fj[q]) + k, -ib * eo); }
         }
-    }
-    __syncthreads();
-    // ---- wave per landmark: S += sum_f Jc^T Jc - invp e e^T, by (group, group) blocks -----------
-    const int wave = t >> 6, lane = t & 63;
-    for (int tl = wave; tl < nl; tl += (int)(blockDim.x >> 6)) {
-        const int l = l0 + tl;
-        const int fs = P.lm_start[l] - f0, fe = P.lm_start[l + 1] - f0;
-        const int m = fe - fs, ng = 3 + m, np = ng * (ng + 1) / 2;
-        const int a = P.vis_i[P.lm_start[l]];
-        const double* lr = lmr + tl * 16;
-        const double invp = lr[0];
-        for (int p = lane; p < np; p += 64) {
-            int g1 = 0, rem = p;
-            while (rem >= ng - g1) { rem -= ng - g1; ++g1; }
-            const int g2 = g1 + rem;
-            // group descriptors: offset in the factor record, #cols, global column, e pointer
-            auto goff = [&](int g) { return g == 0 ? 0 : (g == 1 ? 24 : (g == 2 ? 36 : 12)); };
-            auto gn = [&](int g) { return g == 2 ? 1 : 6; };
-            auto gcol = [&](int g) { return g == 0 ? col_pose(P, a) : (g == 1 ? col_ex(P) : (g == 2 ? col_td(P) : col_pose(P, P.vis_j[f0 + fs + g - 3]))); };
-            const int n1 = gn(g1), n2 = gn(g2), o1 = goff(g1), o2 = goff(g2), c1 = gcol(g1), c2 = gcol(g2);
-            const double* e1 = g1 < 3 ? lr + 1 + (g1 == 0 ? 0 : (g1 == 1 ? 6 : 12)) : Jf + (fs + g1 - 3) * VF_STRIDE + 42;
-            const double* e2 = g2 < 3 ? lr + 1 + (g2 == 0 ? 0 : (g2 == 1 ? 6 : 12)) : Jf + (fs + g2 - 3) * VF_STRIDE + 42;
-            // factors common to both groups
-            int qa, qb;
-            if (g1 >= 3 && g2 >= 3) { if (g1 == g2) { qa = fs + g1 - 3; qb = qa + 1; } else { qa = 0; qb = 0; } }
-            else if (g2 >= 3) { qa = fs + g2 - 3; qb = qa + 1; }
-            else if (g1 >= 3) { qa = fs + g1 - 3; qb = qa + 1; }
-            else { qa = fs; qb = fe; }
-            const int s1 = n1 == 1 ? 1 : 6, s2 = n2 == 1 ? 1 : 6;   // row stride inside a 2 x n block
-            for (int r = 0; r < n1; ++r) for (int c = (g1 == g2 ? r : 0); c < n2; ++c) {
-                double s = 0;
+        __syncthreads();
+        VSTAMP(3);
+        // ---- tri += sum_f Jc^T Jc - invp e e^T : one work item = (landmark, group pair, row of the 6x6 block);
+        //      different landmarks may hit the same entry -> LDS atomic add (ds_add_f64)
+        {
+            int pre[VIL_VCHUNK_LM + 1];
+            pre[0] = 0;
+#pragma unroll
+            for (int q = 0; q < VIL_VCHUNK_LM; ++q) {
+                int items = 0;
+                if (q < nl) { const int m = lms[q + 1] - lms[q]; const int ng = 3 + m; items = 3 * ng * (ng + 1); }   // np pairs x 6 rows
+                pre[q + 1] = pre[q] + items;
+            }
+            const int total = pre[VIL_VCHUNK_LM];
+            for (int it = t; it < total; it += blockDim.x) {
+                int tl = 0;
+#pragma unroll
+                for (int q = 1; q < VIL_VCHUNK_LM; ++q) if (it >= pre[q]) tl = q;
+                const int rem0 = it - pre[tl];
+                const int p = rem0 / 6, r = rem0 - 6 * p;
+                const int fs = lms[tl], fe = lms[tl + 1];
+                const int ng = 3 + (fe - fs);
+                int g1 = 0, rem = p;
+                while (rem >= ng - g1) { rem -= ng - g1; ++g1; }
+                const int g2 = g1 + rem;
+                const int n1 = g1 == 2 ? 1 : 6, n2 = g2 == 2 ? 1 : 6;
+                if (r >= n1) continue;
+                const double* lr = lmr + tl * 16;
+                const double invp = lr[0];
+                const int a = lanc[tl];
+                const int o1 = g1 == 0 ? 0 : (g1 == 1 ? 24 : (g1 == 2 ? 36 : 12)), o2 = g2 == 0 ? 0 : (g2 == 1 ? 24 : (g2 == 2 ? 36 : 12));
+                const int c1 = g1 == 0 ? col_pose(P, a) : (g1 == 1 ? col_ex(P) : (g1 == 2 ? col_td(P) : col_pose(P, fj[fs + g1 - 3])));
+                const int c2 = g2 == 0 ? col_pose(P, a) : (g2 == 1 ? col_ex(P) : (g2 == 2 ? col_td(P) : col_pose(P, fj[fs + g2 - 3])));
+                const double* e1 = g1 < 3 ? lr + 1 + (g1 == 0 ? 0 : (g1 == 1 ? 6 : 12)) : Jf + (fs + g1 - 3) * VF_STRIDE + 42;
+                const double* e2 = g2 < 3 ? lr + 1 + (g2 == 0 ? 0 : (g2 == 1 ? 6 : 12)) : Jf + (fs + g2 - 3) * VF_STRIDE + 42;
+                int qa, qb;   // factors common to both groups
+                if (g1 >= 3 && g2 >= 3) { if (g1 == g2) { qa = fs + g1 - 3; qb = qa + 1; } else { qa = 0; qb = 0; } }
+                else if (g2 >= 3) { qa = fs + g2 - 3; qb = qa + 1; }
+                else { qa = fs; qb = fe; }
+                const int s1 = n1 == 1 ? 1 : 6, s2 = n2 == 1 ? 1 : 6;   // row stride inside a 2 x n block
+                const double ie1 = invp * e1[r];
+                double acc[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) acc[c] = (c < n2) ? -ie1 * e2[c] : 0.0;
                 for (int q = qa; q < qb; ++q) {
                     const double* w = Jf + q * VF_STRIDE;
-                    s += w[o1 + r] * w[o2 + c] + w[o1 + s1 + r] * w[o2 + s2 + c];
+                    const double w0 = w[o1 + r], w1 = w[o1 + s1 + r];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) if (c < n2) acc[c] += w0 * w[o2 + c] + w1 * w[o2 + s2 + c];
                 }
-                s -= invp * e1[r] * e2[c];
-                if (s != 0.0) S_add(P, sb.S, c1 + r, c2 + c, s);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) if (c < n2 && (g1 != g2 || c >= r) && acc[c] != 0.0) lds_add(tri + tri_idx(NV, c1 + r, c2 + c), acc[c]);
             }
         }
     }
+    VSTAMP(4);
+    cost = block_sum(cost, red);
+    double* out = P.vpart + (size_t)wg * P.VP;
+    for (int e = t; e < NVT + 3 * NV; e += blockDim.x) out[e] = tri[e];
+    if (t == 0) out[NVT + 3 * NV] = cost;
+    VSTAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------
 template <int NR>
-__device__ inline void sweep_lidar(const DevP& P, const SolveOpts& O, int chunk, const double* x, SysBuf& sb) {
-    const int* ch = (NR == 1 ? P.pchunk : P.echunk) + 3 * chunk;
-    const int start = ch[0], cnt = ch[1], k = ch[2];
-    const int t = threadIdx.x;
+__device__ __forceinline__ void sweep_lidar(const DevP& P, const SolveOpts& O, int wgc, const double* x, double* sm) {
+    const int per = blockDim.x >> 8;                    // 256-point chunks per workgroup
+    const int sub = threadIdx.x >> 8;
+    const int nchunk = NR == 1 ? P.n_pchunk : P.n_echunk;
+    const int chunk = wgc * per + sub;
+    const bool have = chunk < nchunk;
+    const int* ch = (NR == 1 ? P.pchunk : P.echunk) + 3 * (have ? chunk : 0);
+    const int start = ch[0], cnt = have ? ch[1] : 0, k = ch[2];
+    const int t = threadIdx.x & 255;
+    sm += sub * 128;
     const double* pose = x + xo_pose(P, k);
     const bool cst = P.pose_const && P.pose_const[k];
     double acc[28];
@@ -245,37 +283,35 @@ __device__ inline void sweep_lidar(const DevP& P, const SolveOpts& O, int chunk,
         double rho, rho1;
         loss_eval(O.lidar_loss, O.lidar_loss_scale, sq, rho, rho1);
         acc[27] = 0.5 * rho;
-        // rho1 multiplies J^T J and J^T r (sqrt(rho1) on each factor of the product)
-        int idx = 0;
+        if (!cst) {
+            // rho1 multiplies J^T J and J^T r (sqrt(rho1) on each factor of the product)
+            int idx = 0;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
+            for (int a = 0; a < 6; ++a) {
 #pragma unroll
-            for (int b = a; b < 6; ++b) {
-                double s = 0;
+                for (int b = a; b < 6; ++b) {
+                    double s = 0;
 #pragma unroll
-                for (int q = 0; q < NR; ++q) s += J[q * 6 + a] * J[q * 6 + b];
-                acc[idx++] = rho1 * s;
+                    for (int q = 0; q < NR; ++q) s += J[q * 6 + a] * J[q * 6 + b];
+                    acc[idx++] = rho1 * s;
+                }
+                double g = 0;
+#pragma unroll
+                for (int q = 0; q < NR; ++q) g += J[q * 6 + a] * r[q];
+                acc[21 + a] = rho1 * g;
             }
-            double g = 0;
-#pragma unroll
-            for (int q = 0; q < NR; ++q) g += J[q * 6 + a] * r[q];
-            acc[21 + a] = rho1 * g;
         }
     }
 #pragma unroll
     for (int q = 0; q < 28; ++q) acc[q] = wave_sum(acc[q]);
-    if ((t & 63) == 0 && (t & ~63) < cnt) {
-        atomic_add_f64(sb.cost, acc[27]);
-        if (!cst) {
-            const int c0 = col_pose(P, k);
-            int idx = 0;
-            for (int a = 0; a < 6; ++a) {
-                for (int b = a; b < 6; ++b) { atomic_add_f64(sb.S + (size_t)(c0 + a) * P.D + c0 + b, acc[idx]); if (a == b) atomic_add_f64(sb.diag + c0 + a, acc[idx]); ++idx; }
-                atomic_add_f64(sb.bc + c0 + a, acc[21 + a]);
-                atomic_add_f64(sb.gred + c0 + a, acc[21 + a]);
-            }
-        }
+    const int wave = t >> 6, lane = t & 63;
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 28; ++q) sm[wave * 28 + q] = acc[q];
     }
+    __syncthreads();
+    const int gchunk = (NR == 1 ? 0 : P.n_pchunk) + chunk;
+    if (have && t < 28) P.lpart[(size_t)gchunk * 28 + t] = sm[t] + sm[28 + t] + sm[56 + t] + sm[84 + t];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -284,7 +320,7 @@ __device__ inline const double* prior_block_ptr(const DevP& P, const double* x, 
     return kind == 0 ? x + xo_pose(P, idx) : (kind == 1 ? x + xo_sb(P, idx) : (kind == 2 ? x + xo_ex(P) : x + xo_td(P)));
 }
 
-__device__ inline void sweep_misc(const DevP& P, const SolveOpts& O, const double* x, SysBuf& sb, double* sm) {
+__device__ __forceinline__ void sweep_misc(const DevP& P, const SolveOpts& O, const double* x, double* sm) {
     const int t = threadIdx.x;
     // ---- prior: r = r0 + J0 dx ;  J0^T J0 = pH, J0^T r0 = pg0, r0^T r0 = pc0 are pre-contracted ------------
     if (P.pn > 0) {
@@ -306,20 +342,10 @@ __device__ inline void sweep_misc(const DevP& P, const SolveOpts& O, const doubl
             for (int k = 0; k < n; ++k) s += P.pH[(size_t)k * n + i] * dx[k];
             const double g = P.pg0[i] + s;
             part += dx[i] * (P.pg0[i] + g);
-            const int col = P.pmap[i];
-            if (col >= 0) { atomic_add_f64(sb.bc + col, g); atomic_add_f64(sb.gred + col, g); }
+            P.mpart[i] = g;
         }
         part = block_sum(part, red);
-        if (t == 0) atomic_add_f64(sb.cost, 0.5 * (P.pc0[0] + part));
-        for (int e = t; e < n * n; e += blockDim.x) {
-            const int i = e / n, k = e % n;
-            if (i > k) continue;
-            const int ci = P.pmap[i], ck = P.pmap[k];
-            if (ci < 0 || ck < 0) continue;
-            const double v = P.pH[e];
-            S_add(P, sb.S, ci, ck, v);
-            if (i == k) atomic_add_f64(sb.diag + ci, v);
-        }
+        if (t == 0) P.mpart[n] = 0.5 * (P.pc0[0] + part);
         __syncthreads();
     }
     // ---- ICP (4 pose blocks) and LPS (2 pose blocks): thread per (factor, block) ----------------------------
@@ -327,78 +353,170 @@ __device__ inline void sweep_misc(const DevP& P, const SolveOpts& O, const doubl
     double* rb = sm + 12 * 84;    // 12 x 3
     const int n_rel = P.n_icp + P.n_lps;
     if (n_rel == 0) return;
-    __syncthreads();
-    if (t < 4 * n_rel) {
-        const int f = t >> 2, b = t & 3;
-        double r3[3], J21[21];
+    for (int it = t; it < 28 * n_rel; it += blockDim.x) {
+        const int f = it / 28, rem = it - 28 * f, b = rem / 7, k = rem - 7 * b;
+        double r3[3], d3[3] = {0.0, 0.0, 0.0};
+        bool live = true;
+        const int* id;
         if (f < P.n_icp) {
-            const int* id = P.icp_ids + 4 * f;
-            icp_eval(P.icp_c + (size_t)f * 10, x + xo_pose(P, id[0]), x + xo_pose(P, id[1]), x + xo_pose(P, id[2]), x + xo_pose(P, id[3]), b, r3, J21);
-            if (!O.autodiff_quirk) tangent_fix(x + xo_pose(P, id[b]), J21);
-            for (int k = 0; k < 21; ++k) Jb[(f * 4 + b) * 21 + k] = J21[k];
-            if (b == 0) for (int k = 0; k < 3; ++k) rb[f * 3 + k] = r3[k];
+            id = P.icp_ids + 4 * f;
+            icp_eval1(P.icp_c + (size_t)f * 10, x + xo_pose(P, id[0]), x + xo_pose(P, id[1]), x + xo_pose(P, id[2]), x + xo_pose(P, id[3]), b, k, r3, d3);
         } else if (b < 2) {
-            const int g = f - P.n_icp;
-            const int* id = P.lps_ids + 2 * g;
-            lps_eval(P.lps_c + (size_t)g * 7, x + xo_pose(P, id[0]), x + xo_pose(P, id[1]), b, r3, J21);
-            if (!O.autodiff_quirk) tangent_fix(x + xo_pose(P, id[b]), J21);
-            for (int k = 0; k < 21; ++k) Jb[(f * 4 + b) * 21 + k] = J21[k];
-            if (b == 0) for (int k = 0; k < 3; ++k) rb[f * 3 + k] = r3[k];
-        }
+            id = P.lps_ids + 2 * (f - P.n_icp);
+            lps_eval1(P.lps_c + (size_t)(f - P.n_icp) * 7, x + xo_pose(P, id[0]), x + xo_pose(P, id[1]), b, k, r3, d3);
+        } else { live = false; id = P.lps_ids; r3[0] = r3[1] = r3[2] = 0.0; }
+        if (live && P.pose_const && P.pose_const[id[b]]) d3[0] = d3[1] = d3[2] = 0.0;
+        for (int q = 0; q < 3; ++q) Jb[(f * 4 + b) * 21 + 7 * q + k] = d3[q];
+        if (b == 0 && k == 0) for (int q = 0; q < 3; ++q) rb[f * 3 + q] = r3[q];
     }
     __syncthreads();
-    // per factor: nb blocks x 6 local columns; entries (a,b) of the (6 nb)^2 block + gradient
-    for (int f = 0; f < n_rel; ++f) {
-        const bool icp = f < P.n_icp;
-        const int nb = icp ? 4 : 2, nc = 6 * nb;
-        const int* id = icp ? P.icp_ids + 4 * f : P.lps_ids + 2 * (f - P.n_icp);
+    if (!O.autodiff_quirk) {   // mathematically-correct tangent Jacobian instead of the raw d/d(qx,qy,qz) columns
+        for (int it = t; it < 4 * n_rel; it += blockDim.x) {
+            const int f = it >> 2, b = it & 3;
+            if (f >= P.n_icp && b >= 2) continue;
+            const int* id = f < P.n_icp ? P.icp_ids + 4 * f : P.lps_ids + 2 * (f - P.n_icp);
+            tangent_fix(x + xo_pose(P, id[b]), Jb + (f * 4 + b) * 21);
+        }
+        __syncthreads();
+    }
+    // per factor: 24 x 24 block over the 4 x 6 local columns (LPS: blocks 2,3 are zero) + gradient + cost
+    double* out0 = P.mpart + (P.pn > 0 ? P.pn + 1 : 0);
+    for (int e = t; e < n_rel * 601; e += blockDim.x) {
+        const int f = e / 601, q = e - f * 601;
         const double* r = rb + f * 3;
         double rho, rho1;
         loss_eval(O.rel_loss, O.rel_loss_scale, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho, rho1);
-        if (t == 0) atomic_add_f64(sb.cost, 0.5 * rho);
-        for (int e = t; e < nc * nc + nc; e += blockDim.x) {
-            if (e < nc * nc) {
-                const int a = e / nc, b = e % nc;
-                const int ba = a / 6, bb = b / 6;
-                const int ca = col_pose(P, id[ba]) + a % 6, cb = col_pose(P, id[bb]) + b % 6;
-                if (ca > cb) continue;
-                if (ca == cb && a > b) continue;
-                if ((P.pose_const && (P.pose_const[id[ba]] || P.pose_const[id[bb]]))) continue;
-                const double* Ja = Jb + (f * 4 + ba) * 21 + a % 6;
-                const double* Jc = Jb + (f * 4 + bb) * 21 + b % 6;
-                double s = rho1 * (Ja[0] * Jc[0] + Ja[7] * Jc[7] + Ja[14] * Jc[14]);
-                if (ca == cb && ba != bb) s *= 2.0;   // duplicated pose id inside one factor: both cross terms land on one entry
-                atomic_add_f64(sb.S + (size_t)ca * P.D + cb, s);
-                if (ca == cb) atomic_add_f64(sb.diag + ca, s);
-            } else {
-                const int a = e - nc * nc, ba = a / 6;
-                if (P.pose_const && P.pose_const[id[ba]]) continue;
-                const double* Ja = Jb + (f * 4 + ba) * 21 + a % 6;
-                const double g = rho1 * (Ja[0] * r[0] + Ja[7] * r[1] + Ja[14] * r[2]);
-                const int ca = col_pose(P, id[ba]) + a % 6;
-                atomic_add_f64(sb.bc + ca, g); atomic_add_f64(sb.gred + ca, g);
-            }
-        }
+        double v;
+        if (q < 576) {
+            const int a = q / 24, b = q % 24;
+            const double* Ja = Jb + (f * 4 + a / 6) * 21 + a % 6;
+            const double* Jc = Jb + (f * 4 + b / 6) * 21 + b % 6;
+            v = rho1 * (Ja[0] * Jc[0] + Ja[7] * Jc[7] + Ja[14] * Jc[14]);
+        } else if (q < 600) {
+            const int a = q - 576;
+            const double* Ja = Jb + (f * 4 + a / 6) * 21 + a % 6;
+            v = rho1 * (Ja[0] * r[0] + Ja[7] * r[1] + Ja[14] * r[2]);
+        } else v = 0.5 * rho;
+        out0[e] = v;
     }
+}
+
+// local index (0..29) of reduced column `col` inside IMU factor (i,j), or -1
+__device__ __forceinline__ int imu_local(const DevP& P, int i, int j, int col) {
+    int d = col - col_pose(P, i); if (d >= 0 && d < 6) return d;
+    d = col - col_sb(P, i); if (d >= 0 && d < 9) return 6 + d;
+    d = col - col_pose(P, j); if (d >= 0 && d < 6) return 15 + d;
+    d = col - col_sb(P, j); if (d >= 0 && d < 9) return 21 + d;
+    return -1;
 }
 
 }  // namespace vd
 
-// grid = n_imu + n_vchunk + n_pchunk + n_echunk + 1 workgroups of 256 threads
-__global__ __launch_bounds__(VIL_THREADS) void k_sweep(DevP P, SolveOpts O) {
+// grid = n_imu + n_vwg + n_pchunk + n_echunk + 1 workgroups of 256 threads
+__global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O) {
     extern __shared__ double sm[];
     const Ctl ctl = *P.ctl;
     if (ctl.done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctl->n_sweeps = ctl.n_sweeps + 1;   // live (not early-exited) launches, for the profiler
     const int cand = 1 - ctl.cur;
     const double* x = P.x[cand];
     SysBuf sb = P.sys[cand];
     int b = blockIdx.x;
-    if (b < P.n_imu) { vd::sweep_imu(P, O, b, x, sb, sm); return; }
+    // visual workgroups first: they are the longest-running role
+    if (b < P.n_vwg) { if (!(P.skip_mask & 1)) vd::sweep_visual(P, O, ctl, b, x, sb, sm); return; }
+    b -= P.n_vwg;
+    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm); return; }
     b -= P.n_imu;
-    if (b < P.n_vchunk) { vd::sweep_visual(P, O, ctl, b, x, sb, sm); return; }
-    b -= P.n_vchunk;
-    if (b < P.n_pchunk) { vd::sweep_lidar<1>(P, O, b, x, sb); return; }
-    b -= P.n_pchunk;
-    if (b < P.n_echunk) { vd::sweep_lidar<3>(P, O, b, x, sb); return; }
-    vd::sweep_misc(P, O, x, sb, sm);
+    const int per = VIL_SWEEP_THREADS / 256, npw = (P.n_pchunk + per - 1) / per, new_ = (P.n_echunk + per - 1) / per;
+    if (b < npw) { if (!(P.skip_mask & 4)) vd::sweep_lidar<1>(P, O, b, x, sm); return; }
+    b -= npw;
+    if (b < new_) { if (!(P.skip_mask & 8)) vd::sweep_lidar<3>(P, O, b, x, sm); return; }
+    if (!(P.skip_mask & 16)) vd::sweep_misc(P, O, x, sm);
+}
+
+// Gather of the sweep's partial records into the dense reduced system of the candidate set:
+//   S' (D x D, both triangles), gred, bc, diag, cost.   One thread per S entry (i <= j), fixed
+//   summation order => bitwise reproducible.  Last workgroup handles the vectors and the cost.
+__global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
+    using namespace vd;
+    const Ctl ctl = *P.ctl;
+    if (ctl.done) return;
+    const int cand = 1 - ctl.cur;
+    SysBuf sb = P.sys[cand];
+    const int D = P.D, NV = P.NV, K = P.K, t = threadIdx.x;
+    const int n_rel = P.n_icp + P.n_lps;
+    const double* rel0 = P.mpart + (P.pn > 0 ? P.pn + 1 : 0);
+    const int nSblk = (D * D + VIL_THREADS - 1) / VIL_THREADS;
+    if ((int)blockIdx.x < nSblk) {
+        const int e = blockIdx.x * VIL_THREADS + t;
+        if (e >= D * D) return;
+        const int i = e / D, j = e - i * D;
+        if (i > j) return;
+        double s = 0.0;
+        if (j < NV) {                       // visual sub-space (i <= j < NV)
+            const int idx = tri_idx(NV, i, j);
+            for (int w = 0; w < P.n_vwg; ++w) s += P.vpart[(size_t)w * P.VP + idx];
+            if (j < 6 * K && i / 6 == j / 6) {   // LiDAR points: pose-diagonal blocks
+                const int k = i / 6, a = i - 6 * k, b = j - 6 * k;
+                const int li = a * 6 - ((a * (a - 1)) >> 1) + (b - a);
+                for (int c = P.lchunk_pose[k]; c < P.lchunk_pose[k + 1]; ++c) s += P.lpart[(size_t)c * 28 + li];
+                for (int c = P.lchunk_pose[K + 1 + k]; c < P.lchunk_pose[K + 2 + k]; ++c) s += P.lpart[(size_t)(P.n_pchunk + c) * 28 + li];
+            }
+            if (j < 6 * K) {                    // ICP / LPS blocks live on pose columns
+                for (int f = 0; f < n_rel; ++f) {
+                    const bool icp = f < P.n_icp;
+                    const int* id = icp ? P.icp_ids + 4 * f : P.lps_ids + 2 * (f - P.n_icp);
+                    const int nb = icp ? 4 : 2;
+                    const int pi = i / 6, pj = j / 6;
+                    for (int ba = 0; ba < nb; ++ba) if (id[ba] == pi) for (int bb = 0; bb < nb; ++bb) if (id[bb] == pj)
+                        s += rel0[(size_t)f * 601 + (ba * 6 + i % 6) * 24 + bb * 6 + j % 6];
+                }
+            }
+        }
+        for (int f = 0; f < P.n_imu; ++f) {
+            const int la = imu_local(P, P.imu_i[f], P.imu_j[f], i);
+            if (la < 0) continue;
+            const int lb = imu_local(P, P.imu_i[f], P.imu_j[f], j);
+            if (lb >= 0) s += P.ipart[(size_t)f * 931 + la * 30 + lb];
+        }
+        if (P.pn > 0) { const int pi = P.pinv[i], pj = P.pinv[j]; if (pi >= 0 && pj >= 0) s += P.pH[(size_t)pi * P.pn + pj]; }
+        sb.S[(size_t)i * D + j] = s;
+        sb.S[(size_t)j * D + i] = s;
+        if (i == j) {
+            // un-reduced diagonal: S'_ii plus the Schur term that was subtracted -> recomputed from the visual diag partials
+            double dg = s;
+            if (i < NV) { double vs = 0.0, vd_ = 0.0; const int idx = tri_idx(NV, i, i); for (int w = 0; w < P.n_vwg; ++w) { vs += P.vpart[(size_t)w * P.VP + idx]; vd_ += P.vpart[(size_t)w * P.VP + P.NVT + 2 * NV + i]; } dg += vd_ - vs; }
+            sb.diag[i] = dg;
+        }
+        return;
+    }
+    // ---- vectors + cost (one workgroup) --------------------------------------------------------------
+    __shared__ double red[8];
+    for (int i = t; i < D; i += VIL_THREADS) {
+        double bc = 0.0, gr = 0.0;
+        if (i < NV) for (int w = 0; w < P.n_vwg; ++w) { bc += P.vpart[(size_t)w * P.VP + P.NVT + i]; gr += P.vpart[(size_t)w * P.VP + P.NVT + NV + i]; }
+        double o = 0.0;
+        if (i < 6 * K) {
+            const int k = i / 6, a = i - 6 * k;
+            for (int c = P.lchunk_pose[k]; c < P.lchunk_pose[k + 1]; ++c) o += P.lpart[(size_t)c * 28 + 21 + a];
+            for (int c = P.lchunk_pose[K + 1 + k]; c < P.lchunk_pose[K + 2 + k]; ++c) o += P.lpart[(size_t)(P.n_pchunk + c) * 28 + 21 + a];
+            for (int f = 0; f < n_rel; ++f) {
+                const bool icp = f < P.n_icp;
+                const int* id = icp ? P.icp_ids + 4 * f : P.lps_ids + 2 * (f - P.n_icp);
+                const int nb = icp ? 4 : 2;
+                for (int ba = 0; ba < nb; ++ba) if (id[ba] == k) o += rel0[(size_t)f * 601 + 576 + ba * 6 + a];
+            }
+        }
+        for (int f = 0; f < P.n_imu; ++f) { const int la = imu_local(P, P.imu_i[f], P.imu_j[f], i); if (la >= 0) o += P.ipart[(size_t)f * 931 + 900 + la]; }
+        if (P.pn > 0) { const int pi = P.pinv[i]; if (pi >= 0) o += P.mpart[pi]; }
+        sb.bc[i] = bc + o; sb.gred[i] = gr + o;
+    }
+    double c = 0.0;
+    for (int w = t; w < P.n_vwg; w += VIL_THREADS) c += P.vpart[(size_t)w * P.VP + P.NVT + 3 * NV];
+    for (int q = t; q < P.n_pchunk + P.n_echunk; q += VIL_THREADS) c += P.lpart[(size_t)q * 28 + 27];
+    for (int f = t; f < P.n_imu; f += VIL_THREADS) c += P.ipart[(size_t)f * 931 + 930];
+    for (int f = t; f < n_rel; f += VIL_THREADS) c += rel0[(size_t)f * 601 + 600];
+    if (t == 0 && P.pn > 0) c += P.mpart[P.pn];
+    c = block_sum(c, red);
+    if (t == 0) sb.cost[0] = c;
 }

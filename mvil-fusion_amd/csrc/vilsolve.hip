@@ -43,14 +43,18 @@ struct vil_ctx {
     size_t off_x0 = 0;             // backup of the uploaded state (device)
     double* d_x0 = nullptr;
     std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
-    int n_blocks_sweep = 0;
-    size_t lds_sweep = 0;
+    int n_blocks_sweep = 0, n_blocks_reduce = 0;
+    size_t lds_sweep = 0, lds_step = 0;
+    bool step_lds = false;
     int* d_status = nullptr;
     Ctl* h_ctl = nullptr;          // pinned
     double* h_pin = nullptr;       // pinned scratch
     size_t h_pin_bytes = 0;
     std::vector<int> prior_joff;
     MargWork marg;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    vil_profile prof = {0, 0.0, 0, 0.0};
 };
 
 static SolveOpts to_dev_opts(const vil_options* o) {
@@ -124,6 +128,7 @@ void vil_destroy(vil_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& e : c->ev) hipEventDestroy(e);
     if (c->ar.d) hipFree(c->ar.d);
     if (c->d_status) hipFree(c->d_status);
     if (c->h_ctl) hipHostFree(c->h_ctl);
@@ -216,25 +221,45 @@ int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
         }
         P.n_vchunk = (int)vch.size() / 2;
         put(vch.data(), 4 * vch.size(), (void**)&P.vchunk);
+        // group the sub-chunks into visual workgroups (each owns one LDS triangle / one partial record)
+        int vwg_max = 96;
+        if (const char* ev = getenv("VIL_VWG")) vwg_max = std::max(1, atoi(ev));
+        P.n_vwg = std::min(P.n_vchunk, vwg_max);
+        std::vector<int> vw;
+        for (int w = 0; w < P.n_vwg; ++w) { vw.push_back((int)((long long)P.n_vchunk * w / P.n_vwg)); vw.push_back((int)((long long)P.n_vchunk * (w + 1) / P.n_vwg)); }
+        put(vw.data(), 4 * vw.size(), (void**)&P.vwg);
+        P.NVT = NV * (NV + 1) / 2; P.VP = P.NVT + 3 * NV + 1;
+        put(nullptr, 8 * (size_t)std::max(P.n_vwg, 1) * P.VP, (void**)&P.vpart);
     }
     // LiDAR
     {
         std::vector<double> soa; std::vector<int> ch;
+        std::vector<int> lcp(2 * (K + 1), 0);   // chunk ranges per pose (chunks are pose-ordered): plane [0..K], edge [K+1..2K+1]
+        auto ranges = [&](const std::vector<int>& chunks, int base) {
+            std::vector<int> cnt(K + 1, 0);
+            for (size_t q = 0; q < chunks.size() / 3; ++q) cnt[chunks[3 * q + 2] + 1]++;
+            for (int k = 0; k < K; ++k) cnt[k + 1] += cnt[k];
+            for (int k = 0; k <= K; ++k) lcp[base + k] = cnt[k];
+        };
         pack_lidar(p->n_plane, 7, p->plane_pose, p->plane_const, K, c->plane_perm, soa, P.pl_stride, ch);
-        P.n_plane = p->n_plane; P.n_pchunk = (int)ch.size() / 3;
+        P.n_plane = p->n_plane; P.n_pchunk = (int)ch.size() / 3; ranges(ch, 0);
         put(soa.data(), soa.size() * 8, (void**)&P.pl_c); put(ch.data(), 4 * ch.size(), (void**)&P.pchunk);
         pack_lidar(p->n_edge, 9, p->edge_pose, p->edge_const, K, c->edge_perm, soa, P.ed_stride, ch);
-        P.n_edge = p->n_edge; P.n_echunk = (int)ch.size() / 3;
+        P.n_edge = p->n_edge; P.n_echunk = (int)ch.size() / 3; ranges(ch, K + 1);
         put(soa.data(), soa.size() * 8, (void**)&P.ed_c); put(ch.data(), 4 * ch.size(), (void**)&P.echunk);
+        put(nullptr, 8 * (size_t)28 * std::max(P.n_pchunk + P.n_echunk, 1), (void**)&P.lpart);
+        put(lcp.data(), 4 * lcp.size(), (void**)&P.lchunk_pose);
     }
     // IMU
     P.n_imu = p->n_imu;
     put(p->imu_const, 8 * (size_t)287 * p->n_imu, (void**)&P.imu_c);
     put(nullptr, 8 * (size_t)225 * std::max(p->n_imu, 1), (void**)&P.imu_U);
     put(p->imu_i, 4 * (size_t)p->n_imu, (void**)&P.imu_i); put(p->imu_j, 4 * (size_t)p->n_imu, (void**)&P.imu_j);
+    put(nullptr, 8 * (size_t)931 * std::max(p->n_imu, 1), (void**)&P.ipart);
     // prior
     P.pn = p->prior.n > 0 ? p->prior.n : 0; P.pnblk = P.pn ? p->prior.nblk : 0;
     c->prior_joff.clear();
+    std::vector<int> pinv(D, -1);
     if (P.pn) {
         const vil_prior& pr = p->prior;
         const int n = pr.n;
@@ -255,9 +280,12 @@ int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
         put(pr.blk_kind, 4 * (size_t)pr.nblk, (void**)&P.pblk_kind); put(pr.blk_index, 4 * (size_t)pr.nblk, (void**)&P.pblk_index);
         put(pr.blk_col, 4 * (size_t)pr.nblk, (void**)&P.pblk_col); put(xoff.data(), 4 * (size_t)pr.nblk, (void**)&P.pblk_xoff);
         put(pmap.data(), 4 * (size_t)n, (void**)&P.pmap);
+        for (int q = 0; q < n; ++q) if (pmap[q] >= 0) pinv[pmap[q]] = q;
         put(pr.x0, 8 * (size_t)xo, (void**)&P.px0); put(pr.J0, 8 * (size_t)n * n, (void**)&P.pJ0); put(pr.r0, 8 * (size_t)n, (void**)&P.pr0);
         put(nullptr, 8 * (size_t)n * n, (void**)&P.pH); put(nullptr, 8 * (size_t)n, (void**)&P.pg0); put(nullptr, 8, (void**)&P.pc0);
     }
+    put(pinv.data(), 4 * (size_t)D, (void**)&P.pinv);
+    put(nullptr, 8 * (size_t)((P.pn ? P.pn + 1 : 0) + 601 * (p->n_icp + p->n_lps) + 1), (void**)&P.mpart);
     // ICP / LPS
     P.n_icp = p->n_icp; P.n_lps = p->n_lps;
     put(p->icp_ids, 16 * (size_t)p->n_icp, (void**)&P.icp_ids); put(p->icp_const, 80 * (size_t)p->n_icp, (void**)&P.icp_c);
@@ -274,14 +302,23 @@ int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
     put(nullptr, 8 * (size_t)D * D, (void**)&P.M); put(nullptr, 8 * (size_t)D, (void**)&P.stepc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.stepl);
     put(nullptr, 8 * (size_t)D, (void**)&P.tmpc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.tmpl);
     put(nullptr, sizeof(Ctl), (void**)&P.ctl);
+    put(nullptr, 8 * 64, (void**)&P.dbg);
+    if (const char* ev = getenv("VIL_SKIP")) P.skip_mask = atoi(ev);
     // device allocation + single H2D copy
     const size_t total = (ar.h.size() + 255) & ~size_t(255);
     if (total > ar.cap) { if (ar.d) HIPCHK(hipFree(ar.d)); ar.d = nullptr; HIPCHK(hipMalloc(&ar.d, total)); ar.cap = total; }
     for (const Fix& f : fix) *f.slot = ar.d + f.off;
     HIPCHK(hipMemcpyAsync(ar.d, ar.h.data(), ar.h.size(), hipMemcpyHostToDevice, c->stream));
     c->P = P; c->K = K; c->L = L; c->D = D; c->NS = NS;
-    c->n_blocks_sweep = P.n_imu + P.n_vchunk + P.n_pchunk + P.n_echunk + 1;
-    c->lds_sweep = sizeof(double) * (VIL_VCHUNK_F * VF_STRIDE + VIL_VCHUNK_LM * 16 + 16);
+    { const int per = VIL_SWEEP_THREADS / 256; c->n_blocks_sweep = P.n_imu + P.n_vwg + (P.n_pchunk + per - 1) / per + (P.n_echunk + per - 1) / per + 1; }
+    c->lds_sweep = sizeof(double) * (size_t)(P.NVT + 3 * NV + VIL_VCHUNK_F * VF_STRIDE + VIL_VCHUNK_LM * 16 + 32 + VIL_VCHUNK_F / 2 + 8 + VIL_VCHUNK_LM + 8);
+    if (c->lds_sweep < 8 * 2048) c->lds_sweep = 8 * 2048;
+    if (c->lds_sweep > 160 * 1024) return VIL_ERR_UNSUPPORTED;
+    HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep));
+    c->n_blocks_reduce = (D * D + VIL_THREADS - 1) / VIL_THREADS + 1;
+    c->lds_step = 8 * (size_t)(D + 1) * (D + 2) / 2;
+    c->step_lds = c->lds_step + sizeof(vd::StepShared) + 1024 <= 160 * 1024;
+    if (c->step_lds) HIPCHK(hipFuncSetAttribute((const void*)k_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
     // one-time set-up: IMU sqrt-information, prior contraction
     HIPCHK(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
     const int nb_setup = P.n_imu + (P.pn ? 64 : 0);
@@ -295,8 +332,14 @@ int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
 }
 
 static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
-    hipLaunchKernelGGL(k_sweep, dim3(c->n_blocks_sweep), dim3(VIL_THREADS), c->lds_sweep, c->stream, c->P, so);
+    hipLaunchKernelGGL(k_sweep, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, c->P, so);
     return VIL_OK;
+}
+static void launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step) {
+    hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce), dim3(VIL_THREADS), 0, c->stream, c->P);
+    if (!step) return;
+    if (c->step_lds) hipLaunchKernelGGL(k_step<true>, dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
+    else hipLaunchKernelGGL(k_step<false>, dim3(1), dim3(VIL_STEP_THREADS), 0, c->stream, c->P, so);
 }
 
 static int init_ctl(vil_ctx* c, const vil_options* o, int lin_mode) {
@@ -304,13 +347,26 @@ static int init_ctl(vil_ctx* c, const vil_options* o, int lin_mode) {
     ctl.cur = 0; ctl.first = 1; ctl.radius = o->initial_radius; ctl.mu = o->min_mu; ctl.lin_mode = lin_mode;
     *c->h_ctl = ctl;
     HIPCHK(hipMemcpyAsync(c->P.ctl, c->h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
-    // both system buffers start zeroed; x[1] = x[0] = current state
-    for (int q = 0; q < 2; ++q) {
-        const SysBuf& sb = c->P.sys[q];
-        HIPCHK(hipMemsetAsync(sb.S, 0, 8 * (size_t)c->D * c->D, c->stream));
-        HIPCHK(hipMemsetAsync(sb.gred, 0, 8 * (size_t)c->D, c->stream)); HIPCHK(hipMemsetAsync(sb.bc, 0, 8 * (size_t)c->D, c->stream));
-        HIPCHK(hipMemsetAsync(sb.diag, 0, 8 * (size_t)c->D, c->stream)); HIPCHK(hipMemsetAsync(sb.cost, 0, 8, c->stream));
-    }
+    return VIL_OK;
+}
+
+int vil_profile_enable(vil_ctx* c, int on) {
+    if (!c) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    if (on && c->ev.empty()) { c->ev.resize(32); for (auto& e : c->ev) HIPCHK(hipEventCreate(&e)); }
+    c->profiling = on != 0;
+    return VIL_OK;
+}
+int vil_profile_read(vil_ctx* c, vil_profile* out, int reset) {
+    if (!c || !out) return VIL_ERR_INVALID_ARGUMENT;
+    *out = c->prof;
+    if (reset) c->prof = vil_profile{0, 0.0, 0, 0.0};
+    return VIL_OK;
+}
+
+int vil_debug_read(vil_ctx* c, long long* out64) {
+    if (!c || !c->uploaded) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipMemcpy(out64, c->P.dbg, 8 * 64, hipMemcpyDeviceToHost));
     return VIL_OK;
 }
 
@@ -334,13 +390,27 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     bool finished = false;
     const int chunk = 6;
     for (int it = 0; it <= o->max_iterations + 8 && !finished; ) {
-        for (int q = 0; q < chunk && it <= o->max_iterations + 8; ++q, ++it) {
+        int launched = 0;
+        const int sweeps_before = (it == 0) ? 0 : c->h_ctl->n_sweeps;
+        for (int q = 0; q < chunk && it <= o->max_iterations + 8; ++q, ++it, ++launched) {
+            if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q], c->stream));
             launch_sweep(c, so);
-            hipLaunchKernelGGL(k_step, dim3(1), dim3(VIL_STEP_THREADS), 0, c->stream, c->P, so);
+            if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q + 1], c->stream));
+            launch_reduce_step(c, so, true);
         }
+        if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * launched], c->stream));
         HIPCHK(hipMemcpyAsync(c->h_ctl, c->P.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         finished = c->h_ctl->done != 0;
+        if (c->profiling) {
+            int live = c->h_ctl->n_sweeps - sweeps_before;   // launches that found done == 0
+            live = std::max(0, std::min(live, launched));
+            for (int q = 0; q < live; ++q) {
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * q], c->ev[2 * q + 1])); c->prof.sweep_ms += ms; c->prof.sweep_launches++;
+                HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * q + 1], c->ev[2 * q + 2])); c->prof.step_ms += ms; c->prof.step_launches++;
+            }
+        }
         if (!finished && o->max_time_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= o->max_time_s) {
             c->h_ctl->done = 1; c->h_ctl->term = VIL_TERM_MAX_TIME; finished = true;   // ceres max_solver_time_in_seconds (estimator.cpp:1411)
         }
@@ -426,8 +496,8 @@ int vil_eval_factors(vil_ctx* c, const vil_problem* p, const vil_state* s, int c
     switch (cls) {
         case VIL_FACTOR_IMU: hipLaunchKernelGGL(k_eval_imu, dim3(nfac), dim3(VIL_THREADS), 0, c->stream, P, x, d_r, d_J); break;
         case VIL_FACTOR_VISUAL: hipLaunchKernelGGL(k_eval_visual, dim3(nb), dim3(VIL_THREADS), 0, c->stream, P, x, d_r, d_J); break;
-        case VIL_FACTOR_ICP: hipLaunchKernelGGL(k_eval_rel, dim3(1), dim3(64), 0, c->stream, P, x, 1, d_r, d_J); break;
-        case VIL_FACTOR_LPS: hipLaunchKernelGGL(k_eval_rel, dim3(1), dim3(64), 0, c->stream, P, x, 0, d_r, d_J); break;
+        case VIL_FACTOR_ICP: hipLaunchKernelGGL(k_eval_rel, dim3(2), dim3(VIL_THREADS), 0, c->stream, P, x, 1, d_r, d_J); break;
+        case VIL_FACTOR_LPS: hipLaunchKernelGGL(k_eval_rel, dim3(2), dim3(VIL_THREADS), 0, c->stream, P, x, 0, d_r, d_J); break;
         case VIL_FACTOR_EDGE: hipLaunchKernelGGL(k_eval_lidar<3>, dim3(nb), dim3(VIL_THREADS), 0, c->stream, P, x, d_r, d_J); break;
         case VIL_FACTOR_PLANE: hipLaunchKernelGGL(k_eval_lidar<1>, dim3(nb), dim3(VIL_THREADS), 0, c->stream, P, x, d_r, d_J); break;
         case VIL_FACTOR_PRIOR:
@@ -462,8 +532,8 @@ int vil_linearize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vi
     const SolveOpts so = to_dev_opts(o);
     st = init_ctl(c, o, 1);
     if (st != VIL_OK) return st;
-    launch_sweep(c, so);                                   // writes system set 1 (cand = 1 - cur)
-    hipLaunchKernelGGL(k_mirror, dim3(64), dim3(VIL_THREADS), 0, c->stream, c->P, 1);
+    launch_sweep(c, so);                                   // partial records of system set 1 (cand = 1 - cur)
+    launch_reduce_step(c, so, false);
     const size_t D = c->D;
     st = ensure_pin(c, 8 * (D * D + D + 1));
     if (st != VIL_OK) return st;
