@@ -51,7 +51,6 @@ struct vil_ctx {
     double* h_pin = nullptr;       // pinned scratch
     size_t h_pin_bytes = 0;
     std::vector<int> prior_joff;
-    MargWork marg;
     bool profiling = false;
     std::vector<hipEvent_t> ev;
     vil_profile prof = {0, 0.0, 0, 0.0};
@@ -133,7 +132,6 @@ void vil_destroy(vil_ctx* c) {
     if (c->d_status) hipFree(c->d_status);
     if (c->h_ctl) hipHostFree(c->h_ctl);
     if (c->h_pin) hipHostFree(c->h_pin);
-    marg_free(c->marg);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -548,9 +546,122 @@ int vil_linearize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vi
 
 int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out) {
     if (!c || !p || !s || !o || !spec || !out) return VIL_ERR_INVALID_ARGUMENT;
-    int st = vil_upload(c, p, s);
+    const int K = p->K;
+    if (K < 3) return VIL_ERR_INVALID_ARGUMENT;
+    const bool old_ = spec->flag == VIL_MARGIN_OLD;
+    const int drop_pose = old_ ? 0 : K - 2;
+    // ---- derived sub-problem: the factors MarginalizationInfo collects (estimator.cpp:1489-1589 / 1626-1641), every block free
+    vil_problem q = *p;
+    q.pose_const = nullptr; q.sb_const = nullptr; q.lm_const = nullptr; q.ex_const = 0; q.td_const = 0;
+    q.n_edge = 0; q.n_plane = 0; q.edge_pose = nullptr; q.plane_pose = nullptr; q.edge_const = nullptr; q.plane_const = nullptr;
+    std::vector<int> imu_i, imu_j, vis_i, vis_j, vis_l, icp_ids, lps_ids;
+    std::vector<double> imu_c, vis_c, icp_c, lps_c;
+    std::vector<char> pose_t(K, 0), sb_t(K, 0);
+    bool ex_t = false, td_t = false;
+    int n_lm_elim = 0;
+    if (p->prior.n > 0) {
+        bool has_drop = false;
+        for (int b = 0; b < p->prior.nblk; ++b) {
+            const int kind = p->prior.blk_kind[b], idx = p->prior.blk_index[b];
+            if (kind == VIL_BLK_POSE) { pose_t[idx] = 1; if (idx == drop_pose) has_drop = true; }
+            else if (kind == VIL_BLK_SPEEDBIAS) sb_t[idx] = 1;
+            else if (kind == VIL_BLK_EX) ex_t = true; else td_t = true;
+        }
+        if (!old_ && !has_drop) { out->n = -1; return VIL_OK; }     // estimator.cpp:1620-1621: prior kept as is
+    } else if (!old_) { out->n = -1; return VIL_OK; }
+    if (old_) {
+        for (int f = 0; f < p->n_imu; ++f) if (p->imu_i[f] == 0 && p->imu_j[f] == 1 && p->imu_const[(size_t)f * 287 + 16] < 10.0) {
+            imu_i.push_back(0); imu_j.push_back(1); imu_c.insert(imu_c.end(), p->imu_const + (size_t)f * 287, p->imu_const + (size_t)(f + 1) * 287);
+            pose_t[0] = pose_t[1] = 1; sb_t[0] = sb_t[1] = 1;
+        }
+        int last_l = -1;
+        for (int f = 0; f < p->n_vis; ++f) if (p->vis_i[f] == 0) {
+            vis_i.push_back(0); vis_j.push_back(p->vis_j[f]); vis_l.push_back(p->vis_l[f]);
+            vis_c.insert(vis_c.end(), p->vis_const + (size_t)f * 14, p->vis_const + (size_t)(f + 1) * 14);
+            pose_t[0] = 1; pose_t[p->vis_j[f]] = 1; ex_t = true; if (p->use_td) td_t = true;
+            if (p->vis_l[f] != last_l) { ++n_lm_elim; last_l = p->vis_l[f]; }
+        }
+        if (spec->icp_marg >= 0 && spec->icp_marg < p->n_icp) {
+            for (int b = 0; b < 4; ++b) { const int id = b == 0 ? 0 : p->icp_ids[4 * spec->icp_marg + b]; icp_ids.push_back(id); pose_t[id] = 1; }
+            icp_c.insert(icp_c.end(), p->icp_const + (size_t)spec->icp_marg * 10, p->icp_const + (size_t)(spec->icp_marg + 1) * 10);
+        }
+        if (spec->lps_marg >= 0 && spec->lps_marg < p->n_lps) {
+            for (int b = 0; b < 2; ++b) { const int id = b == 0 ? 0 : p->lps_ids[2 * spec->lps_marg + b]; lps_ids.push_back(id); pose_t[id] = 1; }
+            lps_c.insert(lps_c.end(), p->lps_const + (size_t)spec->lps_marg * 7, p->lps_const + (size_t)(spec->lps_marg + 1) * 7);
+        }
+    }
+    q.n_imu = (int)imu_i.size(); q.imu_i = imu_i.data(); q.imu_j = imu_j.data(); q.imu_const = imu_c.data();
+    q.n_vis = (int)vis_i.size(); q.vis_i = vis_i.data(); q.vis_j = vis_j.data(); q.vis_l = vis_l.data(); q.vis_const = vis_c.data();
+    q.n_icp = (int)icp_ids.size() / 4; q.icp_ids = icp_ids.data(); q.icp_const = icp_c.data();
+    q.n_lps = (int)lps_ids.size() / 2; q.lps_ids = lps_ids.data(); q.lps_const = lps_c.data();
+    int st = vil_upload(c, &q, s);
     if (st != VIL_OK) return st;
-    return marg_run(c->device, c->stream, c->P, c->marg, p, s, to_dev_opts(o), spec, out);
+    const SolveOpts so = to_dev_opts(o);
+    st = init_ctl(c, o, 1);
+    if (st != VIL_OK) return st;
+    launch_sweep(c, so);
+    launch_reduce_step(c, so, false);
+    // ---- which reduced columns are dropped / kept (canonical kept order: poses, speed-biases, ex, td) ----------------
+    const int D = c->D;
+    std::vector<int> drop_cols, keep_cols, kinds, index;
+    if (pose_t[drop_pose]) for (int k = 0; k < 6; ++k) drop_cols.push_back(6 * drop_pose + k);
+    if (old_ && sb_t[0]) for (int k = 0; k < 9; ++k) drop_cols.push_back(6 * K + 7 + k);
+    for (int k = 0; k < K; ++k) if (pose_t[k] && k != drop_pose) { kinds.push_back(VIL_BLK_POSE); index.push_back(k); for (int q2 = 0; q2 < 6; ++q2) keep_cols.push_back(6 * k + q2); }
+    for (int k = 0; k < K; ++k) if (sb_t[k] && !(old_ && k == 0)) { kinds.push_back(VIL_BLK_SPEEDBIAS); index.push_back(k); for (int q2 = 0; q2 < 9; ++q2) keep_cols.push_back(6 * K + 7 + 9 * k + q2); }
+    if (ex_t) { kinds.push_back(VIL_BLK_EX); index.push_back(0); for (int q2 = 0; q2 < 6; ++q2) keep_cols.push_back(6 * K + q2); }
+    if (td_t && p->use_td) { kinds.push_back(VIL_BLK_TD); index.push_back(0); keep_cols.push_back(6 * K + 6); }
+    const int nd = (int)drop_cols.size(), n = (int)keep_cols.size();
+    int n_max, nblk_max, x0_max;
+    vil_prior_capacity(K, &n_max, &nblk_max, &x0_max);
+    if (n > n_max || (int)kinds.size() > nblk_max || n <= 0 || nd <= 0) return VIL_ERR_UNSUPPORTED;
+    // ---- device work space + kernel ------------------------------------------------------------------------------
+    const size_t nn = (size_t)n * n;
+    const size_t bytes = 8 * ((size_t)nd * nd * 2 + nd + nn * 5 + (size_t)n * 3) + 4 * (size_t)(nd + n + 2 * (n + 2)) + 4096;
+    char* dw = nullptr;
+    HIPCHK(hipMalloc(&dw, bytes));
+    size_t off = 0;
+    auto take = [&](size_t b2) { char* r = dw + off; off += (b2 + 255) & ~size_t(255); return r; };
+    MargDev M;
+    M.D = D; M.nd = nd; M.n = n; M.eps = 1e-8;
+    M.S = c->P.sys[1].S; M.g = c->P.sys[1].gred;
+    int* d_drop = (int*)take(4 * (size_t)nd); int* d_keep = (int*)take(4 * (size_t)n);
+    M.drop_cols = d_drop; M.keep_cols = d_keep;
+    M.pairs = (int*)take(4 * (size_t)(n + 2 + nd + 2));
+    M.Add = (double*)take(8 * (size_t)nd * nd); M.Vd = (double*)take(8 * (size_t)nd * nd); M.wd = (double*)take(8 * (size_t)nd);
+    M.T = (double*)take(8 * nn); M.A = (double*)take(8 * nn); M.b = (double*)take(8 * (size_t)n);
+    M.V = (double*)take(8 * nn); M.w = (double*)take(8 * (size_t)n); M.J0 = (double*)take(8 * nn); M.r0 = (double*)take(8 * (size_t)n);
+    if (off > bytes) { hipFree(dw); return VIL_ERR_DEVICE; }
+    HIPCHK(hipMemcpyAsync(d_drop, drop_cols.data(), 4 * (size_t)nd, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_keep, keep_cols.data(), 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_marg, dim3(1), dim3(512), 0, c->stream, M);
+    st = ensure_pin(c, 8 * (nn * 2 + 2 * (size_t)n));
+    if (st != VIL_OK) { hipFree(dw); return st; }
+    HIPCHK(hipMemcpyAsync(c->h_pin, M.J0, 8 * nn, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_pin + nn, M.A, 8 * nn, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_pin + 2 * nn, M.r0, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_pin + 2 * nn + n, M.b, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    hipFree(dw);
+    for (size_t e = 0; e < 2 * nn + 2 * (size_t)n; ++e) if (!std::isfinite(c->h_pin[e])) return VIL_ERR_NON_FINITE;
+    // ---- getParameterBlocks with the address shift as an index remap (estimator.cpp:1599-1611, 1654-1677) --------------
+    out->n = n; out->m = nd + n_lm_elim; out->nblk = (int)kinds.size();
+    memcpy(out->J0, c->h_pin, 8 * nn); memcpy(out->r0, c->h_pin + 2 * nn, 8 * (size_t)n);
+    if (out->A) memcpy(out->A, c->h_pin + nn, 8 * nn);
+    if (out->b) memcpy(out->b, c->h_pin + 2 * nn + n, 8 * (size_t)n);
+    int col = 0, xo = 0;
+    for (size_t b = 0; b < kinds.size(); ++b) {
+        const int kind = kinds[b], idx = index[b];
+        out->blk_kind[b] = kind;
+        int ni = idx;
+        if (kind == VIL_BLK_POSE || kind == VIL_BLK_SPEEDBIAS) ni = old_ ? idx - 1 : (idx == K - 1 ? K - 2 : idx);
+        out->blk_index[b] = ni; out->blk_col[b] = col;
+        const double* src = kind == VIL_BLK_POSE ? s->pose + 7 * idx : (kind == VIL_BLK_SPEEDBIAS ? s->speedbias + 9 * idx : (kind == VIL_BLK_EX ? s->ex_pose : s->td));
+        const int gs = (kind == VIL_BLK_POSE || kind == VIL_BLK_EX) ? 7 : (kind == VIL_BLK_SPEEDBIAS ? 9 : 1), ls = gs == 7 ? 6 : gs;
+        for (int k = 0; k < gs; ++k) out->x0[xo + k] = src[k];
+        xo += gs; col += ls;
+    }
+    return VIL_OK;
 }
 
 // estimator.cpp:960-1011 double2vector(): yaw + translation gauge fix (host logic of the boundary)
