@@ -21,10 +21,12 @@ struct SysBuf {       // one linearisation of the window (double-buffered: curre
     double* eA;       // L x 13 e_l on [anchor pose(6) | ex(6) | td(1)]
     double* eO;       // F x 6  e_l on the observing pose of each factor
     double* cost;     // 1
+    double* ar;       // start of the contiguous all-reduce block [S | gred | bc | diag | cost | xn sn] (D*D + 3D + 3 doubles)
 };
 
 struct Ctl {          // trust-region state, lives in device memory, owned by the step kernel
     int cur, iter, done, term, first, resweep, reuse, nsucc, invalid_run, status, lin_mode, n_sweeps;
+    int phase_need, skip_b;       // split-step hand-off (multi-GPU: step A | all-reduce scalars | step B)
     double radius, mu, cost_cur, model_change, alpha, dogleg_norm, initial_cost, cand_cost;
     double mu_used, gn2, g2, gg;   // dogleg scalars of the current linearisation (reused after a rejected step)
     double cost_trace[64], radius_trace[64];
@@ -74,6 +76,11 @@ struct DevP {
     double* Sl; double* Sc; double* dc; double* dl; double* gradc; double* gradl; double* gnc; double* gnl;
     double* M; double* stepc; double* stepl; double* tmpc; double* tmpl;
     Ctl* ctl;
+    double* arstage;              // world > 1: k_reduce output / all-reduce buffer (D*D + 3D + 3), copied into sys[cand] by step A
+    double* scal;                 // 8 scalars exchanged between step A and step B (all-reduced when world > 1)
+    double* lam0;                 // L: landmark inverse depths at upload (for the final owner merge)
+    int rank, world;              // data-parallel shard of the factor set
+    int split;                    // step kernel split around the scalar all-reduce (world > 1, or forced for single-GPU testing)
     long long* dbg;               // 64 cycle stamps (debug/profiling aid)
     int skip_mask;                // debug: bit0 visual, 1 imu, 2 plane, 3 edge, 4 misc roles skipped in the sweep
 };

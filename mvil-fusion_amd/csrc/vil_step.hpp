@@ -296,7 +296,9 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
 
 }  // namespace vd
 
-template <bool LDSM>
+// PHASE 0: whole step (single GPU).  PHASE 1 / 2: the step split around the all-reduce of the landmark-dependent
+// scalars (multi-GPU: every rank owns a slice of the landmarks).
+template <bool LDSM, int PHASE>
 __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) {
     using namespace vd;
     __shared__ StepShared s;
@@ -307,14 +309,40 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     __syncthreads();
     #define STAMP(k) do { __syncthreads(); if (t == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[k] = tt_; } } while (0)
     if (s.c.done) return;
+    const bool multi = P.split != 0;
+    const bool cam = P.world <= 1 || P.rank == 0;      // camera-side terms of global sums are counted once
     STAMP(0);
+    if (PHASE == 1) {   // the all-reduced candidate system arrives in the staging buffer
+        double* dst = P.sys[1 - s.c.cur].ar;
+        const int cnt = D * D + 3 * D + 3;
+        for (int e = t; e < cnt; e += NT) dst[e] = P.arstage[e];
+        __syncthreads();
+    }
+    if (PHASE == 2) {
+        if (s.c.skip_b) { if (t == 0) { s.c.skip_b = 0; *P.ctl = s.c; } return; }
+        if (t == 0 && s.c.phase_need) {
+            Ctl& c = s.c;
+            const double g2 = P.scal[0], q = P.scal[1], gm = P.scal[2];
+            if (gm <= O.gradient_tolerance) { c.done = 1; c.term = 2; }
+            c.alpha = g2 / q; c.mu_used = c.mu; c.gn2 = P.scal[3]; c.g2 = g2; c.gg = P.scal[4];
+            c.mu = fmax(O.min_mu, 2.0 * c.mu / 10.0);
+            c.phase_need = 0;
+        }
+        __syncthreads();
+        if (s.c.done) { if (t == 0) *P.ctl = s.c; return; }
+    }
     // ---------------- judge the candidate that the sweep just linearised -------------------------
-    if (t == 0) {
+    if (PHASE != 2 && t == 0) {
         Ctl& c = s.c;
         const int cand = 1 - c.cur;
         const double cand_cost = *P.sys[cand].cost;
         c.cand_cost = cand_cost;
-        if (c.first || c.resweep) {
+        if (multi && !c.first && !c.resweep) {     // parameter tolerance of the step just evaluated (norms all-reduced with S)
+            const double* tail = P.sys[cand].ar + (size_t)P.D * P.D + 3 * P.D + 1;
+            if (sqrt(tail[1]) <= O.parameter_tolerance * (sqrt(tail[0]) + O.parameter_tolerance)) { c.done = 1; c.term = 3; }
+        }
+        if (c.done) {}
+        else if (c.first || c.resweep) {
             if (c.first) { c.initial_cost = cand_cost; s.was_first = 1; }
             if (!isfinite(cand_cost)) { c.done = 1; c.term = 6; c.status = -3; }
             c.cur = cand; c.cost_cur = cand_cost; c.first = 0; c.resweep = 0; s.need = 1;
@@ -345,7 +373,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     if (s.c.done) { if (t == 0) *P.ctl = s.c; return; }
     STAMP(1);
     double gn2 = 0, g2 = 0, gg = 0;
-    if (s.need) {
+    if (PHASE != 2 && s.need) {
         // ---- camera vectors: Jacobi scaling (first linearisation), dogleg diagonal, gradient_, u = Sc gradient_/d
         double gm = 0;
         for (int i = t; i < D; i += NT) {
@@ -356,7 +384,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             const double g = Sc * b / d;
             s.sc[i] = Sc; s.dcs[i] = d; s.gr[i] = g; s.y[i] = Sc * g / d;
             P.dc[i] = d; P.gradc[i] = g;
-            g2 += g * g; gm = fmax(gm, fabs(b));
+            if (cam) { g2 += g * g; gm = fmax(gm, fabs(b)); }
         }
         __syncthreads();
         STAMP(9);
@@ -399,7 +427,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                     while (tri_off(i + 1) <= idx) ++i;
                     while (tri_off(i) > idx) --i;
                     const int j = idx - tri_off(i);
-                    q += (i == j ? 1.0 : 2.0) * s.y[i] * v[u] * s.y[j];
+                    if (cam) q += (i == j ? 1.0 : 2.0) * s.y[i] * v[u] * s.y[j];
                     double m = s.sc[i] * v[u] * s.sc[j];
                     if (i == j) m += mu * s.dcs[i] * s.dcs[i];
                     if constexpr (LDSM) Alds[idx] = m; else Ag[idx] = m;
@@ -410,7 +438,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         for (int j = t; j < D; j += NT) { const double m = s.sc[j] * sb.gred[j]; if constexpr (LDSM) Alds[NL + j] = m; else Ag[NL + j] = m; }
         bsum3<true>(g2, q, gm, s);
         STAMP(2);
-        if (gm <= O.gradient_tolerance) { if (t == 0) { s.c.done = 1; s.c.term = 2; *P.ctl = s.c; } return; }
+        if (PHASE == 0 && gm <= O.gradient_tolerance) { if (t == 0) { s.c.done = 1; s.c.term = 2; *P.ctl = s.c; } return; }
         bool ok;
         if constexpr (LDSM) ok = chol_blocked(Alds, D, s); else ok = chol_blocked(Ag, D, s);
         STAMP(3);
@@ -421,7 +449,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                 Ctl& c = s.c;
                 c.mu *= 10.0;
                 if (!(c.mu < O.max_mu)) { c.iter++; c.invalid_run++; c.reuse = 0; if (c.invalid_run >= 5) { c.done = 1; c.term = 6; c.status = -4; } }
-                c.resweep = 1;
+                c.resweep = 1; c.skip_b = (PHASE == 1) ? 1 : 0;
             }
             for (int i = t; i < P.NS; i += NT) xc[i] = x[i];
             __syncthreads();
@@ -435,7 +463,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             const double xi = s.y[i];
             const double gnv = -xi * s.dcs[i];
             s.gn[i] = gnv; P.gnc[i] = gnv;
-            gn2 += gnv * gnv; gg += gnv * s.gr[i];
+            if (cam) { gn2 += gnv * gnv; gg += gnv * s.gr[i]; }
             s.y[i] = s.sc[i] * xi;     // Sc x_c for the landmark back-substitution
         }
         __syncthreads();
@@ -451,6 +479,10 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         }
         double dummy = 0;
         bsum3(gn2, gg, dummy, s);
+        if (PHASE == 1) {
+            if (t == 0) { P.scal[0] = g2; P.scal[1] = q; P.scal[2] = gm; P.scal[3] = gn2; P.scal[4] = gg; s.c.phase_need = 1; *P.ctl = s.c; }
+            return;
+        }
         if (t == 0) {
             Ctl& c = s.c;
             c.alpha = g2 / q; c.mu_used = c.mu; c.gn2 = gn2; c.g2 = g2; c.gg = gg;
@@ -458,6 +490,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         }
         __syncthreads();
     } else {
+        if (PHASE == 1) { if (t == 0) { for (int k = 0; k < 5; ++k) P.scal[k] = 0.0; s.c.phase_need = 0; *P.ctl = s.c; } return; }
         for (int i = t; i < D; i += NT) { s.sc[i] = P.Sc[i]; s.dcs[i] = P.dc[i]; s.gr[i] = P.gradc[i]; s.gn[i] = P.gnc[i]; }
         __syncthreads();
     }
@@ -493,21 +526,21 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         if (k < K) {
             const double* in = x + xo_pose(P, k); double* o = xc + xo_pose(P, k);
             if (P.pose_const && P.pose_const[k]) { for (int q = 0; q < 7; ++q) o[q] = in[q]; }
-            else { pose_plus(in, stepc + col_pose(P, k), o); for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
+            else { pose_plus(in, stepc + col_pose(P, k), o); if (cam) for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
         } else if (k < 2 * K) {
             const int kk = k - K;
             const double* in = x + xo_sb(P, kk); double* o = xc + xo_sb(P, kk);
             const bool cst = P.sb_const && P.sb_const[kk];
-            for (int q = 0; q < 9; ++q) { const double d = cst ? 0.0 : stepc[col_sb(P, kk) + q]; o[q] = in[q] + d; if (!cst) { xn += in[q] * in[q]; sn += d * d; } }
+            for (int q = 0; q < 9; ++q) { const double d = cst ? 0.0 : stepc[col_sb(P, kk) + q]; o[q] = in[q] + d; if (!cst && cam) { xn += in[q] * in[q]; sn += d * d; } }
         } else if (k == 2 * K) {
             const double* in = x + xo_ex(P); double* o = xc + xo_ex(P);
             if (P.ex_const) { for (int q = 0; q < 7; ++q) o[q] = in[q]; }
-            else { pose_plus(in, stepc + col_ex(P), o); for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
+            else { pose_plus(in, stepc + col_ex(P), o); if (cam) for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
         } else {
             const double in = x[xo_td(P)];
             const double d = P.td_free ? stepc[col_td(P)] : 0.0;
             xc[xo_td(P)] = in + d;
-            if (P.td_free) { xn += in * in; sn += d * d; }
+            if (P.td_free && cam) { xn += in * in; sn += d * d; }
         }
     }
     for (int l = t; l < L; l += NT) {
@@ -515,7 +548,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         double d = 0.0;
         if (sb.invp[l] != 0.0) d = P.Sl[l] * (cg * P.gradl[l] + cn * P.gnl[l]) / P.dl[l];
         xc[xo_lam(P) + l] = in + d;
-        if (!(P.lm_const && P.lm_const[l])) { xn += in * in; sn += d * d; }
+        if (multi ? (sb.invp[l] != 0.0) : !(P.lm_const && P.lm_const[l])) { xn += in * in; sn += d * d; }
     }
     double dummy2 = 0;
     bsum3(xn, sn, dummy2, s);
@@ -533,7 +566,8 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             c.mu *= 10.0; c.reuse = 0; c.resweep = 1;
         } else {
             c.invalid_run = 0;
-            if (sqrt(sn) <= O.parameter_tolerance * (sqrt(xn) + O.parameter_tolerance)) { c.done = 1; c.term = 3; }
+            if (!multi) { if (sqrt(sn) <= O.parameter_tolerance * (sqrt(xn) + O.parameter_tolerance)) { c.done = 1; c.term = 3; } }
+            else { double* tail = P.arstage + (size_t)D * D + 3 * D + 1; tail[0] = xn; tail[1] = sn; }   // judged after the next all-reduce
         }
     }
     __syncthreads();

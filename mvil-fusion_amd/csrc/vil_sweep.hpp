@@ -444,6 +444,7 @@ __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
     const int cand = 1 - ctl.cur;
     SysBuf sb = P.sys[cand];
     const int D = P.D, NV = P.NV, K = P.K, t = threadIdx.x;
+    if (P.split) { sb.S = P.arstage; sb.gred = sb.S + (size_t)D * D; sb.bc = sb.gred + D; sb.diag = sb.bc + D; sb.cost = sb.diag + D; }   // reduced across ranks before use
     const int n_rel = P.n_icp + P.n_lps;
     const double* rel0 = P.mpart + (P.pn > 0 ? P.pn + 1 : 0);
     const int nSblk = (D * D + VIL_THREADS - 1) / VIL_THREADS;

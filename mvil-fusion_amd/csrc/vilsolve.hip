@@ -11,6 +11,10 @@
 #include <cstring>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: RCCL is bound at run time (dlopen) so that a process which already
+                         // carries an RCCL (PyTorch bundles one) never ends up with two copies
+
 #include "../../include/vilsolve.h"
 #include "vil_dev.hpp"
 #include "vil_sweep.hpp"
@@ -21,6 +25,27 @@
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[vilsolve] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return VIL_ERR_DEVICE; } } while (0)
 
 namespace {
+
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    bool load() {
+        if (h) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; }     // reuse a copy that is already mapped
+        if (!h) for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) return false;
+        GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
+        AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
+        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+        return GetUniqueId && CommInitRank && AllReduce && CommDestroy;
+    }
+};
+RcclApi g_rccl;
 
 struct Arena {                     // one device allocation per uploaded window, mirrored by a host staging image
     std::vector<char> h;
@@ -51,6 +76,10 @@ struct vil_ctx {
     double* h_pin = nullptr;       // pinned scratch
     size_t h_pin_bytes = 0;
     std::vector<int> prior_joff;
+    ncclComm_t comm = nullptr;     // RCCL communicator over xGMI (world > 1)
+    bool sharded = false;          // the resident problem is this rank's shard of the factor set
+    bool split = false;            // step kernel launched as A | all-reduce | B
+    int lm_b = 0, lm_e = 0;        // owned landmark range
     bool profiling = false;
     std::vector<hipEvent_t> ev;
     vil_profile prof = {0, 0.0, 0, 0.0};
@@ -128,6 +157,7 @@ void vil_destroy(vil_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& e : c->ev) hipEventDestroy(e);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->ar.d) hipFree(c->ar.d);
     if (c->d_status) hipFree(c->d_status);
     if (c->h_ctl) hipHostFree(c->h_ctl);
@@ -168,7 +198,7 @@ static void pack_lidar(int n, int ncomp, const int* pose, const double* c, int K
     for (int k = 0; k < K; ++k) for (int s = cnt[k]; s < cnt[k + 1]; s += VIL_THREADS) { chunks.push_back(s); chunks.push_back(std::min(VIL_THREADS, cnt[k + 1] - s)); chunks.push_back(k); }
 }
 
-int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
+static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, bool sharded) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
     int st = validate(p, s);
     if (st != VIL_OK) return st;
@@ -289,12 +319,20 @@ int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
     put(p->icp_ids, 16 * (size_t)p->n_icp, (void**)&P.icp_ids); put(p->icp_const, 80 * (size_t)p->n_icp, (void**)&P.icp_c);
     put(p->lps_ids, 8 * (size_t)p->n_lps, (void**)&P.lps_ids); put(p->lps_const, 56 * (size_t)p->n_lps, (void**)&P.lps_c);
     // systems + work space (zero-initialised)
+    size_t ar_off[2] = {0, 0};
     for (int q = 0; q < 2; ++q) {
         SysBuf& sb = P.sys[q];
-        put(nullptr, 8 * (size_t)D * D, (void**)&sb.S); put(nullptr, 8 * (size_t)D, (void**)&sb.gred); put(nullptr, 8 * (size_t)D, (void**)&sb.bc); put(nullptr, 8 * (size_t)D, (void**)&sb.diag);
+        ar_off[q] = put(nullptr, 8 * ((size_t)D * D + 3 * (size_t)D + 3), (void**)&sb.ar);   // [S | gred | bc | diag | cost | xn sn] contiguous: one all-reduce
         put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&sb.hll); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&sb.bl); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&sb.invp);
-        put(nullptr, 8 * (size_t)13 * std::max(L, 1), (void**)&sb.eA); put(nullptr, 8 * (size_t)6 * std::max(p->n_vis, 1), (void**)&sb.eO); put(nullptr, 8, (void**)&sb.cost);
+        put(nullptr, 8 * (size_t)13 * std::max(L, 1), (void**)&sb.eA); put(nullptr, 8 * (size_t)6 * std::max(p->n_vis, 1), (void**)&sb.eO);
     }
+    put(nullptr, 8 * ((size_t)D * D + 3 * (size_t)D + 3), (void**)&P.arstage);
+    put(nullptr, 8 * 8, (void**)&P.scal);
+    put(L ? s->inv_depth : nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.lam0);
+    P.rank = sharded ? c->rank : 0; P.world = sharded ? c->world : 1;
+    c->sharded = sharded && c->world > 1;
+    c->split = c->sharded || getenv("VIL_FORCE_SPLIT") != nullptr;
+    P.split = c->split ? 1 : 0;
     put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.Sl); put(nullptr, 8 * (size_t)D, (void**)&P.Sc); put(nullptr, 8 * (size_t)D, (void**)&P.dc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.dl);
     put(nullptr, 8 * (size_t)D, (void**)&P.gradc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gradl); put(nullptr, 8 * (size_t)D, (void**)&P.gnc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gnl);
     put(nullptr, 8 * (size_t)D * D, (void**)&P.M); put(nullptr, 8 * (size_t)D, (void**)&P.stepc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.stepl);
@@ -306,6 +344,7 @@ int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
     const size_t total = (ar.h.size() + 255) & ~size_t(255);
     if (total > ar.cap) { if (ar.d) HIPCHK(hipFree(ar.d)); ar.d = nullptr; HIPCHK(hipMalloc(&ar.d, total)); ar.cap = total; }
     for (const Fix& f : fix) *f.slot = ar.d + f.off;
+    for (int q = 0; q < 2; ++q) { SysBuf& sb = P.sys[q]; sb.S = sb.ar; sb.gred = sb.S + (size_t)D * D; sb.bc = sb.gred + D; sb.diag = sb.bc + D; sb.cost = sb.diag + D; }
     HIPCHK(hipMemcpyAsync(ar.d, ar.h.data(), ar.h.size(), hipMemcpyHostToDevice, c->stream));
     c->P = P; c->K = K; c->L = L; c->D = D; c->NS = NS;
     { const int per = VIL_SWEEP_THREADS / 256; c->n_blocks_sweep = P.n_imu + P.n_vwg + (P.n_pchunk + per - 1) / per + (P.n_echunk + per - 1) / per + 1; }
@@ -316,7 +355,11 @@ int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
     c->n_blocks_reduce = (D * D + VIL_THREADS - 1) / VIL_THREADS + 1;
     c->lds_step = 8 * (size_t)(D + 1) * (D + 2) / 2;
     c->step_lds = c->lds_step + sizeof(vd::StepShared) + 1024 <= 160 * 1024;
-    if (c->step_lds) HIPCHK(hipFuncSetAttribute((const void*)k_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+    if (c->step_lds) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+        HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+        HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+    }
     // one-time set-up: IMU sqrt-information, prior contraction
     HIPCHK(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
     const int nb_setup = P.n_imu + (P.pn ? 64 : 0);
@@ -329,6 +372,38 @@ int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
     return hstat == 0 ? VIL_OK : VIL_ERR_NOT_POSITIVE_DEFINITE;
 }
 
+// rank r keeps the visual factors of its landmark range, a contiguous slice of the LiDAR points, and
+// (rank 0 only) the IMU / prior / ICP / LPS factors.  Landmark indices and the state stay global.
+static int upload_sharded(vil_ctx* c, const vil_problem* p, const vil_state* s) {
+    int32_t lb, le, eb, ee, pb, pe;
+    int st = vil_shard_ranges(p, c->rank, c->world, &lb, &le, &eb, &ee, &pb, &pe);
+    if (st != VIL_OK) return st;
+    vil_problem q = *p;
+    int f0 = 0, f1 = 0;
+    for (int f = 0; f < p->n_vis; ++f) { if (p->vis_l[f] < lb) f0 = f + 1; if (p->vis_l[f] < le) f1 = f + 1; }
+    q.n_vis = f1 - f0; q.vis_i = p->vis_i + f0; q.vis_j = p->vis_j + f0; q.vis_l = p->vis_l + f0; q.vis_const = p->vis_const + (size_t)f0 * 14;
+    q.n_edge = ee - eb; q.edge_pose = p->edge_pose + eb; q.edge_const = p->edge_const + (size_t)eb * 9;
+    q.n_plane = pe - pb; q.plane_pose = p->plane_pose + pb; q.plane_const = p->plane_const + (size_t)pb * 7;
+    if (c->rank != 0) { q.n_imu = 0; q.n_icp = 0; q.n_lps = 0; q.prior.n = 0; q.prior.nblk = 0; }
+    c->lm_b = lb; c->lm_e = le;
+    return upload_impl(c, &q, s, true);
+}
+
+int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
+    if (!c) return VIL_ERR_INVALID_ARGUMENT;
+    if (c->world > 1 && c->comm) return upload_sharded(c, p, s);     // a world > 1 context without a communicator works un-sharded
+    return upload_impl(c, p, s, false);
+}
+
+__global__ void k_lam_delta(DevP P, int lb, int le) {      // owner's change of the inverse depths, zero elsewhere
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < P.L) P.tmpl[l] = (l >= lb && l < le) ? P.x[0][xo_lam(P) + l] - P.lam0[l] : 0.0;
+}
+__global__ void k_lam_apply(DevP P) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < P.L) { const double v = P.lam0[l] + P.tmpl[l]; P.x[0][xo_lam(P) + l] = v; P.x[1][xo_lam(P) + l] = v; }
+}
+
 static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
     hipLaunchKernelGGL(k_sweep, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, c->P, so);
     return VIL_OK;
@@ -336,8 +411,19 @@ static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
 static void launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step) {
     hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce), dim3(VIL_THREADS), 0, c->stream, c->P);
     if (!step) return;
-    if (c->step_lds) hipLaunchKernelGGL(k_step<true>, dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
-    else hipLaunchKernelGGL(k_step<false>, dim3(1), dim3(VIL_STEP_THREADS), 0, c->stream, c->P, so);
+    if (!c->split) {
+        if (c->step_lds) hipLaunchKernelGGL((k_step<true, 0>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
+        else hipLaunchKernelGGL((k_step<false, 0>), dim3(1), dim3(VIL_STEP_THREADS), 0, c->stream, c->P, so);
+        return;
+    }
+    // multi-GPU: all-reduce the partial reduced system (+ step norms), step A, all-reduce 5 scalars, step B
+    const size_t cnt = (size_t)c->D * c->D + 3 * (size_t)c->D + 3;
+    if (c->comm) g_rccl.AllReduce(c->P.arstage, c->P.arstage, cnt, ncclDouble, ncclSum, c->comm, c->stream);
+    if (c->step_lds) hipLaunchKernelGGL((k_step<true, 1>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
+    else hipLaunchKernelGGL((k_step<false, 1>), dim3(1), dim3(VIL_STEP_THREADS), 0, c->stream, c->P, so);
+    if (c->comm) g_rccl.AllReduce(c->P.scal, c->P.scal, 8, ncclDouble, ncclSum, c->comm, c->stream);
+    if (c->step_lds) hipLaunchKernelGGL((k_step<true, 2>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
+    else hipLaunchKernelGGL((k_step<false, 2>), dim3(1), dim3(VIL_STEP_THREADS), 0, c->stream, c->P, so);
 }
 
 static int init_ctl(vil_ctx* c, const vil_options* o, int lin_mode) {
@@ -384,6 +470,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     const SolveOpts so = to_dev_opts(o);
     int st = init_ctl(c, o, 0);
     if (st != VIL_OK) return st;
+    if (c->sharded && c->L) HIPCHK(hipMemcpyAsync(c->P.lam0, c->P.x[0] + 16 * c->K + 8, 8 * (size_t)c->L, hipMemcpyDeviceToDevice, c->stream));
     // every iteration = one sweep + one step kernel; `done` turns the tail into no-ops
     bool finished = false;
     const int chunk = 6;
@@ -423,6 +510,12 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     // the accepted state is x[cur]; keep x[0] as "the" resident state
     if (ctl.cur != 0) HIPCHK(hipMemcpyAsync(c->P.x[0], c->P.x[1], 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
     else HIPCHK(hipMemcpyAsync(c->P.x[1], c->P.x[0], 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
+    if (c->sharded && c->L) {   // every rank updated only the landmarks it owns: merge the owners' changes
+        const int nb = (c->L + 255) / 256;
+        hipLaunchKernelGGL(k_lam_delta, dim3(nb), dim3(256), 0, c->stream, c->P, c->lm_b, c->lm_e);
+        if (g_rccl.AllReduce(c->P.tmpl, c->P.tmpl, (size_t)c->L, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return VIL_ERR_COMM;
+        hipLaunchKernelGGL(k_lam_apply, dim3(nb), dim3(256), 0, c->stream, c->P);
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     if (!finished) return VIL_ERR_DEVICE;
     if (ctl.status != 0) return ctl.status;
@@ -470,7 +563,7 @@ static int ensure_pin(vil_ctx* c, size_t bytes) {
 
 int vil_eval_factors(vil_ctx* c, const vil_problem* p, const vil_state* s, int cls, double* r, double* J) {
     if (!c || !r) return VIL_ERR_INVALID_ARGUMENT;
-    int st = vil_upload(c, p, s);
+    int st = upload_impl(c, p, s, false);
     if (st != VIL_OK) return st;
     const DevP& P = c->P;
     size_t nr = 0, nj = 0; int nfac = 0;
@@ -535,9 +628,14 @@ int vil_linearize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vi
     const size_t D = c->D;
     st = ensure_pin(c, 8 * (D * D + D + 1));
     if (st != VIL_OK) return st;
-    HIPCHK(hipMemcpyAsync(c->h_pin, c->P.sys[1].S, 8 * D * D, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_pin + D * D, c->P.sys[1].gred, 8 * D, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_pin + D * D + D, c->P.sys[1].cost, 8, hipMemcpyDeviceToHost, c->stream));
+    const double* src = c->split ? c->P.arstage : c->P.sys[1].ar;
+    if (c->sharded) {   // each rank linearised its shard: sum over ranks
+        if (g_rccl.AllReduce(c->P.arstage, c->P.arstage, D * D + 3 * D + 3, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return VIL_ERR_COMM;
+        src = c->P.arstage;
+    }
+    HIPCHK(hipMemcpyAsync(c->h_pin, src, 8 * D * D, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_pin + D * D, src + D * D, 8 * D, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_pin + D * D + D, src + D * D + 3 * D, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
     memcpy(S, c->h_pin, 8 * D * D); memcpy(g, c->h_pin + D * D, 8 * D); *cost = c->h_pin[D * D + D];
@@ -594,7 +692,7 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     q.n_vis = (int)vis_i.size(); q.vis_i = vis_i.data(); q.vis_j = vis_j.data(); q.vis_l = vis_l.data(); q.vis_const = vis_c.data();
     q.n_icp = (int)icp_ids.size() / 4; q.icp_ids = icp_ids.data(); q.icp_const = icp_c.data();
     q.n_lps = (int)lps_ids.size() / 2; q.lps_ids = lps_ids.data(); q.lps_const = lps_c.data();
-    int st = vil_upload(c, &q, s);
+    int st = upload_impl(c, &q, s, false);
     if (st != VIL_OK) return st;
     const SolveOpts so = to_dev_opts(o);
     st = init_ctl(c, o, 1);
@@ -623,7 +721,7 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     auto take = [&](size_t b2) { char* r = dw + off; off += (b2 + 255) & ~size_t(255); return r; };
     MargDev M;
     M.D = D; M.nd = nd; M.n = n; M.eps = 1e-8;
-    M.S = c->P.sys[1].S; M.g = c->P.sys[1].gred;
+    M.S = c->split ? c->P.arstage : c->P.sys[1].S; M.g = M.S + (size_t)D * D;
     int* d_drop = (int*)take(4 * (size_t)nd); int* d_keep = (int*)take(4 * (size_t)n);
     M.drop_cols = d_drop; M.keep_cols = d_keep;
     M.pairs = (int*)take(4 * (size_t)(n + 2 + nd + 2));
@@ -730,7 +828,24 @@ int vil_shard_ranges(const vil_problem* p, int rank, int world, int32_t* lm_begi
     return VIL_OK;
 }
 
-int vil_comm_unique_id(void* id128) { (void)id128; return VIL_ERR_UNSUPPORTED; }
-int vil_comm_init(vil_ctx* ctx, const void* id128, int rank, int world) { (void)ctx; (void)id128; (void)rank; (void)world; return VIL_ERR_UNSUPPORTED; }
+int vil_comm_unique_id(void* id128) {
+    if (!id128) return VIL_ERR_INVALID_ARGUMENT;
+    if (!g_rccl.load()) return VIL_ERR_COMM;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return VIL_ERR_COMM;
+    memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return VIL_OK;
+}
+int vil_comm_init(vil_ctx* c, const void* id128, int rank, int world) {
+    if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    if (!g_rccl.load()) return VIL_ERR_COMM;
+    if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    if (g_rccl.CommInitRank(&c->comm, world, id, rank) != ncclSuccess) return VIL_ERR_COMM;
+    c->rank = rank; c->world = world; c->uploaded = false;
+    return VIL_OK;
+}
 
 }  // extern "C"
