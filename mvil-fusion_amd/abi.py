@@ -217,6 +217,30 @@ class Window:
     def set_state(self, s):
         self.pose, self.speedbias, self.ex_pose, self.td, self.inv_depth = (f64(s[k]).copy() for k in ("pose", "speedbias", "ex_pose", "td", "inv_depth"))
 
+    _ARRAYS = ("pose", "speedbias", "ex_pose", "td", "inv_depth", "pose_const", "sb_const", "lm_const", "imu_i", "imu_j", "imu_const",
+               "vis_i", "vis_j", "vis_l", "vis_const", "icp_ids", "icp_const", "lps_ids", "lps_const", "edge_pose", "edge_const",
+               "plane_pose", "plane_const", "q_lb", "t_lb", "G")
+
+    def to_dict(self):
+        """Plain-data image of the window (for golden fixtures)."""
+        self._fix()
+        d = {k: getattr(self, k) for k in self._ARRAYS}
+        d["scalars"] = np.array([self.K, self.L, self.ex_const, self.td_const, self.use_td, self.sqrt_info_px, self.tr_over_row], dtype=np.float64)
+        pr = self.prior
+        d.update(prior_n=np.array([pr.n]), prior_kind=pr.blk_kind, prior_index=pr.blk_index, prior_col=pr.blk_col, prior_x0=pr.x0, prior_J0=pr.J0, prior_r0=pr.r0)
+        return d
+
+    @classmethod
+    def from_dict(cls, d):
+        sc = d["scalars"]
+        w = cls(int(sc[0]), int(sc[1]))
+        for k in cls._ARRAYS:
+            setattr(w, k, np.array(d[k]))
+        w.ex_const, w.td_const, w.use_td, w.sqrt_info_px, w.tr_over_row = int(sc[2]), int(sc[3]), int(sc[4]), float(sc[5]), float(sc[6])
+        w.prior = Prior(int(d["prior_n"][0]), d["prior_kind"], d["prior_index"], d["prior_col"], d["prior_x0"], d["prior_J0"], d["prior_r0"])
+        w._fix()
+        return w
+
     def nfactors(self, cls):
         return {FACTOR_IMU: len(self.imu_i), FACTOR_VISUAL: len(self.vis_i), FACTOR_ICP: len(self.icp_ids), FACTOR_LPS: len(self.lps_ids),
                 FACTOR_EDGE: len(self.edge_pose), FACTOR_PLANE: len(self.plane_pose), FACTOR_PRIOR: 1 if self.prior.n else 0}[cls]

@@ -435,8 +435,10 @@ __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O
 }
 
 // Gather of the sweep's partial records into the dense reduced system of the candidate set:
-//   S' (D x D, both triangles), gred, bc, diag, cost.   One thread per S entry (i <= j), fixed
-//   summation order => bitwise reproducible.  Last workgroup handles the vectors and the cost.
+//   S' (D x D, both triangles), gred, bc, diag, cost.   32 lower-triangle entries per workgroup, 8 threads per
+//   entry splitting the sum over the visual partials; fixed summation order => bitwise reproducible.
+//   The last workgroup handles the vectors and the cost.
+#define RED_EPW 32
 __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
     using namespace vd;
     const Ctl ctl = *P.ctl;
@@ -447,16 +449,37 @@ __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
     if (P.split) { sb.S = P.arstage; sb.gred = sb.S + (size_t)D * D; sb.bc = sb.gred + D; sb.diag = sb.bc + D; sb.cost = sb.diag + D; }   // reduced across ranks before use
     const int n_rel = P.n_icp + P.n_lps;
     const double* rel0 = P.mpart + (P.pn > 0 ? P.pn + 1 : 0);
-    const int nSblk = (D * D + VIL_THREADS - 1) / VIL_THREADS;
+    const int NL = (D * (D + 1)) >> 1;
+    const int nSblk = (NL + RED_EPW - 1) / RED_EPW;
+    __shared__ double part[2][8][RED_EPW];
     if ((int)blockIdx.x < nSblk) {
-        const int e = blockIdx.x * VIL_THREADS + t;
-        if (e >= D * D) return;
-        const int i = e / D, j = e - i * D;
-        if (i > j) return;
-        double s = 0.0;
-        if (j < NV) {                       // visual sub-space (i <= j < NV)
-            const int idx = tri_idx(NV, i, j);
-            for (int w = 0; w < P.n_vwg; ++w) s += P.vpart[(size_t)w * P.VP + idx];
+        const int el = t & (RED_EPW - 1), slice = t >> 5;
+        const int idx = blockIdx.x * RED_EPW + el;
+        int i = 0, j = 0;
+        const bool ok = idx < NL;
+        if (ok) {
+            i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+            while (((i + 1) * (i + 2)) / 2 <= idx) ++i;
+            while ((i * (i + 1)) / 2 > idx) --i;
+            j = idx - (i * (i + 1)) / 2;              // j <= i : (i, j) is a lower-triangle entry; use (row j, col i) as the upper one
+            const int tmp = i; i = j; j = tmp;        // now i <= j
+        }
+        double vs = 0.0, vdg = 0.0;
+        if (ok && j < NV) {
+            const int tix = tri_idx(NV, i, j);
+            for (int w = slice; w < P.n_vwg; w += 8) {
+                vs += P.vpart[(size_t)w * P.VP + tix];
+                if (i == j) vdg += P.vpart[(size_t)w * P.VP + P.NVT + 2 * NV + i];
+            }
+        }
+        part[0][slice][el] = vs; part[1][slice][el] = vdg;
+        __syncthreads();
+        if (slice != 0 || !ok) return;
+        double s = 0.0, vd_ = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s += part[0][q][el]; vd_ += part[1][q][el]; }
+        const double vsum = s;
+        if (j < NV) {
             if (j < 6 * K && i / 6 == j / 6) {   // LiDAR points: pose-diagonal blocks
                 const int k = i / 6, a = i - 6 * k, b = j - 6 * k;
                 const int li = a * 6 - ((a * (a - 1)) >> 1) + (b - a);
@@ -483,12 +506,7 @@ __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
         if (P.pn > 0) { const int pi = P.pinv[i], pj = P.pinv[j]; if (pi >= 0 && pj >= 0) s += P.pH[(size_t)pi * P.pn + pj]; }
         sb.S[(size_t)i * D + j] = s;
         sb.S[(size_t)j * D + i] = s;
-        if (i == j) {
-            // un-reduced diagonal: S'_ii plus the Schur term that was subtracted -> recomputed from the visual diag partials
-            double dg = s;
-            if (i < NV) { double vs = 0.0, vd_ = 0.0; const int idx = tri_idx(NV, i, i); for (int w = 0; w < P.n_vwg; ++w) { vs += P.vpart[(size_t)w * P.VP + idx]; vd_ += P.vpart[(size_t)w * P.VP + P.NVT + 2 * NV + i]; } dg += vd_ - vs; }
-            sb.diag[i] = dg;
-        }
+        if (i == j) sb.diag[i] = s + (i < NV ? vd_ - vsum : 0.0);   // un-reduced diagonal: add back the Schur term of the visual part
         return;
     }
     // ---- vectors + cost (one workgroup) --------------------------------------------------------------

@@ -352,7 +352,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     if (c->lds_sweep < 8 * 2048) c->lds_sweep = 8 * 2048;
     if (c->lds_sweep > 160 * 1024) return VIL_ERR_UNSUPPORTED;
     HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep));
-    c->n_blocks_reduce = (D * D + VIL_THREADS - 1) / VIL_THREADS + 1;
+    c->n_blocks_reduce = (D * (D + 1) / 2 + RED_EPW - 1) / RED_EPW + 1;
     c->lds_step = 8 * (size_t)(D + 1) * (D + 2) / 2;
     c->step_lds = c->lds_step + sizeof(vd::StepShared) + 1024 <= 160 * 1024;
     if (c->step_lds) {
