@@ -24,7 +24,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 class VilProfile(C.Structure):
-    _fields_ = [("sweep_launches", C.c_int64), ("sweep_ms", C.c_double), ("step_launches", C.c_int64), ("step_ms", C.c_double)]
+    _fields_ = [("sweep_launches", C.c_int64), ("sweep_ms", C.c_double), ("step_launches", C.c_int64), ("step_ms", C.c_double), ("reduce_ms", C.c_double)]
 
 
 def algorithmic_bytes(w):
@@ -154,7 +154,7 @@ def main():
             ach = ab / (us * 1e-6) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "k_sweep", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                "algorithmic_bytes_per_launch": ab, "avg_launch_us": us, "launches_timed": int(prof.sweep_launches),
-                               "step_kernel_avg_us": 1e3 * prof.step_ms / max(1, prof.step_launches),
+                               "reduce_plus_step_avg_us": 1e3 * prof.step_ms / max(1, prof.step_launches), "reduce_avg_us": 1e3 * prof.reduce_ms / max(1, prof.step_launches),
                                "variant": "fused sweep (no Jacobian materialisation): read-only bytes, SURVEY 8(d)"}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(w, opts)

@@ -266,7 +266,8 @@ typedef struct vil_profile {
     int64_t sweep_launches;        /* live (not early-exited) sweep launches timed              */
     double sweep_ms;               /* sum of their durations                                    */
     int64_t step_launches;
-    double step_ms;                /* sweep end -> next sweep start (step kernel + boundary)     */
+    double step_ms;                /* sweep end -> next sweep start (reduce + step kernels + boundaries) */
+    double reduce_ms;              /* of which: sweep end -> reduce end                         */
 } vil_profile;
 int vil_profile_enable(vil_ctx* ctx, int on);
 int vil_profile_read(vil_ctx* ctx, vil_profile* out, int reset);

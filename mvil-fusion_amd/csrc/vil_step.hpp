@@ -20,16 +20,17 @@
 
 namespace vd {
 
-#define STEP_NB 8
+#define STEP_NB 4
+#define PF_N ((55 * 256 + VIL_STEP_THREADS - 1) / VIL_STEP_THREADS)   // prefetched S entries per thread (55 tiles for D <= 159; larger windows loop)
 
 struct StepShared {
     Ctl c;
     double red[32];
-    double X[64 * 64];      // inverse of every 8x8 diagonal block of L (<= 64 blocks, D <= 512)
-    double y[512];
-    double sc[512], dcs[512], gr[512], gn[512];   // Sc, dogleg diagonal, gradient_, gauss_newton_step_ (camera part)
+    unsigned char tI[256], tJ[256];   // triangular tile index -> (row, col) of the tile
+    double xs[320], dinv[320];   // solution of the reduced system, reciprocal Cholesky pivots (D <= 320)
+    double y[320];
+    double sc[320], dcs[320], gr[320], gn[320];   // Sc, dogleg diagonal, gradient_, gauss_newton_step_ (camera part)
     int need, was_first, ok;
-    long long tacc[3];
 };
 
 // block-wide sum(a), sum(b) and sum-or-max(c) with one pair of barriers
@@ -110,188 +111,144 @@ __device__ __forceinline__ void pose_plus(const double* in, const double* d, dou
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-// broadcast lane `L` (compile-time constant) of a double through SGPRs: v_readlane_b32 x2, no LDS round trip
-template <int L>
-__device__ __forceinline__ double bcast(double v) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), L);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), L);
-    return __hiloint2double(hi, lo);
-}
-template <int J, int C>
-struct DiagUpd {   // trailing update inside the 8x8 diagonal block for column J, target columns C..7
-    static __device__ __forceinline__ void run(double (&a)[STEP_NB], int r) {
-        const double lcj = bcast<C>(a[J]);
-        if (r >= C) a[C] -= a[J] * lcj;
-        if constexpr (C + 1 < STEP_NB) DiagUpd<J, C + 1>::run(a, r);
-    }
-};
 // sqrt(x) and 1/sqrt(x) together: hardware rsq seed + two coupled Newton steps (no divide on the pivot chain)
 __device__ __forceinline__ void sqrt_rsqrt(double x, double& sq, double& rs) {
+    // v_rsq_f64 seeds ~2^-26; one coupled Newton step squares that (the pivot chain is latency-bound: every
+    // dependent fp64 op costs ~32 cycles), a residual correction on sqrt keeps it within an ulp or two
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
-    double e = fma(-h, g, 0.5);
+    const double e = fma(-h, g, 0.5);
     g = fma(g, e, g); h = fma(h, e, h);
-    e = fma(-h, g, 0.5);
-    g = fma(g, e, g); h = fma(h, e, h);
-    sq = g; rs = h + h;
+    sq = fma(fma(-g, g, x), h, g); rs = h + h;
 }
-template <int J>
-struct DiagCol {
-    static __device__ __forceinline__ void run(double (&a)[STEP_NB], double (&dinv)[STEP_NB], int r, bool& ok) {
-        const double pj = bcast<J>(a[J]);
-        if (!(pj > 0.0) || !isfinite(pj)) ok = false;
-        double dj, inv;
-        sqrt_rsqrt(pj, dj, inv);
-        dinv[J] = inv;
-        if (r == J) a[J] = dj; else if (r > J) a[J] *= inv;
-        if constexpr (J + 1 < STEP_NB) { DiagUpd<J, J + 1>::run(a, r); DiagCol<J + 1>::run(a, dinv, r, ok); }
-    }
-};
-template <int RR, int K>
-struct InvDot {
-    static __device__ __forceinline__ void run(const double (&a)[STEP_NB], const double (&x)[STEP_NB], double& sum) {
-        if constexpr (K < RR) { sum += bcast<RR>(a[K]) * x[K]; InvDot<RR, K + 1>::run(a, x, sum); }
-    }
-};
-template <int RR>
-struct InvRow {
-    static __device__ __forceinline__ void run(const double (&a)[STEP_NB], const double (&dinv)[STEP_NB], double (&x)[STEP_NB], int cc) {
-        double sum = 0.0;
-        InvDot<RR, 0>::run(a, x, sum);
-        x[RR] = (RR == cc) ? dinv[RR] : (RR > cc ? -sum * dinv[RR] : 0.0);
-        if constexpr (RR + 1 < STEP_NB) InvRow<RR + 1>::run(a, dinv, x, cc);
-    }
-};
-
 __device__ __forceinline__ int tri_off(int i) { return (i * (i + 1)) >> 1; }
 
-// Blocked Cholesky of the packed-lower (D+1) x (D+1) array A whose last row is the right-hand side:
-// on return rows < D hold L, row D holds y = L^-1 rhs, s.X the inverses of the diagonal blocks.
-// Returns false (uniformly) if a pivot is not positive.
+// ---- tiled lower storage of the (D+1) x (D+1) reduced matrix (last row = right-hand side): 16 x 16 tiles,
+//      tile (I, J), J <= I, at ((I(I+1)/2 + J) << 8); element (r, c) of a tile at r*16 + c.  An MFMA operand /
+//      accumulator address is then `wave-uniform tile base + per-lane constant`.
+__device__ __forceinline__ int tl_base(int I, int J) { return (tri_off(I) + J) << 8; }
+__device__ __forceinline__ int tl_idx(int i, int j) { return tl_base(i >> 4, j >> 4) + ((i & 15) << 4) + (j & 15); }
+
+// Blocked right-looking Cholesky, NB = 4, on the tiled array A.  fp64 dependent-op latency on gfx950 is ~32
+// cycles and a workgroup barrier only ~44, so the algorithm keeps every serial chain short instead of batching:
+//   (1) EVERY thread factors the 4x4 diagonal block redundantly in registers (no single-wave phase, no broadcast)
+//       and the threads owning a row below it do that row's triangular solve;
+//   (2) the trailing update is one v_mfma_f64_16x16x4_f64 per 16x16 tile (K = NB = 4), software-pipelined over
+//       the <= 8 tiles a wave owns.
+// On return rows < D hold L, row D holds y = L^-1 rhs, s.dinv[j] = 1 / L_jj.  Returns false (uniformly) on a
+// non-positive pivot.
 template <class PTR>
 __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
     const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
-    const int R = D + 1;   // rows including the rhs row
-    long long tacc[3] = {0, 0, 0}, tprev = 0;
-    #define CSTAMP(k) do { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); if (k >= 0) tacc[k < 0 ? 0 : k] += tt_ - tprev; tprev = tt_; } while (0)
-    for (int kb = 0, blk = 0; kb < D; kb += STEP_NB, ++blk) {
+    const int R = D + 1;                 // rows including the rhs row
+    const int T = (R + 15) >> 4;         // tile rows
+    for (int q = t; q < 256; q += NT) { int Ir = (int)((sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f); if (((Ir + 1) * (Ir + 2)) / 2 <= q) ++Ir; if ((Ir * (Ir + 1)) / 2 > q) --Ir; s.tI[q] = (unsigned char)Ir; s.tJ[q] = (unsigned char)(q - (Ir * (Ir + 1)) / 2); }
+    __syncthreads();
+    const int la = ((lane & 15) << 4) + (lane >> 4);       // operand element (row lane&15, k lane>>4) inside a tile
+    const int lc = ((lane >> 4) << 4) + (lane & 15);       // accumulator element (row lane>>4 (+4g), col lane&15)
+    for (int kb = 0; kb < D; kb += STEP_NB) {
         const int nb = min(STEP_NB, D - kb);
-        CSTAMP(-1);
-        // ---- 1. diagonal block: factor + invert in registers of wave 0 --------------------------
-        if (wave == 0) {
-            const int r = lane & 7;
-            double a[STEP_NB];
-#pragma unroll
-            for (int c = 0; c < STEP_NB; ++c) a[c] = (r < nb && c <= r && c < nb) ? A[tri_off(kb + r) + kb + c] : (c == r ? 1.0 : 0.0);
-            bool ok = true;
-            double dinv[STEP_NB];
-            DiagCol<0>::run(a, dinv, r, ok);
-            // inverse: lane c computes column c of X = L^-1
-            double x[STEP_NB];
-#pragma unroll
-            for (int q = 0; q < STEP_NB; ++q) x[q] = 0.0;
-            const int cc = lane & 7;
-            InvRow<0>::run(a, dinv, x, cc);
-            if (lane < STEP_NB) {
-#pragma unroll
-                for (int c = 0; c < STEP_NB; ++c) {
-                    if (lane < nb && c <= lane && c < nb) A[tri_off(kb + lane) + kb + c] = a[c];
-                }
-#pragma unroll
-                for (int rr = 0; rr < STEP_NB; ++rr) s.X[blk * 64 + rr * 8 + lane] = x[rr];   // X[rr][cc]
-            }
-            if (lane == 0) s.ok = ok ? 1 : 0;
-        }
-        __syncthreads();
-        CSTAMP(0);
-        if (!s.ok) return false;
-        // ---- 2. panel: rows below the block (incl. rhs row), L_i = A_i X^T ------------------------
+        const int Kt = kb >> 4, ko = kb & 15;
+        // ---- 1. diagonal 4x4 block, redundantly per thread (identity padding for a short last block) ----------
+        const int db = tl_base(Kt, Kt) + (ko << 4) + ko;
+        double d00 = A[db], d10 = 0, d11 = 1, d20 = 0, d21 = 0, d22 = 1, d30 = 0, d31 = 0, d32 = 0, d33 = 1;
+        if (nb > 1) { d10 = A[db + 16]; d11 = A[db + 17]; }
+        if (nb > 2) { d20 = A[db + 32]; d21 = A[db + 33]; d22 = A[db + 34]; }
+        if (nb > 3) { d30 = A[db + 48]; d31 = A[db + 49]; d32 = A[db + 50]; d33 = A[db + 51]; }
+        double l00, r0_, l11, r1_, l22, r2_, l33, r3_;
+        bool ok = d00 > 0.0 && isfinite(d00);
+        sqrt_rsqrt(d00, l00, r0_);
+        const double l10 = d10 * r0_, l20 = d20 * r0_, l30 = d30 * r0_;
+        d11 -= l10 * l10; ok = ok && d11 > 0.0 && isfinite(d11);
+        sqrt_rsqrt(d11, l11, r1_);
+        const double l21 = (d21 - l20 * l10) * r1_, l31 = (d31 - l30 * l10) * r1_;
+        d22 -= l20 * l20 + l21 * l21; ok = ok && d22 > 0.0 && isfinite(d22);
+        sqrt_rsqrt(d22, l22, r2_);
+        const double l32 = (d32 - l30 * l20 - l31 * l21) * r2_;
+        d33 -= l30 * l30 + l31 * l31 + l32 * l32; ok = ok && d33 > 0.0 && isfinite(d33);
+        sqrt_rsqrt(d33, l33, r3_);
+        if (!ok) return false;          // identical data in every thread: uniform exit
+        // ---- 2. panel rows (incl. the rhs row): forward substitution against the block ----------------------------
         const int r0 = kb + nb;
         for (int i = r0 + t; i < R; i += NT) {
-            double a[STEP_NB], o[STEP_NB];
-            const int base = tri_off(i) + kb;
-#pragma unroll
-            for (int c = 0; c < STEP_NB; ++c) a[c] = c < nb ? A[base + c] : 0.0;
-#pragma unroll
-            for (int c = 0; c < STEP_NB; ++c) { double v = 0;
-#pragma unroll
-                for (int k = 0; k <= c; ++k) v += a[k] * s.X[blk * 64 + c * 8 + k]; o[c] = v; }
-#pragma unroll
-            for (int c = 0; c < STEP_NB; ++c) if (c < nb) A[base + c] = o[c];
+            const int base = tl_base(i >> 4, Kt) + ((i & 15) << 4) + ko;
+            const double a0 = A[base], a1 = nb > 1 ? A[base + 1] : 0.0, a2 = nb > 2 ? A[base + 2] : 0.0, a3 = nb > 3 ? A[base + 3] : 0.0;
+            const double x0 = a0 * r0_;
+            const double x1 = (a1 - x0 * l10) * r1_;
+            const double x2 = (a2 - x0 * l20 - x1 * l21) * r2_;
+            const double x3 = (a3 - x0 * l30 - x1 * l31 - x2 * l32) * r3_;
+            A[base] = x0; if (nb > 1) A[base + 1] = x1; if (nb > 2) A[base + 2] = x2; if (nb > 3) A[base + 3] = x3;
+        }
+        if (t == 0) {                   // the factored block itself and the reciprocal pivots
+            A[db] = l00; s.dinv[kb] = r0_;
+            if (nb > 1) { A[db + 16] = l10; A[db + 17] = l11; s.dinv[kb + 1] = r1_; }
+            if (nb > 2) { A[db + 32] = l20; A[db + 33] = l21; A[db + 34] = l22; s.dinv[kb + 2] = r2_; }
+            if (nb > 3) { A[db + 48] = l30; A[db + 49] = l31; A[db + 50] = l32; A[db + 51] = l33; s.dinv[kb + 3] = r3_; }
         }
         __syncthreads();
-        CSTAMP(1);
-        // ---- 3. trailing update on the fp64 matrix cores: C[r][c] -= sum_k L[r][kb+k] L[c][kb+k] -----
-        const int rem = R - r0;                // rows r0 .. D (rhs row included)
-        if (rem > 0) {
-            const int nt = (rem + 15) >> 4;
-            const int ntile = nt * (nt + 1) / 2;
-            // software-pipelined over up to 8 tiles per wave: all operand loads, then the MFMAs, then the read-modify-writes
+        // ---- 3. trailing update on the fp64 matrix cores: C[r][c] -= sum_{k<4} L[r][kb+k] L[c][kb+k], r, c >= r0 ------
+        if (r0 < R) {
+            const int I0 = r0 >> 4, n = T - I0;
+            const int ntile = n * (n + 1) / 2;
+            const bool kk = (lane >> 4) < nb;
             for (int t0 = 0; t0 < ntile; t0 += 8 * NW) {
-                d4 acc[8]; double av[8][2], bv[8][2]; int rowb[8], colb[8];
+                d4 acc[8]; double av[8], bv[8]; int cb[8];
                 const int cnt = min(8, (ntile - t0 - wave + NW - 1) / NW);   // wave-uniform number of live slots
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (u < cnt) {
                     const int tile = t0 + wave + u * NW;
-                    int I = (int)((sqrtf(8.f * (float)tile + 1.f) - 1.f) * 0.5f);
-                    if (((I + 1) * (I + 2)) / 2 <= tile) ++I;
-                    if ((I * (I + 1)) / 2 > tile) --I;
-                    const int J = tile - (I * (I + 1)) / 2;
-                    const bool valid = tile < ntile;
-                    rowb[u] = valid ? r0 + 16 * I : R; colb[u] = valid ? r0 + 16 * J : D;
-                    const int rr = rowb[u] + (lane & 15), cr = colb[u] + (lane & 15);
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int k = 4 * h + (lane >> 4);
-                        av[u][h] = (rr < R && k < nb) ? A[tri_off(rr) + kb + k] : 0.0;
-                        bv[u][h] = (cr < D && k < nb) ? A[tri_off(cr) + kb + k] : 0.0;
-                    }
+                    const int I = I0 + s.tI[tile], J = I0 + s.tJ[tile];
+                    cb[u] = tl_base(I, J);
+                    const int rr = (I << 4) + (lane & 15), cr = (J << 4) + (lane & 15);
+                    av[u] = (rr >= r0 && rr < R && kk) ? A[tl_base(I, Kt) + la + ko] : 0.0;
+                    bv[u] = (cr >= r0 && cr < D && kk) ? A[tl_base(J, Kt) + la + ko] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) if (u < cnt) { d4 z = {0.0, 0.0, 0.0, 0.0}; acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][0], bv[u][0], z, 0, 0, 0); }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) if (u < cnt) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][1], bv[u][1], acc[u], 0, 0, 0);
+                for (int u = 0; u < 8; ++u) if (u < cnt) { d4 z = {0.0, 0.0, 0.0, 0.0}; acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], z, 0, 0, 0); }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (u < cnt) {
-                    const int col = colb[u] + (lane & 15);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int row = rowb[u] + (lane >> 4) + 4 * g;
-                        if (row < R && col < D && col <= row) A[tri_off(row) + col] -= acc[u][g];
-                    }
+                    for (int g = 0; g < 4; ++g) A[cb[u] + lc + (g << 6)] -= acc[u][g];   // rows / cols outside [r0, R) got zero operands
                 }
             }
         }
         __syncthreads();
-        CSTAMP(2);
     }
-    if (threadIdx.x == 0) { s.tacc[0] = tacc[0]; s.tacc[1] = tacc[1]; s.tacc[2] = tacc[2]; }
     return true;
 }
 
-// back substitution L^T x = y (y = row D of A), blocked; result in s.y[0..D)
+// back substitution L^T x = y (y = row D of A): per 4x4 block every thread solves the block redundantly, the threads
+// owning a column c < kb fold x_blk into y_c; one barrier per block.  Result in s.y[0..D).
 template <class PTR>
 __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
     const int t = threadIdx.x, NT = blockDim.x;
-    for (int i = t; i < D; i += NT) s.y[i] = A[tri_off(D) + i];
+    for (int i = t; i < D; i += NT) s.y[i] = A[tl_idx(D, i)];
     __syncthreads();
     const int nblk = (D + STEP_NB - 1) / STEP_NB;
     for (int blk = nblk - 1; blk >= 0; --blk) {
         const int kb = blk * STEP_NB, nb = min(STEP_NB, D - kb);
-        // x_blk = X^T y_blk
-        double xv = 0.0;
-        if (t < nb) { for (int k = t; k < nb; ++k) xv += s.X[blk * 64 + k * 8 + t] * s.y[kb + k]; }
-        __syncthreads();
-        if (t < nb) s.y[kb + t] = xv;
-        __syncthreads();
-        // y_c -= sum_r L[kb+r][c] x_r  for c < kb
-        for (int c = t; c < kb; c += NT) {
-            double v = s.y[c];
-            for (int r = 0; r < nb; ++r) v -= A[tri_off(kb + r) + c] * s.y[kb + r];
-            s.y[c] = v;
+        const int db = tl_base(kb >> 4, kb >> 4) + ((kb & 15) << 4) + (kb & 15);
+        const double y0 = s.y[kb], y1 = nb > 1 ? s.y[kb + 1] : 0.0, y2 = nb > 2 ? s.y[kb + 2] : 0.0, y3 = nb > 3 ? s.y[kb + 3] : 0.0;
+        const double r0_ = s.dinv[kb], r1_ = nb > 1 ? s.dinv[kb + 1] : 1.0, r2_ = nb > 2 ? s.dinv[kb + 2] : 1.0, r3_ = nb > 3 ? s.dinv[kb + 3] : 1.0;
+        const double l10 = nb > 1 ? A[db + 16] : 0.0, l20 = nb > 2 ? A[db + 32] : 0.0, l21 = nb > 2 ? A[db + 33] : 0.0;
+        const double l30 = nb > 3 ? A[db + 48] : 0.0, l31 = nb > 3 ? A[db + 49] : 0.0, l32 = nb > 3 ? A[db + 50] : 0.0;
+        const double x3 = y3 * r3_;
+        const double x2 = (y2 - l32 * x3) * r2_;
+        const double x1 = (y1 - l21 * x2 - l31 * x3) * r1_;
+        const double x0 = (y0 - l10 * x1 - l20 * x2 - l30 * x3) * r0_;
+        if (t == 0) { s.xs[kb] = x0; if (nb > 1) s.xs[kb + 1] = x1; if (nb > 2) s.xs[kb + 2] = x2; if (nb > 3) s.xs[kb + 3] = x3; }
+        for (int c = t; c < kb; c += NT) {              // y_c -= sum_r L[kb+r][c] x_r
+            const int base = tl_base(kb >> 4, c >> 4) + ((kb & 15) << 4) + (c & 15);
+            double v0 = s.y[c] - A[base] * x0, v1 = 0.0;
+            if (nb > 1) v1 -= A[base + 16] * x1;
+            if (nb > 2) v0 -= A[base + 32] * x2;
+            if (nb > 3) v1 -= A[base + 48] * x3;
+            s.y[c] = v0 + v1;
         }
         __syncthreads();
     }
+    for (int i = t; i < D; i += NT) s.y[i] = s.xs[i];
+    __syncthreads();
 }
 
 }  // namespace vd
@@ -371,6 +328,25 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     const double* x = P.x[cur];
     double* xc = P.x[1 - cur];
     if (s.c.done) { if (t == 0) *P.ctl = s.c; return; }
+    // prefetch this thread's share of S' (tiled order) so that the global latency hides behind the vector passes
+    double pf[PF_N];
+    if (PHASE != 2 && s.need) {
+        const int R = D + 1, T = (R + 15) >> 4, NTL = (tri_off(T)) << 8;
+#pragma unroll
+        for (int u = 0; u < PF_N; ++u) {
+            const int e = t + u * VIL_STEP_THREADS;
+            pf[u] = 0.0;
+            if (e < NTL) {
+                const int tile = e >> 8, w = e & 255;
+                int I = (int)((sqrtf(8.f * (float)tile + 1.f) - 1.f) * 0.5f);
+                if (((I + 1) * (I + 2)) / 2 <= tile) ++I;
+                if ((I * (I + 1)) / 2 > tile) --I;
+                const int J = tile - (I * (I + 1)) / 2;
+                const int i = (I << 4) + (w >> 4), j = (J << 4) + (w & 15);
+                if (i < D && j <= i) pf[u] = sb.S[(size_t)i * D + j];
+            }
+        }
+    }
     STAMP(1);
     double gn2 = 0, g2 = 0, gg = 0;
     if (PHASE != 2 && s.need) {
@@ -405,44 +381,52 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         STAMP(10);
         // ---- camera share of u^T H u, fused with packing M = Sc S' Sc + mu dc^2 (+ rhs row) into LDS ------------
         const double mu = s.c.mu;
-        const int NL = tri_off(D);            // packed lower entries of rows 0..D-1 ; row D (rhs) follows
+        // tiled storage: element e of the tile array -> (i, j); S entries were prefetched into registers at kernel start
         double* Ag = P.M;
-        for (int base = t; base < NL; base += 8 * NT) {
-            double v[8];
+        const int R = D + 1, T = (R + 15) >> 4, NTL = (tri_off(T)) << 8;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * NT;
-                if (idx < NL) {
-                    int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-                    while (tri_off(i + 1) <= idx) ++i;
-                    while (tri_off(i) > idx) --i;
-                    v[u] = sb.S[(size_t)i * D + (idx - tri_off(i))];
-                } else v[u] = 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * NT;
-                if (idx < NL) {
-                    int i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-                    while (tri_off(i + 1) <= idx) ++i;
-                    while (tri_off(i) > idx) --i;
-                    const int j = idx - tri_off(i);
-                    if (cam) q += (i == j ? 1.0 : 2.0) * s.y[i] * v[u] * s.y[j];
-                    double m = s.sc[i] * v[u] * s.sc[j];
+        for (int u = 0; u < PF_N; ++u) {
+            const int e = t + u * VIL_STEP_THREADS;
+            if (e < NTL) {
+                const int tile = e >> 8, w = e & 255;
+                int I = (int)((sqrtf(8.f * (float)tile + 1.f) - 1.f) * 0.5f);
+                if (((I + 1) * (I + 2)) / 2 <= tile) ++I;
+                if ((I * (I + 1)) / 2 > tile) --I;
+                const int J = tile - (I * (I + 1)) / 2;
+                const int i = (I << 4) + (w >> 4), j = (J << 4) + (w & 15);
+                double m = 0.0;
+                if (i < D && j <= i) {
+                    const double v = pf[u];
+                    if (cam) q += (i == j ? 1.0 : 2.0) * s.y[i] * v * s.y[j];
+                    m = s.sc[i] * v * s.sc[j];
                     if (i == j) m += mu * s.dcs[i] * s.dcs[i];
-                    if constexpr (LDSM) Alds[idx] = m; else Ag[idx] = m;
-                }
+                } else if (i == D && j < D) m = s.sc[j] * sb.gred[j];
+                if constexpr (LDSM) Alds[e] = m; else Ag[e] = m;
             }
         }
+        for (int e = t + PF_N * VIL_STEP_THREADS; e < NTL; e += VIL_STEP_THREADS) {     // large windows (K > 10): remainder, direct loads
+            const int tile = e >> 8, w = e & 255;
+            int I = (int)((sqrtf(8.f * (float)tile + 1.f) - 1.f) * 0.5f);
+            if (((I + 1) * (I + 2)) / 2 <= tile) ++I;
+            if ((I * (I + 1)) / 2 > tile) --I;
+            const int J = tile - (I * (I + 1)) / 2;
+            const int i = (I << 4) + (w >> 4), j = (J << 4) + (w & 15);
+            double m = 0.0;
+            if (i < D && j <= i) {
+                const double v = sb.S[(size_t)i * D + j];
+                if (cam) q += (i == j ? 1.0 : 2.0) * s.y[i] * v * s.y[j];
+                m = s.sc[i] * v * s.sc[j];
+                if (i == j) m += mu * s.dcs[i] * s.dcs[i];
+            } else if (i == D && j < D) m = s.sc[j] * sb.gred[j];
+            if constexpr (LDSM) Alds[e] = m; else Ag[e] = m;
+        }
         STAMP(11);
-        for (int j = t; j < D; j += NT) { const double m = s.sc[j] * sb.gred[j]; if constexpr (LDSM) Alds[NL + j] = m; else Ag[NL + j] = m; }
         bsum3<true>(g2, q, gm, s);
         STAMP(2);
         if (PHASE == 0 && gm <= O.gradient_tolerance) { if (t == 0) { s.c.done = 1; s.c.term = 2; *P.ctl = s.c; } return; }
         bool ok;
         if constexpr (LDSM) ok = chol_blocked(Alds, D, s); else ok = chol_blocked(Ag, D, s);
         STAMP(3);
-        if (t == 0) { P.dbg[20] = s.tacc[0]; P.dbg[21] = s.tacc[1]; P.dbg[22] = s.tacc[2]; }
         if (!ok) {
             // dogleg_strategy.cc: mu *= 10 and retry; the Schur pivots depend on mu, so re-sweep at x_cur
             if (t == 0) {

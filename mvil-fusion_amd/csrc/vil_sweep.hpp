@@ -452,7 +452,15 @@ __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
     const int NL = (D * (D + 1)) >> 1;
     const int nSblk = (NL + RED_EPW - 1) / RED_EPW;
     __shared__ double part[2][8][RED_EPW];
+    __shared__ int tab[64 + 48 + 2 * 66];      // imu (i, j) pairs | ICP/LPS pose ids (4 per factor) | LiDAR chunk ranges per pose
+    int* t_imu = tab; int* t_rel = tab + 64; int* t_lch = tab + 112;
     if ((int)blockIdx.x < nSblk) {
+        if (P.skip_mask & 32) return;
+        // stage the small index tables once per workgroup
+        if (t < 2 * P.n_imu && t < 64) t_imu[t] = (t & 1) ? P.imu_j[t >> 1] : P.imu_i[t >> 1];
+        if (t >= 64 && t < 64 + 4 * n_rel) { const int q = t - 64, f = q >> 2, b = q & 3; t_rel[q] = f < P.n_icp ? P.icp_ids[4 * f + b] : (b < 2 ? P.lps_ids[2 * (f - P.n_icp) + b] : -1); }
+        if (t >= 128 && t < 128 + 2 * (K + 1) && t < 128 + 132) t_lch[t - 128] = P.lchunk_pose[t - 128];
+        __syncthreads();
         const int el = t & (RED_EPW - 1), slice = t >> 5;
         const int idx = blockIdx.x * RED_EPW + el;
         int i = 0, j = 0;
@@ -472,64 +480,82 @@ __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
                 if (i == j) vdg += P.vpart[(size_t)w * P.VP + P.NVT + 2 * NV + i];
             }
         }
-        part[0][slice][el] = vs; part[1][slice][el] = vdg;
-        __syncthreads();
-        if (slice != 0 || !ok) return;
-        double s = 0.0, vd_ = 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { s += part[0][q][el]; vd_ += part[1][q][el]; }
-        const double vsum = s;
-        if (j < NV) {
-            if (j < 6 * K && i / 6 == j / 6) {   // LiDAR points: pose-diagonal blocks
+        // the non-visual contributions are spread over the 8 slices of an entry
+        double ms = 0.0;
+        if (ok) {
+            if (slice == 1 && j < 6 * K && i / 6 == j / 6) {   // LiDAR plane points: pose-diagonal blocks
                 const int k = i / 6, a = i - 6 * k, b = j - 6 * k;
                 const int li = a * 6 - ((a * (a - 1)) >> 1) + (b - a);
-                for (int c = P.lchunk_pose[k]; c < P.lchunk_pose[k + 1]; ++c) s += P.lpart[(size_t)c * 28 + li];
-                for (int c = P.lchunk_pose[K + 1 + k]; c < P.lchunk_pose[K + 2 + k]; ++c) s += P.lpart[(size_t)(P.n_pchunk + c) * 28 + li];
+                for (int c = t_lch[k]; c < t_lch[k + 1]; ++c) ms += P.lpart[(size_t)c * 28 + li];
             }
-            if (j < 6 * K) {                    // ICP / LPS blocks live on pose columns
-                for (int f = 0; f < n_rel; ++f) {
-                    const bool icp = f < P.n_icp;
-                    const int* id = icp ? P.icp_ids + 4 * f : P.lps_ids + 2 * (f - P.n_icp);
-                    const int nb = icp ? 4 : 2;
-                    const int pi = i / 6, pj = j / 6;
-                    for (int ba = 0; ba < nb; ++ba) if (id[ba] == pi) for (int bb = 0; bb < nb; ++bb) if (id[bb] == pj)
-                        s += rel0[(size_t)f * 601 + (ba * 6 + i % 6) * 24 + bb * 6 + j % 6];
+            if (slice == 2 && j < 6 * K && i / 6 == j / 6) {   // LiDAR edge points
+                const int k = i / 6, a = i - 6 * k, b = j - 6 * k;
+                const int li = a * 6 - ((a * (a - 1)) >> 1) + (b - a);
+                for (int c = t_lch[K + 1 + k]; c < t_lch[K + 2 + k]; ++c) ms += P.lpart[(size_t)(P.n_pchunk + c) * 28 + li];
+            }
+            if (slice == 3 && j < 6 * K) {                     // ICP / LPS blocks live on pose columns
+                const int pi = i / 6, pj = j / 6, ri = i - 6 * pi, rj = j - 6 * pj;
+                for (int f = 0; f < n_rel; ++f)
+                    for (int ba = 0; ba < 4; ++ba) if (t_rel[4 * f + ba] == pi) for (int bb = 0; bb < 4; ++bb) if (t_rel[4 * f + bb] == pj)
+                        ms += rel0[(size_t)f * 601 + (ba * 6 + ri) * 24 + bb * 6 + rj];
+            }
+            if (slice == 4 || slice == 5) {                    // IMU blocks, two slices split the factors
+                for (int f = slice - 4; f < P.n_imu; f += 2) {
+                    const int la = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], i);
+                    if (la < 0) continue;
+                    const int lb = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], j);
+                    if (lb >= 0) ms += P.ipart[(size_t)f * 931 + la * 30 + lb];
                 }
             }
+            if (slice == 6 && P.pn > 0) { const int pi = P.pinv[i], pj = P.pinv[j]; if (pi >= 0 && pj >= 0) ms += P.pH[(size_t)pi * P.pn + pj]; }
         }
-        for (int f = 0; f < P.n_imu; ++f) {
-            const int la = imu_local(P, P.imu_i[f], P.imu_j[f], i);
-            if (la < 0) continue;
-            const int lb = imu_local(P, P.imu_i[f], P.imu_j[f], j);
-            if (lb >= 0) s += P.ipart[(size_t)f * 931 + la * 30 + lb];
-        }
-        if (P.pn > 0) { const int pi = P.pinv[i], pj = P.pinv[j]; if (pi >= 0 && pj >= 0) s += P.pH[(size_t)pi * P.pn + pj]; }
+        part[0][slice][el] = vs + ms; part[1][slice][el] = vdg - vs;     // [1]: un-reduced minus reduced visual diagonal
+        __syncthreads();
+        if (slice != 0 || !ok) return;
+        double s = 0.0, dd = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s += part[0][q][el]; dd += part[1][q][el]; }
         sb.S[(size_t)i * D + j] = s;
         sb.S[(size_t)j * D + i] = s;
-        if (i == j) sb.diag[i] = s + (i < NV ? vd_ - vsum : 0.0);   // un-reduced diagonal: add back the Schur term of the visual part
+        if (i == j) sb.diag[i] = s + (i < NV ? dd : 0.0);   // un-reduced diagonal: add back the Schur term of the visual part
         return;
     }
-    // ---- vectors + cost (one workgroup) --------------------------------------------------------------
-    __shared__ double red[8];
-    for (int i = t; i < D; i += VIL_THREADS) {
-        double bc = 0.0, gr = 0.0;
-        if (i < NV) for (int w = 0; w < P.n_vwg; ++w) { bc += P.vpart[(size_t)w * P.VP + P.NVT + i]; gr += P.vpart[(size_t)w * P.VP + P.NVT + NV + i]; }
-        double o = 0.0;
-        if (i < 6 * K) {
-            const int k = i / 6, a = i - 6 * k;
-            for (int c = P.lchunk_pose[k]; c < P.lchunk_pose[k + 1]; ++c) o += P.lpart[(size_t)c * 28 + 21 + a];
-            for (int c = P.lchunk_pose[K + 1 + k]; c < P.lchunk_pose[K + 2 + k]; ++c) o += P.lpart[(size_t)(P.n_pchunk + c) * 28 + 21 + a];
-            for (int f = 0; f < n_rel; ++f) {
-                const bool icp = f < P.n_icp;
-                const int* id = icp ? P.icp_ids + 4 * f : P.lps_ids + 2 * (f - P.n_icp);
-                const int nb = icp ? 4 : 2;
-                for (int ba = 0; ba < nb; ++ba) if (id[ba] == k) o += rel0[(size_t)f * 601 + 576 + ba * 6 + a];
+    // ---- gradient vectors bc / gred: 2D entries, same 8-slice scheme -------------------------------------------------
+    const int nVblk = (2 * D + RED_EPW - 1) / RED_EPW;
+    if ((int)blockIdx.x < nSblk + nVblk) {
+        if (P.skip_mask & 64) return;
+        if (t < 2 * P.n_imu && t < 64) t_imu[t] = (t & 1) ? P.imu_j[t >> 1] : P.imu_i[t >> 1];
+        if (t >= 64 && t < 64 + 4 * n_rel) { const int q = t - 64, f = q >> 2, b = q & 3; t_rel[q] = f < P.n_icp ? P.icp_ids[4 * f + b] : (b < 2 ? P.lps_ids[2 * (f - P.n_icp) + b] : -1); }
+        if (t >= 128 && t < 128 + 2 * (K + 1) && t < 128 + 132) t_lch[t - 128] = P.lchunk_pose[t - 128];
+        __syncthreads();
+        const int el = t & (RED_EPW - 1), slice = t >> 5;
+        const int v = ((int)blockIdx.x - nSblk) * RED_EPW + el;
+        const bool ok = v < 2 * D;
+        const int which = v >= D ? 1 : 0, i = which ? v - D : v;       // 0: bc, 1: gred
+        double acc = 0.0;
+        if (ok) {
+            if (i < NV) for (int w = slice; w < P.n_vwg; w += 8) acc += P.vpart[(size_t)w * P.VP + P.NVT + which * NV + i];
+            if (i < 6 * K) {
+                const int k = i / 6, a = i - 6 * k;
+                if (slice == 1) for (int c = t_lch[k]; c < t_lch[k + 1]; ++c) acc += P.lpart[(size_t)c * 28 + 21 + a];
+                if (slice == 2) for (int c = t_lch[K + 1 + k]; c < t_lch[K + 2 + k]; ++c) acc += P.lpart[(size_t)(P.n_pchunk + c) * 28 + 21 + a];
+                if (slice == 3) for (int f = 0; f < n_rel; ++f) for (int ba = 0; ba < 4; ++ba) if (t_rel[4 * f + ba] == k) acc += rel0[(size_t)f * 601 + 576 + ba * 6 + a];
             }
+            if (slice == 4 || slice == 5) for (int f = slice - 4; f < P.n_imu; f += 2) { const int la = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], i); if (la >= 0) acc += P.ipart[(size_t)f * 931 + 900 + la]; }
+            if (slice == 6 && P.pn > 0) { const int pi = P.pinv[i]; if (pi >= 0) acc += P.mpart[pi]; }
         }
-        for (int f = 0; f < P.n_imu; ++f) { const int la = imu_local(P, P.imu_i[f], P.imu_j[f], i); if (la >= 0) o += P.ipart[(size_t)f * 931 + 900 + la]; }
-        if (P.pn > 0) { const int pi = P.pinv[i]; if (pi >= 0) o += P.mpart[pi]; }
-        sb.bc[i] = bc + o; sb.gred[i] = gr + o;
+        part[0][slice][el] = acc;
+        __syncthreads();
+        if (slice != 0 || !ok) return;
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum += part[0][q][el];
+        (which ? sb.gred : sb.bc)[i] = sum;
+        return;
     }
+    // ---- cost (one workgroup, tree reduction) ---------------------------------------------------------------------
+    __shared__ double red[8];
+    if (P.skip_mask & 64) return;
     double c = 0.0;
     for (int w = t; w < P.n_vwg; w += VIL_THREADS) c += P.vpart[(size_t)w * P.VP + P.NVT + 3 * NV];
     for (int q = t; q < P.n_pchunk + P.n_echunk; q += VIL_THREADS) c += P.lpart[(size_t)q * 28 + 27];

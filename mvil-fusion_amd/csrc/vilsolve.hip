@@ -81,8 +81,8 @@ struct vil_ctx {
     bool split = false;            // step kernel launched as A | all-reduce | B
     int lm_b = 0, lm_e = 0;        // owned landmark range
     bool profiling = false;
-    std::vector<hipEvent_t> ev;
-    vil_profile prof = {0, 0.0, 0, 0.0};
+    std::vector<hipEvent_t> ev, ev_mid;
+    vil_profile prof = {0, 0.0, 0, 0.0, 0.0};
 };
 
 static SolveOpts to_dev_opts(const vil_options* o) {
@@ -157,6 +157,7 @@ void vil_destroy(vil_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& e : c->ev) hipEventDestroy(e);
+    for (auto& e : c->ev_mid) hipEventDestroy(e);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->ar.d) hipFree(c->ar.d);
     if (c->d_status) hipFree(c->d_status);
@@ -169,7 +170,7 @@ void vil_destroy(vil_ctx* c) {
 static int validate(const vil_problem* p, const vil_state* s) {
     if (!p || !s) return VIL_ERR_INVALID_ARGUMENT;
     if (p->K < 2 || p->L < 0 || s->K != p->K || s->L != p->L) return VIL_ERR_INVALID_ARGUMENT;
-    if (15 * p->K + 7 > 512) return VIL_ERR_UNSUPPORTED;
+    if (15 * p->K + 7 > 320) return VIL_ERR_UNSUPPORTED;   // K <= 20 (step kernel work space)
     if (p->n_icp + p->n_lps > 12 || p->n_icp < 0 || p->n_lps < 0) return VIL_ERR_UNSUPPORTED;   // reference trims to 5 + 7 (estimator.cpp:1283-1286,1345-1348)
     if (p->prior.n > 512 || p->prior.nblk > 256) return VIL_ERR_UNSUPPORTED;
     for (int f = 0; f < p->n_vis; ++f) {
@@ -352,9 +353,9 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     if (c->lds_sweep < 8 * 2048) c->lds_sweep = 8 * 2048;
     if (c->lds_sweep > 160 * 1024) return VIL_ERR_UNSUPPORTED;
     HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep));
-    c->n_blocks_reduce = (D * (D + 1) / 2 + RED_EPW - 1) / RED_EPW + 1;
-    c->lds_step = 8 * (size_t)(D + 1) * (D + 2) / 2;
-    c->step_lds = c->lds_step + sizeof(vd::StepShared) + 1024 <= 160 * 1024;
+    c->n_blocks_reduce = (D * (D + 1) / 2 + RED_EPW - 1) / RED_EPW + (2 * D + RED_EPW - 1) / RED_EPW + 1;
+    { const size_t T = (size_t)(D + 1 + 15) / 16; c->lds_step = 8 * 256 * (T * (T + 1) / 2); }   // 16x16-tiled lower storage incl. the rhs row
+    c->step_lds = c->lds_step + sizeof(vd::StepShared) + 256 <= 160 * 1024;
     if (c->step_lds) {
         HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
         HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
@@ -408,8 +409,9 @@ static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
     hipLaunchKernelGGL(k_sweep, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, c->P, so);
     return VIL_OK;
 }
-static void launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step) {
+static void launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr) {
     hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce), dim3(VIL_THREADS), 0, c->stream, c->P);
+    if (ev_mid) hipEventRecord(ev_mid, c->stream);
     if (!step) return;
     if (!c->split) {
         if (c->step_lds) hipLaunchKernelGGL((k_step<true, 0>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
@@ -437,14 +439,14 @@ static int init_ctl(vil_ctx* c, const vil_options* o, int lin_mode) {
 int vil_profile_enable(vil_ctx* c, int on) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(c->device));
-    if (on && c->ev.empty()) { c->ev.resize(32); for (auto& e : c->ev) HIPCHK(hipEventCreate(&e)); }
+    if (on && c->ev.empty()) { c->ev.resize(32); for (auto& e : c->ev) HIPCHK(hipEventCreate(&e)); c->ev_mid.resize(16); for (auto& e : c->ev_mid) HIPCHK(hipEventCreate(&e)); }
     c->profiling = on != 0;
     return VIL_OK;
 }
 int vil_profile_read(vil_ctx* c, vil_profile* out, int reset) {
     if (!c || !out) return VIL_ERR_INVALID_ARGUMENT;
     *out = c->prof;
-    if (reset) c->prof = vil_profile{0, 0.0, 0, 0.0};
+    if (reset) c->prof = vil_profile{0, 0.0, 0, 0.0, 0.0};
     return VIL_OK;
 }
 
@@ -481,7 +483,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
             if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q], c->stream));
             launch_sweep(c, so);
             if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q + 1], c->stream));
-            launch_reduce_step(c, so, true);
+            launch_reduce_step(c, so, true, c->profiling ? c->ev_mid[q] : nullptr);
         }
         if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * launched], c->stream));
         HIPCHK(hipMemcpyAsync(c->h_ctl, c->P.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
@@ -494,6 +496,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
                 float ms = 0.f;
                 HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * q], c->ev[2 * q + 1])); c->prof.sweep_ms += ms; c->prof.sweep_launches++;
                 HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * q + 1], c->ev[2 * q + 2])); c->prof.step_ms += ms; c->prof.step_launches++;
+                HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * q + 1], c->ev_mid[q])); c->prof.reduce_ms += ms;
             }
         }
         if (!finished && o->max_time_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= o->max_time_s) {

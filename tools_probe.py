@@ -16,7 +16,7 @@ t0=time.perf_counter(); its=0
 for _ in range(20): be.reset_state(); s=be.solve_resident(opts); its+=s.iterations
 el=time.perf_counter()-t0
 be.lib.vil_profile_read(be.ctx, C.byref(prof), 1)
-print("cfg", cfg, "skip", os.environ.get("VIL_SKIP"), "vwg", os.environ.get("VIL_VWG"), "it/s %.0f"%(its/el), "iters", s.iterations, "sweep_us %.1f"%(1e3*prof.sweep_ms/max(1,prof.sweep_launches)), "reduce+step_us %.1f"%(1e3*prof.step_ms/max(1,prof.step_launches)))
+print("cfg", cfg, "skip", os.environ.get("VIL_SKIP"), "vwg", os.environ.get("VIL_VWG"), "it/s %.0f"%(its/el), "iters", s.iterations, "sweep_us %.1f"%(1e3*prof.sweep_ms/max(1,prof.sweep_launches)), "reduce+step_us %.1f"%(1e3*prof.step_ms/max(1,prof.step_launches)), "reduce_us %.1f"%(1e3*prof.reduce_ms/max(1,prof.step_launches)))
 dbg = (C.c_longlong*64)(); be.lib.vil_debug_read(be.ctx, dbg)
 d = np.array(dbg[:12], dtype=np.int64); print("raw", (d-d[0]).tolist()); print("chol phases diag/panel/update cycles:", list(dbg[20:23]))
 print("step stamps (cycles, deltas):", np.diff(d).tolist())
