@@ -50,6 +50,8 @@ struct DevP {
     const double* vis_c; const int* vis_i; const int* vis_j; const int* vis_l;
     const int* lm_start;      // L+1
     const int* vchunk;        // n_vchunk x 2 landmark ranges
+    const int* lm_acol;       // L   reduced column of the anchor pose (6 * start_frame), -1 if the landmark has no factor
+    const int* fcol;          // F   reduced column of the observing pose of each factor (6 * vis_j)
     // LiDAR points, sorted by pose; chunk = (start, count, pose)
     int n_plane, pl_stride, n_pchunk; const double* pl_c; const int* pchunk;
     int n_edge, ed_stride, n_echunk; const double* ed_c; const int* echunk;

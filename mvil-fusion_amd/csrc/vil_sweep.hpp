@@ -99,7 +99,12 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
     int* fj = (int*)(red + 8);                         // VIL_VCHUNK_F observer frames
     int* lms = fj + VIL_VCHUNK_F;                      // VIL_VCHUNK_LM + 1 chunk-local factor offsets
     int* lanc = lms + VIL_VCHUNK_LM + 1;               // VIL_VCHUNK_LM anchor frames
+    int* fl = lanc + VIL_VCHUNK_LM;                    // VIL_VCHUNK_F factor -> chunk-local landmark
+#ifdef VIL_STAMPS
     #define VSTAMP(k) do { __syncthreads(); if (t == 0 && wg == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[32 + k] = tt_; } } while (0)
+#else
+    #define VSTAMP(k) do {} while (0)
+#endif
     VSTAMP(0);
     for (int e = t; e < NVT + 3 * NV; e += blockDim.x) tri[e] = 0.0;
     const bool exc = P.ex_const != 0, tdc = !P.td_free;
@@ -132,7 +137,7 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             w[36] = tdc ? 0.0 : sr * o.Jt[0]; w[37] = tdc ? 0.0 : sr * o.Jt[1];
             w[38] = cl ? 0.0 : sr * o.Jl[0]; w[39] = cl ? 0.0 : sr * o.Jl[1];
             w[40] = sr * o.r[0]; w[41] = sr * o.r[1];
-            fj[t] = j;
+            fj[t] = j; fl[t] = l - l0;
             // observer-pose pieces that need no landmark-level sum
             for (int k = 0; k < 6; ++k) {
                 const double j0 = w[12 + k], j1 = w[18 + k];
@@ -187,49 +192,28 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
         }
         __syncthreads();
         VSTAMP(3);
-        // ---- tri += sum_f Jc^T Jc - invp e e^T : one work item = (landmark, group pair, row of the 6x6 block);
-        //      different landmarks may hit the same entry -> LDS atomic add (ds_add_f64)
+        // ---- tri += sum_f Jc^T Jc - invp e e^T, in three passes whose work items have (nearly) uniform trip counts
+        //      inside a wave (divergent loops cost the maximum over the lanes).  Groups: A = anchor pose, X = extrinsic,
+        //      T = td (shared by all factors of the landmark), O_f = observing pose of factor f.
         {
-            int pre[VIL_VCHUNK_LM + 1];
-            pre[0] = 0;
-#pragma unroll
-            for (int q = 0; q < VIL_VCHUNK_LM; ++q) {
-                int items = 0;
-                if (q < nl) { const int m = lms[q + 1] - lms[q]; const int ng = 3 + m; items = 3 * ng * (ng + 1); }   // np pairs x 6 rows
-                pre[q + 1] = pre[q] + items;
-            }
-            const int total = pre[VIL_VCHUNK_LM];
-            for (int it = t; it < total; it += blockDim.x) {
-                int tl = 0;
-#pragma unroll
-                for (int q = 1; q < VIL_VCHUNK_LM; ++q) if (it >= pre[q]) tl = q;
-                const int rem0 = it - pre[tl];
-                const int p = rem0 / 6, r = rem0 - 6 * p;
-                const int fs = lms[tl], fe = lms[tl + 1];
-                const int ng = 3 + (fe - fs);
-                int g1 = 0, rem = p;
-                while (rem >= ng - g1) { rem -= ng - g1; ++g1; }
-                const int g2 = g1 + rem;
+            // (a) shared x shared blocks: item = (landmark, pair of {A,X,T}, row); inner loop over the landmark's factors
+            for (int it = t; it < nl * 36; it += blockDim.x) {
+                const int tl = it / 36, pr = it - 36 * tl, p = pr / 6, r = pr - 6 * p;
+                const int g1 = p < 3 ? 0 : (p < 5 ? 1 : 2), g2 = p < 3 ? p : (p < 5 ? p - 2 : 2);
                 const int n1 = g1 == 2 ? 1 : 6, n2 = g2 == 2 ? 1 : 6;
                 if (r >= n1) continue;
+                const int fs = lms[tl], fe = lms[tl + 1];
                 const double* lr = lmr + tl * 16;
-                const double invp = lr[0];
                 const int a = lanc[tl];
-                const int o1 = g1 == 0 ? 0 : (g1 == 1 ? 24 : (g1 == 2 ? 36 : 12)), o2 = g2 == 0 ? 0 : (g2 == 1 ? 24 : (g2 == 2 ? 36 : 12));
-                const int c1 = g1 == 0 ? col_pose(P, a) : (g1 == 1 ? col_ex(P) : (g1 == 2 ? col_td(P) : col_pose(P, fj[fs + g1 - 3])));
-                const int c2 = g2 == 0 ? col_pose(P, a) : (g2 == 1 ? col_ex(P) : (g2 == 2 ? col_td(P) : col_pose(P, fj[fs + g2 - 3])));
-                const double* e1 = g1 < 3 ? lr + 1 + (g1 == 0 ? 0 : (g1 == 1 ? 6 : 12)) : Jf + (fs + g1 - 3) * VF_STRIDE + 42;
-                const double* e2 = g2 < 3 ? lr + 1 + (g2 == 0 ? 0 : (g2 == 1 ? 6 : 12)) : Jf + (fs + g2 - 3) * VF_STRIDE + 42;
-                int qa, qb;   // factors common to both groups
-                if (g1 >= 3 && g2 >= 3) { if (g1 == g2) { qa = fs + g1 - 3; qb = qa + 1; } else { qa = 0; qb = 0; } }
-                else if (g2 >= 3) { qa = fs + g2 - 3; qb = qa + 1; }
-                else { qa = fs; qb = fe; }
-                const int s1 = n1 == 1 ? 1 : 6, s2 = n2 == 1 ? 1 : 6;   // row stride inside a 2 x n block
-                const double ie1 = invp * e1[r];
+                const int o1 = g1 == 0 ? 0 : (g1 == 1 ? 24 : 36), o2 = g2 == 0 ? 0 : (g2 == 1 ? 24 : 36);
+                const int c1 = g1 == 0 ? col_pose(P, a) : (g1 == 1 ? col_ex(P) : col_td(P)), c2 = g2 == 0 ? col_pose(P, a) : (g2 == 1 ? col_ex(P) : col_td(P));
+                const double* e1 = lr + 1 + (g1 == 0 ? 0 : (g1 == 1 ? 6 : 12)); const double* e2 = lr + 1 + (g2 == 0 ? 0 : (g2 == 1 ? 6 : 12));
+                const int s1 = n1 == 1 ? 1 : 6, s2 = n2 == 1 ? 1 : 6;
+                const double ie1 = lr[0] * e1[r];
                 double acc[6];
 #pragma unroll
                 for (int c = 0; c < 6; ++c) acc[c] = (c < n2) ? -ie1 * e2[c] : 0.0;
-                for (int q = qa; q < qb; ++q) {
+                for (int q = fs; q < fe; ++q) {
                     const double* w = Jf + q * VF_STRIDE;
                     const double w0 = w[o1 + r], w1 = w[o1 + s1 + r];
 #pragma unroll
@@ -237,6 +221,45 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
                 }
 #pragma unroll
                 for (int c = 0; c < 6; ++c) if (c < n2 && (g1 != g2 || c >= r) && acc[c] != 0.0) lds_add(tri + tri_idx(NV, c1 + r, c2 + c), acc[c]);
+            }
+            VSTAMP(6);
+            // (b) shared x observer blocks: item = (factor, shared group, row); exactly one factor contributes
+            for (int it = t; it < nf * 18; it += blockDim.x) {
+                const int q = it / 18, rem = it - 18 * q, g1 = rem / 6, r = rem - 6 * g1;
+                if (g1 == 2 && r > 0) continue;
+                const int tl = fl[q];
+                const double* lr = lmr + tl * 16;
+                const double* w = Jf + q * VF_STRIDE;
+                const int o1 = g1 == 0 ? 0 : (g1 == 1 ? 24 : 36), s1 = g1 == 2 ? 1 : 6;
+                const int c1 = g1 == 0 ? col_pose(P, lanc[tl]) : (g1 == 1 ? col_ex(P) : col_td(P)), c2 = col_pose(P, fj[q]);
+                const double ie1 = lr[0] * lr[1 + (g1 == 0 ? 0 : (g1 == 1 ? 6 : 12)) + r];
+                const double w0 = w[o1 + r], w1 = w[o1 + s1 + r];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const double v = w0 * w[12 + c] + w1 * w[18 + c] - ie1 * w[42 + c];
+                    if (v != 0.0) lds_add(tri + tri_idx(NV, c1 + r, c2 + c), v);
+                }
+            }
+            VSTAMP(7);
+            // (c) observer x observer blocks: item = (factor q, row); walks the later factors of the same landmark
+            for (int it = t; it < nf * 6; it += blockDim.x) {
+                const int q = it / 6, r = it - 6 * q;
+                const int tl = fl[q], fe = lms[tl + 1];
+                const double* w = Jf + q * VF_STRIDE;
+                const double ieq = lmr[tl * 16] * w[42 + r];
+                const int c1 = col_pose(P, fj[q]) + r;
+                const double j0 = w[12 + r], j1 = w[18 + r];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) if (c >= r) {          // diagonal block (q, q): upper part
+                    const double v = j0 * w[12 + c] + j1 * w[18 + c] - ieq * w[42 + c];
+                    if (v != 0.0) lds_add(tri + tri_idx(NV, c1, c1 - r + c), v);
+                }
+                for (int f2 = q + 1; f2 < fe; ++f2) {
+                    const double* w2 = Jf + f2 * VF_STRIDE;
+                    const int c2 = col_pose(P, fj[f2]);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) { const double v = -ieq * w2[42 + c]; if (v != 0.0) lds_add(tri + tri_idx(NV, c1, c2 + c), v); }
+                }
             }
         }
     }

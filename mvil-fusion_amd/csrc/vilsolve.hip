@@ -239,6 +239,11 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         for (int f = 0; f < p->n_vis; ++f) lms[p->vis_l[f] + 1]++;
         for (int l = 0; l < L; ++l) lms[l + 1] += lms[l];
         put(lms.data(), 4 * (size_t)(L + 1), (void**)&P.lm_start);
+        {
+            std::vector<int> acol(std::max(L, 1), -1), fcol(std::max(p->n_vis, 1), 0);
+            for (int f = p->n_vis - 1; f >= 0; --f) { acol[p->vis_l[f]] = 6 * p->vis_i[f]; fcol[f] = 6 * p->vis_j[f]; }
+            put(acol.data(), 4 * acol.size(), (void**)&P.lm_acol); put(fcol.data(), 4 * fcol.size(), (void**)&P.fcol);
+        }
         std::vector<int> vch;
         int l0 = 0;
         while (l0 < L) {
@@ -349,7 +354,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     HIPCHK(hipMemcpyAsync(ar.d, ar.h.data(), ar.h.size(), hipMemcpyHostToDevice, c->stream));
     c->P = P; c->K = K; c->L = L; c->D = D; c->NS = NS;
     { const int per = VIL_SWEEP_THREADS / 256; c->n_blocks_sweep = P.n_imu + P.n_vwg + (P.n_pchunk + per - 1) / per + (P.n_echunk + per - 1) / per + 1; }
-    c->lds_sweep = sizeof(double) * (size_t)(P.NVT + 3 * NV + VIL_VCHUNK_F * VF_STRIDE + VIL_VCHUNK_LM * 16 + 32 + VIL_VCHUNK_F / 2 + 8 + VIL_VCHUNK_LM + 8);
+    c->lds_sweep = sizeof(double) * (size_t)(P.NVT + 3 * NV + VIL_VCHUNK_F * VF_STRIDE + VIL_VCHUNK_LM * 16 + 32 + VIL_VCHUNK_F + 8 + VIL_VCHUNK_LM + 8);
     if (c->lds_sweep < 8 * 2048) c->lds_sweep = 8 * 2048;
     if (c->lds_sweep > 160 * 1024) return VIL_ERR_UNSUPPORTED;
     HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep));
@@ -475,7 +480,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     if (c->sharded && c->L) HIPCHK(hipMemcpyAsync(c->P.lam0, c->P.x[0] + 16 * c->K + 8, 8 * (size_t)c->L, hipMemcpyDeviceToDevice, c->stream));
     // every iteration = one sweep + one step kernel; `done` turns the tail into no-ops
     bool finished = false;
-    const int chunk = 6;
+    const int chunk = 5;
     for (int it = 0; it <= o->max_iterations + 8 && !finished; ) {
         int launched = 0;
         const int sweeps_before = (it == 0) ? 0 : c->h_ctl->n_sweeps;

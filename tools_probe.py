@@ -20,4 +20,4 @@ print("cfg", cfg, "skip", os.environ.get("VIL_SKIP"), "vwg", os.environ.get("VIL
 dbg = (C.c_longlong*64)(); be.lib.vil_debug_read(be.ctx, dbg)
 d = np.array(dbg[:12], dtype=np.int64); print("raw", (d-d[0]).tolist()); print("chol phases diag/panel/update cycles:", list(dbg[20:23]))
 print("step stamps (cycles, deltas):", np.diff(d).tolist())
-v = np.array(dbg[32:38], dtype=np.int64); print("visual WG0 phase cycles (zero, A, B, C, dump):", np.diff(v).tolist())
+v = np.array(dbg[32:40], dtype=np.int64); print("visual WG0 stamps rel:", (v - v[0]).tolist())
