@@ -21,6 +21,7 @@
 namespace vd {
 
 #define STEP_NB 4
+#define CH_SLOTS 7     // register-resident 16x16 tiles per wave in the Cholesky (8 waves x 7 >= 55 tiles: D <= 159)
 #define PF_N ((55 * 256 + VIL_STEP_THREADS - 1) / VIL_STEP_THREADS)   // prefetched S entries per thread (55 tiles for D <= 159; larger windows loop)
 
 struct StepShared {
@@ -31,6 +32,7 @@ struct StepShared {
     double y[320];
     double sc[320], dcs[320], gr[320], gn[320];   // Sc, dogleg diagonal, gradient_, gauss_newton_step_ (camera part)
     int need, was_first, ok;
+    long long tacc[3];
 };
 
 // block-wide sum(a), sum(b) and sum-or-max(c) with one pair of barriers
@@ -138,16 +140,52 @@ __device__ __forceinline__ int tl_idx(int i, int j) { return tl_base(i >> 4, j >
 //       the <= 8 tiles a wave owns.
 // On return rows < D hold L, row D holds y = L^-1 rhs, s.dinv[j] = 1 / L_jj.  Returns false (uniformly) on a
 // non-positive pivot.
-template <class PTR>
+template <bool REGRES, class PTR>
 __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
     const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
     const int R = D + 1;                 // rows including the rhs row
     const int T = (R + 15) >> 4;         // tile rows
     const int la = ((lane & 15) << 4) + (lane >> 4);       // operand element (row lane&15, k lane>>4) inside a tile
     const int lc = ((lane >> 4) << 4) + (lane & 15);       // accumulator element (row lane>>4 (+4g), col lane&15)
+#ifdef VIL_STAMPS
+    long long tacc[3] = {0, 0, 0}, tprev = 0;
+    #define CSTAMP(k) do { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); if (k >= 0) tacc[k < 0 ? 0 : k] += tt_ - tprev; tprev = tt_; } while (0)
+#else
+    #define CSTAMP(k) do {} while (0)
+#endif
+    // ---- register-resident trailing matrix: every wave OWNS up to CH_SLOTS fixed 16x16 tiles (triangular tile index
+    //      g = wave + NW*u) and keeps them in MFMA accumulators; a tile goes back to LDS only when the factorisation
+    //      reaches its tile column.  The per-step LDS traffic drops from a read-modify-write of the whole trailing
+    //      matrix to two operand fragments per tile.  Windows with more tiles than NW*CH_SLOTS use the LDS/global RMW path.
+    const int ntile_all = (T * (T + 1)) >> 1;     // REGRES requires ntile_all <= NW * CH_SLOTS (true whenever the matrix fits LDS)
+    d4 Creg[REGRES ? CH_SLOTS : 1]; int tIJ[REGRES ? CH_SLOTS : 1];
+    if constexpr (REGRES) {
+#pragma unroll
+        for (int u = 0; u < CH_SLOTS; ++u) {
+            const int g = wave + NW * u;
+            tIJ[u] = -1;
+            if (g < ntile_all) {
+                const int I = s.tI[g], J = s.tJ[g];
+                tIJ[u] = (I << 8) | J;
+                const int cb = tl_base(I, J) + lc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Creg[u][q] = A[cb + (q << 6)];
+            }
+        }
+    }
     for (int kb = 0; kb < D; kb += STEP_NB) {
         const int nb = min(STEP_NB, D - kb);
         const int Kt = kb >> 4, ko = kb & 15;
+        CSTAMP(-1);
+        if constexpr (REGRES) if (ko == 0) {          // the factorisation enters tile column Kt: its owners publish those tiles
+#pragma unroll
+            for (int u = 0; u < CH_SLOTS; ++u) if (tIJ[u] >= 0 && (tIJ[u] & 255) == Kt) {
+                const int cb = tl_base(tIJ[u] >> 8, Kt) + lc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) A[cb + (q << 6)] = Creg[u][q];
+            }
+            __syncthreads();
+        }
         // ---- 1. diagonal 4x4 block, redundantly per thread (identity padding for a short last block) ----------
         const int db = tl_base(Kt, Kt) + (ko << 4) + ko;
         double d00 = A[db], d10 = 0, d11 = 1, d20 = 0, d21 = 0, d22 = 1, d30 = 0, d31 = 0, d32 = 0, d33 = 1;
@@ -167,6 +205,7 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
         d33 -= l30 * l30 + l31 * l31 + l32 * l32; ok = ok && d33 > 0.0 && isfinite(d33);
         sqrt_rsqrt(d33, l33, r3_);
         if (!ok) return false;          // identical data in every thread: uniform exit
+        CSTAMP(0);
         // ---- 2. panel rows (incl. the rhs row): forward substitution against the block ----------------------------
         const int r0 = kb + nb;
         for (int i = r0 + t; i < R; i += NT) {
@@ -185,18 +224,43 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
             if (nb > 3) { A[db + 48] = l30; A[db + 49] = l31; A[db + 50] = l32; A[db + 51] = l33; s.dinv[kb + 3] = r3_; }
         }
         __syncthreads();
+        CSTAMP(1);
         // ---- 3. trailing update on the fp64 matrix cores: C[r][c] -= sum_{k<4} L[r][kb+k] L[c][kb+k], r, c >= r0 ------
-        if (r0 < R) {
+        const bool kk = (lane >> 4) < nb;
+        if constexpr (REGRES) {
+#pragma unroll
+            for (int u = 0; u < CH_SLOTS; ++u) {
+                const int I = tIJ[u] >> 8, J = tIJ[u] & 255;
+                if (tIJ[u] < 0 || J < Kt) continue;                       // finished (or empty) slot: wave-uniform
+                if (J > Kt) {                                            // register tile: rows/cols are beyond the panel
+                    const double av = kk ? -A[tl_base(I, Kt) + la + ko] : 0.0;
+                    const double bv = kk ? A[tl_base(J, Kt) + la + ko] : 0.0;
+                    Creg[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, Creg[u], 0, 0, 0);
+                } else if (r0 < R) {                                     // tile of the active column: lives in LDS
+                    const int rr = (I << 4) + (lane & 15), cr = (J << 4) + (lane & 15);
+                    const double av = (rr >= r0 && rr < R && kk) ? A[tl_base(I, Kt) + la + ko] : 0.0;
+                    const double bv = (cr >= r0 && cr < D && kk) ? A[tl_base(J, Kt) + la + ko] : 0.0;
+                    d4 z = {0.0, 0.0, 0.0, 0.0};
+                    const d4 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, z, 0, 0, 0);
+                    const int cb = tl_base(I, J) + lc;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) A[cb + (g << 6)] -= acc[g];
+                }
+            }
+        } else { if (r0 < R) {
             const int I0 = r0 >> 4, n = T - I0;
             const int ntile = n * (n + 1) / 2;
-            const bool kk = (lane >> 4) < nb;
             for (int t0 = 0; t0 < ntile; t0 += 8 * NW) {
                 d4 acc[8]; double av[8], bv[8]; int cb[8];
                 const int cnt = min(8, (ntile - t0 - wave + NW - 1) / NW);   // wave-uniform number of live slots
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (u < cnt) {
                     const int tile = t0 + wave + u * NW;
-                    const int I = I0 + s.tI[tile], J = I0 + s.tJ[tile];
+                    int Ir = (int)((sqrtf(8.f * (float)tile + 1.f) - 1.f) * 0.5f);
+                    if (((Ir + 1) * (Ir + 2)) / 2 <= tile) ++Ir;
+                    if ((Ir * (Ir + 1)) / 2 > tile) --Ir;
+                    const int Jr = tile - (Ir * (Ir + 1)) / 2;
+                    const int I = I0 + Ir, J = I0 + Jr;
                     cb[u] = tl_base(I, J);
                     const int rr = (I << 4) + (lane & 15), cr = (J << 4) + (lane & 15);
                     av[u] = (rr >= r0 && rr < R && kk) ? A[tl_base(I, Kt) + la + ko] : 0.0;
@@ -210,9 +274,13 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
                     for (int g = 0; g < 4; ++g) A[cb[u] + lc + (g << 6)] -= acc[u][g];   // rows / cols outside [r0, R) got zero operands
                 }
             }
-        }
+        } }
         __syncthreads();
+        CSTAMP(2);
     }
+#ifdef VIL_STAMPS
+    if (threadIdx.x == 0) { s.tacc[0] = tacc[0]; s.tacc[1] = tacc[1]; s.tacc[2] = tacc[2]; }
+#endif
     return true;
 }
 
@@ -425,8 +493,11 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         STAMP(2);
         if (PHASE == 0 && gm <= O.gradient_tolerance) { if (t == 0) { s.c.done = 1; s.c.term = 2; *P.ctl = s.c; } return; }
         bool ok;
-        if constexpr (LDSM) ok = chol_blocked(Alds, D, s); else ok = chol_blocked(Ag, D, s);
+        if constexpr (LDSM) ok = chol_blocked<true>(Alds, D, s); else ok = chol_blocked<false>(Ag, D, s);
         STAMP(3);
+#ifdef VIL_STAMPS
+        if (t == 0) { P.dbg[20] = s.tacc[0]; P.dbg[21] = s.tacc[1]; P.dbg[22] = s.tacc[2]; }
+#endif
         if (!ok) {
             // dogleg_strategy.cc: mu *= 10 and retry; the Schur pivots depend on mu, so re-sweep at x_cur
             if (t == 0) {
