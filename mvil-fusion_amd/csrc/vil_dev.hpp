@@ -6,7 +6,7 @@
 
 #define VIL_THREADS 256       // eval / reduce kernels, LiDAR chunk size
 #define VIL_SWEEP_THREADS 512 // sweep workgroups: 8 waves = 2 per SIMD for LDS-latency hiding
-#define VIL_VCHUNK_LM 16      // landmarks per visual sub-chunk
+#define VIL_VCHUNK_LM 12      // landmarks per visual sub-chunk
 #define VIL_VCHUNK_F 128      // factors per visual workgroup (LDS staging bound)
 #define VIL_STEP_THREADS 512
 

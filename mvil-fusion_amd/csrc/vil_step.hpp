@@ -28,7 +28,7 @@ struct StepShared {
     Ctl c;
     double red[32];
     unsigned char tI[256], tJ[256];   // triangular tile index -> (row, col) of the tile
-    double xs[320], dinv[320];   // solution of the reduced system, reciprocal Cholesky pivots (D <= 320)
+    double xs[320], dinv[320], Xb[800];   // ... and the inverses of the 4x4 diagonal blocks (80 blocks x 10)   // solution of the reduced system, reciprocal Cholesky pivots (D <= 320)
     double y[320];
     double sc[320], dcs[320], gr[320], gn[320];   // Sc, dogleg diagonal, gradient_, gauss_newton_step_ (camera part)
     int need, was_first, ok;
@@ -217,6 +217,16 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
             const double x3 = (a3 - x0 * l30 - x1 * l31 - x2 * l32) * r3_;
             A[base] = x0; if (nb > 1) A[base + 1] = x1; if (nb > 2) A[base + 2] = x2; if (nb > 3) A[base + 3] = x3;
         }
+        if (t == NT - 1) {              // an idle thread (no panel row): X = L_kk^-1 (lower 4x4) for the back substitution
+            double* X = s.Xb + (kb >> 2) * 10;
+            const double x10 = -l10 * r0_ * r1_;
+            const double x21 = -l21 * r1_ * r2_;
+            const double x32 = -l32 * r2_ * r3_;
+            const double x20 = -(l20 * r0_ + l21 * x10) * r2_;
+            const double x31 = -(l31 * r1_ + l32 * x21) * r3_;
+            const double x30 = -(l30 * r0_ + l31 * x10 + l32 * x20) * r3_;
+            X[0] = r0_; X[1] = x10; X[2] = r1_; X[3] = x20; X[4] = x21; X[5] = r2_; X[6] = x30; X[7] = x31; X[8] = x32; X[9] = r3_;
+        }
         if (t == 0) {                   // the factored block itself and the reciprocal pivots
             A[db] = l00; s.dinv[kb] = r0_;
             if (nb > 1) { A[db + 16] = l10; A[db + 17] = l11; s.dinv[kb + 1] = r1_; }
@@ -296,13 +306,12 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
         const int kb = blk * STEP_NB, nb = min(STEP_NB, D - kb);
         const int db = tl_base(kb >> 4, kb >> 4) + ((kb & 15) << 4) + (kb & 15);
         const double y0 = s.y[kb], y1 = nb > 1 ? s.y[kb + 1] : 0.0, y2 = nb > 2 ? s.y[kb + 2] : 0.0, y3 = nb > 3 ? s.y[kb + 3] : 0.0;
-        const double r0_ = s.dinv[kb], r1_ = nb > 1 ? s.dinv[kb + 1] : 1.0, r2_ = nb > 2 ? s.dinv[kb + 2] : 1.0, r3_ = nb > 3 ? s.dinv[kb + 3] : 1.0;
-        const double l10 = nb > 1 ? A[db + 16] : 0.0, l20 = nb > 2 ? A[db + 32] : 0.0, l21 = nb > 2 ? A[db + 33] : 0.0;
-        const double l30 = nb > 3 ? A[db + 48] : 0.0, l31 = nb > 3 ? A[db + 49] : 0.0, l32 = nb > 3 ? A[db + 50] : 0.0;
-        const double x3 = y3 * r3_;
-        const double x2 = (y2 - l32 * x3) * r2_;
-        const double x1 = (y1 - l21 * x2 - l31 * x3) * r1_;
-        const double x0 = (y0 - l10 * x1 - l20 * x2 - l30 * x3) * r0_;
+        const double* X = s.Xb + blk * 10;      // rows of L_kk^-1: [x00 | x10 x11 | x20 x21 x22 | x30 x31 x32 x33] (identity padded)
+        // x_blk = X^T y_blk: four short independent dot products instead of an 8-deep triangular-solve chain
+        const double x0 = (X[0] * y0 + X[1] * y1) + (X[3] * y2 + X[6] * y3);
+        const double x1 = (X[2] * y1 + X[4] * y2) + X[7] * y3;
+        const double x2 = X[5] * y2 + X[8] * y3;
+        const double x3 = X[9] * y3;
         if (t == 0) { s.xs[kb] = x0; if (nb > 1) s.xs[kb + 1] = x1; if (nb > 2) s.xs[kb + 2] = x2; if (nb > 3) s.xs[kb + 3] = x3; }
         for (int c = t; c < kb; c += NT) {              // y_c -= sum_r L[kb+r][c] x_r
             const int base = tl_base(kb >> 4, c >> 4) + ((kb & 15) << 4) + (c & 15);

@@ -79,6 +79,7 @@ struct vil_ctx {
     ncclComm_t comm = nullptr;     // RCCL communicator over xGMI (world > 1)
     bool sharded = false;          // the resident problem is this rank's shard of the factor set
     bool split = false;            // step kernel launched as A | all-reduce | B
+    int last_live = 5;             // live sweep launches of the previous solve (sizes the first launch chunk)
     int lm_b = 0, lm_e = 0;        // owned landmark range
     bool profiling = false;
     std::vector<hipEvent_t> ev, ev_mid;
@@ -256,7 +257,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         P.n_vchunk = (int)vch.size() / 2;
         put(vch.data(), 4 * vch.size(), (void**)&P.vchunk);
         // group the sub-chunks into visual workgroups (each owns one LDS triangle / one partial record)
-        int vwg_max = 96;
+        int vwg_max = 256;
         if (const char* ev = getenv("VIL_VWG")) vwg_max = std::max(1, atoi(ev));
         P.n_vwg = std::min(P.n_vchunk, vwg_max);
         std::vector<int> vw;
@@ -444,7 +445,7 @@ static int init_ctl(vil_ctx* c, const vil_options* o, int lin_mode) {
 int vil_profile_enable(vil_ctx* c, int on) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(c->device));
-    if (on && c->ev.empty()) { c->ev.resize(32); for (auto& e : c->ev) HIPCHK(hipEventCreate(&e)); c->ev_mid.resize(16); for (auto& e : c->ev_mid) HIPCHK(hipEventCreate(&e)); }
+    if (on && c->ev.empty()) { c->ev.resize(40); for (auto& e : c->ev) HIPCHK(hipEventCreate(&e)); c->ev_mid.resize(20); for (auto& e : c->ev_mid) HIPCHK(hipEventCreate(&e)); }
     c->profiling = on != 0;
     return VIL_OK;
 }
@@ -480,8 +481,10 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     if (c->sharded && c->L) HIPCHK(hipMemcpyAsync(c->P.lam0, c->P.x[0] + 16 * c->K + 8, 8 * (size_t)c->L, hipMemcpyDeviceToDevice, c->stream));
     // every iteration = one sweep + one step kernel; `done` turns the tail into no-ops
     bool finished = false;
-    const int chunk = 5;
-    for (int it = 0; it <= o->max_iterations + 8 && !finished; ) {
+    // iterations are enqueued in chunks without host round trips; the first chunk is sized by the previous solve of
+    // this context (consecutive windows of a tracker need similar iteration counts), later chunks are short
+    int chunk = std::min(15, std::max(3, c->last_live));
+    for (int it = 0; it <= o->max_iterations + 8 && !finished; chunk = 3) {
         int launched = 0;
         const int sweeps_before = (it == 0) ? 0 : c->h_ctl->n_sweeps;
         for (int q = 0; q < chunk && it <= o->max_iterations + 8; ++q, ++it, ++launched) {
@@ -510,6 +513,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     }
     HIPCHK(hipGetLastError());
     const Ctl& ctl = *c->h_ctl;
+    c->last_live = ctl.n_sweeps;
     memset(sum, 0, sizeof *sum);
     sum->iterations = ctl.iter; sum->successful_steps = ctl.nsucc; sum->termination = ctl.term;
     sum->initial_cost = ctl.initial_cost; sum->final_cost = ctl.cost_cur;
