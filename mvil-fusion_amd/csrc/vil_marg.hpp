@@ -116,18 +116,24 @@ __device__ inline void jacobi_eig(double* A, double* V, double* w, int n, int* p
 
 }  // namespace vd
 
-__global__ __launch_bounds__(512) void k_marg(MargDev M) {
+__global__ __launch_bounds__(512) void k_marg(MargDev M, int lds_a, int lds_v) {
     using namespace vd;
     __shared__ double sm[512 + 64];
+    __shared__ int spairs[160];          // tournament schedule (n <= 158)
+    extern __shared__ double mlds[];     // [A n x n | V n x n] when they fit (latency of the ~10 n Jacobi stages is what matters)
     const int t = threadIdx.x, NT = blockDim.x;
     const int D = M.D, nd = M.nd, n = M.n;
     // ---- dropped block, symmetrised (marginalization_factor.cpp:273), eigen pseudo inverse ------------
+    double* Addw = mlds;                 // nd <= 15: the small eigen problem runs entirely in LDS (>= 4 KB are always requested)
+    double* Vdw = mlds + 256;
     for (int e = t; e < nd * nd; e += NT) {
         const int i = e / nd, j = e - i * nd;
-        M.Add[e] = 0.5 * (M.S[(size_t)M.drop_cols[i] * D + M.drop_cols[j]] + M.S[(size_t)M.drop_cols[j] * D + M.drop_cols[i]]);
+        Addw[e] = 0.5 * (M.S[(size_t)M.drop_cols[i] * D + M.drop_cols[j]] + M.S[(size_t)M.drop_cols[j] * D + M.drop_cols[i]]);
     }
     __syncthreads();
-    jacobi_eig(M.Add, M.Vd, M.wd, nd, M.pairs, sm);
+    jacobi_eig(Addw, Vdw, M.wd, nd, spairs, sm);
+    for (int e = t; e < nd * nd; e += NT) M.Vd[e] = Vdw[e];
+    __syncthreads();
     // T = A_kd pinv(A_dd) = (A_kd Vd) diag(1/w) Vd^T
     for (int e = t; e < n * nd; e += NT) {
         const int i = e / nd, k = e - i * nd;
@@ -163,9 +169,12 @@ __global__ __launch_bounds__(512) void k_marg(MargDev M) {
     __syncthreads();
     for (int e = t; e < n * n; e += NT) { M.A[e] = M.V[e]; }
     __syncthreads();
-    for (int e = t; e < n * n; e += NT) M.T[e] = M.J0[e];     // T (n x n capacity) <- symmetric working copy
+    double* Aw = lds_a ? mlds : M.T;                            // working copy of the symmetric matrix
+    double* Vw = lds_v ? mlds + (size_t)n * n : M.V;
+    for (int e = t; e < n * n; e += NT) Aw[e] = M.J0[e];
     __syncthreads();
-    jacobi_eig(M.T, M.V, M.w, n, M.pairs, sm);
+    jacobi_eig(Aw, Vw, M.w, n, spairs, sm);
+    if (lds_v) { for (int e = t; e < n * n; e += NT) M.V[e] = Vw[e]; __syncthreads(); }
     // linearized_jacobians = sqrt(S) V^T (column-major n x n), linearized_residuals = S^-1/2 V^T b
     for (int e = t; e < n * n + n; e += NT) {
         if (e < n * n) {

@@ -492,8 +492,8 @@ __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
             i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
             while (((i + 1) * (i + 2)) / 2 <= idx) ++i;
             while ((i * (i + 1)) / 2 > idx) --i;
-            j = idx - (i * (i + 1)) / 2;              // j <= i : (i, j) is a lower-triangle entry; use (row j, col i) as the upper one
-            const int tmp = i; i = j; j = tmp;        // now i <= j
+            j = idx - (i * (i + 1)) / 2;              // (i, j), j <= i, enumerates a lower triangle row by row ...
+            const int a = i; i = D - 1 - a; j = D - 1 - j;   // ... mirrored to the upper entry (D-1-a, D-1-b): consecutive lanes -> consecutive columns (coalesced partial reads)
         }
         double vs = 0.0, vdg = 0.0;
         if (ok && j < NV) {

@@ -723,7 +723,7 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     const int nd = (int)drop_cols.size(), n = (int)keep_cols.size();
     int n_max, nblk_max, x0_max;
     vil_prior_capacity(K, &n_max, &nblk_max, &x0_max);
-    if (n > n_max || (int)kinds.size() > nblk_max || n <= 0 || nd <= 0) return VIL_ERR_UNSUPPORTED;
+    if (n > n_max || n > 158 || nd > 15 || (int)kinds.size() > nblk_max || n <= 0 || nd <= 0) return VIL_ERR_UNSUPPORTED;
     // ---- device work space + kernel ------------------------------------------------------------------------------
     const size_t nn = (size_t)n * n;
     const size_t bytes = 8 * ((size_t)nd * nd * 2 + nd + nn * 5 + (size_t)n * 3) + 4 * (size_t)(nd + n + 2 * (n + 2)) + 4096;
@@ -743,7 +743,13 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     if (off > bytes) { hipFree(dw); return VIL_ERR_DEVICE; }
     HIPCHK(hipMemcpyAsync(d_drop, drop_cols.data(), 4 * (size_t)nd, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_keep, keep_cols.data(), 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_marg, dim3(1), dim3(512), 0, c->stream, M);
+    {
+        const size_t a_bytes = 8 * nn, cap = 150 * 1024;
+        const int lds_a = a_bytes <= cap ? 1 : 0, lds_v = 2 * a_bytes <= cap ? 1 : 0;
+        const size_t dyn = std::max<size_t>(4096, lds_v ? 2 * a_bytes : (lds_a ? a_bytes : 0));
+        if (dyn > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(k_marg, dim3(1), dim3(512), dyn, c->stream, M, lds_a, lds_v);
+    }
     st = ensure_pin(c, 8 * (nn * 2 + 2 * (size_t)n));
     if (st != VIL_OK) { hipFree(dw); return st; }
     HIPCHK(hipMemcpyAsync(c->h_pin, M.J0, 8 * nn, hipMemcpyDeviceToHost, c->stream));
