@@ -34,6 +34,24 @@ def algorithmic_bytes(w):
             + 8 * (n * n + n) + 8 * (16 * w.K + 8))
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per live k_sweep launch from the committed rocprofv3 --pmc passes of THIS command (profiles/):
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md (HBM section),
+    WRITE_SIZE uncalibrated.  None if the CSVs are missing."""
+    import csv
+    tot = 0.0
+    for fn, mult in (("r01_pmc_fetch_size.csv", 2.0), ("r01_pmc_write_size.csv", 1.0)):
+        path = os.path.join(ROOT, "profiles", fn)
+        if not os.path.exists(path):
+            return None
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if r["Kernel_Name"].startswith("k_sweep")]
+        if not v:
+            return None
+        live = [x for x in v if x > 0.25 * max(v)]
+        tot += mult * 1024.0 * sum(live) / len(live)
+    return tot
+
+
 def cpu_baseline(w, opts, budget_s=12.0):
     """Oracle (CPU restatement, kind 'port') timed on this host: repeated full solves of the same window."""
     from mvil_fusion_amd import lib
@@ -107,28 +125,41 @@ def main():
     w = synth.make_config(args.config, prior_fn=gpu_prior)
     prior_kind = "vil_marginalize of the preceding synthetic window, on the GPU" if got_prior["lib"] else "synthetic dense prior"
     be.upload(w)
-    if not args.no_events:
-        be.lib.vil_profile_enable(be.ctx, 1)
 
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        be.reset_state(); be.solve_resident(opts)
-    prof = VilProfile()
-    be.lib.vil_profile_read(be.ctx, C.byref(prof), 1)
+    def run(n):
+        its, last_ = 0, None
+        for _ in range(n):
+            be.reset_state()
+            last_ = be.solve_resident(opts)
+            its += last_.iterations
+        return its, last_
+
+    run(args.warmup)
     sync()
     t0 = time.perf_counter()
-    iters, last = 0, None
-    for _ in range(args.steps):
-        be.reset_state()
-        last = be.solve_resident(opts)
-        iters += last.iterations
+    iters, last = run(args.steps)
     sync()
     el = time.perf_counter() - t0
-    be.lib.vil_profile_read(be.ctx, C.byref(prof), 1)
+    # roofline leg: the SAME K steps once more with HIP events recorded on the library's stream around every sweep
+    # launch.  Kept out of the `value` region because three event records per ~170 us iteration perturb this
+    # latency-bound pipeline by several percent.
+    prof = VilProfile()
+    if not args.no_events:
+        be.lib.vil_profile_enable(be.ctx, 1)
+        run(2)
+        be.lib.vil_profile_read(be.ctx, C.byref(prof), 1)
+        sync()
+        t1 = time.perf_counter()
+        run(args.steps)
+        sync()
+        el_events = time.perf_counter() - t1
+        be.lib.vil_profile_read(be.ctx, C.byref(prof), 1)
+        be.lib.vil_profile_enable(be.ctx, 0)
     tot_iters, max_el = iters, el
     if dist is not None:
         tt = torch.tensor([float(iters), el], device="cuda", dtype=torch.float64)
@@ -152,9 +183,10 @@ def main():
             ab = algorithmic_bytes(w)
             us = 1e3 * prof.sweep_ms / prof.sweep_launches
             ach = ab / (us * 1e-6) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_sweep", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            out["roofline"] = {"bound": "hbm", "kernel": "k_sweep", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(), "traffic_source": "profiles/r01_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command)",
                                "algorithmic_bytes_per_launch": ab, "avg_launch_us": us, "launches_timed": int(prof.sweep_launches),
                                "reduce_plus_step_avg_us": 1e3 * prof.step_ms / max(1, prof.step_launches), "reduce_avg_us": 1e3 * prof.reduce_ms / max(1, prof.step_launches),
+                               "measured_on": "second pass of the same %d steps with HIP events enabled (%.1f ms/step instrumented vs %.1f ms/step in the value region)" % (args.steps, 1e3 * el_events / args.steps, 1e3 * max_el / args.steps),
                                "variant": "fused sweep (no Jacobian materialisation): read-only bytes, SURVEY 8(d)"}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(w, opts)
