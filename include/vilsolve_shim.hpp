@@ -86,6 +86,30 @@ private:
     std::vector<double> imu_, vis_, icp_, lps_, edge_, plane_;
 };
 
+// ---- timestamp -> window index mapping of the LiDAR constraints (lidar_backend.cpp:3-93) -------------
+// Host logic, O(K).  `stamps[k]` = Headers[k].stamp.toSec() for the K = WINDOW_SIZE + 1 frames, ascending.
+
+// lidar_backend.cpp:3-36: the two window frames bracketing time tl.  The reference sorts tl into the stamp list and
+// takes the neighbours of its first occurrence, i.e. id_b = first frame with stamp >= tl, id_a = id_b - 1;
+// rejected when tl lies before frame 0 or after the last frame.
+inline bool find_nearest_2id(const double* stamps, int K, double tl, int& id_a, int& id_b) {
+    int lb = 0;
+    while (lb < K && stamps[lb] < tl) ++lb;
+    id_a = lb - 1; id_b = lb;
+    return id_b <= K - 1 && id_a >= 0;
+}
+
+// lidar_backend.cpp:38-93: window indices of the four frame stamps of an ICP constraint.  Stamps are matched with
+// exact floating-point equality, as in the reference; an id whose stamp is not in the window KEEPS the value the caller
+// passed in (the reference leaves it untouched), so initialise them to 0 the way estimator.cpp:1352 does.
+inline bool find_windows_id(const double* stamps, int K, double ta, double tb, double tc, double td, int& id_a, int& id_b, int& id_c, int& id_d) {
+    if (stamps[0] > ta || stamps[K - 1] < td || (tb - ta) > 0.5) return false;
+    auto locate = [&](double t, int& id) { for (int k = 0; k < K; ++k) if (stamps[k] == t) { id = k; return; } };
+    locate(ta, id_a); locate(tb, id_b); locate(tc, id_c); locate(td, id_d);
+    if (id_b == id_c) { --id_a; --id_b; }       // scans i and j share a bracket frame: shift the first bracket down
+    return id_b > id_a && id_d > id_c && id_a >= 0 && id_a != id_c;
+}
+
 // Owner of the caller-side storage of a prior across frames (what `last_marginalization_info` +
 // `last_marginalization_parameter_blocks` are in estimator.h:146-147).
 class PriorStore {

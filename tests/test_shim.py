@@ -39,3 +39,44 @@ def test_shim_compiles_and_packs():
         subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", os.path.join(d, "t")])
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
     assert out == ["7", "3", "1", "3", "1", "1", "1", "230.0", "0"]
+
+
+IDS = r"""
+#include <cstdio>
+#include "vilsolve_shim.hpp"
+extern "C" void vil_prior_capacity(int, int*, int*, int*) {}
+int main() {
+    const double st[7] = {10.0, 10.1, 10.2, 10.3, 10.4, 10.5, 10.6};
+    int a = -9, b = -9;
+    bool ok;
+    ok = vil::find_nearest_2id(st, 7, 10.25, a, b); std::printf("%d %d %d\n", (int)ok, a, b);      // bracketed
+    ok = vil::find_nearest_2id(st, 7, 10.3, a, b);  std::printf("%d %d %d\n", (int)ok, a, b);      // equal to a stamp: that frame is id_b
+    ok = vil::find_nearest_2id(st, 7, 9.9, a, b);   std::printf("%d %d %d\n", (int)ok, a, b);      // before the window
+    ok = vil::find_nearest_2id(st, 7, 10.0, a, b);  std::printf("%d %d %d\n", (int)ok, a, b);      // equal to frame 0: no left neighbour
+    ok = vil::find_nearest_2id(st, 7, 10.7, a, b);  std::printf("%d %d %d\n", (int)ok, a, b);      // after the window
+    int ia = 0, ib = 0, ic = 0, id = 0;
+    ok = vil::find_windows_id(st, 7, 10.1, 10.2, 10.4, 10.5, ia, ib, ic, id); std::printf("%d %d %d %d %d\n", (int)ok, ia, ib, ic, id);
+    ia = ib = ic = id = 0;
+    ok = vil::find_windows_id(st, 7, 10.1, 10.2, 10.2, 10.3, ia, ib, ic, id); std::printf("%d %d %d %d %d\n", (int)ok, ia, ib, ic, id);   // shared frame: first bracket shifts down
+    ia = ib = ic = id = 0;
+    ok = vil::find_windows_id(st, 7, 10.0, 10.1, 10.1, 10.2, ia, ib, ic, id); std::printf("%d %d %d %d %d\n", (int)ok, ia, ib, ic, id);   // shift would leave the window
+    ia = ib = ic = id = 0;
+    ok = vil::find_windows_id(st, 7, 9.5, 10.1, 10.4, 10.5, ia, ib, ic, id);  std::printf("%d\n", (int)ok);                               // starts before the window
+    ia = ib = ic = id = 0;
+    ok = vil::find_windows_id(st, 7, 10.0, 10.6, 10.6, 10.6, ia, ib, ic, id); std::printf("%d\n", (int)ok);                               // bracket wider than 0.5 s
+    ia = ib = ic = id = 0;
+    ok = vil::find_windows_id(st, 7, 10.1, 10.25, 10.4, 10.5, ia, ib, ic, id); std::printf("%d %d %d %d %d\n", (int)ok, ia, ib, ic, id); // tb not a frame stamp: id_b keeps 0
+    return 0;
+}
+"""
+
+
+def test_window_id_lookup():
+    """A13: FindNearest2ID / FindWindowsID semantics (lidar_backend.cpp:3-93), incl. the untouched-id quirk."""
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.cpp")
+        open(src, "w").write(IDS)
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", os.path.join(d, "t")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode().strip().split("\n")
+    assert out == ["1 2 3", "1 2 3", "0 -1 0", "0 -1 0", "0 6 7",
+                   "1 1 2 4 5", "1 0 1 2 3", "0 -1 0 1 2", "0", "0", "0 1 0 4 5"]
