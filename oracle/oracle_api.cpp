@@ -11,6 +11,7 @@ double cost_api(const vil_problem* p, const vil_state* st, const vil_options* o)
 int gauge_fix(const double* pose0_before, vil_state* s);
 int marginalize(const vil_problem* p, const vil_state* st, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out);
 void sym_eig(int n, const double* Ain, double* w, double* V);
+void sym_eig_jacobi(int n, const double* Ain, double* w, double* V);
 }  // namespace orc
 
 extern "C" {
@@ -88,6 +89,7 @@ double orc_cost(const vil_problem* p, const vil_state* s, const vil_options* o) 
 int orc_gauge_fix(const double* pose0_before, vil_state* s) { return orc::gauge_fix(pose0_before, s); }
 int orc_marginalize(const vil_problem* p, const vil_state* s, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out) { return orc::marginalize(p, s, o, spec, out); }
 void orc_sym_eig(int n, const double* A, double* w, double* V) { orc::sym_eig(n, A, w, V); }
+void orc_sym_eig_jacobi(int n, const double* A, double* w, double* V) { orc::sym_eig_jacobi(n, A, w, V); }
 int orc_imu_sqrt_info(const double* cov, double* U) { return orc::imu_sqrt_info(cov, U) ? 0 : -1; }
 void orc_loss(int kind, double a, double s, double* rho3) { orc::loss_evaluate(kind, a, s, rho3); }
 void orc_edge_residual_ref(const double* cp, const double* a3, const double* b3, const double* q, const double* t, double* r) { orc::edge_residual_ref(cp, a3, b3, q, t, r); }

@@ -16,7 +16,8 @@ namespace orc {
 
 // cyclic Jacobi eigen-decomposition of a symmetric n x n row-major matrix: A = V diag(w) V^T,
 // eigenvalues ascending (like Eigen::SelfAdjointEigenSolver), V column k = eigenvector k.
-void sym_eig(int n, const double* Ain, double* w, double* V) {
+// Slow (O(n^3) per sweep) but independent of the QL solver below: kept as the cross-check (tests) only.
+void sym_eig_jacobi(int n, const double* Ain, double* w, double* V) {
     std::vector<double> A(Ain, Ain + (size_t)n * n);
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[(size_t)i * n + j] = (i == j);
     double fro = 0; for (size_t i = 0; i < A.size(); ++i) fro += A[i] * A[i];
@@ -55,6 +56,111 @@ void sym_eig(int n, const double* Ain, double* w, double* V) {
     std::vector<double> Vs((size_t)n * n);
     for (int k = 0; k < n; ++k) { w[k] = A[(size_t)ord[k] * n + ord[k]]; for (int i = 0; i < n; ++i) Vs[(size_t)i * n + k] = V[(size_t)i * n + ord[k]]; }
     std::copy(Vs.begin(), Vs.end(), V);
+}
+
+// Householder tridiagonalisation + implicit-shift QL: the same two stages Eigen::SelfAdjointEigenSolver runs
+// (marginalization_factor.cpp:275,301), so the CPU timing of marginalisation is not inflated by the eigen solver.
+// Symmetric n x n row-major in, A = V diag(w) V^T, eigenvalues ascending, V column k = eigenvector k.
+void sym_eig(int n, const double* Ain, double* w, double* V) {
+    if (n <= 0) return;
+    std::vector<double> z(Ain, Ain + (size_t)n * n), e(n, 0.0);
+    double* d = w;
+    auto Z = [&](int i, int j) -> double& { return z[(size_t)i * n + j]; };
+    // ---- stage 1: reduce to tridiagonal (d diagonal, e sub-diagonal), accumulate the orthogonal transform in z
+    for (int i = n - 1; i >= 1; --i) {
+        const int l = i - 1;
+        double h = 0.0;
+        if (l > 0) {
+            double scale = 0.0;
+            for (int k = 0; k <= l; ++k) scale += std::fabs(Z(i, k));
+            if (scale == 0.0) e[i] = Z(i, l);
+            else {
+                for (int k = 0; k <= l; ++k) { Z(i, k) /= scale; h += Z(i, k) * Z(i, k); }
+                double f = Z(i, l);
+                double g = f >= 0.0 ? -std::sqrt(h) : std::sqrt(h);
+                e[i] = scale * g; h -= f * g; Z(i, l) = f - g;
+                f = 0.0;
+                for (int j = 0; j <= l; ++j) {
+                    Z(j, i) = Z(i, j) / h;
+                    g = 0.0;
+                    for (int k = 0; k <= j; ++k) g += Z(j, k) * Z(i, k);
+                    for (int k = j + 1; k <= l; ++k) g += Z(k, j) * Z(i, k);
+                    e[j] = g / h;
+                    f += e[j] * Z(i, j);
+                }
+                const double hh = f / (h + h);
+                for (int j = 0; j <= l; ++j) {
+                    f = Z(i, j);
+                    e[j] = g = e[j] - hh * f;
+                    for (int k = 0; k <= j; ++k) Z(j, k) -= f * e[k] + g * Z(i, k);
+                }
+            }
+        } else e[i] = Z(i, l);
+        d[i] = h;
+    }
+    d[0] = 0.0; e[0] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int l = i - 1;
+        if (d[i] != 0.0) {
+            for (int j = 0; j <= l; ++j) {
+                double g = 0.0;
+                for (int k = 0; k <= l; ++k) g += Z(i, k) * Z(k, j);
+                for (int k = 0; k <= l; ++k) Z(k, j) -= g * Z(k, i);
+            }
+        }
+        d[i] = Z(i, i); Z(i, i) = 1.0;
+        for (int j = 0; j <= l; ++j) Z(j, i) = Z(i, j) = 0.0;
+    }
+    // ---- stage 2: QL with implicit shifts on the tridiagonal; rotations applied to the TRANSPOSED accumulator
+    //      (row i of zt = eigenvector i: the Givens updates are contiguous)
+    std::vector<double> zt((size_t)n * n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) zt[(size_t)j * n + i] = Z(i, j);
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    for (int l = 0; l < n; ++l) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < n - 1; ++m) {
+                const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+                if (std::fabs(e[m]) <= 2.3e-16 * dd) break;
+            }
+            if (m != l) {
+                if (++iter > 200) break;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = std::hypot(g, 1.0);
+                g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+                double sn = 1.0, cs = 1.0, p = 0.0;
+                int i;
+                for (i = m - 1; i >= l; --i) {
+                    double f = sn * e[i];
+                    const double b = cs * e[i];
+                    e[i + 1] = r = std::hypot(f, g);
+                    if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
+                    sn = f / r; cs = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * sn + 2.0 * cs * b;
+                    p = sn * r;
+                    d[i + 1] = g + p;
+                    g = cs * r - b;
+                    double* z0 = &zt[(size_t)i * n];
+                    double* z1 = z0 + n;
+                    for (int k = 0; k < n; ++k) {
+                        const double f1 = z1[k], f0 = z0[k];
+                        z1[k] = sn * f0 + cs * f1;
+                        z0[k] = cs * f0 - sn * f1;
+                    }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p; e[l] = g; e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    std::vector<int> ord(n);
+    for (int i = 0; i < n; ++i) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return d[a] < d[b]; });
+    std::vector<double> ws(n);
+    for (int k = 0; k < n; ++k) { ws[k] = d[ord[k]]; for (int i = 0; i < n; ++i) V[(size_t)i * n + k] = zt[(size_t)ord[k] * n + i]; }
+    std::copy(ws.begin(), ws.end(), w);
 }
 
 namespace {
