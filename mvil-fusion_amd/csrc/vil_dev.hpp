@@ -34,6 +34,7 @@ struct Ctl {          // trust-region state, lives in device memory, owned by th
 
 struct SolveOpts {
     int max_iterations, jacobi_scaling, visual_loss, lidar_loss, rel_loss, autodiff_quirk;
+    int precision;      // 1: visual / LiDAR point factors evaluated in fp32 (accumulation stays fp64)
     double function_tolerance, gradient_tolerance, parameter_tolerance, max_radius, min_relative_decrease, min_mu, max_mu;
     double visual_loss_scale, lidar_loss_scale, rel_loss_scale;
 };

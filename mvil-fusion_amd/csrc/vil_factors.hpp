@@ -12,43 +12,47 @@ namespace vd {
 //   c[14] = pts_i(3) pts_j(3) vel_i(2) vel_j(2) td_i td_j row_i row_j
 // out: r[2]; J blocks 2x6 row-major: Ji, Jj, Jex; Jl[2] (inverse depth); Jt[2] (td)
 // ------------------------------------------------------------------------------------------------
-struct VisJ { double r[2]; double Ji[12], Jj[12], Jex[12], Jl[2], Jt[2]; };
+template <class T> struct VisJT { T r[2]; T Ji[12], Jj[12], Jex[12], Jl[2], Jt[2]; };
+using VisJ = VisJT<double>;
 
-__device__ __forceinline__ void visual_eval(const double* c, const M3& Ri, V3 Pi, const M3& Rj, V3 Pj, const M3& Ric, V3 tic,
-                                            double lam, double td, double s, double k_tr, int use_td, VisJ& o) {
-    V3 pi{c[0], c[1], c[2]}, pj{c[3], c[4], c[5]};
-    const V3 veli{c[6], c[7], 0.0}, velj{c[8], c[9], 0.0};
+template <class T>
+__device__ __forceinline__ void visual_eval_t(const double* c, const M3T<T>& Ri, V3T<T> Pi, const M3T<T>& Rj, V3T<T> Pj, const M3T<T>& Ric, V3T<T> tic,
+                                              T lam, T td, T s, T k_tr, int use_td, VisJT<T>& o) {
+    using V = V3T<T>;
+    const T zero = (T)0;
+    V pi{(T)c[0], (T)c[1], (T)c[2]}, pj{(T)c[3], (T)c[4], (T)c[5]};
+    const V veli{(T)c[6], (T)c[7], zero}, velj{(T)c[8], (T)c[9], zero};
     if (use_td) {
-        const double ti = td - c[10] + k_tr * c[12], tj = td - c[11] + k_tr * c[13];
+        const T ti = td - (T)c[10] + k_tr * (T)c[12], tj = td - (T)c[11] + k_tr * (T)c[13];
         pi = pi - ti * veli;
         pj = pj - tj * velj;
     }
-    const double il = 1.0 / lam;
-    const V3 xci = il * pi;
-    const V3 xbi = mul(Ric, xci) + tic;
-    const V3 xw = mul(Ri, xbi) + Pi;
-    const V3 xbj = mulT(Rj, xw - Pj);
-    const V3 xcj = mulT(Ric, xbj - tic);
-    const double iz = 1.0 / xcj.z;
+    const T il = (T)1 / lam;
+    const V xci = il * pi;
+    const V xbi = mul(Ric, xci) + tic;
+    const V xw = mul(Ri, xbi) + Pi;
+    const V xbj = mulT(Rj, xw - Pj);
+    const V xcj = mulT(Ric, xbj - tic);
+    const T iz = (T)1 / xcj.z;
     o.r[0] = s * (xcj.x * iz - pj.x);
     o.r[1] = s * (xcj.y * iz - pj.y);
     // E = s [[1/z 0 -x/z^2],[0 1/z -y/z^2]]
-    const V3 e0{s * iz, 0.0, -s * xcj.x * iz * iz}, e1{0.0, s * iz, -s * xcj.y * iz * iz};
+    const V e0{s * iz, zero, -s * xcj.x * iz * iz}, e1{zero, s * iz, -s * xcj.y * iz * iz};
     // C = E Ric^T ; A = C Rj^T ; B = A Ri ; T = B Ric       (all 2x3, row vectors)
-    const V3 c0 = rowmulT(e0, Ric), c1 = rowmulT(e1, Ric);
-    const V3 a0 = rowmulT(c0, Rj), a1 = rowmulT(c1, Rj);
-    const V3 b0 = rowmul(a0, Ri), b1 = rowmul(a1, Ri);
-    const V3 t0 = rowmul(b0, Ric), t1 = rowmul(b1, Ric);
+    const V c0 = rowmulT(e0, Ric), c1 = rowmulT(e1, Ric);
+    const V a0 = rowmulT(c0, Rj), a1 = rowmulT(c1, Rj);
+    const V b0 = rowmul(a0, Ri), b1 = rowmul(a1, Ri);
+    const V t0 = rowmul(b0, Ric), t1 = rowmul(b1, Ric);
     // pose i: [A | -B [xbi]x] ;  row^T [v]x = (row x v)^T
-    const V3 ri0 = cross(xbi, b0), ri1 = cross(xbi, b1);
+    const V ri0 = cross(xbi, b0), ri1 = cross(xbi, b1);
     o.Ji[0] = a0.x; o.Ji[1] = a0.y; o.Ji[2] = a0.z; o.Ji[3] = ri0.x; o.Ji[4] = ri0.y; o.Ji[5] = ri0.z;
     o.Ji[6] = a1.x; o.Ji[7] = a1.y; o.Ji[8] = a1.z; o.Ji[9] = ri1.x; o.Ji[10] = ri1.y; o.Ji[11] = ri1.z;
     // pose j: [-A | C [xbj]x]
-    const V3 rj0 = cross(c0, xbj), rj1 = cross(c1, xbj);
+    const V rj0 = cross(c0, xbj), rj1 = cross(c1, xbj);
     o.Jj[0] = -a0.x; o.Jj[1] = -a0.y; o.Jj[2] = -a0.z; o.Jj[3] = rj0.x; o.Jj[4] = rj0.y; o.Jj[5] = rj0.z;
     o.Jj[6] = -a1.x; o.Jj[7] = -a1.y; o.Jj[8] = -a1.z; o.Jj[9] = rj1.x; o.Jj[10] = rj1.y; o.Jj[11] = rj1.z;
     // extrinsic: [B - C | -T [xci]x + E [T xci + w]x],  T xci + w == xcj
-    const V3 rx0 = cross(xci, t0) + cross(e0, xcj), rx1 = cross(xci, t1) + cross(e1, xcj);
+    const V rx0 = cross(xci, t0) + cross(e0, xcj), rx1 = cross(xci, t1) + cross(e1, xcj);
     o.Jex[0] = b0.x - c0.x; o.Jex[1] = b0.y - c0.y; o.Jex[2] = b0.z - c0.z; o.Jex[3] = rx0.x; o.Jex[4] = rx0.y; o.Jex[5] = rx0.z;
     o.Jex[6] = b1.x - c1.x; o.Jex[7] = b1.y - c1.y; o.Jex[8] = b1.z - c1.z; o.Jex[9] = rx1.x; o.Jex[10] = rx1.y; o.Jex[11] = rx1.z;
     // inverse depth: E T pts_i_td (-1/lam^2) = -(T xci)/lam
@@ -57,38 +61,68 @@ __device__ __forceinline__ void visual_eval(const double* c, const M3& Ri, V3 Pi
     if (use_td) {
         o.Jt[0] = -dot(t0, veli) * il + s * velj.x;
         o.Jt[1] = -dot(t1, veli) * il + s * velj.y;
-    } else { o.Jt[0] = 0.0; o.Jt[1] = 0.0; }
+    } else { o.Jt[0] = zero; o.Jt[1] = zero; }
+}
+
+// fp64 entry (reference arithmetic) and the fp32-evaluation variant: same formulas in float, result widened for the
+// fp64 accumulation.  The rotation matrices are formed in fp64 from the quaternions and rounded once.
+__device__ __forceinline__ void visual_eval(const double* c, const M3& Ri, V3 Pi, const M3& Rj, V3 Pj, const M3& Ric, V3 tic,
+                                            double lam, double td, double s, double k_tr, int use_td, VisJ& o) {
+    visual_eval_t<double>(c, Ri, Pi, Rj, Pj, Ric, tic, lam, td, s, k_tr, use_td, o);
+}
+__device__ __forceinline__ void visual_eval_f32(const double* c, const M3& Ri, V3 Pi, const M3& Rj, V3 Pj, const M3& Ric, V3 tic,
+                                                double lam, double td, double s, double k_tr, int use_td, VisJ& o) {
+    VisJT<float> of;
+    visual_eval_t<float>(c, m3cast<float>(Ri), v3cast<float>(Pi), m3cast<float>(Rj), v3cast<float>(Pj), m3cast<float>(Ric), v3cast<float>(tic),
+                         (float)lam, (float)td, (float)s, (float)k_tr, use_td, of);
+    o.r[0] = of.r[0]; o.r[1] = of.r[1]; o.Jl[0] = of.Jl[0]; o.Jl[1] = of.Jl[1]; o.Jt[0] = of.Jt[0]; o.Jt[1] = of.Jt[1];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { o.Ji[k] = of.Ji[k]; o.Jj[k] = of.Jj[k]; o.Jex[k] = of.Jex[k]; }
 }
 
 // ------------------------------------------------------------------------------------------------
 // A14 LiDAR point factors in window-pose form: p_b = R_bl p_l + t_bl, p_w = R p_b + P
 //   plane (lidarFactor.hpp:106-138): r = n.p_w + d            J = [n^T | (p_b x R^T n)^T]
 //   edge  (lidarFactor.hpp:12-55):   r = ((p_w-a)x(p_w-b))/|a-b|   J = [-[dh]x | [dh]x R [p_b]x], dh=(a-b)/|a-b|
+// PREC = 1: the same arithmetic in float, widened on output.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void plane_eval(V3 pl, V3 n, double d, const M3& Rbl, V3 tbl, const M3& R, V3 P, double& r, double* J6) {
-    const V3 pb = mul(Rbl, pl) + tbl;
-    const V3 pw = mul(R, pb) + P;
+template <class T>
+__device__ __forceinline__ void plane_eval_t(V3T<T> pl, V3T<T> n, T d, const M3T<T>& Rbl, V3T<T> tbl, const M3T<T>& R, V3T<T> P, double& r, double* J6) {
+    const V3T<T> pb = mul(Rbl, pl) + tbl;
+    const V3T<T> pw = mul(R, pb) + P;
     r = dot(n, pw) + d;
-    const V3 rn = mulT(R, n);
-    const V3 jr = cross(pb, rn);
+    const V3T<T> rn = mulT(R, n);
+    const V3T<T> jr = cross(pb, rn);
     J6[0] = n.x; J6[1] = n.y; J6[2] = n.z; J6[3] = jr.x; J6[4] = jr.y; J6[5] = jr.z;
 }
 
-__device__ __forceinline__ void edge_eval(V3 pl, V3 a, V3 b, const M3& Rbl, V3 tbl, const M3& R, V3 P, double* r3, double* J18) {
-    const V3 pb = mul(Rbl, pl) + tbl;
-    const V3 pw = mul(R, pb) + P;
-    const V3 de = a - b;
-    const double inv = 1.0 / sqrt(dot(de, de));
-    const V3 nu = cross(pw - a, pw - b);
+template <class T>
+__device__ __forceinline__ void edge_eval_t(V3T<T> pl, V3T<T> a, V3T<T> b, const M3T<T>& Rbl, V3T<T> tbl, const M3T<T>& R, V3T<T> P, double* r3, double* J18) {
+    using V = V3T<T>;
+    const T zero = (T)0;
+    const V pb = mul(Rbl, pl) + tbl;
+    const V pw = mul(R, pb) + P;
+    const V de = a - b;
+    const T inv = (T)1 / sqrt(dot(de, de));
+    const V nu = cross(pw - a, pw - b);
     r3[0] = nu.x * inv; r3[1] = nu.y * inv; r3[2] = nu.z * inv;
-    const V3 dh = inv * de;
+    const V dh = inv * de;
     // G = -[dh]x  (rows g0,g1,g2)
-    const V3 g0{0.0, dh.z, -dh.y}, g1{-dh.z, 0.0, dh.x}, g2{dh.y, -dh.x, 0.0};
+    const V g0{zero, dh.z, -dh.y}, g1{-dh.z, zero, dh.x}, g2{dh.y, -dh.x, zero};
     // rotation part: G (-R [pb]x): row_i = -(g_i^T R) [pb]x = -( (R^T g_i) x pb ) = pb x (R^T g_i)
-    const V3 q0 = cross(pb, mulT(R, g0)), q1 = cross(pb, mulT(R, g1)), q2 = cross(pb, mulT(R, g2));
+    const V q0 = cross(pb, mulT(R, g0)), q1 = cross(pb, mulT(R, g1)), q2 = cross(pb, mulT(R, g2));
     J18[0] = g0.x; J18[1] = g0.y; J18[2] = g0.z; J18[3] = q0.x; J18[4] = q0.y; J18[5] = q0.z;
     J18[6] = g1.x; J18[7] = g1.y; J18[8] = g1.z; J18[9] = q1.x; J18[10] = q1.y; J18[11] = q1.z;
     J18[12] = g2.x; J18[13] = g2.y; J18[14] = g2.z; J18[15] = q2.x; J18[16] = q2.y; J18[17] = q2.z;
+}
+
+__device__ __forceinline__ void plane_eval(V3 pl, V3 n, double d, const M3& Rbl, V3 tbl, const M3& R, V3 P, double& r, double* J6, int prec = 0) {
+    if (prec) plane_eval_t<float>(v3cast<float>(pl), v3cast<float>(n), (float)d, m3cast<float>(Rbl), v3cast<float>(tbl), m3cast<float>(R), v3cast<float>(P), r, J6);
+    else plane_eval_t<double>(pl, n, d, Rbl, tbl, R, P, r, J6);
+}
+__device__ __forceinline__ void edge_eval(V3 pl, V3 a, V3 b, const M3& Rbl, V3 tbl, const M3& R, V3 P, double* r3, double* J18, int prec = 0) {
+    if (prec) edge_eval_t<float>(v3cast<float>(pl), v3cast<float>(a), v3cast<float>(b), m3cast<float>(Rbl), v3cast<float>(tbl), m3cast<float>(R), v3cast<float>(P), r3, J18);
+    else edge_eval_t<double>(pl, a, b, Rbl, tbl, R, P, r3, J18);
 }
 
 // ------------------------------------------------------------------------------------------------

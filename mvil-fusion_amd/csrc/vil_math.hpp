@@ -7,24 +7,29 @@
 
 namespace vd {
 
-struct V3 { double x, y, z; };
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
-__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// T = double everywhere on the reference path; T = float only for the fp32-evaluation mode of the bulk factor classes
+template <class T> struct V3T { T x, y, z; };
+using V3 = V3T<double>;
+template <class T> __device__ __forceinline__ V3T<T> operator+(V3T<T> a, V3T<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class T> __device__ __forceinline__ V3T<T> operator-(V3T<T> a, V3T<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class T> __device__ __forceinline__ V3T<T> operator*(T s, V3T<T> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <class T> __device__ __forceinline__ V3T<T> cross(V3T<T> a, V3T<T> b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+template <class T> __device__ __forceinline__ T dot(V3T<T> a, V3T<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
 // row-major 3x3 in registers
-struct M3 { double m[9]; };
-__device__ __forceinline__ V3 mul(const M3& A, V3 v) {
+template <class T> struct M3T { T m[9]; };
+using M3 = M3T<double>;
+template <class T> __device__ __forceinline__ V3T<T> mul(const M3T<T>& A, V3T<T> v) {
     return {A.m[0] * v.x + A.m[1] * v.y + A.m[2] * v.z, A.m[3] * v.x + A.m[4] * v.y + A.m[5] * v.z, A.m[6] * v.x + A.m[7] * v.y + A.m[8] * v.z};
 }
-__device__ __forceinline__ V3 mulT(const M3& A, V3 v) {  // A^T v
+template <class T> __device__ __forceinline__ V3T<T> mulT(const M3T<T>& A, V3T<T> v) {  // A^T v
     return {A.m[0] * v.x + A.m[3] * v.y + A.m[6] * v.z, A.m[1] * v.x + A.m[4] * v.y + A.m[7] * v.z, A.m[2] * v.x + A.m[5] * v.y + A.m[8] * v.z};
 }
 // row vector times matrix: (v^T A)^T == A^T v
-__device__ __forceinline__ V3 rowmul(V3 v, const M3& A) { return mulT(A, v); }
-__device__ __forceinline__ V3 rowmulT(V3 v, const M3& A) { return mul(A, v); }  // v^T A^T
+template <class T> __device__ __forceinline__ V3T<T> rowmul(V3T<T> v, const M3T<T>& A) { return mulT(A, v); }
+template <class T> __device__ __forceinline__ V3T<T> rowmulT(V3T<T> v, const M3T<T>& A) { return mul(A, v); }  // v^T A^T
+template <class T> __device__ __forceinline__ V3T<T> v3cast(V3 v) { return {(T)v.x, (T)v.y, (T)v.z}; }
+template <class T> __device__ __forceinline__ M3T<T> m3cast(const M3& A) { M3T<T> r; for (int i = 0; i < 9; ++i) r.m[i] = (T)A.m[i]; return r; }
 
 // unit quaternion [x y z w] -> rotation matrix
 __device__ __forceinline__ M3 quatR(const double* q) {

@@ -125,8 +125,12 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             const int i = P.vis_i[f], j = P.vis_j[f], l = P.vis_l[f];
             const double* pi = x + xo_pose(P, i); const double* pj = x + xo_pose(P, j); const double* ex = x + xo_ex(P);
             VisJ o;
-            visual_eval(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
-                        x[xo_lam(P) + l], x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
+            if (O.precision)
+                visual_eval_f32(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
+                                x[xo_lam(P) + l], x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
+            else
+                visual_eval(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
+                            x[xo_lam(P) + l], x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
             double rho, rho1;
             loss_eval(O.visual_loss, O.visual_loss_scale, o.r[0] * o.r[0] + o.r[1] * o.r[1], rho, rho1);
             cost += 0.5 * rho;
@@ -295,10 +299,10 @@ __device__ __forceinline__ void sweep_lidar(const DevP& P, const SolveOpts& O, i
         double r[NR], J[NR * 6];
         if (NR == 1) {
             const double* c = P.pl_c; const int s = P.pl_stride;
-            plane_eval(V3{c[f], c[s + f], c[2 * s + f]}, V3{c[3 * s + f], c[4 * s + f], c[5 * s + f]}, c[6 * s + f], Rbl, tbl, R, Pk, r[0], J);
+            plane_eval(V3{c[f], c[s + f], c[2 * s + f]}, V3{c[3 * s + f], c[4 * s + f], c[5 * s + f]}, c[6 * s + f], Rbl, tbl, R, Pk, r[0], J, O.precision);
         } else {
             const double* c = P.ed_c; const int s = P.ed_stride;
-            edge_eval(V3{c[f], c[s + f], c[2 * s + f]}, V3{c[3 * s + f], c[4 * s + f], c[5 * s + f]}, V3{c[6 * s + f], c[7 * s + f], c[8 * s + f]}, Rbl, tbl, R, Pk, r, J);
+            edge_eval(V3{c[f], c[s + f], c[2 * s + f]}, V3{c[3 * s + f], c[4 * s + f], c[5 * s + f]}, V3{c[6 * s + f], c[7 * s + f], c[8 * s + f]}, Rbl, tbl, R, Pk, r, J, O.precision);
         }
         double sq = 0;
 #pragma unroll

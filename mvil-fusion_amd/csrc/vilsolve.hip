@@ -90,6 +90,7 @@ static SolveOpts to_dev_opts(const vil_options* o) {
     SolveOpts s;
     s.max_iterations = o->max_iterations; s.jacobi_scaling = o->jacobi_scaling;
     s.visual_loss = o->visual_loss; s.lidar_loss = o->lidar_loss; s.rel_loss = o->rel_loss; s.autodiff_quirk = o->autodiff_quirk;
+    s.precision = o->precision == 1 ? 1 : 0;
     s.function_tolerance = o->function_tolerance; s.gradient_tolerance = o->gradient_tolerance; s.parameter_tolerance = o->parameter_tolerance;
     s.max_radius = o->max_radius; s.min_relative_decrease = o->min_relative_decrease; s.min_mu = o->min_mu; s.max_mu = o->max_mu;
     s.visual_loss_scale = o->visual_loss_scale; s.lidar_loss_scale = o->lidar_loss_scale; s.rel_loss_scale = o->rel_loss_scale;
@@ -472,7 +473,7 @@ int vil_reset_state(vil_ctx* c) {
 
 int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     if (!c || !o || !sum || !c->uploaded) return VIL_ERR_INVALID_ARGUMENT;
-    if (o->precision != 0) return VIL_ERR_UNSUPPORTED;
+    if (o->precision != 0 && o->precision != 1) return VIL_ERR_UNSUPPORTED;
     HIPCHK(hipSetDevice(c->device));
     const auto t0 = std::chrono::steady_clock::now();
     const SolveOpts so = to_dev_opts(o);
