@@ -12,6 +12,10 @@ int gauge_fix(const double* pose0_before, vil_state* s);
 int marginalize(const vil_problem* p, const vil_state* st, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out);
 void sym_eig(int n, const double* Ain, double* w, double* V);
 void sym_eig_jacobi(int n, const double* Ain, double* w, double* V);
+void set_threads(int n);
+#ifdef ORC_TIMERS
+extern double g_tm[8];
+#endif
 }  // namespace orc
 
 extern "C" {
@@ -89,6 +93,11 @@ double orc_cost(const vil_problem* p, const vil_state* s, const vil_options* o) 
 int orc_gauge_fix(const double* pose0_before, vil_state* s) { return orc::gauge_fix(pose0_before, s); }
 int orc_marginalize(const vil_problem* p, const vil_state* s, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out) { return orc::marginalize(p, s, o, spec, out); }
 void orc_sym_eig(int n, const double* A, double* w, double* V) { orc::sym_eig(n, A, w, V); }
+#ifdef ORC_TIMERS
+void orc_timers(double* out) { for (int i = 0; i < 8; ++i) { out[i] = orc::g_tm[i]; orc::g_tm[i] = 0; } }
+#endif
+// all-cores variant of the CPU baseline (bench.py only; parity always runs with 1 thread)
+void orc_set_threads(int n) { orc::set_threads(n); }
 void orc_sym_eig_jacobi(int n, const double* A, double* w, double* V) { orc::sym_eig_jacobi(n, A, w, V); }
 int orc_imu_sqrt_info(const double* cov, double* U) { return orc::imu_sqrt_info(cov, U) ? 0 : -1; }
 void orc_loss(int kind, double a, double s, double* rho3) { orc::loss_evaluate(kind, a, s, rho3); }

@@ -12,9 +12,19 @@
 #include <chrono>
 #include <cstdio>
 
+#include <memory>
+#include <thread>
 #include "oracle.hpp"
 
 namespace orc {
+
+#ifdef ORC_TIMERS
+double g_tm[8];
+struct Tm { int k; std::chrono::steady_clock::time_point t0; Tm(int k_) : k(k_), t0(std::chrono::steady_clock::now()) {} ~Tm() { g_tm[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } };
+#define ORC_TM(k) Tm tm_##k(k)
+#else
+#define ORC_TM(k) do {} while (0)
+#endif
 
 struct WState {
     int K, L;
@@ -43,7 +53,13 @@ struct System {
     std::vector<double> Hcc, bc, hll, bl, E;
     std::vector<uint8_t> cconst, lconst;   // 1 => constant (not optimised)
     double cost;
-    explicit System(int K, int L) : lay(K, L), Hcc((size_t)lay.D * lay.D), bc(lay.D), hll(L), bl(L), E((size_t)L * lay.D), cconst(lay.D), lconst(L), cost(0) {}
+    double *Ep, *hp, *bp;                  // landmark rows the accumulation writes to (own storage, or a parent's: see below)
+    explicit System(int K, int L) : lay(K, L), Hcc((size_t)lay.D * lay.D), bc(lay.D), hll(L), bl(L), E((size_t)L * lay.D), cconst(lay.D), lconst(L), cost(0) {
+        Ep = E.data(); hp = hll.data(); bp = bl.data();
+    }
+    // worker-thread accumulator of the all-cores variant: private camera block, landmark rows SHARED with `parent`
+    // (each worker owns a disjoint set of landmarks, like the reference's marginalisation threads own disjoint factors)
+    System(const System& parent, int) : lay(parent.lay), Hcc((size_t)lay.D * lay.D), bc(lay.D), cost(0) { Ep = parent.Ep; hp = parent.hp; bp = parent.bp; }
     void zero() {
         std::fill(Hcc.begin(), Hcc.end(), 0.0); std::fill(bc.begin(), bc.end(), 0.0);
         std::fill(hll.begin(), hll.end(), 0.0); std::fill(bl.begin(), bl.end(), 0.0);
@@ -62,13 +78,13 @@ static void accumulate(System& sys, int nr, const double* r, int nb, const Blk* 
             const int l = -2 - b[a].col;
             double h = 0, g = 0;
             for (int k = 0; k < nr; ++k) { double j = b[a].J[k * b[a].ld]; h += j * j; g += j * r[k]; }
-            sys.hll[l] += h; sys.bl[l] += g;
+            sys.hp[l] += h; sys.bp[l] += g;
             for (int c = 0; c < nb; ++c) {
                 if (b[c].col < 0) continue;
                 for (int jj = 0; jj < b[c].n; ++jj) {
                     double s = 0;
                     for (int k = 0; k < nr; ++k) s += b[a].J[k * b[a].ld] * b[c].J[k * b[c].ld + jj];
-                    sys.E[(size_t)l * D + b[c].col + jj] += s;
+                    sys.Ep[(size_t)l * D + b[c].col + jj] += s;
                 }
             }
             continue;
@@ -116,11 +132,85 @@ struct Ctx {
     int col_lm(int l) const { return (p->lm_const && p->lm_const[l]) ? -1 : -2 - l; }
 };
 
+// ---- bulk factor classes (visual, LiDAR points): worker t of T ---------------------------------------------------------
+static double bulk_part(const Ctx& c, const WState& x, System* sys, int t, int T) {
+    const vil_problem* p = c.p;
+    double cost = 0;
+    // visual  estimator.cpp:1189-1242
+    for (int f = 0; f < p->n_vis; ++f) {
+        const int i = p->vis_i[f], j = p->vis_j[f], l = p->vis_l[f];
+        if (T > 1 && l % T != t) continue;                 // landmark ownership: rows of E / hll / bl are written by one worker only
+        double r[2], J[VIL_VIS_NJ];
+        visual_evaluate(p->vis_const + (size_t)f * VIL_VIS_CONST, p->sqrt_info_px, p->tr_over_row, p->use_td,
+                        &x.pose[7 * i], &x.pose[7 * j], x.ex, x.lam[l], x.td, r, sys ? J : nullptr);
+        double* Jb[5] = {J, J + 14, J + 28, J + 42, J + 44};
+        const int nc[5] = {7, 7, 7, 1, 1};
+        double rho0;
+        if (sys) rho0 = apply_corrector(c.o.visual_loss, c.o.visual_loss_scale, 2, r, 5, Jb, nc);
+        else { double sq = r[0] * r[0] + r[1] * r[1]; double rho[3]; loss_evaluate(c.o.visual_loss, c.o.visual_loss_scale, sq, rho); rho0 = rho[0]; }
+        cost += 0.5 * rho0;
+        if (sys) {
+            Blk b[5] = {{c.col_pose(i), 6, 7, J}, {c.col_pose(j), 6, 7, J + 14}, {c.col_ex(), 6, 7, J + 28}, {c.col_lm(l), 1, 1, J + 42}, {c.col_td(), 1, 1, J + 44}};
+            accumulate(*sys, 2, r, 5, b);
+        }
+    }
+    // LiDAR edge / plane points (extended mode), Huber(0.1) as localMapping.cpp:597
+    for (int f = (int)((int64_t)p->n_edge * t / T); f < (int)((int64_t)p->n_edge * (t + 1) / T); ++f) {
+        const int k = p->edge_pose[f];
+        double r[3], J[21];
+        edge_evaluate(p->edge_const + (size_t)f * VIL_EDGE_CONST, p->q_lb, p->t_lb, &x.pose[7 * k], r, sys ? J : nullptr);
+        double* Jb[1] = {J}; const int nc[1] = {7};
+        double rho0;
+        if (sys) rho0 = apply_corrector(c.o.lidar_loss, c.o.lidar_loss_scale, 3, r, 1, Jb, nc);
+        else { double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2]; double rho[3]; loss_evaluate(c.o.lidar_loss, c.o.lidar_loss_scale, sq, rho); rho0 = rho[0]; }
+        cost += 0.5 * rho0;
+        if (sys) { Blk b[1] = {{c.col_pose(k), 6, 7, J}}; accumulate(*sys, 3, r, 1, b); }
+    }
+    for (int f = (int)((int64_t)p->n_plane * t / T); f < (int)((int64_t)p->n_plane * (t + 1) / T); ++f) {
+        const int k = p->plane_pose[f];
+        double r[1], J[7];
+        plane_evaluate(p->plane_const + (size_t)f * VIL_PLANE_CONST, p->q_lb, p->t_lb, &x.pose[7 * k], r, sys ? J : nullptr);
+        double* Jb[1] = {J}; const int nc[1] = {7};
+        double rho0;
+        if (sys) rho0 = apply_corrector(c.o.lidar_loss, c.o.lidar_loss_scale, 1, r, 1, Jb, nc);
+        else { double sq = r[0] * r[0]; double rho[3]; loss_evaluate(c.o.lidar_loss, c.o.lidar_loss_scale, sq, rho); rho0 = rho[0]; }
+        cost += 0.5 * rho0;
+        if (sys) { Blk b[1] = {{c.col_pose(k), 6, 7, J}}; accumulate(*sys, 1, r, 1, b); }
+    }
+    return cost;
+}
+
+// Number of threads of the "all cores" CPU-baseline variant.  1 = the reference's configuration (ceres::Solve
+// with the default num_threads = 1, estimator.cpp:1400-1411) and the ONLY setting used for parity.
+static int g_threads = 1;
+void set_threads(int n) { g_threads = n < 1 ? 1 : (n > 256 ? 256 : n); }
+
+static double bulk(const Ctx& c, const WState& x, System* sys) {
+    const int T = g_threads;
+    if (T == 1) return bulk_part(c, x, sys, 0, 1);
+    std::vector<double> costs(T, 0.0);
+    std::vector<std::unique_ptr<System>> priv(T);
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) {
+        if (sys) priv[t].reset(new System(*sys, 0));
+        th.emplace_back([&, t]() { costs[t] = bulk_part(c, x, sys ? priv[t].get() : nullptr, t, T); });
+    }
+    costs[0] = bulk_part(c, x, sys, 0, T);
+    for (auto& q : th) q.join();
+    double cost = 0;
+    for (int t = 0; t < T; ++t) cost += costs[t];
+    if (sys) for (int t = 1; t < T; ++t) {
+        for (size_t i = 0; i < sys->Hcc.size(); ++i) sys->Hcc[i] += priv[t]->Hcc[i];
+        for (size_t i = 0; i < sys->bc.size(); ++i) sys->bc[i] += priv[t]->bc[i];
+    }
+    return cost;
+}
+
 // Evaluate every residual block at `x`; if sys != nullptr also build the (corrected) normal equations.
 static double linearize(const Ctx& c, const WState& x, System* sys) {
     const vil_problem* p = c.p;
     double cost = 0;
-    if (sys) sys->zero();
+    if (sys) { ORC_TM(0); sys->zero(); }
     // prior (no loss)  estimator.cpp:1171-1177
     if (p->prior.n > 0) {
         const vil_prior& pr = p->prior;
@@ -172,23 +262,6 @@ static double linearize(const Ctx& c, const WState& x, System* sys) {
             accumulate(*sys, 15, r, 4, b);
         }
     }
-    // visual  estimator.cpp:1189-1242
-    for (int f = 0; f < p->n_vis; ++f) {
-        const int i = p->vis_i[f], j = p->vis_j[f], l = p->vis_l[f];
-        double r[2], J[VIL_VIS_NJ];
-        visual_evaluate(p->vis_const + (size_t)f * VIL_VIS_CONST, p->sqrt_info_px, p->tr_over_row, p->use_td,
-                        &x.pose[7 * i], &x.pose[7 * j], x.ex, x.lam[l], x.td, r, sys ? J : nullptr);
-        double* Jb[5] = {J, J + 14, J + 28, J + 42, J + 44};
-        const int nc[5] = {7, 7, 7, 1, 1};
-        double rho0;
-        if (sys) rho0 = apply_corrector(c.o.visual_loss, c.o.visual_loss_scale, 2, r, 5, Jb, nc);
-        else { double sq = r[0] * r[0] + r[1] * r[1]; double rho[3]; loss_evaluate(c.o.visual_loss, c.o.visual_loss_scale, sq, rho); rho0 = rho[0]; }
-        cost += 0.5 * rho0;
-        if (sys) {
-            Blk b[5] = {{c.col_pose(i), 6, 7, J}, {c.col_pose(j), 6, 7, J + 14}, {c.col_ex(), 6, 7, J + 28}, {c.col_lm(l), 1, 1, J + 42}, {c.col_td(), 1, 1, J + 44}};
-            accumulate(*sys, 2, r, 5, b);
-        }
-    }
     // ICP  estimator.cpp:1371-1396
     for (int f = 0; f < p->n_icp; ++f) {
         const int* id = p->icp_ids + 4 * f;
@@ -224,29 +297,7 @@ static double linearize(const Ctx& c, const WState& x, System* sys) {
             accumulate(*sys, 3, r, 2, b);
         }
     }
-    // LiDAR edge / plane points (extended mode), Huber(0.1) as localMapping.cpp:597
-    for (int f = 0; f < p->n_edge; ++f) {
-        const int k = p->edge_pose[f];
-        double r[3], J[21];
-        edge_evaluate(p->edge_const + (size_t)f * VIL_EDGE_CONST, p->q_lb, p->t_lb, &x.pose[7 * k], r, sys ? J : nullptr);
-        double* Jb[1] = {J}; const int nc[1] = {7};
-        double rho0;
-        if (sys) rho0 = apply_corrector(c.o.lidar_loss, c.o.lidar_loss_scale, 3, r, 1, Jb, nc);
-        else { double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2]; double rho[3]; loss_evaluate(c.o.lidar_loss, c.o.lidar_loss_scale, sq, rho); rho0 = rho[0]; }
-        cost += 0.5 * rho0;
-        if (sys) { Blk b[1] = {{c.col_pose(k), 6, 7, J}}; accumulate(*sys, 3, r, 1, b); }
-    }
-    for (int f = 0; f < p->n_plane; ++f) {
-        const int k = p->plane_pose[f];
-        double r[1], J[7];
-        plane_evaluate(p->plane_const + (size_t)f * VIL_PLANE_CONST, p->q_lb, p->t_lb, &x.pose[7 * k], r, sys ? J : nullptr);
-        double* Jb[1] = {J}; const int nc[1] = {7};
-        double rho0;
-        if (sys) rho0 = apply_corrector(c.o.lidar_loss, c.o.lidar_loss_scale, 1, r, 1, Jb, nc);
-        else { double sq = r[0] * r[0]; double rho[3]; loss_evaluate(c.o.lidar_loss, c.o.lidar_loss_scale, sq, rho); rho0 = rho[0]; }
-        cost += 0.5 * rho0;
-        if (sys) { Blk b[1] = {{c.col_pose(k), 6, 7, J}}; accumulate(*sys, 1, r, 1, b); }
-    }
+    { ORC_TM(1); cost += bulk(c, x, sys); }
     if (sys) {
         sys->cost = cost;
         const int D = c.lay.D;
@@ -346,6 +397,7 @@ struct Dogleg {
     }
     // returns false if no valid GN step could be computed
     bool compute_system(const System& s) {
+        ORC_TM(2);
         // diagonal_ = sqrt(clamp(colnorm^2 of the Jacobi-scaled Jacobian, 1e-6, 1e32))
         for (int i = 0; i < D; ++i) { double v = Sc[i] * Sc[i] * s.Hcc[(size_t)i * D + i]; dc[i] = std::sqrt(std::min(std::max(v, 1e-6), 1e32)); }
         for (int l = 0; l < L; ++l) { double v = Sl[l] * Sl[l] * s.hll[l]; dl[l] = std::sqrt(std::min(std::max(v, 1e-6), 1e32)); }
@@ -384,7 +436,7 @@ struct Dogleg {
                     for (int b = 0; b < nc; ++b) row[cl[b]] -= ea * et[b];
                 }
             }
-            bool chol = cholesky_lower(D, Sred.data(), Lo.data());
+            bool chol; { ORC_TM(3); chol = cholesky_lower(D, Sred.data(), Lo.data()); }
             if (chol) {
                 // forward / backward substitution
                 for (int i = 0; i < D; ++i) { double v = rhs[i]; for (int k = 0; k < i; ++k) v -= Lo[(size_t)i * D + k] * xc[k]; xc[i] = v / Lo[(size_t)i * D + i]; }
