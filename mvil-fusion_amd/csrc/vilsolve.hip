@@ -74,6 +74,8 @@ struct vil_ctx {
     int* d_status = nullptr;
     Ctl* h_ctl = nullptr;          // pinned
     double* h_pin = nullptr;       // pinned scratch
+    char* marg_ws = nullptr;       // device work space of vil_marginalize (grow-only)
+    size_t marg_ws_bytes = 0;
     size_t h_pin_bytes = 0;
     std::vector<int> prior_joff;
     ncclComm_t comm = nullptr;     // RCCL communicator over xGMI (world > 1)
@@ -165,6 +167,7 @@ void vil_destroy(vil_ctx* c) {
     if (c->d_status) hipFree(c->d_status);
     if (c->h_ctl) hipHostFree(c->h_ctl);
     if (c->h_pin) hipHostFree(c->h_pin);
+    if (c->marg_ws) hipFree(c->marg_ws);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -724,12 +727,20 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     const int nd = (int)drop_cols.size(), n = (int)keep_cols.size();
     int n_max, nblk_max, x0_max;
     vil_prior_capacity(K, &n_max, &nblk_max, &x0_max);
-    if (n > n_max || n > 158 || nd > 15 || (int)kinds.size() > nblk_max || n <= 0 || nd <= 0) return VIL_ERR_UNSUPPORTED;
+    if (n > n_max || n > 136 || nd > 15 || (int)kinds.size() > nblk_max || n <= 0 || nd <= 0) return VIL_ERR_UNSUPPORTED;
     // ---- device work space + kernel ------------------------------------------------------------------------------
     const size_t nn = (size_t)n * n;
-    const size_t bytes = 8 * ((size_t)nd * nd * 2 + nd + nn * 5 + (size_t)n * 3) + 4 * (size_t)(nd + n + 2 * (n + 2)) + 4096;
-    char* dw = nullptr;
-    HIPCHK(hipMalloc(&dw, bytes));
+    const int np_ = (n + 1) & ~1;
+    const size_t npp = (size_t)np_ * np_;
+    const size_t log_bytes = 16 * (size_t)30 * (size_t)(np_ - 1) * (size_t)(np_ / 2) + 16 * 30 * 16 * 8;    // MARG_MAX_SWEEPS sweeps
+    const size_t bytes = 8 * ((size_t)nd * nd * 2 + nd + nn * 5 + (size_t)n * 3) + 4 * (size_t)(nd + n) + log_bytes + 8192;
+    if (bytes > c->marg_ws_bytes) {          // grow-only work space: no allocation on the per-frame path once warm
+        if (c->marg_ws) hipFree(c->marg_ws);
+        c->marg_ws = nullptr; c->marg_ws_bytes = 0;
+        HIPCHK(hipMalloc(&c->marg_ws, bytes));
+        c->marg_ws_bytes = bytes;
+    }
+    char* dw = c->marg_ws;
     size_t off = 0;
     auto take = [&](size_t b2) { char* r = dw + off; off += (b2 + 255) & ~size_t(255); return r; };
     MargDev M;
@@ -737,29 +748,32 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     M.S = c->split ? c->P.arstage : c->P.sys[1].S; M.g = M.S + (size_t)D * D;
     int* d_drop = (int*)take(4 * (size_t)nd); int* d_keep = (int*)take(4 * (size_t)n);
     M.drop_cols = d_drop; M.keep_cols = d_keep;
-    M.pairs = (int*)take(4 * (size_t)(n + 2 + nd + 2));
     M.Add = (double*)take(8 * (size_t)nd * nd); M.Vd = (double*)take(8 * (size_t)nd * nd); M.wd = (double*)take(8 * (size_t)nd);
     M.T = (double*)take(8 * nn); M.A = (double*)take(8 * nn); M.b = (double*)take(8 * (size_t)n);
     M.V = (double*)take(8 * nn); M.w = (double*)take(8 * (size_t)n); M.J0 = (double*)take(8 * nn); M.r0 = (double*)take(8 * (size_t)n);
-    if (off > bytes) { hipFree(dw); return VIL_ERR_DEVICE; }
+    M.rlog = (double2*)take(log_bytes);
+    M.stat = (int*)take(16);
+    if (off > bytes) return VIL_ERR_DEVICE;
     HIPCHK(hipMemcpyAsync(d_drop, drop_cols.data(), 4 * (size_t)nd, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_keep, keep_cols.data(), 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     {
-        const size_t a_bytes = 8 * nn, cap = 150 * 1024;
-        const int lds_a = a_bytes <= cap ? 1 : 0, lds_v = 2 * a_bytes <= cap ? 1 : 0;
-        const size_t dyn = std::max<size_t>(4096, lds_v ? 2 * a_bytes : (lds_a ? a_bytes : 0));
+        const size_t a_bytes = 8 * npp, cap = 156 * 1024;
+        if (a_bytes > cap) return VIL_ERR_UNSUPPORTED;
+        const size_t dyn = std::max<size_t>(4096, a_bytes);
         if (dyn > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        hipLaunchKernelGGL(k_marg, dim3(1), dim3(512), dyn, c->stream, M, lds_a, lds_v);
+        hipLaunchKernelGGL(k_marg, dim3(1), dim3(MARG_THREADS), dyn, c->stream, M);
     }
     st = ensure_pin(c, 8 * (nn * 2 + 2 * (size_t)n));
-    if (st != VIL_OK) { hipFree(dw); return st; }
+    if (st != VIL_OK) return st;
     HIPCHK(hipMemcpyAsync(c->h_pin, M.J0, 8 * nn, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_pin + nn, M.A, 8 * nn, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_pin + 2 * nn, M.r0, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_pin + 2 * nn + n, M.b, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    int mstat[4] = {0, 0, 0, 0};
+    if (getenv("VIL_MARG_DEBUG")) HIPCHK(hipMemcpyAsync(mstat, M.stat, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
-    hipFree(dw);
+    if (getenv("VIL_MARG_DEBUG")) fprintf(stderr, "[vil_marginalize] n=%d nd=%d jacobi stages: %d (small) %d (n x n, %.1f sweeps)\n", n, nd, mstat[0], mstat[1], mstat[1] / (double)(np_ - 1));
     for (size_t e = 0; e < 2 * nn + 2 * (size_t)n; ++e) if (!std::isfinite(c->h_pin[e])) return VIL_ERR_NON_FINITE;
     // ---- getParameterBlocks with the address shift as an index remap (estimator.cpp:1599-1611, 1654-1677) --------------
     out->n = n; out->m = nd + n_lm_elim; out->nblk = (int)kinds.size();
