@@ -8,10 +8,9 @@
 //     replaces the reference's m x m SelfAdjointEigenSolver on an arrow-shaped matrix by a 15 x 15 one.
 //   * this kernel (one workgroup) then eliminates pose 0 + speed-bias 0 (or pose K-2 for
 //     MARGIN_SECOND_NEW) with the reference's eigenvalue-thresholded pseudo inverse (eps = 1e-8,
-//     marginalization_factor.h:70), and factors the n x n result A = V S V^T by a parallel-ordered
-//     Jacobi eigen-solver (matrix in LDS, two barriers per stage of n/2 rotations; the eigenvectors are rebuilt from
-//     the rotation log by a barrier-free, wave-synchronous replay) into linearized_jacobians = sqrt(S) V^T, linearized_residuals = S^-1/2 V^T b
-//     (marginalization_factor.cpp:301-309).
+//     marginalization_factor.h:70), and takes a square root of the n x n result A -- pivoted Cholesky in LDS
+//     (gram_sqrt below; see the note in k_marg on the choice of square root) -- into linearized_jacobians = sqrt(S) V^T,
+//     linearized_residuals = S^-1/2 V^T b (marginalization_factor.cpp:301-309).
 // Eigenvector basis / block order are implementation-defined in the reference;
 // parity is on A, b and J0^T J0, J0^T r0.
 #pragma once
@@ -28,8 +27,7 @@ struct MargDev {
     double* Add; double* Vd; double* wd;     // nd x nd work, eigenvectors, eigenvalues
     double* T;                  // n x nd
     double* A; double* b;       // n x n, n   (outputs: reduced information matrix / vector)
-    double* V; double* w;       // n x n eigenvectors (columns), n eigenvalues
-    double2* rlog;              // rotation log: (c, s) per pair per stage, MARG_MAX_SWEEPS sweeps
+    double* V; double* w;       // n x n scratch, n eigenvalues
     double* J0; double* r0;     // n x n column-major, n
     double eps;
     int* stat;                  // [0] stages of the small eigen problem, [1] stages of the n x n one (diagnostic)
@@ -39,6 +37,7 @@ namespace vd {
 
 #define MARG_THREADS 1024
 #define MARG_MAX_SWEEPS 30
+#define MARG_NMAX 136
 
 // round-robin tournament in closed form: position 0 holds player 0, positions 1..np-1 rotate by one per stage;
 // pair k of a stage = positions (k, np-1-k).  `st` = stage mod (np-1).
@@ -51,7 +50,7 @@ __device__ __forceinline__ void rr_pair(int k, int st, int np, int& p, int& q) {
     p = a < b ? a : b; q = a < b ? b : a;
 }
 
-// fp64 1/sqrt(x) and 1/x from the hardware seeds + Newton steps (full precision for the rotation to stay orthogonal)
+// fp64 1/sqrt(x) and 1/x from the hardware seeds + Newton steps
 __device__ __forceinline__ double rsqrt_nr(double x) {
     double y = __builtin_amdgcn_rsq(x);
     y = y * (1.5 - 0.5 * x * y * y);
@@ -65,140 +64,130 @@ __device__ __forceinline__ double rcp_nr(double x) {
     return y;
 }
 
-// Parallel-ordered (round-robin) two-sided Jacobi on a symmetric matrix held in LDS -- eigenvalues + a LOG of the
-// rotations; the eigenvectors are rebuilt afterwards by jacobi_vectors(), which needs no workgroup barrier at all.
-//   A: np x np working copy (np = n rounded up to even; the padding row / column is zero and never rotated).
-//   One stage = np/2 disjoint rotations (p_k, q_k).  The 2 x 2 block of A in rows (p_k, q_k), columns (p_m, q_m)
-//   becomes R_k^T B R_m and is owned by ONE thread, so a stage is: angles (np/2 lanes) | barrier | one pass over the
-//   (np/2)^2 blocks | barrier.  Returns the number of stages logged (uniform over the workgroup).
-__device__ inline int jacobi_eig(double* A, double* w, int n, double2* rlog, double* sm /*>= 3 * 68 + 40 doubles*/) {
+// Square root of a symmetric positive semi-definite matrix, in LDS, optionally orthogonalised into its eigen basis.
+//   in : M  n x n row-major in LDS (full, symmetric); bb (optional) right-hand side of length n in LDS
+//   out: row k of M = g_k with  sum_k g_k g_k^T = M_in ; lam[k] = |g_k|^2 ; bb -> y with sum_k g_k y_k = bb_in
+// Phase 1: diagonally pivoted Cholesky M = G G^T in place (the factor column produced at a step is stored in the ROW of
+//   its pivot index; pivots that lost all their digits -- d <= max(tiny, 16 n eps d_original) -- give zero rows: the
+//   directions SelfAdjointEigenSolver would report as noise-level eigenvalues).  The forward substitution G y = bb rides
+//   along as one more column.
+// Phase 2 (orthogonalise = true): one-sided (Hestenes) Jacobi on the rows of G, round-robin ordered, one wave per pair
+//   (contiguous rows: conflict-free LDS access, the three dot products are wave butterflies), one barrier per stage.
+//   Afterwards the rows are mutually orthogonal: eigenvalue lam[k], eigenvector g_k / sqrt(lam[k]).
+//   Only the 15 x 15 pseudo inverse needs this; bb must be null then.
+__device__ inline int gram_sqrt(double* M, double* lam, int n, double tiny, bool orthogonalise, double* bb, double* yout, double* sm /* >= 3 * MARG_NMAX + 64 doubles */) {
     const int t = threadIdx.x, NT = blockDim.x;
-    const int np = (n + 1) & ~1, half = np >> 1, ring = np - 1;
-    double* cs = sm;                                  // (c, s) per pair
-    int* pq = reinterpret_cast<int*>(sm + 2 * half);   // (p, q) per pair
-    double* red = sm + 3 * half;
-    const float inv_half = 1.0f / (float)half;
-    int gs = 0;
-    for (int sweep = 0; sweep < MARG_MAX_SWEEPS; ++sweep) {
-        double off = 0, dg = 0;
-        for (int e = t; e < np * np; e += NT) { const double v = A[e]; if ((e % (np + 1)) == 0) dg += v * v; else off += v * v; }
-        off = wave_sum(off); dg = wave_sum(dg);
-        __syncthreads();
-        if ((t & 63) == 0) { red[t >> 6] = off; red[16 + (t >> 6)] = dg; }
-        __syncthreads();
-        off = 0; dg = 0;
-        for (int q = 0; q < (NT >> 6); ++q) { off += red[q]; dg += red[16 + q]; }
-        if (off <= 1e-30 * dg || off <= 0.0) break;
-        for (int stage = 0; stage < ring; ++stage, ++gs) {
-            if (t < half) {
-                int p_, q_;
-                rr_pair(t, stage, np, p_, q_);
-                double c = 1.0, sn = 0.0;
-                if (q_ < n) {
-                    const double apq = A[p_ * np + q_];
-                    if (apq != 0.0) {
-                        // t = sign(d) apq / (|d| + sqrt(d^2 + apq^2)), d = (aqq - app)/2 ; c = 1/sqrt(1+t^2) ; s = t c
-                        const double d = 0.5 * (A[q_ * np + q_] - A[p_ * np + p_]);
-                        const double h2 = d * d + apq * apq;
-                        const double h = fabs(d) + h2 * rsqrt_nr(h2);
-                        const double tt = (d >= 0 ? apq : -apq) * rcp_nr(h);
-                        c = rsqrt_nr(1.0 + tt * tt); sn = tt * c;
-                    }
-                }
-                cs[2 * t] = c; cs[2 * t + 1] = sn; pq[2 * t] = p_; pq[2 * t + 1] = q_;
-                rlog[(size_t)gs * half + t] = make_double2(c, sn);
-            }
-            __syncthreads();
-            for (int e = t; e < half * half; e += NT) {
-                int k = (int)((float)e * inv_half);
-                if (k * half > e) --k; else if ((k + 1) * half <= e) ++k;
-                const int m = e - k * half;
-                const double ck = cs[2 * k], sk = cs[2 * k + 1], cm = cs[2 * m], sm_ = cs[2 * m + 1];
-                if (sk == 0.0 && sm_ == 0.0) continue;
-                const int pk = pq[2 * k], qk = pq[2 * k + 1], pm = pq[2 * m], qm = pq[2 * m + 1];
-                double* r0 = A + pk * np; double* r1 = A + qk * np;
-                const double bpp = r0[pm], bpq = r0[qm], bqp = r1[pm], bqq = r1[qm];
-                const double tpp = ck * bpp - sk * bqp, tpq = ck * bpq - sk * bqq;
-                const double tqp = sk * bpp + ck * bqp, tqq = sk * bpq + ck * bqq;
-                const bool dgb = k == m;
-                r0[pm] = cm * tpp - sm_ * tpq; r0[qm] = dgb ? 0.0 : sm_ * tpp + cm * tpq;
-                r1[pm] = dgb ? 0.0 : cm * tqp - sm_ * tqq; r1[qm] = sm_ * tqp + cm * tqq;
-            }
-            __syncthreads();
-        }
-    }
-    for (int i = t; i < n; i += NT) w[i] = A[i * np + i];
-    __syncthreads();
-    return gs;
-}
-
-// V = product of the logged rotations, V(:, k) = eigenvector of w[k].  Row i of V only ever mixes with itself, so each
-// WAVE owns whole rows (LDS, ld = np) and replays the stages in program order: lanes = the disjoint pairs of a stage,
-// no workgroup barrier inside.  The log is read 8 stages ahead to hide the L2 latency.
-__device__ inline void jacobi_vectors(double* V, int n, const double2* rlog, int nstages) {
-    const int t = threadIdx.x, NT = blockDim.x;
-    const int np = (n + 1) & ~1, half = np >> 1, ring = np - 1;
     const int wave = t >> 6, lane = t & 63, NW = NT >> 6;
-    for (int e = t; e < np * np; e += NT) V[e] = (e % (np + 1)) == 0 ? 1.0 : 0.0;
+    double* thr = sm;                                     // per index: smallest acceptable pivot
+    int* done = reinterpret_cast<int*>(sm + MARG_NMAX);   // 0 open, 1 used as pivot, 2 exhausted
+    double* wv = sm + MARG_NMAX + MARG_NMAX / 2;          // per-wave argmax value
+    int* wi = reinterpret_cast<int*>(wv + 16);            // per-wave argmax index ; wi[32] = sweep flag
+    double* ysh = wv + 40;                                // y of the current step
+    if (t < n) { const double d0 = M[t * n + t]; const double rel = 16.0 * n * 2.220446049250313e-16 * d0; thr[t] = rel > tiny ? rel : tiny; done[t] = 0; if (yout) yout[t] = 0.0; }
     __syncthreads();
-    int st = 0;
-    const int k0 = lane, k1 = 64 + lane;                 // np/2 <= 68 pairs per stage: at most two per lane
-    for (int g0 = 0; g0 < nstages; g0 += 8) {
-        const int nu = nstages - g0 < 8 ? nstages - g0 : 8;
-        double2 ra[8], rb[8];
+    // ---- phase 1 -----------------------------------------------------------------------------------------------------
+    for (int step = 0; step < n; ++step) {
+        double v = -1.0; int vi = -1;
+        if (t < n && done[t] == 0) { const double d = M[t * n + t]; if (d > thr[t]) { v = d; vi = t; } }
+        if (wave * 64 < n) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            ra[u] = (u < nu && k0 < half) ? rlog[(size_t)(g0 + u) * half + k0] : make_double2(1.0, 0.0);
-            rb[u] = (u < nu && k1 < half) ? rlog[(size_t)(g0 + u) * half + k1] : make_double2(1.0, 0.0);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            // the pairs of one stage are disjoint, stages must be applied in order
-            if (ra[u].y != 0.0) {
-                int p, q;
-                rr_pair(k0, st, np, p, q);
-                for (int i = wave; i < n; i += NW) {
-                    double* row = V + i * np;
-                    const double vp = row[p], vq = row[q];
-                    row[p] = ra[u].x * vp - ra[u].y * vq; row[q] = ra[u].y * vp + ra[u].x * vq;
-                }
+            for (int o = 32; o > 0; o >>= 1) {
+                const double v2 = __shfl_xor(v, o, 64); const int i2 = __shfl_xor(vi, o, 64);
+                if (v2 > v || (v2 == v && i2 > vi)) { v = v2; vi = i2; }
             }
-            if (rb[u].y != 0.0) {
-                int p, q;
-                rr_pair(k1, st, np, p, q);
-                for (int i = wave; i < n; i += NW) {
-                    double* row = V + i * np;
-                    const double vp = row[p], vq = row[q];
-                    row[p] = rb[u].x * vp - rb[u].y * vq; row[q] = rb[u].y * vp + rb[u].x * vq;
-                }
-            }
-            if (u < nu) { if (++st == ring) st = 0; }
+            if (lane == 0) { wv[wave] = v; wi[wave] = vi; }
         }
+        __syncthreads();
+        double pv = -1.0; int pi_ = -1;
+        for (int q = 0; q * 64 < n; ++q) { const double v2 = wv[q]; const int i2 = wi[q]; if (v2 > pv || (v2 == pv && i2 > pi_)) { pv = v2; pi_ = i2; } }
+        if (pi_ < 0) break;                               // uniform: nothing acceptable is left
+        const double isd = rsqrt_nr(pv);
+        double* rowp = M + pi_ * n;
+        if (t < n) rowp[t] = (done[t] == 0) ? rowp[t] * isd : 0.0;      // includes t == pi_: pv / sqrt(pv)
+        if (t == 0 && bb) { const double y = bb[pi_] * isd; ysh[0] = y; yout[pi_] = y; }
+        __syncthreads();
+        if (t == 0) done[pi_] = 1;
+        if (bb && t < n && t != pi_) bb[t] -= rowp[t] * ysh[0];        // rowp is zero on finished indices
+        for (int i = wave; i < n; i += NW) {
+            if (i == pi_) continue;
+            const double li = rowp[i];
+            if (li == 0.0) continue;
+            double* row = M + i * n;
+            for (int k = lane; k < n; k += 64) row[k] -= li * rowp[k];
+        }
+        __syncthreads();
     }
     __syncthreads();
+    for (int i = wave; i < n; i += NW) if (done[i] != 1) for (int k = lane; k < n; k += 64) M[i * n + k] = 0.0;
+    __syncthreads();
+    // ---- phase 2 -----------------------------------------------------------------------------------------------------
+    const int np = (n + 1) & ~1, half = np >> 1, ring = np - 1;
+    int stages = 0;
+    for (int sweep = 0; orthogonalise && sweep < MARG_MAX_SWEEPS; ++sweep) {
+        if (t == 0) wi[32] = 0;
+        __syncthreads();
+        bool rotated = false;
+        for (int stage = 0; stage < ring; ++stage, ++stages) {
+            for (int k = wave; k < half; k += NW) {
+                int p, q;
+                rr_pair(k, stage, np, p, q);
+                if (q >= n) continue;
+                double* gp = M + p * n; double* gq = M + q * n;
+                const int i0 = lane, i1 = lane + 64, i2 = lane + 128;
+                const double p0 = i0 < n ? gp[i0] : 0.0, p1 = i1 < n ? gp[i1] : 0.0, p2 = i2 < n ? gp[i2] : 0.0;
+                const double q0 = i0 < n ? gq[i0] : 0.0, q1 = i1 < n ? gq[i1] : 0.0, q2 = i2 < n ? gq[i2] : 0.0;
+                double al = p0 * p0 + p1 * p1 + p2 * p2, be = q0 * q0 + q1 * q1 + q2 * q2, ga = p0 * q0 + p1 * q1 + p2 * q2;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { al += __shfl_xor(al, o, 64); be += __shfl_xor(be, o, 64); ga += __shfl_xor(ga, o, 64); }
+                if (ga == 0.0 || ga * ga <= 1e-28 * al * be) continue;
+                rotated = true;
+                // t = sign(d) ga / (|d| + sqrt(d^2 + ga^2)), d = (be - al)/2 ; c = 1/sqrt(1+t^2) ; s = t c
+                const double d = 0.5 * (be - al);
+                const double h2 = d * d + ga * ga;
+                const double h = fabs(d) + h2 * rsqrt_nr(h2);
+                const double tt = (d >= 0 ? ga : -ga) * rcp_nr(h);
+                const double c = rsqrt_nr(1.0 + tt * tt), sn = tt * c;
+                if (i0 < n) { gp[i0] = c * p0 - sn * q0; gq[i0] = sn * p0 + c * q0; }
+                if (i1 < n) { gp[i1] = c * p1 - sn * q1; gq[i1] = sn * p1 + c * q1; }
+                if (i2 < n) { gp[i2] = c * p2 - sn * q2; gq[i2] = sn * p2 + c * q2; }
+            }
+            __syncthreads();
+        }
+        if (rotated && lane == 0) wi[32] = 1;
+        __syncthreads();
+        const int any = wi[32];
+        __syncthreads();
+        if (!any) break;
+    }
+    for (int i = wave; i < n; i += NW) {
+        double s = 0;
+        for (int k = lane; k < n; k += 64) { const double g = M[i * n + k]; s += g * g; }
+        s = wave_sum(s);
+        if (lane == 0) lam[i] = s;
+    }
+    __syncthreads();
+    return stages;
 }
 
 }  // namespace vd
 
 __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M) {
     using namespace vd;
-    __shared__ double sm[3 * 68 + 40];
-    extern __shared__ double mlds[];     // np x np: the symmetric working copy during the rotations, then the eigenvectors
+    __shared__ double sm[3 * MARG_NMAX + 64];
+    __shared__ double bsh[MARG_NMAX];
+    extern __shared__ double mlds[];     // n x n: the symmetric matrix, then its orthogonalised factor rows
     const int t = threadIdx.x, NT = blockDim.x;
     const int D = M.D, nd = M.nd, n = M.n;
-    const int npd = (nd + 1) & ~1, np = (n + 1) & ~1;
     // ---- dropped block, symmetrised (marginalization_factor.cpp:273), eigen pseudo inverse ------------
-    for (int e = t; e < npd * npd; e += NT) {
-        const int i = e / npd, j = e - i * npd;
-        mlds[e] = (i < nd && j < nd) ? 0.5 * (M.S[(size_t)M.drop_cols[i] * D + M.drop_cols[j]] + M.S[(size_t)M.drop_cols[j] * D + M.drop_cols[i]]) : 0.0;
+    for (int e = t; e < nd * nd; e += NT) {
+        const int i = e / nd, j = e - i * nd;
+        mlds[e] = 0.5 * (M.S[(size_t)M.drop_cols[i] * D + M.drop_cols[j]] + M.S[(size_t)M.drop_cols[j] * D + M.drop_cols[i]]);
     }
     __syncthreads();
-    double2* rlog_d = M.rlog + (size_t)MARG_MAX_SWEEPS * (np - 1) * (np >> 1);     // own region: never aliases the big problem's log
-    const int nsd = jacobi_eig(mlds, M.wd, nd, rlog_d, sm);
-    __threadfence_block();
-    jacobi_vectors(mlds, nd, rlog_d, nsd);
+    const int nsd = gram_sqrt(mlds, M.wd, nd, 1e-30, true, nullptr, nullptr, sm);
+    // eigenvectors (columns of Vd) = normalised factor rows
+    for (int e = t; e < nd * nd; e += NT) { const int i = e / nd, k = e - i * nd; const double lk = M.wd[k]; M.Vd[e] = lk > 0.0 ? mlds[k * nd + i] * rsqrt_nr(lk) : 0.0; }
     if (t == 0) M.stat[0] = nsd;
-    for (int e = t; e < nd * nd; e += NT) { const int i = e / nd, j = e - i * nd; M.Vd[e] = mlds[i * npd + j]; }
     __syncthreads();
     // T = A_kd pinv(A_dd) = (A_kd Vd) diag(1/w) Vd^T
     for (int e = t; e < n * nd; e += NT) {
@@ -235,26 +224,18 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M) {
     __syncthreads();
     for (int e = t; e < n * n; e += NT) { M.A[e] = M.V[e]; }
     __syncthreads();
-    for (int e = t; e < np * np; e += NT) { const int i = e / np, j = e - i * np; mlds[e] = (i < n && j < n) ? M.J0[(size_t)i * n + j] : 0.0; }
+    for (int e = t; e < n * n; e += NT) mlds[e] = M.J0[e];
+    if (t < n) bsh[t] = M.b[t];
     __syncthreads();
-    const int ns = jacobi_eig(mlds, M.w, n, M.rlog, sm);
-    __threadfence_block();
-    jacobi_vectors(mlds, n, M.rlog, ns);
+    // linearized_jacobians / linearized_residuals (marginalization_factor.cpp:301-309) are ANY pair with J0^T J0 = A and
+    // J0^T r0 = b: the reference takes sqrt(S) V^T from an eigen-decomposition, whose basis is implementation-defined
+    // (SURVEY App. C #12).  Here J0 = G^T from the pivoted Cholesky A = G G^T and r0 = G^-1 b: the prior residual
+    // r0 + J0 dx is the reference's up to a left orthogonal factor, i.e. the same cost, gradient and Gauss-Newton matrix;
+    // pivots at rounding level are dropped where the reference drops eigenvalues below eps.
+    const int ns = gram_sqrt(mlds, M.w, n, 1e-30, false, bsh, M.r0, sm);
     if (t == 0) M.stat[1] = ns;
-    for (int e = t; e < n * n; e += NT) { const int i = e / n, j = e - i * n; M.V[e] = mlds[(size_t)i * np + j]; }
-    __syncthreads();
-    // linearized_jacobians = sqrt(S) V^T (column-major n x n), linearized_residuals = S^-1/2 V^T b
-    for (int e = t; e < n * n + n; e += NT) {
-        if (e < n * n) {
-            const int j = e / n, k = e - j * n;               // column-major element (k, j): J0[j*n + k]
-            const double wk = M.w[k];
-            M.J0[e] = wk > M.eps ? sqrt(wk) * M.V[(size_t)j * n + k] : 0.0;
-        } else {
-            const int k = e - n * n;
-            const double wk = M.w[k];
-            double s = 0;
-            for (int j = 0; j < n; ++j) s += M.V[(size_t)j * n + k] * M.b[j];
-            M.r0[k] = wk > M.eps ? s / sqrt(wk) : 0.0;
-        }
+    for (int e = t; e < n * n; e += NT) {
+        const int j = e / n, k = e - j * n;                   // column-major element (k, j): J0[j*n + k]
+        M.J0[e] = mlds[k * n + j];
     }
 }

@@ -730,10 +730,7 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     if (n > n_max || n > 136 || nd > 15 || (int)kinds.size() > nblk_max || n <= 0 || nd <= 0) return VIL_ERR_UNSUPPORTED;
     // ---- device work space + kernel ------------------------------------------------------------------------------
     const size_t nn = (size_t)n * n;
-    const int np_ = (n + 1) & ~1;
-    const size_t npp = (size_t)np_ * np_;
-    const size_t log_bytes = 16 * (size_t)30 * (size_t)(np_ - 1) * (size_t)(np_ / 2) + 16 * 30 * 16 * 8;    // MARG_MAX_SWEEPS sweeps
-    const size_t bytes = 8 * ((size_t)nd * nd * 2 + nd + nn * 5 + (size_t)n * 3) + 4 * (size_t)(nd + n) + log_bytes + 8192;
+    const size_t bytes = 8 * ((size_t)nd * nd * 2 + nd + nn * 5 + (size_t)n * 3) + 4 * (size_t)(nd + n) + 8192;
     if (bytes > c->marg_ws_bytes) {          // grow-only work space: no allocation on the per-frame path once warm
         if (c->marg_ws) hipFree(c->marg_ws);
         c->marg_ws = nullptr; c->marg_ws_bytes = 0;
@@ -751,13 +748,12 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     M.Add = (double*)take(8 * (size_t)nd * nd); M.Vd = (double*)take(8 * (size_t)nd * nd); M.wd = (double*)take(8 * (size_t)nd);
     M.T = (double*)take(8 * nn); M.A = (double*)take(8 * nn); M.b = (double*)take(8 * (size_t)n);
     M.V = (double*)take(8 * nn); M.w = (double*)take(8 * (size_t)n); M.J0 = (double*)take(8 * nn); M.r0 = (double*)take(8 * (size_t)n);
-    M.rlog = (double2*)take(log_bytes);
     M.stat = (int*)take(16);
     if (off > bytes) return VIL_ERR_DEVICE;
     HIPCHK(hipMemcpyAsync(d_drop, drop_cols.data(), 4 * (size_t)nd, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_keep, keep_cols.data(), 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     {
-        const size_t a_bytes = 8 * npp, cap = 156 * 1024;
+        const size_t a_bytes = 8 * nn, cap = 156 * 1024;
         if (a_bytes > cap) return VIL_ERR_UNSUPPORTED;
         const size_t dyn = std::max<size_t>(4096, a_bytes);
         if (dyn > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
@@ -773,7 +769,7 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     if (getenv("VIL_MARG_DEBUG")) HIPCHK(hipMemcpyAsync(mstat, M.stat, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
-    if (getenv("VIL_MARG_DEBUG")) fprintf(stderr, "[vil_marginalize] n=%d nd=%d jacobi stages: %d (small) %d (n x n, %.1f sweeps)\n", n, nd, mstat[0], mstat[1], mstat[1] / (double)(np_ - 1));
+    if (getenv("VIL_MARG_DEBUG")) fprintf(stderr, "[vil_marginalize] n=%d nd=%d one-sided Jacobi stages: %d (dropped block) %d (n x n, %.1f sweeps)\n", n, nd, mstat[0], mstat[1], mstat[1] / (double)(((n + 1) & ~1) - 1));
     for (size_t e = 0; e < 2 * nn + 2 * (size_t)n; ++e) if (!std::isfinite(c->h_pin[e])) return VIL_ERR_NON_FINITE;
     // ---- getParameterBlocks with the address shift as an index remap (estimator.cpp:1599-1611, 1654-1677) --------------
     out->n = n; out->m = nd + n_lm_elim; out->nblk = (int)kinds.size();
