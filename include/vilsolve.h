@@ -248,6 +248,10 @@ void vil_destroy(vil_ctx* ctx);
  * (torch.distributed / MPI / anything), every rank calls vil_comm_init. */
 int vil_comm_unique_id(void* id128);
 int vil_comm_init(vil_ctx* ctx, const void* id128, int rank, int world);
+/* Communicator for contexts that live in ONE process (one host thread per context; <= 8): the same sharding and the
+ * same per-iteration reductions as vil_comm_init, summed through device memory instead of RCCL.  Also lets a sharded
+ * solve be exercised on a single device (tests). */
+int vil_comm_init_local(vil_ctx** ctxs, int n);
 
 /* replaces estimator.cpp:1126-1419 (build ceres::Problem ... ceres::Solve): state is updated in
  * place on success and left UNCHANGED on any error. */

@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <memory>
+#include <pthread.h>
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types only: RCCL is bound at run time (dlopen) so that a process which already
@@ -58,6 +60,24 @@ struct Arena {                     // one device allocation per uploaded window,
 
 }  // namespace
 
+// In-process communicator: the contexts of ONE process (one host thread each) sum their buffers through device
+// memory.  Same call sites and the same deterministic result on every rank as the RCCL path; used where the ranks share
+// a process, and by the tests to run a sharded solve on a single device.
+struct LocalComm {
+    int n = 0;
+    pthread_barrier_t bar;
+    double* ptr[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ~LocalComm() { if (n) pthread_barrier_destroy(&bar); }
+};
+struct PeerPtrs { const double* p[8]; int n; };
+__global__ void k_sum_peers(double* out, PeerPtrs pp, size_t cnt) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (size_t)gridDim.x * blockDim.x) {
+        double s = 0;
+        for (int r = 0; r < pp.n; ++r) s += pp.p[r][e];          // rank order: identical bits on every rank
+        out[e] = s;
+    }
+}
+
 struct vil_ctx {
     int device = 0, rank = 0, world = 1;
     hipStream_t stream = nullptr;
@@ -79,6 +99,8 @@ struct vil_ctx {
     size_t h_pin_bytes = 0;
     std::vector<int> prior_joff;
     ncclComm_t comm = nullptr;     // RCCL communicator over xGMI (world > 1)
+    std::shared_ptr<struct LocalComm> lcomm;   // in-process communicator (vil_comm_init_local)
+    double* lc_tmp = nullptr; size_t lc_cap = 0;
     bool sharded = false;          // the resident problem is this rank's shard of the factor set
     bool split = false;            // step kernel launched as A | all-reduce | B
     int last_live = 5;             // live sweep launches of the previous solve (sizes the first launch chunk)
@@ -168,6 +190,7 @@ void vil_destroy(vil_ctx* c) {
     if (c->h_ctl) hipHostFree(c->h_ctl);
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->marg_ws) hipFree(c->marg_ws);
+    if (c->lc_tmp) hipFree(c->lc_tmp);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -402,7 +425,7 @@ static int upload_sharded(vil_ctx* c, const vil_problem* p, const vil_state* s) 
 
 int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
-    if (c->world > 1 && c->comm) return upload_sharded(c, p, s);     // a world > 1 context without a communicator works un-sharded
+    if (c->world > 1 && (c->comm || c->lcomm)) return upload_sharded(c, p, s);     // a world > 1 context without a communicator works un-sharded
     return upload_impl(c, p, s, false);
 }
 
@@ -413,6 +436,25 @@ __global__ void k_lam_delta(DevP P, int lb, int le) {      // owner's change of 
 __global__ void k_lam_apply(DevP P) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l < P.L) { const double v = P.lam0[l] + P.tmpl[l]; P.x[0][xo_lam(P) + l] = v; P.x[1][xo_lam(P) + l] = v; }
+}
+
+// sum over the ranks of the communicator, in stream order
+static int all_reduce(vil_ctx* c, double* buf, size_t cnt) {
+    if (c->comm) return g_rccl.AllReduce(buf, buf, cnt, ncclDouble, ncclSum, c->comm, c->stream) == ncclSuccess ? VIL_OK : VIL_ERR_COMM;
+    if (c->lcomm) {
+        LocalComm* lc = c->lcomm.get();
+        if (cnt > c->lc_cap) { if (c->lc_tmp) hipFree(c->lc_tmp); c->lc_tmp = nullptr; c->lc_cap = 0; HIPCHK(hipMalloc(&c->lc_tmp, 8 * cnt)); c->lc_cap = cnt; }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        lc->ptr[c->rank] = buf;
+        pthread_barrier_wait(&lc->bar);
+        PeerPtrs pp; pp.n = lc->n;
+        for (int r = 0; r < 8; ++r) pp.p[r] = r < lc->n ? lc->ptr[r] : nullptr;
+        hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)std::min<size_t>(256, (cnt + 255) / 256)), dim3(256), 0, c->stream, c->lc_tmp, pp, cnt);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        pthread_barrier_wait(&lc->bar);                       // every rank has read every buffer
+        HIPCHK(hipMemcpyAsync(buf, c->lc_tmp, 8 * cnt, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return VIL_OK;
 }
 
 static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
@@ -430,10 +472,10 @@ static void launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEv
     }
     // multi-GPU: all-reduce the partial reduced system (+ step norms), step A, all-reduce 5 scalars, step B
     const size_t cnt = (size_t)c->D * c->D + 3 * (size_t)c->D + 3;
-    if (c->comm) g_rccl.AllReduce(c->P.arstage, c->P.arstage, cnt, ncclDouble, ncclSum, c->comm, c->stream);
+    all_reduce(c, c->P.arstage, cnt);
     if (c->step_lds) hipLaunchKernelGGL((k_step<true, 1>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
     else hipLaunchKernelGGL((k_step<false, 1>), dim3(1), dim3(VIL_STEP_THREADS), 0, c->stream, c->P, so);
-    if (c->comm) g_rccl.AllReduce(c->P.scal, c->P.scal, 8, ncclDouble, ncclSum, c->comm, c->stream);
+    all_reduce(c, c->P.scal, 8);
     if (c->step_lds) hipLaunchKernelGGL((k_step<true, 2>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
     else hipLaunchKernelGGL((k_step<false, 2>), dim3(1), dim3(VIL_STEP_THREADS), 0, c->stream, c->P, so);
 }
@@ -529,7 +571,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     if (c->sharded && c->L) {   // every rank updated only the landmarks it owns: merge the owners' changes
         const int nb = (c->L + 255) / 256;
         hipLaunchKernelGGL(k_lam_delta, dim3(nb), dim3(256), 0, c->stream, c->P, c->lm_b, c->lm_e);
-        if (g_rccl.AllReduce(c->P.tmpl, c->P.tmpl, (size_t)c->L, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return VIL_ERR_COMM;
+        if (all_reduce(c, c->P.tmpl, (size_t)c->L) != VIL_OK) return VIL_ERR_COMM;
         hipLaunchKernelGGL(k_lam_apply, dim3(nb), dim3(256), 0, c->stream, c->P);
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -646,7 +688,7 @@ int vil_linearize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vi
     if (st != VIL_OK) return st;
     const double* src = c->split ? c->P.arstage : c->P.sys[1].ar;
     if (c->sharded) {   // each rank linearised its shard: sum over ranks
-        if (g_rccl.AllReduce(c->P.arstage, c->P.arstage, D * D + 3 * D + 3, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return VIL_ERR_COMM;
+        if (all_reduce(c, c->P.arstage, D * D + 3 * D + 3) != VIL_OK) return VIL_ERR_COMM;
         src = c->P.arstage;
     }
     HIPCHK(hipMemcpyAsync(c->h_pin, src, 8 * D * D, hipMemcpyDeviceToHost, c->stream));
@@ -873,7 +915,20 @@ int vil_comm_init(vil_ctx* c, const void* id128, int rank, int world) {
     if (!g_rccl.load()) return VIL_ERR_COMM;
     if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     if (g_rccl.CommInitRank(&c->comm, world, id, rank) != ncclSuccess) return VIL_ERR_COMM;
-    c->rank = rank; c->world = world; c->uploaded = false;
+    c->rank = rank; c->world = world; c->uploaded = false; c->lcomm.reset();
+    return VIL_OK;
+}
+int vil_comm_init_local(vil_ctx** ctxs, int n) {
+    if (!ctxs || n < 1 || n > 8) return VIL_ERR_INVALID_ARGUMENT;
+    for (int r = 0; r < n; ++r) if (!ctxs[r]) return VIL_ERR_INVALID_ARGUMENT;
+    auto lc = std::make_shared<LocalComm>();
+    if (pthread_barrier_init(&lc->bar, nullptr, (unsigned)n) != 0) return VIL_ERR_COMM;
+    lc->n = n;
+    for (int r = 0; r < n; ++r) {
+        vil_ctx* c = ctxs[r];
+        if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+        c->lcomm = lc; c->rank = r; c->world = n; c->uploaded = false;
+    }
     return VIL_OK;
 }
 

@@ -41,3 +41,51 @@ def test_forced_split_path_matches_oracle(use_comm):
     env = dict(os.environ, VIL_FORCE_SPLIT="1", USE_COMM=use_comm)
     out = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, ROOT)], env=env, capture_output=True, text=True, timeout=600)
     assert "SPLIT_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+SHARD_SCRIPT = r'''
+import sys, os, ctypes as C, threading
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import __graft_entry__ as g; g.load_package()
+from mvil_fusion_amd import abi, lib, synth
+import oracle_lib
+orc = oracle_lib.open_oracle()
+pf = lambda pre: orc.marginalize(pre).to_prior()
+for world in (2, 3):
+    bes = [lib.open_vilsolve() for _ in range(world)]
+    arr = (C.c_void_p * world)(*[b.ctx for b in bes])
+    assert bes[0].lib.vil_comm_init_local(arr, world) == 0
+    for cid, kw in ((2, dict(L=150, n_plane=3000, n_edge=800)), (1, {})):
+        wo = synth.make_config(cid, prior_fn=pf, **kw)
+        ws = [synth.make_config(cid, prior_fn=pf, **kw) for _ in range(world)]
+        res = [None] * world
+        def run(r):
+            try:
+                lin = bes[r].linearize(ws[r])                                           # at the initial state, before the solve moves it
+                res[r] = ("ok", bes[r].solve(ws[r]), lin)                              # every rank: its shard, the same reductions
+            except Exception as e:
+                res[r] = ("err", repr(e))
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in th]; [t.join(300) for t in th]
+        assert all(x is not None and x[0] == "ok" for x in res), res
+        co, So, go = orc.linearize(wo)
+        so = orc.solve(wo)
+        for r in range(world):
+            sg, (cg, Sg, gg) = res[r][1], res[r][2]
+            assert sg.iterations == so.iterations and sg.termination == so.termination, (world, cid, r, sg.iterations, so.iterations)
+            assert abs(sg.final_cost - so.final_cost) <= 1e-7 * so.final_cost
+            if wo.prior.n:
+                assert np.abs(ws[r].pose - wo.pose).max() < 1e-6 and np.abs(ws[r].inv_depth - wo.inv_depth).max() < 1e-6
+            assert np.array_equal(ws[r].pose, ws[0].pose) and np.array_equal(ws[r].inv_depth, ws[0].inv_depth)     # ranks agree bit for bit
+            assert abs(cg - co) <= 1e-11 * co and np.abs(Sg - So).max() <= 1e-9 * np.abs(So).max()
+    for b in bes: b.close()
+print("SHARD_OK")
+'''
+
+
+def test_sharded_solve_local_communicator():
+    """2 and 3 ranks of the factor-sharded solve on ONE device through the in-process communicator: the shard ranges,
+    ranks without IMU / prior factors, the split step, the scalar reduction and the landmark merge all run as on N GPUs."""
+    out = subprocess.run([sys.executable, "-c", SHARD_SCRIPT % (ROOT, ROOT)], capture_output=True, text=True, timeout=900)
+    assert "SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
