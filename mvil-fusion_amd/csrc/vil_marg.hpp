@@ -68,14 +68,14 @@ __device__ __forceinline__ double rcp_nr(double x) {
 //   in : M  n x n row-major in LDS (full, symmetric); bb (optional) right-hand side of length n in LDS
 //   out: row k of M = g_k with  sum_k g_k g_k^T = M_in ; lam[k] = |g_k|^2 ; bb -> y with sum_k g_k y_k = bb_in
 // Phase 1: diagonally pivoted Cholesky M = G G^T in place (the factor column produced at a step is stored in the ROW of
-//   its pivot index; pivots that lost all their digits -- d <= max(tiny, 16 n eps d_original) -- give zero rows: the
-//   directions SelfAdjointEigenSolver would report as noise-level eigenvalues).  The forward substitution G y = bb rides
+//   its pivot index; pivots that lost all their digits -- d <= max(tiny, 16 n eps d_original, floor_rel max_diag) --
+//   give zero rows: the directions SelfAdjointEigenSolver would report as noise-level eigenvalues).  The forward substitution G y = bb rides
 //   along as one more column.
 // Phase 2 (orthogonalise = true): one-sided (Hestenes) Jacobi on the rows of G, round-robin ordered, one wave per pair
 //   (contiguous rows: conflict-free LDS access, the three dot products are wave butterflies), one barrier per stage.
 //   Afterwards the rows are mutually orthogonal: eigenvalue lam[k], eigenvector g_k / sqrt(lam[k]).
 //   Only the 15 x 15 pseudo inverse needs this; bb must be null then.
-__device__ inline int gram_sqrt(double* M, double* lam, int n, double tiny, bool orthogonalise, double* bb, double* yout, double* sm /* >= 3 * MARG_NMAX + 64 doubles */) {
+__device__ inline int gram_sqrt(double* M, double* lam, int n, double tiny, double floor_rel, bool orthogonalise, double* bb, double* yout, double* sm /* >= 3 * MARG_NMAX + 64 doubles */) {
     const int t = threadIdx.x, NT = blockDim.x;
     const int wave = t >> 6, lane = t & 63, NW = NT >> 6;
     double* thr = sm;                                     // per index: smallest acceptable pivot
@@ -83,7 +83,19 @@ __device__ inline int gram_sqrt(double* M, double* lam, int n, double tiny, bool
     double* wv = sm + MARG_NMAX + MARG_NMAX / 2;          // per-wave argmax value
     int* wi = reinterpret_cast<int*>(wv + 16);            // per-wave argmax index ; wi[32] = sweep flag
     double* ysh = wv + 40;                                // y of the current step
-    if (t < n) { const double d0 = M[t * n + t]; const double rel = 16.0 * n * 2.220446049250313e-16 * d0; thr[t] = rel > tiny ? rel : tiny; done[t] = 0; if (yout) yout[t] = 0.0; }
+    // largest diagonal entry (every wave reduces the whole diagonal: n <= 136 = three values per lane)
+    double dmax = 0.0;
+    for (int i = lane; i < n; i += 64) dmax = fmax(dmax, M[i * n + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
+    if (t < n) {
+        // acceptable pivot: above the rounding level of its own entry AND of the matrix it came from.  The input is a
+        // Schur complement whose entries carry ~1e-11 relative noise from the cancellation upstream: a gauge direction
+        // shows up as a pivot of pure noise, and dividing a column by its root would amplify that noise.
+        const double d0 = M[t * n + t];
+        const double rel = fmax(16.0 * n * 2.220446049250313e-16 * d0, floor_rel * dmax);
+        thr[t] = rel > tiny ? rel : tiny; done[t] = 0; if (yout) yout[t] = 0.0;
+    }
     __syncthreads();
     // ---- phase 1 -----------------------------------------------------------------------------------------------------
     for (int step = 0; step < n; ++step) {
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M) {
         mlds[e] = 0.5 * (M.S[(size_t)M.drop_cols[i] * D + M.drop_cols[j]] + M.S[(size_t)M.drop_cols[j] * D + M.drop_cols[i]]);
     }
     __syncthreads();
-    const int nsd = gram_sqrt(mlds, M.wd, nd, 1e-30, true, nullptr, nullptr, sm);
+    const int nsd = gram_sqrt(mlds, M.wd, nd, 1e-30, 0.0, true, nullptr, nullptr, sm);
     // eigenvectors (columns of Vd) = normalised factor rows
     for (int e = t; e < nd * nd; e += NT) { const int i = e / nd, k = e - i * nd; const double lk = M.wd[k]; M.Vd[e] = lk > 0.0 ? mlds[k * nd + i] * rsqrt_nr(lk) : 0.0; }
     if (t == 0) M.stat[0] = nsd;
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M) {
     // (SURVEY App. C #12).  Here J0 = G^T from the pivoted Cholesky A = G G^T and r0 = G^-1 b: the prior residual
     // r0 + J0 dx is the reference's up to a left orthogonal factor, i.e. the same cost, gradient and Gauss-Newton matrix;
     // pivots at rounding level are dropped where the reference drops eigenvalues below eps.
-    const int ns = gram_sqrt(mlds, M.w, n, 1e-30, false, bsh, M.r0, sm);
+    const int ns = gram_sqrt(mlds, M.w, n, 1e-30, 1e-10, false, bsh, M.r0, sm);
     if (t == 0) M.stat[1] = ns;
     for (int e = t; e < n * n; e += NT) {
         const int j = e / n, k = e - j * n;                   // column-major element (k, j): J0[j*n + k]

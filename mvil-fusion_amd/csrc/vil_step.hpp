@@ -127,10 +127,17 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double& sq, double& rs) {
 __device__ __forceinline__ int tri_off(int i) { return (i * (i + 1)) >> 1; }
 
 // ---- tiled lower storage of the (D+1) x (D+1) reduced matrix (last row = right-hand side): 16 x 16 tiles,
-//      tile (I, J), J <= I, at ((I(I+1)/2 + J) << 8); element (r, c) of a tile at r*16 + c.  An MFMA operand /
-//      accumulator address is then `wave-uniform tile base + per-lane constant`.
-__device__ __forceinline__ int tl_base(int I, int J) { return (tri_off(I) + J) << 8; }
-__device__ __forceinline__ int tl_idx(int i, int j) { return tl_base(i >> 4, j >> 4) + ((i & 15) << 4) + (j & 15); }
+//      tile (I, J), J <= I, at (I(I+1)/2 + J) * TILE_SZ; element (r, c) of a tile at r*TILE_RS + c.  An MFMA operand /
+//      accumulator address is then `wave-uniform tile base + per-lane constant`.  TILE_RS = 17 (one padding double
+//      per row): an MFMA A/B operand fragment is 16 rows x 4 k -- with a row stride of 16 doubles its 16 row-lanes
+//      fall on two LDS bank pairs (8-way conflict, measured 1400 cycles per block step for the operand reads alone);
+//      stride 17 spreads them over 16 bank pairs, and the panel's thread-per-row accesses likewise.
+#define TILE_RS 17
+#define TILE_SZ (16 * TILE_RS)
+__device__ __forceinline__ int tl_base(int I, int J) { return (tri_off(I) + J) * TILE_SZ; }
+__device__ __forceinline__ int tl_idx(int i, int j) { return tl_base(i >> 4, j >> 4) + (i & 15) * TILE_RS + (j & 15); }
+// logical element e = tile*256 + r*16 + c (how the fill loops enumerate the tiles) -> storage index
+__device__ __forceinline__ int tl_phys(int e) { return (e >> 8) * TILE_SZ + ((e >> 4) & 15) * TILE_RS + (e & 15); }
 
 // Blocked right-looking Cholesky, NB = 4, on the tiled array A.  fp64 dependent-op latency on gfx950 is ~32
 // cycles and a workgroup barrier only ~44, so the algorithm keeps every serial chain short instead of batching:
@@ -145,8 +152,8 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
     const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
     const int R = D + 1;                 // rows including the rhs row
     const int T = (R + 15) >> 4;         // tile rows
-    const int la = ((lane & 15) << 4) + (lane >> 4);       // operand element (row lane&15, k lane>>4) inside a tile
-    const int lc = ((lane >> 4) << 4) + (lane & 15);       // accumulator element (row lane>>4 (+4g), col lane&15)
+    const int la = (lane & 15) * TILE_RS + (lane >> 4);     // operand element (row lane&15, k lane>>4) inside a tile
+    const int lc = (lane >> 4) * TILE_RS + (lane & 15);     // accumulator element (row lane>>4 (+4g), col lane&15)
 #ifdef VIL_STAMPS
     long long tacc[3] = {0, 0, 0}, tprev = 0;
     #define CSTAMP(k) do { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); if (k >= 0) tacc[k < 0 ? 0 : k] += tt_ - tprev; tprev = tt_; } while (0)
@@ -169,7 +176,7 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
                 tIJ[u] = (I << 8) | J;
                 const int cb = tl_base(I, J) + lc;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) Creg[u][q] = A[cb + (q << 6)];
+                for (int q = 0; q < 4; ++q) Creg[u][q] = A[cb + q * (4 * TILE_RS)];
             }
         }
     }
@@ -182,16 +189,16 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
             for (int u = 0; u < CH_SLOTS; ++u) if (tIJ[u] >= 0 && (tIJ[u] & 255) == Kt) {
                 const int cb = tl_base(tIJ[u] >> 8, Kt) + lc;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) A[cb + (q << 6)] = Creg[u][q];
+                for (int q = 0; q < 4; ++q) A[cb + q * (4 * TILE_RS)] = Creg[u][q];
             }
             __syncthreads();
         }
         // ---- 1. diagonal 4x4 block, redundantly per thread (identity padding for a short last block) ----------
-        const int db = tl_base(Kt, Kt) + (ko << 4) + ko;
+        const int db = tl_base(Kt, Kt) + ko * TILE_RS + ko;
         double d00 = A[db], d10 = 0, d11 = 1, d20 = 0, d21 = 0, d22 = 1, d30 = 0, d31 = 0, d32 = 0, d33 = 1;
-        if (nb > 1) { d10 = A[db + 16]; d11 = A[db + 17]; }
-        if (nb > 2) { d20 = A[db + 32]; d21 = A[db + 33]; d22 = A[db + 34]; }
-        if (nb > 3) { d30 = A[db + 48]; d31 = A[db + 49]; d32 = A[db + 50]; d33 = A[db + 51]; }
+        if (nb > 1) { d10 = A[db + TILE_RS]; d11 = A[db + TILE_RS + 1]; }
+        if (nb > 2) { d20 = A[db + 2 * TILE_RS]; d21 = A[db + 2 * TILE_RS + 1]; d22 = A[db + 2 * TILE_RS + 2]; }
+        if (nb > 3) { d30 = A[db + 3 * TILE_RS]; d31 = A[db + 3 * TILE_RS + 1]; d32 = A[db + 3 * TILE_RS + 2]; d33 = A[db + 3 * TILE_RS + 3]; }
         double l00, r0_, l11, r1_, l22, r2_, l33, r3_;
         bool ok = d00 > 0.0 && isfinite(d00);
         sqrt_rsqrt(d00, l00, r0_);
@@ -209,7 +216,7 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
         // ---- 2. panel rows (incl. the rhs row): forward substitution against the block ----------------------------
         const int r0 = kb + nb;
         for (int i = r0 + t; i < R; i += NT) {
-            const int base = tl_base(i >> 4, Kt) + ((i & 15) << 4) + ko;
+            const int base = tl_base(i >> 4, Kt) + (i & 15) * TILE_RS + ko;
             const double a0 = A[base], a1 = nb > 1 ? A[base + 1] : 0.0, a2 = nb > 2 ? A[base + 2] : 0.0, a3 = nb > 3 ? A[base + 3] : 0.0;
             const double x0 = a0 * r0_;
             const double x1 = (a1 - x0 * l10) * r1_;
@@ -229,9 +236,9 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
         }
         if (t == 0) {                   // the factored block itself and the reciprocal pivots
             A[db] = l00; s.dinv[kb] = r0_;
-            if (nb > 1) { A[db + 16] = l10; A[db + 17] = l11; s.dinv[kb + 1] = r1_; }
-            if (nb > 2) { A[db + 32] = l20; A[db + 33] = l21; A[db + 34] = l22; s.dinv[kb + 2] = r2_; }
-            if (nb > 3) { A[db + 48] = l30; A[db + 49] = l31; A[db + 50] = l32; A[db + 51] = l33; s.dinv[kb + 3] = r3_; }
+            if (nb > 1) { A[db + TILE_RS] = l10; A[db + TILE_RS + 1] = l11; s.dinv[kb + 1] = r1_; }
+            if (nb > 2) { A[db + 2 * TILE_RS] = l20; A[db + 2 * TILE_RS + 1] = l21; A[db + 2 * TILE_RS + 2] = l22; s.dinv[kb + 2] = r2_; }
+            if (nb > 3) { A[db + 3 * TILE_RS] = l30; A[db + 3 * TILE_RS + 1] = l31; A[db + 3 * TILE_RS + 2] = l32; A[db + 3 * TILE_RS + 3] = l33; s.dinv[kb + 3] = r3_; }
         }
         __syncthreads();
         CSTAMP(1);
@@ -254,7 +261,7 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
                     const d4 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, z, 0, 0, 0);
                     const int cb = tl_base(I, J) + lc;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) A[cb + (g << 6)] -= acc[g];
+                    for (int g = 0; g < 4; ++g) A[cb + g * (4 * TILE_RS)] -= acc[g];
                 }
             }
         } else { if (r0 < R) {
@@ -281,7 +288,7 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (u < cnt) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) A[cb[u] + lc + (g << 6)] -= acc[u][g];   // rows / cols outside [r0, R) got zero operands
+                    for (int g = 0; g < 4; ++g) A[cb[u] + lc + g * (4 * TILE_RS)] -= acc[u][g];   // rows / cols outside [r0, R) got zero operands
                 }
             }
         } }
@@ -304,7 +311,7 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
     const int nblk = (D + STEP_NB - 1) / STEP_NB;
     for (int blk = nblk - 1; blk >= 0; --blk) {
         const int kb = blk * STEP_NB, nb = min(STEP_NB, D - kb);
-        const int db = tl_base(kb >> 4, kb >> 4) + ((kb & 15) << 4) + (kb & 15);
+        const int db = tl_base(kb >> 4, kb >> 4) + (kb & 15) * TILE_RS + (kb & 15);
         const double y0 = s.y[kb], y1 = nb > 1 ? s.y[kb + 1] : 0.0, y2 = nb > 2 ? s.y[kb + 2] : 0.0, y3 = nb > 3 ? s.y[kb + 3] : 0.0;
         const double* X = s.Xb + blk * 10;      // rows of L_kk^-1: [x00 | x10 x11 | x20 x21 x22 | x30 x31 x32 x33] (identity padded)
         // x_blk = X^T y_blk: four short independent dot products instead of an 8-deep triangular-solve chain
@@ -314,11 +321,11 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
         const double x3 = X[9] * y3;
         if (t == 0) { s.xs[kb] = x0; if (nb > 1) s.xs[kb + 1] = x1; if (nb > 2) s.xs[kb + 2] = x2; if (nb > 3) s.xs[kb + 3] = x3; }
         for (int c = t; c < kb; c += NT) {              // y_c -= sum_r L[kb+r][c] x_r
-            const int base = tl_base(kb >> 4, c >> 4) + ((kb & 15) << 4) + (c & 15);
+            const int base = tl_base(kb >> 4, c >> 4) + (kb & 15) * TILE_RS + (c & 15);
             double v0 = s.y[c] - A[base] * x0, v1 = 0.0;
-            if (nb > 1) v1 -= A[base + 16] * x1;
-            if (nb > 2) v0 -= A[base + 32] * x2;
-            if (nb > 3) v1 -= A[base + 48] * x3;
+            if (nb > 1) v1 -= A[base + TILE_RS] * x1;
+            if (nb > 2) v0 -= A[base + 2 * TILE_RS] * x2;
+            if (nb > 3) v1 -= A[base + 3 * TILE_RS] * x3;
             s.y[c] = v0 + v1;
         }
         __syncthreads();
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                     m = s.sc[i] * v * s.sc[j];
                     if (i == j) m += mu * s.dcs[i] * s.dcs[i];
                 } else if (i == D && j < D) m = s.sc[j] * sb.gred[j];
-                if constexpr (LDSM) Alds[e] = m; else Ag[e] = m;
+                if constexpr (LDSM) Alds[tl_phys(e)] = m; else Ag[tl_phys(e)] = m;
             }
         }
         for (int e = t + PF_N * VIL_STEP_THREADS; e < NTL; e += VIL_STEP_THREADS) {     // large windows (K > 10): remainder, direct loads
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                 m = s.sc[i] * v * s.sc[j];
                 if (i == j) m += mu * s.dcs[i] * s.dcs[i];
             } else if (i == D && j < D) m = s.sc[j] * sb.gred[j];
-            if constexpr (LDSM) Alds[e] = m; else Ag[e] = m;
+            if constexpr (LDSM) Alds[tl_phys(e)] = m; else Ag[tl_phys(e)] = m;
         }
         STAMP(11);
         bsum3<true>(g2, q, gm, s);

@@ -369,7 +369,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     P.split = c->split ? 1 : 0;
     put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.Sl); put(nullptr, 8 * (size_t)D, (void**)&P.Sc); put(nullptr, 8 * (size_t)D, (void**)&P.dc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.dl);
     put(nullptr, 8 * (size_t)D, (void**)&P.gradc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gradl); put(nullptr, 8 * (size_t)D, (void**)&P.gnc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gnl);
-    put(nullptr, 8 * (size_t)D * D, (void**)&P.M); put(nullptr, 8 * (size_t)D, (void**)&P.stepc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.stepl);
+    { const size_t Tm = (size_t)(D + 16) / 16; put(nullptr, 8 * std::max((size_t)D * D, (size_t)TILE_SZ * (Tm * (Tm + 1) / 2)), (void**)&P.M); } put(nullptr, 8 * (size_t)D, (void**)&P.stepc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.stepl);
     put(nullptr, 8 * (size_t)D, (void**)&P.tmpc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.tmpl);
     put(nullptr, sizeof(Ctl), (void**)&P.ctl);
     put(nullptr, 8 * 64, (void**)&P.dbg);
@@ -387,7 +387,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     if (c->lds_sweep > 160 * 1024) return VIL_ERR_UNSUPPORTED;
     HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep));
     c->n_blocks_reduce = (D * (D + 1) / 2 + RED_EPW - 1) / RED_EPW + (2 * D + RED_EPW - 1) / RED_EPW + 1;
-    { const size_t T = (size_t)(D + 1 + 15) / 16; c->lds_step = 8 * 256 * (T * (T + 1) / 2); }   // 16x16-tiled lower storage incl. the rhs row
+    { const size_t T = (size_t)(D + 1 + 15) / 16; c->lds_step = 8 * TILE_SZ * (T * (T + 1) / 2); }   // 16x16-tiled (row stride 17) lower storage incl. the rhs row
     c->step_lds = c->lds_step + sizeof(vd::StepShared) + 256 <= 160 * 1024;
     if (c->step_lds) {
         HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));

@@ -42,6 +42,6 @@ def test_replay_lockstep(hip, oracle):
             sc = np.sqrt(np.outer(np.abs(np.diag(Ao)) + 1e-300, np.abs(np.diag(Ao)) + 1e-300))
             assert (np.abs(Ag - Ao) / sc).max() < 2e-5          # states agree to ~1e-9; the pseudo-inverse of the dropped block amplifies that
             Jg = pg.to_prior().J_matrix()
-            assert (np.abs(Jg.T @ Jg - 0.5 * (Ag + Ag.T)) / sc).max() < 1e-9          # the square root reproduces the library's own A
+            assert np.abs(Jg.T @ Jg - 0.5 * (Ag + Ag.T)).max() < 1e-8 * np.abs(Ag).max()   # J0^T J0 = A (marginalization_factor.cpp:313), normwise: pivots below 1e-10 max(diag) are noise and dropped
         assert rp.absorb(w, pg, flag)
     assert flags == {abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW}
