@@ -301,32 +301,72 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
     return true;
 }
 
-// back substitution L^T x = y (y = row D of A): per 4x4 block every thread solves the block redundantly, the threads
-// owning a column c < kb fold x_blk into y_c; one barrier per block.  Result in s.y[0..D).
+// back substitution L^T x = y (y = row D of A) with 16 x 16 diagonal blocks: 10 dependent stages instead of 40.
+//   (I)  W_t = L_tt^-1 for every diagonal tile at once (one thread per tile column, 16-step forward substitution in
+//        registers); W_t is stored TRANSPOSED into the unused upper triangle of its tile, its diagonal is s.dinv.
+//   (II) from the last tile up: x_blk = W^T y_blk (16 lanes, one short dot product each), barrier, the threads owning a
+//        column c < kb fold x_blk into y_c (16-term dot product down a tile column), barrier.
+// Result in s.y[0..D).
 template <class PTR>
 __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
     const int t = threadIdx.x, NT = blockDim.x;
     for (int i = t; i < D; i += NT) s.y[i] = A[tl_idx(D, i)];
+    const int TD = (D + 15) >> 4;                           // diagonal tiles that hold rows of L
+    for (int i = D + t; i < (TD << 4); i += NT) { s.xs[i] = 0.0; s.y[i] = 0.0; }   // padding of the last tile: its products vanish
+    // ---- (I) ----------------------------------------------------------------------------------------------------
+    for (int q = t; q < (TD << 4); q += NT) {
+        const int tt = q >> 4, j = q & 15;
+        const int n_t = min(16, D - (tt << 4));
+        if (j < n_t) {
+            const int tb = tl_base(tt, tt);
+            const double* dv = s.dinv + (tt << 4);
+            double w[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < i; ++k) {                  // w_k = 0 for k < j: the products vanish, no predicate needed
+                    const double l = A[tb + i * TILE_RS + k];
+                    if (k & 1) acc1 += l * w[k]; else acc0 += l * w[k];
+                }
+                w[i] = i < j ? 0.0 : (i == j ? dv[i] : (i < n_t ? -(acc0 + acc1) * dv[i] : 0.0));
+            }
+#pragma unroll
+            for (int i = 1; i < 16; ++i) if (i > j && i < n_t) A[tb + j * TILE_RS + i] = w[i];      // W_ij at (j, i)
+        }
+    }
     __syncthreads();
-    const int nblk = (D + STEP_NB - 1) / STEP_NB;
-    for (int blk = nblk - 1; blk >= 0; --blk) {
-        const int kb = blk * STEP_NB, nb = min(STEP_NB, D - kb);
-        const int db = tl_base(kb >> 4, kb >> 4) + (kb & 15) * TILE_RS + (kb & 15);
-        const double y0 = s.y[kb], y1 = nb > 1 ? s.y[kb + 1] : 0.0, y2 = nb > 2 ? s.y[kb + 2] : 0.0, y3 = nb > 3 ? s.y[kb + 3] : 0.0;
-        const double* X = s.Xb + blk * 10;      // rows of L_kk^-1: [x00 | x10 x11 | x20 x21 x22 | x30 x31 x32 x33] (identity padded)
-        // x_blk = X^T y_blk: four short independent dot products instead of an 8-deep triangular-solve chain
-        const double x0 = (X[0] * y0 + X[1] * y1) + (X[3] * y2 + X[6] * y3);
-        const double x1 = (X[2] * y1 + X[4] * y2) + X[7] * y3;
-        const double x2 = X[5] * y2 + X[8] * y3;
-        const double x3 = X[9] * y3;
-        if (t == 0) { s.xs[kb] = x0; if (nb > 1) s.xs[kb + 1] = x1; if (nb > 2) s.xs[kb + 2] = x2; if (nb > 3) s.xs[kb + 3] = x3; }
-        for (int c = t; c < kb; c += NT) {              // y_c -= sum_r L[kb+r][c] x_r
-            const int base = tl_base(kb >> 4, c >> 4) + (kb & 15) * TILE_RS + (c & 15);
-            double v0 = s.y[c] - A[base] * x0, v1 = 0.0;
-            if (nb > 1) v1 -= A[base + TILE_RS] * x1;
-            if (nb > 2) v0 -= A[base + 2 * TILE_RS] * x2;
-            if (nb > 3) v1 -= A[base + 3 * TILE_RS] * x3;
-            s.y[c] = v0 + v1;
+#ifdef VIL_STAMPS
+    if (t == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); s.tacc[0] = tt_; }
+#endif
+    // ---- (II) ---------------------------------------------------------------------------------------------------
+    for (int blk = TD - 1; blk >= 0; --blk) {
+        const int kb = blk << 4, n_b = min(16, D - kb);
+        if (t < 16) {
+            // unconditional reads (addresses stay inside the tile / s.y), the triangular mask is a select: no exec-mask
+            // branches with their waits in the unrolled loop
+            const int tb = tl_base(blk, blk) + t * TILE_RS;
+            double a0 = s.dinv[kb + t] * s.y[kb + t], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int i = 1; i < 16; ++i) {
+                const double p = A[tb + i] * s.y[kb + i];
+                const double v = (i > t && i < n_b) ? p : 0.0;
+                if ((i & 3) == 0) a0 += v; else if ((i & 3) == 1) a1 += v; else if ((i & 3) == 2) a2 += v; else a3 += v;
+            }
+            if (t < n_b) s.xs[kb + t] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        for (int c = t; c < kb; c += NT) {                  // y_c -= sum_r L[kb+r][c] x_r
+            const int base = tl_base(blk, c >> 4) + (c & 15);
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {                  // rows >= n_b of the last tile: xs is zero there (see below)
+                v0 += A[base + r * TILE_RS] * s.xs[kb + r];
+                v1 += A[base + (r + 1) * TILE_RS] * s.xs[kb + r + 1];
+                v2 += A[base + (r + 2) * TILE_RS] * s.xs[kb + r + 2];
+                v3 += A[base + (r + 3) * TILE_RS] * s.xs[kb + r + 3];
+            }
+            s.y[c] -= (v0 + v1) + (v2 + v3);
         }
         __syncthreads();
     }
@@ -529,6 +569,9 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         }
         if constexpr (LDSM) back_subst(Alds, D, s); else back_subst(Ag, D, s);
         STAMP(4);
+#ifdef VIL_STAMPS
+        if (t == 0) P.dbg[23] = s.tacc[0];
+#endif
         // ---- gauss-newton step in dogleg space; landmark back-substitution fused with the dogleg sums ------------
         for (int i = t; i < D; i += NT) {
             const double xi = s.y[i];

@@ -18,6 +18,6 @@ el=time.perf_counter()-t0
 be.lib.vil_profile_read(be.ctx, C.byref(prof), 1)
 print("cfg", cfg, "skip", os.environ.get("VIL_SKIP"), "vwg", os.environ.get("VIL_VWG"), "it/s %.0f"%(its/el), "iters", s.iterations, "sweep_us %.1f"%(1e3*prof.sweep_ms/max(1,prof.sweep_launches)), "reduce+step_us %.1f"%(1e3*prof.step_ms/max(1,prof.step_launches)), "reduce_us %.1f"%(1e3*prof.reduce_ms/max(1,prof.step_launches)))
 dbg = (C.c_longlong*64)(); be.lib.vil_debug_read(be.ctx, dbg)
-d = np.array(dbg[:12], dtype=np.int64); print("raw", (d-d[0]).tolist()); print("chol phases diag/panel/update cycles:", list(dbg[20:23]))
+d = np.array(dbg[:12], dtype=np.int64); print("raw", (d-d[0]).tolist()); print("backsubst phase I end stamp rel to stamp3:", dbg[23]-dbg[3], "of total", dbg[4]-dbg[3])
 print("step stamps (cycles, deltas):", np.diff(d).tolist())
 v = np.array(dbg[32:40], dtype=np.int64); print("visual WG0 stamps rel:", (v - v[0]).tolist())
