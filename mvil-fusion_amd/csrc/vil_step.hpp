@@ -250,13 +250,16 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
                 const int I = tIJ[u] >> 8, J = tIJ[u] & 255;
                 if (tIJ[u] < 0 || J < Kt) continue;                       // finished (or empty) slot: wave-uniform
                 if (J > Kt) {                                            // register tile: rows/cols are beyond the panel
-                    const double av = kk ? -A[tl_base(I, Kt) + la + ko] : 0.0;
-                    const double bv = kk ? A[tl_base(J, Kt) + la + ko] : 0.0;
+                    // unconditional reads (inside the tile for every lane) + select: a per-lane predicated load would
+                    // compile to an exec-mask branch with its own wait
+                    const double a_ = A[tl_base(I, Kt) + la + ko], b_ = A[tl_base(J, Kt) + la + ko];
+                    const double av = kk ? -a_ : 0.0, bv = kk ? b_ : 0.0;
                     Creg[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, Creg[u], 0, 0, 0);
                 } else if (r0 < R) {                                     // tile of the active column: lives in LDS
                     const int rr = (I << 4) + (lane & 15), cr = (J << 4) + (lane & 15);
-                    const double av = (rr >= r0 && rr < R && kk) ? A[tl_base(I, Kt) + la + ko] : 0.0;
-                    const double bv = (cr >= r0 && cr < D && kk) ? A[tl_base(J, Kt) + la + ko] : 0.0;
+                    const double a_ = A[tl_base(I, Kt) + la + ko], b_ = A[tl_base(J, Kt) + la + ko];
+                    const double av = (rr >= r0 && rr < R && kk) ? a_ : 0.0;
+                    const double bv = (cr >= r0 && cr < D && kk) ? b_ : 0.0;
                     d4 z = {0.0, 0.0, 0.0, 0.0};
                     const d4 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, z, 0, 0, 0);
                     const int cb = tl_base(I, J) + lc;
