@@ -82,9 +82,21 @@ __device__ __forceinline__ double lm_dot(const DevP& P, const SysBuf& sb, int l,
     s0 += e[4] * va[4]; s1 += e[5] * va[5];
     s2 += e[6] * vx[0]; s3 += e[7] * vx[1]; s0 += e[8] * vx[2]; s1 += e[9] * vx[3]; s2 += e[10] * vx[4]; s3 += e[11] * vx[5];
     s0 += e[12] * vc[col_td(P)];
-    for (int f = fs; f < fe; ++f) {
-        const double* eo = sb.eO + (size_t)f * 6; const double* vj = vc + P.fcol[f];
-        s0 += eo[0] * vj[0]; s1 += eo[1] * vj[1]; s2 += eo[2] * vj[2]; s3 += eo[3] * vj[3]; s0 += eo[4] * vj[4]; s1 += eo[5] * vj[5];
+    // observers three at a time: index clamped into the landmark's own range (always a valid address), contribution
+    // masked by a select -- the global loads of a group are all in flight together instead of one dependent round trip
+    // per factor, and there is no per-lane predicated load (those compile to exec-mask branches with their own waits)
+    for (int f = fs; f < fe; f += 3) {
+        const int f1 = min(f + 1, fe - 1), f2 = min(f + 2, fe - 1);
+        const int c0 = P.fcol[f], c1 = P.fcol[f1], c2 = P.fcol[f2];
+        const double* e0 = sb.eO + (size_t)f * 6; const double* e1 = sb.eO + (size_t)f1 * 6; const double* e2 = sb.eO + (size_t)f2 * 6;
+        double a[6], b[6], c[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { a[k] = e0[k]; b[k] = e1[k]; c[k] = e2[k]; }
+        const double* v0 = vc + c0; const double* v1 = vc + c1; const double* v2 = vc + c2;
+        const double m1 = (f + 1 < fe) ? 1.0 : 0.0, m2 = (f + 2 < fe) ? 1.0 : 0.0;
+        s0 += a[0] * v0[0]; s1 += a[1] * v0[1]; s2 += a[2] * v0[2]; s3 += a[3] * v0[3]; s0 += a[4] * v0[4]; s1 += a[5] * v0[5];
+        s2 += m1 * (b[0] * v1[0] + b[1] * v1[1] + b[2] * v1[2]); s3 += m1 * (b[3] * v1[3] + b[4] * v1[4] + b[5] * v1[5]);
+        s0 += m2 * (c[0] * v2[0] + c[1] * v2[1] + c[2] * v2[2]); s1 += m2 * (c[3] * v2[3] + c[4] * v2[4] + c[5] * v2[5]);
     }
     return (s0 + s1) + (s2 + s3);
 }
