@@ -86,14 +86,21 @@ def cpu_baseline(w, opts, budget_s=10.0):
         ncpu = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    nthr = max(1, min(ncpu, 64))
-    its_mt, ts_mt = leg(nthr, 4.0, 10)
+    # all-cores variant: the factor sweep is ~3 ms of work per linearisation, so more threads is not better -- time a
+    # few team sizes and report the best one
+    best = None
+    for nthr in sorted({min(ncpu, k) for k in (4, 8, 16, 32)}):
+        its_k, ts_k = leg(nthr, 1.5, 8)
+        rate = its_k / sum(ts_k)
+        if best is None or rate > best[0]:
+            best = (rate, nthr, len(ts_k))
+    mt_rate, nthr, mt_n = best
     w.set_state(st0)
     return {"value": its / sum(ts), "unit": "iterations/s", "cores": 1, "kind": "port",
             "sample": "%d full solves (%d trust-region iterations) of the same configs[1] window after 3 warm-up solves, %.1f s; median solve %.2f ms"
                       % (len(ts), its, sum(ts), 1e3 * float(np.median(ts))),
-            "all_cores": {"value": its_mt / sum(ts_mt), "unit": "iterations/s", "cores": nthr,
-                          "sample": "%d solves, factor sweep on %d threads (Schur complement / Cholesky / dogleg stay serial)" % (len(ts_mt), nthr)},
+            "all_cores": {"value": mt_rate, "unit": "iterations/s", "cores": nthr,
+                          "sample": "%d solves, factor sweep on %d threads = best of the team sizes 4/8/16/32 (Schur complement / Cholesky / dogleg stay serial)" % (mt_n, nthr)},
             "note": "CPU restatement of the reference algorithm (Ceres unavailable); host has %d usable cores" % ncpu}
 
 

@@ -221,7 +221,11 @@ typedef struct vil_prior_out {
     int32_t* blk_index;
     int32_t* blk_col;
     double* x0;                     /* capacity 7*K + 9 + 7 + 1 ... see vil_prior_capacity */
-    double* J0;                     /* n_max x n_max, written n x n column-major */
+    double* J0;                     /* n_max x n_max, written n x n column-major.  A square root of the marginal information:
+                                     * J0^T J0 = A, J0^T r0 = b (marginalization_factor.cpp:313-314).  The reference takes
+                                     * sqrt(S) V^T of an eigen-decomposition (basis implementation-defined); the library
+                                     * returns the transposed pivoted-Cholesky factor -- the same prior cost, gradient and
+                                     * Gauss-Newton matrix */
     double* r0;
     double* A;                      /* optional n_max x n_max: reduced information matrix (J0^T J0 up to eps-truncation) */
     double* b;                      /* optional n_max */

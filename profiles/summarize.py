@@ -5,7 +5,8 @@
 set the remaining launches of a chunk return immediately, ~3-5 us) are separated from LIVE launches, because
 bench.py's HIP-event figure (`roofline.avg_launch_us`) times live launches only.
 
-usage: summarize.py kernel_trace.csv [pmc_fetch.csv pmc_write.csv]
+usage: summarize.py kernel_trace.csv [pmc_fetch.csv pmc_write.csv [pmc_mfma.csv]]
+(the MFMA file holds SQ_INSTS_VALU_MFMA_MOPS_F64 / SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of one --pmc pass)
 """
 import collections
 import csv
@@ -22,7 +23,7 @@ def main():
         thr = 8.0 if k.startswith(("k_sweep", "k_reduce", "void k_step")) else 0.0
         live = [x for x in v if x > thr]
         print("%-44s %6d %10.2f %6d %10.2f %10.2f" % (k[:44], len(v), sum(v) / len(v), len(live), sum(live) / max(1, len(live)), max(v)))
-    for f in sys.argv[2:]:
+    for f in sys.argv[2:4]:
         acc = collections.defaultdict(list)
         name = None
         for r in csv.DictReader(open(f)):
@@ -31,6 +32,22 @@ def main():
             if k.startswith(("k_sweep", "k_reduce", "void k_step")):
                 live = [x for x in v if x > 0.25 * max(v)]
                 print("%s %-40s live launches %4d  mean %.1f KB" % (name, k[:40], len(live), sum(live) / max(1, len(live))))
+    if len(sys.argv) > 4:
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(sys.argv[4])):
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        for k, v in acc.items():
+            if not k.startswith("void k_step"):
+                continue
+            d = [x[1] for x in v["SQ_VALU_MFMA_BUSY_CYCLES"]]
+            live = [i for i, x in enumerate(d) if x > 0.5 * max(d)]
+            mops = sum(v["SQ_INSTS_VALU_MFMA_MOPS_F64"][i][0] for i in live) / len(live)
+            busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"][i][0] for i in live) / len(live)
+            us = sum(d[i] for i in live) / len(live) / 1e3
+            print("MFMA %-36s live launches %4d  %.0f x 512 fp64 flop = %.2f MFLOP per launch, MFMA busy %.0f cycles (= %.0f v_mfma_f64_16x16x4 x 64), launch %.1f us"
+                  % (k[:36], len(live), mops, mops * 512 / 1e6, busy, busy / 64, us))
+            print("     -> %.1f GFLOP/s on the one CU that runs the step = %.3f %% of the 78.6 TFLOP/s fp64-matrix peak of the chip; MFMA pipes busy %.1f %% of the launch on that CU (4 SIMDs)"
+                  % (mops * 512 / us / 1e3, 100 * (mops * 512 / us / 1e3) / 78600.0, 100 * busy / 4 / (us * 2400)))
 
 
 if __name__ == "__main__":
