@@ -1,0 +1,145 @@
+"""Edge cases of the window the reference can produce (SURVEY 8a-A1 rules), GPU vs oracle through the C-ABI:
+empty factor classes, ragged landmark tracks, the IMU sum_dt > 10 skip (estimator.cpp:1182), ICP mode 4 (frozen frame,
+estimator.cpp:1354-1370), all landmarks constant (lidar_depth_flag everywhere), iteration caps, minimal windows."""
+import numpy as np
+import pytest
+
+from mvil_fusion_amd import abi, synth
+from mvil_fusion_amd.abi import Window
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(cid=2, **kw):
+    kw = dict(dict(L=120, n_plane=1500, n_edge=500), **kw) if cid == 2 else kw
+    return synth.make_config(cid, **kw), synth.make_config(cid, **kw)
+
+
+def _check_solve(hip, oracle, wg, wo, opts=None, pos_tol=1e-6, after_solve=None):
+    opts = opts or abi.default_options()
+    p0 = wg.pose[0].copy()
+    sg, so = hip.solve(wg, opts), oracle.solve(wo, opts)
+    assert sg.iterations == so.iterations and sg.termination == so.termination and sg.successful_steps == so.successful_steps, \
+        (sg.iterations, so.iterations, sg.termination, so.termination)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-7 * max(1e-12, abs(so.final_cost))
+    if after_solve is not None:
+        after_solve()                                   # before the gauge fix re-derives every quaternion from its rotation matrix
+    hip.gauge_fix(p0, wg); oracle.gauge_fix(p0, wo)
+    assert np.abs(wg.pose[:, :3] - wo.pose[:, :3]).max() <= pos_tol
+    assert np.abs(wg.inv_depth - wo.inv_depth).max() <= 1e-6 if wg.L else True
+    return sg
+
+
+def _check_lin(hip, oracle, w):
+    co, So, go = oracle.linearize(w)
+    cg, Sg, gg = hip.linearize(w)
+    assert abs(cg - co) <= 1e-11 * max(abs(co), 1e-300)
+    assert np.abs(Sg - So).max() <= 1e-10 * max(np.abs(So).max(), 1e-300) and np.abs(gg - go).max() <= 1e-10 * max(np.abs(go).max(), 1e-300)
+
+
+def test_no_lidar_no_relative_constraints(hip, oracle):
+    wg, wo = _pair(n_plane=0, n_edge=0, n_icp=0, n_lps=0)
+    _check_lin(hip, oracle, wg)
+    _check_solve(hip, oracle, wg, wo)
+
+
+def test_only_plane_points_or_only_edge_points(hip, oracle):
+    for kw in (dict(n_plane=2000, n_edge=0), dict(n_plane=0, n_edge=700)):
+        wg, wo = _pair(**kw)
+        _check_lin(hip, oracle, wg)
+        _check_solve(hip, oracle, wg, wo)
+
+
+def test_lidar_points_on_a_single_pose_and_ragged_chunks(hip, oracle):
+    wg, wo = _pair(n_plane=777, n_edge=0)
+    for w in (wg, wo):
+        w.plane_pose[:] = 3                             # one pose carries every point: chunks of 256 + a ragged tail of 9
+    _check_lin(hip, oracle, wg)
+    _check_solve(hip, oracle, wg, wo)
+
+
+def test_all_landmarks_constant(hip, oracle):
+    wg, wo = _pair()
+    for w in (wg, wo):
+        w.lm_const[:] = 1                               # lidar_depth_flag on every feature (estimator.cpp:1217-1221)
+    _check_lin(hip, oracle, wg)
+    _check_solve(hip, oracle, wg, wo)
+    assert np.array_equal(wg.inv_depth, synth.make_config(2, L=120, n_plane=1500, n_edge=500).inv_depth)   # untouched
+
+
+def test_no_visual_factors(hip, oracle):
+    wg, wo = _pair()
+    for w in (wg, wo):
+        w.vis_i = w.vis_i[:0]; w.vis_j = w.vis_j[:0]; w.vis_l = w.vis_l[:0]; w.vis_const = w.vis_const[:0]
+    _check_lin(hip, oracle, wg)
+    _check_solve(hip, oracle, wg, wo)
+
+
+def test_landmark_without_factors_and_long_track(hip, oracle):
+    wg, wo = _pair()
+    for w in (wg, wo):
+        keep = w.vis_l != 5                             # landmark 5 loses all its observations: must stay where it is
+        w.vis_i, w.vis_j, w.vis_l, w.vis_const = w.vis_i[keep], w.vis_j[keep], w.vis_l[keep], w.vis_const[keep]
+    lam5 = wg.inv_depth[5]
+    _check_lin(hip, oracle, wg)
+    _check_solve(hip, oracle, wg, wo)
+    assert wg.inv_depth[5] == lam5
+    assert np.bincount(wg.vis_l).max() == wg.K - 1      # a track seen in every frame of the window is present
+
+
+def test_imu_factor_skipped_when_sum_dt_exceeds_10s(hip, oracle):
+    wg, wo = _pair()
+    for w in (wg, wo):
+        w.imu_const[4, 16] = 10.5                       # estimator.cpp:1182
+    _check_lin(hip, oracle, wg)
+    _check_solve(hip, oracle, wg, wo)
+
+
+def test_frozen_frame_zero_velocity_mode(hip, oracle):
+    wg, wo = _pair()
+    for w in (wg, wo):                                   # ICP constraint_mode 4: freeze pose / speed-bias WINDOW_SIZE-1, zero its velocity
+        k = w.K - 2
+        w.pose_const[k] = 1; w.sb_const[k] = 1; w.speedbias[k, :3] = 0.0
+    _check_lin(hip, oracle, wg)
+    sg = _check_solve(hip, oracle, wg, wo)
+    assert sg.iterations > 0
+
+
+def test_extrinsic_and_td_fixed(hip, oracle):
+    wg, wo = _pair()
+    for w in (wg, wo):
+        w.ex_const = 1; w.td_const = 1
+    ex, td = wg.ex_pose.copy(), wg.td.copy()
+
+    def untouched():
+        assert np.array_equal(wg.ex_pose, ex) and np.array_equal(wg.td, td)      # constant blocks come back bit for bit
+    _check_solve(hip, oracle, wg, wo, after_solve=untouched)
+
+
+@pytest.mark.parametrize("cap", [0, 1, 3])
+def test_iteration_cap(hip, oracle, cap):
+    wg, wo = _pair()
+    opts = abi.default_options(max_iterations=cap)
+    sg = _check_solve(hip, oracle, wg, wo, opts)
+    assert sg.iterations == cap and sg.termination == abi.TERM_NAMES.index("max_iterations")
+
+
+def test_minimal_window_two_frames(hip, oracle):
+    """K = 2: one IMU factor, landmarks anchored in frame 0 seen in frame 1, no prior (start-up)."""
+    rng = np.random.default_rng(7)
+    base = synth.make_config(1)
+    def build():
+        w = Window(2, 12)
+        w.pose, w.speedbias = base.pose[:2].copy(), base.speedbias[:2].copy()
+        w.ex_pose, w.td = base.ex_pose.copy(), base.td.copy()
+        w.G, w.sqrt_info_px = base.G.copy(), base.sqrt_info_px
+        w.imu_i, w.imu_j, w.imu_const = np.array([0], np.int32), np.array([1], np.int32), base.imu_const[:1].copy()
+        sel = np.where((base.vis_i == 0) & (base.vis_j == 1))[0][:12]
+        w.vis_i, w.vis_j, w.vis_l = base.vis_i[sel].copy(), base.vis_j[sel].copy(), np.arange(len(sel), dtype=np.int32)
+        w.vis_const = base.vis_const[sel].copy()
+        w.L = len(sel); w.inv_depth = base.inv_depth[base.vis_l[sel]].copy(); w.lm_const = np.zeros(w.L, np.uint8)
+        return w
+    wg, wo = build(), build()
+    assert wg.L >= 3
+    _check_lin(hip, oracle, wg)
+    _check_solve(hip, oracle, wg, wo, pos_tol=1e-5)      # prior-less: the gauge null space amplifies rounding
