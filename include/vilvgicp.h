@@ -1,0 +1,63 @@
+/* vilvgicp.h -- C-ABI of the scan-to-scan voxelised GICP registration that produces mVIL-Fusion's LiDAR ICP constraint
+ * (the first "next" row after the sliding-window solve).
+ *
+ * Replaces, in vils_estimator's Estimator::processLidar (estimator.cpp:269-300), the object
+ *     fast_gicp::FastVGICP<POINT, POINT> gicp;  gicp.setResolution(0.5); gicp.setInputSource(..); gicp.setInputTarget(..); gicp.align(.., guess)
+ * i.e. the third-party fast_gicp sources vendored under vils_estimator/src/lidar_functions/fast_gicp:
+ *   vgicp_set_target      GaussianVoxelMap::create_voxelmap            gicp/fast_vgicp_voxel.hpp:128-159 (ADDITIVE voxels :107-125)
+ *   vgicp_linearize       FastVGICP::update_correspondences + linearize gicp/impl/fast_vgicp_impl.hpp:73-170
+ *   vgicp_compute_error   FastVGICP::compute_error                      gicp/impl/fast_vgicp_impl.hpp:173-196
+ *   vgicp_align           LsqRegistration::computeTransformation / step_lm / step_gn / is_converged   gicp/impl/lsq_registration_impl.hpp:48-165
+ * Per-point covariances (FastGICP::calculate_covariances, kNN + PLANE regularisation, gicp/impl/fast_gicp_impl.hpp:241-300)
+ * are INPUTS here (row-major 3x3 = the upper-left block of fast_gicp's 4x4 matrices); computing them on the device is the
+ * next step of this row.
+ * Plain C, POD only, host pointers; fp64 arithmetic on points given as float xyz (PCL points are float, cast to double
+ * exactly like getVector4fMap().cast<double>()). */
+#ifndef VILVGICP_H
+#define VILVGICP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vgicp_ctx vgicp_ctx;
+
+enum { VGICP_DIRECT1 = 1, VGICP_DIRECT7 = 7, VGICP_DIRECT27 = 27 };   /* NeighborSearchMethod, gicp_settings.hpp:8 */
+enum { VGICP_LM = 0, VGICP_GN = 1 };                                   /* LSQ_OPTIMIZER_TYPE */
+
+typedef struct vgicp_options {
+    int32_t neighbor_mode;            /* DIRECT1 (FastVGICP ctor default, fast_vgicp_impl.hpp:23) */
+    int32_t optimizer;                /* LevenbergMarquardt (lsq_registration_impl.hpp:17) */
+    int32_t max_iterations;           /* 64 */
+    int32_t lm_max_iterations;        /* 10 */
+    double rotation_epsilon;          /* 2e-3 */
+    double transformation_epsilon;    /* 5e-4 */
+    double lm_init_lambda_factor;     /* 1e-9 */
+} vgicp_options;
+
+typedef struct vgicp_summary {
+    int32_t iterations;               /* outer iterations executed (nr_iterations_ + 1) */
+    int32_t converged;
+    int32_t n_correspondences;        /* of the last linearisation */
+    int32_t lm_failed;                /* step_lm ran out of lm_max_iterations ("lm not converged!!") */
+    double final_error;               /* y0 of the last linearisation */
+    double final_hessian[36];         /* LsqRegistration::final_hessian_ */
+} vgicp_summary;
+
+int vgicp_create(int32_t device, vgicp_ctx** out);
+void vgicp_destroy(vgicp_ctx* ctx);
+void vgicp_default_options(vgicp_options* o);
+/* target cloud + covariances -> Gaussian voxel map of edge `resolution` (estimator.cpp:271 uses 0.5) */
+int vgicp_set_target(vgicp_ctx* ctx, int32_t n, const float* xyz, const double* cov9, double resolution);
+int vgicp_set_source(vgicp_ctx* ctx, int32_t n, const float* xyz, const double* cov9);
+/* T: row-major 4x4 isometry (source -> target).  Recomputes the correspondences and their Mahalanobis matrices at T.
+ * H (6x6 row-major, [rotation | translation] order), b (6) may both be NULL (error only). */
+int vgicp_linearize(vgicp_ctx* ctx, const double* T, int32_t neighbor_mode, double* err, double* H, double* b, int32_t* n_corr);
+/* error at T with the correspondences / Mahalanobis matrices of the LAST vgicp_linearize (as the reference) */
+int vgicp_compute_error(vgicp_ctx* ctx, const double* T, double* err);
+int vgicp_align(vgicp_ctx* ctx, const double* guess, const vgicp_options* opts, double* T_out, vgicp_summary* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

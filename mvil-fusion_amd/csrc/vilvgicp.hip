@@ -1,0 +1,394 @@
+// vilvgicp.hip -- voxelised GICP scan-to-scan registration on gfx950 behind include/vilvgicp.h.
+//
+// What the reference does per LiDAR scan (estimator.cpp:269-300 -> fast_gicp FastVGICP, OpenMP on the host):
+//   voxel map of the target (once per scan pair)  |  per LM iteration: correspondences by voxel look-up of every transformed
+//   source point, a 3x3 inverse per correspondence, then a 6x6 / 6x1 / scalar reduction over all correspondences.
+// MI355X-first layout of the same arithmetic:
+//   * target voxel map: built on the host in the reference's sequential order (it is summed once per scan and must not
+//     depend on atomics), stored as an open-addressing table of packed 63-bit voxel keys + SoA voxel records in HBM;
+//   * ONE kernel per linearisation: thread = (source point, neighbour offset) does transform, hash probe, RCR inverse,
+//     stores the correspondence (voxel id + Mahalanobis matrix, what compute_error reuses) and its 28 partial sums,
+//     wave64 butterflies + LDS fold them per workgroup, a second tiny kernel adds the workgroup partials in fixed order
+//     (deterministic, no fp64 atomics);
+//   * compute_error: thread = stored correspondence, one sum;
+//   * the 6x6 LM / GN step logic (lsq_registration_impl.hpp:88-165) runs on the host between launches: it is a handful of flops.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/vilvgicp.h"
+
+#define VG_OK 0
+#define VG_ERR_INVALID -1
+#define VG_ERR_DEVICE -2
+#define VG_ERR_NONFINITE -3
+#define VG_THREADS 256
+#define VGCHK(x) do { if ((x) != hipSuccess) return VG_ERR_DEVICE; } while (0)
+
+namespace {
+
+struct Iso { double m[12]; };                       // rows of [R | t]
+struct VoxTab { const long long* keys; const int* slot_vox; int mask; const int* num; const double* mean; const double* cov; };   // mean 3 x nv, cov 9 x nv (SoA)
+
+__host__ __device__ inline long long pack_key(int x, int y, int z) { return ((long long)(x & 0x1FFFFF) << 42) | ((long long)(y & 0x1FFFFF) << 21) | (long long)(z & 0x1FFFFF); }
+__host__ __device__ inline unsigned hash_key(long long k) { unsigned long long h = (unsigned long long)k * 0x9E3779B97F4A7C15ull; return (unsigned)(h >> 32); }
+
+__device__ __forceinline__ double wave_sum64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void inv3(const double* a, double* o) {
+    const double c0 = a[4] * a[8] - a[5] * a[7], c1 = a[5] * a[6] - a[3] * a[8], c2 = a[3] * a[7] - a[4] * a[6];
+    const double id = 1.0 / (a[0] * c0 + a[1] * c1 + a[2] * c2);
+    o[0] = c0 * id; o[1] = (a[2] * a[7] - a[1] * a[8]) * id; o[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+    o[3] = c1 * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+    o[6] = c2 * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+}
+
+// per-workgroup fold of NV per-thread values: wave butterflies, then the 4 wave results through LDS
+template <int NV>
+__device__ __forceinline__ void block_fold(double* v, double* part /* gridDim.x x NV */) {
+    __shared__ double sm[4][NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = wave_sum64(v[q]);
+    if (lane == 0) for (int q = 0; q < NV; ++q) sm[wave][q] = v[q];
+    __syncthreads();
+    if (threadIdx.x < NV) part[(size_t)blockIdx.x * NV + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+// FastVGICP::update_correspondences + linearize (fast_vgicp_impl.hpp:73-170), one thread per (source point, offset)
+__global__ __launch_bounds__(VG_THREADS) void k_vgicp_lin(int n, int noff, const float* __restrict__ sxyz, const double* __restrict__ scov, Iso T, double res, VoxTab V,
+                                                          int* __restrict__ c_vox, double* __restrict__ c_M, double* __restrict__ part, int want_H) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[28];
+#pragma unroll
+    for (int q = 0; q < 28; ++q) acc[q] = 0.0;
+    if (tid < n * noff) {
+        const int i = tid / noff, o = tid - i * noff;
+        const double ax = (double)sxyz[3 * i], ay = (double)sxyz[3 * i + 1], az = (double)sxyz[3 * i + 2];
+        const double tx = T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3];
+        const double ty = T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7];
+        const double tz = T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11];
+        int kx = (int)floor(tx / res - 0.5), ky = (int)floor(ty / res - 0.5), kz = (int)floor(tz / res - 0.5);
+        if (noff == 7) { const int d = (o + 1) >> 1, s = (o & 1) ? 1 : -1; if (o) { if (d == 1) kx += s; else if (d == 2) ky += s; else kz += s; } }   // (0) (+x -x) (+y -y) (+z -z)
+        else if (noff == 27) { kx += o / 9 - 1; ky += (o / 3) % 3 - 1; kz += o % 3 - 1; }
+        const long long key = pack_key(kx, ky, kz);
+        int v = -1;
+        for (unsigned h = hash_key(key) & V.mask;; h = (h + 1) & V.mask) {      // linear probing; the table is never full
+            const long long k = V.keys[h];
+            if (k == key) { v = V.slot_vox[h]; break; }
+            if (k < 0) break;
+        }
+        c_vox[tid] = v;
+        if (v >= 0) {
+            double ca[9], cb[9], RC[9], RCR[9], M[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { ca[q] = scov[(size_t)9 * i + q]; cb[q] = V.cov[(size_t)9 * v + q]; }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) RC[3 * r + q] = T.m[4 * r] * ca[q] + T.m[4 * r + 1] * ca[3 + q] + T.m[4 * r + 2] * ca[6 + q];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) RCR[3 * r + q] = cb[3 * r + q] + RC[3 * r] * T.m[4 * q] + RC[3 * r + 1] * T.m[4 * q + 1] + RC[3 * r + 2] * T.m[4 * q + 2];
+            inv3(RCR, M);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) c_M[(size_t)9 * tid + q] = M[q];
+            const double e0 = V.mean[(size_t)3 * v] - tx, e1 = V.mean[(size_t)3 * v + 1] - ty, e2 = V.mean[(size_t)3 * v + 2] - tz;
+            const double w = sqrt((double)V.num[v]);
+            const double m0 = M[0] * e0 + M[1] * e1 + M[2] * e2, m1 = M[3] * e0 + M[4] * e1 + M[5] * e2, m2 = M[6] * e0 + M[7] * e1 + M[8] * e2;
+            acc[27] = w * (e0 * m0 + e1 * m1 + e2 * m2);
+            if (want_H) {
+                // J = [skew(ta) | -I] ; H += w J^T M J (upper triangle, 21 values) ; b += w J^T M e
+                const double J[18] = {0.0, -tz, ty, -1.0, 0.0, 0.0, tz, 0.0, -tx, 0.0, -1.0, 0.0, -ty, tx, 0.0, 0.0, 0.0, -1.0};
+                double MJ[18];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) MJ[6 * r + q] = M[3 * r] * J[q] + M[3 * r + 1] * J[6 + q] + M[3 * r + 2] * J[12 + q];
+                int idx = 0;
+#pragma unroll
+                for (int p = 0; p < 6; ++p) {
+#pragma unroll
+                    for (int q = p; q < 6; ++q) acc[idx++] = w * (J[p] * MJ[q] + J[6 + p] * MJ[6 + q] + J[12 + p] * MJ[12 + q]);
+                    acc[21 + p] = w * (J[p] * m0 + J[6 + p] * m1 + J[12 + p] * m2);
+                }
+            }
+        }
+    }
+    block_fold<28>(acc, part);
+}
+
+// FastVGICP::compute_error (fast_vgicp_impl.hpp:173-196): stored correspondences and Mahalanobis matrices, new transform
+__global__ __launch_bounds__(VG_THREADS) void k_vgicp_err(int ncorr_slots, int noff, const float* __restrict__ sxyz, Iso T, VoxTab V, const int* __restrict__ c_vox, const double* __restrict__ c_M, double* __restrict__ part) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[1] = {0.0};
+    if (tid < ncorr_slots) {
+        const int v = c_vox[tid];
+        if (v >= 0) {
+            const int i = tid / noff;
+            const double ax = (double)sxyz[3 * i], ay = (double)sxyz[3 * i + 1], az = (double)sxyz[3 * i + 2];
+            const double e0 = V.mean[(size_t)3 * v] - (T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3]);
+            const double e1 = V.mean[(size_t)3 * v + 1] - (T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7]);
+            const double e2 = V.mean[(size_t)3 * v + 2] - (T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11]);
+            const double* M = c_M + (size_t)9 * tid;
+            const double m0 = M[0] * e0 + M[1] * e1 + M[2] * e2, m1 = M[3] * e0 + M[4] * e1 + M[5] * e2, m2 = M[6] * e0 + M[7] * e1 + M[8] * e2;
+            acc[0] = sqrt((double)V.num[v]) * (e0 * m0 + e1 * m1 + e2 * m2);
+        }
+    }
+    block_fold<1>(acc, part);
+}
+
+// fixed-order sum of the workgroup partials; out[NV] (+ out[NV] = number of correspondences when counting)
+template <int NV>
+__global__ __launch_bounds__(VG_THREADS) void k_vgicp_sum(int nblk, const double* __restrict__ part, double* __restrict__ out, const int* __restrict__ c_vox, int nslots) {
+    __shared__ double sm[VG_THREADS];
+    const int t = threadIdx.x;
+    for (int q = 0; q < NV; ++q) {
+        double s = 0.0;
+        for (int b = t; b < nblk; b += VG_THREADS) s += part[(size_t)b * NV + q];
+        sm[t] = s;
+        __syncthreads();
+        for (int st = VG_THREADS / 2; st > 0; st >>= 1) { if (t < st) sm[t] += sm[t + st]; __syncthreads(); }
+        if (t == 0) out[q] = sm[0];
+        __syncthreads();
+    }
+    if (c_vox) {
+        int cnt = 0;
+        for (int e = t; e < nslots; e += VG_THREADS) cnt += c_vox[e] >= 0;
+        sm[t] = (double)cnt;
+        __syncthreads();
+        for (int st = VG_THREADS / 2; st > 0; st >>= 1) { if (t < st) sm[t] += sm[t + st]; __syncthreads(); }
+        if (t == 0) out[NV] = sm[0];
+    }
+}
+
+struct HostKeyHash { size_t operator()(long long k) const { return (size_t)hash_key(k) * 2654435761u ^ (size_t)(k >> 17); } };
+
+}  // namespace
+
+struct vgicp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // target voxel map
+    double res = 1.0; int nvox = 0, cap = 0;
+    long long* d_keys = nullptr; int* d_slot = nullptr; int* d_num = nullptr; double* d_mean = nullptr; double* d_cov = nullptr;
+    // source
+    int n = 0; float* d_sxyz = nullptr; double* d_scov = nullptr;
+    // correspondences of the last linearisation
+    int noff = 1, slots = 0, slots_cap = 0; int* d_cvox = nullptr; double* d_cM = nullptr;
+    double* d_part = nullptr; int part_cap = 0; double* d_out = nullptr; double* h_out = nullptr;
+    bool linearized = false;
+};
+
+static void free_target(vgicp_ctx* c) { hipFree(c->d_keys); hipFree(c->d_slot); hipFree(c->d_num); hipFree(c->d_mean); hipFree(c->d_cov); c->d_keys = nullptr; c->d_slot = nullptr; c->d_num = nullptr; c->d_mean = nullptr; c->d_cov = nullptr; c->nvox = 0; }
+static void free_source(vgicp_ctx* c) { hipFree(c->d_sxyz); hipFree(c->d_scov); c->d_sxyz = nullptr; c->d_scov = nullptr; c->n = 0; }
+
+static Iso to_iso(const double* T) { Iso r; for (int q = 0; q < 12; ++q) r.m[q] = T[q]; return r; }
+static VoxTab tab(const vgicp_ctx* c) { return VoxTab{c->d_keys, c->d_slot, c->cap - 1, c->d_num, c->d_mean, c->d_cov}; }
+
+extern "C" {
+
+int vgicp_create(int32_t device, vgicp_ctx** out) {
+    if (!out) return VG_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VG_ERR_DEVICE;      // no CPU fallback
+    VGCHK(hipSetDevice(device));
+    vgicp_ctx* c = new vgicp_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VG_ERR_DEVICE; }
+    if (hipMalloc(&c->d_out, 8 * 32) != hipSuccess || hipHostMalloc(&c->h_out, 8 * 32) != hipSuccess) { delete c; return VG_ERR_DEVICE; }
+    *out = c;
+    return VG_OK;
+}
+void vgicp_destroy(vgicp_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    free_target(c); free_source(c);
+    hipFree(c->d_cvox); hipFree(c->d_cM); hipFree(c->d_part); hipFree(c->d_out); if (c->h_out) hipHostFree(c->h_out);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+void vgicp_default_options(vgicp_options* o) {
+    if (!o) return;
+    o->neighbor_mode = VGICP_DIRECT1; o->optimizer = VGICP_LM; o->max_iterations = 64; o->lm_max_iterations = 10;
+    o->rotation_epsilon = 2e-3; o->transformation_epsilon = 5e-4; o->lm_init_lambda_factor = 1e-9;
+}
+
+int vgicp_set_target(vgicp_ctx* c, int32_t n, const float* xyz, const double* cov9, double resolution) {
+    if (!c || n <= 0 || !xyz || !cov9 || !(resolution > 0.0)) return VG_ERR_INVALID;
+    VGCHK(hipSetDevice(c->device));
+    // GaussianVoxelMap::create_voxelmap (fast_vgicp_voxel.hpp:128-159), ADDITIVE voxels: sequential sums in point order
+    std::unordered_map<long long, int, HostKeyHash> index;
+    std::vector<long long> keys; std::vector<int> num; std::vector<double> mean, cov;
+    index.reserve((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const double p[3] = {(double)xyz[3 * i], (double)xyz[3 * i + 1], (double)xyz[3 * i + 2]};
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) return VG_ERR_NONFINITE;
+        const long long k = pack_key((int)std::floor(p[0] / resolution - 0.5), (int)std::floor(p[1] / resolution - 0.5), (int)std::floor(p[2] / resolution - 0.5));
+        auto it = index.find(k);
+        int v;
+        if (it == index.end()) { v = (int)keys.size(); index.emplace(k, v); keys.push_back(k); num.push_back(0); mean.insert(mean.end(), 3, 0.0); cov.insert(cov.end(), 9, 0.0); }
+        else v = it->second;
+        num[v]++;
+        for (int q = 0; q < 3; ++q) mean[3 * (size_t)v + q] += p[q];
+        for (int q = 0; q < 9; ++q) cov[9 * (size_t)v + q] += cov9[9 * (size_t)i + q];
+    }
+    const int nv = (int)keys.size();
+    for (int v = 0; v < nv; ++v) { for (int q = 0; q < 3; ++q) mean[3 * (size_t)v + q] /= num[v]; for (int q = 0; q < 9; ++q) cov[9 * (size_t)v + q] /= num[v]; }   // finalize()
+    int cap = 64; while (cap < 2 * nv) cap <<= 1;
+    std::vector<long long> tkeys((size_t)cap, -1); std::vector<int> tslot((size_t)cap, -1);
+    for (int v = 0; v < nv; ++v) { unsigned h = hash_key(keys[v]) & (cap - 1); while (tkeys[h] >= 0) h = (h + 1) & (cap - 1); tkeys[h] = keys[v]; tslot[h] = v; }
+    free_target(c);
+    VGCHK(hipMalloc(&c->d_keys, 8 * (size_t)cap)); VGCHK(hipMalloc(&c->d_slot, 4 * (size_t)cap)); VGCHK(hipMalloc(&c->d_num, 4 * (size_t)nv));
+    VGCHK(hipMalloc(&c->d_mean, 8 * 3 * (size_t)nv)); VGCHK(hipMalloc(&c->d_cov, 8 * 9 * (size_t)nv));
+    VGCHK(hipMemcpy(c->d_keys, tkeys.data(), 8 * (size_t)cap, hipMemcpyHostToDevice)); VGCHK(hipMemcpy(c->d_slot, tslot.data(), 4 * (size_t)cap, hipMemcpyHostToDevice));
+    VGCHK(hipMemcpy(c->d_num, num.data(), 4 * (size_t)nv, hipMemcpyHostToDevice)); VGCHK(hipMemcpy(c->d_mean, mean.data(), 8 * 3 * (size_t)nv, hipMemcpyHostToDevice));
+    VGCHK(hipMemcpy(c->d_cov, cov.data(), 8 * 9 * (size_t)nv, hipMemcpyHostToDevice));
+    c->res = resolution; c->nvox = nv; c->cap = cap; c->linearized = false;
+    return VG_OK;
+}
+
+int vgicp_set_source(vgicp_ctx* c, int32_t n, const float* xyz, const double* cov9) {
+    if (!c || n <= 0 || !xyz || !cov9) return VG_ERR_INVALID;
+    VGCHK(hipSetDevice(c->device));
+    free_source(c);
+    VGCHK(hipMalloc(&c->d_sxyz, 4 * 3 * (size_t)n)); VGCHK(hipMalloc(&c->d_scov, 8 * 9 * (size_t)n));
+    VGCHK(hipMemcpy(c->d_sxyz, xyz, 4 * 3 * (size_t)n, hipMemcpyHostToDevice)); VGCHK(hipMemcpy(c->d_scov, cov9, 8 * 9 * (size_t)n, hipMemcpyHostToDevice));
+    c->n = n; c->linearized = false;
+    return VG_OK;
+}
+
+int vgicp_linearize(vgicp_ctx* c, const double* T, int32_t mode, double* err, double* H, double* b, int32_t* n_corr) {
+    if (!c || !T || !err || !c->nvox || !c->n || (mode != VGICP_DIRECT1 && mode != VGICP_DIRECT7 && mode != VGICP_DIRECT27)) return VG_ERR_INVALID;
+    VGCHK(hipSetDevice(c->device));
+    const int slots = c->n * mode, nblk = (slots + VG_THREADS - 1) / VG_THREADS;
+    if (slots > c->slots_cap) { hipFree(c->d_cvox); hipFree(c->d_cM); c->d_cvox = nullptr; c->d_cM = nullptr; c->slots_cap = 0; VGCHK(hipMalloc(&c->d_cvox, 4 * (size_t)slots)); VGCHK(hipMalloc(&c->d_cM, 8 * 9 * (size_t)slots)); c->slots_cap = slots; }
+    if (nblk > c->part_cap) { hipFree(c->d_part); c->d_part = nullptr; c->part_cap = 0; VGCHK(hipMalloc(&c->d_part, 8 * 28 * (size_t)nblk)); c->part_cap = nblk; }
+    const int want = (H && b) ? 1 : 0;
+    hipLaunchKernelGGL(k_vgicp_lin, dim3(nblk), dim3(VG_THREADS), 0, c->stream, c->n, (int)mode, c->d_sxyz, c->d_scov, to_iso(T), c->res, tab(c), c->d_cvox, c->d_cM, c->d_part, want);
+    hipLaunchKernelGGL((k_vgicp_sum<28>), dim3(1), dim3(VG_THREADS), 0, c->stream, nblk, c->d_part, c->d_out, c->d_cvox, slots);
+    VGCHK(hipMemcpyAsync(c->h_out, c->d_out, 8 * 29, hipMemcpyDeviceToHost, c->stream));
+    VGCHK(hipStreamSynchronize(c->stream));
+    VGCHK(hipGetLastError());
+    c->noff = mode; c->slots = slots; c->linearized = true;
+    *err = c->h_out[27];
+    if (n_corr) *n_corr = (int32_t)c->h_out[28];
+    if (want) {
+        int idx = 0;
+        for (int p = 0; p < 6; ++p) { for (int q = p; q < 6; ++q) { H[6 * p + q] = c->h_out[idx]; H[6 * q + p] = c->h_out[idx]; ++idx; } b[p] = c->h_out[21 + p]; }
+    }
+    return std::isfinite(*err) ? VG_OK : VG_ERR_NONFINITE;
+}
+
+int vgicp_compute_error(vgicp_ctx* c, const double* T, double* err) {
+    if (!c || !T || !err || !c->linearized) return VG_ERR_INVALID;
+    VGCHK(hipSetDevice(c->device));
+    const int nblk = (c->slots + VG_THREADS - 1) / VG_THREADS;
+    hipLaunchKernelGGL(k_vgicp_err, dim3(nblk), dim3(VG_THREADS), 0, c->stream, c->slots, c->noff, c->d_sxyz, to_iso(T), tab(c), c->d_cvox, c->d_cM, c->d_part);
+    hipLaunchKernelGGL((k_vgicp_sum<1>), dim3(1), dim3(VG_THREADS), 0, c->stream, nblk, c->d_part, c->d_out, (const int*)nullptr, 0);
+    VGCHK(hipMemcpyAsync(c->h_out, c->d_out, 8, hipMemcpyDeviceToHost, c->stream));
+    VGCHK(hipStreamSynchronize(c->stream));
+    *err = c->h_out[0];
+    return std::isfinite(*err) ? VG_OK : VG_ERR_NONFINITE;
+}
+
+// ---- host side of LsqRegistration (lsq_registration_impl.hpp:48-165): 6 x 6 algebra between device reductions --------------
+static bool solve6(const double* A, const double* rhs, double* x) {
+    double L[36] = {0};
+    for (int j = 0; j < 6; ++j) {
+        double d = A[6 * j + j];
+        for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k];
+        if (!(d > 0.0)) return false;
+        L[6 * j + j] = std::sqrt(d);
+        for (int i = j + 1; i < 6; ++i) { double s = A[6 * i + j]; for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k]; L[6 * i + j] = s / L[6 * j + j]; }
+    }
+    double y[6];
+    for (int i = 0; i < 6; ++i) { double s = rhs[i]; for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k]; y[i] = s / L[6 * i + i]; }
+    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k]; x[i] = s / L[6 * i + i]; }
+    return true;
+}
+static void so3_exp_R(const double* w, double* R) {      // so3.hpp:53-77, then Quaternion::toRotationMatrix
+    const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double im, re;
+    if (t2 < 1e-10) { const double t4 = t2 * t2; im = 0.5 - 1.0 / 48.0 * t2 + 1.0 / 3840.0 * t4; re = 1.0 - 1.0 / 8.0 * t2 + 1.0 / 384.0 * t4; }
+    else { const double t = std::sqrt(t2), h = 0.5 * t; im = std::sin(h) / t; re = std::cos(h); }
+    const double qw = re, qx = im * w[0], qy = im * w[1], qz = im * w[2];
+    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz, twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy; R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx; R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+static void compose(const double* d, const double* x0, double* xi) {
+    double R[9]; so3_exp_R(d, R);
+    for (int r = 0; r < 3; ++r) {
+        for (int q = 0; q < 4; ++q) xi[4 * r + q] = R[3 * r] * x0[q] + R[3 * r + 1] * x0[4 + q] + R[3 * r + 2] * x0[8 + q];
+        xi[4 * r + 3] += d[3 + r];
+    }
+    xi[12] = 0; xi[13] = 0; xi[14] = 0; xi[15] = 1;
+}
+static bool is_converged(const double* d, double reps, double teps) {
+    double R[9]; so3_exp_R(d, R);
+    double m = 0;
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) m = std::fmax(m, std::fabs(R[3 * r + q] - (r == q ? 1.0 : 0.0)) / reps);
+    for (int r = 0; r < 3; ++r) m = std::fmax(m, std::fabs(d[3 + r]) / teps);
+    return m < 1;
+}
+
+int vgicp_align(vgicp_ctx* c, const double* guess, const vgicp_options* o, double* T_out, vgicp_summary* out) {
+    if (!c || !guess || !o || !T_out || !out) return VG_ERR_INVALID;
+    double x0[16]; std::memcpy(x0, guess, sizeof x0);
+    double lambda = -1.0;
+    bool converged = false;
+    std::memset(out, 0, sizeof *out);
+    for (int k = 0; k < 36; ++k) out->final_hessian[k] = (k % 7 == 0) ? 1.0 : 0.0;
+    int it = 0;
+    for (; it < o->max_iterations && !converged; ++it) {
+        double H[36], b[6], d[6] = {0, 0, 0, 0, 0, 0}, nb[6], y0;
+        int32_t nc = 0;
+        int st = vgicp_linearize(c, x0, o->neighbor_mode, &y0, H, b, &nc);
+        if (st != VG_OK) return st;
+        out->n_correspondences = nc; out->final_error = y0;
+        for (int k = 0; k < 6; ++k) nb[k] = -b[k];
+        bool stepped = false;
+        if (o->optimizer == VGICP_GN) {                                        // step_gn
+            if (!solve6(H, nb, d)) { out->lm_failed = 1; break; }
+            double xi[16]; compose(d, x0, xi); std::memcpy(x0, xi, sizeof x0); std::memcpy(out->final_hessian, H, sizeof H); stepped = true;
+        } else {                                                               // step_lm
+            if (lambda < 0.0) { double m = 0; for (int k = 0; k < 6; ++k) m = std::fmax(m, std::fabs(H[7 * k])); lambda = o->lm_init_lambda_factor * m; }
+            double nu = 2.0;
+            for (int i = 0; i < o->lm_max_iterations; ++i) {
+                double Hl[36]; std::memcpy(Hl, H, sizeof H);
+                for (int k = 0; k < 6; ++k) Hl[7 * k] += lambda;
+                if (!solve6(Hl, nb, d)) { lambda = nu * lambda; nu = 2 * nu; continue; }
+                double xi[16], yi; compose(d, x0, xi);
+                st = vgicp_compute_error(c, xi, &yi);
+                if (st != VG_OK) return st;
+                double den = 0; for (int k = 0; k < 6; ++k) den += d[k] * (lambda * d[k] - b[k]);
+                const double rho = (y0 - yi) / den;
+                if (rho < 0) {
+                    if (is_converged(d, o->rotation_epsilon, o->transformation_epsilon)) { stepped = true; break; }
+                    lambda = nu * lambda; nu = 2 * nu; continue;
+                }
+                std::memcpy(x0, xi, sizeof x0);
+                lambda = lambda * std::fmax(1.0 / 3.0, 1 - std::pow(2 * rho - 1, 3));
+                std::memcpy(out->final_hessian, H, sizeof H);
+                stepped = true;
+                break;
+            }
+        }
+        if (!stepped) { out->lm_failed = 1; ++it; break; }
+        converged = is_converged(d, o->rotation_epsilon, o->transformation_epsilon);
+    }
+    out->iterations = it; out->converged = converged ? 1 : 0;
+    std::memcpy(T_out, x0, sizeof x0);
+    return VG_OK;
+}
+
+}  // extern "C"

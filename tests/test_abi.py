@@ -27,6 +27,29 @@ def test_library_exports_every_declared_symbol():
     assert so.vil_abi_version() == 1
 
 
+def test_library_exports_every_vgicp_symbol():
+    """include/vilvgicp.h is served by the same shared library."""
+    so = lib.load_vilsolve()
+    src = open(os.path.join(ROOT, "include", "vilvgicp.h")).read()
+    syms = sorted(set(re.findall(r"\b(vgicp_[a-z_0-9]+)\s*\(", src)))
+    assert len(syms) == 8, syms
+    for s in syms:
+        assert hasattr(so, s), "libvilsolve.so does not export %s" % s
+    import subprocess, tempfile
+    from mvil_fusion_amd import vgicp
+    prog = '#include <stdio.h>\n#include "vilvgicp.h"\nint main(void){printf("%zu %zu\\n", sizeof(vgicp_options), sizeof(vgicp_summary));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        out = subprocess.check_output([os.path.join(d, "s")]).decode().split()
+    assert [C.sizeof(vgicp.VgicpOptions), C.sizeof(vgicp.VgicpSummary)] == [int(v) for v in out]
+    with pytest.raises(vgicp.VgicpError):
+        import torch
+        if torch.cuda.is_available():
+            raise vgicp.VgicpError("GPU present")
+        vgicp.Vgicp(so, "vgicp_")                       # no device -> refuses, no CPU fallback
+
+
 def test_struct_layouts_match_header():
     """sizeof() of the ctypes mirrors equals what the C compiler lays out (checked through a tiny C program)."""
     import subprocess, tempfile

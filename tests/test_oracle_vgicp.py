@@ -1,0 +1,97 @@
+"""Pins of the CPU restatement of fast_gicp's voxelised GICP (oracle/oracle_vgicp.cpp): voxel map against a numpy
+re-derivation, b = half the gradient of the error at fixed correspondences (finite differences with the reference's
+left-multiplicative so3_exp update), H = Gauss-Newton matrix of the same error, and the LM loop recovers the relative pose."""
+import numpy as np
+import pytest
+
+from mvil_fusion_amd import vgicp
+
+
+@pytest.fixture(scope="module")
+def pair():
+    return vgicp.make_pair(seed=3, rings=8, az=300)
+
+
+@pytest.fixture()
+def reg(oracle, pair):
+    r = vgicp.Vgicp(oracle.lib, "orc_vgicp_")
+    tx, tc, sx, sc, _ = pair
+    r.set_target(tx, tc, 0.5); r.set_source(sx, sc)
+    yield r
+    r.close()
+
+
+def _numpy_linearize(pair, T, res=0.5):
+    tx, tc, sx, sc, _ = pair
+    tx = tx.astype(np.float64); sx = sx.astype(np.float64)
+    key = np.floor(tx / res - 0.5).astype(np.int64)
+    vox = {}
+    for i, k in enumerate(map(tuple, key)):
+        v = vox.setdefault(k, [0, np.zeros(3), np.zeros((3, 3))])
+        v[0] += 1; v[1] += tx[i]; v[2] += tc[i].reshape(3, 3)
+    R, t = T[:3, :3], T[:3, 3]
+    err, H, b, n = 0.0, np.zeros((6, 6)), np.zeros(6), 0
+    for i in range(len(sx)):
+        ta = R @ sx[i] + t
+        k = tuple(np.floor(ta / res - 0.5).astype(np.int64))
+        if k not in vox:
+            continue
+        num, ms, cs = vox[k]
+        M = np.linalg.inv(cs / num + R @ sc[i].reshape(3, 3) @ R.T)
+        e = ms / num - ta
+        J = np.hstack([np.array([[0, -ta[2], ta[1]], [ta[2], 0, -ta[0]], [-ta[1], ta[0], 0]]), -np.eye(3)])
+        w = np.sqrt(num)
+        err += w * e @ M @ e; H += w * J.T @ M @ J; b += w * J.T @ M @ e; n += 1
+    return err, H, b, n
+
+
+def test_linearize_matches_numpy(reg, pair):
+    T = np.eye(4); T[:3, 3] = [0.05, -0.02, 0.01]
+    err, H, b, n = reg.linearize(T)
+    e2, H2, b2, n2 = _numpy_linearize(pair, T)
+    assert n == n2 and n > 500
+    assert abs(err - e2) <= 1e-10 * e2
+    assert np.abs(H - H2).max() <= 1e-10 * np.abs(H2).max() and np.abs(b - b2).max() <= 1e-10 * np.abs(b2).max()
+    assert np.allclose(H, H.T, rtol=0, atol=1e-9 * np.abs(H).max())
+
+
+def _exp_left(d, T):
+    th = np.linalg.norm(d[:3])
+    K = np.array([[0, -d[2], d[1]], [d[2], 0, -d[0]], [-d[1], d[0], 0]])
+    R = np.eye(3) + K + 0.5 * K @ K if th < 1e-8 else np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+    D = np.eye(4); D[:3, :3] = R; D[:3, 3] = d[3:]
+    return D @ T
+
+
+def test_gradient_and_hessian_by_finite_differences(reg):
+    T = np.eye(4); T[:3, 3] = [0.04, 0.03, -0.01]
+    err, H, b, _ = reg.linearize(T)
+    h = 1e-6
+    g = np.zeros(6)
+    for k in range(6):
+        d = np.zeros(6); d[k] = h
+        g[k] = (reg.compute_error(_exp_left(d, T)) - reg.compute_error(_exp_left(-d, T))) / (2 * h)
+    assert np.abs(g - 2 * b).max() <= 1e-5 * np.abs(b).max()              # d err / d delta = 2 J^T M e w
+    # the model err(delta) ~ err + 2 b.delta + delta^T H delta is exact for the translation part (J constant there)
+    d = np.array([0, 0, 0, 2e-3, -1e-3, 1.5e-3])
+    assert abs(reg.compute_error(_exp_left(d, T)) - (err + 2 * b @ d + d @ H @ d)) <= 1e-9 * err
+
+
+@pytest.mark.parametrize("optimizer", [vgicp.LM, vgicp.GN])
+def test_align_recovers_relative_pose(reg, pair, optimizer):
+    T_true = pair[4]
+    guess = np.eye(4)
+    T, s = reg.align(guess, reg.default_options(optimizer=optimizer))
+    assert s.converged == 1 and s.lm_failed == 0 and 1 <= s.iterations <= 64
+    assert np.abs(T[:3, 3] - T_true[:3, 3]).max() < 0.03 and np.abs(T[:3, :3] - T_true[:3, :3]).max() < 5e-3
+    assert np.allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-12)
+    e0 = reg.linearize(guess)[0]
+    assert reg.linearize(T)[0] < e0
+
+
+@pytest.mark.parametrize("mode", [vgicp.DIRECT7, vgicp.DIRECT27])
+def test_neighbour_modes_superset(reg, mode):
+    T = np.eye(4)
+    e1, _, _, n1 = reg.linearize(T, vgicp.DIRECT1)
+    em, Hm, _, nm = reg.linearize(T, mode)
+    assert nm > n1 and em > e1 and np.all(np.linalg.eigvalsh(Hm) > 0)
