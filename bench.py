@@ -153,6 +153,65 @@ def replay_mode(args, be, abi, lib):
     print(json.dumps(out), flush=True)
 
 
+def vgicp_mode(args):
+    """voxelised GICP scan-to-scan registration (the producer of the LiDAR ICP constraint,
+    estimator.cpp:269-300).  Step = one linearisation (correspondences + 6x6 system) of a synthetic 16-ring scan pair with
+    the clouds and the voxel map resident in HBM; plus whole alignments per second.  HIP events on the library's stream
+    are not exposed for this row yet: the kernel time is the wall time of the call minus the measured D2H + sync floor."""
+    import numpy as np
+    import torch
+    from mvil_fusion_amd import lib, vgicp
+    rings, az = args.vgicp_rings, args.vgicp_az
+    tx, tc, sx, sc, T_true = vgicp.make_pair(seed=20240606, rings=rings, az=az)
+    g = vgicp.Vgicp(lib.load_vilsolve(), "vgicp_")
+    g.set_target(tx, tc, 0.5); g.set_source(sx, sc)
+    T = np.eye(4)
+    for _ in range(args.warmup):
+        g.linearize(T)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        e, H, b, nc = g.linearize(T)
+    el = time.perf_counter() - t0
+    t0 = time.perf_counter(); na = 0
+    while time.perf_counter() - t0 < 1.0:
+        Tg, sg = g.align(np.eye(4)); na += 1
+    el_a = time.perf_counter() - t0
+    n = len(sx)
+    # algorithmic bytes of one linearisation (DIRECT1): source point 12 + covariance 72, per correspondence voxel record
+    # (num 4 + mean 24 + cov 72) + key probe 8 + slot 4, stored correspondence 4 + 72
+    ab = n * (12 + 72 + 4) + nc * (100 + 12 + 72)
+    out = {"metric": "VGICP linearisations/sec (scan-to-scan, %d-ring x %d synthetic scan pair, voxel 0.5 m, DIRECT1)" % (rings, az),
+           "value": args.steps / el, "unit": "linearisations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "SURVEY 8(f) row 1: %d source points, %d correspondences, target voxel map resident" % (n, nc),
+                      "alignments_per_s": na / el_a, "lm_iterations_per_alignment": int(sg.iterations),
+                      "translation_error_m": float(np.abs(Tg[:3, 3] - T_true[:3, 3]).max())},
+           "roofline": {"bound": "hbm", "kernel": "k_vgicp_lin", "achieved": ab / (el / args.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ab / (el / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": ab,
+                        "note": "wall time of the whole call (2 launches + D2H of 29 doubles + stream sync): a latency floor of ~20 us dominates at this size"}}
+    if not args.no_cpu:
+        orc = vgicp.Vgicp(C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "orc_vgicp_")
+        orc.set_target(tx, tc, 0.5); orc.set_source(sx, sc)
+        for _ in range(2):
+            orc.linearize(T)
+        t0 = time.perf_counter(); k = 0
+        while time.perf_counter() - t0 < 3.0:
+            orc.linearize(T); k += 1
+        elc = time.perf_counter() - t0
+        t0 = time.perf_counter(); ka = 0
+        while time.perf_counter() - t0 < 3.0:
+            To, so = orc.align(np.eye(4)); ka += 1
+        elca = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": k / elc, "unit": "linearisations/s", "cores": 1, "kind": "port", "sample": "%d linearisations, %.1f s; %d alignments %.1f s" % (k, elc, ka, elca),
+                               "alignments_per_s": ka / elca,
+                               "note": "single-threaded restatement of fast_gicp's FastVGICP (the reference runs it with OpenMP NumThreads from the yaml)"}
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        out["max_abs_T_difference"] = float(np.abs(Tg - To).max())
+    print(json.dumps(out), flush=True)
+    g.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +222,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--replay", type=int, default=0, help="config 5: run N images of the synthetic replay and report per-frame latency instead of the headline metric")
     ap.add_argument("--precision", type=int, default=0, help="0 = fp64 (reference arithmetic), 1 = fp32 factor evaluation with fp64 accumulation (replay mode only)")
+    ap.add_argument("--vgicp", action="store_true", help="SURVEY 8(f) row 1: bench the voxelised GICP linearisation instead of the headline metric")
+    ap.add_argument("--vgicp-rings", type=int, default=16)
+    ap.add_argument("--vgicp-az", type=int, default=1800)
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of sharding one window over RCCL")
     args = ap.parse_args()
 
@@ -176,6 +238,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     graft.load_package()
     from mvil_fusion_amd import abi, lib, synth
+    if args.vgicp:
+        vgicp_mode(args)
+        return
 
     be = lib.open_vilsolve(device=local, rank=rank, world=world)
     opts = abi.default_options()

@@ -67,9 +67,9 @@ __device__ __forceinline__ void block_fold(double* v, double* part /* gridDim.x 
 __global__ __launch_bounds__(VG_THREADS) void k_vgicp_lin(int n, int noff, const float* __restrict__ sxyz, const double* __restrict__ scov, Iso T, double res, VoxTab V,
                                                           int* __restrict__ c_vox, double* __restrict__ c_M, double* __restrict__ part, int want_H) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    double acc[28];
+    double acc[29];                                   // 21 H (upper) | 6 b | error | number of correspondences
 #pragma unroll
-    for (int q = 0; q < 28; ++q) acc[q] = 0.0;
+    for (int q = 0; q < 29; ++q) acc[q] = 0.0;
     if (tid < n * noff) {
         const int i = tid / noff, o = tid - i * noff;
         const double ax = (double)sxyz[3 * i], ay = (double)sxyz[3 * i + 1], az = (double)sxyz[3 * i + 2];
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(VG_THREADS) void k_vgicp_lin(int n, int noff, const
             const double e0 = V.mean[(size_t)3 * v] - tx, e1 = V.mean[(size_t)3 * v + 1] - ty, e2 = V.mean[(size_t)3 * v + 2] - tz;
             const double w = sqrt((double)V.num[v]);
             const double m0 = M[0] * e0 + M[1] * e1 + M[2] * e2, m1 = M[3] * e0 + M[4] * e1 + M[5] * e2, m2 = M[6] * e0 + M[7] * e1 + M[8] * e2;
-            acc[27] = w * (e0 * m0 + e1 * m1 + e2 * m2);
+            acc[27] = w * (e0 * m0 + e1 * m1 + e2 * m2); acc[28] = 1.0;
             if (want_H) {
                 // J = [skew(ta) | -I] ; H += w J^T M J (upper triangle, 21 values) ; b += w J^T M e
                 const double J[18] = {0.0, -tz, ty, -1.0, 0.0, 0.0, tz, 0.0, -tx, 0.0, -1.0, 0.0, -ty, tx, 0.0, 0.0, 0.0, -1.0};
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(VG_THREADS) void k_vgicp_lin(int n, int noff, const
             }
         }
     }
-    block_fold<28>(acc, part);
+    block_fold<29>(acc, part);
 }
 
 // FastVGICP::compute_error (fast_vgicp_impl.hpp:173-196): stored correspondences and Mahalanobis matrices, new transform
@@ -147,28 +147,15 @@ __global__ __launch_bounds__(VG_THREADS) void k_vgicp_err(int ncorr_slots, int n
     block_fold<1>(acc, part);
 }
 
-// fixed-order sum of the workgroup partials; out[NV] (+ out[NV] = number of correspondences when counting)
+// fixed-order sum of the workgroup partials: value q is summed by the 8 lanes 8q..8q+7 (strided partial sums, then a
+// 3-step butterfly inside the group) -- one pass, no barrier, same bits on every run
 template <int NV>
-__global__ __launch_bounds__(VG_THREADS) void k_vgicp_sum(int nblk, const double* __restrict__ part, double* __restrict__ out, const int* __restrict__ c_vox, int nslots) {
-    __shared__ double sm[VG_THREADS];
-    const int t = threadIdx.x;
-    for (int q = 0; q < NV; ++q) {
-        double s = 0.0;
-        for (int b = t; b < nblk; b += VG_THREADS) s += part[(size_t)b * NV + q];
-        sm[t] = s;
-        __syncthreads();
-        for (int st = VG_THREADS / 2; st > 0; st >>= 1) { if (t < st) sm[t] += sm[t + st]; __syncthreads(); }
-        if (t == 0) out[q] = sm[0];
-        __syncthreads();
-    }
-    if (c_vox) {
-        int cnt = 0;
-        for (int e = t; e < nslots; e += VG_THREADS) cnt += c_vox[e] >= 0;
-        sm[t] = (double)cnt;
-        __syncthreads();
-        for (int st = VG_THREADS / 2; st > 0; st >>= 1) { if (t < st) sm[t] += sm[t + st]; __syncthreads(); }
-        if (t == 0) out[NV] = sm[0];
-    }
+__global__ __launch_bounds__(VG_THREADS) void k_vgicp_sum(int nblk, const double* __restrict__ part, double* __restrict__ out) {
+    const int t = threadIdx.x, q = t >> 3, r = t & 7;
+    double s = 0.0;
+    if (q < NV) for (int b = r; b < nblk; b += 8) s += part[(size_t)b * NV + q];
+    s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+    if (q < NV && r == 0) out[q] = s;
 }
 
 struct HostKeyHash { size_t operator()(long long k) const { return (size_t)hash_key(k) * 2654435761u ^ (size_t)(k >> 17); } };
@@ -272,10 +259,10 @@ int vgicp_linearize(vgicp_ctx* c, const double* T, int32_t mode, double* err, do
     VGCHK(hipSetDevice(c->device));
     const int slots = c->n * mode, nblk = (slots + VG_THREADS - 1) / VG_THREADS;
     if (slots > c->slots_cap) { hipFree(c->d_cvox); hipFree(c->d_cM); c->d_cvox = nullptr; c->d_cM = nullptr; c->slots_cap = 0; VGCHK(hipMalloc(&c->d_cvox, 4 * (size_t)slots)); VGCHK(hipMalloc(&c->d_cM, 8 * 9 * (size_t)slots)); c->slots_cap = slots; }
-    if (nblk > c->part_cap) { hipFree(c->d_part); c->d_part = nullptr; c->part_cap = 0; VGCHK(hipMalloc(&c->d_part, 8 * 28 * (size_t)nblk)); c->part_cap = nblk; }
+    if (nblk > c->part_cap) { hipFree(c->d_part); c->d_part = nullptr; c->part_cap = 0; VGCHK(hipMalloc(&c->d_part, 8 * 29 * (size_t)nblk)); c->part_cap = nblk; }
     const int want = (H && b) ? 1 : 0;
     hipLaunchKernelGGL(k_vgicp_lin, dim3(nblk), dim3(VG_THREADS), 0, c->stream, c->n, (int)mode, c->d_sxyz, c->d_scov, to_iso(T), c->res, tab(c), c->d_cvox, c->d_cM, c->d_part, want);
-    hipLaunchKernelGGL((k_vgicp_sum<28>), dim3(1), dim3(VG_THREADS), 0, c->stream, nblk, c->d_part, c->d_out, c->d_cvox, slots);
+    hipLaunchKernelGGL((k_vgicp_sum<29>), dim3(1), dim3(VG_THREADS), 0, c->stream, nblk, c->d_part, c->d_out);
     VGCHK(hipMemcpyAsync(c->h_out, c->d_out, 8 * 29, hipMemcpyDeviceToHost, c->stream));
     VGCHK(hipStreamSynchronize(c->stream));
     VGCHK(hipGetLastError());
@@ -294,7 +281,7 @@ int vgicp_compute_error(vgicp_ctx* c, const double* T, double* err) {
     VGCHK(hipSetDevice(c->device));
     const int nblk = (c->slots + VG_THREADS - 1) / VG_THREADS;
     hipLaunchKernelGGL(k_vgicp_err, dim3(nblk), dim3(VG_THREADS), 0, c->stream, c->slots, c->noff, c->d_sxyz, to_iso(T), tab(c), c->d_cvox, c->d_cM, c->d_part);
-    hipLaunchKernelGGL((k_vgicp_sum<1>), dim3(1), dim3(VG_THREADS), 0, c->stream, nblk, c->d_part, c->d_out, (const int*)nullptr, 0);
+    hipLaunchKernelGGL((k_vgicp_sum<1>), dim3(1), dim3(VG_THREADS), 0, c->stream, nblk, c->d_part, c->d_out);
     VGCHK(hipMemcpyAsync(c->h_out, c->d_out, 8, hipMemcpyDeviceToHost, c->stream));
     VGCHK(hipStreamSynchronize(c->stream));
     *err = c->h_out[0];

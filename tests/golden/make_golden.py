@@ -55,6 +55,30 @@ def main():
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
         print(name, "K=%d L=%d Fv=%d" % (w.K, w.L, len(w.vis_i)), "%.0f KB" % (os.path.getsize(path) / 1024))
+    make_vgicp(orc)
+
+
+def make_vgicp(orc):
+    """tests/golden/vgicp/vgicp_mini.npz: a small scan pair (inputs) + the oracle's linearisation at a fixed transform for
+    the three neighbour modes and the aligned transform of both optimisers (expected outputs).  SURVEY 8(f) row 1."""
+    from mvil_fusion_amd import vgicp
+    tx, tc, sx, sc, T_true = vgicp.make_pair(seed=11, rings=6, az=240)
+    out = dict(tgt_xyz=tx, tgt_cov=tc, src_xyz=sx, src_cov=sc, T_true=T_true, resolution=np.array([0.5]))
+    reg = vgicp.Vgicp(orc.lib, "orc_vgicp_")
+    reg.set_target(tx, tc, 0.5); reg.set_source(sx, sc)
+    T = np.eye(4); T[:3, :3] = vgicp._rot(0.003, -0.002, 0.008); T[:3, 3] = [0.04, -0.03, 0.01]
+    out["T_lin"] = T
+    for mode in (vgicp.DIRECT1, vgicp.DIRECT7, vgicp.DIRECT27):
+        e, H, b, n = reg.linearize(T, mode)
+        out["lin%d_err" % mode], out["lin%d_H" % mode], out["lin%d_b" % mode], out["lin%d_n" % mode] = np.array([e]), H, b, np.array([n])
+    for name, opt in (("lm", vgicp.LM), ("gn", vgicp.GN)):
+        Ta, s = reg.align(np.eye(4), reg.default_options(optimizer=opt))
+        out["align_%s_T" % name] = Ta
+        out["align_%s_meta" % name] = np.array([s.iterations, s.converged, s.n_correspondences, s.final_error])
+    os.makedirs(os.path.join(HERE, "vgicp"), exist_ok=True)
+    path = os.path.join(HERE, "vgicp", "vgicp_mini.npz")
+    np.savez_compressed(path, **out)
+    print("vgicp_mini", "%d target / %d source points" % (len(tx), len(sx)), "%.0f KB" % (os.path.getsize(path) / 1024))
 
 
 if __name__ == "__main__":

@@ -56,3 +56,10 @@ def test_errors_and_determinism(regs):
     far = np.eye(4); far[:3, 3] = [500.0, 0, 0]
     e, H, bb, n = g.linearize(far)
     assert n == 0 and e == 0.0 and not H.any()                             # no correspondence at all
+
+
+def test_gpu_reproduces_golden_fixture():
+    from test_oracle_vgicp import _check_golden
+    g = vgicp.Vgicp(lib.load_vilsolve(), "vgicp_")
+    _check_golden(g, vgicp)
+    g.close()

@@ -95,3 +95,26 @@ def test_neighbour_modes_superset(reg, mode):
     e1, _, _, n1 = reg.linearize(T, vgicp.DIRECT1)
     em, Hm, _, nm = reg.linearize(T, mode)
     assert nm > n1 and em > e1 and np.all(np.linalg.eigvalsh(Hm) > 0)
+
+
+def _check_golden(reg, vg):
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vgicp", "vgicp_mini.npz"))
+    reg.set_target(d["tgt_xyz"], d["tgt_cov"], float(d["resolution"][0])); reg.set_source(d["src_xyz"], d["src_cov"])
+    for mode in (vg.DIRECT1, vg.DIRECT7, vg.DIRECT27):
+        e, H, b, n = reg.linearize(d["T_lin"], mode)
+        assert n == int(d["lin%d_n" % mode][0])
+        assert abs(e - d["lin%d_err" % mode][0]) <= 1e-11 * d["lin%d_err" % mode][0]
+        assert np.abs(H - d["lin%d_H" % mode]).max() <= 1e-11 * np.abs(d["lin%d_H" % mode]).max()
+        assert np.abs(b - d["lin%d_b" % mode]).max() <= 1e-10 * np.abs(d["lin%d_b" % mode]).max()
+    for name, opt in (("lm", vg.LM), ("gn", vg.GN)):
+        T, s = reg.align(np.eye(4), reg.default_options(optimizer=opt))
+        meta = d["align_%s_meta" % name]
+        assert (s.iterations, s.converged, s.n_correspondences) == (int(meta[0]), int(meta[1]), int(meta[2]))
+        assert np.abs(T - d["align_%s_T" % name]).max() <= 1e-9 and abs(s.final_error - meta[3]) <= 1e-9 * meta[3]
+
+
+def test_oracle_reproduces_golden_fixture(oracle):
+    r = vgicp.Vgicp(oracle.lib, "orc_vgicp_")
+    _check_golden(r, vgicp)
+    r.close()
