@@ -8,9 +8,9 @@
  *   vgicp_linearize       FastVGICP::update_correspondences + linearize gicp/impl/fast_vgicp_impl.hpp:73-170
  *   vgicp_compute_error   FastVGICP::compute_error                      gicp/impl/fast_vgicp_impl.hpp:173-196
  *   vgicp_align           LsqRegistration::computeTransformation / step_lm / step_gn / is_converged   gicp/impl/lsq_registration_impl.hpp:48-165
- * Per-point covariances (FastGICP::calculate_covariances, kNN + PLANE regularisation, gicp/impl/fast_gicp_impl.hpp:241-300)
- * are INPUTS here (row-major 3x3 = the upper-left block of fast_gicp's 4x4 matrices); computing them on the device is the
- * next step of this row.
+ *   vgicp_covariances     FastGICP::calculate_covariances               gicp/impl/fast_gicp_impl.hpp:241-300 (k = 20, PLANE)
+ * Per-point covariances are row-major 3x3 (the upper-left block of fast_gicp's 4x4 matrices); vgicp_set_source /
+ * vgicp_set_target accept cov9 = NULL and then compute them with vgicp_covariances' kernel.
  * Plain C, POD only, host pointers; fp64 arithmetic on points given as float xyz (PCL points are float, cast to double
  * exactly like getVector4fMap().cast<double>()). */
 #ifndef VILVGICP_H
@@ -50,6 +50,11 @@ void vgicp_default_options(vgicp_options* o);
 /* target cloud + covariances -> Gaussian voxel map of edge `resolution` (estimator.cpp:271 uses 0.5) */
 int vgicp_set_target(vgicp_ctx* ctx, int32_t n, const float* xyz, const double* cov9, double resolution);
 int vgicp_set_source(vgicp_ctx* ctx, int32_t n, const float* xyz, const double* cov9);
+/* Covariance of the k nearest neighbours of every point (the point itself included, as pcl's nearestKSearch returns it),
+ * regularised like RegularizationMethod::PLANE: singular values replaced by (1, 1, 1e-3).  The reference finds the
+ * neighbours with a kd-tree in float; this is an EXACT search with the same float distances (ties may order differently).
+ * out_cov9: n x 9 host buffer. */
+int vgicp_covariances(vgicp_ctx* ctx, int32_t n, const float* xyz, int32_t k, double* out_cov9);
 /* T: row-major 4x4 isometry (source -> target).  Recomputes the correspondences and their Mahalanobis matrices at T.
  * H (6x6 row-major, [rotation | translation] order), b (6) may both be NULL (error only). */
 int vgicp_linearize(vgicp_ctx* ctx, const double* T, int32_t neighbor_mode, double* err, double* H, double* b, int32_t* n_corr);

@@ -158,6 +158,87 @@ __global__ __launch_bounds__(VG_THREADS) void k_vgicp_sum(int nblk, const double
     if (q < NV && r == 0) out[q] = s;
 }
 
+// FastGICP::calculate_covariances (fast_gicp_impl.hpp:241-300), k <= 20, RegularizationMethod::PLANE.
+// Exact k-nearest-neighbour search by tiles: thread = query point, the candidate points stream through LDS 256 at a time,
+// the running k best (float squared distance, index) live in registers as a sorted list updated by an unrolled,
+// branch-free insertion (static register indices: no scratch).  Same float arithmetic and tie order (smaller index
+// first) as the oracle, so both select the same neighbours.  Then mean / covariance in fp64 and
+// U diag(1, 1, 1e-3) V^T = I - (1 - 1e-3) n n^T with n the eigenvector of the smallest eigenvalue (cyclic Jacobi, 3 x 3).
+#define KNN_MAX 20
+__global__ __launch_bounds__(VG_THREADS) void k_knn_cov(int n, const float* __restrict__ xyz, int k, double* __restrict__ cov9) {
+    __shared__ float sx[VG_THREADS], sy[VG_THREADS], sz[VG_THREADS];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const float qx = live ? xyz[3 * i] : 0.f, qy = live ? xyz[3 * i + 1] : 0.f, qz = live ? xyz[3 * i + 2] : 0.f;
+    float bd[KNN_MAX]; int bi[KNN_MAX];
+#pragma unroll
+    for (int m = 0; m < KNN_MAX; ++m) { bd[m] = 3.0e38f; bi[m] = -1; }
+    for (int t0 = 0; t0 < n; t0 += VG_THREADS) {
+        const int j0 = t0 + threadIdx.x;
+        __syncthreads();
+        if (j0 < n) { sx[threadIdx.x] = xyz[3 * j0]; sy[threadIdx.x] = xyz[3 * j0 + 1]; sz[threadIdx.x] = xyz[3 * j0 + 2]; }
+        __syncthreads();
+        const int cnt = min(VG_THREADS, n - t0);
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float dx = __fsub_rn(qx, sx[jj]), dy = __fsub_rn(qy, sy[jj]), dz = __fsub_rn(qz, sz[jj]);
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));     // no fma: bit-equal to the CPU sum
+            if (d < bd[KNN_MAX - 1]) {
+                const int j = t0 + jj;
+#pragma unroll
+                for (int m = KNN_MAX - 1; m >= 1; --m) {
+                    const bool up = d < bd[m - 1], here = !up && d < bd[m];
+                    bd[m] = up ? bd[m - 1] : (here ? d : bd[m]);
+                    bi[m] = up ? bi[m - 1] : (here ? j : bi[m]);
+                }
+                if (d < bd[0]) { bd[0] = d; bi[0] = j; }
+            }
+        }
+    }
+    if (!live) return;
+    double mx = 0, my = 0, mz = 0;
+#pragma unroll
+    for (int m = 0; m < KNN_MAX; ++m) if (m < k && bi[m] >= 0) { mx += (double)xyz[3 * bi[m]]; my += (double)xyz[3 * bi[m] + 1]; mz += (double)xyz[3 * bi[m] + 2]; }
+    mx /= k; my /= k; mz /= k;
+    double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < KNN_MAX; ++m) if (m < k && bi[m] >= 0) {
+        const double c0 = (double)xyz[3 * bi[m]] - mx, c1 = (double)xyz[3 * bi[m] + 1] - my, c2 = (double)xyz[3 * bi[m] + 2] - mz;
+        A[0] += c0 * c0; A[1] += c0 * c1; A[2] += c0 * c2; A[3] += c1 * c0; A[4] += c1 * c1; A[5] += c1 * c2; A[6] += c2 * c0; A[7] += c2 * c1; A[8] += c2 * c2;
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) A[q] /= k;
+    double V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+        if (off <= 1e-40 * (A[0] * A[0] + A[4] * A[4] + A[8] * A[8]) || off == 0.0) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = A[3 * p + q];
+                if (apq != 0.0) {
+                    const double tau = (A[3 * q + q] - A[3 * p + p]) / (2.0 * apq);
+                    const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    const double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) { const double akp = A[3 * r + p], akq = A[3 * r + q]; A[3 * r + p] = c * akp - sn * akq; A[3 * r + q] = sn * akp + c * akq; }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) { const double apk = A[3 * p + r], aqk = A[3 * q + r]; A[3 * p + r] = c * apk - sn * aqk; A[3 * q + r] = sn * apk + c * aqk; }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) { const double vkp = V[3 * r + p], vkq = V[3 * r + q]; V[3 * r + p] = c * vkp - sn * vkq; V[3 * r + q] = sn * vkp + c * vkq; }
+                }
+            }
+    }
+    double n0 = V[0], n1 = V[3], n2 = V[6], lmin = A[0];
+    if (A[4] < lmin) { lmin = A[4]; n0 = V[1]; n1 = V[4]; n2 = V[7]; }
+    if (A[8] < lmin) { n0 = V[2]; n1 = V[5]; n2 = V[8]; }
+    const double f = 1.0 - 1e-3;
+    double* o = cov9 + (size_t)9 * i;
+    o[0] = 1.0 - f * n0 * n0; o[1] = -f * n0 * n1; o[2] = -f * n0 * n2;
+    o[3] = -f * n1 * n0; o[4] = 1.0 - f * n1 * n1; o[5] = -f * n1 * n2;
+    o[6] = -f * n2 * n0; o[7] = -f * n2 * n1; o[8] = 1.0 - f * n2 * n2;
+}
+
 struct HostKeyHash { size_t operator()(long long k) const { return (size_t)hash_key(k) * 2654435761u ^ (size_t)(k >> 17); } };
 
 }  // namespace
@@ -182,7 +263,28 @@ static void free_source(vgicp_ctx* c) { hipFree(c->d_sxyz); hipFree(c->d_scov); 
 static Iso to_iso(const double* T) { Iso r; for (int q = 0; q < 12; ++q) r.m[q] = T[q]; return r; }
 static VoxTab tab(const vgicp_ctx* c) { return VoxTab{c->d_keys, c->d_slot, c->cap - 1, c->d_num, c->d_mean, c->d_cov}; }
 
+// device covariances of a device-resident cloud (d_xyz) into d_cov (n x 9)
+static int covariances_dev(vgicp_ctx* c, int n, const float* d_xyz, int k, double* d_cov) {
+    if (k < 1 || k > KNN_MAX) return VG_ERR_INVALID;
+    hipLaunchKernelGGL(k_knn_cov, dim3((n + VG_THREADS - 1) / VG_THREADS), dim3(VG_THREADS), 0, c->stream, n, d_xyz, k, d_cov);
+    VGCHK(hipStreamSynchronize(c->stream));
+    VGCHK(hipGetLastError());
+    return VG_OK;
+}
+
 extern "C" {
+
+int vgicp_covariances(vgicp_ctx* c, int32_t n, const float* xyz, int32_t k, double* out) {
+    if (!c || n <= 0 || !xyz || !out) return VG_ERR_INVALID;
+    VGCHK(hipSetDevice(c->device));
+    float* dx = nullptr; double* dc = nullptr;
+    VGCHK(hipMalloc(&dx, 12 * (size_t)n));
+    if (hipMalloc(&dc, 72 * (size_t)n) != hipSuccess) { hipFree(dx); return VG_ERR_DEVICE; }
+    int st = hipMemcpy(dx, xyz, 12 * (size_t)n, hipMemcpyHostToDevice) == hipSuccess ? covariances_dev(c, n, dx, k, dc) : VG_ERR_DEVICE;
+    if (st == VG_OK && hipMemcpy(out, dc, 72 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) st = VG_ERR_DEVICE;
+    hipFree(dx); hipFree(dc);
+    return st;
+}
 
 int vgicp_create(int32_t device, vgicp_ctx** out) {
     if (!out) return VG_ERR_INVALID;
@@ -210,9 +312,12 @@ void vgicp_default_options(vgicp_options* o) {
     o->rotation_epsilon = 2e-3; o->transformation_epsilon = 5e-4; o->lm_init_lambda_factor = 1e-9;
 }
 
-int vgicp_set_target(vgicp_ctx* c, int32_t n, const float* xyz, const double* cov9, double resolution) {
-    if (!c || n <= 0 || !xyz || !cov9 || !(resolution > 0.0)) return VG_ERR_INVALID;
+int vgicp_set_target(vgicp_ctx* c, int32_t n, const float* xyz, const double* cov9_in, double resolution) {
+    if (!c || n <= 0 || !xyz || !(resolution > 0.0)) return VG_ERR_INVALID;
     VGCHK(hipSetDevice(c->device));
+    std::vector<double> own;
+    const double* cov9 = cov9_in;
+    if (!cov9) { own.resize(9 * (size_t)n); const int st = vgicp_covariances(c, n, xyz, KNN_MAX, own.data()); if (st != VG_OK) return st; cov9 = own.data(); }
     // GaussianVoxelMap::create_voxelmap (fast_vgicp_voxel.hpp:128-159), ADDITIVE voxels: sequential sums in point order
     std::unordered_map<long long, int, HostKeyHash> index;
     std::vector<long long> keys; std::vector<int> num; std::vector<double> mean, cov;
@@ -245,11 +350,13 @@ int vgicp_set_target(vgicp_ctx* c, int32_t n, const float* xyz, const double* co
 }
 
 int vgicp_set_source(vgicp_ctx* c, int32_t n, const float* xyz, const double* cov9) {
-    if (!c || n <= 0 || !xyz || !cov9) return VG_ERR_INVALID;
+    if (!c || n <= 0 || !xyz) return VG_ERR_INVALID;
     VGCHK(hipSetDevice(c->device));
     free_source(c);
     VGCHK(hipMalloc(&c->d_sxyz, 4 * 3 * (size_t)n)); VGCHK(hipMalloc(&c->d_scov, 8 * 9 * (size_t)n));
-    VGCHK(hipMemcpy(c->d_sxyz, xyz, 4 * 3 * (size_t)n, hipMemcpyHostToDevice)); VGCHK(hipMemcpy(c->d_scov, cov9, 8 * 9 * (size_t)n, hipMemcpyHostToDevice));
+    VGCHK(hipMemcpy(c->d_sxyz, xyz, 4 * 3 * (size_t)n, hipMemcpyHostToDevice));
+    if (cov9) VGCHK(hipMemcpy(c->d_scov, cov9, 8 * 9 * (size_t)n, hipMemcpyHostToDevice));
+    else { const int st = covariances_dev(c, n, c->d_sxyz, KNN_MAX, c->d_scov); if (st != VG_OK) return st; }      // source covariances never leave the device
     c->n = n; c->linearized = false;
     return VG_OK;
 }

@@ -65,13 +65,22 @@ class Vgicp:
         if st != 0:
             raise VgicpError("%s%s failed: status %d" % (self.prefix, name, st))
 
-    def set_target(self, xyz, cov, resolution=0.5):
-        xyz = np.ascontiguousarray(xyz, np.float32); cov = np.ascontiguousarray(cov, np.float64)
-        self._chk("set_target", self._f("set_target")(self.ctx, C.c_int32(len(xyz)), xyz.ctypes.data_as(_fp), cov.ctypes.data_as(_dp), C.c_double(resolution)))
+    def set_target(self, xyz, cov=None, resolution=0.5):
+        """cov None: the library estimates the covariances itself (k = 20 neighbours, PLANE regularisation)."""
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        cp = C.cast(None, _dp) if cov is None else np.ascontiguousarray(cov, np.float64).ctypes.data_as(_dp)
+        self._chk("set_target", self._f("set_target")(self.ctx, C.c_int32(len(xyz)), xyz.ctypes.data_as(_fp), cp, C.c_double(resolution)))
 
-    def set_source(self, xyz, cov):
-        xyz = np.ascontiguousarray(xyz, np.float32); cov = np.ascontiguousarray(cov, np.float64)
-        self._chk("set_source", self._f("set_source")(self.ctx, C.c_int32(len(xyz)), xyz.ctypes.data_as(_fp), cov.ctypes.data_as(_dp)))
+    def set_source(self, xyz, cov=None):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        cp = C.cast(None, _dp) if cov is None else np.ascontiguousarray(cov, np.float64).ctypes.data_as(_dp)
+        self._chk("set_source", self._f("set_source")(self.ctx, C.c_int32(len(xyz)), xyz.ctypes.data_as(_fp), cp))
+
+    def covariances(self, xyz, k=20):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        out = np.zeros((len(xyz), 9))
+        self._chk("covariances", self._f("covariances")(self.ctx, C.c_int32(len(xyz)), xyz.ctypes.data_as(_fp), C.c_int32(k), out.ctypes.data_as(_dp)))
+        return out
 
     def linearize(self, T, mode=DIRECT1, jac=True):
         T = np.ascontiguousarray(T, np.float64)

@@ -7,7 +7,9 @@
 //   FastVGICP::update_correspondences / linearize / compute_error   gicp/impl/fast_vgicp_impl.hpp:73-196
 //   LsqRegistration::computeTransformation / is_converged / step_gn / step_lm   gicp/impl/lsq_registration_impl.hpp:48-165
 //   so3_exp                                        so3/so3.hpp:53-77
+//   FastGICP::calculate_covariances (k nearest neighbours, PLANE regularisation)   gicp/impl/fast_gicp_impl.hpp:241-300
 // Same sequential accumulation order as the reference with one thread.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -143,6 +145,51 @@ bool is_converged(const double* d, double reps, double teps) {    // lsq_registr
     return m < 1;
 }
 
+// smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi); the PLANE regularisation U diag(1,1,1e-3) V^T of a
+// symmetric PSD matrix is I - (1 - 1e-3) n n^T with n that vector (JacobiSVD of a symmetric matrix: U = V up to signs)
+void smallest_eigvec3(const double* Cin, double* nrm) {
+    double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::memcpy(A, Cin, sizeof A);
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+        if (off <= 1e-40 * (A[0] * A[0] + A[4] * A[4] + A[8] * A[8]) || off == 0.0) break;
+        for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
+            const double apq = A[3 * p + q];
+            if (apq == 0.0) continue;
+            const double tau = (A[3 * q + q] - A[3 * p + p]) / (2.0 * apq);
+            const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+            const double c = 1.0 / std::sqrt(1.0 + t * t), s = t * c;
+            for (int k = 0; k < 3; ++k) { const double akp = A[3 * k + p], akq = A[3 * k + q]; A[3 * k + p] = c * akp - s * akq; A[3 * k + q] = s * akp + c * akq; }
+            for (int k = 0; k < 3; ++k) { const double apk = A[3 * p + k], aqk = A[3 * q + k]; A[3 * p + k] = c * apk - s * aqk; A[3 * q + k] = s * apk + c * aqk; }
+            for (int k = 0; k < 3; ++k) { const double vkp = V[3 * k + p], vkq = V[3 * k + q]; V[3 * k + p] = c * vkp - s * vkq; V[3 * k + q] = s * vkp + c * vkq; }
+        }
+    }
+    int m = 0; if (A[4] < A[3 * m + m]) m = 1; if (A[8] < A[3 * m + m]) m = 2;
+    for (int k = 0; k < 3; ++k) nrm[k] = V[3 * k + m];
+}
+
+__attribute__((optimize("fp-contract=off"))) void covariances(int n, const float* xyz, int k, double* out) {
+    std::vector<std::pair<float, int>> d((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) {                                  // float squared distances, like FLANN's L2_Simple
+            const float dx = xyz[3 * i] - xyz[3 * j], dy = xyz[3 * i + 1] - xyz[3 * j + 1], dz = xyz[3 * i + 2] - xyz[3 * j + 2];
+            d[j] = {dx * dx + dy * dy + dz * dz, j};
+        }
+        const int kk = std::min(k, n);
+        std::partial_sort(d.begin(), d.begin() + kk, d.end());
+        double mean[3] = {0, 0, 0}, C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < kk; ++q) for (int r = 0; r < 3; ++r) mean[r] += (double)xyz[3 * d[q].second + r];
+        for (int r = 0; r < 3; ++r) mean[r] /= k;                       // rowwise().mean() over the k columns
+        for (int q = 0; q < kk; ++q) {
+            const double c[3] = {(double)xyz[3 * d[q].second] - mean[0], (double)xyz[3 * d[q].second + 1] - mean[1], (double)xyz[3 * d[q].second + 2] - mean[2]};
+            for (int r = 0; r < 3; ++r) for (int t = 0; t < 3; ++t) C[3 * r + t] += c[r] * c[t];
+        }
+        for (int r = 0; r < 9; ++r) C[r] /= k;
+        double nv[3]; smallest_eigvec3(C, nv);
+        for (int r = 0; r < 3; ++r) for (int t = 0; t < 3; ++t) out[9 * (size_t)i + 3 * r + t] = (r == t ? 1.0 : 0.0) - (1.0 - 1e-3) * nv[r] * nv[t];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -155,7 +202,10 @@ void orc_vgicp_default_options(vgicp_options* o) {
     o->neighbor_mode = VGICP_DIRECT1; o->optimizer = VGICP_LM; o->max_iterations = 64; o->lm_max_iterations = 10;
     o->rotation_epsilon = 2e-3; o->transformation_epsilon = 5e-4; o->lm_init_lambda_factor = 1e-9;
 }
-int orc_vgicp_set_target(vgicp_ctx* c, int32_t n, const float* xyz, const double* cov9, double resolution) {
+int orc_vgicp_covariances(vgicp_ctx*, int32_t n, const float* xyz, int32_t k, double* out) { covariances(n, xyz, k, out); return 0; }
+int orc_vgicp_set_target(vgicp_ctx* c, int32_t n, const float* xyz, const double* cov9_in, double resolution) {
+    std::vector<double> own; const double* cov9 = cov9_in;
+    if (!cov9) { own.resize(9 * (size_t)n); covariances(n, xyz, 20, own.data()); cov9 = own.data(); }
     c->c.res = resolution; c->c.vox.clear(); c->c.corr.clear();
     for (int i = 0; i < n; ++i) {                                   // create_voxelmap + AdditiveGaussianVoxel::append
         const double p[3] = {(double)xyz[3 * i], (double)xyz[3 * i + 1], (double)xyz[3 * i + 2]};
@@ -167,7 +217,9 @@ int orc_vgicp_set_target(vgicp_ctx* c, int32_t n, const float* xyz, const double
     for (auto& kv : c->c.vox) { Voxel& v = kv.second; for (int k = 0; k < 3; ++k) v.mean[k] /= v.num; for (int k = 0; k < 9; ++k) v.cov[k] /= v.num; }   // finalize
     return 0;
 }
-int orc_vgicp_set_source(vgicp_ctx* c, int32_t n, const float* xyz, const double* cov9) {
+int orc_vgicp_set_source(vgicp_ctx* c, int32_t n, const float* xyz, const double* cov9_in) {
+    std::vector<double> own; const double* cov9 = cov9_in;
+    if (!cov9) { own.resize(9 * (size_t)n); covariances(n, xyz, 20, own.data()); cov9 = own.data(); }
     c->c.sxyz.assign(xyz, xyz + 3 * (size_t)n); c->c.scov.assign(cov9, cov9 + 9 * (size_t)n); c->c.corr.clear();
     return 0;
 }

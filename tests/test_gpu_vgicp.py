@@ -63,3 +63,19 @@ def test_gpu_reproduces_golden_fixture():
     g = vgicp.Vgicp(lib.load_vilsolve(), "vgicp_")
     _check_golden(g, vgicp)
     g.close()
+
+
+def test_covariances_parity(oracle):
+    tx, _, sx, _, _ = vgicp.make_pair(seed=9, rings=8, az=400)
+    g = vgicp.Vgicp(lib.load_vilsolve(), "vgicp_"); o = vgicp.Vgicp(oracle.lib, "orc_vgicp_")
+    for k in (20, 10):
+        cg, co = g.covariances(sx, k), o.covariances(sx, k)
+        assert np.abs(cg - co).max() < 1e-10                          # same neighbours (exact search, same float distances), same 3 x 3 Jacobi
+    small = sx[:7]                                                       # fewer points than k
+    assert np.abs(g.covariances(small, 20) - o.covariances(small, 20)).max() < 1e-10
+    # covariances estimated inside set_source / set_target: the whole alignment still matches
+    for r in (g, o):
+        r.set_target(tx, None, 0.5); r.set_source(sx, None)
+    Tg, sg = g.align(np.eye(4)); To, so = o.align(np.eye(4))
+    assert sg.iterations == so.iterations and sg.converged == so.converged == 1 and np.abs(Tg - To).max() < 1e-8
+    g.close(); o.close()

@@ -118,3 +118,30 @@ def test_oracle_reproduces_golden_fixture(oracle):
     r = vgicp.Vgicp(oracle.lib, "orc_vgicp_")
     _check_golden(r, vgicp)
     r.close()
+
+
+def test_covariances_match_numpy(oracle, pair):
+    """calculate_covariances (fast_gicp_impl.hpp:241-300): 20 nearest neighbours incl. the point, covariance / k,
+    singular values -> (1, 1, 1e-3): numpy brute force + eigh."""
+    xyz = pair[2][:400]
+    r = vgicp.Vgicp(oracle.lib, "orc_vgicp_")
+    cov = r.covariances(xyz, 20).reshape(-1, 3, 3)
+    r.close()
+    x64 = xyz.astype(np.float64)
+    for i in (0, 7, 123, 399):
+        d = ((xyz[i] - xyz) ** 2).sum(axis=1)
+        nb = x64[np.argsort(d, kind="stable")[:20]]
+        Cm = (nb - nb.mean(axis=0)).T @ (nb - nb.mean(axis=0)) / 20
+        w, V = np.linalg.eigh(Cm)
+        ref = V @ np.diag([1e-3, 1.0, 1.0]) @ V.T
+        assert np.abs(cov[i] - ref).max() < 1e-9 * max(1.0, 1.0 / max(w[1] - w[0], 1e-12) * 1e-3)
+        assert np.allclose(cov[i], cov[i].T, atol=1e-15) and abs(np.trace(cov[i]) - 2.001) < 1e-12
+
+
+def test_align_with_estimated_covariances(oracle, pair):
+    tx, _, sx, _, T_true = pair
+    r = vgicp.Vgicp(oracle.lib, "orc_vgicp_")
+    r.set_target(tx, None, 0.5); r.set_source(sx, None)
+    T, s = r.align(np.eye(4))
+    r.close()
+    assert s.converged == 1 and np.abs(T[:3, 3] - T_true[:3, 3]).max() < 0.05
