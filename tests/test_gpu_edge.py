@@ -15,13 +15,13 @@ def _pair(cid=2, **kw):
     return synth.make_config(cid, **kw), synth.make_config(cid, **kw)
 
 
-def _check_solve(hip, oracle, wg, wo, opts=None, pos_tol=1e-6, after_solve=None):
+def _check_solve(hip, oracle, wg, wo, opts=None, pos_tol=1e-6, after_solve=None, cost_tol=1e-7):
     opts = opts or abi.default_options()
     p0 = wg.pose[0].copy()
     sg, so = hip.solve(wg, opts), oracle.solve(wo, opts)
     assert sg.iterations == so.iterations and sg.termination == so.termination and sg.successful_steps == so.successful_steps, \
         (sg.iterations, so.iterations, sg.termination, so.termination)
-    assert abs(sg.final_cost - so.final_cost) <= 1e-7 * max(1e-12, abs(so.final_cost))
+    assert abs(sg.final_cost - so.final_cost) <= cost_tol * max(1e-12, abs(so.final_cost))
     if after_solve is not None:
         after_solve()                                   # before the gauge fix re-derives every quaternion from its rotation matrix
     hip.gauge_fix(p0, wg); oracle.gauge_fix(p0, wo)
@@ -142,4 +142,4 @@ def test_minimal_window_two_frames(hip, oracle):
     wg, wo = build(), build()
     assert wg.L >= 3
     _check_lin(hip, oracle, wg)
-    _check_solve(hip, oracle, wg, wo, pos_tol=1e-5)      # prior-less: the gauge null space amplifies rounding
+    _check_solve(hip, oracle, wg, wo, pos_tol=1e-5, cost_tol=1e-5)      # prior-less: the gauge null space (regularised by mu = 1e-8 only) amplifies rounding
