@@ -1,5 +1,6 @@
+"""Phase timing of the step kernel: build csrc with -DVIL_STAMPS first (s_memtime stamps land in P.dbg), then run this on a GPU box."""
 import sys, os, ctypes as C, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g; g.load_package()
 from mvil_fusion_amd import abi, lib, synth
 import numpy as np
