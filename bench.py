@@ -251,18 +251,30 @@ def main():
         be.close()
         return
     sharded = False
+    shard_note = None
     if world > 1 and not args.replicas:
-        # one RCCL communicator over xGMI, created inside the library; the 128-byte id travels through torch.distributed
+        # one RCCL communicator over xGMI, created inside the library; the 128-byte id travels through torch.distributed.
+        # Every rank must agree on the outcome: if any rank cannot join, ALL fall back to independent replicas (reported).
         uid = (C.c_char * 128)()
+        ok = 1
         if rank == 0:
-            assert be.lib.vil_comm_unique_id(uid) == 0
+            ok = 1 if be.lib.vil_comm_unique_id(uid) == 0 else 0
         t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).cuda()
         dist.broadcast(t, 0)
-        uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
-        st = be.lib.vil_comm_init(be.ctx, uid, rank, world)
-        if st != 0:
-            raise RuntimeError("vil_comm_init failed: %d" % st)
-        sharded = True
+        flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+        dist.broadcast(flag, 0)
+        st = -5
+        if int(flag[0]) == 1:
+            uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+            st = be.lib.vil_comm_init(be.ctx, uid, rank, world)
+        good = torch.tensor([1 if st == 0 else 0], device="cuda", dtype=torch.int32)
+        dist.all_reduce(good, op=dist.ReduceOp.MIN)
+        if int(good[0]) == 1:
+            sharded = True
+        else:
+            shard_note = "RCCL communicator could not be created inside the library (status %d on rank %d): fell back to independent replicas" % (st, rank)
+            be.close()
+            be = lib.open_vilsolve(device=local, rank=0, world=1)
 
     got_prior = {"lib": False}
 
@@ -330,6 +342,8 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else ("factor set of ONE window sharded over %d GPUs: visual by landmark owner, LiDAR points in contiguous slices, RCCL all-reduce of [S|g|cost] + 5 scalars per iteration" % world if sharded else "%d independent replicas" % world),
                        "step": "one full window solve, inputs resident in HBM"},
         }
+        if shard_note:
+            out["config"]["note"] = shard_note
         if prof.sweep_launches > 0:
             ab = algorithmic_bytes(w)
             us = 1e3 * prof.sweep_ms / prof.sweep_launches
