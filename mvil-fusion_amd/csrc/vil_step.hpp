@@ -357,18 +357,29 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
     // ---- (II) ---------------------------------------------------------------------------------------------------
     for (int blk = TD - 1; blk >= 0; --blk) {
         const int kb = blk << 4, n_b = min(16, D - kb);
-        if (t < 16) {
-            // unconditional reads (addresses stay inside the tile / s.y), the triangular mask is a select: no exec-mask
-            // branches with their waits in the unrolled loop
-            const int tb = tl_base(blk, blk) + t * TILE_RS;
-            double a0 = s.dinv[kb + t] * s.y[kb + t], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (t < 64) {                                         // wave 0 (scalar branch); lanes 16..63 mirror lanes 0..15 and do not store
+            // all reads first, unconditionally (addresses stay inside the tile / s.y); the triangular mask is folded in as a
+            // 0/1 factor so that the loop stays straight-line code
+            const int tt = t & 15;
+            const int tb = tl_base(blk, blk) + tt * TILE_RS;
+            double av[16], yv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { av[i] = A[tb + i]; yv[i] = s.y[kb + i]; }
+            const double dv = s.dinv[kb + tt];
+            double a0 = dv * yv[0], a1 = 0.0, a2 = 0.0, a3 = 0.0;        // placeholder for lane 0; fixed below
+            a0 = 0.0;
 #pragma unroll
             for (int i = 1; i < 16; ++i) {
-                const double p = A[tb + i] * s.y[kb + i];
-                const double v = (i > t && i < n_b) ? p : 0.0;
-                if ((i & 3) == 0) a0 += v; else if ((i & 3) == 1) a1 += v; else if ((i & 3) == 2) a2 += v; else a3 += v;
+                const double msk = (double)(int)((i > tt) & (i < n_b));
+                const double p = msk * av[i] * yv[i];
+                if ((i & 3) == 0) a0 += p; else if ((i & 3) == 1) a1 += p; else if ((i & 3) == 2) a2 += p; else a3 += p;
             }
-            if (t < n_b) s.xs[kb + t] = (a0 + a1) + (a2 + a3);
+            // diagonal term: y[kb + tt] by shuffle-free select over the already loaded yv
+            double yd = yv[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) yd = (i == tt) ? yv[i] : yd;
+            const double x = dv * yd + ((a0 + a1) + (a2 + a3));
+            if (t < n_b) s.xs[kb + t] = x;
         }
         __syncthreads();
         for (int c = t; c < kb; c += NT) {                  // y_c -= sum_r L[kb+r][c] x_r
