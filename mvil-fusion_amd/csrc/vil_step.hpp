@@ -6,14 +6,14 @@
 //   landmark back-substitution -> traditional dogleg blend -> model decrease -> candidate state.
 // All trust-region state lives in `Ctl` in device memory; `done` makes later launches no-ops.
 //
-// Dense solve: the scaled reduced matrix M = Sc S' Sc + mu dc^2 (D x D, D = 15K+7) plus the
-// right-hand side as an extra row is held PACKED-LOWER in LDS (100 KB at K = 10) and factored by a
-// right-looking blocked Cholesky, NB = 8: wave 0 factors and inverts the 8x8 diagonal block in
-// registers (wave shuffles), one thread per row applies the inverse to the panel, and the trailing
-// update -- the only dense contraction on this path -- runs on the fp64 matrix cores
-// (v_mfma_f64_16x16x4_f64, one 16x16 tile per wave per step).  The forward substitution is the
-// factorisation of the extra row.  Windows whose packed matrix exceeds LDS (K >= 14) use the same
-// code on a packed global (L2-resident) buffer.
+// Dense solve: the scaled reduced matrix M = Sc S' Sc + mu dc^2 (D x D, D = 15K+7) plus the right-hand side as an
+// extra row is held in LDS as 16 x 16 lower tiles with a row stride of 17 doubles (120 KB at K = 10) and factored by
+// a right-looking blocked Cholesky, NB = 4 (chol_blocked below): every thread factors the 4x4 diagonal block
+// redundantly in registers, one thread per row solves the panel, and the trailing update -- the only dense
+// contraction on this path -- runs on the fp64 matrix cores (v_mfma_f64_16x16x4_f64) with the trailing tiles resident
+// in the MFMA accumulators.  The forward substitution is the factorisation of the extra row; the back substitution
+// uses the inverses of the 16 x 16 diagonal tiles.  Windows whose tiles exceed LDS (K > 10) run the same code on a
+// global (L2-resident) buffer.
 #pragma once
 #include "vil_dev.hpp"
 #include "vil_factors.hpp"

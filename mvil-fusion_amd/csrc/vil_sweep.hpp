@@ -4,13 +4,14 @@
 // No global atomics: every workgroup accumulates in registers / LDS and writes ONE partial record;
 // k_reduce then gathers the partials into the dense reduced system S', g (deterministic order).
 //
-// Work-group roles by blockIdx (all 256 threads):
+// Work-group roles by blockIdx (workgroups of VIL_SWEEP_THREADS = 512 threads):
 //   [imu]     one WG per IMU factor: lane 0 forms the raw 15x30 block, the WG whitens with the
 //             pre-factored sqrt-information and contracts to a 30x30 H block
-//   [visual]  one WG per group of landmark sub-chunks (<= 8 landmarks each): thread-per-factor
-//             evaluation staged in LDS, thread-per-landmark Schur pivots, wave-per-landmark block outer
-//             products accumulated into an LDS-resident packed triangle of the (6K+7)^2 visual sub-space
-//   [plane]/[edge] one WG per <=256 pose-uniform LiDAR points: thread-per-point evaluation,
+//   [visual]  one WG per group of landmark sub-chunks (<= VIL_VCHUNK_LM landmarks / VIL_VCHUNK_F factors each):
+//             thread-per-factor evaluation staged in LDS, 16 lanes per landmark for the Schur pivots, then three uniform
+//             passes of block outer products (shared x shared, shared x observer, observer x observer) accumulated
+//             with ds_add_f64 into an LDS-resident packed triangle of the (6K+7)^2 visual sub-space
+//   [plane]/[edge] 256 threads per <=256 pose-uniform LiDAR points (two chunks per WG): thread-per-point evaluation,
 //             wave64 butterfly reduction of the 6x6 + 6 + cost
 //   [misc]    prior (n x n gemv on the pre-contracted J0^T J0), ICP and LPS AutoDiff factors
 #pragma once
@@ -439,7 +440,7 @@ __device__ __forceinline__ int imu_local(const DevP& P, int i, int j, int col) {
 
 }  // namespace vd
 
-// grid = n_imu + n_vwg + n_pchunk + n_echunk + 1 workgroups of 256 threads
+// grid = n_imu + n_vwg + ceil(n_pchunk / 2) + ceil(n_echunk / 2) + 1 workgroups of VIL_SWEEP_THREADS threads
 __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O) {
     extern __shared__ double sm[];
     const Ctl ctl = *P.ctl;
