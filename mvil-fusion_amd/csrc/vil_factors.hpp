@@ -261,7 +261,7 @@ __device__ __forceinline__ D1 operator-(D1 x, D1 y) { return {x.a - y.a, x.d - y
 __device__ __forceinline__ D1 operator-(D1 x) { return {-x.a, -x.d}; }
 __device__ __forceinline__ D1 operator*(D1 x, D1 y) { return {x.a * y.a, x.a * y.d + x.d * y.a}; }
 __device__ __forceinline__ D1 operator/(D1 x, D1 y) { const double inv = 1.0 / y.a; const double q = x.a * inv; return {q, (x.d - q * y.d) * inv}; }
-__device__ __forceinline__ D1 dsin(D1 x) { return {sin(x.a), cos(x.a) * x.d}; }
+__device__ __forceinline__ D1 dsin(D1 x) { double sn, cs; sincos(x.a, &sn, &cs); return {sn, cs * x.d}; }   // one range reduction for both
 __device__ __forceinline__ D1 dacos(D1 x) { return {acos(x.a), -x.d / sqrt(1.0 - x.a * x.a)}; }
 struct DQ { D1 w, x, y, z; };
 struct DV { D1 x, y, z; };

@@ -13,7 +13,8 @@
 //             with ds_add_f64 into an LDS-resident packed triangle of the (6K+7)^2 visual sub-space
 //   [plane]/[edge] 256 threads per <=256 pose-uniform LiDAR points (two chunks per WG): thread-per-point evaluation,
 //             wave64 butterfly reduction of the 6x6 + 6 + cost
-//   [misc]    prior (n x n gemv on the pre-contracted J0^T J0), ICP and LPS AutoDiff factors
+//   [prior]   n x n gemv on the pre-contracted J0^T J0
+//   [rel]     ICP and LPS AutoDiff factors (scalar forward-mode duals, thread = (factor, block, coordinate))
 #pragma once
 #include "vil_dev.hpp"
 #include "vil_factors.hpp"
@@ -348,34 +349,43 @@ __device__ inline const double* prior_block_ptr(const DevP& P, const double* x, 
     return kind == 0 ? x + xo_pose(P, idx) : (kind == 1 ? x + xo_sb(P, idx) : (kind == 2 ? x + xo_ex(P) : x + xo_td(P)));
 }
 
-__device__ __forceinline__ void sweep_misc(const DevP& P, const SolveOpts& O, const double* x, double* sm) {
+// [prior] workgroup: r = r0 + J0 dx ;  J0^T J0 = pH, J0^T r0 = pg0, r0^T r0 = pc0 are pre-contracted, so the prior costs
+// one n x n gemv.  8 threads per output column split the k range (loads in flight instead of one dependent chain of n
+// global loads per thread), folded with three xor-shuffles.
+__device__ __forceinline__ void sweep_prior(const DevP& P, const double* x, double* sm) {
     const int t = threadIdx.x;
-    // ---- prior: r = r0 + J0 dx ;  J0^T J0 = pH, J0^T r0 = pg0, r0^T r0 = pc0 are pre-contracted ------------
-    if (P.pn > 0) {
-        const int n = P.pn;
-        double* dx = sm;           // n
-        double* red = sm + 512;
-        if (t < P.pnblk) {
-            const int kind = P.pblk_kind[t];
-            const int gs = kind == 0 || kind == 2 ? 7 : (kind == 1 ? 9 : 1);
-            double d[9];
-            prior_block_dx(gs, prior_block_ptr(P, x, t), P.px0 + P.pblk_xoff[t], d);
-            const int ls = gs == 7 ? 6 : gs;
-            for (int k = 0; k < ls; ++k) dx[P.pblk_col[t] + k] = d[k];
-        }
-        __syncthreads();
-        double part = 0;
-        for (int i = t; i < n; i += blockDim.x) {
-            double s = 0;
-            for (int k = 0; k < n; ++k) s += P.pH[(size_t)k * n + i] * dx[k];
+    if (P.pn <= 0) return;
+    const int n = P.pn;
+    double* dx = sm;           // n
+    double* red = sm + 512;
+    if (t < P.pnblk) {
+        const int kind = P.pblk_kind[t];
+        const int gs = kind == 0 || kind == 2 ? 7 : (kind == 1 ? 9 : 1);
+        double d[9];
+        prior_block_dx(gs, prior_block_ptr(P, x, t), P.px0 + P.pblk_xoff[t], d);
+        const int ls = gs == 7 ? 6 : gs;
+        for (int k = 0; k < ls; ++k) dx[P.pblk_col[t] + k] = d[k];
+    }
+    __syncthreads();
+    double part = 0;
+    for (int i0 = 0; i0 < n; i0 += (int)(blockDim.x >> 3)) {
+        const int i = i0 + (t >> 3), r = t & 7;
+        double s = 0;
+        if (i < n) for (int k = r; k < n; k += 8) s += P.pH[(size_t)k * n + i] * dx[k];
+        s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+        if (i < n && r == 0) {
             const double g = P.pg0[i] + s;
             part += dx[i] * (P.pg0[i] + g);
             P.mpart[i] = g;
         }
-        part = block_sum(part, red);
-        if (t == 0) P.mpart[n] = 0.5 * (P.pc0[0] + part);
-        __syncthreads();
     }
+    part = block_sum(part, red);
+    if (t == 0) P.mpart[n] = 0.5 * (P.pc0[0] + part);
+}
+
+// [rel] workgroup: the scan-to-scan ICP and LPS AutoDiff factors
+__device__ __forceinline__ void sweep_misc(const DevP& P, const SolveOpts& O, const double* x, double* sm) {
+    const int t = threadIdx.x;
     // ---- ICP (4 pose blocks) and LPS (2 pose blocks): thread per (factor, block) ----------------------------
     double* Jb = sm;              // up to 12 factors x 4 blocks x 21
     double* rb = sm + 12 * 84;    // 12 x 3
@@ -440,7 +450,7 @@ __device__ __forceinline__ int imu_local(const DevP& P, int i, int j, int col) {
 
 }  // namespace vd
 
-// grid = n_imu + n_vwg + ceil(n_pchunk / 2) + ceil(n_echunk / 2) + 1 workgroups of VIL_SWEEP_THREADS threads
+// grid = n_vwg + n_imu + ceil(n_pchunk / 2) + ceil(n_echunk / 2) + 2 (prior, relative constraints) workgroups of VIL_SWEEP_THREADS threads
 __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O) {
     extern __shared__ double sm[];
     const Ctl ctl = *P.ctl;
@@ -459,6 +469,8 @@ __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O
     if (b < npw) { if (!(P.skip_mask & 4)) vd::sweep_lidar<1>(P, O, b, x, sm); return; }
     b -= npw;
     if (b < new_) { if (!(P.skip_mask & 8)) vd::sweep_lidar<3>(P, O, b, x, sm); return; }
+    b -= new_;
+    if (b == 0) { if (!(P.skip_mask & 16)) vd::sweep_prior(P, x, sm); return; }
     if (!(P.skip_mask & 16)) vd::sweep_misc(P, O, x, sm);
 }
 

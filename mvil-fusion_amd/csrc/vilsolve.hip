@@ -390,7 +390,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     for (int q = 0; q < 2; ++q) { SysBuf& sb = P.sys[q]; sb.S = sb.ar; sb.gred = sb.S + (size_t)D * D; sb.bc = sb.gred + D; sb.diag = sb.bc + D; sb.cost = sb.diag + D; }
     HIPCHK(hipMemcpyAsync(ar.d, ar.h.data(), ar.h.size(), hipMemcpyHostToDevice, c->stream));
     c->P = P; c->K = K; c->L = L; c->D = D; c->NS = NS;
-    { const int per = VIL_SWEEP_THREADS / 256; c->n_blocks_sweep = P.n_imu + P.n_vwg + (P.n_pchunk + per - 1) / per + (P.n_echunk + per - 1) / per + 1; }
+    { const int per = VIL_SWEEP_THREADS / 256; c->n_blocks_sweep = P.n_imu + P.n_vwg + (P.n_pchunk + per - 1) / per + (P.n_echunk + per - 1) / per + 2; }
     c->lds_sweep = sizeof(double) * (size_t)(P.NVT + 3 * NV + VIL_VCHUNK_F * VF_STRIDE + VIL_VCHUNK_LM * 16 + 32 + VIL_VCHUNK_F + 8 + VIL_VCHUNK_LM + 8);
     if (c->lds_sweep < 8 * 2048) c->lds_sweep = 8 * 2048;
     if (c->lds_sweep > 160 * 1024) return VIL_ERR_UNSUPPORTED;
