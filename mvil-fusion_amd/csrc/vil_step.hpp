@@ -428,12 +428,9 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     const bool multi = P.split != 0;
     const bool cam = P.world <= 1 || P.rank == 0;      // camera-side terms of global sums are counted once
     STAMP(0);
-    if (PHASE == 1) {   // the all-reduced candidate system arrives in the staging buffer
-        double* dst = P.sys[1 - s.c.cur].ar;
-        const int cnt = D * D + 3 * D + 3;
-        for (int e = t; e < cnt; e += NT) dst[e] = P.arstage[e];
-        __syncthreads();
-    }
+    // PHASE 1: the all-reduced candidate system [S | gred | bc | diag | cost | xn sn] sits in the staging buffer and is
+    // consumed from there (it is read once, by the judge and by the fill of the tile matrix: no copy into the set)
+    const double* arblk = (PHASE == 1) ? P.arstage : nullptr;
     if (PHASE == 2) {
         if (s.c.skip_b) { if (t == 0) { s.c.skip_b = 0; *P.ctl = s.c; } return; }
         if (t == 0 && s.c.phase_need) {
@@ -451,10 +448,10 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     if (PHASE != 2 && t == 0) {
         Ctl& c = s.c;
         const int cand = 1 - c.cur;
-        const double cand_cost = *P.sys[cand].cost;
+        const double cand_cost = (PHASE == 1) ? arblk[(size_t)P.D * P.D + 3 * P.D] : *P.sys[cand].cost;
         c.cand_cost = cand_cost;
         if (multi && !c.first && !c.resweep) {     // parameter tolerance of the step just evaluated (norms all-reduced with S)
-            const double* tail = P.sys[cand].ar + (size_t)P.D * P.D + 3 * P.D + 1;
+            const double* tail = ((PHASE == 1) ? arblk : P.sys[cand].ar) + (size_t)P.D * P.D + 3 * P.D + 1;
             if (sqrt(tail[1]) <= O.parameter_tolerance * (sqrt(tail[0]) + O.parameter_tolerance)) { c.done = 1; c.term = 3; }
         }
         if (c.done) {}
@@ -484,6 +481,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     __syncthreads();
     const int cur = s.c.cur;
     SysBuf sb = P.sys[cur];
+    if (PHASE == 1) { sb.S = P.arstage; sb.gred = sb.S + (size_t)D * D; sb.bc = sb.gred + D; sb.diag = sb.bc + D; }   // read only when the candidate was just accepted
     const double* x = P.x[cur];
     double* xc = P.x[1 - cur];
     if (s.c.done) { if (t == 0) *P.ctl = s.c; return; }
