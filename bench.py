@@ -330,6 +330,25 @@ def main():
         el_max = tt.clone(); dist.all_reduce(el_max, op=dist.ReduceOp.MAX)
         # sharded: all ranks work on the SAME solves (units = its iterations, counted once); replicas: units add up
         tot_iters, max_el = (float(iters) if sharded else float(it_sum[0])), float(el_max[1])
+    # N > 1, sharded: a second, clearly labelled leg with the SAME K steps run as N independent replicas (one whole window
+    # per GPU, no collective) -- the throughput a multi-session deployment gets from the same hardware.  Not `value`.
+    replicas_leg = None
+    if sharded and dist is not None:
+        be2 = lib.open_vilsolve(device=local, rank=0, world=1)
+        be2.upload(w)
+        for _ in range(max(1, args.warmup)):
+            be2.reset_state(); be2.solve_resident(opts)
+        sync()
+        t2 = time.perf_counter(); its2 = 0
+        for _ in range(args.steps):
+            be2.reset_state(); its2 += be2.solve_resident(opts).iterations
+        sync()
+        el2 = time.perf_counter() - t2
+        tt2 = torch.tensor([float(its2), el2], device="cuda", dtype=torch.float64)
+        s2 = tt2.clone(); dist.all_reduce(s2, op=dist.ReduceOp.SUM)
+        m2 = tt2.clone(); dist.all_reduce(m2, op=dist.ReduceOp.MAX)
+        replicas_leg = {"value": float(s2[0]) / float(m2[1]), "unit": "iterations/s", "scaling": "weak", "what": "%d independent replicas of the same window, %d steps each, no collective" % (world, args.steps)}
+        be2.close()
     if rank == 0:
         out = {
             "metric": "sliding-window solve iterations/sec (10 KF, 1k feat, 30k LiDAR pts)",
@@ -344,6 +363,8 @@ def main():
         }
         if shard_note:
             out["config"]["note"] = shard_note
+        if replicas_leg:
+            out["replicas"] = replicas_leg
         if prof.sweep_launches > 0:
             ab = algorithmic_bytes(w)
             us = 1e3 * prof.sweep_ms / prof.sweep_launches
