@@ -225,13 +225,14 @@ def main():
     ap.add_argument("--vgicp", action="store_true", help="SURVEY 8(f) row 1: bench the voxelised GICP linearisation instead of the headline metric")
     ap.add_argument("--vgicp-rings", type=int, default=16)
     ap.add_argument("--vgicp-az", type=int, default=1800)
+    ap.add_argument("--force-comm", action="store_true", help="test hook: take the multi-GPU code path (process group, communicator, replicas leg) with a single rank")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of sharding one window over RCCL")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or args.force_comm:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
@@ -252,7 +253,7 @@ def main():
         return
     sharded = False
     shard_note = None
-    if world > 1 and not args.replicas:
+    if (world > 1 or args.force_comm) and not args.replicas:
         # one RCCL communicator over xGMI, created inside the library; the 128-byte id travels through torch.distributed.
         # Every rank must agree on the outcome: if any rank cannot join, ALL fall back to independent replicas (reported).
         uid = (C.c_char * 128)()
