@@ -280,30 +280,56 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
                 }
             }
         } else { if (r0 < R) {
-            const int I0 = r0 >> 4, n = T - I0;
-            const int ntile = n * (n + 1) / 2;
-            for (int t0 = 0; t0 < ntile; t0 += 8 * NW) {
-                d4 acc[8]; double av[8], bv[8]; int cb[8];
-                const int cnt = min(8, (ntile - t0 - wave + NW - 1) / NW);   // wave-uniform number of live slots
+            // Matrix in global (L2) memory, K > 10.  Only the tiles of the ACTIVE tile column need this block step's update
+            // now (the next diagonal block and panel read them); every tile to the right of it is updated ONCE per tile
+            // column with the whole 16-wide panel (four MFMAs in the accumulator, one read-modify-write) -- a quarter of the
+            // read-modify-write traffic through L2, which is what bounds this path.
+            {   // (i) tiles (I, Kt), I >= r0 >> 4
+                const int I0 = r0 >> 4, nact = T - I0;
+                for (int u0 = wave; u0 < nact; u0 += NW) {
+                    const int I = I0 + u0;
+                    const int rr = (I << 4) + (lane & 15), cr = (Kt << 4) + (lane & 15);
+                    const double a_ = A[tl_base(I, Kt) + la + ko], b_ = A[tl_base(Kt, Kt) + la + ko];
+                    const double av = (rr >= r0 && rr < R && kk) ? a_ : 0.0, bv = (cr >= r0 && cr < D && kk) ? b_ : 0.0;
+                    d4 z = {0.0, 0.0, 0.0, 0.0};
+                    const d4 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, z, 0, 0, 0);
+                    const int cb = tl_base(I, Kt) + lc;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) if (u < cnt) {
-                    const int tile = t0 + wave + u * NW;
-                    int Ir = (int)((sqrtf(8.f * (float)tile + 1.f) - 1.f) * 0.5f);
-                    if (((Ir + 1) * (Ir + 2)) / 2 <= tile) ++Ir;
-                    if ((Ir * (Ir + 1)) / 2 > tile) --Ir;
-                    const int Jr = tile - (Ir * (Ir + 1)) / 2;
-                    const int I = I0 + Ir, J = I0 + Jr;
-                    cb[u] = tl_base(I, J);
-                    const int rr = (I << 4) + (lane & 15), cr = (J << 4) + (lane & 15);
-                    av[u] = (rr >= r0 && rr < R && kk) ? A[tl_base(I, Kt) + la + ko] : 0.0;
-                    bv[u] = (cr >= r0 && cr < D && kk) ? A[tl_base(J, Kt) + la + ko] : 0.0;
+                    for (int g = 0; g < 4; ++g) A[cb + g * (4 * TILE_RS)] -= acc[g];
                 }
+            }
+            const bool col_done = (ko + nb >= 16) || (kb + nb >= D);          // last block step inside tile column Kt
+            if (col_done && Kt + 1 < T) {   // (ii) tiles (I, J), Kt < J <= I, with the panel columns [16 Kt, min(16 Kt + 16, D))
+                __syncthreads();            // the panel of this block step (written by other threads) is part of the operands
+                const int I0 = Kt + 1, n = T - I0, ntile = n * (n + 1) / 2;
+                const int kv = min(16, D - (Kt << 4));                        // valid factor columns in this tile column
+                for (int t0 = 0; t0 < ntile; t0 += 4 * NW) {
+                    d4 acc[4]; int cb[4];
+                    const int cnt = min(4, (ntile - t0 - wave + NW - 1) / NW);   // wave-uniform number of live slots
 #pragma unroll
-                for (int u = 0; u < 8; ++u) if (u < cnt) { d4 z = {0.0, 0.0, 0.0, 0.0}; acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], z, 0, 0, 0); }
+                    for (int u = 0; u < 4; ++u) if (u < cnt) {
+                        const int tile = t0 + wave + u * NW;
+                        int Ir = (int)((sqrtf(8.f * (float)tile + 1.f) - 1.f) * 0.5f);
+                        if (((Ir + 1) * (Ir + 2)) / 2 <= tile) ++Ir;
+                        if ((Ir * (Ir + 1)) / 2 > tile) --Ir;
+                        const int Jr = tile - (Ir * (Ir + 1)) / 2;
+                        const int I = I0 + Ir, J = I0 + Jr;
+                        cb[u] = tl_base(I, J);
+                        const int rr = (I << 4) + (lane & 15), cr = (J << 4) + (lane & 15);
+                        d4 c4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int u = 0; u < 8; ++u) if (u < cnt) {
+                        for (int ks = 0; ks < 16; ks += 4) {
+                            const bool kq = ks + (lane >> 4) < kv;
+                            const double a_ = A[tl_base(I, Kt) + la + ks], b_ = A[tl_base(J, Kt) + la + ks];
+                            c4 = __builtin_amdgcn_mfma_f64_16x16x4f64((rr < R && kq) ? a_ : 0.0, (cr < D && kq) ? b_ : 0.0, c4, 0, 0, 0);
+                        }
+                        acc[u] = c4;
+                    }
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) A[cb[u] + lc + g * (4 * TILE_RS)] -= acc[u][g];   // rows / cols outside [r0, R) got zero operands
+                    for (int u = 0; u < 4; ++u) if (u < cnt) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) A[cb[u] + lc + g * (4 * TILE_RS)] -= acc[u][g];
+                    }
                 }
             }
         } }
