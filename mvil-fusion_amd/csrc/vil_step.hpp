@@ -160,7 +160,7 @@ __device__ __forceinline__ int tl_phys(int e) { return (e >> 8) * TILE_SZ + ((e 
 // On return rows < D hold L, row D holds y = L^-1 rhs, s.dinv[j] = 1 / L_jj.  Returns false (uniformly) on a
 // non-positive pivot.
 template <bool REGRES, class PTR>
-__device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
+__device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double* Acol = nullptr) {
     const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
     const int R = D + 1;                 // rows including the rhs row
     const int T = (R + 15) >> 4;         // tile rows
@@ -205,12 +205,20 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
             }
             __syncthreads();
         }
+        if constexpr (!REGRES) if (ko == 0) {         // global path: stage the ACTIVE tile column in LDS for its four block steps
+            __syncthreads();                          // the deferred updates of the previous column have landed in A
+            for (int e = t; e < (T - Kt) * TILE_SZ; e += NT) { const int I = Kt + e / TILE_SZ, w = e - (I - Kt) * TILE_SZ; Acol[e] = A[tl_base(I, Kt) + w]; }
+            __syncthreads();
+        }
+        // tile (I, Kt) of the active column lives at AC[cbase(I) ...]: the tile array itself (LDS path) or the staged copy
+        double* const AC = REGRES ? (double*)A : Acol;
+        auto cbase = [&](int I) { return REGRES ? tl_base(I, Kt) : (I - Kt) * TILE_SZ; };
         // ---- 1. diagonal 4x4 block, redundantly per thread (identity padding for a short last block) ----------
-        const int db = tl_base(Kt, Kt) + ko * TILE_RS + ko;
-        double d00 = A[db], d10 = 0, d11 = 1, d20 = 0, d21 = 0, d22 = 1, d30 = 0, d31 = 0, d32 = 0, d33 = 1;
-        if (nb > 1) { d10 = A[db + TILE_RS]; d11 = A[db + TILE_RS + 1]; }
-        if (nb > 2) { d20 = A[db + 2 * TILE_RS]; d21 = A[db + 2 * TILE_RS + 1]; d22 = A[db + 2 * TILE_RS + 2]; }
-        if (nb > 3) { d30 = A[db + 3 * TILE_RS]; d31 = A[db + 3 * TILE_RS + 1]; d32 = A[db + 3 * TILE_RS + 2]; d33 = A[db + 3 * TILE_RS + 3]; }
+        const int db = cbase(Kt) + ko * TILE_RS + ko;
+        double d00 = AC[db], d10 = 0, d11 = 1, d20 = 0, d21 = 0, d22 = 1, d30 = 0, d31 = 0, d32 = 0, d33 = 1;
+        if (nb > 1) { d10 = AC[db + TILE_RS]; d11 = AC[db + TILE_RS + 1]; }
+        if (nb > 2) { d20 = AC[db + 2 * TILE_RS]; d21 = AC[db + 2 * TILE_RS + 1]; d22 = AC[db + 2 * TILE_RS + 2]; }
+        if (nb > 3) { d30 = AC[db + 3 * TILE_RS]; d31 = AC[db + 3 * TILE_RS + 1]; d32 = AC[db + 3 * TILE_RS + 2]; d33 = AC[db + 3 * TILE_RS + 3]; }
         double l00, r0_, l11, r1_, l22, r2_, l33, r3_;
         bool ok = d00 > 0.0 && isfinite(d00);
         sqrt_rsqrt(d00, l00, r0_);
@@ -228,13 +236,13 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
         // ---- 2. panel rows (incl. the rhs row): forward substitution against the block ----------------------------
         const int r0 = kb + nb;
         for (int i = r0 + t; i < R; i += NT) {
-            const int base = tl_base(i >> 4, Kt) + (i & 15) * TILE_RS + ko;
-            const double a0 = A[base], a1 = nb > 1 ? A[base + 1] : 0.0, a2 = nb > 2 ? A[base + 2] : 0.0, a3 = nb > 3 ? A[base + 3] : 0.0;
+            const int base = cbase(i >> 4) + (i & 15) * TILE_RS + ko;
+            const double a0 = AC[base], a1 = nb > 1 ? AC[base + 1] : 0.0, a2 = nb > 2 ? AC[base + 2] : 0.0, a3 = nb > 3 ? AC[base + 3] : 0.0;
             const double x0 = a0 * r0_;
             const double x1 = (a1 - x0 * l10) * r1_;
             const double x2 = (a2 - x0 * l20 - x1 * l21) * r2_;
             const double x3 = (a3 - x0 * l30 - x1 * l31 - x2 * l32) * r3_;
-            A[base] = x0; if (nb > 1) A[base + 1] = x1; if (nb > 2) A[base + 2] = x2; if (nb > 3) A[base + 3] = x3;
+            AC[base] = x0; if (nb > 1) AC[base + 1] = x1; if (nb > 2) AC[base + 2] = x2; if (nb > 3) AC[base + 3] = x3;
         }
         if (t == NT - 1) {              // an idle thread (no panel row): X = L_kk^-1 (lower 4x4) for the back substitution
             double* X = s.Xb + (kb >> 2) * 10;
@@ -247,10 +255,10 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
             X[0] = r0_; X[1] = x10; X[2] = r1_; X[3] = x20; X[4] = x21; X[5] = r2_; X[6] = x30; X[7] = x31; X[8] = x32; X[9] = r3_;
         }
         if (t == 0) {                   // the factored block itself and the reciprocal pivots
-            A[db] = l00; s.dinv[kb] = r0_;
-            if (nb > 1) { A[db + TILE_RS] = l10; A[db + TILE_RS + 1] = l11; s.dinv[kb + 1] = r1_; }
-            if (nb > 2) { A[db + 2 * TILE_RS] = l20; A[db + 2 * TILE_RS + 1] = l21; A[db + 2 * TILE_RS + 2] = l22; s.dinv[kb + 2] = r2_; }
-            if (nb > 3) { A[db + 3 * TILE_RS] = l30; A[db + 3 * TILE_RS + 1] = l31; A[db + 3 * TILE_RS + 2] = l32; A[db + 3 * TILE_RS + 3] = l33; s.dinv[kb + 3] = r3_; }
+            AC[db] = l00; s.dinv[kb] = r0_;
+            if (nb > 1) { AC[db + TILE_RS] = l10; AC[db + TILE_RS + 1] = l11; s.dinv[kb + 1] = r1_; }
+            if (nb > 2) { AC[db + 2 * TILE_RS] = l20; AC[db + 2 * TILE_RS + 1] = l21; AC[db + 2 * TILE_RS + 2] = l22; s.dinv[kb + 2] = r2_; }
+            if (nb > 3) { AC[db + 3 * TILE_RS] = l30; AC[db + 3 * TILE_RS + 1] = l31; AC[db + 3 * TILE_RS + 2] = l32; AC[db + 3 * TILE_RS + 3] = l33; s.dinv[kb + 3] = r3_; }
         }
         __syncthreads();
         CSTAMP(1);
@@ -289,13 +297,13 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
                 for (int u0 = wave; u0 < nact; u0 += NW) {
                     const int I = I0 + u0;
                     const int rr = (I << 4) + (lane & 15), cr = (Kt << 4) + (lane & 15);
-                    const double a_ = A[tl_base(I, Kt) + la + ko], b_ = A[tl_base(Kt, Kt) + la + ko];
+                    const double a_ = AC[cbase(I) + la + ko], b_ = AC[cbase(Kt) + la + ko];
                     const double av = (rr >= r0 && rr < R && kk) ? a_ : 0.0, bv = (cr >= r0 && cr < D && kk) ? b_ : 0.0;
                     d4 z = {0.0, 0.0, 0.0, 0.0};
                     const d4 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, z, 0, 0, 0);
-                    const int cb = tl_base(I, Kt) + lc;
+                    const int cb = cbase(I) + lc;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) A[cb + g * (4 * TILE_RS)] -= acc[g];
+                    for (int g = 0; g < 4; ++g) AC[cb + g * (4 * TILE_RS)] -= acc[g];
                 }
             }
             const bool col_done = (ko + nb >= 16) || (kb + nb >= D);          // last block step inside tile column Kt
@@ -320,7 +328,7 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
 #pragma unroll
                         for (int ks = 0; ks < 16; ks += 4) {
                             const bool kq = ks + (lane >> 4) < kv;
-                            const double a_ = A[tl_base(I, Kt) + la + ks], b_ = A[tl_base(J, Kt) + la + ks];
+                            const double a_ = AC[cbase(I) + la + ks], b_ = AC[cbase(J) + la + ks];
                             c4 = __builtin_amdgcn_mfma_f64_16x16x4f64((rr < R && kq) ? a_ : 0.0, (cr < D && kq) ? b_ : 0.0, c4, 0, 0, 0);
                         }
                         acc[u] = c4;
@@ -331,6 +339,10 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s) {
                         for (int g = 0; g < 4; ++g) A[cb[u] + lc + g * (4 * TILE_RS)] -= acc[u][g];
                     }
                 }
+            }
+            if (col_done) {                 // the factored tile column goes back to the tile array (back substitution, later operands)
+                __syncthreads();
+                for (int e = t; e < (T - Kt) * TILE_SZ; e += NT) { const int I = Kt + e / TILE_SZ, w = e - (I - Kt) * TILE_SZ; A[tl_base(I, Kt) + w] = Acol[e]; }
             }
         } }
         __syncthreads();
@@ -599,7 +611,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         STAMP(2);
         if (PHASE == 0 && gm <= O.gradient_tolerance) { if (t == 0) { s.c.done = 1; s.c.term = 2; *P.ctl = s.c; } return; }
         bool ok;
-        if constexpr (LDSM) ok = chol_blocked<true>(Alds, D, s); else ok = chol_blocked<false>(Ag, D, s);
+        if constexpr (LDSM) ok = chol_blocked<true>(Alds, D, s); else ok = chol_blocked<false>(Ag, D, s, Alds);      // Alds = staging of the active tile column
         STAMP(3);
 #ifdef VIL_STAMPS
         if (t == 0) { P.dbg[20] = s.tacc[0]; P.dbg[21] = s.tacc[1]; P.dbg[22] = s.tacc[2]; }

@@ -402,6 +402,14 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
         HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
         HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+    } else {
+        // tile array in global memory; LDS stages the active tile column of the factorisation (T tiles)
+        const size_t T = (size_t)(D + 1 + 15) / 16;
+        c->lds_step = 8 * (size_t)TILE_SZ * T;
+        if (c->lds_step + sizeof(vd::StepShared) + 256 > 160 * 1024) return VIL_ERR_UNSUPPORTED;
+        HIPCHK(hipFuncSetAttribute((const void*)k_step<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+        HIPCHK(hipFuncSetAttribute((const void*)k_step<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+        HIPCHK(hipFuncSetAttribute((const void*)k_step<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
     }
     // one-time set-up: IMU sqrt-information, prior contraction
     HIPCHK(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
@@ -476,17 +484,17 @@ static void launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEv
     if (!step) return;
     if (!c->split) {
         if (c->step_lds) hipLaunchKernelGGL((k_step<true, 0>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
-        else hipLaunchKernelGGL((k_step<false, 0>), dim3(1), dim3(VIL_STEP_THREADS), 0, c->stream, c->P, so);
+        else hipLaunchKernelGGL((k_step<false, 0>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
         return;
     }
     // multi-GPU: all-reduce the partial reduced system (+ step norms), step A, all-reduce 5 scalars, step B
     const size_t cnt = (size_t)c->D * c->D + 3 * (size_t)c->D + 3;
     all_reduce(c, c->P.arstage, cnt);
     if (c->step_lds) hipLaunchKernelGGL((k_step<true, 1>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
-    else hipLaunchKernelGGL((k_step<false, 1>), dim3(1), dim3(VIL_STEP_THREADS), 0, c->stream, c->P, so);
+    else hipLaunchKernelGGL((k_step<false, 1>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
     all_reduce(c, c->P.scal, 8);
     if (c->step_lds) hipLaunchKernelGGL((k_step<true, 2>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
-    else hipLaunchKernelGGL((k_step<false, 2>), dim3(1), dim3(VIL_STEP_THREADS), 0, c->stream, c->P, so);
+    else hipLaunchKernelGGL((k_step<false, 2>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
 }
 
 static int init_ctl(vil_ctx* c, const vil_options* o, int lin_mode) {
