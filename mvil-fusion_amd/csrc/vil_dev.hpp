@@ -25,6 +25,7 @@ struct SysBuf {       // one linearisation of the window (double-buffered: curre
 };
 
 struct Ctl {          // trust-region state, lives in device memory, owned by the step kernel
+    int gen;          // solve generation (host): with n_sweeps it forms the epoch of the helper-workgroup flags
     int cur, iter, done, term, first, resweep, reuse, nsucc, invalid_run, status, lin_mode, n_sweeps;
     int phase_need, skip_b;       // split-step hand-off (multi-GPU: step A | all-reduce scalars | step B)
     double radius, mu, cost_cur, model_change, alpha, dogleg_norm, initial_cost, cand_cost;
@@ -86,6 +87,9 @@ struct DevP {
     int split;                    // step kernel split around the scalar all-reduce (world > 1, or forced for single-GPU testing)
     long long* dbg;               // 64 cycle stamps (debug/profiling aid)
     int skip_mask;                // debug: bit0 visual, 1 imu, 2 plane, 3 edge, 4 misc roles skipped in the sweep
+    // helper workgroups of the single-GPU step kernel (landmark pre-pass on extra CUs): n_help of them, each publishes
+    // {q, g2, gm} in hpart[4 * k ..] and then stores the launch epoch in hflag[k]; only the master workgroup ever waits
+    int n_help; double* hpart; int* hflag;
 };
 
 __host__ __device__ inline int xo_pose(const DevP& P, int k) { return 7 * k; }

@@ -449,6 +449,12 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     extern __shared__ double Alds[];
     const int t = threadIdx.x, NT = blockDim.x;
     const int D = P.D, L = P.L;
+    // PHASE 0 may be launched with 1 + P.n_help workgroups: the extra ones run the same judge on their own copy of Ctl,
+    // then do the landmark pre-pass of their slice on their own CU (that pass is bound by what ONE CU can pull out of
+    // L2), publish three partial sums and leave.  They never wait for anything; only the master spins (on their flags)
+    // and only the master writes Ctl / the candidate -- after every helper has signalled, i.e. has read the old Ctl.
+    const bool helper = PHASE == 0 && blockIdx.x > 0;
+    const int nhelp = (PHASE == 0) ? (int)gridDim.x - 1 : 0;
     if (t == 0) { s.c = *P.ctl; s.need = 0; s.was_first = 0; s.ok = 1; }
     for (int q = t; q < 256; q += NT) {      // triangular tile index -> (tile row, tile col)
         int Ir = (int)((sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
@@ -462,7 +468,12 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
 #else
     #define STAMP(k) do {} while (0)
 #endif
-    if (s.c.done) return;
+    if (s.c.done) return;                    // finished in an earlier launch: nobody writes anything
+    const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
+    auto helper_done = [&]() { if (t == 0) { __threadfence(); __hip_atomic_store(P.hflag + (blockIdx.x - 1), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); } };
+    auto wait_helpers = [&]() {              // master, thread 0: all helpers have read Ctl (and published their sums)
+        if (t == 0) for (int k = 0; k < nhelp; ++k) while (__hip_atomic_load(P.hflag + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+    };
     const bool multi = P.split != 0;
     const bool cam = P.world <= 1 || P.rank == 0;      // camera-side terms of global sums are counted once
     STAMP(0);
@@ -522,7 +533,37 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     if (PHASE == 1) { sb.S = P.arstage; sb.gred = sb.S + (size_t)D * D; sb.bc = sb.gred + D; sb.diag = sb.bc + D; }   // read only when the candidate was just accepted
     const double* x = P.x[cur];
     double* xc = P.x[1 - cur];
-    if (s.c.done) { if (t == 0) *P.ctl = s.c; return; }
+    if (helper) {
+        if (!s.c.done && s.need) {
+            // camera vectors u = Sc gradient_/d in LDS (nothing global is written here: that is the master's job)
+            for (int i = t; i < D; i += NT) {
+                const double dg = sb.diag[i], b = sb.bc[i];
+                const double Sc = s.was_first ? (O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0) : P.Sc[i];
+                const double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
+                s.y[i] = Sc * (Sc * b / d) / d;
+            }
+            __syncthreads();
+            const int per = (L + nhelp - 1) / nhelp, l0 = ((int)blockIdx.x - 1) * per, l1 = min(L, l0 + per);
+            double q = 0, g2 = 0, gm = 0;
+            for (int l = l0 + t; l < l1; l += NT) {
+                const double ip = sb.invp[l], Sl = P.Sl[l], h = sb.hll[l], b = sb.bl[l];
+                const double d = sqrt(fmin(fmax(Sl * Sl * h, 1e-6), 1e32));
+                const double g = ip != 0.0 ? Sl * b / d : 0.0;
+                P.dl[l] = d; P.gradl[l] = g;
+                if (ip != 0.0) {
+                    const double ul = Sl * g / d;
+                    const double ev = lm_dot(P, sb, l, s.y);
+                    q += ip * ev * ev + 2.0 * ul * ev + h * ul * ul;
+                    g2 += g * g; gm = fmax(gm, fabs(b));
+                }
+            }
+            bsum3<true>(g2, q, gm, s);
+            if (t == 0) { double* hp = P.hpart + 4 * ((int)blockIdx.x - 1); hp[0] = q; hp[1] = g2; hp[2] = gm; }
+        }
+        helper_done();
+        return;
+    }
+    if (s.c.done) { if (t == 0) { wait_helpers(); *P.ctl = s.c; } return; }
     // prefetch this thread's share of S' (tiled order) so that the global latency hides behind the vector passes
     double pf[PF_N];
     if (PHASE != 2 && s.need) {
@@ -558,7 +599,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         STAMP(9);
         // ---- one pass over the landmarks: dl, gradient_, and their share of u^T H u --------------------------
         double q = 0;
-        for (int l = t; l < L; l += NT) {
+        for (int l = t; l < (nhelp ? 0 : L); l += NT) {      // with helper workgroups this pass runs on their CUs
             const double ip = sb.invp[l], Sl = P.Sl[l], h = sb.hll[l], b = sb.bl[l];
             const double d = sqrt(fmin(fmax(Sl * Sl * h, 1e-6), 1e32));
             const double g = ip != 0.0 ? Sl * b / d : 0.0;
@@ -608,6 +649,20 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         }
         STAMP(11);
         bsum3<true>(g2, q, gm, s);
+        if (nhelp) {                          // the helpers' landmark sums, added in workgroup order (deterministic)
+            if (t == 0) {
+                wait_helpers();
+                for (int k = 0; k < nhelp; ++k) {
+                    q += __hip_atomic_load(P.hpart + 4 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g2 += __hip_atomic_load(P.hpart + 4 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gm = fmax(gm, __hip_atomic_load(P.hpart + 4 * k + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                s.red[0] = q; s.red[1] = g2; s.red[2] = gm;
+            }
+            __syncthreads();
+            q = s.red[0]; g2 = s.red[1]; gm = s.red[2];
+            __syncthreads();
+        }
         STAMP(2);
         if (PHASE == 0 && gm <= O.gradient_tolerance) { if (t == 0) { s.c.done = 1; s.c.term = 2; *P.ctl = s.c; } return; }
         bool ok;
@@ -749,5 +804,5 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     __syncthreads();
     if (s.c.resweep && !s.c.done) { for (int i = t; i < P.NS; i += NT) xc[i] = x[i]; }
     STAMP(7);
-    if (t == 0) *P.ctl = s.c;
+    if (t == 0) { if (nhelp) wait_helpers(); *P.ctl = s.c; }      // (idempotent when the sums were already collected)
 }

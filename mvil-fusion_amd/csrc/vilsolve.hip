@@ -106,6 +106,7 @@ struct vil_ctx {
     struct ChunkGraph { int n; SolveOpts so; hipGraphExec_t exec; };
     std::vector<ChunkGraph> graphs;
     int use_graph = -1;            // VIL_GRAPH=0 disables
+    int solve_gen = 0;             // generation counter of the helper-workgroup flags (Ctl::gen)
     int solves_since_upload = 0;
     bool split = false;            // step kernel launched as A | all-reduce | B
     int last_live = 5;             // live sweep launches of the previous solve (sizes the first launch chunk)
@@ -378,11 +379,14 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     P.split = c->split ? 1 : 0;
     put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.Sl); put(nullptr, 8 * (size_t)D, (void**)&P.Sc); put(nullptr, 8 * (size_t)D, (void**)&P.dc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.dl);
     put(nullptr, 8 * (size_t)D, (void**)&P.gradc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gradl); put(nullptr, 8 * (size_t)D, (void**)&P.gnc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gnl);
-    { const size_t Tm = (size_t)(D + 16) / 16; put(nullptr, 8 * std::max((size_t)D * D, (size_t)TILE_SZ * (Tm * (Tm + 1) / 2)), (void**)&P.M); } put(nullptr, 8 * (size_t)D, (void**)&P.stepc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.stepl);
+    { const size_t Tm = (size_t)(D + 16) / 16; put(nullptr, 8 * std::max((size_t)D * D, (size_t)TILE_SZ * (Tm * (Tm + 1) / 2)), (void**)&P.M); } put(nullptr, 8 * (size_t)D, (void**)&P.stepc); put(nullptr, 8 * 4 * 16, (void**)&P.hpart); put(nullptr, 4 * 16, (void**)&P.hflag); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.stepl);
     put(nullptr, 8 * (size_t)D, (void**)&P.tmpc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.tmpl);
     put(nullptr, sizeof(Ctl), (void**)&P.ctl);
     put(nullptr, 8 * 64, (void**)&P.dbg);
     if (const char* ev = getenv("VIL_SKIP")) P.skip_mask = atoi(ev);
+    // helper workgroups of the step kernel: worth it once every master thread would own more than one landmark
+    P.n_help = L >= 2 * VIL_STEP_THREADS ? 7 : (L >= VIL_STEP_THREADS ? 3 : 0);
+    if (const char* ev = getenv("VIL_HELP")) P.n_help = std::max(0, std::min(15, atoi(ev)));
     // device allocation + single H2D copy
     const size_t total = (ar.h.size() + 255) & ~size_t(255);
     if (total > ar.cap) { if (ar.d) HIPCHK(hipFree(ar.d)); ar.d = nullptr; HIPCHK(hipMalloc(&ar.d, total)); ar.cap = total; }
@@ -483,8 +487,8 @@ static void launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEv
     if (ev_mid) hipEventRecord(ev_mid, c->stream);
     if (!step) return;
     if (!c->split) {
-        if (c->step_lds) hipLaunchKernelGGL((k_step<true, 0>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
-        else hipLaunchKernelGGL((k_step<false, 0>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
+        if (c->step_lds) hipLaunchKernelGGL((k_step<true, 0>), dim3(1 + c->P.n_help), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
+        else hipLaunchKernelGGL((k_step<false, 0>), dim3(1 + c->P.n_help), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
         return;
     }
     // multi-GPU: all-reduce the partial reduced system (+ step norms), step A, all-reduce 5 scalars, step B
@@ -499,7 +503,7 @@ static void launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEv
 
 static int init_ctl(vil_ctx* c, const vil_options* o, int lin_mode) {
     Ctl ctl; memset(&ctl, 0, sizeof ctl);
-    ctl.cur = 0; ctl.first = 1; ctl.radius = o->initial_radius; ctl.mu = o->min_mu; ctl.lin_mode = lin_mode;
+    ctl.gen = ++c->solve_gen; ctl.cur = 0; ctl.first = 1; ctl.radius = o->initial_radius; ctl.mu = o->min_mu; ctl.lin_mode = lin_mode;
     *c->h_ctl = ctl;
     HIPCHK(hipMemcpyAsync(c->P.ctl, c->h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
     return VIL_OK;
