@@ -239,6 +239,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     graft.load_package()
     from mvil_fusion_amd import abi, lib, synth
+    if not os.path.exists(lib.LIB_PATH) or not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        if rank == 0:
+            graft.build()              # a checkout without built artefacts (the .so files are git-ignored): compile, do not fall back
+        if dist is not None:
+            dist.barrier()
     if args.vgicp:
         vgicp_mode(args)
         return
