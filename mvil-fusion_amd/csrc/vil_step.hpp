@@ -254,7 +254,7 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double
             const double x30 = -(l30 * r0_ + l31 * x10 + l32 * x20) * r3_;
             X[0] = r0_; X[1] = x10; X[2] = r1_; X[3] = x20; X[4] = x21; X[5] = r2_; X[6] = x30; X[7] = x31; X[8] = x32; X[9] = r3_;
         }
-        if (t == 0) {                   // the factored block itself and the reciprocal pivots
+        if (t == NT - 2) {              // the factored block itself and the reciprocal pivots (a thread without a panel row)
             AC[db] = l00; s.dinv[kb] = r0_;
             if (nb > 1) { AC[db + TILE_RS] = l10; AC[db + TILE_RS + 1] = l11; s.dinv[kb + 1] = r1_; }
             if (nb > 2) { AC[db + 2 * TILE_RS] = l20; AC[db + 2 * TILE_RS + 1] = l21; AC[db + 2 * TILE_RS + 2] = l22; s.dinv[kb + 2] = r2_; }
