@@ -61,6 +61,10 @@ int vgicp_linearize(vgicp_ctx* ctx, const double* T, int32_t neighbor_mode, doub
 /* error at T with the correspondences / Mahalanobis matrices of the LAST vgicp_linearize (as the reference) */
 int vgicp_compute_error(vgicp_ctx* ctx, const double* T, double* err);
 int vgicp_align(vgicp_ctx* ctx, const double* guess, const vgicp_options* opts, double* T_out, vgicp_summary* out);
+/* profiling aid (bench.py): with enable != 0 every vgicp_linearize brackets its main kernel with HIP events on the library's
+ * own stream; vgicp_profile_read returns the number of timed launches and their total duration, and resets both. */
+int vgicp_profile_enable(vgicp_ctx* ctx, int32_t enable);
+int vgicp_profile_read(vgicp_ctx* ctx, int64_t* launches, double* total_ms);
 
 #ifdef __cplusplus
 }

@@ -255,6 +255,7 @@ struct vgicp_ctx {
     int noff = 1, slots = 0, slots_cap = 0; int* d_cvox = nullptr; double* d_cM = nullptr;
     double* d_part = nullptr; int part_cap = 0; double* d_out = nullptr; double* h_out = nullptr;
     bool linearized = false;
+    bool profiling = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; long long prof_n = 0; double prof_ms = 0.0;
 };
 
 static void free_target(vgicp_ctx* c) { hipFree(c->d_keys); hipFree(c->d_slot); hipFree(c->d_num); hipFree(c->d_mean); hipFree(c->d_cov); c->d_keys = nullptr; c->d_slot = nullptr; c->d_num = nullptr; c->d_mean = nullptr; c->d_cov = nullptr; c->nvox = 0; }
@@ -303,6 +304,7 @@ void vgicp_destroy(vgicp_ctx* c) {
     hipSetDevice(c->device);
     free_target(c); free_source(c);
     hipFree(c->d_cvox); hipFree(c->d_cM); hipFree(c->d_part); hipFree(c->d_out); if (c->h_out) hipHostFree(c->h_out);
+    if (c->ev0) { hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -368,11 +370,14 @@ int vgicp_linearize(vgicp_ctx* c, const double* T, int32_t mode, double* err, do
     if (slots > c->slots_cap) { hipFree(c->d_cvox); hipFree(c->d_cM); c->d_cvox = nullptr; c->d_cM = nullptr; c->slots_cap = 0; VGCHK(hipMalloc(&c->d_cvox, 4 * (size_t)slots)); VGCHK(hipMalloc(&c->d_cM, 8 * 9 * (size_t)slots)); c->slots_cap = slots; }
     if (nblk > c->part_cap) { hipFree(c->d_part); c->d_part = nullptr; c->part_cap = 0; VGCHK(hipMalloc(&c->d_part, 8 * 29 * (size_t)nblk)); c->part_cap = nblk; }
     const int want = (H && b) ? 1 : 0;
+    if (c->profiling) hipEventRecord(c->ev0, c->stream);
     hipLaunchKernelGGL(k_vgicp_lin, dim3(nblk), dim3(VG_THREADS), 0, c->stream, c->n, (int)mode, c->d_sxyz, c->d_scov, to_iso(T), c->res, tab(c), c->d_cvox, c->d_cM, c->d_part, want);
+    if (c->profiling) hipEventRecord(c->ev1, c->stream);
     hipLaunchKernelGGL((k_vgicp_sum<29>), dim3(1), dim3(VG_THREADS), 0, c->stream, nblk, c->d_part, c->d_out);
     VGCHK(hipMemcpyAsync(c->h_out, c->d_out, 8 * 29, hipMemcpyDeviceToHost, c->stream));
     VGCHK(hipStreamSynchronize(c->stream));
     VGCHK(hipGetLastError());
+    if (c->profiling) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) { c->prof_ms += ms; c->prof_n++; } }
     c->noff = mode; c->slots = slots; c->linearized = true;
     *err = c->h_out[27];
     if (n_corr) *n_corr = (int32_t)c->h_out[28];
@@ -381,6 +386,19 @@ int vgicp_linearize(vgicp_ctx* c, const double* T, int32_t mode, double* err, do
         for (int p = 0; p < 6; ++p) { for (int q = p; q < 6; ++q) { H[6 * p + q] = c->h_out[idx]; H[6 * q + p] = c->h_out[idx]; ++idx; } b[p] = c->h_out[21 + p]; }
     }
     return std::isfinite(*err) ? VG_OK : VG_ERR_NONFINITE;
+}
+
+int vgicp_profile_enable(vgicp_ctx* c, int32_t enable) {
+    if (!c) return VG_ERR_INVALID;
+    VGCHK(hipSetDevice(c->device));
+    if (enable && !c->ev0) { VGCHK(hipEventCreate(&c->ev0)); VGCHK(hipEventCreate(&c->ev1)); }
+    c->profiling = enable != 0;
+    return VG_OK;
+}
+int vgicp_profile_read(vgicp_ctx* c, int64_t* launches, double* total_ms) {
+    if (!c || !launches || !total_ms) return VG_ERR_INVALID;
+    *launches = c->prof_n; *total_ms = c->prof_ms; c->prof_n = 0; c->prof_ms = 0.0;
+    return VG_OK;
 }
 
 int vgicp_compute_error(vgicp_ctx* c, const double* T, double* err) {

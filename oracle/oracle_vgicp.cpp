@@ -231,6 +231,9 @@ int orc_vgicp_linearize(vgicp_ctx* c, const double* T, int32_t mode, double* err
 }
 int orc_vgicp_compute_error(vgicp_ctx* c, const double* T, double* err) { *err = accumulate(c->c, T, nullptr, nullptr); return 0; }
 
+int orc_vgicp_profile_enable(vgicp_ctx*, int32_t) { return 0; }
+int orc_vgicp_profile_read(vgicp_ctx*, int64_t* n, double* ms) { *n = 0; *ms = 0.0; return 0; }
+
 int orc_vgicp_align(vgicp_ctx* c, const double* guess, const vgicp_options* o, double* T_out, vgicp_summary* out) {
     double x0[16]; std::memcpy(x0, guess, sizeof x0);
     double lambda = -1.0;

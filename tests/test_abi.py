@@ -32,7 +32,7 @@ def test_library_exports_every_vgicp_symbol():
     so = lib.load_vilsolve()
     src = open(os.path.join(ROOT, "include", "vilvgicp.h")).read()
     syms = sorted(set(re.findall(r"\b(vgicp_[a-z_0-9]+)\s*\(", src)))
-    assert len(syms) == 9, syms
+    assert len(syms) == 11, syms
     for s in syms:
         assert hasattr(so, s), "libvilsolve.so does not export %s" % s
     import subprocess, tempfile
