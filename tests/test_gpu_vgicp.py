@@ -79,3 +79,20 @@ def test_covariances_parity(oracle):
     Tg, sg = g.align(np.eye(4)); To, so = o.align(np.eye(4))
     assert sg.iterations == so.iterations and sg.converged == so.converged == 1 and np.abs(Tg - To).max() < 1e-8
     g.close(); o.close()
+
+
+def test_covariances_grid_search_parity(oracle, monkeypatch):
+    """The uniform-grid neighbour search (used for clouds >= 4096 points) is exact: forced on a small cloud it reproduces the
+    oracle's exhaustive search, for several cell sizes (many rings / exhaustive fallback for isolated points included)."""
+    _, _, sx, _, _ = vgicp.make_pair(seed=13, rings=8, az=400)
+    sx = np.vstack([sx, np.array([[80.0, -70.0, 30.0], [81.0, -70.5, 30.2]], np.float32)])      # two isolated points far from everything
+    o = vgicp.Vgicp(oracle.lib, "orc_vgicp_")
+    co = o.covariances(sx, 20)
+    monkeypatch.setenv("VGICP_GRID_MIN", "0")
+    for h in ("1.0", "0.3", "4.0"):
+        monkeypatch.setenv("VGICP_GRID_H", h)
+        g = vgicp.Vgicp(lib.load_vilsolve(), "vgicp_")
+        cg = g.covariances(sx, 20)
+        g.close()
+        assert np.abs(cg - co).max() < 1e-10, h
+    o.close()
