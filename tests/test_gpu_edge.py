@@ -145,3 +145,25 @@ def test_minimal_window_two_frames(hip, oracle):
     # prior-less, two frames 0.1 s apart: gauge null space + barely observable scale -- rounding differences are amplified
     # along those directions, so this case is held to looser tolerances (the reference never runs such a window)
     _check_solve(hip, oracle, wg, wo, pos_tol=1e-5, cost_tol=1e-5, lam_tol=1e-3)
+
+
+def test_gross_outliers_and_bad_initial_guess(hip, oracle):
+    """10 % of the visual observations are wrong by up to 40 px and the initial poses are off by ~0.3 m / 5 deg: the Cauchy loss
+    is deep in its flat part, steps get rejected and the trust region shrinks -- both paths must take the same decisions."""
+    wg, wo = _pair()
+    rng = np.random.default_rng(5)
+    bad = rng.choice(len(wg.vis_i), len(wg.vis_i) // 10, replace=False)
+    dpix = rng.uniform(-40, 40, (len(bad), 2)) / 460.0
+    dpos = rng.normal(0, 0.3, wg.pose[:, :3].shape)
+    for w in (wg, wo):
+        w.vis_const[bad, 3:5] += dpix
+        w.pose[:, :3] += dpos
+        w.inv_depth *= 1.5
+    opts = abi.default_options(max_iterations=40)
+    sg, so = hip.solve(wg, opts), oracle.solve(wo, opts)
+    assert sg.iterations == so.iterations and sg.successful_steps == so.successful_steps and sg.termination == so.termination
+    assert sg.successful_steps < sg.iterations                      # at least one rejected step was exercised
+    n = min(sg.iterations, 64)
+    assert np.allclose(np.array(sg.cost_trace[:n]), np.array(so.cost_trace[:n]), rtol=1e-7)
+    assert np.allclose(np.array(sg.radius_trace[:n]), np.array(so.radius_trace[:n]), rtol=1e-9)
+    assert np.abs(wg.pose[:, :3] - wo.pose[:, :3]).max() < 1e-6
