@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/vilvgicp.h"
+#include "vil_knn.hpp"
 
 #define VG_OK 0
 #define VG_ERR_INVALID -1
@@ -35,8 +36,7 @@ namespace {
 struct Iso { double m[12]; };                       // rows of [R | t]
 struct VoxTab { const long long* keys; const int* slot_vox; int mask; const int* num; const double* mean; const double* cov; };   // mean 3 x nv, cov 9 x nv (SoA)
 
-__host__ __device__ inline long long pack_key(int x, int y, int z) { return ((long long)(x & 0x1FFFFF) << 42) | ((long long)(y & 0x1FFFFF) << 21) | (long long)(z & 0x1FFFFF); }
-__host__ __device__ inline unsigned hash_key(long long k) { unsigned long long h = (unsigned long long)k * 0x9E3779B97F4A7C15ull; return (unsigned)(h >> 32); }
+using vknn::pack_key; using vknn::hash_key;
 
 __device__ __forceinline__ double wave_sum64(double v) {
 #pragma unroll
@@ -165,30 +165,8 @@ __global__ __launch_bounds__(VG_THREADS) void k_vgicp_sum(int nblk, const double
 // branch-free insertion (static register indices: no scratch).  Same float arithmetic and tie order (smaller index
 // first) as the oracle, so both select the same neighbours.  Then mean / covariance in fp64 and
 // U diag(1, 1, 1e-3) V^T = I - (1 - 1e-3) n n^T with n the eigenvector of the smallest eigenvalue (cyclic Jacobi, 3 x 3).
-#define KNN_MAX 20
-struct KnnList { float bd[KNN_MAX]; int bi[KNN_MAX]; };
-__device__ __forceinline__ void knn_init(KnnList& L) {
-#pragma unroll
-    for (int m = 0; m < KNN_MAX; ++m) { L.bd[m] = 3.0e38f; L.bi[m] = 0x7fffffff; }
-}
-// insert candidate (d, j) into the list sorted by (distance, index): unrolled, branch-free, static register indices.
-// The lexicographic order makes the result independent of the order in which candidates arrive.
-__device__ __forceinline__ void knn_insert(KnnList& L, float d, int j) {
-    if (d < L.bd[KNN_MAX - 1] || (d == L.bd[KNN_MAX - 1] && j < L.bi[KNN_MAX - 1])) {
-#pragma unroll
-        for (int m = KNN_MAX - 1; m >= 1; --m) {
-            const bool up = d < L.bd[m - 1] || (d == L.bd[m - 1] && j < L.bi[m - 1]);
-            const bool here = !up && (d < L.bd[m] || (d == L.bd[m] && j < L.bi[m]));
-            L.bd[m] = up ? L.bd[m - 1] : (here ? d : L.bd[m]);
-            L.bi[m] = up ? L.bi[m - 1] : (here ? j : L.bi[m]);
-        }
-        if (d < L.bd[0] || (d == L.bd[0] && j < L.bi[0])) { L.bd[0] = d; L.bi[0] = j; }
-    }
-}
-__device__ __forceinline__ float sqdist_nofma(float qx, float qy, float qz, float x, float y, float z) {
-    const float dx = __fsub_rn(qx, x), dy = __fsub_rn(qy, y), dz = __fsub_rn(qz, z);
-    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));        // no fma: bit-equal to the CPU sum
-}
+using namespace vknn;
+
 // mean / covariance of the k neighbours in fp64, then U diag(1, 1, 1e-3) V^T = I - (1 - 1e-3) n n^T (cyclic Jacobi, 3 x 3)
 __device__ __forceinline__ void knn_plane_cov(const KnnList& L, const float* __restrict__ xyz, int k, double* __restrict__ o) {
     double mx = 0, my = 0, mz = 0;
@@ -252,78 +230,13 @@ __global__ __launch_bounds__(VG_THREADS) void k_knn_cov(int n, const float* __re
     if (live) knn_plane_cov(L, xyz, k, cov9 + (size_t)9 * i);
 }
 
-// ---- uniform-grid search for larger clouds: count points per cell (hash table of packed cell keys), exclusive scan,
-//      scatter into cell order, then every query walks Chebyshev rings of cells around its own cell until the k-th best
-//      distance is provably final (everything unvisited is at least ring * h away).  Exact, like the tiled search.
-struct GridTab { long long* keys; int* cnt; int* start; int* cur; int mask; float h; };
-__device__ __forceinline__ int grid_slot(const GridTab& G, long long key, bool insert) {
-    for (unsigned hh = hash_key(key) & G.mask;; hh = (hh + 1) & G.mask) {
-        long long k = G.keys[hh];
-        if (k == key) return (int)hh;
-        if (k < 0) {
-            if (!insert) return -1;
-            k = (long long)atomicCAS((unsigned long long*)(G.keys + hh), (unsigned long long)-1LL, (unsigned long long)key);
-            if (k < 0 || k == key) return (int)hh;
-        }
-    }
-}
-__device__ __forceinline__ long long cell_key(float x, float y, float z, float h, int dx, int dy, int dz) {
-    return pack_key((int)floorf(x / h) + dx, (int)floorf(y / h) + dy, (int)floorf(z / h) + dz);
-}
-__global__ void k_grid_count(int n, const float* __restrict__ xyz, GridTab G, int* __restrict__ pslot) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int s = grid_slot(G, cell_key(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], G.h, 0, 0, 0), true);
-    pslot[i] = s;
-    atomicAdd(G.cnt + s, 1);
-}
-// single-workgroup exclusive scan of the per-slot counts (the table has at most a few 100 k slots)
-__global__ __launch_bounds__(1024) void k_grid_scan(GridTab G) {
-    __shared__ int part[1024];
-    const int t = threadIdx.x, cap = G.mask + 1, per = (cap + 1023) / 1024;
-    int s = 0;
-    for (int e = t * per; e < min(cap, (t + 1) * per); ++e) s += G.cnt[e];
-    part[t] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) { const int v = t >= o ? part[t - o] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
-    int run = part[t] - s;
-    for (int e = t * per; e < min(cap, (t + 1) * per); ++e) { G.start[e] = run; run += G.cnt[e]; }
-}
-__global__ void k_grid_fill(int n, const float* __restrict__ xyz, GridTab G, const int* __restrict__ pslot, int* __restrict__ order, float* __restrict__ cxyz) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int s = pslot[i];
-    const int pos = G.start[s] + atomicAdd(G.cur + s, 1);
-    order[pos] = i; cxyz[3 * pos] = xyz[3 * i]; cxyz[3 * pos + 1] = xyz[3 * i + 1]; cxyz[3 * pos + 2] = xyz[3 * i + 2];
-}
-#define KNN_RMAX 6
+// larger clouds: queries in cell order (neighbouring threads walk the same cells), exact grid search (vil_knn.hpp)
 __global__ __launch_bounds__(VG_THREADS) void k_knn_grid(int n, const float* __restrict__ xyz, GridTab G, const int* __restrict__ order, const float* __restrict__ cxyz, int k, double* __restrict__ cov9) {
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;      // queries in cell order: neighbouring threads walk the same cells
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= n) return;
-    const int i = order[pos];
-    const float qx = cxyz[3 * pos], qy = cxyz[3 * pos + 1], qz = cxyz[3 * pos + 2];
-    KnnList L; knn_init(L);
-    const int kk = min(k, n);
-    bool done = false;
-    for (int r = 0; r <= KNN_RMAX && !done; ++r) {
-        for (int dx = -r; dx <= r; ++dx) for (int dy = -r; dy <= r; ++dy) for (int dz = -r; dz <= r; ++dz) {
-            if (max(max(abs(dx), abs(dy)), abs(dz)) != r) continue;
-            const int s = grid_slot(G, cell_key(qx, qy, qz, G.h, dx, dy, dz), false);
-            if (s < 0) continue;
-            const int b = G.start[s], e = b + G.cnt[s];
-            for (int j = b; j < e; ++j) knn_insert(L, sqdist_nofma(qx, qy, qz, cxyz[3 * j], cxyz[3 * j + 1], cxyz[3 * j + 2]), order[j]);
-        }
-        const float bound = (float)r * G.h;
-        float bk = 3.0e38f;                                     // k-th best so far (select chain: no dynamic register index)
-#pragma unroll
-        for (int m = 0; m < KNN_MAX; ++m) bk = (m == kk - 1) ? L.bd[m] : bk;
-        done = r >= 1 && bk < bound * bound;
-    }
-    if (!done) {                                                 // isolated point: exhaustive scan keeps the result exact
-        knn_init(L);
-        for (int j = 0; j < n; ++j) knn_insert(L, sqdist_nofma(qx, qy, qz, cxyz[3 * j], cxyz[3 * j + 1], cxyz[3 * j + 2]), order[j]);
-    }
-    knn_plane_cov(L, xyz, k, cov9 + (size_t)9 * i);
+    KnnList L;
+    knn_grid_query(L, cxyz[3 * pos], cxyz[3 * pos + 1], cxyz[3 * pos + 2], min(k, n), n, G, order, cxyz);
+    knn_plane_cov(L, xyz, k, cov9 + (size_t)9 * order[pos]);
 }
 
 struct HostKeyHash { size_t operator()(long long k) const { return (size_t)hash_key(k) * 2654435761u ^ (size_t)(k >> 17); } };
@@ -360,23 +273,13 @@ static int covariances_dev(vgicp_ctx* c, int n, const float* d_xyz, int k, doubl
     if (n < grid_min) {
         hipLaunchKernelGGL(k_knn_cov, dim3(nblk), dim3(VG_THREADS), 0, c->stream, n, d_xyz, k, d_cov);
     } else {
-        int cap = 1024; while (cap < 2 * n) cap <<= 1;
-        char* ws = nullptr;
-        const size_t bytes = 8 * (size_t)cap + 3 * 4 * (size_t)cap + 2 * 4 * (size_t)n + 12 * (size_t)n + 256;
-        VGCHK(hipMalloc(&ws, bytes));
-        GridTab G;
-        G.keys = (long long*)ws; G.cnt = (int*)(ws + 8 * (size_t)cap); G.start = G.cnt + cap; G.cur = G.start + cap; G.mask = cap - 1;
-        G.h = 1.0f;
-        if (const char* ev = getenv("VGICP_GRID_H")) G.h = (float)atof(ev);
-        int* pslot = G.cur + cap; int* order = pslot + n; float* cxyz = (float*)(order + n);
-        hipMemsetAsync(G.keys, 0xFF, 8 * (size_t)cap, c->stream);                  // every key = -1 (empty)
-        hipMemsetAsync(G.cnt, 0, 3 * 4 * (size_t)cap, c->stream);
-        hipLaunchKernelGGL(k_grid_count, dim3(nblk), dim3(VG_THREADS), 0, c->stream, n, d_xyz, G, pslot);
-        hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, c->stream, G);
-        hipLaunchKernelGGL(k_grid_fill, dim3(nblk), dim3(VG_THREADS), 0, c->stream, n, d_xyz, G, pslot, order, cxyz);
-        hipLaunchKernelGGL(k_knn_grid, dim3(nblk), dim3(VG_THREADS), 0, c->stream, n, d_xyz, G, order, cxyz, k, d_cov);
+        float h = 1.0f;
+        if (const char* ev = getenv("VGICP_GRID_H")) h = (float)atof(ev);
+        vknn::GridBuild gb;
+        if (vknn::grid_build(gb, n, d_xyz, 3, h, c->stream) != hipSuccess) { if (gb.ws) hipFree(gb.ws); return VG_ERR_DEVICE; }
+        hipLaunchKernelGGL(k_knn_grid, dim3(nblk), dim3(VG_THREADS), 0, c->stream, n, d_xyz, gb.G, gb.order, gb.cxyz, k, d_cov);
         const hipError_t e = hipStreamSynchronize(c->stream);
-        hipFree(ws);
+        hipFree(gb.ws);
         if (e != hipSuccess) return VG_ERR_DEVICE;
     }
     VGCHK(hipStreamSynchronize(c->stream));
