@@ -35,7 +35,7 @@ __device__ __forceinline__ float sqdist_nofma(float qx, float qy, float qz, floa
 // ---- uniform-grid search for larger clouds: count points per cell (hash table of packed cell keys), exclusive scan,
 //      scatter into cell order, then every query walks Chebyshev rings of cells around its own cell until the k-th best
 //      distance is provably final (everything unvisited is at least ring * h away).  Exact, like the tiled search.
-struct GridTab { long long* keys; int* cnt; int* start; int* cur; int mask; float h; };
+struct GridTab { long long* keys; int* cnt; int* start; int* cur; int* nocc; int mask; float h; };
 __device__ __forceinline__ int grid_slot(const GridTab& G, long long key, bool insert) {
     for (unsigned hh = hash_key(key) & G.mask;; hh = (hh + 1) & G.mask) {
         long long k = G.keys[hh];
@@ -50,7 +50,7 @@ __device__ __forceinline__ int grid_slot(const GridTab& G, long long key, bool i
 __device__ __forceinline__ long long cell_key(float x, float y, float z, float h, int dx, int dy, int dz) {
     return pack_key((int)floorf(x / h) + dx, (int)floorf(y / h) + dy, (int)floorf(z / h) + dz);
 }
-__global__ void k_grid_count(int n, const float* __restrict__ xyz, int stride, GridTab G, int* __restrict__ pslot) {
+static __global__ void k_grid_count(int n, const float* __restrict__ xyz, int stride, GridTab G, int* __restrict__ pslot) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int s = grid_slot(G, cell_key(xyz[stride * i], xyz[stride * i + 1], xyz[stride * i + 2], G.h, 0, 0, 0), true);
@@ -58,7 +58,7 @@ __global__ void k_grid_count(int n, const float* __restrict__ xyz, int stride, G
     atomicAdd(G.cnt + s, 1);
 }
 // single-workgroup exclusive scan of the per-slot counts (the table has at most a few 100 k slots)
-__global__ __launch_bounds__(1024) void k_grid_scan(GridTab G) {
+static __global__ __launch_bounds__(1024) void k_grid_scan(GridTab G) {
     __shared__ int part[1024];
     const int t = threadIdx.x, cap = G.mask + 1, per = (cap + 1023) / 1024;
     int s = 0;
@@ -66,10 +66,11 @@ __global__ __launch_bounds__(1024) void k_grid_scan(GridTab G) {
     part[t] = s;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) { const int v = t >= o ? part[t - o] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
-    int run = part[t] - s;
-    for (int e = t * per; e < min(cap, (t + 1) * per); ++e) { G.start[e] = run; run += G.cnt[e]; }
+    int run = part[t] - s, occ = 0;
+    for (int e = t * per; e < min(cap, (t + 1) * per); ++e) { G.start[e] = run; run += G.cnt[e]; occ += G.cnt[e] != 0; }
+    if (occ) atomicAdd(G.nocc, occ);                                        // occupied cells: the host adapts the cell size to it
 }
-__global__ void k_grid_fill(int n, const float* __restrict__ xyz, int stride, GridTab G, const int* __restrict__ pslot, int* __restrict__ order, float* __restrict__ cxyz) {
+static __global__ void k_grid_fill(int n, const float* __restrict__ xyz, int stride, GridTab G, const int* __restrict__ pslot, int* __restrict__ order, float* __restrict__ cxyz) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int s = pslot[i];
@@ -108,19 +109,108 @@ __device__ __forceinline__ void knn_grid_query(KnnList& L, float qx, float qy, f
     }
 }
 
+// ---- wave-per-query search: the 64 lanes of a wave hold the best candidates as ONE sorted list (lane i = i-th smallest
+//      64-bit key (float distance bits << 32 | index): unsigned order == the lexicographic (distance, index) order of KnnList),
+//      candidates are gathered 64 at a time with coalesced loads, and a candidate that beats the current k-th is inserted by
+//      a single DPP shift + select across the wave.  Control flow is wave-uniform.
+#define KNN_WL_CAP 512          // per-wave LDS work list (ints): candidate positions of one pass over up to 64 cells
+__device__ __forceinline__ unsigned long long knn_key(float d, int j) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j; }
+__device__ __forceinline__ float knn_key_d(unsigned long long k) { return __uint_as_float((unsigned)(k >> 32)); }
+__device__ __forceinline__ unsigned long long wave_shr1_u64(unsigned long long v) {     // lane i <- lane i-1, lane 0 <- 0
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x138, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), 0x138, 0xf, 0xf, false);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// every lane offers one candidate key (~0 = none); all 64 lanes must be active
+__device__ __forceinline__ void knn_wave_offer(unsigned long long& best, unsigned long long key, int kk) {
+    unsigned long long thr = readlane_u64(best, kk - 1);
+    unsigned long long m = __ballot(key < thr);
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        const unsigned long long c = readlane_u64(key, l);
+        const unsigned long long prev = wave_shr1_u64(best);
+        best = c < best ? (c > prev ? c : prev) : best;
+        thr = readlane_u64(best, kk - 1);
+        m &= m - 1;
+        m &= __ballot(key < thr);
+    }
+}
+__device__ __forceinline__ unsigned long long knn_wave_cand(int t, int total, float qx, float qy, float qz, const int* pos, const int* __restrict__ order, const float* __restrict__ cxyz) {
+    if (t >= total) return ~0ull;
+    const int j = pos ? pos[t] : t;
+    return knn_key(sqdist_nofma(qx, qy, qz, cxyz[3 * j], cxyz[3 * j + 1], cxyz[3 * j + 2]), order[j]);
+}
+// Exact kk nearest neighbours (kk <= 64) of a WAVE-UNIFORM query; result: lane i < kk holds the i-th best key in `best`.
+// Returns false when the query is rejected early: everything unvisited is at least sqrt(reject_d2) away and the reject_k-th
+// best is not below reject_d2 (the callers discard such queries anyway).  wl: KNN_WL_CAP ints of LDS owned by this wave.
+__device__ __forceinline__ bool knn_wave_query(unsigned long long& best, float qx, float qy, float qz, int kk, int n, const GridTab& G, const int* __restrict__ order,
+                                               const float* __restrict__ cxyz, int* wl, float reject_d2, int reject_k) {
+    const int lane = threadIdx.x & 63;
+    best = ~0ull;
+    const int cx = (int)floorf(qx / G.h), cy = (int)floorf(qy / G.h), cz = (int)floorf(qz / G.h);
+    for (int r = 1; r <= KNN_RMAX; ++r) {
+        const int side = 2 * r + 1, ncell = side * side * side;
+        for (int base = 0; base < ncell; base += 64) {
+            const int e = base + lane;
+            int b = 0, cnt = 0;
+            if (e < ncell) {
+                const int dz = e % side - r, dy = (e / side) % side - r, dx = e / (side * side) - r;
+                if (r == 1 || max(max(abs(dx), abs(dy)), abs(dz)) == r) {
+                    const int s = grid_slot(G, pack_key(cx + dx, cy + dy, cz + dz), false);
+                    if (s >= 0) { b = G.start[s]; cnt = G.cnt[s]; }
+                }
+            }
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); incl += lane >= o ? v : 0; }
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            if (total == 0) continue;
+            if (total <= KNN_WL_CAP) {
+                const int excl = incl - cnt;
+                for (int u = 0; u < cnt; ++u) wl[excl + u] = b + u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int t0 = 0; t0 < total; t0 += 64) knn_wave_offer(best, knn_wave_cand(t0 + lane, total, qx, qy, qz, wl, order, cxyz), kk);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                for (int c = 0; c < 64; ++c) {
+                    const int cb = __builtin_amdgcn_readlane(b, c), cc = __builtin_amdgcn_readlane(cnt, c);
+                    for (int t0 = 0; t0 < cc; t0 += 64) knn_wave_offer(best, knn_wave_cand(cb + t0 + lane, cb + cc, qx, qy, qz, nullptr, order, cxyz), kk);
+                }
+            }
+        }
+        const float bound = (float)r * G.h, b2 = bound * bound;
+        if (knn_key_d(readlane_u64(best, kk - 1)) < b2) return true;
+        if (b2 >= reject_d2 && !(knn_key_d(readlane_u64(best, reject_k - 1)) < reject_d2)) return false;
+    }
+    best = ~0ull;
+    for (int t0 = 0; t0 < n; t0 += 64) knn_wave_offer(best, knn_wave_cand(t0 + lane, n, qx, qy, qz, nullptr, order, cxyz), kk);
+    return true;
+}
+
 // host: device work space + launches that build the grid of a device-resident cloud (stride floats per point)
-struct GridBuild { char* ws = nullptr; GridTab G; int* order = nullptr; float* cxyz = nullptr; int n = 0; };
+struct GridBuild { char* ws = nullptr; size_t ws_bytes = 0; GridTab G; int* order = nullptr; float* cxyz = nullptr; int n = 0; };
 inline hipError_t grid_build(GridBuild& gb, int n, const float* d_xyz, int stride, float h, hipStream_t stream) {
-    if (gb.ws) { hipFree(gb.ws); gb.ws = nullptr; }
     int cap = 1024; while (cap < 2 * n) cap <<= 1;
-    const size_t bytes = 8 * (size_t)cap + 3 * 4 * (size_t)cap + 2 * 4 * (size_t)n + 12 * (size_t)n + 256;
-    hipError_t e = hipMalloc(&gb.ws, bytes);
-    if (e != hipSuccess) return e;
+    const size_t bytes = 8 * (size_t)cap + 3 * 4 * (size_t)cap + 2 * 4 * (size_t)n + 12 * (size_t)n + 512;
+    if (bytes > gb.ws_bytes) {
+        if (gb.ws) { hipFree(gb.ws); gb.ws = nullptr; gb.ws_bytes = 0; }
+        const size_t want = bytes + bytes / 2;                              // head room: the next scans' maps are about this size
+        hipError_t e = hipMalloc(&gb.ws, want);
+        if (e != hipSuccess) return e;
+        gb.ws_bytes = want;
+    }
     GridTab& G = gb.G;
     G.keys = (long long*)gb.ws; G.cnt = (int*)(gb.ws + 8 * (size_t)cap); G.start = G.cnt + cap; G.cur = G.start + cap; G.mask = cap - 1; G.h = h;
-    int* pslot = G.cur + cap; gb.order = pslot + n; gb.cxyz = (float*)(gb.order + n); gb.n = n;
+    G.nocc = G.cur + cap;
+    int* pslot = G.nocc + 64; gb.order = pslot + n; gb.cxyz = (float*)(gb.order + n); gb.n = n;
     hipMemsetAsync(G.keys, 0xFF, 8 * (size_t)cap, stream);                  // every key = -1 (empty)
-    hipMemsetAsync(G.cnt, 0, 3 * 4 * (size_t)cap, stream);
+    hipMemsetAsync(G.cnt, 0, 3 * 4 * (size_t)cap + 256, stream);
     const int nblk = (n + 255) / 256;
     hipLaunchKernelGGL(k_grid_count, dim3(nblk), dim3(256), 0, stream, n, d_xyz, stride, G, pslot);
     hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, stream, G);

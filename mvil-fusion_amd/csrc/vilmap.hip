@@ -1,0 +1,353 @@
+// vilmap.hip -- LiDAR scan-to-map registration on gfx950 behind include/vilmap.h (SURVEY 8(f) row 2,
+// lidar_mapping/src/localMapping.cpp:590-791).
+//
+// Per scan point the reference does a kd-tree query in the local map and a tiny dense fit (3x3 eigen-decomposition for
+// corner points, 5x3 least squares for surf points), then hands the accepted points to Ceres as edge / plane factors.
+// Here: the two map clouds are gridded once per scan (vil_knn.hpp), ONE kernel per feature class does query + fit with a
+// thread per scan point (everything in registers), the accepted correspondences are compacted on the host in scan order,
+// and the 7-parameter solve is vil_solve on a one-pose window that holds exactly these factors (k_sweep's LiDAR roles).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/vilmap.h"
+#include "vil_knn.hpp"
+
+#define VM_OK 0
+#define VM_ERR_INVALID -1
+#define VM_ERR_DEVICE -2
+#define VM_THREADS 256
+#define VMCHK(x) do { if ((x) != hipSuccess) return VM_ERR_DEVICE; } while (0)
+
+namespace {
+using namespace vknn;
+
+struct PoseD { double R[9]; double t[3]; };
+
+// eigen-decomposition of a symmetric 3x3 (cyclic Jacobi): A -> eigenvalues on its diagonal, V columns = eigenvectors
+__device__ __forceinline__ void jacobi3(double* A, double* V) {
+    V[0] = 1; V[1] = 0; V[2] = 0; V[3] = 0; V[4] = 1; V[5] = 0; V[6] = 0; V[7] = 0; V[8] = 1;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+        if (off <= 1e-40 * (A[0] * A[0] + A[4] * A[4] + A[8] * A[8]) || off == 0.0) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = A[3 * p + q];
+                if (apq != 0.0) {
+                    const double tau = (A[3 * q + q] - A[3 * p + p]) / (2.0 * apq);
+                    const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    const double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) { const double akp = A[3 * r + p], akq = A[3 * r + q]; A[3 * r + p] = c * akp - sn * akq; A[3 * r + q] = sn * akp + c * akq; }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) { const double apk = A[3 * p + r], aqk = A[3 * q + r]; A[3 * p + r] = c * apk - sn * aqk; A[3 * q + r] = sn * apk + c * aqk; }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) { const double vkp = V[3 * r + p], vkq = V[3 * r + q]; V[3 * r + p] = c * vkp - sn * vkq; V[3 * r + q] = sn * vkp + c * vkq; }
+                }
+            }
+    }
+}
+
+__device__ __forceinline__ void to_map(const PoseD& T, const float* p, float& sx, float& sy, float& sz) {   // pointAssociateToMap: double, stored as float
+    const double x = p[0], y = p[1], z = p[2];
+    sx = (float)(T.R[0] * x + T.R[1] * y + T.R[2] * z + T.t[0]);
+    sy = (float)(T.R[3] * x + T.R[4] * y + T.R[5] * z + T.t[1]);
+    sz = (float)(T.R[6] * x + T.R[7] * y + T.R[8] * z + T.t[2]);
+}
+
+// min |A x - b| for a 5 x 3 A (row-major in P, overwritten) by column-pivoted Householder QR -- what
+// matA0.colPivHouseholderQr().solve(matB0) does (localMapping.cpp:716)
+__device__ __forceinline__ void qr_solve_5x3(double* P, double* b, double* x) {
+    int perm[3] = {0, 1, 2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int pv = k; double best = -1.0;
+#pragma unroll
+        for (int c = k; c < 3; ++c) { double s = 0; for (int r = k; r < 5; ++r) s += P[3 * r + c] * P[3 * r + c]; if (s > best) { best = s; pv = c; } }
+        if (pv != k) { for (int r = 0; r < 5; ++r) { const double tmp = P[3 * r + k]; P[3 * r + k] = P[3 * r + pv]; P[3 * r + pv] = tmp; } const int tp = perm[k]; perm[k] = perm[pv]; perm[pv] = tp; }
+        const double nrm = sqrt(best), akk = P[3 * k + k], alpha = akk > 0 ? -nrm : nrm;
+        const double v0 = akk - alpha;
+        double vv = v0 * v0;
+        for (int r = k + 1; r < 5; ++r) vv += P[3 * r + k] * P[3 * r + k];
+        if (vv > 0) {
+            const double beta = 2.0 / vv;
+#pragma unroll
+            for (int c = k + 1; c < 3; ++c) {
+                double s = v0 * P[3 * k + c];
+                for (int r = k + 1; r < 5; ++r) s += P[3 * r + k] * P[3 * r + c];
+                s *= beta;
+                P[3 * k + c] -= s * v0;
+                for (int r = k + 1; r < 5; ++r) P[3 * r + c] -= s * P[3 * r + k];
+            }
+            double s = v0 * b[k];
+            for (int r = k + 1; r < 5; ++r) s += P[3 * r + k] * b[r];
+            s *= beta;
+            b[k] -= s * v0;
+            for (int r = k + 1; r < 5; ++r) b[r] -= s * P[3 * r + k];
+        }
+        P[3 * k + k] = alpha;
+    }
+    double y[3];
+    y[2] = b[2] / P[8];
+    y[1] = (b[1] - P[5] * y[2]) / P[4];
+    y[0] = (b[0] - P[1] * y[1] - P[2] * y[2]) / P[0];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x[perm[k]] = y[k];
+}
+
+// ---- search: one WAVE per scan point (vil_knn.hpp); queries [0, nqc) are corner points against the corner map (5-NN),
+//      [nqc, nqc + nqs) surf points against the surf map (10-NN).  nn: 10 ints per query, nd5: the 5th squared distance
+//      (or a value >= 1 when the query is rejected: fewer than five map points within 1 m, localMapping.cpp:613,:705)
+#define VM_QPB 4
+__global__ __launch_bounds__(64 * VM_QPB) void k_map_search(int nqc, int nqs, const float* __restrict__ scan, PoseD T, int ncm, GridTab Gc, const int* __restrict__ oc, const float* __restrict__ xc,
+                                                            int nsm, GridTab Gs, const int* __restrict__ os, const float* __restrict__ xs, int* __restrict__ nn, float* __restrict__ nd5) {
+    __shared__ int wl_all[VM_QPB * KNN_WL_CAP];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * VM_QPB + wave;
+    if (qi >= nqc + nqs) return;
+    const bool surf = qi >= nqc;
+    const int kk = surf ? 10 : 5, nmap = surf ? nsm : ncm;
+    float d5 = 3.0e38f;
+    unsigned long long best = ~0ull;
+    if (nmap >= kk) {
+        float sx, sy, sz;
+        to_map(T, scan + 4 * (size_t)qi, sx, sy, sz);
+        const bool ok = surf ? knn_wave_query(best, sx, sy, sz, 10, nsm, Gs, os, xs, wl_all + wave * KNN_WL_CAP, 1.0f, 5)
+                             : knn_wave_query(best, sx, sy, sz, 5, ncm, Gc, oc, xc, wl_all + wave * KNN_WL_CAP, 1.0f, 5);
+        if (ok) d5 = knn_key_d(readlane_u64(best, 4));
+    }
+    if (lane < 10) nn[10 * (size_t)qi + lane] = (int)(unsigned)best;
+    if (lane == 0) nd5[qi] = d5;
+}
+
+// ---- fit: one thread per scan point; slot = 10 doubles: corner [valid, cp(3), a(3), b(3)], surf [valid, cp(3), n(3), d, -]
+__global__ __launch_bounds__(VM_THREADS) void k_map_fit(int nqc, int nqs, const float* __restrict__ scan, const float* __restrict__ cmap, const float* __restrict__ smap,
+                                                        const int* __restrict__ nn, const float* __restrict__ nd5, double* __restrict__ slot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nqc + nqs) return;
+    double* o = slot + (size_t)10 * i;
+    o[0] = 0.0;
+    if (!(nd5[i] < 1.0f)) return;
+    const int* nb = nn + 10 * (size_t)i;
+    if (i < nqc) {                                                           // corner points (localMapping.cpp:607-660)
+        double cx = 0, cy = 0, cz = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { cx += (double)cmap[4 * nb[j]]; cy += (double)cmap[4 * nb[j] + 1]; cz += (double)cmap[4 * nb[j] + 2]; }
+        cx /= 5.0; cy /= 5.0; cz /= 5.0;
+        double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, V[9];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const double d0 = (double)cmap[4 * nb[j]] - cx, d1 = (double)cmap[4 * nb[j] + 1] - cy, d2 = (double)cmap[4 * nb[j] + 2] - cz;
+            A[0] += d0 * d0; A[1] += d0 * d1; A[2] += d0 * d2; A[3] += d1 * d0; A[4] += d1 * d1; A[5] += d1 * d2; A[6] += d2 * d0; A[7] += d2 * d1; A[8] += d2 * d2;
+        }
+        jacobi3(A, V);
+        int m2 = 0; if (A[4] > A[0]) m2 = 1; if (A[8] > A[4 * m2]) m2 = 2;      // largest and middle eigenvalue
+        const int ma = (m2 + 1) % 3, mb = (m2 + 2) % 3;
+        const double l2 = A[4 * m2], l1 = fmax(A[4 * ma], A[4 * mb]);
+        if (!(l2 > 3.0 * l1)) return;
+        const double ux = m2 == 0 ? V[0] : (m2 == 1 ? V[1] : V[2]), uy = m2 == 0 ? V[3] : (m2 == 1 ? V[4] : V[5]), uz = m2 == 0 ? V[6] : (m2 == 1 ? V[7] : V[8]);
+        o[0] = 1.0; o[1] = scan[4 * i]; o[2] = scan[4 * i + 1]; o[3] = scan[4 * i + 2];
+        o[4] = 0.1 * ux + cx; o[5] = 0.1 * uy + cy; o[6] = 0.1 * uz + cz;
+        o[7] = -0.1 * ux + cx; o[8] = -0.1 * uy + cy; o[9] = -0.1 * uz + cz;
+        return;
+    }
+    // surf points (localMapping.cpp:683-741): re-rank the ten by |intensity difference| (ties: smaller map index), keep five
+    const float qi = scan[4 * i + 3];
+    KnnList S; knn_init(S);
+#pragma unroll
+    for (int m = 0; m < 10; ++m) knn_insert(S, fabsf(smap[4 * nb[m] + 3] - qi), nb[m]);
+    double P[15], Q[15], rhs[5] = {-1, -1, -1, -1, -1}, nv[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { P[3 * j] = (double)smap[4 * S.bi[j]]; P[3 * j + 1] = (double)smap[4 * S.bi[j] + 1]; P[3 * j + 2] = (double)smap[4 * S.bi[j] + 2]; }
+#pragma unroll
+    for (int j = 0; j < 15; ++j) Q[j] = P[j];
+    qr_solve_5x3(Q, rhs, nv);
+    double nx = nv[0], ny = nv[1], nz = nv[2];
+    const double nrm = sqrt(nx * nx + ny * ny + nz * nz);
+    const double d = 1.0 / nrm;
+    nx /= nrm; ny /= nrm; nz /= nrm;
+    bool ok = isfinite(d) && isfinite(nx);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) ok = ok && !(fabs(nx * P[3 * j] + ny * P[3 * j + 1] + nz * P[3 * j + 2] + d) > 0.2);
+    if (!ok) return;
+    o[0] = 1.0; o[1] = scan[4 * i]; o[2] = scan[4 * i + 1]; o[3] = scan[4 * i + 2];
+    o[4] = nx; o[5] = ny; o[6] = nz; o[7] = d;
+}
+
+void quat_to_R(const double* q, double* R) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+}  // namespace
+
+struct vmap_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int nc = 0, ns = 0;
+    float* d_cmap = nullptr; float* d_smap = nullptr; size_t cmap_cap = 0, smap_cap = 0;
+    vknn::GridBuild gc, gs;
+    float hc = 1.0f, hs = 1.0f;                      // cell sizes, adapted to the maps' densities
+    // scan staging: corner points then surf points
+    float* d_scan = nullptr; size_t scan_cap = 0; char* d_work = nullptr; size_t work_cap = 0;
+    const float* up_corner = nullptr; const float* up_surf = nullptr; int up_nc = -1, up_ns = -1; bool scan_valid = false;
+    std::vector<double> h_slot;
+    bool profiling = false; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; long long prof_n[2] = {0, 0}; double prof_ms[2] = {0.0, 0.0};
+};
+
+namespace {
+// grid of one map cloud with a cell size that keeps about VM_OCC points per occupied cell (27 cells -> a few batches of 64
+// candidates per query); the search is exact for any cell size, this only bounds its cost
+#define VM_OCC 6.0
+int build_adaptive(vmap_ctx* c, vknn::GridBuild& gb, int n, const float* d_xyz, float& h) {
+    for (int pass = 0; pass < 3; ++pass) {
+        VMCHK(vknn::grid_build(gb, n, d_xyz, 4, h, c->stream));
+        int nocc = 0;
+        VMCHK(hipMemcpyAsync(&nocc, gb.G.nocc, 4, hipMemcpyDeviceToHost, c->stream));
+        VMCHK(hipStreamSynchronize(c->stream));
+        const double occ = (double)n / std::max(1, nocc);
+        if (occ <= 2.0 * VM_OCC && (occ >= 0.4 * VM_OCC || h >= 1.0f)) break;
+        float hn = (float)(h * std::sqrt(VM_OCC / occ));
+        hn = std::fmin(1.0f, std::fmax(0.125f, hn));
+        if (hn == h) break;
+        h = hn;
+    }
+    return VM_OK;
+}
+int upload_scan(vmap_ctx* c, int n_corner, const float* corner, int n_surf, const float* surf) {
+    const int nq = n_corner + n_surf;
+    const size_t need_scan = 16 * (size_t)nq + 16, need_work = (size_t)nq * (40 + 4 + 80) + 256;
+    if (need_scan > c->scan_cap) { hipFree(c->d_scan); c->d_scan = nullptr; c->scan_cap = 0; VMCHK(hipMalloc(&c->d_scan, 2 * need_scan)); c->scan_cap = 2 * need_scan; }
+    if (need_work > c->work_cap) { hipFree(c->d_work); c->d_work = nullptr; c->work_cap = 0; VMCHK(hipMalloc(&c->d_work, 2 * need_work)); c->work_cap = 2 * need_work; }
+    if (n_corner) VMCHK(hipMemcpyAsync(c->d_scan, corner, 16 * (size_t)n_corner, hipMemcpyHostToDevice, c->stream));
+    if (n_surf) VMCHK(hipMemcpyAsync(c->d_scan + 4 * (size_t)n_corner, surf, 16 * (size_t)n_surf, hipMemcpyHostToDevice, c->stream));
+    return VM_OK;
+}
+// association of the uploaded scan at pose (q, t); compacted on the host in scan order
+int associate_uploaded(vmap_ctx* c, int n_corner, int n_surf, const double* q, const double* t, int32_t* n_edge, double* edge9, int32_t* n_plane, double* plane7) {
+    PoseD T; quat_to_R(q, T.R); T.t[0] = t[0]; T.t[1] = t[1]; T.t[2] = t[2];
+    *n_edge = 0; *n_plane = 0;
+    const int nqc = c->nc ? n_corner : 0, nqs = c->ns ? n_surf : 0;       // an empty map yields no factors of that class
+    const int nq = n_corner + n_surf;
+    if (nq == 0 || nqc + nqs == 0) return VM_OK;
+    // queries are addressed in the uploaded layout (corner block, then surf block); a class without a map is skipped by nmap < k
+    double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq);
+    if (c->profiling) hipEventRecord(c->ev[0], c->stream);
+    hipLaunchKernelGGL(k_map_search, dim3((nq + VM_QPB - 1) / VM_QPB), dim3(64 * VM_QPB), 0, c->stream, n_corner, n_surf, c->d_scan, T, c->nc, c->gc.G, c->gc.order, c->gc.cxyz,
+                       c->ns, c->gs.G, c->gs.order, c->gs.cxyz, d_nn, d_nd5);
+    if (c->profiling) { hipEventRecord(c->ev[1], c->stream); hipEventRecord(c->ev[2], c->stream); }
+    hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_slot);
+    if (c->profiling) hipEventRecord(c->ev[3], c->stream);
+    c->h_slot.resize(10 * (size_t)nq);
+    VMCHK(hipMemcpyAsync(c->h_slot.data(), d_slot, 80 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+    VMCHK(hipStreamSynchronize(c->stream));
+    if (c->profiling) for (int k = 0; k < 2; ++k) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]) == hipSuccess) { c->prof_ms[k] += ms; c->prof_n[k]++; } }
+    for (int i = 0; i < n_corner; ++i) if (c->h_slot[10 * (size_t)i] != 0.0) { memcpy(edge9 + 9 * (size_t)(*n_edge), &c->h_slot[10 * (size_t)i + 1], 72); ++*n_edge; }
+    for (int i = n_corner; i < nq; ++i) if (c->h_slot[10 * (size_t)i] != 0.0) { memcpy(plane7 + 7 * (size_t)(*n_plane), &c->h_slot[10 * (size_t)i + 1], 56); ++*n_plane; }
+    VMCHK(hipGetLastError());
+    return VM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int vmap_create(int32_t device, vmap_ctx** out) {
+    if (!out) return VM_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VM_ERR_DEVICE;      // no CPU fallback
+    VMCHK(hipSetDevice(device));
+    vmap_ctx* c = new vmap_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VM_ERR_DEVICE; }
+    *out = c;
+    return VM_OK;
+}
+void vmap_destroy(vmap_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipFree(c->d_cmap); hipFree(c->d_smap); hipFree(c->gc.ws); hipFree(c->gs.ws); hipFree(c->d_scan); hipFree(c->d_work);
+    for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int vmap_set_map(vmap_ctx* c, int32_t nc, const float* corner, int32_t ns, const float* surf) {
+    if (!c || nc < 0 || ns < 0 || (nc && !corner) || (ns && !surf)) return VM_ERR_INVALID;
+    VMCHK(hipSetDevice(c->device));
+    c->nc = 0; c->ns = 0;
+    if (16 * (size_t)nc > c->cmap_cap) { hipFree(c->d_cmap); c->d_cmap = nullptr; c->cmap_cap = 0; VMCHK(hipMalloc(&c->d_cmap, 24 * (size_t)nc)); c->cmap_cap = 24 * (size_t)nc; }
+    if (16 * (size_t)ns > c->smap_cap) { hipFree(c->d_smap); c->d_smap = nullptr; c->smap_cap = 0; VMCHK(hipMalloc(&c->d_smap, 24 * (size_t)ns)); c->smap_cap = 24 * (size_t)ns; }
+    if (nc) VMCHK(hipMemcpyAsync(c->d_cmap, corner, 16 * (size_t)nc, hipMemcpyHostToDevice, c->stream));
+    if (ns) VMCHK(hipMemcpyAsync(c->d_smap, surf, 16 * (size_t)ns, hipMemcpyHostToDevice, c->stream));
+    if (nc) { const int st = build_adaptive(c, c->gc, nc, c->d_cmap, c->hc); if (st != VM_OK) return st; }
+    if (ns) { const int st = build_adaptive(c, c->gs, ns, c->d_smap, c->hs); if (st != VM_OK) return st; }
+    VMCHK(hipStreamSynchronize(c->stream));
+    c->nc = nc; c->ns = ns;
+    return VM_OK;
+}
+
+int vmap_associate(vmap_ctx* c, int32_t n_corner, const float* corner, int32_t n_surf, const float* surf, const double* q, const double* t,
+                   int32_t* n_edge, double* edge9, int32_t* n_plane, double* plane7) {
+    if (!c || !q || !t || !n_edge || !n_plane || n_corner < 0 || n_surf < 0 || (n_corner && (!corner || !edge9)) || (n_surf && (!surf || !plane7))) return VM_ERR_INVALID;
+    VMCHK(hipSetDevice(c->device));
+    const int st = upload_scan(c, n_corner, corner, n_surf, surf);
+    if (st != VM_OK) return st;
+    return associate_uploaded(c, n_corner, n_surf, q, t, n_edge, edge9, n_plane, plane7);
+}
+
+int vmap_profile_enable(vmap_ctx* c, int32_t enable) {
+    if (!c) return VM_ERR_INVALID;
+    VMCHK(hipSetDevice(c->device));
+    if (enable && !c->ev[0]) for (hipEvent_t& e : c->ev) VMCHK(hipEventCreate(&e));
+    c->profiling = enable != 0;
+    return VM_OK;
+}
+int vmap_profile_read(vmap_ctx* c, int64_t* launches2, double* total_ms2) {
+    if (!c || !launches2 || !total_ms2) return VM_ERR_INVALID;
+    for (int k = 0; k < 2; ++k) { launches2[k] = c->prof_n[k]; total_ms2[k] = c->prof_ms[k]; c->prof_n[k] = 0; c->prof_ms[k] = 0.0; }
+    return VM_OK;
+}
+
+int vmap_align(vmap_ctx* c, vil_ctx* solver, int32_t n_corner, const float* corner, int32_t n_surf, const float* surf,
+               double* q, double* t, const vil_options* opts, vmap_summary* out) {
+    if (!c || !solver || !q || !t || !opts || !out) return VM_ERR_INVALID;
+    memset(out, 0, sizeof *out);
+    if (!(c->nc > 10 && c->ns > 50)) return VM_OK;                      // localMapping.cpp:586 "corner and surf num are not enough"
+    std::vector<double> edge(9 * (size_t)std::max(1, n_corner)), plane(7 * (size_t)std::max(1, n_surf));
+    std::vector<int32_t> epose, ppose;
+    if (n_corner < 0 || n_surf < 0 || (n_corner && !corner) || (n_surf && !surf)) return VM_ERR_INVALID;
+    VMCHK(hipSetDevice(c->device));
+    int st = upload_scan(c, n_corner, corner, n_surf, surf);             // the scan is uploaded once for both rounds
+    if (st != VM_OK) return st;
+    for (int round = 0; round < 2; ++round) {
+        int32_t ne = 0, np = 0;
+        st = associate_uploaded(c, n_corner, n_surf, q, t, &ne, edge.data(), &np, plane.data());
+        if (st != VM_OK) return st;
+        epose.assign((size_t)std::max(1, ne), 0); ppose.assign((size_t)std::max(1, np), 0);
+        // one-pose window: pose free, everything else constant, identity LiDAR extrinsic, only the point factors
+        vil_problem p; memset(&p, 0, sizeof p);
+        uint8_t pose_const = 0, sb_const = 1;
+        p.K = 1; p.L = 0; p.pose_const = &pose_const; p.sb_const = &sb_const; p.ex_const = 1; p.td_const = 1; p.use_td = 0;
+        p.n_edge = ne; p.edge_pose = epose.data(); p.edge_const = edge.data();
+        p.n_plane = np; p.plane_pose = ppose.data(); p.plane_const = plane.data();
+        p.q_lb[3] = 1.0; p.sqrt_info_px = 230.0; p.G[2] = 9.8;
+        double pose[7] = {t[0], t[1], t[2], q[0], q[1], q[2], q[3]}, sb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ex[7] = {0, 0, 0, 0, 0, 0, 1}, td = 0.0, lam = 0.0;
+        vil_state s; memset(&s, 0, sizeof s);
+        s.K = 1; s.L = 0; s.pose = pose; s.speedbias = sb; s.ex_pose = ex; s.td = &td; s.inv_depth = &lam;
+        vil_summary sum;
+        st = vil_solve(solver, &p, &s, opts, &sum);
+        if (st != VIL_OK) return st;
+        t[0] = pose[0]; t[1] = pose[1]; t[2] = pose[2]; q[0] = pose[3]; q[1] = pose[4]; q[2] = pose[5]; q[3] = pose[6];
+        out->rounds = round + 1; out->n_edge = ne; out->n_plane = np; out->iterations = sum.iterations; out->initial_cost = sum.initial_cost; out->final_cost = sum.final_cost;
+    }
+    return VM_OK;
+}
+
+}  // extern "C"

@@ -205,7 +205,7 @@ void vil_destroy(vil_ctx* c) {
 
 static int validate(const vil_problem* p, const vil_state* s) {
     if (!p || !s) return VIL_ERR_INVALID_ARGUMENT;
-    if (p->K < 2 || p->L < 0 || s->K != p->K || s->L != p->L) return VIL_ERR_INVALID_ARGUMENT;
+    if (p->K < 1 || p->L < 0 || s->K != p->K || s->L != p->L) return VIL_ERR_INVALID_ARGUMENT;
     if (15 * p->K + 7 > 320) return VIL_ERR_UNSUPPORTED;   // K <= 20 (step kernel work space)
     if (p->n_icp + p->n_lps > 12 || p->n_icp < 0 || p->n_lps < 0) return VIL_ERR_UNSUPPORTED;   // reference trims to 5 + 7 (estimator.cpp:1283-1286,1345-1348)
     if (p->prior.n > 512 || p->prior.nblk > 256) return VIL_ERR_UNSUPPORTED;

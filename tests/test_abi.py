@@ -50,6 +50,29 @@ def test_library_exports_every_vgicp_symbol():
         vgicp.Vgicp(so, "vgicp_")                       # no device -> refuses, no CPU fallback
 
 
+def test_library_exports_every_vmap_symbol():
+    """include/vilmap.h (scan-to-map registration) is served by the same shared library."""
+    so = lib.load_vilsolve()
+    src = open(os.path.join(ROOT, "include", "vilmap.h")).read()
+    syms = sorted(set(re.findall(r"\b(vmap_[a-z_0-9]+)\s*\(", src)))
+    assert len(syms) == 7, syms
+    for s in syms:
+        assert hasattr(so, s), "libvilsolve.so does not export %s" % s
+    import subprocess, tempfile
+    from mvil_fusion_amd import mapreg
+    prog = '#include <stdio.h>\n#include "vilmap.h"\nint main(void){printf("%zu\\n", sizeof(vmap_summary));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        out = subprocess.check_output([os.path.join(d, "s")]).decode().split()
+    assert C.sizeof(mapreg.VmapSummary) == int(out[0])
+    with pytest.raises(mapreg.MapRegError):
+        import torch
+        if torch.cuda.is_available():
+            raise mapreg.MapRegError("GPU present")
+        mapreg.MapReg(so, "vmap_")                      # no device -> refuses, no CPU fallback
+
+
 def test_struct_layouts_match_header():
     """sizeof() of the ctypes mirrors equals what the C compiler lays out (checked through a tiny C program)."""
     import subprocess, tempfile
