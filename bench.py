@@ -185,6 +185,11 @@ def vgicp_mode(args):
     while time.perf_counter() - t0 < 1.0:
         Tg, sg = g.align(np.eye(4)); na += 1
     el_a = time.perf_counter() - t0
+    g.covariances(sx, 20)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        g.covariances(sx, 20)
+    cov_ms = 1e3 * (time.perf_counter() - t0) / 5
     n = len(sx)
     # algorithmic bytes of one linearisation (DIRECT1): source point 12 + covariance 72, per correspondence voxel record
     # (num 4 + mean 24 + cov 72) + key probe 8 + slot 4, stored correspondence 4 + 72
@@ -193,7 +198,7 @@ def vgicp_mode(args):
            "value": args.steps / el, "unit": "linearisations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "SURVEY 8(f) row 1: %d source points, %d correspondences, target voxel map resident" % (n, nc),
-                      "alignments_per_s": na / el_a, "lm_iterations_per_alignment": int(sg.iterations),
+                      "alignments_per_s": na / el_a, "lm_iterations_per_alignment": int(sg.iterations), "covariances_20nn_ms": cov_ms,
                       "translation_error_m": float(np.abs(Tg[:3, 3] - T_true[:3, 3]).max())},
            "roofline": {"bound": "hbm", "kernel": "k_vgicp_lin", "achieved": ab / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ab / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": ab, "avg_launch_us": k_us, "launches_timed": int(pn.value),

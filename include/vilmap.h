@@ -27,6 +27,8 @@ typedef struct vmap_summary {
     int32_t n_edge, n_plane;          /* factors of the last round (corner_num, surf_num) */
     int32_t iterations;               /* trust-region iterations of the last solve */
     double initial_cost, final_cost;  /* of the last solve */
+    double t_associate_ms, t_prepare_ms, t_solve_ms;  /* wall time over both rounds: "mapping data assosiation time" / "mapping solver time"
+                                                         (localMapping.cpp:764,778); prepare = factor upload of vil_solve */
 } vmap_summary;
 
 int vmap_create(int32_t device, vmap_ctx** out);

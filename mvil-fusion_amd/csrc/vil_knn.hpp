@@ -218,4 +218,24 @@ inline hipError_t grid_build(GridBuild& gb, int n, const float* d_xyz, int strid
     return hipGetLastError();
 }
 
+// grid with a cell size that keeps about `target` points per occupied cell (27 cells -> a few batches of 64 candidates per
+// wave query); the searches are exact for any cell size, this only bounds their cost.  h is updated in place, so a caller that
+// keeps it across scans converges after the first build.
+inline hipError_t grid_build_adaptive(GridBuild& gb, int n, const float* d_xyz, int stride, float& h, double target, hipStream_t stream) {
+    for (int pass = 0; pass < 3; ++pass) {
+        hipError_t e = grid_build(gb, n, d_xyz, stride, h, stream);
+        if (e != hipSuccess) return e;
+        int nocc = 0;
+        if ((e = hipMemcpyAsync(&nocc, gb.G.nocc, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        const double occ = (double)n / (nocc > 0 ? nocc : 1);
+        if (occ <= 2.0 * target && (occ >= 0.4 * target || h >= 1.0f)) break;
+        float hn = (float)(h * sqrt(target / occ));
+        hn = fminf(1.0f, fmaxf(0.125f, hn));
+        if (hn == h) break;
+        h = hn;
+    }
+    return hipSuccess;
+}
+
 }  // namespace vknn

@@ -8,6 +8,7 @@
 // and the 7-parameter solve is vil_solve on a one-pose window that holds exactly these factors (k_sweep's LiDAR roles).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -203,24 +204,7 @@ struct vmap_ctx {
 };
 
 namespace {
-// grid of one map cloud with a cell size that keeps about VM_OCC points per occupied cell (27 cells -> a few batches of 64
-// candidates per query); the search is exact for any cell size, this only bounds its cost
-#define VM_OCC 6.0
-int build_adaptive(vmap_ctx* c, vknn::GridBuild& gb, int n, const float* d_xyz, float& h) {
-    for (int pass = 0; pass < 3; ++pass) {
-        VMCHK(vknn::grid_build(gb, n, d_xyz, 4, h, c->stream));
-        int nocc = 0;
-        VMCHK(hipMemcpyAsync(&nocc, gb.G.nocc, 4, hipMemcpyDeviceToHost, c->stream));
-        VMCHK(hipStreamSynchronize(c->stream));
-        const double occ = (double)n / std::max(1, nocc);
-        if (occ <= 2.0 * VM_OCC && (occ >= 0.4 * VM_OCC || h >= 1.0f)) break;
-        float hn = (float)(h * std::sqrt(VM_OCC / occ));
-        hn = std::fmin(1.0f, std::fmax(0.125f, hn));
-        if (hn == h) break;
-        h = hn;
-    }
-    return VM_OK;
-}
+#define VM_OCC 6.0              // points per occupied grid cell the cell sizes are steered to
 int upload_scan(vmap_ctx* c, int n_corner, const float* corner, int n_surf, const float* surf) {
     const int nq = n_corner + n_surf;
     const size_t need_scan = 16 * (size_t)nq + 16, need_work = (size_t)nq * (40 + 4 + 80) + 256;
@@ -286,8 +270,8 @@ int vmap_set_map(vmap_ctx* c, int32_t nc, const float* corner, int32_t ns, const
     if (16 * (size_t)ns > c->smap_cap) { hipFree(c->d_smap); c->d_smap = nullptr; c->smap_cap = 0; VMCHK(hipMalloc(&c->d_smap, 24 * (size_t)ns)); c->smap_cap = 24 * (size_t)ns; }
     if (nc) VMCHK(hipMemcpyAsync(c->d_cmap, corner, 16 * (size_t)nc, hipMemcpyHostToDevice, c->stream));
     if (ns) VMCHK(hipMemcpyAsync(c->d_smap, surf, 16 * (size_t)ns, hipMemcpyHostToDevice, c->stream));
-    if (nc) { const int st = build_adaptive(c, c->gc, nc, c->d_cmap, c->hc); if (st != VM_OK) return st; }
-    if (ns) { const int st = build_adaptive(c, c->gs, ns, c->d_smap, c->hs); if (st != VM_OK) return st; }
+    if (nc) VMCHK(vknn::grid_build_adaptive(c->gc, nc, c->d_cmap, 4, c->hc, VM_OCC, c->stream));
+    if (ns) VMCHK(vknn::grid_build_adaptive(c->gs, ns, c->d_smap, 4, c->hs, VM_OCC, c->stream));
     VMCHK(hipStreamSynchronize(c->stream));
     c->nc = nc; c->ns = ns;
     return VM_OK;
@@ -328,8 +312,10 @@ int vmap_align(vmap_ctx* c, vil_ctx* solver, int32_t n_corner, const float* corn
     if (st != VM_OK) return st;
     for (int round = 0; round < 2; ++round) {
         int32_t ne = 0, np = 0;
+        const auto ta = std::chrono::steady_clock::now();
         st = associate_uploaded(c, n_corner, n_surf, q, t, &ne, edge.data(), &np, plane.data());
         if (st != VM_OK) return st;
+        out->t_associate_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count();
         epose.assign((size_t)std::max(1, ne), 0); ppose.assign((size_t)std::max(1, np), 0);
         // one-pose window: pose free, everything else constant, identity LiDAR extrinsic, only the point factors
         vil_problem p; memset(&p, 0, sizeof p);
@@ -345,6 +331,7 @@ int vmap_align(vmap_ctx* c, vil_ctx* solver, int32_t n_corner, const float* corn
         st = vil_solve(solver, &p, &s, opts, &sum);
         if (st != VIL_OK) return st;
         t[0] = pose[0]; t[1] = pose[1]; t[2] = pose[2]; q[0] = pose[3]; q[1] = pose[4]; q[2] = pose[5]; q[3] = pose[6];
+        out->t_prepare_ms += sum.t_prepare_ms; out->t_solve_ms += sum.t_solve_ms + sum.t_readback_ms;
         out->rounds = round + 1; out->n_edge = ne; out->n_plane = np; out->iterations = sum.iterations; out->initial_cost = sum.initial_cost; out->final_cost = sum.final_cost;
     }
     return VM_OK;

@@ -230,13 +230,25 @@ __global__ __launch_bounds__(VG_THREADS) void k_knn_cov(int n, const float* __re
     if (live) knn_plane_cov(L, xyz, k, cov9 + (size_t)9 * i);
 }
 
-// larger clouds: queries in cell order (neighbouring threads walk the same cells), exact grid search (vil_knn.hpp)
-__global__ __launch_bounds__(VG_THREADS) void k_knn_grid(int n, const float* __restrict__ xyz, GridTab G, const int* __restrict__ order, const float* __restrict__ cxyz, int k, double* __restrict__ cov9) {
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+// larger clouds: exact grid search with one WAVE per query point (vil_knn.hpp) writing the k neighbour indices in (distance,
+// index) order, then one thread per point for the fp64 mean / covariance / regularisation
+#define VG_QPB 4
+__global__ __launch_bounds__(64 * VG_QPB) void k_knn_wave(int n, const float* __restrict__ xyz, GridTab G, const int* __restrict__ order, const float* __restrict__ cxyz, int k, int* __restrict__ nn) {
+    __shared__ int wl_all[VG_QPB * KNN_WL_CAP];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int pos = blockIdx.x * VG_QPB + wave;                              // queries in cell order: neighbouring waves share cells in L2
     if (pos >= n) return;
-    KnnList L;
-    knn_grid_query(L, cxyz[3 * pos], cxyz[3 * pos + 1], cxyz[3 * pos + 2], min(k, n), n, G, order, cxyz);
-    knn_plane_cov(L, xyz, k, cov9 + (size_t)9 * order[pos]);
+    unsigned long long best;
+    knn_wave_query(best, cxyz[3 * pos], cxyz[3 * pos + 1], cxyz[3 * pos + 2], min(k, n), n, G, order, cxyz, wl_all + wave * KNN_WL_CAP, 3.0e38f, 1);
+    if (lane < KNN_MAX) nn[(size_t)KNN_MAX * order[pos] + lane] = lane < min(k, n) ? (int)(unsigned)best : 0x7fffffff;
+}
+__global__ __launch_bounds__(VG_THREADS) void k_knn_fit(int n, const float* __restrict__ xyz, const int* __restrict__ nn, int k, double* __restrict__ cov9) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    KnnList L; knn_init(L);
+#pragma unroll
+    for (int m = 0; m < KNN_MAX; ++m) L.bi[m] = nn[(size_t)KNN_MAX * i + m];
+    knn_plane_cov(L, xyz, k, cov9 + (size_t)9 * i);
 }
 
 struct HostKeyHash { size_t operator()(long long k) const { return (size_t)hash_key(k) * 2654435761u ^ (size_t)(k >> 17); } };
@@ -256,6 +268,8 @@ struct vgicp_ctx {
     double* d_part = nullptr; int part_cap = 0; double* d_out = nullptr; double* h_out = nullptr;
     bool linearized = false;
     bool profiling = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; long long prof_n = 0; double prof_ms = 0.0;
+    // neighbour search of the covariance estimation
+    vknn::GridBuild gb; float grid_h = 1.0f; int* d_nn = nullptr; size_t nn_cap = 0;
 };
 
 static void free_target(vgicp_ctx* c) { hipFree(c->d_keys); hipFree(c->d_slot); hipFree(c->d_num); hipFree(c->d_mean); hipFree(c->d_cov); c->d_keys = nullptr; c->d_slot = nullptr; c->d_num = nullptr; c->d_mean = nullptr; c->d_cov = nullptr; c->nvox = 0; }
@@ -273,14 +287,11 @@ static int covariances_dev(vgicp_ctx* c, int n, const float* d_xyz, int k, doubl
     if (n < grid_min) {
         hipLaunchKernelGGL(k_knn_cov, dim3(nblk), dim3(VG_THREADS), 0, c->stream, n, d_xyz, k, d_cov);
     } else {
-        float h = 1.0f;
-        if (const char* ev = getenv("VGICP_GRID_H")) h = (float)atof(ev);
-        vknn::GridBuild gb;
-        if (vknn::grid_build(gb, n, d_xyz, 3, h, c->stream) != hipSuccess) { if (gb.ws) hipFree(gb.ws); return VG_ERR_DEVICE; }
-        hipLaunchKernelGGL(k_knn_grid, dim3(nblk), dim3(VG_THREADS), 0, c->stream, n, d_xyz, gb.G, gb.order, gb.cxyz, k, d_cov);
-        const hipError_t e = hipStreamSynchronize(c->stream);
-        hipFree(gb.ws);
-        if (e != hipSuccess) return VG_ERR_DEVICE;
+        if (const char* ev = getenv("VGICP_GRID_H")) c->grid_h = (float)atof(ev);
+        if ((size_t)n * KNN_MAX * 4 > c->nn_cap) { hipFree(c->d_nn); c->d_nn = nullptr; c->nn_cap = 0; VGCHK(hipMalloc(&c->d_nn, (size_t)n * KNN_MAX * 6)); c->nn_cap = (size_t)n * KNN_MAX * 6; }
+        VGCHK(vknn::grid_build_adaptive(c->gb, n, d_xyz, 3, c->grid_h, 8.0, c->stream));
+        hipLaunchKernelGGL(k_knn_wave, dim3((n + VG_QPB - 1) / VG_QPB), dim3(64 * VG_QPB), 0, c->stream, n, d_xyz, c->gb.G, c->gb.order, c->gb.cxyz, k, c->d_nn);
+        hipLaunchKernelGGL(k_knn_fit, dim3(nblk), dim3(VG_THREADS), 0, c->stream, n, d_xyz, c->d_nn, k, d_cov);
     }
     VGCHK(hipStreamSynchronize(c->stream));
     VGCHK(hipGetLastError());
@@ -318,6 +329,7 @@ void vgicp_destroy(vgicp_ctx* c) {
     hipSetDevice(c->device);
     free_target(c); free_source(c);
     hipFree(c->d_cvox); hipFree(c->d_cM); hipFree(c->d_part); hipFree(c->d_out); if (c->h_out) hipHostFree(c->h_out);
+    hipFree(c->gb.ws); hipFree(c->d_nn);
     if (c->ev0) { hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;

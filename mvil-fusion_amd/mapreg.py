@@ -13,7 +13,8 @@ from .vgicp import _rot
 
 class VmapSummary(C.Structure):
     _fields_ = [("rounds", C.c_int32), ("n_edge", C.c_int32), ("n_plane", C.c_int32), ("iterations", C.c_int32),
-                ("initial_cost", C.c_double), ("final_cost", C.c_double)]
+                ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("t_associate_ms", C.c_double), ("t_prepare_ms", C.c_double), ("t_solve_ms", C.c_double)]
 
 
 class MapRegError(RuntimeError):

@@ -244,6 +244,7 @@ int orc_vmap_align(vmap_ctx* c, vil_ctx*, int32_t nc, const float* corner, int32
         const int st = orc_solve(&p, &s, opts, &sum);
         if (st != 0) return st;
         t[0] = pose[0]; t[1] = pose[1]; t[2] = pose[2]; q[0] = pose[3]; q[1] = pose[4]; q[2] = pose[5]; q[3] = pose[6];
+        out->t_prepare_ms += sum.t_prepare_ms; out->t_solve_ms += sum.t_solve_ms + sum.t_readback_ms;
         out->rounds = round + 1; out->n_edge = ne; out->n_plane = np; out->iterations = sum.iterations; out->initial_cost = sum.initial_cost; out->final_cost = sum.final_cost;
     }
     return 0;
