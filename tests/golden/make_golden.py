@@ -56,6 +56,28 @@ def main():
         np.savez_compressed(path, **out)
         print(name, "K=%d L=%d Fv=%d" % (w.K, w.L, len(w.vis_i)), "%.0f KB" % (os.path.getsize(path) / 1024))
     make_vgicp(orc)
+    make_mapreg(orc)
+
+
+def make_mapreg(orc):
+    """tests/golden/mapreg/mapreg_mini.npz: a small local map + scan (inputs), the oracle's correspondences at a fixed pose and
+    the registered pose of the two-round alignment (expected outputs).  SURVEY 8(f) row 2."""
+    from mvil_fusion_amd import mapreg
+    from mvil_fusion_amd.vgicp import _rot
+    cm, sm = mapreg.make_map(seed=31, n_surf=3000, n_corner=700)
+    R, t = _rot(0.008, -0.012, 0.35), np.array([0.8, -1.2, 0.2])
+    sc, ss = mapreg.make_scan(cm, sm, R, t, seed=32, n_surf=400, n_corner=120)
+    q0 = mapreg.quat_from_R(R @ _rot(0.004, -0.003, 0.008)); t0 = t + np.array([0.05, -0.04, 0.03])
+    reg = mapreg.MapReg(orc.lib, "orc_vmap_")
+    reg.set_map(cm, sm)
+    edge, plane = reg.associate(sc, ss, q0, t0)
+    q, tt, s = reg.align(None, sc, ss, q0, t0)
+    out = dict(map_corner=cm, map_surf=sm, scan_corner=sc, scan_surf=ss, q0=q0, t0=t0, q_true=mapreg.quat_from_R(R), t_true=t, edge=edge, plane=plane,
+               align_q=q, align_t=tt, align_meta=np.array([s.rounds, s.n_edge, s.n_plane, s.iterations, s.initial_cost, s.final_cost]))
+    os.makedirs(os.path.join(HERE, "mapreg"), exist_ok=True)
+    path = os.path.join(HERE, "mapreg", "mapreg_mini.npz")
+    np.savez_compressed(path, **out)
+    print("mapreg_mini", "%d+%d map / %d+%d scan points, %d edge + %d plane factors" % (len(cm), len(sm), len(sc), len(ss), len(edge), len(plane)), "%.0f KB" % (os.path.getsize(path) / 1024))
 
 
 def make_vgicp(orc):
@@ -82,4 +104,7 @@ def make_vgicp(orc):
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:                      # e.g. `make_golden.py mapreg`: only that fixture
+        {"vgicp": make_vgicp, "mapreg": make_mapreg}[sys.argv[1]](oracle_lib.open_oracle())
+    else:
+        main()

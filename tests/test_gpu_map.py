@@ -53,3 +53,10 @@ def test_empty_inputs(hip, setup):
     far = np.array([500.0, 0.0, 0.0])
     e, p = g.associate(sc, ss, q, far)                               # nothing within 1 m of the map
     assert len(e) == 0 and len(p) == 0
+
+
+def test_gpu_reproduces_golden_fixture(hip):
+    from test_oracle_map import _check_golden
+    g = mapreg.MapReg(lib.load_vilsolve(), "vmap_")
+    _check_golden(g, hip.ctx)
+    g.close()

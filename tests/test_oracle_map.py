@@ -85,3 +85,25 @@ def test_kdtree_search_equals_exhaustive(oracle, scene):
     ea, pa = a.associate(sc, ss, q, t); eb, pb = b.associate(sc, ss, q, t)
     assert np.array_equal(ea, eb) and np.array_equal(pa, pb)
     a.close(); b.close()
+
+
+def _check_golden(reg, solver_ctx):
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mapreg", "mapreg_mini.npz"))
+    reg.set_map(d["map_corner"], d["map_surf"])
+    edge, plane = reg.associate(d["scan_corner"], d["scan_surf"], d["q0"], d["t0"])
+    assert edge.shape == d["edge"].shape and plane.shape == d["plane"].shape
+    assert np.array_equal(edge[:, :3], d["edge"][:, :3]) and np.array_equal(plane[:, :3], d["plane"][:, :3])
+    same = np.abs(edge[:, 3:] - d["edge"][:, 3:]).max(axis=1) < 1e-9
+    swapped = np.abs(edge[:, 3:6] - d["edge"][:, 6:9]).max(axis=1) + np.abs(edge[:, 6:9] - d["edge"][:, 3:6]).max(axis=1) < 1e-9
+    assert np.all(same | swapped) and np.abs(plane[:, 3:] - d["plane"][:, 3:]).max() < 1e-9
+    q, t, s = reg.align(solver_ctx, d["scan_corner"], d["scan_surf"], d["q0"], d["t0"])
+    m = d["align_meta"]
+    assert (s.rounds, s.n_edge, s.n_plane, s.iterations) == tuple(int(v) for v in m[:4])
+    assert abs(s.final_cost - m[5]) <= 1e-8 * m[5] and np.abs(q - d["align_q"]).max() < 1e-9 and np.abs(t - d["align_t"]).max() < 1e-8
+
+
+def test_oracle_reproduces_golden_fixture(oracle):
+    r = mapreg.MapReg(oracle.lib, "orc_vmap_")
+    _check_golden(r, None)
+    r.close()
