@@ -292,6 +292,54 @@ def mapreg_mode(args):
     g.close(); be.close()
 
 
+def preint_mode(args):
+    """IMU pre-integration (integration_base.h:30-158).  Step = re-propagation of all K-1 = 9
+    intervals of a configs[1] window (20-40 samples each at 200 Hz), host buffers in and out; the roofline leg times k_preint
+    with HIP events on the library's stream."""
+    import numpy as np
+    from mvil_fusion_amd import lib, preint
+    s = preint.make_stream(n_intervals=args.preint_intervals, samples=(20, 40), seed=20240608)
+    ns = int(s[0][-1])
+    g = preint.Preint(lib.load_vilsolve(), "vpre_")
+    call, rg, jg = g.bind(*s)                                          # arguments marshalled once: the timed region is the C call
+    for _ in range(args.warmup):
+        call()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        call()
+    el = time.perf_counter() - t0
+    g.lib.vpre_profile_enable(g.ctx, 1)
+    for _ in range(args.steps):
+        call()
+    pn, pms = C.c_int64(), C.c_double()
+    g.lib.vpre_profile_read(g.ctx, C.byref(pn), C.byref(pms))
+    k_us = 1e3 * pms.value / max(1, pn.value)
+    n = args.preint_intervals
+    ab = ns * 56 + n * (96 + 8 * 287 + 8 * 225)                  # samples (dt, acc, gyr) in; per interval acc0/gyr0/ba/bg in, record + jacobian out
+    fl = ns * 2 * (3 * 15 ** 3 + 15 * 15 * 18 * 2)               # F J, F P, (F P) F^T, V N V^T
+    out = {"metric": "IMU re-propagations/sec (all %d intervals of a window, %d samples)" % (n, ns), "value": args.steps / el, "unit": "windows/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic", "config": {"workload": "SURVEY 8(f) row 3: mid-point pre-integration with 15x15 jacobian / covariance propagation", "samples": ns, "intervals": n},
+           "roofline": {"bound": "hbm", "kernel": "k_preint", "achieved": ab / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "algorithmic_bytes_per_launch": ab, "avg_launch_us": k_us, "launches_timed": int(pn.value), "gflops": fl / (k_us * 1e-6) / 1e9,
+                        "note": "one workgroup per interval, batches of 16 samples folded by a pairwise tree of affine maps: latency / LDS bound, neither HBM nor MFMA"}}
+    if not args.no_cpu:
+        o = preint.Preint(C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "orc_vpre_")
+        ocall, ro, jo = o.bind(*s)
+        ocall()
+        t0 = time.perf_counter(); k = 0
+        while time.perf_counter() - t0 < 3.0:
+            ocall(); k += 1
+        elc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": k / elc, "unit": "windows/s", "cores": 1, "kind": "port", "sample": "%d windows, %.1f s" % (k, elc),
+                               "note": "single-threaded restatement with static arrays (the reference allocates MatrixXd F, V per sample)"}
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        out["max_rel_covariance_difference"] = float(np.abs(rg[:, 62:] - ro[:, 62:]).max() / np.abs(ro[:, 62:]).max())
+        o.close()
+    print(json.dumps(out), flush=True)
+    g.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -308,6 +356,8 @@ def main():
     ap.add_argument("--mapreg", action="store_true", help="SURVEY 8(f) row 2: bench the LiDAR scan-to-map registration instead of the headline metric")
     ap.add_argument("--map-surf", type=int, default=60000); ap.add_argument("--map-corner", type=int, default=8000)
     ap.add_argument("--scan-surf", type=int, default=6000); ap.add_argument("--scan-corner", type=int, default=800)
+    ap.add_argument("--preint", action="store_true", help="SURVEY 8(f) row 3: bench the IMU pre-integration instead of the headline metric")
+    ap.add_argument("--preint-intervals", type=int, default=9)
     ap.add_argument("--force-comm", action="store_true", help="test hook: take the multi-GPU code path (process group, communicator, replicas leg) with a single rank")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of sharding one window over RCCL")
     args = ap.parse_args()
@@ -332,6 +382,9 @@ def main():
         return
     if args.mapreg:
         mapreg_mode(args)
+        return
+    if args.preint:
+        preint_mode(args)
         return
 
     be = lib.open_vilsolve(device=local, rank=rank, world=world)

@@ -113,4 +113,21 @@ void orc_preintegrate(int n, const double* dt, const double* acc, const double* 
     orc::preint_pack(s, out287);
 }
 
+
+// include/vilpreint.h on the CPU: IntegrationBase::repropagate for n intervals; interval k owns samples [start[k], start[k+1])
+struct vpre_ctx { int unused; };
+int orc_vpre_create(int32_t, vpre_ctx** out) { *out = new vpre_ctx(); return 0; }
+void orc_vpre_destroy(vpre_ctx* c) { delete c; }
+int orc_vpre_integrate(vpre_ctx*, int32_t n, const int32_t* start, const double* dt, const double* acc, const double* gyr, const double* acc0, const double* gyr0,
+                       const double* ba, const double* bg, const double* noise4, double* imu_const, double* jacobian) {
+    for (int k = 0; k < n; ++k) {
+        orc::Preint s;
+        orc::preint_init(s, acc0 + 3 * k, gyr0 + 3 * k, ba + 3 * k, bg + 3 * k, noise4);
+        for (int i = start[k]; i < start[k + 1]; ++i) orc::preint_push(s, dt[i], acc + 3 * (size_t)i, gyr + 3 * (size_t)i);
+        orc::preint_pack(s, imu_const + (size_t)287 * k);
+        if (jacobian) std::memcpy(jacobian + (size_t)225 * k, s.jac, sizeof s.jac);
+    }
+    return 0;
+}
+
 }  // extern "C"

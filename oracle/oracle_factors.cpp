@@ -469,7 +469,7 @@ void preint_push(Preint& s, double dt, const double* acc1, const double* gyr1) {
     const Vec3 w_x = (g0 + g1) * 0.5 - bg, a_0_x = a0 - ba, a_1_x = a1 - ba;
     const Mat3 R_w_x = skew(w_x), R_a_0_x = skew(a_0_x), R_a_1_x = skew(a_1_x);
     const Mat3 Rd = quat_R(dq), Rr = quat_R(rq), I3 = mat_ident();
-    std::vector<double> F(225, 0.0), V(15 * 18, 0.0);
+    double F[225] = {0.0}, V[15 * 18] = {0.0};
     auto putF = [&](int r0, int c0, const Mat3& m) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) F[(r0 + i) * 15 + c0 + j] = m(i, j); };
     auto putV = [&](int r0, int c0, const Mat3& m) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[(r0 + i) * 18 + c0 + j] = m(i, j); };
     const Mat3 ImW = mat_sub(I3, mat_scale(R_w_x, dt));
@@ -501,7 +501,7 @@ void preint_push(Preint& s, double dt, const double* acc1, const double* gyr1) {
     putV(9, 12, mat_scale(I3, dt));
     putV(12, 15, mat_scale(I3, dt));
     // jacobian = F * jacobian ; covariance = F cov F^T + V noise V^T
-    std::vector<double> nj(225), FC(225), nc(225);
+    double nj[225], FC[225], nc[225];
     for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) {
         double s1 = 0, s2 = 0;
         for (int k = 0; k < 15; ++k) { s1 += F[i * 15 + k] * s.jac[k * 15 + j]; s2 += F[i * 15 + k] * s.cov[k * 15 + j]; }
@@ -518,8 +518,8 @@ void preint_push(Preint& s, double dt, const double* acc1, const double* gyr1) {
         for (int k = 0; k < 18; ++k) s1 += V[i * 18 + k] * nd[k] * V[j * 18 + k];
         nc[i * 15 + j] = s1;
     }
-    std::memcpy(s.jac, nj.data(), sizeof s.jac);
-    std::memcpy(s.cov, nc.data(), sizeof s.cov);
+    std::memcpy(s.jac, nj, sizeof s.jac);
+    std::memcpy(s.cov, nc, sizeof s.cov);
     // :147-157
     s.dp[0] = rp.x; s.dp[1] = rp.y; s.dp[2] = rp.z;
     Quat rn = quat_normalized(rq);

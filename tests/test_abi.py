@@ -73,6 +73,22 @@ def test_library_exports_every_vmap_symbol():
         mapreg.MapReg(so, "vmap_")                      # no device -> refuses, no CPU fallback
 
 
+def test_library_exports_every_vpre_symbol():
+    """include/vilpreint.h (IMU pre-integration) is served by the same shared library."""
+    so = lib.load_vilsolve()
+    src = open(os.path.join(ROOT, "include", "vilpreint.h")).read()
+    syms = sorted(set(re.findall(r"\b(vpre_[a-z_0-9]+)\s*\(", src)))
+    assert len(syms) == 5, syms
+    for s in syms:
+        assert hasattr(so, s), "libvilsolve.so does not export %s" % s
+    from mvil_fusion_amd import preint
+    with pytest.raises(preint.PreintError):
+        import torch
+        if torch.cuda.is_available():
+            raise preint.PreintError("GPU present")
+        preint.Preint(so, "vpre_")                      # no device -> refuses, no CPU fallback
+
+
 def test_struct_layouts_match_header():
     """sizeof() of the ctypes mirrors equals what the C compiler lays out (checked through a tiny C program)."""
     import subprocess, tempfile
