@@ -57,18 +57,14 @@ static __global__ void k_grid_count(int n, const float* __restrict__ xyz, int st
     pslot[i] = s;
     atomicAdd(G.cnt + s, 1);
 }
-// single-workgroup exclusive scan of the per-slot counts (the table has at most a few 100 k slots)
-static __global__ __launch_bounds__(1024) void k_grid_scan(GridTab G) {
-    __shared__ int part[1024];
-    const int t = threadIdx.x, cap = G.mask + 1, per = (cap + 1023) / 1024;
-    int s = 0;
-    for (int e = t * per; e < min(cap, (t + 1) * per); ++e) s += G.cnt[e];
-    part[t] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) { const int v = t >= o ? part[t - o] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
-    int run = part[t] - s, occ = 0;
-    for (int e = t * per; e < min(cap, (t + 1) * per); ++e) { G.start[e] = run; run += G.cnt[e]; occ += G.cnt[e] != 0; }
-    if (occ) atomicAdd(G.nocc, occ);                                        // occupied cells: the host adapts the cell size to it
+// cell offsets: every occupied slot claims a contiguous range of the cell-ordered arrays with one atomic (the order of the
+// cells in memory is irrelevant -- only the points of one cell must be contiguous -- so no scan is needed); G.nocc[0] counts
+// the occupied cells (the host adapts the cell size to it), G.nocc[1] is the running total
+static __global__ void k_grid_offsets(GridTab G) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > G.mask) return;
+    const int c = G.cnt[e];
+    if (c) { G.start[e] = atomicAdd(G.nocc + 1, c); atomicAdd(G.nocc, 1); }
 }
 static __global__ void k_grid_fill(int n, const float* __restrict__ xyz, int stride, GridTab G, const int* __restrict__ pslot, int* __restrict__ order, float* __restrict__ cxyz) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,7 +209,7 @@ inline hipError_t grid_build(GridBuild& gb, int n, const float* d_xyz, int strid
     hipMemsetAsync(G.cnt, 0, 3 * 4 * (size_t)cap + 256, stream);
     const int nblk = (n + 255) / 256;
     hipLaunchKernelGGL(k_grid_count, dim3(nblk), dim3(256), 0, stream, n, d_xyz, stride, G, pslot);
-    hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, stream, G);
+    hipLaunchKernelGGL(k_grid_offsets, dim3((cap + 255) / 256), dim3(256), 0, stream, G);
     hipLaunchKernelGGL(k_grid_fill, dim3(nblk), dim3(256), 0, stream, n, d_xyz, stride, G, pslot, gb.order, gb.cxyz);
     return hipGetLastError();
 }

@@ -356,9 +356,11 @@ class Replay:
         return self.pose_true[self.frames]
 
 
-def run(backend, rp, n_steps=None, on_frame=None, with_marg=True):
-    """Drive `rp` with `backend` for n_steps images; returns per-frame records (latencies in ms, errors vs truth)."""
+def run(backend, rp, n_steps=None, on_frame=None, with_marg=True, log_path=None):
+    """Drive `rp` with `backend` for n_steps images; returns per-frame records (latencies in ms, errors vs truth).
+    log_path: append the newest pose of every image in the reference's Frontend.txt format (visualization.cpp:199-212)."""
     out = []
+    log = open(log_path, "a") if log_path else None
     step = 0
     while n_steps is None or step < n_steps:
         w = rp.window()
@@ -378,8 +380,13 @@ def run(backend, rp, n_steps=None, on_frame=None, with_marg=True):
                    pos_err_newest=float(np.linalg.norm(w.pose[-1, :3] - tw[-1, :3])), new_prior_n=(po.c.n if po is not None else -1))
         if on_frame is not None:
             on_frame(rp, w, po, rec)
+        if log is not None:
+            from . import formats
+            log.write(formats.format_trajectory_line(float(rp.t[rp.newest]), w.pose[-1, :3], w.pose[-1, 3:7]))
         out.append(rec)
         step += 1
         if not rp.absorb(w, po, flag):
             break
+    if log is not None:
+        log.close()
     return out

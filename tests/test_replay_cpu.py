@@ -27,8 +27,13 @@ def test_replay_chain_oracle(oracle):
         else:
             assert po.c.n in (-1, 6 * (K - 2) + 9 + 6 + 1)                                        # pose K-2 dropped from the prior (or prior untouched)
 
-    recs = replay.run(oracle, rp, n_steps=14, on_frame=check)
+    import os, tempfile
+    from mvil_fusion_amd import formats
+    log = os.path.join(tempfile.mkdtemp(), "Frontend.txt")
+    recs = replay.run(oracle, rp, n_steps=14, on_frame=check, log_path=log)
     assert len(recs) == 14 and seen == {abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW}
+    traj = formats.parse_trajectory(open(log).read())                                             # the reference's trajectory log format
+    assert traj.shape == (14, 8) and np.all(np.diff(traj[:, 0]) > 0) and np.allclose(np.linalg.norm(traj[:, 4:], axis=1), 1.0, atol=2e-5)
     assert recs[0]["prior_n"] == 0 and all(r["prior_n"] > 0 for r in recs[1:])
     # merged pre-integration after a MARGIN_SECOND_NEW slide spans two keyframe intervals
     assert max(r["pos_err_newest"] for r in recs) < 0.5
