@@ -1,5 +1,9 @@
-// ORACLE -- TEST INFRASTRUCTURE ONLY (never linked into or called by the product path).  PARITY UNPINNED: the
-// reference ships no tests or golden vectors for fast_gicp and cannot be built here (Eigen / PCL absent).
+// ORACLE -- TEST INFRASTRUCTURE ONLY (never linked into or called by the product path).
+// PINNED by the reference's own known-answer test: the vendored fast_gicp ships src/test/gicp_test.cpp with two real scans
+// and their relative pose (fast_gicp-master.zip: data/251370668.pcd, data/251371071.pcd, data/relative.txt); the restatement
+// passes it forward and backward at the test's tolerances (0.05 m, 1 degree, converged) --
+// tests/golden/vgicp/fast_gicp_kat.npz, tests/test_oracle_vgicp.py::test_reference_known_answer.  fast_gicp itself cannot be
+// built here (Eigen / PCL absent), so parity finer than that tolerance rests on the numpy / finite-difference pins.
 //
 // CPU restatement of the voxelised GICP registration vendored in the reference under
 // vils_estimator/src/lidar_functions/fast_gicp (third party: SMRT-AIST fast_gicp, unpinned snapshot):

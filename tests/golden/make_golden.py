@@ -80,6 +80,47 @@ def make_mapreg(orc):
     print("mapreg_mini", "%d+%d map / %d+%d scan points, %d edge + %d plane factors" % (len(cm), len(sm), len(sc), len(ss), len(edge), len(plane)), "%.0f KB" % (os.path.getsize(path) / 1024))
 
 
+def make_fast_gicp_kat(_orc=None):
+    """tests/golden/vgicp/fast_gicp_kat.npz: the KNOWN-ANSWER data of the reference's own registration test -- the vendored
+    fast_gicp ships `src/test/gicp_test.cpp` with two real LiDAR scans and their relative pose
+    (vils_estimator/src/lidar_functions/fast_gicp-master.zip: data/251370668.pcd, data/251371071.pcd, data/relative.txt).
+    The test down-samples both scans with a 0.2 m voxel grid (centroid per voxel, pcl::VoxelGrid) and requires every
+    registration to land within 0.05 m / 1 degree of relative.txt and to report convergence (gicp_test.cpp:43-60, :133-150).
+    The fixture holds the down-sampled scans (float32) and the pose; only this script reads /root/reference."""
+    import io, zipfile
+    z = zipfile.ZipFile("/root/reference/vils_estimator/src/lidar_functions/fast_gicp-master.zip")
+
+    def load_pcd(name):
+        raw = z.read("fast_gicp-master/data/" + name)
+        head, body = raw.split(b"DATA binary\n", 1)
+        fields = dict(l.split(" ", 1) for l in head.decode().splitlines() if " " in l)
+        assert fields["FIELDS"] == "x y z intensity" and fields["SIZE"] == "4 4 4 4" and fields["TYPE"] == "F F F F"
+        n = int(fields["POINTS"])
+        return np.frombuffer(body[:16 * n], np.float32).reshape(n, 4)[:, :3].copy()
+
+    def voxel_grid(xyz, leaf):
+        # pcl::VoxelGrid: voxel = floor(p / leaf), centroid of the points of a voxel, output ordered by the linear voxel index
+        xyz = xyz[np.all(np.isfinite(xyz), axis=1)]
+        ijk = np.floor(xyz.astype(np.float64) / leaf).astype(np.int64)
+        ijk -= ijk.min(axis=0)
+        dim = ijk.max(axis=0) + 1
+        lin = ijk[:, 0] + ijk[:, 1] * dim[0] + ijk[:, 2] * dim[0] * dim[1]
+        order = np.argsort(lin, kind="stable")
+        lin_s, pts = lin[order], xyz[order].astype(np.float64)
+        first = np.concatenate([[True], lin_s[1:] != lin_s[:-1]])
+        grp = np.cumsum(first) - 1
+        cnt = np.bincount(grp)
+        cen = np.stack([np.bincount(grp, weights=pts[:, c]) / cnt for c in range(3)], axis=1)
+        return cen.astype(np.float32)
+
+    rel = np.array([float(v) for v in z.read("fast_gicp-master/data/relative.txt").decode().split()]).reshape(4, 4)
+    tgt, src = voxel_grid(load_pcd("251370668.pcd"), 0.2), voxel_grid(load_pcd("251371071.pcd"), 0.2)
+    os.makedirs(os.path.join(HERE, "vgicp"), exist_ok=True)
+    path = os.path.join(HERE, "vgicp", "fast_gicp_kat.npz")
+    np.savez_compressed(path, target=tgt, source=src, relative_pose=rel, t_tol=np.array([0.05]), r_tol_deg=np.array([1.0]))
+    print("fast_gicp_kat", "%d target / %d source points after the 0.2 m voxel grid" % (len(tgt), len(src)), "%.0f KB" % (os.path.getsize(path) / 1024))
+
+
 def make_vgicp(orc):
     """tests/golden/vgicp/vgicp_mini.npz: a small scan pair (inputs) + the oracle's linearisation at a fixed transform for
     the three neighbour modes and the aligned transform of both optimisers (expected outputs).  SURVEY 8(f) row 1."""
@@ -105,6 +146,6 @@ def make_vgicp(orc):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # e.g. `make_golden.py mapreg`: only that fixture
-        {"vgicp": make_vgicp, "mapreg": make_mapreg}[sys.argv[1]](oracle_lib.open_oracle())
+        {"vgicp": make_vgicp, "mapreg": make_mapreg, "fast_gicp_kat": make_fast_gicp_kat}[sys.argv[1]](oracle_lib.open_oracle())
     else:
         main()

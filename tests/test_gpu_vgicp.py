@@ -96,3 +96,12 @@ def test_covariances_grid_search_parity(oracle, monkeypatch):
         g.close()
         assert np.abs(cg - co).max() < 1e-10, h
     o.close()
+
+
+def test_reference_known_answer(oracle):
+    """fast_gicp's own registration test data: the GPU passes it, and lands on the oracle's transforms."""
+    from test_oracle_vgicp import _kat
+    g = vgicp.Vgicp(lib.load_vilsolve(), "vgicp_"); o = vgicp.Vgicp(oracle.lib, "orc_vgicp_")
+    Tg, To = _kat(g), _kat(o)
+    g.close(); o.close()
+    assert np.abs(Tg[0] - To[0]).max() < 1e-8 and np.abs(Tg[1] - To[1]).max() < 1e-8

@@ -145,3 +145,34 @@ def test_align_with_estimated_covariances(oracle, pair):
     T, s = r.align(np.eye(4))
     r.close()
     assert s.converged == 1 and np.abs(T[:3, 3] - T_true[:3, 3]).max() < 0.05
+
+
+def _kat(reg):
+    """The reference's own known-answer test for FastVGICP (fast_gicp src/test/gicp_test.cpp:133-150 on data/251370668.pcd,
+    251371071.pcd, relative.txt -- committed down-sampled as tests/golden/vgicp/fast_gicp_kat.npz by make_golden.py):
+    forward and backward registration from identity with the class defaults must land within 0.05 m / 1 degree of the
+    recorded relative pose and report convergence."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vgicp", "fast_gicp_kat.npz"))
+    rel, t_tol, r_tol = d["relative_pose"], float(d["t_tol"][0]), float(d["r_tol_deg"][0])
+
+    def err(T):
+        D = np.linalg.inv(rel) @ T
+        return np.linalg.norm(D[:3, 3]), np.degrees(np.arccos(np.clip((np.trace(D[:3, :3]) - 1) / 2, -1, 1)))
+    out = []
+    reg.set_target(d["target"], None, 1.0); reg.set_source(d["source"], None)          # FastVGICP(): voxel resolution 1.0, 20-NN covariances
+    T, s = reg.align(np.eye(4))
+    assert err(T)[0] < t_tol and err(T)[1] < r_tol and s.converged == 1
+    out.append(T)
+    reg.set_target(d["source"], None, 1.0); reg.set_source(d["target"], None)
+    T, s = reg.align(np.eye(4))
+    e = err(np.linalg.inv(T))
+    assert e[0] < t_tol and e[1] < r_tol and s.converged == 1
+    out.append(T)
+    return out
+
+
+def test_reference_known_answer(oracle):
+    r = vgicp.Vgicp(oracle.lib, "orc_vgicp_")
+    _kat(r)
+    r.close()
