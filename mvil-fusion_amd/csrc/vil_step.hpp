@@ -28,11 +28,11 @@ struct StepShared {
     Ctl c;
     double red[32];
     unsigned char tI[256], tJ[256];   // triangular tile index -> (row, col) of the tile
-    double xs[320], dinv[320], Xb[800];   // ... and the inverses of the 4x4 diagonal blocks (80 blocks x 10)   // solution of the reduced system, reciprocal Cholesky pivots (D <= 320)
+    double xs[320], dinv[320];            // solution of the reduced system, reciprocal Cholesky pivots (D <= 320)
     double y[320];
     double sc[320], dcs[320], gr[320], gn[320];   // Sc, dogleg diagonal, gradient_, gauss_newton_step_ (camera part)
     int need, was_first, ok;
-    long long tacc[3];
+    long long tacc[6];
 };
 
 // block-wide sum(a), sum(b) and sum-or-max(c) with one pair of barriers
@@ -167,7 +167,7 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double
     const int la = (lane & 15) * TILE_RS + (lane >> 4);     // operand element (row lane&15, k lane>>4) inside a tile
     const int lc = (lane >> 4) * TILE_RS + (lane & 15);     // accumulator element (row lane>>4 (+4g), col lane&15)
 #ifdef VIL_STAMPS
-    long long tacc[3] = {0, 0, 0}, tprev = 0;
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     #define CSTAMP(k) do { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); if (k >= 0) tacc[k < 0 ? 0 : k] += tt_ - tprev; tprev = tt_; } while (0)
 #else
     #define CSTAMP(k) do {} while (0)
@@ -204,6 +204,7 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double
                 for (int q = 0; q < 4; ++q) A[cb + q * (4 * TILE_RS)] = Creg[u][q];
             }
             __syncthreads();
+            CSTAMP(4);
         }
         if constexpr (!REGRES) if (ko == 0) {         // global path: stage the ACTIVE tile column in LDS for its four block steps
             __syncthreads();                          // the deferred updates of the previous column have landed in A
@@ -244,22 +245,13 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double
             const double x3 = (a3 - x0 * l30 - x1 * l31 - x2 * l32) * r3_;
             AC[base] = x0; if (nb > 1) AC[base + 1] = x1; if (nb > 2) AC[base + 2] = x2; if (nb > 3) AC[base + 3] = x3;
         }
-        if (t == NT - 1) {              // an idle thread (no panel row): X = L_kk^-1 (lower 4x4) for the back substitution
-            double* X = s.Xb + (kb >> 2) * 10;
-            const double x10 = -l10 * r0_ * r1_;
-            const double x21 = -l21 * r1_ * r2_;
-            const double x32 = -l32 * r2_ * r3_;
-            const double x20 = -(l20 * r0_ + l21 * x10) * r2_;
-            const double x31 = -(l31 * r1_ + l32 * x21) * r3_;
-            const double x30 = -(l30 * r0_ + l31 * x10 + l32 * x20) * r3_;
-            X[0] = r0_; X[1] = x10; X[2] = r1_; X[3] = x20; X[4] = x21; X[5] = r2_; X[6] = x30; X[7] = x31; X[8] = x32; X[9] = r3_;
-        }
         if (t == NT - 2) {              // the factored block itself and the reciprocal pivots (a thread without a panel row)
             AC[db] = l00; s.dinv[kb] = r0_;
             if (nb > 1) { AC[db + TILE_RS] = l10; AC[db + TILE_RS + 1] = l11; s.dinv[kb + 1] = r1_; }
             if (nb > 2) { AC[db + 2 * TILE_RS] = l20; AC[db + 2 * TILE_RS + 1] = l21; AC[db + 2 * TILE_RS + 2] = l22; s.dinv[kb + 2] = r2_; }
             if (nb > 3) { AC[db + 3 * TILE_RS] = l30; AC[db + 3 * TILE_RS + 1] = l31; AC[db + 3 * TILE_RS + 2] = l32; AC[db + 3 * TILE_RS + 3] = l33; s.dinv[kb + 3] = r3_; }
         }
+        CSTAMP(5);
         __syncthreads();
         CSTAMP(1);
         // ---- 3. trailing update on the fp64 matrix cores: C[r][c] -= sum_{k<4} L[r][kb+k] L[c][kb+k], r, c >= r0 ------
@@ -345,11 +337,12 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double
                 for (int e = t; e < (T - Kt) * TILE_SZ; e += NT) { const int I = Kt + e / TILE_SZ, w = e - (I - Kt) * TILE_SZ; A[tl_base(I, Kt) + w] = Acol[e]; }
             }
         } }
-        __syncthreads();
         CSTAMP(2);
+        __syncthreads();
+        CSTAMP(3);
     }
 #ifdef VIL_STAMPS
-    if (threadIdx.x == 0) { s.tacc[0] = tacc[0]; s.tacc[1] = tacc[1]; s.tacc[2] = tacc[2]; }
+    if (threadIdx.x == 0) { for (int q = 0; q < 6; ++q) s.tacc[q] = tacc[q]; }
 #endif
     return true;
 }
@@ -669,7 +662,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         if constexpr (LDSM) ok = chol_blocked<true>(Alds, D, s); else ok = chol_blocked<false>(Ag, D, s, Alds);      // Alds = staging of the active tile column
         STAMP(3);
 #ifdef VIL_STAMPS
-        if (t == 0) { P.dbg[20] = s.tacc[0]; P.dbg[21] = s.tacc[1]; P.dbg[22] = s.tacc[2]; }
+        if (t == 0) { P.dbg[20] = s.tacc[0]; P.dbg[21] = s.tacc[1]; P.dbg[22] = s.tacc[2]; P.dbg[24] = s.tacc[3]; P.dbg[25] = s.tacc[4]; P.dbg[26] = s.tacc[5]; }
 #endif
         if (!ok) {
             // dogleg_strategy.cc: mu *= 10 and retry; the Schur pivots depend on mu, so re-sweep at x_cur

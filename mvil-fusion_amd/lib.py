@@ -15,7 +15,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvilsolve.so")
+LIB_PATH = os.environ.get("VIL_LIB") or os.path.join(_HERE, "csrc", "libvilsolve.so")      # VIL_LIB: tooling builds (tools/probe_step.py), never a fallback
 
 STATUS = {0: "ok", -1: "invalid argument", -2: "device error", -3: "non-finite", -4: "not positive definite", -5: "comm error", -6: "unsupported"}
 

@@ -22,3 +22,4 @@ dbg = (C.c_longlong*64)(); be.lib.vil_debug_read(be.ctx, dbg)
 d = np.array(dbg[:12], dtype=np.int64); print("raw", (d-d[0]).tolist()); print("backsubst phase I end stamp rel to stamp3:", dbg[23]-dbg[3], "of total", dbg[4]-dbg[3])
 print("step stamps (cycles, deltas):", np.diff(d).tolist())
 v = np.array(dbg[32:40], dtype=np.int64); print("visual WG0 stamps rel:", (v - v[0]).tolist())
+print("cholesky cycles (wave 0): diag %d, panel %d, barrier after panel %d, trailing %d, barrier after trailing %d, publish+barrier %d" % (dbg[20], dbg[26], dbg[21], dbg[22], dbg[24], dbg[25]))
