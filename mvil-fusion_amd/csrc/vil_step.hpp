@@ -15,6 +15,8 @@
 // uses the inverses of the 16 x 16 diagonal tiles.  Windows whose tiles exceed LDS (K > 10) run the same code on a
 // global (L2-resident) buffer.
 #pragma once
+#include <type_traits>
+
 #include "vil_dev.hpp"
 #include "vil_factors.hpp"
 
@@ -31,6 +33,7 @@ struct StepShared {
     double xs[320], dinv[320];            // solution of the reduced system, reciprocal Cholesky pivots (D <= 320)
     double y[320];
     double sc[320], dcs[320], gr[320], gn[320];   // Sc, dogleg diagonal, gradient_, gauss_newton_step_ (camera part)
+    double gd[320];                               // reduced gradient (rhs row of M): staged once, the packing loop must not touch global memory
     int need, was_first, ok;
     long long tacc[6];
 };
@@ -125,6 +128,17 @@ __device__ __forceinline__ void pose_plus(const double* in, const double* d, dou
 }
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+// triangular tile index -> tile row / column as compile-time constants, and a compile-time counted loop: element
+// e = t + u * VIL_STEP_THREADS of the tile array belongs to tile 2u or 2u + 1 (512 threads, 256 elements per tile), so inside a
+// statically unrolled loop the tile coordinates are constants selected by one wave-uniform bit -- no table look-up in LDS on
+// the address path of the S' prefetch and of the packing loop
+__host__ __device__ constexpr int tri_row_c(int q) { int I = 0; while ((I + 1) * (I + 2) / 2 <= q) ++I; return I; }
+__host__ __device__ constexpr int tri_col_c(int q) { return q - tri_row_c(q) * (tri_row_c(q) + 1) / 2; }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+static_assert(VIL_STEP_THREADS == 512, "the tile <-> element mapping above assumes two tiles per 512-thread stride");
 
 // sqrt(x) and 1/sqrt(x) together: hardware rsq seed + two coupled Newton steps (no divide on the pivot chain)
 __device__ __forceinline__ void sqrt_rsqrt(double x, double& sq, double& rs) {
@@ -561,17 +575,18 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     double pf[PF_N];
     if (PHASE != 2 && s.need) {
         const int R = D + 1, T = (R + 15) >> 4, NTL = (tri_off(T)) << 8;
-#pragma unroll
-        for (int u = 0; u < PF_N; ++u) {
+        const int half = __builtin_amdgcn_readfirstlane(t >> 8), w = t & 255;
+        static_for<PF_N>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int I0 = tri_row_c(2 * u), J0 = tri_col_c(2 * u), I1 = tri_row_c(2 * u + 1), J1 = tri_col_c(2 * u + 1);
             const int e = t + u * VIL_STEP_THREADS;
             pf[u] = 0.0;
             if (e < NTL) {
-                const int tile = e >> 8, w = e & 255;
-                const int I = s.tI[tile], J = s.tJ[tile];
+                const int I = half ? I1 : I0, J = half ? J1 : J0;
                 const int i = (I << 4) + (w >> 4), j = (J << 4) + (w & 15);
                 if (i < D && j <= i) pf[u] = sb.S[(size_t)i * D + j];
             }
-        }
+        });
     }
     STAMP(1);
     double gn2 = 0, g2 = 0, gg = 0;
@@ -584,7 +599,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             if (s.was_first) { Sc = O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0; P.Sc[i] = Sc; } else Sc = P.Sc[i];
             const double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
             const double g = Sc * b / d;
-            s.sc[i] = Sc; s.dcs[i] = d; s.gr[i] = g; s.y[i] = Sc * g / d;
+            s.sc[i] = Sc; s.dcs[i] = d; s.gr[i] = g; s.y[i] = Sc * g / d; s.gd[i] = sb.gred[i];
             P.dc[i] = d; P.gradc[i] = g;
             if (cam) { g2 += g * g; gm = fmax(gm, fabs(b)); }
         }
@@ -610,12 +625,16 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         // tiled storage: element e of the tile array -> (i, j); S entries were prefetched into registers at kernel start
         double* Ag = P.M;
         const int R = D + 1, T = (R + 15) >> 4, NTL = (tri_off(T)) << 8;
-#pragma unroll
-        for (int u = 0; u < PF_N; ++u) {
+        const int half = __builtin_amdgcn_readfirstlane(t >> 8), w = t & 255;
+#ifdef VIL_STAMPS
+        long long tpk0 = 0; if (t == 0) { asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tpk0) :: "memory"); }
+#endif
+        static_for<PF_N>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int I0 = tri_row_c(2 * u), J0 = tri_col_c(2 * u), I1 = tri_row_c(2 * u + 1), J1 = tri_col_c(2 * u + 1);
             const int e = t + u * VIL_STEP_THREADS;
             if (e < NTL) {
-                const int tile = e >> 8, w = e & 255;
-                const int I = s.tI[tile], J = s.tJ[tile];
+                const int I = half ? I1 : I0, J = half ? J1 : J0;
                 const int i = (I << 4) + (w >> 4), j = (J << 4) + (w & 15);
                 double m = 0.0;
                 if (i < D && j <= i) {
@@ -623,10 +642,13 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                     if (cam) q += (i == j ? 1.0 : 2.0) * s.y[i] * v * s.y[j];
                     m = s.sc[i] * v * s.sc[j];
                     if (i == j) m += mu * s.dcs[i] * s.dcs[i];
-                } else if (i == D && j < D) m = s.sc[j] * sb.gred[j];
+                } else if (i == D && j < D) m = s.sc[j] * s.gd[j];
                 if constexpr (LDSM) Alds[tl_phys(e)] = m; else Ag[tl_phys(e)] = m;
             }
-        }
+        });
+#ifdef VIL_STAMPS
+        if (t == 0) { long long tpk1; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tpk1) :: "memory"); P.dbg[27] = tpk1 - tpk0; }
+#endif
         for (int e = t + PF_N * VIL_STEP_THREADS; e < NTL; e += VIL_STEP_THREADS) {     // large windows (K > 10): remainder, direct loads
             const int tile = e >> 8, w = e & 255;
             const int I = s.tI[tile], J = s.tJ[tile];
@@ -637,7 +659,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                 if (cam) q += (i == j ? 1.0 : 2.0) * s.y[i] * v * s.y[j];
                 m = s.sc[i] * v * s.sc[j];
                 if (i == j) m += mu * s.dcs[i] * s.dcs[i];
-            } else if (i == D && j < D) m = s.sc[j] * sb.gred[j];
+            } else if (i == D && j < D) m = s.sc[j] * s.gd[j];
             if constexpr (LDSM) Alds[tl_phys(e)] = m; else Ag[tl_phys(e)] = m;
         }
         STAMP(11);

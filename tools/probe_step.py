@@ -23,3 +23,4 @@ d = np.array(dbg[:12], dtype=np.int64); print("raw", (d-d[0]).tolist()); print("
 print("step stamps (cycles, deltas):", np.diff(d).tolist())
 v = np.array(dbg[32:40], dtype=np.int64); print("visual WG0 stamps rel:", (v - v[0]).tolist())
 print("cholesky cycles (wave 0): diag %d, panel %d, barrier after panel %d, trailing %d, barrier after trailing %d, publish+barrier %d" % (dbg[20], dbg[26], dbg[21], dbg[22], dbg[24], dbg[25]))
+print("packing loop, wave 0 own cycles:", dbg[27], " stamps 10->11:", dbg[11]-dbg[10], " 9->10:", dbg[10]-dbg[9], " 1->9:", dbg[9]-dbg[1], " 11->2:", dbg[2]-dbg[11], " 4->5:", dbg[5]-dbg[4], " 5->6:", dbg[6]-dbg[5])
