@@ -32,9 +32,9 @@ __device__ __forceinline__ float sqdist_nofma(float qx, float qy, float qz, floa
     const float dx = __fsub_rn(qx, x), dy = __fsub_rn(qy, y), dz = __fsub_rn(qz, z);
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));        // no fma: bit-equal to the CPU sum
 }
-// ---- uniform-grid search for larger clouds: count points per cell (hash table of packed cell keys), exclusive scan,
-//      scatter into cell order, then every query walks Chebyshev rings of cells around its own cell until the k-th best
-//      distance is provably final (everything unvisited is at least ring * h away).  Exact, like the tiled search.
+// ---- uniform grid for larger clouds: count points per cell (hash table of packed cell keys), one atomic range claim per
+//      occupied cell, scatter into cell order; a query (knn_wave_query below) then walks Chebyshev rings of cells around its
+//      own cell until the k-th best distance is provably final (everything unvisited is at least ring * h away).  Exact.
 struct GridTab { long long* keys; int* cnt; int* start; int* cur; int* nocc; int mask; float h; };
 __device__ __forceinline__ int grid_slot(const GridTab& G, long long key, bool insert) {
     for (unsigned hh = hash_key(key) & G.mask;; hh = (hh + 1) & G.mask) {
@@ -74,37 +74,7 @@ static __global__ void k_grid_fill(int n, const float* __restrict__ xyz, int str
     order[pos] = i; cxyz[3 * pos] = xyz[stride * i]; cxyz[3 * pos + 1] = xyz[stride * i + 1]; cxyz[3 * pos + 2] = xyz[stride * i + 2];
 }
 
-// the k-th best distance of a list (select chain: no dynamic register index)
-__device__ __forceinline__ float knn_kth(const KnnList& L, int kk) {
-    float bk = 3.0e38f;
-#pragma unroll
-    for (int m = 0; m < KNN_MAX; ++m) bk = (m == kk - 1) ? L.bd[m] : bk;
-    return bk;
-}
-
-#define KNN_RMAX 6
-// Exact k nearest neighbours of (qx, qy, qz) in a gridded cloud: Chebyshev rings of cells around the query's cell until the
-// k-th best distance is below ring * h (everything unvisited is farther); isolated queries fall back to an exhaustive scan.
-__device__ __forceinline__ void knn_grid_query(KnnList& L, float qx, float qy, float qz, int kk, int n, const GridTab& G, const int* __restrict__ order, const float* __restrict__ cxyz) {
-    knn_init(L);
-    bool done = false;
-    for (int r = 0; r <= KNN_RMAX && !done; ++r) {
-        for (int dx = -r; dx <= r; ++dx) for (int dy = -r; dy <= r; ++dy) for (int dz = -r; dz <= r; ++dz) {
-            if (max(max(abs(dx), abs(dy)), abs(dz)) != r) continue;
-            const int s = grid_slot(G, cell_key(qx, qy, qz, G.h, dx, dy, dz), false);
-            if (s < 0) continue;
-            const int b = G.start[s], e = b + G.cnt[s];
-            for (int j = b; j < e; ++j) knn_insert(L, sqdist_nofma(qx, qy, qz, cxyz[3 * j], cxyz[3 * j + 1], cxyz[3 * j + 2]), order[j]);
-        }
-        const float bound = (float)r * G.h;
-        done = r >= 1 && knn_kth(L, kk) < bound * bound;
-    }
-    if (!done) {
-        knn_init(L);
-        for (int j = 0; j < n; ++j) knn_insert(L, sqdist_nofma(qx, qy, qz, cxyz[3 * j], cxyz[3 * j + 1], cxyz[3 * j + 2]), order[j]);
-    }
-}
-
+#define KNN_RMAX 6     // rings of cells searched before the exhaustive fallback
 // ---- wave-per-query search: the 64 lanes of a wave hold the best candidates as ONE sorted list (lane i = i-th smallest
 //      64-bit key (float distance bits << 32 | index): unsigned order == the lexicographic (distance, index) order of KnnList),
 //      candidates are gathered 64 at a time with coalesced loads, and a candidate that beats the current k-th is inserted by
