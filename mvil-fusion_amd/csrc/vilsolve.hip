@@ -49,13 +49,28 @@ struct RcclApi {
 };
 RcclApi g_rccl;
 
-struct Arena {                     // one device allocation per uploaded window, mirrored by a host staging image
-    std::vector<char> h;
-    char* d = nullptr;
-    size_t cap = 0;
-    size_t take(size_t bytes) { size_t o = (h.size() + 255) & ~size_t(255); h.resize(o + bytes, 0); return o; }
-    template <class T> T* host(size_t off) { return reinterpret_cast<T*>(h.data() + off); }
-    template <class T> T* dev(size_t off) const { return reinterpret_cast<T*>(d + off); }
+// One device allocation per uploaded window: [tables | work space].  The tables (everything the caller hands over) are
+// assembled in a PINNED host image and go up in one DMA; the work space (partial records, systems, step vectors) exists on the
+// device only and is cleared by a memset -- it used to travel as zeros through a pageable staging vector.
+struct Arena {
+    char* h = nullptr; size_t hcap = 0, hsize = 0;     // pinned host image of the tables
+    char* d = nullptr; size_t cap = 0;                 // device
+    size_t ssize = 0;                                  // work-space bytes
+    bool grow(size_t need) {
+        if (need <= hcap) return true;
+        size_t ncap = hcap ? hcap : (size_t)1 << 20;
+        while (ncap < need) ncap *= 2;
+        char* nh = nullptr;
+        if (hipHostMalloc((void**)&nh, ncap, hipHostMallocDefault) != hipSuccess) return false;
+        if (hsize) memcpy(nh, h, hsize);
+        if (h) hipHostFree(h);
+        h = nh; hcap = ncap;
+        return true;
+    }
+    // returns (size_t)-1 when the pinned image cannot grow
+    size_t take(size_t bytes) { const size_t o = (hsize + 255) & ~size_t(255); if (!grow(o + bytes)) return (size_t)-1; if (o > hsize) memset(h + hsize, 0, o - hsize); hsize = o + bytes; return o; }
+    size_t take_scratch(size_t bytes) { const size_t o = (ssize + 255) & ~size_t(255); ssize = o + bytes; return o; }
+    void reset() { hsize = 0; ssize = 0; }
 };
 
 }  // namespace
@@ -82,6 +97,7 @@ struct vil_ctx {
     int device = 0, rank = 0, world = 1;
     hipStream_t stream = nullptr;
     Arena ar;
+    hipEvent_t up_ev = nullptr; bool up_pending = false;   // the DMA out of the pinned image must finish before the image is rewritten
     DevP P;                        // device pointers
     bool uploaded = false;
     int K = 0, L = 0, D = 0, NS = 0;
@@ -194,6 +210,8 @@ void vil_destroy(vil_ctx* c) {
     for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->ar.d) hipFree(c->ar.d);
+    if (c->ar.h) hipHostFree(c->ar.h);
+    if (c->up_ev) hipEventDestroy(c->up_ev);
     if (c->d_status) hipFree(c->d_status);
     if (c->h_ctl) hipHostFree(c->h_ctl);
     if (c->h_pin) hipHostFree(c->h_pin);
@@ -242,16 +260,25 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     HIPCHK(hipSetDevice(c->device));
     const int K = p->K, L = p->L, D = 15 * K + 7, NV = 6 * K + 7, NS = 16 * K + 8 + L;
     Arena& ar = c->ar;
-    ar.h.clear();
+    if (c->up_pending) { HIPCHK(hipEventSynchronize(c->up_ev)); c->up_pending = false; }
+    ar.reset();
     DevP P; memset(&P, 0, sizeof P);
     P.K = K; P.L = L; P.D = D; P.NV = NV; P.NS = NS;
     P.ex_const = p->ex_const; P.use_td = p->use_td; P.td_free = (p->use_td && !p->td_const) ? 1 : 0;
     memcpy(P.G, p->G, sizeof P.G); P.sqrt_info = p->sqrt_info_px; P.k_tr = p->tr_over_row;
     { double R[9]; quat_to_R_host(p->q_lb, R); for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) P.Rbl[3 * i + j] = R[3 * j + i]; }
       for (int i = 0; i < 3; ++i) P.tbl[i] = -(P.Rbl[3 * i] * p->t_lb[0] + P.Rbl[3 * i + 1] * p->t_lb[1] + P.Rbl[3 * i + 2] * p->t_lb[2]); }
-    struct Fix { size_t off; void** slot; };
+    struct Fix { size_t off; void** slot; bool scratch; };
     std::vector<Fix> fix;
-    auto put = [&](const void* src, size_t bytes, void** slot) { size_t o = ar.take(bytes ? bytes : 8); if (src && bytes) memcpy(ar.h.data() + o, src, bytes); fix.push_back({o, slot}); return o; };
+    bool oom = false;
+    // src != null: a table (copied into the pinned image); src == null: zero-initialised device work space
+    auto put = [&](const void* src, size_t bytes, void** slot) {
+        if (!src || !bytes) { const size_t o = ar.take_scratch(bytes ? bytes : 8); fix.push_back({o, slot, true}); return o; }
+        const size_t o = ar.take(bytes);
+        if (o == (size_t)-1) { oom = true; return (size_t)0; }
+        memcpy(ar.h + o, src, bytes); fix.push_back({o, slot, false});
+        return o;
+    };
     // constancy
     if (p->pose_const) put(p->pose_const, K, (void**)&P.pose_const);
     if (p->sb_const) put(p->sb_const, K, (void**)&P.sb_const);
@@ -388,11 +415,17 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     P.n_help = L >= 2 * VIL_STEP_THREADS ? 7 : (L >= VIL_STEP_THREADS ? 3 : 0);
     if (const char* ev = getenv("VIL_HELP")) P.n_help = std::max(0, std::min(15, atoi(ev)));
     // device allocation + single H2D copy
-    const size_t total = (ar.h.size() + 255) & ~size_t(255);
-    if (total > ar.cap) { if (ar.d) HIPCHK(hipFree(ar.d)); ar.d = nullptr; HIPCHK(hipMalloc(&ar.d, total)); ar.cap = total; }
-    for (const Fix& f : fix) *f.slot = ar.d + f.off;
+    if (oom) return VIL_ERR_DEVICE;
+    const size_t tables = (ar.hsize + 255) & ~size_t(255), total = tables + ((ar.ssize + 255) & ~size_t(255));
+    if (total > ar.cap) { if (ar.d) HIPCHK(hipFree(ar.d)); ar.d = nullptr; ar.cap = 0; HIPCHK(hipMalloc(&ar.d, total + total / 4)); ar.cap = total + total / 4; }
+    for (const Fix& f : fix) *f.slot = ar.d + (f.scratch ? tables : 0) + f.off;
     for (int q = 0; q < 2; ++q) { SysBuf& sb = P.sys[q]; sb.S = sb.ar; sb.gred = sb.S + (size_t)D * D; sb.bc = sb.gred + D; sb.diag = sb.bc + D; sb.cost = sb.diag + D; }
-    HIPCHK(hipMemcpyAsync(ar.d, ar.h.data(), ar.h.size(), hipMemcpyHostToDevice, c->stream));
+    if (ar.hsize) {
+        HIPCHK(hipMemcpyAsync(ar.d, ar.h, ar.hsize, hipMemcpyHostToDevice, c->stream));
+        if (!c->up_ev) HIPCHK(hipEventCreateWithFlags(&c->up_ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->up_ev, c->stream)); c->up_pending = true;
+    }
+    if (ar.ssize) HIPCHK(hipMemsetAsync(ar.d + tables, 0, ar.ssize, c->stream));
     c->P = P; c->K = K; c->L = L; c->D = D; c->NS = NS;
     { const int per = VIL_SWEEP_THREADS / 256; c->n_blocks_sweep = P.n_imu + P.n_vwg + (P.n_pchunk + per - 1) / per + (P.n_echunk + per - 1) / per + 2; }
     c->lds_sweep = sizeof(double) * (size_t)(P.NVT + 3 * NV + VIL_VCHUNK_F * VF_STRIDE + VIL_VCHUNK_LM * 16 + 32 + VIL_VCHUNK_F + 8 + VIL_VCHUNK_LM + 8);
