@@ -476,7 +476,8 @@ __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O
 
 // Gather of the sweep's partial records into the dense reduced system of the candidate set:
 //   S' (D x D, both triangles), gred, bc, diag, cost.   32 lower-triangle entries per workgroup, 8 threads per
-//   entry splitting the sum over the visual partials; fixed summation order => bitwise reproducible.
+//   entry splitting the sum over the visual partials; fixed summation order across workgroups (the partials themselves are
+//   accumulated with LDS atomics inside a visual workgroup, so two runs agree to rounding, not bit for bit).
 //   The last workgroup handles the vectors and the cost.
 #define RED_EPW 32
 __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
