@@ -199,7 +199,7 @@ struct vmap_ctx {
     // scan staging: corner points then surf points
     float* d_scan = nullptr; size_t scan_cap = 0; char* d_work = nullptr; size_t work_cap = 0;
     const float* up_corner = nullptr; const float* up_surf = nullptr; int up_nc = -1, up_ns = -1; bool scan_valid = false;
-    std::vector<double> h_slot;
+    double* h_slot = nullptr; size_t h_slot_cap = 0;       // pinned: the slot read-back is a plain DMA
     bool profiling = false; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; long long prof_n[2] = {0, 0}; double prof_ms[2] = {0.0, 0.0};
 };
 
@@ -229,8 +229,12 @@ int associate_uploaded(vmap_ctx* c, int n_corner, int n_surf, const double* q, c
     if (c->profiling) { hipEventRecord(c->ev[1], c->stream); hipEventRecord(c->ev[2], c->stream); }
     hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_slot);
     if (c->profiling) hipEventRecord(c->ev[3], c->stream);
-    c->h_slot.resize(10 * (size_t)nq);
-    VMCHK(hipMemcpyAsync(c->h_slot.data(), d_slot, 80 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+    if (10 * (size_t)nq > c->h_slot_cap) {
+        if (c->h_slot) hipHostFree(c->h_slot);
+        c->h_slot = nullptr; c->h_slot_cap = 0;
+        VMCHK(hipHostMalloc((void**)&c->h_slot, 8 * 20 * (size_t)nq, hipHostMallocDefault)); c->h_slot_cap = 20 * (size_t)nq;
+    }
+    VMCHK(hipMemcpyAsync(c->h_slot, d_slot, 80 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
     VMCHK(hipStreamSynchronize(c->stream));
     if (c->profiling) for (int k = 0; k < 2; ++k) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]) == hipSuccess) { c->prof_ms[k] += ms; c->prof_n[k]++; } }
     for (int i = 0; i < n_corner; ++i) if (c->h_slot[10 * (size_t)i] != 0.0) { memcpy(edge9 + 9 * (size_t)(*n_edge), &c->h_slot[10 * (size_t)i + 1], 72); ++*n_edge; }
@@ -256,7 +260,7 @@ int vmap_create(int32_t device, vmap_ctx** out) {
 void vmap_destroy(vmap_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    hipFree(c->d_cmap); hipFree(c->d_smap); hipFree(c->gc.ws); hipFree(c->gs.ws); hipFree(c->d_scan); hipFree(c->d_work);
+    hipFree(c->d_cmap); hipFree(c->d_smap); hipFree(c->gc.ws); hipFree(c->gs.ws); hipFree(c->d_scan); hipFree(c->d_work); if (c->h_slot) hipHostFree(c->h_slot);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;

@@ -1,0 +1,70 @@
+"""examples/estimator_patch.cpp -- the patch of INTEGRATION.md as a compilable program: it must build against include/ and
+link against libvilsolve.so on any machine, and on a GPU its optimization() must reproduce the harness' own solve + gauge
+fix + marginalisation of the same window."""
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from mvil_fusion_amd import abi, lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(d):
+    exe = os.path.join(d, "estimator_patch")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "estimator_patch.cpp"),
+                           lib.LIB_PATH, "-Wl,-rpath," + os.path.dirname(lib.LIB_PATH), "-o", exe])
+    return exe
+
+
+def _dump(w, path):
+    w._fix()
+    def arr(f, a, dt):
+        a = np.ascontiguousarray(a, dt).ravel()
+        f.write(struct.pack("<q", a.size)); f.write(a.tobytes())
+    with open(path, "wb") as f:
+        arr(f, [w.K, w.L, int(w.use_td), int(w.ex_const), int(w.td_const), w.prior.n], np.int32)
+        arr(f, [w.sqrt_info_px, w.tr_over_row, *w.G, *w.q_lb, *w.t_lb], np.float64)
+        for a in (w.pose, w.speedbias, w.ex_pose, w.td, w.inv_depth):
+            arr(f, a, np.float64)
+        for a in (w.pose_const, w.sb_const, w.lm_const):
+            arr(f, a, np.uint8)
+        arr(f, w.imu_i, np.int32); arr(f, w.imu_j, np.int32); arr(f, w.imu_const, np.float64)
+        arr(f, w.vis_i, np.int32); arr(f, w.vis_j, np.int32); arr(f, w.vis_l, np.int32); arr(f, w.vis_const, np.float64)
+        arr(f, w.icp_ids, np.int32); arr(f, w.icp_const, np.float64); arr(f, w.lps_ids, np.int32); arr(f, w.lps_const, np.float64)
+        arr(f, w.edge_pose, np.int32); arr(f, w.edge_const, np.float64); arr(f, w.plane_pose, np.int32); arr(f, w.plane_const, np.float64)
+        pr = w.prior
+        arr(f, pr.blk_kind, np.int32); arr(f, pr.blk_index, np.int32); arr(f, pr.blk_col, np.int32); arr(f, pr.x0, np.float64); arr(f, pr.J0, np.float64); arr(f, pr.r0, np.float64)
+
+
+def test_example_builds_and_refuses_without_gpu():
+    lib.load_vilsolve()
+    with tempfile.TemporaryDirectory() as d:
+        exe = _build(d)
+        import torch
+        if torch.cuda.is_available():
+            return
+        p = os.path.join(d, "w.bin"); _dump(synth.make_config(1), p)
+        r = subprocess.run([exe, p], capture_output=True, text=True)
+        assert r.returncode == 3 and "vil_create" in r.stderr             # no device: loud failure, no CPU path
+
+
+@pytest.mark.gpu
+def test_example_reproduces_harness(hip, oracle):
+    pf = lambda pre: oracle.marginalize(pre).to_prior()
+    for cid, kw in ((2, dict(L=150, n_plane=3000, n_edge=800)), (1, {})):
+        w = synth.make_config(cid, prior_fn=pf, **kw)
+        with tempfile.TemporaryDirectory() as d:
+            p = os.path.join(d, "w.bin"); _dump(w, p)
+            out = subprocess.check_output([_build(d), p], text=True)
+        tok = [l for l in out.splitlines() if l.startswith("RESULT")][0].split()
+        p0 = w.pose[0].copy()
+        s = hip.solve(w); hip.gauge_fix(p0, w); m = hip.marginalize(w, abi.MARGIN_OLD)
+        assert (int(tok[1]), int(tok[2])) == (s.iterations, s.termination)
+        assert abs(float(tok[3]) - s.initial_cost) <= 1e-12 * s.initial_cost and abs(float(tok[4]) - s.final_cost) <= 1e-10 * s.final_cost
+        assert int(tok[5]) == m.c.n
+        assert np.abs(np.array([float(v) for v in tok[6:13]]) - w.pose[-1]).max() < 1e-9
