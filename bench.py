@@ -519,6 +519,14 @@ def main():
                                "reduce_plus_step_avg_us": 1e3 * prof.step_ms / max(1, prof.step_launches), "reduce_avg_us": 1e3 * prof.reduce_ms / max(1, prof.step_launches),
                                "measured_on": "second pass of the same %d steps with HIP events enabled (%.1f ms/step instrumented vs %.1f ms/step in the value region)" % (args.steps, 1e3 * el_events / args.steps, 1e3 * max_el / args.steps),
                                "variant": "fused sweep (no Jacobian materialisation): read-only bytes, SURVEY 8(d)"}
+            # the kernel that dominates the iteration's TIME is the single-workgroup trust-region step; it is neither HBM- nor
+            # MFMA-bound (one CU, dependent chains), so it is reported next to the sweep rather than as the roofline object
+            D = 15 * w.K + 7
+            step_us = 1e3 * (prof.step_ms - prof.reduce_ms) / max(1, prof.step_launches)
+            chol_flop = D ** 3 / 3.0 + 2.0 * D * D                   # factorisation + the two triangular solves
+            out["roofline"]["critical_path_kernel"] = {"kernel": "k_step", "avg_launch_us": step_us, "bound": "latency (one workgroup: 157-pivot Cholesky chain, dependent L2 round trips)",
+                                                       "dense_flop_per_launch": chol_flop, "achieved_gflops": chol_flop / (step_us * 1e-6) / 1e9, "peak_tflops_fp64_matrix": 78.6,
+                                                       "frac": chol_flop / (step_us * 1e-6) / 78.6e12, "see": "profiles/r01_summary.txt (MFMA pipes 5 % busy on that CU), DESIGN.md section 4"}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(w, opts)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
