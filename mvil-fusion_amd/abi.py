@@ -118,6 +118,8 @@ def default_options(**kw):
     o.rel_loss, o.rel_loss_scale = LOSS_CAUCHY, 1.0
     o.autodiff_quirk, o.precision = 1, 0
     for k, v in kw.items():
+        if k not in dict(VilOptions._fields_):
+            raise AttributeError("vil_options has no field %r" % k)
         setattr(o, k, v)
     return o
 

@@ -58,6 +58,8 @@ class Vgicp:
         f = getattr(self.lib, self.prefix + "default_options"); f.restype = None
         f(C.byref(o))
         for k, v in kw.items():
+            if k not in dict(VgicpOptions._fields_):
+                raise AttributeError("vgicp_options has no field %r" % k)
             setattr(o, k, v)
         return o
 

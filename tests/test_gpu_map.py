@@ -60,3 +60,43 @@ def test_gpu_reproduces_golden_fixture(hip):
     g = mapreg.MapReg(lib.load_vilsolve(), "vmap_")
     _check_golden(g, hip.ctx)
     g.close()
+
+
+def test_duplicate_map_points_and_ties(oracle):
+    """Exact distance ties (duplicated map points, a scan point coinciding with map points): the (distance, index) order of the
+    wave search is the oracle's, so the same neighbours -- and the same factors -- come out."""
+    cm, sm = mapreg.make_map(seed=8, n_surf=5000, n_corner=900)
+    cm2 = np.concatenate([cm, cm[:400], cm[:150]]); sm2 = np.concatenate([sm, sm[:2500]])              # up to three copies of a point
+    R, t = _rot(0.0, 0.0, 0.2), np.array([0.5, 0.5, 0.1])
+    sc, ss = mapreg.make_scan(cm, sm, R, t, seed=9, n_surf=900, n_corner=200)
+    # a few scan points that land exactly on map points (zero distance to all copies)
+    ss[:20, :3] = ((sm[:20, :3].astype(np.float64) - t) @ R).astype(np.float32); sc[:10, :3] = ((cm[:10, :3].astype(np.float64) - t) @ R).astype(np.float32)
+    g = mapreg.MapReg(lib.load_vilsolve(), "vmap_"); o = mapreg.MapReg(oracle.lib, "orc_vmap_")
+    q = mapreg.quat_from_R(R)
+    for r in (g, o):
+        r.set_map(cm2, sm2)
+    eg, pg = g.associate(sc, ss, q, t); eo, po = o.associate(sc, ss, q, t)
+    g.close(); o.close()
+    assert eg.shape == eo.shape and pg.shape == po.shape and len(pg) > 300
+    assert np.array_equal(eg[:, :3], eo[:, :3]) and np.array_equal(pg[:, :3], po[:, :3])
+    assert np.abs(pg[:, 3:] - po[:, 3:]).max() < 1e-8
+
+
+def test_sparse_map_far_queries_and_fallback(oracle):
+    """A map so sparse that most queries need several rings or the exhaustive fallback, and a cell size the adaptive build
+    shrinks: still the oracle's factors."""
+    rng = np.random.default_rng(3)
+    sm = np.concatenate([rng.uniform(-40, 40, (600, 2)), np.zeros((600, 1)) + rng.normal(0, 0.01, (600, 1)), rng.uniform(0, 50, (600, 1))], axis=1).astype(np.float32)   # a ground plane, ~0.1 pt / m^2
+    cm = np.concatenate([np.linspace(-30, 30, 400)[:, None], np.zeros((400, 1)), np.ones((400, 1)), np.zeros((400, 1))], axis=1).astype(np.float32)                     # one long edge
+    ss = np.concatenate([rng.uniform(-35, 35, (300, 2)), rng.normal(0, 0.02, (300, 1)), rng.uniform(0, 50, (300, 1))], axis=1).astype(np.float32)
+    sc = np.concatenate([rng.uniform(-25, 25, (80, 1)), rng.normal(0, 0.02, (80, 1)), 1 + rng.normal(0, 0.02, (80, 1)), np.zeros((80, 1))], axis=1).astype(np.float32)
+    q, t = np.array([0, 0, 0, 1.0]), np.zeros(3)
+    g = mapreg.MapReg(lib.load_vilsolve(), "vmap_"); o = mapreg.MapReg(oracle.lib, "orc_vmap_")
+    for r in (g, o):
+        r.set_map(cm, sm)
+    eg, pg = g.associate(sc, ss, q, t); eo, po = o.associate(sc, ss, q, t)
+    g.close(); o.close()
+    assert eg.shape == eo.shape and pg.shape == po.shape and len(eg) > 40
+    assert np.array_equal(eg[:, :3], eo[:, :3]) and np.array_equal(pg[:, :3], po[:, :3])
+    if len(pg):
+        assert np.abs(pg[:, 3:] - po[:, 3:]).max() < 1e-8

@@ -44,3 +44,15 @@ def test_records_drive_the_imu_factor(hip, oracle):
     wa.imu_const[:n] = rg[:n]; wb.imu_const[:n] = ro[:n]
     ra, Ja = hip.eval_factors(wa, abi.FACTOR_IMU); rb, Jb = oracle.eval_factors(wb, abi.FACTOR_IMU)
     assert np.abs(ra - rb).max() <= 1e-6 * max(1.0, np.abs(rb).max()) and np.abs(Ja - Jb).max() <= 1e-6 * max(1.0, np.abs(Jb).max())
+
+
+def test_long_intervals_and_degenerate_samples(oracle):
+    """Intervals far longer than one batch (several hundred samples), zero-length time steps, large biases."""
+    s = list(preint.make_stream(n_intervals=3, samples=(150, 400), seed=11))
+    s[1] = s[1].copy(); s[1][::17] = 0.0                                  # dt = 0 samples
+    s[6] = s[6] * 20.0; s[7] = s[7] * 20.0                                # biases of 1 m/s^2 and 0.1 rad/s
+    g = preint.Preint(lib.load_vilsolve(), "vpre_"); o = preint.Preint(oracle.lib, "orc_vpre_")
+    rg, jg = g.integrate(*s); ro, jo = o.integrate(*s)
+    g.close(); o.close()
+    assert np.abs(rg[:, :17] - ro[:, :17]).max() <= 1e-11 * max(1.0, np.abs(ro[:, :17]).max())
+    assert np.abs(jg - jo).max() <= 1e-10 * np.abs(jo).max() and np.abs(rg[:, 62:] - ro[:, 62:]).max() <= 1e-10 * np.abs(ro[:, 62:]).max()

@@ -105,3 +105,19 @@ def test_reference_known_answer(oracle):
     Tg, To = _kat(g), _kat(o)
     g.close(); o.close()
     assert np.abs(Tg[0] - To[0]).max() < 1e-8 and np.abs(Tg[1] - To[1]).max() < 1e-8
+
+
+def test_known_answer_data_all_neighbour_modes(oracle):
+    """On the real scans of the reference's own test: GPU and oracle agree for DIRECT7 / DIRECT27 too (linearisation and
+    alignment), with the covariances estimated on the device."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vgicp", "fast_gicp_kat.npz"))
+    g = vgicp.Vgicp(lib.load_vilsolve(), "vgicp_"); o = vgicp.Vgicp(oracle.lib, "orc_vgicp_")
+    for r in (g, o):
+        r.set_target(d["target"], None, 1.0); r.set_source(d["source"], None)
+    for mode in (vgicp.DIRECT1, vgicp.DIRECT7, vgicp.DIRECT27):
+        eg, Hg, bg, ng = g.linearize(np.eye(4), mode); eo, Ho, bo, no = o.linearize(np.eye(4), mode)
+        assert ng == no and abs(eg - eo) <= 1e-10 * eo and np.abs(Hg - Ho).max() <= 1e-10 * np.abs(Ho).max() and np.abs(bg - bo).max() <= 1e-9 * np.abs(bo).max()
+    Tg, sg = g.align(np.eye(4), g.default_options(neighbor_mode=vgicp.DIRECT7)); To, so = o.align(np.eye(4), o.default_options(neighbor_mode=vgicp.DIRECT7))
+    g.close(); o.close()
+    assert sg.iterations == so.iterations and np.abs(Tg - To).max() < 1e-8
