@@ -11,17 +11,20 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "../../include/vilmap.h"
+#include "vil_internal.h"
 #include "vil_knn.hpp"
 
 #define VM_OK 0
 #define VM_ERR_INVALID -1
 #define VM_ERR_DEVICE -2
 #define VM_THREADS 256
-#define VMCHK(x) do { if ((x) != hipSuccess) return VM_ERR_DEVICE; } while (0)
+#define VMCHK(x) do { const hipError_t e_ = (x); if (e_ != hipSuccess) { if (getenv("VIL_DEBUG")) fprintf(stderr, "vilmap.hip:%d: %s\n", __LINE__, hipGetErrorString(e_)); return VM_ERR_DEVICE; } } while (0)
 
 namespace {
 using namespace vknn;
@@ -180,6 +183,35 @@ __global__ __launch_bounds__(VM_THREADS) void k_map_fit(int nqc, int nqs, const 
     o[4] = nx; o[5] = ny; o[6] = nz; o[7] = d;
 }
 
+// ---- ordered compaction of the accepted slots into the solver's structure-of-arrays factor tables (vil_internal.h): one
+//      workgroup; thread t owns a contiguous range of scan points, counts its accepted corner / surf slots, a block-wide
+//      exclusive scan turns the counts into output positions, and the range is copied in scan order (the order in which the
+//      reference adds the residual blocks).  cnt[0] = edges, cnt[1] = planes.
+#define VM_CT 1024
+__global__ __launch_bounds__(VM_CT) void k_map_compact(int nqc, int nqs, const double* __restrict__ slot, double* __restrict__ edge_soa, int es, double* __restrict__ plane_soa, int ps, int* __restrict__ cnt) {
+    __shared__ int se[VM_CT], sp[VM_CT];
+    const int t = threadIdx.x, nq = nqc + nqs, per = (nq + VM_CT - 1) / VM_CT;
+    const int b = min(nq, t * per), e = min(nq, b + per);
+    int ne = 0, np = 0;
+    for (int i = b; i < e; ++i) if (slot[(size_t)10 * i] != 0.0) { if (i < nqc) ++ne; else ++np; }
+    se[t] = ne; sp[t] = np;
+    __syncthreads();
+    for (int o = 1; o < VM_CT; o <<= 1) {
+        const int ve = t >= o ? se[t - o] : 0, vp = t >= o ? sp[t - o] : 0;
+        __syncthreads();
+        se[t] += ve; sp[t] += vp;
+        __syncthreads();
+    }
+    int oe = se[t] - ne, op = sp[t] - np;
+    for (int i = b; i < e; ++i) {
+        const double* o = slot + (size_t)10 * i;
+        if (o[0] == 0.0) continue;
+        if (i < nqc) { for (int q = 0; q < 9; ++q) edge_soa[(size_t)q * es + oe] = o[1 + q]; ++oe; }
+        else { for (int q = 0; q < 7; ++q) plane_soa[(size_t)q * ps + op] = o[1 + q]; ++op; }
+    }
+    if (t == VM_CT - 1) { cnt[0] = se[t]; cnt[1] = sp[t]; }
+}
+
 void quat_to_R(const double* q, double* R) {
     const double x = q[0], y = q[1], z = q[2], w = q[3];
     R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
@@ -200,6 +232,7 @@ struct vmap_ctx {
     float* d_scan = nullptr; size_t scan_cap = 0; char* d_work = nullptr; size_t work_cap = 0;
     const float* up_corner = nullptr; const float* up_surf = nullptr; int up_nc = -1, up_ns = -1; bool scan_valid = false;
     double* h_slot = nullptr; size_t h_slot_cap = 0;       // pinned: the slot read-back is a plain DMA
+    double* d_soa = nullptr; size_t soa_cap = 0; int* d_cnt = nullptr; int* h_cnt = nullptr;   // device-resident factor tables of vmap_align
     bool profiling = false; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; long long prof_n[2] = {0, 0}; double prof_ms[2] = {0.0, 0.0};
 };
 
@@ -242,6 +275,28 @@ int associate_uploaded(vmap_ctx* c, int n_corner, int n_surf, const double* q, c
     VMCHK(hipGetLastError());
     return VM_OK;
 }
+// association of the uploaded scan with the factor tables left ON THE DEVICE in the solver's layout; only the two counts come back
+int associate_device(vmap_ctx* c, int n_corner, int n_surf, const double* q, const double* t, int32_t* n_edge, int32_t* n_plane, vil_device_lidar* dl) {
+    PoseD T; quat_to_R(q, T.R); T.t[0] = t[0]; T.t[1] = t[1]; T.t[2] = t[2];
+    *n_edge = 0; *n_plane = 0;
+    const int nq = n_corner + n_surf;
+    const int es = (std::max(n_corner, 1) + 31) & ~31, ps = (std::max(n_surf, 1) + 31) & ~31;
+    const size_t need = 8 * ((size_t)9 * es + (size_t)7 * ps);
+    if (need > c->soa_cap) { hipFree(c->d_soa); c->d_soa = nullptr; c->soa_cap = 0; VMCHK(hipMalloc(&c->d_soa, 2 * need)); c->soa_cap = 2 * need; }
+    if (!c->d_cnt) { VMCHK(hipMalloc(&c->d_cnt, 16)); VMCHK(hipHostMalloc((void**)&c->h_cnt, 16, hipHostMallocDefault)); }
+    dl->edge_soa = c->d_soa; dl->edge_stride = es; dl->plane_soa = c->d_soa + (size_t)9 * es; dl->plane_stride = ps;
+    if (nq == 0) return VM_OK;
+    double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq);
+    hipLaunchKernelGGL(k_map_search, dim3((nq + VM_QPB - 1) / VM_QPB), dim3(64 * VM_QPB), 0, c->stream, n_corner, n_surf, c->d_scan, T, c->nc, c->gc.G, c->gc.order, c->gc.cxyz,
+                       c->ns, c->gs.G, c->gs.order, c->gs.cxyz, d_nn, d_nd5);
+    hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_slot);
+    hipLaunchKernelGGL(k_map_compact, dim3(1), dim3(VM_CT), 0, c->stream, n_corner, n_surf, d_slot, c->d_soa, es, c->d_soa + (size_t)9 * es, ps, c->d_cnt);
+    VMCHK(hipMemcpyAsync(c->h_cnt, c->d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    VMCHK(hipStreamSynchronize(c->stream));
+    VMCHK(hipGetLastError());
+    *n_edge = c->h_cnt[0]; *n_plane = c->h_cnt[1];
+    return VM_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -260,7 +315,7 @@ int vmap_create(int32_t device, vmap_ctx** out) {
 void vmap_destroy(vmap_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    hipFree(c->d_cmap); hipFree(c->d_smap); hipFree(c->gc.ws); hipFree(c->gs.ws); hipFree(c->d_scan); hipFree(c->d_work); if (c->h_slot) hipHostFree(c->h_slot);
+    hipFree(c->d_cmap); hipFree(c->d_smap); hipFree(c->gc.ws); hipFree(c->gs.ws); hipFree(c->d_scan); hipFree(c->d_work); if (c->h_slot) hipHostFree(c->h_slot); hipFree(c->d_soa); hipFree(c->d_cnt); if (c->h_cnt) hipHostFree(c->h_cnt);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -308,8 +363,6 @@ int vmap_align(vmap_ctx* c, vil_ctx* solver, int32_t n_corner, const float* corn
     if (!c || !solver || !q || !t || !opts || !out) return VM_ERR_INVALID;
     memset(out, 0, sizeof *out);
     if (!(c->nc > 10 && c->ns > 50)) return VM_OK;                      // localMapping.cpp:586 "corner and surf num are not enough"
-    std::vector<double> edge(9 * (size_t)std::max(1, n_corner)), plane(7 * (size_t)std::max(1, n_surf));
-    std::vector<int32_t> epose, ppose;
     if (n_corner < 0 || n_surf < 0 || (n_corner && !corner) || (n_surf && !surf)) return VM_ERR_INVALID;
     VMCHK(hipSetDevice(c->device));
     int st = upload_scan(c, n_corner, corner, n_surf, surf);             // the scan is uploaded once for both rounds
@@ -317,22 +370,21 @@ int vmap_align(vmap_ctx* c, vil_ctx* solver, int32_t n_corner, const float* corn
     for (int round = 0; round < 2; ++round) {
         int32_t ne = 0, np = 0;
         const auto ta = std::chrono::steady_clock::now();
-        st = associate_uploaded(c, n_corner, n_surf, q, t, &ne, edge.data(), &np, plane.data());
+        vil_device_lidar dl;
+        st = associate_device(c, n_corner, n_surf, q, t, &ne, &np, &dl);   // the factor tables stay on the device, in the solver's layout
         if (st != VM_OK) return st;
         out->t_associate_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count();
-        epose.assign((size_t)std::max(1, ne), 0); ppose.assign((size_t)std::max(1, np), 0);
         // one-pose window: pose free, everything else constant, identity LiDAR extrinsic, only the point factors
         vil_problem p; memset(&p, 0, sizeof p);
         uint8_t pose_const = 0, sb_const = 1;
         p.K = 1; p.L = 0; p.pose_const = &pose_const; p.sb_const = &sb_const; p.ex_const = 1; p.td_const = 1; p.use_td = 0;
-        p.n_edge = ne; p.edge_pose = epose.data(); p.edge_const = edge.data();
-        p.n_plane = np; p.plane_pose = ppose.data(); p.plane_const = plane.data();
+        p.n_edge = ne; p.n_plane = np;
         p.q_lb[3] = 1.0; p.sqrt_info_px = 230.0; p.G[2] = 9.8;
         double pose[7] = {t[0], t[1], t[2], q[0], q[1], q[2], q[3]}, sb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ex[7] = {0, 0, 0, 0, 0, 0, 1}, td = 0.0, lam = 0.0;
         vil_state s; memset(&s, 0, sizeof s);
         s.K = 1; s.L = 0; s.pose = pose; s.speedbias = sb; s.ex_pose = ex; s.td = &td; s.inv_depth = &lam;
         vil_summary sum;
-        st = vil_solve(solver, &p, &s, opts, &sum);
+        st = vil_solve_device_lidar(solver, &p, &dl, c->stream, &s, opts, &sum);
         if (st != VIL_OK) return st;
         t[0] = pose[0]; t[1] = pose[1]; t[2] = pose[2]; q[0] = pose[3]; q[1] = pose[4]; q[2] = pose[5]; q[3] = pose[6];
         out->t_prepare_ms += sum.t_prepare_ms; out->t_solve_ms += sum.t_solve_ms + sum.t_readback_ms;

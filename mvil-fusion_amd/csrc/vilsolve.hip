@@ -18,6 +18,7 @@
                          // carries an RCCL (PyTorch bundles one) never ends up with two copies
 
 #include "../../include/vilsolve.h"
+#include "vil_internal.h"
 #include "vil_dev.hpp"
 #include "vil_sweep.hpp"
 #include "vil_eval.hpp"
@@ -97,6 +98,7 @@ struct vil_ctx {
     int device = 0, rank = 0, world = 1;
     hipStream_t stream = nullptr;
     Arena ar;
+    hipEvent_t dep_ev = nullptr;                           // orders the solve after a producer stream (vil_solve_device_lidar)
     hipEvent_t up_ev = nullptr; bool up_pending = false;   // the DMA out of the pinned image must finish before the image is rewritten
     DevP P;                        // device pointers
     bool uploaded = false;
@@ -212,6 +214,7 @@ void vil_destroy(vil_ctx* c) {
     if (c->ar.d) hipFree(c->ar.d);
     if (c->ar.h) hipHostFree(c->ar.h);
     if (c->up_ev) hipEventDestroy(c->up_ev);
+    if (c->dep_ev) hipEventDestroy(c->dep_ev);
     if (c->d_status) hipFree(c->d_status);
     if (c->h_ctl) hipHostFree(c->h_ctl);
     if (c->h_pin) hipHostFree(c->h_pin);
@@ -221,7 +224,7 @@ void vil_destroy(vil_ctx* c) {
     delete c;
 }
 
-static int validate(const vil_problem* p, const vil_state* s) {
+static int validate(const vil_problem* p, const vil_state* s, bool device_lidar = false) {
     if (!p || !s) return VIL_ERR_INVALID_ARGUMENT;
     if (p->K < 1 || p->L < 0 || s->K != p->K || s->L != p->L) return VIL_ERR_INVALID_ARGUMENT;
     if (15 * p->K + 7 > 320) return VIL_ERR_UNSUPPORTED;   // K <= 20 (step kernel work space)
@@ -232,8 +235,11 @@ static int validate(const vil_problem* p, const vil_state* s) {
         if (f && p->vis_l[f] < p->vis_l[f - 1]) return VIL_ERR_INVALID_ARGUMENT;
         if (f && p->vis_l[f] == p->vis_l[f - 1] && p->vis_i[f] != p->vis_i[f - 1]) return VIL_ERR_INVALID_ARGUMENT;
     }
-    for (int f = 0; f < p->n_plane; ++f) if (p->plane_pose[f] < 0 || p->plane_pose[f] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
-    for (int f = 0; f < p->n_edge; ++f) if (p->edge_pose[f] < 0 || p->edge_pose[f] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
+    if (p->n_plane < 0 || p->n_edge < 0) return VIL_ERR_INVALID_ARGUMENT;
+    if (!device_lidar) {
+        for (int f = 0; f < p->n_plane; ++f) if (p->plane_pose[f] < 0 || p->plane_pose[f] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
+        for (int f = 0; f < p->n_edge; ++f) if (p->edge_pose[f] < 0 || p->edge_pose[f] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
+    }
     for (int f = 0; f < p->n_imu; ++f) if (p->imu_i[f] < 0 || p->imu_i[f] >= p->K || p->imu_j[f] < 0 || p->imu_j[f] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
     return VIL_OK;
 }
@@ -253,9 +259,9 @@ static void pack_lidar(int n, int ncomp, const int* pose, const double* c, int K
     for (int k = 0; k < K; ++k) for (int s = cnt[k]; s < cnt[k + 1]; s += VIL_THREADS) { chunks.push_back(s); chunks.push_back(std::min(VIL_THREADS, cnt[k + 1] - s)); chunks.push_back(k); }
 }
 
-static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, bool sharded) {
+static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, bool sharded, const vil_device_lidar* dl = nullptr) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
-    int st = validate(p, s);
+    int st = validate(p, s, dl != nullptr);
     if (st != VIL_OK) return st;
     HIPCHK(hipSetDevice(c->device));
     const int K = p->K, L = p->L, D = 15 * K + 7, NV = 6 * K + 7, NS = 16 * K + 8 + L;
@@ -338,10 +344,14 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             for (int k = 0; k < K; ++k) cnt[k + 1] += cnt[k];
             for (int k = 0; k <= K; ++k) lcp[base + k] = cnt[k];
         };
-        pack_lidar(p->n_plane, 7, p->plane_pose, p->plane_const, K, c->plane_perm, soa, P.pl_stride, ch);
+        // device-resident tables (vil_internal.h): every factor sits on pose 0 in the caller's order -- only the chunk list is built here
+        auto chunks_pose0 = [&](int n) { ch.clear(); for (int s0 = 0; s0 < n; s0 += VIL_THREADS) { ch.push_back(s0); ch.push_back(std::min(VIL_THREADS, n - s0)); ch.push_back(0); } };
+        if (dl) { chunks_pose0(p->n_plane); c->plane_perm.clear(); soa.clear(); }
+        else pack_lidar(p->n_plane, 7, p->plane_pose, p->plane_const, K, c->plane_perm, soa, P.pl_stride, ch);
         P.n_plane = p->n_plane; P.n_pchunk = (int)ch.size() / 3; ranges(ch, 0);
         put(soa.data(), soa.size() * 8, (void**)&P.pl_c); put(ch.data(), 4 * ch.size(), (void**)&P.pchunk);
-        pack_lidar(p->n_edge, 9, p->edge_pose, p->edge_const, K, c->edge_perm, soa, P.ed_stride, ch);
+        if (dl) { chunks_pose0(p->n_edge); c->edge_perm.clear(); soa.clear(); }
+        else pack_lidar(p->n_edge, 9, p->edge_pose, p->edge_const, K, c->edge_perm, soa, P.ed_stride, ch);
         P.n_edge = p->n_edge; P.n_echunk = (int)ch.size() / 3; ranges(ch, K + 1);
         put(soa.data(), soa.size() * 8, (void**)&P.ed_c); put(ch.data(), 4 * ch.size(), (void**)&P.echunk);
         put(nullptr, 8 * (size_t)28 * std::max(P.n_pchunk + P.n_echunk, 1), (void**)&P.lpart);
@@ -419,6 +429,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     const size_t tables = (ar.hsize + 255) & ~size_t(255), total = tables + ((ar.ssize + 255) & ~size_t(255));
     if (total > ar.cap) { if (ar.d) HIPCHK(hipFree(ar.d)); ar.d = nullptr; ar.cap = 0; HIPCHK(hipMalloc(&ar.d, total + total / 4)); ar.cap = total + total / 4; }
     for (const Fix& f : fix) *f.slot = ar.d + (f.scratch ? tables : 0) + f.off;
+    if (dl) { P.pl_c = dl->plane_soa; P.pl_stride = dl->plane_stride; P.ed_c = dl->edge_soa; P.ed_stride = dl->edge_stride; }
     for (int q = 0; q < 2; ++q) { SysBuf& sb = P.sys[q]; sb.S = sb.ar; sb.gred = sb.S + (size_t)D * D; sb.bc = sb.gred + D; sb.diag = sb.bc + D; sb.cost = sb.diag + D; }
     if (ar.hsize) {
         HIPCHK(hipMemcpyAsync(ar.d, ar.h, ar.hsize, hipMemcpyHostToDevice, c->stream));
@@ -678,6 +689,29 @@ int vil_solve(vil_ctx* c, const vil_problem* p, vil_state* s, const vil_options*
     st = vil_solve_resident(c, o, sum);
     sum->t_prepare_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     if (st != VIL_OK) return st;                       // state left unchanged on any error
+    const auto t2 = std::chrono::steady_clock::now();
+    st = vil_download_state(c, s);
+    sum->t_readback_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
+    return st;
+}
+
+int vil_solve_device_lidar(vil_ctx* c, const vil_problem* p, const vil_device_lidar* dl, void* producer_stream, vil_state* s, const vil_options* o, vil_summary* sum) {
+    if (!c || !p || !dl || !s || !o || !sum) return VIL_ERR_INVALID_ARGUMENT;
+    if ((p->n_plane > 0 && (!dl->plane_soa || dl->plane_stride < p->n_plane)) || (p->n_edge > 0 && (!dl->edge_soa || dl->edge_stride < p->n_edge))) return VIL_ERR_INVALID_ARGUMENT;
+    if (c->world > 1 && (c->comm || c->lcomm)) return VIL_ERR_UNSUPPORTED;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(hipSetDevice(c->device));
+    if (producer_stream && (hipStream_t)producer_stream != c->stream) {      // the tables are written by work on another stream: order after it on the device
+        if (!c->dep_ev) HIPCHK(hipEventCreateWithFlags(&c->dep_ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->dep_ev, (hipStream_t)producer_stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->dep_ev, 0));
+    }
+    int st = upload_impl(c, p, s, false, dl);
+    if (st != VIL_OK) return st;
+    const auto t1 = std::chrono::steady_clock::now();
+    st = vil_solve_resident(c, o, sum);
+    sum->t_prepare_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (st != VIL_OK) return st;
     const auto t2 = std::chrono::steady_clock::now();
     st = vil_download_state(c, s);
     sum->t_readback_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();

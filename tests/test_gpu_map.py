@@ -100,3 +100,18 @@ def test_sparse_map_far_queries_and_fallback(oracle):
     assert np.array_equal(eg[:, :3], eo[:, :3]) and np.array_equal(pg[:, :3], po[:, :3])
     if len(pg):
         assert np.abs(pg[:, 3:] - po[:, 3:]).max() < 1e-8
+
+
+def test_interleaved_calls_and_map_updates(hip, setup):
+    """align / associate / set_map interleaved on one context (buffers grow and are reused): the registration is unchanged."""
+    g, o, sc, ss, R, t = setup
+    q0 = mapreg.quat_from_R(R @ _rot(0.004, -0.003, 0.008)); t0 = t + np.array([0.05, -0.04, 0.03])
+    q1, t1, s1 = g.align(hip.ctx, sc, ss, q0, t0)
+    e, p = g.associate(sc, ss, q0, t0)                         # host-side tables (first use allocates the pinned read-back)
+    q2, t2, s2 = g.align(hip.ctx, sc, ss, q0, t0)
+    e2, p2 = g.associate(np.concatenate([sc, sc]), np.concatenate([ss, ss]), q0, t0)      # a larger scan: buffers regrow
+    q3, t3, s3 = g.align(hip.ctx, sc, ss, q0, t0)
+    assert len(e2) == 2 * len(e) and len(p2) == 2 * len(p)
+    for (qa, ta, sa) in ((q2, t2, s2), (q3, t3, s3)):
+        assert (sa.n_edge, sa.n_plane, sa.iterations) == (s1.n_edge, s1.n_plane, s1.iterations)        # (counts of the second round)
+        assert np.abs(ta - t1).max() < 1e-10 and np.abs(qa - q1).max() < 1e-10
