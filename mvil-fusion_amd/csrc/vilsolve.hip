@@ -244,17 +244,23 @@ static int validate(const vil_problem* p, const vil_state* s, bool device_lidar 
     return VIL_OK;
 }
 
-// pose-sort LiDAR points, transpose to SoA, build (start,count,pose) chunks of <= 256 points
-static void pack_lidar(int n, int ncomp, const int* pose, const double* c, int K, std::vector<int>& perm, std::vector<double>& soa, int& stride, std::vector<int>& chunks) {
+// pose-sort LiDAR points, transpose to SoA (straight into `dst`, ncomp x stride doubles), build (start,count,pose) chunks of <= 256 points
+static void lidar_order(int n, const int* pose, int K, std::vector<int>& perm, std::vector<int>& cnt) {
     perm.resize(n);
-    std::vector<int> cnt(K + 1, 0);
+    cnt.assign(K + 1, 0);
     for (int f = 0; f < n; ++f) cnt[pose[f] + 1]++;
     for (int k = 0; k < K; ++k) cnt[k + 1] += cnt[k];
     std::vector<int> pos(cnt.begin(), cnt.end() - 1);
     for (int f = 0; f < n; ++f) perm[pos[pose[f]]++] = f;
-    stride = (n + 31) & ~31;
-    soa.assign((size_t)ncomp * stride, 0.0);
-    for (int sidx = 0; sidx < n; ++sidx) for (int q = 0; q < ncomp; ++q) soa[(size_t)q * stride + sidx] = c[(size_t)perm[sidx] * ncomp + q];
+}
+static void lidar_soa(int n, int ncomp, const double* c, const std::vector<int>& perm, int stride, double* dst) {
+    for (int q = 0; q < ncomp; ++q) {
+        double* row = dst + (size_t)q * stride;
+        for (int sidx = 0; sidx < n; ++sidx) row[sidx] = c[(size_t)perm[sidx] * ncomp + q];
+        for (int sidx = n; sidx < stride; ++sidx) row[sidx] = 0.0;
+    }
+}
+static void lidar_chunks(const std::vector<int>& cnt, int K, std::vector<int>& chunks) {
     chunks.clear();
     for (int k = 0; k < K; ++k) for (int s = cnt[k]; s < cnt[k + 1]; s += VIL_THREADS) { chunks.push_back(s); chunks.push_back(std::min(VIL_THREADS, cnt[k + 1] - s)); chunks.push_back(k); }
 }
@@ -285,6 +291,13 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         memcpy(ar.h + o, src, bytes); fix.push_back({o, slot, false});
         return o;
     };
+    // a table that is produced in place (transpositions): space in the pinned image, to be filled before the next put()
+    auto reserve = [&](size_t bytes, void** slot) -> char* {
+        const size_t o = ar.take(bytes ? bytes : 8);
+        if (o == (size_t)-1) { oom = true; return nullptr; }
+        fix.push_back({o, slot, false});
+        return ar.h + o;
+    };
     // constancy
     if (p->pose_const) put(p->pose_const, K, (void**)&P.pose_const);
     if (p->sb_const) put(p->sb_const, K, (void**)&P.sb_const);
@@ -300,9 +313,13 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     // visual
     P.n_vis = p->n_vis; P.vis_stride = (p->n_vis + 31) & ~31;
     {
-        std::vector<double> soa((size_t)14 * std::max(P.vis_stride, 1), 0.0);
-        for (int f = 0; f < p->n_vis; ++f) for (int q = 0; q < 14; ++q) soa[(size_t)q * P.vis_stride + f] = p->vis_const[(size_t)f * 14 + q];
-        put(soa.data(), soa.size() * 8, (void**)&P.vis_c);
+        if (double* soa = (double*)reserve(8 * (size_t)14 * std::max(P.vis_stride, 1), (void**)&P.vis_c)) {
+            for (int q = 0; q < 14; ++q) {
+                double* row = soa + (size_t)q * P.vis_stride;
+                for (int f = 0; f < p->n_vis; ++f) row[f] = p->vis_const[(size_t)f * 14 + q];
+                for (int f = p->n_vis; f < P.vis_stride; ++f) row[f] = 0.0;
+            }
+        }
         put(p->vis_i, 4 * (size_t)p->n_vis, (void**)&P.vis_i); put(p->vis_j, 4 * (size_t)p->n_vis, (void**)&P.vis_j); put(p->vis_l, 4 * (size_t)p->n_vis, (void**)&P.vis_l);
         std::vector<int> lms(L + 1, 0);
         for (int f = 0; f < p->n_vis; ++f) lms[p->vis_l[f] + 1]++;
@@ -336,7 +353,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     }
     // LiDAR
     {
-        std::vector<double> soa; std::vector<int> ch;
+        std::vector<int> ch;
         std::vector<int> lcp(2 * (K + 1), 0);   // chunk ranges per pose (chunks are pose-ordered): plane [0..K], edge [K+1..2K+1]
         auto ranges = [&](const std::vector<int>& chunks, int base) {
             std::vector<int> cnt(K + 1, 0);
@@ -346,14 +363,23 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         };
         // device-resident tables (vil_internal.h): every factor sits on pose 0 in the caller's order -- only the chunk list is built here
         auto chunks_pose0 = [&](int n) { ch.clear(); for (int s0 = 0; s0 < n; s0 += VIL_THREADS) { ch.push_back(s0); ch.push_back(std::min(VIL_THREADS, n - s0)); ch.push_back(0); } };
-        if (dl) { chunks_pose0(p->n_plane); c->plane_perm.clear(); soa.clear(); }
-        else pack_lidar(p->n_plane, 7, p->plane_pose, p->plane_const, K, c->plane_perm, soa, P.pl_stride, ch);
+        std::vector<int> cnt;
+        if (dl) { chunks_pose0(p->n_plane); c->plane_perm.clear(); put(nullptr, 8, (void**)&P.pl_c); }
+        else {
+            lidar_order(p->n_plane, p->plane_pose, K, c->plane_perm, cnt); lidar_chunks(cnt, K, ch);
+            P.pl_stride = (p->n_plane + 31) & ~31;
+            if (double* dst = (double*)reserve(8 * (size_t)7 * std::max(P.pl_stride, 1), (void**)&P.pl_c)) lidar_soa(p->n_plane, 7, p->plane_const, c->plane_perm, P.pl_stride, dst);
+        }
         P.n_plane = p->n_plane; P.n_pchunk = (int)ch.size() / 3; ranges(ch, 0);
-        put(soa.data(), soa.size() * 8, (void**)&P.pl_c); put(ch.data(), 4 * ch.size(), (void**)&P.pchunk);
-        if (dl) { chunks_pose0(p->n_edge); c->edge_perm.clear(); soa.clear(); }
-        else pack_lidar(p->n_edge, 9, p->edge_pose, p->edge_const, K, c->edge_perm, soa, P.ed_stride, ch);
+        put(ch.data(), 4 * ch.size(), (void**)&P.pchunk);
+        if (dl) { chunks_pose0(p->n_edge); c->edge_perm.clear(); put(nullptr, 8, (void**)&P.ed_c); }
+        else {
+            lidar_order(p->n_edge, p->edge_pose, K, c->edge_perm, cnt); lidar_chunks(cnt, K, ch);
+            P.ed_stride = (p->n_edge + 31) & ~31;
+            if (double* dst = (double*)reserve(8 * (size_t)9 * std::max(P.ed_stride, 1), (void**)&P.ed_c)) lidar_soa(p->n_edge, 9, p->edge_const, c->edge_perm, P.ed_stride, dst);
+        }
         P.n_edge = p->n_edge; P.n_echunk = (int)ch.size() / 3; ranges(ch, K + 1);
-        put(soa.data(), soa.size() * 8, (void**)&P.ed_c); put(ch.data(), 4 * ch.size(), (void**)&P.echunk);
+        put(ch.data(), 4 * ch.size(), (void**)&P.echunk);
         put(nullptr, 8 * (size_t)28 * std::max(P.n_pchunk + P.n_echunk, 1), (void**)&P.lpart);
         put(lcp.data(), 4 * lcp.size(), (void**)&P.lchunk_pose);
     }
