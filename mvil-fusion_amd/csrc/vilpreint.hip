@@ -208,57 +208,87 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preint(PreArgs A) {
         for (int e = t; e < nb * 225; e += PRE_THREADS) {
             const int s = e / 225, ij = e - 225 * s, qi = ij / 15, qj = ij - 15 * qi;
             const double* Vi = sV + 270 * s + 18 * qi; const double* Vj = sV + 270 * s + 18 * qj;
-            double acc = 0.0;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;              // three partial sums: a dependent fp64 op costs ~40 cycles here
 #pragma unroll
-            for (int q = 0; q < 18; ++q) acc += Vi[q] * nd[q] * Vj[q];
-            sQ[e] = acc;
+            for (int q = 0; q < 18; q += 3) { a0 += Vi[q] * nd[q] * Vj[q]; a1 += Vi[q + 1] * nd[q + 1] * Vj[q + 1]; a2 += Vi[q + 2] * nd[q + 2] * Vj[q + 2]; }
+            sQ[e] = (a0 + a1) + a2;
         }
         __syncthreads();
-        // (4) pairwise tree over the batch: slot a <- slot b o slot a  (b = a + st the later samples)
+        // (4) pairwise tree over the batch: slot a <- slot b o slot a  (b = a + st the later samples).  Wide levels run as
+        //     3 x 3 register blocks (a third of the LDS reads per multiply-add); narrow levels -- and the final fold into the
+        //     running (J, P) -- as one output per lane, which keeps all 256 lanes busy when only one or two pairs are left.
         for (int st = 1; st < nb; st <<= 1) {
             const int npair = (nb - st + 2 * st - 1) / (2 * st);              // slots a = 2 st p with a + st < nb
-            for (int task = t; task < npair * 50; task += PRE_THREADS) {
-                const int p = task / 50, r = task - 50 * p, which = r / 25, blk = r - 25 * which, br = blk / 5, bc = blk - 5 * br;
-                const int sa = 2 * st * p, sb = sa + st;
-                double o[9];
-                blk33(sF + 225 * sb, which ? sQ + 225 * sa : sF + 225 * sa, false, br, bc, o);
-                put33((which ? sTmpT : sTmpF) + 225 * p, br, bc, o);
+            const bool wide = npair * 50 >= PRE_THREADS;
+            if (wide) {
+                for (int task = t; task < npair * 50; task += PRE_THREADS) {
+                    const int p = task / 50, r = task - 50 * p, which = r / 25, blk = r - 25 * which, br = blk / 5, bc = blk - 5 * br;
+                    const int sa = 2 * st * p, sb = sa + st;
+                    double o[9];
+                    blk33(sF + 225 * sb, which ? sQ + 225 * sa : sF + 225 * sa, false, br, bc, o);
+                    put33((which ? sTmpT : sTmpF) + 225 * p, br, bc, o);
+                }
+            } else {
+                for (int task = t; task < npair * 450; task += PRE_THREADS) {
+                    const int p = task / 450, r = task - 450 * p, which = r / 225, ij = r - 225 * which, i = ij / 15, j = ij - 15 * i;
+                    const int sa = 2 * st * p, sb = sa + st;
+                    const double* L = sF + 225 * sb + 15 * i; const double* R = (which ? sQ + 225 * sa : sF + 225 * sa) + j;
+                    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 15; q += 3) { a0 += L[q] * R[15 * q]; a1 += L[q + 1] * R[15 * (q + 1)]; a2 += L[q + 2] * R[15 * (q + 2)]; }
+                    (which ? sTmpT : sTmpF)[225 * p + ij] = (a0 + a1) + a2;
+                }
             }
             __syncthreads();
-            for (int task = t; task < npair * 25; task += PRE_THREADS) {
-                const int p = task / 25, blk = task - 25 * p, br = blk / 5, bc = blk - 5 * br;
-                const int sa = 2 * st * p, sb = sa + st;
-                double o[9];
-                blk33(sTmpT + 225 * p, sF + 225 * sb, true, br, bc, o);
+            if (wide) {
+                for (int task = t; task < npair * 25; task += PRE_THREADS) {
+                    const int p = task / 25, blk = task - 25 * p, br = blk / 5, bc = blk - 5 * br;
+                    const int sa = 2 * st * p, sb = sa + st;
+                    double o[9];
+                    blk33(sTmpT + 225 * p, sF + 225 * sb, true, br, bc, o);
 #pragma unroll
-                for (int a = 0; a < 3; ++a)
+                    for (int a = 0; a < 3; ++a)
 #pragma unroll
-                    for (int b = 0; b < 3; ++b) o[3 * a + b] += sQ[225 * sb + (3 * br + a) * 15 + 3 * bc + b];
-                put33(sQ + 225 * sa, br, bc, o);
+                        for (int b = 0; b < 3; ++b) o[3 * a + b] += sQ[225 * sb + (3 * br + a) * 15 + 3 * bc + b];
+                    put33(sQ + 225 * sa, br, bc, o);
+                }
+            } else {
+                for (int task = t; task < npair * 225; task += PRE_THREADS) {
+                    const int p = task / 225, ij = task - 225 * p, i = ij / 15, j = ij - 15 * i;
+                    const int sa = 2 * st * p, sb = sa + st;
+                    const double* L = sTmpT + 225 * p + 15 * i; const double* R = sF + 225 * sb + 15 * j;
+                    double a0 = sQ[225 * sb + ij], a1 = 0.0, a2 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 15; q += 3) { a0 += L[q] * R[q]; a1 += L[q + 1] * R[q + 1]; a2 += L[q + 2] * R[q + 2]; }
+                    sQ[225 * sa + ij] = (a0 + a1) + a2;
+                }
             }
             // this phase reads only the F of the b slots, so the a slots can take their new F at the same time
             for (int e = t; e < npair * 225; e += PRE_THREADS) { const int p = e / 225; sF[225 * (2 * st * p) + (e - 225 * p)] = sTmpF[e]; }
             __syncthreads();
         }
-        // fold the batch into the running jacobian / covariance (:122-123)
-        if (t < 50) {
-            const int which = t / 25, blk = t - 25 * which, br = blk / 5, bc = blk - 5 * br;
-            double o[9];
-            blk33(sF, which ? sC : sJ, false, br, bc, o);
-            put33((which ? sTmpT : sTmpF), br, bc, o);
+        // fold the batch into the running jacobian / covariance (:122-123): J <- F J, T = F P, then P <- T F^T + Q
+        if (t < 225) {
+            const int i = t / 15, j = t - 15 * i;
+            const double* L = sF + 15 * i;
+            double aj0 = 0.0, aj1 = 0.0, aj2 = 0.0, ap0 = 0.0, ap1 = 0.0, ap2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 15; q += 3) {
+                const double f0 = L[q], f1 = L[q + 1], f2 = L[q + 2];
+                aj0 += f0 * sJ[15 * q + j]; aj1 += f1 * sJ[15 * (q + 1) + j]; aj2 += f2 * sJ[15 * (q + 2) + j];
+                ap0 += f0 * sC[15 * q + j]; ap1 += f1 * sC[15 * (q + 1) + j]; ap2 += f2 * sC[15 * (q + 2) + j];
+            }
+            sTmpF[t] = (aj0 + aj1) + aj2; sTmpT[t] = (ap0 + ap1) + ap2;
         }
         __syncthreads();
-        if (t < 25) {
-            const int br = t / 5, bc = t - 5 * br;
-            double o[9];
-            blk33(sTmpT, sF, true, br, bc, o);
+        if (t < 225) {
+            const int i = t / 15, j = t - 15 * i;
+            const double* L = sTmpT + 15 * i; const double* R = sF + 15 * j;
+            double a0 = sQ[t], a1 = 0.0, a2 = 0.0;
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) o[3 * a + b] += sQ[(3 * br + a) * 15 + 3 * bc + b];
-            put33(sC, br, bc, o);
+            for (int q = 0; q < 15; q += 3) { a0 += L[q] * R[q]; a1 += L[q + 1] * R[q + 1]; a2 += L[q + 2] * R[q + 2]; }
+            sC[t] = (a0 + a1) + a2; sJ[t] = sTmpF[t];
         }
-        if (t < 225) sJ[t] = sTmpF[t];
         __syncthreads();
     }
     // pack (vilsolve.h: VIL_IMU_CONST layout)
