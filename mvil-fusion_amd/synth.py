@@ -344,7 +344,7 @@ def make_config(config_id, prior_fn=None, **override):
     `synthetic_prior`.
     """
     cfg = dict(CONFIGS[config_id]); cfg.update(override)
-    seed = 20240601 + config_id
+    seed = 20240601 + config_id + int(cfg.pop("seed_offset", 0))       # seed_offset: other scenes of the same shape (fuzz runs)
     sc = Scene(cfg["K"], seed)
     w = sc.window(1, cfg["K"], cfg["L"], cfg["n_plane"], cfg["n_edge"], cfg["n_icp"], cfg["n_lps"])
     w.config_id = config_id
