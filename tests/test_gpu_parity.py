@@ -124,3 +124,19 @@ def test_resident_solve_repeatable(hip):
     s2 = hip.solve_resident()
     assert s1.iterations == s2.iterations
     assert abs(s1.final_cost - s2.final_cost) <= 1e-9 * s1.final_cost
+
+
+@pytest.mark.parametrize("cid,kw", [(1, dict(L=60)), (2, dict(L=100, n_plane=1500, n_edge=500)), (2, dict(K=7, L=80, n_plane=600, n_edge=200))])
+def test_solve_parity_over_seeds(hip, oracle, cid, kw):
+    """Differently seeded scenes of the same shape (tools/fuzz_parity.py runs 1200 of them): the trust-region trajectory --
+    iteration count, termination -- and the solution match the oracle in every one."""
+    pf = lambda pre: oracle.marginalize(pre).to_prior()
+    for k in range(8):
+        wg = synth.make_config(cid, prior_fn=pf, seed_offset=1000 * (k + 1), **kw)
+        wo = synth.make_config(cid, prior_fn=pf, seed_offset=1000 * (k + 1), **kw)
+        p0 = wg.pose[0].copy()
+        sg, so = hip.solve(wg), oracle.solve(wo)
+        assert (sg.iterations, sg.termination, sg.successful_steps) == (so.iterations, so.termination, so.successful_steps), (cid, k)
+        assert abs(sg.final_cost - so.final_cost) <= (1e-5 if wg.prior.n == 0 else 1e-8) * so.final_cost
+        hip.gauge_fix(p0, wg); oracle.gauge_fix(p0, wo)
+        compare_states(wg, wo, pos_tol=1e-4 if wg.prior.n == 0 else 1e-6, rot_tol=1e-5 if wg.prior.n == 0 else 1e-7)
