@@ -70,3 +70,33 @@ def test_example_reproduces_harness(hip, oracle):
         assert abs(float(tok[3]) - s.initial_cost) <= 1e-12 * s.initial_cost and abs(float(tok[4]) - s.final_cost) <= ctol * s.final_cost
         assert int(tok[5]) == m.c.n
         assert np.abs(np.array([float(v) for v in tok[6:13]]) - w.pose[-1]).max() < ptol
+
+
+def _build_lidar(d):
+    exe = os.path.join(d, "lidar_patch")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "lidar_patch.cpp"),
+                           lib.LIB_PATH, "-Wl,-rpath," + os.path.dirname(lib.LIB_PATH), "-o", exe])
+    return exe
+
+
+def test_lidar_example_builds_and_refuses_without_gpu():
+    lib.load_vilsolve()
+    with tempfile.TemporaryDirectory() as d:
+        exe = _build_lidar(d)
+        import torch
+        if torch.cuda.is_available():
+            return
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 3 and "no CPU path" in r.stderr
+
+
+@pytest.mark.gpu
+def test_lidar_example_registers_the_synthetic_room():
+    """examples/lidar_patch.cpp: the processLidar / localMapping patches of INTEGRATION.md sections 7-8 recover the pose the
+    synthetic scans were taken from (0.6, -0.4, 0.1 m, yaw 0.05 rad)."""
+    with tempfile.TemporaryDirectory() as d:
+        out = subprocess.check_output([_build_lidar(d)], text=True).splitlines()
+    v = [l.split() for l in out if l.startswith("VGICP")][0]; m = [l.split() for l in out if l.startswith("VMAP")][0]
+    assert v[1:3] == ["0", "1"] and np.abs(np.array([float(x) for x in v[4:8]]) - [0.6, -0.4, 0.1, 0.05]).max() < 0.02
+    assert m[1:3] == ["0", "2"] and int(m[3]) > 100 and int(m[4]) > 1000
+    assert np.abs(np.array([float(x) for x in m[5:9]]) - [0.6, -0.4, 0.1, 0.05]).max() < 0.02
