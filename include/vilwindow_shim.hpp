@@ -140,9 +140,9 @@ private:
 // pre-integration (vilsolve.h), produced by vpre_integrate for the frames marked dirty.
 class WindowFrames {
 public:
-    explicit WindowFrames(int K) : K_(K), stamp(K, 0.0), pose(7 * (size_t)K, 0.0), speedbias(9 * (size_t)K, 0.0), dt(K), acc(K), gyr(K),
+    explicit WindowFrames(int K) : stamp(K, 0.0), pose(7 * (size_t)K, 0.0), speedbias(9 * (size_t)K, 0.0), dt(K), acc(K), gyr(K),
                                    acc0(3 * (size_t)K, 0.0), gyr0(3 * (size_t)K, 0.0), lin_ba(3 * (size_t)K, 0.0), lin_bg(3 * (size_t)K, 0.0),
-                                   record((size_t)VIL_IMU_CONST * K, 0.0), dirty(K, 1) { for (int k = 0; k < K; ++k) pose[7 * k + 6] = 1.0; }
+                                   record((size_t)VIL_IMU_CONST * K, 0.0), dirty(K, 1), K_(K) { for (int k = 0; k < K; ++k) pose[7 * k + 6] = 1.0; }
     int K() const { return K_; }
     // processIMU (estimator.cpp:121-146): a sample arrives for the newest frame `k`
     void push_sample(int k, double dt_, const double a[3], const double g[3]) { dt[k].push_back(dt_); acc[k].insert(acc[k].end(), a, a + 3); gyr[k].insert(gyr[k].end(), g, g + 3); dirty[k] = 1; }
