@@ -167,3 +167,20 @@ def test_gross_outliers_and_bad_initial_guess(hip, oracle):
     assert np.allclose(np.array(sg.cost_trace[:n]), np.array(so.cost_trace[:n]), rtol=1e-7)
     assert np.allclose(np.array(sg.radius_trace[:n]), np.array(so.radius_trace[:n]), rtol=1e-9)
     assert np.abs(wg.pose[:, :3] - wo.pose[:, :3]).max() < 1e-6
+
+
+@pytest.mark.parametrize("kw", [
+    dict(jacobi_scaling=0), dict(autodiff_quirk=0), dict(visual_loss=abi.LOSS_NONE), dict(visual_loss=abi.LOSS_HUBER, visual_loss_scale=0.5),
+    dict(lidar_loss=abi.LOSS_NONE), dict(lidar_loss=abi.LOSS_CAUCHY, lidar_loss_scale=0.2), dict(rel_loss=abi.LOSS_NONE),
+    dict(initial_radius=1.0), dict(initial_radius=1e-2, max_iterations=25), dict(function_tolerance=1e-10, max_iterations=40)])
+def test_solver_options_parity(hip, oracle, kw):
+    """Every vil_options knob the reference path touches or the tests rely on: same trajectory and solution as the oracle."""
+    pf = lambda pre: oracle.marginalize(pre).to_prior()
+    wg = synth.make_config(2, prior_fn=pf, L=120, n_plane=1500, n_edge=500); wo = synth.make_config(2, prior_fn=pf, L=120, n_plane=1500, n_edge=500)
+    opts = abi.default_options(**kw)
+    p0 = wg.pose[0].copy()
+    sg, so = hip.solve(wg, opts), oracle.solve(wo, opts)
+    assert (sg.iterations, sg.termination, sg.successful_steps) == (so.iterations, so.termination, so.successful_steps), kw
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    hip.gauge_fix(p0, wg); oracle.gauge_fix(p0, wo)
+    assert np.abs(wg.pose - wo.pose).max() < 1e-6 and np.abs(wg.inv_depth - wo.inv_depth).max() < 1e-5
