@@ -130,13 +130,11 @@ __global__ __launch_bounds__(64 * VM_QPB) void k_map_search(int nqc, int nqs, co
 }
 
 // ---- fit: one thread per scan point; slot = 10 doubles: corner [valid, cp(3), a(3), b(3)], surf [valid, cp(3), n(3), d, -]
-__global__ __launch_bounds__(VM_THREADS) void k_map_fit(int nqc, int nqs, const float* __restrict__ scan, const float* __restrict__ cmap, const float* __restrict__ smap,
-                                                        const int* __restrict__ nn, const float* __restrict__ nd5, double* __restrict__ slot) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nqc + nqs) return;
+__device__ __forceinline__ bool map_fit_one(int i, int nqc, const float* __restrict__ scan, const float* __restrict__ cmap, const float* __restrict__ smap,
+                                            const int* __restrict__ nn, const float* __restrict__ nd5, double* __restrict__ slot) {
     double* o = slot + (size_t)10 * i;
     o[0] = 0.0;
-    if (!(nd5[i] < 1.0f)) return;
+    if (!(nd5[i] < 1.0f)) return false;
     const int* nb = nn + 10 * (size_t)i;
     if (i < nqc) {                                                           // corner points (localMapping.cpp:607-660)
         double cx = 0, cy = 0, cz = 0;
@@ -153,12 +151,12 @@ __global__ __launch_bounds__(VM_THREADS) void k_map_fit(int nqc, int nqs, const 
         int m2 = 0; if (A[4] > A[0]) m2 = 1; if (A[8] > A[4 * m2]) m2 = 2;      // largest and middle eigenvalue
         const int ma = (m2 + 1) % 3, mb = (m2 + 2) % 3;
         const double l2 = A[4 * m2], l1 = fmax(A[4 * ma], A[4 * mb]);
-        if (!(l2 > 3.0 * l1)) return;
+        if (!(l2 > 3.0 * l1)) return false;
         const double ux = m2 == 0 ? V[0] : (m2 == 1 ? V[1] : V[2]), uy = m2 == 0 ? V[3] : (m2 == 1 ? V[4] : V[5]), uz = m2 == 0 ? V[6] : (m2 == 1 ? V[7] : V[8]);
         o[0] = 1.0; o[1] = scan[4 * i]; o[2] = scan[4 * i + 1]; o[3] = scan[4 * i + 2];
         o[4] = 0.1 * ux + cx; o[5] = 0.1 * uy + cy; o[6] = 0.1 * uz + cz;
         o[7] = -0.1 * ux + cx; o[8] = -0.1 * uy + cy; o[9] = -0.1 * uz + cz;
-        return;
+        return true;
     }
     // surf points (localMapping.cpp:683-741): re-rank the ten by |intensity difference| (ties: smaller map index), keep five
     const float qi = scan[4 * i + 3];
@@ -178,38 +176,53 @@ __global__ __launch_bounds__(VM_THREADS) void k_map_fit(int nqc, int nqs, const 
     bool ok = isfinite(d) && isfinite(nx);
 #pragma unroll
     for (int j = 0; j < 5; ++j) ok = ok && !(fabs(nx * P[3 * j] + ny * P[3 * j + 1] + nz * P[3 * j + 2] + d) > 0.2);
-    if (!ok) return;
+    if (!ok) return false;
     o[0] = 1.0; o[1] = scan[4 * i]; o[2] = scan[4 * i + 1]; o[3] = scan[4 * i + 2];
     o[4] = nx; o[5] = ny; o[6] = nz; o[7] = d;
+    return true;
+}
+// blk[2 b], blk[2 b + 1] = accepted corner / surf slots of workgroup b: the compaction's offsets without a second pass over the slots
+__global__ __launch_bounds__(VM_THREADS) void k_map_fit(int nqc, int nqs, const float* __restrict__ scan, const float* __restrict__ cmap, const float* __restrict__ smap,
+                                                        const int* __restrict__ nn, const float* __restrict__ nd5, double* __restrict__ slot, int* __restrict__ blk) {
+    __shared__ int s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * VM_THREADS + threadIdx.x;
+    const bool ok = i < nqc + nqs && map_fit_one(i, nqc, scan, cmap, smap, nn, nd5, slot);
+    const unsigned long long be = __ballot(ok && i < nqc), bp = __ballot(ok && i >= nqc);
+    if ((threadIdx.x & 63) == 0) { if (be) atomicAdd(&s_cnt[0], __popcll(be)); if (bp) atomicAdd(&s_cnt[1], __popcll(bp)); }
+    __syncthreads();
+    if (threadIdx.x < 2) blk[2 * blockIdx.x + threadIdx.x] = s_cnt[threadIdx.x];
 }
 
-// ---- ordered compaction of the accepted slots into the solver's structure-of-arrays factor tables (vil_internal.h): one
-//      workgroup; thread t owns a contiguous range of scan points, counts its accepted corner / surf slots, a block-wide
-//      exclusive scan turns the counts into output positions, and the range is copied in scan order (the order in which the
-//      reference adds the residual blocks).  cnt[0] = edges, cnt[1] = planes.
-#define VM_CT 1024
-__global__ __launch_bounds__(VM_CT) void k_map_compact(int nqc, int nqs, const double* __restrict__ slot, double* __restrict__ edge_soa, int es, double* __restrict__ plane_soa, int ps, int* __restrict__ cnt) {
-    __shared__ int se[VM_CT], sp[VM_CT];
-    const int t = threadIdx.x, nq = nqc + nqs, per = (nq + VM_CT - 1) / VM_CT;
-    const int b = min(nq, t * per), e = min(nq, b + per);
-    int ne = 0, np = 0;
-    for (int i = b; i < e; ++i) if (slot[(size_t)10 * i] != 0.0) { if (i < nqc) ++ne; else ++np; }
-    se[t] = ne; sp[t] = np;
+
+// ---- ordered compaction of the accepted slots into the solver's structure-of-arrays factor tables (vil_internal.h): the same
+//      workgroup partition as k_map_fit; a workgroup's output offset is the sum of the preceding workgroups' counts (blk), a
+//      slot's position inside it comes from wave ballots, so the tables keep the scan order (the order in which the reference
+//      adds the residual blocks).  cnt[0] = edges, cnt[1] = planes.
+__global__ __launch_bounds__(VM_THREADS) void k_map_compact(int nqc, int nqs, const double* __restrict__ slot, const int* __restrict__ blk, double* __restrict__ edge_soa, int es,
+                                                            double* __restrict__ plane_soa, int ps, int* __restrict__ cnt) {
+    __shared__ int s_off[2], s_w[2][VM_THREADS / 64];
+    const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, w = t >> 6;
+    if (t < 2) s_off[t] = 0;
     __syncthreads();
-    for (int o = 1; o < VM_CT; o <<= 1) {
-        const int ve = t >= o ? se[t - o] : 0, vp = t >= o ? sp[t - o] : 0;
-        __syncthreads();
-        se[t] += ve; sp[t] += vp;
-        __syncthreads();
+    int pe = 0, pp = 0;
+    for (int j = t; j < b; j += VM_THREADS) { pe += blk[2 * j]; pp += blk[2 * j + 1]; }
+    for (int o = 32; o; o >>= 1) { pe += __shfl_xor(pe, o); pp += __shfl_xor(pp, o); }
+    if (lane == 0 && (pe | pp)) { atomicAdd(&s_off[0], pe); atomicAdd(&s_off[1], pp); }
+    const int i = b * VM_THREADS + t;
+    const double* o = slot + (size_t)10 * i;
+    const bool ok = i < nqc + nqs && o[0] != 0.0, edge = i < nqc;
+    const unsigned long long be = __ballot(ok && edge), bp = __ballot(ok && !edge), below = (1ull << lane) - 1ull;
+    if (lane == 0) { s_w[0][w] = __popcll(be); s_w[1][w] = __popcll(bp); }
+    __syncthreads();
+    if (ok) {
+        int pos = s_off[edge ? 0 : 1] + __popcll((edge ? be : bp) & below);
+        for (int v = 0; v < w; ++v) pos += s_w[edge ? 0 : 1][v];
+        if (edge) { for (int q = 0; q < 9; ++q) edge_soa[(size_t)q * es + pos] = o[1 + q]; }
+        else { for (int q = 0; q < 7; ++q) plane_soa[(size_t)q * ps + pos] = o[1 + q]; }
     }
-    int oe = se[t] - ne, op = sp[t] - np;
-    for (int i = b; i < e; ++i) {
-        const double* o = slot + (size_t)10 * i;
-        if (o[0] == 0.0) continue;
-        if (i < nqc) { for (int q = 0; q < 9; ++q) edge_soa[(size_t)q * es + oe] = o[1 + q]; ++oe; }
-        else { for (int q = 0; q < 7; ++q) plane_soa[(size_t)q * ps + op] = o[1 + q]; ++op; }
-    }
-    if (t == VM_CT - 1) { cnt[0] = se[t]; cnt[1] = sp[t]; }
+    if (b == (int)gridDim.x - 1 && t < 2) cnt[t] = s_off[t] + blk[2 * b + t];
 }
 
 void quat_to_R(const double* q, double* R) {
@@ -240,7 +253,7 @@ namespace {
 #define VM_OCC 6.0              // points per occupied grid cell the cell sizes are steered to
 int upload_scan(vmap_ctx* c, int n_corner, const float* corner, int n_surf, const float* surf) {
     const int nq = n_corner + n_surf;
-    const size_t need_scan = 16 * (size_t)nq + 16, need_work = (size_t)nq * (40 + 4 + 80) + 256;
+    const size_t need_scan = 16 * (size_t)nq + 16, need_work = (size_t)nq * (40 + 4 + 80) + 8 * ((size_t)nq / VM_THREADS + 1) + 256;
     if (need_scan > c->scan_cap) { hipFree(c->d_scan); c->d_scan = nullptr; c->scan_cap = 0; VMCHK(hipMalloc(&c->d_scan, 2 * need_scan)); c->scan_cap = 2 * need_scan; }
     if (need_work > c->work_cap) { hipFree(c->d_work); c->d_work = nullptr; c->work_cap = 0; VMCHK(hipMalloc(&c->d_work, 2 * need_work)); c->work_cap = 2 * need_work; }
     if (n_corner) VMCHK(hipMemcpyAsync(c->d_scan, corner, 16 * (size_t)n_corner, hipMemcpyHostToDevice, c->stream));
@@ -255,12 +268,12 @@ int associate_uploaded(vmap_ctx* c, int n_corner, int n_surf, const double* q, c
     const int nq = n_corner + n_surf;
     if (nq == 0 || nqc + nqs == 0) return VM_OK;
     // queries are addressed in the uploaded layout (corner block, then surf block); a class without a map is skipped by nmap < k
-    double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq);
+    double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq); int* d_blk = (int*)(c->d_work + (((size_t)124 * nq + 7) & ~(size_t)7));
     if (c->profiling) hipEventRecord(c->ev[0], c->stream);
     hipLaunchKernelGGL(k_map_search, dim3((nq + VM_QPB - 1) / VM_QPB), dim3(64 * VM_QPB), 0, c->stream, n_corner, n_surf, c->d_scan, T, c->nc, c->gc.G, c->gc.order, c->gc.cxyz,
                        c->ns, c->gs.G, c->gs.order, c->gs.cxyz, d_nn, d_nd5);
     if (c->profiling) { hipEventRecord(c->ev[1], c->stream); hipEventRecord(c->ev[2], c->stream); }
-    hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_slot);
+    hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_slot, d_blk);
     if (c->profiling) hipEventRecord(c->ev[3], c->stream);
     if (10 * (size_t)nq > c->h_slot_cap) {
         if (c->h_slot) hipHostFree(c->h_slot);
@@ -286,11 +299,11 @@ int associate_device(vmap_ctx* c, int n_corner, int n_surf, const double* q, con
     if (!c->d_cnt) { VMCHK(hipMalloc(&c->d_cnt, 16)); VMCHK(hipHostMalloc((void**)&c->h_cnt, 16, hipHostMallocDefault)); }
     dl->edge_soa = c->d_soa; dl->edge_stride = es; dl->plane_soa = c->d_soa + (size_t)9 * es; dl->plane_stride = ps;
     if (nq == 0) return VM_OK;
-    double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq);
+    double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq); int* d_blk = (int*)(c->d_work + (((size_t)124 * nq + 7) & ~(size_t)7));
     hipLaunchKernelGGL(k_map_search, dim3((nq + VM_QPB - 1) / VM_QPB), dim3(64 * VM_QPB), 0, c->stream, n_corner, n_surf, c->d_scan, T, c->nc, c->gc.G, c->gc.order, c->gc.cxyz,
                        c->ns, c->gs.G, c->gs.order, c->gs.cxyz, d_nn, d_nd5);
-    hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_slot);
-    hipLaunchKernelGGL(k_map_compact, dim3(1), dim3(VM_CT), 0, c->stream, n_corner, n_surf, d_slot, c->d_soa, es, c->d_soa + (size_t)9 * es, ps, c->d_cnt);
+    hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_slot, d_blk);
+    hipLaunchKernelGGL(k_map_compact, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, d_slot, d_blk, c->d_soa, es, c->d_soa + (size_t)9 * es, ps, c->d_cnt);
     VMCHK(hipMemcpyAsync(c->h_cnt, c->d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
     VMCHK(hipStreamSynchronize(c->stream));
     VMCHK(hipGetLastError());
