@@ -70,6 +70,22 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// wave64 sum on the DPP crossbar (no LDS traffic, a few cycles per step instead of a ds_bpermute round trip): rotate-and-add
+// inside each row of 16 lanes, then the two row broadcasts carry the row totals to lane 63, which is read back as a
+// wave-uniform value.  Different summation order from wave_sum (same value to rounding).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false), h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(h2, l2);
+}
+__device__ __forceinline__ double wave_total(double v) {
+    v = dpp_add<0x128, 0xf>(v); v = dpp_add<0x124, 0xf>(v); v = dpp_add<0x122, 0xf>(v); v = dpp_add<0x121, 0xf>(v);   // row_ror 8, 4, 2, 1
+    v = dpp_add<0x142, 0xa>(v);                                                                                           // row_bcast15 into rows 1, 3
+    v = dpp_add<0x143, 0xc>(v);                                                                                           // row_bcast31 into rows 2, 3
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
 // robust loss: rho(s), rho'(s) for ceres CauchyLoss(a)/HuberLoss(a). Both have rho'' <= 0, so the

@@ -19,6 +19,7 @@
 #include "../../include/vilmap.h"
 #include "vil_internal.h"
 #include "vil_knn.hpp"
+#include "vil_pose1.hpp"
 
 #define VM_OK 0
 #define VM_ERR_INVALID -1
@@ -29,7 +30,7 @@
 namespace {
 using namespace vknn;
 
-struct PoseD { double R[9]; double t[3]; };
+using PoseD = vp1::PoseRT;      // rotation matrix + translation of the scan pose (double)
 
 // eigen-decomposition of a symmetric 3x3 (cyclic Jacobi): A -> eigenvalues on its diagonal, V columns = eigenvectors
 __device__ __forceinline__ void jacobi3(double* A, double* V) {
@@ -108,12 +109,13 @@ __device__ __forceinline__ void qr_solve_5x3(double* P, double* b, double* x) {
 //      [nqc, nqc + nqs) surf points against the surf map (10-NN).  nn: 10 ints per query, nd5: the 5th squared distance
 //      (or a value >= 1 when the query is rejected: fewer than five map points within 1 m, localMapping.cpp:613,:705)
 #define VM_QPB 4
-__global__ __launch_bounds__(64 * VM_QPB) void k_map_search(int nqc, int nqs, const float* __restrict__ scan, PoseD T, int ncm, GridTab Gc, const int* __restrict__ oc, const float* __restrict__ xc,
+__global__ __launch_bounds__(64 * VM_QPB) void k_map_search(int nqc, int nqs, const float* __restrict__ scan, PoseD T, const PoseD* __restrict__ Tdev, int ncm, GridTab Gc, const int* __restrict__ oc, const float* __restrict__ xc,
                                                             int nsm, GridTab Gs, const int* __restrict__ os, const float* __restrict__ xs, int* __restrict__ nn, float* __restrict__ nd5) {
     __shared__ int wl_all[VM_QPB * KNN_WL_CAP];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int qi = blockIdx.x * VM_QPB + wave;
     if (qi >= nqc + nqs) return;
+    if (Tdev) T = *Tdev;                 // second round of the single-submission registration: the pose the first solve left on the device
     const bool surf = qi >= nqc;
     const int kk = surf ? 10 : 5, nmap = surf ? nsm : ncm;
     float d5 = 3.0e38f;
@@ -246,6 +248,9 @@ struct vmap_ctx {
     const float* up_corner = nullptr; const float* up_surf = nullptr; int up_nc = -1, up_ns = -1; bool scan_valid = false;
     double* h_slot = nullptr; size_t h_slot_cap = 0;       // pinned: the slot read-back is a plain DMA
     double* d_soa = nullptr; size_t soa_cap = 0; int* d_cnt = nullptr; int* h_cnt = nullptr;   // device-resident factor tables of vmap_align
+    vp1::Pose1Coop* d_coop = nullptr; int reg_epoch = 0;   // meeting point of the pose solve's workgroups; epoch numbers are never reused
+    char* d_reg = nullptr; char* h_reg = nullptr;     // single-submission registration: pose (7 doubles) | PoseRT | 2 x Pose1Out, and its pinned mirror
+    int fused_max = 16384;                            // scans up to this many points take the one-launch pose solve (VIL_MAP_FUSED_MAX overrides; 0 = always the window solver)
     bool profiling = false; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; long long prof_n[2] = {0, 0}; double prof_ms[2] = {0.0, 0.0};
 };
 
@@ -270,7 +275,7 @@ int associate_uploaded(vmap_ctx* c, int n_corner, int n_surf, const double* q, c
     // queries are addressed in the uploaded layout (corner block, then surf block); a class without a map is skipped by nmap < k
     double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq); int* d_blk = (int*)(c->d_work + (((size_t)124 * nq + 7) & ~(size_t)7));
     if (c->profiling) hipEventRecord(c->ev[0], c->stream);
-    hipLaunchKernelGGL(k_map_search, dim3((nq + VM_QPB - 1) / VM_QPB), dim3(64 * VM_QPB), 0, c->stream, n_corner, n_surf, c->d_scan, T, c->nc, c->gc.G, c->gc.order, c->gc.cxyz,
+    hipLaunchKernelGGL(k_map_search, dim3((nq + VM_QPB - 1) / VM_QPB), dim3(64 * VM_QPB), 0, c->stream, n_corner, n_surf, c->d_scan, T, (const PoseD*)nullptr, c->nc, c->gc.G, c->gc.order, c->gc.cxyz,
                        c->ns, c->gs.G, c->gs.order, c->gs.cxyz, d_nn, d_nd5);
     if (c->profiling) { hipEventRecord(c->ev[1], c->stream); hipEventRecord(c->ev[2], c->stream); }
     hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_slot, d_blk);
@@ -300,7 +305,7 @@ int associate_device(vmap_ctx* c, int n_corner, int n_surf, const double* q, con
     dl->edge_soa = c->d_soa; dl->edge_stride = es; dl->plane_soa = c->d_soa + (size_t)9 * es; dl->plane_stride = ps;
     if (nq == 0) return VM_OK;
     double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq); int* d_blk = (int*)(c->d_work + (((size_t)124 * nq + 7) & ~(size_t)7));
-    hipLaunchKernelGGL(k_map_search, dim3((nq + VM_QPB - 1) / VM_QPB), dim3(64 * VM_QPB), 0, c->stream, n_corner, n_surf, c->d_scan, T, c->nc, c->gc.G, c->gc.order, c->gc.cxyz,
+    hipLaunchKernelGGL(k_map_search, dim3((nq + VM_QPB - 1) / VM_QPB), dim3(64 * VM_QPB), 0, c->stream, n_corner, n_surf, c->d_scan, T, (const PoseD*)nullptr, c->nc, c->gc.G, c->gc.order, c->gc.cxyz,
                        c->ns, c->gs.G, c->gs.order, c->gs.cxyz, d_nn, d_nd5);
     hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_slot, d_blk);
     hipLaunchKernelGGL(k_map_compact, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, d_slot, d_blk, c->d_soa, es, c->d_soa + (size_t)9 * es, ps, c->d_cnt);
@@ -308,6 +313,61 @@ int associate_device(vmap_ctx* c, int n_corner, int n_surf, const double* q, con
     VMCHK(hipStreamSynchronize(c->stream));
     VMCHK(hipGetLastError());
     *n_edge = c->h_cnt[0]; *n_plane = c->h_cnt[1];
+    return VM_OK;
+}
+
+// The whole registration in one submission: both rounds of {search, fit, compact, one-launch pose solve} are enqueued back
+// to back -- the counts, the factor tables and the pose between the rounds never leave the device -- and one read-back of the
+// two result records ends the call.
+#define REG_POSE 0
+#define REG_RT 64
+#define REG_OUT 192
+#define REG_BYTES (REG_OUT + 2 * sizeof(vp1::Pose1Out))
+int align_fused(vmap_ctx* c, int n_corner, int n_surf, double* q, double* t, const vil_options* opts, vmap_summary* out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int nq = n_corner + n_surf;
+    const int es = (std::max(n_corner, 1) + 31) & ~31, ps = (std::max(n_surf, 1) + 31) & ~31;
+    const size_t need = 8 * ((size_t)9 * es + (size_t)7 * ps);
+    if (need > c->soa_cap) { hipFree(c->d_soa); c->d_soa = nullptr; c->soa_cap = 0; VMCHK(hipMalloc(&c->d_soa, 2 * need)); c->soa_cap = 2 * need; }
+    if (!c->d_cnt) { VMCHK(hipMalloc(&c->d_cnt, 16)); VMCHK(hipHostMalloc((void**)&c->h_cnt, 16, hipHostMallocDefault)); }
+    if (!c->d_reg) { VMCHK(hipMalloc(&c->d_reg, REG_BYTES)); VMCHK(hipHostMalloc((void**)&c->h_reg, REG_BYTES, hipHostMallocDefault)); }
+    if (!c->d_coop) { VMCHK(hipMalloc(&c->d_coop, sizeof(vp1::Pose1Coop))); VMCHK(hipMemsetAsync(c->d_coop, 0, sizeof(vp1::Pose1Coop), c->stream)); }
+    const int G = std::min(VP1_MAXG, std::max(1, (nq + VP1_THREADS - 1) / VP1_THREADS));
+    double* edge_soa = c->d_soa; double* plane_soa = c->d_soa + (size_t)9 * es;
+    double* h_pose = (double*)(c->h_reg + REG_POSE);
+    h_pose[0] = t[0]; h_pose[1] = t[1]; h_pose[2] = t[2]; h_pose[3] = q[0]; h_pose[4] = q[1]; h_pose[5] = q[2]; h_pose[6] = q[3];
+    VMCHK(hipMemcpyAsync(c->d_reg + REG_POSE, h_pose, 56, hipMemcpyHostToDevice, c->stream));
+    PoseD T; quat_to_R(q, T.R); T.t[0] = t[0]; T.t[1] = t[1]; T.t[2] = t[2];
+    double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq); int* d_blk = (int*)(c->d_work + (((size_t)124 * nq + 7) & ~(size_t)7));
+    vp1::Pose1Out* d_out = (vp1::Pose1Out*)(c->d_reg + REG_OUT);
+    for (int round = 0; round < 2; ++round) {
+        if (nq > 0) {
+            if (c->profiling && round == 0) VMCHK(hipEventRecord(c->ev[0], c->stream));
+            hipLaunchKernelGGL(k_map_search, dim3((nq + VM_QPB - 1) / VM_QPB), dim3(64 * VM_QPB), 0, c->stream, n_corner, n_surf, c->d_scan, T, round ? (const PoseD*)(c->d_reg + REG_RT) : (const PoseD*)nullptr,
+                               c->nc, c->gc.G, c->gc.order, c->gc.cxyz, c->ns, c->gs.G, c->gs.order, c->gs.cxyz, d_nn, d_nd5);
+            if (c->profiling && round == 0) VMCHK(hipEventRecord(c->ev[1], c->stream));
+            hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_slot, d_blk);
+            if (c->profiling && round == 0) VMCHK(hipEventRecord(c->ev[2], c->stream));
+            hipLaunchKernelGGL(k_map_compact, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, d_slot, d_blk, edge_soa, es, plane_soa, ps, c->d_cnt);
+        } else VMCHK(hipMemsetAsync(c->d_cnt, 0, 8, c->stream));
+        hipLaunchKernelGGL(vp1::k_pose_solve, dim3(G), dim3(VP1_THREADS), 0, c->stream, c->d_cnt, edge_soa, es, plane_soa, ps, (double*)(c->d_reg + REG_POSE), (PoseD*)(c->d_reg + REG_RT), *opts,
+                           round ? d_out : (const vp1::Pose1Out*)nullptr, d_out + round, c->d_coop, c->reg_epoch);
+        c->reg_epoch += std::min(std::max(opts->max_iterations, 0), VP1_MAX_ITER) + 8;     // one epoch per evaluation: at most max_iterations + 1
+        if (c->reg_epoch > (1 << 30)) c->reg_epoch = 0;         // stale flags then hold values near 2^30, far from the small epochs that follow
+    }
+    VMCHK(hipMemcpyAsync(c->h_reg + REG_OUT, d_out, 2 * sizeof(vp1::Pose1Out), hipMemcpyDeviceToHost, c->stream));
+    VMCHK(hipStreamSynchronize(c->stream));
+    VMCHK(hipGetLastError());
+    if (c->profiling && nq > 0) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) { c->prof_ms[0] += ms; c->prof_n[0]++; }
+        if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) { c->prof_ms[1] += ms; c->prof_n[1]++; }
+    }
+    const vp1::Pose1Out* r = (const vp1::Pose1Out*)(c->h_reg + REG_OUT);
+    if (r[1].status != 0) return r[1].status;
+    t[0] = r[1].pose[0]; t[1] = r[1].pose[1]; t[2] = r[1].pose[2]; q[0] = r[1].pose[3]; q[1] = r[1].pose[4]; q[2] = r[1].pose[5]; q[3] = r[1].pose[6];
+    out->rounds = 2; out->n_edge = r[1].n_edge; out->n_plane = r[1].n_plane; out->iterations = r[1].iterations; out->initial_cost = r[1].initial_cost; out->final_cost = r[1].final_cost;
+    out->t_solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();   // one submission: association and solve are not separable on the host clock
     return VM_OK;
 }
 }  // namespace
@@ -322,13 +382,14 @@ int vmap_create(int32_t device, vmap_ctx** out) {
     vmap_ctx* c = new vmap_ctx();
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VM_ERR_DEVICE; }
+    if (const char* e = getenv("VIL_MAP_FUSED_MAX")) c->fused_max = atoi(e);
     *out = c;
     return VM_OK;
 }
 void vmap_destroy(vmap_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    hipFree(c->d_cmap); hipFree(c->d_smap); hipFree(c->gc.ws); hipFree(c->gs.ws); hipFree(c->d_scan); hipFree(c->d_work); if (c->h_slot) hipHostFree(c->h_slot); hipFree(c->d_soa); hipFree(c->d_cnt); if (c->h_cnt) hipHostFree(c->h_cnt);
+    hipFree(c->d_cmap); hipFree(c->d_smap); hipFree(c->gc.ws); hipFree(c->gs.ws); hipFree(c->d_scan); hipFree(c->d_work); if (c->h_slot) hipHostFree(c->h_slot); hipFree(c->d_soa); hipFree(c->d_cnt); if (c->h_cnt) hipHostFree(c->h_cnt); hipFree(c->d_reg); if (c->h_reg) hipHostFree(c->h_reg); hipFree(c->d_coop);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -380,6 +441,7 @@ int vmap_align(vmap_ctx* c, vil_ctx* solver, int32_t n_corner, const float* corn
     VMCHK(hipSetDevice(c->device));
     int st = upload_scan(c, n_corner, corner, n_surf, surf);             // the scan is uploaded once for both rounds
     if (st != VM_OK) return st;
+    if (n_corner + n_surf <= c->fused_max) return align_fused(c, n_corner, n_surf, q, t, opts, out);
     for (int round = 0; round < 2; ++round) {
         int32_t ne = 0, np = 0;
         const auto ta = std::chrono::steady_clock::now();
