@@ -267,7 +267,7 @@ def mapreg_mode(args):
     out = {"metric": "scan-to-map registrations/sec (lidar_mapping, %d+%d scan points vs %d+%d map points, 2 rounds)" % (len(sc), len(ss), len(cm), len(sm)),
            "value": args.steps / el, "unit": "registrations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 search / f64 fit+solve", "data": "synthetic",
-           "config": {"workload": "SURVEY 8(f) row 2: association (%d edge + %d plane factors) + DOGLEG solve, twice" % (sg.n_edge, sg.n_plane),
+           "config": {"workload": "SURVEY 8(f) row 2: association (%d edge + %d plane factors) + one-launch 6-dof DOGLEG solve, twice, one submission per registration" % (sg.n_edge, sg.n_plane),
                       "associate_ms": 1e3 * el_assoc / args.steps, "set_map_ms": 1e3 * t_map, "solve_iterations_last_round": int(sg.iterations),
                       "translation_error_m": float(np.linalg.norm(tg - t)), "k_map_fit_us": f_us},
            "roofline": {"bound": "hbm", "kernel": "k_map_search", "achieved": ab / (s_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -4,9 +4,15 @@
  *   vmap_set_map     kdtreeCornerFromMap->setInputCloud / kdtreeSurfFromMap->setInputCloud                     :590-591
  *   vmap_associate   per corner point: pointAssociateToMap (:170-179), 5-NN, line test by PCA (:613-660) -> LidarEdgeFactor(cp, a, b, 1.0)
  *                    per surf point: 10-NN re-ranked by |intensity difference| (:688-703), plane fit (:705-741) -> LidarPlaneNormFactor(cp, n, d)
- *   vmap_align       two rounds of {vmap_associate, 7-parameter solve with HuberLoss(0.1), DOGLEG, max 4 iterations (:596-600,:766-777)};
- *                    the solve is vil_solve of include/vilsolve.h on a one-pose window that holds only these point factors
- *                    (lidarFactor.hpp:12-55,106-138 in window-pose form with identity extrinsic).  NOTE: the library's pose
+ *   vmap_align       two rounds of {vmap_associate, 7-parameter solve with HuberLoss(0.1), DOGLEG, max 4 iterations (:596-600,:766-777)},
+ *                    submitted to the GPU as ONE batch: per round a search, a fit, a compaction and a one-launch 6-dof dogleg
+ *                    solve (the trust-region algorithm of vil_solve restricted to one pose block; csrc/vil_pose1.hpp); counts,
+ *                    factor tables and the pose between the rounds stay on the device, one read-back ends the call.  The
+ *                    factors are lidarFactor.hpp:12-55,106-138 in window-pose form with identity extrinsic.  `solver` is the
+ *                    fallback for scans above 2^20 points (and the cross-check of the tests: environment variable
+ *                    VIL_MAP_FUSED_MAX=<points>, read by vmap_create, 0 = always): vil_solve of include/vilsolve.h on a one-pose
+ *                    window holding these factors -- same result, three launches per iteration.  opts->max_time_s is not
+ *                    consulted by the one-launch solve (four iterations take tens of microseconds).  NOTE: the library's pose
  *                    update is right-multiplicative (q (x) dq, pose_local_parameterization.cpp) where the reference uses
  *                    ceres::EigenQuaternionParameterization here; both minimise the same cost, the four capped trust-region
  *                    iterations may land on slightly different iterates.
@@ -28,7 +34,9 @@ typedef struct vmap_summary {
     int32_t iterations;               /* trust-region iterations of the last solve */
     double initial_cost, final_cost;  /* of the last solve */
     double t_associate_ms, t_prepare_ms, t_solve_ms;  /* wall time over both rounds: "mapping data assosiation time" / "mapping solver time"
-                                                         (localMapping.cpp:764,778); prepare = factor upload of vil_solve */
+                                                         (localMapping.cpp:764,778); prepare = factor upload of vil_solve.  The single-
+                                                         submission path cannot split them on the host clock: the whole call is in
+                                                         t_solve_ms, the other two are 0 (per-kernel times: vmap_profile_read) */
 } vmap_summary;
 
 int vmap_create(int32_t device, vmap_ctx** out);

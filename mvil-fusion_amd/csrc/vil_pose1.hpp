@@ -15,9 +15,9 @@
 namespace vp1 {
 using namespace vd;
 
-#define VP1_THREADS 512
+#define VP1_THREADS 256
 #define VP1_WAVES (VP1_THREADS / 64)
-#define VP1_MAXG 32
+#define VP1_MAXG 64
 #define VP1_MAX_ITER (1 << 20)       // iteration cap of one launch (the host reserves that many epochs)
 
 struct PoseRT { double R[9]; double t[3]; };   // what the search kernel consumes (pointAssociateToMap)
@@ -195,7 +195,7 @@ struct Pose1State {
 // evaluated (sh.sysn), then the checks before an iteration, the dogleg step and the next candidate (invalid steps retry
 // without an evaluation).  Returns false when the solve is finished.  Not inlined: its register working set (everything
 // unrolled over compile-time indices) must not compete with the evaluation loop's.
-__device__ __noinline__ bool pose1_serial(Pose1Shared& sh, Pose1State& st, const vil_options& O) {
+__device__ __forceinline__ bool pose1_serial(Pose1Shared& sh, Pose1State& st, const vil_options& O) {
 #ifdef VP1_STAMPS
     long long q0 = wall_clock64(), q1;
 #define VP1_SK(k) do { q1 = wall_clock64(); st.tk[k] += q1 - q0; q0 = q1; } while (0)

@@ -332,7 +332,7 @@ __device__ __forceinline__ void sweep_lidar(const DevP& P, const SolveOpts& O, i
         }
     }
 #pragma unroll
-    for (int q = 0; q < 28; ++q) acc[q] = wave_sum(acc[q]);
+    for (int q = 0; q < 28; ++q) acc[q] = wave_total(acc[q]);
     const int wave = t >> 6, lane = t & 63;
     if (lane == 0) {
 #pragma unroll

@@ -250,7 +250,7 @@ struct vmap_ctx {
     double* d_soa = nullptr; size_t soa_cap = 0; int* d_cnt = nullptr; int* h_cnt = nullptr;   // device-resident factor tables of vmap_align
     vp1::Pose1Coop* d_coop = nullptr; int reg_epoch = 0;   // meeting point of the pose solve's workgroups; epoch numbers are never reused
     char* d_reg = nullptr; char* h_reg = nullptr;     // single-submission registration: pose (7 doubles) | PoseRT | 2 x Pose1Out, and its pinned mirror
-    int fused_max = 16384;                            // scans up to this many points take the one-launch pose solve (VIL_MAP_FUSED_MAX overrides; 0 = always the window solver)
+    int fused_max = 1 << 20;                           // scans up to this many points take the one-launch pose solve (VIL_MAP_FUSED_MAX overrides; 0 = always the window solver)
     bool profiling = false; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; long long prof_n[2] = {0, 0}; double prof_ms[2] = {0.0, 0.0};
 };
 

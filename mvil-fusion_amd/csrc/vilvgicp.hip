@@ -23,6 +23,7 @@
 
 #include "../../include/vilvgicp.h"
 #include "vil_knn.hpp"
+#include "vil_math.hpp"
 
 #define VG_OK 0
 #define VG_ERR_INVALID -1
@@ -38,11 +39,7 @@ struct VoxTab { const long long* keys; const int* slot_vox; int mask; const int*
 
 using vknn::pack_key; using vknn::hash_key;
 
-__device__ __forceinline__ double wave_sum64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum64(double v) { return vd::wave_total(v); }   // DPP rotate-and-add, no LDS round trips
 
 __device__ __forceinline__ void inv3(const double* a, double* o) {
     const double c0 = a[4] * a[8] - a[5] * a[7], c1 = a[5] * a[6] - a[3] * a[8], c2 = a[3] * a[7] - a[4] * a[6];

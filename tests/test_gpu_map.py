@@ -115,3 +115,61 @@ def test_interleaved_calls_and_map_updates(hip, setup):
     for (qa, ta, sa) in ((q2, t2, s2), (q3, t3, s3)):
         assert (sa.n_edge, sa.n_plane, sa.iterations) == (s1.n_edge, s1.n_plane, s1.iterations)        # (counts of the second round)
         assert np.abs(ta - t1).max() < 1e-10 and np.abs(qa - q1).max() < 1e-10
+
+
+@pytest.fixture(scope="module")
+def window_path(setup):
+    """The same registration routed through the window solver (three launches per iteration): the cross-check of the one-launch pose solve."""
+    import os
+    g, o, sc, ss, R, t = setup
+    os.environ["VIL_MAP_FUSED_MAX"] = "0"
+    try:
+        w = mapreg.MapReg(lib.load_vilsolve(), "vmap_")
+    finally:
+        del os.environ["VIL_MAP_FUSED_MAX"]
+    w.set_map(*[a for a in (mapreg.make_map(seed=4, n_surf=12000, n_corner=2000))])
+    yield w
+    w.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(max_iterations=12), dict(max_iterations=0), dict(jacobi_scaling=0), dict(lidar_loss=abi.LOSS_NONE),
+                                dict(lidar_loss=abi.LOSS_CAUCHY, lidar_loss_scale=0.3), dict(initial_radius=1e-3, max_iterations=10), dict(precision=1),
+                                dict(function_tolerance=1e-12, parameter_tolerance=1e-14, max_iterations=25)])
+def test_pose_solve_matches_window_solver_and_oracle(hip, setup, window_path, kw):
+    """One-launch pose solve == window solver == CPU oracle: same iteration count, same termination path, same pose, for every option it reads."""
+    g, o, sc, ss, R, t = setup
+    opts = abi.default_options(**({"max_iterations": 4} | kw))
+    q0 = mapreg.quat_from_R(R @ _rot(0.004, -0.003, 0.008)); t0 = t + np.array([0.05, -0.04, 0.03])
+    qg, tg, sg = g.align(hip.ctx, sc, ss, q0, t0, opts)
+    qw, tw, sw = window_path.align(hip.ctx, sc, ss, q0, t0, opts)
+    assert (sg.rounds, sg.n_edge, sg.n_plane, sg.iterations) == (sw.rounds, sw.n_edge, sw.n_plane, sw.iterations), kw
+    tol = 1e-6 if kw.get("precision") else 1e-9               # fp32 factor arithmetic: the two paths differ by float rounding, amplified by the solve
+    assert abs(sg.final_cost - sw.final_cost) <= tol * max(sw.final_cost, 1e-30) and abs(sg.initial_cost - sw.initial_cost) <= tol * max(sw.initial_cost, 1e-30)
+    assert np.abs(tg - tw).max() < tol and np.abs(qg - qw).max() < tol
+    if not kw.get("precision"):
+        qo, to, so = o.align(None, sc, ss, q0, t0, opts)
+        assert (sg.n_edge, sg.n_plane, sg.iterations) == (so.n_edge, so.n_plane, so.iterations), kw
+        assert np.abs(tg - to).max() < 1e-8 and np.abs(qg - qo).max() < 1e-9
+
+
+@pytest.mark.parametrize("nc,ns", [(0, 0), (0, 300), (60, 0), (3, 40), (400, 2500)])
+def test_pose_solve_scan_shapes(hip, setup, window_path, nc, ns):
+    """Empty, one-class and tiny scans (one workgroup) through the single-submission path."""
+    g, o, sc, ss, R, t = setup
+    q0 = mapreg.quat_from_R(R @ _rot(0.002, -0.001, 0.004)); t0 = t + np.array([0.02, -0.02, 0.01])
+    qg, tg, sg = g.align(hip.ctx, sc[:nc], ss[:ns], q0, t0)
+    qw, tw, sw = window_path.align(hip.ctx, sc[:nc], ss[:ns], q0, t0)
+    assert (sg.rounds, sg.n_edge, sg.n_plane, sg.iterations) == (sw.rounds, sw.n_edge, sw.n_plane, sw.iterations)
+    assert np.abs(tg - tw).max() < 1e-9 and np.abs(qg - qw).max() < 1e-10
+    if nc + ns == 0:
+        assert np.array_equal(tg, t0) and sg.iterations == 0
+
+
+def test_pose_solve_many_in_a_row(hip, setup):
+    """The workgroups of consecutive launches meet through the same block of device memory: 300 registrations, every one the same answer."""
+    g, o, sc, ss, R, t = setup
+    q0 = mapreg.quat_from_R(R @ _rot(0.004, -0.003, 0.008)); t0 = t + np.array([0.05, -0.04, 0.03])
+    q1, t1, s1 = g.align(hip.ctx, sc, ss, q0, t0)
+    for _ in range(300):
+        q2, t2, s2 = g.align(hip.ctx, sc, ss, q0, t0)
+        assert s2.iterations == s1.iterations and np.abs(t2 - t1).max() < 1e-12 and np.abs(q2 - q1).max() < 1e-12
