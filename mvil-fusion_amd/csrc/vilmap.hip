@@ -244,7 +244,7 @@ struct vmap_ctx {
     vknn::GridBuild gc, gs;
     float hc = 1.0f, hs = 1.0f;                      // cell sizes, adapted to the maps' densities
     // scan staging: corner points then surf points
-    float* d_scan = nullptr; size_t scan_cap = 0; char* d_work = nullptr; size_t work_cap = 0;
+    float* d_scan = nullptr; size_t scan_cap = 0; float* h_scan = nullptr; size_t h_scan_cap = 0; char* d_work = nullptr; size_t work_cap = 0;
     const float* up_corner = nullptr; const float* up_surf = nullptr; int up_nc = -1, up_ns = -1; bool scan_valid = false;
     double* h_slot = nullptr; size_t h_slot_cap = 0;       // pinned: the slot read-back is a plain DMA
     double* d_soa = nullptr; size_t soa_cap = 0; int* d_cnt = nullptr; int* h_cnt = nullptr;   // device-resident factor tables of vmap_align
@@ -261,8 +261,12 @@ int upload_scan(vmap_ctx* c, int n_corner, const float* corner, int n_surf, cons
     const size_t need_scan = 16 * (size_t)nq + 16, need_work = (size_t)nq * (40 + 4 + 80) + 8 * ((size_t)nq / VM_THREADS + 1) + 256;
     if (need_scan > c->scan_cap) { hipFree(c->d_scan); c->d_scan = nullptr; c->scan_cap = 0; VMCHK(hipMalloc(&c->d_scan, 2 * need_scan)); c->scan_cap = 2 * need_scan; }
     if (need_work > c->work_cap) { hipFree(c->d_work); c->d_work = nullptr; c->work_cap = 0; VMCHK(hipMalloc(&c->d_work, 2 * need_work)); c->work_cap = 2 * need_work; }
-    if (n_corner) VMCHK(hipMemcpyAsync(c->d_scan, corner, 16 * (size_t)n_corner, hipMemcpyHostToDevice, c->stream));
-    if (n_surf) VMCHK(hipMemcpyAsync(c->d_scan + 4 * (size_t)n_corner, surf, 16 * (size_t)n_surf, hipMemcpyHostToDevice, c->stream));
+    // through a pinned image: one DMA instead of two staged pageable copies (every entry point ends with a stream
+    // synchronisation, so the image is free again when the next call starts)
+    if (need_scan > c->h_scan_cap) { if (c->h_scan) hipHostFree(c->h_scan); c->h_scan = nullptr; c->h_scan_cap = 0; VMCHK(hipHostMalloc((void**)&c->h_scan, 2 * need_scan, hipHostMallocDefault)); c->h_scan_cap = 2 * need_scan; }
+    if (n_corner) memcpy(c->h_scan, corner, 16 * (size_t)n_corner);
+    if (n_surf) memcpy(c->h_scan + 4 * (size_t)n_corner, surf, 16 * (size_t)n_surf);
+    if (nq) VMCHK(hipMemcpyAsync(c->d_scan, c->h_scan, 16 * (size_t)nq, hipMemcpyHostToDevice, c->stream));
     return VM_OK;
 }
 // association of the uploaded scan at pose (q, t); compacted on the host in scan order
@@ -389,7 +393,7 @@ int vmap_create(int32_t device, vmap_ctx** out) {
 void vmap_destroy(vmap_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    hipFree(c->d_cmap); hipFree(c->d_smap); hipFree(c->gc.ws); hipFree(c->gs.ws); hipFree(c->d_scan); hipFree(c->d_work); if (c->h_slot) hipHostFree(c->h_slot); hipFree(c->d_soa); hipFree(c->d_cnt); if (c->h_cnt) hipHostFree(c->h_cnt); hipFree(c->d_reg); if (c->h_reg) hipHostFree(c->h_reg); hipFree(c->d_coop);
+    hipFree(c->d_cmap); hipFree(c->d_smap); hipFree(c->gc.ws); hipFree(c->gs.ws); hipFree(c->d_scan); hipFree(c->d_work); if (c->h_slot) hipHostFree(c->h_slot); hipFree(c->d_soa); hipFree(c->d_cnt); if (c->h_cnt) hipHostFree(c->h_cnt); hipFree(c->d_reg); if (c->h_reg) hipHostFree(c->h_reg); hipFree(c->d_coop); if (c->h_scan) hipHostFree(c->h_scan);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
