@@ -79,6 +79,23 @@ __device__ __forceinline__ double dpp_add(double v) {
     const int l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false), h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
     return v + __hiloint2double(h2, l2);
 }
+// the same fold, result left in lane 63 only (no scalar registers involved)
+__device__ __forceinline__ double wave_total_l63(double v) {
+    v = dpp_add<0x128, 0xf>(v); v = dpp_add<0x124, 0xf>(v); v = dpp_add<0x122, 0xf>(v); v = dpp_add<0x121, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v);
+    return dpp_add<0x143, 0xc>(v);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max(double v) {          // v >= 0 (a zero from a masked-off row never wins)
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false), h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return fmax(v, __hiloint2double(h2, l2));
+}
+__device__ __forceinline__ double wave_max_l63(double v) {     // non-negative inputs
+    v = dpp_max<0x128, 0xf>(v); v = dpp_max<0x124, 0xf>(v); v = dpp_max<0x122, 0xf>(v); v = dpp_max<0x121, 0xf>(v);
+    v = dpp_max<0x142, 0xa>(v);
+    return dpp_max<0x143, 0xc>(v);
+}
 __device__ __forceinline__ double wave_total(double v) {
     v = dpp_add<0x128, 0xf>(v); v = dpp_add<0x124, 0xf>(v); v = dpp_add<0x122, 0xf>(v); v = dpp_add<0x121, 0xf>(v);   // row_ror 8, 4, 2, 1
     v = dpp_add<0x142, 0xa>(v);                                                                                           // row_bcast15 into rows 1, 3

@@ -41,20 +41,20 @@ struct StepShared {
 // block-wide sum(a), sum(b) and sum-or-max(c) with one pair of barriers
 template <bool CMAX = false>
 __device__ __forceinline__ void bsum3(double& a, double& b, double& c, StepShared& s) {
-    a = wave_sum(a); b = wave_sum(b);
-    if (CMAX) { for (int o = 32; o > 0; o >>= 1) c = fmax(c, __shfl_xor(c, o, 64)); } else c = wave_sum(c);
+    a = wave_total_l63(a); b = wave_total_l63(b);          // DPP folds: the wave totals land in lane 63
+    c = CMAX ? wave_max_l63(c) : wave_total_l63(c);
     __syncthreads();
     const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s.red[w] = a; s.red[8 + w] = b; s.red[16 + w] = c; }
+    if ((threadIdx.x & 63) == 63) { s.red[w] = a; s.red[8 + w] = b; s.red[16 + w] = c; }
     __syncthreads();
     a = 0; b = 0; c = 0;
     for (int q = 0; q < nw; ++q) { a += s.red[q]; b += s.red[8 + q]; c = CMAX ? fmax(c, s.red[16 + q]) : c + s.red[16 + q]; }
 }
 
 __device__ __forceinline__ double bsum(double v, StepShared& s) {
-    v = wave_sum(v);
+    v = wave_total_l63(v);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) s.red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 63) s.red[threadIdx.x >> 6] = v;
     __syncthreads();
     double t = 0;
     const int nw = blockDim.x >> 6;
@@ -62,9 +62,9 @@ __device__ __forceinline__ double bsum(double v, StepShared& s) {
     return t;
 }
 __device__ __forceinline__ double bmax(double v, StepShared& s) {
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    v = wave_max_l63(v);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) s.red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 63) s.red[threadIdx.x >> 6] = v;
     __syncthreads();
     double t = 0;
     const int nw = blockDim.x >> 6;
