@@ -86,8 +86,7 @@ __device__ inline int gram_sqrt(double* M, double* lam, int n, double tiny, doub
     // largest diagonal entry (every wave reduces the whole diagonal: n <= 136 = three values per lane)
     double dmax = 0.0;
     for (int i = lane; i < n; i += 64) dmax = fmax(dmax, M[i * n + i]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
+    dmax = wave_fmax_all(dmax);
     if (t < n) {
         // acceptable pivot: above the rounding level of its own entry AND of the matrix it came from.  The input is a
         // Schur complement whose entries carry ~1e-11 relative noise from the cancellation upstream: a gauge direction
@@ -102,12 +101,9 @@ __device__ inline int gram_sqrt(double* M, double* lam, int n, double tiny, doub
         double v = -1.0; int vi = -1;
         if (t < n && done[t] == 0) { const double d = M[t * n + t]; if (d > thr[t]) { v = d; vi = t; } }
         if (wave * 64 < n) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double v2 = __shfl_xor(v, o, 64); const int i2 = __shfl_xor(vi, o, 64);
-                if (v2 > v || (v2 == v && i2 > vi)) { v = v2; vi = i2; }
-            }
-            if (lane == 0) { wv[wave] = v; wi[wave] = vi; }
+            const double vm = wave_fmax_all(v);                     // largest pivot of the wave, then the largest index that holds it
+            const int im = wave_imax_all(v == vm ? vi : -1);
+            if (lane == 0) { wv[wave] = vm; wi[wave] = im; }
         }
         __syncthreads();
         double pv = -1.0; int pi_ = -1;
@@ -149,8 +145,7 @@ __device__ inline int gram_sqrt(double* M, double* lam, int n, double tiny, doub
                 const double p0 = i0 < n ? gp[i0] : 0.0, p1 = i1 < n ? gp[i1] : 0.0, p2 = i2 < n ? gp[i2] : 0.0;
                 const double q0 = i0 < n ? gq[i0] : 0.0, q1 = i1 < n ? gq[i1] : 0.0, q2 = i2 < n ? gq[i2] : 0.0;
                 double al = p0 * p0 + p1 * p1 + p2 * p2, be = q0 * q0 + q1 * q1 + q2 * q2, ga = p0 * q0 + p1 * q1 + p2 * q2;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { al += __shfl_xor(al, o, 64); be += __shfl_xor(be, o, 64); ga += __shfl_xor(ga, o, 64); }
+                al = wave_total(al); be = wave_total(be); ga = wave_total(ga);      // DPP folds, wave-uniform results
                 if (ga == 0.0 || ga * ga <= 1e-28 * al * be) continue;
                 rotated = true;
                 // t = sign(d) ga / (|d| + sqrt(d^2 + ga^2)), d = (be - al)/2 ; c = 1/sqrt(1+t^2) ; s = t c
@@ -174,7 +169,7 @@ __device__ inline int gram_sqrt(double* M, double* lam, int n, double tiny, doub
     for (int i = wave; i < n; i += NW) {
         double s = 0;
         for (int k = lane; k < n; k += 64) { const double g = M[i * n + k]; s += g * g; }
-        s = wave_sum(s);
+        s = wave_total(s);
         if (lane == 0) lam[i] = s;
     }
     __syncthreads();

@@ -96,6 +96,25 @@ __device__ __forceinline__ double wave_max_l63(double v) {     // non-negative i
     v = dpp_max<0x142, 0xa>(v);
     return dpp_max<0x143, 0xc>(v);
 }
+// maxima of arbitrary-sign values, result wave-uniform: a row that a broadcast step does not address keeps its own value
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fmax(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int l2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false), h2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return fmax(v, __hiloint2double(h2, l2));
+}
+__device__ __forceinline__ double wave_fmax_all(double v) {
+    v = dpp_fmax<0x128, 0xf>(v); v = dpp_fmax<0x124, 0xf>(v); v = dpp_fmax<0x122, 0xf>(v); v = dpp_fmax<0x121, 0xf>(v);
+    v = dpp_fmax<0x142, 0xa>(v); v = dpp_fmax<0x143, 0xc>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_imax(int v) { return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false)); }
+__device__ __forceinline__ int wave_imax_all(int v) {
+    v = dpp_imax<0x128, 0xf>(v); v = dpp_imax<0x124, 0xf>(v); v = dpp_imax<0x122, 0xf>(v); v = dpp_imax<0x121, 0xf>(v);
+    v = dpp_imax<0x142, 0xa>(v); v = dpp_imax<0x143, 0xc>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ double wave_total(double v) {
     v = dpp_add<0x128, 0xf>(v); v = dpp_add<0x124, 0xf>(v); v = dpp_add<0x122, 0xf>(v); v = dpp_add<0x121, 0xf>(v);   // row_ror 8, 4, 2, 1
     v = dpp_add<0x142, 0xa>(v);                                                                                           // row_bcast15 into rows 1, 3
