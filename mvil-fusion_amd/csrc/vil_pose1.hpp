@@ -38,13 +38,15 @@ struct Pose1Shared {
 };
 
 // Evaluation is spread over a few workgroups (one factor per thread at lidar_mapping's scan sizes; a single compute unit's
-// fp64 rate would otherwise be the whole solve time); they meet through this block of device memory, zeroed once at
-// allocation.  Every launch gets a fresh range of epoch numbers from the host, so nothing is reset between launches.
+// fp64 rate would otherwise be the whole solve time); they meet through this block of device memory, zeroed at allocation.
+// The exchange is symmetric: every workgroup publishes its 28 partial sums and a flag, waits for everybody's flag, sums all
+// partials in workgroup order and runs the trust-region pass itself -- one hop per evaluation, no command to wait for.
+// A workgroup can be one evaluation ahead of the slowest (it cannot finish evaluation e + 1 before everybody has published
+// e + 1, i.e. has finished reading e), hence two partial buffers.  Every launch gets a fresh, growing range of epoch numbers
+// from the host, so nothing is reset between launches.
 struct Pose1Coop {
-    int flag[VP1_MAXG];          // workgroup g: "my partial sums of evaluation `epoch` are in part[g]"
-    int go, cmd;                 // workgroup 0: "the command for evaluation `epoch` is published"; cmd 1 = evaluate at pose, 0 = finished
-    double pose[7];
-    double part[VP1_MAXG][28];
+    int flag[VP1_MAXG];          // workgroup g: "my partial sums of evaluation `epoch` are in part[epoch & 1][g]" (epochs only grow)
+    double part[2][VP1_MAXG][28];
 };
 
 // R(q) exactly as the host computes it for the first round (no fused multiply-adds: the scan points are rounded to float
@@ -271,15 +273,16 @@ __device__ __forceinline__ bool pose1_serial(Pose1Shared& sh, Pose1State& st, co
 // pose_io: t, q of the starting pose, overwritten with the result (left untouched when the solve fails); rt_out: the same
 // pose as rotation matrix + translation for the next round's search.  cnt[0] = edges, cnt[1] = planes (device).
 // prev: the previous round's record (nullptr in the first round) -- a failed round is propagated, not built upon.
-// Grid: G <= VP1_MAXG workgroups, all resident (G is a handful); workgroup 0 also runs the trust-region logic.  Each candidate
-// is linearised where it is evaluated (the window solver does the same), so an accepted step costs one evaluation, not two.
+// Grid: G <= VP1_MAXG workgroups, all resident (G is a handful); workgroup 0 writes the result.  Each candidate is linearised
+// where it is evaluated (the window solver does the same), so an accepted step costs one evaluation, not two.
 __global__ __launch_bounds__(VP1_THREADS) void k_pose_solve(const int* __restrict__ cnt, const double* __restrict__ ed, int es, const double* __restrict__ pl, int ps, double* pose_io,
                                                             PoseRT* rt_out, vil_options O, const Pose1Out* prev, Pose1Out* out, Pose1Coop* coop, int epoch) {
     __shared__ Pose1Shared sh;
     __shared__ Pose1State st;
     const int t = threadIdx.x, g = blockIdx.x, G = gridDim.x;
     const int ne = cnt[0], np = cnt[1];
-    if (prev && prev->status != 0) { if (t == 0 && g == 0) { Pose1Out o = *prev; o.n_edge = ne; o.n_plane = np; *out = o; } return; }
+    const int prev_status = prev ? prev->status : 0;
+    if (prev_status != 0) { if (t == 0 && g == 0) { Pose1Out o = *prev; o.n_edge = ne; o.n_plane = np; *out = o; } return; }
     if (t < 7) sh.cand[t] = sh.x[t] = pose_io[t];
     if (t == 0) { st.cost = st.initial_cost = st.model_change = 0.0; st.iter = st.nsucc = st.invalid_run = 0; st.term = VIL_TERM_NONE; st.status = 0; st.first = 1; for (int q = 0; q < 6; ++q) st.tk[q] = 0; }
     __syncthreads();
@@ -291,43 +294,36 @@ __global__ __launch_bounds__(VP1_THREADS) void k_pose_solve(const int* __restric
 #endif
     while (true) {
         ++epoch;
+        double (*part)[28] = coop->part[epoch & 1];
         pose1_eval(sh, sh.cand, ne, ed, es, np, pl, ps, O.lidar_loss, O.lidar_loss_scale, O.precision);
         VP1_ST(st_eval0);
-        if (t < 28) __hip_atomic_store(&coop->part[g][t], sh.mine[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < 28) __hip_atomic_store(&part[g][t], sh.mine[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (t == 0) { __threadfence(); __hip_atomic_store(&coop->flag[g], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-        if (g != 0) {                                                // ---- workers: wait for the next command
-            if (t < 8) {                                             // eight lanes poll, then fetch the command and the pose side by side
-                while (__hip_atomic_load(&coop->go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
-                if (t < 7) sh.cand[t] = __hip_atomic_load(&coop->pose[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else sh.go = __hip_atomic_load(&coop->cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-            if (!sh.go) return;
-            continue;
-        }
         VP1_ST(st_eval);
-        // ---- workgroup 0: gather the partial sums in workgroup order
-        if (t < G) while (__hip_atomic_load(&coop->flag[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+        // every workgroup gathers everybody's partial sums (workgroup order: the same bits everywhere) ...
+        if (t < G) while (__hip_atomic_load(&coop->flag[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) __builtin_amdgcn_s_sleep(1);
         __syncthreads();
-        for (int e = t; e < 28 * G; e += VP1_THREADS) (&sh.gath[0][0])[e] = __hip_atomic_load(&coop->part[0][0] + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one load per thread, all in flight
+        {   // 28 G <= 1792 values, up to 7 per thread: issue every load before the first use
+            constexpr int NLD = (28 * VP1_MAXG + VP1_THREADS - 1) / VP1_THREADS;
+            double gv[NLD];
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) { const int e = t + u * VP1_THREADS; gv[u] = e < 28 * G ? __hip_atomic_load(&part[0][0] + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) { const int e = t + u * VP1_THREADS; if (e < 28 * G) (&sh.gath[0][0])[e] = gv[u]; }
+        }
         __syncthreads();
         if (t < 28) { double s = 0.0; for (int w = 0; w < G; ++w) s += sh.gath[w][t]; sh.sysn[t] = s; }
         __syncthreads();
         VP1_ST(st_gather);
-        if (t == 0) {
-            const bool more = pose1_serial(sh, st, O);
-            VP1_ST(st_call);
-            for (int q = 0; q < 7; ++q) __hip_atomic_store(&coop->pose[q], sh.cand[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&coop->cmd, more ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence();
-            __hip_atomic_store(&coop->go, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            sh.go = more ? 1 : 0;
-        }
+        // ... and runs the same trust-region pass on them: identical code on identical numbers, so all workgroups agree on
+        // the next candidate without another exchange
+        if (t == 0) { sh.go = pose1_serial(sh, st, O) ? 1 : 0; VP1_ST(st_call); }
         __syncthreads();
         VP1_ST(st_serial);
         if (!sh.go) break;
     }
+    if (g != 0) return;
 #ifdef VP1_STAMPS
     if (t == 0) printf("pose1: G %d iters %d  eval-compute %lld  publish %lld  gather %lld  serial %lld  [10 ns ticks]  call %lld = judge %lld system %lld dogleg %lld plus %lld save %lld\n", G, st.iter, st_eval0, st_eval, st_gather, st_serial, st_call, st.tk[0], st.tk[1], st.tk[2], st.tk[3], st.tk[4]);
 #endif

@@ -357,7 +357,7 @@ int align_fused(vmap_ctx* c, int n_corner, int n_surf, double* q, double* t, con
         hipLaunchKernelGGL(vp1::k_pose_solve, dim3(G), dim3(VP1_THREADS), 0, c->stream, c->d_cnt, edge_soa, es, plane_soa, ps, (double*)(c->d_reg + REG_POSE), (PoseD*)(c->d_reg + REG_RT), *opts,
                            round ? d_out : (const vp1::Pose1Out*)nullptr, d_out + round, c->d_coop, c->reg_epoch);
         c->reg_epoch += std::min(std::max(opts->max_iterations, 0), VP1_MAX_ITER) + 8;     // one epoch per evaluation: at most max_iterations + 1
-        if (c->reg_epoch > (1 << 30)) c->reg_epoch = 0;         // stale flags then hold values near 2^30, far from the small epochs that follow
+        if (c->reg_epoch > (1 << 30)) { c->reg_epoch = 0; VMCHK(hipMemsetAsync(c->d_coop, 0, sizeof(vp1::Pose1Coop), c->stream)); }   // flags are compared by order: start over from zeroed flags
     }
     VMCHK(hipMemcpyAsync(c->h_reg + REG_OUT, d_out, 2 * sizeof(vp1::Pose1Out), hipMemcpyDeviceToHost, c->stream));
     VMCHK(hipStreamSynchronize(c->stream));
