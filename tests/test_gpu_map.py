@@ -173,3 +173,38 @@ def test_pose_solve_many_in_a_row(hip, setup):
     for _ in range(300):
         q2, t2, s2 = g.align(hip.ctx, sc, ss, q0, t0)
         assert s2.iterations == s1.iterations and np.abs(t2 - t1).max() < 1e-12 and np.abs(q2 - q1).max() < 1e-12
+
+
+def test_registration_concurrent_with_window_solver(hip, setup):
+    """lidar_mapping and the estimator share the GPU: registrations (spinning cooperative workgroups) on one thread, window
+    solves (helper workgroups spinning on their own launch) on another, different streams -- neither starves the other and
+    both keep their answers."""
+    import threading
+    from mvil_fusion_amd import synth
+    g, o, sc, ss, R, t = setup
+    q0 = mapreg.quat_from_R(R @ _rot(0.004, -0.003, 0.008)); t0 = t + np.array([0.05, -0.04, 0.03])
+    solver_a = lib.open_vilsolve()                                   # the registration's fallback solver handle (unused on this path)
+    solver_b = lib.open_vilsolve()
+    w = synth.make_config(2, L=300, n_plane=6000, n_edge=1500)
+    opts = abi.default_options()
+    solver_b.upload(w); ref = solver_b.solve_resident(opts)
+    q1, t1, s1 = g.align(solver_a.ctx, sc, ss, q0, t0)
+    out = {"reg": [], "sol": []}
+
+    def reg():
+        for _ in range(150):
+            q2, t2, s2 = g.align(solver_a.ctx, sc, ss, q0, t0)
+            out["reg"].append((s2.iterations, float(np.abs(t2 - t1).max())))
+
+    def sol():
+        for _ in range(150):
+            solver_b.reset_state(); s = solver_b.solve_resident(opts)
+            out["sol"].append((s.iterations, s.final_cost))
+
+    th = [threading.Thread(target=reg), threading.Thread(target=sol)]
+    for x in th: x.start()
+    for x in th: x.join(timeout=120)
+    assert not any(x.is_alive() for x in th), "a launch starved"
+    assert len(out["reg"]) == 150 and all(it == s1.iterations and d < 1e-12 for it, d in out["reg"])
+    assert len(out["sol"]) == 150 and all(it == ref.iterations and abs(c - ref.final_cost) <= 1e-9 * ref.final_cost for it, c in out["sol"])
+    solver_a.close(); solver_b.close()
