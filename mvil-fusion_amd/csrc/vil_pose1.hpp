@@ -184,10 +184,9 @@ __device__ __forceinline__ void pose1_plus(const double* in, const double* d, do
     o[3] = q.x * n; o[4] = q.y * n; o[5] = q.z * n; o[6] = q.w * n;
 }
 
-// what workgroup 0 keeps between evaluations (LDS): the trust-region state, the linearisation at x, the loop counters
+// loop counters and costs of the trust-region logic (LDS; the trust-region state proper and the linearisation at x stay in
+// thread 0's registers across evaluations: 256-thread workgroups leave it 512 of them)
 struct Pose1State {
-    Dog6 dg;
-    double sys[27];
     double cost, initial_cost, model_change;
     int iter, nsucc, invalid_run, term, status, first;
     long long tk[6];             // VP1_STAMPS only
@@ -197,17 +196,13 @@ struct Pose1State {
 // evaluated (sh.sysn), then the checks before an iteration, the dogleg step and the next candidate (invalid steps retry
 // without an evaluation).  Returns false when the solve is finished.  Not inlined: its register working set (everything
 // unrolled over compile-time indices) must not compete with the evaluation loop's.
-__device__ __forceinline__ bool pose1_serial(Pose1Shared& sh, Pose1State& st, const vil_options& O) {
+__device__ __forceinline__ bool pose1_serial(Pose1Shared& sh, Pose1State& st, Dog6& dg, double* Hs /*21*/, double* bs /*6*/, const vil_options& O) {
 #ifdef VP1_STAMPS
     long long q0 = wall_clock64(), q1;
 #define VP1_SK(k) do { q1 = wall_clock64(); st.tk[k] += q1 - q0; q0 = q1; } while (0)
 #else
 #define VP1_SK(k)
 #endif
-    Dog6 dg = st.dg;
-    double Hs[21], bs[6];
-    VP1_U for (int q = 0; q < 21; ++q) Hs[q] = st.sys[q];
-    VP1_U for (int q = 0; q < 6; ++q) bs[q] = st.sys[21 + q];
     double cost = st.cost, model_change = st.model_change;
     int iter = st.iter, invalid_run = st.invalid_run, term = st.term;
     bool done = false;
@@ -262,9 +257,6 @@ __device__ __forceinline__ bool pose1_serial(Pose1Shared& sh, Pose1State& st, co
         if (++invalid_run >= 5) { term = VIL_TERM_FAILURE; done = true; break; }
         dg.mu *= 10.0; dg.reuse = false;
     }
-    st.dg = dg;
-    VP1_U for (int q = 0; q < 21; ++q) st.sys[q] = Hs[q];
-    VP1_U for (int q = 0; q < 6; ++q) st.sys[21 + q] = bs[q];
     st.cost = cost; st.model_change = model_change; st.iter = iter; st.invalid_run = invalid_run; st.term = term;
     VP1_SK(4);
     return !done;
@@ -292,6 +284,12 @@ __global__ __launch_bounds__(VP1_THREADS) void k_pose_solve(const int* __restric
 #else
 #define VP1_ST(acc)
 #endif
+    Dog6 dg;                                  // live in thread 0 only
+    double Hs[21], bs[6];
+    VP1_U for (int q = 0; q < 21; ++q) Hs[q] = 0.0;
+    VP1_U for (int q = 0; q < 6; ++q) bs[q] = 0.0;
+    VP1_U for (int q = 0; q < 6; ++q) { dg.Sc[q] = 1.0; dg.dc[q] = dg.idc[q] = 1.0; dg.grad[q] = dg.gn[q] = 0.0; }
+    dg.alpha = dg.radius = dg.mu = dg.step_norm = 0.0; dg.reuse = false;
     while (true) {
         ++epoch;
         double (*part)[28] = coop->part[epoch & 1];
@@ -318,7 +316,7 @@ __global__ __launch_bounds__(VP1_THREADS) void k_pose_solve(const int* __restric
         VP1_ST(st_gather);
         // ... and runs the same trust-region pass on them: identical code on identical numbers, so all workgroups agree on
         // the next candidate without another exchange
-        if (t == 0) { sh.go = pose1_serial(sh, st, O) ? 1 : 0; VP1_ST(st_call); }
+        if (t == 0) { sh.go = pose1_serial(sh, st, dg, Hs, bs, O) ? 1 : 0; VP1_ST(st_call); }
         __syncthreads();
         VP1_ST(st_serial);
         if (!sh.go) break;
