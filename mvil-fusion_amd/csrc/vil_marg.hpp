@@ -51,19 +51,6 @@ __device__ __forceinline__ void rr_pair(int k, int st, int np, int& p, int& q) {
 }
 
 // fp64 1/sqrt(x) and 1/x from the hardware seeds + Newton steps
-__device__ __forceinline__ double rsqrt_nr(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * (1.5 - 0.5 * x * y * y);
-    y = y * (1.5 - 0.5 * x * y * y);
-    return y;
-}
-__device__ __forceinline__ double rcp_nr(double x) {
-    double y = __builtin_amdgcn_rcp(x);
-    y = y * (2.0 - x * y);
-    y = y * (2.0 - x * y);
-    return y;
-}
-
 // Square root of a symmetric positive semi-definite matrix, in LDS, optionally orthogonalised into its eigen basis.
 //   in : M  n x n row-major in LDS (full, symmetric); bb (optional) right-hand side of length n in LDS
 //   out: row k of M = g_k with  sum_k g_k g_k^T = M_in ; lam[k] = |g_k|^2 ; bb -> y with sum_k g_k y_k = bb_in

@@ -122,6 +122,20 @@ __device__ __forceinline__ double wave_total(double v) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// hardware reciprocal (square root) estimate + two Newton steps: 1-2 ulp, a fraction of the IEEE divide / sqrt latency
+__device__ __forceinline__ double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+__device__ __forceinline__ double rcp_nr(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * (2.0 - x * y);
+    y = y * (2.0 - x * y);
+    return y;
+}
+
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
 // robust loss: rho(s), rho'(s) for ceres CauchyLoss(a)/HuberLoss(a). Both have rho'' <= 0, so the

@@ -44,9 +44,13 @@ __device__ __forceinline__ void jacobi3(double* A, double* V) {
             for (int q = p + 1; q < 3; ++q) {
                 const double apq = A[3 * p + q];
                 if (apq != 0.0) {
-                    const double tau = (A[3 * q + q] - A[3 * p + p]) / (2.0 * apq);
-                    const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    const double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
+                    // the rotation of the textbook form  tau = d / (2 apq), t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), c = 1 / sqrt(1 + t^2), s = t c
+                    // written without its three divisions: u = |d| + sqrt(d^2 + 4 apq^2), c = u / sqrt(u^2 + 4 apq^2), s = sgn(tau) 2 |apq| / sqrt(...)
+                    // (a lone thread's divide / sqrt latency is what this kernel costs: 2 reciprocal square roots per rotation instead of 2 sqrt + 3 div)
+                    const double d = A[3 * q + q] - A[3 * p + p], a2 = 4.0 * apq * apq, h2 = d * d + a2;
+                    const double u = fabs(d) + h2 * vd::rsqrt_nr(h2), r = vd::rsqrt_nr(u * u + a2);
+                    const bool pos = (d >= 0.0 && apq > 0.0) || (d <= 0.0 && apq < 0.0);
+                    const double c = u * r, sn = (pos ? 2.0 : -2.0) * fabs(apq) * r;
 #pragma unroll
                     for (int r = 0; r < 3; ++r) { const double akp = A[3 * r + p], akq = A[3 * r + q]; A[3 * r + p] = c * akp - sn * akq; A[3 * r + q] = sn * akp + c * akq; }
 #pragma unroll
