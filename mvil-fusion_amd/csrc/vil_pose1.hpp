@@ -129,7 +129,7 @@ struct Dog6 {
     }
     __device__ __forceinline__ bool compute_system(const double* H, const double* b, double min_mu, double max_mu) {
         double v[6], g2 = 0.0;
-        VP1_U for (int i = 0; i < 6; ++i) { const double s = Sc[i] * Sc[i] * H[tri6(i, i)]; dc[i] = sqrt(fmin(fmax(s, 1e-6), 1e32)); idc[i] = 1.0 / dc[i]; }
+        VP1_U for (int i = 0; i < 6; ++i) { const double s = fmin(fmax(Sc[i] * Sc[i] * H[tri6(i, i)], 1e-6), 1e32); idc[i] = rsqrt_nr(s); dc[i] = s * idc[i]; }
         VP1_U for (int i = 0; i < 6; ++i) grad[i] = Sc[i] * b[i] * idc[i];
         VP1_U for (int i = 0; i < 6; ++i) { v[i] = Sc[i] * grad[i] * idc[i]; g2 += grad[i] * grad[i]; }
         alpha = g2 / quad(H, v);
@@ -142,7 +142,7 @@ struct Dog6 {
                 double d = Sc[j] * H[tri6(j, j)] * Sc[j] + mu * dc[j] * dc[j];
                 VP1_U for (int k = 0; k < j; ++k) d -= Lo[tri6(k, j)] * Lo[tri6(k, j)];
                 chol = chol && d > 0.0;
-                d = sqrt(d); Lo[tri6(j, j)] = d; rd[j] = 1.0 / d;
+                rd[j] = rsqrt_nr(d); Lo[tri6(j, j)] = d * rd[j];          // hardware estimate + two Newton steps: the six pivots are one dependency chain
                 VP1_U for (int i = j + 1; i < 6; ++i) { double s = Sc[i] * H[tri6(i, j)] * Sc[j]; VP1_U for (int k = 0; k < j; ++k) s -= Lo[tri6(k, i)] * Lo[tri6(k, j)]; Lo[tri6(j, i)] = s * rd[j]; }
             }
             if (chol) {
