@@ -122,6 +122,44 @@ __device__ __forceinline__ double wave_total(double v) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// Fold of N <= 32 per-lane values over the wave at once.  A value-by-value fold spends 6 steps on each of the N registers; here
+// every exchange step also halves the number of live registers: lane pairs (i, i ^ m), m = 15, 7, 3, 1 (row_mirror,
+// row_half_mirror and two quad permutations: a basis of the 16 lanes of a row), split the register pairs between them -- the
+// lane whose distinguishing bit is 0 keeps collecting the even register, its partner the odd one.  After the four steps lane j of
+// a row holds the row totals of values 16 s + rev4(j) (s = 0, 1; rev4 = the four lane bits reversed) in two registers; two
+// butterflies across the rows (the only LDS-crossbar traffic: 8 ds_bpermute) leave the wave totals in every row:
+// out[s] on lane 16 r + j  =  total of value 16 s + rev4(j).  ~230 instructions for 28 values instead of ~560.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false));
+}
+template <int N, int M, int CTRL>
+__device__ __forceinline__ void fold_step(double* r, bool bit) {          // N live registers -> (N + 1) / 2
+#pragma unroll
+    for (int k = 0; k < (N + 1) / 2; ++k) {
+        const double a = r[2 * k], b = (2 * k + 1 < N) ? r[2 * k + 1] : 0.0;
+        const double keep = bit ? b : a, send = bit ? a : b;
+        r[k] = keep + dpp_move<CTRL>(send);
+    }
+}
+__device__ __forceinline__ int fold_slot(int lane) { const int j = lane & 15; return ((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3); }   // rev4
+template <int N>
+__device__ __forceinline__ void wave_fold(const double* v, double& out0, double& out1) {
+    static_assert(N >= 1 && N <= 32, "wave_fold: at most 32 values");
+    const int lane = threadIdx.x & 63;
+    double r[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) r[q] = q < N ? v[q] : 0.0;
+    fold_step<32, 15, 0x140>(r, (lane & 8) != 0);          // row_mirror
+    fold_step<16, 7, 0x141>(r, (lane & 4) != 0);           // row_half_mirror
+    fold_step<8, 3, 0x1B>(r, (lane & 2) != 0);             // quad_perm [3 2 1 0]
+    fold_step<4, 1, 0xB1>(r, (lane & 1) != 0);             // quad_perm [1 0 3 2]
+    // the four rows hold lane-wise partials: a lane-wise exchange across rows is not a DPP pattern, two butterflies through the LDS crossbar
+    out0 = r[0]; out1 = r[1];
+    out0 += __shfl_xor(out0, 16, 64); out1 += __shfl_xor(out1, 16, 64);
+    out0 += __shfl_xor(out0, 32, 64); out1 += __shfl_xor(out1, 32, 64);
+}
+
 // hardware reciprocal (square root) estimate + two Newton steps: 1-2 ulp, a fraction of the IEEE divide / sqrt latency
 __device__ __forceinline__ double rsqrt_nr(double x) {
     double y = __builtin_amdgcn_rsq(x);

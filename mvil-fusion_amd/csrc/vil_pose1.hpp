@@ -101,12 +101,9 @@ __device__ __forceinline__ void pose1_eval(Pose1Shared& sh, const double* pose, 
             acc[21 + a] += rho1 * (J[a] * r[0] + J[6 + a] * r[1] + J[12 + a] * r[2]);
         }
     }
-#pragma unroll
-    for (int q = 0; q < 28; ++q) acc[q] = wave_total(acc[q]);
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < 28; ++q) sh.red[wave][q] = acc[q];
-    }
+    double f0, f1;
+    wave_fold<28>(acc, f0, f1);                           // lanes 0..15: totals of values rev4(lane) and 16 + rev4(lane)
+    if (lane < 16) { const int q = fold_slot(lane); sh.red[wave][q] = f0; if (q + 16 < 28) sh.red[wave][q + 16] = f1; }
     __syncthreads();
     if (t < 28) { double s = 0.0; for (int w = 0; w < VP1_WAVES; ++w) s += sh.red[w][t]; sh.mine[t] = s; }
     __syncthreads();

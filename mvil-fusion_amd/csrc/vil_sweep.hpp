@@ -331,13 +331,10 @@ __device__ __forceinline__ void sweep_lidar(const DevP& P, const SolveOpts& O, i
             }
         }
     }
-#pragma unroll
-    for (int q = 0; q < 28; ++q) acc[q] = wave_total(acc[q]);
     const int wave = t >> 6, lane = t & 63;
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < 28; ++q) sm[wave * 28 + q] = acc[q];
-    }
+    double f0, f1;
+    wave_fold<28>(acc, f0, f1);                           // lanes 0..15: totals of values rev4(lane) and 16 + rev4(lane)
+    if (lane < 16) { const int q = fold_slot(lane); sm[wave * 28 + q] = f0; if (q + 16 < 28) sm[wave * 28 + q + 16] = f1; }
     __syncthreads();
     const int gchunk = (NR == 1 ? 0 : P.n_pchunk) + chunk;
     if (have && t < 28) P.lpart[(size_t)gchunk * 28 + t] = sm[t] + sm[28 + t] + sm[56 + t] + sm[84 + t];

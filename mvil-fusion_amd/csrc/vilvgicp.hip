@@ -54,9 +54,15 @@ template <int NV>
 __device__ __forceinline__ void block_fold(double* v, double* part /* gridDim.x x NV */) {
     __shared__ double sm[4][NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (NV > 2) {                                        // all values in one pass (vil_math.hpp wave_fold): lanes 0..15 end with the totals
+        double f0, f1;
+        vd::wave_fold<NV>(v, f0, f1);
+        if (lane < 16) { const int q = vd::fold_slot(lane); if (q < NV) sm[wave][q] = f0; if (q + 16 < NV) sm[wave][q + 16] = f1; }
+    } else {
 #pragma unroll
-    for (int q = 0; q < NV; ++q) v[q] = wave_sum64(v[q]);
-    if (lane == 0) for (int q = 0; q < NV; ++q) sm[wave][q] = v[q];
+        for (int q = 0; q < NV; ++q) v[q] = wave_sum64(v[q]);
+        if (lane == 0) for (int q = 0; q < NV; ++q) sm[wave][q] = v[q];
+    }
     __syncthreads();
     if (threadIdx.x < NV) part[(size_t)blockIdx.x * NV + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
