@@ -8,6 +8,7 @@ row() { # name, bench args...
 }
 row mapreg --mapreg --steps 200 --warmup 5
 row vgicp16 --vgicp --steps 200 --warmup 5
+timeout 400 python $R/bench.py --vgicp --vgicp-rings 64 --vgicp-az 2048 --steps 200 --warmup 5 > $O/r01_vgicp64.json 2>/dev/null
 row preint --preint --steps 300 --warmup 10
 timeout 600 python $R/bench.py --mapreg --map-surf 256000 --map-corner 85000 --scan-surf 25600 --scan-corner 8500 --steps 50 --warmup 3 > $O/r01_mapreg_big.json 2>/dev/null
 ls -la $O | tail -12
