@@ -34,17 +34,17 @@ def algorithmic_bytes(w):
             + 8 * (n * n + n) + 8 * (16 * w.K + 8))
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per live k_sweep launch from the committed rocprofv3 --pmc passes of THIS command (profiles/):
+def pmc_traffic_bytes(files=("r01_pmc_fetch_size.csv", "r01_pmc_write_size.csv"), kernel="k_sweep"):
+    """HBM bytes per live launch of `kernel` from the committed rocprofv3 --pmc passes of THIS command (profiles/):
     (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md (HBM section),
     WRITE_SIZE uncalibrated.  None if the CSVs are missing."""
     import csv
     tot = 0.0
-    for fn, mult in (("r01_pmc_fetch_size.csv", 2.0), ("r01_pmc_write_size.csv", 1.0)):
+    for fn, mult in ((files[0], 2.0), (files[1], 1.0)):
         path = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(path):
             return None
-        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if r["Kernel_Name"].startswith("k_sweep")]
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel in r["Kernel_Name"]]
         if not v:
             return None
         live = [x for x in v if x > 0.25 * max(v)]
@@ -201,7 +201,10 @@ def vgicp_mode(args):
                       "alignments_per_s": na / el_a, "lm_iterations_per_alignment": int(sg.iterations), "covariances_20nn_ms": cov_ms,
                       "translation_error_m": float(np.abs(Tg[:3, 3] - T_true[:3, 3]).max())},
            "roofline": {"bound": "hbm", "kernel": "k_vgicp_lin", "achieved": ab / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ab / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": ab, "avg_launch_us": k_us, "launches_timed": int(pn.value),
+                        "frac": ab / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": pmc_traffic_bytes(("r01_vgicp64_pmc_FETCH_SIZE.csv", "r01_vgicp64_pmc_WRITE_SIZE.csv"), "k_vgicp_lin") if (rings, az) == (64, 2048) else None,
+                        "traffic_source": "profiles/r01_vgicp64_pmc_*.csv (64-ring x 2048 pair only; tools/collect_pmc_rows.sh)",
+                        "algorithmic_bytes_per_launch": ab, "avg_launch_us": k_us, "launches_timed": int(pn.value),
                         "note": "HIP events on the library's stream around the kernel; a whole vgicp_linearize call is %.1f us of wall time (2 launches + D2H of 29 doubles + stream sync)" % (1e6 * el / args.steps)}}
     if not args.no_cpu:
         orc = vgicp.Vgicp(C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "orc_vgicp_")
@@ -271,7 +274,10 @@ def mapreg_mode(args):
                       "associate_ms": 1e3 * el_assoc / args.steps, "set_map_ms": 1e3 * t_map, "solve_iterations_last_round": int(sg.iterations),
                       "translation_error_m": float(np.linalg.norm(tg - t)), "k_map_fit_us": f_us},
            "roofline": {"bound": "hbm", "kernel": "k_map_search", "achieved": ab / (s_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ab / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": ab, "avg_launch_us": s_us, "launches_timed": int(pn[0]),
+                        "frac": ab / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": pmc_traffic_bytes(("r01_mapreg_pmc_FETCH_SIZE.csv", "r01_mapreg_pmc_WRITE_SIZE.csv"), "k_map_search") if (len(sc), len(ss), len(cm), len(sm)) == (800, 6000, 8000, 60000) else None,
+                        "traffic_source": "profiles/r01_mapreg_pmc_*.csv (default sizes only; tools/collect_pmc_rows.sh)",
+                        "algorithmic_bytes_per_launch": ab, "avg_launch_us": s_us, "launches_timed": int(pn[0]),
                         "note": "one wave per scan point: 27-cell gather, coalesced candidate loads, sorted list across the wave's lanes"}}
     if not args.no_cpu:
         o = mapreg.MapReg(C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "orc_vmap_")
