@@ -79,12 +79,12 @@ __device__ __forceinline__ void qr_solve_5x3(double* P, double* b, double* x) {
 #pragma unroll
         for (int c = k; c < 3; ++c) { double s = 0; for (int r = k; r < 5; ++r) s += P[3 * r + c] * P[3 * r + c]; if (s > best) { best = s; pv = c; } }
         if (pv != k) { for (int r = 0; r < 5; ++r) { const double tmp = P[3 * r + k]; P[3 * r + k] = P[3 * r + pv]; P[3 * r + pv] = tmp; } const int tp = perm[k]; perm[k] = perm[pv]; perm[pv] = tp; }
-        const double nrm = sqrt(best), akk = P[3 * k + k], alpha = akk > 0 ? -nrm : nrm;
+        const double nrm = best > 0.0 ? best * vd::rsqrt_nr(best) : 0.0, akk = P[3 * k + k], alpha = akk > 0 ? -nrm : nrm;   // reciprocal estimates + Newton steps: this thread's divide / sqrt chain is the kernel's critical path
         const double v0 = akk - alpha;
         double vv = v0 * v0;
         for (int r = k + 1; r < 5; ++r) vv += P[3 * r + k] * P[3 * r + k];
         if (vv > 0) {
-            const double beta = 2.0 / vv;
+            const double beta = 2.0 * vd::rcp_nr(vv);
 #pragma unroll
             for (int c = k + 1; c < 3; ++c) {
                 double s = v0 * P[3 * k + c];
@@ -102,9 +102,10 @@ __device__ __forceinline__ void qr_solve_5x3(double* P, double* b, double* x) {
         P[3 * k + k] = alpha;
     }
     double y[3];
-    y[2] = b[2] / P[8];
-    y[1] = (b[1] - P[5] * y[2]) / P[4];
-    y[0] = (b[0] - P[1] * y[1] - P[2] * y[2]) / P[0];
+    const double r0 = vd::rcp_nr(P[0]), r1 = vd::rcp_nr(P[4]), r2 = vd::rcp_nr(P[8]);      // independent of each other (a zero pivot gives a NaN the caller rejects)
+    y[2] = b[2] * r2;
+    y[1] = (b[1] - P[5] * y[2]) * r1;
+    y[0] = (b[0] - P[1] * y[1] - P[2] * y[2]) * r0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) x[perm[k]] = y[k];
 }
@@ -114,7 +115,8 @@ __device__ __forceinline__ void qr_solve_5x3(double* P, double* b, double* x) {
 //      (or a value >= 1 when the query is rejected: fewer than five map points within 1 m, localMapping.cpp:613,:705)
 #define VM_QPB 4
 __global__ __launch_bounds__(64 * VM_QPB) void k_map_search(int nqc, int nqs, const float* __restrict__ scan, PoseD T, const PoseD* __restrict__ Tdev, int ncm, GridTab Gc, const int* __restrict__ oc, const float* __restrict__ xc,
-                                                            int nsm, GridTab Gs, const int* __restrict__ os, const float* __restrict__ xs, int* __restrict__ nn, float* __restrict__ nd5) {
+                                                            int nsm, GridTab Gs, const int* __restrict__ os, const float* __restrict__ xs, int* __restrict__ nn, float* __restrict__ nd5,
+                                                            const float* __restrict__ smap4, float* __restrict__ nint) {
     __shared__ int wl_all[VM_QPB * KNN_WL_CAP];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int qi = blockIdx.x * VM_QPB + wave;
@@ -131,13 +133,19 @@ __global__ __launch_bounds__(64 * VM_QPB) void k_map_search(int nqc, int nqs, co
                              : knn_wave_query(best, sx, sy, sz, 5, ncm, Gc, oc, xc, wl_all + wave * KNN_WL_CAP, 1.0f, 5);
         if (ok) d5 = knn_key_d(readlane_u64(best, 4));
     }
-    if (lane < 10) nn[10 * (size_t)qi + lane] = (int)(unsigned)best;
+    if (lane < 10) {
+        const unsigned idx = (unsigned)best;
+        nn[10 * (size_t)qi + lane] = (int)idx;
+        // the fit re-ranks a surf point's ten neighbours by intensity: fetch the ten intensities here, ten lanes side by side with
+        // thousands of other waves to hide the gather behind, instead of ten dependent loads in the fit's lone thread
+        if (surf) nint[10 * (size_t)qi + lane] = idx < (unsigned)nsm ? smap4[4 * (size_t)idx + 3] : 0.0f;
+    }
     if (lane == 0) nd5[qi] = d5;
 }
 
 // ---- fit: one thread per scan point; slot = 10 doubles: corner [valid, cp(3), a(3), b(3)], surf [valid, cp(3), n(3), d, -]
 __device__ __forceinline__ bool map_fit_one(int i, int nqc, const float* __restrict__ scan, const float* __restrict__ cmap, const float* __restrict__ smap,
-                                            const int* __restrict__ nn, const float* __restrict__ nd5, double* __restrict__ slot) {
+                                            const int* __restrict__ nn, const float* __restrict__ nd5, const float* __restrict__ nint, double* __restrict__ slot) {
     double* o = slot + (size_t)10 * i;
     o[0] = 0.0;
     if (!(nd5[i] < 1.0f)) return false;
@@ -168,7 +176,7 @@ __device__ __forceinline__ bool map_fit_one(int i, int nqc, const float* __restr
     const float qi = scan[4 * i + 3];
     KnnList S; knn_init(S);
 #pragma unroll
-    for (int m = 0; m < 10; ++m) knn_insert(S, fabsf(smap[4 * nb[m] + 3] - qi), nb[m]);
+    for (int m = 0; m < 10; ++m) knn_insert(S, fabsf(nint[10 * (size_t)i + m] - qi), nb[m]);      // intensities gathered by the search kernel
     double P[15], Q[15], rhs[5] = {-1, -1, -1, -1, -1}, nv[3] = {0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 5; ++j) { P[3 * j] = (double)smap[4 * S.bi[j]]; P[3 * j + 1] = (double)smap[4 * S.bi[j] + 1]; P[3 * j + 2] = (double)smap[4 * S.bi[j] + 2]; }
@@ -176,9 +184,8 @@ __device__ __forceinline__ bool map_fit_one(int i, int nqc, const float* __restr
     for (int j = 0; j < 15; ++j) Q[j] = P[j];
     qr_solve_5x3(Q, rhs, nv);
     double nx = nv[0], ny = nv[1], nz = nv[2];
-    const double nrm = sqrt(nx * nx + ny * ny + nz * nz);
-    const double d = 1.0 / nrm;
-    nx /= nrm; ny /= nrm; nz /= nrm;
+    const double d = vd::rsqrt_nr(nx * nx + ny * ny + nz * nz);          // 1 / |n|
+    nx *= d; ny *= d; nz *= d;
     bool ok = isfinite(d) && isfinite(nx);
 #pragma unroll
     for (int j = 0; j < 5; ++j) ok = ok && !(fabs(nx * P[3 * j] + ny * P[3 * j + 1] + nz * P[3 * j + 2] + d) > 0.2);
@@ -189,12 +196,12 @@ __device__ __forceinline__ bool map_fit_one(int i, int nqc, const float* __restr
 }
 // blk[2 b], blk[2 b + 1] = accepted corner / surf slots of workgroup b: the compaction's offsets without a second pass over the slots
 __global__ __launch_bounds__(VM_THREADS) void k_map_fit(int nqc, int nqs, const float* __restrict__ scan, const float* __restrict__ cmap, const float* __restrict__ smap,
-                                                        const int* __restrict__ nn, const float* __restrict__ nd5, double* __restrict__ slot, int* __restrict__ blk) {
+                                                        const int* __restrict__ nn, const float* __restrict__ nd5, const float* __restrict__ nint, double* __restrict__ slot, int* __restrict__ blk) {
     __shared__ int s_cnt[2];
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const int i = blockIdx.x * VM_THREADS + threadIdx.x;
-    const bool ok = i < nqc + nqs && map_fit_one(i, nqc, scan, cmap, smap, nn, nd5, slot);
+    const bool ok = i < nqc + nqs && map_fit_one(i, nqc, scan, cmap, smap, nn, nd5, nint, slot);
     const unsigned long long be = __ballot(ok && i < nqc), bp = __ballot(ok && i >= nqc);
     if ((threadIdx.x & 63) == 0) { if (be) atomicAdd(&s_cnt[0], __popcll(be)); if (bp) atomicAdd(&s_cnt[1], __popcll(bp)); }
     __syncthreads();
@@ -262,7 +269,7 @@ namespace {
 #define VM_OCC 6.0              // points per occupied grid cell the cell sizes are steered to
 int upload_scan(vmap_ctx* c, int n_corner, const float* corner, int n_surf, const float* surf) {
     const int nq = n_corner + n_surf;
-    const size_t need_scan = 16 * (size_t)nq + 16, need_work = (size_t)nq * (40 + 4 + 80) + 8 * ((size_t)nq / VM_THREADS + 1) + 256;
+    const size_t need_scan = 16 * (size_t)nq + 16, need_work = (size_t)nq * (40 + 4 + 80 + 40) + 8 * ((size_t)nq / VM_THREADS + 1) + 256;
     if (need_scan > c->scan_cap) { hipFree(c->d_scan); c->d_scan = nullptr; c->scan_cap = 0; VMCHK(hipMalloc(&c->d_scan, 2 * need_scan)); c->scan_cap = 2 * need_scan; }
     if (need_work > c->work_cap) { hipFree(c->d_work); c->d_work = nullptr; c->work_cap = 0; VMCHK(hipMalloc(&c->d_work, 2 * need_work)); c->work_cap = 2 * need_work; }
     // through a pinned image: one DMA instead of two staged pageable copies (every entry point ends with a stream
@@ -281,12 +288,12 @@ int associate_uploaded(vmap_ctx* c, int n_corner, int n_surf, const double* q, c
     const int nq = n_corner + n_surf;
     if (nq == 0 || nqc + nqs == 0) return VM_OK;
     // queries are addressed in the uploaded layout (corner block, then surf block); a class without a map is skipped by nmap < k
-    double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq); int* d_blk = (int*)(c->d_work + (((size_t)124 * nq + 7) & ~(size_t)7));
+    double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq); float* d_nint = d_nd5 + nq; int* d_blk = (int*)(c->d_work + (((size_t)164 * nq + 7) & ~(size_t)7));
     if (c->profiling) hipEventRecord(c->ev[0], c->stream);
     hipLaunchKernelGGL(k_map_search, dim3((nq + VM_QPB - 1) / VM_QPB), dim3(64 * VM_QPB), 0, c->stream, n_corner, n_surf, c->d_scan, T, (const PoseD*)nullptr, c->nc, c->gc.G, c->gc.order, c->gc.cxyz,
-                       c->ns, c->gs.G, c->gs.order, c->gs.cxyz, d_nn, d_nd5);
+                       c->ns, c->gs.G, c->gs.order, c->gs.cxyz, d_nn, d_nd5, c->d_smap, d_nint);
     if (c->profiling) { hipEventRecord(c->ev[1], c->stream); hipEventRecord(c->ev[2], c->stream); }
-    hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_slot, d_blk);
+    hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_nint, d_slot, d_blk);
     if (c->profiling) hipEventRecord(c->ev[3], c->stream);
     if (10 * (size_t)nq > c->h_slot_cap) {
         if (c->h_slot) hipHostFree(c->h_slot);
@@ -312,10 +319,10 @@ int associate_device(vmap_ctx* c, int n_corner, int n_surf, const double* q, con
     if (!c->d_cnt) { VMCHK(hipMalloc(&c->d_cnt, 16)); VMCHK(hipHostMalloc((void**)&c->h_cnt, 16, hipHostMallocDefault)); }
     dl->edge_soa = c->d_soa; dl->edge_stride = es; dl->plane_soa = c->d_soa + (size_t)9 * es; dl->plane_stride = ps;
     if (nq == 0) return VM_OK;
-    double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq); int* d_blk = (int*)(c->d_work + (((size_t)124 * nq + 7) & ~(size_t)7));
+    double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq); float* d_nint = d_nd5 + nq; int* d_blk = (int*)(c->d_work + (((size_t)164 * nq + 7) & ~(size_t)7));
     hipLaunchKernelGGL(k_map_search, dim3((nq + VM_QPB - 1) / VM_QPB), dim3(64 * VM_QPB), 0, c->stream, n_corner, n_surf, c->d_scan, T, (const PoseD*)nullptr, c->nc, c->gc.G, c->gc.order, c->gc.cxyz,
-                       c->ns, c->gs.G, c->gs.order, c->gs.cxyz, d_nn, d_nd5);
-    hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_slot, d_blk);
+                       c->ns, c->gs.G, c->gs.order, c->gs.cxyz, d_nn, d_nd5, c->d_smap, d_nint);
+    hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_nint, d_slot, d_blk);
     hipLaunchKernelGGL(k_map_compact, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, d_slot, d_blk, c->d_soa, es, c->d_soa + (size_t)9 * es, ps, c->d_cnt);
     VMCHK(hipMemcpyAsync(c->h_cnt, c->d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
     VMCHK(hipStreamSynchronize(c->stream));
@@ -346,15 +353,15 @@ int align_fused(vmap_ctx* c, int n_corner, int n_surf, double* q, double* t, con
     h_pose[0] = t[0]; h_pose[1] = t[1]; h_pose[2] = t[2]; h_pose[3] = q[0]; h_pose[4] = q[1]; h_pose[5] = q[2]; h_pose[6] = q[3];
     VMCHK(hipMemcpyAsync(c->d_reg + REG_POSE, h_pose, 56, hipMemcpyHostToDevice, c->stream));
     PoseD T; quat_to_R(q, T.R); T.t[0] = t[0]; T.t[1] = t[1]; T.t[2] = t[2];
-    double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq); int* d_blk = (int*)(c->d_work + (((size_t)124 * nq + 7) & ~(size_t)7));
+    double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq); float* d_nint = d_nd5 + nq; int* d_blk = (int*)(c->d_work + (((size_t)164 * nq + 7) & ~(size_t)7));
     vp1::Pose1Out* d_out = (vp1::Pose1Out*)(c->d_reg + REG_OUT);
     for (int round = 0; round < 2; ++round) {
         if (nq > 0) {
             if (c->profiling && round == 0) VMCHK(hipEventRecord(c->ev[0], c->stream));
             hipLaunchKernelGGL(k_map_search, dim3((nq + VM_QPB - 1) / VM_QPB), dim3(64 * VM_QPB), 0, c->stream, n_corner, n_surf, c->d_scan, T, round ? (const PoseD*)(c->d_reg + REG_RT) : (const PoseD*)nullptr,
-                               c->nc, c->gc.G, c->gc.order, c->gc.cxyz, c->ns, c->gs.G, c->gs.order, c->gs.cxyz, d_nn, d_nd5);
+                               c->nc, c->gc.G, c->gc.order, c->gc.cxyz, c->ns, c->gs.G, c->gs.order, c->gs.cxyz, d_nn, d_nd5, c->d_smap, d_nint);
             if (c->profiling && round == 0) VMCHK(hipEventRecord(c->ev[1], c->stream));
-            hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_slot, d_blk);
+            hipLaunchKernelGGL(k_map_fit, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, c->d_scan, c->d_cmap, c->d_smap, d_nn, d_nd5, d_nint, d_slot, d_blk);
             if (c->profiling && round == 0) VMCHK(hipEventRecord(c->ev[2], c->stream));
             hipLaunchKernelGGL(k_map_compact, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, d_slot, d_blk, edge_soa, es, plane_soa, ps, c->d_cnt);
         } else VMCHK(hipMemsetAsync(c->d_cnt, 0, 8, c->stream));
