@@ -36,9 +36,17 @@ public:
 
     // addFeatureCheckParallax (feature_manager.cpp:44-106): appends the observations of image `frame_count`; returns true when
     // the second-newest frame is a keyframe (=> MARGIN_OLD), false => MARGIN_SECOND_NEW.  obs8 = n x [x y z u v vx vy depth].
+    // The reference receives the image as a std::map<int, ...> and walks it in ascending feature id (feature_manager.cpp:51),
+    // which fixes the order of f_manager.feature, hence feature_index / para_Feature and the factor order: the observations
+    // are visited in ascending id here too, whatever order the caller's arrays are in (first entry wins for a repeated id).
     bool add_frame(int frame_count, const int* ids, const double* obs8, int n, double td) {
         last_track_num = 0;
-        for (int k = 0; k < n; ++k) {
+        std::vector<int> order(n);
+        for (int k = 0; k < n; ++k) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ids[a] < ids[b]; });
+        for (int q = 0; q < n; ++q) {
+            const int k = order[q];
+            if (q > 0 && ids[k] == ids[order[q - 1]]) continue;       // std::map keeps one entry per id
             FeatureObs o;
             const double* p = obs8 + 8 * (size_t)k;
             o.point[0] = p[0]; o.point[1] = p[1]; o.point[2] = p[2]; o.uv[0] = p[3]; o.uv[1] = p[4]; o.velocity[0] = p[5]; o.velocity[1] = p[6]; o.depth = p[7]; o.cur_td = td;

@@ -184,7 +184,10 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             else Sl = P.Sl[l];
             double dl2 = Sl * Sl * h; dl2 = fmin(fmax(dl2, 1e-6), 1e32);
             const double p = ctl.lin_mode ? h : h + ctl.mu * dl2 / (Sl * Sl);
-            const double invp = (cl || !(p > 0.0)) ? 0.0 : 1.0 / p;
+            // lin_mode 2 (marginalisation): MarginalizationInfo's pseudo inverse zeroes every direction of A_mm whose eigenvalue is
+            // <= eps = 1e-8 (marginalization_factor.cpp:277); for a landmark without parallax that direction IS the landmark
+            // (eigenvalue = h_ll to first order), so its pivot is dropped and its factors enter the prior as if it were fixed
+            const double invp = (cl || !(p > (ctl.lin_mode == 2 ? 1e-8 : 0.0))) ? 0.0 : 1.0 / p;
             const double ib = invp * b;
             double* lr = lmr + tl * 16;
             if (k == 13) { sb.hll[l] = h; sb.bl[l] = b; sb.invp[l] = invp; lr[0] = invp; lr[14] = (double)a; }

@@ -83,7 +83,10 @@ struct LocalComm {
     int n = 0;
     pthread_barrier_t bar;
     double* ptr[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int err[8] = {0, 0, 0, 0, 0, 0, 0, 0};        // per-rank status of the current collective: an error on one rank is an error on all (nobody is left at a barrier)
     ~LocalComm() { if (n) pthread_barrier_destroy(&bar); }
+    // every rank posts its status, waits, and reads the worst one: collective error exits
+    int agree(int rank, int st) { err[rank] = st; pthread_barrier_wait(&bar); int w = 0; for (int r = 0; r < n; ++r) w = std::min(w, err[r]); pthread_barrier_wait(&bar); return w; }
 };
 struct PeerPtrs { const double* p[8]; int n; };
 __global__ void k_sum_peers(double* out, PeerPtrs pp, size_t cnt) {
@@ -102,6 +105,8 @@ struct vil_ctx {
     hipEvent_t up_ev = nullptr; bool up_pending = false;   // the DMA out of the pinned image must finish before the image is rewritten
     DevP P;                        // device pointers
     bool uploaded = false;
+    int resident_kind = 0;         // 1: a window handed over through vil_upload / vil_solve (the only kind vil_solve_resident accepts);
+                                   // 2: a derived problem of vil_marginalize / vil_eval_factors / vil_linearize (they replace the resident window)
     int K = 0, L = 0, D = 0, NS = 0;
     size_t off_x0 = 0;             // backup of the uploaded state (device)
     double* d_x0 = nullptr;
@@ -227,20 +232,42 @@ void vil_destroy(vil_ctx* c) {
 static int validate(const vil_problem* p, const vil_state* s, bool device_lidar = false) {
     if (!p || !s) return VIL_ERR_INVALID_ARGUMENT;
     if (p->K < 1 || p->L < 0 || s->K != p->K || s->L != p->L) return VIL_ERR_INVALID_ARGUMENT;
+    if (!s->pose || !s->speedbias || !s->ex_pose || !s->td || (p->L > 0 && !s->inv_depth)) return VIL_ERR_INVALID_ARGUMENT;
     if (15 * p->K + 7 > 320) return VIL_ERR_UNSUPPORTED;   // K <= 20 (step kernel work space)
-    if (p->n_icp + p->n_lps > 12 || p->n_icp < 0 || p->n_lps < 0) return VIL_ERR_UNSUPPORTED;   // reference trims to 5 + 7 (estimator.cpp:1283-1286,1345-1348)
+    if (p->n_vis < 0 || p->n_imu < 0 || p->n_icp < 0 || p->n_lps < 0 || p->n_plane < 0 || p->n_edge < 0 || p->prior.n < 0) return VIL_ERR_INVALID_ARGUMENT;
+    if (p->n_icp + p->n_lps > 12) return VIL_ERR_UNSUPPORTED;   // reference trims to 5 + 7 (estimator.cpp:1283-1286,1345-1348)
     if (p->prior.n > 512 || p->prior.nblk > 256) return VIL_ERR_UNSUPPORTED;
+    // a table may be NULL only when its count is zero
+    if (p->n_vis > 0 && (!p->vis_i || !p->vis_j || !p->vis_l || !p->vis_const)) return VIL_ERR_INVALID_ARGUMENT;
+    if (p->n_imu > 0 && (!p->imu_i || !p->imu_j || !p->imu_const)) return VIL_ERR_INVALID_ARGUMENT;
+    if (p->n_icp > 0 && (!p->icp_ids || !p->icp_const)) return VIL_ERR_INVALID_ARGUMENT;
+    if (p->n_lps > 0 && (!p->lps_ids || !p->lps_const)) return VIL_ERR_INVALID_ARGUMENT;
+    if (!device_lidar && p->n_plane > 0 && (!p->plane_pose || !p->plane_const)) return VIL_ERR_INVALID_ARGUMENT;
+    if (!device_lidar && p->n_edge > 0 && (!p->edge_pose || !p->edge_const)) return VIL_ERR_INVALID_ARGUMENT;
     for (int f = 0; f < p->n_vis; ++f) {
         if (p->vis_l[f] < 0 || p->vis_l[f] >= p->L || p->vis_i[f] < 0 || p->vis_i[f] >= p->K || p->vis_j[f] < 0 || p->vis_j[f] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
+        if (p->vis_i[f] == p->vis_j[f]) return VIL_ERR_INVALID_ARGUMENT;     // the reference never builds such a factor (estimator.cpp:1205: `if (imu_i == imu_j) continue;`)
         if (f && p->vis_l[f] < p->vis_l[f - 1]) return VIL_ERR_INVALID_ARGUMENT;
         if (f && p->vis_l[f] == p->vis_l[f - 1] && p->vis_i[f] != p->vis_i[f - 1]) return VIL_ERR_INVALID_ARGUMENT;
     }
-    if (p->n_plane < 0 || p->n_edge < 0) return VIL_ERR_INVALID_ARGUMENT;
     if (!device_lidar) {
         for (int f = 0; f < p->n_plane; ++f) if (p->plane_pose[f] < 0 || p->plane_pose[f] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
         for (int f = 0; f < p->n_edge; ++f) if (p->edge_pose[f] < 0 || p->edge_pose[f] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
     }
     for (int f = 0; f < p->n_imu; ++f) if (p->imu_i[f] < 0 || p->imu_i[f] >= p->K || p->imu_j[f] < 0 || p->imu_j[f] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
+    for (int q = 0; q < 4 * p->n_icp; ++q) if (p->icp_ids[q] < 0 || p->icp_ids[q] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
+    for (int q = 0; q < 2 * p->n_lps; ++q) if (p->lps_ids[q] < 0 || p->lps_ids[q] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
+    if (p->prior.n > 0) {
+        const vil_prior& pr = p->prior;
+        if (pr.nblk <= 0 || !pr.blk_kind || !pr.blk_index || !pr.blk_col || !pr.x0 || !pr.J0 || !pr.r0) return VIL_ERR_INVALID_ARGUMENT;
+        for (int b = 0; b < pr.nblk; ++b) {
+            const int kind = pr.blk_kind[b], idx = pr.blk_index[b];
+            if (kind < VIL_BLK_POSE || kind > VIL_BLK_TD) return VIL_ERR_INVALID_ARGUMENT;
+            if ((kind == VIL_BLK_POSE || kind == VIL_BLK_SPEEDBIAS) && (idx < 0 || idx >= p->K)) return VIL_ERR_INVALID_ARGUMENT;
+            const int ls = (kind == VIL_BLK_POSE || kind == VIL_BLK_EX) ? 6 : (kind == VIL_BLK_SPEEDBIAS ? 9 : 1);
+            if (pr.blk_col[b] < 0 || pr.blk_col[b] + ls > pr.n) return VIL_ERR_INVALID_ARGUMENT;
+        }
+    }
     return VIL_OK;
 }
 
@@ -268,7 +295,9 @@ static void lidar_chunks(const std::vector<int>& cnt, int K, std::vector<int>& c
 static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, bool sharded, const vil_device_lidar* dl = nullptr) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
     int st = validate(p, s, dl != nullptr);
-    if (st != VIL_OK) return st;
+    if (st != VIL_OK) return st;                 // an invalid problem leaves the resident one untouched
+    c->uploaded = false;                         // from here on the arena is rewritten: resident only again after a complete upload
+    c->resident_kind = 0;
     HIPCHK(hipSetDevice(c->device));
     const int K = p->K, L = p->L, D = 15 * K + 7, NV = 6 * K + 7, NS = 16 * K + 8 + L;
     Arena& ar = c->ar;
@@ -493,16 +522,20 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     HIPCHK(hipMemcpyAsync(&hstat, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
-    c->uploaded = true;
-    return hstat == 0 ? VIL_OK : VIL_ERR_NOT_POSITIVE_DEFINITE;
+    if (hstat != 0) return VIL_ERR_NOT_POSITIVE_DEFINITE;
+    c->uploaded = true; c->resident_kind = 2;    // vil_upload / vil_solve promote it to 1
+    return VIL_OK;
 }
+
+static int comm_agree(vil_ctx* c, int st);
 
 // rank r keeps the visual factors of its landmark range, a contiguous slice of the LiDAR points, and
 // (rank 0 only) the IMU / prior / ICP / LPS factors.  Landmark indices and the state stay global.
 static int upload_sharded(vil_ctx* c, const vil_problem* p, const vil_state* s) {
     int32_t lb, le, eb, ee, pb, pe;
-    int st = vil_shard_ranges(p, c->rank, c->world, &lb, &le, &eb, &ee, &pb, &pe);
-    if (st != VIL_OK) return st;
+    int st = validate(p, s);                     // vil_shard_ranges indexes with vis_l: check the tables first
+    if (st == VIL_OK) st = vil_shard_ranges(p, c->rank, c->world, &lb, &le, &eb, &ee, &pb, &pe);
+    if (st != VIL_OK) return comm_agree(c, st);  // every rank sees the same problem, but stay collective anyway
     vil_problem q = *p;
     int f0 = 0, f1 = 0;
     for (int f = 0; f < p->n_vis; ++f) { if (p->vis_l[f] < lb) f0 = f + 1; if (p->vis_l[f] < le) f1 = f + 1; }
@@ -511,13 +544,17 @@ static int upload_sharded(vil_ctx* c, const vil_problem* p, const vil_state* s) 
     q.n_plane = pe - pb; q.plane_pose = p->plane_pose + pb; q.plane_const = p->plane_const + (size_t)pb * 7;
     if (c->rank != 0) { q.n_imu = 0; q.n_icp = 0; q.n_lps = 0; q.prior.n = 0; q.prior.nblk = 0; }
     c->lm_b = lb; c->lm_e = le;
-    return upload_impl(c, &q, s, true);
+    st = comm_agree(c, upload_impl(c, &q, s, true));       // e.g. rank 0's IMU set-up failed: every rank reports it
+    if (st != VIL_OK) c->uploaded = false;
+    return st;
 }
 
 int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
-    if (c->world > 1 && (c->comm || c->lcomm)) return upload_sharded(c, p, s);     // a world > 1 context without a communicator works un-sharded
-    return upload_impl(c, p, s, false);
+    const int st = (c->world > 1 && (c->comm || c->lcomm)) ? upload_sharded(c, p, s)      // a world > 1 context without a communicator works un-sharded
+                                                           : upload_impl(c, p, s, false);
+    if (st == VIL_OK) c->resident_kind = 1;
+    return st;
 }
 
 __global__ void k_lam_delta(DevP P, int lb, int le) {      // owner's change of the inverse depths, zero elsewhere
@@ -533,42 +570,64 @@ __global__ void k_lam_apply(DevP P) {
 static int all_reduce(vil_ctx* c, double* buf, size_t cnt) {
     if (c->comm) return g_rccl.AllReduce(buf, buf, cnt, ncclDouble, ncclSum, c->comm, c->stream) == ncclSuccess ? VIL_OK : VIL_ERR_COMM;
     if (c->lcomm) {
+        // every HIP failure is carried to the next agreement point instead of returning past a barrier the other ranks wait at
         LocalComm* lc = c->lcomm.get();
-        if (cnt > c->lc_cap) { if (c->lc_tmp) hipFree(c->lc_tmp); c->lc_tmp = nullptr; c->lc_cap = 0; HIPCHK(hipMalloc(&c->lc_tmp, 8 * cnt)); c->lc_cap = cnt; }
-        HIPCHK(hipStreamSynchronize(c->stream));
+        int st = VIL_OK;
+        if (cnt > c->lc_cap) { if (c->lc_tmp) hipFree(c->lc_tmp); c->lc_tmp = nullptr; c->lc_cap = 0; if (hipMalloc(&c->lc_tmp, 8 * cnt) == hipSuccess) c->lc_cap = cnt; else st = VIL_ERR_DEVICE; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) st = VIL_ERR_DEVICE;
         lc->ptr[c->rank] = buf;
-        pthread_barrier_wait(&lc->bar);
+        st = lc->agree(c->rank, st);                          // all buffers are complete and published (or somebody failed)
+        if (st != VIL_OK) return st;
         PeerPtrs pp; pp.n = lc->n;
         for (int r = 0; r < 8; ++r) pp.p[r] = r < lc->n ? lc->ptr[r] : nullptr;
         hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)std::min<size_t>(256, (cnt + 255) / 256)), dim3(256), 0, c->stream, c->lc_tmp, pp, cnt);
-        HIPCHK(hipStreamSynchronize(c->stream));
-        pthread_barrier_wait(&lc->bar);                       // every rank has read every buffer
+        if (hipStreamSynchronize(c->stream) != hipSuccess) st = VIL_ERR_DEVICE;
+        st = lc->agree(c->rank, st);                          // every rank has read every buffer
+        if (st != VIL_OK) return st;
         HIPCHK(hipMemcpyAsync(buf, c->lc_tmp, 8 * cnt, hipMemcpyDeviceToDevice, c->stream));
     }
     return VIL_OK;
+}
+
+// the ranks of a communicator agree on a status (the worst one): a rank-asymmetric failure -- only rank 0 holds the IMU / prior
+// factors whose set-up can fail -- must not leave the other ranks waiting in the first collective of the solve
+static int comm_agree(vil_ctx* c, int st) {
+    if (c->lcomm) return c->lcomm->agree(c->rank, st);
+    if (c->comm) {
+        int h = st;
+        if (hipMemcpyAsync(c->d_status, &h, sizeof(int), hipMemcpyHostToDevice, c->stream) != hipSuccess) return VIL_ERR_DEVICE;
+        if (g_rccl.AllReduce(c->d_status, c->d_status, 1, ncclInt, ncclMin, c->comm, c->stream) != ncclSuccess) return VIL_ERR_COMM;
+        if (hipMemcpyAsync(&h, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return VIL_ERR_DEVICE;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return VIL_ERR_DEVICE;
+        return h;
+    }
+    return st;
 }
 
 static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
     hipLaunchKernelGGL(k_sweep, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, c->P, so);
     return VIL_OK;
 }
-static void launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr) {
+static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr) {
     hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce), dim3(VIL_THREADS), 0, c->stream, c->P);
     if (ev_mid) hipEventRecord(ev_mid, c->stream);
-    if (!step) return;
+    if (!step) return VIL_OK;
     if (!c->split) {
         if (c->step_lds) hipLaunchKernelGGL((k_step<true, 0>), dim3(1 + c->P.n_help), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
         else hipLaunchKernelGGL((k_step<false, 0>), dim3(1 + c->P.n_help), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
-        return;
+        return VIL_OK;
     }
     // multi-GPU: all-reduce the partial reduced system (+ step norms), step A, all-reduce 5 scalars, step B
     const size_t cnt = (size_t)c->D * c->D + 3 * (size_t)c->D + 3;
-    all_reduce(c, c->P.arstage, cnt);
+    int st = all_reduce(c, c->P.arstage, cnt);
+    if (st != VIL_OK) return st;
     if (c->step_lds) hipLaunchKernelGGL((k_step<true, 1>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
     else hipLaunchKernelGGL((k_step<false, 1>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
-    all_reduce(c, c->P.scal, 8);
+    st = all_reduce(c, c->P.scal, 8);
+    if (st != VIL_OK) return st;
     if (c->step_lds) hipLaunchKernelGGL((k_step<true, 2>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
     else hipLaunchKernelGGL((k_step<false, 2>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
+    return VIL_OK;
 }
 
 static int init_ctl(vil_ctx* c, const vil_options* o, int lin_mode) {
@@ -608,7 +667,7 @@ int vil_reset_state(vil_ctx* c) {
 }
 
 int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
-    if (!c || !o || !sum || !c->uploaded) return VIL_ERR_INVALID_ARGUMENT;
+    if (!c || !o || !sum || !c->uploaded || c->resident_kind != 1) return VIL_ERR_INVALID_ARGUMENT;   // vil_marginalize / vil_eval_factors / vil_linearize replaced the window
     if (o->precision != 0 && o->precision != 1) return VIL_ERR_UNSUPPORTED;
     HIPCHK(hipSetDevice(c->device));
     const auto t0 = std::chrono::steady_clock::now();
@@ -647,7 +706,8 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
             if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q], c->stream));
             launch_sweep(c, so);
             if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q + 1], c->stream));
-            launch_reduce_step(c, so, true, c->profiling ? c->ev_mid[q] : nullptr);
+            st = launch_reduce_step(c, so, true, c->profiling ? c->ev_mid[q] : nullptr);
+            if (st != VIL_OK) return st;          // a failed collective fails on every rank (all_reduce): nobody is left waiting
         }
         if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * launched], c->stream));
         HIPCHK(hipMemcpyAsync(c->h_ctl, c->P.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
@@ -734,6 +794,7 @@ int vil_solve_device_lidar(vil_ctx* c, const vil_problem* p, const vil_device_li
     }
     int st = upload_impl(c, p, s, false, dl);
     if (st != VIL_OK) return st;
+    c->resident_kind = 1;
     const auto t1 = std::chrono::steady_clock::now();
     st = vil_solve_resident(c, o, sum);
     sum->t_prepare_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -772,6 +833,7 @@ int vil_eval_factors(vil_ctx* c, const vil_problem* p, const vil_state* s, int c
     if (nfac == 0) return VIL_OK;
     const size_t br = 8 * nr * nfac, bj = J ? 8 * nj * nfac : 0;
     double *d_r = nullptr, *d_J = nullptr; int* d_joff = nullptr;
+    struct Free { double*& r; double*& J; int*& o; ~Free() { if (r) hipFree(r); if (J) hipFree(J); if (o) hipFree(o); } } free_tmp{d_r, d_J, d_joff};   // also on the error returns
     HIPCHK(hipMalloc(&d_r, br));
     if (J) HIPCHK(hipMalloc(&d_J, bj));
     const double* x = P.x[0];
@@ -804,7 +866,6 @@ int vil_eval_factors(vil_ctx* c, const vil_problem* p, const vil_state* s, int c
             if (J) memcpy(J + (size_t)f * nj, hj + (size_t)sidx * nj, 8 * nj);
         }
     } else { memcpy(r, hr, br); if (J) memcpy(J, hj, bj); }
-    hipFree(d_r); if (d_J) hipFree(d_J); if (d_joff) hipFree(d_joff);
     return VIL_OK;
 }
 
@@ -836,6 +897,7 @@ int vil_linearize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vi
 
 int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out) {
     if (!c || !p || !s || !o || !spec || !out) return VIL_ERR_INVALID_ARGUMENT;
+    { const int vst = validate(p, s); if (vst != VIL_OK) return vst; }      // the host tables are indexed below, before upload_impl sees them
     const int K = p->K;
     if (K < 3) return VIL_ERR_INVALID_ARGUMENT;
     const bool old_ = spec->flag == VIL_MARGIN_OLD;
@@ -844,8 +906,8 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     vil_problem q = *p;
     q.pose_const = nullptr; q.sb_const = nullptr; q.lm_const = nullptr; q.ex_const = 0; q.td_const = 0;
     q.n_edge = 0; q.n_plane = 0; q.edge_pose = nullptr; q.plane_pose = nullptr; q.edge_const = nullptr; q.plane_const = nullptr;
-    std::vector<int> imu_i, imu_j, vis_i, vis_j, vis_l, icp_ids, lps_ids;
-    std::vector<double> imu_c, vis_c, icp_c, lps_c;
+    std::vector<int> imu_i, imu_j, vis_i, vis_j, vis_l, icp_ids, lps_ids, edge_pose, plane_pose;
+    std::vector<double> imu_c, vis_c, icp_c, lps_c, edge_c, plane_c;
     std::vector<char> pose_t(K, 0), sb_t(K, 0);
     bool ex_t = false, td_t = false;
     int n_lm_elim = 0;
@@ -879,15 +941,22 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
             for (int b = 0; b < 2; ++b) { const int id = b == 0 ? 0 : p->lps_ids[2 * spec->lps_marg + b]; lps_ids.push_back(id); pose_t[id] = 1; }
             lps_c.insert(lps_c.end(), p->lps_const + (size_t)spec->lps_marg * 7, p->lps_const + (size_t)(spec->lps_marg + 1) * 7);
         }
+        // LiDAR point factors of the dropped pose (extended mode): MarginalizationInfo folds every factor that touches a
+        // dropped block (marginalization_factor.cpp:176-316); these touch pose 0 only and reach the prior through A_mm / b_m
+        for (int f = 0; f < p->n_edge; ++f) if (p->edge_pose[f] == 0) { edge_pose.push_back(0); edge_c.insert(edge_c.end(), p->edge_const + (size_t)f * 9, p->edge_const + (size_t)(f + 1) * 9); }
+        for (int f = 0; f < p->n_plane; ++f) if (p->plane_pose[f] == 0) { plane_pose.push_back(0); plane_c.insert(plane_c.end(), p->plane_const + (size_t)f * 7, p->plane_const + (size_t)(f + 1) * 7); }
+        if (!edge_pose.empty() || !plane_pose.empty()) pose_t[0] = 1;
     }
     q.n_imu = (int)imu_i.size(); q.imu_i = imu_i.data(); q.imu_j = imu_j.data(); q.imu_const = imu_c.data();
     q.n_vis = (int)vis_i.size(); q.vis_i = vis_i.data(); q.vis_j = vis_j.data(); q.vis_l = vis_l.data(); q.vis_const = vis_c.data();
     q.n_icp = (int)icp_ids.size() / 4; q.icp_ids = icp_ids.data(); q.icp_const = icp_c.data();
     q.n_lps = (int)lps_ids.size() / 2; q.lps_ids = lps_ids.data(); q.lps_const = lps_c.data();
+    q.n_edge = (int)edge_pose.size(); q.edge_pose = edge_pose.data(); q.edge_const = edge_c.data();
+    q.n_plane = (int)plane_pose.size(); q.plane_pose = plane_pose.data(); q.plane_const = plane_c.data();
     int st = upload_impl(c, &q, s, false);
     if (st != VIL_OK) return st;
     const SolveOpts so = to_dev_opts(o);
-    st = init_ctl(c, o, 1);
+    st = init_ctl(c, o, 2);
     if (st != VIL_OK) return st;
     launch_sweep(c, so);
     launch_reduce_step(c, so, false);
@@ -1055,6 +1124,17 @@ int vil_comm_init(vil_ctx* c, const void* id128, int rank, int world) {
 int vil_comm_init_local(vil_ctx** ctxs, int n) {
     if (!ctxs || n < 1 || n > 8) return VIL_ERR_INVALID_ARGUMENT;
     for (int r = 0; r < n; ++r) if (!ctxs[r]) return VIL_ERR_INVALID_ARGUMENT;
+    // k_sum_peers reads the other contexts' buffers directly: contexts on different devices need peer access in both
+    // directions (xGMI / PCIe P2P), checked and enabled here; without it the configuration is refused, not faulted at run time
+    for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) {
+        if (ctxs[a]->device == ctxs[b]->device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, ctxs[a]->device, ctxs[b]->device) != hipSuccess || !can) return VIL_ERR_UNSUPPORTED;
+        if (hipSetDevice(ctxs[a]->device) != hipSuccess) return VIL_ERR_DEVICE;
+        const hipError_t e = hipDeviceEnablePeerAccess(ctxs[b]->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return VIL_ERR_UNSUPPORTED;
+        (void)hipGetLastError();
+    }
     auto lc = std::make_shared<LocalComm>();
     if (pthread_barrier_init(&lc->bar, nullptr, (unsigned)n) != 0) return VIL_ERR_COMM;
     lc->n = n;

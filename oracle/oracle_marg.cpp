@@ -273,6 +273,27 @@ int marginalize(const vil_problem* p, const vil_state* st, const vil_options* o,
             split(rb, J); finish(rb, o->visual_loss, o->visual_loss_scale);
             facs.push_back(std::move(rb));
         }
+        // LiDAR edge / plane point factors attached to frame 0 (extended mode of this build; the reference has
+        // no such factors in the window).  marginalization_factor.cpp:176-316 folds EVERY factor that touches a dropped block:
+        // these touch pose 0 only, so they add to A_mm / b_m and reach the prior through the Schur complement.
+        for (int f = 0; f < p->n_edge; ++f) {
+            if (p->edge_pose[f] != 0) continue;
+            RBlock rb; rb.nr = 3; rb.r.resize(3);
+            add_blocks(rb, {{VIL_BLK_POSE, 0}});
+            double J[VIL_EDGE_NJ];
+            edge_evaluate(p->edge_const + (size_t)f * VIL_EDGE_CONST, p->q_lb, p->t_lb, st->pose, rb.r.data(), J);
+            split(rb, J); finish(rb, o->lidar_loss, o->lidar_loss_scale);
+            facs.push_back(std::move(rb));
+        }
+        for (int f = 0; f < p->n_plane; ++f) {
+            if (p->plane_pose[f] != 0) continue;
+            RBlock rb; rb.nr = 1; rb.r.resize(1);
+            add_blocks(rb, {{VIL_BLK_POSE, 0}});
+            double J[VIL_PLANE_NJ];
+            plane_evaluate(p->plane_const + (size_t)f * VIL_PLANE_CONST, p->q_lb, p->t_lb, st->pose, rb.r.data(), J);
+            split(rb, J); finish(rb, o->lidar_loss, o->lidar_loss_scale);
+            facs.push_back(std::move(rb));
+        }
     } else {
         dropped.push_back({VIL_BLK_POSE, drop_pose});
     }

@@ -83,3 +83,52 @@ def test_prior_chain_solve(hip, oracle):
     assert sg.iterations == so.iterations
     assert abs(sg.final_cost - so.final_cost) <= 1e-7 * so.final_cost
     assert np.abs(wg.pose - wo.pose).max() < 1e-6
+
+
+# ---- independent of the oracle: GPU factors -> numpy normal equations -> 60-digit Schur complement (tests/numpy_ref.py) ----------
+import numpy_ref as nr
+
+
+@pytest.mark.parametrize("flag", [abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW])
+def test_marginal_equals_exact_schur_complement(hip, wsolved, flag):
+    """vil_marginalize's A, b against the reference's rule (marginalization_factor.cpp:273-290) evaluated with 60-digit
+    arithmetic on normal equations assembled in numpy from vil_eval_factors' own r / J -- nothing of the oracle is involved.
+    The reference's fp64 eigen route only reaches ~1e-6 (diagonally scaled) on these matrices; the library, which eliminates
+    the landmarks exactly and only the 15 x 15 pose / speed-bias block by eigen-decomposition, is asserted an order closer."""
+    opts = abi.default_options()
+    ref = nr.marg_numpy(hip, wsolved, opts, flag, lidar=True)
+    Ax, bx, _ = nr.exact_schur(ref["A_full"], ref["b_full"], ref["m"])
+    out = hip.marginalize(wsolved, flag)
+    assert out.c.n == Ax.shape[0] and out.c.m == ref["m"]
+    e = nr.scaled_err(out.A_matrix(), Ax)
+    assert e <= 1e-7, e
+    assert np.abs(out.b_vector() - bx).max() <= 1e-7 * np.abs(bx).max()
+    print("GPU marginal vs exact: %.2e (numpy fp64 eigen route: %.2e)" % (e, nr.scaled_err(ref["A"], Ax)))
+
+
+def test_lidar_factors_of_dropped_pose_reach_the_prior(hip, oracle, wsolved):
+    """Extended mode: the edge / plane point factors attached to frame 0 are part of the marginalised information
+    (marginalization_factor.cpp:176-316 folds every factor touching a dropped block)."""
+    w = wsolved
+    assert (w.plane_pose == 0).sum() > 0 and (w.edge_pose == 0).sum() > 0
+    w0 = synth.make_config(2, L=150, n_plane=0, n_edge=0)
+    w0.set_state(w.state_copy()); w0.prior = w.prior
+    a_with, a_without = hip.marginalize(w, abi.MARGIN_OLD).A_matrix(), hip.marginalize(w0, abi.MARGIN_OLD).A_matrix()
+    assert nr.scaled_err(a_with, a_without) > 1e-3            # they carry real information about the kept poses
+    check(hip.marginalize(w, abi.MARGIN_OLD), oracle.marginalize(w, abi.MARGIN_OLD))
+
+
+def test_rank_deficient_landmark_follows_reference_rule(hip, oracle):
+    """Landmarks of frame 0 without parallax (h_ll <= eps = 1e-8): the reference's pseudo inverse zeroes those directions
+    (marginalization_factor.cpp:277); the library drops the same pivots (k_sweep, lin_mode 2).  Compared with the rule
+    evaluated at 60 digits, and shown to differ materially from the plain inverse."""
+    w, weak = nr.rank_deficient_window(oracle)
+    opts = abi.default_options()
+    ref = nr.marg_numpy(hip, w, opts, abi.MARGIN_OLD, lidar=True)
+    Ax, bx, E = nr.exact_schur(ref["A_full"], ref["b_full"], ref["m"])
+    assert (E <= 1e-8).sum() == len(weak) >= 1
+    out = hip.marginalize(w, abi.MARGIN_OLD)
+    e = nr.scaled_err(out.A_matrix(), Ax)
+    assert e <= 1e-6, e
+    A0, _, _ = nr.exact_schur(ref["A_full"], ref["b_full"], ref["m"], eps=0.0)
+    assert nr.scaled_err(A0, Ax) > 1e-3

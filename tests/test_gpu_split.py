@@ -52,12 +52,16 @@ from mvil_fusion_amd import abi, lib, synth
 import oracle_lib
 orc = oracle_lib.open_oracle()
 pf = lambda pre: orc.marginalize(pre).to_prior()
-for world in (2, 3):
+full = os.environ.get("SHARD_FULL") == "1"
+for world in ((8,) if full else (2, 3)):
     bes = [lib.open_vilsolve() for _ in range(world)]
     arr = (C.c_void_p * world)(*[b.ctx for b in bes])
     assert bes[0].lib.vil_comm_init_local(arr, world) == 0
-    for cid, kw in ((2, dict(L=150, n_plane=3000, n_edge=800)), (1, {})):
+    for cid, kw in (((3, {}), (2, {})) if full else ((2, dict(L=150, n_plane=3000, n_edge=800)), (1, {}))):
         wo = synth.make_config(cid, prior_fn=pf, **kw)
+        if full and cid == 3: assert (wo.K, wo.L, len(wo.plane_pose) + len(wo.edge_pose)) == (10, 4000, 120000)     # BASELINE.json configs[2]
+        w1 = synth.make_config(cid, prior_fn=pf, **kw)
+        be1 = lib.open_vilsolve(); s1 = be1.solve(w1); be1.close()                      # the un-sharded solve of the same window
         ws = [synth.make_config(cid, prior_fn=pf, **kw) for _ in range(world)]
         res = [None] * world
         def run(r):
@@ -78,6 +82,11 @@ for world in (2, 3):
             if wo.prior.n:
                 assert np.abs(ws[r].pose - wo.pose).max() < 1e-6 and np.abs(ws[r].inv_depth - wo.inv_depth).max() < 1e-6
             assert np.array_equal(ws[r].pose, ws[0].pose) and np.array_equal(ws[r].inv_depth, ws[0].inv_depth)     # ranks agree bit for bit
+            assert np.array_equal(ws[r].speedbias, ws[0].speedbias) and np.array_equal(ws[r].ex_pose, ws[0].ex_pose)
+            # sharded vs un-sharded on the same device: same iterations, states equal to summation-order rounding
+            assert sg.iterations == s1.iterations and abs(sg.final_cost - s1.final_cost) <= 1e-10 * s1.final_cost
+            if wo.prior.n:      # (a prior-less window has a 4-dof gauge null space)
+                assert np.abs(ws[r].pose - w1.pose).max() < 1e-9 and np.abs(ws[r].inv_depth - w1.inv_depth).max() < 1e-8
             assert abs(cg - co) <= 1e-11 * co and np.abs(Sg - So).max() <= 1e-9 * np.abs(So).max()
     for b in bes: b.close()
 print("SHARD_OK")
@@ -88,4 +97,13 @@ def test_sharded_solve_local_communicator():
     """2 and 3 ranks of the factor-sharded solve on ONE device through the in-process communicator: the shard ranges,
     ranks without IMU / prior factors, the split step, the scalar reduction and the landmark merge all run as on N GPUs."""
     out = subprocess.run([sys.executable, "-c", SHARD_SCRIPT % (ROOT, ROOT)], capture_output=True, text=True, timeout=900)
+    assert "SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_sharded_full_size_8_ranks():
+    """BASELINE.json configs[2] (K = 10, L = 4000, 120 k LiDAR points) and configs[1] at FULL size as an 8-rank factor-sharded
+    solve -- eight contexts, eight host threads, the in-process communicator on one device: every rank bit-identical, equal to
+    the oracle and to the un-sharded solve."""
+    env = dict(os.environ, SHARD_FULL="1")
+    out = subprocess.run([sys.executable, "-c", SHARD_SCRIPT % (ROOT, ROOT)], env=env, capture_output=True, text=True, timeout=1500)
     assert "SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
