@@ -90,6 +90,8 @@ struct DevP {
     // helper workgroups of the single-GPU step kernel (landmark pre-pass on extra CUs): n_help of them, each publishes
     // {q, g2, gm} in hpart[4 * k ..] and then stores the launch epoch in hflag[k]; only the master workgroup ever waits
     int n_help; double* hpart; int* hflag;
+    // structure-exploiting solve (vil_chain.hpp): 0 dense, 1 chain with W^T in LDS, 2 chain with W^T in global memory (P.M)
+    int chain, chain_rs;
 };
 
 __host__ __device__ inline int xo_pose(const DevP& P, int k) { return 7 * k; }

@@ -151,6 +151,9 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double& sq, double& rs) {
     sq = fma(fma(-g, g, x), h, g); rs = h + h;
 }
 __device__ __forceinline__ int tri_off(int i) { return (i * (i + 1)) >> 1; }
+}  // namespace vd
+#include "vil_chain.hpp"
+namespace vd {
 
 // ---- tiled lower storage of the (D+1) x (D+1) reduced matrix (last row = right-hand side): 16 x 16 tiles,
 //      tile (I, J), J <= I, at (I(I+1)/2 + J) * TILE_SZ; element (r, c) of a tile at r*TILE_RS + c.  An MFMA operand /
@@ -173,8 +176,10 @@ __device__ __forceinline__ int tl_phys(int e) { return (e >> 8) * TILE_SZ + ((e 
 //       the <= 8 tiles a wave owns.
 // On return rows < D hold L, row D holds y = L^-1 rhs, s.dinv[j] = 1 / L_jj.  Returns false (uniformly) on a
 // non-positive pivot.
-template <bool REGRES, class PTR>
-__device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double* Acol = nullptr) {
+struct NoPre { template <class C> __device__ __forceinline__ void operator()(C*, const int*) const {} };
+// PRE: called once with the freshly loaded register tiles (REGRES) -- the chain path subtracts W W^T there
+template <bool REGRES, class PTR, class PRE = NoPre>
+__device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double* Acol = nullptr, PRE pre = PRE()) {
     const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
     const int R = D + 1;                 // rows including the rhs row
     const int T = (R + 15) >> 4;         // tile rows
@@ -205,6 +210,7 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double
                 for (int q = 0; q < 4; ++q) Creg[u][q] = A[cb + q * (4 * TILE_RS)];
             }
         }
+        pre(Creg, tIJ);
     }
     for (int kb = 0; kb < D; kb += STEP_NB) {
         const int nb = min(STEP_NB, D - kb);
@@ -445,11 +451,267 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
     __syncthreads();
 }
 
+// ---- chain path (vil_chain.hpp): pack the pose part, eliminate the speed-bias chain from both ends, Schur-update the pose
+//      tiles on the matrix cores, dense Cholesky + back substitution on 6K + 8 rows, back-substitute the chain.
+// In: s.sc, s.dcs, s.y (= u, for the camera share of u^T H u), s.gd.  Out: solution of M x = rhs in s.y[0 .. D); qpart gets
+// this thread's share of u_c^T S' u_c.  Returns false (uniformly) when a pivot is not positive.
+// Thread roles: t in [0, 192) forward direction, [192, 384) backward direction -- lane q of a direction owns panel row q
+// (q < 9: row q of the neighbouring chain block, then the 6K + 8 pose rows; the last one is the right-hand side);
+// every other thread (whole waves) packs the pose tiles meanwhile, two of those waves also keep the factors for the
+// back substitution.
+template <bool WLDS>
+__device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart) {
+    const int t = threadIdx.x;
+    const int K = P.K, D = P.D, NP = P.NV, R = NP + 1, T = (R + 15) >> 4, ntile = (T * (T + 1)) >> 1;
+    const int RS = P.chain_rs, NB = 9 * K;
+    double* Tl = lds;
+    double* Wt = WLDS ? lds + ntile * TILE_SZ : P.M;                       // W^T: column j of the chain at Wt[j * RS + row]
+    double* cs = lds + ntile * TILE_SZ + (WLDS ? (size_t)(NB + 3) * RS : 0);
+    double* Dk = cs; double* Ls = cs + 162; double* cB = cs + 324;
+    double* Ldg = cB + 9 * R; double* Lsb = Ldg + even_up(54 * K); double* tB = Lsb + even_up(81 * K);
+    const int m = K >> 1, nf = m, nb = K - 1 - m, nst = max(nf, nb);
+    const int d = t < 192 ? 0 : (t < 384 ? 1 : 2);
+    const int q = t - 192 * d;
+    const int NR = 9 + R, NRpad = (NR + 63) & ~63;
+    const bool chainl = d < 2 && q < NR;              // owns a panel row
+    const bool dlane = d < 2 && q < 45;               // owns entry (di, dj) of the 9 x 9 diagonal blocks (NR < 45 when K <= 4)
+    const bool packl = d == 2 || q >= NRpad;
+    const int nxtra = 192 - NRpad, npack = 128 + 2 * nxtra;
+    const int pl = d == 2 ? q : 128 + d * nxtra + (q - NRpad);
+    const int nd = d == 0 ? nf : nb;
+    // ---- packing of the pose tiles, sliced over the barrier intervals of the chain --------------------------------------
+    const int NE = ntile << 8, per_lane = (NE + npack - 1) / npack, NI = 2 * nst + 2, pcnt = (per_lane + NI - 1) / NI;
+    auto pack_slice = [&](int iv) {
+        if (!packl) return;
+        for (int j = iv * pcnt; j < (iv + 1) * pcnt; ++j) {
+            const int e = pl + j * npack;
+            if (e >= NE) break;
+            const int tile = e >> 8, w = e & 255;
+            const int i = (s.tI[tile] << 4) + (w >> 4), jj = (s.tJ[tile] << 4) + (w & 15);
+            double mv = 0.0;
+            if (i < NP && jj <= i) {
+                const double v = sb.S[(size_t)i * D + jj];
+                if (cam) qpart += (i == jj ? 1.0 : 2.0) * s.y[i] * v * s.y[jj];
+                mv = s.sc[i] * v * s.sc[jj];
+                if (i == jj) mv += mu * s.dcs[i] * s.dcs[i];
+            } else if (i == NP && jj < NP) mv = s.sc[jj] * s.gd[jj];
+            Tl[tl_phys(e)] = mv;
+        }
+    };
+    // ---- raw entries of this lane's panel row against the columns of block k (address always valid; the rhs row reads LDS)
+    const bool prow = q >= 9;                         // pose-part row (incl. rhs) vs row of the neighbouring chain block
+    const int r = q - 9;                              // pose row index (r == NP: right-hand side)
+    auto fetch = [&](int k, int kn, double* a) {
+        const int row = prow ? min(r, NP - 1) : NP + 9 * min(max(kn, 0), K - 1) + q;
+        const double* p = sb.S + (size_t)min(row, D - 1) * D + NP + 9 * k;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) a[c] = p[c];
+        if (prow && r == NP) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) a[c] = s.gd[NP + 9 * k + c];
+        }
+    };
+    // entry (i, j), j <= i, of a 9 x 9 diagonal block for the lanes q < 45
+    int di = 0, dj = 0;
+    { int e = q < 45 ? q : 0; while ((di + 1) * (di + 2) / 2 <= e) ++di; dj = e - di * (di + 1) / 2; }
+    auto diag_raw = [&](int k) { return sb.S[(size_t)(NP + 9 * k + di) * D + NP + 9 * k + dj]; };
+    auto diag_scaled = [&](int k, double v) {
+        const double si = s.sc[NP + 9 * k + di], sj = s.sc[NP + 9 * k + dj];
+        double mv = si * v * sj;
+        if (di == dj) { const double dd = s.dcs[NP + 9 * k + di]; mv += mu * dd * dd; }
+        return mv;
+    };
+    double carry[9], an[9], qa = 0.0, dnext = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { carry[c] = 0.0; an[c] = 0.0; }
+    const int k0 = d == 0 ? 0 : K - 1;
+    if (chainl) {
+        if (nd > 0) fetch(k0, d == 0 ? 1 : K - 2, an);
+        else if (d == 0) fetch(m, m, an);             // K = 1: only the middle block
+    }
+    if (dlane && nd > 0) {                            // D of the first block of this direction
+        const double v = diag_raw(k0);
+        Dk[81 * d + di * 9 + dj] = diag_scaled(k0, v);
+        if (cam) qpart += (di == dj ? 1.0 : 2.0) * s.y[NP + 9 * k0 + di] * v * s.y[NP + 9 * k0 + dj];
+    }
+    const double yrow = (chainl && prow && r < NP) ? s.y[r] : 0.0;
+    const double scrow_p = (chainl && prow) ? (r < NP ? s.sc[r] : 1.0) : 0.0;
+    __syncthreads();
+    bool ok = true;
+    for (int st = 0; st < nst; ++st) {
+        const bool act = chainl && st < nd;
+        const int k = d == 0 ? st : K - 1 - st, kn = d == 0 ? k + 1 : k - 1;
+        double w[9];
+        const bool dact = dlane && st < nd;
+        if (dact) dnext = diag_raw(kn);                // raw entry of the next diagonal block (consumed after the barrier)
+        if (act) {
+            double a[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) a[c] = an[c];
+            // next step's rows (or the middle block's) while this one computes
+            if (st + 1 < nd) fetch(d == 0 ? k + 1 : k - 1, d == 0 ? k + 2 : k - 2, an);
+            else if (d == 0) fetch(m, m, an);
+            L9 Lf;
+            ok = chol9(Dk + 81 * d, Lf) && ok;
+            const double rsc = prow ? scrow_p : s.sc[NP + 9 * kn + q];
+            const double yr = prow ? yrow : s.y[NP + 9 * kn + q];
+            double qs = 0.0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                qs += a[c] * s.y[NP + 9 * k + c];
+                a[c] = rsc * a[c] * s.sc[NP + 9 * k + c] - (prow ? carry[c] : 0.0);
+            }
+            qa += yr * qs;                            // (row, block k) and its mirror image: counted twice at the end
+#pragma unroll
+            for (int p = 0; p < 9; ++p) {
+                double acc = a[p];
+#pragma unroll
+                for (int c = 0; c < p; ++c) acc -= w[c] * Lf.l[(p * (p + 1) >> 1) + c];
+                w[p] = acc * Lf.r[p];
+            }
+            if (prow) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) Wt[(size_t)(9 * k + c) * RS + r] = w[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) { Ls[81 * d + q * 9 + c] = w[c]; Lsb[81 * k + q * 9 + c] = w[c]; }
+            }
+        } else if (d == 2 && (q == 0 || q == 64) && st < (q == 0 ? nf : nb)) {
+            // a packing wave keeps the factor of this block for the back substitution (off the chain's critical path)
+            const int dd = q == 0 ? 0 : 1, kk = dd == 0 ? st : K - 1 - st;
+            L9 Lf;
+            chol9(Dk + 81 * dd, Lf);
+#pragma unroll
+            for (int e = 0; e < 45; ++e) Ldg[54 * kk + e] = Lf.l[e];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) Ldg[54 * kk + 45 + e] = Lf.r[e];
+        }
+        pack_slice(2 * st);
+        __syncthreads();
+        if (act || dact) {
+            const double* L1 = Ls + 81 * d;
+            if (act && prow) {                         // fill carried into the next block of this direction
+#pragma unroll
+                for (int cn = 0; cn < 9; ++cn) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) acc += w[c] * L1[cn * 9 + c];
+                    carry[cn] = acc;
+                }
+            }
+            if (dact && kn != m) {                     // diagonal block of the next step (the middle block is formed below)
+                const double v = dnext;
+                double acc = diag_scaled(kn, v);
+#pragma unroll
+                for (int c = 0; c < 9; ++c) acc -= L1[di * 9 + c] * L1[dj * 9 + c];
+                Dk[81 * d + di * 9 + dj] = acc;
+                if (cam) qpart += (di == dj ? 1.0 : 2.0) * s.y[NP + 9 * kn + di] * v * s.y[NP + 9 * kn + dj];
+            }
+        }
+        pack_slice(2 * st + 1);
+        __syncthreads();
+    }
+    // ---- middle block m: both directions meet ---------------------------------------------------------------------------
+    if (chainl && d == 1 && prow && nb > 0) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) cB[r * 9 + c] = carry[c];
+    }
+    if (dlane && d == 0) {
+        const double v = nf > 0 ? dnext : diag_raw(m);     // (the forward direction's last step fetched it)
+        double acc = diag_scaled(m, v);
+        if (nf > 0) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) acc -= Ls[di * 9 + c] * Ls[dj * 9 + c];
+        }
+        if (nb > 0) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) acc -= Ls[81 + di * 9 + c] * Ls[81 + dj * 9 + c];
+        }
+        Dk[di * 9 + dj] = acc;
+        if (cam) qpart += (di == dj ? 1.0 : 2.0) * s.y[NP + 9 * m + di] * v * s.y[NP + 9 * m + dj];
+    }
+    pack_slice(2 * nst);
+    __syncthreads();
+    if (chainl && d == 0 && prow) {
+        L9 Lf;
+        ok = chol9(Dk, Lf) && ok;
+        double a[9], w[9], qs = 0.0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            qs += an[c] * s.y[NP + 9 * m + c];
+            a[c] = scrow_p * an[c] * s.sc[NP + 9 * m + c] - carry[c] - (nb > 0 ? cB[r * 9 + c] : 0.0);
+        }
+        qa += yrow * qs;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            double acc = a[p];
+#pragma unroll
+            for (int c = 0; c < p; ++c) acc -= w[c] * Lf.l[(p * (p + 1) >> 1) + c];
+            w[p] = acc * Lf.r[p];
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) Wt[(size_t)(9 * m + c) * RS + r] = w[c];
+    } else if (d == 2 && q == 0) {
+        L9 Lf;
+        chol9(Dk, Lf);
+#pragma unroll
+        for (int e = 0; e < 45; ++e) Ldg[54 * m + e] = Lf.l[e];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Ldg[54 * m + 45 + e] = Lf.r[e];
+    }
+    if (cam) qpart += 2.0 * qa;
+    pack_slice(2 * nst + 1);
+    if (!ok) s.ok = 0;
+    __syncthreads();
+    if (!s.ok) return false;
+    // ---- S_pp -= W W^T on the matrix cores, straight into the accumulators of the blocked Cholesky; dense part -------------
+    auto schur = [&](d4* Creg, const int* tIJ) {
+        const int lane = t & 63, row = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int u = 0; u < CH_SLOTS; ++u) {
+            if (tIJ[u] < 0) continue;
+            const int I = tIJ[u] >> 8, J = tIJ[u] & 255;
+            const bool va = (I << 4) + row < R, vb = (J << 4) + row < R;
+            const double* pa = Wt + (size_t)kq * RS + (I << 4) + row;
+            const double* pb = Wt + (size_t)kq * RS + (J << 4) + row;
+            d4 c4 = Creg[u];
+            for (int kk = 0; kk < NB; kk += 4) {
+                const bool kv = kk + kq < NB;
+                const double a_ = pa[(size_t)kk * RS], b_ = pb[(size_t)kk * RS];
+                c4 = __builtin_amdgcn_mfma_f64_16x16x4f64((va && kv) ? -a_ : 0.0, (vb && kv) ? b_ : 0.0, c4, 0, 0, 0);
+            }
+            Creg[u] = c4;
+        }
+    };
+    if (!chol_blocked<true>(Tl, NP, s, nullptr, schur)) return false;
+    back_subst(Tl, NP, s);                             // x_p in s.y[0 .. NP)
+    // ---- chain back substitution: t = y_b - W^T x_p, then outwards from the middle block -----------------------------------
+    {
+        const int G = (4 * NB <= VIL_STEP_THREADS) ? 4 : 2;
+        const int j = t / G, part = t - j * G;
+        const int jc = min(j, NB - 1);
+        double acc = 0.0;
+        for (int rr = part; rr < NP; rr += G) acc += Wt[(size_t)jc * RS + rr] * s.y[rr];
+        acc += __shfl_xor(acc, 1, 64);
+        if (G == 4) acc += __shfl_xor(acc, 2, 64);
+        if (j < NB && part == 0) tB[j] = Wt[(size_t)j * RS + NP] - acc;
+    }
+    __syncthreads();
+    if (t < 64) chain_block_back(Ldg + 54 * m, nullptr, tB + 9 * m, nullptr, s.y + NP + 9 * m);
+    __syncthreads();
+    if (t < 64) { for (int k = m - 1; k >= 0; --k) chain_block_back(Ldg + 54 * k, Lsb + 81 * k, tB + 9 * k, s.y + NP + 9 * (k + 1), s.y + NP + 9 * k); }
+    else if (t < 128) { for (int k = m + 1; k < K; ++k) chain_block_back(Ldg + 54 * k, Lsb + 81 * k, tB + 9 * k, s.y + NP + 9 * (k - 1), s.y + NP + 9 * k); }
+    __syncthreads();
+    return true;
+}
+
 }  // namespace vd
 
 // PHASE 0: whole step (single GPU).  PHASE 1 / 2: the step split around the all-reduce of the landmark-dependent
 // scalars (multi-GPU: every rank owns a slice of the landmarks).
-template <bool LDSM, int PHASE>
+// CHAIN 0: dense factorisation of all D columns (LDSM: tile array in LDS or global).  CHAIN 1 / 2: vil_chain.hpp, with W^T in
+// LDS / in global memory (tiles always in LDS).
+template <bool LDSM, int PHASE, int CHAIN = 0>
 __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) {
     using namespace vd;
     __shared__ StepShared s;
@@ -573,7 +835,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     if (s.c.done) { if (t == 0) { wait_helpers(); *P.ctl = s.c; } return; }
     // prefetch this thread's share of S' (tiled order) so that the global latency hides behind the vector passes
     double pf[PF_N];
-    if (PHASE != 2 && s.need) {
+    if (CHAIN == 0 && PHASE != 2 && s.need) {
         const int R = D + 1, T = (R + 15) >> 4, NTL = (tri_off(T)) << 8;
         const int half = __builtin_amdgcn_readfirstlane(t >> 8), w = t & 255;
         static_for<PF_N>([&](auto uc) {
@@ -622,6 +884,11 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         STAMP(10);
         // ---- camera share of u^T H u, fused with packing M = Sc S' Sc + mu dc^2 (+ rhs row) into LDS ------------
         const double mu = s.c.mu;
+        bool ok = true;
+        if constexpr (CHAIN != 0) {
+            __syncthreads();
+            ok = solve_chain<CHAIN == 1>(P, sb, s, Alds, mu, cam, q);      // packing, chain, Schur update, dense part, back substitution
+        } else {
         // tiled storage: element e of the tile array -> (i, j); S entries were prefetched into registers at kernel start
         double* Ag = P.M;
         const int R = D + 1, T = (R + 15) >> 4, NTL = (tri_off(T)) << 8;
@@ -662,6 +929,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             } else if (i == D && j < D) m = s.sc[j] * s.gd[j];
             if constexpr (LDSM) Alds[tl_phys(e)] = m; else Ag[tl_phys(e)] = m;
         }
+        }
         STAMP(11);
         bsum3<true>(g2, q, gm, s);
         if (nhelp) {                          // the helpers' landmark sums, added in workgroup order (deterministic)
@@ -680,8 +948,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         }
         STAMP(2);
         if (PHASE == 0 && gm <= O.gradient_tolerance) { if (t == 0) { s.c.done = 1; s.c.term = 2; *P.ctl = s.c; } return; }
-        bool ok;
-        if constexpr (LDSM) ok = chol_blocked<true>(Alds, D, s); else ok = chol_blocked<false>(Ag, D, s, Alds);      // Alds = staging of the active tile column
+        if constexpr (CHAIN == 0) { if constexpr (LDSM) ok = chol_blocked<true>(Alds, D, s); else ok = chol_blocked<false>(P.M, D, s, Alds); }      // Alds = staging of the active tile column
         STAMP(3);
 #ifdef VIL_STAMPS
         if (t == 0) { P.dbg[20] = s.tacc[0]; P.dbg[21] = s.tacc[1]; P.dbg[22] = s.tacc[2]; P.dbg[24] = s.tacc[3]; P.dbg[25] = s.tacc[4]; P.dbg[26] = s.tacc[5]; }
@@ -699,7 +966,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             if (t == 0) *P.ctl = s.c;
             return;
         }
-        if constexpr (LDSM) back_subst(Alds, D, s); else back_subst(Ag, D, s);
+        if constexpr (CHAIN == 0) { if constexpr (LDSM) back_subst(Alds, D, s); else back_subst(P.M, D, s); }
         STAMP(4);
 #ifdef VIL_STAMPS
         if (t == 0) P.dbg[23] = s.tacc[0];

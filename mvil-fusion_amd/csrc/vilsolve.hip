@@ -499,6 +499,37 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     if (c->lds_sweep > 160 * 1024) return VIL_ERR_UNSUPPORTED;
     HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep));
     c->n_blocks_reduce = (D * (D + 1) / 2 + RED_EPW - 1) / RED_EPW + (2 * D + RED_EPW - 1) / RED_EPW + 1;
+    // ---- step kernel variant: the speed-bias part of the reduced matrix is a chain whenever every IMU factor couples (k, k+1)
+    //      and the prior's speed-bias blocks are neighbours (VINS: exactly one) -> vil_chain.hpp; anything else: dense path
+    {
+        bool chain = getenv("VIL_DENSE_STEP") == nullptr;
+        for (int f = 0; f < p->n_imu && chain; ++f) if (std::abs(p->imu_i[f] - p->imu_j[f]) > 1) chain = false;
+        if (P.pn) {
+            std::vector<int> psb;
+            for (int b = 0; b < p->prior.nblk; ++b) if (p->prior.blk_kind[b] == VIL_BLK_SPEEDBIAS) psb.push_back(p->prior.blk_index[b]);
+            for (int a : psb) for (int b : psb) if (std::abs(a - b) > 1) chain = false;
+        }
+        P.chain = 0; P.chain_rs = vd::chain_rs(K);
+        if (chain) {
+            const size_t Tp = (size_t)(NV + 1 + 15) / 16, tiles = (size_t)TILE_SZ * (Tp * (Tp + 1) / 2), wt = (size_t)(9 * K + 3) * P.chain_rs, scr = vd::chain_scratch_doubles(K);
+            const size_t fixed = sizeof(vd::StepShared) + 512;
+            if (8 * (tiles + wt + scr) + fixed <= 160 * 1024) { P.chain = 1; c->lds_step = 8 * (tiles + wt + scr); }
+            else if (8 * (tiles + scr) + fixed <= 160 * 1024) { P.chain = 2; c->lds_step = 8 * (tiles + scr); }
+        }
+        c->P.chain = P.chain; c->P.chain_rs = P.chain_rs;
+    }
+    if (P.chain) {
+        c->step_lds = true;
+        if (P.chain == 1) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+        } else {
+            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+        }
+    } else {
     { const size_t T = (size_t)(D + 1 + 15) / 16; c->lds_step = 8 * TILE_SZ * (T * (T + 1) / 2); }   // 16x16-tiled (row stride 17) lower storage incl. the rhs row
     c->step_lds = c->lds_step + sizeof(vd::StepShared) + 256 <= 160 * 1024;
     if (c->step_lds) {
@@ -513,6 +544,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         HIPCHK(hipFuncSetAttribute((const void*)k_step<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
         HIPCHK(hipFuncSetAttribute((const void*)k_step<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
         HIPCHK(hipFuncSetAttribute((const void*)k_step<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+    }
     }
     // one-time set-up: IMU sqrt-information, prior contraction
     HIPCHK(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
@@ -612,21 +644,27 @@ static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEve
     hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce), dim3(VIL_THREADS), 0, c->stream, c->P);
     if (ev_mid) hipEventRecord(ev_mid, c->stream);
     if (!step) return VIL_OK;
-    if (!c->split) {
-        if (c->step_lds) hipLaunchKernelGGL((k_step<true, 0>), dim3(1 + c->P.n_help), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
-        else hipLaunchKernelGGL((k_step<false, 0>), dim3(1 + c->P.n_help), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
-        return VIL_OK;
-    }
+    auto launch_step = [&](int phase, int nwg) {
+        const dim3 g(nwg), b(VIL_STEP_THREADS);
+        #define VIL_STEP_LAUNCH(L, CH) do { \
+            if (phase == 0) hipLaunchKernelGGL((k_step<L, 0, CH>), g, b, c->lds_step, c->stream, c->P, so); \
+            else if (phase == 1) hipLaunchKernelGGL((k_step<L, 1, CH>), g, b, c->lds_step, c->stream, c->P, so); \
+            else hipLaunchKernelGGL((k_step<L, 2, CH>), g, b, c->lds_step, c->stream, c->P, so); } while (0)
+        if (c->P.chain == 1) VIL_STEP_LAUNCH(true, 1);
+        else if (c->P.chain == 2) VIL_STEP_LAUNCH(true, 2);
+        else if (c->step_lds) VIL_STEP_LAUNCH(true, 0);
+        else VIL_STEP_LAUNCH(false, 0);
+        #undef VIL_STEP_LAUNCH
+    };
+    if (!c->split) { launch_step(0, 1 + c->P.n_help); return VIL_OK; }
     // multi-GPU: all-reduce the partial reduced system (+ step norms), step A, all-reduce 5 scalars, step B
     const size_t cnt = (size_t)c->D * c->D + 3 * (size_t)c->D + 3;
     int st = all_reduce(c, c->P.arstage, cnt);
     if (st != VIL_OK) return st;
-    if (c->step_lds) hipLaunchKernelGGL((k_step<true, 1>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
-    else hipLaunchKernelGGL((k_step<false, 1>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
+    launch_step(1, 1);
     st = all_reduce(c, c->P.scal, 8);
     if (st != VIL_OK) return st;
-    if (c->step_lds) hipLaunchKernelGGL((k_step<true, 2>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
-    else hipLaunchKernelGGL((k_step<false, 2>), dim3(1), dim3(VIL_STEP_THREADS), c->lds_step, c->stream, c->P, so);
+    launch_step(2, 1);
     return VIL_OK;
 }
 
