@@ -22,9 +22,20 @@ namespace vd {
 
 __host__ __device__ inline int chain_rs(int K) { int rs = ((6 * K + 8 + 15) >> 4) << 4; if ((rs & 31) != 16) rs += 16; return rs; }   // row stride of W^T: >= 16 T, = 16 mod 32 (LDS banks)
 __host__ __device__ inline int even_up(int v) { return (v + 1) & ~1; }
-// doubles of chain scratch behind the tile array (and W^T): Dk 2x81 | Ls 2x81 | carry of the backward direction R x 9 |
-// L_kk (45 + 9 reciprocal pivots) per block | sub-diagonal block per block | t (9K)
-__host__ __device__ inline size_t chain_scratch_doubles(int K) { const int R = 6 * K + 8; return 162 + 162 + (size_t)9 * R + even_up(54 * K) + even_up(81 * K) + even_up(9 * K) + 16; }
+// Chain scratch in LDS behind the tile array (and W^T), in doubles:
+//   Dk 2 x 82 | L_kk (45 + 9 reciprocal pivots) per block | sub-diagonal block per block (82 each) | carry of the backward
+//   direction R x 9 | t (9K) | 8 ints of flags
+struct ChainLds {
+    double* Dk; double* Ldg; double* Lsb; double* cB; double* tB;
+    volatile int* flag;       // [0], [1]: blocks published by the recursion wave of direction d; [2]: middle factor published;
+                              // [3], [4]: carry of the backward direction published by its two row waves; [5]: a pivot was not positive
+};
+__host__ __device__ inline size_t chain_scratch_doubles(int K) { const int R = 6 * K + 8; return 164 + (size_t)54 * K + (size_t)82 * K + (size_t)9 * R + even_up(9 * K) + 8; }
+__device__ __forceinline__ ChainLds chain_lds(double* cs, int K) {
+    ChainLds L; const int R = 6 * K + 8;
+    L.Dk = cs; L.Ldg = cs + 164; L.Lsb = L.Ldg + 54 * K; L.cB = L.Lsb + 82 * K; L.tB = L.cB + 9 * R; L.flag = (volatile int*)(L.tB + even_up(9 * K));
+    return L;
+}
 
 struct L9 { double l[45]; double r[9]; };     // lower factor, l[i(i+1)/2 + j], and reciprocal pivots
 
@@ -55,6 +66,222 @@ __device__ __forceinline__ bool chol9(const double* Dk, L9& o) {
 }
 
 #define CHAIN_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+__device__ __forceinline__ void chain_wait(volatile int* f, int v) { while (*f < v) __builtin_amdgcn_s_sleep(1); CHAIN_FENCE(); }
+__device__ __forceinline__ void chain_post(volatile int* f, int v) { CHAIN_FENCE(); if ((threadIdx.x & 63) == 0) *f = v; }   // LDS operations of a wave execute in order
+
+// solve one panel row against the factored 9 x 9 block: w = a L^-T
+__device__ __forceinline__ void row_solve9(const double* l, const double* r, const double* a, double* w) {
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+        double acc = a[p];
+#pragma unroll
+        for (int c = 0; c < p; ++c) acc -= w[c] * l[(p * (p + 1) >> 1) + c];
+        w[p] = acc * r[p];
+    }
+}
+
+// Two-sided elimination of the speed-bias chain, barrier-free inside the workgroup.  Waves 0 / 1 run the 9 x 9 recursion of the
+// forward / backward direction (D_k -> L_kk -> L_{k+-1,k} -> D_{k+-1}) and publish every factored block through LDS + a flag;
+// waves 2,3 / 4,5 own the pose-part rows (incl. the right-hand side) of the forward / backward direction and follow the flags:
+// row solve against L_kk, W^T column block to Wt, fill carried into the next block.  Wave 0 finally factors the middle block,
+// waves 2,3 finish its rows.  Other waves return at once (the caller gives them the tile packing).  The caller zeroes the flags
+// before and puts a workgroup barrier after.
+// SRC: raw(i, j) raw S' entry; sc(j) scale of reduced column j; madd(j) = mu dc_j^2; rowscale(r) scale applied to pose row r
+// (1 when the row scaling is deferred); rhsraw(j) reduced gradient of column j; u(j) (WITHQ) the vector of the quadratic form
+// on the chain columns; row_done(d, r, z, q): z = (S'_pb u_b)[r] over the blocks of direction d (the step kernel adds 2 u_r z).
+// WITHQ: qacc receives this lane's share of u^T S' u over every entry of S' with a row or a column in the chain part (each
+// raw entry passes through exactly one lane here: pose row x chain block in the row waves, diagonal and sub-diagonal blocks in
+// the recursion waves).
+template <bool WITHQ, class SRC>
+__device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, const int NP, const int RS, double* Wt, const ChainLds& L, double& qacc, long long* dbg = nullptr) {
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+#ifdef VIL_STAMPS
+    #define CSTMP(k) do { if (lane == 0 && dbg) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); dbg[k] = tt_; } } while (0)
+#else
+    #define CSTMP(k) do {} while (0)
+#endif
+    if (wave >= 6) return;
+    const int R = NP + 1, m = K >> 1, nf = m, nb = K - 1 - m;
+    if (wave < 2) {
+        // ---------------- recursion wave of direction d ----------------------------------------------------------------------
+        const int d = wave, nd = d == 0 ? nf : nb;
+        int di = 0, dj = 0;
+        { const int e = lane < 45 ? lane : 0; while ((di + 1) * (di + 2) / 2 <= e) ++di; dj = e - di * (di + 1) / 2; }
+        bool ok = true;
+        auto diag_entry = [&](int k) { const int gi = NP + 9 * k + di, gj = NP + 9 * k + dj; return src.raw(gi, gj); };
+        auto diag_scaled = [&](int k, double v) { const int gi = NP + 9 * k + di, gj = NP + 9 * k + dj; double mv = src.sc(gi) * v * src.sc(gj); if (di == dj) mv += src.madd(gi); return mv; };
+        auto sub_rows = [&](int k, int kn, double* a) {           // row `lane` of block kn against the columns of block k
+            const int row = NP + 9 * min(max(kn, 0), K - 1) + min(lane, 8);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) a[c] = src.raw(row, NP + 9 * k + c);
+        };
+        double dv = 0.0, an[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) an[c] = 0.0;
+        const int k0 = d == 0 ? 0 : K - 1;
+        if (nd > 0) { dv = diag_entry(k0); sub_rows(k0, d == 0 ? 1 : K - 2, an); }
+        else if (d == 0) dv = diag_entry(m);
+        for (int st = 0; st < nd; ++st) {
+            const int k = d == 0 ? st : K - 1 - st, kn = d == 0 ? k + 1 : k - 1, kp = d == 0 ? k - 1 : k + 1;
+            double a[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) a[c] = an[c];
+            const double dcur = dv;
+            // next step's raw entries (or the middle block's diagonal) while this one computes
+            if (st + 1 < nd) { dv = diag_entry(kn); sub_rows(kn, d == 0 ? kn + 1 : kn - 1, an); }
+            else if (d == 0) dv = diag_entry(m);
+            if (lane < 45) {
+                double v = diag_scaled(k, dcur);
+                if (WITHQ) qacc += (di == dj ? 1.0 : 2.0) * src.u(NP + 9 * k + di) * dcur * src.u(NP + 9 * k + dj);
+                if (st > 0) { const double* Lp = L.Lsb + 82 * kp;
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) v -= Lp[di * 9 + c] * Lp[dj * 9 + c]; }
+                L.Dk[82 * d + di * 9 + dj] = v;
+            }
+            CHAIN_FENCE();
+            L9 Lf;
+            ok = chol9(L.Dk + 82 * d, Lf) && ok;
+            if (lane < 9) {
+                const double rsc = src.sc(NP + 9 * kn + lane);
+                double w[9];
+                if (WITHQ) {
+                    double qs = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) qs += a[c] * src.u(NP + 9 * k + c);
+                    qacc += 2.0 * src.u(NP + 9 * kn + lane) * qs;
+                }
+#pragma unroll
+                for (int c = 0; c < 9; ++c) a[c] = rsc * a[c] * src.sc(NP + 9 * k + c);
+                row_solve9(Lf.l, Lf.r, a, w);
+#pragma unroll
+                for (int c = 0; c < 9; ++c) L.Lsb[82 * k + lane * 9 + c] = w[c];
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int e = 0; e < 45; ++e) L.Ldg[54 * k + e] = Lf.l[e];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) L.Ldg[54 * k + 45 + e] = Lf.r[e];
+            }
+            chain_post(L.flag + d, st + 1);
+            if (d == 0 && st < 6) CSTMP(48 + st);
+        }
+        if (d == 0) {                                  // middle block: both directions meet
+            if (nb > 0) chain_wait(L.flag + 1, nb);
+            if (lane < 45) {
+                double v = diag_scaled(m, dv);
+                if (WITHQ) qacc += (di == dj ? 1.0 : 2.0) * src.u(NP + 9 * m + di) * dv * src.u(NP + 9 * m + dj);
+                if (nf > 0) { const double* Lp = L.Lsb + 82 * (m - 1);
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) v -= Lp[di * 9 + c] * Lp[dj * 9 + c]; }
+                if (nb > 0) { const double* Lp = L.Lsb + 82 * (m + 1);
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) v -= Lp[di * 9 + c] * Lp[dj * 9 + c]; }
+                L.Dk[di * 9 + dj] = v;
+            }
+            CHAIN_FENCE();
+            L9 Lf;
+            ok = chol9(L.Dk, Lf) && ok;
+            if (lane == 0) {
+#pragma unroll
+                for (int e = 0; e < 45; ++e) L.Ldg[54 * m + e] = Lf.l[e];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) L.Ldg[54 * m + 45 + e] = Lf.r[e];
+            }
+            chain_post(L.flag + 2, 1);
+            CSTMP(54);
+        }
+        if (!ok) L.flag[5] = 1;
+        return;
+    }
+    // ---------------- row waves: pose-part row r (r == NP: right-hand side) of direction d -------------------------------------
+    const int d = (wave - 2) >> 1, half = (wave - 2) & 1, r = half * 64 + lane, nd = d == 0 ? nf : nb;
+    const bool valid = r < R;
+    const int rc = min(r, NP - 1);
+    const double rsc = r < NP ? src.rowscale(rc) : 1.0;
+    double zr = 0.0;                                   // (S'_pb u_b)[r], accumulated over the blocks of this direction
+    auto fetch = [&](int k, double* a) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) a[c] = src.raw(rc, NP + 9 * k + c);
+        if (r >= NP) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) a[c] = src.rhsraw(NP + 9 * k + c);
+        }
+    };
+    auto load_factor = [&](int k, double* l, double* rv) {
+        const double* p = L.Ldg + 54 * k;
+#pragma unroll
+        for (int e = 0; e < 45; ++e) l[e] = p[e];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) rv[e] = p[45 + e];
+    };
+    double carry[9], an[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { carry[c] = 0.0; an[c] = 0.0; }
+    if (nd > 0) fetch(d == 0 ? 0 : K - 1, an);
+    else if (d == 0) fetch(m, an);
+    for (int st = 0; st < nd; ++st) {
+        const int k = d == 0 ? st : K - 1 - st, kn = d == 0 ? k + 1 : k - 1;
+        double a[9], w[9], l[45], rv[9];
+        if (WITHQ) {
+            double qs = 0.0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) qs += an[c] * src.u(NP + 9 * k + c);
+            zr += qs;
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) a[c] = rsc * an[c] * src.sc(NP + 9 * k + c) - carry[c];
+        if (st + 1 < nd) fetch(kn, an);
+        else if (d == 0) fetch(m, an);
+        chain_wait(L.flag + d, st + 1);
+        load_factor(k, l, rv);
+        row_solve9(l, rv, a, w);
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) Wt[(size_t)(9 * k + c) * RS + r] = w[c];
+        }
+        const double* L1 = L.Lsb + 82 * k;
+#pragma unroll
+        for (int cn = 0; cn < 9; ++cn) {
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) acc += w[c] * L1[cn * 9 + c];
+            carry[cn] = acc;
+        }
+    }
+    if (d == 1) {
+        if (nb > 0) {
+            if (valid) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) L.cB[r * 9 + c] = carry[c];
+            }
+            chain_post(L.flag + 3 + half, 1);
+        }
+        if (WITHQ && r < NP) src.row_done(1, r, zr, qacc);       // (not the right-hand-side row)
+        if (half == 0) CSTMP(56);
+        return;
+    }
+    chain_wait(L.flag + 2, 1);
+    if (nb > 0) { chain_wait(L.flag + 3, 1); chain_wait(L.flag + 4, 1); }
+    {
+        double a[9], w[9], l[45], rv[9];
+        if (WITHQ) {
+            double qs = 0.0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) qs += an[c] * src.u(NP + 9 * m + c);
+            zr += qs;
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) a[c] = rsc * an[c] * src.sc(NP + 9 * m + c) - carry[c] - ((nb > 0 && valid) ? L.cB[min(r, R - 1) * 9 + c] : 0.0);
+        load_factor(m, l, rv);
+        row_solve9(l, rv, a, w);
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) Wt[(size_t)(9 * m + c) * RS + r] = w[c];
+        }
+    }
+    if (WITHQ && r < NP) src.row_done(0, r, zr, qacc);
+    if (half == 0) CSTMP(55);
+}
 
 // One block of the chain back substitution, executed by ONE wave:  x_k = L_kk^-T (t_k - Ls_k^T x_next).
 // Ldg: 45 + 9 doubles of block k; Lsb: its sub-diagonal block (rows of the neighbouring block that was eliminated after it)

@@ -30,6 +30,8 @@ struct Ctl {          // trust-region state, lives in device memory, owned by th
     int phase_need, skip_b;       // split-step hand-off (multi-GPU: step A | all-reduce scalars | step B)
     double radius, mu, cost_cur, model_change, alpha, dogleg_norm, initial_cost, cand_cost;
     double mu_used, gn2, g2, gg;   // dogleg scalars of the current linearisation (reused after a rejected step)
+    double cg, cn;                 // dogleg coefficients of the candidate: the sweep forms lambda_cand = lambda_cur + cg la + cn lb
+    double saa, sab, sbb, xnl;     // landmark sums |la|^2, la.lb, |lb|^2, |lambda|^2 of the current linearisation (step norm without a landmark pass)
     double cost_trace[64], radius_trace[64];
 };
 
@@ -90,8 +92,16 @@ struct DevP {
     // helper workgroups of the single-GPU step kernel (landmark pre-pass on extra CUs): n_help of them, each publishes
     // {q, g2, gm} in hpart[4 * k ..] and then stores the launch epoch in hflag[k]; only the master workgroup ever waits
     int n_help; double* hpart; int* hflag;
+    double* hpart2; int* hflag2; int* xflag; int* xstat;      // second landmark pass of the helpers (k_step)
+    double* la; double* lb;        // L each: step directions of the inverse depths (Cauchy, Gauss-Newton), written by the step kernel's landmark pass
     // structure-exploiting solve (vil_chain.hpp): 0 dense, 1 chain with W^T in LDS, 2 chain with W^T in global memory (P.M)
     int chain, chain_rs;
+    // chain eliminated ahead of the step kernel by an extra workgroup of k_reduce (vil_prechain.hpp), straight from the IMU / prior
+    // partial records: prechain = 1 (single GPU, IMU factors (k, k+1) only).  imu_as_i[k] / imu_as_j[k]: the IMU factor in which
+    // frame k is the first / second frame (-1: none).  Outputs (global): W^T with unscaled pose rows, the factored 9 x 9 blocks,
+    // scales of the chain columns, pieces of u^T S' u, status.
+    int prechain; const int* imu_as_i; const int* imu_as_j;
+    double* chW; double* chLdg; double* chLsb; double* chSc; double* chDc; double* chZ; double* chQ; int* chOk;
 };
 
 __host__ __device__ inline int xo_pose(const DevP& P, int k) { return 7 * k; }

@@ -455,237 +455,110 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
 //      tiles on the matrix cores, dense Cholesky + back substitution on 6K + 8 rows, back-substitute the chain.
 // In: s.sc, s.dcs, s.y (= u, for the camera share of u^T H u), s.gd.  Out: solution of M x = rhs in s.y[0 .. D); qpart gets
 // this thread's share of u_c^T S' u_c.  Returns false (uniformly) when a pivot is not positive.
-// Thread roles: t in [0, 192) forward direction, [192, 384) backward direction -- lane q of a direction owns panel row q
-// (q < 9: row q of the neighbouring chain block, then the 6K + 8 pose rows; the last one is the right-hand side);
-// every other thread (whole waves) packs the pose tiles meanwhile, two of those waves also keep the factors for the
-// back substitution.
-template <bool WLDS>
-__device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart) {
+struct ChainSrcStep {                      // the chain's view of the system inside the step kernel: S' in global memory, scales in LDS
+    const double* S; int D; const double* sc_; const double* dcs_; const double* gd_; const double* u_; double mu;
+    __device__ __forceinline__ double u(int i) const { return u_[i]; }
+    __device__ __forceinline__ double raw(int i, int j) const { return S[(size_t)i * D + j]; }
+    __device__ __forceinline__ double sc(int j) const { return sc_[j]; }
+    __device__ __forceinline__ double madd(int j) const { const double d = dcs_[j]; return mu * d * d; }
+    __device__ __forceinline__ double rowscale(int r) const { return sc_[r]; }
+    __device__ __forceinline__ double rhsraw(int j) const { return gd_[j]; }
+    __device__ __forceinline__ void row_done(int, int r, double zr, double& q) const { q += 2.0 * u_[r] * zr; }
+};
+
+template <bool WLDS, class PUB>
+__device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart, PUB pub) {
     const int t = threadIdx.x;
+#ifdef VIL_STAMPS
+    #define SSTAMP(k) do { if (t == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[40 + k] = tt_; } } while (0)
+#else
+    #define SSTAMP(k) do {} while (0)
+#endif
+    SSTAMP(0);
     const int K = P.K, D = P.D, NP = P.NV, R = NP + 1, T = (R + 15) >> 4, ntile = (T * (T + 1)) >> 1;
-    const int RS = P.chain_rs, NB = 9 * K;
+    const int RS = P.chain_rs, NB = 9 * K, m = K >> 1;
     double* Tl = lds;
     double* Wt = WLDS ? lds + ntile * TILE_SZ : P.M;                       // W^T: column j of the chain at Wt[j * RS + row]
-    double* cs = lds + ntile * TILE_SZ + (WLDS ? (size_t)(NB + 3) * RS : 0);
-    double* Dk = cs; double* Ls = cs + 162; double* cB = cs + 324;
-    double* Ldg = cB + 9 * R; double* Lsb = Ldg + even_up(54 * K); double* tB = Lsb + even_up(81 * K);
-    const int m = K >> 1, nf = m, nb = K - 1 - m, nst = max(nf, nb);
-    const int d = t < 192 ? 0 : (t < 384 ? 1 : 2);
-    const int q = t - 192 * d;
-    const int NR = 9 + R, NRpad = (NR + 63) & ~63;
-    const bool chainl = d < 2 && q < NR;              // owns a panel row
-    const bool dlane = d < 2 && q < 45;               // owns entry (di, dj) of the 9 x 9 diagonal blocks (NR < 45 when K <= 4)
-    const bool packl = d == 2 || q >= NRpad;
-    const int nxtra = 192 - NRpad, npack = 128 + 2 * nxtra;
-    const int pl = d == 2 ? q : 128 + d * nxtra + (q - NRpad);
-    const int nd = d == 0 ? nf : nb;
-    // ---- packing of the pose tiles, sliced over the barrier intervals of the chain --------------------------------------
-    const int NE = ntile << 8, per_lane = (NE + npack - 1) / npack, NI = 2 * nst + 2, pcnt = (per_lane + NI - 1) / NI;
-    auto pack_slice = [&](int iv) {
-        if (!packl) return;
-        for (int j = iv * pcnt; j < (iv + 1) * pcnt; ++j) {
-            const int e = pl + j * npack;
-            if (e >= NE) break;
-            const int tile = e >> 8, w = e & 255;
-            const int i = (s.tI[tile] << 4) + (w >> 4), jj = (s.tJ[tile] << 4) + (w & 15);
-            double mv = 0.0;
-            if (i < NP && jj <= i) {
-                const double v = sb.S[(size_t)i * D + jj];
-                if (cam) qpart += (i == jj ? 1.0 : 2.0) * s.y[i] * v * s.y[jj];
-                mv = s.sc[i] * v * s.sc[jj];
-                if (i == jj) mv += mu * s.dcs[i] * s.dcs[i];
-            } else if (i == NP && jj < NP) mv = s.sc[jj] * s.gd[jj];
-            Tl[tl_phys(e)] = mv;
-        }
-    };
-    // ---- raw entries of this lane's panel row against the columns of block k (address always valid; the rhs row reads LDS)
-    const bool prow = q >= 9;                         // pose-part row (incl. rhs) vs row of the neighbouring chain block
-    const int r = q - 9;                              // pose row index (r == NP: right-hand side)
-    auto fetch = [&](int k, int kn, double* a) {
-        const int row = prow ? min(r, NP - 1) : NP + 9 * min(max(kn, 0), K - 1) + q;
-        const double* p = sb.S + (size_t)min(row, D - 1) * D + NP + 9 * k;
-#pragma unroll
-        for (int c = 0; c < 9; ++c) a[c] = p[c];
-        if (prow && r == NP) {
-#pragma unroll
-            for (int c = 0; c < 9; ++c) a[c] = s.gd[NP + 9 * k + c];
-        }
-    };
-    // entry (i, j), j <= i, of a 9 x 9 diagonal block for the lanes q < 45
-    int di = 0, dj = 0;
-    { int e = q < 45 ? q : 0; while ((di + 1) * (di + 2) / 2 <= e) ++di; dj = e - di * (di + 1) / 2; }
-    auto diag_raw = [&](int k) { return sb.S[(size_t)(NP + 9 * k + di) * D + NP + 9 * k + dj]; };
-    auto diag_scaled = [&](int k, double v) {
-        const double si = s.sc[NP + 9 * k + di], sj = s.sc[NP + 9 * k + dj];
-        double mv = si * v * sj;
-        if (di == dj) { const double dd = s.dcs[NP + 9 * k + di]; mv += mu * dd * dd; }
-        return mv;
-    };
-    double carry[9], an[9], qa = 0.0, dnext = 0.0;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) { carry[c] = 0.0; an[c] = 0.0; }
-    const int k0 = d == 0 ? 0 : K - 1;
-    if (chainl) {
-        if (nd > 0) fetch(k0, d == 0 ? 1 : K - 2, an);
-        else if (d == 0) fetch(m, m, an);             // K = 1: only the middle block
-    }
-    if (dlane && nd > 0) {                            // D of the first block of this direction
-        const double v = diag_raw(k0);
-        Dk[81 * d + di * 9 + dj] = diag_scaled(k0, v);
-        if (cam) qpart += (di == dj ? 1.0 : 2.0) * s.y[NP + 9 * k0 + di] * v * s.y[NP + 9 * k0 + dj];
-    }
-    const double yrow = (chainl && prow && r < NP) ? s.y[r] : 0.0;
-    const double scrow_p = (chainl && prow) ? (r < NP ? s.sc[r] : 1.0) : 0.0;
+    const ChainLds L = chain_lds(lds + ntile * TILE_SZ + (WLDS ? (size_t)(NB + 3) * RS : 0), K);
+    if (t < 8) L.flag[t] = 0;
     __syncthreads();
-    bool ok = true;
-    for (int st = 0; st < nst; ++st) {
-        const bool act = chainl && st < nd;
-        const int k = d == 0 ? st : K - 1 - st, kn = d == 0 ? k + 1 : k - 1;
-        double w[9];
-        const bool dact = dlane && st < nd;
-        if (dact) dnext = diag_raw(kn);                // raw entry of the next diagonal block (consumed after the barrier)
-        if (act) {
-            double a[9];
+    SSTAMP(1);
+    if (t < 384) {
+        const ChainSrcStep src{sb.S, D, s.sc, s.dcs, s.gd, s.y, mu};
+        double qc = 0.0;
+        if (cam) chain_eliminate<true>(src, K, NP, RS, Wt, L, qc, P.dbg); else chain_eliminate<false>(src, K, NP, RS, Wt, L, qc, P.dbg);
+        qpart += qc;
+    } else {
+        // waves 6, 7 meanwhile: the pose tiles M_pp = Sc S'_pp Sc + mu dc^2 (+ rhs row) with their share of u^T S' u; four
+        // elements per round so that the loads are in flight together
+        const int pl = t - 384, NE = ntile << 8;
+        for (int e0 = pl; e0 < NE; e0 += 4 * 128) {
+            double v[4]; int ii[4], jj[4];
 #pragma unroll
-            for (int c = 0; c < 9; ++c) a[c] = an[c];
-            // next step's rows (or the middle block's) while this one computes
-            if (st + 1 < nd) fetch(d == 0 ? k + 1 : k - 1, d == 0 ? k + 2 : k - 2, an);
-            else if (d == 0) fetch(m, m, an);
-            L9 Lf;
-            ok = chol9(Dk + 81 * d, Lf) && ok;
-            const double rsc = prow ? scrow_p : s.sc[NP + 9 * kn + q];
-            const double yr = prow ? yrow : s.y[NP + 9 * kn + q];
-            double qs = 0.0;
-#pragma unroll
-            for (int c = 0; c < 9; ++c) {
-                qs += a[c] * s.y[NP + 9 * k + c];
-                a[c] = rsc * a[c] * s.sc[NP + 9 * k + c] - (prow ? carry[c] : 0.0);
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + 128 * u, NE - 1), tile = e >> 8, w = e & 255;
+                ii[u] = (s.tI[tile] << 4) + (w >> 4); jj[u] = (s.tJ[tile] << 4) + (w & 15);
+                v[u] = sb.S[(size_t)min(ii[u], NP - 1) * D + min(jj[u], NP - 1)];
             }
-            qa += yr * qs;                            // (row, block k) and its mirror image: counted twice at the end
 #pragma unroll
-            for (int p = 0; p < 9; ++p) {
-                double acc = a[p];
-#pragma unroll
-                for (int c = 0; c < p; ++c) acc -= w[c] * Lf.l[(p * (p + 1) >> 1) + c];
-                w[p] = acc * Lf.r[p];
-            }
-            if (prow) {
-#pragma unroll
-                for (int c = 0; c < 9; ++c) Wt[(size_t)(9 * k + c) * RS + r] = w[c];
-            } else {
-#pragma unroll
-                for (int c = 0; c < 9; ++c) { Ls[81 * d + q * 9 + c] = w[c]; Lsb[81 * k + q * 9 + c] = w[c]; }
-            }
-        } else if (d == 2 && (q == 0 || q == 64) && st < (q == 0 ? nf : nb)) {
-            // a packing wave keeps the factor of this block for the back substitution (off the chain's critical path)
-            const int dd = q == 0 ? 0 : 1, kk = dd == 0 ? st : K - 1 - st;
-            L9 Lf;
-            chol9(Dk + 81 * dd, Lf);
-#pragma unroll
-            for (int e = 0; e < 45; ++e) Ldg[54 * kk + e] = Lf.l[e];
-#pragma unroll
-            for (int e = 0; e < 9; ++e) Ldg[54 * kk + 45 + e] = Lf.r[e];
-        }
-        pack_slice(2 * st);
-        __syncthreads();
-        if (act || dact) {
-            const double* L1 = Ls + 81 * d;
-            if (act && prow) {                         // fill carried into the next block of this direction
-#pragma unroll
-                for (int cn = 0; cn < 9; ++cn) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int c = 0; c < 9; ++c) acc += w[c] * L1[cn * 9 + c];
-                    carry[cn] = acc;
-                }
-            }
-            if (dact && kn != m) {                     // diagonal block of the next step (the middle block is formed below)
-                const double v = dnext;
-                double acc = diag_scaled(kn, v);
-#pragma unroll
-                for (int c = 0; c < 9; ++c) acc -= L1[di * 9 + c] * L1[dj * 9 + c];
-                Dk[81 * d + di * 9 + dj] = acc;
-                if (cam) qpart += (di == dj ? 1.0 : 2.0) * s.y[NP + 9 * kn + di] * v * s.y[NP + 9 * kn + dj];
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 128 * u;
+                if (e >= NE) break;
+                const int i = ii[u], j = jj[u];
+                double mv = 0.0;
+                if (i < NP && j <= i) {
+                    if (cam) qpart += (i == j ? 1.0 : 2.0) * s.y[i] * v[u] * s.y[j];
+                    mv = s.sc[i] * v[u] * s.sc[j];
+                    if (i == j) mv += mu * s.dcs[i] * s.dcs[i];
+                } else if (i == NP && j < NP) mv = s.sc[j] * s.gd[j];
+                Tl[tl_phys(e)] = mv;
             }
         }
-        pack_slice(2 * st + 1);
-        __syncthreads();
+#ifdef VIL_STAMPS
+        if (t == 384) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[57] = tt_; P.dbg[58] = tt_; }
+#endif
     }
-    // ---- middle block m: both directions meet ---------------------------------------------------------------------------
-    if (chainl && d == 1 && prow && nb > 0) {
-#pragma unroll
-        for (int c = 0; c < 9; ++c) cB[r * 9 + c] = carry[c];
-    }
-    if (dlane && d == 0) {
-        const double v = nf > 0 ? dnext : diag_raw(m);     // (the forward direction's last step fetched it)
-        double acc = diag_scaled(m, v);
-        if (nf > 0) {
-#pragma unroll
-            for (int c = 0; c < 9; ++c) acc -= Ls[di * 9 + c] * Ls[dj * 9 + c];
-        }
-        if (nb > 0) {
-#pragma unroll
-            for (int c = 0; c < 9; ++c) acc -= Ls[81 + di * 9 + c] * Ls[81 + dj * 9 + c];
-        }
-        Dk[di * 9 + dj] = acc;
-        if (cam) qpart += (di == dj ? 1.0 : 2.0) * s.y[NP + 9 * m + di] * v * s.y[NP + 9 * m + dj];
-    }
-    pack_slice(2 * nst);
     __syncthreads();
-    if (chainl && d == 0 && prow) {
-        L9 Lf;
-        ok = chol9(Dk, Lf) && ok;
-        double a[9], w[9], qs = 0.0;
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            qs += an[c] * s.y[NP + 9 * m + c];
-            a[c] = scrow_p * an[c] * s.sc[NP + 9 * m + c] - carry[c] - (nb > 0 ? cB[r * 9 + c] : 0.0);
-        }
-        qa += yrow * qs;
-#pragma unroll
-        for (int p = 0; p < 9; ++p) {
-            double acc = a[p];
-#pragma unroll
-            for (int c = 0; c < p; ++c) acc -= w[c] * Lf.l[(p * (p + 1) >> 1) + c];
-            w[p] = acc * Lf.r[p];
-        }
-#pragma unroll
-        for (int c = 0; c < 9; ++c) Wt[(size_t)(9 * m + c) * RS + r] = w[c];
-    } else if (d == 2 && q == 0) {
-        L9 Lf;
-        chol9(Dk, Lf);
-#pragma unroll
-        for (int e = 0; e < 45; ++e) Ldg[54 * m + e] = Lf.l[e];
-#pragma unroll
-        for (int e = 0; e < 9; ++e) Ldg[54 * m + 45 + e] = Lf.r[e];
-    }
-    if (cam) qpart += 2.0 * qa;
-    pack_slice(2 * nst + 1);
-    if (!ok) s.ok = 0;
-    __syncthreads();
-    if (!s.ok) return false;
+    SSTAMP(2);
+    if (L.flag[5]) return false;
+    SSTAMP(3);
     // ---- S_pp -= W W^T on the matrix cores, straight into the accumulators of the blocked Cholesky; dense part -------------
     auto schur = [&](d4* Creg, const int* tIJ) {
         const int lane = t & 63, row = lane & 15, kq = lane >> 4;
+        if (P.skip_mask & 128) return;                 // (timing probe only)
+        // eight k-steps (32 chain columns) per round: all sixteen operand loads are issued before the first MFMA, so the
+        // LDS / L2 latency is paid once per round instead of once per MFMA
 #pragma unroll
         for (int u = 0; u < CH_SLOTS; ++u) {
             if (tIJ[u] < 0) continue;
             const int I = tIJ[u] >> 8, J = tIJ[u] & 255;
             const bool va = (I << 4) + row < R, vb = (J << 4) + row < R;
-            const double* pa = Wt + (size_t)kq * RS + (I << 4) + row;
-            const double* pb = Wt + (size_t)kq * RS + (J << 4) + row;
+            const double* pa = Wt + (I << 4) + row;
+            const double* pb = Wt + (J << 4) + row;
             d4 c4 = Creg[u];
-            for (int kk = 0; kk < NB; kk += 4) {
-                const bool kv = kk + kq < NB;
-                const double a_ = pa[(size_t)kk * RS], b_ = pb[(size_t)kk * RS];
-                c4 = __builtin_amdgcn_mfma_f64_16x16x4f64((va && kv) ? -a_ : 0.0, (vb && kv) ? b_ : 0.0, c4, 0, 0, 0);
+            for (int kk = 0; kk < NB; kk += 32) {
+                double av[8], bv[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int kr = min(kk + 4 * g + kq, NB + 2);           // (rows NB .. NB+2 of W^T exist as padding)
+                    av[g] = pa[(size_t)kr * RS]; bv[g] = pb[(size_t)kr * RS];
+                }
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const bool kv = kk + 4 * g + kq < NB;
+                    c4 = __builtin_amdgcn_mfma_f64_16x16x4f64((va && kv) ? -av[g] : 0.0, (vb && kv) ? bv[g] : 0.0, c4, 0, 0, 0);
+                }
             }
             Creg[u] = c4;
         }
     };
     if (!chol_blocked<true>(Tl, NP, s, nullptr, schur)) return false;
+    SSTAMP(4);
     back_subst(Tl, NP, s);                             // x_p in s.y[0 .. NP)
+    pub();                                             // the landmark workgroups can start: they only need the pose part
+    SSTAMP(5);
     // ---- chain back substitution: t = y_b - W^T x_p, then outwards from the middle block -----------------------------------
+    double* tB = L.tB;
     {
         const int G = (4 * NB <= VIL_STEP_THREADS) ? 4 : 2;
         const int j = t / G, part = t - j * G;
@@ -697,11 +570,109 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
         if (j < NB && part == 0) tB[j] = Wt[(size_t)j * RS + NP] - acc;
     }
     __syncthreads();
+    if (t < 64) chain_block_back(L.Ldg + 54 * m, nullptr, tB + 9 * m, nullptr, s.y + NP + 9 * m);
+    __syncthreads();
+    if (t < 64) { for (int k = m - 1; k >= 0; --k) chain_block_back(L.Ldg + 54 * k, L.Lsb + 82 * k, tB + 9 * k, s.y + NP + 9 * (k + 1), s.y + NP + 9 * k); }
+    else if (t < 128) { for (int k = m + 1; k < K; ++k) chain_block_back(L.Ldg + 54 * k, L.Lsb + 82 * k, tB + 9 * k, s.y + NP + 9 * (k - 1), s.y + NP + 9 * k); }
+    __syncthreads();
+    SSTAMP(6);
+    return true;
+}
+
+// ---- chain eliminated ahead by k_reduce's extra workgroup (vil_prechain.hpp): pack the pose tiles, scale the pose rows of W
+//      while subtracting W W^T, dense part, chain back substitution.  Same contract as solve_chain.
+template <class PUB>
+__device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart, PUB pub) {
+    const int t = threadIdx.x;
+    SSTAMP(0);
+    const int K = P.K, D = P.D, NP = P.NV, R = NP + 1, T = (R + 15) >> 4, ntile = (T * (T + 1)) >> 1;
+    const int RS = P.chain_rs, NB = 9 * K, m = K >> 1;
+    double* Tl = lds;
+    const double* Wt = P.chW;
+    double* Ldg = lds + ntile * TILE_SZ; double* Lsb = Ldg + 54 * K; double* tB = Lsb + 82 * K;
+    {   // pose tiles M_pp = Sc S'_pp Sc + mu dc^2 (+ rhs row), their share of u^T S' u; loads batched eight at a time
+        const int NE = ntile << 8;
+        for (int e0 = t; e0 < NE; e0 += 8 * VIL_STEP_THREADS) {
+            double v[8]; int ii[8], jj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(e0 + VIL_STEP_THREADS * u, NE - 1), tile = e >> 8, w = e & 255;
+                ii[u] = (s.tI[tile] << 4) + (w >> 4); jj[u] = (s.tJ[tile] << 4) + (w & 15);
+                v[u] = sb.S[(size_t)min(ii[u], NP - 1) * D + min(jj[u], NP - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + VIL_STEP_THREADS * u;
+                if (e >= NE) break;
+                const int i = ii[u], j = jj[u];
+                double mv = 0.0;
+                if (i < NP && j <= i) {
+                    if (cam) qpart += (i == j ? 1.0 : 2.0) * s.y[i] * v[u] * s.y[j];
+                    mv = s.sc[i] * v[u] * s.sc[j];
+                    if (i == j) mv += mu * s.dcs[i] * s.dcs[i];
+                } else if (i == NP && j < NP) mv = s.sc[j] * s.gd[j];
+                Tl[tl_phys(e)] = mv;
+            }
+        }
+        for (int e = t; e < 54 * K; e += VIL_STEP_THREADS) Ldg[e] = P.chLdg[e];
+        for (int e = t; e < 82 * K; e += VIL_STEP_THREADS) Lsb[e] = P.chLsb[e];
+        if (cam) {                                     // chain share of u^T S' u: chain x chain + 2 u_p . (S'_pb u_b)
+            if (t < NP) qpart += 2.0 * s.y[t] * (P.chZ[t] + P.chZ[R + t]);
+            if (t == 0) qpart += P.chQ[0] + P.chQ[1];
+        }
+        if (t == 0 && !P.chOk[0]) s.ok = 0;
+    }
+    __syncthreads();
+    SSTAMP(2); SSTAMP(3);
+    if (!s.ok) return false;
+    auto schur = [&](d4* Creg, const int* tIJ) {
+        const int lane = t & 63, row = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int u = 0; u < CH_SLOTS; ++u) {
+            if (tIJ[u] < 0) continue;
+            const int I = tIJ[u] >> 8, J = tIJ[u] & 255;
+            const int ra = (I << 4) + row, rb = (J << 4) + row;
+            const double sa = ra < NP ? -s.sc[ra] : (ra == NP ? -1.0 : 0.0), sbv = rb < NP ? s.sc[rb] : (rb == NP ? 1.0 : 0.0);    // row scaling deferred by the chain workgroup
+            const double* pa = Wt + ra; const double* pb = Wt + rb;
+            d4 c4 = Creg[u];
+            for (int kk = 0; kk < NB; kk += 32) {
+                double av[8], bv[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int kr = min(kk + 4 * g + kq, NB + 2);
+                    av[g] = pa[(size_t)kr * RS]; bv[g] = pb[(size_t)kr * RS];
+                }
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const bool kv = kk + 4 * g + kq < NB;
+                    c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(kv ? sa * av[g] : 0.0, kv ? sbv * bv[g] : 0.0, c4, 0, 0, 0);
+                }
+            }
+            Creg[u] = c4;
+        }
+    };
+    if (!chol_blocked<true>(Tl, NP, s, nullptr, schur)) return false;
+    SSTAMP(4);
+    back_subst(Tl, NP, s);
+    pub();
+    SSTAMP(5);
+    {
+        const int G = (4 * NB <= VIL_STEP_THREADS) ? 4 : 2;
+        const int j = t / G, part = t - j * G;
+        const int jc = min(j, NB - 1);
+        double acc = 0.0;
+        for (int rr = part; rr < NP; rr += G) acc += Wt[(size_t)jc * RS + rr] * s.sc[rr] * s.y[rr];
+        acc += __shfl_xor(acc, 1, 64);
+        if (G == 4) acc += __shfl_xor(acc, 2, 64);
+        if (j < NB && part == 0) tB[j] = Wt[(size_t)j * RS + NP] - acc;
+    }
+    __syncthreads();
     if (t < 64) chain_block_back(Ldg + 54 * m, nullptr, tB + 9 * m, nullptr, s.y + NP + 9 * m);
     __syncthreads();
-    if (t < 64) { for (int k = m - 1; k >= 0; --k) chain_block_back(Ldg + 54 * k, Lsb + 81 * k, tB + 9 * k, s.y + NP + 9 * (k + 1), s.y + NP + 9 * k); }
-    else if (t < 128) { for (int k = m + 1; k < K; ++k) chain_block_back(Ldg + 54 * k, Lsb + 81 * k, tB + 9 * k, s.y + NP + 9 * (k - 1), s.y + NP + 9 * k); }
+    if (t < 64) { for (int k = m - 1; k >= 0; --k) chain_block_back(Ldg + 54 * k, Lsb + 82 * k, tB + 9 * k, s.y + NP + 9 * (k + 1), s.y + NP + 9 * k); }
+    else if (t < 128) { for (int k = m + 1; k < K; ++k) chain_block_back(Ldg + 54 * k, Lsb + 82 * k, tB + 9 * k, s.y + NP + 9 * (k - 1), s.y + NP + 9 * k); }
     __syncthreads();
+    SSTAMP(6);
     return true;
 }
 
@@ -710,7 +681,13 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
 // PHASE 0: whole step (single GPU).  PHASE 1 / 2: the step split around the all-reduce of the landmark-dependent
 // scalars (multi-GPU: every rank owns a slice of the landmarks).
 // CHAIN 0: dense factorisation of all D columns (LDSM: tile array in LDS or global).  CHAIN 1 / 2: vil_chain.hpp, with W^T in
-// LDS / in global memory (tiles always in LDS).
+// LDS / in global memory (tiles always in LDS).  CHAIN 3: the chain was eliminated by k_reduce's extra workgroup (vil_prechain.hpp).
+//
+// Landmarks never enter the step kernel's serial part: per landmark the pass after the solve leaves the two step directions
+//   la = Sl gradient_l / dl  (Cauchy direction),  lb = Sl gn_l / dl  (Gauss-Newton direction)
+// and six sums (|gn_l|^2, gn_l . g_l, |la|^2, la . lb, |lb|^2, |lambda|^2); the candidate inverse depth lambda + cg la + cn lb is
+// formed by the NEXT sweep's visual workgroups from the two dogleg coefficients in Ctl, and its norm follows from the sums.
+// With helper workgroups (PHASE 0, grid = 1 + n_help) that pass runs on their CUs while the master back-substitutes the chain.
 template <bool LDSM, int PHASE, int CHAIN = 0>
 __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) {
     using namespace vd;
@@ -718,10 +695,11 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     extern __shared__ double Alds[];
     const int t = threadIdx.x, NT = blockDim.x;
     const int D = P.D, L = P.L;
-    // PHASE 0 may be launched with 1 + P.n_help workgroups: the extra ones run the same judge on their own copy of Ctl,
-    // then do the landmark pre-pass of their slice on their own CU (that pass is bound by what ONE CU can pull out of
-    // L2), publish three partial sums and leave.  They never wait for anything; only the master spins (on their flags)
-    // and only the master writes Ctl / the candidate -- after every helper has signalled, i.e. has read the old Ctl.
+    // PHASE 0 may be launched with 1 + P.n_help workgroups: the extra ones run the same judge on their own copy of Ctl and
+    // do the two landmark passes of their slice on their own CU (those passes are bound by what ONE CU can pull out of L2).
+    // Flags (all compared with the launch epoch): hflag[k] -- helper k has read Ctl and published its pre-pass sums;
+    // xflag -- the master has published Sc x_p (xstat = 1) or given up (xstat = 0); hflag2[k] -- helper k's second pass is done.
+    // Only the master writes Ctl / the camera candidate, after every helper has signalled hflag.
     const bool helper = PHASE == 0 && blockIdx.x > 0;
     const int nhelp = (PHASE == 0) ? (int)gridDim.x - 1 : 0;
     if (t == 0) { s.c = *P.ctl; s.need = 0; s.was_first = 0; s.ok = 1; }
@@ -739,10 +717,9 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
 #endif
     if (s.c.done) return;                    // finished in an earlier launch: nobody writes anything
     const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
-    auto helper_done = [&]() { if (t == 0) { __threadfence(); __hip_atomic_store(P.hflag + (blockIdx.x - 1), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); } };
-    auto wait_helpers = [&]() {              // master, thread 0: all helpers have read Ctl (and published their sums)
-        if (t == 0) for (int k = 0; k < nhelp; ++k) while (__hip_atomic_load(P.hflag + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
-    };
+    auto post = [&](int* f) { if (t == 0) { __threadfence(); __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); } };
+    auto wait1 = [&](int* f) { while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1); };
+    auto wait_helpers = [&]() { if (t == 0) for (int k = 0; k < nhelp; ++k) wait1(P.hflag + k); };     // master: every helper has read Ctl
     const bool multi = P.split != 0;
     const bool cam = P.world <= 1 || P.rank == 0;      // camera-side terms of global sums are counted once
     STAMP(0);
@@ -756,6 +733,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             const double g2 = P.scal[0], q = P.scal[1], gm = P.scal[2];
             if (gm <= O.gradient_tolerance) { c.done = 1; c.term = 2; }
             c.alpha = g2 / q; c.mu_used = c.mu; c.gn2 = P.scal[3]; c.g2 = g2; c.gg = P.scal[4];
+            c.saa = P.scal[5]; c.sab = P.scal[6]; c.sbb = P.scal[7]; c.xnl = P.scal[8];
             c.mu = fmax(O.min_mu, 2.0 * c.mu / 10.0);
             c.phase_need = 0;
         }
@@ -802,37 +780,82 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     if (PHASE == 1) { sb.S = P.arstage; sb.gred = sb.S + (size_t)D * D; sb.bc = sb.gred + D; sb.diag = sb.bc + D; }   // read only when the candidate was just accepted
     const double* x = P.x[cur];
     double* xc = P.x[1 - cur];
+    // ---- the two landmark passes over [l0, l1) (helper: its slice; master without helpers: everything) -----------------------
+    // pass 1 (needs u = Sc gradient_/d of the camera part in vc): dl, gradient_l, share of u^T H u, |g|^2, max |b|
+    auto lm_pass1 = [&](int l0, int l1, const double* vc, double& q, double& g2, double& gm) {
+        for (int l = l0 + t; l < l1; l += NT) {
+            const double ip = sb.invp[l], Sl = P.Sl[l], h = sb.hll[l], b = sb.bl[l];
+            const double d = sqrt(fmin(fmax(Sl * Sl * h, 1e-6), 1e32));
+            const double g = ip != 0.0 ? Sl * b / d : 0.0;
+            P.dl[l] = d; P.gradl[l] = g;
+            if (ip != 0.0) {
+                const double ul = Sl * g / d;
+                const double ev = lm_dot(P, sb, l, vc);
+                q += ip * ev * ev + 2.0 * ul * ev + h * ul * ul;
+                g2 += g * g; gm = fmax(gm, fabs(b));
+            }
+        }
+    };
+    // pass 2 (needs Sc x_c of the pose part in vc): landmark back-substitution, step directions, the six sums
+    auto lm_pass2 = [&](int l0, int l1, const double* vc, double* sm /*6*/) {
+        for (int l = l0 + t; l < l1; l += NT) {
+            const double ip = sb.invp[l];
+            double a = 0.0, b = 0.0;
+            if (ip != 0.0) {
+                const double Sl = P.Sl[l], dl = P.dl[l], g = P.gradl[l];
+                const double xl = (sb.bl[l] - lm_dot(P, sb, l, vc)) * ip / Sl;
+                const double gnv = -xl * dl;
+                sm[0] += gnv * gnv; sm[1] += gnv * g;
+                a = Sl * g / dl; b = Sl * gnv / dl;
+                sm[2] += a * a; sm[3] += a * b; sm[4] += b * b;
+            }
+            P.la[l] = a; P.lb[l] = b;
+            if (multi ? (ip != 0.0) : !(P.lm_const && P.lm_const[l])) { const double lam = x[xo_lam(P) + l]; sm[5] += lam * lam; }
+        }
+    };
     if (helper) {
+        const int hk = (int)blockIdx.x - 1;
         if (!s.c.done && s.need) {
             // camera vectors u = Sc gradient_/d in LDS (nothing global is written here: that is the master's job)
-            for (int i = t; i < D; i += NT) {
+            for (int i = t; i < P.NV; i += NT) {
                 const double dg = sb.diag[i], b = sb.bc[i];
                 const double Sc = s.was_first ? (O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0) : P.Sc[i];
                 const double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
                 s.y[i] = Sc * (Sc * b / d) / d;
             }
             __syncthreads();
-            const int per = (L + nhelp - 1) / nhelp, l0 = ((int)blockIdx.x - 1) * per, l1 = min(L, l0 + per);
+            const int per = (L + nhelp - 1) / nhelp, l0 = hk * per, l1 = min(L, l0 + per);
             double q = 0, g2 = 0, gm = 0;
-            for (int l = l0 + t; l < l1; l += NT) {
-                const double ip = sb.invp[l], Sl = P.Sl[l], h = sb.hll[l], b = sb.bl[l];
-                const double d = sqrt(fmin(fmax(Sl * Sl * h, 1e-6), 1e32));
-                const double g = ip != 0.0 ? Sl * b / d : 0.0;
-                P.dl[l] = d; P.gradl[l] = g;
-                if (ip != 0.0) {
-                    const double ul = Sl * g / d;
-                    const double ev = lm_dot(P, sb, l, s.y);
-                    q += ip * ev * ev + 2.0 * ul * ev + h * ul * ul;
-                    g2 += g * g; gm = fmax(gm, fabs(b));
-                }
-            }
+            lm_pass1(l0, l1, s.y, q, g2, gm);
             bsum3<true>(g2, q, gm, s);
-            if (t == 0) { double* hp = P.hpart + 4 * ((int)blockIdx.x - 1); hp[0] = q; hp[1] = g2; hp[2] = gm; }
-        }
-        helper_done();
+            if (t == 0) { double* hp = P.hpart + 4 * hk; hp[0] = q; hp[1] = g2; hp[2] = gm; }
+            post(P.hflag + hk);
+            // second pass once the master has the pose part of the solution
+            if (t == 0) { wait1(P.xflag); s.ok = __hip_atomic_load(P.xstat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            __syncthreads();
+            if (s.ok) {
+                for (int i = t; i < P.NV; i += NT) s.y[i] = __hip_atomic_load(P.stepc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                double sm[6] = {0, 0, 0, 0, 0, 0};
+                lm_pass2(l0, l1, s.y, sm);
+                bsum3(sm[0], sm[1], sm[2], s); bsum3(sm[3], sm[4], sm[5], s);
+                if (t == 0) { double* hp = P.hpart2 + 8 * hk; for (int k = 0; k < 6; ++k) hp[k] = sm[k]; }
+                post(P.hflag2 + hk);
+            }
+        } else post(P.hflag + hk);
         return;
     }
     if (s.c.done) { if (t == 0) { wait_helpers(); *P.ctl = s.c; } return; }
+    bool xpub = false;                                 // the master owes the waiting helpers an xflag on every path through the need branch
+    auto publish_xp = [&](int okk) {                   // called by all threads; s.y[0 .. NV) = x_p when okk
+        if (nhelp) {
+            if (okk) for (int i = t; i < P.NV; i += NT) P.stepc[i] = s.sc[i] * s.y[i];
+            __syncthreads();
+            if (t == 0) { __hip_atomic_store(P.xstat, okk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            post(P.xflag);
+        }
+        xpub = true;
+    };
     // prefetch this thread's share of S' (tiled order) so that the global latency hides behind the vector passes
     double pf[PF_N];
     if (CHAIN == 0 && PHASE != 2 && s.need) {
@@ -858,8 +881,9 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         for (int i = t; i < D; i += NT) {
             const double dg = sb.diag[i], b = sb.bc[i];
             double Sc;
-            if (s.was_first) { Sc = O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0; P.Sc[i] = Sc; } else Sc = P.Sc[i];
-            const double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
+            if (s.was_first) { Sc = O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0; if (CHAIN == 3 && i >= P.NV) Sc = P.chSc[i - P.NV]; P.Sc[i] = Sc; } else Sc = P.Sc[i];
+            double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
+            if (CHAIN == 3 && i >= P.NV) d = P.chDc[i - P.NV];      // the very numbers the chain workgroup scaled M_bb with
             const double g = Sc * b / d;
             s.sc[i] = Sc; s.dcs[i] = d; s.gr[i] = g; s.y[i] = Sc * g / d; s.gd[i] = sb.gred[i];
             P.dc[i] = d; P.gradc[i] = g;
@@ -867,27 +891,17 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         }
         __syncthreads();
         STAMP(9);
-        // ---- one pass over the landmarks: dl, gradient_, and their share of u^T H u --------------------------
         double q = 0;
-        for (int l = t; l < (nhelp ? 0 : L); l += NT) {      // with helper workgroups this pass runs on their CUs
-            const double ip = sb.invp[l], Sl = P.Sl[l], h = sb.hll[l], b = sb.bl[l];
-            const double d = sqrt(fmin(fmax(Sl * Sl * h, 1e-6), 1e32));
-            const double g = ip != 0.0 ? Sl * b / d : 0.0;
-            P.dl[l] = d; P.gradl[l] = g;
-            if (ip != 0.0) {
-                const double ul = Sl * g / d;
-                const double ev = lm_dot(P, sb, l, s.y);
-                q += ip * ev * ev + 2.0 * ul * ev + h * ul * ul;
-                g2 += g * g; gm = fmax(gm, fabs(b));
-            }
-        }
+        if (!nhelp) lm_pass1(0, L, s.y, q, g2, gm);        // with helper workgroups this pass runs on their CUs
         STAMP(10);
         // ---- camera share of u^T H u, fused with packing M = Sc S' Sc + mu dc^2 (+ rhs row) into LDS ------------
         const double mu = s.c.mu;
         bool ok = true;
         if constexpr (CHAIN != 0) {
             __syncthreads();
-            ok = solve_chain<CHAIN == 1>(P, sb, s, Alds, mu, cam, q);      // packing, chain, Schur update, dense part, back substitution
+            auto pub = [&]() { publish_xp(1); };
+            if constexpr (CHAIN == 3) ok = solve_prechain(P, sb, s, Alds, mu, cam, q, pub);
+            else ok = solve_chain<CHAIN == 1>(P, sb, s, Alds, mu, cam, q, pub);      // packing, chain, Schur update, dense part, back substitution
         } else {
         // tiled storage: element e of the tile array -> (i, j); S entries were prefetched into registers at kernel start
         double* Ag = P.M;
@@ -947,7 +961,11 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             __syncthreads();
         }
         STAMP(2);
-        if (PHASE == 0 && gm <= O.gradient_tolerance) { if (t == 0) { s.c.done = 1; s.c.term = 2; *P.ctl = s.c; } return; }
+        if (PHASE == 0 && gm <= O.gradient_tolerance) {
+            if (!xpub) publish_xp(0);
+            if (t == 0) { s.c.done = 1; s.c.term = 2; *P.ctl = s.c; }
+            return;
+        }
         if constexpr (CHAIN == 0) { if constexpr (LDSM) ok = chol_blocked<true>(Alds, D, s); else ok = chol_blocked<false>(P.M, D, s, Alds); }      // Alds = staging of the active tile column
         STAMP(3);
 #ifdef VIL_STAMPS
@@ -955,23 +973,24 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
 #endif
         if (!ok) {
             // dogleg_strategy.cc: mu *= 10 and retry; the Schur pivots depend on mu, so re-sweep at x_cur
+            if (!xpub) publish_xp(0);
             if (t == 0) {
                 Ctl& c = s.c;
                 c.mu *= 10.0;
                 if (!(c.mu < O.max_mu)) { c.iter++; c.invalid_run++; c.reuse = 0; if (c.invalid_run >= 5) { c.done = 1; c.term = 6; c.status = -4; } }
-                c.resweep = 1; c.skip_b = (PHASE == 1) ? 1 : 0;
+                c.resweep = 1; c.cg = 0.0; c.cn = 0.0; c.skip_b = (PHASE == 1) ? 1 : 0;
             }
             for (int i = t; i < P.NS; i += NT) xc[i] = x[i];
             __syncthreads();
             if (t == 0) *P.ctl = s.c;
             return;
         }
-        if constexpr (CHAIN == 0) { if constexpr (LDSM) back_subst(Alds, D, s); else back_subst(P.M, D, s); }
+        if constexpr (CHAIN == 0) { if constexpr (LDSM) back_subst(Alds, D, s); else back_subst(P.M, D, s); publish_xp(1); }
         STAMP(4);
 #ifdef VIL_STAMPS
         if (t == 0) P.dbg[23] = s.tacc[0];
 #endif
-        // ---- gauss-newton step in dogleg space; landmark back-substitution fused with the dogleg sums ------------
+        // ---- gauss-newton step in dogleg space (camera part); landmark back-substitution + sums -----------------------------
         for (int i = t; i < D; i += NT) {
             const double xi = s.y[i];
             const double gnv = -xi * s.dcs[i];
@@ -980,30 +999,40 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             s.y[i] = s.sc[i] * xi;     // Sc x_c for the landmark back-substitution
         }
         __syncthreads();
-        for (int l = t; l < L; l += NT) {
-            const double ip = sb.invp[l];
-            double gnv = 0.0;
-            if (ip != 0.0) {
-                const double xl = (sb.bl[l] - lm_dot(P, sb, l, s.y)) * ip / P.Sl[l];
-                gnv = -xl * P.dl[l];
-                gn2 += gnv * gnv; gg += gnv * P.gradl[l];
+        double sm[6] = {0, 0, 0, 0, 0, 0};
+        if (!nhelp) lm_pass2(0, L, s.y, sm);
+        sm[0] += gn2; sm[1] += gg;
+        bsum3(sm[0], sm[1], sm[2], s); bsum3(sm[3], sm[4], sm[5], s);
+        if (nhelp) {
+            if (t == 0) {
+                for (int k = 0; k < nhelp; ++k) {
+                    wait1(P.hflag2 + k);
+                    for (int e = 0; e < 6; ++e) sm[e] += __hip_atomic_load(P.hpart2 + 8 * k + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                for (int e = 0; e < 6; ++e) s.red[e] = sm[e];
             }
-            P.gnl[l] = gnv;
+            __syncthreads();
+            for (int e = 0; e < 6; ++e) sm[e] = s.red[e];
+            __syncthreads();
         }
-        double dummy = 0;
-        bsum3(gn2, gg, dummy, s);
+        gn2 = sm[0]; gg = sm[1];
         if (PHASE == 1) {
-            if (t == 0) { P.scal[0] = g2; P.scal[1] = q; P.scal[2] = gm; P.scal[3] = gn2; P.scal[4] = gg; s.c.phase_need = 1; *P.ctl = s.c; }
+            if (t == 0) {
+                P.scal[0] = g2; P.scal[1] = q; P.scal[2] = gm; P.scal[3] = gn2; P.scal[4] = gg;
+                P.scal[5] = sm[2]; P.scal[6] = sm[3]; P.scal[7] = sm[4]; P.scal[8] = sm[5];
+                s.c.phase_need = 1; *P.ctl = s.c;
+            }
             return;
         }
         if (t == 0) {
             Ctl& c = s.c;
             c.alpha = g2 / q; c.mu_used = c.mu; c.gn2 = gn2; c.g2 = g2; c.gg = gg;
+            c.saa = sm[2]; c.sab = sm[3]; c.sbb = sm[4]; c.xnl = sm[5];
             c.mu = fmax(O.min_mu, 2.0 * c.mu / 10.0);
         }
         __syncthreads();
     } else {
-        if (PHASE == 1) { if (t == 0) { for (int k = 0; k < 5; ++k) P.scal[k] = 0.0; s.c.phase_need = 0; *P.ctl = s.c; } return; }
+        if (PHASE == 1) { if (t == 0) { for (int k = 0; k < 9; ++k) P.scal[k] = 0.0; s.c.phase_need = 0; *P.ctl = s.c; } return; }
         for (int i = t; i < D; i += NT) { s.sc[i] = P.Sc[i]; s.dcs[i] = P.dc[i]; s.gr[i] = P.gradc[i]; s.gn[i] = P.gnc[i]; }
         __syncthreads();
     }
@@ -1029,7 +1058,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     const double qd = cg * cg * (g2 / alpha) + 2.0 * cg * cn * (-g2 - mu_u * gg) + cn * cn * (-gg - mu_u * gn2);
     const double gd = cg * g2 + cn * gg;
     const double model_change = -(0.5 * qd + gd);
-    // ---------------- candidate state x_cur (+) step, parameter tolerance ---------------------------
+    // ---------------- candidate state x_cur (+) step: camera blocks here, inverse depths in the next sweep ----------------------
     for (int i = t; i < D; i += NT) s.y[i] = s.sc[i] * (cg * s.gr[i] + cn * s.gn[i]) / s.dcs[i];
     __syncthreads();
     const double* stepc = s.y;
@@ -1056,15 +1085,10 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             if (P.td_free && cam) { xn += in * in; sn += d * d; }
         }
     }
-    for (int l = t; l < L; l += NT) {
-        const double in = x[xo_lam(P) + l];
-        double d = 0.0;
-        if (sb.invp[l] != 0.0) d = P.Sl[l] * (cg * P.gradl[l] + cn * P.gnl[l]) / P.dl[l];
-        xc[xo_lam(P) + l] = in + d;
-        if (multi ? (sb.invp[l] != 0.0) : !(P.lm_const && P.lm_const[l])) { xn += in * in; sn += d * d; }
-    }
     double dummy2 = 0;
     bsum3(xn, sn, dummy2, s);
+    // landmark share of the norms from the sums of the pass (global sums after the all-reduce in the multi-GPU path: once)
+    if (!multi || cam) { xn += s.c.xnl; sn += cg * cg * s.c.saa + 2.0 * cg * cn * s.c.sab + cn * cn * s.c.sbb; }
     STAMP(6);
     if (t == 0) {
         Ctl& c = s.c;
@@ -1072,11 +1096,12 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         if (c.iter <= 64) { c.radius_trace[c.iter - 1] = c.radius; c.cost_trace[c.iter - 1] = c.cost_cur; }
         c.dogleg_norm = dnorm;
         c.model_change = model_change;
+        c.cg = cg; c.cn = cn;               // the sweep forms lambda + cg la + cn lb
         if (!(model_change > 0.0)) {
             // invalid step (trust_region_minimizer.cc HandleInvalidStep): mu *= 10, same linearisation, new pivots
             c.invalid_run++;
             if (c.invalid_run >= 5) { c.done = 1; c.term = 6; c.status = -4; }
-            c.mu *= 10.0; c.reuse = 0; c.resweep = 1;
+            c.mu *= 10.0; c.reuse = 0; c.resweep = 1; c.cg = 0.0; c.cn = 0.0;
         } else {
             c.invalid_run = 0;
             if (!multi) { if (sqrt(sn) <= O.parameter_tolerance * (sqrt(xn) + O.parameter_tolerance)) { c.done = 1; c.term = 3; } }
@@ -1084,7 +1109,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         }
     }
     __syncthreads();
-    if (s.c.resweep && !s.c.done) { for (int i = t; i < P.NS; i += NT) xc[i] = x[i]; }
+    if (s.c.resweep && !s.c.done) { for (int i = t; i < 16 * P.K + 8; i += NT) xc[i] = x[i]; }
     STAMP(7);
     if (t == 0) { if (nhelp) wait_helpers(); *P.ctl = s.c; }      // (idempotent when the sums were already collected)
 }

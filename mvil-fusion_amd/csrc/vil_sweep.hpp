@@ -88,6 +88,9 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
 // ---------------------------------------------------------------------------------------------
 // LDS per factor: [Ji 12 | Jj 12 | Jex 12 | Jt 2 | Jl 2 | r 2 | eO 6] = 48 doubles
 #define VF_STRIDE 49   // odd stride: conflict-free column access
+// The candidate inverse depth is formed HERE: lambda_cand = lambda_cur + cg la + cn lb (la, lb: the step directions the step
+// kernel's landmark pass left, cg / cn: the dogleg coefficients in Ctl; first sweep and re-sweeps: cg = cn = 0), and written
+// into the candidate state by the landmark's lane group.
 __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, const Ctl& ctl, int wg, const double* x, SysBuf& sb, double* sm) {
     const int NV = P.NV, NVT = P.NVT;
     const int t = threadIdx.x;
@@ -108,6 +111,9 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
     #define VSTAMP(k) do {} while (0)
 #endif
     VSTAMP(0);
+    const double* xcur = P.x[ctl.cur];
+    double* xcand = P.x[1 - ctl.cur];
+    const double cg = ctl.cg, cn = ctl.cn;
     for (int e = t; e < NVT + 3 * NV; e += blockDim.x) tri[e] = 0.0;
     const bool exc = P.ex_const != 0, tdc = !P.td_free;
     double cost = 0.0;
@@ -127,12 +133,13 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             const int i = P.vis_i[f], j = P.vis_j[f], l = P.vis_l[f];
             const double* pi = x + xo_pose(P, i); const double* pj = x + xo_pose(P, j); const double* ex = x + xo_ex(P);
             VisJ o;
+            const double lam = xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l];
             if (O.precision)
                 visual_eval_f32(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
-                                x[xo_lam(P) + l], x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
+                                lam, x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
             else
                 visual_eval(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
-                            x[xo_lam(P) + l], x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
+                            lam, x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
             double rho, rho1;
             loss_eval(O.visual_loss, O.visual_loss_scale, o.r[0] * o.r[0] + o.r[1] * o.r[1], rho, rho1);
             cost += 0.5 * rho;
@@ -191,6 +198,7 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             const double ib = invp * b;
             double* lr = lmr + tl * 16;
             if (k == 13) { sb.hll[l] = h; sb.bl[l] = b; sb.invp[l] = invp; lr[0] = invp; lr[14] = (double)a; }
+            if (k == 14) xcand[xo_lam(P) + l] = xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l];      // the same expression the factor threads evaluated
             if (k < 13) {
                 lr[1 + k] = e; sb.eA[(size_t)l * 13 + k] = e;
                 const int col = k < 6 ? col_pose(P, a) + k : (k < 12 ? col_ex(P) + k - 6 : col_td(P));
@@ -480,10 +488,10 @@ __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O
 //   accumulated with LDS atomics inside a visual workgroup, so two runs agree to rounding, not bit for bit).
 //   The last workgroup handles the vectors and the cost.
 #define RED_EPW 32
-__global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
+#define VIL_REDUCE_THREADS 384      // k_reduce (vil_prechain.hpp): the gather below uses the first 256, the chain workgroup all six waves
+__device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl) {
     using namespace vd;
-    const Ctl ctl = *P.ctl;
-    if (ctl.done) return;
+    if (threadIdx.x >= VIL_THREADS) return;
     const int cand = 1 - ctl.cur;
     SysBuf sb = P.sys[cand];
     const int D = P.D, NV = P.NV, K = P.K, t = threadIdx.x;
@@ -603,6 +611,8 @@ __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
     for (int f = t; f < P.n_imu; f += VIL_THREADS) c += P.ipart[(size_t)f * 931 + 930];
     for (int f = t; f < n_rel; f += VIL_THREADS) c += rel0[(size_t)f * 601 + 600];
     if (t == 0 && P.pn > 0) c += P.mpart[P.pn];
-    c = block_sum(c, red);
-    if (t == 0) sb.cost[0] = c;
+    c = wave_sum(c);                                   // (256 live threads: four waves)
+    if ((t & 63) == 0) red[t >> 6] = c;
+    __syncthreads();
+    if (t == 0) sb.cost[0] = red[0] + red[1] + red[2] + red[3];
 }

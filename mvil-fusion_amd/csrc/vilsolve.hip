@@ -23,6 +23,7 @@
 #include "vil_sweep.hpp"
 #include "vil_eval.hpp"
 #include "vil_step.hpp"
+#include "vil_prechain.hpp"
 #include "vil_marg.hpp"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[vilsolve] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return VIL_ERR_DEVICE; } } while (0)
@@ -112,7 +113,7 @@ struct vil_ctx {
     double* d_x0 = nullptr;
     std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
     int n_blocks_sweep = 0, n_blocks_reduce = 0;
-    size_t lds_sweep = 0, lds_step = 0;
+    size_t lds_sweep = 0, lds_step = 0, lds_reduce = 0;
     bool step_lds = false;
     int* d_status = nullptr;
     Ctl* h_ctl = nullptr;          // pinned
@@ -461,7 +462,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         put(nullptr, 8 * (size_t)13 * std::max(L, 1), (void**)&sb.eA); put(nullptr, 8 * (size_t)6 * std::max(p->n_vis, 1), (void**)&sb.eO);
     }
     put(nullptr, 8 * ((size_t)D * D + 3 * (size_t)D + 3), (void**)&P.arstage);
-    put(nullptr, 8 * 8, (void**)&P.scal);
+    put(nullptr, 8 * 16, (void**)&P.scal);
     put(L ? s->inv_depth : nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.lam0);
     P.rank = sharded ? c->rank : 0; P.world = sharded ? c->world : 1;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
@@ -471,10 +472,31 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     P.split = c->split ? 1 : 0;
     put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.Sl); put(nullptr, 8 * (size_t)D, (void**)&P.Sc); put(nullptr, 8 * (size_t)D, (void**)&P.dc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.dl);
     put(nullptr, 8 * (size_t)D, (void**)&P.gradc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gradl); put(nullptr, 8 * (size_t)D, (void**)&P.gnc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gnl);
-    { const size_t Tm = (size_t)(D + 16) / 16; put(nullptr, 8 * std::max((size_t)D * D, (size_t)TILE_SZ * (Tm * (Tm + 1) / 2)), (void**)&P.M); } put(nullptr, 8 * (size_t)D, (void**)&P.stepc); put(nullptr, 8 * 4 * 16, (void**)&P.hpart); put(nullptr, 4 * 16, (void**)&P.hflag); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.stepl);
+    { const size_t Tm = (size_t)(D + 16) / 16; put(nullptr, 8 * std::max((size_t)D * D, (size_t)TILE_SZ * (Tm * (Tm + 1) / 2)), (void**)&P.M); } put(nullptr, 8 * (size_t)D, (void**)&P.stepc); put(nullptr, 8 * 4 * 16, (void**)&P.hpart); put(nullptr, 4 * 16, (void**)&P.hflag);
+    put(nullptr, 8 * 8 * 16, (void**)&P.hpart2); put(nullptr, 4 * 16, (void**)&P.hflag2); put(nullptr, 16, (void**)&P.xflag); put(nullptr, 16, (void**)&P.xstat);
+    put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.la); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.lb); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.stepl);
     put(nullptr, 8 * (size_t)D, (void**)&P.tmpc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.tmpl);
     put(nullptr, sizeof(Ctl), (void**)&P.ctl);
     put(nullptr, 8 * 64, (void**)&P.dbg);
+    // chain eliminated ahead of the step kernel (vil_prechain.hpp): needs every IMU factor to join frames (k, k+1), at most one per pair
+    {
+        std::vector<int> as_i(K, -1), as_j(K, -1);
+        bool canon = true;
+        for (int f = 0; f < p->n_imu; ++f) {
+            const int i = p->imu_i[f], j = p->imu_j[f];
+            if (j != i + 1 || as_i[i] >= 0 || as_j[j] >= 0) { canon = false; break; }
+            as_i[i] = f; as_j[j] = f;
+        }
+        // (measured r2: assembling the raw entries from the partial records costs the chain workgroup more than the step kernel
+        //  saves -- 52 us of k_reduce against 14.6 us inside k_step at K = 10; off unless VIL_PRECHAIN=1 until the entries are staged)
+        P.prechain = (canon && !sharded && getenv("VIL_PRECHAIN") != nullptr) ? 1 : 0;      // decided for good below, once the chain structure is known
+        put(as_i.data(), 4 * (size_t)K, (void**)&P.imu_as_i); put(as_j.data(), 4 * (size_t)K, (void**)&P.imu_as_j);
+        const int rs = vd::chain_rs(K);
+        put(nullptr, 8 * (size_t)(9 * K + 3) * rs, (void**)&P.chW);
+        put(nullptr, 8 * (size_t)54 * K, (void**)&P.chLdg); put(nullptr, 8 * (size_t)82 * K, (void**)&P.chLsb);
+        put(nullptr, 8 * (size_t)9 * K, (void**)&P.chSc); put(nullptr, 8 * (size_t)9 * K, (void**)&P.chDc);
+        put(nullptr, 8 * (size_t)2 * (NV + 1), (void**)&P.chZ); put(nullptr, 8 * 4, (void**)&P.chQ); put(nullptr, 16, (void**)&P.chOk);
+    }
     if (const char* ev = getenv("VIL_SKIP")) P.skip_mask = atoi(ev);
     // helper workgroups of the step kernel: worth it once every master thread would own more than one landmark
     P.n_help = L >= 2 * VIL_STEP_THREADS ? 7 : (L >= VIL_STEP_THREADS ? 3 : 0);
@@ -516,11 +538,20 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             if (8 * (tiles + wt + scr) + fixed <= 160 * 1024) { P.chain = 1; c->lds_step = 8 * (tiles + wt + scr); }
             else if (8 * (tiles + scr) + fixed <= 160 * 1024) { P.chain = 2; c->lds_step = 8 * (tiles + scr); }
         }
-        c->P.chain = P.chain; c->P.chain_rs = P.chain_rs;
+        if (!P.chain || c->split) P.prechain = 0;
+        if (P.prechain) {
+            const size_t Tp = (size_t)(NV + 1 + 15) / 16, tiles = (size_t)TILE_SZ * (Tp * (Tp + 1) / 2);
+            P.chain = 3;
+            c->lds_step = 8 * (tiles + 54 * (size_t)K + 82 * (size_t)K + vd::even_up(9 * K) + 16);
+            c->lds_reduce = 8 * (vd::chain_scratch_doubles(K) + 3 * (size_t)vd::even_up(9 * K) + 16);
+        } else c->lds_reduce = 0;
+        c->P.chain = P.chain; c->P.chain_rs = P.chain_rs; c->P.prechain = P.prechain;
     }
     if (P.chain) {
         c->step_lds = true;
-        if (P.chain == 1) {
+        if (P.chain == 3) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+        } else if (P.chain == 1) {
             HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
             HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
             HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
@@ -641,7 +672,8 @@ static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
     return VIL_OK;
 }
 static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr) {
-    hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce), dim3(VIL_THREADS), 0, c->stream, c->P);
+    if (c->P.prechain) hipLaunchKernelGGL(k_reduce_pc, dim3(c->n_blocks_reduce + 1), dim3(VIL_REDUCE_THREADS), c->lds_reduce, c->stream, c->P, so.jacobi_scaling);
+    else hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce), dim3(VIL_THREADS), 0, c->stream, c->P);
     if (ev_mid) hipEventRecord(ev_mid, c->stream);
     if (!step) return VIL_OK;
     auto launch_step = [&](int phase, int nwg) {
@@ -650,7 +682,8 @@ static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEve
             if (phase == 0) hipLaunchKernelGGL((k_step<L, 0, CH>), g, b, c->lds_step, c->stream, c->P, so); \
             else if (phase == 1) hipLaunchKernelGGL((k_step<L, 1, CH>), g, b, c->lds_step, c->stream, c->P, so); \
             else hipLaunchKernelGGL((k_step<L, 2, CH>), g, b, c->lds_step, c->stream, c->P, so); } while (0)
-        if (c->P.chain == 1) VIL_STEP_LAUNCH(true, 1);
+        if (c->P.chain == 3) hipLaunchKernelGGL((k_step<true, 0, 3>), g, b, c->lds_step, c->stream, c->P, so);
+        else if (c->P.chain == 1) VIL_STEP_LAUNCH(true, 1);
         else if (c->P.chain == 2) VIL_STEP_LAUNCH(true, 2);
         else if (c->step_lds) VIL_STEP_LAUNCH(true, 0);
         else VIL_STEP_LAUNCH(false, 0);
@@ -662,7 +695,7 @@ static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEve
     int st = all_reduce(c, c->P.arstage, cnt);
     if (st != VIL_OK) return st;
     launch_step(1, 1);
-    st = all_reduce(c, c->P.scal, 8);
+    st = all_reduce(c, c->P.scal, 9);
     if (st != VIL_OK) return st;
     launch_step(2, 1);
     return VIL_OK;

@@ -24,3 +24,7 @@ print("step stamps (cycles, deltas):", np.diff(d).tolist())
 v = np.array(dbg[32:40], dtype=np.int64); print("visual WG0 stamps rel:", (v - v[0]).tolist())
 print("cholesky cycles (wave 0): diag %d, panel %d, barrier after panel %d, trailing %d, barrier after trailing %d, publish+barrier %d" % (dbg[20], dbg[26], dbg[21], dbg[22], dbg[24], dbg[25]))
 print("packing loop, wave 0 own cycles:", dbg[27], " stamps 10->11:", dbg[11]-dbg[10], " 9->10:", dbg[10]-dbg[9], " 1->9:", dbg[9]-dbg[1], " 11->2:", dbg[2]-dbg[11], " 4->5:", dbg[5]-dbg[4], " 5->6:", dbg[6]-dbg[5])
+c = np.array(dbg[40:47], dtype=np.int64)
+print("chain path (cycles): init %d, chain steps %d, middle %d, schur+dense cholesky %d, dense back-subst %d, chain back-subst %d" % tuple(np.diff(c).tolist()))
+e = np.array(dbg[48:59], dtype=np.int64) - dbg[41]
+print("chain waves, ticks after the start: recursion steps", e[:6].tolist(), "middle done", int(e[6]), "| fwd row wave done", int(e[7]), "| bwd row wave done", int(e[8]), "| pack done", int(e[9]), "| q done", int(e[10]))
