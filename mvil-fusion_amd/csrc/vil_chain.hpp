@@ -22,6 +22,7 @@ namespace vd {
 
 __host__ __device__ inline int chain_rs(int K) { int rs = ((6 * K + 8 + 15) >> 4) << 4; if ((rs & 31) != 16) rs += 16; return rs; }   // row stride of W^T: >= 16 T, = 16 mod 32 (LDS banks)
 __host__ __device__ inline int even_up(int v) { return (v + 1) & ~1; }
+__host__ __device__ inline int chain_wcols(int K) { return (9 * K + 31) & ~31; }     // columns of W^T incl. padding: the Schur contraction reads 32 at a time
 // Chain scratch in LDS behind the tile array (and W^T), in doubles:
 //   Dk 2 x 82 | L_kk (45 + 9 reciprocal pivots) per block | sub-diagonal block per block (82 each) | carry of the backward
 //   direction R x 9 | t (9K) | 8 ints of flags

@@ -479,7 +479,7 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
     const int RS = P.chain_rs, NB = 9 * K, m = K >> 1;
     double* Tl = lds;
     double* Wt = WLDS ? lds + ntile * TILE_SZ : P.M;                       // W^T: column j of the chain at Wt[j * RS + row]
-    const ChainLds L = chain_lds(lds + ntile * TILE_SZ + (WLDS ? (size_t)(NB + 3) * RS : 0), K);
+    const ChainLds L = chain_lds(lds + ntile * TILE_SZ + (WLDS ? (size_t)chain_wcols(K) * RS : 0), K);
     if (t < 8) L.flag[t] = 0;
     __syncthreads();
     SSTAMP(1);
@@ -527,22 +527,22 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
         const int lane = t & 63, row = lane & 15, kq = lane >> 4;
         if (P.skip_mask & 128) return;                 // (timing probe only)
         // eight k-steps (32 chain columns) per round: all sixteen operand loads are issued before the first MFMA, so the
-        // LDS / L2 latency is paid once per round instead of once per MFMA
+        // LDS / L2 latency is paid once per round instead of once per MFMA.  Addresses are `lane base + wave-uniform offset`
+        // (32-bit): W^T is padded to a multiple of 32 columns, nothing is clamped per lane.
+        const int RS4 = 4 * RS;
 #pragma unroll
         for (int u = 0; u < CH_SLOTS; ++u) {
             if (tIJ[u] < 0) continue;
             const int I = tIJ[u] >> 8, J = tIJ[u] & 255;
             const bool va = (I << 4) + row < R, vb = (J << 4) + row < R;
-            const double* pa = Wt + (I << 4) + row;
-            const double* pb = Wt + (J << 4) + row;
+            const double* pa = Wt + kq * RS + (I << 4) + row;
+            const double* pb = Wt + kq * RS + (J << 4) + row;
             d4 c4 = Creg[u];
             for (int kk = 0; kk < NB; kk += 32) {
+                const double* qa = pa + kk * RS; const double* qb = pb + kk * RS;
                 double av[8], bv[8];
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const int kr = min(kk + 4 * g + kq, NB + 2);           // (rows NB .. NB+2 of W^T exist as padding)
-                    av[g] = pa[(size_t)kr * RS]; bv[g] = pb[(size_t)kr * RS];
-                }
+                for (int g = 0; g < 8; ++g) { av[g] = qa[g * RS4]; bv[g] = qb[g * RS4]; }
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
                     const bool kv = kk + 4 * g + kq < NB;

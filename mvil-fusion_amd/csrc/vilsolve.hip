@@ -492,7 +492,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         P.prechain = (canon && !sharded && getenv("VIL_PRECHAIN") != nullptr) ? 1 : 0;      // decided for good below, once the chain structure is known
         put(as_i.data(), 4 * (size_t)K, (void**)&P.imu_as_i); put(as_j.data(), 4 * (size_t)K, (void**)&P.imu_as_j);
         const int rs = vd::chain_rs(K);
-        put(nullptr, 8 * (size_t)(9 * K + 3) * rs, (void**)&P.chW);
+        put(nullptr, 8 * (size_t)vd::chain_wcols(K) * rs, (void**)&P.chW);
         put(nullptr, 8 * (size_t)54 * K, (void**)&P.chLdg); put(nullptr, 8 * (size_t)82 * K, (void**)&P.chLsb);
         put(nullptr, 8 * (size_t)9 * K, (void**)&P.chSc); put(nullptr, 8 * (size_t)9 * K, (void**)&P.chDc);
         put(nullptr, 8 * (size_t)2 * (NV + 1), (void**)&P.chZ); put(nullptr, 8 * 4, (void**)&P.chQ); put(nullptr, 16, (void**)&P.chOk);
@@ -533,7 +533,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         }
         P.chain = 0; P.chain_rs = vd::chain_rs(K);
         if (chain) {
-            const size_t Tp = (size_t)(NV + 1 + 15) / 16, tiles = (size_t)TILE_SZ * (Tp * (Tp + 1) / 2), wt = (size_t)(9 * K + 3) * P.chain_rs, scr = vd::chain_scratch_doubles(K);
+            const size_t Tp = (size_t)(NV + 1 + 15) / 16, tiles = (size_t)TILE_SZ * (Tp * (Tp + 1) / 2), wt = (size_t)vd::chain_wcols(K) * P.chain_rs, scr = vd::chain_scratch_doubles(K);
             const size_t fixed = sizeof(vd::StepShared) + 512;
             if (8 * (tiles + wt + scr) + fixed <= 160 * 1024) { P.chain = 1; c->lds_step = 8 * (tiles + wt + scr); }
             else if (8 * (tiles + scr) + fixed <= 160 * 1024) { P.chain = 2; c->lds_step = 8 * (tiles + scr); }
