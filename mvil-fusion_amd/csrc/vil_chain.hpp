@@ -87,7 +87,8 @@ __device__ __forceinline__ void row_solve9(const double* l, const double* r, con
 // row solve against L_kk, W^T column block to Wt, fill carried into the next block.  Wave 0 finally factors the middle block,
 // waves 2,3 finish its rows.  Other waves return at once (the caller gives them the tile packing).  The caller zeroes the flags
 // before and puts a workgroup barrier after.
-// SRC: raw(i, j) raw S' entry; sc(j) scale of reduced column j; madd(j) = mu dc_j^2; rowscale(r) scale applied to pose row r
+// SRC: raw S' entries -- diag(k, i, j): entry (i, j <= i) of diagonal block k; sub(k, kn, q, c): row q of block kn = k +- 1, column c
+// of block k; prow(r, k, c): pose row r, column c of block k --; sc(j) scale of reduced column j; madd(j) = mu dc_j^2; rowscale(r) scale applied to pose row r
 // (1 when the row scaling is deferred); rhsraw(j) reduced gradient of column j; u(j) (WITHQ) the vector of the quadratic form
 // on the chain columns; row_done(d, r, z, q): z = (S'_pb u_b)[r] over the blocks of direction d (the step kernel adds 2 u_r z).
 // WITHQ: qacc receives this lane's share of u^T S' u over every entry of S' with a row or a column in the chain part (each
@@ -109,12 +110,12 @@ __device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, con
         int di = 0, dj = 0;
         { const int e = lane < 45 ? lane : 0; while ((di + 1) * (di + 2) / 2 <= e) ++di; dj = e - di * (di + 1) / 2; }
         bool ok = true;
-        auto diag_entry = [&](int k) { const int gi = NP + 9 * k + di, gj = NP + 9 * k + dj; return src.raw(gi, gj); };
+        auto diag_entry = [&](int k) { return src.diag(k, di, dj); };
         auto diag_scaled = [&](int k, double v) { const int gi = NP + 9 * k + di, gj = NP + 9 * k + dj; double mv = src.sc(gi) * v * src.sc(gj); if (di == dj) mv += src.madd(gi); return mv; };
         auto sub_rows = [&](int k, int kn, double* a) {           // row `lane` of block kn against the columns of block k
-            const int row = NP + 9 * min(max(kn, 0), K - 1) + min(lane, 8);
+            const int kc = min(max(kn, 0), K - 1), q = min(lane, 8);
 #pragma unroll
-            for (int c = 0; c < 9; ++c) a[c] = src.raw(row, NP + 9 * k + c);
+            for (int c = 0; c < 9; ++c) a[c] = src.sub(k, kc, q, c);
         };
         double dv = 0.0, an[9];
 #pragma unroll
@@ -202,7 +203,7 @@ __device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, con
     double zr = 0.0;                                   // (S'_pb u_b)[r], accumulated over the blocks of this direction
     auto fetch = [&](int k, double* a) {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) a[c] = src.raw(rc, NP + 9 * k + c);
+        for (int c = 0; c < 9; ++c) a[c] = src.prow(rc, k, c);
         if (r >= NP) {
 #pragma unroll
             for (int c = 0; c < 9; ++c) a[c] = src.rhsraw(NP + 9 * k + c);

@@ -28,6 +28,7 @@ struct Ctl {          // trust-region state, lives in device memory, owned by th
     int gen;          // solve generation (host): with n_sweeps it forms the epoch of the helper-workgroup flags
     int cur, iter, done, term, first, resweep, reuse, nsucc, invalid_run, status, lin_mode, n_sweeps;
     int phase_need, skip_b;       // split-step hand-off (multi-GPU: step A | all-reduce scalars | step B)
+    int swe;                      // advanced by every live step-kernel launch: epoch of the sweep's workgroup flags (swflag)
     double radius, mu, cost_cur, model_change, alpha, dogleg_norm, initial_cost, cand_cost;
     double mu_used, gn2, g2, gg;   // dogleg scalars of the current linearisation (reused after a rejected step)
     double cg, cn;                 // dogleg coefficients of the candidate: the sweep forms lambda_cand = lambda_cur + cg la + cn lb
@@ -101,6 +102,8 @@ struct DevP {
     // frame k is the first / second frame (-1: none).  Outputs (global): W^T with unscaled pose rows, the factored 9 x 9 blocks,
     // scales of the chain columns, pieces of u^T S' u, status.
     int prechain; const int* imu_as_i; const int* imu_as_j;
+    int ch_npc; const int* ch_pcol;      // chain columns (0 .. 9K-1) the prior holds
+    int* swflag;                   // n_imu + 1 flags: the IMU / prior workgroups of the current sweep have written their records
     double* chW; double* chLdg; double* chLsb; double* chSc; double* chDc; double* chZ; double* chQ; int* chOk;
 };
 

@@ -458,7 +458,11 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
 struct ChainSrcStep {                      // the chain's view of the system inside the step kernel: S' in global memory, scales in LDS
     const double* S; int D; const double* sc_; const double* dcs_; const double* gd_; const double* u_; double mu;
     __device__ __forceinline__ double u(int i) const { return u_[i]; }
+    int NP;
     __device__ __forceinline__ double raw(int i, int j) const { return S[(size_t)i * D + j]; }
+    __device__ __forceinline__ double diag(int k, int i, int j) const { return raw(NP + 9 * k + i, NP + 9 * k + j); }
+    __device__ __forceinline__ double sub(int k, int kn, int q, int c) const { return raw(NP + 9 * kn + q, NP + 9 * k + c); }
+    __device__ __forceinline__ double prow(int r, int k, int c) const { return raw(r, NP + 9 * k + c); }
     __device__ __forceinline__ double sc(int j) const { return sc_[j]; }
     __device__ __forceinline__ double madd(int j) const { const double d = dcs_[j]; return mu * d * d; }
     __device__ __forceinline__ double rowscale(int r) const { return sc_[r]; }
@@ -484,7 +488,7 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
     __syncthreads();
     SSTAMP(1);
     if (t < 384) {
-        const ChainSrcStep src{sb.S, D, s.sc, s.dcs, s.gd, s.y, mu};
+        const ChainSrcStep src{sb.S, D, s.sc, s.dcs, s.gd, s.y, mu, NP};
         double qc = 0.0;
         if (cam) chain_eliminate<true>(src, K, NP, RS, Wt, L, qc, P.dbg); else chain_eliminate<false>(src, K, NP, RS, Wt, L, qc, P.dbg);
         qpart += qc;
@@ -633,15 +637,13 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
             const int I = tIJ[u] >> 8, J = tIJ[u] & 255;
             const int ra = (I << 4) + row, rb = (J << 4) + row;
             const double sa = ra < NP ? -s.sc[ra] : (ra == NP ? -1.0 : 0.0), sbv = rb < NP ? s.sc[rb] : (rb == NP ? 1.0 : 0.0);    // row scaling deferred by the chain workgroup
-            const double* pa = Wt + ra; const double* pb = Wt + rb;
+            const double* pa = Wt + kq * RS + ra; const double* pb = Wt + kq * RS + rb;
             d4 c4 = Creg[u];
             for (int kk = 0; kk < NB; kk += 32) {
+                const double* qa = pa + kk * RS; const double* qb = pb + kk * RS;
                 double av[8], bv[8];
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const int kr = min(kk + 4 * g + kq, NB + 2);
-                    av[g] = pa[(size_t)kr * RS]; bv[g] = pb[(size_t)kr * RS];
-                }
+                for (int g = 0; g < 8; ++g) { av[g] = qa[g * 4 * RS]; bv[g] = qb[g * 4 * RS]; }
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
                     const bool kv = kk + 4 * g + kq < NB;
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     // Only the master writes Ctl / the camera candidate, after every helper has signalled hflag.
     const bool helper = PHASE == 0 && blockIdx.x > 0;
     const int nhelp = (PHASE == 0) ? (int)gridDim.x - 1 : 0;
-    if (t == 0) { s.c = *P.ctl; s.need = 0; s.was_first = 0; s.ok = 1; }
+    if (t == 0) { s.c = *P.ctl; s.c.swe++; s.need = 0; s.was_first = 0; s.ok = 1; }      // (every path that writes Ctl back carries the new swe)
     for (int q = t; q < 256; q += NT) {      // triangular tile index -> (tile row, tile col)
         int Ir = (int)((sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
         if (((Ir + 1) * (Ir + 2)) / 2 <= q) ++Ir;

@@ -458,28 +458,15 @@ __device__ __forceinline__ int imu_local(const DevP& P, int i, int j, int col) {
 
 }  // namespace vd
 
-// grid = n_vwg + n_imu + ceil(n_pchunk / 2) + ceil(n_echunk / 2) + 2 (prior, relative constraints) workgroups of VIL_SWEEP_THREADS threads
-__global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O) {
-    extern __shared__ double sm[];
-    const Ctl ctl = *P.ctl;
-    if (ctl.done) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctl->n_sweeps = ctl.n_sweeps + 1;   // live (not early-exited) launches, for the profiler
-    const int cand = 1 - ctl.cur;
-    const double* x = P.x[cand];
-    SysBuf sb = P.sys[cand];
-    int b = blockIdx.x;
-    // visual workgroups first: they are the longest-running role
-    if (b < P.n_vwg) { if (!(P.skip_mask & 1)) vd::sweep_visual(P, O, ctl, b, x, sb, sm); return; }
-    b -= P.n_vwg;
-    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm); return; }
-    b -= P.n_imu;
-    const int per = VIL_SWEEP_THREADS / 256, npw = (P.n_pchunk + per - 1) / per, new_ = (P.n_echunk + per - 1) / per;
-    if (b < npw) { if (!(P.skip_mask & 4)) vd::sweep_lidar<1>(P, O, b, x, sm); return; }
-    b -= npw;
-    if (b < new_) { if (!(P.skip_mask & 8)) vd::sweep_lidar<3>(P, O, b, x, sm); return; }
-    b -= new_;
-    if (b == 0) { if (!(P.skip_mask & 16)) vd::sweep_prior(P, x, sm); return; }
-    if (!(P.skip_mask & 16)) vd::sweep_misc(P, O, x, sm);
+// The sweep kernel itself (k_sweep) is defined in vil_prechain.hpp: with P.prechain one more workgroup eliminates the
+// speed-bias chain as soon as the IMU / prior workgroups have published their records.
+// Workgroup order: [imu x n_imu | prior | rel | (chain) | visual x n_vwg | plane | edge] -- the short roles the chain waits for come
+// first, the chain workgroup (the longest-running one) right after them, then the visual workgroups.
+// Epoch of the flags: solve generation + Ctl::swe, which only the step kernel advances (n_sweeps is bumped by block 0 of the
+// sweep itself, so workgroups of one launch may read either value of it).
+__device__ __forceinline__ void sweep_signal(const DevP& P, const Ctl& ctl, int slot) {     // this workgroup's record is complete
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence(); __hip_atomic_store(P.swflag + slot, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 // Gather of the sweep's partial records into the dense reduced system of the candidate set:

@@ -495,6 +495,9 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         put(nullptr, 8 * (size_t)vd::chain_wcols(K) * rs, (void**)&P.chW);
         put(nullptr, 8 * (size_t)54 * K, (void**)&P.chLdg); put(nullptr, 8 * (size_t)82 * K, (void**)&P.chLsb);
         put(nullptr, 8 * (size_t)9 * K, (void**)&P.chSc); put(nullptr, 8 * (size_t)9 * K, (void**)&P.chDc);
+        put(nullptr, 4 * (size_t)(K + 8), (void**)&P.swflag);
+        { std::vector<int> pcol; for (int jc = 0; jc < 9 * K; ++jc) if (pinv[NV + jc] >= 0) pcol.push_back(jc);
+          P.ch_npc = (int)pcol.size(); pcol.resize(9 * K + 1, 0); put(pcol.data(), 4 * pcol.size(), (void**)&P.ch_pcol); }
         put(nullptr, 8 * (size_t)2 * (NV + 1), (void**)&P.chZ); put(nullptr, 8 * 4, (void**)&P.chQ); put(nullptr, 16, (void**)&P.chOk);
     }
     if (const char* ev = getenv("VIL_SKIP")) P.skip_mask = atoi(ev);
@@ -539,12 +542,16 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             else if (8 * (tiles + scr) + fixed <= 160 * 1024) { P.chain = 2; c->lds_step = 8 * (tiles + scr); }
         }
         if (!P.chain || c->split) P.prechain = 0;
+        if (P.prechain && 8 * (vd::chain_scratch_doubles(K) + 3 * (size_t)vd::even_up(9 * K) + vd::chain_slab_doubles(K) + 16) > 150 * 1024) P.prechain = 0;      // the staged slab must fit LDS (K <= 12)
         if (P.prechain) {
             const size_t Tp = (size_t)(NV + 1 + 15) / 16, tiles = (size_t)TILE_SZ * (Tp * (Tp + 1) / 2);
             P.chain = 3;
             c->lds_step = 8 * (tiles + 54 * (size_t)K + 82 * (size_t)K + vd::even_up(9 * K) + 16);
-            c->lds_reduce = 8 * (vd::chain_scratch_doubles(K) + 3 * (size_t)vd::even_up(9 * K) + 16);
-        } else c->lds_reduce = 0;
+            // the chain workgroup rides in k_sweep: its LDS need must fit the sweep's dynamic allocation
+            c->lds_sweep = std::max(c->lds_sweep, (size_t)8 * (vd::chain_scratch_doubles(K) + 3 * (size_t)vd::even_up(9 * K) + vd::chain_slab_doubles(K) + 16));
+            HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep));
+            c->n_blocks_sweep += 1;
+        }
         c->P.chain = P.chain; c->P.chain_rs = P.chain_rs; c->P.prechain = P.prechain;
     }
     if (P.chain) {
@@ -672,8 +679,7 @@ static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
     return VIL_OK;
 }
 static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr) {
-    if (c->P.prechain) hipLaunchKernelGGL(k_reduce_pc, dim3(c->n_blocks_reduce + 1), dim3(VIL_REDUCE_THREADS), c->lds_reduce, c->stream, c->P, so.jacobi_scaling);
-    else hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce), dim3(VIL_THREADS), 0, c->stream, c->P);
+    hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce), dim3(VIL_THREADS), 0, c->stream, c->P);
     if (ev_mid) hipEventRecord(ev_mid, c->stream);
     if (!step) return VIL_OK;
     auto launch_step = [&](int phase, int nwg) {
