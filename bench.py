@@ -118,32 +118,57 @@ def replay_mode(args, be, abi, lib):
         so_path = os.path.join(ROOT, "oracle", "liboracle.so")
         orc = lib.Backend(C.CDLL(so_path), "orc_")
     opts_cpu = abi.default_options(max_iterations=8)
-    g_solve, g_marg, c_solve, c_marg, dpos, its, Ls, nvis = [], [], [], [], [], [], [], []
+    g_solve, g_marg, g_slide, c_solve, c_marg, dpos, its, Ls, nvis = [], [], [], [], [], [], [], [], []
+    resident = not args.classic
+    K = rp.K
+    if resident:                                   # window residency (include/vilsolve.h): LiDAR frame slabs on the device, gauge fix on the device,
+        be.set_gauge_fix(True); be.lidar_reset()   # marginalisation of the resident window; per image only the new frame's points cross PCIe
+        for k in range(K):
+            be.lidar_push(rp.lidar[k][0], rp.lidar[k][1])
     for step in range(args.replay):
-        w = rp.window(); flag = rp.margin_flag()
-        wo = Window.from_dict(w.to_dict()) if orc is not None else None
-        p0 = w.pose[0].copy()
-        t0 = time.perf_counter(); sg = be.solve(w, rp.opts); be.gauge_fix(p0, w); t1 = time.perf_counter()
-        pg = be.marginalize(w, flag, w._icp_marg, w._lps_marg, rp.opts); t2 = time.perf_counter()
+        flag = rp.margin_flag()
+        if resident:
+            w = rp.window(with_lidar=False)
+            wo = None
+            if orc is not None:
+                wo = Window.from_dict(rp.window().to_dict())
+            p0 = w.pose[0].copy()
+            t0 = time.perf_counter(); sg = be.solve(w, rp.opts); t1 = time.perf_counter()
+            pg = be.marginalize_resident(w, flag, w._icp_marg, w._lps_marg, rp.opts); t2 = time.perf_counter()
+        else:
+            w = rp.window()
+            wo = Window.from_dict(w.to_dict()) if orc is not None else None
+            p0 = w.pose[0].copy()
+            t0 = time.perf_counter(); sg = be.solve(w, rp.opts); be.gauge_fix(p0, w); t1 = time.perf_counter()
+            pg = be.marginalize(w, flag, w._icp_marg, w._lps_marg, rp.opts); t2 = time.perf_counter()
         g_solve.append(1e3 * (t1 - t0)); g_marg.append(1e3 * (t2 - t1)); its.append(sg.iterations); Ls.append(w.L); nvis.append(len(w.vis_i))
         if orc is not None:
             t0 = time.perf_counter(); orc.solve(wo, opts_cpu); orc.gauge_fix(p0, wo); t1 = time.perf_counter()
             orc.marginalize(wo, flag, w._icp_marg, w._lps_marg, opts_cpu); t2 = time.perf_counter()
             c_solve.append(1e3 * (t1 - t0)); c_marg.append(1e3 * (t2 - t1))
             dpos.append(float(np.abs(w.pose[:, :3] - wo.pose[:, :3]).max()))
+        if resident:
+            t3 = time.perf_counter(); be.lidar_drop(0 if flag == abi.MARGIN_OLD else K - 2)
         if not rp.absorb(w, pg, flag):
             break
+        if resident:
+            t4 = time.perf_counter(); be.lidar_push(rp.lidar[K - 1][0], rp.lidar[K - 1][1]); g_slide.append(1e3 * (time.perf_counter() - t4))
 
     def st(v):
         v = np.array(v)
         return {"median": float(np.median(v)), "p95": float(np.percentile(v, 95)), "max": float(v.max())}
     tot_g = np.array(g_solve) + np.array(g_marg)
+    if resident and g_slide:
+        tot_g = tot_g[:len(g_slide)] + np.array(g_slide)          # the new frame's LiDAR points going up belongs to the image's latency
     out = {"metric": "per-frame backend latency, synthetic replay (solve + gauge fix + marginalisation, host buffers in, host buffers out)",
            "value": float(np.median(tot_g)), "unit": "ms/frame", "higher_is_better": False, "n_gpus": 1, "frames": len(g_solve), "dtype": "f64" if args.precision == 0 else "f32 eval / f64 accumulate",
            "data": "synthetic replay (3indoor.bag unavailable offline)",
            "config": {"workload": "BASELINE.json configs[4] substitute: K=10, ~%d landmarks / ~%d visual factors per window, 30000 LiDAR points, max 8 iterations, every 5th image a non-keyframe (MARGIN_SECOND_NEW)" % (int(np.mean(Ls)), int(np.mean(nvis))),
                       "iterations_per_frame": float(np.mean(its))},
-           "gpu": {"solve_ms": st(g_solve), "marg_ms": st(g_marg), "total_ms": st(tot_g), "note": "includes H2D upload of the window and D2H of the state / prior (PCIe-inclusive)"}}
+           "gpu": {"solve_ms": st(g_solve), "marg_ms": st(g_marg), "total_ms": st(tot_g), "note": "includes H2D upload of the window and D2H of the state / prior (PCIe-inclusive)",
+                   "mode": "resident window: LiDAR frame slabs stay in HBM (per image only the new frame's points go up: lidar_push_ms), gauge fix on the device, vil_marginalize_resident" if resident else "classic: every table handed over on every image (vil_solve + vil_gauge_fix + vil_marginalize)"}}
+    if resident and g_slide:
+        out["gpu"]["lidar_push_ms"] = st(g_slide)
     if orc is not None:
         tot_c = np.array(c_solve) + np.array(c_marg)
         out["cpu_baseline"] = {"solve_ms": st(c_solve), "marg_ms": st(c_marg), "total_ms": st(tot_c), "cores": 4, "kind": "port",
@@ -355,6 +380,7 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not record HIP events around sweep launches in the timed region")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--replay", type=int, default=0, help="config 5: run N images of the synthetic replay and report per-frame latency instead of the headline metric")
+    ap.add_argument("--classic", action="store_true", help="replay mode: hand every table over on every image (vil_solve + vil_gauge_fix + vil_marginalize) instead of the resident-window entry points")
     ap.add_argument("--precision", type=int, default=0, help="0 = fp64 (reference arithmetic), 1 = fp32 factor evaluation with fp64 accumulation (replay mode only)")
     ap.add_argument("--vgicp", action="store_true", help="SURVEY 8(f) row 1: bench the voxelised GICP linearisation instead of the headline metric")
     ap.add_argument("--vgicp-rings", type=int, default=16)

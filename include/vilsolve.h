@@ -296,6 +296,28 @@ int vil_linearize(vil_ctx* ctx, const vil_problem* problem, const vil_state* sta
 int vil_marginalize(vil_ctx* ctx, const vil_problem* problem, const vil_state* state,
                     const vil_options* options, const vil_marg_spec* spec, vil_prior_out* out);
 
+/* ---- window residency across frames (slideWindow, estimator.cpp:1689-1814) ------------------------------------
+ * What does not change between two images stays in HBM:
+ *  - LiDAR point factors live on the device as one slab per window frame.  vil_lidar_push appends the newest frame's points
+ *    (the only LiDAR bytes that cross PCIe per image), vil_lidar_drop removes a frame (0 for MARGIN_OLD, count-2 for
+ *    MARGIN_SECOND_NEW; later slabs move down -- an index remap, no data moves).  A problem with
+ *    n_plane = n_edge = VIL_LIDAR_RESIDENT takes its point factors from the slabs: slab i belongs to window pose
+ *    K - count + i (the newest slab is the newest frame); plane_* / edge_* of the problem are ignored.
+ *  - vil_set_gauge_fix(ctx, 1): vil_solve applies double2vector()'s yaw / translation gauge fix (estimator.cpp:960-1011) on
+ *    the device before the state is read back (vil_gauge_fix on the returned state is then the identity).
+ *  - vil_marginalize_resident marginalises the window that vil_solve / vil_upload left on the device, at its solved (and
+ *    gauge-fixed) state: the factors MarginalizationInfo collects are selected by masks inside the sweep, nothing is packed
+ *    or uploaded again.  `solved` must be the state vil_solve returned (it only supplies the linearisation point x0 of the
+ *    new prior).  Same results as vil_marginalize on the same window and state. */
+#define VIL_LIDAR_RESIDENT (-1)
+int vil_lidar_reset(vil_ctx* ctx);
+int vil_lidar_push(vil_ctx* ctx, int32_t n_plane, const double* plane_const, int32_t n_edge, const double* edge_const);
+int vil_lidar_drop(vil_ctx* ctx, int32_t slab);
+int vil_lidar_count(vil_ctx* ctx, int32_t* n_slabs, int32_t* n_plane, int32_t* n_edge);
+int vil_set_gauge_fix(vil_ctx* ctx, int32_t on);
+int vil_marginalize_resident(vil_ctx* ctx, const vil_state* solved, const vil_options* options,
+                             const vil_marg_spec* spec, vil_prior_out* out);
+
 /* host-side helpers of the boundary */
 int vil_reduced_dim(int K);                               /* 15K + 7 */
 void vil_prior_capacity(int K, int* n_max, int* nblk_max, int* x0_max);

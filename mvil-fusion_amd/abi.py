@@ -171,16 +171,25 @@ class Window:
         self.sqrt_info_px = 230.0
         self.tr_over_row = 0.0
         self.truth = None  # optional dict with ground-truth arrays (generator only)
+        self.lidar_resident = False  # True: the point factors are the context's frame slabs (vil_lidar_push), n_plane = n_edge = VIL_LIDAR_RESIDENT
 
     # -- normalise dtypes/contiguity so the pointers stay valid for the struct's lifetime
     def _fix(self):
+        def ok(a, dt):      # already what the struct needs: nothing to copy (the per-image loop of the replay calls this twice per image)
+            return isinstance(a, np.ndarray) and a.dtype == dt and a.flags.c_contiguous
         for name in ("pose", "speedbias", "ex_pose", "td", "inv_depth", "imu_const", "vis_const", "icp_const", "lps_const",
                      "edge_const", "plane_const", "q_lb", "t_lb", "G"):
-            setattr(self, name, f64(getattr(self, name)))
+            a = getattr(self, name)
+            if not ok(a, np.float64):
+                setattr(self, name, f64(a))
         for name in ("imu_i", "imu_j", "vis_i", "vis_j", "vis_l", "icp_ids", "lps_ids", "edge_pose", "plane_pose"):
-            setattr(self, name, i32(getattr(self, name)))
+            a = getattr(self, name)
+            if not ok(a, np.int32):
+                setattr(self, name, i32(a))
         for name in ("pose_const", "sb_const", "lm_const"):
-            setattr(self, name, np.ascontiguousarray(np.asarray(getattr(self, name), dtype=np.uint8)))
+            a = getattr(self, name)
+            if not ok(a, np.uint8):
+                setattr(self, name, np.ascontiguousarray(np.asarray(a, dtype=np.uint8)))
 
     def c_state(self):
         self._fix()
@@ -202,6 +211,9 @@ class Window:
         p.n_lps = len(self.lps_ids); p.lps_ids, p.lps_const = _i(self.lps_ids), _d(self.lps_const)
         p.n_edge = len(self.edge_pose); p.edge_pose, p.edge_const = _i(self.edge_pose), _d(self.edge_const)
         p.n_plane = len(self.plane_pose); p.plane_pose, p.plane_const = _i(self.plane_pose), _d(self.plane_const)
+        if getattr(self, "lidar_resident", False):
+            p.n_plane = p.n_edge = -1
+            p.plane_pose = p.edge_pose = C.cast(None, _ip); p.plane_const = p.edge_const = C.cast(None, _dp)
         for k in range(4):
             p.q_lb[k] = self.q_lb[k]
         for k in range(3):

@@ -89,6 +89,10 @@ struct DevP {
     int rank, world;              // data-parallel shard of the factor set
     int split;                    // step kernel split around the scalar all-reduce (world > 1, or forced for single-GPU testing)
     long long* dbg;               // 64 cycle stamps (debug/profiling aid)
+    // marginalisation of the RESIDENT window (vil_marginalize_resident): 1 = MARGIN_OLD -- only the factors touching frame 0 are live
+    // (IMU (0,1), landmarks anchored in frame 0, LiDAR points of pose 0, the chosen ICP / LPS constraint, the prior), every block
+    // free; 2 = MARGIN_SECOND_NEW -- only the prior.  0 = a solve.
+    int marg, marg_icp, marg_lps;
     int skip_mask;                // debug: bit0 visual, 1 imu, 2 plane, 3 edge, 4 misc roles skipped in the sweep
     // helper workgroups of the single-GPU step kernel (landmark pre-pass on extra CUs): n_help of them, each publishes
     // {q, g2, gm} in hpart[4 * k ..] and then stores the launch epoch in hflag[k]; only the master workgroup ever waits

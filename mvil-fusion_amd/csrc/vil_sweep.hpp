@@ -42,8 +42,8 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
     const double* c = P.imu_c + (size_t)f * 287;
     double* out = P.ipart + (size_t)f * 931;
     const int t = threadIdx.x;
-    if (c[16] > 10.0) { for (int e = t; e < 931; e += blockDim.x) out[e] = 0.0; return; }   // estimator.cpp:1182
     const int i = P.imu_i[f], j = P.imu_j[f];
+    if (c[16] > 10.0 || (P.marg && !(P.marg == 1 && i == 0 && j == 1 && c[16] < 10.0))) { for (int e = t; e < 931; e += blockDim.x) out[e] = 0.0; return; }   // estimator.cpp:1182 / :1535
     for (int e = t; e < 450; e += blockDim.x) Jraw[e] = 0.0;
     __syncthreads();
     if (t <= IMU_NBLOCKS) {   // lanes 0..16: one 3x3 block each (common terms recomputed per lane); lane 17: residual
@@ -59,8 +59,9 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
     }
     __syncthreads();
     const double* U = P.imu_U + (size_t)f * 225;
-    const bool ci = P.pose_const && P.pose_const[i], cj = P.pose_const && P.pose_const[j];
-    const bool si = P.sb_const && P.sb_const[i], sj = P.sb_const && P.sb_const[j];
+    const bool fr = P.marg != 0;             // marginalisation: every block free
+    const bool ci = !fr && P.pose_const && P.pose_const[i], cj = !fr && P.pose_const && P.pose_const[j];
+    const bool si = !fr && P.sb_const && P.sb_const[i], sj = !fr && P.sb_const && P.sb_const[j];
     for (int e = t; e < 465; e += blockDim.x) {
         if (e < 450) {
             const int row = e / 30, col = e % 30;
@@ -115,7 +116,8 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
     double* xcand = P.x[1 - ctl.cur];
     const double cg = ctl.cg, cn = ctl.cn;
     for (int e = t; e < NVT + 3 * NV; e += blockDim.x) tri[e] = 0.0;
-    const bool exc = P.ex_const != 0, tdc = !P.td_free;
+    const bool mfree = P.marg != 0;            // marginalisation of the resident window: every block free, factors masked
+    const bool exc = !mfree && P.ex_const != 0, tdc = mfree ? !P.use_td : !P.td_free;
     double cost = 0.0;
     const int sc0 = P.vwg[2 * wg], sc1 = P.vwg[2 * wg + 1];
     for (int chunk = sc0; chunk < sc1; ++chunk) {
@@ -142,9 +144,11 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
                             lam, x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
             double rho, rho1;
             loss_eval(O.visual_loss, O.visual_loss_scale, o.r[0] * o.r[0] + o.r[1] * o.r[1], rho, rho1);
+            const bool live = !mfree || (P.marg == 1 && i == 0);      // estimator.cpp:1547-1589: landmarks anchored in frame 0
+            if (!live) { rho = 0.0; rho1 = 0.0; }
             cost += 0.5 * rho;
             const double sr = sqrt(rho1);
-            const bool ci = P.pose_const && P.pose_const[i], cj = P.pose_const && P.pose_const[j], cl = P.lm_const && P.lm_const[l];
+            const bool ci = !mfree && P.pose_const && P.pose_const[i], cj = !mfree && P.pose_const && P.pose_const[j], cl = !mfree && P.lm_const && P.lm_const[l];
             double* w = Jf + t * VF_STRIDE;
             for (int k = 0; k < 12; ++k) { w[k] = ci ? 0.0 : sr * o.Ji[k]; w[12 + k] = cj ? 0.0 : sr * o.Jj[k]; w[24 + k] = exc ? 0.0 : sr * o.Jex[k]; }
             w[36] = tdc ? 0.0 : sr * o.Jt[0]; w[37] = tdc ? 0.0 : sr * o.Jt[1];
@@ -185,7 +189,7 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             }
             // broadcast (h, b) of lane 13 to the 16-lane group
             h = __shfl(h, (t & ~15) + 13, 64); b = __shfl(b, (t & ~15) + 13, 64);
-            const bool cl = P.lm_const && P.lm_const[l];
+            const bool cl = !mfree && P.lm_const && P.lm_const[l];
             double Sl = 1.0;
             if (ctl.first) { Sl = (O.jacobi_scaling && !ctl.lin_mode) ? 1.0 / (1.0 + sqrt(h)) : 1.0; if (k == 13) P.Sl[l] = Sl; }
             else Sl = P.Sl[l];
@@ -301,11 +305,12 @@ __device__ __forceinline__ void sweep_lidar(const DevP& P, const SolveOpts& O, i
     const int t = threadIdx.x & 255;
     sm += sub * 128;
     const double* pose = x + xo_pose(P, k);
-    const bool cst = P.pose_const && P.pose_const[k];
+    const bool cst = !P.marg && P.pose_const && P.pose_const[k];
+    const bool masked = P.marg && !(P.marg == 1 && k == 0);       // marginalisation: only the points of the dropped pose
     double acc[28];
 #pragma unroll
     for (int q = 0; q < 28; ++q) acc[q] = 0.0;
-    if (t < cnt) {
+    if (t < cnt && !masked) {
         const int f = start + t;
         const M3 R = quatR(pose + 3), Rbl = loadM3(P.Rbl);
         const V3 Pk{pose[0], pose[1], pose[2]}, tbl{P.tbl[0], P.tbl[1], P.tbl[2]};
@@ -411,7 +416,7 @@ __device__ __forceinline__ void sweep_misc(const DevP& P, const SolveOpts& O, co
             id = P.lps_ids + 2 * (f - P.n_icp);
             lps_eval1(P.lps_c + (size_t)(f - P.n_icp) * 7, x + xo_pose(P, id[0]), x + xo_pose(P, id[1]), b, k, r3, d3);
         } else { live = false; id = P.lps_ids; r3[0] = r3[1] = r3[2] = 0.0; }
-        if (live && P.pose_const && P.pose_const[id[b]]) d3[0] = d3[1] = d3[2] = 0.0;
+        if (live && !P.marg && P.pose_const && P.pose_const[id[b]]) d3[0] = d3[1] = d3[2] = 0.0;
         for (int q = 0; q < 3; ++q) Jb[(f * 4 + b) * 21 + 7 * q + k] = d3[q];
         if (b == 0 && k == 0) for (int q = 0; q < 3; ++q) rb[f * 3 + q] = r3[q];
     }
@@ -432,6 +437,7 @@ __device__ __forceinline__ void sweep_misc(const DevP& P, const SolveOpts& O, co
         const double* r = rb + f * 3;
         double rho, rho1;
         loss_eval(O.rel_loss, O.rel_loss_scale, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho, rho1);
+        if (P.marg && !(P.marg == 1 && (f < P.n_icp ? f == P.marg_icp : f - P.n_icp == P.marg_lps))) { rho = 0.0; rho1 = 0.0; }    // estimator.cpp:1508-1533
         double v;
         if (q < 576) {
             const int a = q / 24, b = q % 24;

@@ -135,6 +135,22 @@ struct vil_ctx {
     bool split = false;            // step kernel launched as A | all-reduce | B
     int last_live = 5;             // live sweep launches of the previous solve (sizes the first launch chunk)
     int lm_b = 0, lm_e = 0;        // owned landmark range
+    // ---- window residency across frames (vil_lidar_*, vil_set_gauge_fix, vil_marginalize_resident) --------------------------------
+    struct Slab { int np, ne, slot; };
+    std::vector<Slab> slabs;       // window order: slab i <-> pose K - count + i
+    std::vector<int> free_slots;
+    int cap_p = 0, cap_e = 0, nslot = 0;      // points per slab (capacity), physical slabs
+    double* d_pl = nullptr; double* d_ed = nullptr;       // component-major: row q of the plane table at d_pl + q * nslot * cap_p
+    double* d_lstage = nullptr; double* h_lstage = nullptr; size_t lstage_cap = 0;     // AoS staging of one pushed frame (device / pinned)
+    hipEvent_t lpush_ev = nullptr; bool lpush_pending = false;
+    bool lidar_resident = false;   // the resident problem takes its point factors from the slabs
+    bool gauge_on = false;
+    struct MargMeta {              // what vil_marginalize_resident needs to know about the resident window (captured at upload)
+        std::vector<int> prior_kind, prior_index; bool has_prior = false;
+        std::vector<char> obs0;    // frames observing a landmark anchored in frame 0
+        int n_lm0 = 0; bool imu01 = false; bool lidar0 = false; bool use_td = false;
+        std::vector<int> icp_ids, lps_ids;
+    } mm;
     bool profiling = false;
     std::vector<hipEvent_t> ev, ev_mid;
     vil_profile prof = {0, 0.0, 0, 0.0, 0.0};
@@ -157,6 +173,19 @@ static void quat_to_R_host(const double* q, double* R) {
     R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
     R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
     R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+__global__ void k_aos2soa(const double* aos, int n, int ncomp, double* dst, size_t stride) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n) for (int q = 0; q < ncomp; ++q) dst[(size_t)q * stride + f] = aos[(size_t)f * ncomp + q];
+}
+__host__ __device__ static void gauge_fix_core(const double* pose0_before, int K, double* pose, double* speedbias, double* ex_pose);
+// double2vector()'s gauge fix on the device: one thread (K <= 20 poses), both state buffers
+__global__ void k_gauge_fix(DevP P, const double* x0) {
+    if (threadIdx.x || blockIdx.x) return;
+    double* x = P.x[0];
+    gauge_fix_core(x0 + xo_pose(P, 0), P.K, x + xo_pose(P, 0), x + xo_sb(P, 0), x + xo_ex(P));
+    for (int i = 0; i < 16 * P.K + 8; ++i) P.x[1][i] = x[i];
 }
 
 extern "C" {
@@ -226,6 +255,11 @@ void vil_destroy(vil_ctx* c) {
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->marg_ws) hipFree(c->marg_ws);
     if (c->lc_tmp) hipFree(c->lc_tmp);
+    if (c->d_pl) hipFree(c->d_pl);
+    if (c->d_ed) hipFree(c->d_ed);
+    if (c->d_lstage) hipFree(c->d_lstage);
+    if (c->h_lstage) hipHostFree(c->h_lstage);
+    if (c->lpush_ev) hipEventDestroy(c->lpush_ev);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -235,7 +269,9 @@ static int validate(const vil_problem* p, const vil_state* s, bool device_lidar 
     if (p->K < 1 || p->L < 0 || s->K != p->K || s->L != p->L) return VIL_ERR_INVALID_ARGUMENT;
     if (!s->pose || !s->speedbias || !s->ex_pose || !s->td || (p->L > 0 && !s->inv_depth)) return VIL_ERR_INVALID_ARGUMENT;
     if (15 * p->K + 7 > 320) return VIL_ERR_UNSUPPORTED;   // K <= 20 (step kernel work space)
-    if (p->n_vis < 0 || p->n_imu < 0 || p->n_icp < 0 || p->n_lps < 0 || p->n_plane < 0 || p->n_edge < 0 || p->prior.n < 0) return VIL_ERR_INVALID_ARGUMENT;
+    const bool res_lidar = p->n_plane == VIL_LIDAR_RESIDENT && p->n_edge == VIL_LIDAR_RESIDENT;
+    if (res_lidar) device_lidar = true;          // the tables are the context's slabs: nothing of the caller's to check
+    if (p->n_vis < 0 || p->n_imu < 0 || p->n_icp < 0 || p->n_lps < 0 || (!res_lidar && (p->n_plane < 0 || p->n_edge < 0)) || p->prior.n < 0) return VIL_ERR_INVALID_ARGUMENT;
     if (p->n_icp + p->n_lps > 12) return VIL_ERR_UNSUPPORTED;   // reference trims to 5 + 7 (estimator.cpp:1283-1286,1345-1348)
     if (p->prior.n > 512 || p->prior.nblk > 256) return VIL_ERR_UNSUPPORTED;
     // a table may be NULL only when its count is zero
@@ -394,21 +430,43 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         // device-resident tables (vil_internal.h): every factor sits on pose 0 in the caller's order -- only the chunk list is built here
         auto chunks_pose0 = [&](int n) { ch.clear(); for (int s0 = 0; s0 < n; s0 += VIL_THREADS) { ch.push_back(s0); ch.push_back(std::min(VIL_THREADS, n - s0)); ch.push_back(0); } };
         std::vector<int> cnt;
-        if (dl) { chunks_pose0(p->n_plane); c->plane_perm.clear(); put(nullptr, 8, (void**)&P.pl_c); }
+        const bool res_lidar = p->n_plane == VIL_LIDAR_RESIDENT && p->n_edge == VIL_LIDAR_RESIDENT;
+        c->lidar_resident = res_lidar;
+        // resident frame slabs (vil_lidar_push): slab i belongs to pose K - count + i; only the chunk list is built here
+        auto chunks_slabs = [&](bool plane) {
+            ch.clear();
+            const int ns = (int)c->slabs.size();
+            for (int i = 0; i < ns; ++i) {
+                const int n = plane ? c->slabs[i].np : c->slabs[i].ne, cap = plane ? c->cap_p : c->cap_e, pose = K - ns + i;
+                for (int s0 = 0; s0 < n; s0 += VIL_THREADS) { ch.push_back(c->slabs[i].slot * cap + s0); ch.push_back(std::min(VIL_THREADS, n - s0)); ch.push_back(pose); }
+            }
+        };
+        int np_tot = p->n_plane, ne_tot = p->n_edge;
+        if (res_lidar) {
+            if (sharded || (int)c->slabs.size() > K) return VIL_ERR_UNSUPPORTED;
+            np_tot = ne_tot = 0;
+            for (auto& sl : c->slabs) { np_tot += sl.np; ne_tot += sl.ne; }
+        }
+        if (res_lidar) { chunks_slabs(true); c->plane_perm.clear(); put(nullptr, 8, (void**)&P.pl_c); }
+        else if (dl) { chunks_pose0(p->n_plane); c->plane_perm.clear(); put(nullptr, 8, (void**)&P.pl_c); }
         else {
             lidar_order(p->n_plane, p->plane_pose, K, c->plane_perm, cnt); lidar_chunks(cnt, K, ch);
             P.pl_stride = (p->n_plane + 31) & ~31;
             if (double* dst = (double*)reserve(8 * (size_t)7 * std::max(P.pl_stride, 1), (void**)&P.pl_c)) lidar_soa(p->n_plane, 7, p->plane_const, c->plane_perm, P.pl_stride, dst);
         }
-        P.n_plane = p->n_plane; P.n_pchunk = (int)ch.size() / 3; ranges(ch, 0);
+        P.n_plane = np_tot; P.n_pchunk = (int)ch.size() / 3; ranges(ch, 0);
+        c->mm.lidar0 = false;
+        for (size_t q = 0; q < ch.size() / 3; ++q) if (ch[3 * q + 2] == 0) c->mm.lidar0 = true;
         put(ch.data(), 4 * ch.size(), (void**)&P.pchunk);
-        if (dl) { chunks_pose0(p->n_edge); c->edge_perm.clear(); put(nullptr, 8, (void**)&P.ed_c); }
+        if (res_lidar) { chunks_slabs(false); c->edge_perm.clear(); put(nullptr, 8, (void**)&P.ed_c); }
+        else if (dl) { chunks_pose0(p->n_edge); c->edge_perm.clear(); put(nullptr, 8, (void**)&P.ed_c); }
         else {
             lidar_order(p->n_edge, p->edge_pose, K, c->edge_perm, cnt); lidar_chunks(cnt, K, ch);
             P.ed_stride = (p->n_edge + 31) & ~31;
             if (double* dst = (double*)reserve(8 * (size_t)9 * std::max(P.ed_stride, 1), (void**)&P.ed_c)) lidar_soa(p->n_edge, 9, p->edge_const, c->edge_perm, P.ed_stride, dst);
         }
-        P.n_edge = p->n_edge; P.n_echunk = (int)ch.size() / 3; ranges(ch, K + 1);
+        P.n_edge = ne_tot; P.n_echunk = (int)ch.size() / 3; ranges(ch, K + 1);
+        for (size_t q = 0; q < ch.size() / 3; ++q) if (ch[3 * q + 2] == 0) c->mm.lidar0 = true;
         put(ch.data(), 4 * ch.size(), (void**)&P.echunk);
         put(nullptr, 8 * (size_t)28 * std::max(P.n_pchunk + P.n_echunk, 1), (void**)&P.lpart);
         put(lcp.data(), 4 * lcp.size(), (void**)&P.lchunk_pose);
@@ -510,6 +568,21 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     if (total > ar.cap) { if (ar.d) HIPCHK(hipFree(ar.d)); ar.d = nullptr; ar.cap = 0; HIPCHK(hipMalloc(&ar.d, total + total / 4)); ar.cap = total + total / 4; }
     for (const Fix& f : fix) *f.slot = ar.d + (f.scratch ? tables : 0) + f.off;
     if (dl) { P.pl_c = dl->plane_soa; P.pl_stride = dl->plane_stride; P.ed_c = dl->edge_soa; P.ed_stride = dl->edge_stride; }
+    if (c->lidar_resident) { P.pl_c = c->d_pl; P.pl_stride = c->nslot * c->cap_p; P.ed_c = c->d_ed; P.ed_stride = c->nslot * c->cap_e; }
+    {   // what vil_marginalize_resident will need (a few passes over int tables)
+        vil_ctx::MargMeta& mm = c->mm;
+        mm.has_prior = p->prior.n > 0; mm.prior_kind.clear(); mm.prior_index.clear();
+        if (mm.has_prior) { mm.prior_kind.assign(p->prior.blk_kind, p->prior.blk_kind + p->prior.nblk); mm.prior_index.assign(p->prior.blk_index, p->prior.blk_index + p->prior.nblk); }
+        mm.obs0.assign(K, 0); mm.n_lm0 = 0; mm.imu01 = false; mm.use_td = p->use_td != 0;
+        int last_l = -1;
+        for (int f = 0; f < p->n_vis; ++f) if (p->vis_i[f] == 0) { mm.obs0[p->vis_j[f]] = 1; if (p->vis_l[f] != last_l) { ++mm.n_lm0; last_l = p->vis_l[f]; } }
+        for (int f = 0; f < p->n_imu; ++f) if (p->imu_i[f] == 0 && p->imu_j[f] == 1 && p->imu_const[(size_t)f * 287 + 16] < 10.0) mm.imu01 = true;
+        mm.icp_ids.assign(p->icp_ids, p->icp_ids + 4 * (size_t)p->n_icp); mm.lps_ids.assign(p->lps_ids, p->lps_ids + 2 * (size_t)p->n_lps);
+        if (!c->lidar_resident && !dl) {
+            for (int f = 0; f < p->n_plane && !mm.lidar0; ++f) if (p->plane_pose[f] == 0) mm.lidar0 = true;
+            for (int f = 0; f < p->n_edge && !mm.lidar0; ++f) if (p->edge_pose[f] == 0) mm.lidar0 = true;
+        }
+    }
     for (int q = 0; q < 2; ++q) { SysBuf& sb = P.sys[q]; sb.S = sb.ar; sb.gred = sb.S + (size_t)D * D; sb.bc = sb.gred + D; sb.diag = sb.bc + D; sb.cost = sb.diag + D; }
     if (ar.hsize) {
         HIPCHK(hipMemcpyAsync(ar.d, ar.h, ar.hsize, hipMemcpyHostToDevice, c->stream));
@@ -816,6 +889,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     // the accepted state is x[cur]; keep x[0] as "the" resident state
     if (ctl.cur != 0) HIPCHK(hipMemcpyAsync(c->P.x[0], c->P.x[1], 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
     else HIPCHK(hipMemcpyAsync(c->P.x[1], c->P.x[0], 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
+    if (c->gauge_on && finished && c->h_ctl->status == 0) hipLaunchKernelGGL(k_gauge_fix, dim3(1), dim3(64), 0, c->stream, c->P, c->d_x0);      // estimator.cpp:960-1011 before the read-back
     if (c->sharded && c->L) {   // every rank updated only the landmarks it owns: merge the owners' changes
         const int nb = (c->L + 255) / 256;
         hipLaunchKernelGGL(k_lam_delta, dim3(nb), dim3(256), 0, c->stream, c->P, c->lm_b, c->lm_e);
@@ -972,71 +1046,12 @@ int vil_linearize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vi
     return VIL_OK;
 }
 
-int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out) {
-    if (!c || !p || !s || !o || !spec || !out) return VIL_ERR_INVALID_ARGUMENT;
-    { const int vst = validate(p, s); if (vst != VIL_OK) return vst; }      // the host tables are indexed below, before upload_impl sees them
-    const int K = p->K;
-    if (K < 3) return VIL_ERR_INVALID_ARGUMENT;
-    const bool old_ = spec->flag == VIL_MARGIN_OLD;
-    const int drop_pose = old_ ? 0 : K - 2;
-    // ---- derived sub-problem: the factors MarginalizationInfo collects (estimator.cpp:1489-1589 / 1626-1641), every block free
-    vil_problem q = *p;
-    q.pose_const = nullptr; q.sb_const = nullptr; q.lm_const = nullptr; q.ex_const = 0; q.td_const = 0;
-    q.n_edge = 0; q.n_plane = 0; q.edge_pose = nullptr; q.plane_pose = nullptr; q.edge_const = nullptr; q.plane_const = nullptr;
-    std::vector<int> imu_i, imu_j, vis_i, vis_j, vis_l, icp_ids, lps_ids, edge_pose, plane_pose;
-    std::vector<double> imu_c, vis_c, icp_c, lps_c, edge_c, plane_c;
-    std::vector<char> pose_t(K, 0), sb_t(K, 0);
-    bool ex_t = false, td_t = false;
-    int n_lm_elim = 0;
-    if (p->prior.n > 0) {
-        bool has_drop = false;
-        for (int b = 0; b < p->prior.nblk; ++b) {
-            const int kind = p->prior.blk_kind[b], idx = p->prior.blk_index[b];
-            if (kind == VIL_BLK_POSE) { pose_t[idx] = 1; if (idx == drop_pose) has_drop = true; }
-            else if (kind == VIL_BLK_SPEEDBIAS) sb_t[idx] = 1;
-            else if (kind == VIL_BLK_EX) ex_t = true; else td_t = true;
-        }
-        if (!old_ && !has_drop) { out->n = -1; return VIL_OK; }     // estimator.cpp:1620-1621: prior kept as is
-    } else if (!old_) { out->n = -1; return VIL_OK; }
-    if (old_) {
-        for (int f = 0; f < p->n_imu; ++f) if (p->imu_i[f] == 0 && p->imu_j[f] == 1 && p->imu_const[(size_t)f * 287 + 16] < 10.0) {
-            imu_i.push_back(0); imu_j.push_back(1); imu_c.insert(imu_c.end(), p->imu_const + (size_t)f * 287, p->imu_const + (size_t)(f + 1) * 287);
-            pose_t[0] = pose_t[1] = 1; sb_t[0] = sb_t[1] = 1;
-        }
-        int last_l = -1;
-        for (int f = 0; f < p->n_vis; ++f) if (p->vis_i[f] == 0) {
-            vis_i.push_back(0); vis_j.push_back(p->vis_j[f]); vis_l.push_back(p->vis_l[f]);
-            vis_c.insert(vis_c.end(), p->vis_const + (size_t)f * 14, p->vis_const + (size_t)(f + 1) * 14);
-            pose_t[0] = 1; pose_t[p->vis_j[f]] = 1; ex_t = true; if (p->use_td) td_t = true;
-            if (p->vis_l[f] != last_l) { ++n_lm_elim; last_l = p->vis_l[f]; }
-        }
-        if (spec->icp_marg >= 0 && spec->icp_marg < p->n_icp) {
-            for (int b = 0; b < 4; ++b) { const int id = b == 0 ? 0 : p->icp_ids[4 * spec->icp_marg + b]; icp_ids.push_back(id); pose_t[id] = 1; }
-            icp_c.insert(icp_c.end(), p->icp_const + (size_t)spec->icp_marg * 10, p->icp_const + (size_t)(spec->icp_marg + 1) * 10);
-        }
-        if (spec->lps_marg >= 0 && spec->lps_marg < p->n_lps) {
-            for (int b = 0; b < 2; ++b) { const int id = b == 0 ? 0 : p->lps_ids[2 * spec->lps_marg + b]; lps_ids.push_back(id); pose_t[id] = 1; }
-            lps_c.insert(lps_c.end(), p->lps_const + (size_t)spec->lps_marg * 7, p->lps_const + (size_t)(spec->lps_marg + 1) * 7);
-        }
-        // LiDAR point factors of the dropped pose (extended mode): MarginalizationInfo folds every factor that touches a
-        // dropped block (marginalization_factor.cpp:176-316); these touch pose 0 only and reach the prior through A_mm / b_m
-        for (int f = 0; f < p->n_edge; ++f) if (p->edge_pose[f] == 0) { edge_pose.push_back(0); edge_c.insert(edge_c.end(), p->edge_const + (size_t)f * 9, p->edge_const + (size_t)(f + 1) * 9); }
-        for (int f = 0; f < p->n_plane; ++f) if (p->plane_pose[f] == 0) { plane_pose.push_back(0); plane_c.insert(plane_c.end(), p->plane_const + (size_t)f * 7, p->plane_const + (size_t)(f + 1) * 7); }
-        if (!edge_pose.empty() || !plane_pose.empty()) pose_t[0] = 1;
-    }
-    q.n_imu = (int)imu_i.size(); q.imu_i = imu_i.data(); q.imu_j = imu_j.data(); q.imu_const = imu_c.data();
-    q.n_vis = (int)vis_i.size(); q.vis_i = vis_i.data(); q.vis_j = vis_j.data(); q.vis_l = vis_l.data(); q.vis_const = vis_c.data();
-    q.n_icp = (int)icp_ids.size() / 4; q.icp_ids = icp_ids.data(); q.icp_const = icp_c.data();
-    q.n_lps = (int)lps_ids.size() / 2; q.lps_ids = lps_ids.data(); q.lps_const = lps_c.data();
-    q.n_edge = (int)edge_pose.size(); q.edge_pose = edge_pose.data(); q.edge_const = edge_c.data();
-    q.n_plane = (int)plane_pose.size(); q.plane_pose = plane_pose.data(); q.plane_const = plane_c.data();
-    int st = upload_impl(c, &q, s, false);
-    if (st != VIL_OK) return st;
-    const SolveOpts so = to_dev_opts(o);
-    st = init_ctl(c, o, 2);
-    if (st != VIL_OK) return st;
-    launch_sweep(c, so);
-    launch_reduce_step(c, so, false);
+// common tail of vil_marginalize / vil_marginalize_resident: the normal equations of the collected factors sit in sys[1] (or the
+// all-reduce staging buffer); Schur complement + square root on the device (k_marg), block metadata with the address shift as an
+// index remap (estimator.cpp:1599-1611, 1654-1677)
+static int marg_finish(vil_ctx* c, const int K, const bool old_, const int drop_pose, const std::vector<char>& pose_t, const std::vector<char>& sb_t,
+                       const bool ex_t, const bool td_t, const bool use_td, const int n_lm_elim, const vil_state* s, vil_prior_out* out) {
+    int st = VIL_OK;
     // ---- which reduced columns are dropped / kept (canonical kept order: poses, speed-biases, ex, td) ----------------
     const int D = c->D;
     std::vector<int> drop_cols, keep_cols, kinds, index;
@@ -1045,7 +1060,7 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     for (int k = 0; k < K; ++k) if (pose_t[k] && k != drop_pose) { kinds.push_back(VIL_BLK_POSE); index.push_back(k); for (int q2 = 0; q2 < 6; ++q2) keep_cols.push_back(6 * k + q2); }
     for (int k = 0; k < K; ++k) if (sb_t[k] && !(old_ && k == 0)) { kinds.push_back(VIL_BLK_SPEEDBIAS); index.push_back(k); for (int q2 = 0; q2 < 9; ++q2) keep_cols.push_back(6 * K + 7 + 9 * k + q2); }
     if (ex_t) { kinds.push_back(VIL_BLK_EX); index.push_back(0); for (int q2 = 0; q2 < 6; ++q2) keep_cols.push_back(6 * K + q2); }
-    if (td_t && p->use_td) { kinds.push_back(VIL_BLK_TD); index.push_back(0); keep_cols.push_back(6 * K + 6); }
+    if (td_t && use_td) { kinds.push_back(VIL_BLK_TD); index.push_back(0); keep_cols.push_back(6 * K + 6); }
     const int nd = (int)drop_cols.size(), n = (int)keep_cols.size();
     int n_max, nblk_max, x0_max;
     vil_prior_capacity(K, &n_max, &nblk_max, &x0_max);
@@ -1113,48 +1128,127 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     return VIL_OK;
 }
 
-// estimator.cpp:960-1011 double2vector(): yaw + translation gauge fix (host logic of the boundary)
-int vil_gauge_fix(const double* pose0_before, vil_state* s) {
-    if (!pose0_before || !s) return VIL_ERR_INVALID_ARGUMENT;
-    auto R2ypr = [](const double* R, double* ypr) {
-        const double y = atan2(R[3], R[0]);
-        const double pch = atan2(-R[6], R[0] * cos(y) + R[3] * sin(y));
-        const double rl = atan2(R[2] * sin(y) - R[5] * cos(y), -R[1] * sin(y) + R[4] * cos(y));
-        ypr[0] = y / M_PI * 180.0; ypr[1] = pch / M_PI * 180.0; ypr[2] = rl / M_PI * 180.0;
-    };
-    auto R2q = [](const double* R, double* q /*xyzw*/) {
-        double t = R[0] + R[4] + R[8];
-        if (t > 0) { t = sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t; }
-        else {
-            int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > R[4 * i]) i = 2;
-            const int j = (i + 1) % 3, k = (j + 1) % 3;
-            t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
-            q[i] = 0.5 * t; t = 0.5 / t;
-            q[3] = (R[3 * k + j] - R[3 * j + k]) * t; q[j] = (R[3 * j + i] + R[3 * i + j]) * t; q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out) {
+    if (!c || !p || !s || !o || !spec || !out) return VIL_ERR_INVALID_ARGUMENT;
+    { const int vst = validate(p, s); if (vst != VIL_OK) return vst; }      // the host tables are indexed below, before upload_impl sees them
+    const int K = p->K;
+    if (K < 3) return VIL_ERR_INVALID_ARGUMENT;
+    const bool old_ = spec->flag == VIL_MARGIN_OLD;
+    const int drop_pose = old_ ? 0 : K - 2;
+    // ---- derived sub-problem: the factors MarginalizationInfo collects (estimator.cpp:1489-1589 / 1626-1641), every block free
+    vil_problem q = *p;
+    q.pose_const = nullptr; q.sb_const = nullptr; q.lm_const = nullptr; q.ex_const = 0; q.td_const = 0;
+    q.n_edge = 0; q.n_plane = 0; q.edge_pose = nullptr; q.plane_pose = nullptr; q.edge_const = nullptr; q.plane_const = nullptr;
+    std::vector<int> imu_i, imu_j, vis_i, vis_j, vis_l, icp_ids, lps_ids, edge_pose, plane_pose;
+    std::vector<double> imu_c, vis_c, icp_c, lps_c, edge_c, plane_c;
+    std::vector<char> pose_t(K, 0), sb_t(K, 0);
+    bool ex_t = false, td_t = false;
+    int n_lm_elim = 0;
+    if (p->prior.n > 0) {
+        bool has_drop = false;
+        for (int b = 0; b < p->prior.nblk; ++b) {
+            const int kind = p->prior.blk_kind[b], idx = p->prior.blk_index[b];
+            if (kind == VIL_BLK_POSE) { pose_t[idx] = 1; if (idx == drop_pose) has_drop = true; }
+            else if (kind == VIL_BLK_SPEEDBIAS) sb_t[idx] = 1;
+            else if (kind == VIL_BLK_EX) ex_t = true; else td_t = true;
         }
-    };
-    auto normq = [](const double* q, double* o) { const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]); for (int i = 0; i < 4; ++i) o[i] = q[i] / n; };
+        if (!old_ && !has_drop) { out->n = -1; return VIL_OK; }     // estimator.cpp:1620-1621: prior kept as is
+    } else if (!old_) { out->n = -1; return VIL_OK; }
+    if (old_) {
+        for (int f = 0; f < p->n_imu; ++f) if (p->imu_i[f] == 0 && p->imu_j[f] == 1 && p->imu_const[(size_t)f * 287 + 16] < 10.0) {
+            imu_i.push_back(0); imu_j.push_back(1); imu_c.insert(imu_c.end(), p->imu_const + (size_t)f * 287, p->imu_const + (size_t)(f + 1) * 287);
+            pose_t[0] = pose_t[1] = 1; sb_t[0] = sb_t[1] = 1;
+        }
+        int last_l = -1;
+        for (int f = 0; f < p->n_vis; ++f) if (p->vis_i[f] == 0) {
+            vis_i.push_back(0); vis_j.push_back(p->vis_j[f]); vis_l.push_back(p->vis_l[f]);
+            vis_c.insert(vis_c.end(), p->vis_const + (size_t)f * 14, p->vis_const + (size_t)(f + 1) * 14);
+            pose_t[0] = 1; pose_t[p->vis_j[f]] = 1; ex_t = true; if (p->use_td) td_t = true;
+            if (p->vis_l[f] != last_l) { ++n_lm_elim; last_l = p->vis_l[f]; }
+        }
+        if (spec->icp_marg >= 0 && spec->icp_marg < p->n_icp) {
+            for (int b = 0; b < 4; ++b) { const int id = b == 0 ? 0 : p->icp_ids[4 * spec->icp_marg + b]; icp_ids.push_back(id); pose_t[id] = 1; }
+            icp_c.insert(icp_c.end(), p->icp_const + (size_t)spec->icp_marg * 10, p->icp_const + (size_t)(spec->icp_marg + 1) * 10);
+        }
+        if (spec->lps_marg >= 0 && spec->lps_marg < p->n_lps) {
+            for (int b = 0; b < 2; ++b) { const int id = b == 0 ? 0 : p->lps_ids[2 * spec->lps_marg + b]; lps_ids.push_back(id); pose_t[id] = 1; }
+            lps_c.insert(lps_c.end(), p->lps_const + (size_t)spec->lps_marg * 7, p->lps_const + (size_t)(spec->lps_marg + 1) * 7);
+        }
+        // LiDAR point factors of the dropped pose (extended mode): MarginalizationInfo folds every factor that touches a
+        // dropped block (marginalization_factor.cpp:176-316); these touch pose 0 only and reach the prior through A_mm / b_m
+        for (int f = 0; f < p->n_edge; ++f) if (p->edge_pose[f] == 0) { edge_pose.push_back(0); edge_c.insert(edge_c.end(), p->edge_const + (size_t)f * 9, p->edge_const + (size_t)(f + 1) * 9); }
+        for (int f = 0; f < p->n_plane; ++f) if (p->plane_pose[f] == 0) { plane_pose.push_back(0); plane_c.insert(plane_c.end(), p->plane_const + (size_t)f * 7, p->plane_const + (size_t)(f + 1) * 7); }
+        if (!edge_pose.empty() || !plane_pose.empty()) pose_t[0] = 1;
+    }
+    q.n_imu = (int)imu_i.size(); q.imu_i = imu_i.data(); q.imu_j = imu_j.data(); q.imu_const = imu_c.data();
+    q.n_vis = (int)vis_i.size(); q.vis_i = vis_i.data(); q.vis_j = vis_j.data(); q.vis_l = vis_l.data(); q.vis_const = vis_c.data();
+    q.n_icp = (int)icp_ids.size() / 4; q.icp_ids = icp_ids.data(); q.icp_const = icp_c.data();
+    q.n_lps = (int)lps_ids.size() / 2; q.lps_ids = lps_ids.data(); q.lps_const = lps_c.data();
+    q.n_edge = (int)edge_pose.size(); q.edge_pose = edge_pose.data(); q.edge_const = edge_c.data();
+    q.n_plane = (int)plane_pose.size(); q.plane_pose = plane_pose.data(); q.plane_const = plane_c.data();
+    int st = upload_impl(c, &q, s, false);
+    if (st != VIL_OK) return st;
+    const SolveOpts so = to_dev_opts(o);
+    st = init_ctl(c, o, 2);
+    if (st != VIL_OK) return st;
+    launch_sweep(c, so);
+    launch_reduce_step(c, so, false);
+    return marg_finish(c, K, old_, drop_pose, pose_t, sb_t, ex_t, td_t, p->use_td != 0, n_lm_elim, s, out);
+}
+
+// estimator.cpp:960-1011 double2vector(): yaw + translation gauge fix.  One arithmetic for the host entry point (vil_gauge_fix)
+// and the device kernel (vil_set_gauge_fix): pose K x 7 [p q(xyzw)], speed-bias K x 9, ex 7.
+__host__ __device__ static void gauge_q2R(const double* q, double* R) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+__host__ __device__ static void gauge_R2ypr(const double* R, double* ypr) {
+    const double y = atan2(R[3], R[0]);
+    const double pch = atan2(-R[6], R[0] * cos(y) + R[3] * sin(y));
+    const double rl = atan2(R[2] * sin(y) - R[5] * cos(y), -R[1] * sin(y) + R[4] * cos(y));
+    ypr[0] = y / M_PI * 180.0; ypr[1] = pch / M_PI * 180.0; ypr[2] = rl / M_PI * 180.0;
+}
+__host__ __device__ static void gauge_R2q(const double* R, double* q /*xyzw*/) {
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) { t = sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t; }
+    else {
+        int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+        q[i] = 0.5 * t; t = 0.5 / t;
+        q[3] = (R[3 * k + j] - R[3 * j + k]) * t; q[j] = (R[3 * j + i] + R[3 * i + j]) * t; q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+    }
+}
+__host__ __device__ static void gauge_fix_core(const double* pose0_before, int K, double* pose, double* speedbias, double* ex_pose) {
     double R0[9], R00[9], a0[3], a00[3], rot[9];
-    quat_to_R_host(pose0_before + 3, R0); quat_to_R_host(s->pose + 3, R00);
-    R2ypr(R0, a0); R2ypr(R00, a00);
+    gauge_q2R(pose0_before + 3, R0); gauge_q2R(pose + 3, R00);
+    gauge_R2ypr(R0, a0); gauge_R2ypr(R00, a00);
     const double yd = (a0[0] - a00[0]) / 180.0 * M_PI;
     rot[0] = cos(yd); rot[1] = -sin(yd); rot[2] = 0; rot[3] = sin(yd); rot[4] = cos(yd); rot[5] = 0; rot[6] = 0; rot[7] = 0; rot[8] = 1;
     if (fabs(fabs(a0[1]) - 90) < 1.0 || fabs(fabs(a00[1]) - 90) < 1.0)
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double v = 0; for (int k = 0; k < 3; ++k) v += R0[3 * i + k] * R00[3 * j + k]; rot[3 * i + j] = v; }
-    const double p0[3] = {s->pose[0], s->pose[1], s->pose[2]};
-    for (int f = 0; f < s->K; ++f) {
-        double* pp = s->pose + 7 * f; double qn[4], Rf[9], Rn[9], d[3], P[3], V[3];
-        normq(pp + 3, qn); quat_to_R_host(qn, Rf);
+    const double p0[3] = {pose[0], pose[1], pose[2]};
+    for (int f = 0; f < K; ++f) {
+        double* pp = pose + 7 * f; double qn[4], Rf[9], Rn[9], d[3], Pn[3], V[3];
+        { const double n = sqrt(pp[3] * pp[3] + pp[4] * pp[4] + pp[5] * pp[5] + pp[6] * pp[6]); for (int i = 0; i < 4; ++i) qn[i] = pp[3 + i] / n; }
+        gauge_q2R(qn, Rf);
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double v = 0; for (int k = 0; k < 3; ++k) v += rot[3 * i + k] * Rf[3 * k + j]; Rn[3 * i + j] = v; }
         for (int i = 0; i < 3; ++i) d[i] = pp[i] - p0[i];
-        for (int i = 0; i < 3; ++i) P[i] = rot[3 * i] * d[0] + rot[3 * i + 1] * d[1] + rot[3 * i + 2] * d[2] + pose0_before[i];
-        R2q(Rn, pp + 3); pp[0] = P[0]; pp[1] = P[1]; pp[2] = P[2];
-        double* sb = s->speedbias + 9 * f;
+        for (int i = 0; i < 3; ++i) Pn[i] = rot[3 * i] * d[0] + rot[3 * i + 1] * d[1] + rot[3 * i + 2] * d[2] + pose0_before[i];
+        gauge_R2q(Rn, pp + 3); pp[0] = Pn[0]; pp[1] = Pn[1]; pp[2] = Pn[2];
+        double* sb = speedbias + 9 * f;
         for (int i = 0; i < 3; ++i) V[i] = rot[3 * i] * sb[0] + rot[3 * i + 1] * sb[1] + rot[3 * i + 2] * sb[2];
         sb[0] = V[0]; sb[1] = V[1]; sb[2] = V[2];
     }
     double qe[4], Re[9];
-    normq(s->ex_pose + 3, qe); quat_to_R_host(qe, Re); R2q(Re, s->ex_pose + 3);
+    { const double n = sqrt(ex_pose[3] * ex_pose[3] + ex_pose[4] * ex_pose[4] + ex_pose[5] * ex_pose[5] + ex_pose[6] * ex_pose[6]); for (int i = 0; i < 4; ++i) qe[i] = ex_pose[3 + i] / n; }
+    gauge_q2R(qe, Re); gauge_R2q(Re, ex_pose + 3);
+}
+int vil_gauge_fix(const double* pose0_before, vil_state* s) {
+    if (!pose0_before || !s) return VIL_ERR_INVALID_ARGUMENT;
+    gauge_fix_core(pose0_before, s->K, s->pose, s->speedbias, s->ex_pose);
     return VIL_OK;
 }
 
@@ -1177,6 +1271,125 @@ int vil_shard_ranges(const vil_problem* p, int rank, int world, int32_t* lm_begi
     if (plane_begin) *plane_begin = (int)((long long)p->n_plane * rank / world);
     if (plane_end) *plane_end = (int)((long long)p->n_plane * (rank + 1) / world);
     return VIL_OK;
+}
+
+// ---- window residency across frames (include/vilsolve.h) ------------------------------------------------------------------------
+int vil_set_gauge_fix(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->gauge_on = on != 0; return VIL_OK; }
+
+int vil_lidar_reset(vil_ctx* c) {
+    if (!c) return VIL_ERR_INVALID_ARGUMENT;
+    c->slabs.clear(); c->free_slots.clear();
+    for (int q = c->nslot - 1; q >= 0; --q) c->free_slots.push_back(q);
+    return VIL_OK;
+}
+int vil_lidar_count(vil_ctx* c, int32_t* n_slabs, int32_t* n_plane, int32_t* n_edge) {
+    if (!c) return VIL_ERR_INVALID_ARGUMENT;
+    int np = 0, ne = 0;
+    for (auto& sl : c->slabs) { np += sl.np; ne += sl.ne; }
+    if (n_slabs) *n_slabs = (int)c->slabs.size(); if (n_plane) *n_plane = np; if (n_edge) *n_edge = ne;
+    return VIL_OK;
+}
+int vil_lidar_drop(vil_ctx* c, int32_t slab) {
+    if (!c || slab < 0 || slab >= (int)c->slabs.size()) return VIL_ERR_INVALID_ARGUMENT;
+    c->free_slots.push_back(c->slabs[slab].slot);
+    c->slabs.erase(c->slabs.begin() + slab);          // the later frames move down: an index remap, the points stay where they are
+    return VIL_OK;
+}
+int vil_lidar_push(vil_ctx* c, int32_t n_plane, const double* plane_const, int32_t n_edge, const double* edge_const) {
+    if (!c || n_plane < 0 || n_edge < 0 || (n_plane > 0 && !plane_const) || (n_edge > 0 && !edge_const)) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    // capacity: points per slab and number of physical slabs only ever grow (the existing slabs are copied once when they do)
+    if (n_plane > c->cap_p || n_edge > c->cap_e || c->free_slots.empty()) {
+        const int ncp = std::max(c->cap_p, ((n_plane + n_plane / 4 + 255) / 256) * 256), nce = std::max(c->cap_e, ((n_edge + n_edge / 4 + 255) / 256) * 256);
+        const int nns = std::max(c->nslot, (int)c->slabs.size() + 4);
+        double *npl = nullptr, *ned = nullptr;
+        HIPCHK(hipMalloc(&npl, 8 * (size_t)7 * nns * std::max(ncp, 256))); HIPCHK(hipMalloc(&ned, 8 * (size_t)9 * nns * std::max(nce, 256)));
+        const int cp2 = std::max(ncp, 256), ce2 = std::max(nce, 256);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (auto& sl : c->slabs) {
+            for (int q = 0; q < 7 && sl.np; ++q) HIPCHK(hipMemcpyAsync(npl + ((size_t)q * nns + sl.slot) * cp2, c->d_pl + ((size_t)q * c->nslot + sl.slot) * c->cap_p, 8 * (size_t)sl.np, hipMemcpyDeviceToDevice, c->stream));
+            for (int q = 0; q < 9 && sl.ne; ++q) HIPCHK(hipMemcpyAsync(ned + ((size_t)q * nns + sl.slot) * ce2, c->d_ed + ((size_t)q * c->nslot + sl.slot) * c->cap_e, 8 * (size_t)sl.ne, hipMemcpyDeviceToDevice, c->stream));
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->d_pl) hipFree(c->d_pl); if (c->d_ed) hipFree(c->d_ed);
+        c->d_pl = npl; c->d_ed = ned;
+        for (int q = nns - 1; q >= c->nslot; --q) c->free_slots.push_back(q);
+        c->cap_p = cp2; c->cap_e = ce2; c->nslot = nns;
+        c->uploaded = false;                          // a resident problem holds pointers / strides of the old tables
+    }
+    const size_t need = (size_t)7 * n_plane + (size_t)9 * n_edge;
+    if (need > c->lstage_cap) {
+        if (c->lpush_pending) { HIPCHK(hipEventSynchronize(c->lpush_ev)); c->lpush_pending = false; }
+        if (c->d_lstage) hipFree(c->d_lstage); if (c->h_lstage) hipHostFree(c->h_lstage);
+        c->d_lstage = nullptr; c->h_lstage = nullptr; c->lstage_cap = 0;
+        const size_t cap = need + need / 4 + 1024;
+        HIPCHK(hipMalloc(&c->d_lstage, 8 * cap)); HIPCHK(hipHostMalloc(&c->h_lstage, 8 * cap, hipHostMallocDefault));
+        c->lstage_cap = cap;
+    }
+    if (c->lpush_pending) { HIPCHK(hipEventSynchronize(c->lpush_ev)); c->lpush_pending = false; }     // the previous frame's DMA has left the pinned image
+    const int slot = c->free_slots.back(); c->free_slots.pop_back();
+    if (need) {
+        if (n_plane) memcpy(c->h_lstage, plane_const, 8 * (size_t)7 * n_plane);
+        if (n_edge) memcpy(c->h_lstage + (size_t)7 * n_plane, edge_const, 8 * (size_t)9 * n_edge);
+        HIPCHK(hipMemcpyAsync(c->d_lstage, c->h_lstage, 8 * need, hipMemcpyHostToDevice, c->stream));
+        if (!c->lpush_ev) HIPCHK(hipEventCreateWithFlags(&c->lpush_ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->lpush_ev, c->stream)); c->lpush_pending = true;
+        // point-major rows -> the component-major tables the sweep reads (coalesced, thread = point)
+        if (n_plane) hipLaunchKernelGGL(k_aos2soa, dim3((n_plane + 255) / 256), dim3(256), 0, c->stream, c->d_lstage, n_plane, 7, c->d_pl + (size_t)slot * c->cap_p, (size_t)c->nslot * c->cap_p);
+        if (n_edge) hipLaunchKernelGGL(k_aos2soa, dim3((n_edge + 255) / 256), dim3(256), 0, c->stream, c->d_lstage + (size_t)7 * n_plane, n_edge, 9, c->d_ed + (size_t)slot * c->cap_e, (size_t)c->nslot * c->cap_e);
+    }
+    c->slabs.push_back({n_plane, n_edge, slot});
+    return VIL_OK;
+}
+
+int vil_marginalize_resident(vil_ctx* c, const vil_state* s, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out) {
+    if (!c || !s || !o || !spec || !out || !c->uploaded || c->resident_kind != 1) return VIL_ERR_INVALID_ARGUMENT;
+    if (c->sharded) return VIL_ERR_UNSUPPORTED;
+    const int K = c->K;
+    if (K < 3 || s->K != K || s->L != c->L) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    const vil_ctx::MargMeta& mm = c->mm;
+    const bool old_ = spec->flag == VIL_MARGIN_OLD;
+    const int drop_pose = old_ ? 0 : K - 2;
+    std::vector<char> pose_t(K, 0), sb_t(K, 0);
+    bool ex_t = false, td_t = false;
+    int n_lm_elim = 0;
+    if (mm.has_prior) {
+        bool has_drop = false;
+        for (size_t b = 0; b < mm.prior_kind.size(); ++b) {
+            const int kind = mm.prior_kind[b], idx = mm.prior_index[b];
+            if (kind == VIL_BLK_POSE) { pose_t[idx] = 1; if (idx == drop_pose) has_drop = true; }
+            else if (kind == VIL_BLK_SPEEDBIAS) sb_t[idx] = 1;
+            else if (kind == VIL_BLK_EX) ex_t = true; else td_t = true;
+        }
+        if (!old_ && !has_drop) { out->n = -1; return VIL_OK; }     // estimator.cpp:1620-1621: prior kept as is
+    } else if (!old_) { out->n = -1; return VIL_OK; }
+    int icp_m = -1, lps_m = -1;
+    if (old_) {
+        if (mm.imu01) { pose_t[0] = pose_t[1] = 1; sb_t[0] = sb_t[1] = 1; }
+        if (mm.n_lm0 > 0) { pose_t[0] = 1; for (int k = 0; k < K; ++k) if (mm.obs0[k]) pose_t[k] = 1; ex_t = true; if (mm.use_td) td_t = true; n_lm_elim = mm.n_lm0; }
+        if (spec->icp_marg >= 0 && 4 * (size_t)spec->icp_marg + 3 < mm.icp_ids.size()) {
+            icp_m = spec->icp_marg;
+            if (mm.icp_ids[4 * icp_m] != 0) return VIL_ERR_UNSUPPORTED;      // the remembered constraint starts in frame 0 (estimator.cpp:1381-1389)
+            for (int b = 0; b < 4; ++b) pose_t[mm.icp_ids[4 * icp_m + b]] = 1;
+        }
+        if (spec->lps_marg >= 0 && 2 * (size_t)spec->lps_marg + 1 < mm.lps_ids.size()) {
+            lps_m = spec->lps_marg;
+            if (mm.lps_ids[2 * lps_m] != 0) return VIL_ERR_UNSUPPORTED;
+            for (int b = 0; b < 2; ++b) pose_t[mm.lps_ids[2 * lps_m + b]] = 1;
+        }
+        if (mm.lidar0) pose_t[0] = 1;
+    }
+    const SolveOpts so = to_dev_opts(o);
+    int st = init_ctl(c, o, 2);
+    if (st != VIL_OK) return st;
+    const DevP keep = c->P;
+    c->P.marg = old_ ? 1 : 2; c->P.marg_icp = icp_m; c->P.marg_lps = lps_m;
+    launch_sweep(c, so);                               // the resident tables at the resident (solved, gauge-fixed) state; masks select the factors
+    launch_reduce_step(c, so, false);
+    c->P = keep;
+    c->resident_kind = 2;                              // the work space now holds the marginalisation's linearisation
+    return marg_finish(c, K, old_, drop_pose, pose_t, sb_t, ex_t, td_t, mm.use_td, n_lm_elim, s, out);
 }
 
 int vil_comm_unique_id(void* id128) {

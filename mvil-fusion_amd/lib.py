@@ -131,6 +131,29 @@ class Backend:
     def reset_state(self):
         self._call("reset_state")
 
+    # -- window residency across frames (HIP library only; include/vilsolve.h)
+    def lidar_reset(self):
+        self._call("lidar_reset")
+
+    def lidar_push(self, plane_const, edge_const):
+        pc, ec = abi.f64(plane_const).reshape(-1, 7), abi.f64(edge_const).reshape(-1, 9)
+        self._call("lidar_push", C.c_int32(len(pc)), _ptr(pc) if len(pc) else C.cast(None, _dp), C.c_int32(len(ec)), _ptr(ec) if len(ec) else C.cast(None, _dp))
+
+    def lidar_drop(self, slab):
+        self._call("lidar_drop", C.c_int32(slab))
+
+    def set_gauge_fix(self, on=True):
+        self._call("set_gauge_fix", C.c_int32(1 if on else 0))
+
+    def marginalize_resident(self, w, flag=abi.MARGIN_OLD, icp_marg=-1, lps_marg=-1, opts=None):
+        """Marginalise the window the last solve() left on the device, at its solved state (w only supplies that state for x0)."""
+        opts = opts or abi.default_options()
+        s = w.c_state()
+        spec = abi.VilMargSpec(flag, icp_marg, lps_marg, 4)
+        out = abi.PriorOut(w.K)
+        self._call("marginalize_resident", C.byref(s), C.byref(opts), C.byref(spec), C.byref(out.c))
+        return out
+
     def download_state(self, w):
         s = w.c_state()
         self._call("download_state", C.byref(s))

@@ -208,7 +208,9 @@ class Replay:
             self.lps = self.lps[-7:]                          # estimator.cpp:1283-1286
 
     # ---- one window for the backend ----------------------------------------------------------------------------------
-    def window(self):
+    def window(self, with_lidar=True):
+        """with_lidar=False: the point factors are resident on the device as frame slabs (lib.Backend.lidar_push of self.lidar[k]);
+        the window carries no LiDAR tables and asks for them with n_plane = n_edge = VIL_LIDAR_RESIDENT."""
         K = self.K
         sel = [tr for tr in self.tracks if len(tr.obs) >= 2 and tr.start < K - 3]          # feature_manager.cpp:36
         w = Window(K, len(sel))
@@ -230,10 +232,13 @@ class Replay:
         w.vis_i, w.vis_j, w.vis_l = np.array(vi, np.int32), np.array(vj, np.int32), np.array(vl, np.int32)
         w.vis_const = np.array(vc).reshape(-1, 14)
         w.inv_depth, w.lm_const = lam, lmc
-        w.plane_pose = np.concatenate([np.full(len(self.lidar[k][0]), k, np.int32) for k in range(K)])
-        w.plane_const = np.concatenate([self.lidar[k][0] for k in range(K)])
-        w.edge_pose = np.concatenate([np.full(len(self.lidar[k][1]), k, np.int32) for k in range(K)])
-        w.edge_const = np.concatenate([self.lidar[k][1] for k in range(K)])
+        if with_lidar:
+            w.plane_pose = np.concatenate([np.full(len(self.lidar[k][0]), k, np.int32) for k in range(K)])
+            w.plane_const = np.concatenate([self.lidar[k][0] for k in range(K)])
+            w.edge_pose = np.concatenate([np.full(len(self.lidar[k][1]), k, np.int32) for k in range(K)])
+            w.edge_const = np.concatenate([self.lidar[k][1] for k in range(K)])
+        else:
+            w.lidar_resident = True
         slot = {f: k for k, f in enumerate(self.frames)}
         icp_ids, icp_c, lps_ids, lps_c = [], [], [], []
         icp_marg = lps_marg = -1
