@@ -165,19 +165,87 @@ __device__ inline int gram_sqrt(double* M, double* lam, int n, double tiny, doub
 
 }  // namespace vd
 
-__global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M) {
+// phase 0: dropped block, Schur complement -> A, b (and the symmetrised copy in J0).  phase 1: pivoted square root, unless the
+// fast path (k_marg_fast, between the two) already produced J0 / r0 (stat[2] == 1).
+__global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M, int phase) {
     using namespace vd;
     __shared__ double sm[3 * MARG_NMAX + 64];
     __shared__ double bsh[MARG_NMAX];
     extern __shared__ double mlds[];     // n x n: the symmetric matrix, then its orthogonalised factor rows
     const int t = threadIdx.x, NT = blockDim.x;
     const int D = M.D, nd = M.nd, n = M.n;
+    if (phase == 1) {
+        if (M.stat[2] == 1) return;                      // the un-pivoted factorisation went through
+        for (int e = t; e < n * n; e += NT) mlds[e] = M.J0[e];
+        if (t < n) bsh[t] = M.b[t];
+        __syncthreads();
+        const int ns = gram_sqrt(mlds, M.w, n, 1e-30, 1e-10, false, bsh, M.r0, sm);
+        if (t == 0) M.stat[1] = ns;
+        for (int e = t; e < n * n; e += NT) {
+            const int j = e / n, k = e - j * n;                   // column-major element (k, j): J0[j*n + k]
+            M.J0[e] = mlds[k * n + j];
+        }
+        return;
+    }
     // ---- dropped block, symmetrised (marginalization_factor.cpp:273), eigen pseudo inverse ------------
     for (int e = t; e < nd * nd; e += NT) {
         const int i = e / nd, j = e - i * nd;
         mlds[e] = 0.5 * (M.S[(size_t)M.drop_cols[i] * D + M.drop_cols[j]] + M.S[(size_t)M.drop_cols[j] * D + M.drop_cols[i]]);
     }
     __syncthreads();
+    // Fast path for the dropped block: when every eigenvalue of A_dd is safely above eps the thresholded pseudo inverse of
+    // marginalization_factor.cpp:277 IS the inverse, and a 15 x 15 Cholesky inverse costs a few microseconds where the
+    // eigen-decomposition (one-sided Jacobi, a workgroup barrier per rotation stage) costs ~100.  Certificate:
+    // lambda_min = 1 / lambda_max(A_dd^-1) >= 1 / ||A_dd^-1||_F.  Anything else takes the eigen route below.
+    __shared__ int fast_ok;
+    double* W = sm; double* Li = sm + 225;               // nd <= 15: factor, its inverse (sm holds 3 * 136 + 64 doubles)
+    if (t == 0) fast_ok = nd <= 15 ? 1 : 0;
+    for (int e = t; e < nd * nd; e += NT) W[e] = mlds[e];
+    __syncthreads();
+    for (int p = 0; p < nd && fast_ok; ++p) {
+        const double d = W[p * nd + p];
+        if (!(d > 0.0) || !isfinite(d)) { __syncthreads(); if (t == 0) fast_ok = 0; __syncthreads(); break; }
+        const double r = rsqrt_nr(d);
+        __syncthreads();
+        if (t >= p && t < nd) W[t * nd + p] *= r;
+        __syncthreads();
+        for (int e = t; e < nd * nd; e += NT) { const int i = e / nd, j = e - i * nd; if (j > p && i >= j) W[e] -= W[i * nd + p] * W[j * nd + p]; }
+        __syncthreads();
+    }
+    if (fast_ok) {
+        if (t < nd) {                                    // column t of L^-1 by forward substitution
+            const int j = t;
+            for (int i = 0; i < nd; ++i) {
+                double acc = i == j ? 1.0 : 0.0;
+                for (int k = j; k < i; ++k) acc -= W[i * nd + k] * Li[k * nd + j];
+                Li[i * nd + j] = i < j ? 0.0 : acc / W[i * nd + i];
+            }
+        }
+        __syncthreads();
+        double f2 = 0.0;
+        for (int e = t; e < nd * nd; e += NT) {           // A_dd^-1 = L^-T L^-1 -> Vd (scratch)
+            const int i = e / nd, j = e - i * nd;
+            double acc = 0.0;
+            for (int k = (i > j ? i : j); k < nd; ++k) acc += Li[k * nd + i] * Li[k * nd + j];
+            M.Vd[e] = acc; f2 += acc * acc;
+        }
+        f2 = wave_total(f2);
+        __shared__ double f2w[16];
+        if ((t & 63) == 0) f2w[t >> 6] = f2;
+        __syncthreads();
+        if (t == 0) { double tot = 0.0; for (int q = 0; q < (NT >> 6); ++q) tot += f2w[q]; if (!(tot > 0.0) || !(rsqrt_nr(tot) > 4.0 * M.eps)) fast_ok = 0; }
+        __syncthreads();
+    }
+    if (fast_ok) {
+        if (t == 0) M.stat[0] = 0;
+        for (int e = t; e < n * nd; e += NT) {           // T = A_kd A_dd^-1
+            const int i = e / nd, j = e - i * nd;
+            double acc = 0.0;
+            for (int q = 0; q < nd; ++q) acc += M.S[(size_t)M.keep_cols[i] * D + M.drop_cols[q]] * M.Vd[(size_t)q * nd + j];
+            M.T[e] = acc;
+        }
+        __syncthreads();
+    } else {
     const int nsd = gram_sqrt(mlds, M.wd, nd, 1e-30, 0.0, true, nullptr, nullptr, sm);
     // eigenvectors (columns of Vd) = normalised factor rows
     for (int e = t; e < nd * nd; e += NT) { const int i = e / nd, k = e - i * nd; const double lk = M.wd[k]; M.Vd[e] = lk > 0.0 ? mlds[k * nd + i] * rsqrt_nr(lk) : 0.0; }
@@ -198,6 +266,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M) {
         M.T[e] = s;
     }
     __syncthreads();
+    }
     // A = A_kk - T A_dk ; b = b_k - T b_d      (marginalization_factor.cpp:289-290)
     for (int e = t; e < n * n + n; e += NT) {
         if (e < n * n) {
@@ -218,18 +287,59 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M) {
     __syncthreads();
     for (int e = t; e < n * n; e += NT) { M.A[e] = M.V[e]; }
     __syncthreads();
-    for (int e = t; e < n * n; e += NT) mlds[e] = M.J0[e];
-    if (t < n) bsh[t] = M.b[t];
-    __syncthreads();
+    if (t == 0) M.stat[2] = 0;
     // linearized_jacobians / linearized_residuals (marginalization_factor.cpp:301-309) are ANY pair with J0^T J0 = A and
     // J0^T r0 = b: the reference takes sqrt(S) V^T from an eigen-decomposition, whose basis is implementation-defined
-    // (SURVEY App. C #12).  Here J0 = G^T from the pivoted Cholesky A = G G^T and r0 = G^-1 b: the prior residual
-    // r0 + J0 dx is the reference's up to a left orthogonal factor, i.e. the same cost, gradient and Gauss-Newton matrix;
-    // pivots at rounding level are dropped where the reference drops eigenvalues below eps.
-    const int ns = gram_sqrt(mlds, M.w, n, 1e-30, 1e-10, false, bsh, M.r0, sm);
-    if (t == 0) M.stat[1] = ns;
-    for (int e = t; e < n * n; e += NT) {
-        const int j = e / n, k = e - j * n;                   // column-major element (k, j): J0[j*n + k]
-        M.J0[e] = mlds[k * n + j];
+    // (SURVEY App. C #12).  Here J0 = G^T from a Cholesky A = G G^T and r0 = G^-1 b: the prior residual r0 + J0 dx is the
+    // reference's up to a left orthogonal factor, i.e. the same cost, gradient and Gauss-Newton matrix.  k_marg_fast tries the
+    // un-pivoted blocked factorisation of the step kernel first (matrix cores, ~25 us at n = 70); if a pivot falls to its
+    // rounding level -- where the reference drops eigenvalues below eps -- phase 1 redoes it with diagonal pivoting (gram_sqrt).
+}
+
+// Fast path of the square root: A (symmetrised, in J0) = L L^T with chol_blocked (vil_step.hpp), r0 = L^-1 b as the extra row.
+// Accepted only if every pivot clears the threshold gram_sqrt would apply to it; then J0 = L^T (column-major), r0, stat[2] = 1.
+__global__ __launch_bounds__(VIL_STEP_THREADS) void k_marg_fast(MargDev M) {
+    using namespace vd;
+    __shared__ StepShared s;
+    extern __shared__ double tl[];
+    const int t = threadIdx.x, NT = blockDim.x, n = M.n;
+    for (int q = t; q < 256; q += NT) {
+        int Ir = (int)((sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
+        if (((Ir + 1) * (Ir + 2)) / 2 <= q) ++Ir;
+        if ((Ir * (Ir + 1)) / 2 > q) --Ir;
+        s.tI[q] = (unsigned char)Ir; s.tJ[q] = (unsigned char)(q - (Ir * (Ir + 1)) / 2);
     }
+    if (t == 0) s.ok = 1;
+    __syncthreads();
+    const int R = n + 1, T = (R + 15) >> 4, NE = ((T * (T + 1)) >> 1) << 8;
+    double dmax = 0.0;
+    for (int i = t; i < n; i += NT) dmax = fmax(dmax, M.J0[(size_t)i * n + i]);
+    dmax = bmax(dmax, s);
+    for (int e = t; e < NE; e += NT) {
+        const int tile = e >> 8, w = e & 255;
+        const int i = (s.tI[tile] << 4) + (w >> 4), j = (s.tJ[tile] << 4) + (w & 15);
+        double v = 0.0;
+        if (i < n && j <= i) v = M.J0[(size_t)i * n + j];
+        else if (i == n && j < n) v = M.b[j];
+        tl[tl_phys(e)] = v;
+    }
+    for (int i = t; i < n; i += NT) {                    // smallest acceptable pivot of column i (the rule of gram_sqrt)
+        const double rel = fmax(16.0 * n * 2.220446049250313e-16 * M.J0[(size_t)i * n + i], 1e-10 * dmax);
+        s.gr[i] = rel > 1e-30 ? rel : 1e-30;
+    }
+    __syncthreads();
+    bool ok = chol_blocked<true>(tl, n, s);
+    __syncthreads();
+    if (ok) {
+        for (int i = t; i < n; i += NT) { const double l = 1.0 / s.dinv[i]; if (!(l * l > s.gr[i])) s.ok = 0; }
+        __syncthreads();
+        ok = s.ok != 0;
+    }
+    if (!ok) return;                                     // stat[2] stays 0: phase 1 of k_marg takes over
+    for (int e = t; e < n * n; e += NT) {
+        const int j = e / n, k = e - j * n;              // column-major element (k, j) of J0 = L^T: L[j][k] for k <= j
+        M.J0[e] = k <= j ? tl[tl_idx(j, k)] : 0.0;
+    }
+    for (int i = t; i < n; i += NT) M.r0[i] = tl[tl_idx(n, i)];
+    if (t == 0) { M.stat[2] = 1; M.stat[1] = 0; }
 }

@@ -1085,7 +1085,7 @@ static int marg_finish(vil_ctx* c, const int K, const bool old_, const int drop_
     M.Add = (double*)take(8 * (size_t)nd * nd); M.Vd = (double*)take(8 * (size_t)nd * nd); M.wd = (double*)take(8 * (size_t)nd);
     M.T = (double*)take(8 * nn); M.A = (double*)take(8 * nn); M.b = (double*)take(8 * (size_t)n);
     M.V = (double*)take(8 * nn); M.w = (double*)take(8 * (size_t)n); M.J0 = (double*)take(8 * nn); M.r0 = (double*)take(8 * (size_t)n);
-    M.stat = (int*)take(16);
+    M.stat = (int*)take(32);
     if (off > bytes) return VIL_ERR_DEVICE;
     HIPCHK(hipMemcpyAsync(d_drop, drop_cols.data(), 4 * (size_t)nd, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_keep, keep_cols.data(), 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
@@ -1094,7 +1094,15 @@ static int marg_finish(vil_ctx* c, const int K, const bool old_, const int drop_
         if (a_bytes > cap) return VIL_ERR_UNSUPPORTED;
         const size_t dyn = std::max<size_t>(4096, a_bytes);
         if (dyn > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        hipLaunchKernelGGL(k_marg, dim3(1), dim3(MARG_THREADS), dyn, c->stream, M);
+        hipLaunchKernelGGL(k_marg, dim3(1), dim3(MARG_THREADS), dyn, c->stream, M, 0);
+        if (!getenv("VIL_MARG_PIVOTED")) {               // un-pivoted factorisation on the matrix cores first; pivoted fallback below
+            const size_t Tm = (size_t)(n + 1 + 15) / 16, tb = 8 * (size_t)TILE_SZ * (Tm * (Tm + 1) / 2);
+            if (tb + sizeof(vd::StepShared) + 512 <= 160 * 1024) {
+                if (tb > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_marg_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
+                hipLaunchKernelGGL(k_marg_fast, dim3(1), dim3(VIL_STEP_THREADS), tb, c->stream, M);
+            }
+        }
+        hipLaunchKernelGGL(k_marg, dim3(1), dim3(MARG_THREADS), dyn, c->stream, M, 1);
     }
     st = ensure_pin(c, 8 * (nn * 2 + 2 * (size_t)n));
     if (st != VIL_OK) return st;
