@@ -34,7 +34,7 @@ def algorithmic_bytes(w):
             + 8 * (n * n + n) + 8 * (16 * w.K + 8))
 
 
-def pmc_traffic_bytes(files=("r01_pmc_fetch_size.csv", "r01_pmc_write_size.csv"), kernel="k_sweep"):
+def pmc_traffic_bytes(files=("r02_pmc_fetch_size.csv", "r02_pmc_write_size.csv"), kernel="k_sweep"):
     """HBM bytes per live launch of `kernel` from the committed rocprofv3 --pmc passes of THIS command (profiles/):
     (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md (HBM section),
     WRITE_SIZE uncalibrated.  None if the CSVs are missing."""
@@ -380,6 +380,7 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not record HIP events around sweep launches in the timed region")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--replay", type=int, default=0, help="config 5: run N images of the synthetic replay and report per-frame latency instead of the headline metric")
+    ap.add_argument("--no-cfg3", dest="no_cfg3", action="store_true", help="skip the extra configs[2] (K=10, L=4000, 120k points) leg")
     ap.add_argument("--classic", action="store_true", help="replay mode: hand every table over on every image (vil_solve + vil_gauge_fix + vil_marginalize) instead of the resident-window entry points")
     ap.add_argument("--precision", type=int, default=0, help="0 = fp64 (reference arithmetic), 1 = fp32 factor evaluation with fp64 accumulation (replay mode only)")
     ap.add_argument("--vgicp", action="store_true", help="SURVEY 8(f) row 1: bench the voxelised GICP linearisation instead of the headline metric")
@@ -526,6 +527,39 @@ def main():
         m2 = tt2.clone(); dist.all_reduce(m2, op=dist.ReduceOp.MAX)
         replicas_leg = {"value": float(s2[0]) / float(m2[1]), "unit": "iterations/s", "scaling": "weak", "what": "%d independent replicas of the same window, %d steps each, no collective" % (world, args.steps)}
         be2.close()
+    # what a tracker gets: a fresh upload per image (vil_solve = pack + H2D + set-up + solve + read-back), never a re-solve of a resident
+    # upload -- reported beside `value`, never as `value`
+    pcie_leg = None
+    if world == 1:
+        saved = w.state_copy()
+        for _ in range(2):
+            w.set_state(saved); be.solve(w, opts)
+        n_p = max(5, args.steps // 2); its_p = 0
+        torch.cuda.synchronize(); tp = time.perf_counter()
+        for _ in range(n_p):
+            w.set_state(saved); its_p += be.solve(w, opts).iterations
+        torch.cuda.synchronize(); elp = time.perf_counter() - tp
+        w.set_state(saved)
+        pcie_leg = {"value": its_p / elp, "unit": "iterations/s", "ms_per_solve": 1e3 * elp / n_p, "what": "vil_solve per step: host tables packed and uploaded, solved, state read back (%d solves); first solve of an upload launches directly (no hipGraph)" % n_p}
+    # BASELINE.json configs[2] (K = 10, L = 4000, 120 k LiDAR points): the window the 8-GPU sharding is specified on -- same protocol, fewer steps
+    cfg3_leg = None
+    if args.config == 2 and not args.no_cfg3:
+        w3 = synth.make_config(3, prior_fn=gpu_prior)
+        be.upload(w3)
+        for _ in range(2):
+            be.reset_state(); be.solve_resident(opts)
+        sync()
+        n3 = max(4, args.steps // 4); t3 = time.perf_counter(); it3 = 0
+        for _ in range(n3):
+            be.reset_state(); l3 = be.solve_resident(opts); it3 += l3.iterations
+        sync()
+        el3 = time.perf_counter() - t3
+        if dist is not None:
+            tt3 = torch.tensor([float(it3), el3], device="cuda", dtype=torch.float64)
+            s3 = tt3.clone(); dist.all_reduce(s3, op=dist.ReduceOp.SUM); m3 = tt3.clone(); dist.all_reduce(m3, op=dist.ReduceOp.MAX)
+            it3, el3 = (float(it3) if sharded else float(s3[0])), float(m3[1])
+        cfg3_leg = {"value": it3 / el3, "unit": "iterations/s", "n_gpus": world, "ms_per_step": 1e3 * el3 / n3, "steps": n3, "iterations_per_solve": l3.iterations,
+                    "workload": "BASELINE.json configs[2]: K=%d, L=%d, %d visual factors, %d LiDAR points, %s" % (w3.K, w3.L, len(w3.vis_i), len(w3.plane_pose) + len(w3.edge_pose), "sharded over %d GPUs" % world if sharded else ("1 GPU" if world == 1 else "%d replicas" % world))}
     if rank == 0:
         out = {
             "metric": "sliding-window solve iterations/sec (10 KF, 1k feat, 30k LiDAR pts)",
@@ -535,7 +569,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[%d]: K=%d keyframes, L=%d landmarks, %d visual factors, %d plane + %d edge LiDAR points, %d IMU, %d ICP, %d LPS, prior n=%d (%s)"
                        % (args.config - 1, w.K, w.L, len(w.vis_i), len(w.plane_pose), len(w.edge_pose), len(w.imu_i), len(w.icp_ids), len(w.lps_ids), w.prior.n, prior_kind),
                        "iterations_per_solve": last.iterations, "termination": abi.TERM_NAMES[last.termination], "final_cost": last.final_cost,
-                       "parallelism": "1 GPU" if world == 1 else ("factor set of ONE window sharded over %d GPUs: visual by landmark owner, LiDAR points in contiguous slices, RCCL all-reduce of [S|g|cost] + 5 scalars per iteration" % world if sharded else "%d independent replicas" % world),
+                       "parallelism": "1 GPU" if world == 1 else ("factor set of ONE window sharded over %d GPUs: visual by landmark owner, LiDAR points in contiguous slices, ONE RCCL all-reduce per iteration of the whole linear-system set ([S|g|cost] + the owners' landmark arrays), then the complete step kernel redundantly on every rank" % world if sharded else "%d independent replicas" % world),
                        "step": "one full window solve, inputs resident in HBM"},
         }
         if shard_note:
@@ -546,19 +580,24 @@ def main():
             ab = algorithmic_bytes(w)
             us = 1e3 * prof.sweep_ms / prof.sweep_launches
             ach = ab / (us * 1e-6) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_sweep", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(), "traffic_source": "profiles/r01_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command)",
+            out["roofline"] = {"bound": "hbm", "kernel": "k_sweep", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(), "traffic_source": "profiles/r02_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command)",
                                "algorithmic_bytes_per_launch": ab, "avg_launch_us": us, "launches_timed": int(prof.sweep_launches),
                                "reduce_plus_step_avg_us": 1e3 * prof.step_ms / max(1, prof.step_launches), "reduce_avg_us": 1e3 * prof.reduce_ms / max(1, prof.step_launches),
                                "measured_on": "second pass of the same %d steps with HIP events enabled (%.1f ms/step instrumented vs %.1f ms/step in the value region)" % (args.steps, 1e3 * el_events / args.steps, 1e3 * max_el / args.steps),
                                "variant": "fused sweep (no Jacobian materialisation): read-only bytes, SURVEY 8(d)"}
             # the kernel that dominates the iteration's TIME is the single-workgroup trust-region step; it is neither HBM- nor
             # MFMA-bound (one CU, dependent chains), so it is reported next to the sweep rather than as the roofline object
-            D = 15 * w.K + 7
+            NP, NB = 6 * w.K + 7, 9 * w.K
             step_us = 1e3 * (prof.step_ms - prof.reduce_ms) / max(1, prof.step_launches)
-            chol_flop = D ** 3 / 3.0 + 2.0 * D * D                   # factorisation + the two triangular solves
-            out["roofline"]["critical_path_kernel"] = {"kernel": "k_step", "avg_launch_us": step_us, "bound": "latency (one workgroup: 157-pivot Cholesky chain, dependent L2 round trips)",
+            # chain path: K 9x9 factorisations + their panels, the Schur contraction of the pose block, the dense factorisation of 6K+8 rows, the solves
+            chol_flop = w.K * (9 ** 3 / 3.0 + 2.0 * 81 * (NP + 1 + 9)) + 1.0 * (NP + 1) ** 2 * NB + NP ** 3 / 3.0 + 2.0 * (NP * NP + NB * (NP + 9))
+            out["roofline"]["critical_path_kernel"] = {"kernel": "k_step", "avg_launch_us": step_us, "bound": "latency (one workgroup + helper workgroups: two-sided 9x9 chain of %d blocks, then a %d-pivot dense Cholesky; dependent fp64 chains)" % (w.K, NP),
                                                        "dense_flop_per_launch": chol_flop, "achieved_gflops": chol_flop / (step_us * 1e-6) / 1e9, "peak_tflops_fp64_matrix": 78.6,
-                                                       "frac": chol_flop / (step_us * 1e-6) / 78.6e12, "see": "profiles/r01_summary.txt (MFMA pipes 5 % busy on that CU), DESIGN.md section 4"}
+                                                       "frac": chol_flop / (step_us * 1e-6) / 78.6e12, "see": "profiles/r02_summary.txt, DESIGN.md section 4"}
+        if world == 1:
+            out["pcie_inclusive"] = pcie_leg
+        if cfg3_leg:
+            out["configs2_window"] = cfg3_leg
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(w, opts)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -18,10 +18,12 @@ struct SysBuf {       // one linearisation of the window (double-buffered: curre
     double* hll;      // L      J_l^T J_l
     double* bl;       // L      J_l^T r
     double* invp;     // L      1 / (hll + mu dl^2 / Sl^2), 0 for constant landmarks
+    double* sl;       // L      Jacobi scale of the landmark (fixed at the first linearisation; carried with the set so that it travels with the all-reduce)
     double* eA;       // L x 13 e_l on [anchor pose(6) | ex(6) | td(1)]
     double* eO;       // F x 6  e_l on the observing pose of each factor
     double* cost;     // 1
-    double* ar;       // start of the contiguous all-reduce block [S | gred | bc | diag | cost | xn sn] (D*D + 3D + 3 doubles)
+    double* ar;       // start of the set: ONE contiguous block [S | gred | bc | diag | cost | 2 spare | hll | bl | invp | sl | eA | eO] --
+                      // multi-GPU: every rank fills the landmark arrays of the landmarks it owns (zeros elsewhere) and the whole block is all-reduced once
 };
 
 struct Ctl {          // trust-region state, lives in device memory, owned by the step kernel
@@ -57,6 +59,10 @@ struct DevP {
     const int* vchunk;        // n_vchunk x 2 landmark ranges
     const int* lm_acol;       // L   reduced column of the anchor pose (6 * start_frame), -1 if the landmark has no factor
     const int* fcol;          // F   reduced column of the observing pose of each factor (6 * vis_j)
+    // the same three tables over the WHOLE window and the offset of this rank's first visual factor in it: with the factor set
+    // sharded over ranks the sweep writes e_O at global factor positions and the step kernel walks every landmark (the local
+    // tables only know this rank's factors).  Un-sharded: aliases of the local tables, vis_f0 = 0.
+    const int* glm_start; const int* glm_acol; const int* gfcol; int vis_f0;
     // LiDAR points, sorted by pose; chunk = (start, count, pose)
     int n_plane, pl_stride, n_pchunk; const double* pl_c; const int* pchunk;
     int n_edge, ed_stride, n_echunk; const double* ed_c; const int* echunk;

@@ -199,7 +199,15 @@ __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O
     if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm); if (P.prechain) sweep_signal(P, ctl, b); return; }
     b -= P.n_imu;
     if (b == 0) { if (!(P.skip_mask & 16)) vd::sweep_prior(P, x, sm); if (P.prechain) sweep_signal(P, ctl, P.n_imu); return; }
-    if (b == 1) { if (!(P.skip_mask & 16)) vd::sweep_misc(P, O, x, sm); return; }
+    if (b == 1) {
+        if (!(P.skip_mask & 16)) vd::sweep_misc(P, O, x, sm);
+        if (P.world > 1) {                               // factor set sharded over ranks: the visual workgroups of this rank form the candidate inverse depth of
+            const double* xcur = P.x[ctl.cur];           // the landmarks it owns; every rank holds la / lb of ALL landmarks (the step kernel runs on the all-reduced
+            double* xcand = P.x[1 - ctl.cur];            // system), so the rest is filled in here and the states stay identical on all ranks
+            for (int l = threadIdx.x; l < P.L; l += blockDim.x) xcand[xo_lam(P) + l] = xcur[xo_lam(P) + l] + ctl.cg * P.la[l] + ctl.cn * P.lb[l];
+        }
+        return;
+    }
     b -= 2;
     if (P.prechain) { if (b == 0) { vd::reduce_chain_wg(P, ctl, O.jacobi_scaling, sm, true); return; } b -= 1; }
     // visual workgroups next: the longest-running factor role

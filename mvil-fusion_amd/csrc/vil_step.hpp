@@ -76,8 +76,8 @@ __device__ __forceinline__ double bmax(double v, StepShared& s) {
 // Dependent fp64 ops cost ~32 cycles each on gfx950: four independent accumulators, column tables instead of
 // chained index loads.
 __device__ __forceinline__ double lm_dot(const DevP& P, const SysBuf& sb, int l, const double* vc) {
-    const int fs = P.lm_start[l], fe = P.lm_start[l + 1];
-    const int ac = P.lm_acol[l];
+    const int fs = P.glm_start[l], fe = P.glm_start[l + 1];
+    const int ac = P.glm_acol[l];
     if (fe == fs) return 0.0;
     const double* e = sb.eA + (size_t)l * 13;
     const double* va = vc + ac; const double* vx = vc + col_ex(P);
@@ -90,7 +90,7 @@ __device__ __forceinline__ double lm_dot(const DevP& P, const SysBuf& sb, int l,
     // per factor, and there is no per-lane predicated load (those compile to exec-mask branches with their own waits)
     for (int f = fs; f < fe; f += 3) {
         const int f1 = min(f + 1, fe - 1), f2 = min(f + 2, fe - 1);
-        const int c0 = P.fcol[f], c1 = P.fcol[f1], c2 = P.fcol[f2];
+        const int c0 = P.gfcol[f], c1 = P.gfcol[f1], c2 = P.gfcol[f2];
         const double* e0 = sb.eO + (size_t)f * 6; const double* e1 = sb.eO + (size_t)f1 * 6; const double* e2 = sb.eO + (size_t)f2 * 6;
         double a[6], b[6], c[6];
 #pragma unroll
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     // pass 1 (needs u = Sc gradient_/d of the camera part in vc): dl, gradient_l, share of u^T H u, |g|^2, max |b|
     auto lm_pass1 = [&](int l0, int l1, const double* vc, double& q, double& g2, double& gm) {
         for (int l = l0 + t; l < l1; l += NT) {
-            const double ip = sb.invp[l], Sl = P.Sl[l], h = sb.hll[l], b = sb.bl[l];
+            const double ip = sb.invp[l], Sl = sb.sl[l], h = sb.hll[l], b = sb.bl[l];
             const double d = sqrt(fmin(fmax(Sl * Sl * h, 1e-6), 1e32));
             const double g = ip != 0.0 ? Sl * b / d : 0.0;
             P.dl[l] = d; P.gradl[l] = g;
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             const double ip = sb.invp[l];
             double a = 0.0, b = 0.0;
             if (ip != 0.0) {
-                const double Sl = P.Sl[l], dl = P.dl[l], g = P.gradl[l];
+                const double Sl = sb.sl[l], dl = P.dl[l], g = P.gradl[l];
                 const double xl = (sb.bl[l] - lm_dot(P, sb, l, vc)) * ip / Sl;
                 const double gnv = -xl * dl;
                 sm[0] += gnv * gnv; sm[1] += gnv * g;

@@ -160,7 +160,7 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
                 const double j0 = w[12 + k], j1 = w[18 + k];
                 const double eo = j0 * w[38] + j1 * w[39];
                 w[42 + k] = eo;
-                sb.eO[(size_t)f * 6 + k] = eo;
+                sb.eO[(size_t)(P.vis_f0 + f) * 6 + k] = eo;
                 if (!cj) {
                     const double g = j0 * w[40] + j1 * w[41];
                     lds_add(vbc + col_pose(P, j) + k, g);
@@ -201,10 +201,12 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             const double invp = (cl || !(p > (ctl.lin_mode == 2 ? 1e-8 : 0.0))) ? 0.0 : 1.0 / p;
             const double ib = invp * b;
             double* lr = lmr + tl * 16;
-            if (k == 13) { sb.hll[l] = h; sb.bl[l] = b; sb.invp[l] = invp; lr[0] = invp; lr[14] = (double)a; }
-            if (k == 14) xcand[xo_lam(P) + l] = xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l];      // the same expression the factor threads evaluated
+            // (a landmark without a factor in this workgroup's table -- none at all, or owned by another rank -- leaves the set untouched:
+            //  its entries stay zero here and the all-reduce takes them from the owner)
+            if (k == 13) { if (fe > fs) { sb.hll[l] = h; sb.bl[l] = b; sb.invp[l] = invp; sb.sl[l] = Sl; } lr[0] = invp; lr[14] = (double)a; }
+            if (k == 14 && fe > fs) xcand[xo_lam(P) + l] = xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l];      // the same expression the factor threads evaluated
             if (k < 13) {
-                lr[1 + k] = e; sb.eA[(size_t)l * 13 + k] = e;
+                lr[1 + k] = e; if (fe > fs) sb.eA[(size_t)l * 13 + k] = e;
                 const int col = k < 6 ? col_pose(P, a) + k : (k < 12 ? col_ex(P) + k - 6 : col_td(P));
                 if (g != 0.0 || dg != 0.0) { lds_add(vbc + col, g); lds_add(vgr + col, g - ib * e); lds_add(vdg + col, dg); }
             }
@@ -488,7 +490,6 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl) {
     const int cand = 1 - ctl.cur;
     SysBuf sb = P.sys[cand];
     const int D = P.D, NV = P.NV, K = P.K, t = threadIdx.x;
-    if (P.split) { sb.S = P.arstage; sb.gred = sb.S + (size_t)D * D; sb.bc = sb.gred + D; sb.diag = sb.bc + D; sb.cost = sb.diag + D; }   // reduced across ranks before use
     const int n_rel = P.n_icp + P.n_lps;
     const double* rel0 = P.mpart + (P.pn > 0 ? P.pn + 1 : 0);
     const int NL = (D * (D + 1)) >> 1;

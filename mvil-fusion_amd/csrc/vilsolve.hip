@@ -114,6 +114,7 @@ struct vil_ctx {
     std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
     int n_blocks_sweep = 0, n_blocks_reduce = 0;
     size_t lds_sweep = 0, lds_step = 0, lds_reduce = 0;
+    size_t span = 0;               // doubles of one linear-system set (SysBuf::ar): the multi-GPU all-reduce message
     bool step_lds = false;
     int* d_status = nullptr;
     Ctl* h_ctl = nullptr;          // pinned
@@ -329,7 +330,8 @@ static void lidar_chunks(const std::vector<int>& cnt, int K, std::vector<int>& c
     for (int k = 0; k < K; ++k) for (int s = cnt[k]; s < cnt[k + 1]; s += VIL_THREADS) { chunks.push_back(s); chunks.push_back(std::min(VIL_THREADS, cnt[k + 1] - s)); chunks.push_back(k); }
 }
 
-static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, bool sharded, const vil_device_lidar* dl = nullptr) {
+// gp / vis_f0 (sharded): the whole window's problem and the index of this rank's first visual factor in it
+static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, bool sharded, const vil_device_lidar* dl = nullptr, const vil_problem* gp = nullptr, int vis_f0 = 0) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
     int st = validate(p, s, dl != nullptr);
     if (st != VIL_OK) return st;                 // an invalid problem leaves the resident one untouched
@@ -395,6 +397,15 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             std::vector<int> acol(std::max(L, 1), -1), fcol(std::max(p->n_vis, 1), 0);
             for (int f = p->n_vis - 1; f >= 0; --f) { acol[p->vis_l[f]] = 6 * p->vis_i[f]; fcol[f] = 6 * p->vis_j[f]; }
             put(acol.data(), 4 * acol.size(), (void**)&P.lm_acol); put(fcol.data(), 4 * fcol.size(), (void**)&P.fcol);
+        }
+        P.vis_f0 = 0;
+        if (gp) {                                        // tables of the whole window for the step kernel (every rank walks every landmark)
+            std::vector<int> gl(L + 1, 0), gac(std::max(L, 1), -1), gfc(std::max(gp->n_vis, 1), 0);
+            for (int f = 0; f < gp->n_vis; ++f) gl[gp->vis_l[f] + 1]++;
+            for (int l = 0; l < L; ++l) gl[l + 1] += gl[l];
+            for (int f = gp->n_vis - 1; f >= 0; --f) { gac[gp->vis_l[f]] = 6 * gp->vis_i[f]; gfc[f] = 6 * gp->vis_j[f]; }
+            put(gl.data(), 4 * gl.size(), (void**)&P.glm_start); put(gac.data(), 4 * gac.size(), (void**)&P.glm_acol); put(gfc.data(), 4 * gfc.size(), (void**)&P.gfcol);
+            P.vis_f0 = vis_f0;
         }
         std::vector<int> vch;
         int l0 = 0;
@@ -512,22 +523,22 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     put(p->icp_ids, 16 * (size_t)p->n_icp, (void**)&P.icp_ids); put(p->icp_const, 80 * (size_t)p->n_icp, (void**)&P.icp_c);
     put(p->lps_ids, 8 * (size_t)p->n_lps, (void**)&P.lps_ids); put(p->lps_const, 56 * (size_t)p->n_lps, (void**)&P.lps_c);
     // systems + work space (zero-initialised)
-    size_t ar_off[2] = {0, 0};
-    for (int q = 0; q < 2; ++q) {
-        SysBuf& sb = P.sys[q];
-        ar_off[q] = put(nullptr, 8 * ((size_t)D * D + 3 * (size_t)D + 3), (void**)&sb.ar);   // [S | gred | bc | diag | cost | xn sn] contiguous: one all-reduce
-        put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&sb.hll); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&sb.bl); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&sb.invp);
-        put(nullptr, 8 * (size_t)13 * std::max(L, 1), (void**)&sb.eA); put(nullptr, 8 * (size_t)6 * std::max(p->n_vis, 1), (void**)&sb.eO);
-    }
-    put(nullptr, 8 * ((size_t)D * D + 3 * (size_t)D + 3), (void**)&P.arstage);
+    // one contiguous block per set: [S | gred | bc | diag | cost | 2 spare | hll | bl | invp | sl | eA | eO]
+    const size_t Lp = (size_t)std::max(L, 1), Fp = (size_t)std::max(gp ? gp->n_vis : p->n_vis, 1);
+    const size_t ar_cam = ((size_t)D * D + 3 * (size_t)D + 3 + 1) & ~size_t(1);
+    c->span = ar_cam + 4 * Lp + 13 * Lp + 6 * Fp;
+    for (int q = 0; q < 2; ++q) put(nullptr, 8 * c->span, (void**)&P.sys[q].ar);
+    put(nullptr, 8 * 8, (void**)&P.arstage);             // (unused: the sharded path all-reduces set 0 into set 1)
     put(nullptr, 8 * 16, (void**)&P.scal);
     put(L ? s->inv_depth : nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.lam0);
     P.rank = sharded ? c->rank : 0; P.world = sharded ? c->world : 1;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
     c->graphs.clear(); c->solves_since_upload = 0;
     c->sharded = sharded && c->world > 1;
+    // multi-GPU plumbing (set 0 = this rank's partial system, all-reduced into set 1, which the step kernel reads); VIL_FORCE_SPLIT
+    // runs it on a single rank (tests)
     c->split = c->sharded || getenv("VIL_FORCE_SPLIT") != nullptr;
-    P.split = c->split ? 1 : 0;
+    P.split = 0;
     put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.Sl); put(nullptr, 8 * (size_t)D, (void**)&P.Sc); put(nullptr, 8 * (size_t)D, (void**)&P.dc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.dl);
     put(nullptr, 8 * (size_t)D, (void**)&P.gradc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gradl); put(nullptr, 8 * (size_t)D, (void**)&P.gnc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gnl);
     { const size_t Tm = (size_t)(D + 16) / 16; put(nullptr, 8 * std::max((size_t)D * D, (size_t)TILE_SZ * (Tm * (Tm + 1) / 2)), (void**)&P.M); } put(nullptr, 8 * (size_t)D, (void**)&P.stepc); put(nullptr, 8 * 4 * 16, (void**)&P.hpart); put(nullptr, 4 * 16, (void**)&P.hflag);
@@ -568,6 +579,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     if (total > ar.cap) { if (ar.d) HIPCHK(hipFree(ar.d)); ar.d = nullptr; ar.cap = 0; HIPCHK(hipMalloc(&ar.d, total + total / 4)); ar.cap = total + total / 4; }
     for (const Fix& f : fix) *f.slot = ar.d + (f.scratch ? tables : 0) + f.off;
     if (dl) { P.pl_c = dl->plane_soa; P.pl_stride = dl->plane_stride; P.ed_c = dl->edge_soa; P.ed_stride = dl->edge_stride; }
+    if (!gp) { P.glm_start = P.lm_start; P.glm_acol = P.lm_acol; P.gfcol = P.fcol; }
     if (c->lidar_resident) { P.pl_c = c->d_pl; P.pl_stride = c->nslot * c->cap_p; P.ed_c = c->d_ed; P.ed_stride = c->nslot * c->cap_e; }
     {   // what vil_marginalize_resident will need (a few passes over int tables)
         vil_ctx::MargMeta& mm = c->mm;
@@ -583,7 +595,11 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             for (int f = 0; f < p->n_edge && !mm.lidar0; ++f) if (p->edge_pose[f] == 0) mm.lidar0 = true;
         }
     }
-    for (int q = 0; q < 2; ++q) { SysBuf& sb = P.sys[q]; sb.S = sb.ar; sb.gred = sb.S + (size_t)D * D; sb.bc = sb.gred + D; sb.diag = sb.bc + D; sb.cost = sb.diag + D; }
+    for (int q = 0; q < 2; ++q) {
+        SysBuf& sb = P.sys[q];
+        sb.S = sb.ar; sb.gred = sb.S + (size_t)D * D; sb.bc = sb.gred + D; sb.diag = sb.bc + D; sb.cost = sb.diag + D;
+        sb.hll = sb.ar + ar_cam; sb.bl = sb.hll + Lp; sb.invp = sb.bl + Lp; sb.sl = sb.invp + Lp; sb.eA = sb.sl + Lp; sb.eO = sb.eA + 13 * Lp;
+    }
     if (ar.hsize) {
         HIPCHK(hipMemcpyAsync(ar.d, ar.h, ar.hsize, hipMemcpyHostToDevice, c->stream));
         if (!c->up_ev) HIPCHK(hipEventCreateWithFlags(&c->up_ev, hipEventDisableTiming));
@@ -633,28 +649,20 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
         } else if (P.chain == 1) {
             HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
-            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
-            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
         } else {
             HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
-            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
-            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
         }
     } else {
     { const size_t T = (size_t)(D + 1 + 15) / 16; c->lds_step = 8 * TILE_SZ * (T * (T + 1) / 2); }   // 16x16-tiled (row stride 17) lower storage incl. the rhs row
     c->step_lds = c->lds_step + sizeof(vd::StepShared) + 256 <= 160 * 1024;
     if (c->step_lds) {
         HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
-        HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
-        HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
     } else {
         // tile array in global memory; LDS stages the active tile column of the factorisation (T tiles)
         const size_t T = (size_t)(D + 1 + 15) / 16;
         c->lds_step = 8 * (size_t)TILE_SZ * T;
         if (c->lds_step + sizeof(vd::StepShared) + 256 > 160 * 1024) return VIL_ERR_UNSUPPORTED;
         HIPCHK(hipFuncSetAttribute((const void*)k_step<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
-        HIPCHK(hipFuncSetAttribute((const void*)k_step<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
-        HIPCHK(hipFuncSetAttribute((const void*)k_step<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
     }
     }
     // one-time set-up: IMU sqrt-information, prior contraction
@@ -687,7 +695,7 @@ static int upload_sharded(vil_ctx* c, const vil_problem* p, const vil_state* s) 
     q.n_plane = pe - pb; q.plane_pose = p->plane_pose + pb; q.plane_const = p->plane_const + (size_t)pb * 7;
     if (c->rank != 0) { q.n_imu = 0; q.n_icp = 0; q.n_lps = 0; q.prior.n = 0; q.prior.nblk = 0; }
     c->lm_b = lb; c->lm_e = le;
-    st = comm_agree(c, upload_impl(c, &q, s, true));       // e.g. rank 0's IMU set-up failed: every rank reports it
+    st = comm_agree(c, upload_impl(c, &q, s, true, nullptr, p, f0));       // e.g. rank 0's IMU set-up failed: every rank reports it
     if (st != VIL_OK) c->uploaded = false;
     return st;
 }
@@ -709,7 +717,30 @@ __global__ void k_lam_apply(DevP P) {
     if (l < P.L) { const double v = P.lam0[l] + P.tmpl[l]; P.x[0][xo_lam(P) + l] = v; P.x[1][xo_lam(P) + l] = v; }
 }
 
-// sum over the ranks of the communicator, in stream order
+// sum over the ranks of the communicator, in stream order: recv = sum of every rank's send (recv may be send)
+static int all_reduce2(vil_ctx* c, const double* send, double* recv, size_t cnt) {
+    if (c->comm) return g_rccl.AllReduce(send, recv, cnt, ncclDouble, ncclSum, c->comm, c->stream) == ncclSuccess ? VIL_OK : VIL_ERR_COMM;
+    if (c->lcomm) {
+        LocalComm* lc = c->lcomm.get();
+        int st = VIL_OK;
+        const bool inplace = send == recv;
+        if (inplace && cnt > c->lc_cap) { if (c->lc_tmp) hipFree(c->lc_tmp); c->lc_tmp = nullptr; c->lc_cap = 0; if (hipMalloc(&c->lc_tmp, 8 * cnt) == hipSuccess) c->lc_cap = cnt; else st = VIL_ERR_DEVICE; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) st = VIL_ERR_DEVICE;
+        lc->ptr[c->rank] = const_cast<double*>(send);
+        st = lc->agree(c->rank, st);                          // all buffers are complete and published (or somebody failed)
+        if (st != VIL_OK) return st;
+        PeerPtrs pp; pp.n = lc->n;
+        for (int r = 0; r < 8; ++r) pp.p[r] = r < lc->n ? lc->ptr[r] : nullptr;
+        hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)std::min<size_t>(256, (cnt + 255) / 256)), dim3(256), 0, c->stream, inplace ? c->lc_tmp : recv, pp, cnt);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) st = VIL_ERR_DEVICE;
+        st = lc->agree(c->rank, st);                          // every rank has read every buffer
+        if (st != VIL_OK) return st;
+        if (inplace) HIPCHK(hipMemcpyAsync(recv, c->lc_tmp, 8 * cnt, hipMemcpyDeviceToDevice, c->stream));
+        return VIL_OK;
+    }
+    if (send != recv) HIPCHK(hipMemcpyAsync(recv, send, 8 * cnt, hipMemcpyDeviceToDevice, c->stream));     // a single rank (VIL_FORCE_SPLIT)
+    return VIL_OK;
+}
 static int all_reduce(vil_ctx* c, double* buf, size_t cnt) {
     if (c->comm) return g_rccl.AllReduce(buf, buf, cnt, ncclDouble, ncclSum, c->comm, c->stream) == ncclSuccess ? VIL_OK : VIL_ERR_COMM;
     if (c->lcomm) {
@@ -747,36 +778,35 @@ static int comm_agree(vil_ctx* c, int st) {
     return st;
 }
 
+// Multi-GPU: ONE collective per trust-region iteration.  Every rank sweeps its shard into set 0 -- the reduced camera
+// system of its factors plus the landmark arrays (h_ll, b_l, 1/pivot, scale, e_l) of the landmarks it owns, zeros elsewhere -- the
+// whole set is all-reduced into set 1, and every rank runs the complete single-GPU step kernel (helper workgroups, chain path)
+// on identical data: identical decisions, identical candidates, no second exchange.  view 0: what the sweep / gather write
+// (both buffer slots alias set 0: the partial system is consumed by the collective at once); view 1: what the step kernel reads.
+static DevP view(const vil_ctx* c, int which) {
+    DevP P = c->P;
+    if (c->split) { P.sys[0] = P.sys[1] = c->P.sys[which]; if (which == 1) { P.rank = 0; P.world = 1; } }
+    return P;
+}
 static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
-    hipLaunchKernelGGL(k_sweep, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, c->P, so);
+    hipLaunchKernelGGL(k_sweep, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, view(c, 0), so);
     return VIL_OK;
 }
 static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr) {
-    hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce), dim3(VIL_THREADS), 0, c->stream, c->P);
+    hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce), dim3(VIL_THREADS), 0, c->stream, view(c, 0));
     if (ev_mid) hipEventRecord(ev_mid, c->stream);
+    if (c->split) {                                    // the one collective of the iteration
+        const int st = all_reduce2(c, c->P.sys[0].ar, c->P.sys[1].ar, c->span);
+        if (st != VIL_OK) return st;
+    }
     if (!step) return VIL_OK;
-    auto launch_step = [&](int phase, int nwg) {
-        const dim3 g(nwg), b(VIL_STEP_THREADS);
-        #define VIL_STEP_LAUNCH(L, CH) do { \
-            if (phase == 0) hipLaunchKernelGGL((k_step<L, 0, CH>), g, b, c->lds_step, c->stream, c->P, so); \
-            else if (phase == 1) hipLaunchKernelGGL((k_step<L, 1, CH>), g, b, c->lds_step, c->stream, c->P, so); \
-            else hipLaunchKernelGGL((k_step<L, 2, CH>), g, b, c->lds_step, c->stream, c->P, so); } while (0)
-        if (c->P.chain == 3) hipLaunchKernelGGL((k_step<true, 0, 3>), g, b, c->lds_step, c->stream, c->P, so);
-        else if (c->P.chain == 1) VIL_STEP_LAUNCH(true, 1);
-        else if (c->P.chain == 2) VIL_STEP_LAUNCH(true, 2);
-        else if (c->step_lds) VIL_STEP_LAUNCH(true, 0);
-        else VIL_STEP_LAUNCH(false, 0);
-        #undef VIL_STEP_LAUNCH
-    };
-    if (!c->split) { launch_step(0, 1 + c->P.n_help); return VIL_OK; }
-    // multi-GPU: all-reduce the partial reduced system (+ step norms), step A, all-reduce 5 scalars, step B
-    const size_t cnt = (size_t)c->D * c->D + 3 * (size_t)c->D + 3;
-    int st = all_reduce(c, c->P.arstage, cnt);
-    if (st != VIL_OK) return st;
-    launch_step(1, 1);
-    st = all_reduce(c, c->P.scal, 9);
-    if (st != VIL_OK) return st;
-    launch_step(2, 1);
+    const DevP Ps = view(c, 1);
+    const dim3 g(1 + c->P.n_help), b(VIL_STEP_THREADS);
+    if (c->P.chain == 3) hipLaunchKernelGGL((k_step<true, 0, 3>), g, b, c->lds_step, c->stream, Ps, so);
+    else if (c->P.chain == 1) hipLaunchKernelGGL((k_step<true, 0, 1>), g, b, c->lds_step, c->stream, Ps, so);
+    else if (c->P.chain == 2) hipLaunchKernelGGL((k_step<true, 0, 2>), g, b, c->lds_step, c->stream, Ps, so);
+    else if (c->step_lds) hipLaunchKernelGGL((k_step<true, 0, 0>), g, b, c->lds_step, c->stream, Ps, so);
+    else hipLaunchKernelGGL((k_step<false, 0, 0>), g, b, c->lds_step, c->stream, Ps, so);
     return VIL_OK;
 }
 
@@ -824,7 +854,6 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     const SolveOpts so = to_dev_opts(o);
     int st = init_ctl(c, o, 0);
     if (st != VIL_OK) return st;
-    if (c->sharded && c->L) HIPCHK(hipMemcpyAsync(c->P.lam0, c->P.x[0] + 16 * c->K + 8, 8 * (size_t)c->L, hipMemcpyDeviceToDevice, c->stream));
     // every iteration = one sweep + one step kernel; `done` turns the tail into no-ops
     bool finished = false;
     // iterations are enqueued in chunks without host round trips; the first chunk is sized by the previous solve of
@@ -837,7 +866,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
         // ~2 % less inter-kernel gap.  The first solve of an upload launches directly -- capturing costs more than it saves.
         if (c->use_graph < 0) c->use_graph = getenv("VIL_GRAPH") ? atoi(getenv("VIL_GRAPH")) : 1;
         const int nthis = std::min(chunk, o->max_iterations + 9 - it);
-        if (c->use_graph && c->solves_since_upload > 0 && !c->profiling && !c->split && nthis > 0) {
+        if (c->use_graph && c->solves_since_upload > 0 && !c->profiling && !c->split && nthis > 0) {     // (the local communicator's host barriers cannot be captured)
             hipGraphExec_t exec = nullptr;
             for (auto& g : c->graphs) if (g.n == nthis && memcmp(&g.so, &so, sizeof so) == 0) exec = g.exec;
             if (!exec) {
@@ -890,12 +919,6 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     if (ctl.cur != 0) HIPCHK(hipMemcpyAsync(c->P.x[0], c->P.x[1], 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
     else HIPCHK(hipMemcpyAsync(c->P.x[1], c->P.x[0], 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
     if (c->gauge_on && finished && c->h_ctl->status == 0) hipLaunchKernelGGL(k_gauge_fix, dim3(1), dim3(64), 0, c->stream, c->P, c->d_x0);      // estimator.cpp:960-1011 before the read-back
-    if (c->sharded && c->L) {   // every rank updated only the landmarks it owns: merge the owners' changes
-        const int nb = (c->L + 255) / 256;
-        hipLaunchKernelGGL(k_lam_delta, dim3(nb), dim3(256), 0, c->stream, c->P, c->lm_b, c->lm_e);
-        if (all_reduce(c, c->P.tmpl, (size_t)c->L) != VIL_OK) return VIL_ERR_COMM;
-        hipLaunchKernelGGL(k_lam_apply, dim3(nb), dim3(256), 0, c->stream, c->P);
-    }
     HIPCHK(hipStreamSynchronize(c->stream));
     if (!finished) return VIL_ERR_DEVICE;
     if (ctl.status != 0) return ctl.status;
@@ -1032,11 +1055,7 @@ int vil_linearize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vi
     const size_t D = c->D;
     st = ensure_pin(c, 8 * (D * D + D + 1));
     if (st != VIL_OK) return st;
-    const double* src = c->split ? c->P.arstage : c->P.sys[1].ar;
-    if (c->sharded) {   // each rank linearised its shard: sum over ranks
-        if (all_reduce(c, c->P.arstage, D * D + 3 * D + 3) != VIL_OK) return VIL_ERR_COMM;
-        src = c->P.arstage;
-    }
+    const double* src = c->P.sys[1].ar;        // un-sharded: the candidate set (cur = 0); sharded: the all-reduced set
     HIPCHK(hipMemcpyAsync(c->h_pin, src, 8 * D * D, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_pin + D * D, src + D * D, 8 * D, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_pin + D * D + D, src + D * D + 3 * D, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1079,7 +1098,7 @@ static int marg_finish(vil_ctx* c, const int K, const bool old_, const int drop_
     auto take = [&](size_t b2) { char* r = dw + off; off += (b2 + 255) & ~size_t(255); return r; };
     MargDev M;
     M.D = D; M.nd = nd; M.n = n; M.eps = 1e-8;
-    M.S = c->split ? c->P.arstage : c->P.sys[1].S; M.g = M.S + (size_t)D * D;
+    M.S = c->P.sys[1].S; M.g = M.S + (size_t)D * D;
     int* d_drop = (int*)take(4 * (size_t)nd); int* d_keep = (int*)take(4 * (size_t)n);
     M.drop_cols = d_drop; M.keep_cols = d_keep;
     M.Add = (double*)take(8 * (size_t)nd * nd); M.Vd = (double*)take(8 * (size_t)nd * nd); M.wd = (double*)take(8 * (size_t)nd);
