@@ -29,7 +29,6 @@ struct SysBuf {       // one linearisation of the window (double-buffered: curre
 struct Ctl {          // trust-region state, lives in device memory, owned by the step kernel
     int gen;          // solve generation (host): with n_sweeps it forms the epoch of the helper-workgroup flags
     int cur, iter, done, term, first, resweep, reuse, nsucc, invalid_run, status, lin_mode, n_sweeps;
-    int phase_need, skip_b;       // split-step hand-off (multi-GPU: step A | all-reduce scalars | step B)
     int swe;                      // advanced by every live step-kernel launch: epoch of the sweep's workgroup flags (swflag)
     double radius, mu, cost_cur, model_change, alpha, dogleg_norm, initial_cost, cand_cost;
     double mu_used, gn2, g2, gg;   // dogleg scalars of the current linearisation (reused after a rejected step)
@@ -89,11 +88,7 @@ struct DevP {
     double* Sl; double* Sc; double* dc; double* dl; double* gradc; double* gradl; double* gnc; double* gnl;
     double* M; double* stepc; double* stepl; double* tmpc; double* tmpl;
     Ctl* ctl;
-    double* arstage;              // world > 1: k_reduce output / all-reduce buffer (D*D + 3D + 3), copied into sys[cand] by step A
-    double* scal;                 // 8 scalars exchanged between step A and step B (all-reduced when world > 1)
-    double* lam0;                 // L: landmark inverse depths at upload (for the final owner merge)
     int rank, world;              // data-parallel shard of the factor set
-    int split;                    // step kernel split around the scalar all-reduce (world > 1, or forced for single-GPU testing)
     long long* dbg;               // 64 cycle stamps (debug/profiling aid)
     // marginalisation of the RESIDENT window (vil_marginalize_resident): 1 = MARGIN_OLD -- only the factors touching frame 0 are live
     // (IMU (0,1), landmarks anchored in frame 0, LiDAR points of pose 0, the chosen ICP / LPS constraint, the prior), every block

@@ -680,8 +680,8 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
 
 }  // namespace vd
 
-// PHASE 0: whole step (single GPU).  PHASE 1 / 2: the step split around the all-reduce of the landmark-dependent
-// scalars (multi-GPU: every rank owns a slice of the landmarks).
+// The step kernel is the same on one GPU and on N: in the multi-GPU path the whole linear-system set has been all-reduced
+// before it starts (vilsolve.hip: view), so every rank runs it on identical data.
 // CHAIN 0: dense factorisation of all D columns (LDSM: tile array in LDS or global).  CHAIN 1 / 2: vil_chain.hpp, with W^T in
 // LDS / in global memory (tiles always in LDS).  CHAIN 3: the chain was eliminated by k_reduce's extra workgroup (vil_prechain.hpp).
 //
@@ -689,21 +689,21 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
 //   la = Sl gradient_l / dl  (Cauchy direction),  lb = Sl gn_l / dl  (Gauss-Newton direction)
 // and six sums (|gn_l|^2, gn_l . g_l, |la|^2, la . lb, |lb|^2, |lambda|^2); the candidate inverse depth lambda + cg la + cn lb is
 // formed by the NEXT sweep's visual workgroups from the two dogleg coefficients in Ctl, and its norm follows from the sums.
-// With helper workgroups (PHASE 0, grid = 1 + n_help) that pass runs on their CUs while the master back-substitutes the chain.
-template <bool LDSM, int PHASE, int CHAIN = 0>
+// With helper workgroups (grid = 1 + n_help) that pass runs on their CUs while the master back-substitutes the chain.
+template <bool LDSM, int CHAIN = 0>
 __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) {
     using namespace vd;
     __shared__ StepShared s;
     extern __shared__ double Alds[];
     const int t = threadIdx.x, NT = blockDim.x;
     const int D = P.D, L = P.L;
-    // PHASE 0 may be launched with 1 + P.n_help workgroups: the extra ones run the same judge on their own copy of Ctl and
+    // The grid is 1 + P.n_help workgroups: the extra ones run the same judge on their own copy of Ctl and
     // do the two landmark passes of their slice on their own CU (those passes are bound by what ONE CU can pull out of L2).
     // Flags (all compared with the launch epoch): hflag[k] -- helper k has read Ctl and published its pre-pass sums;
     // xflag -- the master has published Sc x_p (xstat = 1) or given up (xstat = 0); hflag2[k] -- helper k's second pass is done.
     // Only the master writes Ctl / the camera candidate, after every helper has signalled hflag.
-    const bool helper = PHASE == 0 && blockIdx.x > 0;
-    const int nhelp = (PHASE == 0) ? (int)gridDim.x - 1 : 0;
+    const bool helper = blockIdx.x > 0;
+    const int nhelp = (int)gridDim.x - 1;
     if (t == 0) { s.c = *P.ctl; s.c.swe++; s.need = 0; s.was_first = 0; s.ok = 1; }      // (every path that writes Ctl back carries the new swe)
     for (int q = t; q < 256; q += NT) {      // triangular tile index -> (tile row, tile col)
         int Ir = (int)((sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
@@ -722,38 +722,15 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     auto post = [&](int* f) { if (t == 0) { __threadfence(); __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); } };
     auto wait1 = [&](int* f) { while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1); };
     auto wait_helpers = [&]() { if (t == 0) for (int k = 0; k < nhelp; ++k) wait1(P.hflag + k); };     // master: every helper has read Ctl
-    const bool multi = P.split != 0;
-    const bool cam = P.world <= 1 || P.rank == 0;      // camera-side terms of global sums are counted once
+    const bool cam = true;             // (every rank holds the complete system: nothing is counted per rank any more)
     STAMP(0);
-    // PHASE 1: the all-reduced candidate system [S | gred | bc | diag | cost | xn sn] sits in the staging buffer and is
-    // consumed from there (it is read once, by the judge and by the fill of the tile matrix: no copy into the set)
-    const double* arblk = (PHASE == 1) ? P.arstage : nullptr;
-    if (PHASE == 2) {
-        if (s.c.skip_b) { if (t == 0) { s.c.skip_b = 0; *P.ctl = s.c; } return; }
-        if (t == 0 && s.c.phase_need) {
-            Ctl& c = s.c;
-            const double g2 = P.scal[0], q = P.scal[1], gm = P.scal[2];
-            if (gm <= O.gradient_tolerance) { c.done = 1; c.term = 2; }
-            c.alpha = g2 / q; c.mu_used = c.mu; c.gn2 = P.scal[3]; c.g2 = g2; c.gg = P.scal[4];
-            c.saa = P.scal[5]; c.sab = P.scal[6]; c.sbb = P.scal[7]; c.xnl = P.scal[8];
-            c.mu = fmax(O.min_mu, 2.0 * c.mu / 10.0);
-            c.phase_need = 0;
-        }
-        __syncthreads();
-        if (s.c.done) { if (t == 0) *P.ctl = s.c; return; }
-    }
     // ---------------- judge the candidate that the sweep just linearised -------------------------
-    if (PHASE != 2 && t == 0) {
+    if (t == 0) {
         Ctl& c = s.c;
         const int cand = 1 - c.cur;
-        const double cand_cost = (PHASE == 1) ? arblk[(size_t)P.D * P.D + 3 * P.D] : *P.sys[cand].cost;
+        const double cand_cost = *P.sys[cand].cost;
         c.cand_cost = cand_cost;
-        if (multi && !c.first && !c.resweep) {     // parameter tolerance of the step just evaluated (norms all-reduced with S)
-            const double* tail = ((PHASE == 1) ? arblk : P.sys[cand].ar) + (size_t)P.D * P.D + 3 * P.D + 1;
-            if (sqrt(tail[1]) <= O.parameter_tolerance * (sqrt(tail[0]) + O.parameter_tolerance)) { c.done = 1; c.term = 3; }
-        }
-        if (c.done) {}
-        else if (c.first || c.resweep) {
+        if (c.first || c.resweep) {
             if (c.first) { c.initial_cost = cand_cost; s.was_first = 1; }
             if (!isfinite(cand_cost)) { c.done = 1; c.term = 6; c.status = -3; }
             c.cur = cand; c.cost_cur = cand_cost; c.first = 0; c.resweep = 0; s.need = 1;
@@ -779,7 +756,6 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     __syncthreads();
     const int cur = s.c.cur;
     SysBuf sb = P.sys[cur];
-    if (PHASE == 1) { sb.S = P.arstage; sb.gred = sb.S + (size_t)D * D; sb.bc = sb.gred + D; sb.diag = sb.bc + D; }   // read only when the candidate was just accepted
     const double* x = P.x[cur];
     double* xc = P.x[1 - cur];
     // ---- the two landmark passes over [l0, l1) (helper: its slice; master without helpers: everything) -----------------------
@@ -812,7 +788,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                 sm[2] += a * a; sm[3] += a * b; sm[4] += b * b;
             }
             P.la[l] = a; P.lb[l] = b;
-            if (multi ? (ip != 0.0) : !(P.lm_const && P.lm_const[l])) { const double lam = x[xo_lam(P) + l]; sm[5] += lam * lam; }
+            if (!(P.lm_const && P.lm_const[l])) { const double lam = x[xo_lam(P) + l]; sm[5] += lam * lam; }
         }
     };
     if (helper) {
@@ -860,7 +836,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     };
     // prefetch this thread's share of S' (tiled order) so that the global latency hides behind the vector passes
     double pf[PF_N];
-    if (CHAIN == 0 && PHASE != 2 && s.need) {
+    if (CHAIN == 0 && s.need) {
         const int R = D + 1, T = (R + 15) >> 4, NTL = (tri_off(T)) << 8;
         const int half = __builtin_amdgcn_readfirstlane(t >> 8), w = t & 255;
         static_for<PF_N>([&](auto uc) {
@@ -877,7 +853,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     }
     STAMP(1);
     double gn2 = 0, g2 = 0, gg = 0;
-    if (PHASE != 2 && s.need) {
+    if (s.need) {
         // ---- camera vectors: Jacobi scaling (first linearisation), dogleg diagonal, gradient_, u = Sc gradient_/d
         double gm = 0;
         for (int i = t; i < D; i += NT) {
@@ -963,7 +939,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             __syncthreads();
         }
         STAMP(2);
-        if (PHASE == 0 && gm <= O.gradient_tolerance) {
+        if (gm <= O.gradient_tolerance) {
             if (!xpub) publish_xp(0);
             if (t == 0) { s.c.done = 1; s.c.term = 2; *P.ctl = s.c; }
             return;
@@ -980,7 +956,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                 Ctl& c = s.c;
                 c.mu *= 10.0;
                 if (!(c.mu < O.max_mu)) { c.iter++; c.invalid_run++; c.reuse = 0; if (c.invalid_run >= 5) { c.done = 1; c.term = 6; c.status = -4; } }
-                c.resweep = 1; c.cg = 0.0; c.cn = 0.0; c.skip_b = (PHASE == 1) ? 1 : 0;
+                c.resweep = 1; c.cg = 0.0; c.cn = 0.0;
             }
             for (int i = t; i < P.NS; i += NT) xc[i] = x[i];
             __syncthreads();
@@ -1018,14 +994,6 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             __syncthreads();
         }
         gn2 = sm[0]; gg = sm[1];
-        if (PHASE == 1) {
-            if (t == 0) {
-                P.scal[0] = g2; P.scal[1] = q; P.scal[2] = gm; P.scal[3] = gn2; P.scal[4] = gg;
-                P.scal[5] = sm[2]; P.scal[6] = sm[3]; P.scal[7] = sm[4]; P.scal[8] = sm[5];
-                s.c.phase_need = 1; *P.ctl = s.c;
-            }
-            return;
-        }
         if (t == 0) {
             Ctl& c = s.c;
             c.alpha = g2 / q; c.mu_used = c.mu; c.gn2 = gn2; c.g2 = g2; c.gg = gg;
@@ -1034,7 +1002,6 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         }
         __syncthreads();
     } else {
-        if (PHASE == 1) { if (t == 0) { for (int k = 0; k < 9; ++k) P.scal[k] = 0.0; s.c.phase_need = 0; *P.ctl = s.c; } return; }
         for (int i = t; i < D; i += NT) { s.sc[i] = P.Sc[i]; s.dcs[i] = P.dc[i]; s.gr[i] = P.gradc[i]; s.gn[i] = P.gnc[i]; }
         __syncthreads();
     }
@@ -1089,8 +1056,8 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     }
     double dummy2 = 0;
     bsum3(xn, sn, dummy2, s);
-    // landmark share of the norms from the sums of the pass (global sums after the all-reduce in the multi-GPU path: once)
-    if (!multi || cam) { xn += s.c.xnl; sn += cg * cg * s.c.saa + 2.0 * cg * cn * s.c.sab + cn * cn * s.c.sbb; }
+    // landmark share of the norms from the sums of the pass
+    xn += s.c.xnl; sn += cg * cg * s.c.saa + 2.0 * cg * cn * s.c.sab + cn * cn * s.c.sbb;
     STAMP(6);
     if (t == 0) {
         Ctl& c = s.c;
@@ -1106,8 +1073,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             c.mu *= 10.0; c.reuse = 0; c.resweep = 1; c.cg = 0.0; c.cn = 0.0;
         } else {
             c.invalid_run = 0;
-            if (!multi) { if (sqrt(sn) <= O.parameter_tolerance * (sqrt(xn) + O.parameter_tolerance)) { c.done = 1; c.term = 3; } }
-            else { double* tail = P.arstage + (size_t)D * D + 3 * D + 1; tail[0] = xn; tail[1] = sn; }   // judged after the next all-reduce
+            if (sqrt(sn) <= O.parameter_tolerance * (sqrt(xn) + O.parameter_tolerance)) { c.done = 1; c.term = 3; }
         }
     }
     __syncthreads();

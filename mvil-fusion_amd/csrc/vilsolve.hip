@@ -528,9 +528,6 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     const size_t ar_cam = ((size_t)D * D + 3 * (size_t)D + 3 + 1) & ~size_t(1);
     c->span = ar_cam + 4 * Lp + 13 * Lp + 6 * Fp;
     for (int q = 0; q < 2; ++q) put(nullptr, 8 * c->span, (void**)&P.sys[q].ar);
-    put(nullptr, 8 * 8, (void**)&P.arstage);             // (unused: the sharded path all-reduces set 0 into set 1)
-    put(nullptr, 8 * 16, (void**)&P.scal);
-    put(L ? s->inv_depth : nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.lam0);
     P.rank = sharded ? c->rank : 0; P.world = sharded ? c->world : 1;
     for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
     c->graphs.clear(); c->solves_since_upload = 0;
@@ -538,7 +535,6 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     // multi-GPU plumbing (set 0 = this rank's partial system, all-reduced into set 1, which the step kernel reads); VIL_FORCE_SPLIT
     // runs it on a single rank (tests)
     c->split = c->sharded || getenv("VIL_FORCE_SPLIT") != nullptr;
-    P.split = 0;
     put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.Sl); put(nullptr, 8 * (size_t)D, (void**)&P.Sc); put(nullptr, 8 * (size_t)D, (void**)&P.dc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.dl);
     put(nullptr, 8 * (size_t)D, (void**)&P.gradc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gradl); put(nullptr, 8 * (size_t)D, (void**)&P.gnc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gnl);
     { const size_t Tm = (size_t)(D + 16) / 16; put(nullptr, 8 * std::max((size_t)D * D, (size_t)TILE_SZ * (Tm * (Tm + 1) / 2)), (void**)&P.M); } put(nullptr, 8 * (size_t)D, (void**)&P.stepc); put(nullptr, 8 * 4 * 16, (void**)&P.hpart); put(nullptr, 4 * 16, (void**)&P.hflag);
@@ -646,11 +642,11 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     if (P.chain) {
         c->step_lds = true;
         if (P.chain == 3) {
-            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
         } else if (P.chain == 1) {
-            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
         } else {
-            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
         }
     } else {
     { const size_t T = (size_t)(D + 1 + 15) / 16; c->lds_step = 8 * TILE_SZ * (T * (T + 1) / 2); }   // 16x16-tiled (row stride 17) lower storage incl. the rhs row
@@ -706,15 +702,6 @@ int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
                                                            : upload_impl(c, p, s, false);
     if (st == VIL_OK) c->resident_kind = 1;
     return st;
-}
-
-__global__ void k_lam_delta(DevP P, int lb, int le) {      // owner's change of the inverse depths, zero elsewhere
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < P.L) P.tmpl[l] = (l >= lb && l < le) ? P.x[0][xo_lam(P) + l] - P.lam0[l] : 0.0;
-}
-__global__ void k_lam_apply(DevP P) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < P.L) { const double v = P.lam0[l] + P.tmpl[l]; P.x[0][xo_lam(P) + l] = v; P.x[1][xo_lam(P) + l] = v; }
 }
 
 // sum over the ranks of the communicator, in stream order: recv = sum of every rank's send (recv may be send)
@@ -802,11 +789,11 @@ static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEve
     if (!step) return VIL_OK;
     const DevP Ps = view(c, 1);
     const dim3 g(1 + c->P.n_help), b(VIL_STEP_THREADS);
-    if (c->P.chain == 3) hipLaunchKernelGGL((k_step<true, 0, 3>), g, b, c->lds_step, c->stream, Ps, so);
-    else if (c->P.chain == 1) hipLaunchKernelGGL((k_step<true, 0, 1>), g, b, c->lds_step, c->stream, Ps, so);
-    else if (c->P.chain == 2) hipLaunchKernelGGL((k_step<true, 0, 2>), g, b, c->lds_step, c->stream, Ps, so);
-    else if (c->step_lds) hipLaunchKernelGGL((k_step<true, 0, 0>), g, b, c->lds_step, c->stream, Ps, so);
-    else hipLaunchKernelGGL((k_step<false, 0, 0>), g, b, c->lds_step, c->stream, Ps, so);
+    if (c->P.chain == 3) hipLaunchKernelGGL((k_step<true, 3>), g, b, c->lds_step, c->stream, Ps, so);
+    else if (c->P.chain == 1) hipLaunchKernelGGL((k_step<true, 1>), g, b, c->lds_step, c->stream, Ps, so);
+    else if (c->P.chain == 2) hipLaunchKernelGGL((k_step<true, 2>), g, b, c->lds_step, c->stream, Ps, so);
+    else if (c->step_lds) hipLaunchKernelGGL((k_step<true, 0>), g, b, c->lds_step, c->stream, Ps, so);
+    else hipLaunchKernelGGL((k_step<false, 0>), g, b, c->lds_step, c->stream, Ps, so);
     return VIL_OK;
 }
 
