@@ -67,14 +67,10 @@ __device__ __forceinline__ void block_fold(double* v, double* part /* gridDim.x 
     if (threadIdx.x < NV) part[(size_t)blockIdx.x * NV + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
-// FastVGICP::update_correspondences + linearize (fast_vgicp_impl.hpp:73-170), one thread per (source point, offset)
-__global__ __launch_bounds__(VG_THREADS) void k_vgicp_lin(int n, int noff, const float* __restrict__ sxyz, const double* __restrict__ scov, Iso T, double res, VoxTab V,
-                                                          int* __restrict__ c_vox, double* __restrict__ c_M, double* __restrict__ part, int want_H) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    double acc[29];                                   // 21 H (upper) | 6 b | error | number of correspondences
-#pragma unroll
-    for (int q = 0; q < 29; ++q) acc[q] = 0.0;
-    if (tid < n * noff) {
+// FastVGICP::update_correspondences + linearize (fast_vgicp_impl.hpp:73-170) for ONE (source point, offset) slot: the
+// correspondence (voxel id + Mahalanobis matrix) is stored, the 29 sums are ADDED to acc (21 H upper | 6 b | error | count)
+__device__ __forceinline__ void vgicp_lin_slot(int tid, int noff, const float* __restrict__ sxyz, const double* __restrict__ scov, const Iso& T, double res, const VoxTab& V,
+                                               int* __restrict__ c_vox, double* __restrict__ c_M, double* acc, int want_H) {
         const int i = tid / noff, o = tid - i * noff;
         const double ax = (double)sxyz[3 * i], ay = (double)sxyz[3 * i + 1], az = (double)sxyz[3 * i + 2];
         const double tx = T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3];
@@ -109,7 +105,7 @@ __global__ __launch_bounds__(VG_THREADS) void k_vgicp_lin(int n, int noff, const
             const double e0 = V.mean[(size_t)3 * v] - tx, e1 = V.mean[(size_t)3 * v + 1] - ty, e2 = V.mean[(size_t)3 * v + 2] - tz;
             const double w = sqrt((double)V.num[v]);
             const double m0 = M[0] * e0 + M[1] * e1 + M[2] * e2, m1 = M[3] * e0 + M[4] * e1 + M[5] * e2, m2 = M[6] * e0 + M[7] * e1 + M[8] * e2;
-            acc[27] = w * (e0 * m0 + e1 * m1 + e2 * m2); acc[28] = 1.0;
+            acc[27] += w * (e0 * m0 + e1 * m1 + e2 * m2); acc[28] += 1.0;
             if (want_H) {
                 // J = [skew(ta) | -I] ; H += w J^T M J (upper triangle, 21 values) ; b += w J^T M e
                 const double J[18] = {0.0, -tz, ty, -1.0, 0.0, 0.0, tz, 0.0, -tx, 0.0, -1.0, 0.0, -ty, tx, 0.0, 0.0, 0.0, -1.0};
@@ -122,32 +118,41 @@ __global__ __launch_bounds__(VG_THREADS) void k_vgicp_lin(int n, int noff, const
 #pragma unroll
                 for (int p = 0; p < 6; ++p) {
 #pragma unroll
-                    for (int q = p; q < 6; ++q) acc[idx++] = w * (J[p] * MJ[q] + J[6 + p] * MJ[6 + q] + J[12 + p] * MJ[12 + q]);
-                    acc[21 + p] = w * (J[p] * m0 + J[6 + p] * m1 + J[12 + p] * m2);
+                    for (int q = p; q < 6; ++q) acc[idx++] += w * (J[p] * MJ[q] + J[6 + p] * MJ[6 + q] + J[12 + p] * MJ[12 + q]);
+                    acc[21 + p] += w * (J[p] * m0 + J[6 + p] * m1 + J[12 + p] * m2);
                 }
             }
         }
-    }
+}
+
+// one thread per (source point, offset)
+__global__ __launch_bounds__(VG_THREADS) void k_vgicp_lin(int n, int noff, const float* __restrict__ sxyz, const double* __restrict__ scov, Iso T, double res, VoxTab V,
+                                                          int* __restrict__ c_vox, double* __restrict__ c_M, double* __restrict__ part, int want_H) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[29];                                   // 21 H (upper) | 6 b | error | number of correspondences
+#pragma unroll
+    for (int q = 0; q < 29; ++q) acc[q] = 0.0;
+    if (tid < n * noff) vgicp_lin_slot(tid, noff, sxyz, scov, T, res, V, c_vox, c_M, acc, want_H);
     block_fold<29>(acc, part);
 }
 
 // FastVGICP::compute_error (fast_vgicp_impl.hpp:173-196): stored correspondences and Mahalanobis matrices, new transform
+__device__ __forceinline__ double vgicp_err_slot(int tid, int noff, const float* __restrict__ sxyz, const Iso& T, const VoxTab& V, const int* __restrict__ c_vox, const double* __restrict__ c_M) {
+    const int v = c_vox[tid];
+    if (v < 0) return 0.0;
+    const int i = tid / noff;
+    const double ax = (double)sxyz[3 * i], ay = (double)sxyz[3 * i + 1], az = (double)sxyz[3 * i + 2];
+    const double e0 = V.mean[(size_t)3 * v] - (T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3]);
+    const double e1 = V.mean[(size_t)3 * v + 1] - (T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7]);
+    const double e2 = V.mean[(size_t)3 * v + 2] - (T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11]);
+    const double* M = c_M + (size_t)9 * tid;
+    const double m0 = M[0] * e0 + M[1] * e1 + M[2] * e2, m1 = M[3] * e0 + M[4] * e1 + M[5] * e2, m2 = M[6] * e0 + M[7] * e1 + M[8] * e2;
+    return sqrt((double)V.num[v]) * (e0 * m0 + e1 * m1 + e2 * m2);
+}
 __global__ __launch_bounds__(VG_THREADS) void k_vgicp_err(int ncorr_slots, int noff, const float* __restrict__ sxyz, Iso T, VoxTab V, const int* __restrict__ c_vox, const double* __restrict__ c_M, double* __restrict__ part) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     double acc[1] = {0.0};
-    if (tid < ncorr_slots) {
-        const int v = c_vox[tid];
-        if (v >= 0) {
-            const int i = tid / noff;
-            const double ax = (double)sxyz[3 * i], ay = (double)sxyz[3 * i + 1], az = (double)sxyz[3 * i + 2];
-            const double e0 = V.mean[(size_t)3 * v] - (T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3]);
-            const double e1 = V.mean[(size_t)3 * v + 1] - (T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7]);
-            const double e2 = V.mean[(size_t)3 * v + 2] - (T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11]);
-            const double* M = c_M + (size_t)9 * tid;
-            const double m0 = M[0] * e0 + M[1] * e1 + M[2] * e2, m1 = M[3] * e0 + M[4] * e1 + M[5] * e2, m2 = M[6] * e0 + M[7] * e1 + M[8] * e2;
-            acc[0] = sqrt((double)V.num[v]) * (e0 * m0 + e1 * m1 + e2 * m2);
-        }
-    }
+    if (tid < ncorr_slots) acc[0] = vgicp_err_slot(tid, noff, sxyz, T, V, c_vox, c_M);
     block_fold<1>(acc, part);
 }
 
@@ -271,6 +276,7 @@ struct vgicp_ctx {
     double* d_part = nullptr; int part_cap = 0; double* d_out = nullptr; double* h_out = nullptr;
     bool linearized = false;
     bool profiling = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; long long prof_n = 0; double prof_ms = 0.0;
+    void* d_coop = nullptr; void* d_aout = nullptr; void* h_aout = nullptr; int coop_epoch = 0;       // one-launch alignment (k_vgicp_align)
     // neighbour search of the covariance estimation
     vknn::GridBuild gb; float grid_h = 1.0f; int* d_nn = nullptr; size_t nn_cap = 0;
 };
@@ -333,6 +339,7 @@ void vgicp_destroy(vgicp_ctx* c) {
     free_target(c); free_source(c);
     hipFree(c->d_cvox); hipFree(c->d_cM); hipFree(c->d_part); hipFree(c->d_out); if (c->h_out) hipHostFree(c->h_out);
     hipFree(c->gb.ws); hipFree(c->d_nn);
+    if (c->d_coop) hipFree(c->d_coop); if (c->d_aout) hipFree(c->d_aout); if (c->h_aout) hipHostFree(c->h_aout);
     if (c->ev0) { hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -443,13 +450,13 @@ int vgicp_compute_error(vgicp_ctx* c, const double* T, double* err) {
 }
 
 // ---- host side of LsqRegistration (lsq_registration_impl.hpp:48-165): 6 x 6 algebra between device reductions --------------
-static bool solve6(const double* A, const double* rhs, double* x) {
+__host__ __device__ static bool solve6(const double* A, const double* rhs, double* x) {
     double L[36] = {0};
     for (int j = 0; j < 6; ++j) {
         double d = A[6 * j + j];
         for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k];
         if (!(d > 0.0)) return false;
-        L[6 * j + j] = std::sqrt(d);
+        L[6 * j + j] = sqrt(d);
         for (int i = j + 1; i < 6; ++i) { double s = A[6 * i + j]; for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k]; L[6 * i + j] = s / L[6 * j + j]; }
     }
     double y[6];
@@ -457,16 +464,16 @@ static bool solve6(const double* A, const double* rhs, double* x) {
     for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k]; x[i] = s / L[6 * i + i]; }
     return true;
 }
-static void so3_exp_R(const double* w, double* R) {      // so3.hpp:53-77, then Quaternion::toRotationMatrix
+__host__ __device__ static void so3_exp_R(const double* w, double* R) {      // so3.hpp:53-77, then Quaternion::toRotationMatrix
     const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
     double im, re;
     if (t2 < 1e-10) { const double t4 = t2 * t2; im = 0.5 - 1.0 / 48.0 * t2 + 1.0 / 3840.0 * t4; re = 1.0 - 1.0 / 8.0 * t2 + 1.0 / 384.0 * t4; }
-    else { const double t = std::sqrt(t2), h = 0.5 * t; im = std::sin(h) / t; re = std::cos(h); }
+    else { const double t = sqrt(t2), h = 0.5 * t; im = sin(h) / t; re = cos(h); }
     const double qw = re, qx = im * w[0], qy = im * w[1], qz = im * w[2];
     const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz, twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
     R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy; R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx; R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
 }
-static void compose(const double* d, const double* x0, double* xi) {
+__host__ __device__ static void compose(const double* d, const double* x0, double* xi) {
     double R[9]; so3_exp_R(d, R);
     for (int r = 0; r < 3; ++r) {
         for (int q = 0; q < 4; ++q) xi[4 * r + q] = R[3 * r] * x0[q] + R[3 * r + 1] * x0[4 + q] + R[3 * r + 2] * x0[8 + q];
@@ -474,16 +481,199 @@ static void compose(const double* d, const double* x0, double* xi) {
     }
     xi[12] = 0; xi[13] = 0; xi[14] = 0; xi[15] = 1;
 }
-static bool is_converged(const double* d, double reps, double teps) {
+// the same two with the increment's rotation matrix shared (the device loop calls both on the same d: one sin / cos less per pass)
+__device__ static void compose_R(const double* d, const double* x0, double* xi, double* R) {
+    so3_exp_R(d, R);
+    for (int r = 0; r < 3; ++r) {
+        for (int q = 0; q < 4; ++q) xi[4 * r + q] = R[3 * r] * x0[q] + R[3 * r + 1] * x0[4 + q] + R[3 * r + 2] * x0[8 + q];
+        xi[4 * r + 3] += d[3 + r];
+    }
+    xi[12] = 0; xi[13] = 0; xi[14] = 0; xi[15] = 1;
+}
+__device__ static bool converged_R(const double* R, const double* d, double reps, double teps) {
+    double m = 0;
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) m = fmax(m, fabs(R[3 * r + q] - (r == q ? 1.0 : 0.0)) / reps);
+    for (int r = 0; r < 3; ++r) m = fmax(m, fabs(d[3 + r]) / teps);
+    return m < 1;
+}
+__host__ __device__ static bool is_converged(const double* d, double reps, double teps) {
     double R[9]; so3_exp_R(d, R);
     double m = 0;
-    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) m = std::fmax(m, std::fabs(R[3 * r + q] - (r == q ? 1.0 : 0.0)) / reps);
-    for (int r = 0; r < 3; ++r) m = std::fmax(m, std::fabs(d[3 + r]) / teps);
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) m = fmax(m, fabs(R[3 * r + q] - (r == q ? 1.0 : 0.0)) / reps);
+    for (int r = 0; r < 3; ++r) m = fmax(m, fabs(d[3 + r]) / teps);
     return m < 1;
 }
 
+}  // extern "C"
+
+// ---- the whole LsqRegistration::align loop (lsq_registration_impl.hpp:48-165) in ONE launch ------------------------------------
+// G resident workgroups share the slots; every pass (a linearisation at x0, or the error of a trial transform with the stored
+// correspondences) ends in a symmetric exchange: each workgroup publishes its partial sums + an epoch flag, waits for all
+// flags, adds all partials in workgroup order -- the same bits everywhere -- and its thread 0 advances the same Levenberg-
+// Marquardt / Gauss-Newton state machine on them.  Identical code on identical numbers: every workgroup arrives at the same
+// next transform, so a pass costs one exchange and the host sees one launch and one 0.5 kB read-back per alignment.
+#define VG_MAXG 64
+struct VgCoop { int flag[VG_MAXG]; double part[2][VG_MAXG][32]; };
+struct VgAlignOut { double T[16]; double H[36]; double err; int iterations, converged, n_corr, lm_failed, status, pad; };
+struct VgLm {                          // state of the optimiser (thread 0 of every workgroup)
+    double x0[16], xi[16], H[36], Hout[36], b[6], d[6], Rd[9];      // Rd: rotation of the current increment d
+    double lambda, nu, y0;
+    int it, inner, converged, lm_failed, n_corr, phase;     // phase 1: linearise at x0, 2: error at xi
+};
+// consumes the sums of the pass just exchanged, returns the next pass (0 = finished); mirrors the host loop statement by statement
+__device__ static int vg_lm_advance(VgLm& L, const double* tot, const vgicp_options& o) {
+    if (L.phase == 1) {
+        int idx = 0;
+        for (int p = 0; p < 6; ++p) { for (int q = p; q < 6; ++q) { L.H[6 * p + q] = tot[idx]; L.H[6 * q + p] = tot[idx]; ++idx; } L.b[p] = tot[21 + p]; }
+        L.y0 = tot[27]; L.n_corr = (int)tot[28];
+        double nb[6];
+        for (int k = 0; k < 6; ++k) { nb[k] = -L.b[k]; L.d[k] = 0.0; }
+        if (o.optimizer == VGICP_GN) {
+            if (!solve6(L.H, nb, L.d)) { L.lm_failed = 1; return 0; }
+            compose_R(L.d, L.x0, L.xi, L.Rd);
+            for (int k = 0; k < 16; ++k) L.x0[k] = L.xi[k];
+            for (int k = 0; k < 36; ++k) L.Hout[k] = L.H[k];
+            ++L.it;
+            L.converged = converged_R(L.Rd, L.d, o.rotation_epsilon, o.transformation_epsilon) ? 1 : 0;
+            return (L.converged || L.it >= o.max_iterations) ? 0 : 1;
+        }
+        if (L.lambda < 0.0) { double m = 0; for (int k = 0; k < 6; ++k) m = fmax(m, fabs(L.H[7 * k])); L.lambda = o.lm_init_lambda_factor * m; }
+        L.nu = 2.0; L.inner = 0;
+    } else {
+        // trial step evaluated: accept / reject (step_lm)
+        const double yi = tot[0];
+        double den = 0; for (int k = 0; k < 6; ++k) den += L.d[k] * (L.lambda * L.d[k] - L.b[k]);
+        const double rho = (L.y0 - yi) / den;
+        bool stepped = false;
+        if (rho < 0) {
+            if (converged_R(L.Rd, L.d, o.rotation_epsilon, o.transformation_epsilon)) stepped = true;
+            else { L.lambda = L.nu * L.lambda; L.nu = 2 * L.nu; ++L.inner; }
+        } else {
+            for (int k = 0; k < 16; ++k) L.x0[k] = L.xi[k];
+            const double c3 = 2 * rho - 1;
+            L.lambda = L.lambda * fmax(1.0 / 3.0, 1 - c3 * c3 * c3);
+            for (int k = 0; k < 36; ++k) L.Hout[k] = L.H[k];
+            stepped = true;
+        }
+        if (stepped) {
+            ++L.it;
+            L.converged = converged_R(L.Rd, L.d, o.rotation_epsilon, o.transformation_epsilon) ? 1 : 0;
+            if (L.converged || L.it >= o.max_iterations) return 0;
+            L.phase = 1; return 1;
+        }
+    }
+    // next trial of the inner loop: damped solve until one succeeds or the budget is spent
+    double nb[6]; for (int k = 0; k < 6; ++k) nb[k] = -L.b[k];
+    for (; L.inner < o.lm_max_iterations; ++L.inner) {
+        double Hl[36]; for (int k = 0; k < 36; ++k) Hl[k] = L.H[k];
+        for (int k = 0; k < 6; ++k) Hl[7 * k] += L.lambda;
+        if (!solve6(Hl, nb, L.d)) { L.lambda = L.nu * L.lambda; L.nu = 2 * L.nu; continue; }
+        compose_R(L.d, L.x0, L.xi, L.Rd);
+        L.phase = 2; return 2;
+    }
+    L.lm_failed = 1; ++L.it;                              // "lm not converged!!"
+    return 0;
+}
+
+__global__ __launch_bounds__(VG_THREADS) void k_vgicp_align(int n, int noff, const float* __restrict__ sxyz, const double* __restrict__ scov, double res, VoxTab V,
+                                                            int* __restrict__ c_vox, double* __restrict__ c_M, vgicp_options o, VgCoop* coop, int epoch, VgAlignOut* out) {
+    __shared__ VgLm L;
+    __shared__ double mine[4][29], gath[VG_MAXG][29 + 1], tot[32];
+    __shared__ Iso Tsh; __shared__ int action;
+    const int t = threadIdx.x, g = blockIdx.x, G = gridDim.x, slots = n * noff;
+    if (t == 0) {
+        for (int k = 0; k < 16; ++k) L.x0[k] = out->T[k];             // the guess arrives in the output record
+        for (int k = 0; k < 36; ++k) L.Hout[k] = (k % 7 == 0) ? 1.0 : 0.0;
+        L.lambda = -1.0; L.nu = 2.0; L.y0 = 0.0; L.it = 0; L.inner = 0; L.converged = 0; L.lm_failed = 0; L.n_corr = 0; L.phase = 1;
+        for (int q = 0; q < 12; ++q) Tsh.m[q] = L.x0[q];
+        action = o.max_iterations > 0 ? 1 : 0;
+    }
+    __syncthreads();
+    while (action) {
+        ++epoch;
+        const int nv = action == 1 ? 29 : 1;
+        const Iso T = Tsh;
+        double acc[29];
+#pragma unroll
+        for (int q = 0; q < 29; ++q) acc[q] = 0.0;
+        if (action == 1) { for (int tid = g * VG_THREADS + t; tid < slots; tid += G * VG_THREADS) vgicp_lin_slot(tid, noff, sxyz, scov, T, res, V, c_vox, c_M, acc, 1); }
+        else { for (int tid = g * VG_THREADS + t; tid < slots; tid += G * VG_THREADS) acc[0] += vgicp_err_slot(tid, noff, sxyz, T, V, c_vox, c_M); }
+        {   // workgroup fold (as block_fold), result in mine
+            const int lane = t & 63, wave = t >> 6;
+            if (action == 1) {
+                double f0, f1;
+                vd::wave_fold<29>(acc, f0, f1);
+                if (lane < 16) { const int q = vd::fold_slot(lane); if (q < 29) mine[wave][q] = f0; if (q + 16 < 29) mine[wave][q + 16] = f1; }
+            } else { const double v = wave_sum64(acc[0]); if (lane == 0) mine[wave][0] = v; }
+        }
+        __syncthreads();
+        double (*part)[32] = coop->part[epoch & 1];
+        if (t < nv) __hip_atomic_store(&part[g][t], (mine[0][t] + mine[1][t]) + (mine[2][t] + mine[3][t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (t == 0) { __threadfence(); __hip_atomic_store(&coop->flag[g], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        if (t < G) while (__hip_atomic_load(&coop->flag[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+        {   // <= 29 x 64 values: every load issued before the first use (the gather is bound by L2 round trips)
+            constexpr int NLD = (29 * VG_MAXG + VG_THREADS - 1) / VG_THREADS;
+            double gv[NLD];
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) { const int e = t + u * VG_THREADS, w = e / nv, q = e - w * nv; gv[u] = e < G * nv ? __hip_atomic_load(&part[w][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) { const int e = t + u * VG_THREADS, w = e / nv, q = e - w * nv; if (e < G * nv) gath[w][q] = gv[u]; }
+        }
+        __syncthreads();
+        if (t < nv) { double sacc = 0.0; for (int w = 0; w < G; ++w) sacc += gath[w][t]; tot[t] = sacc; }
+        __syncthreads();
+        if (t == 0) {
+            int a = 0;
+            if (!isfinite(tot[action == 1 ? 27 : 0])) { L.lm_failed = -1; a = 0; }      // non-finite error: stop, the host reports it
+            else a = vg_lm_advance(L, tot, o);
+            if (a == 1) for (int q = 0; q < 12; ++q) Tsh.m[q] = L.x0[q];
+            if (a == 2) for (int q = 0; q < 12; ++q) Tsh.m[q] = L.xi[q];
+            action = a;
+        }
+        __syncthreads();
+    }
+    if (g == 0 && t == 0) {
+        for (int k = 0; k < 16; ++k) out->T[k] = L.x0[k];
+        for (int k = 0; k < 36; ++k) out->H[k] = L.Hout[k];
+        out->err = L.y0; out->iterations = L.it; out->converged = L.converged; out->n_corr = L.n_corr;
+        out->lm_failed = L.lm_failed > 0 ? 1 : 0; out->status = L.lm_failed < 0 ? VG_ERR_NONFINITE : VG_OK;
+    }
+}
+
+extern "C" {
+
+static int vgicp_align_host(vgicp_ctx* c, const double* guess, const vgicp_options* o, double* T_out, vgicp_summary* out);
+
 int vgicp_align(vgicp_ctx* c, const double* guess, const vgicp_options* o, double* T_out, vgicp_summary* out) {
     if (!c || !guess || !o || !T_out || !out) return VG_ERR_INVALID;
+    if (!c->nvox || !c->n || (o->neighbor_mode != VGICP_DIRECT1 && o->neighbor_mode != VGICP_DIRECT7 && o->neighbor_mode != VGICP_DIRECT27)) return VG_ERR_INVALID;
+    if (getenv("VGICP_HOST_LOOP")) return vgicp_align_host(c, guess, o, T_out, out);       // the step logic on the host between launches (cross-check)
+    VGCHK(hipSetDevice(c->device));
+    const int mode = o->neighbor_mode, slots = c->n * mode, nblk = (slots + VG_THREADS - 1) / VG_THREADS;
+    if (slots > c->slots_cap) { hipFree(c->d_cvox); hipFree(c->d_cM); c->d_cvox = nullptr; c->d_cM = nullptr; c->slots_cap = 0; VGCHK(hipMalloc(&c->d_cvox, 4 * (size_t)slots)); VGCHK(hipMalloc(&c->d_cM, 8 * 9 * (size_t)slots)); c->slots_cap = slots; }
+    if (!c->d_coop) { VGCHK(hipMalloc(&c->d_coop, sizeof(VgCoop))); VGCHK(hipMemsetAsync(c->d_coop, 0, sizeof(VgCoop), c->stream)); VGCHK(hipMalloc(&c->d_aout, sizeof(VgAlignOut))); VGCHK(hipHostMalloc(&c->h_aout, sizeof(VgAlignOut), hipHostMallocDefault)); c->coop_epoch = 0; }
+    VgAlignOut* ho = (VgAlignOut*)c->h_aout;
+    std::memcpy(ho->T, guess, sizeof ho->T);
+    VGCHK(hipMemcpyAsync(c->d_aout, ho, sizeof(VgAlignOut), hipMemcpyHostToDevice, c->stream));
+    int G = std::min(nblk, std::min(VG_MAXG, std::max(32, nblk / 8)));     // (measured on the 16-ring pair: 16 -> 7.7 k, 32 -> 9.4 k, 64 -> 9.2 k alignments/s) all workgroups resident: they wait for each other; the exchange costs O(G)
+    if (const char* ev = getenv("VGICP_G")) G = std::max(1, std::min(VG_MAXG, atoi(ev)));
+    hipLaunchKernelGGL(k_vgicp_align, dim3(G), dim3(VG_THREADS), 0, c->stream, c->n, mode, c->d_sxyz, c->d_scov, c->res, tab(c), c->d_cvox, c->d_cM, *o, (VgCoop*)c->d_coop, c->coop_epoch, (VgAlignOut*)c->d_aout);
+    c->coop_epoch += 4 * (o->max_iterations * (o->lm_max_iterations + 1) + 4);      // epochs only grow: nothing to reset between calls
+    if (c->coop_epoch > (1 << 30)) { VGCHK(hipMemsetAsync(c->d_coop, 0, sizeof(VgCoop), c->stream)); c->coop_epoch = 0; }
+    VGCHK(hipMemcpyAsync(ho, c->d_aout, sizeof(VgAlignOut), hipMemcpyDeviceToHost, c->stream));
+    VGCHK(hipStreamSynchronize(c->stream));
+    VGCHK(hipGetLastError());
+    c->noff = mode; c->slots = slots; c->linearized = true;
+    std::memset(out, 0, sizeof *out);
+    out->iterations = ho->iterations; out->converged = ho->converged; out->n_correspondences = ho->n_corr; out->lm_failed = ho->lm_failed; out->final_error = ho->err;
+    std::memcpy(out->final_hessian, ho->H, sizeof ho->H);
+    std::memcpy(T_out, ho->T, sizeof ho->T);
+    return ho->status;
+}
+
+static int vgicp_align_host(vgicp_ctx* c, const double* guess, const vgicp_options* o, double* T_out, vgicp_summary* out) {
     double x0[16]; std::memcpy(x0, guess, sizeof x0);
     double lambda = -1.0;
     bool converged = false;
