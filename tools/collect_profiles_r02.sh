@@ -1,0 +1,30 @@
+# Round-2 evidence (one gpurun call): bench line, rocprofv3 --kernel-trace --stats of the same command for configs[1], [2], [3],
+# separate --pmc passes (FETCH_SIZE / WRITE_SIZE / MFMA counters) of the configs[1] command, replay, full-size config table.
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd /tmp
+timeout 300 python $R/bench.py --steps 40 --warmup 5 > $O/r02_bench.json 2>/dev/null
+for cfg in 2 3 4; do
+  rm -rf /tmp/p_trace
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_trace -- python $R/bench.py --config $cfg --steps 20 --warmup 3 --no-cpu --no-cfg3 > /dev/null 2>&1
+  sfx=""; [ $cfg != 2 ] && sfx="_c$cfg"
+  find /tmp/p_trace -name "*kernel_stats.csv" -exec cp {} $O/r02_kernel_stats$sfx.csv \;
+  find /tmp/p_trace -name "*kernel_trace.csv" -exec cp {} $O/r02_kernel_trace$sfx.csv \;
+done
+for cfg in 2 4; do
+  sfx=""; [ $cfg != 2 ] && sfx="_c$cfg"
+  rm -rf /tmp/p_fetch /tmp/p_write
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- python $R/bench.py --config $cfg --steps 10 --warmup 2 --no-cpu --no-events --no-cfg3 > /dev/null 2>&1
+  find /tmp/p_fetch -name "*counter_collection.csv" -exec cp {} $O/r02_pmc_fetch_size$sfx.csv \;
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- python $R/bench.py --config $cfg --steps 10 --warmup 2 --no-cpu --no-events --no-cfg3 > /dev/null 2>&1
+  find /tmp/p_write -name "*counter_collection.csv" -exec cp {} $O/r02_pmc_write_size$sfx.csv \;
+done
+rm -rf /tmp/p_mfma
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/p_mfma -- python $R/bench.py --steps 10 --warmup 2 --no-cpu --no-events --no-cfg3 > /dev/null 2>&1
+find /tmp/p_mfma -name "*counter_collection.csv" -exec cp {} $O/r02_pmc_mfma.csv \;
+cd $R
+timeout 600 python bench.py --replay 600 --precision 1 > $O/r02_replay600_fp32.json 2>/dev/null
+timeout 600 python bench.py --replay 300 --classic --no-cpu > $O/r02_replay300_classic.json 2>/dev/null
+timeout 900 python tools/run_configs.py > $O/r02_configs.txt 2>&1
+# the per-dispatch traces are large: keep the live-launch summary and drop anything above 2 MB
+for f in $O/r02_kernel_trace*.csv; do python $R/profiles/summarize.py $f > ${f%.csv}_summary.txt 2>&1; done
+python $R/profiles/summarize.py $O/r02_kernel_trace.csv $O/r02_pmc_fetch_size.csv $O/r02_pmc_write_size.csv $O/r02_pmc_mfma.csv > $O/r02_summary.txt 2>&1
+ls -la $O | tail -30
