@@ -249,7 +249,9 @@ int vil_create(const vil_device_cfg* cfg, vil_ctx** out);
 void vil_destroy(vil_ctx* ctx);
 
 /* multi-GPU: rank 0 calls vil_comm_unique_id, the 128 bytes are broadcast by the host launcher
- * (torch.distributed / MPI / anything), every rank calls vil_comm_init. */
+ * (torch.distributed / MPI / anything), every rank calls vil_comm_init.  Afterwards vil_upload keeps this rank's shard of the
+ * factor set (vil_shard_ranges) and every trust-region iteration performs ONE all-reduce of the linear-system set; all ranks
+ * return the same state bit for bit.  Every rank must make the same sequence of calls; a failing upload is reported on all. */
 int vil_comm_unique_id(void* id128);
 int vil_comm_init(vil_ctx* ctx, const void* id128, int rank, int world);
 /* Communicator for contexts that live in ONE process (one host thread per context; <= 8): the same sharding and the
@@ -292,7 +294,15 @@ int vil_linearize(vil_ctx* ctx, const vil_problem* problem, const vil_state* sta
                   const vil_options* options, double* cost, double* S, double* g);
 
 /* replaces estimator.cpp:1486-1616 / 1624-1681 (MarginalizationInfo: preMarginalize + marginalize
- * + getParameterBlocks with the i->i-1 address shift done as an index remap). */
+ * + getParameterBlocks with the i->i-1 address shift done as an index remap).
+ * Collected factors: the prior, IMU (0,1), every visual factor anchored in frame 0, the remembered ICP / LPS constraint and --
+ * extended mode -- the LiDAR edge / plane points attached to frame 0 (marginalization_factor.cpp:176-316 folds every factor
+ * that touches a dropped block; they touch pose 0 only).  Rank rule: directions of A_mm at or below eps = 1e-8 are zeroed like
+ * the reference's eigenvalue threshold (:277) -- a landmark without parallax (h_ll <= eps) keeps its factors' information on
+ * the poses; the 15 x 15 pose / speed-bias block is inverted by Cholesky when certified full rank, by thresholded
+ * eigen-decomposition otherwise.
+ * NOTE: vil_marginalize, vil_eval_factors and vil_linearize upload a derived problem and thereby REPLACE the window left
+ * resident by vil_upload / vil_solve (vil_solve_resident then returns VIL_ERR_INVALID_ARGUMENT until the next upload). */
 int vil_marginalize(vil_ctx* ctx, const vil_problem* problem, const vil_state* state,
                     const vil_options* options, const vil_marg_spec* spec, vil_prior_out* out);
 
