@@ -287,6 +287,19 @@ int vil_profile_read(vil_ctx* ctx, vil_profile* out, int reset);
 int vil_eval_factors(vil_ctx* ctx, const vil_problem* problem, const vil_state* state,
                      int factor_class, double* residuals, double* jacobians);
 
+/* The four functors of lidar_mapping/src/lidarFactor.hpp in window-pose form (point in the LiDAR frame, LiDAR->body extrinsic
+ * q_lb / t_lb, one window pose [p q(xyzw)]), Evaluate()-compatible: residuals n x nr, Jacobians n x nr x 7 row-major (pose tangent
+ * in the first six columns).  kind / constants per point / nr:
+ *   VIL_LIDAR_EDGE       [cp a b]      9   3   LidarEdgeFactor       :12-54  (s = 1)
+ *   VIL_LIDAR_PLANE3     [cp j l m]   12   1   LidarPlaneFactor      :57-104 (s = 1; unit normal of (j-l) x (j-m), as the functor's ctor)
+ *   VIL_LIDAR_PLANE_NORM [cp n d]      7   1   LidarPlaneNormFactor  :107-138
+ *   VIL_LIDAR_DISTANCE   [cp closed]   6   3   LidarDistanceFactor   :141-172
+ * The window solve uses EDGE and PLANE_NORM (problem.edge_* / plane_*); PLANE3 and DISTANCE are never instantiated by the
+ * reference (localMapping.cpp:668-685, 748-765 are commented out) and are provided for completeness of the per-factor surface. */
+enum { VIL_LIDAR_EDGE = 0, VIL_LIDAR_PLANE3 = 1, VIL_LIDAR_PLANE_NORM = 2, VIL_LIDAR_DISTANCE = 3 };
+int vil_eval_lidar_functors(vil_ctx* ctx, int32_t kind, int32_t n, const double* consts, const double* q_lb, const double* t_lb,
+                            const double* pose7, double* residuals, double* jacobians);
+
 /* one linearisation of the whole window: robustified cost and the Schur-reduced normal equations
  * S (D x D row-major, D = vil_reduced_dim(K)), g (D), at `state`, with trust-region damping mu = 0
  * and no Jacobi scaling.  Diagnostic / parity surface of the hot loop's sweep + reduction. */

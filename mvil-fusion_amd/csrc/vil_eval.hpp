@@ -53,6 +53,42 @@ __global__ void k_eval_lidar(DevP P, const double* x, double* r, double* J) {
     }
 }
 
+// all four lidarFactor.hpp functors at one pose (vil_eval_lidar_functors): thread = point, constants point-major
+struct LidarFunctorArgs { double Rbl[9], tbl[3], pose[7]; };
+__global__ void k_eval_lidar_functors(int kind, int n, const double* __restrict__ c, LidarFunctorArgs A, double* __restrict__ r, double* __restrict__ J) {
+    using namespace vd;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    const M3 R = quatR(A.pose + 3), Rbl = loadM3(A.Rbl);
+    const V3 Pk{A.pose[0], A.pose[1], A.pose[2]}, tbl{A.tbl[0], A.tbl[1], A.tbl[2]};
+    const int nc = kind == 0 ? 9 : (kind == 1 ? 12 : (kind == 2 ? 7 : 6)), nr = (kind == 0 || kind == 3) ? 3 : 1;
+    const double* q = c + (size_t)f * nc;
+    const V3 cp{q[0], q[1], q[2]};
+    double rr[3] = {0, 0, 0}, JJ[18];
+    for (int e = 0; e < 18; ++e) JJ[e] = 0.0;
+    if (kind == 0) edge_eval(cp, V3{q[3], q[4], q[5]}, V3{q[6], q[7], q[8]}, Rbl, tbl, R, Pk, rr, JJ);
+    else if (kind == 1) {                               // LidarPlaneFactor: ljm_norm = ((j - l) x (j - m)).normalized(), residual (lp - j) . ljm_norm
+        const V3 pj{q[3], q[4], q[5]}, pl_{q[6], q[7], q[8]}, pm{q[9], q[10], q[11]};
+        V3 nv = cross(pj - pl_, pj - pm);
+        const double inv = 1.0 / sqrt(dot(nv, nv));
+        nv = inv * nv;
+        plane_eval(cp, nv, -dot(nv, pj), Rbl, tbl, R, Pk, rr[0], JJ);
+    } else if (kind == 2) plane_eval(cp, V3{q[3], q[4], q[5]}, q[6], Rbl, tbl, R, Pk, rr[0], JJ);
+    else {                                              // LidarDistanceFactor: r = p_w - closed ; J = [I | -R [p_b]x]
+        const V3 pb = mul(Rbl, cp) + tbl, pw = mul(R, pb) + Pk;
+        rr[0] = pw.x - q[3]; rr[1] = pw.y - q[4]; rr[2] = pw.z - q[5];
+        for (int i = 0; i < 3; ++i) {
+            const V3 ei{i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0};
+            const V3 jr = cross(pb, mulT(R, ei));         // row i of -R [p_b]x
+            JJ[6 * i + i] = 1.0; JJ[6 * i + 3] = jr.x; JJ[6 * i + 4] = jr.y; JJ[6 * i + 5] = jr.z;
+        }
+    }
+    for (int i = 0; i < nr; ++i) {
+        r[(size_t)f * nr + i] = rr[i];
+        if (J) { for (int c2 = 0; c2 < 6; ++c2) J[((size_t)f * nr + i) * 7 + c2] = JJ[i * 6 + c2]; J[((size_t)f * nr + i) * 7 + 6] = 0.0; }
+    }
+}
+
 // one WG per IMU factor; J: 480/factor = [15x7 | 15x9 | 15x7 | 15x9]
 __global__ void k_eval_imu(DevP P, const double* x, double* r, double* J) {
     using namespace vd;

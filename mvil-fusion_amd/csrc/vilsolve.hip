@@ -1030,6 +1030,29 @@ int vil_eval_factors(vil_ctx* c, const vil_problem* p, const vil_state* s, int c
     return VIL_OK;
 }
 
+int vil_eval_lidar_functors(vil_ctx* c, int32_t kind, int32_t n, const double* consts, const double* q_lb, const double* t_lb, const double* pose7, double* r, double* J) {
+    if (!c || kind < VIL_LIDAR_EDGE || kind > VIL_LIDAR_DISTANCE || n < 0 || (n > 0 && !consts) || !q_lb || !t_lb || !pose7 || !r) return VIL_ERR_INVALID_ARGUMENT;
+    if (n == 0) return VIL_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const int nc = kind == VIL_LIDAR_EDGE ? 9 : (kind == VIL_LIDAR_PLANE3 ? 12 : (kind == VIL_LIDAR_PLANE_NORM ? 7 : 6)), nr = (kind == VIL_LIDAR_EDGE || kind == VIL_LIDAR_DISTANCE) ? 3 : 1;
+    LidarFunctorArgs A;
+    { double R[9]; quat_to_R_host(q_lb, R); for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A.Rbl[3 * i + j] = R[3 * j + i];          // body <- LiDAR: (R_lb^T, -R_lb^T t_lb), as the window upload
+      for (int i = 0; i < 3; ++i) A.tbl[i] = -(A.Rbl[3 * i] * t_lb[0] + A.Rbl[3 * i + 1] * t_lb[1] + A.Rbl[3 * i + 2] * t_lb[2]); }
+    memcpy(A.pose, pose7, sizeof A.pose);
+    const size_t bc = 8 * (size_t)nc * n, br = 8 * (size_t)nr * n, bj = J ? 8 * (size_t)nr * 7 * n : 0;
+    double *d_c = nullptr, *d_r = nullptr, *d_J = nullptr;
+    struct Free { double*& a; double*& b; double*& c; ~Free() { if (a) hipFree(a); if (b) hipFree(b); if (c) hipFree(c); } } free_tmp{d_c, d_r, d_J};
+    HIPCHK(hipMalloc(&d_c, bc)); HIPCHK(hipMalloc(&d_r, br));
+    if (J) HIPCHK(hipMalloc(&d_J, bj));
+    HIPCHK(hipMemcpyAsync(d_c, consts, bc, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_eval_lidar_functors, dim3((n + VIL_THREADS - 1) / VIL_THREADS), dim3(VIL_THREADS), 0, c->stream, (int)kind, (int)n, d_c, A, d_r, d_J);
+    HIPCHK(hipMemcpyAsync(r, d_r, br, hipMemcpyDeviceToHost, c->stream));
+    if (J) HIPCHK(hipMemcpyAsync(J, d_J, bj, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    return VIL_OK;
+}
+
 int vil_linearize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vil_options* o, double* cost, double* S, double* g) {
     if (!c || !o || !cost || !S || !g) return VIL_ERR_INVALID_ARGUMENT;
     int st = vil_upload(c, p, s);

@@ -29,6 +29,8 @@ void icp_evaluate(const double* c, const double* pa, const double* pb, const dou
 void lps_evaluate(const double* c, const double* pa, const double* pb, double* r, double* J);
 void edge_evaluate(const double* c, const double* q_lb, const double* t_lb, const double* pose, double* r, double* J);
 void plane_evaluate(const double* c, const double* q_lb, const double* t_lb, const double* pose, double* r, double* J);
+void plane3_evaluate(const double* c12, const double* q_lb, const double* t_lb, const double* pose, double* r, double* J);      // LidarPlaneFactor   lidarFactor.hpp:57-104
+void distance_evaluate(const double* c6, const double* q_lb, const double* t_lb, const double* pose, double* r, double* J);    // LidarDistanceFactor :141-172
 void edge_residual_ref(const double* cp, const double* a3, const double* b3, const double* q_wl_xyzw, const double* t_wl, double* r);
 void plane_residual_ref(const double* cp, const double* n3, double d, const double* q_wl_xyzw, const double* t_wl, double* r);
 void loss_evaluate(int kind, double a, double s, double rho[3]);

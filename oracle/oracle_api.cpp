@@ -86,6 +86,21 @@ int orc_eval_factors(const vil_problem* p, const vil_state* s, int cls, double* 
     return VIL_ERR_INVALID_ARGUMENT;
 }
 
+// the four functors of lidar_mapping/src/lidarFactor.hpp in window-pose form (include/vilsolve.h: vil_eval_lidar_functors)
+int orc_eval_lidar_functors(int32_t kind, int32_t n, const double* c, const double* q_lb, const double* t_lb, const double* pose7, double* r, double* J) {
+    using namespace orc;
+    for (int f = 0; f < n; ++f) {
+        switch (kind) {
+            case VIL_LIDAR_EDGE: edge_evaluate(c + 9 * (size_t)f, q_lb, t_lb, pose7, r + 3 * (size_t)f, J ? J + 21 * (size_t)f : nullptr); break;
+            case VIL_LIDAR_PLANE_NORM: plane_evaluate(c + 7 * (size_t)f, q_lb, t_lb, pose7, r + (size_t)f, J ? J + 7 * (size_t)f : nullptr); break;
+            case VIL_LIDAR_PLANE3: plane3_evaluate(c + 12 * (size_t)f, q_lb, t_lb, pose7, r + (size_t)f, J ? J + 7 * (size_t)f : nullptr); break;
+            case VIL_LIDAR_DISTANCE: distance_evaluate(c + 6 * (size_t)f, q_lb, t_lb, pose7, r + 3 * (size_t)f, J ? J + 21 * (size_t)f : nullptr); break;
+            default: return VIL_ERR_INVALID_ARGUMENT;
+        }
+    }
+    return VIL_OK;
+}
+
 int orc_solve(const vil_problem* p, vil_state* s, const vil_options* o, vil_summary* sum) { return orc::solve(p, s, o, sum); }
 int orc_linearize(const vil_problem* p, const vil_state* s, const vil_options* o, double* cost, double* S, double* g) { return orc::linearize_api(p, s, o, cost, S, g); }
 int orc_linearize_full(const vil_problem* p, const vil_state* s, const vil_options* o, double* cost, double* Hcc, double* bc, double* hll, double* bl, double* E) { return orc::linearize_full_api(p, s, o, cost, Hcc, bc, hll, bl, E); }

@@ -373,6 +373,30 @@ void plane_evaluate(const double* c, const double* q_lb, const double* t_lb, con
     J[6] = 0.0;
 }
 
+// LidarPlaneFactor (lidarFactor.hpp:57-104), s = 1: the constructor normalises (j - l) x (j - m); residual (lp - j) . ljm_norm --
+// a plane-normal factor with n = ljm_norm, d = -n . j.  Dead code in the reference (localMapping.cpp:748-765 commented out).
+void plane3_evaluate(const double* c, const double* q_lb, const double* t_lb, const double* pose, double* r, double* J) {
+    const Vec3 pj = vec_from(c + 3), pl = vec_from(c + 6), pm = vec_from(c + 9);
+    Vec3 n = cross(pj - pl, pj - pm);
+    const double inv = 1.0 / std::sqrt(dot(n, n));
+    n = n * inv;
+    const double c7[7] = {c[0], c[1], c[2], n.x, n.y, n.z, -dot(n, pj)};
+    plane_evaluate(c7, q_lb, t_lb, pose, r, J);
+}
+// LidarDistanceFactor (:141-172): r = point_w - closed_point.  Dead code in the reference (localMapping.cpp:668-685).
+void distance_evaluate(const double* c, const double* q_lb, const double* t_lb, const double* pose, double* r, double* J) {
+    const Vec3 pb = lidar_to_body(q_lb, t_lb, vec_from(c));
+    const Quat Q = quat_from_block(pose);
+    const Vec3 pw = qrot(Q, pb) + vec_from(pose);
+    r[0] = pw.x - c[3]; r[1] = pw.y - c[4]; r[2] = pw.z - c[5];
+    if (!J) return;
+    const Mat3 dpw_dth = mat_scale(mat_mul(quat_R(Q), skew(pb)), -1.0);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) { J[7 * i + j] = i == j ? 1.0 : 0.0; J[7 * i + 3 + j] = dpw_dth(i, j); }
+        J[7 * i + 6] = 0.0;
+    }
+}
+
 // Literal lidarFactor.hpp functors on the LiDAR->world transform (q_wl, t_wl), used by the tests
 // to check that the window-pose form above reproduces the reference residuals.
 void edge_residual_ref(const double* cp, const double* a3, const double* b3, const double* q_wl_xyzw, const double* t_wl, double* r) {

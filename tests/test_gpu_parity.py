@@ -140,3 +140,19 @@ def test_solve_parity_over_seeds(hip, oracle, cid, kw):
         assert abs(sg.final_cost - so.final_cost) <= (1e-5 if wg.prior.n == 0 else 1e-8) * so.final_cost
         hip.gauge_fix(p0, wg); oracle.gauge_fix(p0, wo)
         compare_states(wg, wo, pos_tol=1e-4 if wg.prior.n == 0 else 1e-6, rot_tol=1e-5 if wg.prior.n == 0 else 1e-7)
+
+
+@pytest.mark.parametrize("kind,nr", [(0, 3), (1, 1), (2, 1), (3, 3)])
+def test_lidar_functors_parity(hip, oracle, kind, nr):
+    """All four functors of lidar_mapping/src/lidarFactor.hpp (vil_eval_lidar_functors) -- incl. the two the reference never
+    instantiates, LidarPlaneFactor and LidarDistanceFactor -- GPU vs oracle <= 1e-12."""
+    from test_oracle_factors import eval_functors, functor_tables
+    q_lb, t_lb, pose, cp, c12, c6 = functor_tables()
+    rng = np.random.default_rng(11)
+    n = len(cp)
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    consts = {0: np.hstack([cp, c12[:, 3:6], c12[:, 6:9]]), 1: c12, 2: np.hstack([cp, nrm, rng.normal(size=(n, 1))]), 3: c6}[kind]
+    rg, Jg = eval_functors(hip, kind, consts, q_lb, t_lb, pose, nr)
+    ro, Jo = eval_functors(oracle, kind, consts, q_lb, t_lb, pose, nr)
+    assert np.abs(rg - ro).max() <= 1e-12 * max(1.0, np.abs(ro).max())
+    assert np.abs(Jg - Jo).max() <= 1e-12 * max(1.0, np.abs(Jo).max())

@@ -294,3 +294,71 @@ def test_preintegration_matches_numpy(oracle):
                                 np.ascontiguousarray(acc[0]).ctypes.data_as(dp), np.ascontiguousarray(gyr[0]).ctypes.data_as(dp),
                                 ba.ctypes.data_as(dp), bg.ctypes.data_as(dp), noise.ctypes.data_as(dp), out.ctypes.data_as(dp))
     assert np.allclose(out, ref, rtol=1e-10, atol=1e-14)
+
+
+# ---- the four functors of lidar_mapping/src/lidarFactor.hpp at one pose (vil_eval_lidar_functors / orc_eval_lidar_functors) --------
+def _functor_case(seed=5, n=40):
+    rng = np.random.default_rng(seed)
+    q_lb = rng.normal(size=4); q_lb /= np.linalg.norm(q_lb)
+    t_lb = rng.normal(size=3) * 0.1
+    pose = np.concatenate([rng.normal(size=3), (lambda q: q / np.linalg.norm(q))(rng.normal(size=4))])
+    cp = rng.normal(size=(n, 3)) * 5
+    return rng, q_lb, t_lb, pose, cp
+
+
+def _lidar_to_world(q_lb, t_lb, pose, cp):
+    Rlb = synth.quat_to_R(q_lb); R = synth.quat_to_R(pose[3:])
+    pb = (cp - t_lb) @ Rlb                      # R_lb^T (p_l - t_lb)
+    return pb @ R.T + pose[:3], pb, R
+
+
+def eval_functors(be, kind, consts, q_lb, t_lb, pose, nr):
+    import ctypes as C
+    n = len(consts)
+    c = np.ascontiguousarray(consts, dtype=np.float64)
+    r = np.zeros(n * nr); J = np.zeros(n * nr * 7)
+    dp = C.POINTER(C.c_double)
+    f = getattr(be.lib, be.prefix + "eval_lidar_functors"); f.restype = C.c_int
+    args = (C.c_int32(kind), C.c_int32(n), c.ctypes.data_as(dp), abi.f64(q_lb).ctypes.data_as(dp), abi.f64(t_lb).ctypes.data_as(dp), abi.f64(pose).ctypes.data_as(dp), r.ctypes.data_as(dp), J.ctypes.data_as(dp))
+    st = f(be.ctx, *args) if be.has_ctx else f(*args)
+    assert st == 0
+    return r.reshape(n, nr), J.reshape(n, nr, 7)
+
+
+def functor_tables():
+    rng, q_lb, t_lb, pose, cp = _functor_case()
+    n = len(cp)
+    j, l, m = rng.normal(size=(n, 3)) * 4, rng.normal(size=(n, 3)) * 4, rng.normal(size=(n, 3)) * 4
+    closed = rng.normal(size=(n, 3)) * 5
+    return q_lb, t_lb, pose, cp, np.hstack([cp, j, l, m]), np.hstack([cp, closed])
+
+
+def test_plane3_and_distance_functors_match_the_literal_functors(oracle):
+    """LidarPlaneFactor (lidarFactor.hpp:57-104, s = 1: slerp(1) is the quaternion itself) and LidarDistanceFactor (:141-172)
+    re-derived in numpy on the LiDAR->world transform, and their Jacobians by the reference's finite-difference recipe."""
+    q_lb, t_lb, pose, cp, c12, c6 = functor_tables()
+    pw, pb, R = _lidar_to_world(q_lb, t_lb, pose, cp)
+    r3, J3 = eval_functors(oracle, 1, c12, q_lb, t_lb, pose, 1)
+    nrm = np.cross(c12[:, 3:6] - c12[:, 6:9], c12[:, 3:6] - c12[:, 9:12]); nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    assert np.abs(r3[:, 0] - np.einsum("ij,ij->i", pw - c12[:, 3:6], nrm)).max() < 1e-12
+    rd, Jd = eval_functors(oracle, 3, c6, q_lb, t_lb, pose, 3)
+    assert np.abs(rd - (pw - c6[:, 3:6])).max() < 1e-12
+    for kind, c, nr, ana in ((1, c12, 1, J3), (3, c6, 3, Jd)):
+        for col in range(6):
+            d = np.zeros(6); d[col] = 1e-6
+            rp, _ = eval_functors(oracle, kind, c, q_lb, t_lb, plus_pose(pose, d), nr)
+            rm, _ = eval_functors(oracle, kind, c, q_lb, t_lb, plus_pose(pose, -d), nr)
+            assert np.allclose((rp - rm) / 2e-6, ana[:, :, col], rtol=1e-6, atol=1e-6)
+        assert np.all(ana[:, :, 6] == 0.0)
+
+
+def test_edge_and_plane_norm_functor_batches_equal_the_window_classes(oracle):
+    """kinds 0 / 2 are the window's EDGE / PLANE classes evaluated at one pose."""
+    w = synth.make_config(2, L=20, n_plane=60, n_edge=40)
+    k = 3
+    pm, em = w.plane_pose == k, w.edge_pose == k
+    rP, JP = oracle.eval_factors(w, abi.FACTOR_PLANE); rE, JE = oracle.eval_factors(w, abi.FACTOR_EDGE)
+    r2, J2 = eval_functors(oracle, 2, w.plane_const[pm], w.q_lb, w.t_lb, w.pose[k], 1)
+    r0, J0 = eval_functors(oracle, 0, w.edge_const[em], w.q_lb, w.t_lb, w.pose[k], 3)
+    assert np.array_equal(r2[:, 0], rP[pm]) and np.array_equal(J2.reshape(-1, 7), JP.reshape(-1, 7)[pm])
+    assert np.array_equal(r0, rE.reshape(-1, 3)[em]) and np.array_equal(J0.reshape(-1, 21), JE.reshape(-1, 21)[em])
