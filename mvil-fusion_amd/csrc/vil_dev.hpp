@@ -98,7 +98,9 @@ struct DevP {
     // helper workgroups of the single-GPU step kernel (landmark pre-pass on extra CUs): n_help of them, each publishes
     // {q, g2, gm} in hpart[4 * k ..] and then stores the launch epoch in hflag[k]; only the master workgroup ever waits
     int n_help; double* hpart; int* hflag;
-    double* hpart2; int* hflag2; int* xflag; int* xstat;      // second landmark pass of the helpers (k_step)
+    // second landmark pass of the helpers (k_step): the master posts the epoch in xflag (Sc x_p is in stepc) or in xstat (no step
+    // this launch); every helper WAVE then leaves its six sums in hpart2[8 * slot ..] and the epoch in hflag2[slot], slot = 8 k + wave
+    double* hpart2; int* hflag2; int* xflag; int* xstat;
     double* la; double* lb;        // L each: step directions of the inverse depths (Cauchy, Gauss-Newton), written by the step kernel's landmark pass
     // structure-exploiting solve (vil_chain.hpp): 0 dense, 1 chain with W^T in LDS, 2 chain with W^T in global memory (P.M)
     int chain, chain_rs;

@@ -28,12 +28,16 @@ namespace vd {
 
 struct StepShared {
     Ctl c;
-    double red[32];
+    double red[64];
     unsigned char tI[256], tJ[256];   // triangular tile index -> (row, col) of the tile
     double xs[320], dinv[320];            // solution of the reduced system, reciprocal Cholesky pivots (D <= 320)
     double y[320];
     double sc[320], dcs[320], gr[320], gn[320];   // Sc, dogleg diagonal, gradient_, gauss_newton_step_ (camera part)
     double gd[320];                               // reduced gradient (rhs row of M): staged once, the packing loop must not touch global memory
+    double rt[320];                               // Sc / dogleg diagonal: the candidate step is formed without a divide
+    double x0[328];                               // camera part of x_cur (16K + 8 doubles), fetched while the system is being solved
+    unsigned char cst[48];                        // pose_const[K] | sb_const[K]
+    double hs[12];                                // the helpers' sums, gathered by a spare wave during the chain back substitution
     int need, was_first, ok;
     long long tacc[6];
 };
@@ -49,6 +53,29 @@ __device__ __forceinline__ void bsum3(double& a, double& b, double& c, StepShare
     __syncthreads();
     a = 0; b = 0; c = 0;
     for (int q = 0; q < nw; ++q) { a += s.red[q]; b += s.red[8 + q]; c = CMAX ? fmax(c, s.red[16 + q]) : c + s.red[16 + q]; }
+}
+
+// block-wide sum of a, b, d, e and max of c with one pair of barriers
+__device__ __forceinline__ void bsum5(double& a, double& b, double& c, double& d, double& e, StepShared& s) {
+    a = wave_total_l63(a); b = wave_total_l63(b); c = wave_max_l63(c); d = wave_total_l63(d); e = wave_total_l63(e);
+    __syncthreads();
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 63) { s.red[w] = a; s.red[8 + w] = b; s.red[16 + w] = c; s.red[24 + w] = d; s.red[32 + w] = e; }
+    __syncthreads();
+    a = 0; b = 0; c = 0; d = 0; e = 0;
+    for (int q = 0; q < nw; ++q) { a += s.red[q]; b += s.red[8 + q]; c = fmax(c, s.red[16 + q]); d += s.red[24 + q]; e += s.red[32 + q]; }
+}
+
+// block-wide sums of six values with one pair of barriers
+__device__ __forceinline__ void bsum6(double* v, StepShared& s) {
+#pragma unroll
+    for (int e = 0; e < 6; ++e) v[e] = wave_total_l63(v[e]);
+    __syncthreads();
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 63) { for (int e = 0; e < 6; ++e) s.red[8 * e + w] = v[e]; }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 6; ++e) { double a = 0; for (int q = 0; q < nw; ++q) a += s.red[8 * e + q]; v[e] = a; }
 }
 
 __device__ __forceinline__ double bsum(double v, StepShared& s) {
@@ -74,34 +101,59 @@ __device__ __forceinline__ double bmax(double v, StepShared& s) {
 
 // e_l . v_c  for landmark l (compact e storage: anchor 6 | ex 6 | td 1 | per-factor observer 6).
 // Dependent fp64 ops cost ~32 cycles each on gfx950: four independent accumulators, column tables instead of
-// chained index loads.
-__device__ __forceinline__ double lm_dot(const DevP& P, const SysBuf& sb, int l, const double* vc) {
-    const int fs = P.glm_start[l], fe = P.glm_start[l + 1];
-    const int ac = P.glm_acol[l];
-    if (fe == fs) return 0.0;
+// chained index loads.  The landmark's rows are first fetched into an LmRows (anchor/ex/td row + the first three observers:
+// all loads in flight together); a helper workgroup keeps that between its two passes, so the second one -- which sits on
+// the step kernel's critical path -- touches no global memory for the usual landmark.
+struct LmRows { double e[13], a[6], b[6], c[6]; double m1, m2; int fs, fe, ac, c0, c1, c2; };
+__device__ __forceinline__ void lm_rows(const DevP& P, const SysBuf& sb, int l, LmRows& r) {
+    r.fs = P.glm_start[l]; r.fe = P.glm_start[l + 1]; r.ac = P.glm_acol[l];
+    if (r.fe == r.fs) return;
     const double* e = sb.eA + (size_t)l * 13;
-    const double* va = vc + ac; const double* vx = vc + col_ex(P);
+#pragma unroll
+    for (int k = 0; k < 13; ++k) r.e[k] = e[k];
+    // observers three at a time: index clamped into the landmark's own range (always a valid address), contribution
+    // masked by a select -- the global loads of a group are all in flight together instead of one dependent round trip
+    // per factor, and there is no per-lane predicated load (those compile to exec-mask branches with their own waits)
+    const int f = r.fs, f1 = min(f + 1, r.fe - 1), f2 = min(f + 2, r.fe - 1);
+    r.c0 = P.gfcol[f]; r.c1 = P.gfcol[f1]; r.c2 = P.gfcol[f2];
+    const double* e0 = sb.eO + (size_t)f * 6; const double* e1 = sb.eO + (size_t)f1 * 6; const double* e2 = sb.eO + (size_t)f2 * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { r.a[k] = e0[k]; r.b[k] = e1[k]; r.c[k] = e2[k]; }
+    r.m1 = (f + 1 < r.fe) ? 1.0 : 0.0; r.m2 = (f + 2 < r.fe) ? 1.0 : 0.0;
+}
+__device__ __forceinline__ double lm_dot_rows(const DevP& P, const SysBuf& sb, const LmRows& r, const double* vc) {
+    if (r.fe == r.fs) return 0.0;
+    const double* e = r.e;
+    const double* va = vc + r.ac; const double* vx = vc + col_ex(P);
     double s0 = e[0] * va[0], s1 = e[1] * va[1], s2 = e[2] * va[2], s3 = e[3] * va[3];
     s0 += e[4] * va[4]; s1 += e[5] * va[5];
     s2 += e[6] * vx[0]; s3 += e[7] * vx[1]; s0 += e[8] * vx[2]; s1 += e[9] * vx[3]; s2 += e[10] * vx[4]; s3 += e[11] * vx[5];
     s0 += e[12] * vc[col_td(P)];
-    // observers three at a time: index clamped into the landmark's own range (always a valid address), contribution
-    // masked by a select -- the global loads of a group are all in flight together instead of one dependent round trip
-    // per factor, and there is no per-lane predicated load (those compile to exec-mask branches with their own waits)
-    for (int f = fs; f < fe; f += 3) {
-        const int f1 = min(f + 1, fe - 1), f2 = min(f + 2, fe - 1);
+    {
+        const double* v0 = vc + r.c0; const double* v1 = vc + r.c1; const double* v2 = vc + r.c2;
+        const double* a = r.a; const double* b = r.b; const double* c = r.c;
+        s0 += a[0] * v0[0]; s1 += a[1] * v0[1]; s2 += a[2] * v0[2]; s3 += a[3] * v0[3]; s0 += a[4] * v0[4]; s1 += a[5] * v0[5];
+        s2 += r.m1 * (b[0] * v1[0] + b[1] * v1[1] + b[2] * v1[2]); s3 += r.m1 * (b[3] * v1[3] + b[4] * v1[4] + b[5] * v1[5]);
+        s0 += r.m2 * (c[0] * v2[0] + c[1] * v2[1] + c[2] * v2[2]); s1 += r.m2 * (c[3] * v2[3] + c[4] * v2[4] + c[5] * v2[5]);
+    }
+    for (int f = r.fs + 3; f < r.fe; f += 3) {          // landmarks seen from more than three frames: the rest from memory
+        const int f1 = min(f + 1, r.fe - 1), f2 = min(f + 2, r.fe - 1);
         const int c0 = P.gfcol[f], c1 = P.gfcol[f1], c2 = P.gfcol[f2];
         const double* e0 = sb.eO + (size_t)f * 6; const double* e1 = sb.eO + (size_t)f1 * 6; const double* e2 = sb.eO + (size_t)f2 * 6;
         double a[6], b[6], c[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) { a[k] = e0[k]; b[k] = e1[k]; c[k] = e2[k]; }
         const double* v0 = vc + c0; const double* v1 = vc + c1; const double* v2 = vc + c2;
-        const double m1 = (f + 1 < fe) ? 1.0 : 0.0, m2 = (f + 2 < fe) ? 1.0 : 0.0;
+        const double m1 = (f + 1 < r.fe) ? 1.0 : 0.0, m2 = (f + 2 < r.fe) ? 1.0 : 0.0;
         s0 += a[0] * v0[0]; s1 += a[1] * v0[1]; s2 += a[2] * v0[2]; s3 += a[3] * v0[3]; s0 += a[4] * v0[4]; s1 += a[5] * v0[5];
         s2 += m1 * (b[0] * v1[0] + b[1] * v1[1] + b[2] * v1[2]); s3 += m1 * (b[3] * v1[3] + b[4] * v1[4] + b[5] * v1[5]);
         s0 += m2 * (c[0] * v2[0] + c[1] * v2[1] + c[2] * v2[2]); s1 += m2 * (c[3] * v2[3] + c[4] * v2[4] + c[5] * v2[5]);
     }
     return (s0 + s1) + (s2 + s3);
+}
+__device__ __forceinline__ double lm_dot(const DevP& P, const SysBuf& sb, int l, const double* vc) {
+    LmRows r; lm_rows(P, sb, l, r);
+    return lm_dot_rows(P, sb, r, vc);
 }
 
 // v^T H v over all free parameters, H = J^T J of the corrected Jacobian, from the reduced pieces:
@@ -470,8 +522,8 @@ struct ChainSrcStep {                      // the chain's view of the system ins
     __device__ __forceinline__ void row_done(int, int r, double zr, double& q) const { q += 2.0 * u_[r] * zr; }
 };
 
-template <bool WLDS, class PUB>
-__device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart, PUB pub) {
+template <bool WLDS, class PUB, class SIDE>
+__device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart, PUB pub, SIDE side) {
     const int t = threadIdx.x;
 #ifdef VIL_STAMPS
     #define SSTAMP(k) do { if (t == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[40 + k] = tt_; } } while (0)
@@ -578,6 +630,7 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
     __syncthreads();
     if (t < 64) { for (int k = m - 1; k >= 0; --k) chain_block_back(L.Ldg + 54 * k, L.Lsb + 82 * k, tB + 9 * k, s.y + NP + 9 * (k + 1), s.y + NP + 9 * k); }
     else if (t < 128) { for (int k = m + 1; k < K; ++k) chain_block_back(L.Ldg + 54 * k, L.Lsb + 82 * k, tB + 9 * k, s.y + NP + 9 * (k - 1), s.y + NP + 9 * k); }
+    else if (t >= VIL_STEP_THREADS - 64) side();       // a spare wave: whatever the caller can hide behind the two chain walks
     __syncthreads();
     SSTAMP(6);
     return true;
@@ -585,8 +638,8 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
 
 // ---- chain eliminated ahead by k_reduce's extra workgroup (vil_prechain.hpp): pack the pose tiles, scale the pose rows of W
 //      while subtracting W W^T, dense part, chain back substitution.  Same contract as solve_chain.
-template <class PUB>
-__device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart, PUB pub) {
+template <class PUB, class SIDE>
+__device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart, PUB pub, SIDE side) {
     const int t = threadIdx.x;
     SSTAMP(0);
     const int K = P.K, D = P.D, NP = P.NV, R = NP + 1, T = (R + 15) >> 4, ntile = (T * (T + 1)) >> 1;
@@ -673,6 +726,7 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
     __syncthreads();
     if (t < 64) { for (int k = m - 1; k >= 0; --k) chain_block_back(Ldg + 54 * k, Lsb + 82 * k, tB + 9 * k, s.y + NP + 9 * (k + 1), s.y + NP + 9 * k); }
     else if (t < 128) { for (int k = m + 1; k < K; ++k) chain_block_back(Ldg + 54 * k, Lsb + 82 * k, tB + 9 * k, s.y + NP + 9 * (k - 1), s.y + NP + 9 * k); }
+    else if (t >= VIL_STEP_THREADS - 64) side();
     __syncthreads();
     SSTAMP(6);
     return true;
@@ -700,9 +754,11 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     // The grid is 1 + P.n_help workgroups: the extra ones run the same judge on their own copy of Ctl and
     // do the two landmark passes of their slice on their own CU (those passes are bound by what ONE CU can pull out of L2).
     // Flags (all compared with the launch epoch): hflag[k] -- helper k has read Ctl and published its pre-pass sums;
-    // xflag -- the master has published Sc x_p (xstat = 1) or given up (xstat = 0); hflag2[k] -- helper k's second pass is done.
+    // xflag -- the master has published Sc x_p; xstat -- it has given up for this launch (the helpers poll both at once);
+    // hflag2[8 k + w] -- wave w of helper k has left the sums of its second pass (no block reduction on that path).
     // Only the master writes Ctl / the camera candidate, after every helper has signalled hflag.
-    const bool helper = blockIdx.x > 0;
+    const int bid = (int)blockIdx.x;
+    const bool helper = bid > 0;
     const int nhelp = (int)gridDim.x - 1;
     if (t == 0) { s.c = *P.ctl; s.c.swe++; s.need = 0; s.was_first = 0; s.ok = 1; }      // (every path that writes Ctl back carries the new swe)
     for (int q = t; q < 256; q += NT) {      // triangular tile index -> (tile row, tile col)
@@ -719,9 +775,11 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
 #endif
     if (s.c.done) return;                    // finished in an earlier launch: nobody writes anything
     const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
-    auto post = [&](int* f) { if (t == 0) { __threadfence(); __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); } };
+    auto post = [&](int* f) { if (t == 0) __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); };      // (callers: after a barrier)
     auto wait1 = [&](int* f) { while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1); };
-    auto wait_helpers = [&]() { if (t == 0) for (int k = 0; k < nhelp; ++k) wait1(P.hflag + k); };     // master: every helper has read Ctl
+    // master: every helper has read Ctl (one lane per helper: the polls overlap instead of queueing behind one another)
+    bool hseen = false;
+    auto wait_helpers = [&]() { if (!hseen && t < nhelp) wait1(P.hflag + t); hseen = true; };
     const bool cam = true;             // (every rank holds the complete system: nothing is counted per rank any more)
     STAMP(0);
     // ---------------- judge the candidate that the sweep just linearised -------------------------
@@ -791,8 +849,42 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             if (!(P.lm_const && P.lm_const[l])) { const double lam = x[xo_lam(P) + l]; sm[5] += lam * lam; }
         }
     };
+    // helper side of the second pass: poll "published" and "given up" together (one round trip), then every wave posts its own
+    // sums -- the master's gathering wave adds the <= 8 nhelp slots with a fixed tree, no block reduction on the critical path
+    auto wait_x = [&]() {
+        if (t == 0) {
+            for (;;) {
+                const int a = __hip_atomic_load(P.xflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(P.xstat, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (a == epoch) { s.ok = 1; break; }
+                if (b == epoch) { s.ok = 0; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+    };
+    auto post_wave2 = [&](double* sm) {
+        bsum6(sm, s);
+        const int slot = bid - 1;
+        if (t == 0) { double* hp = P.hpart2 + 8 * slot; for (int e = 0; e < 6; ++e) hp[e] = sm[e]; }
+        post(P.hflag2 + slot);
+    };
+    // master side: one wave gathers the helper waves' sums (h[0..6)) and, when with1, the first pass's three numbers (h[6..9))
+    auto gather2 = [&](double* h, bool with1) {
+        const int ln = t & 63;
+        for (int e = 0; e < 9; ++e) h[e] = 0.0;
+        for (int s0 = 0; s0 < nhelp; s0 += 64) {
+            const int slot = s0 + ln;
+            if (slot < nhelp) {
+                wait1(P.hflag2 + slot);
+                for (int e = 0; e < 6; ++e) h[e] += __hip_atomic_load(P.hpart2 + 8 * slot + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (with1 && ln < nhelp) for (int e = 0; e < 3; ++e) h[6 + e] = __hip_atomic_load(P.hpart + 4 * ln + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int e = 0; e < 8; ++e) h[e] = wave_total_l63(h[e]);          // a fixed tree: deterministic
+        h[8] = wave_max_l63(h[8]);
+    };
     if (helper) {
-        const int hk = (int)blockIdx.x - 1;
+        const int hk = bid - 1;
         if (!s.c.done && s.need) {
             // camera vectors u = Sc gradient_/d in LDS (nothing global is written here: that is the master's job)
             for (int i = t; i < P.NV; i += NT) {
@@ -804,33 +896,79 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             __syncthreads();
             const int per = (L + nhelp - 1) / nhelp, l0 = hk * per, l1 = min(L, l0 + per);
             double q = 0, g2 = 0, gm = 0;
+            if (per <= NT) {
+                // one landmark per thread: its rows and scalars stay in registers between the two passes, the second pass
+                // (which the master waits for) reads only Sc x_p
+                const int l = l0 + t;
+                const bool have = l < l1;
+                LmRows r; r.fs = 0; r.fe = 0;
+                double ip = 0, b = 0, d = 1, g = 0, lam2 = 0, ipS = 0, Sd = 0, a_ = 0;      // ipS = invp / Sl, Sd = Sl / dl, a_ = la
+                if (have) {
+                    lm_rows(P, sb, l, r);
+                    ip = sb.invp[l]; b = sb.bl[l];
+                    const double Sl = sb.sl[l], h = sb.hll[l];
+                    if (!(P.lm_const && P.lm_const[l])) { const double lam = x[xo_lam(P) + l]; lam2 = lam * lam; }
+                    d = sqrt(fmin(fmax(Sl * Sl * h, 1e-6), 1e32));
+                    g = ip != 0.0 ? Sl * b / d : 0.0;
+                    P.dl[l] = d; P.gradl[l] = g;
+                    if (ip != 0.0) {
+                        Sd = Sl / d; ipS = ip / Sl;               // the divides of the second pass, done while the master solves
+                        const double ul = Sd * g;
+                        a_ = ul;
+                        const double ev = lm_dot_rows(P, sb, r, s.y);
+                        q += ip * ev * ev + 2.0 * ul * ev + h * ul * ul;
+                        g2 += g * g; gm = fmax(gm, fabs(b));
+                    }
+                }
+                bsum3<true>(g2, q, gm, s);
+                if (t == 0) { double* hp = P.hpart + 4 * hk; hp[0] = q; hp[1] = g2; hp[2] = gm; }
+                post(P.hflag + hk);
+                wait_x();
+                if (s.ok) {
+                    for (int i = t; i < P.NV; i += NT) s.gn[i] = __hip_atomic_load(P.stepc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __syncthreads();
+                    double sm[6] = {0, 0, 0, 0, 0, 0};
+                    double b_ = 0.0;
+                    if (have) {
+                        if (ip != 0.0) {
+                            const double xl = (b - lm_dot_rows(P, sb, r, s.gn)) * ipS;
+                            const double gnv = -xl * d;
+                            sm[0] = gnv * gnv; sm[1] = gnv * g;
+                            b_ = Sd * gnv;
+                            sm[2] = a_ * a_; sm[3] = a_ * b_; sm[4] = b_ * b_;
+                        }
+                        sm[5] = lam2;
+                    }
+                    post_wave2(sm);
+                    if (have) { P.la[l] = a_; P.lb[l] = b_; }      // (for the next sweep: not part of what the master waits for)
+                }
+                return;
+            }
             lm_pass1(l0, l1, s.y, q, g2, gm);
             bsum3<true>(g2, q, gm, s);
             if (t == 0) { double* hp = P.hpart + 4 * hk; hp[0] = q; hp[1] = g2; hp[2] = gm; }
             post(P.hflag + hk);
             // second pass once the master has the pose part of the solution
-            if (t == 0) { wait1(P.xflag); s.ok = __hip_atomic_load(P.xstat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            __syncthreads();
+            wait_x();
             if (s.ok) {
                 for (int i = t; i < P.NV; i += NT) s.y[i] = __hip_atomic_load(P.stepc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __syncthreads();
                 double sm[6] = {0, 0, 0, 0, 0, 0};
                 lm_pass2(l0, l1, s.y, sm);
-                bsum3(sm[0], sm[1], sm[2], s); bsum3(sm[3], sm[4], sm[5], s);
-                if (t == 0) { double* hp = P.hpart2 + 8 * hk; for (int k = 0; k < 6; ++k) hp[k] = sm[k]; }
-                post(P.hflag2 + hk);
+                post_wave2(sm);
             }
         } else post(P.hflag + hk);
         return;
     }
-    if (s.c.done) { if (t == 0) { wait_helpers(); *P.ctl = s.c; } return; }
+    if (s.c.done) { if (t < 64) { wait_helpers(); if (t == 0) *P.ctl = s.c; } return; }
+    for (int i = t; i < 16 * P.K + 8; i += NT) s.x0[i] = x[i];          // (read after several barriers)
+    for (int k = t; k < 2 * P.K; k += NT) s.cst[k] = k < P.K ? (P.pose_const ? P.pose_const[k] : 0) : (P.sb_const ? P.sb_const[k - P.K] : 0);
     bool xpub = false;                                 // the master owes the waiting helpers an xflag on every path through the need branch
     auto publish_xp = [&](int okk) {                   // called by all threads; s.y[0 .. NV) = x_p when okk
         if (nhelp) {
-            if (okk) for (int i = t; i < P.NV; i += NT) P.stepc[i] = s.sc[i] * s.y[i];
+            if (okk) { for (int i = t; i < P.NV; i += NT) P.stepc[i] = s.sc[i] * s.y[i]; __threadfence(); }      // (__syncthreads does not wait for global stores)
             __syncthreads();
-            if (t == 0) { __hip_atomic_store(P.xstat, okk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            post(P.xflag);
+            post(okk ? P.xflag : P.xstat);
         }
         xpub = true;
     };
@@ -863,7 +1001,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
             if (CHAIN == 3 && i >= P.NV) d = P.chDc[i - P.NV];      // the very numbers the chain workgroup scaled M_bb with
             const double g = Sc * b / d;
-            s.sc[i] = Sc; s.dcs[i] = d; s.gr[i] = g; s.y[i] = Sc * g / d; s.gd[i] = sb.gred[i];
+            s.sc[i] = Sc; s.dcs[i] = d; s.gr[i] = g; s.y[i] = Sc * g / d; s.gd[i] = sb.gred[i]; s.rt[i] = Sc / d;
             P.dc[i] = d; P.gradc[i] = g;
             if (cam) { g2 += g * g; gm = fmax(gm, fabs(b)); }
         }
@@ -878,8 +1016,14 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         if constexpr (CHAIN != 0) {
             __syncthreads();
             auto pub = [&]() { publish_xp(1); };
-            if constexpr (CHAIN == 3) ok = solve_prechain(P, sb, s, Alds, mu, cam, q, pub);
-            else ok = solve_chain<CHAIN == 1>(P, sb, s, Alds, mu, cam, q, pub);      // packing, chain, Schur update, dense part, back substitution
+            auto side = [&]() {            // last wave: the helpers' sums of both passes (hflag2 is posted after hflag) -> s.hs
+                if (!nhelp) return;
+                double h[9];
+                gather2(h, true);
+                if ((t & 63) == 63) for (int e = 0; e < 9; ++e) s.hs[e] = h[e];
+            };
+            if constexpr (CHAIN == 3) ok = solve_prechain(P, sb, s, Alds, mu, cam, q, pub, side);
+            else ok = solve_chain<CHAIN == 1>(P, sb, s, Alds, mu, cam, q, pub, side);      // packing, chain, Schur update, dense part, back substitution
         } else {
         // tiled storage: element e of the tile array -> (i, j); S entries were prefetched into registers at kernel start
         double* Ag = P.M;
@@ -923,23 +1067,28 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         }
         }
         STAMP(11);
-        bsum3<true>(g2, q, gm, s);
-        if (nhelp) {                          // the helpers' landmark sums, added in workgroup order (deterministic)
-            if (t == 0) {
+        // chain path with helpers: the solve is already behind us, so the helpers' first sums are collected together with
+        // their second ones (one block reduction, one poll, one round trip instead of two of each)
+        const bool defer = CHAIN != 0 && nhelp > 0 && ok;
+        if (!defer) bsum3<true>(g2, q, gm, s);
+        if (nhelp && !defer) {                // the helpers' landmark sums, added in workgroup order (deterministic)
+            if (t < 64) {                     // lane k fetches helper k's three numbers, lane 0 adds them in order
                 wait_helpers();
-                for (int k = 0; k < nhelp; ++k) {
-                    q += __hip_atomic_load(P.hpart + 4 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    g2 += __hip_atomic_load(P.hpart + 4 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    gm = fmax(gm, __hip_atomic_load(P.hpart + 4 * k + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                double h0 = 0, h1 = 0, h2 = 0;
+                if (t < nhelp) {
+                    h0 = __hip_atomic_load(P.hpart + 4 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    h1 = __hip_atomic_load(P.hpart + 4 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    h2 = __hip_atomic_load(P.hpart + 4 * t + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                s.red[0] = q; s.red[1] = g2; s.red[2] = gm;
+                for (int k = 0; k < nhelp; ++k) { q += __shfl(h0, k); g2 += __shfl(h1, k); gm = fmax(gm, __shfl(h2, k)); }
+                if (t == 0) { s.red[0] = q; s.red[1] = g2; s.red[2] = gm; }
             }
             __syncthreads();
             q = s.red[0]; g2 = s.red[1]; gm = s.red[2];
             __syncthreads();
         }
         STAMP(2);
-        if (gm <= O.gradient_tolerance) {
+        if (!defer && gm <= O.gradient_tolerance) {
             if (!xpub) publish_xp(0);
             if (t == 0) { s.c.done = 1; s.c.term = 2; *P.ctl = s.c; }
             return;
@@ -980,18 +1129,28 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         double sm[6] = {0, 0, 0, 0, 0, 0};
         if (!nhelp) lm_pass2(0, L, s.y, sm);
         sm[0] += gn2; sm[1] += gg;
-        bsum3(sm[0], sm[1], sm[2], s); bsum3(sm[3], sm[4], sm[5], s);
+        if (defer) bsum5(g2, q, gm, sm[0], sm[1], s);
+        else { bsum3(sm[0], sm[1], sm[2], s); if (!nhelp) bsum3(sm[3], sm[4], sm[5], s); }      // (with helpers the master's share of the last three is zero)
+        if (defer) {                              // the helpers' nine numbers are already in LDS (side(), above)
+            hseen = true;
+            for (int e = 0; e < 6; ++e) sm[e] += s.hs[e];
+            q += s.hs[6]; g2 += s.hs[7]; gm = fmax(gm, s.hs[8]);
+        }
         if (nhelp) {
-            if (t == 0) {
-                for (int k = 0; k < nhelp; ++k) {
-                    wait1(P.hflag2 + k);
-                    for (int e = 0; e < 6; ++e) sm[e] += __hip_atomic_load(P.hpart2 + 8 * k + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                for (int e = 0; e < 6; ++e) s.red[e] = sm[e];
+            if (!defer) {
+            if (t < 64) {
+                double h[9];
+                gather2(h, false);
+                if (t == 63) for (int e = 0; e < 6; ++e) s.red[e] = sm[e] + h[e];
             }
             __syncthreads();
             for (int e = 0; e < 6; ++e) sm[e] = s.red[e];
             __syncthreads();
+            }
+            if (defer && gm <= O.gradient_tolerance) {          // (the check the other paths make before the factorisation)
+                if (t == 0) { s.c.done = 1; s.c.term = 2; *P.ctl = s.c; }
+                return;
+            }
         }
         gn2 = sm[0]; gg = sm[1];
         if (t == 0) {
@@ -1002,7 +1161,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         }
         __syncthreads();
     } else {
-        for (int i = t; i < D; i += NT) { s.sc[i] = P.Sc[i]; s.dcs[i] = P.dc[i]; s.gr[i] = P.gradc[i]; s.gn[i] = P.gnc[i]; }
+        for (int i = t; i < D; i += NT) { s.sc[i] = P.Sc[i]; s.dcs[i] = P.dc[i]; s.gr[i] = P.gradc[i]; s.gn[i] = P.gnc[i]; s.rt[i] = s.sc[i] / s.dcs[i]; }
         __syncthreads();
     }
     STAMP(5);
@@ -1028,27 +1187,27 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     const double gd = cg * g2 + cn * gg;
     const double model_change = -(0.5 * qd + gd);
     // ---------------- candidate state x_cur (+) step: camera blocks here, inverse depths in the next sweep ----------------------
-    for (int i = t; i < D; i += NT) s.y[i] = s.sc[i] * (cg * s.gr[i] + cn * s.gn[i]) / s.dcs[i];
+    for (int i = t; i < D; i += NT) s.y[i] = (cg * s.gr[i] + cn * s.gn[i]) * s.rt[i];
     __syncthreads();
     const double* stepc = s.y;
     double xn = 0, sn = 0;
     const int K = P.K;
     for (int k = t; k < 2 * K + 2; k += NT) {
         if (k < K) {
-            const double* in = x + xo_pose(P, k); double* o = xc + xo_pose(P, k);
-            if (P.pose_const && P.pose_const[k]) { for (int q = 0; q < 7; ++q) o[q] = in[q]; }
+            const double* in = s.x0 + xo_pose(P, k); double* o = xc + xo_pose(P, k);
+            if (s.cst[k]) { for (int q = 0; q < 7; ++q) o[q] = in[q]; }
             else { pose_plus(in, stepc + col_pose(P, k), o); if (cam) for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
         } else if (k < 2 * K) {
             const int kk = k - K;
-            const double* in = x + xo_sb(P, kk); double* o = xc + xo_sb(P, kk);
-            const bool cst = P.sb_const && P.sb_const[kk];
+            const double* in = s.x0 + xo_sb(P, kk); double* o = xc + xo_sb(P, kk);
+            const bool cst = s.cst[K + kk] != 0;
             for (int q = 0; q < 9; ++q) { const double d = cst ? 0.0 : stepc[col_sb(P, kk) + q]; o[q] = in[q] + d; if (!cst && cam) { xn += in[q] * in[q]; sn += d * d; } }
         } else if (k == 2 * K) {
-            const double* in = x + xo_ex(P); double* o = xc + xo_ex(P);
+            const double* in = s.x0 + xo_ex(P); double* o = xc + xo_ex(P);
             if (P.ex_const) { for (int q = 0; q < 7; ++q) o[q] = in[q]; }
             else { pose_plus(in, stepc + col_ex(P), o); if (cam) for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
         } else {
-            const double in = x[xo_td(P)];
+            const double in = s.x0[xo_td(P)];
             const double d = P.td_free ? stepc[col_td(P)] : 0.0;
             xc[xo_td(P)] = in + d;
             if (P.td_free && cam) { xn += in * in; sn += d * d; }
@@ -1077,7 +1236,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         }
     }
     __syncthreads();
-    if (s.c.resweep && !s.c.done) { for (int i = t; i < 16 * P.K + 8; i += NT) xc[i] = x[i]; }
+    if (s.c.resweep && !s.c.done) { for (int i = t; i < 16 * P.K + 8; i += NT) xc[i] = s.x0[i]; }
     STAMP(7);
-    if (t == 0) { if (nhelp) wait_helpers(); *P.ctl = s.c; }      // (idempotent when the sums were already collected)
+    if (t < 64) { if (nhelp) wait_helpers(); if (t == 0) *P.ctl = s.c; }      // (no second poll when the sums were already collected)
 }

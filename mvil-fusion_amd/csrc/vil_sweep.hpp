@@ -473,8 +473,9 @@ __device__ __forceinline__ int imu_local(const DevP& P, int i, int j, int col) {
 // Epoch of the flags: solve generation + Ctl::swe, which only the step kernel advances (n_sweeps is bumped by block 0 of the
 // sweep itself, so workgroups of one launch may read either value of it).
 __device__ __forceinline__ void sweep_signal(const DevP& P, const Ctl& ctl, int slot) {     // this workgroup's record is complete
+    __threadfence();                 // every wave's stores of the record (__syncthreads alone does not wait for global stores)
     __syncthreads();
-    if (threadIdx.x == 0) { __threadfence(); __hip_atomic_store(P.swflag + slot, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+    if (threadIdx.x == 0) { __hip_atomic_store(P.swflag + slot, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 // Gather of the sweep's partial records into the dense reduced system of the candidate set:
