@@ -30,12 +30,13 @@
 #define VG_ERR_DEVICE -2
 #define VG_ERR_NONFINITE -3
 #define VG_THREADS 256
+#define VGA_THREADS 512     // k_vgicp_align: one slot per thread on the usual scan (a pass is a chain of dependent gathers per slot; two waves per SIMD hide part of it)
 #define VGCHK(x) do { if ((x) != hipSuccess) return VG_ERR_DEVICE; } while (0)
 
 namespace {
 
 struct Iso { double m[12]; };                       // rows of [R | t]
-struct VoxTab { const long long* keys; const int* slot_vox; int mask; const int* num; const double* mean; const double* cov; };   // mean 3 x nv, cov 9 x nv (SoA)
+struct VoxTab { const long long* keys; const int* slot_vox; int mask; const int* num; const double* mean; const double* cov; const double* wsq; };   // mean 3 x nv, cov 9 x nv (SoA); wsq = sqrt(num), rounded once on the host
 
 using vknn::pack_key; using vknn::hash_key;
 
@@ -43,7 +44,7 @@ __device__ __forceinline__ double wave_sum64(double v) { return vd::wave_total(v
 
 __device__ __forceinline__ void inv3(const double* a, double* o) {
     const double c0 = a[4] * a[8] - a[5] * a[7], c1 = a[5] * a[6] - a[3] * a[8], c2 = a[3] * a[7] - a[4] * a[6];
-    const double id = 1.0 / (a[0] * c0 + a[1] * c1 + a[2] * c2);
+    const double id = vd::rcp_nr(a[0] * c0 + a[1] * c1 + a[2] * c2);      // (1-2 ulp; the IEEE divide is a 1 k-cycle chain in the middle of every slot)
     o[0] = c0 * id; o[1] = (a[2] * a[7] - a[1] * a[8]) * id; o[2] = (a[1] * a[5] - a[2] * a[4]) * id;
     o[3] = c1 * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
     o[6] = c2 * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
@@ -67,30 +68,45 @@ __device__ __forceinline__ void block_fold(double* v, double* part /* gridDim.x 
     if (threadIdx.x < NV) part[(size_t)blockIdx.x * NV + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
+// floor(x / res - 0.5) of fast_vgicp_voxel.hpp:140 without the IEEE divide on every slot's dependent chain: x * (1 / res) is within a
+// few ulp of the quotient, so the floor can only differ when that product sits within 1e-9 (relative) of a cell boundary -- those
+// lanes (about one in 1e8) take the exact expression
+__device__ __forceinline__ int vox_coord(double x, double res, double ires) {
+    const double q = x * ires - 0.5, f = floor(q);
+    const double m = fmin(q - f, f + 1.0 - q);
+    if (m <= 1e-9 * (fabs(q) + 1.0)) return (int)floor(x / res - 0.5);
+    return (int)f;
+}
 // FastVGICP::update_correspondences + linearize (fast_vgicp_impl.hpp:73-170) for ONE (source point, offset) slot: the
 // correspondence (voxel id + Mahalanobis matrix) is stored, the 29 sums are ADDED to acc (21 H upper | 6 b | error | count)
 __device__ __forceinline__ void vgicp_lin_slot(int tid, int noff, const float* __restrict__ sxyz, const double* __restrict__ scov, const Iso& T, double res, const VoxTab& V,
                                                int* __restrict__ c_vox, double* __restrict__ c_M, double* acc, int want_H) {
         const int i = tid / noff, o = tid - i * noff;
+        const double ires = vd::rcp_nr(res);
         const double ax = (double)sxyz[3 * i], ay = (double)sxyz[3 * i + 1], az = (double)sxyz[3 * i + 2];
         const double tx = T.m[0] * ax + T.m[1] * ay + T.m[2] * az + T.m[3];
         const double ty = T.m[4] * ax + T.m[5] * ay + T.m[6] * az + T.m[7];
         const double tz = T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11];
-        int kx = (int)floor(tx / res - 0.5), ky = (int)floor(ty / res - 0.5), kz = (int)floor(tz / res - 0.5);
+        int kx = vox_coord(tx, res, ires), ky = vox_coord(ty, res, ires), kz = vox_coord(tz, res, ires);
         if (noff == 7) { const int d = (o + 1) >> 1, s = (o & 1) ? 1 : -1; if (o) { if (d == 1) kx += s; else if (d == 2) ky += s; else kz += s; } }   // (0) (+x -x) (+y -y) (+z -z)
         else if (noff == 27) { kx += o / 9 - 1; ky += (o / 3) % 3 - 1; kz += o % 3 - 1; }
         const long long key = pack_key(kx, ky, kz);
+        // the source covariance does not depend on the probe: its loads go out before the dependent chain key -> voxel -> mean / cov
+        double ca[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) ca[q] = scov[(size_t)9 * i + q];
         int v = -1;
         for (unsigned h = hash_key(key) & V.mask;; h = (h + 1) & V.mask) {      // linear probing; the table is never full
             const long long k = V.keys[h];
-            if (k == key) { v = V.slot_vox[h]; break; }
+            const int sv = V.slot_vox[h];                                        // (same index as the key: one round trip, not two)
+            if (k == key) { v = sv; break; }
             if (k < 0) break;
         }
         c_vox[tid] = v;
         if (v >= 0) {
-            double ca[9], cb[9], RC[9], RCR[9], M[9];
+            double cb[9], RC[9], RCR[9], M[9];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) { ca[q] = scov[(size_t)9 * i + q]; cb[q] = V.cov[(size_t)9 * v + q]; }
+            for (int q = 0; q < 9; ++q) cb[q] = V.cov[(size_t)9 * v + q];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -103,7 +119,7 @@ __device__ __forceinline__ void vgicp_lin_slot(int tid, int noff, const float* _
 #pragma unroll
             for (int q = 0; q < 9; ++q) c_M[(size_t)9 * tid + q] = M[q];
             const double e0 = V.mean[(size_t)3 * v] - tx, e1 = V.mean[(size_t)3 * v + 1] - ty, e2 = V.mean[(size_t)3 * v + 2] - tz;
-            const double w = sqrt((double)V.num[v]);
+            const double w = V.wsq[v];
             const double m0 = M[0] * e0 + M[1] * e1 + M[2] * e2, m1 = M[3] * e0 + M[4] * e1 + M[5] * e2, m2 = M[6] * e0 + M[7] * e1 + M[8] * e2;
             acc[27] += w * (e0 * m0 + e1 * m1 + e2 * m2); acc[28] += 1.0;
             if (want_H) {
@@ -147,7 +163,7 @@ __device__ __forceinline__ double vgicp_err_slot(int tid, int noff, const float*
     const double e2 = V.mean[(size_t)3 * v + 2] - (T.m[8] * ax + T.m[9] * ay + T.m[10] * az + T.m[11]);
     const double* M = c_M + (size_t)9 * tid;
     const double m0 = M[0] * e0 + M[1] * e1 + M[2] * e2, m1 = M[3] * e0 + M[4] * e1 + M[5] * e2, m2 = M[6] * e0 + M[7] * e1 + M[8] * e2;
-    return sqrt((double)V.num[v]) * (e0 * m0 + e1 * m1 + e2 * m2);
+    return V.wsq[v] * (e0 * m0 + e1 * m1 + e2 * m2);
 }
 __global__ __launch_bounds__(VG_THREADS) void k_vgicp_err(int ncorr_slots, int noff, const float* __restrict__ sxyz, Iso T, VoxTab V, const int* __restrict__ c_vox, const double* __restrict__ c_M, double* __restrict__ part) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -268,11 +284,12 @@ struct vgicp_ctx {
     hipStream_t stream = nullptr;
     // target voxel map
     double res = 1.0; int nvox = 0, cap = 0;
-    long long* d_keys = nullptr; int* d_slot = nullptr; int* d_num = nullptr; double* d_mean = nullptr; double* d_cov = nullptr;
+    long long* d_keys = nullptr; int* d_slot = nullptr; int* d_num = nullptr; double* d_mean = nullptr; double* d_cov = nullptr; double* d_wsq = nullptr;
     // source
     int n = 0; float* d_sxyz = nullptr; double* d_scov = nullptr;
     // correspondences of the last linearisation
     int noff = 1, slots = 0, slots_cap = 0; int* d_cvox = nullptr; double* d_cM = nullptr;
+    int slots_cap2 = 0; int* d_cvox2 = nullptr; double* d_cM2 = nullptr;            // second correspondence cache of k_vgicp_align (speculative linearisation)
     double* d_part = nullptr; int part_cap = 0; double* d_out = nullptr; double* h_out = nullptr;
     bool linearized = false;
     bool profiling = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; long long prof_n = 0; double prof_ms = 0.0;
@@ -281,11 +298,11 @@ struct vgicp_ctx {
     vknn::GridBuild gb; float grid_h = 1.0f; int* d_nn = nullptr; size_t nn_cap = 0;
 };
 
-static void free_target(vgicp_ctx* c) { hipFree(c->d_keys); hipFree(c->d_slot); hipFree(c->d_num); hipFree(c->d_mean); hipFree(c->d_cov); c->d_keys = nullptr; c->d_slot = nullptr; c->d_num = nullptr; c->d_mean = nullptr; c->d_cov = nullptr; c->nvox = 0; }
+static void free_target(vgicp_ctx* c) { hipFree(c->d_keys); hipFree(c->d_slot); hipFree(c->d_num); hipFree(c->d_mean); hipFree(c->d_cov); hipFree(c->d_wsq); c->d_wsq = nullptr; c->d_keys = nullptr; c->d_slot = nullptr; c->d_num = nullptr; c->d_mean = nullptr; c->d_cov = nullptr; c->nvox = 0; }
 static void free_source(vgicp_ctx* c) { hipFree(c->d_sxyz); hipFree(c->d_scov); c->d_sxyz = nullptr; c->d_scov = nullptr; c->n = 0; }
 
 static Iso to_iso(const double* T) { Iso r; for (int q = 0; q < 12; ++q) r.m[q] = T[q]; return r; }
-static VoxTab tab(const vgicp_ctx* c) { return VoxTab{c->d_keys, c->d_slot, c->cap - 1, c->d_num, c->d_mean, c->d_cov}; }
+static VoxTab tab(const vgicp_ctx* c) { return VoxTab{c->d_keys, c->d_slot, c->cap - 1, c->d_num, c->d_mean, c->d_cov, c->d_wsq}; }
 
 // device covariances of a device-resident cloud (d_xyz) into d_cov (n x 9)
 static int covariances_dev(vgicp_ctx* c, int n, const float* d_xyz, int k, double* d_cov) {
@@ -337,9 +354,9 @@ void vgicp_destroy(vgicp_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     free_target(c); free_source(c);
-    hipFree(c->d_cvox); hipFree(c->d_cM); hipFree(c->d_part); hipFree(c->d_out); if (c->h_out) hipHostFree(c->h_out);
+    hipFree(c->d_cvox); hipFree(c->d_cM); hipFree(c->d_cvox2); hipFree(c->d_cM2); hipFree(c->d_part); hipFree(c->d_out); if (c->h_out) hipHostFree(c->h_out);
     hipFree(c->gb.ws); hipFree(c->d_nn);
-    if (c->d_coop) hipFree(c->d_coop); if (c->d_aout) hipFree(c->d_aout); if (c->h_aout) hipHostFree(c->h_aout);
+    if (c->d_coop) hipFree(c->d_coop); if (c->h_aout) hipHostFree(c->h_aout);
     if (c->ev0) { hipEventDestroy(c->ev0); hipEventDestroy(c->ev1); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -381,6 +398,7 @@ int vgicp_set_target(vgicp_ctx* c, int32_t n, const float* xyz, const double* co
     VGCHK(hipMalloc(&c->d_keys, 8 * (size_t)cap)); VGCHK(hipMalloc(&c->d_slot, 4 * (size_t)cap)); VGCHK(hipMalloc(&c->d_num, 4 * (size_t)nv));
     VGCHK(hipMalloc(&c->d_mean, 8 * 3 * (size_t)nv)); VGCHK(hipMalloc(&c->d_cov, 8 * 9 * (size_t)nv));
     VGCHK(hipMemcpy(c->d_keys, tkeys.data(), 8 * (size_t)cap, hipMemcpyHostToDevice)); VGCHK(hipMemcpy(c->d_slot, tslot.data(), 4 * (size_t)cap, hipMemcpyHostToDevice));
+    { std::vector<double> wsq((size_t)nv); for (int v = 0; v < nv; ++v) wsq[v] = std::sqrt((double)num[v]); VGCHK(hipMalloc(&c->d_wsq, 8 * (size_t)nv)); VGCHK(hipMemcpy(c->d_wsq, wsq.data(), 8 * (size_t)nv, hipMemcpyHostToDevice)); }
     VGCHK(hipMemcpy(c->d_num, num.data(), 4 * (size_t)nv, hipMemcpyHostToDevice)); VGCHK(hipMemcpy(c->d_mean, mean.data(), 8 * 3 * (size_t)nv, hipMemcpyHostToDevice));
     VGCHK(hipMemcpy(c->d_cov, cov.data(), 8 * 9 * (size_t)nv, hipMemcpyHostToDevice));
     c->res = resolution; c->nvox = nv; c->cap = cap; c->linearized = false;
@@ -490,11 +508,20 @@ __device__ static void compose_R(const double* d, const double* x0, double* xi, 
     }
     xi[12] = 0; xi[13] = 0; xi[14] = 0; xi[15] = 1;
 }
+// is_converged without its twelve divides (one lane, every workgroup waiting): for eps > 0, fl(a / eps) < 1 exactly when a < eps
+// (a < eps: the quotient is below 1 and rounds to at most the largest double below 1; a >= eps: it is at least 1), and the
+// maximum is below 1 exactly when every term is -- the same decision, bit for bit
 __device__ static bool converged_R(const double* R, const double* d, double reps, double teps) {
-    double m = 0;
-    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) m = fmax(m, fabs(R[3 * r + q] - (r == q ? 1.0 : 0.0)) / reps);
-    for (int r = 0; r < 3; ++r) m = fmax(m, fabs(d[3 + r]) / teps);
-    return m < 1;
+    if (!(reps > 0.0) || !(teps > 0.0)) {
+        double m = 0;
+        for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) m = fmax(m, fabs(R[3 * r + q] - (r == q ? 1.0 : 0.0)) / reps);
+        for (int r = 0; r < 3; ++r) m = fmax(m, fabs(d[3 + r]) / teps);
+        return m < 1;
+    }
+    bool ok = true;
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) ok = ok && fabs(R[3 * r + q] - (r == q ? 1.0 : 0.0)) < reps;
+    for (int r = 0; r < 3; ++r) ok = ok && fabs(d[3 + r]) < teps;
+    return ok;
 }
 __host__ __device__ static bool is_converged(const double* d, double reps, double teps) {
     double R[9]; so3_exp_R(d, R);
@@ -507,19 +534,54 @@ __host__ __device__ static bool is_converged(const double* d, double reps, doubl
 }  // extern "C"
 
 // ---- the whole LsqRegistration::align loop (lsq_registration_impl.hpp:48-165) in ONE launch ------------------------------------
-// G resident workgroups share the slots; every pass (a linearisation at x0, or the error of a trial transform with the stored
-// correspondences) ends in a symmetric exchange: each workgroup publishes its partial sums + an epoch flag, waits for all
+// G resident workgroups share the slots.  Passes: (1) a linearisation at x0; (3) Levenberg-Marquardt's trial -- the error of the
+// trial transform xi with the stored correspondences AND, in the same sweep over the slots, the linearisation at xi with fresh
+// correspondences into the other cache: when the trial is accepted (the usual case) xi is the next x0 and that linearisation
+// is exactly the one the next iteration would have computed (same slots per thread, same order of sums: the same bits), so an
+// iteration costs one pass instead of two; a rejected trial just discards it.  Every pass ends in a symmetric exchange: each workgroup publishes its partial sums + an epoch flag, waits for all
 // flags, adds all partials in workgroup order -- the same bits everywhere -- and its thread 0 advances the same Levenberg-
 // Marquardt / Gauss-Newton state machine on them.  Identical code on identical numbers: every workgroup arrives at the same
 // next transform, so a pass costs one exchange and the host sees one launch and one 0.5 kB read-back per alignment.
-#define VG_MAXG 64
+#define VG_MAXG 128
 struct VgCoop { int flag[VG_MAXG]; double part[2][VG_MAXG][32]; };
 struct VgAlignOut { double T[16]; double H[36]; double err; int iterations, converged, n_corr, lm_failed, status, pad; };
+struct VgGuess { double m[16]; };      // the initial transform travels in the kernel arguments, the result is written straight into pinned host memory
 struct VgLm {                          // state of the optimiser (thread 0 of every workgroup)
     double x0[16], xi[16], H[36], Hout[36], b[6], d[6], Rd[9];      // Rd: rotation of the current increment d
     double lambda, nu, y0;
     int it, inner, converged, lm_failed, n_corr, phase;     // phase 1: linearise at x0, 2: error at xi
+    int flip;                                               // set when the speculative linearisation was taken: its cache becomes the current one
 };
+// solve6 for the one lane that advances the optimiser between two passes (every workgroup waits for it): right-looking Cholesky
+// with reciprocal pivots from v_rsq_f64 + two Newton steps (1-2 ulp) -- no IEEE divide or square root on the dependent chain
+// (those cost about 1 k cycles each in one lane; solve6 has 33 of them in sequence).  Same algebra, same failure rule.
+__device__ static bool solve6_dev(const double* A, const double* rhs, double* x) {
+    double a[6][6], ri[6], y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) a[i][j] = A[6 * i + j];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const double d = a[j][j];
+        ok = ok && d > 0.0;
+        const double r = vd::rsqrt_nr(d);
+        ri[j] = r;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) a[i][j] *= r;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i)
+#pragma unroll
+            for (int k = j + 1; k <= i; ++k) a[i][k] -= a[i][j] * a[k][j];
+    }
+    if (!ok) return false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { double s = rhs[i]; for (int k = 0; k < i; ++k) s -= a[i][k] * y[k]; y[i] = s * ri[i]; }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= a[k][i] * x[k]; x[i] = s * ri[i]; }
+    return true;
+}
 // consumes the sums of the pass just exchanged, returns the next pass (0 = finished); mirrors the host loop statement by statement
 __device__ static int vg_lm_advance(VgLm& L, const double* tot, const vgicp_options& o) {
     if (L.phase == 1) {
@@ -529,7 +591,7 @@ __device__ static int vg_lm_advance(VgLm& L, const double* tot, const vgicp_opti
         double nb[6];
         for (int k = 0; k < 6; ++k) { nb[k] = -L.b[k]; L.d[k] = 0.0; }
         if (o.optimizer == VGICP_GN) {
-            if (!solve6(L.H, nb, L.d)) { L.lm_failed = 1; return 0; }
+            if (!solve6_dev(L.H, nb, L.d)) { L.lm_failed = 1; return 0; }
             compose_R(L.d, L.x0, L.xi, L.Rd);
             for (int k = 0; k < 16; ++k) L.x0[k] = L.xi[k];
             for (int k = 0; k < 36; ++k) L.Hout[k] = L.H[k];
@@ -541,7 +603,8 @@ __device__ static int vg_lm_advance(VgLm& L, const double* tot, const vgicp_opti
         L.nu = 2.0; L.inner = 0;
     } else {
         // trial step evaluated: accept / reject (step_lm)
-        const double yi = tot[0];
+        const double yi = tot[29];
+        bool moved = false;
         double den = 0; for (int k = 0; k < 6; ++k) den += L.d[k] * (L.lambda * L.d[k] - L.b[k]);
         const double rho = (L.y0 - yi) / den;
         bool stepped = false;
@@ -553,13 +616,20 @@ __device__ static int vg_lm_advance(VgLm& L, const double* tot, const vgicp_opti
             const double c3 = 2 * rho - 1;
             L.lambda = L.lambda * fmax(1.0 / 3.0, 1 - c3 * c3 * c3);
             for (int k = 0; k < 36; ++k) L.Hout[k] = L.H[k];
-            stepped = true;
+            stepped = true; moved = true;
         }
         if (stepped) {
             ++L.it;
             L.converged = converged_R(L.Rd, L.d, o.rotation_epsilon, o.transformation_epsilon) ? 1 : 0;
             if (L.converged || L.it >= o.max_iterations) return 0;
-            L.phase = 1; return 1;
+            if (!moved) { L.phase = 1; return 1; }           // x0 stayed: the linearisation at xi is of no use
+            // x0 = xi: the pass that judged the trial has linearised there already (tot[0 .. 29), correspondences in the other cache)
+            if (!isfinite(tot[27])) { L.lm_failed = -1; return 0; }
+            L.flip = 1;
+            int idx = 0;
+            for (int p = 0; p < 6; ++p) { for (int q = p; q < 6; ++q) { L.H[6 * p + q] = tot[idx]; L.H[6 * q + p] = tot[idx]; ++idx; } L.b[p] = tot[21 + p]; }
+            L.y0 = tot[27]; L.n_corr = (int)tot[28];
+            L.nu = 2.0; L.inner = 0;
         }
     }
     // next trial of the inner loop: damped solve until one succeeds or the budget is spent
@@ -567,78 +637,129 @@ __device__ static int vg_lm_advance(VgLm& L, const double* tot, const vgicp_opti
     for (; L.inner < o.lm_max_iterations; ++L.inner) {
         double Hl[36]; for (int k = 0; k < 36; ++k) Hl[k] = L.H[k];
         for (int k = 0; k < 6; ++k) Hl[7 * k] += L.lambda;
-        if (!solve6(Hl, nb, L.d)) { L.lambda = L.nu * L.lambda; L.nu = 2 * L.nu; continue; }
+        if (!solve6_dev(Hl, nb, L.d)) { L.lambda = L.nu * L.lambda; L.nu = 2 * L.nu; continue; }
         compose_R(L.d, L.x0, L.xi, L.Rd);
-        L.phase = 2; return 2;
+        L.phase = 2; return 3;
     }
     L.lm_failed = 1; ++L.it;                              // "lm not converged!!"
     return 0;
 }
 
-__global__ __launch_bounds__(VG_THREADS) void k_vgicp_align(int n, int noff, const float* __restrict__ sxyz, const double* __restrict__ scov, double res, VoxTab V,
-                                                            int* __restrict__ c_vox, double* __restrict__ c_M, vgicp_options o, VgCoop* coop, int epoch, VgAlignOut* out) {
+__global__ __launch_bounds__(VGA_THREADS) void k_vgicp_align(int n, int noff, const float* __restrict__ sxyz, const double* __restrict__ scov, double res, VoxTab V,
+                                                            int* __restrict__ c_vox0, double* __restrict__ c_M0, int* __restrict__ c_vox1, double* __restrict__ c_M1,
+                                                            vgicp_options o, VgCoop* coop, int epoch, VgGuess guess, VgAlignOut* out) {
     __shared__ VgLm L;
-    __shared__ double mine[4][29], gath[VG_MAXG][29 + 1], tot[32];
-    __shared__ Iso Tsh; __shared__ int action;
+    __shared__ double mine[VGA_THREADS / 64][30], gath[VGA_THREADS / 32][32], tot[32];
+    __shared__ Iso Tsh; __shared__ int action, cbuf;
     const int t = threadIdx.x, g = blockIdx.x, G = gridDim.x, slots = n * noff;
     if (t == 0) {
-        for (int k = 0; k < 16; ++k) L.x0[k] = out->T[k];             // the guess arrives in the output record
+        for (int k = 0; k < 16; ++k) L.x0[k] = guess.m[k];
         for (int k = 0; k < 36; ++k) L.Hout[k] = (k % 7 == 0) ? 1.0 : 0.0;
-        L.lambda = -1.0; L.nu = 2.0; L.y0 = 0.0; L.it = 0; L.inner = 0; L.converged = 0; L.lm_failed = 0; L.n_corr = 0; L.phase = 1;
+        L.lambda = -1.0; L.nu = 2.0; L.y0 = 0.0; L.it = 0; L.inner = 0; L.converged = 0; L.lm_failed = 0; L.n_corr = 0; L.phase = 1; L.flip = 0; cbuf = 0;
         for (int q = 0; q < 12; ++q) Tsh.m[q] = L.x0[q];
         action = o.max_iterations > 0 ? 1 : 0;
     }
     __syncthreads();
+#ifdef VG_STAMPS
+    long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sp = wall_clock64(), sq; int npass = 0;
+    #define VGS(k) do { sq = wall_clock64(); st[k] += sq - sp; sp = sq; } while (0)
+#else
+    #define VGS(k)
+#endif
     while (action) {
         ++epoch;
-        const int nv = action == 1 ? 29 : 1;
+        VGS(7);
+        const int nv = action == 1 ? 29 : 30;
         const Iso T = Tsh;
-        double acc[29];
+        int* const cv_cur = cbuf ? c_vox1 : c_vox0; double* const cM_cur = cbuf ? c_M1 : c_M0;
+        int* const cv_new = cbuf ? c_vox0 : c_vox1; double* const cM_new = cbuf ? c_M0 : c_M1;
+        double acc[29], eacc = 0.0;
 #pragma unroll
         for (int q = 0; q < 29; ++q) acc[q] = 0.0;
-        if (action == 1) { for (int tid = g * VG_THREADS + t; tid < slots; tid += G * VG_THREADS) vgicp_lin_slot(tid, noff, sxyz, scov, T, res, V, c_vox, c_M, acc, 1); }
-        else { for (int tid = g * VG_THREADS + t; tid < slots; tid += G * VG_THREADS) acc[0] += vgicp_err_slot(tid, noff, sxyz, T, V, c_vox, c_M); }
+        if (action == 1) { for (int tid = g * VGA_THREADS + t; tid < slots; tid += G * VGA_THREADS) vgicp_lin_slot(tid, noff, sxyz, scov, T, res, V, cv_cur, cM_cur, acc, 1); }
+        else {
+            for (int tid = g * VGA_THREADS + t; tid < slots; tid += G * VGA_THREADS) {
+                eacc += vgicp_err_slot(tid, noff, sxyz, T, V, cv_cur, cM_cur);
+                vgicp_lin_slot(tid, noff, sxyz, scov, T, res, V, cv_new, cM_new, acc, 1);
+            }
+        }
+        VGS(0);
         {   // workgroup fold (as block_fold), result in mine
             const int lane = t & 63, wave = t >> 6;
-            if (action == 1) {
-                double f0, f1;
-                vd::wave_fold<29>(acc, f0, f1);
-                if (lane < 16) { const int q = vd::fold_slot(lane); if (q < 29) mine[wave][q] = f0; if (q + 16 < 29) mine[wave][q + 16] = f1; }
-            } else { const double v = wave_sum64(acc[0]); if (lane == 0) mine[wave][0] = v; }
+            double f0, f1;
+            vd::wave_fold<29>(acc, f0, f1);
+            if (lane < 16) { const int q = vd::fold_slot(lane); if (q < 29) mine[wave][q] = f0; if (q + 16 < 29) mine[wave][q + 16] = f1; }
+            if (action != 1) { const double v = wave_sum64(eacc); if (lane == 0) mine[wave][29] = v; }
         }
         __syncthreads();
         double (*part)[32] = coop->part[epoch & 1];
-        if (t < nv) __hip_atomic_store(&part[g][t], (mine[0][t] + mine[1][t]) + (mine[2][t] + mine[3][t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < 64) {                      // wave 0 publishes: its lanes' stores, then lane 0's release (a fence waits for the whole wave's stores)
+            if (t < nv) {
+                double ws = 0.0;
+#pragma unroll
+                for (int w = 0; w < VGA_THREADS / 64; w += 4) ws += (mine[w][t] + mine[w + 1][t]) + (mine[w + 2][t] + mine[w + 3][t]);      // fixed order
+                __hip_atomic_store(&part[g][t], ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // everything another workgroup reads from this one (the partials) was stored with agent-scope atomics, i.e. at the level
+            // all XCDs share: waiting for those stores is all the ordering the flag needs -- a release fence would also write back
+            // this XCD's whole L2 (the correspondence cache just written), an acquire on the other side would invalidate theirs
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (t == 0) __hip_atomic_store(&coop->flag[g], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        VGS(1);
+        if (t < G) while (__hip_atomic_load(&coop->flag[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) __builtin_amdgcn_s_sleep(1);
         __syncthreads();
-        if (t == 0) { __threadfence(); __hip_atomic_store(&coop->flag[g], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-        if (t < G) while (__hip_atomic_load(&coop->flag[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) __builtin_amdgcn_s_sleep(1);
-        __syncthreads();
-        {   // <= 29 x 64 values: every load issued before the first use (the gather is bound by L2 round trips)
-            constexpr int NLD = (29 * VG_MAXG + VG_THREADS - 1) / VG_THREADS;
+        VGS(2);
+        {   // thread (chunk c = t / 32, value q = t % 32) adds the partials of workgroups c, c + 16, ... in that order -- every load issued
+            // before the first add (the gather is bound by L2 round trips) -- then 16 chunk sums per value are combined by a fixed tree
+            constexpr int NCH = VGA_THREADS / 32, NLD = (VG_MAXG + NCH - 1) / NCH;
+            const int q = t & 31, c = t >> 5;
             double gv[NLD];
 #pragma unroll
-            for (int u = 0; u < NLD; ++u) { const int e = t + u * VG_THREADS, w = e / nv, q = e - w * nv; gv[u] = e < G * nv ? __hip_atomic_load(&part[w][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }
+            for (int u = 0; u < NLD; ++u) { const int w = c + u * NCH; gv[u] = (w < G && q < nv) ? __hip_atomic_load(&part[w][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0; }
+            double cs = 0.0;
 #pragma unroll
-            for (int u = 0; u < NLD; ++u) { const int e = t + u * VG_THREADS, w = e / nv, q = e - w * nv; if (e < G * nv) gath[w][q] = gv[u]; }
+            for (int u = 0; u < NLD; ++u) cs += gv[u];
+            gath[c][q] = cs;
         }
         __syncthreads();
-        if (t < nv) { double sacc = 0.0; for (int w = 0; w < G; ++w) sacc += gath[w][t]; tot[t] = sacc; }
+        if (t < nv) {
+            double r[VGA_THREADS / 32];
+#pragma unroll
+            for (int c = 0; c < VGA_THREADS / 32; ++c) r[c] = gath[c][t];
+#pragma unroll
+            for (int st = 1; st < VGA_THREADS / 32; st <<= 1)
+#pragma unroll
+                for (int c = 0; c < VGA_THREADS / 32; c += 2 * st) r[c] += r[c + st];
+            tot[t] = r[0];
+        }
         __syncthreads();
+        VGS(3);
         if (t == 0) {
             int a = 0;
-            if (!isfinite(tot[action == 1 ? 27 : 0])) { L.lm_failed = -1; a = 0; }      // non-finite error: stop, the host reports it
+            if (!isfinite(tot[action == 1 ? 27 : 29])) { L.lm_failed = -1; a = 0; }      // non-finite error: stop, the host reports it
             else a = vg_lm_advance(L, tot, o);
+            if (L.flip) { cbuf ^= 1; L.flip = 0; }
             if (a == 1) for (int q = 0; q < 12; ++q) Tsh.m[q] = L.x0[q];
-            if (a == 2) for (int q = 0; q < 12; ++q) Tsh.m[q] = L.xi[q];
+            if (a == 3) for (int q = 0; q < 12; ++q) Tsh.m[q] = L.xi[q];
             action = a;
         }
         __syncthreads();
+        VGS(4);
+#ifdef VG_STAMPS
+        ++npass;
+#endif
     }
+#ifdef VG_STAMPS
+    if (t == 0 && g != 0) printf("wg %d eval %lld wait %lld\n", g, st[0], st[2]);
+    if (g == 0 && t == 0) printf("passes %d; 100 MHz ticks: eval %lld, fold+publish %lld, wait %lld, gather+sum %lld, LM %lld\n", npass, st[0], st[1], st[2], st[3], st[4]);
+#endif
     if (g == 0 && t == 0) {
         for (int k = 0; k < 16; ++k) out->T[k] = L.x0[k];
         for (int k = 0; k < 36; ++k) out->H[k] = L.Hout[k];
         out->err = L.y0; out->iterations = L.it; out->converged = L.converged; out->n_corr = L.n_corr;
         out->lm_failed = L.lm_failed > 0 ? 1 : 0; out->status = L.lm_failed < 0 ? VG_ERR_NONFINITE : VG_OK;
+        out->pad = cbuf;                                    // which cache holds the correspondences of the last linearisation used
     }
 }
 
@@ -651,20 +772,20 @@ int vgicp_align(vgicp_ctx* c, const double* guess, const vgicp_options* o, doubl
     if (!c->nvox || !c->n || (o->neighbor_mode != VGICP_DIRECT1 && o->neighbor_mode != VGICP_DIRECT7 && o->neighbor_mode != VGICP_DIRECT27)) return VG_ERR_INVALID;
     if (getenv("VGICP_HOST_LOOP")) return vgicp_align_host(c, guess, o, T_out, out);       // the step logic on the host between launches (cross-check)
     VGCHK(hipSetDevice(c->device));
-    const int mode = o->neighbor_mode, slots = c->n * mode, nblk = (slots + VG_THREADS - 1) / VG_THREADS;
+    const int mode = o->neighbor_mode, slots = c->n * mode, nblk = (slots + VGA_THREADS - 1) / VGA_THREADS;
     if (slots > c->slots_cap) { hipFree(c->d_cvox); hipFree(c->d_cM); c->d_cvox = nullptr; c->d_cM = nullptr; c->slots_cap = 0; VGCHK(hipMalloc(&c->d_cvox, 4 * (size_t)slots)); VGCHK(hipMalloc(&c->d_cM, 8 * 9 * (size_t)slots)); c->slots_cap = slots; }
-    if (!c->d_coop) { VGCHK(hipMalloc(&c->d_coop, sizeof(VgCoop))); VGCHK(hipMemsetAsync(c->d_coop, 0, sizeof(VgCoop), c->stream)); VGCHK(hipMalloc(&c->d_aout, sizeof(VgAlignOut))); VGCHK(hipHostMalloc(&c->h_aout, sizeof(VgAlignOut), hipHostMallocDefault)); c->coop_epoch = 0; }
+    if (slots > c->slots_cap2) { hipFree(c->d_cvox2); hipFree(c->d_cM2); c->d_cvox2 = nullptr; c->d_cM2 = nullptr; c->slots_cap2 = 0; VGCHK(hipMalloc(&c->d_cvox2, 4 * (size_t)c->slots_cap)); VGCHK(hipMalloc(&c->d_cM2, 8 * 9 * (size_t)c->slots_cap)); c->slots_cap2 = c->slots_cap; }
+    if (!c->d_coop) { VGCHK(hipMalloc(&c->d_coop, sizeof(VgCoop))); VGCHK(hipMemsetAsync(c->d_coop, 0, sizeof(VgCoop), c->stream)); VGCHK(hipHostMalloc(&c->h_aout, sizeof(VgAlignOut), hipHostMallocMapped)); VGCHK(hipHostGetDevicePointer(&c->d_aout, c->h_aout, 0)); c->coop_epoch = 0; }
     VgAlignOut* ho = (VgAlignOut*)c->h_aout;
-    std::memcpy(ho->T, guess, sizeof ho->T);
-    VGCHK(hipMemcpyAsync(c->d_aout, ho, sizeof(VgAlignOut), hipMemcpyHostToDevice, c->stream));
-    int G = std::min(nblk, std::min(VG_MAXG, std::max(32, nblk / 8)));     // (measured on the 16-ring pair: 16 -> 7.7 k, 32 -> 9.4 k, 64 -> 9.2 k alignments/s) all workgroups resident: they wait for each other; the exchange costs O(G)
+    VgGuess gs; std::memcpy(gs.m, guess, sizeof gs.m);
+    int G = std::min(nblk, VG_MAXG);     // all workgroups resident: they wait for each other.  A pass is bound by the slots per thread (each a chain of dependent gathers), so as many workgroups as there are 256-slot blocks, up to 128 (VGICP_G sweeps it)
     if (const char* ev = getenv("VGICP_G")) G = std::max(1, std::min(VG_MAXG, atoi(ev)));
-    hipLaunchKernelGGL(k_vgicp_align, dim3(G), dim3(VG_THREADS), 0, c->stream, c->n, mode, c->d_sxyz, c->d_scov, c->res, tab(c), c->d_cvox, c->d_cM, *o, (VgCoop*)c->d_coop, c->coop_epoch, (VgAlignOut*)c->d_aout);
+    hipLaunchKernelGGL(k_vgicp_align, dim3(G), dim3(VGA_THREADS), 0, c->stream, c->n, mode, c->d_sxyz, c->d_scov, c->res, tab(c), c->d_cvox, c->d_cM, c->d_cvox2, c->d_cM2, *o, (VgCoop*)c->d_coop, c->coop_epoch, gs, (VgAlignOut*)c->d_aout);
     c->coop_epoch += 4 * (o->max_iterations * (o->lm_max_iterations + 1) + 4);      // epochs only grow: nothing to reset between calls
     if (c->coop_epoch > (1 << 30)) { VGCHK(hipMemsetAsync(c->d_coop, 0, sizeof(VgCoop), c->stream)); c->coop_epoch = 0; }
-    VGCHK(hipMemcpyAsync(ho, c->d_aout, sizeof(VgAlignOut), hipMemcpyDeviceToHost, c->stream));
-    VGCHK(hipStreamSynchronize(c->stream));
+    VGCHK(hipStreamSynchronize(c->stream));                 // (the record is in host memory when the kernel has finished)
     VGCHK(hipGetLastError());
+    if (ho->pad) { std::swap(c->d_cvox, c->d_cvox2); std::swap(c->d_cM, c->d_cM2); std::swap(c->slots_cap, c->slots_cap2); }      // vgicp_error() after an alignment sees its last linearisation
     c->noff = mode; c->slots = slots; c->linearized = true;
     std::memset(out, 0, sizeof *out);
     out->iterations = ho->iterations; out->converged = ho->converged; out->n_correspondences = ho->n_corr; out->lm_failed = ho->lm_failed; out->final_error = ho->err;
