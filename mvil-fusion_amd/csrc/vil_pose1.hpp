@@ -292,12 +292,16 @@ __global__ __launch_bounds__(VP1_THREADS) void k_pose_solve(const int* __restric
         double (*part)[28] = coop->part[epoch & 1];
         pose1_eval(sh, sh.cand, ne, ed, es, np, pl, ps, O.lidar_loss, O.lidar_loss_scale, O.precision);
         VP1_ST(st_eval0);
-        if (t < 28) __hip_atomic_store(&part[g][t], sh.mine[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (t == 0) { __threadfence(); __hip_atomic_store(&coop->flag[g], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        // The partials are stored (and read) with agent-scope atomics -- at the level all XCDs share -- so waiting for wave 0's stores is
+        // all the ordering the flag needs: a release fence would also write back this XCD's L2, an acquire on the other side invalidate theirs.
+        if (t < 64) {
+            if (t < 28) __hip_atomic_store(&part[g][t], sh.mine[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (t == 0) __hip_atomic_store(&coop->flag[g], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         VP1_ST(st_eval);
         // every workgroup gathers everybody's partial sums (workgroup order: the same bits everywhere) ...
-        if (t < G) while (__hip_atomic_load(&coop->flag[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) __builtin_amdgcn_s_sleep(1);
+        if (t < G) while (__hip_atomic_load(&coop->flag[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) __builtin_amdgcn_s_sleep(1);
         __syncthreads();
         {   // 28 G <= 1792 values, up to 7 per thread: issue every load before the first use
             constexpr int NLD = (28 * VP1_MAXG + VP1_THREADS - 1) / VP1_THREADS;
@@ -308,7 +312,13 @@ __global__ __launch_bounds__(VP1_THREADS) void k_pose_solve(const int* __restric
             for (int u = 0; u < NLD; ++u) { const int e = t + u * VP1_THREADS; if (e < 28 * G) (&sh.gath[0][0])[e] = gv[u]; }
         }
         __syncthreads();
-        if (t < 28) { double s = 0.0; for (int w = 0; w < G; ++w) s += sh.gath[w][t]; sh.sysn[t] = s; }
+        if (t < 28) {                  // four interleaved chains, combined in a fixed order: the same bits in every workgroup
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int w = 0;
+            for (; w + 3 < G; w += 4) { s0 += sh.gath[w][t]; s1 += sh.gath[w + 1][t]; s2 += sh.gath[w + 2][t]; s3 += sh.gath[w + 3][t]; }
+            for (; w < G; ++w) s0 += sh.gath[w][t];
+            sh.sysn[t] = (s0 + s1) + (s2 + s3);
+        }
         __syncthreads();
         VP1_ST(st_gather);
         // ... and runs the same trust-region pass on them: identical code on identical numbers, so all workgroups agree on

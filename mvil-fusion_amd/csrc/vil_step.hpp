@@ -775,8 +775,13 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
 #endif
     if (s.c.done) return;                    // finished in an earlier launch: nobody writes anything
     const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
-    auto post = [&](int* f) { if (t == 0) __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); };      // (callers: after a barrier)
-    auto wait1 = [&](int* f) { while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1); };
+    // Everything the master and its helpers hand each other inside this launch (hpart, hpart2, stepc) is stored AND loaded with agent-scope
+    // atomics, i.e. at the level all XCDs share, so a flag only has to be ordered after the poster's own stores (s_waitcnt).  A release
+    // fence would also write back the XCD's L2 and an acquire invalidate the reader's: microseconds on the critical path, for data
+    // nobody reads before the next kernel.
+    auto post = [&](int* f) { if (t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } };
+    auto wait1 = [&](int* f) { while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1); };
+    auto put = [&](double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     // master: every helper has read Ctl (one lane per helper: the polls overlap instead of queueing behind one another)
     bool hseen = false;
     auto wait_helpers = [&]() { if (!hseen && t < nhelp) wait1(P.hflag + t); hseen = true; };
@@ -854,7 +859,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     auto wait_x = [&]() {
         if (t == 0) {
             for (;;) {
-                const int a = __hip_atomic_load(P.xflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(P.xstat, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                const int a = __hip_atomic_load(P.xflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(P.xstat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (a == epoch) { s.ok = 1; break; }
                 if (b == epoch) { s.ok = 0; break; }
                 __builtin_amdgcn_s_sleep(1);
@@ -865,7 +870,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     auto post_wave2 = [&](double* sm) {
         bsum6(sm, s);
         const int slot = bid - 1;
-        if (t == 0) { double* hp = P.hpart2 + 8 * slot; for (int e = 0; e < 6; ++e) hp[e] = sm[e]; }
+        if (t == 0) { double* hp = P.hpart2 + 8 * slot; for (int e = 0; e < 6; ++e) put(hp + e, sm[e]); }
         post(P.hflag2 + slot);
     };
     // master side: one wave gathers the helper waves' sums (h[0..6)) and, when with1, the first pass's three numbers (h[6..9))
@@ -921,7 +926,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                     }
                 }
                 bsum3<true>(g2, q, gm, s);
-                if (t == 0) { double* hp = P.hpart + 4 * hk; hp[0] = q; hp[1] = g2; hp[2] = gm; }
+                if (t == 0) { double* hp = P.hpart + 4 * hk; put(hp, q); put(hp + 1, g2); put(hp + 2, gm); }
                 post(P.hflag + hk);
                 wait_x();
                 if (s.ok) {
@@ -946,7 +951,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             }
             lm_pass1(l0, l1, s.y, q, g2, gm);
             bsum3<true>(g2, q, gm, s);
-            if (t == 0) { double* hp = P.hpart + 4 * hk; hp[0] = q; hp[1] = g2; hp[2] = gm; }
+            if (t == 0) { double* hp = P.hpart + 4 * hk; put(hp, q); put(hp + 1, g2); put(hp + 2, gm); }
             post(P.hflag + hk);
             // second pass once the master has the pose part of the solution
             wait_x();
@@ -966,7 +971,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     bool xpub = false;                                 // the master owes the waiting helpers an xflag on every path through the need branch
     auto publish_xp = [&](int okk) {                   // called by all threads; s.y[0 .. NV) = x_p when okk
         if (nhelp) {
-            if (okk) { for (int i = t; i < P.NV; i += NT) P.stepc[i] = s.sc[i] * s.y[i]; __threadfence(); }      // (__syncthreads does not wait for global stores)
+            if (okk) { for (int i = t; i < P.NV; i += NT) put(P.stepc + i, s.sc[i] * s.y[i]); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // (__syncthreads does not wait for global stores)
             __syncthreads();
             post(okk ? P.xflag : P.xstat);
         }
