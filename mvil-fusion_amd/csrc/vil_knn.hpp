@@ -124,7 +124,13 @@ __device__ __forceinline__ bool knn_wave_query(unsigned long long& best, float q
             const int e = base + lane;
             int b = 0, cnt = 0;
             if (e < ncell) {
-                const int dz = e % side - r, dy = (e / side) % side - r, dx = e / (side * side) - r;
+                int dz = e % side - r, dy = (e / side) % side - r, dx = e / (side * side) - r;
+                if (r == 1) {
+                    // first ring: the query's own cell first, then its 6 face, 12 edge and 8 corner neighbours (two bits per offset in three
+                    // words).  The candidates reach the sorted list in lane order, so the near cells set the k-th best distance and most
+                    // of what the far cells hold fails the threshold test before the serial insertion (the result does not depend on order).
+                    dx = (int)((0x2a802a95402551ull >> (2 * e)) & 3) - 1; dy = (int)((0x28282528251945ull >> (2 * e)) & 3) - 1; dz = (int)((0x22221862185615ull >> (2 * e)) & 3) - 1;
+                }
                 if (r == 1 || max(max(abs(dx), abs(dy)), abs(dz)) == r) {
                     const int s = grid_slot(G, pack_key(cx + dx, cy + dy, cz + dz), false);
                     if (s >= 0) { b = G.start[s]; cnt = G.cnt[s]; }
