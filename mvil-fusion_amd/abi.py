@@ -19,9 +19,11 @@ LOSS_NONE, LOSS_CAUCHY, LOSS_HUBER = range(3)
 MARGIN_OLD, MARGIN_SECOND_NEW = 0, 1
 TERM_NAMES = ["none", "function_tolerance", "gradient_tolerance", "parameter_tolerance", "max_iterations", "max_time", "failure"]
 
-_dp = C.POINTER(C.c_double)
-_ip = C.POINTER(C.c_int32)
-_bp = C.POINTER(C.c_uint8)
+# pointer fields of the C structs: declared void* here (same layout) so that a field takes the array's address as a plain integer --
+# building a typed ctypes pointer per table costs 3 us, and the per-image loop of the replay fills ~40 of them
+_dp = C.c_void_p
+_ip = C.c_void_p
+_bp = C.c_void_p
 
 
 class VilState(C.Structure):
@@ -85,15 +87,11 @@ class VilDeviceCfg(C.Structure):
 
 
 def _d(a):
-    return a.ctypes.data_as(_dp) if a is not None and a.size else C.cast(None, _dp)
+    return a.ctypes.data if a is not None and a.size else None
 
 
-def _i(a):
-    return a.ctypes.data_as(_ip) if a is not None and a.size else C.cast(None, _ip)
-
-
-def _b(a):
-    return a.ctypes.data_as(_bp) if a is not None and a.size else C.cast(None, _bp)
+_i = _d
+_b = _d
 
 
 def f64(a, shape=None):
@@ -213,7 +211,7 @@ class Window:
         p.n_plane = len(self.plane_pose); p.plane_pose, p.plane_const = _i(self.plane_pose), _d(self.plane_const)
         if getattr(self, "lidar_resident", False):
             p.n_plane = p.n_edge = -1
-            p.plane_pose = p.edge_pose = C.cast(None, _ip); p.plane_const = p.edge_const = C.cast(None, _dp)
+            p.plane_pose = p.edge_pose = None; p.plane_const = p.edge_const = None
         for k in range(4):
             p.q_lb[k] = self.q_lb[k]
         for k in range(3):
