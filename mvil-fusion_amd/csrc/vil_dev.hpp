@@ -8,6 +8,7 @@
 #define VIL_SWEEP_THREADS 512 // sweep workgroups: 8 waves = 2 per SIMD for LDS-latency hiding
 #define VIL_VCHUNK_LM 12      // landmarks per visual sub-chunk
 #define VIL_VCHUNK_F 128      // factors per visual workgroup (LDS staging bound)
+#define VIL_VCHUNK_FBAL 32    // factors at which a chunk is closed when the partial records are small (balance between the visual workgroups)
 #define VIL_STEP_THREADS 512
 
 struct SysBuf {       // one linearisation of the window (double-buffered: current / candidate)

@@ -112,6 +112,9 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
     #define VSTAMP(k) do {} while (0)
 #endif
     VSTAMP(0);
+#ifdef VIL_STAMPS
+    long long vt0 = 0; if (t == 0) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(vt0) :: "memory");
+#endif
     const double* xcur = P.x[ctl.cur];
     double* xcand = P.x[1 - ctl.cur];
     const double cg = ctl.cg, cn = ctl.cn;
@@ -215,16 +218,18 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
         }
         __syncthreads();
         VSTAMP(3);
-        // ---- tri += sum_f Jc^T Jc - invp e e^T, in three passes whose work items have (nearly) uniform trip counts
-        //      inside a wave (divergent loops cost the maximum over the lanes).  Groups: A = anchor pose, X = extrinsic,
-        //      T = td (shared by all factors of the landmark), O_f = observing pose of factor f.
+        // ---- tri += sum_f Jc^T Jc - invp e e^T.  Three kinds of work items with (nearly) uniform trip counts inside a wave
+        //      (divergent loops cost the maximum over the lanes); the kinds only read the staged factors and add into tri with LDS
+        //      atomics, so they run side by side: every kind's item range is padded to whole waves and the waves of the workgroup
+        //      walk the concatenation -- two or three rounds of latency instead of one or two per kind with barriers in between.
+        //      Groups: A = anchor pose, X = extrinsic, T = td (shared by all factors of the landmark), O_f = observing pose of factor f.
         {
             // (a) shared x shared blocks: item = (landmark, pair of {A,X,T}, row); inner loop over the landmark's factors
-            for (int it = t; it < nl * 36; it += blockDim.x) {
+            auto item_a = [&](int it) {
                 const int tl = it / 36, pr = it - 36 * tl, p = pr / 6, r = pr - 6 * p;
                 const int g1 = p < 3 ? 0 : (p < 5 ? 1 : 2), g2 = p < 3 ? p : (p < 5 ? p - 2 : 2);
                 const int n1 = g1 == 2 ? 1 : 6, n2 = g2 == 2 ? 1 : 6;
-                if (r >= n1) continue;
+                if (r >= n1) return;
                 const int fs = lms[tl], fe = lms[tl + 1];
                 const double* lr = lmr + tl * 16;
                 const int a = lanc[tl];
@@ -244,12 +249,11 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
                 }
 #pragma unroll
                 for (int c = 0; c < 6; ++c) if (c < n2 && (g1 != g2 || c >= r) && acc[c] != 0.0) lds_add(tri + tri_idx(NV, c1 + r, c2 + c), acc[c]);
-            }
-            VSTAMP(6);
+            };
             // (b) shared x observer blocks: item = (factor, shared group, row); exactly one factor contributes
-            for (int it = t; it < nf * 18; it += blockDim.x) {
+            auto item_b = [&](int it) {
                 const int q = it / 18, rem = it - 18 * q, g1 = rem / 6, r = rem - 6 * g1;
-                if (g1 == 2 && r > 0) continue;
+                if (g1 == 2 && r > 0) return;
                 const int tl = fl[q];
                 const double* lr = lmr + tl * 16;
                 const double* w = Jf + q * VF_STRIDE;
@@ -262,10 +266,9 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
                     const double v = w0 * w[12 + c] + w1 * w[18 + c] - ie1 * w[42 + c];
                     if (v != 0.0) lds_add(tri + tri_idx(NV, c1 + r, c2 + c), v);
                 }
-            }
-            VSTAMP(7);
+            };
             // (c) observer x observer blocks: item = (factor q, row); walks the later factors of the same landmark
-            for (int it = t; it < nf * 6; it += blockDim.x) {
+            auto item_c = [&](int it) {
                 const int q = it / 6, r = it - 6 * q;
                 const int tl = fl[q], fe = lms[tl + 1];
                 const double* w = Jf + q * VF_STRIDE;
@@ -283,6 +286,13 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
 #pragma unroll
                     for (int c = 0; c < 6; ++c) { const double v = -ieq * w2[42 + c]; if (v != 0.0) lds_add(tri + tri_idx(NV, c1, c2 + c), v); }
                 }
+            };
+            const int na = nl * 36, nb_ = nf * 18, nc_ = nf * 6;
+            const int pa = (na + 63) & ~63, pc = (nc_ + 63) & ~63, pb = (nb_ + 63) & ~63;      // the kinds with inner loops first
+            for (int it = t; it < pa + pc + pb; it += blockDim.x) {
+                if (it < pa) { if (it < na) item_a(it); }
+                else if (it < pa + pc) { const int i2 = it - pa; if (i2 < nc_) item_c(i2); }
+                else { const int i3 = it - pa - pc; if (i3 < nb_) item_b(i3); }
             }
         }
     }
@@ -292,6 +302,9 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
     for (int e = t; e < NVT + 3 * NV; e += blockDim.x) out[e] = tri[e];
     if (t == 0) out[NVT + 3 * NV] = cost;
     VSTAMP(5);
+#ifdef VIL_STAMPS
+    if (t == 0) { long long vt1; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(vt1) :: "memory"); atomicMax((unsigned long long*)(P.dbg + 60), (unsigned long long)(vt1 - vt0)); atomicAdd((unsigned long long*)(P.dbg + 61), (unsigned long long)(vt1 - vt0)); }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -409,9 +409,15 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         }
         std::vector<int> vch;
         int l0 = 0;
+        // a visual workgroup's time grows with the factors of its chunk (rounds of work items), the kernel's with its slowest workgroup:
+        // chunks are closed at VIL_VCHUNK_FBAL factors (old landmarks carry up to K - 1 observations, new ones two), a single landmark may exceed it.
+        // Every workgroup also writes one partial record of NV (NV + 1) / 2 doubles that k_reduce reads back: measured K = 10 (20 kB records)
+        // 32 factors: sweep 24.7 -> 22.5 us, reduce 15.0 -> 15.4; K = 20 (65 kB records): sweep 42 -> 60 us -- so only for the small records
+        int fbal = NV <= 80 ? VIL_VCHUNK_FBAL : VIL_VCHUNK_F;
+        if (const char* ev = getenv("VIL_VFBAL")) fbal = std::max(1, atoi(ev));
         while (l0 < L) {
             int l1 = l0, nf = 0;
-            while (l1 < L && l1 - l0 < VIL_VCHUNK_LM && nf + (lms[l1 + 1] - lms[l1]) <= VIL_VCHUNK_F) { nf += lms[l1 + 1] - lms[l1]; ++l1; }
+            while (l1 < L && l1 - l0 < VIL_VCHUNK_LM && nf + (lms[l1 + 1] - lms[l1]) <= VIL_VCHUNK_F && (l1 == l0 || nf + (lms[l1 + 1] - lms[l1]) <= fbal)) { nf += lms[l1 + 1] - lms[l1]; ++l1; }
             if (l1 == l0) return VIL_ERR_UNSUPPORTED;   // a single landmark with > VIL_VCHUNK_F observations
             if (nf > 0) { vch.push_back(l0); vch.push_back(l1); }
             l0 = l1;

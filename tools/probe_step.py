@@ -30,3 +30,4 @@ e = np.array(dbg[48:59], dtype=np.int64) - dbg[41]
 print("chain waves, ticks after the start: recursion steps", e[:6].tolist(), "middle done", int(e[6]), "| fwd row wave done", int(e[7]), "| bwd row wave done", int(e[8]), "| pack done", int(e[9]), "| q done", int(e[10]))
 f = np.array(dbg[12:18], dtype=np.int64)
 print("chain workgroup in k_sweep (ticks): wait for IMU/prior %d, stage %d, scales %d, chain (wave 0) %d, write-out %d; visual WG0 ends %d ticks after the chain WG started" % (tuple(np.diff(f).tolist()) + (int(dbg[37] - dbg[12]),)))
+print("visual workgroups: longest entry-to-exit of any of them in any launch since the upload: %d ticks" % dbg[60])
