@@ -21,7 +21,14 @@ rm -rf /tmp/p_mfma
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/p_mfma -- python $R/bench.py --steps 10 --warmup 2 --no-cpu --no-events --no-cfg3 > /dev/null 2>&1
 find /tmp/p_mfma -name "*counter_collection.csv" -exec cp {} $O/r02_pmc_mfma.csv \;
 cd $R
+timeout 600 python bench.py --replay 600 > $O/r02_replay600_fp64.json 2>/dev/null
 timeout 600 python bench.py --replay 600 --precision 1 > $O/r02_replay600_fp32.json 2>/dev/null
+timeout 300 python bench.py --vgicp > $O/r02_vgicp16.json 2>/dev/null
+timeout 300 python bench.py --vgicp --vgicp-rings 64 --vgicp-az 2048 > $O/r02_vgicp64.json 2>/dev/null
+timeout 300 python bench.py --mapreg > $O/r02_mapreg.json 2>/dev/null
+timeout 300 python bench.py --preint > $O/r02_preint.json 2>/dev/null
+(cd /tmp; rm -rf /tmp/p_rows; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_rows -- python $R/bench.py --vgicp --steps 20 --warmup 3 > /dev/null 2>&1; find /tmp/p_rows -name "*kernel_stats.csv" -exec cp {} $O/r02_vgicp_kernel_stats.csv \;
+ rm -rf /tmp/p_rows; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_rows -- python $R/bench.py --mapreg --steps 20 --warmup 3 > /dev/null 2>&1; find /tmp/p_rows -name "*kernel_stats.csv" -exec cp {} $O/r02_mapreg_kernel_stats.csv \;)
 timeout 600 python bench.py --replay 300 --classic --no-cpu > $O/r02_replay300_classic.json 2>/dev/null
 timeout 900 python tools/run_configs.py > $O/r02_configs.txt 2>&1
 # the per-dispatch traces are large: keep the live-launch summary and drop anything above 2 MB
