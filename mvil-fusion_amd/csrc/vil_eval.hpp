@@ -169,16 +169,18 @@ __global__ void k_eval_prior(DevP P, const double* x, double* r, double* J, cons
 // prior contractions pH = J0^T J0, pg0 = J0^T r0, pc0 = r0^T r0.
 // 15 x 15 Cholesky of the matrix in LDS `A` (row-major, lower triangle used), right-looking, 256 threads:
 // column scale by one lane per row, trailing update by one thread per element.  Result: lower factor in A.
-__device__ inline bool chol15_wg(double* A, int* bad) {
+// Pivots through v_rsq_f64 + two Newton steps (1-2 ulp): the IEEE square root and divide are 1 k-cycle dependent chains each, thirty
+// of them in a row here, and this kernel runs at the head of every frame's upload.  rinv (optional): 1 / L_jj per column.
+__device__ inline bool chol15_wg(double* A, int* bad, double* rinv = nullptr) {
     const int t = threadIdx.x;
     const int i = t / 15, k = t - 15 * (t / 15);
     for (int j = 0; j < 15; ++j) {
         const double d = A[j * 15 + j];
         if (!(d > 0.0)) { if (t == 0) *bad = 1; }
-        const double sd = sqrt(d);
+        const double r = vd::rsqrt_nr(d);
         __syncthreads();
-        if (t == j) A[j * 15 + j] = sd;
-        else if (t > j && t < 15) A[t * 15 + j] /= sd;
+        if (t == j) { A[j * 15 + j] = d * r; if (rinv) rinv[j] = r; }
+        else if (t > j && t < 15) A[t * 15 + j] *= r;
         __syncthreads();
         if (t < 225 && i > j && k > j && k <= i) A[i * 15 + k] -= A[i * 15 + j] * A[k * 15 + j];
         __syncthreads();
@@ -191,17 +193,18 @@ __global__ __launch_bounds__(VIL_THREADS) void k_setup(DevP P, double* imu_U, in
     const int b = blockIdx.x, t = threadIdx.x;
     if (b < P.n_imu) {
         // U with U^T U = cov^-1: cov = C C^T, W = C^-1, cov^-1 = W^T W = L L^T, U = L^T   (imu_factor.h:64)
-        __shared__ double C[225], W[225], A[225];
+        __shared__ double C[225], W[225], A[225], rC[16];
         __shared__ int bad;
         const double* cov = P.imu_c + (size_t)b * 287 + 62;
         if (t == 0) bad = 0;
         if (t < 225) { C[t] = cov[t]; W[t] = 0.0; }
         __syncthreads();
-        chol15_wg(C, &bad);
+        chol15_wg(C, &bad, rC);
+        __syncthreads();
         if (t < 15) {                                    // column t of W = C^-1 by forward substitution
             const int j = t;
-            W[j * 15 + j] = 1.0 / C[j * 15 + j];
-            for (int i = j + 1; i < 15; ++i) { double s = 0; for (int k = j; k < i; ++k) s -= C[i * 15 + k] * W[k * 15 + j]; W[i * 15 + j] = s / C[i * 15 + i]; }
+            W[j * 15 + j] = rC[j];
+            for (int i = j + 1; i < 15; ++i) { double s = 0; for (int k = j; k < i; ++k) s -= C[i * 15 + k] * W[k * 15 + j]; W[i * 15 + j] = s * rC[i]; }
         }
         __syncthreads();
         if (t < 225) { const int i = t / 15, j = t - 15 * i; double s = 0; if (j <= i) for (int k = i; k < 15; ++k) s += W[k * 15 + i] * W[k * 15 + j]; A[t] = s; }

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M, int phase) {
     // eigen-decomposition (one-sided Jacobi, a workgroup barrier per rotation stage) costs ~100.  Certificate:
     // lambda_min = 1 / lambda_max(A_dd^-1) >= 1 / ||A_dd^-1||_F.  Anything else takes the eigen route below.
     __shared__ int fast_ok;
-    double* W = sm; double* Li = sm + 225;               // nd <= 15: factor, its inverse (sm holds 3 * 136 + 64 doubles)
+    double* W = sm; double* Li = sm + 225; double* Wr = sm + 450;      // nd <= 15: factor, its inverse, reciprocal pivots (sm holds 3 * 136 + 64 doubles)
     if (t == 0) fast_ok = nd <= 15 ? 1 : 0;
     for (int e = t; e < nd * nd; e += NT) W[e] = mlds[e];
     __syncthreads();
@@ -207,6 +207,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M, int phase) {
         if (!(d > 0.0) || !isfinite(d)) { __syncthreads(); if (t == 0) fast_ok = 0; __syncthreads(); break; }
         const double r = rsqrt_nr(d);
         __syncthreads();
+        if (t == 0) Wr[p] = r;
         if (t >= p && t < nd) W[t * nd + p] *= r;
         __syncthreads();
         for (int e = t; e < nd * nd; e += NT) { const int i = e / nd, j = e - i * nd; if (j > p && i >= j) W[e] -= W[i * nd + p] * W[j * nd + p]; }
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M, int phase) {
             for (int i = 0; i < nd; ++i) {
                 double acc = i == j ? 1.0 : 0.0;
                 for (int k = j; k < i; ++k) acc -= W[i * nd + k] * Li[k * nd + j];
-                Li[i * nd + j] = i < j ? 0.0 : acc / W[i * nd + i];
+                Li[i * nd + j] = i < j ? 0.0 : acc * Wr[i];
             }
         }
         __syncthreads();

@@ -181,12 +181,22 @@ __global__ void k_aos2soa(const double* aos, int n, int ncomp, double* dst, size
     if (f < n) for (int q = 0; q < ncomp; ++q) dst[(size_t)q * stride + f] = aos[(size_t)f * ncomp + q];
 }
 __host__ __device__ static void gauge_fix_core(const double* pose0_before, int K, double* pose, double* speedbias, double* ex_pose);
-// double2vector()'s gauge fix on the device: one thread (K <= 20 poses), both state buffers
+__host__ __device__ static void gauge_rot(const double* pose0_before, const double* pose0_now, double* rot);
+__host__ __device__ static void gauge_frame(const double* rot, const double* p0, const double* pose0_before, double* pp, double* sb);
+__host__ __device__ static void gauge_ex(double* ex_pose);
+// double2vector()'s gauge fix on the device, both state buffers: one thread per frame (+ one for the extrinsic); every thread derives the
+// yaw correction from frame 0 itself, before anybody overwrites it (the frames are independent after that: one lane's latency instead of K)
 __global__ void k_gauge_fix(DevP P, const double* x0) {
-    if (threadIdx.x || blockIdx.x) return;
+    const int t = threadIdx.x, K = P.K;
     double* x = P.x[0];
-    gauge_fix_core(x0 + xo_pose(P, 0), P.K, x + xo_pose(P, 0), x + xo_sb(P, 0), x + xo_ex(P));
-    for (int i = 0; i < 16 * P.K + 8; ++i) P.x[1][i] = x[i];
+    double rot[9], p0[3];
+    gauge_rot(x0 + xo_pose(P, 0), x + xo_pose(P, 0), rot);
+    for (int i = 0; i < 3; ++i) p0[i] = x[xo_pose(P, 0) + i];
+    __syncthreads();
+    if (t < K) gauge_frame(rot, p0, x0 + xo_pose(P, 0), x + xo_pose(P, t), x + xo_sb(P, t));
+    else if (t == K) gauge_ex(x + xo_ex(P));
+    __syncthreads();
+    for (int i = t; i < 16 * K + 8; i += blockDim.x) P.x[1][i] = x[i];
 }
 
 extern "C" {
@@ -1265,30 +1275,39 @@ __host__ __device__ static void gauge_R2q(const double* R, double* q /*xyzw*/) {
         q[3] = (R[3 * k + j] - R[3 * j + k]) * t; q[j] = (R[3 * j + i] + R[3 * i + j]) * t; q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
     }
 }
-__host__ __device__ static void gauge_fix_core(const double* pose0_before, int K, double* pose, double* speedbias, double* ex_pose) {
-    double R0[9], R00[9], a0[3], a00[3], rot[9];
-    gauge_q2R(pose0_before + 3, R0); gauge_q2R(pose + 3, R00);
+__host__ __device__ static void gauge_rot(const double* pose0_before, const double* pose0_now, double* rot) {
+    double R0[9], R00[9], a0[3], a00[3];
+    gauge_q2R(pose0_before + 3, R0); gauge_q2R(pose0_now + 3, R00);
     gauge_R2ypr(R0, a0); gauge_R2ypr(R00, a00);
     const double yd = (a0[0] - a00[0]) / 180.0 * M_PI;
     rot[0] = cos(yd); rot[1] = -sin(yd); rot[2] = 0; rot[3] = sin(yd); rot[4] = cos(yd); rot[5] = 0; rot[6] = 0; rot[7] = 0; rot[8] = 1;
     if (fabs(fabs(a0[1]) - 90) < 1.0 || fabs(fabs(a00[1]) - 90) < 1.0)
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double v = 0; for (int k = 0; k < 3; ++k) v += R0[3 * i + k] * R00[3 * j + k]; rot[3 * i + j] = v; }
-    const double p0[3] = {pose[0], pose[1], pose[2]};
-    for (int f = 0; f < K; ++f) {
-        double* pp = pose + 7 * f; double qn[4], Rf[9], Rn[9], d[3], Pn[3], V[3];
+}
+__host__ __device__ static void gauge_frame(const double* rot, const double* p0, const double* pose0_before, double* pp, double* sb) {
+    {
+        double qn[4], Rf[9], Rn[9], d[3], Pn[3], V[3];
         { const double n = sqrt(pp[3] * pp[3] + pp[4] * pp[4] + pp[5] * pp[5] + pp[6] * pp[6]); for (int i = 0; i < 4; ++i) qn[i] = pp[3 + i] / n; }
         gauge_q2R(qn, Rf);
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double v = 0; for (int k = 0; k < 3; ++k) v += rot[3 * i + k] * Rf[3 * k + j]; Rn[3 * i + j] = v; }
         for (int i = 0; i < 3; ++i) d[i] = pp[i] - p0[i];
         for (int i = 0; i < 3; ++i) Pn[i] = rot[3 * i] * d[0] + rot[3 * i + 1] * d[1] + rot[3 * i + 2] * d[2] + pose0_before[i];
         gauge_R2q(Rn, pp + 3); pp[0] = Pn[0]; pp[1] = Pn[1]; pp[2] = Pn[2];
-        double* sb = speedbias + 9 * f;
         for (int i = 0; i < 3; ++i) V[i] = rot[3 * i] * sb[0] + rot[3 * i + 1] * sb[1] + rot[3 * i + 2] * sb[2];
         sb[0] = V[0]; sb[1] = V[1]; sb[2] = V[2];
     }
+}
+__host__ __device__ static void gauge_ex(double* ex_pose) {
     double qe[4], Re[9];
     { const double n = sqrt(ex_pose[3] * ex_pose[3] + ex_pose[4] * ex_pose[4] + ex_pose[5] * ex_pose[5] + ex_pose[6] * ex_pose[6]); for (int i = 0; i < 4; ++i) qe[i] = ex_pose[3 + i] / n; }
     gauge_q2R(qe, Re); gauge_R2q(Re, ex_pose + 3);
+}
+__host__ __device__ static void gauge_fix_core(const double* pose0_before, int K, double* pose, double* speedbias, double* ex_pose) {
+    double rot[9];
+    gauge_rot(pose0_before, pose, rot);
+    const double p0[3] = {pose[0], pose[1], pose[2]};
+    for (int f = 0; f < K; ++f) gauge_frame(rot, p0, pose0_before, pose + 7 * f, speedbias + 9 * f);
+    gauge_ex(ex_pose);
 }
 int vil_gauge_fix(const double* pose0_before, vil_state* s) {
     if (!pose0_before || !s) return VIL_ERR_INVALID_ARGUMENT;
