@@ -228,7 +228,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M, int phase) {
             const int i = e / nd, j = e - i * nd;
             double acc = 0.0;
             for (int k = (i > j ? i : j); k < nd; ++k) acc += Li[k * nd + i] * Li[k * nd + j];
-            M.Vd[e] = acc; f2 += acc * acc;
+            M.Vd[e] = acc; W[e] = acc; f2 += acc * acc;          // (W: the factor is not read any more)
         }
         f2 = wave_total(f2);
         __shared__ double f2w[16];
@@ -237,7 +237,28 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M, int phase) {
         if (t == 0) { double tot = 0.0; for (int q = 0; q < (NT >> 6); ++q) tot += f2w[q]; if (!(tot > 0.0) || !(rsqrt_nr(tot) > 4.0 * M.eps)) fast_ok = 0; }
         __syncthreads();
     }
-    if (fast_ok) {
+    // staged = the products below run out of LDS: the kept x dropped blocks of S, A_dd^-1 and T are gathered once, with every load of a
+    // thread independent of the others -- the direct loops chase index -> S entry -> product nd times in a row per output element
+    // (n = 70: some 75 dependent L2 round trips per thread, most of this kernel's time)
+    const bool staged = fast_ok && (size_t)n * n >= 3 * (size_t)n * nd;
+    double* Skd = mlds; double* Sdk = mlds + (size_t)n * nd; double* Tl = mlds + 2 * (size_t)n * nd;
+    if (staged) {
+        if (t == 0) M.stat[0] = 0;
+        const double* Ai = W;                            // A_dd^-1 (written over the factor above)
+        for (int e = t; e < n * nd; e += NT) {
+            const int i = e / nd, q = e - i * nd;
+            Skd[e] = M.S[(size_t)M.keep_cols[i] * D + M.drop_cols[q]];
+            Sdk[(size_t)q * n + i] = M.S[(size_t)M.drop_cols[q] * D + M.keep_cols[i]];
+        }
+        __syncthreads();
+        for (int e = t; e < n * nd; e += NT) {           // T = A_kd A_dd^-1
+            const int i = e / nd, j = e - i * nd;
+            double acc = 0.0;
+            for (int q = 0; q < nd; ++q) acc += Skd[i * nd + q] * Ai[q * nd + j];
+            Tl[e] = acc; M.T[e] = acc;
+        }
+        __syncthreads();
+    } else if (fast_ok) {
         if (t == 0) M.stat[0] = 0;
         for (int e = t; e < n * nd; e += NT) {           // T = A_kd A_dd^-1
             const int i = e / nd, j = e - i * nd;
@@ -273,7 +294,8 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M, int phase) {
         if (e < n * n) {
             const int i = e / n, j = e - i * n;
             double s = M.S[(size_t)M.keep_cols[i] * D + M.keep_cols[j]];
-            for (int k = 0; k < nd; ++k) s -= M.T[(size_t)i * nd + k] * M.S[(size_t)M.drop_cols[k] * D + M.keep_cols[j]];
+            if (staged) { for (int k = 0; k < nd; ++k) s -= Tl[i * nd + k] * Sdk[(size_t)k * n + j]; }
+            else for (int k = 0; k < nd; ++k) s -= M.T[(size_t)i * nd + k] * M.S[(size_t)M.drop_cols[k] * D + M.keep_cols[j]];
             M.V[e] = s;                                    // staged in V, symmetrised copy goes to A below
         } else {
             const int i = e - n * n;

@@ -1126,15 +1126,16 @@ static int marg_finish(vil_ctx* c, const int K, const bool old_, const int drop_
     MargDev M;
     M.D = D; M.nd = nd; M.n = n; M.eps = 1e-8;
     M.S = c->P.sys[1].S; M.g = M.S + (size_t)D * D;
-    int* d_drop = (int*)take(4 * (size_t)nd); int* d_keep = (int*)take(4 * (size_t)n);
+    int* d_drop = (int*)take(4 * (size_t)(nd + n)); int* d_keep = d_drop + nd;       // one table, one copy
     M.drop_cols = d_drop; M.keep_cols = d_keep;
     M.Add = (double*)take(8 * (size_t)nd * nd); M.Vd = (double*)take(8 * (size_t)nd * nd); M.wd = (double*)take(8 * (size_t)nd);
-    M.T = (double*)take(8 * nn); M.A = (double*)take(8 * nn); M.b = (double*)take(8 * (size_t)n);
-    M.V = (double*)take(8 * nn); M.w = (double*)take(8 * (size_t)n); M.J0 = (double*)take(8 * nn); M.r0 = (double*)take(8 * (size_t)n);
+    M.T = (double*)take(8 * nn);
+    M.V = (double*)take(8 * nn); M.w = (double*)take(8 * (size_t)n);
+    M.J0 = (double*)take(8 * (2 * nn + 2 * (size_t)n)); M.A = M.J0 + nn; M.r0 = M.A + nn; M.b = M.r0 + n;      // what goes back to the host: one block, one copy
     M.stat = (int*)take(32);
     if (off > bytes) return VIL_ERR_DEVICE;
-    HIPCHK(hipMemcpyAsync(d_drop, drop_cols.data(), 4 * (size_t)nd, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d_keep, keep_cols.data(), 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    std::vector<int> cols(drop_cols.begin(), drop_cols.end()); cols.insert(cols.end(), keep_cols.begin(), keep_cols.end());      // (alive until the stream has been synchronised below)
+    HIPCHK(hipMemcpyAsync(d_drop, cols.data(), 4 * cols.size(), hipMemcpyHostToDevice, c->stream));
     {
         const size_t a_bytes = 8 * nn, cap = 156 * 1024;
         if (a_bytes > cap) return VIL_ERR_UNSUPPORTED;
@@ -1152,10 +1153,7 @@ static int marg_finish(vil_ctx* c, const int K, const bool old_, const int drop_
     }
     st = ensure_pin(c, 8 * (nn * 2 + 2 * (size_t)n));
     if (st != VIL_OK) return st;
-    HIPCHK(hipMemcpyAsync(c->h_pin, M.J0, 8 * nn, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_pin + nn, M.A, 8 * nn, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_pin + 2 * nn, M.r0, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_pin + 2 * nn + n, M.b, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_pin, M.J0, 8 * (2 * nn + 2 * (size_t)n), hipMemcpyDeviceToHost, c->stream));      // J0 | A | r0 | b
     int mstat[4] = {0, 0, 0, 0};
     if (getenv("VIL_MARG_DEBUG")) HIPCHK(hipMemcpyAsync(mstat, M.stat, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
