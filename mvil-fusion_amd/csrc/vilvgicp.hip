@@ -18,6 +18,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
 #include <unordered_map>
 #include <vector>
 
@@ -486,7 +488,7 @@ __host__ __device__ static void so3_exp_R(const double* w, double* R) {      // 
     const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
     double im, re;
     if (t2 < 1e-10) { const double t4 = t2 * t2; im = 0.5 - 1.0 / 48.0 * t2 + 1.0 / 3840.0 * t4; re = 1.0 - 1.0 / 8.0 * t2 + 1.0 / 384.0 * t4; }
-    else { const double t = sqrt(t2), h = 0.5 * t; im = sin(h) / t; re = cos(h); }
+    else { const double t = sqrt(t2), h = 0.5 * t; double sh, ch; sincos(h, &sh, &ch); im = sh / t; re = ch; }      // (one argument reduction for both)
     const double qw = re, qx = im * w[0], qy = im * w[1], qz = im * w[2];
     const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz, twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
     R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy; R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx; R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
@@ -544,7 +546,7 @@ __host__ __device__ static bool is_converged(const double* d, double reps, doubl
 // next transform, so a pass costs one exchange and the host sees one launch and one 0.5 kB read-back per alignment.
 #define VG_MAXG 128
 struct VgCoop { int flag[VG_MAXG]; double part[2][VG_MAXG][32]; };
-struct VgAlignOut { double T[16]; double H[36]; double err; int iterations, converged, n_corr, lm_failed, status, pad; };
+struct VgAlignOut { double T[16]; double H[36]; double err; int iterations, converged, n_corr, lm_failed, status, pad; int seq, pad2; };      // seq: written last, the host polls it
 struct VgGuess { double m[16]; };      // the initial transform travels in the kernel arguments, the result is written straight into pinned host memory
 struct VgLm {                          // state of the optimiser (thread 0 of every workgroup)
     double x0[16], xi[16], H[36], Hout[36], b[6], d[6], Rd[9];      // Rd: rotation of the current increment d
@@ -652,6 +654,7 @@ __global__ __launch_bounds__(VGA_THREADS) void k_vgicp_align(int n, int noff, co
     __shared__ double mine[VGA_THREADS / 64][30], gath[VGA_THREADS / 32][32], tot[32];
     __shared__ Iso Tsh; __shared__ int action, cbuf;
     const int t = threadIdx.x, g = blockIdx.x, G = gridDim.x, slots = n * noff;
+    const int epoch0 = epoch;                              // (unique per call: the host hands out growing epochs)
     if (t == 0) {
         for (int k = 0; k < 16; ++k) L.x0[k] = guess.m[k];
         for (int k = 0; k < 36; ++k) L.Hout[k] = (k % 7 == 0) ? 1.0 : 0.0;
@@ -760,6 +763,8 @@ __global__ __launch_bounds__(VGA_THREADS) void k_vgicp_align(int n, int noff, co
         out->err = L.y0; out->iterations = L.it; out->converged = L.converged; out->n_corr = L.n_corr;
         out->lm_failed = L.lm_failed > 0 ? 1 : 0; out->status = L.lm_failed < 0 ? VG_ERR_NONFINITE : VG_OK;
         out->pad = cbuf;                                    // which cache holds the correspondences of the last linearisation used
+        __threadfence_system();                             // the record is in (pinned) host memory before its sequence number
+        __hip_atomic_store(&out->seq, epoch0 + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -780,10 +785,24 @@ int vgicp_align(vgicp_ctx* c, const double* guess, const vgicp_options* o, doubl
     VgGuess gs; std::memcpy(gs.m, guess, sizeof gs.m);
     int G = std::min(nblk, VG_MAXG);     // all workgroups resident: they wait for each other.  A pass is bound by the slots per thread (each a chain of dependent gathers), so as many workgroups as there are 256-slot blocks, up to 128 (VGICP_G sweeps it)
     if (const char* ev = getenv("VGICP_G")) G = std::max(1, std::min(VG_MAXG, atoi(ev)));
+    const int epoch_of_call = c->coop_epoch;
+    ho->seq = -1;
     hipLaunchKernelGGL(k_vgicp_align, dim3(G), dim3(VGA_THREADS), 0, c->stream, c->n, mode, c->d_sxyz, c->d_scov, c->res, tab(c), c->d_cvox, c->d_cM, c->d_cvox2, c->d_cM2, *o, (VgCoop*)c->d_coop, c->coop_epoch, gs, (VgAlignOut*)c->d_aout);
     c->coop_epoch += 4 * (o->max_iterations * (o->lm_max_iterations + 1) + 4);      // epochs only grow: nothing to reset between calls
     if (c->coop_epoch > (1 << 30)) { VGCHK(hipMemsetAsync(c->d_coop, 0, sizeof(VgCoop), c->stream)); c->coop_epoch = 0; }
-    VGCHK(hipStreamSynchronize(c->stream));                 // (the record is in host memory when the kernel has finished)
+    {   // the kernel's last act is the record's sequence number in pinned memory: polling it returns a few microseconds before the
+        // stream's completion signal would (the launch queue stays in order either way); a kernel that never gets there is left to
+        // hipStreamSynchronize, which reports the fault
+        volatile int* seq = &ho->seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (long spin = 0;; ++spin) {
+            if (*seq == epoch_of_call + 1) { seen = true; break; }
+            if ((spin & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        }
+        if (!seen) VGCHK(hipStreamSynchronize(c->stream));
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     VGCHK(hipGetLastError());
     if (ho->pad) { std::swap(c->d_cvox, c->d_cvox2); std::swap(c->d_cM, c->d_cM2); std::swap(c->slots_cap, c->slots_cap2); }      // vgicp_error() after an alignment sees its last linearisation
     c->noff = mode; c->slots = slots; c->linearized = true;

@@ -38,8 +38,12 @@ class Vgicp:
             raise VgicpError("%screate failed: status %d (no HIP device? there is no CPU fallback)" % (prefix, st))
 
     def _f(self, name):
-        f = getattr(self.lib, self.prefix + name)
-        f.restype = C.c_int
+        fc = self.__dict__.setdefault("_fcache", {})
+        f = fc.get(name)
+        if f is None:
+            f = getattr(self.lib, self.prefix + name)
+            f.restype = C.c_int
+            fc[name] = f
         return f
 
     def close(self):
@@ -100,9 +104,12 @@ class Vgicp:
 
     def align(self, guess, opts=None):
         guess = np.ascontiguousarray(guess, np.float64)
-        opts = opts or self.default_options()
-        T = np.zeros((4, 4)); s = VgicpSummary()
-        self._chk("align", self._f("align")(self.ctx, guess.ctypes.data_as(_dp), C.byref(opts), T.ctypes.data_as(_dp), C.byref(s)))
+        if opts is None:                       # the library only reads the options: one default record per wrapper
+            opts = self.__dict__.get("_defopts")
+            if opts is None:
+                opts = self._defopts = self.default_options()
+        T = np.empty((4, 4)); s = VgicpSummary()
+        self._chk("align", self._f("align")(self.ctx, C.c_void_p(guess.ctypes.data), C.byref(opts), C.c_void_p(T.ctypes.data), C.byref(s)))
         return T, s
 
 
