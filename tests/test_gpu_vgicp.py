@@ -45,6 +45,35 @@ def test_align_parity(regs, optimizer):
     assert np.abs(Tg[:3, 3] - T_true[:3, 3]).max() < 0.03
 
 
+@pytest.mark.parametrize("case", ["poor_guess", "one_iteration", "two_iterations", "small_lm_budget"])
+def test_align_one_pass_per_iteration_paths(regs, case):
+    """k_vgicp_align evaluates an LM trial and the NEXT linearisation in one pass and keeps two correspondence caches: rejected trials
+    (the speculative linearisation is dropped), loops that end right after an accepted trial (it is never used), and the cache that
+    vgicp_error() sees after the alignment must all match the reference flow (linearise, then error passes)."""
+    g, o, _ = regs
+    guess = np.eye(4)
+    kw = {}
+    if case == "poor_guess":
+        guess[:3, :3] = vgicp._rot(0.05, -0.04, 0.12); guess[:3, 3] = [0.9, -0.7, 0.25]
+    elif case == "one_iteration":
+        kw = dict(max_iterations=1)
+    elif case == "two_iterations":
+        kw = dict(max_iterations=2)
+    else:
+        guess[:3, :3] = vgicp._rot(0.03, 0.02, -0.08); guess[:3, 3] = [-0.6, 0.5, 0.1]
+        kw = dict(lm_max_iterations=2, lm_init_lambda_factor=1e-12)
+    Tg, sg = g.align(guess, g.default_options(**kw))
+    To, so = o.align(guess, o.default_options(**kw))
+    assert (sg.iterations, sg.converged, sg.lm_failed, sg.n_correspondences) == (so.iterations, so.converged, so.lm_failed, so.n_correspondences)
+    assert np.abs(Tg - To).max() <= 1e-9
+    assert abs(sg.final_error - so.final_error) <= 1e-9 * max(so.final_error, 1.0)
+    assert np.abs(np.array(sg.final_hessian) - np.array(so.final_hessian)).max() <= 1e-9 * np.abs(np.array(so.final_hessian)).max()
+    # the correspondences left behind are those of the last linearisation the loop USED
+    T2 = To.copy(); T2[:3, 3] += [0.01, -0.005, 0.002]
+    eo = o.compute_error(T2)
+    assert abs(g.compute_error(T2) - eo) <= 1e-10 * max(eo, 1.0)
+
+
 def test_errors_and_determinism(regs):
     g, _, _ = regs
     T = np.eye(4)
