@@ -523,7 +523,7 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl) {
         int i = 0, j = 0;
         const bool ok = idx < NL;
         if (ok) {
-            i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+            i = (int)((sqrtf(8.f * (float)idx + 1.f) - 1.f) * 0.5f);      // (the two loops below make it exact; the fp64 square root is a 1 k-cycle chain)
             while (((i + 1) * (i + 2)) / 2 <= idx) ++i;
             while ((i * (i + 1)) / 2 > idx) --i;
             j = idx - (i * (i + 1)) / 2;              // (i, j), j <= i, enumerates a lower triangle row by row ...
@@ -532,23 +532,26 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl) {
         double vs = 0.0, vdg = 0.0;
         if (ok && j < NV) {
             const int tix = tri_idx(NV, i, j);
-            for (int w = slice; w < P.n_vwg; w += 8) {
-                vs += P.vpart[(size_t)w * P.VP + tix];
-                if (i == j) vdg += P.vpart[(size_t)w * P.VP + P.NVT + 2 * NV + i];
+            // eight records per round, every load issued before the first add (clamped record index + select: no predicated loads)
+            const double* vp = P.vpart + tix;
+            const double* vd_ = P.vpart + P.NVT + 2 * NV + i;
+            const int nw = P.n_vwg, wlast = nw - 1;
+            for (int w = slice; w < nw; w += 64) {
+                double a[8], d[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int wc = min(w + 8 * u, wlast); a[u] = vp[(size_t)wc * P.VP]; d[u] = (i == j) ? vd_[(size_t)wc * P.VP] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const bool in = w + 8 * u < nw; vs += in ? a[u] : 0.0; vdg += in ? d[u] : 0.0; }
             }
         }
         // the non-visual contributions are spread over the 8 slices of an entry
         double ms = 0.0;
         if (ok) {
-            if (slice == 1 && j < 6 * K && i / 6 == j / 6) {   // LiDAR plane points: pose-diagonal blocks
-                const int k = i / 6, a = i - 6 * k, b = j - 6 * k;
-                const int li = a * 6 - ((a * (a - 1)) >> 1) + (b - a);
-                for (int c = t_lch[k]; c < t_lch[k + 1]; ++c) ms += P.lpart[(size_t)c * 28 + li];
-            }
-            if (slice == 2 && j < 6 * K && i / 6 == j / 6) {   // LiDAR edge points
-                const int k = i / 6, a = i - 6 * k, b = j - 6 * k;
-                const int li = a * 6 - ((a * (a - 1)) >> 1) + (b - a);
-                for (int c = t_lch[K + 1 + k]; c < t_lch[K + 2 + k]; ++c) ms += P.lpart[(size_t)(P.n_pchunk + c) * 28 + li];
+            if (j < 6 * K && i / 6 == j / 6) {                 // LiDAR plane and edge points: pose-diagonal blocks.  The chunk records of a pose
+                const int k = i / 6, a = i - 6 * k, b = j - 6 * k;   // (one per 256 points: 9 per pose at 24 k points, 37 at 96 k) are dealt to the eight slices
+                const int li = a * 6 - ((a * (a - 1)) >> 1) + (b - a);   // of the entry -- one slice walking them all was the longest chain of this kernel
+                for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += 8) ms += P.lpart[(size_t)c * 28 + li];
+                for (int c = t_lch[K + 1 + k] + slice; c < t_lch[K + 2 + k]; c += 8) ms += P.lpart[(size_t)(P.n_pchunk + c) * 28 + li];
             }
             if (slice == 3 && j < 6 * K) {                     // ICP / LPS blocks live on pose columns
                 const int pi = i / 6, pj = j / 6, ri = i - 6 * pi, rj = j - 6 * pj;
@@ -594,8 +597,8 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl) {
             if (i < NV) for (int w = slice; w < P.n_vwg; w += 8) acc += P.vpart[(size_t)w * P.VP + P.NVT + which * NV + i];
             if (i < 6 * K) {
                 const int k = i / 6, a = i - 6 * k;
-                if (slice == 1) for (int c = t_lch[k]; c < t_lch[k + 1]; ++c) acc += P.lpart[(size_t)c * 28 + 21 + a];
-                if (slice == 2) for (int c = t_lch[K + 1 + k]; c < t_lch[K + 2 + k]; ++c) acc += P.lpart[(size_t)(P.n_pchunk + c) * 28 + 21 + a];
+                for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += 8) acc += P.lpart[(size_t)c * 28 + 21 + a];      // (chunk records dealt to the eight slices, as above)
+                for (int c = t_lch[K + 1 + k] + slice; c < t_lch[K + 2 + k]; c += 8) acc += P.lpart[(size_t)(P.n_pchunk + c) * 28 + 21 + a];
                 if (slice == 3) for (int f = 0; f < n_rel; ++f) for (int ba = 0; ba < 4; ++ba) if (t_rel[4 * f + ba] == k) acc += rel0[(size_t)f * 601 + 576 + ba * 6 + a];
             }
             if (slice == 4 || slice == 5) for (int f = slice - 4; f < P.n_imu; f += 2) { const int la = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], i); if (la >= 0) acc += P.ipart[(size_t)f * 931 + 900 + la]; }
