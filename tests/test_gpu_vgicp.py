@@ -74,6 +74,24 @@ def test_align_one_pass_per_iteration_paths(regs, case):
     assert abs(g.compute_error(T2) - eo) <= 1e-10 * max(eo, 1.0)
 
 
+def test_align_repeats_bit_identically(regs):
+    """The cooperative kernel's exchange uses relaxed agent-scope atomics and s_waitcnt instead of release / acquire fences, and the
+    host polls a sequence number in pinned memory instead of synchronising the stream: 300 back-to-back alignments (alternating guesses,
+    so a stale record or a missed partial sum would show) must return the same bits every time."""
+    g, _, _ = regs
+    g2 = np.eye(4); g2[:3, 3] = [0.05, -0.02, 0.01]
+    ref = {}
+    for it in range(300):
+        k = it & 1
+        T, s = g.align(np.eye(4) if k == 0 else g2)
+        key = (T.tobytes(), s.iterations, s.n_correspondences, s.final_error)
+        if k in ref:
+            assert key == ref[k], it
+        else:
+            ref[k] = key
+    assert ref[0][0] != ref[1][0]
+
+
 def test_errors_and_determinism(regs):
     g, _, _ = regs
     T = np.eye(4)
