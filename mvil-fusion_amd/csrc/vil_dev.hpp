@@ -98,6 +98,9 @@ struct DevP {
     int skip_mask;                // debug: bit0 visual, 1 imu, 2 plane, 3 edge, 4 misc roles skipped in the sweep
     // helper workgroups of the single-GPU step kernel (landmark pre-pass on extra CUs): n_help of them, each publishes
     // {q, g2, gm} in hpart[4 * k ..] and then stores the launch epoch in hflag[k]; only the master workgroup ever waits
+    // pinned host mirror of Ctl (device pointers into mapped host memory; null: off): the step kernel that finishes the solve copies
+    // its Ctl there and then stores the solve generation in hseq -- the host polls that word instead of synchronising the stream
+    Ctl* hctl; int* hseq;
     int n_help; double* hpart; int* hflag;
     // second landmark pass of the helpers (k_step): the master posts the epoch in xflag (Sc x_p is in stepc) or in xstat (no step
     // this launch); every helper WAVE then leaves its six sums in hpart2[8 * slot ..] and the epoch in hflag2[slot], slot = 8 k + wave

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -118,6 +119,7 @@ struct vil_ctx {
     bool step_lds = false;
     int* d_status = nullptr;
     Ctl* h_ctl = nullptr;          // pinned
+    char* h_mirror = nullptr; Ctl* d_hctl = nullptr; int* d_hseq = nullptr;      // pinned + mapped: Ctl | sequence word, written by the step kernel (DevP::hctl)
     double* h_pin = nullptr;       // pinned scratch
     char* marg_ws = nullptr;       // device work space of vil_marginalize (grow-only)
     size_t marg_ws_bytes = 0;
@@ -244,6 +246,11 @@ int vil_create(const vil_device_cfg* cfg, vil_ctx** out) {
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc(&c->d_status, sizeof(int)));
     HIPCHK(hipHostMalloc(&c->h_ctl, sizeof(Ctl), hipHostMallocDefault));
+    if (!getenv("VIL_NO_POLL") && hipHostMalloc((void**)&c->h_mirror, sizeof(Ctl) + 64, hipHostMallocMapped) == hipSuccess) {
+        memset(c->h_mirror, 0, sizeof(Ctl) + 64);
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, c->h_mirror, 0) == hipSuccess) { c->d_hctl = (Ctl*)dp; c->d_hseq = (int*)((char*)dp + sizeof(Ctl)); }
+    }
     memset(&c->P, 0, sizeof c->P);
     *out = c;
     return VIL_OK;
@@ -263,6 +270,7 @@ void vil_destroy(vil_ctx* c) {
     if (c->dep_ev) hipEventDestroy(c->dep_ev);
     if (c->d_status) hipFree(c->d_status);
     if (c->h_ctl) hipHostFree(c->h_ctl);
+    if (c->h_mirror) hipHostFree(c->h_mirror);
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->marg_ws) hipFree(c->marg_ws);
     if (c->lc_tmp) hipFree(c->lc_tmp);
@@ -620,6 +628,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     }
     if (ar.ssize) HIPCHK(hipMemsetAsync(ar.d + tables, 0, ar.ssize, c->stream));
     c->P = P; c->K = K; c->L = L; c->D = D; c->NS = NS;
+    c->P.hctl = c->d_hctl; c->P.hseq = c->d_hseq;
     { const int per = VIL_SWEEP_THREADS / 256; c->n_blocks_sweep = P.n_imu + P.n_vwg + (P.n_pchunk + per - 1) / per + (P.n_echunk + per - 1) / per + 2; }
     c->lds_sweep = sizeof(double) * (size_t)(P.NVT + 3 * NV + VIL_VCHUNK_F * VF_STRIDE + VIL_VCHUNK_LM * 16 + 32 + VIL_VCHUNK_F + 8 + VIL_VCHUNK_LM + 8);
     if (c->lds_sweep < 8 * 2048) c->lds_sweep = 8 * 2048;
@@ -859,7 +868,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     int st = init_ctl(c, o, 0);
     if (st != VIL_OK) return st;
     // every iteration = one sweep + one step kernel; `done` turns the tail into no-ops
-    bool finished = false;
+    bool finished = false, polled_done = false;
     // iterations are enqueued in chunks without host round trips; the first chunk is sized by the previous solve of
     // this context (consecutive windows of a tracker need similar iteration counts), later chunks are short
     int chunk = std::min(15, std::max(3, c->last_live));
@@ -893,8 +902,29 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
             if (st != VIL_OK) return st;          // a failed collective fails on every rank (all_reduce): nobody is left waiting
         }
         if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * launched], c->stream));
-        HIPCHK(hipMemcpyAsync(c->h_ctl, c->P.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        // The step kernel that finishes the solve leaves Ctl + the solve generation in pinned host memory: poll that word instead of
+        // synchronising (a few microseconds earlier, and the no-op tail of the chunk is not waited for).  A chunk that runs out without
+        // finishing is seen by hipStreamQuery and takes the copy + synchronise route, as do profiling and multi-rank solves.
+        bool polled = false;
+        if (c->d_hseq && !c->profiling && !c->split) {
+            volatile int* seq = (volatile int*)(c->h_mirror + sizeof(Ctl));
+            const int gen = c->solve_gen;
+            const auto tp0 = std::chrono::steady_clock::now();
+            for (long spin = 1;; ++spin) {
+                if (*seq == gen) { polled = true; break; }
+                if ((spin & 0x3ff) == 0) {
+                    const hipError_t q = hipStreamQuery(c->stream);
+                    if (q == hipSuccess) { polled = *seq == gen; break; }
+                    if (q != hipErrorNotReady) return VIL_ERR_DEVICE;
+                    if (std::chrono::steady_clock::now() - tp0 > std::chrono::seconds(2)) break;
+                }
+            }
+            if (polled) { std::atomic_thread_fence(std::memory_order_acquire); memcpy(c->h_ctl, c->h_mirror, sizeof(Ctl)); polled_done = true; }
+        }
+        if (!polled) {
+            HIPCHK(hipMemcpyAsync(c->h_ctl, c->P.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
         finished = c->h_ctl->done != 0;
         if (c->profiling) {
             int live = c->h_ctl->n_sweeps - sweeps_before;   // launches that found done == 0
@@ -923,7 +953,9 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     if (ctl.cur != 0) HIPCHK(hipMemcpyAsync(c->P.x[0], c->P.x[1], 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
     else HIPCHK(hipMemcpyAsync(c->P.x[1], c->P.x[0], 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
     if (c->gauge_on && finished && c->h_ctl->status == 0) hipLaunchKernelGGL(k_gauge_fix, dim3(1), dim3(64), 0, c->stream, c->P, c->d_x0);      // estimator.cpp:960-1011 before the read-back
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // (whoever reads the state back -- vil_download_state, vil_marginalize_resident -- orders itself behind these on the stream and
+    //  synchronises for its own copy; a solve whose end was polled does not wait for its no-op tail here)
+    if (!polled_done) HIPCHK(hipStreamSynchronize(c->stream));
     if (!finished) return VIL_ERR_DEVICE;
     if (ctl.status != 0) return ctl.status;
     if (!std::isfinite(ctl.cost_cur)) return VIL_ERR_NON_FINITE;
