@@ -264,7 +264,11 @@ int vil_comm_init_local(vil_ctx** ctxs, int n);
 int vil_solve(vil_ctx* ctx, const vil_problem* problem, vil_state* state_inout,
               const vil_options* options, vil_summary* summary);
 
-/* resident variant: upload once, solve many times without host<->device traffic of the factor tables */
+/* resident variant: upload once, solve many times without host<->device traffic of the factor tables.
+ * vil_solve_resident returns when the summary is known: the launch that finishes the solve leaves its trust-region record in pinned host
+ * memory and the host polls it, so the tail of the stream (launches that find the solve finished, the copy of the accepted state,
+ * the gauge fix) may still be draining.  Everything that reads the window afterwards (vil_download_state, vil_marginalize_resident,
+ * the next vil_solve_resident, vil_upload) is ordered behind it on the context's stream; VIL_NO_POLL=1 restores copy + synchronise. */
 int vil_upload(vil_ctx* ctx, const vil_problem* problem, const vil_state* state);
 int vil_solve_resident(vil_ctx* ctx, const vil_options* options, vil_summary* summary);
 int vil_reset_state(vil_ctx* ctx);                       /* restore the uploaded state on device */
