@@ -28,6 +28,7 @@ struct Pose1Out {                // one record per round, read back once per reg
     int iterations, successful_steps, termination, status, n_edge, n_plane;
 };
 
+struct Pose1In { double pose[7]; int use; int pad; };      // starting pose in the kernel arguments (use != 0) instead of a 56-byte upload
 struct Pose1Shared {
     double red[VP1_WAVES][28];
     double mine[28];             // this workgroup's partial sums of the current evaluation
@@ -265,14 +266,22 @@ __device__ __forceinline__ bool pose1_serial(Pose1Shared& sh, Pose1State& st, Do
 // Grid: G <= VP1_MAXG workgroups, all resident (G is a handful); workgroup 0 writes the result.  Each candidate is linearised
 // where it is evaluated (the window solver does the same), so an accepted step costs one evaluation, not two.
 __global__ __launch_bounds__(VP1_THREADS) void k_pose_solve(const int* __restrict__ cnt, const double* __restrict__ ed, int es, const double* __restrict__ pl, int ps, double* pose_io,
-                                                            PoseRT* rt_out, vil_options O, const Pose1Out* prev, Pose1Out* out, Pose1Coop* coop, int epoch) {
+                                                            PoseRT* rt_out, vil_options O, const Pose1Out* prev, Pose1Out* out, Pose1Coop* coop, int epoch,
+                                                            Pose1In pin, Pose1Out* hout, int* hseq) {      // hout / hseq: pinned host mirror of the record + its sequence word (or null)
+    const int epoch0 = epoch;
     __shared__ Pose1Shared sh;
     __shared__ Pose1State st;
     const int t = threadIdx.x, g = blockIdx.x, G = gridDim.x;
     const int ne = cnt[0], np = cnt[1];
     const int prev_status = prev ? prev->status : 0;
-    if (prev_status != 0) { if (t == 0 && g == 0) { Pose1Out o = *prev; o.n_edge = ne; o.n_plane = np; *out = o; } return; }
-    if (t < 7) sh.cand[t] = sh.x[t] = pose_io[t];
+    if (prev_status != 0) {
+        if (t == 0 && g == 0) {
+            Pose1Out o = *prev; o.n_edge = ne; o.n_plane = np; *out = o;
+            if (hout) { *hout = o; __threadfence_system(); __hip_atomic_store(hseq, epoch0 + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        }
+        return;
+    }
+    if (t < 7) sh.cand[t] = sh.x[t] = pin.use ? pin.pose[t] : pose_io[t];
     if (t == 0) { st.cost = st.initial_cost = st.model_change = 0.0; st.iter = st.nsucc = st.invalid_run = 0; st.term = VIL_TERM_NONE; st.status = 0; st.first = 1; for (int q = 0; q < 6; ++q) st.tk[q] = 0; }
     __syncthreads();
 #ifdef VP1_STAMPS
@@ -339,13 +348,14 @@ __global__ __launch_bounds__(VP1_THREADS) void k_pose_solve(const int* __restric
         int status = st.status;
         if (status == 0) status = !finite ? VIL_ERR_NON_FINITE : (st.term == VIL_TERM_FAILURE ? VIL_ERR_NOT_POSITIVE_DEFINITE : 0);
         Pose1Out o;
-        for (int q = 0; q < 7; ++q) o.pose[q] = finite ? sh.x[q] : pose_io[q];
+        for (int q = 0; q < 7; ++q) o.pose[q] = finite ? sh.x[q] : (pin.use ? pin.pose[q] : pose_io[q]);
         o.initial_cost = st.initial_cost; o.final_cost = cost; o.iterations = st.iter; o.successful_steps = st.nsucc; o.termination = st.term; o.status = status; o.n_edge = ne; o.n_plane = np;
         *out = o;
         if (finite) {
             for (int q = 0; q < 7; ++q) pose_io[q] = sh.x[q];
             PoseRT T; pose_rt(sh.x, T); *rt_out = T;
-        }
+        } else if (pin.use) { for (int q = 0; q < 7; ++q) pose_io[q] = pin.pose[q]; }
+        if (hout) { *hout = o; __threadfence_system(); __hip_atomic_store(hseq, epoch0 + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }      // the host polls this word
     }
 }
 

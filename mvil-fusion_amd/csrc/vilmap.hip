@@ -8,6 +8,7 @@
 // and the 7-parameter solve is vil_solve on a one-pose window that holds exactly these factors (k_sweep's LiDAR roles).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -261,6 +262,7 @@ struct vmap_ctx {
     double* d_soa = nullptr; size_t soa_cap = 0; int* d_cnt = nullptr; int* h_cnt = nullptr;   // device-resident factor tables of vmap_align
     vp1::Pose1Coop* d_coop = nullptr; int reg_epoch = 0;   // meeting point of the pose solve's workgroups; epoch numbers are never reused
     char* d_reg = nullptr; char* h_reg = nullptr;     // single-submission registration: pose (7 doubles) | PoseRT | 2 x Pose1Out, and its pinned mirror
+    char* h_res = nullptr; void* d_res = nullptr;     // pinned + mapped: the second round's Pose1Out | sequence word, written by k_pose_solve, polled by the host
     int fused_max = 1 << 20;                           // scans up to this many points take the one-launch pose solve (VIL_MAP_FUSED_MAX overrides; 0 = always the window solver)
     bool profiling = false; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; long long prof_n[2] = {0, 0}; double prof_ms[2] = {0.0, 0.0};
 };
@@ -347,11 +349,22 @@ int align_fused(vmap_ctx* c, int n_corner, int n_surf, double* q, double* t, con
     if (!c->d_cnt) { VMCHK(hipMalloc(&c->d_cnt, 16)); VMCHK(hipHostMalloc((void**)&c->h_cnt, 16, hipHostMallocDefault)); }
     if (!c->d_reg) { VMCHK(hipMalloc(&c->d_reg, REG_BYTES)); VMCHK(hipHostMalloc((void**)&c->h_reg, REG_BYTES, hipHostMallocDefault)); }
     if (!c->d_coop) { VMCHK(hipMalloc(&c->d_coop, sizeof(vp1::Pose1Coop))); VMCHK(hipMemsetAsync(c->d_coop, 0, sizeof(vp1::Pose1Coop), c->stream)); }
+    if (!c->h_res && !getenv("VIL_NO_POLL")) {
+        if (hipHostMalloc((void**)&c->h_res, sizeof(vp1::Pose1Out) + 64, hipHostMallocMapped) == hipSuccess) {
+            memset(c->h_res, 0, sizeof(vp1::Pose1Out) + 64);
+            if (hipHostGetDevicePointer(&c->d_res, c->h_res, 0) != hipSuccess) { hipHostFree(c->h_res); c->h_res = nullptr; c->d_res = nullptr; }
+        } else c->h_res = nullptr;
+    }
     const int G = std::min(VP1_MAXG, std::max(1, (nq + VP1_THREADS - 1) / VP1_THREADS));
     double* edge_soa = c->d_soa; double* plane_soa = c->d_soa + (size_t)9 * es;
     double* h_pose = (double*)(c->h_reg + REG_POSE);
     h_pose[0] = t[0]; h_pose[1] = t[1]; h_pose[2] = t[2]; h_pose[3] = q[0]; h_pose[4] = q[1]; h_pose[5] = q[2]; h_pose[6] = q[3];
-    VMCHK(hipMemcpyAsync(c->d_reg + REG_POSE, h_pose, 56, hipMemcpyHostToDevice, c->stream));
+    vp1::Pose1In pin0, pin1; memset(&pin0, 0, sizeof pin0); memset(&pin1, 0, sizeof pin1);
+    for (int k = 0; k < 7; ++k) pin0.pose[k] = h_pose[k];
+    pin0.use = 1;                                        // the starting pose rides in the first solve's arguments (no 56-byte upload)
+    int seq_expect = 0;
+    volatile int* hseq = c->h_res ? (volatile int*)(c->h_res + sizeof(vp1::Pose1Out)) : nullptr;
+    if (hseq) *hseq = -1;
     PoseD T; quat_to_R(q, T.R); T.t[0] = t[0]; T.t[1] = t[1]; T.t[2] = t[2];
     double* d_slot = (double*)c->d_work; int* d_nn = (int*)(c->d_work + 80 * (size_t)nq); float* d_nd5 = (float*)(d_nn + 10 * (size_t)nq); float* d_nint = d_nd5 + nq; int* d_blk = (int*)(c->d_work + (((size_t)164 * nq + 7) & ~(size_t)7));
     vp1::Pose1Out* d_out = (vp1::Pose1Out*)(c->d_reg + REG_OUT);
@@ -366,12 +379,25 @@ int align_fused(vmap_ctx* c, int n_corner, int n_surf, double* q, double* t, con
             hipLaunchKernelGGL(k_map_compact, dim3((nq + VM_THREADS - 1) / VM_THREADS), dim3(VM_THREADS), 0, c->stream, n_corner, n_surf, d_slot, d_blk, edge_soa, es, plane_soa, ps, c->d_cnt);
         } else VMCHK(hipMemsetAsync(c->d_cnt, 0, 8, c->stream));
         hipLaunchKernelGGL(vp1::k_pose_solve, dim3(G), dim3(VP1_THREADS), 0, c->stream, c->d_cnt, edge_soa, es, plane_soa, ps, (double*)(c->d_reg + REG_POSE), (PoseD*)(c->d_reg + REG_RT), *opts,
-                           round ? d_out : (const vp1::Pose1Out*)nullptr, d_out + round, c->d_coop, c->reg_epoch);
+                           round ? d_out : (const vp1::Pose1Out*)nullptr, d_out + round, c->d_coop, c->reg_epoch, round ? pin1 : pin0,
+                           (round && c->d_res) ? (vp1::Pose1Out*)c->d_res : (vp1::Pose1Out*)nullptr, (round && c->d_res) ? (int*)((char*)c->d_res + sizeof(vp1::Pose1Out)) : (int*)nullptr);
+        if (round) seq_expect = c->reg_epoch + 1;
         c->reg_epoch += std::min(std::max(opts->max_iterations, 0), VP1_MAX_ITER) + 8;     // one epoch per evaluation: at most max_iterations + 1
         if (c->reg_epoch > (1 << 30)) { c->reg_epoch = 0; VMCHK(hipMemsetAsync(c->d_coop, 0, sizeof(vp1::Pose1Coop), c->stream)); }   // flags are compared by order: start over from zeroed flags
     }
-    VMCHK(hipMemcpyAsync(c->h_reg + REG_OUT, d_out, 2 * sizeof(vp1::Pose1Out), hipMemcpyDeviceToHost, c->stream));
-    VMCHK(hipStreamSynchronize(c->stream));
+    bool polled = false;
+    if (hseq && !c->profiling) {                         // the second solve's last act is the record + its sequence word in pinned memory
+        const auto tp0 = std::chrono::steady_clock::now();
+        for (long spin = 1;; ++spin) {
+            if (*hseq == seq_expect) { polled = true; break; }
+            if ((spin & 0xfff) == 0 && std::chrono::steady_clock::now() - tp0 > std::chrono::milliseconds(500)) break;
+        }
+        if (polled) { std::atomic_thread_fence(std::memory_order_acquire); memcpy(c->h_reg + REG_OUT + sizeof(vp1::Pose1Out), c->h_res, sizeof(vp1::Pose1Out)); }
+    }
+    if (!polled) {
+        VMCHK(hipMemcpyAsync(c->h_reg + REG_OUT, d_out, 2 * sizeof(vp1::Pose1Out), hipMemcpyDeviceToHost, c->stream));
+        VMCHK(hipStreamSynchronize(c->stream));
+    }
     VMCHK(hipGetLastError());
     if (c->profiling && nq > 0) {
         float ms = 0.f;
@@ -404,7 +430,7 @@ int vmap_create(int32_t device, vmap_ctx** out) {
 void vmap_destroy(vmap_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    hipFree(c->d_cmap); hipFree(c->d_smap); hipFree(c->gc.ws); hipFree(c->gs.ws); hipFree(c->d_scan); hipFree(c->d_work); if (c->h_slot) hipHostFree(c->h_slot); hipFree(c->d_soa); hipFree(c->d_cnt); if (c->h_cnt) hipHostFree(c->h_cnt); hipFree(c->d_reg); if (c->h_reg) hipHostFree(c->h_reg); hipFree(c->d_coop); if (c->h_scan) hipHostFree(c->h_scan);
+    hipFree(c->d_cmap); hipFree(c->d_smap); hipFree(c->gc.ws); hipFree(c->gs.ws); hipFree(c->d_scan); hipFree(c->d_work); if (c->h_slot) hipHostFree(c->h_slot); hipFree(c->d_soa); hipFree(c->d_cnt); if (c->h_cnt) hipHostFree(c->h_cnt); hipFree(c->d_reg); if (c->h_reg) hipHostFree(c->h_reg); if (c->h_res) hipHostFree(c->h_res); hipFree(c->d_coop); if (c->h_scan) hipHostFree(c->h_scan);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
