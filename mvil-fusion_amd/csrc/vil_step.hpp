@@ -782,10 +782,19 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     auto post = [&](int* f) { if (t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } };
     auto wait1 = [&](int* f) { while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1); };
     auto put = [&](double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    // thread 0: Ctl back to device memory; the launch that finishes the solve also leaves it in the host's pinned mirror, then the generation
+    // wave 0 (all 64 lanes call it): Ctl back to device memory; the launch that finishes the solve also leaves it in the host's pinned mirror --
+    // 1.5 kB across PCIe, one coalesced store per lane and round instead of a lone lane's 190 -- then the generation
     auto store_ctl = [&]() {
-        *P.ctl = s.c;
-        if (s.c.done && P.hctl) { *P.hctl = s.c; __threadfence_system(); __hip_atomic_store(P.hseq, s.c.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        static_assert(sizeof(Ctl) % 8 == 0, "Ctl is copied as doubles");
+        const double* src = (const double*)&s.c;
+        double* dst = (double*)P.ctl;
+        for (int i = t; i < (int)(sizeof(Ctl) / 8); i += 64) dst[i] = src[i];
+        if (s.c.done && P.hctl) {
+            double* h = (double*)P.hctl;
+            for (int i = t; i < (int)(sizeof(Ctl) / 8); i += 64) h[i] = src[i];
+            __threadfence_system();
+            if (t == 0) __hip_atomic_store(P.hseq, s.c.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     };
     // master: every helper has read Ctl (one lane per helper: the polls overlap instead of queueing behind one another)
     bool hseen = false;
@@ -970,7 +979,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         } else post(P.hflag + hk);
         return;
     }
-    if (s.c.done) { if (t < 64) { wait_helpers(); if (t == 0) store_ctl(); } return; }
+    if (s.c.done) { if (t < 64) { wait_helpers(); store_ctl(); } return; }
     for (int i = t; i < 16 * P.K + 8; i += NT) s.x0[i] = x[i];          // (read after several barriers)
     for (int k = t; k < 2 * P.K; k += NT) s.cst[k] = k < P.K ? (P.pose_const ? P.pose_const[k] : 0) : (P.sb_const ? P.sb_const[k - P.K] : 0);
     bool xpub = false;                                 // the master owes the waiting helpers an xflag on every path through the need branch
@@ -1100,7 +1109,8 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         STAMP(2);
         if (!defer && gm <= O.gradient_tolerance) {
             if (!xpub) publish_xp(0);
-            if (t == 0) { s.c.done = 1; s.c.term = 2; store_ctl(); }
+            if (t == 0) { s.c.done = 1; s.c.term = 2; }
+            if (t < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); store_ctl(); }
             return;
         }
         if constexpr (CHAIN == 0) { if constexpr (LDSM) ok = chol_blocked<true>(Alds, D, s); else ok = chol_blocked<false>(P.M, D, s, Alds); }      // Alds = staging of the active tile column
@@ -1119,7 +1129,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             }
             for (int i = t; i < P.NS; i += NT) xc[i] = x[i];
             __syncthreads();
-            if (t == 0) store_ctl();
+            if (t < 64) store_ctl();
             return;
         }
         if constexpr (CHAIN == 0) { if constexpr (LDSM) back_subst(Alds, D, s); else back_subst(P.M, D, s); publish_xp(1); }
@@ -1158,7 +1168,8 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             __syncthreads();
             }
             if (defer && gm <= O.gradient_tolerance) {          // (the check the other paths make before the factorisation)
-                if (t == 0) { s.c.done = 1; s.c.term = 2; store_ctl(); }
+                if (t == 0) { s.c.done = 1; s.c.term = 2; }
+                if (t < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); store_ctl(); }
                 return;
             }
         }
@@ -1248,5 +1259,5 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     __syncthreads();
     if (s.c.resweep && !s.c.done) { for (int i = t; i < 16 * P.K + 8; i += NT) xc[i] = s.x0[i]; }
     STAMP(7);
-    if (t < 64) { if (nhelp) wait_helpers(); if (t == 0) store_ctl(); }      // (no second poll when the sums were already collected)
+    if (t < 64) { if (nhelp) wait_helpers(); store_ctl(); }      // (no second poll when the sums were already collected)
 }
