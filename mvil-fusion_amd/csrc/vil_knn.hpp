@@ -95,6 +95,20 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
 __device__ __forceinline__ void knn_wave_offer(unsigned long long& best, unsigned long long key, int kk) {
     unsigned long long thr = readlane_u64(best, kk - 1);
     unsigned long long m = __ballot(key < thr);
+    if (thr == ~0ull && __builtin_popcountll(m) > kk) {
+        // The list is not full yet (first batch of a query): every candidate passes the k-th best test and the serial loop below would take
+        // k (1 + ln(n / k)) insertions to find the k smallest of n.  Find instead the smallest 16-bit prefix P of the distance bits
+        // (sign, exponent, seven mantissa bits; distances are >= 0, so bit order = value order) with at least k candidates at or below
+        // it -- sixteen ballots -- and offer only those: a candidate above P is beaten by k others of this very batch, so the result is
+        // unchanged, and the loop runs k (+ the few that share the prefix) times.
+        const unsigned hi = (unsigned)(key >> 48);
+        unsigned lo = 0u, up = 0xFFFFu;
+        while (lo < up) {
+            const unsigned mid = (lo + up) >> 1;
+            if (__builtin_popcountll(__ballot(hi <= mid)) >= kk) up = mid; else lo = mid + 1u;
+        }
+        m &= __ballot(hi <= lo);
+    }
     while (m) {
         const int l = __builtin_ctzll(m);
         const unsigned long long c = readlane_u64(key, l);
