@@ -760,13 +760,19 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     const int bid = (int)blockIdx.x;
     const bool helper = bid > 0;
     const int nhelp = (int)gridDim.x - 1;
-    if (t == 0) { s.c = *P.ctl; s.c.swe++; s.need = 0; s.was_first = 0; s.ok = 1; }      // (every path that writes Ctl back carries the new swe)
+    {   // Ctl (1.5 kB with its traces) into LDS: one coalesced load per lane, not 190 loads of a lone lane with everybody waiting at the barrier
+        const double* src = (const double*)P.ctl; double* dst = (double*)&s.c;
+        for (int i = t; i < (int)(sizeof(Ctl) / 8); i += NT) dst[i] = src[i];
+        if (t == 0) { s.need = 0; s.was_first = 0; s.ok = 1; }
+    }
     for (int q = t; q < 256; q += NT) {      // triangular tile index -> (tile row, tile col)
         int Ir = (int)((sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
         if (((Ir + 1) * (Ir + 2)) / 2 <= q) ++Ir;
         if ((Ir * (Ir + 1)) / 2 > q) --Ir;
         s.tI[q] = (unsigned char)Ir; s.tJ[q] = (unsigned char)(q - (Ir * (Ir + 1)) / 2);
     }
+    __syncthreads();
+    if (t == 0) s.c.swe++;                   // (every path that writes Ctl back carries the new swe)
     __syncthreads();
 #ifdef VIL_STAMPS
     #define STAMP(k) do { __syncthreads(); if (t == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[k] = tt_; } } while (0)
