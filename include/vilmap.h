@@ -49,6 +49,11 @@ int vmap_associate(vmap_ctx* ctx, int32_t n_corner, const float* corner_xyzi, in
 /* localMapping.cpp:594-791: q_xyzw / t hold the initial guess (transformAssociateToMap) and receive the result */
 int vmap_align(vmap_ctx* ctx, vil_ctx* solver, int32_t n_corner, const float* corner_xyzi, int32_t n_surf, const float* surf_xyzi,
                double* q_xyzw, double* t, const vil_options* opts, vmap_summary* out);
+/* Scans of up to max_points points (default 2^20) take the one-launch 6-dof solve (k_pose_solve); larger ones -- and every scan when
+ * max_points = 0 -- go through vil_solve on a one-pose window (the cross-check of the tests).  The one-launch solve is a persistent
+ * kernel whose workgroups wait for one another: its grid is clamped to what the device holds at once and launches of such kernels are
+ * serialised process-wide (csrc/vil_coop.hpp). */
+int vmap_set_fused_max(vmap_ctx* ctx, int32_t max_points);
 /* measurement hook (bench.py): HIP events on the library's stream around the two association kernels; read returns
  * {k_map_search, k_map_fit} launch counts and total durations and resets them */
 int vmap_profile_enable(vmap_ctx* ctx, int32_t enable);

@@ -244,7 +244,10 @@ int vil_abi_version(void);
 const char* vil_strerror(int status);
 
 /* context: device buffers, stream, (optional) RCCL communicator. Non-reentrant per ctx
- * (the reference never re-enters optimization(): estimator_node.cpp:388,352-355). */
+ * (the reference never re-enters optimization(): estimator_node.cpp:388,352-355).
+ * Window size: K <= 20 frames (reduced dimension 15 K + 7 <= 307: the step kernel's LDS work space; the reference runs K = 7,
+ * parameters.h:12); larger windows return VIL_ERR_UNSUPPORTED.  Per landmark at most 128 observations, at most 12 ICP + LPS
+ * constraints (the reference trims to 5 + 7), prior dimension <= 136 for vil_marginalize. */
 int vil_create(const vil_device_cfg* cfg, vil_ctx** out);
 void vil_destroy(vil_ctx* ctx);
 
@@ -258,6 +261,9 @@ int vil_comm_init(vil_ctx* ctx, const void* id128, int rank, int world);
  * same per-iteration reductions as vil_comm_init, summed through device memory instead of RCCL.  Also lets a sharded
  * solve be exercised on a single device (tests). */
 int vil_comm_init_local(vil_ctx** ctxs, int n);
+/* test hook: run the multi-GPU plumbing (partial system in set 0, the collective sums it into set 1, step kernel on set 1) on a
+ * single rank, with or without a 1-rank communicator.  Invalidates the resident window. */
+int vil_debug_set_split(vil_ctx* ctx, int32_t on);
 
 /* replaces estimator.cpp:1126-1419 (build ceres::Problem ... ceres::Solve): state is updated in
  * place on success and left UNCHANGED on any error. */
@@ -330,12 +336,16 @@ int vil_marginalize(vil_ctx* ctx, const vil_problem* problem, const vil_state* s
  *    MARGIN_SECOND_NEW; later slabs move down -- an index remap, no data moves).  A problem with
  *    n_plane = n_edge = VIL_LIDAR_RESIDENT takes its point factors from the slabs: slab i belongs to window pose
  *    K - count + i (the newest slab is the newest frame); plane_* / edge_* of the problem are ignored.
+ *    vil_lidar_push / drop / reset change which slab belongs to which pose (and recycle physical slabs): a window that was uploaded
+ *    with resident point factors is INVALIDATED by them -- vil_solve_resident / vil_marginalize_resident return
+ *    VIL_ERR_INVALID_ARGUMENT until the next vil_upload / vil_solve.  Per image: solve, marginalise, THEN drop and push.
  *  - vil_set_gauge_fix(ctx, 1): vil_solve applies double2vector()'s yaw / translation gauge fix (estimator.cpp:960-1011) on
  *    the device before the state is read back (vil_gauge_fix on the returned state is then the identity).
  *  - vil_marginalize_resident marginalises the window that vil_solve / vil_upload left on the device, at its solved (and
  *    gauge-fixed) state: the factors MarginalizationInfo collects are selected by masks inside the sweep, nothing is packed
- *    or uploaded again.  `solved` must be the state vil_solve returned (it only supplies the linearisation point x0 of the
- *    new prior).  Same results as vil_marginalize on the same window and state. */
+ *    or uploaded again.  The linearisation point x0 of the new prior is read back from the DEVICE state the factors were
+ *    linearised at (`solved` only supplies K and L; with the device gauge fix on, that is the state vil_solve returned).
+ *    Same results as vil_marginalize on the same window and state. */
 #define VIL_LIDAR_RESIDENT (-1)
 int vil_lidar_reset(vil_ctx* ctx);
 int vil_lidar_push(vil_ctx* ctx, int32_t n_plane, const double* plane_const, int32_t n_edge, const double* edge_const);

@@ -55,11 +55,16 @@ int vgicp_set_source(vgicp_ctx* ctx, int32_t n, const float* xyz, const double* 
  * neighbours with a kd-tree in float; this is an EXACT search with the same float distances (ties may order differently).
  * out_cov9: n x 9 host buffer. */
 int vgicp_covariances(vgicp_ctx* ctx, int32_t n, const float* xyz, int32_t k, double* out_cov9);
+/* neighbour search of vgicp_covariances: clouds of at least min_points points (default 4096) use the uniform-grid search with an initial
+ * cell edge `cell` (default 1.0 m, adapted to ~8 points per cell), smaller ones the tiled exhaustive search; both are exact. */
+int vgicp_set_knn_grid(vgicp_ctx* ctx, int32_t min_points, double cell);
 /* T: row-major 4x4 isometry (source -> target).  Recomputes the correspondences and their Mahalanobis matrices at T.
  * H (6x6 row-major, [rotation | translation] order), b (6) may both be NULL (error only). */
 int vgicp_linearize(vgicp_ctx* ctx, const double* T, int32_t neighbor_mode, double* err, double* H, double* b, int32_t* n_corr);
 /* error at T with the correspondences / Mahalanobis matrices of the LAST vgicp_linearize (as the reference) */
 int vgicp_compute_error(vgicp_ctx* ctx, const double* T, double* err);
+/* One launch per alignment: a persistent kernel whose workgroups wait for one another.  Its grid is clamped to what the device holds at
+ * once, launches of such kernels are serialised process-wide (csrc/vil_coop.hpp), and a device that cannot hold it takes one launch per pass. */
 int vgicp_align(vgicp_ctx* ctx, const double* guess, const vgicp_options* opts, double* T_out, vgicp_summary* out);
 /* profiling aid (bench.py): with enable != 0 every vgicp_linearize brackets its main kernel with HIP events on the library's
  * own stream; vgicp_profile_read returns the number of timed launches and their total duration, and resets both. */

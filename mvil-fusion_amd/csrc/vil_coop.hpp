@@ -1,0 +1,20 @@
+// Persistent kernels whose workgroups wait for one another (k_vgicp_align, k_pose_solve, the helper workgroups of k_step) only
+// finish if ALL of their workgroups are resident at once.  Two guards, shared by the three translation units of the library:
+//   capacity(): how many workgroups of a kernel the device can hold at the same time (occupancy x compute units) -- the grid of a
+//               persistent launch is clamped to it, and a kernel that cannot be resident at all takes its multi-launch fallback;
+//   gate():     a process-wide mutex held from the launch of a spinning kernel until its result has arrived, so that two of them
+//               (two contexts, two host threads) never sit half-resident on the device waiting for CUs the other one holds.
+// Every other kernel of the library is finite: it can delay a persistent launch, never starve it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <mutex>
+
+namespace vilcoop {
+inline std::mutex& gate() { static std::mutex m; return m; }          // (inline function: one instance per shared object)
+inline int capacity(const void* func, int threads, size_t dyn_lds, int device) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, func, threads, dyn_lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return per_cu * cus;
+}
+}  // namespace vilcoop

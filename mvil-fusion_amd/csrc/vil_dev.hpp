@@ -30,7 +30,7 @@ struct SysBuf {       // one linearisation of the window (double-buffered: curre
 struct Ctl {          // trust-region state, lives in device memory, owned by the step kernel
     int gen;          // solve generation (host): with n_sweeps it forms the epoch of the helper-workgroup flags
     int cur, iter, done, term, first, resweep, reuse, nsucc, invalid_run, status, lin_mode, n_sweeps;
-    int swe;                      // advanced by every live step-kernel launch: epoch of the sweep's workgroup flags (swflag)
+    int swe;                      // advanced by every live step-kernel launch
     double radius, mu, cost_cur, model_change, alpha, dogleg_norm, initial_cost, cand_cost;
     double mu_used, gn2, g2, gg;   // dogleg scalars of the current linearisation (reused after a rejected step)
     double cg, cn;                 // dogleg coefficients of the candidate: the sweep forms lambda_cand = lambda_cur + cg la + cn lb
@@ -108,14 +108,6 @@ struct DevP {
     double* la; double* lb;        // L each: step directions of the inverse depths (Cauchy, Gauss-Newton), written by the step kernel's landmark pass
     // structure-exploiting solve (vil_chain.hpp): 0 dense, 1 chain with W^T in LDS, 2 chain with W^T in global memory (P.M)
     int chain, chain_rs;
-    // chain eliminated ahead of the step kernel by an extra workgroup of k_reduce (vil_prechain.hpp), straight from the IMU / prior
-    // partial records: prechain = 1 (single GPU, IMU factors (k, k+1) only).  imu_as_i[k] / imu_as_j[k]: the IMU factor in which
-    // frame k is the first / second frame (-1: none).  Outputs (global): W^T with unscaled pose rows, the factored 9 x 9 blocks,
-    // scales of the chain columns, pieces of u^T S' u, status.
-    int prechain; const int* imu_as_i; const int* imu_as_j;
-    int ch_npc; const int* ch_pcol;      // chain columns (0 .. 9K-1) the prior holds
-    int* swflag;                   // n_imu + 1 flags: the IMU / prior workgroups of the current sweep have written their records
-    double* chW; double* chLdg; double* chLsb; double* chSc; double* chDc; double* chZ; double* chQ; int* chOk;
 };
 
 __host__ __device__ inline int xo_pose(const DevP& P, int k) { return 7 * k; }

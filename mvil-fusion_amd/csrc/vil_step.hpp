@@ -636,108 +636,12 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
     return true;
 }
 
-// ---- chain eliminated ahead by k_reduce's extra workgroup (vil_prechain.hpp): pack the pose tiles, scale the pose rows of W
-//      while subtracting W W^T, dense part, chain back substitution.  Same contract as solve_chain.
-template <class PUB, class SIDE>
-__device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart, PUB pub, SIDE side) {
-    const int t = threadIdx.x;
-    SSTAMP(0);
-    const int K = P.K, D = P.D, NP = P.NV, R = NP + 1, T = (R + 15) >> 4, ntile = (T * (T + 1)) >> 1;
-    const int RS = P.chain_rs, NB = 9 * K, m = K >> 1;
-    double* Tl = lds;
-    const double* Wt = P.chW;
-    double* Ldg = lds + ntile * TILE_SZ; double* Lsb = Ldg + 54 * K; double* tB = Lsb + 82 * K;
-    {   // pose tiles M_pp = Sc S'_pp Sc + mu dc^2 (+ rhs row), their share of u^T S' u; loads batched eight at a time
-        const int NE = ntile << 8;
-        for (int e0 = t; e0 < NE; e0 += 8 * VIL_STEP_THREADS) {
-            double v[8]; int ii[8], jj[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = min(e0 + VIL_STEP_THREADS * u, NE - 1), tile = e >> 8, w = e & 255;
-                ii[u] = (s.tI[tile] << 4) + (w >> 4); jj[u] = (s.tJ[tile] << 4) + (w & 15);
-                v[u] = sb.S[(size_t)min(ii[u], NP - 1) * D + min(jj[u], NP - 1)];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + VIL_STEP_THREADS * u;
-                if (e >= NE) break;
-                const int i = ii[u], j = jj[u];
-                double mv = 0.0;
-                if (i < NP && j <= i) {
-                    if (cam) qpart += (i == j ? 1.0 : 2.0) * s.y[i] * v[u] * s.y[j];
-                    mv = s.sc[i] * v[u] * s.sc[j];
-                    if (i == j) mv += mu * s.dcs[i] * s.dcs[i];
-                } else if (i == NP && j < NP) mv = s.sc[j] * s.gd[j];
-                Tl[tl_phys(e)] = mv;
-            }
-        }
-        for (int e = t; e < 54 * K; e += VIL_STEP_THREADS) Ldg[e] = P.chLdg[e];
-        for (int e = t; e < 82 * K; e += VIL_STEP_THREADS) Lsb[e] = P.chLsb[e];
-        if (cam) {                                     // chain share of u^T S' u: chain x chain + 2 u_p . (S'_pb u_b)
-            if (t < NP) qpart += 2.0 * s.y[t] * (P.chZ[t] + P.chZ[R + t]);
-            if (t == 0) qpart += P.chQ[0] + P.chQ[1];
-        }
-        if (t == 0 && !P.chOk[0]) s.ok = 0;
-    }
-    __syncthreads();
-    SSTAMP(2); SSTAMP(3);
-    if (!s.ok) return false;
-    auto schur = [&](d4* Creg, const int* tIJ) {
-        const int lane = t & 63, row = lane & 15, kq = lane >> 4;
-#pragma unroll
-        for (int u = 0; u < CH_SLOTS; ++u) {
-            if (tIJ[u] < 0) continue;
-            const int I = tIJ[u] >> 8, J = tIJ[u] & 255;
-            const int ra = (I << 4) + row, rb = (J << 4) + row;
-            const double sa = ra < NP ? -s.sc[ra] : (ra == NP ? -1.0 : 0.0), sbv = rb < NP ? s.sc[rb] : (rb == NP ? 1.0 : 0.0);    // row scaling deferred by the chain workgroup
-            const double* pa = Wt + kq * RS + ra; const double* pb = Wt + kq * RS + rb;
-            d4 c4 = Creg[u];
-            for (int kk = 0; kk < NB; kk += 32) {
-                const double* qa = pa + kk * RS; const double* qb = pb + kk * RS;
-                double av[8], bv[8];
-#pragma unroll
-                for (int g = 0; g < 8; ++g) { av[g] = qa[g * 4 * RS]; bv[g] = qb[g * 4 * RS]; }
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const bool kv = kk + 4 * g + kq < NB;
-                    c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(kv ? sa * av[g] : 0.0, kv ? sbv * bv[g] : 0.0, c4, 0, 0, 0);
-                }
-            }
-            Creg[u] = c4;
-        }
-    };
-    if (!chol_blocked<true>(Tl, NP, s, nullptr, schur)) return false;
-    SSTAMP(4);
-    back_subst(Tl, NP, s);
-    pub();
-    SSTAMP(5);
-    {
-        const int G = (4 * NB <= VIL_STEP_THREADS) ? 4 : 2;
-        const int j = t / G, part = t - j * G;
-        const int jc = min(j, NB - 1);
-        double acc = 0.0;
-        for (int rr = part; rr < NP; rr += G) acc += Wt[(size_t)jc * RS + rr] * s.sc[rr] * s.y[rr];
-        acc += __shfl_xor(acc, 1, 64);
-        if (G == 4) acc += __shfl_xor(acc, 2, 64);
-        if (j < NB && part == 0) tB[j] = Wt[(size_t)j * RS + NP] - acc;
-    }
-    __syncthreads();
-    if (t < 64) chain_block_back(Ldg + 54 * m, nullptr, tB + 9 * m, nullptr, s.y + NP + 9 * m);
-    __syncthreads();
-    if (t < 64) { for (int k = m - 1; k >= 0; --k) chain_block_back(Ldg + 54 * k, Lsb + 82 * k, tB + 9 * k, s.y + NP + 9 * (k + 1), s.y + NP + 9 * k); }
-    else if (t < 128) { for (int k = m + 1; k < K; ++k) chain_block_back(Ldg + 54 * k, Lsb + 82 * k, tB + 9 * k, s.y + NP + 9 * (k - 1), s.y + NP + 9 * k); }
-    else if (t >= VIL_STEP_THREADS - 64) side();
-    __syncthreads();
-    SSTAMP(6);
-    return true;
-}
-
 }  // namespace vd
 
 // The step kernel is the same on one GPU and on N: in the multi-GPU path the whole linear-system set has been all-reduced
 // before it starts (vilsolve.hip: view), so every rank runs it on identical data.
 // CHAIN 0: dense factorisation of all D columns (LDSM: tile array in LDS or global).  CHAIN 1 / 2: vil_chain.hpp, with W^T in
-// LDS / in global memory (tiles always in LDS).  CHAIN 3: the chain was eliminated by k_reduce's extra workgroup (vil_prechain.hpp).
+// LDS / in global memory (tiles always in LDS).
 //
 // Landmarks never enter the step kernel's serial part: per landmark the pass after the solve leaves the two step directions
 //   la = Sl gradient_l / dl  (Cauchy direction),  lb = Sl gn_l / dl  (Gauss-Newton direction)
@@ -1022,9 +926,8 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         for (int i = t; i < D; i += NT) {
             const double dg = sb.diag[i], b = sb.bc[i];
             double Sc;
-            if (s.was_first) { Sc = O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0; if (CHAIN == 3 && i >= P.NV) Sc = P.chSc[i - P.NV]; P.Sc[i] = Sc; } else Sc = P.Sc[i];
-            double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
-            if (CHAIN == 3 && i >= P.NV) d = P.chDc[i - P.NV];      // the very numbers the chain workgroup scaled M_bb with
+            if (s.was_first) { Sc = O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0; P.Sc[i] = Sc; } else Sc = P.Sc[i];
+            const double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
             const double g = Sc * b / d;
             s.sc[i] = Sc; s.dcs[i] = d; s.gr[i] = g; s.y[i] = Sc * g / d; s.gd[i] = sb.gred[i]; s.rt[i] = Sc / d;
             P.dc[i] = d; P.gradc[i] = g;
@@ -1047,8 +950,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                 gather2(h, true);
                 if ((t & 63) == 63) for (int e = 0; e < 9; ++e) s.hs[e] = h[e];
             };
-            if constexpr (CHAIN == 3) ok = solve_prechain(P, sb, s, Alds, mu, cam, q, pub, side);
-            else ok = solve_chain<CHAIN == 1>(P, sb, s, Alds, mu, cam, q, pub, side);      // packing, chain, Schur update, dense part, back substitution
+            ok = solve_chain<CHAIN == 1>(P, sb, s, Alds, mu, cam, q, pub, side);      // packing, chain, Schur update, dense part, back substitution
         } else {
         // tiled storage: element e of the tile array -> (i, j); S entries were prefetched into registers at kernel start
         double* Ag = P.M;
@@ -1135,7 +1037,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             }
             for (int i = t; i < P.NS; i += NT) xc[i] = x[i];
             __syncthreads();
-            if (t < 64) store_ctl();
+            if (t < 64) { wait_helpers(); store_ctl(); }      // (a late helper may still be copying Ctl into its LDS)
             return;
         }
         if constexpr (CHAIN == 0) { if constexpr (LDSM) back_subst(Alds, D, s); else back_subst(P.M, D, s); publish_xp(1); }

@@ -118,6 +118,9 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
     const double* xcur = P.x[ctl.cur];
     double* xcand = P.x[1 - ctl.cur];
     const double cg = ctl.cg, cn = ctl.cn;
+    // first sweep of a solve and re-sweeps: cg = cn = 0 and la / lb still hold the PREVIOUS solve's directions -- possibly inf / NaN after a
+    // diverged solve, and 0 * inf is NaN: the terms are dropped, not multiplied by zero (same bits whenever la, lb are finite)
+    const bool stepped = cg != 0.0 || cn != 0.0;
     for (int e = t; e < NVT + 3 * NV; e += blockDim.x) tri[e] = 0.0;
     const bool mfree = P.marg != 0;            // marginalisation of the resident window: every block free, factors masked
     const bool exc = !mfree && P.ex_const != 0, tdc = mfree ? !P.use_td : !P.td_free;
@@ -138,7 +141,7 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             const int i = P.vis_i[f], j = P.vis_j[f], l = P.vis_l[f];
             const double* pi = x + xo_pose(P, i); const double* pj = x + xo_pose(P, j); const double* ex = x + xo_ex(P);
             VisJ o;
-            const double lam = xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l];
+            const double lam = stepped ? xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l] : xcur[xo_lam(P) + l];
             if (O.precision)
                 visual_eval_f32(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
                                 lam, x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
@@ -207,7 +210,7 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             // (a landmark without a factor in this workgroup's table -- none at all, or owned by another rank -- leaves the set untouched:
             //  its entries stay zero here and the all-reduce takes them from the owner)
             if (k == 13) { if (fe > fs) { sb.hll[l] = h; sb.bl[l] = b; sb.invp[l] = invp; sb.sl[l] = Sl; } lr[0] = invp; lr[14] = (double)a; }
-            if (k == 14 && fe > fs) xcand[xo_lam(P) + l] = xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l];      // the same expression the factor threads evaluated
+            if (k == 14 && fe > fs) xcand[xo_lam(P) + l] = stepped ? xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l] : xcur[xo_lam(P) + l];      // the same expression the factor threads evaluated
             if (k < 13) {
                 lr[1 + k] = e; if (fe > fs) sb.eA[(size_t)l * 13 + k] = e;
                 const int col = k < 6 ? col_pose(P, a) + k : (k < 12 ? col_ex(P) + k - 6 : col_td(P));
@@ -479,25 +482,12 @@ __device__ __forceinline__ int imu_local(const DevP& P, int i, int j, int col) {
 
 }  // namespace vd
 
-// The sweep kernel itself (k_sweep) is defined in vil_prechain.hpp: with P.prechain one more workgroup eliminates the
-// speed-bias chain as soon as the IMU / prior workgroups have published their records.
-// Workgroup order: [imu x n_imu | prior | rel | (chain) | visual x n_vwg | plane | edge] -- the short roles the chain waits for come
-// first, the chain workgroup (the longest-running one) right after them, then the visual workgroups.
-// Epoch of the flags: solve generation + Ctl::swe, which only the step kernel advances (n_sweeps is bumped by block 0 of the
-// sweep itself, so workgroups of one launch may read either value of it).
-__device__ __forceinline__ void sweep_signal(const DevP& P, const Ctl& ctl, int slot) {     // this workgroup's record is complete
-    __threadfence();                 // every wave's stores of the record (__syncthreads alone does not wait for global stores)
-    __syncthreads();
-    if (threadIdx.x == 0) { __hip_atomic_store(P.swflag + slot, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-}
-
 // Gather of the sweep's partial records into the dense reduced system of the candidate set:
 //   S' (D x D, both triangles), gred, bc, diag, cost.   32 lower-triangle entries per workgroup, 8 threads per
 //   entry splitting the sum over the visual partials; fixed summation order across workgroups (the partials themselves are
 //   accumulated with LDS atomics inside a visual workgroup, so two runs agree to rounding, not bit for bit).
 //   The last workgroup handles the vectors and the cost.
 #define RED_EPW 32
-#define VIL_REDUCE_THREADS 384      // k_reduce (vil_prechain.hpp): the gather below uses the first 256, the chain workgroup all six waves
 __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl) {
     using namespace vd;
     if (threadIdx.x >= VIL_THREADS) return;
@@ -626,4 +616,45 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl) {
     if ((t & 63) == 0) red[t >> 6] = c;
     __syncthreads();
     if (t == 0) sb.cost[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+// Gather of the sweep's partial records (reduce_gather above): 256 threads, a handful of registers.
+__global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
+    const Ctl ctl = *P.ctl;
+    if (ctl.done) return;
+    reduce_gather(P, ctl);
+}
+
+// The sweep: grid = n_imu + 2 + n_vwg + ceil(n_pchunk / 2) + ceil(n_echunk / 2) workgroups of VIL_SWEEP_THREADS threads.
+// Workgroup order: [imu x n_imu | prior | rel | visual x n_vwg | plane | edge] (roles: top of this file)
+__global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O) {
+    extern __shared__ double sm[];
+    const Ctl ctl = *P.ctl;
+    if (ctl.done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctl->n_sweeps = ctl.n_sweeps + 1;   // live (not early-exited) launches, for the profiler
+    const int cand = 1 - ctl.cur;
+    const double* x = P.x[cand];
+    SysBuf sb = P.sys[cand];
+    int b = blockIdx.x;
+    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm); return; }
+    b -= P.n_imu;
+    if (b == 0) { if (!(P.skip_mask & 16)) vd::sweep_prior(P, x, sm); return; }
+    if (b == 1) {
+        if (!(P.skip_mask & 16)) vd::sweep_misc(P, O, x, sm);
+        if (P.world > 1) {                               // factor set sharded over ranks: the visual workgroups of this rank form the candidate inverse depth of
+            const double* xcur = P.x[ctl.cur];           // the landmarks it owns; every rank holds la / lb of ALL landmarks (the step kernel runs on the all-reduced
+            double* xcand = P.x[1 - ctl.cur];            // system), so the rest is filled in here and the states stay identical on all ranks
+            const bool stepped = ctl.cg != 0.0 || ctl.cn != 0.0;      // (as in sweep_visual: stale la / lb are not multiplied by zero)
+            for (int l = threadIdx.x; l < P.L; l += blockDim.x) xcand[xo_lam(P) + l] = stepped ? xcur[xo_lam(P) + l] + ctl.cg * P.la[l] + ctl.cn * P.lb[l] : xcur[xo_lam(P) + l];
+        }
+        return;
+    }
+    b -= 2;
+    // visual workgroups next: the longest-running factor role
+    if (b < P.n_vwg) { if (!(P.skip_mask & 1)) vd::sweep_visual(P, O, ctl, b, x, sb, sm); return; }
+    b -= P.n_vwg;
+    const int per = VIL_SWEEP_THREADS / 256, npw = (P.n_pchunk + per - 1) / per;
+    if (b < npw) { if (!(P.skip_mask & 4)) vd::sweep_lidar<1>(P, O, b, x, sm); return; }
+    b -= npw;
+    if (!(P.skip_mask & 8)) vd::sweep_lidar<3>(P, O, b, x, sm);
 }

@@ -19,6 +19,7 @@
 
 #include "../../include/vilmap.h"
 #include "vil_internal.h"
+#include "vil_coop.hpp"
 #include "vil_knn.hpp"
 #include "vil_pose1.hpp"
 
@@ -263,7 +264,8 @@ struct vmap_ctx {
     vp1::Pose1Coop* d_coop = nullptr; int reg_epoch = 0;   // meeting point of the pose solve's workgroups; epoch numbers are never reused
     char* d_reg = nullptr; char* h_reg = nullptr;     // single-submission registration: pose (7 doubles) | PoseRT | 2 x Pose1Out, and its pinned mirror
     char* h_res = nullptr; void* d_res = nullptr;     // pinned + mapped: the second round's Pose1Out | sequence word, written by k_pose_solve, polled by the host
-    int fused_max = 1 << 20;                           // scans up to this many points take the one-launch pose solve (VIL_MAP_FUSED_MAX overrides; 0 = always the window solver)
+    int coop_cap = -1;                                 // workgroups of k_pose_solve the device holds at once (vil_coop.hpp)
+    int fused_max = 1 << 20;                           // scans up to this many points take the one-launch pose solve (vmap_set_fused_max; 0 = always the window solver)
     bool profiling = false; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; long long prof_n[2] = {0, 0}; double prof_ms[2] = {0.0, 0.0};
 };
 
@@ -355,7 +357,8 @@ int align_fused(vmap_ctx* c, int n_corner, int n_surf, double* q, double* t, con
             if (hipHostGetDevicePointer(&c->d_res, c->h_res, 0) != hipSuccess) { hipHostFree(c->h_res); c->h_res = nullptr; c->d_res = nullptr; }
         } else c->h_res = nullptr;
     }
-    const int G = std::min(VP1_MAXG, std::max(1, (nq + VP1_THREADS - 1) / VP1_THREADS));
+    std::lock_guard<std::mutex> coop_lock(vilcoop::gate());                     // k_pose_solve's workgroups wait for one another (vil_coop.hpp)
+    const int G = std::min(std::min(VP1_MAXG, c->coop_cap), std::max(1, (nq + VP1_THREADS - 1) / VP1_THREADS));
     double* edge_soa = c->d_soa; double* plane_soa = c->d_soa + (size_t)9 * es;
     double* h_pose = (double*)(c->h_reg + REG_POSE);
     h_pose[0] = t[0]; h_pose[1] = t[1]; h_pose[2] = t[2]; h_pose[3] = q[0]; h_pose[4] = q[1]; h_pose[5] = q[2]; h_pose[6] = q[3];
@@ -423,7 +426,6 @@ int vmap_create(int32_t device, vmap_ctx** out) {
     vmap_ctx* c = new vmap_ctx();
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VM_ERR_DEVICE; }
-    if (const char* e = getenv("VIL_MAP_FUSED_MAX")) c->fused_max = atoi(e);
     *out = c;
     return VM_OK;
 }
@@ -460,6 +462,8 @@ int vmap_associate(vmap_ctx* c, int32_t n_corner, const float* corner, int32_t n
     return associate_uploaded(c, n_corner, n_surf, q, t, n_edge, edge9, n_plane, plane7);
 }
 
+int vmap_set_fused_max(vmap_ctx* c, int32_t max_points) { if (!c || max_points < 0) return VM_ERR_INVALID; c->fused_max = max_points; return VM_OK; }
+
 int vmap_profile_enable(vmap_ctx* c, int32_t enable) {
     if (!c) return VM_ERR_INVALID;
     VMCHK(hipSetDevice(c->device));
@@ -482,7 +486,8 @@ int vmap_align(vmap_ctx* c, vil_ctx* solver, int32_t n_corner, const float* corn
     VMCHK(hipSetDevice(c->device));
     int st = upload_scan(c, n_corner, corner, n_surf, surf);             // the scan is uploaded once for both rounds
     if (st != VM_OK) return st;
-    if (n_corner + n_surf <= c->fused_max) return align_fused(c, n_corner, n_surf, q, t, opts, out);
+    if (c->coop_cap < 0) c->coop_cap = vilcoop::capacity((const void*)vp1::k_pose_solve, VP1_THREADS, 0, c->device);
+    if (n_corner + n_surf <= c->fused_max && c->coop_cap >= 1) return align_fused(c, n_corner, n_surf, q, t, opts, out);
     for (int round = 0; round < 2; ++round) {
         int32_t ne = 0, np = 0;
         const auto ta = std::chrono::steady_clock::now();

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/vilpreint.h"
+#include "vil_tuning.hpp"
 
 #define VP_OK 0
 #define VP_ERR_INVALID -1
@@ -343,7 +344,7 @@ int vpre_integrate(vpre_ctx* c, int32_t n, const int32_t* start, const double* d
     const size_t ns = (size_t)start[n];
     if (ns && (!dt || !acc || !gyr)) return VP_ERR_INVALID;
     VPCHK(hipSetDevice(c->device));
-    static const bool timing = getenv("VPRE_TIMING") != nullptr;
+    static const bool timing = VIL_TUNE_ENV("VPRE_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     const auto t0 = now();

@@ -20,11 +20,12 @@
 
 #include "../../include/vilsolve.h"
 #include "vil_internal.h"
+#include "vil_tuning.hpp"
+#include "vil_coop.hpp"
 #include "vil_dev.hpp"
 #include "vil_sweep.hpp"
 #include "vil_eval.hpp"
 #include "vil_step.hpp"
-#include "vil_prechain.hpp"
 #include "vil_marg.hpp"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[vilsolve] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return VIL_ERR_DEVICE; } } while (0)
@@ -135,7 +136,8 @@ struct vil_ctx {
     int use_graph = -1;            // VIL_GRAPH=0 disables
     int solve_gen = 0;             // generation counter of the helper-workgroup flags (Ctl::gen)
     int solves_since_upload = 0;
-    bool split = false;            // step kernel launched as A | all-reduce | B
+    bool split = false;            // sweep + gather fill set 0, the collective sums it into set 1, the step kernel reads set 1
+    bool force_split = false;      // vil_debug_set_split: that plumbing on a single rank
     int last_live = 5;             // live sweep launches of the previous solve (sizes the first launch chunk)
     int lm_b = 0, lm_e = 0;        // owned landmark range
     // ---- window residency across frames (vil_lidar_*, vil_set_gauge_fix, vil_marginalize_resident) --------------------------------
@@ -432,7 +434,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         // Every workgroup also writes one partial record of NV (NV + 1) / 2 doubles that k_reduce reads back: measured K = 10 (20 kB records)
         // 32 factors: sweep 24.7 -> 22.5 us, reduce 15.0 -> 15.4; K = 20 (65 kB records): sweep 42 -> 60 us -- so only for the small records
         int fbal = NV <= 80 ? VIL_VCHUNK_FBAL : VIL_VCHUNK_F;
-        if (const char* ev = getenv("VIL_VFBAL")) fbal = std::max(1, atoi(ev));
+        if (const char* ev = VIL_TUNE_ENV("VIL_VFBAL")) fbal = std::max(1, atoi(ev));
         while (l0 < L) {
             int l1 = l0, nf = 0;
             while (l1 < L && l1 - l0 < VIL_VCHUNK_LM && nf + (lms[l1 + 1] - lms[l1]) <= VIL_VCHUNK_F && (l1 == l0 || nf + (lms[l1 + 1] - lms[l1]) <= fbal)) { nf += lms[l1 + 1] - lms[l1]; ++l1; }
@@ -444,7 +446,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         put(vch.data(), 4 * vch.size(), (void**)&P.vchunk);
         // group the sub-chunks into visual workgroups (each owns one LDS triangle / one partial record)
         int vwg_max = 256;
-        if (const char* ev = getenv("VIL_VWG")) vwg_max = std::max(1, atoi(ev));
+        if (const char* ev = VIL_TUNE_ENV("VIL_VWG")) vwg_max = std::max(1, atoi(ev));
         P.n_vwg = std::min(P.n_vchunk, vwg_max);
         std::vector<int> vw;
         for (int w = 0; w < P.n_vwg; ++w) { vw.push_back((int)((long long)P.n_vchunk * w / P.n_vwg)); vw.push_back((int)((long long)P.n_vchunk * (w + 1) / P.n_vwg)); }
@@ -556,9 +558,9 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
     c->graphs.clear(); c->solves_since_upload = 0;
     c->sharded = sharded && c->world > 1;
-    // multi-GPU plumbing (set 0 = this rank's partial system, all-reduced into set 1, which the step kernel reads); VIL_FORCE_SPLIT
+    // multi-GPU plumbing (set 0 = this rank's partial system, all-reduced into set 1, which the step kernel reads); vil_debug_set_split
     // runs it on a single rank (tests)
-    c->split = c->sharded || getenv("VIL_FORCE_SPLIT") != nullptr;
+    c->split = c->sharded || c->force_split;
     put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.Sl); put(nullptr, 8 * (size_t)D, (void**)&P.Sc); put(nullptr, 8 * (size_t)D, (void**)&P.dc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.dl);
     put(nullptr, 8 * (size_t)D, (void**)&P.gradc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gradl); put(nullptr, 8 * (size_t)D, (void**)&P.gnc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gnl);
     { const size_t Tm = (size_t)(D + 16) / 16; put(nullptr, 8 * std::max((size_t)D * D, (size_t)TILE_SZ * (Tm * (Tm + 1) / 2)), (void**)&P.M); } put(nullptr, 8 * (size_t)D, (void**)&P.stepc); put(nullptr, 8 * 4 * 16, (void**)&P.hpart); put(nullptr, 4 * 16, (void**)&P.hflag);
@@ -568,32 +570,17 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     put(nullptr, 8 * (size_t)D, (void**)&P.tmpc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.tmpl);
     put(nullptr, sizeof(Ctl), (void**)&P.ctl);
     put(nullptr, 8 * 64, (void**)&P.dbg);
-    // chain eliminated ahead of the step kernel (vil_prechain.hpp): needs every IMU factor to join frames (k, k+1), at most one per pair
-    {
-        std::vector<int> as_i(K, -1), as_j(K, -1);
-        bool canon = true;
-        for (int f = 0; f < p->n_imu; ++f) {
-            const int i = p->imu_i[f], j = p->imu_j[f];
-            if (j != i + 1 || as_i[i] >= 0 || as_j[j] >= 0) { canon = false; break; }
-            as_i[i] = f; as_j[j] = f;
-        }
-        // (measured r2: assembling the raw entries from the partial records costs the chain workgroup more than the step kernel
-        //  saves -- 52 us of k_reduce against 14.6 us inside k_step at K = 10; off unless VIL_PRECHAIN=1 until the entries are staged)
-        P.prechain = (canon && !sharded && getenv("VIL_PRECHAIN") != nullptr) ? 1 : 0;      // decided for good below, once the chain structure is known
-        put(as_i.data(), 4 * (size_t)K, (void**)&P.imu_as_i); put(as_j.data(), 4 * (size_t)K, (void**)&P.imu_as_j);
-        const int rs = vd::chain_rs(K);
-        put(nullptr, 8 * (size_t)vd::chain_wcols(K) * rs, (void**)&P.chW);
-        put(nullptr, 8 * (size_t)54 * K, (void**)&P.chLdg); put(nullptr, 8 * (size_t)82 * K, (void**)&P.chLsb);
-        put(nullptr, 8 * (size_t)9 * K, (void**)&P.chSc); put(nullptr, 8 * (size_t)9 * K, (void**)&P.chDc);
-        put(nullptr, 4 * (size_t)(K + 8), (void**)&P.swflag);
-        { std::vector<int> pcol; for (int jc = 0; jc < 9 * K; ++jc) if (pinv[NV + jc] >= 0) pcol.push_back(jc);
-          P.ch_npc = (int)pcol.size(); pcol.resize(9 * K + 1, 0); put(pcol.data(), 4 * pcol.size(), (void**)&P.ch_pcol); }
-        put(nullptr, 8 * (size_t)2 * (NV + 1), (void**)&P.chZ); put(nullptr, 8 * 4, (void**)&P.chQ); put(nullptr, 16, (void**)&P.chOk);
-    }
-    if (const char* ev = getenv("VIL_SKIP")) P.skip_mask = atoi(ev);
+    if (const char* ev = VIL_TUNE_ENV("VIL_SKIP")) P.skip_mask = atoi(ev);
     // helper workgroups of the step kernel: worth it once every master thread would own more than one landmark
     P.n_help = L >= 2 * VIL_STEP_THREADS ? 7 : (L >= VIL_STEP_THREADS ? 3 : 0);
-    if (const char* ev = getenv("VIL_HELP")) P.n_help = std::max(0, std::min(15, atoi(ev)));
+    if (const char* ev = VIL_TUNE_ENV("VIL_HELP")) P.n_help = std::max(0, std::min(15, atoi(ev)));
+    // master and helpers wait for one another inside the launch: all of them must be resident at once (vil_coop.hpp).  With its
+    // dynamic LDS a step workgroup owns a compute unit; a device with fewer units than 1 + n_help runs without helpers.
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) cus = 0;
+        if (1 + P.n_help > cus / 2) P.n_help = 0;
+    }
     // device allocation + single H2D copy
     if (oom) return VIL_ERR_DEVICE;
     const size_t tables = (ar.hsize + 255) & ~size_t(255), total = tables + ((ar.ssize + 255) & ~size_t(255));
@@ -638,7 +625,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     // ---- step kernel variant: the speed-bias part of the reduced matrix is a chain whenever every IMU factor couples (k, k+1)
     //      and the prior's speed-bias blocks are neighbours (VINS: exactly one) -> vil_chain.hpp; anything else: dense path
     {
-        bool chain = getenv("VIL_DENSE_STEP") == nullptr;
+        bool chain = VIL_TUNE_ENV("VIL_DENSE_STEP") == nullptr;
         for (int f = 0; f < p->n_imu && chain; ++f) if (std::abs(p->imu_i[f] - p->imu_j[f]) > 1) chain = false;
         if (P.pn) {
             std::vector<int> psb;
@@ -652,24 +639,11 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             if (8 * (tiles + wt + scr) + fixed <= 160 * 1024) { P.chain = 1; c->lds_step = 8 * (tiles + wt + scr); }
             else if (8 * (tiles + scr) + fixed <= 160 * 1024) { P.chain = 2; c->lds_step = 8 * (tiles + scr); }
         }
-        if (!P.chain || c->split) P.prechain = 0;
-        if (P.prechain && 8 * (vd::chain_scratch_doubles(K) + 3 * (size_t)vd::even_up(9 * K) + vd::chain_slab_doubles(K) + 16) > 150 * 1024) P.prechain = 0;      // the staged slab must fit LDS (K <= 12)
-        if (P.prechain) {
-            const size_t Tp = (size_t)(NV + 1 + 15) / 16, tiles = (size_t)TILE_SZ * (Tp * (Tp + 1) / 2);
-            P.chain = 3;
-            c->lds_step = 8 * (tiles + 54 * (size_t)K + 82 * (size_t)K + vd::even_up(9 * K) + 16);
-            // the chain workgroup rides in k_sweep: its LDS need must fit the sweep's dynamic allocation
-            c->lds_sweep = std::max(c->lds_sweep, (size_t)8 * (vd::chain_scratch_doubles(K) + 3 * (size_t)vd::even_up(9 * K) + vd::chain_slab_doubles(K) + 16));
-            HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep));
-            c->n_blocks_sweep += 1;
-        }
-        c->P.chain = P.chain; c->P.chain_rs = P.chain_rs; c->P.prechain = P.prechain;
+        c->P.chain = P.chain; c->P.chain_rs = P.chain_rs;
     }
     if (P.chain) {
         c->step_lds = true;
-        if (P.chain == 3) {
-            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
-        } else if (P.chain == 1) {
+        if (P.chain == 1) {
             HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
         } else {
             HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
@@ -815,8 +789,7 @@ static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEve
     if (!step) return VIL_OK;
     const DevP Ps = view(c, 1);
     const dim3 g(1 + c->P.n_help), b(VIL_STEP_THREADS);
-    if (c->P.chain == 3) hipLaunchKernelGGL((k_step<true, 3>), g, b, c->lds_step, c->stream, Ps, so);
-    else if (c->P.chain == 1) hipLaunchKernelGGL((k_step<true, 1>), g, b, c->lds_step, c->stream, Ps, so);
+    if (c->P.chain == 1) hipLaunchKernelGGL((k_step<true, 1>), g, b, c->lds_step, c->stream, Ps, so);
     else if (c->P.chain == 2) hipLaunchKernelGGL((k_step<true, 2>), g, b, c->lds_step, c->stream, Ps, so);
     else if (c->step_lds) hipLaunchKernelGGL((k_step<true, 0>), g, b, c->lds_step, c->stream, Ps, so);
     else hipLaunchKernelGGL((k_step<false, 0>), g, b, c->lds_step, c->stream, Ps, so);
@@ -877,7 +850,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
         const int sweeps_before = (it == 0) ? 0 : c->h_ctl->n_sweeps;
         // Repeated solves of ONE upload (bench, re-solves after a rejected frame) replay a captured hipGraph of the chunk:
         // ~2 % less inter-kernel gap.  The first solve of an upload launches directly -- capturing costs more than it saves.
-        if (c->use_graph < 0) c->use_graph = getenv("VIL_GRAPH") ? atoi(getenv("VIL_GRAPH")) : 1;
+        if (c->use_graph < 0) { const char* ev = VIL_TUNE_ENV("VIL_GRAPH"); c->use_graph = ev ? atoi(ev) : 1; }
         const int nthis = std::min(chunk, o->max_iterations + 9 - it);
         if (c->use_graph && c->solves_since_upload > 0 && !c->profiling && !c->split && nthis > 0) {     // (the local communicator's host barriers cannot be captured)
             hipGraphExec_t exec = nullptr;
@@ -1174,7 +1147,7 @@ static int marg_finish(vil_ctx* c, const int K, const bool old_, const int drop_
         const size_t dyn = std::max<size_t>(4096, a_bytes);
         if (dyn > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL(k_marg, dim3(1), dim3(MARG_THREADS), dyn, c->stream, M, 0);
-        if (!getenv("VIL_MARG_PIVOTED")) {               // un-pivoted factorisation on the matrix cores first; pivoted fallback below
+        if (!VIL_TUNE_ENV("VIL_MARG_PIVOTED")) {               // un-pivoted factorisation on the matrix cores first; pivoted fallback below
             const size_t Tm = (size_t)(n + 1 + 15) / 16, tb = 8 * (size_t)TILE_SZ * (Tm * (Tm + 1) / 2);
             if (tb + sizeof(vd::StepShared) + 512 <= 160 * 1024) {
                 if (tb > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_marg_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
@@ -1183,14 +1156,19 @@ static int marg_finish(vil_ctx* c, const int K, const bool old_, const int drop_
         }
         hipLaunchKernelGGL(k_marg, dim3(1), dim3(MARG_THREADS), dyn, c->stream, M, 1);
     }
-    st = ensure_pin(c, 8 * (nn * 2 + 2 * (size_t)n));
+    const size_t ncam = 16 * (size_t)K + 8;
+    st = ensure_pin(c, 8 * (nn * 2 + 2 * (size_t)n + ncam));
     if (st != VIL_OK) return st;
     HIPCHK(hipMemcpyAsync(c->h_pin, M.J0, 8 * (2 * nn + 2 * (size_t)n), hipMemcpyDeviceToHost, c->stream));      // J0 | A | r0 | b
+    // x0 of the new prior = the state the factors were LINEARISED at, i.e. the device state (the reference stores the very values it
+    // marginalises at, marginalization_factor.cpp:110-139) -- not whatever the caller holds
+    double* hx = c->h_pin + 2 * nn + 2 * (size_t)n;
+    HIPCHK(hipMemcpyAsync(hx, c->P.x[0], 8 * ncam, hipMemcpyDeviceToHost, c->stream));
     int mstat[4] = {0, 0, 0, 0};
-    if (getenv("VIL_MARG_DEBUG")) HIPCHK(hipMemcpyAsync(mstat, M.stat, 8, hipMemcpyDeviceToHost, c->stream));
+    if (VIL_TUNE_ENV("VIL_MARG_DEBUG")) HIPCHK(hipMemcpyAsync(mstat, M.stat, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
-    if (getenv("VIL_MARG_DEBUG")) fprintf(stderr, "[vil_marginalize] n=%d nd=%d one-sided Jacobi stages: %d (dropped block) %d (n x n, %.1f sweeps)\n", n, nd, mstat[0], mstat[1], mstat[1] / (double)(((n + 1) & ~1) - 1));
+    if (VIL_TUNE_ENV("VIL_MARG_DEBUG")) fprintf(stderr, "[vil_marginalize] n=%d nd=%d one-sided Jacobi stages: %d (dropped block) %d (n x n, %.1f sweeps)\n", n, nd, mstat[0], mstat[1], mstat[1] / (double)(((n + 1) & ~1) - 1));
     for (size_t e = 0; e < 2 * nn + 2 * (size_t)n; ++e) if (!std::isfinite(c->h_pin[e])) return VIL_ERR_NON_FINITE;
     // ---- getParameterBlocks with the address shift as an index remap (estimator.cpp:1599-1611, 1654-1677) --------------
     out->n = n; out->m = nd + n_lm_elim; out->nblk = (int)kinds.size();
@@ -1204,7 +1182,7 @@ static int marg_finish(vil_ctx* c, const int K, const bool old_, const int drop_
         int ni = idx;
         if (kind == VIL_BLK_POSE || kind == VIL_BLK_SPEEDBIAS) ni = old_ ? idx - 1 : (idx == K - 1 ? K - 2 : idx);
         out->blk_index[b] = ni; out->blk_col[b] = col;
-        const double* src = kind == VIL_BLK_POSE ? s->pose + 7 * idx : (kind == VIL_BLK_SPEEDBIAS ? s->speedbias + 9 * idx : (kind == VIL_BLK_EX ? s->ex_pose : s->td));
+        const double* src = kind == VIL_BLK_POSE ? hx + 7 * idx : (kind == VIL_BLK_SPEEDBIAS ? hx + 7 * K + 9 * idx : (kind == VIL_BLK_EX ? hx + 16 * K : hx + 16 * K + 7));
         const int gs = (kind == VIL_BLK_POSE || kind == VIL_BLK_EX) ? 7 : (kind == VIL_BLK_SPEEDBIAS ? 9 : 1), ls = gs == 7 ? 6 : gs;
         for (int k = 0; k < gs; ++k) out->x0[xo + k] = src[k];
         xo += gs; col += ls;
@@ -1367,12 +1345,14 @@ int vil_shard_ranges(const vil_problem* p, int rank, int world, int32_t* lm_begi
 }
 
 // ---- window residency across frames (include/vilsolve.h) ------------------------------------------------------------------------
+int vil_debug_set_split(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->force_split = on != 0; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
 int vil_set_gauge_fix(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->gauge_on = on != 0; return VIL_OK; }
 
 int vil_lidar_reset(vil_ctx* c) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
     c->slabs.clear(); c->free_slots.clear();
     for (int q = c->nslot - 1; q >= 0; --q) c->free_slots.push_back(q);
+    if (c->lidar_resident) { c->uploaded = false; c->resident_kind = 0; }      // the resident window's chunk list points into the old slab order
     return VIL_OK;
 }
 int vil_lidar_count(vil_ctx* c, int32_t* n_slabs, int32_t* n_plane, int32_t* n_edge) {
@@ -1386,6 +1366,7 @@ int vil_lidar_drop(vil_ctx* c, int32_t slab) {
     if (!c || slab < 0 || slab >= (int)c->slabs.size()) return VIL_ERR_INVALID_ARGUMENT;
     c->free_slots.push_back(c->slabs[slab].slot);
     c->slabs.erase(c->slabs.begin() + slab);          // the later frames move down: an index remap, the points stay where they are
+    if (c->lidar_resident) { c->uploaded = false; c->resident_kind = 0; }      // slab <-> pose changed under the resident window's chunk list
     return VIL_OK;
 }
 int vil_lidar_push(vil_ctx* c, int32_t n_plane, const double* plane_const, int32_t n_edge, const double* edge_const) {
@@ -1432,6 +1413,7 @@ int vil_lidar_push(vil_ctx* c, int32_t n_plane, const double* plane_const, int32
         if (n_edge) hipLaunchKernelGGL(k_aos2soa, dim3((n_edge + 255) / 256), dim3(256), 0, c->stream, c->d_lstage + (size_t)7 * n_plane, n_edge, 9, c->d_ed + (size_t)slot * c->cap_e, (size_t)c->nslot * c->cap_e);
     }
     c->slabs.push_back({n_plane, n_edge, slot});
+    if (c->lidar_resident) { c->uploaded = false; c->resident_kind = 0; }      // (a recycled slot would feed this frame's points to the old pose)
     return VIL_OK;
 }
 

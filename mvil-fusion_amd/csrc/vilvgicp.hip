@@ -24,8 +24,10 @@
 #include <vector>
 
 #include "../../include/vilvgicp.h"
+#include "vil_coop.hpp"
 #include "vil_knn.hpp"
 #include "vil_math.hpp"
+#include "vil_tuning.hpp"
 
 #define VG_OK 0
 #define VG_ERR_INVALID -1
@@ -304,7 +306,7 @@ struct vgicp_ctx {
     bool profiling = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; long long prof_n = 0; double prof_ms = 0.0;
     void* d_coop = nullptr; void* d_aout = nullptr; void* h_aout = nullptr; int coop_epoch = 0;       // one-launch alignment (k_vgicp_align)
     // neighbour search of the covariance estimation
-    vknn::GridBuild gb; float grid_h = 1.0f; int* d_nn = nullptr; size_t nn_cap = 0;
+    vknn::GridBuild gb; float grid_h = 1.0f; int grid_min = 4096; int coop_cap = -1; int* d_nn = nullptr; size_t nn_cap = 0;
 };
 
 static void free_target(vgicp_ctx* c) { hipFree(c->d_keys); hipFree(c->d_slot); hipFree(c->d_num); hipFree(c->d_mean); hipFree(c->d_cov); hipFree(c->d_wsq); c->d_wsq = nullptr; c->d_keys = nullptr; c->d_slot = nullptr; c->d_num = nullptr; c->d_mean = nullptr; c->d_cov = nullptr; c->nvox = 0; }
@@ -317,12 +319,10 @@ static VoxTab tab(const vgicp_ctx* c) { return VoxTab{c->d_keys, c->d_slot, c->c
 static int covariances_dev(vgicp_ctx* c, int n, const float* d_xyz, int k, double* d_cov) {
     if (k < 1 || k > KNN_MAX) return VG_ERR_INVALID;
     const int nblk = (n + VG_THREADS - 1) / VG_THREADS;
-    int grid_min = 4096;                                         // below this the O(n^2) tiled search is faster than building the grid
-    if (const char* ev = getenv("VGICP_GRID_MIN")) grid_min = atoi(ev);
+    const int grid_min = c->grid_min;                            // below this the O(n^2) tiled search is faster than building the grid (vgicp_set_knn_grid)
     if (n < grid_min) {
         hipLaunchKernelGGL(k_knn_cov, dim3(nblk), dim3(VG_THREADS), 0, c->stream, n, d_xyz, k, d_cov);
     } else {
-        if (const char* ev = getenv("VGICP_GRID_H")) c->grid_h = (float)atof(ev);
         if ((size_t)n * KNN_MAX * 4 > c->nn_cap) { hipFree(c->d_nn); c->d_nn = nullptr; c->nn_cap = 0; VGCHK(hipMalloc(&c->d_nn, (size_t)n * KNN_MAX * 6)); c->nn_cap = (size_t)n * KNN_MAX * 6; }
         VGCHK(vknn::grid_build_adaptive(c->gb, n, d_xyz, 3, c->grid_h, 8.0, c->stream));
         hipLaunchKernelGGL(k_knn_wave, dim3((n + VG_QPB - 1) / VG_QPB), dim3(64 * VG_QPB), 0, c->stream, n, d_xyz, c->gb.G, c->gb.order, c->gb.cxyz, k, c->d_nn);
@@ -804,10 +804,16 @@ extern "C" {
 
 static int vgicp_align_host(vgicp_ctx* c, const double* guess, const vgicp_options* o, double* T_out, vgicp_summary* out);
 
+int vgicp_set_knn_grid(vgicp_ctx* c, int32_t min_points, double cell) {
+    if (!c || min_points < 0 || !(cell > 0.0)) return VG_ERR_INVALID;
+    c->grid_min = min_points; c->grid_h = (float)cell;
+    return VG_OK;
+}
+
 int vgicp_align(vgicp_ctx* c, const double* guess, const vgicp_options* o, double* T_out, vgicp_summary* out) {
     if (!c || !guess || !o || !T_out || !out) return VG_ERR_INVALID;
     if (!c->nvox || !c->n || (o->neighbor_mode != VGICP_DIRECT1 && o->neighbor_mode != VGICP_DIRECT7 && o->neighbor_mode != VGICP_DIRECT27)) return VG_ERR_INVALID;
-    if (getenv("VGICP_HOST_LOOP")) return vgicp_align_host(c, guess, o, T_out, out);       // the step logic on the host between launches (cross-check)
+    if (VIL_TUNE_ENV("VGICP_HOST_LOOP")) return vgicp_align_host(c, guess, o, T_out, out);       // the step logic on the host between launches (cross-check)
     VGCHK(hipSetDevice(c->device));
     const int mode = o->neighbor_mode, slots = c->n * mode, nblk = (slots + VGA_THREADS - 1) / VGA_THREADS;
     if (slots > c->slots_cap) { hipFree(c->d_cvox); hipFree(c->d_cM); c->d_cvox = nullptr; c->d_cM = nullptr; c->slots_cap = 0; VGCHK(hipMalloc(&c->d_cvox, 4 * (size_t)slots)); VGCHK(hipMalloc(&c->d_cM, 8 * 9 * (size_t)slots)); c->slots_cap = slots; }
@@ -815,8 +821,11 @@ int vgicp_align(vgicp_ctx* c, const double* guess, const vgicp_options* o, doubl
     if (!c->d_coop) { VGCHK(hipMalloc(&c->d_coop, sizeof(VgCoop))); VGCHK(hipMemsetAsync(c->d_coop, 0, sizeof(VgCoop), c->stream)); VGCHK(hipHostMalloc(&c->h_aout, sizeof(VgAlignOut), hipHostMallocMapped)); VGCHK(hipHostGetDevicePointer(&c->d_aout, c->h_aout, 0)); c->coop_epoch = 0; }
     VgAlignOut* ho = (VgAlignOut*)c->h_aout;
     VgGuess gs; std::memcpy(gs.m, guess, sizeof gs.m);
-    int G = std::min(nblk, VG_MAXG);     // all workgroups resident: they wait for each other.  A pass is bound by the slots per thread (each a chain of dependent gathers), so as many workgroups as there are 256-slot blocks, up to 128 (VGICP_G sweeps it)
-    if (const char* ev = getenv("VGICP_G")) G = std::max(1, std::min(VG_MAXG, atoi(ev)));
+    if (c->coop_cap < 0) c->coop_cap = vilcoop::capacity((const void*)k_vgicp_align, VGA_THREADS, 0, c->device);
+    if (c->coop_cap < 1) return vgicp_align_host(c, guess, o, T_out, out);      // the kernel cannot be resident on this device: one launch per pass instead
+    std::lock_guard<std::mutex> coop_lock(vilcoop::gate());                     // held until the result record has arrived (vil_coop.hpp)
+    int G = std::min(std::min(nblk, VG_MAXG), c->coop_cap);     // all workgroups resident: they wait for each other.  A pass is bound by the slots per thread (each a chain of dependent gathers), so as many workgroups as there are 256-slot blocks, up to 128 (VGICP_G sweeps it)
+    if (const char* ev = VIL_TUNE_ENV("VGICP_G")) G = std::max(1, std::min(VG_MAXG, atoi(ev)));
     const int epoch_of_call = c->coop_epoch;
     ho->seq = -1;
     hipLaunchKernelGGL(k_vgicp_align, dim3(G), dim3(VGA_THREADS), 0, c->stream, c->n, mode, c->d_sxyz, c->d_scov, c->res, tab(c), c->d_cvox, c->d_cM, c->d_cvox2, c->d_cM2, *o, (VgCoop*)c->d_coop, c->coop_epoch, gs, (VgAlignOut*)c->d_aout);

@@ -32,7 +32,7 @@ def test_library_exports_every_vgicp_symbol():
     so = lib.load_vilsolve()
     src = open(os.path.join(ROOT, "include", "vilvgicp.h")).read()
     syms = sorted(set(re.findall(r"\b(vgicp_[a-z_0-9]+)\s*\(", src)))
-    assert len(syms) == 11, syms
+    assert len(syms) == 12, syms
     for s in syms:
         assert hasattr(so, s), "libvilsolve.so does not export %s" % s
     import subprocess, tempfile
@@ -55,7 +55,7 @@ def test_library_exports_every_vmap_symbol():
     so = lib.load_vilsolve()
     src = open(os.path.join(ROOT, "include", "vilmap.h")).read()
     syms = sorted(set(re.findall(r"\b(vmap_[a-z_0-9]+)\s*\(", src)))
-    assert len(syms) == 7, syms
+    assert len(syms) == 8, syms
     for s in syms:
         assert hasattr(so, s), "libvilsolve.so does not export %s" % s
     import subprocess, tempfile
@@ -87,6 +87,15 @@ def test_library_exports_every_vpre_symbol():
         if torch.cuda.is_available():
             raise preint.PreintError("GPU present")
         preint.Preint(so, "vpre_")                      # no device -> refuses, no CPU fallback
+
+
+def test_release_build_has_no_tuning_knobs():
+    """The development knobs (csrc/vil_tuning.hpp: chunking, kernel variants, role masks, debug prints) exist only in the
+    -DVIL_TUNING build; the shipping library does not even contain their names."""
+    blob = open(lib.LIB_PATH, "rb").read()
+    for knob in (b"VIL_SKIP", b"VIL_HELP", b"VIL_VWG", b"VIL_VFBAL", b"VIL_DENSE_STEP", b"VIL_MARG_PIVOTED", b"VIL_MARG_DEBUG", b"VIL_GRAPH",
+                 b"VIL_FORCE_SPLIT", b"VIL_PRECHAIN", b"VIL_MAP_FUSED_MAX", b"VGICP_", b"VPRE_TIMING"):
+        assert knob not in blob, knob
 
 
 def test_struct_layouts_match_header():

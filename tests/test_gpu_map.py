@@ -120,13 +120,9 @@ def test_interleaved_calls_and_map_updates(hip, setup):
 @pytest.fixture(scope="module")
 def window_path(setup):
     """The same registration routed through the window solver (three launches per iteration): the cross-check of the one-launch pose solve."""
-    import os
     g, o, sc, ss, R, t = setup
-    os.environ["VIL_MAP_FUSED_MAX"] = "0"
-    try:
-        w = mapreg.MapReg(lib.load_vilsolve(), "vmap_")
-    finally:
-        del os.environ["VIL_MAP_FUSED_MAX"]
+    w = mapreg.MapReg(lib.load_vilsolve(), "vmap_")
+    assert w.lib.vmap_set_fused_max(w.ctx, 0) == 0
     w.set_map(*[a for a in (mapreg.make_map(seed=4, n_surf=12000, n_corner=2000))])
     yield w
     w.close()

@@ -1,5 +1,6 @@
-"""The multi-GPU step (k_step split around the scalar all-reduce, staged all-reduce buffer, RCCL calls
-in-stream) exercised on ONE GPU: forced split path, with and without a 1-rank RCCL communicator."""
+"""The multi-GPU iteration -- sweep + gather into set 0, ONE collective that sums the whole linear-system set into set 1, the
+complete step kernel on set 1 -- exercised on ONE GPU: the plumbing forced on a single rank (vil_debug_set_split) with and
+without a 1-rank RCCL communicator, then complete factor-sharded solves of 2, 3 and 8 ranks through the in-process communicator."""
 import os
 import subprocess
 import sys
@@ -18,6 +19,7 @@ from mvil_fusion_amd import abi, lib, synth
 import oracle_lib
 orc = oracle_lib.open_oracle()
 be = lib.open_vilsolve()
+assert be.lib.vil_debug_set_split(be.ctx, 1) == 0
 if os.environ.get("USE_COMM") == "1":
     uid = (C.c_char * 128)()
     assert be.lib.vil_comm_unique_id(uid) == 0
@@ -38,7 +40,7 @@ print("SPLIT_OK")
 
 @pytest.mark.parametrize("use_comm", ["0", "1"])
 def test_forced_split_path_matches_oracle(use_comm):
-    env = dict(os.environ, VIL_FORCE_SPLIT="1", USE_COMM=use_comm)
+    env = dict(os.environ, USE_COMM=use_comm)
     out = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, ROOT)], env=env, capture_output=True, text=True, timeout=600)
     assert "SPLIT_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 

@@ -135,10 +135,10 @@ def test_covariances_grid_search_parity(oracle, monkeypatch):
     sx = np.vstack([sx, np.array([[80.0, -70.0, 30.0], [81.0, -70.5, 30.2]], np.float32)])      # two isolated points far from everything
     o = vgicp.Vgicp(oracle.lib, "orc_vgicp_")
     co = o.covariances(sx, 20)
-    monkeypatch.setenv("VGICP_GRID_MIN", "0")
-    for h in ("1.0", "0.3", "4.0"):
-        monkeypatch.setenv("VGICP_GRID_H", h)
+    import ctypes as C
+    for h in (1.0, 0.3, 4.0):
         g = vgicp.Vgicp(lib.load_vilsolve(), "vgicp_")
+        assert g.lib.vgicp_set_knn_grid(g.ctx, 0, C.c_double(h)) == 0
         cg = g.covariances(sx, 20)
         g.close()
         assert np.abs(cg - co).max() < 1e-10, h
