@@ -109,6 +109,7 @@ def replay_mode(args, be, abi, lib):
     solve -> gauge fix -> marginalise -> slide is driven by the HIP library; on every frame the CPU restatement gets the
     SAME input window (cpu_baseline leg), so the two latencies and the state difference are per-frame comparable."""
     import numpy as np
+    import torch
     from mvil_fusion_amd import replay
     from mvil_fusion_amd.abi import Window
     rp = replay.Replay(K=10, n_frames=args.replay + 10, L=1000, n_plane=24000, n_edge=6000, seed=20240605, max_iterations=8)
@@ -118,18 +119,35 @@ def replay_mode(args, be, abi, lib):
         so_path = os.path.join(ROOT, "oracle", "liboracle.so")
         orc = lib.Backend(C.CDLL(so_path), "orc_")
     opts_cpu = abi.default_options(max_iterations=8)
-    g_solve, g_marg, g_slide, c_solve, c_marg, dpos, its, Ls, nvis = [], [], [], [], [], [], [], [], []
-    resident = not args.classic
+    g_solve, g_marg, g_slide, g_period, c_solve, c_marg, dpos, its, Ls, nvis = [], [], [], [], [], [], [], [], [], []
+    mode = "classic" if args.classic else ("slabs" if args.slabs else "window")
     K = rp.K
-    if resident:                                   # window residency (include/vilsolve.h): LiDAR frame slabs on the device, gauge fix on the device,
-        be.set_gauge_fix(True); be.lidar_reset()   # marginalisation of the resident window; per image only the new frame's points cross PCIe
+    if mode == "slabs":                            # round-2 residency: LiDAR frame slabs on the device, gauge fix on the device, marginalisation of the
+        be.set_gauge_fix(True); be.lidar_reset()   # resident window; visual / IMU tables, the state and the prior still travel every image
         for k in range(K):
             be.lidar_push(rp.lidar[k][0], rp.lidar[k][1])
+    if mode == "window":                           # the fully resident window (vil_win_*): per image the new frame + the small tables go up, the state comes back
+        be.set_gauge_fix(True); be.win_open(**rp.win_open_args())
+        for k in range(K):
+            be.win_push_frame(rp.win_frame(k))
+    t_prev = None
     for step in range(args.replay):
         flag = rp.margin_flag()
-        if resident:
+        wo = None
+        if mode == "window":
+            w = rp.win_window()
+            if orc is not None:
+                rp.prior = be.win_prior_download(K).to_prior() or rp.prior           # CPU leg only: the prior never leaves the device on the product path
+                wo = Window.from_dict(rp.window().to_dict())
+            p0 = w.pose[0].copy()
+            t0 = time.perf_counter(); sg = be.win_solve(w, rp.opts); t1 = time.perf_counter()
+            be.win_marginalize(flag, w._icp_marg, w._lps_marg, rp.opts)
+            if step & 1:                               # every other image waits for the marginalisation kernels inside the timed region: the
+                torch.cuda.synchronize()               # serialised figure (no overlap with the host's bookkeeping) next to the overlapped one
+            t2 = time.perf_counter()
+            pg = None
+        elif mode == "slabs":
             w = rp.window(with_lidar=False)
-            wo = None
             if orc is not None:
                 wo = Window.from_dict(rp.window().to_dict())
             p0 = w.pose[0].copy()
@@ -147,28 +165,49 @@ def replay_mode(args, be, abi, lib):
             orc.marginalize(wo, flag, w._icp_marg, w._lps_marg, opts_cpu); t2 = time.perf_counter()
             c_solve.append(1e3 * (t1 - t0)); c_marg.append(1e3 * (t2 - t1))
             dpos.append(float(np.abs(w.pose[:, :3] - wo.pose[:, :3]).max()))
-        if resident:
-            t3 = time.perf_counter(); be.lidar_drop(0 if flag == abi.MARGIN_OLD else K - 2)
+        t3 = time.perf_counter()
+        if mode == "slabs":
+            be.lidar_drop(0 if flag == abi.MARGIN_OLD else K - 2)
+        if mode == "window":
+            be.win_drop_frame(flag)
+        t3b = time.perf_counter()
         if not rp.absorb(w, pg, flag):
             break
-        if resident:
-            t4 = time.perf_counter(); be.lidar_push(rp.lidar[K - 1][0], rp.lidar[K - 1][1]); g_slide.append(1e3 * (time.perf_counter() - t4))
+        t4 = time.perf_counter()
+        if mode == "slabs":
+            be.lidar_push(rp.lidar[K - 1][0], rp.lidar[K - 1][1])
+        if mode == "window":
+            fr = rp.win_frame(K - 1); t4 = time.perf_counter()
+            be.win_push_frame(fr)
+        if mode != "classic":
+            g_slide.append(1e3 * (time.perf_counter() - t4 + t3b - t3))
 
     def st(v):
         v = np.array(v)
         return {"median": float(np.median(v)), "p95": float(np.percentile(v, 95)), "max": float(v.max())}
     tot_g = np.array(g_solve) + np.array(g_marg)
-    if resident and g_slide:
-        tot_g = tot_g[:len(g_slide)] + np.array(g_slide)          # the new frame's LiDAR points going up belongs to the image's latency
+    if g_slide:
+        tot_g = tot_g[:len(g_slide)] + np.array(g_slide)          # dropping a frame and sending the new one up belongs to the image's latency
+    tot_all = tot_g
+    if mode == "window":                                           # `value`: the SERIALISED images (odd steps: the marginalisation kernels are waited for inside marg_ms)
+        tot_g = tot_all[1::2]
     out = {"metric": "per-frame backend latency, synthetic replay (solve + gauge fix + marginalisation, host buffers in, host buffers out)",
            "value": float(np.median(tot_g)), "unit": "ms/frame", "higher_is_better": False, "n_gpus": 1, "frames": len(g_solve), "dtype": "f64" if args.precision == 0 else "f32 eval / f64 accumulate",
            "data": "synthetic replay (3indoor.bag unavailable offline)",
            "config": {"workload": "BASELINE.json configs[4] substitute: K=10, ~%d landmarks / ~%d visual factors per window, 30000 LiDAR points, max 8 iterations, every 5th image a non-keyframe (MARGIN_SECOND_NEW)" % (int(np.mean(Ls)), int(np.mean(nvis))),
                       "iterations_per_frame": float(np.mean(its))},
            "gpu": {"solve_ms": st(g_solve), "marg_ms": st(g_marg), "total_ms": st(tot_g), "note": "includes H2D upload of the window and D2H of the state / prior (PCIe-inclusive)",
-                   "mode": "resident window: LiDAR frame slabs stay in HBM (per image only the new frame's points go up: lidar_push_ms), gauge fix on the device, vil_marginalize_resident" if resident else "classic: every table handed over on every image (vil_solve + vil_gauge_fix + vil_marginalize)"}}
-    if resident and g_slide:
-        out["gpu"]["lidar_push_ms"] = st(g_slide)
+                   "mode": {"window": "fully resident window (vil_win_*): observations, IMU samples / records, LiDAR points and the prior stay in HBM; per image the new frame (IMU samples pre-integrated on the device, observations, LiDAR points: slide_push_ms) and the window's small tables go up, the state comes back through pinned memory; the marginalisation is enqueued (marg_ms = the call) and its prior is written device-to-device -- its GPU time is inside the NEXT image's solve_ms",
+                            "slabs": "round-2 residency: LiDAR frame slabs stay in HBM, gauge fix on the device, vil_marginalize_resident; visual / IMU tables, state and prior travel every image",
+                            "classic": "every table handed over on every image (vil_solve + vil_gauge_fix + vil_marginalize)"}[mode]}}
+    if g_slide:
+        out["gpu"]["slide_push_ms"] = st(g_slide)
+    if mode == "window":
+        out["gpu"]["total_overlapped_ms"] = st(tot_all[0::2])
+        out["gpu"]["marg_call_ms"] = st(np.array(g_marg)[0::2]); out["gpu"]["marg_serialised_ms"] = st(np.array(g_marg)[1::2])
+        out["gpu"]["note"] = ("value / total_ms = images whose marginalisation kernels are waited for inside the timed region (every other image); total_overlapped_ms = the other "
+                              "half, where vil_win_marginalize returns once its launches are enqueued and the GPU works while the host does its bookkeeping.  PCIe-inclusive: per image "
+                              "the new frame + the small tables up, the state back")
     if orc is not None:
         tot_c = np.array(c_solve) + np.array(c_marg)
         out["cpu_baseline"] = {"solve_ms": st(c_solve), "marg_ms": st(c_marg), "total_ms": st(tot_c), "cores": 4, "kind": "port",
@@ -382,6 +421,7 @@ def main():
     ap.add_argument("--replay", type=int, default=0, help="config 5: run N images of the synthetic replay and report per-frame latency instead of the headline metric")
     ap.add_argument("--no-cfg3", dest="no_cfg3", action="store_true", help="skip the extra configs[2] (K=10, L=4000, 120k points) leg")
     ap.add_argument("--classic", action="store_true", help="replay mode: hand every table over on every image (vil_solve + vil_gauge_fix + vil_marginalize) instead of the resident-window entry points")
+    ap.add_argument("--slabs", action="store_true", help="replay mode: round-2 residency (LiDAR frame slabs + vil_marginalize_resident) instead of the fully resident window (vil_win_*)")
     ap.add_argument("--precision", type=int, default=0, help="0 = fp64 (reference arithmetic), 1 = fp32 factor evaluation with fp64 accumulation (replay mode only)")
     ap.add_argument("--vgicp", action="store_true", help="SURVEY 8(f) row 1: bench the voxelised GICP linearisation instead of the headline metric")
     ap.add_argument("--vgicp-rings", type=int, default=16)

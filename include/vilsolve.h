@@ -355,6 +355,58 @@ int vil_set_gauge_fix(vil_ctx* ctx, int32_t on);
 int vil_marginalize_resident(vil_ctx* ctx, const vil_state* solved, const vil_options* options,
                              const vil_marg_spec* spec, vil_prior_out* out);
 
+/* ---- the fully resident window -----------------------------------------------------------------------------------
+ * Everything slideWindow() leaves unchanged stays in HBM across images -- observations, IMU samples and pre-integration records,
+ * LiDAR points, the marginalisation prior -- in SLOTS the library hands out and recycles: sliding the window is an index remap on
+ * the host, nothing moves on the device.  Per image the host sends
+ *    vil_win_push_frame   the new frame: the IMU samples since the previous frame (pre-integrated ON the device into the frame's IMU
+ *                         slot, integration_base.h:30-158), its feature observations (by track slot), its LiDAR points     -- one DMA
+ *    vil_win_solve        the window's small tables: landmark list (track slot, anchor frame, observation count, constancy, inverse
+ *                         depth), the camera state (the host predicts the newest frame, estimator.cpp:170-200, and owns the depth
+ *                         bookkeeping of FeatureManager, so the state is host-authoritative: 16 K + 8 + L doubles), ICP / LPS      -- one DMA
+ *    vil_win_marginalize  nothing: the factors MarginalizationInfo collects are selected by masks on the resident tables, the new
+ *                         prior (J0, r0, x0 and the contractions the solve uses) is written device-to-device into the prior slot
+ *                         and read there by the next vil_win_solve.  The call returns when the work is enqueued; it reports the
+ *                         block structure of the new prior (a function of the window's structure alone), a failure surfaces as the
+ *                         status of the next vil_win_solve / vil_win_prior_download.
+ *    vil_win_drop_frame   nothing: MARGIN_OLD -- frame 0 leaves; MARGIN_SECOND_NEW -- frame count-2 leaves and the newest frame's IMU
+ *                         samples continue its interval (estimator.cpp:1763-1772, re-integrated on the device).
+ * and receives the solved, gauge-fixed state (vil_state) in pinned memory the finishing kernel wrote (no copy, no synchronisation).
+ * Track slots are the caller's: one per live feature track (FeaturePerId), < max_tracks, reusable once the track is gone.
+ * Observation layout (VIL_WIN_OBS = 8 doubles): [x y z vx vy cur_td row 0], row = v - ROW/2 (projection_td_factor.cpp:12-19).
+ * Not combinable with a communicator (the multi-GPU path shards a window handed over through vil_upload). */
+#define VIL_WIN_OBS 8
+typedef struct vil_win_cfg {
+    int32_t K;                      /* frames in the window */
+    int32_t max_tracks;             /* track slots */
+    int32_t max_samples;            /* IMU samples per interval kept on the device (a merged interval counts its parts) */
+    int32_t use_td;                 /* ProjectionTdFactor (1) / ProjectionFactor (0) */
+    double noise[4];                /* ACC_N GYR_N ACC_W GYR_W (integration_base.h:21-27) */
+    double G[3], sqrt_info_px, tr_over_row, q_lb[4], t_lb[3];      /* as in vil_problem */
+} vil_win_cfg;
+typedef struct vil_win_frame {
+    int32_t n_samples; const double* dt; const double* acc; const double* gyr;       /* n, n x 3, n x 3: the interval that ENDS in this frame (0 for the first frame) */
+    double acc0[3], gyr0[3], lin_ba[3], lin_bg[3];     /* IntegrationBase{acc_0, gyr_0, Bas, Bgs} (estimator.cpp:125-128) */
+    int32_t n_obs; const int32_t* obs_track; const double* obs;                       /* n_obs, n_obs x VIL_WIN_OBS */
+    int32_t n_plane; const double* plane_const; int32_t n_edge; const double* edge_const;
+} vil_win_frame;
+typedef struct vil_win_problem {
+    int32_t L; const int32_t* lm_track; const int32_t* lm_start; const int32_t* lm_nobs;   /* landmark l: track slot, anchor frame, observations in consecutive frames (>= 2) */
+    const uint8_t* lm_const;        /* L or NULL */
+    const uint8_t* pose_const; const uint8_t* sb_const; int32_t ex_const, td_const;
+    int32_t n_icp; const int32_t* icp_ids; const double* icp_const;
+    int32_t n_lps; const int32_t* lps_ids; const double* lps_const;
+} vil_win_problem;
+#define VIL_WIN_MAXBLK 24
+typedef struct vil_win_prior_info { int32_t n, nblk, m; int32_t blk_kind[VIL_WIN_MAXBLK], blk_index[VIL_WIN_MAXBLK], blk_col[VIL_WIN_MAXBLK]; } vil_win_prior_info;
+int vil_win_open(vil_ctx* ctx, const vil_win_cfg* cfg);                      /* (re)opens an empty window; the prior slot is cleared */
+int vil_win_push_frame(vil_ctx* ctx, const vil_win_frame* frame);
+int vil_win_drop_frame(vil_ctx* ctx, int32_t marg_flag);
+int vil_win_solve(vil_ctx* ctx, const vil_win_problem* problem, vil_state* state_inout, const vil_options* options, vil_summary* summary);
+int vil_win_marginalize(vil_ctx* ctx, const vil_options* options, const vil_marg_spec* spec, vil_win_prior_info* info /* may be NULL */);
+int vil_win_prior_download(vil_ctx* ctx, vil_prior_out* out);              /* on request (tests, logging): the resident prior; out->n = 0 when there is none */
+int vil_win_prior_set(vil_ctx* ctx, const vil_prior* prior);               /* seed the prior slot from the host (NULL or n == 0: none) */
+
 /* host-side helpers of the boundary */
 int vil_reduced_dim(int K);                               /* 15K + 7 */
 void vil_prior_capacity(int K, int* n_max, int* nblk_max, int* x0_max);

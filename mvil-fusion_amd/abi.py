@@ -82,6 +82,31 @@ class VilPriorOut(C.Structure):
                 ("x0", _dp), ("J0", _dp), ("r0", _dp), ("A", _dp), ("b", _dp)]
 
 
+VIL_WIN_OBS, VIL_WIN_MAXBLK = 8, 24
+
+
+class VilWinCfg(C.Structure):
+    _fields_ = [("K", C.c_int32), ("max_tracks", C.c_int32), ("max_samples", C.c_int32), ("use_td", C.c_int32), ("noise", C.c_double * 4),
+                ("G", C.c_double * 3), ("sqrt_info_px", C.c_double), ("tr_over_row", C.c_double), ("q_lb", C.c_double * 4), ("t_lb", C.c_double * 3)]
+
+
+class VilWinFrame(C.Structure):
+    _fields_ = [("n_samples", C.c_int32), ("dt", _dp), ("acc", _dp), ("gyr", _dp),
+                ("acc0", C.c_double * 3), ("gyr0", C.c_double * 3), ("lin_ba", C.c_double * 3), ("lin_bg", C.c_double * 3),
+                ("n_obs", C.c_int32), ("obs_track", _ip), ("obs", _dp),
+                ("n_plane", C.c_int32), ("plane_const", _dp), ("n_edge", C.c_int32), ("edge_const", _dp)]
+
+
+class VilWinProblem(C.Structure):
+    _fields_ = [("L", C.c_int32), ("lm_track", _ip), ("lm_start", _ip), ("lm_nobs", _ip), ("lm_const", _bp),
+                ("pose_const", _bp), ("sb_const", _bp), ("ex_const", C.c_int32), ("td_const", C.c_int32),
+                ("n_icp", C.c_int32), ("icp_ids", _ip), ("icp_const", _dp), ("n_lps", C.c_int32), ("lps_ids", _ip), ("lps_const", _dp)]
+
+
+class VilWinPriorInfo(C.Structure):
+    _fields_ = [("n", C.c_int32), ("nblk", C.c_int32), ("m", C.c_int32), ("blk_kind", C.c_int32 * VIL_WIN_MAXBLK), ("blk_index", C.c_int32 * VIL_WIN_MAXBLK), ("blk_col", C.c_int32 * VIL_WIN_MAXBLK)]
+
+
 class VilDeviceCfg(C.Structure):
     _fields_ = [("device", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("reserved", C.c_int32)]
 

@@ -31,6 +31,7 @@ struct Ctl {          // trust-region state, lives in device memory, owned by th
     int gen;          // solve generation (host): with n_sweeps it forms the epoch of the helper-workgroup flags
     int cur, iter, done, term, first, resweep, reuse, nsucc, invalid_run, status, lin_mode, n_sweeps;
     int swe;                      // advanced by every live step-kernel launch
+    int outd, pad_;               // outd: the finished solve has been written out (solve_finish: accepted state -> x[0], gauge fix, host mirror)
     double radius, mu, cost_cur, model_change, alpha, dogleg_norm, initial_cost, cand_cost;
     double mu_used, gn2, g2, gg;   // dogleg scalars of the current linearisation (reused after a rejected step)
     double cg, cn;                 // dogleg coefficients of the candidate: the sweep forms lambda_cand = lambda_cur + cg la + cn lb
@@ -101,6 +102,10 @@ struct DevP {
     // pinned host mirror of Ctl (device pointers into mapped host memory; null: off): the step kernel that finishes the solve copies
     // its Ctl there and then stores the solve generation in hseq -- the host polls that word instead of synchronising the stream
     Ctl* hctl; int* hseq;
+    double* hstate;               // same mirror: the NS doubles of the final state (solve_finish)
+    const double* xorig;          // the state the solve started from (the gauge fix re-anchors on its frame 0)
+    int gauge_on;                 // double2vector()'s yaw / translation gauge fix as part of solve_finish
+    const int* setup_stat;        // != 0: k_setup found an IMU covariance that is not positive definite -- the first step kernel ends the solve with it
     int n_help; double* hpart; int* hflag;
     // second landmark pass of the helpers (k_step): the master posts the epoch in xflag (Sc x_p is in stepc) or in xstat (no step
     // this launch); every helper WAVE then leaves its six sums in hpart2[8 * slot ..] and the epoch in hflag2[slot], slot = 8 k + wave

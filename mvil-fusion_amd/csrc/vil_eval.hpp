@@ -188,32 +188,34 @@ __device__ inline bool chol15_wg(double* A, int* bad, double* rinv = nullptr) {
     return true;
 }
 
+// U with U^T U = cov^-1: cov = C C^T, W = C^-1, cov^-1 = W^T W = L L^T, U = L^T   (imu_factor.h:64).  One workgroup of VIL_THREADS.
+__device__ inline void imu_sqrtinfo_wg(const double* cov, double* U_out, int* status) {
+    using namespace vd;
+    const int t = threadIdx.x;
+    __shared__ double C[225], W[225], A[225], rC[16];
+    __shared__ int bad;
+    if (t == 0) bad = 0;
+    if (t < 225) { C[t] = cov[t]; W[t] = 0.0; }
+    __syncthreads();
+    chol15_wg(C, &bad, rC);
+    __syncthreads();
+    if (t < 15) {                                    // column t of W = C^-1 by forward substitution
+        const int j = t;
+        W[j * 15 + j] = rC[j];
+        for (int i = j + 1; i < 15; ++i) { double s = 0; for (int k = j; k < i; ++k) s -= C[i * 15 + k] * W[k * 15 + j]; W[i * 15 + j] = s * rC[i]; }
+    }
+    __syncthreads();
+    if (t < 225) { const int i = t / 15, j = t - 15 * i; double s = 0; if (j <= i) for (int k = i; k < 15; ++k) s += W[k * 15 + i] * W[k * 15 + j]; A[t] = s; }
+    __syncthreads();
+    chol15_wg(A, &bad);
+    if (t < 225) { const int i = t / 15, j = t - 15 * i; U_out[t] = j >= i ? A[j * 15 + i] : 0.0; }   // U = L^T
+    if (t == 0 && (bad || !(A[224] == A[224]))) atomicExch(status, -4);
+}
+
 __global__ __launch_bounds__(VIL_THREADS) void k_setup(DevP P, double* imu_U, int* status) {
     using namespace vd;
     const int b = blockIdx.x, t = threadIdx.x;
-    if (b < P.n_imu) {
-        // U with U^T U = cov^-1: cov = C C^T, W = C^-1, cov^-1 = W^T W = L L^T, U = L^T   (imu_factor.h:64)
-        __shared__ double C[225], W[225], A[225], rC[16];
-        __shared__ int bad;
-        const double* cov = P.imu_c + (size_t)b * 287 + 62;
-        if (t == 0) bad = 0;
-        if (t < 225) { C[t] = cov[t]; W[t] = 0.0; }
-        __syncthreads();
-        chol15_wg(C, &bad, rC);
-        __syncthreads();
-        if (t < 15) {                                    // column t of W = C^-1 by forward substitution
-            const int j = t;
-            W[j * 15 + j] = rC[j];
-            for (int i = j + 1; i < 15; ++i) { double s = 0; for (int k = j; k < i; ++k) s -= C[i * 15 + k] * W[k * 15 + j]; W[i * 15 + j] = s * rC[i]; }
-        }
-        __syncthreads();
-        if (t < 225) { const int i = t / 15, j = t - 15 * i; double s = 0; if (j <= i) for (int k = i; k < 15; ++k) s += W[k * 15 + i] * W[k * 15 + j]; A[t] = s; }
-        __syncthreads();
-        chol15_wg(A, &bad);
-        if (t < 225) { const int i = t / 15, j = t - 15 * i; imu_U[(size_t)b * 225 + t] = j >= i ? A[j * 15 + i] : 0.0; }   // U = L^T
-        if (t == 0 && (bad || !(A[224] == A[224]))) atomicExch(status, -4);
-        return;
-    }
+    if (b < P.n_imu) { imu_sqrtinfo_wg(P.imu_c + (size_t)b * 287 + 62, imu_U + (size_t)b * 225, status); return; }
     const int n = P.pn;
     if (n <= 0) return;
     const int nb = gridDim.x - P.n_imu;

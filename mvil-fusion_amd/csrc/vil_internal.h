@@ -13,3 +13,7 @@ struct vil_device_lidar { const double* plane_soa; int plane_stride; const doubl
 // valid until the call returns; they are written by work enqueued on `producer` (the call waits for it on the device).
 extern "C" int vil_solve_device_lidar(vil_ctx* ctx, const vil_problem* p, const vil_device_lidar* dl, void* producer_stream,
                                       vil_state* s, const vil_options* o, vil_summary* sum);
+
+// vilpreint.hip: pre-integrates ONE interval whose samples (dt[ns], acc[3 ns], gyr[3 ns]), header (acc0 gyr0 lin_ba lin_bg) and
+// 287-double record all live on the device -- the IMU slots of the resident window (vil_window.hpp).  Asynchronous on `stream`.
+void vpre_launch_slot(hipStream_t stream, int ns, const double* dt, const double* acc, const double* gyr, const double* hdr12, const double* noise4, double* rec);

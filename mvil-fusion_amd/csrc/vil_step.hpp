@@ -692,19 +692,13 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     auto post = [&](int* f) { if (t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } };
     auto wait1 = [&](int* f) { while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1); };
     auto put = [&](double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    // wave 0 (all 64 lanes call it): Ctl back to device memory; the launch that finishes the solve also leaves it in the host's pinned mirror --
-    // 1.5 kB across PCIe, one coalesced store per lane and round instead of a lone lane's 190 -- then the generation
+    // wave 0 (all 64 lanes call it): Ctl back to device memory, one coalesced store per lane and round instead of a lone lane's 190.  (The host's
+    // copy is written by solve_finish, vil_finish.hpp: the next sweep launch finds the solve finished and leaves Ctl + the final state there.)
     auto store_ctl = [&]() {
         static_assert(sizeof(Ctl) % 8 == 0, "Ctl is copied as doubles");
         const double* src = (const double*)&s.c;
         double* dst = (double*)P.ctl;
         for (int i = t; i < (int)(sizeof(Ctl) / 8); i += 64) dst[i] = src[i];
-        if (s.c.done && P.hctl) {
-            double* h = (double*)P.hctl;
-            for (int i = t; i < (int)(sizeof(Ctl) / 8); i += 64) h[i] = src[i];
-            __threadfence_system();
-            if (t == 0) __hip_atomic_store(P.hseq, s.c.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
     };
     // master: every helper has read Ctl (one lane per helper: the polls overlap instead of queueing behind one another)
     bool hseen = false;
@@ -717,6 +711,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         const int cand = 1 - c.cur;
         const double cand_cost = *P.sys[cand].cost;
         c.cand_cost = cand_cost;
+        if (c.first && *P.setup_stat != 0) { c.done = 1; c.term = 6; c.status = *P.setup_stat; }      // k_setup: an IMU covariance is not positive definite (resident window: or its prior is not finite)
         if (c.first || c.resweep) {
             if (c.first) { c.initial_cost = cand_cost; s.was_first = 1; }
             if (!isfinite(cand_cost)) { c.done = 1; c.term = 6; c.status = -3; }

@@ -18,6 +18,7 @@
 #pragma once
 #include "vil_dev.hpp"
 #include "vil_factors.hpp"
+#include "vil_finish.hpp"
 
 namespace vd {
 
@@ -630,7 +631,10 @@ __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
 __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O) {
     extern __shared__ double sm[];
     const Ctl ctl = *P.ctl;
-    if (ctl.done) return;
+    if (ctl.done) {                                      // the solve has ended: the first launch to see it writes the result out (vil_finish.hpp)
+        if (blockIdx.x == 0 && !ctl.outd && ctl.lin_mode == 0) vd::solve_finish(P, ctl.cur, ctl.status, ctl.gen);
+        return;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) P.ctl->n_sweeps = ctl.n_sweeps + 1;   // live (not early-exited) launches, for the profiler
     const int cand = 1 - ctl.cur;
     const double* x = P.x[cand];

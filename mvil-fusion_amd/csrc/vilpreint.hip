@@ -29,6 +29,7 @@ namespace {
 struct PreArgs {
     int n; const int* start; const double* dt; const double* acc; const double* gyr; const double* acc0; const double* gyr0; const double* ba; const double* bg;
     double nz[4]; double* out; double* jac;
+    int s0_, s1_;               // start == nullptr: the one interval [s0_, s1_) (the resident window's IMU slots, vil_window.hpp)
 };
 
 // Eigen::Quaternion::toRotationMatrix of a (possibly un-normalised) quaternion w, x, y, z
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preint(PreArgs A) {
     double* sTmpF = sV;                                        // after Q is formed the V region holds the tree's temporaries:
     double* sTmpT = sV + (PRE_B / 2) * 225;                    // F_b F_a and F_b Q_a of up to PRE_B / 2 pairs
     const int k = blockIdx.x, t = threadIdx.x;
-    const int s0 = A.start[k], s1 = A.start[k + 1];
+    const int s0 = A.start ? A.start[k] : A.s0_, s1 = A.start ? A.start[k + 1] : A.s1_;
     if (t < 225) { sJ[t] = (t / 15 == t % 15) ? 1.0 : 0.0; sC[t] = 0.0; }
     if (t == 0) {
         // dp(0:3) dv(3:6) dq w x y z (6:10) - - - - - - sum_dt(16)
@@ -304,6 +305,16 @@ __global__ __launch_bounds__(PRE_THREADS) void k_preint(PreArgs A) {
 }
 
 }  // namespace
+
+// the resident window (vilsolve.hip): one interval whose samples, first measurement, biases and record all live on the device
+void vpre_launch_slot(hipStream_t stream, int ns, const double* dt, const double* acc, const double* gyr, const double* hdr12, const double* noise4, double* rec) {
+    PreArgs A;
+    A.n = 1; A.start = nullptr; A.s0_ = 0; A.s1_ = ns; A.dt = dt; A.acc = acc; A.gyr = gyr;
+    A.acc0 = hdr12; A.gyr0 = hdr12 + 3; A.ba = hdr12 + 6; A.bg = hdr12 + 9;
+    for (int q = 0; q < 4; ++q) A.nz[q] = noise4[q];
+    A.out = rec; A.jac = nullptr;
+    hipLaunchKernelGGL(k_preint, dim3(1), dim3(PRE_THREADS), 0, stream, A);
+}
 
 struct vpre_ctx {
     int device = 0;

@@ -23,10 +23,12 @@
 #include "vil_tuning.hpp"
 #include "vil_coop.hpp"
 #include "vil_dev.hpp"
+#include "vil_finish.hpp"
 #include "vil_sweep.hpp"
 #include "vil_eval.hpp"
 #include "vil_step.hpp"
 #include "vil_marg.hpp"
+#include "vil_window.hpp"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[vilsolve] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return VIL_ERR_DEVICE; } } while (0)
 
@@ -120,7 +122,10 @@ struct vil_ctx {
     bool step_lds = false;
     int* d_status = nullptr;
     Ctl* h_ctl = nullptr;          // pinned
-    char* h_mirror = nullptr; Ctl* d_hctl = nullptr; int* d_hseq = nullptr;      // pinned + mapped: Ctl | sequence word, written by the step kernel (DevP::hctl)
+    char* h_mirror = nullptr; Ctl* d_hctl = nullptr; int* d_hseq = nullptr; double* d_hstate = nullptr; size_t mirror_ns = 0;      // pinned + mapped: Ctl | sequence word | final state, written by solve_finish (vil_finish.hpp)
+    bool no_poll = false;          // VIL_NO_POLL=1: copy + synchronise instead of polling the mirror
+    bool mirror_state = false;     // the mirror holds the final state of the last solve (vil_download_state needs no device operation)
+    int attr_sweep = 0, attr_step[5] = {0, 0, 0, 0, 0}, attr_marg[2] = {0, 0};      // dynamic-LDS sizes already granted to the kernels (hipFuncSetAttribute is not free)
     double* h_pin = nullptr;       // pinned scratch
     char* marg_ws = nullptr;       // device work space of vil_marginalize (grow-only)
     size_t marg_ws_bytes = 0;
@@ -156,10 +161,48 @@ struct vil_ctx {
         int n_lm0 = 0; bool imu01 = false; bool lidar0 = false; bool use_td = false;
         std::vector<int> icp_ids, lps_ids;
     } mm;
+    // ---- the fully resident window (vil_win_*, vil_window.hpp) ---------------------------------------------------------------------
+    struct WinStore {
+        bool open = false; vil_win_cfg cfg;
+        int K = 0, T = 0, S = 0, NF = 0, nmax = 0, x0max = 0;
+        std::vector<int> fslot, islot, free_f, free_i;           // window frame -> observation slot / IMU slot; free lists
+        std::vector<int> ns; std::vector<double> sum_dt;          // per IMU slot: samples held, duration of the interval
+        double* d_store = nullptr; double* d_samp = nullptr; double* d_hdr = nullptr; double* d_rec = nullptr; double* d_U = nullptr;
+        double* d_prior[2] = {nullptr, nullptr}; int cur = 0;     // prior slots: [J0 nmax^2 | r0 nmax | x0 x0max | pH nmax^2 | pg0 nmax | pc0 8]
+        int pn = 0, pm = 0; std::vector<int> pkind, pindex, pcol;  // the current prior's block structure (host)
+        int* d_wstat = nullptr;                                   // sticky status of the asynchronous work (a covariance that is not positive definite, a prior that is not finite)
+        char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_cap = 0; hipEvent_t ev = nullptr; bool pending = false;
+        double* dt(int q) const { return d_samp + (size_t)q * 7 * S; }
+        double* acc(int q) const { return dt(q) + S; }
+        double* gyr(int q) const { return dt(q) + 4 * (size_t)S; }
+        double* pJ0(int w) const { return d_prior[w]; }
+        double* pr0(int w) const { return d_prior[w] + (size_t)nmax * nmax; }
+        double* px0(int w) const { return pr0(w) + nmax; }
+        double* pH(int w) const { return px0(w) + x0max; }
+        double* pg0(int w) const { return pH(w) + (size_t)nmax * nmax; }
+        double* pc0(int w) const { return pg0(w) + nmax; }
+        size_t prior_doubles() const { return 2 * (size_t)nmax * nmax + 2 * (size_t)nmax + x0max + 8; }
+    } win;
     bool profiling = false;
     std::vector<hipEvent_t> ev, ev_mid;
     vil_profile prof = {0, 0.0, 0, 0.0, 0.0};
 };
+
+// pinned, device-mapped mirror [Ctl | sequence word (64 B) | final state (ns doubles)]; grow-only
+static int ensure_mirror(vil_ctx* c, size_t ns) {
+    if (c->h_mirror && ns <= c->mirror_ns) return VIL_OK;
+    if (c->stream) HIPCHK(hipStreamSynchronize(c->stream));       // nobody is writing the old one
+    if (c->h_mirror) hipHostFree(c->h_mirror);
+    c->h_mirror = nullptr; c->d_hctl = nullptr; c->d_hseq = nullptr; c->d_hstate = nullptr; c->mirror_ns = 0; c->mirror_state = false;
+    const size_t cap = ns + ns / 2 + 256, bytes = sizeof(Ctl) + 64 + 8 * cap;
+    HIPCHK(hipHostMalloc((void**)&c->h_mirror, bytes, hipHostMallocMapped));
+    memset(c->h_mirror, 0, bytes);
+    void* dp = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dp, c->h_mirror, 0));
+    c->d_hctl = (Ctl*)dp; c->d_hseq = (int*)((char*)dp + sizeof(Ctl)); c->d_hstate = (double*)((char*)dp + sizeof(Ctl) + 64);
+    c->mirror_ns = cap;
+    return VIL_OK;
+}
 
 static SolveOpts to_dev_opts(const vil_options* o) {
     SolveOpts s;
@@ -184,25 +227,6 @@ __global__ void k_aos2soa(const double* aos, int n, int ncomp, double* dst, size
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f < n) for (int q = 0; q < ncomp; ++q) dst[(size_t)q * stride + f] = aos[(size_t)f * ncomp + q];
 }
-__host__ __device__ static void gauge_fix_core(const double* pose0_before, int K, double* pose, double* speedbias, double* ex_pose);
-__host__ __device__ static void gauge_rot(const double* pose0_before, const double* pose0_now, double* rot);
-__host__ __device__ static void gauge_frame(const double* rot, const double* p0, const double* pose0_before, double* pp, double* sb);
-__host__ __device__ static void gauge_ex(double* ex_pose);
-// double2vector()'s gauge fix on the device, both state buffers: one thread per frame (+ one for the extrinsic); every thread derives the
-// yaw correction from frame 0 itself, before anybody overwrites it (the frames are independent after that: one lane's latency instead of K)
-__global__ void k_gauge_fix(DevP P, const double* x0) {
-    const int t = threadIdx.x, K = P.K;
-    double* x = P.x[0];
-    double rot[9], p0[3];
-    gauge_rot(x0 + xo_pose(P, 0), x + xo_pose(P, 0), rot);
-    for (int i = 0; i < 3; ++i) p0[i] = x[xo_pose(P, 0) + i];
-    __syncthreads();
-    if (t < K) gauge_frame(rot, p0, x0 + xo_pose(P, 0), x + xo_pose(P, t), x + xo_sb(P, t));
-    else if (t == K) gauge_ex(x + xo_ex(P));
-    __syncthreads();
-    for (int i = t; i < 16 * K + 8; i += blockDim.x) P.x[1][i] = x[i];
-}
-
 extern "C" {
 
 int vil_abi_version(void) { return VIL_ABI_VERSION; }
@@ -248,11 +272,7 @@ int vil_create(const vil_device_cfg* cfg, vil_ctx** out) {
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc(&c->d_status, sizeof(int)));
     HIPCHK(hipHostMalloc(&c->h_ctl, sizeof(Ctl), hipHostMallocDefault));
-    if (!getenv("VIL_NO_POLL") && hipHostMalloc((void**)&c->h_mirror, sizeof(Ctl) + 64, hipHostMallocMapped) == hipSuccess) {
-        memset(c->h_mirror, 0, sizeof(Ctl) + 64);
-        void* dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, c->h_mirror, 0) == hipSuccess) { c->d_hctl = (Ctl*)dp; c->d_hseq = (int*)((char*)dp + sizeof(Ctl)); }
-    }
+    c->no_poll = getenv("VIL_NO_POLL") != nullptr;
     memset(&c->P, 0, sizeof c->P);
     *out = c;
     return VIL_OK;
@@ -281,11 +301,13 @@ void vil_destroy(vil_ctx* c) {
     if (c->d_lstage) hipFree(c->d_lstage);
     if (c->h_lstage) hipHostFree(c->h_lstage);
     if (c->lpush_ev) hipEventDestroy(c->lpush_ev);
+    { auto& w = c->win; hipFree(w.d_store); hipFree(w.d_samp); hipFree(w.d_hdr); hipFree(w.d_rec); hipFree(w.d_U); hipFree(w.d_prior[0]); hipFree(w.d_prior[1]); hipFree(w.d_wstat); hipFree(w.d_stage);
+      if (w.h_stage) hipHostFree(w.h_stage); if (w.ev) hipEventDestroy(w.ev); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
-static int validate(const vil_problem* p, const vil_state* s, bool device_lidar = false) {
+static int validate(const vil_problem* p, const vil_state* s, bool device_lidar = false, bool win = false) {
     if (!p || !s) return VIL_ERR_INVALID_ARGUMENT;
     if (p->K < 1 || p->L < 0 || s->K != p->K || s->L != p->L) return VIL_ERR_INVALID_ARGUMENT;
     if (!s->pose || !s->speedbias || !s->ex_pose || !s->td || (p->L > 0 && !s->inv_depth)) return VIL_ERR_INVALID_ARGUMENT;
@@ -297,7 +319,7 @@ static int validate(const vil_problem* p, const vil_state* s, bool device_lidar 
     if (p->prior.n > 512 || p->prior.nblk > 256) return VIL_ERR_UNSUPPORTED;
     // a table may be NULL only when its count is zero
     if (p->n_vis > 0 && (!p->vis_i || !p->vis_j || !p->vis_l || !p->vis_const)) return VIL_ERR_INVALID_ARGUMENT;
-    if (p->n_imu > 0 && (!p->imu_i || !p->imu_j || !p->imu_const)) return VIL_ERR_INVALID_ARGUMENT;
+    if (p->n_imu > 0 && (!p->imu_i || !p->imu_j || (!p->imu_const && !win))) return VIL_ERR_INVALID_ARGUMENT;
     if (p->n_icp > 0 && (!p->icp_ids || !p->icp_const)) return VIL_ERR_INVALID_ARGUMENT;
     if (p->n_lps > 0 && (!p->lps_ids || !p->lps_const)) return VIL_ERR_INVALID_ARGUMENT;
     if (!device_lidar && p->n_plane > 0 && (!p->plane_pose || !p->plane_const)) return VIL_ERR_INVALID_ARGUMENT;
@@ -317,7 +339,7 @@ static int validate(const vil_problem* p, const vil_state* s, bool device_lidar 
     for (int q = 0; q < 2 * p->n_lps; ++q) if (p->lps_ids[q] < 0 || p->lps_ids[q] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
     if (p->prior.n > 0) {
         const vil_prior& pr = p->prior;
-        if (pr.nblk <= 0 || !pr.blk_kind || !pr.blk_index || !pr.blk_col || !pr.x0 || !pr.J0 || !pr.r0) return VIL_ERR_INVALID_ARGUMENT;
+        if (pr.nblk <= 0 || !pr.blk_kind || !pr.blk_index || !pr.blk_col || (!win && (!pr.x0 || !pr.J0 || !pr.r0))) return VIL_ERR_INVALID_ARGUMENT;
         for (int b = 0; b < pr.nblk; ++b) {
             const int kind = pr.blk_kind[b], idx = pr.blk_index[b];
             if (kind < VIL_BLK_POSE || kind > VIL_BLK_TD) return VIL_ERR_INVALID_ARGUMENT;
@@ -351,14 +373,34 @@ static void lidar_chunks(const std::vector<int>& cnt, int K, std::vector<int>& c
 }
 
 // gp / vis_f0 (sharded): the whole window's problem and the index of this rank's first visual factor in it
-static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, bool sharded, const vil_device_lidar* dl = nullptr, const vil_problem* gp = nullptr, int vis_f0 = 0) {
+// Resident sources of the big tables (vil_win_solve, vil_window.hpp): the visual factor tables are expanded on the device from the landmark
+// list + observation store, IMU records / sqrt-information come from the IMU slots, the prior is the device prior slot.  The vil_problem
+// handed to upload_impl then carries n_vis = 0, imu_const = NULL and the prior's block tables only.
+struct WinSrc {
+    const int* lm_track; const int* lm_startf; const int* lm_nobs;      // host, L each
+    int n_vis, T;
+    const double* d_store; const int* fslot; const int* islot;          // slots of the window frames (host, K each)
+    const double* d_rec; const double* d_U; const double* sum_dt;       // IMU slots (device) and the intervals' durations (host, per physical slot)
+    const double* pJ0; const double* pr0; const double* px0; double* pH; double* pg0; double* pc0;     // device prior slot (prior.n > 0)
+};
+
+// check_setup: wait for k_setup's verdict (an IMU covariance that is not positive definite) and return it; false: nothing is waited for --
+// the first step kernel of the solve ends it with that status (DevP::setup_stat), and the launches of the solve queue up behind the upload
+static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, bool sharded, const vil_device_lidar* dl = nullptr, const vil_problem* gp = nullptr, int vis_f0 = 0, bool check_setup = true, const WinSrc* ws = nullptr) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
-    int st = validate(p, s, dl != nullptr);
+    int st = validate(p, s, dl != nullptr, ws != nullptr);
     if (st != VIL_OK) return st;                 // an invalid problem leaves the resident one untouched
     c->uploaded = false;                         // from here on the arena is rewritten: resident only again after a complete upload
     c->resident_kind = 0;
     HIPCHK(hipSetDevice(c->device));
     const int K = p->K, L = p->L, D = 15 * K + 7, NV = 6 * K + 7, NS = 16 * K + 8 + L;
+#ifdef VIL_TUNING
+    static const bool up_trace = getenv("VIL_UPLOAD_TRACE") != nullptr;
+    auto up_t0 = std::chrono::steady_clock::now();
+    #define UPTICK(name) do { if (up_trace) { const auto t_ = std::chrono::steady_clock::now(); fprintf(stderr, "[upload] %-10s %7.1f us\n", name, std::chrono::duration<double, std::micro>(t_ - up_t0).count()); up_t0 = t_; } } while (0)
+#else
+    #define UPTICK(name) do {} while (0)
+#endif
     Arena& ar = c->ar;
     if (c->up_pending) { HIPCHK(hipEventSynchronize(c->up_ev)); c->up_pending = false; }
     ar.reset();
@@ -396,27 +438,44 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     memcpy(&x[16 * K], s->ex_pose, sizeof(double) * 7); x[16 * K + 7] = s->td[0];
     if (L) memcpy(&x[16 * K + 8], s->inv_depth, sizeof(double) * L);
     put(x.data(), sizeof(double) * NS, (void**)&P.x[0]);
-    put(x.data(), sizeof(double) * NS, (void**)&P.x[1]);
-    put(x.data(), sizeof(double) * NS, (void**)&c->d_x0);
+    if (ws) { put(nullptr, sizeof(double) * NS, (void**)&P.x[1]); put(nullptr, sizeof(double) * NS, (void**)&c->d_x0); }      // (k_win_pack copies them on the device)
+    else { put(x.data(), sizeof(double) * NS, (void**)&P.x[1]); put(x.data(), sizeof(double) * NS, (void**)&c->d_x0); }
+    UPTICK("head");
     // visual
-    P.n_vis = p->n_vis; P.vis_stride = (p->n_vis + 31) & ~31;
+    const int n_vis = ws ? ws->n_vis : p->n_vis;
+    P.n_vis = n_vis; P.vis_stride = (n_vis + 31) & ~31;
+    int* wd_track = nullptr; int* wd_startf = nullptr;       // device copies of the landmark table (resident window)
     {
-        if (double* soa = (double*)reserve(8 * (size_t)14 * std::max(P.vis_stride, 1), (void**)&P.vis_c)) {
-            for (int q = 0; q < 14; ++q) {
-                double* row = soa + (size_t)q * P.vis_stride;
-                for (int f = 0; f < p->n_vis; ++f) row[f] = p->vis_const[(size_t)f * 14 + q];
-                for (int f = p->n_vis; f < P.vis_stride; ++f) row[f] = 0.0;
-            }
-        }
-        put(p->vis_i, 4 * (size_t)p->n_vis, (void**)&P.vis_i); put(p->vis_j, 4 * (size_t)p->n_vis, (void**)&P.vis_j); put(p->vis_l, 4 * (size_t)p->n_vis, (void**)&P.vis_l);
         std::vector<int> lms(L + 1, 0);
-        for (int f = 0; f < p->n_vis; ++f) lms[p->vis_l[f] + 1]++;
-        for (int l = 0; l < L; ++l) lms[l + 1] += lms[l];
+        if (ws) {
+            // resident window: the factor tables are device work space, k_win_pack fills them from the observation store
+            put(nullptr, 8 * (size_t)14 * std::max(P.vis_stride, 1), (void**)&P.vis_c);
+            put(nullptr, 4 * (size_t)std::max(n_vis, 1), (void**)&P.vis_i); put(nullptr, 4 * (size_t)std::max(n_vis, 1), (void**)&P.vis_j); put(nullptr, 4 * (size_t)std::max(n_vis, 1), (void**)&P.vis_l);
+            for (int l = 0; l < L; ++l) lms[l + 1] = lms[l] + ws->lm_nobs[l] - 1;
+            put(ws->lm_track, 4 * (size_t)std::max(L, 1), (void**)&wd_track); put(ws->lm_startf, 4 * (size_t)std::max(L, 1), (void**)&wd_startf);
+        } else {
+            if (double* soa = (double*)reserve(8 * (size_t)14 * std::max(P.vis_stride, 1), (void**)&P.vis_c)) {
+                for (int q = 0; q < 14; ++q) {
+                    double* row = soa + (size_t)q * P.vis_stride;
+                    for (int f = 0; f < p->n_vis; ++f) row[f] = p->vis_const[(size_t)f * 14 + q];
+                    for (int f = p->n_vis; f < P.vis_stride; ++f) row[f] = 0.0;
+                }
+            }
+            put(p->vis_i, 4 * (size_t)p->n_vis, (void**)&P.vis_i); put(p->vis_j, 4 * (size_t)p->n_vis, (void**)&P.vis_j); put(p->vis_l, 4 * (size_t)p->n_vis, (void**)&P.vis_l);
+            for (int f = 0; f < p->n_vis; ++f) lms[p->vis_l[f] + 1]++;
+            for (int l = 0; l < L; ++l) lms[l + 1] += lms[l];
+        }
         put(lms.data(), 4 * (size_t)(L + 1), (void**)&P.lm_start);
         {
-            std::vector<int> acol(std::max(L, 1), -1), fcol(std::max(p->n_vis, 1), 0);
-            for (int f = p->n_vis - 1; f >= 0; --f) { acol[p->vis_l[f]] = 6 * p->vis_i[f]; fcol[f] = 6 * p->vis_j[f]; }
-            put(acol.data(), 4 * acol.size(), (void**)&P.lm_acol); put(fcol.data(), 4 * fcol.size(), (void**)&P.fcol);
+            std::vector<int> acol(std::max(L, 1), -1);
+            if (ws) {
+                for (int l = 0; l < L; ++l) acol[l] = 6 * ws->lm_startf[l];
+                put(acol.data(), 4 * acol.size(), (void**)&P.lm_acol); put(nullptr, 4 * (size_t)std::max(n_vis, 1), (void**)&P.fcol);
+            } else {
+                std::vector<int> fcol(std::max(p->n_vis, 1), 0);
+                for (int f = p->n_vis - 1; f >= 0; --f) { acol[p->vis_l[f]] = 6 * p->vis_i[f]; fcol[f] = 6 * p->vis_j[f]; }
+                put(acol.data(), 4 * acol.size(), (void**)&P.lm_acol); put(fcol.data(), 4 * fcol.size(), (void**)&P.fcol);
+            }
         }
         P.vis_f0 = 0;
         if (gp) {                                        // tables of the whole window for the step kernel (every rank walks every landmark)
@@ -454,6 +513,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         P.NVT = NV * (NV + 1) / 2; P.VP = P.NVT + 3 * NV + 1;
         put(nullptr, 8 * (size_t)std::max(P.n_vwg, 1) * P.VP, (void**)&P.vpart);
     }
+    UPTICK("visual");
     // LiDAR
     {
         std::vector<int> ch;
@@ -508,9 +568,11 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         put(nullptr, 8 * (size_t)28 * std::max(P.n_pchunk + P.n_echunk, 1), (void**)&P.lpart);
         put(lcp.data(), 4 * lcp.size(), (void**)&P.lchunk_pose);
     }
+    UPTICK("lidar");
     // IMU
     P.n_imu = p->n_imu;
-    put(p->imu_const, 8 * (size_t)287 * p->n_imu, (void**)&P.imu_c);
+    if (ws) put(nullptr, 8 * (size_t)287 * std::max(p->n_imu, 1), (void**)&P.imu_c);      // gathered from the IMU slots by k_win_pack, like U
+    else put(p->imu_const, 8 * (size_t)287 * p->n_imu, (void**)&P.imu_c);
     put(nullptr, 8 * (size_t)225 * std::max(p->n_imu, 1), (void**)&P.imu_U);
     put(p->imu_i, 4 * (size_t)p->n_imu, (void**)&P.imu_i); put(p->imu_j, 4 * (size_t)p->n_imu, (void**)&P.imu_j);
     put(nullptr, 8 * (size_t)931 * std::max(p->n_imu, 1), (void**)&P.ipart);
@@ -539,8 +601,10 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         put(pr.blk_col, 4 * (size_t)pr.nblk, (void**)&P.pblk_col); put(xoff.data(), 4 * (size_t)pr.nblk, (void**)&P.pblk_xoff);
         put(pmap.data(), 4 * (size_t)n, (void**)&P.pmap);
         for (int q = 0; q < n; ++q) if (pmap[q] >= 0) pinv[pmap[q]] = q;
-        put(pr.x0, 8 * (size_t)xo, (void**)&P.px0); put(pr.J0, 8 * (size_t)n * n, (void**)&P.pJ0); put(pr.r0, 8 * (size_t)n, (void**)&P.pr0);
-        put(nullptr, 8 * (size_t)n * n, (void**)&P.pH); put(nullptr, 8 * (size_t)n, (void**)&P.pg0); put(nullptr, 8, (void**)&P.pc0);
+        if (!ws) {
+            put(pr.x0, 8 * (size_t)xo, (void**)&P.px0); put(pr.J0, 8 * (size_t)n * n, (void**)&P.pJ0); put(pr.r0, 8 * (size_t)n, (void**)&P.pr0);
+            put(nullptr, 8 * (size_t)n * n, (void**)&P.pH); put(nullptr, 8 * (size_t)n, (void**)&P.pg0); put(nullptr, 8, (void**)&P.pc0);
+        }
     }
     put(pinv.data(), 4 * (size_t)D, (void**)&P.pinv);
     put(nullptr, 8 * (size_t)((P.pn ? P.pn + 1 : 0) + 601 * (p->n_icp + p->n_lps) + 1), (void**)&P.mpart);
@@ -548,9 +612,10 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     P.n_icp = p->n_icp; P.n_lps = p->n_lps;
     put(p->icp_ids, 16 * (size_t)p->n_icp, (void**)&P.icp_ids); put(p->icp_const, 80 * (size_t)p->n_icp, (void**)&P.icp_c);
     put(p->lps_ids, 8 * (size_t)p->n_lps, (void**)&P.lps_ids); put(p->lps_const, 56 * (size_t)p->n_lps, (void**)&P.lps_c);
+    UPTICK("imu+prior");
     // systems + work space (zero-initialised)
     // one contiguous block per set: [S | gred | bc | diag | cost | 2 spare | hll | bl | invp | sl | eA | eO]
-    const size_t Lp = (size_t)std::max(L, 1), Fp = (size_t)std::max(gp ? gp->n_vis : p->n_vis, 1);
+    const size_t Lp = (size_t)std::max(L, 1), Fp = (size_t)std::max(gp ? gp->n_vis : n_vis, 1);
     const size_t ar_cam = ((size_t)D * D + 3 * (size_t)D + 3 + 1) & ~size_t(1);
     c->span = ar_cam + 4 * Lp + 13 * Lp + 6 * Fp;
     for (int q = 0; q < 2; ++q) put(nullptr, 8 * c->span, (void**)&P.sys[q].ar);
@@ -581,6 +646,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) cus = 0;
         if (1 + P.n_help > cus / 2) P.n_help = 0;
     }
+    UPTICK("workspace");
     // device allocation + single H2D copy
     if (oom) return VIL_ERR_DEVICE;
     const size_t tables = (ar.hsize + 255) & ~size_t(255), total = tables + ((ar.ssize + 255) & ~size_t(255));
@@ -589,14 +655,20 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     if (dl) { P.pl_c = dl->plane_soa; P.pl_stride = dl->plane_stride; P.ed_c = dl->edge_soa; P.ed_stride = dl->edge_stride; }
     if (!gp) { P.glm_start = P.lm_start; P.glm_acol = P.lm_acol; P.gfcol = P.fcol; }
     if (c->lidar_resident) { P.pl_c = c->d_pl; P.pl_stride = c->nslot * c->cap_p; P.ed_c = c->d_ed; P.ed_stride = c->nslot * c->cap_e; }
+    if (ws && P.pn) { P.px0 = ws->px0; P.pJ0 = ws->pJ0; P.pr0 = ws->pr0; P.pH = ws->pH; P.pg0 = ws->pg0; P.pc0 = ws->pc0; }      // the device prior slot, contractions included
     {   // what vil_marginalize_resident will need (a few passes over int tables)
         vil_ctx::MargMeta& mm = c->mm;
         mm.has_prior = p->prior.n > 0; mm.prior_kind.clear(); mm.prior_index.clear();
         if (mm.has_prior) { mm.prior_kind.assign(p->prior.blk_kind, p->prior.blk_kind + p->prior.nblk); mm.prior_index.assign(p->prior.blk_index, p->prior.blk_index + p->prior.nblk); }
         mm.obs0.assign(K, 0); mm.n_lm0 = 0; mm.imu01 = false; mm.use_td = p->use_td != 0;
-        int last_l = -1;
-        for (int f = 0; f < p->n_vis; ++f) if (p->vis_i[f] == 0) { mm.obs0[p->vis_j[f]] = 1; if (p->vis_l[f] != last_l) { ++mm.n_lm0; last_l = p->vis_l[f]; } }
-        for (int f = 0; f < p->n_imu; ++f) if (p->imu_i[f] == 0 && p->imu_j[f] == 1 && p->imu_const[(size_t)f * 287 + 16] < 10.0) mm.imu01 = true;
+        if (ws) {
+            for (int l = 0; l < L; ++l) if (ws->lm_startf[l] == 0) { ++mm.n_lm0; for (int q = 1; q < ws->lm_nobs[l]; ++q) mm.obs0[q] = 1; }
+            for (int f = 0; f < p->n_imu; ++f) if (p->imu_i[f] == 0 && p->imu_j[f] == 1 && ws->sum_dt[ws->islot[1]] < 10.0) mm.imu01 = true;
+        } else {
+            int last_l = -1;
+            for (int f = 0; f < p->n_vis; ++f) if (p->vis_i[f] == 0) { mm.obs0[p->vis_j[f]] = 1; if (p->vis_l[f] != last_l) { ++mm.n_lm0; last_l = p->vis_l[f]; } }
+            for (int f = 0; f < p->n_imu; ++f) if (p->imu_i[f] == 0 && p->imu_j[f] == 1 && p->imu_const[(size_t)f * 287 + 16] < 10.0) mm.imu01 = true;
+        }
         mm.icp_ids.assign(p->icp_ids, p->icp_ids + 4 * (size_t)p->n_icp); mm.lps_ids.assign(p->lps_ids, p->lps_ids + 2 * (size_t)p->n_lps);
         if (!c->lidar_resident && !dl) {
             for (int f = 0; f < p->n_plane && !mm.lidar0; ++f) if (p->plane_pose[f] == 0) mm.lidar0 = true;
@@ -615,12 +687,15 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     }
     if (ar.ssize) HIPCHK(hipMemsetAsync(ar.d + tables, 0, ar.ssize, c->stream));
     c->P = P; c->K = K; c->L = L; c->D = D; c->NS = NS;
-    c->P.hctl = c->d_hctl; c->P.hseq = c->d_hseq;
+    c->mirror_state = false;
+    if (!c->no_poll) { const int ms = ensure_mirror(c, (size_t)NS); if (ms != VIL_OK) return ms; }
+    c->P.hctl = c->d_hctl; c->P.hseq = c->d_hseq; c->P.hstate = c->d_hstate;
+    c->P.xorig = c->d_x0; c->P.gauge_on = c->gauge_on ? 1 : 0; c->P.setup_stat = c->d_status;
     { const int per = VIL_SWEEP_THREADS / 256; c->n_blocks_sweep = P.n_imu + P.n_vwg + (P.n_pchunk + per - 1) / per + (P.n_echunk + per - 1) / per + 2; }
     c->lds_sweep = sizeof(double) * (size_t)(P.NVT + 3 * NV + VIL_VCHUNK_F * VF_STRIDE + VIL_VCHUNK_LM * 16 + 32 + VIL_VCHUNK_F + 8 + VIL_VCHUNK_LM + 8);
     if (c->lds_sweep < 8 * 2048) c->lds_sweep = 8 * 2048;
     if (c->lds_sweep > 160 * 1024) return VIL_ERR_UNSUPPORTED;
-    HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep));
+    if ((int)c->lds_sweep > c->attr_sweep) { HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep)); c->attr_sweep = (int)c->lds_sweep; }
     c->n_blocks_reduce = (D * (D + 1) / 2 + RED_EPW - 1) / RED_EPW + (2 * D + RED_EPW - 1) / RED_EPW + 1;
     // ---- step kernel variant: the speed-bias part of the reduced matrix is a chain whenever every IMU factor couples (k, k+1)
     //      and the prior's speed-bias blocks are neighbours (VINS: exactly one) -> vil_chain.hpp; anything else: dense path
@@ -644,32 +719,49 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     if (P.chain) {
         c->step_lds = true;
         if (P.chain == 1) {
-            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+            if ((int)c->lds_step > c->attr_step[1]) { HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step)); c->attr_step[1] = (int)c->lds_step; }
         } else {
-            HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+            if ((int)c->lds_step > c->attr_step[2]) { HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step)); c->attr_step[2] = (int)c->lds_step; }
         }
     } else {
     { const size_t T = (size_t)(D + 1 + 15) / 16; c->lds_step = 8 * TILE_SZ * (T * (T + 1) / 2); }   // 16x16-tiled (row stride 17) lower storage incl. the rhs row
     c->step_lds = c->lds_step + sizeof(vd::StepShared) + 256 <= 160 * 1024;
     if (c->step_lds) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+        if ((int)c->lds_step > c->attr_step[0]) { HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step)); c->attr_step[0] = (int)c->lds_step; }
     } else {
         // tile array in global memory; LDS stages the active tile column of the factorisation (T tiles)
         const size_t T = (size_t)(D + 1 + 15) / 16;
         c->lds_step = 8 * (size_t)TILE_SZ * T;
         if (c->lds_step + sizeof(vd::StepShared) + 256 > 160 * 1024) return VIL_ERR_UNSUPPORTED;
-        HIPCHK(hipFuncSetAttribute((const void*)k_step<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step));
+        if ((int)c->lds_step > c->attr_step[3]) { HIPCHK(hipFuncSetAttribute((const void*)k_step<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step)); c->attr_step[3] = (int)c->lds_step; }
     }
     }
+    UPTICK("h2d+attrs");
     // one-time set-up: IMU sqrt-information, prior contraction
     HIPCHK(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
-    const int nb_setup = P.n_imu + (P.pn ? 64 : 0);
+    if (ws) {
+        // resident window: expand the landmark table into the factor tables, gather the IMU records, copy the state -- everything k_setup
+        // would compute (sqrt-information, prior contractions) already sits next to its source
+        WinPack W; memset(&W, 0, sizeof W);
+        W.L = L; W.F = n_vis; W.stride = P.vis_stride; W.T = ws->T;
+        W.lm_start = P.lm_start; W.lm_track = wd_track; W.lm_startf = wd_startf; W.store = ws->d_store;
+        for (int k = 0; k < K; ++k) { W.fslot[k] = ws->fslot[k]; W.islot[k] = ws->islot[k]; }
+        W.vis_c = const_cast<double*>(P.vis_c); W.vis_i = const_cast<int*>(P.vis_i); W.vis_j = const_cast<int*>(P.vis_j); W.vis_l = const_cast<int*>(P.vis_l); W.fcol = const_cast<int*>(P.fcol);
+        W.n_imu = P.n_imu; W.rec = ws->d_rec; W.U = ws->d_U; W.imu_c = const_cast<double*>(P.imu_c); W.imu_U = const_cast<double*>(P.imu_U);
+        W.NS = NS; W.x0 = P.x[0]; W.x1 = P.x[1]; W.xorig = c->d_x0;
+        const int nbf = (n_vis + 255) / 256, nbs = (NS + 255) / 256;
+        hipLaunchKernelGGL(k_win_pack, dim3(nbf + P.n_imu + nbs), dim3(256), 0, c->stream, W, nbf);
+    }
+    const int nb_setup = ws ? 0 : P.n_imu + (P.pn ? 64 : 0);
     if (nb_setup > 0) hipLaunchKernelGGL(k_setup, dim3(nb_setup), dim3(VIL_THREADS), 0, c->stream, P, const_cast<double*>(P.imu_U), c->d_status);
-    int hstat = 0;
-    HIPCHK(hipMemcpyAsync(&hstat, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipGetLastError());
-    if (hstat != 0) return VIL_ERR_NOT_POSITIVE_DEFINITE;
+    if (check_setup) {
+        int hstat = 0;
+        HIPCHK(hipMemcpyAsync(&hstat, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipGetLastError());
+        if (hstat != 0) return VIL_ERR_NOT_POSITIVE_DEFINITE;
+    }
+    UPTICK("setup");
     c->uploaded = true; c->resident_kind = 2;    // vil_upload / vil_solve promote it to 1
     return VIL_OK;
 }
@@ -696,13 +788,14 @@ static int upload_sharded(vil_ctx* c, const vil_problem* p, const vil_state* s) 
     return st;
 }
 
-int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) {
+static int upload_window(vil_ctx* c, const vil_problem* p, const vil_state* s, bool check_setup) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
     const int st = (c->world > 1 && (c->comm || c->lcomm)) ? upload_sharded(c, p, s)      // a world > 1 context without a communicator works un-sharded
-                                                           : upload_impl(c, p, s, false);
+                                                           : upload_impl(c, p, s, false, nullptr, nullptr, 0, check_setup);
     if (st == VIL_OK) c->resident_kind = 1;
     return st;
 }
+int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) { return upload_window(c, p, s, true); }
 
 // sum over the ranks of the communicator, in stream order: recv = sum of every rank's send (recv may be send)
 static int all_reduce2(vil_ctx* c, const double* send, double* recv, size_t cnt) {
@@ -829,6 +922,7 @@ int vil_reset_state(vil_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->P.x[0], c->d_x0, 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->P.x[1], c->d_x0, 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
+    c->mirror_state = false;
     return VIL_OK;
 }
 
@@ -838,9 +932,16 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     HIPCHK(hipSetDevice(c->device));
     const auto t0 = std::chrono::steady_clock::now();
     const SolveOpts so = to_dev_opts(o);
+    c->mirror_state = false;
+    if ((c->P.gauge_on != 0) != c->gauge_on) {            // vil_set_gauge_fix since the upload: the captured graphs carry the old flag
+        c->P.gauge_on = c->gauge_on ? 1 : 0;
+        for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
+        c->graphs.clear();
+    }
     int st = init_ctl(c, o, 0);
     if (st != VIL_OK) return st;
-    // every iteration = one sweep + one step kernel; `done` turns the tail into no-ops
+    // every iteration = sweep + gather + step kernel; `done` turns the tail of a chunk into no-ops, and the first sweep launch that finds
+    // the solve finished writes the result out (vil_finish.hpp); k_finish at the end of every chunk covers a solve that ends in its last iteration
     bool finished = false, polled_done = false;
     // iterations are enqueued in chunks without host round trips; the first chunk is sized by the previous solve of
     // this context (consecutive windows of a tracker need similar iteration counts), later chunks are short
@@ -859,6 +960,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
                 hipGraph_t graph = nullptr;
                 HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
                 for (int q = 0; q < nthis; ++q) { launch_sweep(c, so); launch_reduce_step(c, so, true, nullptr); }
+                hipLaunchKernelGGL(k_finish, dim3(1), dim3(VIL_SWEEP_THREADS), 0, c->stream, view(c, 0), -1);
                 HIPCHK(hipStreamEndCapture(c->stream, &graph));
                 HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
                 hipGraphDestroy(graph);
@@ -866,17 +968,19 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
             }
             HIPCHK(hipGraphLaunch(exec, c->stream));
             it += nthis; launched = nthis;
-        } else
-        for (int q = 0; q < chunk && it <= o->max_iterations + 8; ++q, ++it, ++launched) {
-            if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q], c->stream));
-            launch_sweep(c, so);
-            if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q + 1], c->stream));
-            st = launch_reduce_step(c, so, true, c->profiling ? c->ev_mid[q] : nullptr);
-            if (st != VIL_OK) return st;          // a failed collective fails on every rank (all_reduce): nobody is left waiting
+        } else {
+            for (int q = 0; q < chunk && it <= o->max_iterations + 8; ++q, ++it, ++launched) {
+                if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q], c->stream));
+                launch_sweep(c, so);
+                if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q + 1], c->stream));
+                st = launch_reduce_step(c, so, true, c->profiling ? c->ev_mid[q] : nullptr);
+                if (st != VIL_OK) return st;          // a failed collective fails on every rank (all_reduce): nobody is left waiting
+            }
+            if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * launched], c->stream));
+            hipLaunchKernelGGL(k_finish, dim3(1), dim3(VIL_SWEEP_THREADS), 0, c->stream, view(c, 0), -1);      // the write-out of a solve that ended in the chunk's last iteration
         }
-        if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * launched], c->stream));
-        // The step kernel that finishes the solve leaves Ctl + the solve generation in pinned host memory: poll that word instead of
-        // synchronising (a few microseconds earlier, and the no-op tail of the chunk is not waited for).  A chunk that runs out without
+        // solve_finish leaves Ctl, the final state and then the solve generation in pinned host memory: poll that word instead of
+        // synchronising (the no-op tail of the chunk is not waited for, nothing is copied afterwards).  A chunk that runs out without
         // finishing is seen by hipStreamQuery and takes the copy + synchronise route, as do profiling and multi-rank solves.
         bool polled = false;
         if (c->d_hseq && !c->profiling && !c->split) {
@@ -910,7 +1014,11 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
             }
         }
         if (!finished && o->max_time_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= o->max_time_s) {
-            c->h_ctl->done = 1; c->h_ctl->term = VIL_TERM_MAX_TIME; finished = true;   // ceres max_solver_time_in_seconds (estimator.cpp:1411)
+            // ceres max_solver_time_in_seconds (estimator.cpp:1411): the host ends the solve; the accepted state is written out on request
+            hipLaunchKernelGGL(k_finish, dim3(1), dim3(VIL_SWEEP_THREADS), 0, c->stream, c->P, (int)VIL_TERM_MAX_TIME);
+            HIPCHK(hipMemcpyAsync(c->h_ctl, c->P.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            finished = true; polled_done = false;
         }
     }
     HIPCHK(hipGetLastError());
@@ -922,14 +1030,10 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     sum->initial_cost = ctl.initial_cost; sum->final_cost = ctl.cost_cur;
     for (int i = 0; i < VIL_MAX_TRACE; ++i) { sum->cost_trace[i] = ctl.cost_trace[i]; sum->radius_trace[i] = ctl.radius_trace[i]; }
     sum->t_solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    // the accepted state is x[cur]; keep x[0] as "the" resident state
-    if (ctl.cur != 0) HIPCHK(hipMemcpyAsync(c->P.x[0], c->P.x[1], 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
-    else HIPCHK(hipMemcpyAsync(c->P.x[1], c->P.x[0], 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
-    if (c->gauge_on && finished && c->h_ctl->status == 0) hipLaunchKernelGGL(k_gauge_fix, dim3(1), dim3(64), 0, c->stream, c->P, c->d_x0);      // estimator.cpp:960-1011 before the read-back
-    // (whoever reads the state back -- vil_download_state, vil_marginalize_resident -- orders itself behind these on the stream and
-    //  synchronises for its own copy; a solve whose end was polled does not wait for its no-op tail here)
-    if (!polled_done) HIPCHK(hipStreamSynchronize(c->stream));
+    // (the accepted state is x[0] = x[1] on the device, gauge-fixed when asked for: solve_finish ran in stream order; whoever reads the
+    //  window afterwards orders itself behind it on the stream)
     if (!finished) return VIL_ERR_DEVICE;
+    c->mirror_state = polled_done && c->d_hstate != nullptr;
     if (ctl.status != 0) return ctl.status;
     if (!std::isfinite(ctl.cost_cur)) return VIL_ERR_NON_FINITE;
     return VIL_OK;
@@ -938,10 +1042,16 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
 int vil_download_state(vil_ctx* c, vil_state* s) {
     if (!c || !s || !c->uploaded || s->K != c->K || s->L != c->L) return VIL_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(c->device));
-    std::vector<double> x(c->NS);
-    HIPCHK(hipMemcpyAsync(x.data(), c->P.x[0], 8 * (size_t)c->NS, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (double v : x) if (!std::isfinite(v)) return VIL_ERR_NON_FINITE;
+    const double* x = nullptr;
+    std::vector<double> xb;
+    if (c->mirror_state) x = (const double*)(c->h_mirror + sizeof(Ctl) + 64);      // left there by solve_finish: no device operation
+    else {
+        xb.resize(c->NS);
+        HIPCHK(hipMemcpyAsync(xb.data(), c->P.x[0], 8 * (size_t)c->NS, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        x = xb.data();
+    }
+    for (int i = 0; i < c->NS; ++i) if (!std::isfinite(x[i])) return VIL_ERR_NON_FINITE;
     const int K = c->K, L = c->L;
     memcpy(s->pose, &x[0], 8 * (size_t)7 * K); memcpy(s->speedbias, &x[7 * K], 8 * (size_t)9 * K);
     memcpy(s->ex_pose, &x[16 * K], 56); s->td[0] = x[16 * K + 7];
@@ -952,7 +1062,7 @@ int vil_download_state(vil_ctx* c, vil_state* s) {
 int vil_solve(vil_ctx* c, const vil_problem* p, vil_state* s, const vil_options* o, vil_summary* sum) {
     if (!c || !p || !s || !o || !sum) return VIL_ERR_INVALID_ARGUMENT;
     const auto t0 = std::chrono::steady_clock::now();
-    int st = vil_upload(c, p, s);
+    int st = upload_window(c, p, s, false);            // nothing is waited for: the solve's launches queue up behind the upload
     if (st != VIL_OK) return st;
     const auto t1 = std::chrono::steady_clock::now();
     st = vil_solve_resident(c, o, sum);
@@ -1101,7 +1211,8 @@ int vil_linearize(vil_ctx* c, const vil_problem* p, const vil_state* s, const vi
 // all-reduce staging buffer); Schur complement + square root on the device (k_marg), block metadata with the address shift as an
 // index remap (estimator.cpp:1599-1611, 1654-1677)
 static int marg_finish(vil_ctx* c, const int K, const bool old_, const int drop_pose, const std::vector<char>& pose_t, const std::vector<char>& sb_t,
-                       const bool ex_t, const bool td_t, const bool use_td, const int n_lm_elim, const vil_state* s, vil_prior_out* out) {
+                       const bool ex_t, const bool td_t, const bool use_td, const int n_lm_elim, const vil_state* s, vil_prior_out* out,
+                       const bool to_slot = false, vil_win_prior_info* winfo = nullptr) {
     int st = VIL_OK;
     // ---- which reduced columns are dropped / kept (canonical kept order: poses, speed-biases, ex, td) ----------------
     const int D = c->D;
@@ -1139,26 +1250,57 @@ static int marg_finish(vil_ctx* c, const int K, const bool old_, const int drop_
     M.J0 = (double*)take(8 * (2 * nn + 2 * (size_t)n)); M.A = M.J0 + nn; M.r0 = M.A + nn; M.b = M.r0 + n;      // what goes back to the host: one block, one copy
     M.stat = (int*)take(32);
     if (off > bytes) return VIL_ERR_DEVICE;
-    std::vector<int> cols(drop_cols.begin(), drop_cols.end()); cols.insert(cols.end(), keep_cols.begin(), keep_cols.end());      // (alive until the stream has been synchronised below)
-    HIPCHK(hipMemcpyAsync(d_drop, cols.data(), 4 * cols.size(), hipMemcpyHostToDevice, c->stream));
+    // the column table travels through pinned memory: the copy is asynchronous and the resident window never waits for it (the next use
+    // of this staging area is a whole solve away)
+    st = ensure_pin(c, 8 * (nn * 2 + 2 * (size_t)n + 16 * (size_t)K + 8) + 4 * (size_t)(nd + n) + 64);
+    if (st != VIL_OK) return st;
+    int* hcols = (int*)((char*)c->h_pin + 8 * (nn * 2 + 2 * (size_t)n + 16 * (size_t)K + 8));
+    for (int q = 0; q < nd; ++q) hcols[q] = drop_cols[q];
+    for (int q = 0; q < n; ++q) hcols[nd + q] = keep_cols[q];
+    HIPCHK(hipMemcpyAsync(d_drop, hcols, 4 * (size_t)(nd + n), hipMemcpyHostToDevice, c->stream));
     {
         const size_t a_bytes = 8 * nn, cap = 156 * 1024;
         if (a_bytes > cap) return VIL_ERR_UNSUPPORTED;
         const size_t dyn = std::max<size_t>(4096, a_bytes);
-        if (dyn > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        if (dyn > 48 * 1024 && (int)dyn > c->attr_marg[0]) { HIPCHK(hipFuncSetAttribute((const void*)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn)); c->attr_marg[0] = (int)dyn; }
         hipLaunchKernelGGL(k_marg, dim3(1), dim3(MARG_THREADS), dyn, c->stream, M, 0);
         if (!VIL_TUNE_ENV("VIL_MARG_PIVOTED")) {               // un-pivoted factorisation on the matrix cores first; pivoted fallback below
             const size_t Tm = (size_t)(n + 1 + 15) / 16, tb = 8 * (size_t)TILE_SZ * (Tm * (Tm + 1) / 2);
             if (tb + sizeof(vd::StepShared) + 512 <= 160 * 1024) {
-                if (tb > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_marg_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb));
+                if (tb > 48 * 1024 && (int)tb > c->attr_marg[1]) { HIPCHK(hipFuncSetAttribute((const void*)k_marg_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb)); c->attr_marg[1] = (int)tb; }
                 hipLaunchKernelGGL(k_marg_fast, dim3(1), dim3(VIL_STEP_THREADS), tb, c->stream, M);
             }
         }
         hipLaunchKernelGGL(k_marg, dim3(1), dim3(MARG_THREADS), dyn, c->stream, M, 1);
     }
+    if (to_slot) {
+        // resident window: the new prior goes device-to-device into the other prior slot (J0, r0, x0 from the device state, contractions);
+        // nothing is read back, nothing is waited for.  A non-finite result raises the window's status word.
+        auto& w = c->win;
+        if (n > w.nmax || (int)kinds.size() > VIL_WIN_MAXBLK) return VIL_ERR_UNSUPPORTED;
+        const int dst = 1 - w.cur;
+        PriorCommit pc; memset(&pc, 0, sizeof pc);
+        pc.n = n; pc.nblk = (int)kinds.size(); pc.J0 = M.J0; pc.r0 = M.r0; pc.x = c->P.x[0]; pc.K = K;
+        for (size_t b = 0; b < kinds.size(); ++b) { pc.kind[b] = kinds[b]; pc.index[b] = index[b]; }
+        pc.pJ0 = w.pJ0(dst); pc.pr0 = w.pr0(dst); pc.px0 = w.px0(dst); pc.pH = w.pH(dst); pc.pg0 = w.pg0(dst); pc.pc0 = w.pc0(dst); pc.status = w.d_wstat;
+        hipLaunchKernelGGL(k_prior_commit, dim3(32), dim3(256), 0, c->stream, pc);
+        w.cur = dst; w.pn = n; w.pm = nd + n_lm_elim;
+        w.pkind.assign(kinds.begin(), kinds.end()); w.pindex.clear(); w.pcol.clear();
+        int col = 0;
+        for (size_t b = 0; b < kinds.size(); ++b) {
+            const int kind = kinds[b], idx = index[b];
+            int ni = idx;
+            if (kind == VIL_BLK_POSE || kind == VIL_BLK_SPEEDBIAS) ni = old_ ? idx - 1 : (idx == K - 1 ? K - 2 : idx);      // the address shift as an index remap (estimator.cpp:1599-1611, 1654-1677)
+            w.pindex.push_back(ni); w.pcol.push_back(col);
+            col += (kind == VIL_BLK_POSE || kind == VIL_BLK_EX) ? 6 : (kind == VIL_BLK_SPEEDBIAS ? 9 : 1);
+        }
+        if (winfo) {
+            winfo->n = n; winfo->nblk = (int)kinds.size(); winfo->m = w.pm;
+            for (size_t b = 0; b < kinds.size(); ++b) { winfo->blk_kind[b] = w.pkind[b]; winfo->blk_index[b] = w.pindex[b]; winfo->blk_col[b] = w.pcol[b]; }
+        }
+        return VIL_OK;
+    }
     const size_t ncam = 16 * (size_t)K + 8;
-    st = ensure_pin(c, 8 * (nn * 2 + 2 * (size_t)n + ncam));
-    if (st != VIL_OK) return st;
     HIPCHK(hipMemcpyAsync(c->h_pin, M.J0, 8 * (2 * nn + 2 * (size_t)n), hipMemcpyDeviceToHost, c->stream));      // J0 | A | r0 | b
     // x0 of the new prior = the state the factors were LINEARISED at, i.e. the device state (the reference stores the very values it
     // marginalises at, marginalization_factor.cpp:110-139) -- not whatever the caller holds
@@ -1258,65 +1400,6 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     return marg_finish(c, K, old_, drop_pose, pose_t, sb_t, ex_t, td_t, p->use_td != 0, n_lm_elim, s, out);
 }
 
-// estimator.cpp:960-1011 double2vector(): yaw + translation gauge fix.  One arithmetic for the host entry point (vil_gauge_fix)
-// and the device kernel (vil_set_gauge_fix): pose K x 7 [p q(xyzw)], speed-bias K x 9, ex 7.
-__host__ __device__ static void gauge_q2R(const double* q, double* R) {
-    const double x = q[0], y = q[1], z = q[2], w = q[3];
-    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
-    R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
-    R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
-}
-__host__ __device__ static void gauge_R2ypr(const double* R, double* ypr) {
-    const double y = atan2(R[3], R[0]);
-    const double pch = atan2(-R[6], R[0] * cos(y) + R[3] * sin(y));
-    const double rl = atan2(R[2] * sin(y) - R[5] * cos(y), -R[1] * sin(y) + R[4] * cos(y));
-    ypr[0] = y / M_PI * 180.0; ypr[1] = pch / M_PI * 180.0; ypr[2] = rl / M_PI * 180.0;
-}
-__host__ __device__ static void gauge_R2q(const double* R, double* q /*xyzw*/) {
-    double t = R[0] + R[4] + R[8];
-    if (t > 0) { t = sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t; }
-    else {
-        int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > R[4 * i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
-        q[i] = 0.5 * t; t = 0.5 / t;
-        q[3] = (R[3 * k + j] - R[3 * j + k]) * t; q[j] = (R[3 * j + i] + R[3 * i + j]) * t; q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
-    }
-}
-__host__ __device__ static void gauge_rot(const double* pose0_before, const double* pose0_now, double* rot) {
-    double R0[9], R00[9], a0[3], a00[3];
-    gauge_q2R(pose0_before + 3, R0); gauge_q2R(pose0_now + 3, R00);
-    gauge_R2ypr(R0, a0); gauge_R2ypr(R00, a00);
-    const double yd = (a0[0] - a00[0]) / 180.0 * M_PI;
-    rot[0] = cos(yd); rot[1] = -sin(yd); rot[2] = 0; rot[3] = sin(yd); rot[4] = cos(yd); rot[5] = 0; rot[6] = 0; rot[7] = 0; rot[8] = 1;
-    if (fabs(fabs(a0[1]) - 90) < 1.0 || fabs(fabs(a00[1]) - 90) < 1.0)
-        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double v = 0; for (int k = 0; k < 3; ++k) v += R0[3 * i + k] * R00[3 * j + k]; rot[3 * i + j] = v; }
-}
-__host__ __device__ static void gauge_frame(const double* rot, const double* p0, const double* pose0_before, double* pp, double* sb) {
-    {
-        double qn[4], Rf[9], Rn[9], d[3], Pn[3], V[3];
-        { const double n = sqrt(pp[3] * pp[3] + pp[4] * pp[4] + pp[5] * pp[5] + pp[6] * pp[6]); for (int i = 0; i < 4; ++i) qn[i] = pp[3 + i] / n; }
-        gauge_q2R(qn, Rf);
-        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double v = 0; for (int k = 0; k < 3; ++k) v += rot[3 * i + k] * Rf[3 * k + j]; Rn[3 * i + j] = v; }
-        for (int i = 0; i < 3; ++i) d[i] = pp[i] - p0[i];
-        for (int i = 0; i < 3; ++i) Pn[i] = rot[3 * i] * d[0] + rot[3 * i + 1] * d[1] + rot[3 * i + 2] * d[2] + pose0_before[i];
-        gauge_R2q(Rn, pp + 3); pp[0] = Pn[0]; pp[1] = Pn[1]; pp[2] = Pn[2];
-        for (int i = 0; i < 3; ++i) V[i] = rot[3 * i] * sb[0] + rot[3 * i + 1] * sb[1] + rot[3 * i + 2] * sb[2];
-        sb[0] = V[0]; sb[1] = V[1]; sb[2] = V[2];
-    }
-}
-__host__ __device__ static void gauge_ex(double* ex_pose) {
-    double qe[4], Re[9];
-    { const double n = sqrt(ex_pose[3] * ex_pose[3] + ex_pose[4] * ex_pose[4] + ex_pose[5] * ex_pose[5] + ex_pose[6] * ex_pose[6]); for (int i = 0; i < 4; ++i) qe[i] = ex_pose[3 + i] / n; }
-    gauge_q2R(qe, Re); gauge_R2q(Re, ex_pose + 3);
-}
-__host__ __device__ static void gauge_fix_core(const double* pose0_before, int K, double* pose, double* speedbias, double* ex_pose) {
-    double rot[9];
-    gauge_rot(pose0_before, pose, rot);
-    const double p0[3] = {pose[0], pose[1], pose[2]};
-    for (int f = 0; f < K; ++f) gauge_frame(rot, p0, pose0_before, pose + 7 * f, speedbias + 9 * f);
-    gauge_ex(ex_pose);
-}
 int vil_gauge_fix(const double* pose0_before, vil_state* s) {
     if (!pose0_before || !s) return VIL_ERR_INVALID_ARGUMENT;
     gauge_fix_core(pose0_before, s->K, s->pose, s->speedbias, s->ex_pose);
@@ -1346,7 +1429,7 @@ int vil_shard_ranges(const vil_problem* p, int rank, int world, int32_t* lm_begi
 
 // ---- window residency across frames (include/vilsolve.h) ------------------------------------------------------------------------
 int vil_debug_set_split(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->force_split = on != 0; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
-int vil_set_gauge_fix(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->gauge_on = on != 0; return VIL_OK; }
+int vil_set_gauge_fix(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->gauge_on = on != 0; return VIL_OK; }      // (takes effect in the next solve)
 
 int vil_lidar_reset(vil_ctx* c) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
@@ -1417,11 +1500,12 @@ int vil_lidar_push(vil_ctx* c, int32_t n_plane, const double* plane_const, int32
     return VIL_OK;
 }
 
-int vil_marginalize_resident(vil_ctx* c, const vil_state* s, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out) {
-    if (!c || !s || !o || !spec || !out || !c->uploaded || c->resident_kind != 1) return VIL_ERR_INVALID_ARGUMENT;
+static int marginalize_resident_impl(vil_ctx* c, const vil_state* s, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out, const bool to_slot, vil_win_prior_info* winfo) {
+    if (!c || !o || !spec || (!to_slot && (!s || !out)) || !c->uploaded || c->resident_kind != 1) return VIL_ERR_INVALID_ARGUMENT;
     if (c->sharded) return VIL_ERR_UNSUPPORTED;
     const int K = c->K;
-    if (K < 3 || s->K != K || s->L != c->L) return VIL_ERR_INVALID_ARGUMENT;
+    if (K < 3 || (s && (s->K != K || s->L != c->L))) return VIL_ERR_INVALID_ARGUMENT;
+    int none = 0; int& out_n = out ? out->n : none;
     HIPCHK(hipSetDevice(c->device));
     const vil_ctx::MargMeta& mm = c->mm;
     const bool old_ = spec->flag == VIL_MARGIN_OLD;
@@ -1437,8 +1521,8 @@ int vil_marginalize_resident(vil_ctx* c, const vil_state* s, const vil_options* 
             else if (kind == VIL_BLK_SPEEDBIAS) sb_t[idx] = 1;
             else if (kind == VIL_BLK_EX) ex_t = true; else td_t = true;
         }
-        if (!old_ && !has_drop) { out->n = -1; return VIL_OK; }     // estimator.cpp:1620-1621: prior kept as is
-    } else if (!old_) { out->n = -1; return VIL_OK; }
+        if (!old_ && !has_drop) { out_n = -1; if (winfo) winfo->n = -1; return VIL_OK; }     // estimator.cpp:1620-1621: prior kept as is
+    } else if (!old_) { out_n = -1; if (winfo) winfo->n = -1; return VIL_OK; }
     int icp_m = -1, lps_m = -1;
     if (old_) {
         if (mm.imu01) { pose_t[0] = pose_t[1] = 1; sb_t[0] = sb_t[1] = 1; }
@@ -1464,7 +1548,206 @@ int vil_marginalize_resident(vil_ctx* c, const vil_state* s, const vil_options* 
     launch_reduce_step(c, so, false);
     c->P = keep;
     c->resident_kind = 2;                              // the work space now holds the marginalisation's linearisation
-    return marg_finish(c, K, old_, drop_pose, pose_t, sb_t, ex_t, td_t, mm.use_td, n_lm_elim, s, out);
+    return marg_finish(c, K, old_, drop_pose, pose_t, sb_t, ex_t, td_t, mm.use_td, n_lm_elim, s, out, to_slot, winfo);
+}
+int vil_marginalize_resident(vil_ctx* c, const vil_state* s, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out) {
+    return marginalize_resident_impl(c, s, o, spec, out, false, nullptr);
+}
+
+// ---- the fully resident window (include/vilsolve.h: vil_win_*; device side: vil_window.hpp) ------------------------------------------
+int vil_win_open(vil_ctx* c, const vil_win_cfg* cfg) {
+    if (!c || !cfg || cfg->K < 3 || cfg->K > VIL_WIN_MAXK || cfg->max_tracks < 1 || cfg->max_samples < 1) return VIL_ERR_INVALID_ARGUMENT;
+    if (c->world > 1 && (c->comm || c->lcomm)) return VIL_ERR_UNSUPPORTED;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    auto& w = c->win;
+    const int K = cfg->K, NF = K + 2;
+    int nmax, nblk_max, x0max;
+    vil_prior_capacity(K, &nmax, &nblk_max, &x0max);
+    if (!w.open || w.K != K || w.T != cfg->max_tracks || w.S != cfg->max_samples) {
+        hipFree(w.d_store); hipFree(w.d_samp); hipFree(w.d_hdr); hipFree(w.d_rec); hipFree(w.d_U); hipFree(w.d_prior[0]); hipFree(w.d_prior[1]);
+        w.d_store = w.d_samp = w.d_hdr = w.d_rec = w.d_U = w.d_prior[0] = w.d_prior[1] = nullptr; w.open = false;
+        w.K = K; w.T = cfg->max_tracks; w.S = cfg->max_samples; w.NF = NF; w.nmax = nmax; w.x0max = x0max;
+        HIPCHK(hipMalloc(&w.d_store, 8 * (size_t)NF * w.T * VIL_WIN_OBS));
+        HIPCHK(hipMalloc(&w.d_samp, 8 * (size_t)NF * 7 * w.S)); HIPCHK(hipMalloc(&w.d_hdr, 8 * (size_t)NF * 12));
+        HIPCHK(hipMalloc(&w.d_rec, 8 * (size_t)NF * 287)); HIPCHK(hipMalloc(&w.d_U, 8 * (size_t)NF * 225));
+        for (int q = 0; q < 2; ++q) HIPCHK(hipMalloc(&w.d_prior[q], 8 * w.prior_doubles()));
+        if (!w.d_wstat) HIPCHK(hipMalloc(&w.d_wstat, 64));
+    }
+    HIPCHK(hipMemsetAsync(w.d_store, 0, 8 * (size_t)NF * w.T * VIL_WIN_OBS, c->stream));
+    HIPCHK(hipMemsetAsync(w.d_rec, 0, 8 * (size_t)NF * 287, c->stream)); HIPCHK(hipMemsetAsync(w.d_U, 0, 8 * (size_t)NF * 225, c->stream));
+    HIPCHK(hipMemsetAsync(w.d_wstat, 0, 64, c->stream));
+    w.cfg = *cfg; w.open = true;
+    w.fslot.clear(); w.islot.clear(); w.free_f.clear(); w.free_i.clear();
+    for (int q = NF - 1; q >= 0; --q) { w.free_f.push_back(q); w.free_i.push_back(q); }
+    w.ns.assign(NF, 0); w.sum_dt.assign(NF, 0.0);
+    w.cur = 0; w.pn = 0; w.pm = 0; w.pkind.clear(); w.pindex.clear(); w.pcol.clear();
+    c->uploaded = false; c->resident_kind = 0;
+    return vil_lidar_reset(c);
+}
+
+int vil_win_push_frame(vil_ctx* c, const vil_win_frame* f) {
+    if (!c || !f || !c->win.open) return VIL_ERR_INVALID_ARGUMENT;
+    auto& w = c->win;
+    if ((int)w.fslot.size() >= w.K || f->n_samples < 0 || f->n_samples > w.S || f->n_obs < 0 || f->n_obs > w.T) return VIL_ERR_INVALID_ARGUMENT;
+    if ((f->n_samples > 0 && (!f->dt || !f->acc || !f->gyr)) || (f->n_obs > 0 && (!f->obs_track || !f->obs))) return VIL_ERR_INVALID_ARGUMENT;
+    for (int q = 0; q < f->n_obs; ++q) if (f->obs_track[q] < 0 || f->obs_track[q] >= w.T) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    const int ns = f->n_samples, no = f->n_obs;
+    // one staging block, one DMA: [hdr 12 | dt | acc | gyr | observations | track slots]
+    const size_t o_samp = 0, o_obs = 8 * (size_t)(12 + 7 * ns), o_trk = o_obs + 8 * (size_t)no * VIL_WIN_OBS, total = o_trk + 4 * (size_t)no + 64;
+    if (w.pending) { HIPCHK(hipEventSynchronize(w.ev)); w.pending = false; }     // the previous frame's DMA has left the pinned block
+    if (total > w.stage_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (w.h_stage) hipHostFree(w.h_stage); hipFree(w.d_stage); w.h_stage = nullptr; w.d_stage = nullptr; w.stage_cap = 0;
+        const size_t cap = 2 * total + 4096;
+        HIPCHK(hipHostMalloc((void**)&w.h_stage, cap, hipHostMallocDefault)); HIPCHK(hipMalloc(&w.d_stage, cap));
+        w.stage_cap = cap;
+    }
+    double* hs = (double*)(w.h_stage + o_samp);
+    memcpy(hs, f->acc0, 24); memcpy(hs + 3, f->gyr0, 24); memcpy(hs + 6, f->lin_ba, 24); memcpy(hs + 9, f->lin_bg, 24);
+    double sum = 0.0;
+    if (ns) { memcpy(hs + 12, f->dt, 8 * (size_t)ns); memcpy(hs + 12 + ns, f->acc, 24 * (size_t)ns); memcpy(hs + 12 + 4 * (size_t)ns, f->gyr, 24 * (size_t)ns); for (int q = 0; q < ns; ++q) sum += f->dt[q]; }
+    if (no) { memcpy(w.h_stage + o_obs, f->obs, 8 * (size_t)no * VIL_WIN_OBS); memcpy(w.h_stage + o_trk, f->obs_track, 4 * (size_t)no); }
+    HIPCHK(hipMemcpyAsync(w.d_stage, w.h_stage, o_trk + 4 * (size_t)no, hipMemcpyHostToDevice, c->stream));
+    if (!w.ev) HIPCHK(hipEventCreateWithFlags(&w.ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(w.ev, c->stream)); w.pending = true;
+    const int fs = w.free_f.back(), is = w.free_i.back();
+    w.free_f.pop_back(); w.free_i.pop_back();
+    WinFrameIn A;
+    A.n_obs = no; A.track = (const int*)(w.d_stage + o_trk); A.obs = (const double*)(w.d_stage + o_obs); A.store = w.d_store; A.T = w.T; A.fslot = fs;
+    A.ns = ns; A.samp = (const double*)(w.d_stage + o_samp); A.hdr = w.d_hdr + 12 * (size_t)is; A.dt = w.dt(is); A.acc = w.acc(is); A.gyr = w.gyr(is);
+    const int nbo = (no * VIL_WIN_OBS + 255) / 256;
+    hipLaunchKernelGGL(k_win_frame_in, dim3(nbo + 1), dim3(256), 0, c->stream, A, nbo);
+    if (ns > 0) {                                        // the interval's record and its sqrt-information, where the solver will read them
+        vpre_launch_slot(c->stream, ns, w.dt(is), w.acc(is), w.gyr(is), w.d_hdr + 12 * (size_t)is, w.cfg.noise, w.d_rec + 287 * (size_t)is);
+        hipLaunchKernelGGL(k_imu_sqrtinfo, dim3(1), dim3(VIL_THREADS), 0, c->stream, w.d_rec + 287 * (size_t)is, w.d_U + 225 * (size_t)is, w.d_wstat, 1);
+    }
+    w.fslot.push_back(fs); w.islot.push_back(is); w.ns[is] = ns; w.sum_dt[is] = sum;
+    c->uploaded = false; c->resident_kind = 0;
+    return vil_lidar_push(c, f->n_plane, f->plane_const, f->n_edge, f->edge_const);
+}
+
+int vil_win_drop_frame(vil_ctx* c, int32_t flag) {
+    if (!c || !c->win.open) return VIL_ERR_INVALID_ARGUMENT;
+    auto& w = c->win;
+    const int n = (int)w.fslot.size();
+    if (n < 2) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    c->uploaded = false; c->resident_kind = 0;
+    if (flag == VIL_MARGIN_OLD) {
+        // frame 0 leaves.  Its IMU slot held the interval that ENDED in it -- not a factor of the window; the interval (0, 1) stays with frame 1
+        w.free_f.push_back(w.fslot[0]); w.free_i.push_back(w.islot[0]);
+        w.fslot.erase(w.fslot.begin()); w.islot.erase(w.islot.begin());
+        return vil_lidar_drop(c, 0);
+    }
+    // MARGIN_SECOND_NEW (estimator.cpp:1754-1786): frame n-2 leaves; the newest frame takes its place and its samples continue the interval
+    // that ended in n-2 (same first measurement, same linearisation point): appended on the device, re-integrated, re-factored
+    const int ia = w.islot[n - 2], ib = w.islot[n - 1];
+    if (w.ns[ia] + w.ns[ib] > w.S) return VIL_ERR_UNSUPPORTED;
+    if (w.ns[ib] > 0) {
+        hipLaunchKernelGGL(k_win_append, dim3(1), dim3(256), 0, c->stream, w.dt(ia), w.acc(ia), w.gyr(ia), w.ns[ia], w.dt(ib), w.acc(ib), w.gyr(ib), w.ns[ib]);
+        w.ns[ia] += w.ns[ib]; w.sum_dt[ia] += w.sum_dt[ib];
+        vpre_launch_slot(c->stream, w.ns[ia], w.dt(ia), w.acc(ia), w.gyr(ia), w.d_hdr + 12 * (size_t)ia, w.cfg.noise, w.d_rec + 287 * (size_t)ia);
+        hipLaunchKernelGGL(k_imu_sqrtinfo, dim3(1), dim3(VIL_THREADS), 0, c->stream, w.d_rec + 287 * (size_t)ia, w.d_U + 225 * (size_t)ia, w.d_wstat, 1);
+    }
+    w.free_f.push_back(w.fslot[n - 2]); w.free_i.push_back(ib);
+    w.fslot.erase(w.fslot.begin() + (n - 2));            // the newest frame's observations and LiDAR points stay where they are
+    w.islot.erase(w.islot.begin() + (n - 1));            // ... and it now ends the merged interval
+    return vil_lidar_drop(c, n - 2);
+}
+
+int vil_win_solve(vil_ctx* c, const vil_win_problem* wp, vil_state* s, const vil_options* o, vil_summary* sum) {
+    if (!c || !wp || !s || !o || !sum || !c->win.open) return VIL_ERR_INVALID_ARGUMENT;
+    auto& w = c->win;
+    const int K = w.K, L = wp->L;
+    if ((int)w.fslot.size() != K || L < 0 || s->K != K || s->L != L) return VIL_ERR_INVALID_ARGUMENT;
+    if (L > 0 && (!wp->lm_track || !wp->lm_start || !wp->lm_nobs)) return VIL_ERR_INVALID_ARGUMENT;
+    int n_vis = 0;
+    for (int l = 0; l < L; ++l) {
+        if (wp->lm_track[l] < 0 || wp->lm_track[l] >= w.T || wp->lm_start[l] < 0 || wp->lm_nobs[l] < 2 || wp->lm_start[l] + wp->lm_nobs[l] > K) return VIL_ERR_INVALID_ARGUMENT;
+        n_vis += wp->lm_nobs[l] - 1;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    vil_problem q; memset(&q, 0, sizeof q);
+    q.K = K; q.L = L; q.pose_const = wp->pose_const; q.sb_const = wp->sb_const; q.lm_const = wp->lm_const;
+    q.ex_const = wp->ex_const; q.td_const = wp->td_const; q.use_td = w.cfg.use_td;
+    int imu_i[VIL_WIN_MAXK], imu_j[VIL_WIN_MAXK];
+    for (int k = 0; k + 1 < K; ++k) { imu_i[k] = k; imu_j[k] = k + 1; }
+    q.n_imu = K - 1; q.imu_i = imu_i; q.imu_j = imu_j; q.imu_const = nullptr;
+    q.prior.n = w.pn; q.prior.nblk = (int)w.pkind.size(); q.prior.blk_kind = w.pkind.data(); q.prior.blk_index = w.pindex.data(); q.prior.blk_col = w.pcol.data();
+    q.n_icp = wp->n_icp; q.icp_ids = wp->icp_ids; q.icp_const = wp->icp_const; q.n_lps = wp->n_lps; q.lps_ids = wp->lps_ids; q.lps_const = wp->lps_const;
+    q.n_plane = q.n_edge = VIL_LIDAR_RESIDENT;
+    memcpy(q.q_lb, w.cfg.q_lb, sizeof q.q_lb); memcpy(q.t_lb, w.cfg.t_lb, sizeof q.t_lb); memcpy(q.G, w.cfg.G, sizeof q.G);
+    q.sqrt_info_px = w.cfg.sqrt_info_px; q.tr_over_row = w.cfg.tr_over_row;
+    WinSrc ws; memset(&ws, 0, sizeof ws);
+    ws.lm_track = wp->lm_track; ws.lm_startf = wp->lm_start; ws.lm_nobs = wp->lm_nobs; ws.n_vis = n_vis; ws.T = w.T;
+    ws.d_store = w.d_store; ws.fslot = w.fslot.data(); ws.islot = w.islot.data(); ws.d_rec = w.d_rec; ws.d_U = w.d_U; ws.sum_dt = w.sum_dt.data();
+    ws.pJ0 = w.pJ0(w.cur); ws.pr0 = w.pr0(w.cur); ws.px0 = w.px0(w.cur); ws.pH = w.pH(w.cur); ws.pg0 = w.pg0(w.cur); ws.pc0 = w.pc0(w.cur);
+    int st = upload_impl(c, &q, s, false, nullptr, nullptr, 0, false, &ws);
+    if (st != VIL_OK) return st;
+    c->resident_kind = 1;
+    c->P.setup_stat = w.d_wstat;                       // the window's sticky status word: a failed pre-integration / prior ends the solve with it
+    const auto t1 = std::chrono::steady_clock::now();
+    st = vil_solve_resident(c, o, sum);
+    sum->t_prepare_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (st != VIL_OK) return st;                       // state left unchanged on any error
+    const auto t2 = std::chrono::steady_clock::now();
+    st = vil_download_state(c, s);
+    sum->t_readback_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count();
+    return st;
+}
+
+int vil_win_marginalize(vil_ctx* c, const vil_options* o, const vil_marg_spec* spec, vil_win_prior_info* info) {
+    if (!c || !c->win.open) return VIL_ERR_INVALID_ARGUMENT;
+    return marginalize_resident_impl(c, nullptr, o, spec, nullptr, true, info);
+}
+
+int vil_win_prior_download(vil_ctx* c, vil_prior_out* out) {
+    if (!c || !out || !c->win.open) return VIL_ERR_INVALID_ARGUMENT;
+    auto& w = c->win;
+    HIPCHK(hipSetDevice(c->device));
+    int wst = 0;
+    HIPCHK(hipMemcpyAsync(&wst, w.d_wstat, 4, hipMemcpyDeviceToHost, c->stream));
+    out->n = w.pn; out->nblk = (int)w.pkind.size(); out->m = w.pm;
+    if (w.pn > 0) {
+        const size_t n = (size_t)w.pn;
+        int xo = 0;
+        for (size_t b = 0; b < w.pkind.size(); ++b) { out->blk_kind[b] = w.pkind[b]; out->blk_index[b] = w.pindex[b]; out->blk_col[b] = w.pcol[b]; xo += (w.pkind[b] == VIL_BLK_POSE || w.pkind[b] == VIL_BLK_EX) ? 7 : (w.pkind[b] == VIL_BLK_SPEEDBIAS ? 9 : 1); }
+        HIPCHK(hipMemcpyAsync(out->J0, w.pJ0(w.cur), 8 * n * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(out->r0, w.pr0(w.cur), 8 * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(out->x0, w.px0(w.cur), 8 * (size_t)xo, hipMemcpyDeviceToHost, c->stream));
+        if (out->A) HIPCHK(hipMemcpyAsync(out->A, w.pH(w.cur), 8 * n * n, hipMemcpyDeviceToHost, c->stream));      // J0^T J0
+        if (out->b) HIPCHK(hipMemcpyAsync(out->b, w.pg0(w.cur), 8 * n, hipMemcpyDeviceToHost, c->stream));          // J0^T r0
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    return wst;
+}
+
+int vil_win_prior_set(vil_ctx* c, const vil_prior* pr) {
+    if (!c || !c->win.open) return VIL_ERR_INVALID_ARGUMENT;
+    auto& w = c->win;
+    HIPCHK(hipSetDevice(c->device));
+    if (!pr || pr->n <= 0) { w.pn = 0; w.pm = 0; w.pkind.clear(); w.pindex.clear(); w.pcol.clear(); return VIL_OK; }
+    if (pr->n > w.nmax || pr->nblk <= 0 || pr->nblk > VIL_WIN_MAXBLK || !pr->blk_kind || !pr->blk_index || !pr->blk_col || !pr->x0 || !pr->J0 || !pr->r0) return VIL_ERR_INVALID_ARGUMENT;
+    const size_t n = (size_t)pr->n;
+    int xo = 0;
+    for (int b = 0; b < pr->nblk; ++b) xo += (pr->blk_kind[b] == VIL_BLK_POSE || pr->blk_kind[b] == VIL_BLK_EX) ? 7 : (pr->blk_kind[b] == VIL_BLK_SPEEDBIAS ? 9 : 1);
+    if (xo > w.x0max) return VIL_ERR_INVALID_ARGUMENT;
+    const int dst = 1 - w.cur;
+    // stage J0 | r0 in the marginalisation work space layout k_prior_commit reads, x0 directly
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(w.pJ0(dst), pr->J0, 8 * n * n, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(w.pr0(dst), pr->r0, 8 * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(w.px0(dst), pr->x0, 8 * (size_t)xo, hipMemcpyHostToDevice));
+    PriorCommit pc; memset(&pc, 0, sizeof pc);
+    pc.n = pr->n; pc.nblk = 0; pc.J0 = w.pJ0(dst); pc.r0 = w.pr0(dst); pc.x = nullptr; pc.K = w.K;      // nblk = 0: x0 already in place
+    pc.pJ0 = w.pJ0(dst); pc.pr0 = w.pr0(dst); pc.px0 = w.px0(dst); pc.pH = w.pH(dst); pc.pg0 = w.pg0(dst); pc.pc0 = w.pc0(dst); pc.status = w.d_wstat;
+    hipLaunchKernelGGL(k_prior_commit, dim3(32), dim3(256), 0, c->stream, pc);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    w.cur = dst; w.pn = pr->n; w.pm = 0;
+    w.pkind.assign(pr->blk_kind, pr->blk_kind + pr->nblk); w.pindex.assign(pr->blk_index, pr->blk_index + pr->nblk); w.pcol.assign(pr->blk_col, pr->blk_col + pr->nblk);
+    return VIL_OK;
 }
 
 int vil_comm_unique_id(void* id128) {

@@ -154,6 +154,67 @@ class Backend:
         self._call("marginalize_resident", C.byref(s), C.byref(opts), C.byref(spec), C.byref(out.c))
         return out
 
+    # -- the fully resident window (HIP library only; include/vilsolve.h: vil_win_*)
+    def win_open(self, K, max_tracks, max_samples, noise, G, sqrt_info_px, tr_over_row, q_lb, t_lb, use_td=1):
+        cfg = abi.VilWinCfg()
+        cfg.K, cfg.max_tracks, cfg.max_samples, cfg.use_td = int(K), int(max_tracks), int(max_samples), int(use_td)
+        for k in range(4):
+            cfg.noise[k] = float(noise[k]); cfg.q_lb[k] = float(q_lb[k])
+        for k in range(3):
+            cfg.G[k] = float(G[k]); cfg.t_lb[k] = float(t_lb[k])
+        cfg.sqrt_info_px, cfg.tr_over_row = float(sqrt_info_px), float(tr_over_row)
+        self._call("win_open", C.byref(cfg))
+
+    def win_push_frame(self, fr):
+        """fr: dict with dt (n), acc (n x 3), gyr (n x 3), acc0, gyr0, lin_ba, lin_bg, obs_track (m), obs (m x 8), plane (p x 7), edge (e x 9)."""
+        f = abi.VilWinFrame()
+        keep = [abi.f64(fr["dt"]), abi.f64(fr["acc"]).reshape(-1, 3), abi.f64(fr["gyr"]).reshape(-1, 3), abi.i32(fr["obs_track"]), abi.f64(fr["obs"]).reshape(-1, abi.VIL_WIN_OBS),
+                abi.f64(fr["plane"]).reshape(-1, 7), abi.f64(fr["edge"]).reshape(-1, 9)]
+        f.n_samples = len(keep[0]); f.dt, f.acc, f.gyr = abi._d(keep[0]), abi._d(keep[1]), abi._d(keep[2])
+        for k in range(3):
+            f.acc0[k], f.gyr0[k], f.lin_ba[k], f.lin_bg[k] = float(fr["acc0"][k]), float(fr["gyr0"][k]), float(fr["lin_ba"][k]), float(fr["lin_bg"][k])
+        f.n_obs = len(keep[3]); f.obs_track, f.obs = abi._d(keep[3]), abi._d(keep[4])
+        f.n_plane = len(keep[5]); f.plane_const = abi._d(keep[5]); f.n_edge = len(keep[6]); f.edge_const = abi._d(keep[6])
+        self._call("win_push_frame", C.byref(f))
+
+    def win_drop_frame(self, flag):
+        self._call("win_drop_frame", C.c_int32(int(flag)))
+
+    def win_solve(self, w, opts=None):
+        """w: a Window whose visual structure is given per landmark (w.lm_track / lm_start / lm_nobs); state in place, like solve()."""
+        opts = opts or abi.default_options()
+        w._fix()
+        p = abi.VilWinProblem()
+        keep = [abi.i32(w.lm_track), abi.i32(w.lm_start), abi.i32(w.lm_nobs)]
+        p.L = w.L; p.lm_track, p.lm_start, p.lm_nobs = abi._d(keep[0]), abi._d(keep[1]), abi._d(keep[2])
+        p.lm_const, p.pose_const, p.sb_const = abi._d(w.lm_const), abi._d(w.pose_const), abi._d(w.sb_const)
+        p.ex_const, p.td_const = int(w.ex_const), int(w.td_const)
+        p.n_icp = len(w.icp_ids); p.icp_ids, p.icp_const = abi._d(w.icp_ids), abi._d(w.icp_const)
+        p.n_lps = len(w.lps_ids); p.lps_ids, p.lps_const = abi._d(w.lps_ids), abi._d(w.lps_const)
+        s = w.c_state()
+        summ = abi.VilSummary()
+        self._call("win_solve", C.byref(p), C.byref(s), C.byref(opts), C.byref(summ))
+        return summ
+
+    def win_marginalize(self, flag=abi.MARGIN_OLD, icp_marg=-1, lps_marg=-1, opts=None):
+        opts = opts or abi.default_options()
+        spec = abi.VilMargSpec(flag, icp_marg, lps_marg, 4)
+        info = abi.VilWinPriorInfo()
+        self._call("win_marginalize", C.byref(opts), C.byref(spec), C.byref(info))
+        return info
+
+    def win_prior_download(self, K):
+        out = abi.PriorOut(K)
+        self._call("win_prior_download", C.byref(out.c))
+        return out
+
+    def win_prior_set(self, prior):
+        if prior is None or prior.n == 0:
+            self._call("win_prior_set", None)
+        else:
+            p = prior.c_struct()
+            self._call("win_prior_set", C.byref(p))
+
     def download_state(self, w):
         s = w.c_state()
         self._call("download_state", C.byref(s))

@@ -31,10 +31,11 @@ INIT_DEPTH = 5.0        # parameters.cpp:189
 
 class Track:
     """FeaturePerId (feature_manager.h:50-78): observations of one landmark in consecutive window frames."""
-    __slots__ = ("fid", "start", "obs", "depth", "lidar_flag", "future", "Xw")
+    __slots__ = ("fid", "start", "obs", "depth", "lidar_flag", "future", "Xw", "slot")
 
     def __init__(self, fid, start, Xw, lidar_flag):
         self.fid, self.start, self.Xw, self.lidar_flag = fid, start, Xw, lidar_flag
+        self.slot = -1           # track slot of the device-resident observation store (vil_win_*), handed out by Replay
         self.obs = []            # [(pt3, vel2, lidar_depth)] one per window frame start, start+1, ...
         self.depth = -1.0        # estimated_depth
         self.future = None       # {absolute frame: observation} still to arrive
@@ -65,6 +66,8 @@ class Replay:
             self.raw.append((acc, gyr))
         self.opts = abi.default_options(max_iterations=max_iterations)      # NUM_ITERATIONS = 8 (yaml max_num_iterations), time cap disabled
         self._next_fid = 0
+        self.max_tracks = 4096                               # track slots of the resident window (vil_win_cfg.max_tracks)
+        self._free_slots = list(range(self.max_tracks - 1, -1, -1))
         self._spawn_rate = L / max(1.0, 1.75 * K - 4.5)      # new tracks per image; the divisor (measured) = mean number of windows a track is a member of
         self._init_window()
 
@@ -139,6 +142,7 @@ class Replay:
                 continue
             tr.future = fut
             tr.depth = depth * rng.uniform(0.8, 1.25)        # stands in for triangulate() (feature_manager.cpp:214-273)
+            tr.slot = self._free_slots.pop()
             self.tracks.append(tr)
 
     def _proj_t(self, Xw, t):
@@ -336,6 +340,8 @@ class Replay:
             self.samples = self.samples[:K - 2] + [merged]; self.imu = self.imu[:K - 2] + [self._preint(merged, lin)]
             self.lidar = self.lidar[:K - 2] + [self.lidar[K - 1]]
         self.tracks = [tr for tr in self.tracks if tr.obs or tr.future]
+        used = {tr.slot for tr in self.tracks}               # slots of tracks that are gone can be handed out again
+        self._free_slots = [q for q in range(self.max_tracks - 1, -1, -1) if q not in used]
         # next image
         self.newest += 1
         f = self.newest
@@ -356,6 +362,36 @@ class Replay:
         self._observe(f, K - 1)
         self._rel_constraints(f)
         return True
+
+    # ---- the fully resident window (vil_win_*): what crosses PCIe per image ---------------------------------------------
+    def win_open_args(self):
+        from .synth import ACC_W, GYR_W
+        return dict(K=self.K, max_tracks=self.max_tracks, max_samples=256, noise=(ACC_N, GYR_N, ACC_W, GYR_W), G=(0.0, 0.0, G_NORM),
+                    sqrt_info_px=FOCAL_LENGTH / 2.0, tr_over_row=0.0, q_lb=R_to_quat(self.RLB), t_lb=TLB, use_td=1)
+
+    def win_frame(self, k):
+        """vil_win_frame of window frame k: the IMU samples of the interval ending in it (its first measurement and the bias
+        linearisation point of frame k-1), the observations made in it (by track slot), its LiDAR points."""
+        fr = dict(dt=np.zeros(0), acc=np.zeros((0, 3)), gyr=np.zeros((0, 3)), acc0=np.zeros(3), gyr0=np.zeros(3), lin_ba=np.zeros(3), lin_bg=np.zeros(3))
+        if k >= 1:
+            acc, gyr = self.samples[k]
+            fr.update(dt=np.full(len(acc) - 1, IMU_DT), acc=acc[1:], gyr=gyr[1:], acc0=acc[0], gyr0=gyr[0], lin_ba=self.imu[k][10:13], lin_bg=self.imu[k][13:16])
+        trk, obs = [], []
+        for tr in self.tracks:
+            q = k - tr.start
+            if tr.obs and 0 <= q < len(tr.obs):
+                pt, vel, _ = tr.obs[q]
+                trk.append(tr.slot); obs.append((pt[0], pt[1], pt[2], vel[0], vel[1], 0.0, pt[1] * FOCAL_LENGTH, 0.0))
+        fr.update(obs_track=np.array(trk, np.int32), obs=np.array(obs).reshape(-1, 8), plane=self.lidar[k][0], edge=self.lidar[k][1])
+        return fr
+
+    def win_window(self):
+        """The window for vil_win_solve: the small tables only -- visual structure per landmark, no factor constants, no LiDAR, no IMU records, no prior."""
+        w = self.window(with_lidar=False)
+        w.lm_track = np.array([tr.slot for tr in w._sel], np.int32)
+        w.lm_start = np.array([tr.start for tr in w._sel], np.int32)
+        w.lm_nobs = np.array([len(tr.obs) for tr in w._sel], np.int32)
+        return w
 
     def truth_window(self):
         return self.pose_true[self.frames]

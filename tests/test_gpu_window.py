@@ -1,0 +1,114 @@
+"""The fully resident window (include/vilsolve.h: vil_win_*): observations, IMU samples / records, LiDAR points and the
+marginalisation prior stay in HBM across images; per image only the new frame and the window's small tables go up, the solved state
+comes back.  The ORACLE is the comparator: on every image it is handed the same input window -- host tables rebuilt from the replay's
+bookkeeping, the prior downloaded from the device prior slot -- and must produce the same solve and the same new prior."""
+import numpy as np
+import pytest
+
+from mvil_fusion_amd import abi, lib, replay
+from mvil_fusion_amd.abi import Window
+
+pytestmark = pytest.mark.gpu
+
+
+def _rot_angle(qa, qb):
+    d = abs(float(np.dot(qa, qb)) / (np.linalg.norm(qa) * np.linalg.norm(qb)))
+    return 2.0 * np.arccos(min(1.0, d))
+
+
+def _open(be, rp):
+    be.set_gauge_fix(True)
+    be.win_open(**rp.win_open_args())
+    for k in range(rp.K):
+        be.win_push_frame(rp.win_frame(k))
+
+
+def test_resident_window_chain_matches_oracle(oracle):
+    K, N = 8, 44
+    rp = replay.Replay(K=K, n_frames=N + K + 2, L=150, n_plane=2400, n_edge=800, seed=21, second_new_every=4)
+    be = lib.open_vilsolve()
+    _open(be, rp)
+    flags, priors = set(), 0
+    for step in range(N):
+        flag = rp.margin_flag(); flags.add(flag)
+        w = rp.win_window()
+        wo = Window.from_dict(rp.window().to_dict())                    # the same window with every table on the host (rp.prior = the downloaded device prior)
+        p0 = w.pose[0].copy()
+        sg = be.win_solve(w, rp.opts)                                   # comes back gauge-fixed
+        so = oracle.solve(wo, rp.opts); oracle.gauge_fix(p0, wo)
+        assert sg.iterations == so.iterations and sg.termination == so.termination, (step, sg.iterations, so.iterations)
+        assert abs(sg.final_cost - so.final_cost) <= 1e-7 * max(1.0, abs(so.final_cost)) * (100.0 if wo.prior.n == 0 else 1.0), step
+        assert np.abs(w.pose[:, :3] - wo.pose[:, :3]).max() < 1e-6, step
+        assert max(_rot_angle(w.pose[k, 3:], wo.pose[k, 3:]) for k in range(K)) < 1e-7
+        assert np.abs(w.speedbias - wo.speedbias).max() < 1e-6 and np.abs(w.inv_depth - wo.inv_depth).max() < 1e-6
+        info = be.win_marginalize(flag, w._icp_marg, w._lps_marg, rp.opts)          # returns at once: the prior stays on the device
+        po = oracle.marginalize(wo, flag, w._icp_marg, w._lps_marg, rp.opts)
+        assert info.n == po.c.n, (step, info.n, po.c.n)
+        pg = be.win_prior_download(K)                                   # (test only: the product path never reads the prior back)
+        if info.n > 0:
+            priors += 1
+            nb = po.c.nblk
+            assert pg.c.n == po.c.n and pg.c.nblk == nb
+            assert np.array_equal(pg.blk_kind[:nb], po.blk_kind[:nb]) and np.array_equal(pg.blk_index[:nb], po.blk_index[:nb]) and np.array_equal(pg.blk_col[:nb], po.blk_col[:nb])
+            ng = sum({0: 7, 1: 9, 2: 7, 3: 1}[int(k)] for k in po.blk_kind[:nb])
+            assert np.abs(pg.x0[:ng] - po.x0[:ng]).max() < 1e-6                      # x0 = the kept blocks of the device state the factors were linearised at
+            Ag, Ao = pg.A_matrix(), po.A_matrix()                       # device: J0^T J0 of the committed square root; oracle: the marginal information
+            sc = np.sqrt(np.outer(np.abs(np.diag(Ao)) + 1e-300, np.abs(np.diag(Ao)) + 1e-300))
+            assert (np.abs(Ag - Ao) / sc).max() < 2e-5, step           # (the marginal's fp64 noise floor; as test_gpu_replay.py)
+            Jg = pg.to_prior().J_matrix()
+            assert np.abs(Jg.T @ Jg - Ag).max() < 1e-9 * np.abs(Ag).max()
+            bo = po.b_vector(); bg = pg.b_vector()                      # J0^T r0
+            assert np.abs(bg - bo).max() <= 2e-5 * max(1.0, np.abs(bo).max())
+        be.win_drop_frame(flag)
+        assert rp.absorb(w, pg, flag)
+        be.win_push_frame(rp.win_frame(K - 1))
+    assert flags == {abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW} and priors >= 30
+    be.close()
+
+
+def test_resident_window_equals_classic_entry_points():
+    """The same chain through vil_solve / vil_gauge_fix / vil_marginalize with every table handed over on every image (regression, not parity)."""
+    kw = dict(K=10, n_frames=30, L=200, n_plane=4000, n_edge=1200, seed=20240611, max_iterations=8)
+    be = lib.open_vilsolve()
+    rc = replay.Replay(**kw)
+    ref = []
+    for _ in range(16):
+        w = rc.window(); flag = rc.margin_flag(); p0 = w.pose[0].copy()
+        sm = be.solve(w, rc.opts); be.gauge_fix(p0, w)
+        pg = be.marginalize(w, flag, w._icp_marg, w._lps_marg, rc.opts)
+        ref.append((sm.iterations, w.pose.copy(), w.inv_depth.copy()))
+        assert rc.absorb(w, pg, flag)
+    rp = replay.Replay(**kw)
+    _open(be, rp)
+    for f in range(16):
+        w = rp.win_window(); flag = rp.margin_flag()
+        sm = be.win_solve(w, rp.opts)
+        be.win_marginalize(flag, w._icp_marg, w._lps_marg, rp.opts)
+        assert sm.iterations == ref[f][0], (f, sm.iterations, ref[f][0])
+        assert np.abs(w.pose - ref[f][1]).max() < 1e-7 and np.abs(w.inv_depth - ref[f][2]).max() < 1e-6, (f, np.abs(w.pose - ref[f][1]).max())
+        be.win_drop_frame(flag)
+        assert rp.absorb(w, None, flag)                                 # the host never sees the prior
+        be.win_push_frame(rp.win_frame(rp.K - 1))
+    be.close()
+
+
+def test_resident_window_rejects_misuse():
+    be = lib.open_vilsolve()
+    rp = replay.Replay(K=8, n_frames=14, L=60, n_plane=800, n_edge=200, seed=3, max_iterations=4)
+    w = rp.win_window()
+    with pytest.raises(lib.VilError):
+        be.win_solve(w, rp.opts)                                        # no window open
+    be.win_open(**rp.win_open_args())
+    for k in range(rp.K - 1):
+        be.win_push_frame(rp.win_frame(k))
+    with pytest.raises(lib.VilError):
+        be.win_solve(w, rp.opts)                                        # one frame short
+    be.win_push_frame(rp.win_frame(rp.K - 1))
+    with pytest.raises(lib.VilError):
+        be.win_push_frame(rp.win_frame(rp.K - 1))                       # a ninth frame in a window of eight
+    bad = rp.win_window(); bad.lm_nobs = bad.lm_nobs.copy(); bad.lm_nobs[0] = rp.K + 1
+    with pytest.raises(lib.VilError):
+        be.win_solve(bad, rp.opts)                                      # a track longer than the window
+    s = be.win_solve(w, rp.opts)
+    assert s.iterations >= 1
+    be.close()
