@@ -17,6 +17,7 @@
 // Windows whose speed-bias coupling is not a chain (checked on the host at upload) keep the dense path.
 #pragma once
 #include "vil_dev.hpp"
+#include "vil_math.hpp"
 
 namespace vd {
 
@@ -90,7 +91,8 @@ __device__ __forceinline__ void row_solve9(const double* l, const double* r, con
 // SRC: raw S' entries -- diag(k, i, j): entry (i, j <= i) of diagonal block k; sub(k, kn, q, c): row q of block kn = k +- 1, column c
 // of block k; prow(r, k, c): pose row r, column c of block k --; sc(j) scale of reduced column j; madd(j) = mu dc_j^2; rowscale(r) scale applied to pose row r
 // (1 when the row scaling is deferred); rhsraw(j) reduced gradient of column j; u(j) (WITHQ) the vector of the quadratic form
-// on the chain columns; row_done(d, r, z, q): z = (S'_pb u_b)[r] over the blocks of direction d (the step kernel adds 2 u_r z).
+// on the chain columns; row_done(d, r, z, q): z = (S'_pb u_b)[r] over the blocks of direction d (the step kernel adds 2 u_r z);
+// wput(p, v): store of an entry of W^T (plain, or at agent scope when another workgroup of the launch reads it).
 // WITHQ: qacc receives this lane's share of u^T S' u over every entry of S' with a row or a column in the chain part (each
 // raw entry passes through exactly one lane here: pose row x chain block in the row waves, diagonal and sub-diagonal blocks in
 // the recursion waves).
@@ -239,7 +241,7 @@ __device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, con
         row_solve9(l, rv, a, w);
         if (valid) {
 #pragma unroll
-            for (int c = 0; c < 9; ++c) Wt[(size_t)(9 * k + c) * RS + r] = w[c];
+            for (int c = 0; c < 9; ++c) src.wput(Wt + (size_t)(9 * k + c) * RS + r, w[c]);
         }
         const double* L1 = L.Lsb + 82 * k;
 #pragma unroll
@@ -278,7 +280,7 @@ __device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, con
         row_solve9(l, rv, a, w);
         if (valid) {
 #pragma unroll
-            for (int c = 0; c < 9; ++c) Wt[(size_t)(9 * m + c) * RS + r] = w[c];
+            for (int c = 0; c < 9; ++c) src.wput(Wt + (size_t)(9 * m + c) * RS + r, w[c]);
         }
     }
     if (WITHQ && r < NP) src.row_done(0, r, zr, qacc);

@@ -30,7 +30,7 @@ struct SysBuf {       // one linearisation of the window (double-buffered: curre
 struct Ctl {          // trust-region state, lives in device memory, owned by the step kernel
     int gen;          // solve generation (host): with n_sweeps it forms the epoch of the helper-workgroup flags
     int cur, iter, done, term, first, resweep, reuse, nsucc, invalid_run, status, lin_mode, n_sweeps;
-    int swe;                      // advanced by every live step-kernel launch
+    int swe;                      // advanced by every live step-kernel launch: epoch of the sweep's workgroup flags (swflag)
     int outd, pad_;               // outd: the finished solve has been written out (solve_finish: accepted state -> x[0], gauge fix, host mirror)
     double radius, mu, cost_cur, model_change, alpha, dogleg_norm, initial_cost, cand_cost;
     double mu_used, gn2, g2, gg;   // dogleg scalars of the current linearisation (reused after a rejected step)
@@ -113,6 +113,16 @@ struct DevP {
     double* la; double* lb;        // L each: step directions of the inverse depths (Cauchy, Gauss-Newton), written by the step kernel's landmark pass
     // structure-exploiting solve (vil_chain.hpp): 0 dense, 1 chain with W^T in LDS, 2 chain with W^T in global memory (P.M)
     int chain, chain_rs;
+    // ---- speed-bias chain eliminated BESIDE the gather (vil_prechain.hpp): prechain = 1 (single GPU, every IMU factor couples
+    // frames (k, k+1), chain step kernel).  One extra workgroup of the merged gather + step launch gathers
+    // the chain part of S' from the IMU / prior records through a host-built table (chtab: n_chtab x {dst, src a, src b, src c}), eliminates the
+    // chain and leaves: W^T with unscaled pose rows (chW), the factored blocks (chLdg, chLsb), the chain columns' scales (chSc, chDc),
+    // pieces of u^T S' u (chZ, chQ), status (chOk).  Further workgroups then form W W^T tile by tile (chWW, tiled lower layout).
+    int prechain, n_chtab; const int* chtab;
+    // gather + step in ONE launch (rs_merged): grid = [master | helpers | chain | W W^T tiles (n_ww) | gather (n_gather)]; a workgroup that is
+    // done posts the launch epoch in its flag -- gflag[n_gather], chflag, wwflag[n_ww] -- and the master / helpers / tile workgroups wait on them
+    int rs_merged, n_ww, n_gather; int* gflag; int* chflag; int* wwflag;
+    double* chW; double* chLdg; double* chLsb; double* chSc; double* chDc; double* chZ; double* chQ; int* chOk; double* chWW;
 };
 
 __host__ __device__ inline int xo_pose(const DevP& P, int k) { return 7 * k; }

@@ -189,4 +189,21 @@ __device__ __forceinline__ void loss_eval(int kind, double a, double s, double& 
     } else { rho = s; rho1 = 1.0; }
 }
 
+// sqrt(x) and 1/sqrt(x) together: hardware rsq seed + two coupled Newton steps (no divide on the pivot chain)
+__device__ __forceinline__ void sqrt_rsqrt(double x, double& sq, double& rs) {
+    // v_rsq_f64 seeds ~2^-26; one coupled Newton step squares that (the pivot chain is latency-bound: every
+    // dependent fp64 op costs ~32 cycles), a residual correction on sqrt keeps it within an ulp or two
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g); h = fma(h, e, h);
+    sq = fma(fma(-g, g, x), h, g); rs = h + h;
+}
+// Data that crosses workgroups INSIDE one launch is stored and loaded at agent scope -- the level the eight XCDs share -- so that a flag only
+// has to be ordered behind the poster's own stores (s_waitcnt vmcnt(0)).  A release fence instead writes the whole XCD's L2 back
+// (buffer_wbl2): measured with 390 gather workgroups doing that in one launch, the launch took 100 us instead of 75.
+__device__ __forceinline__ double ld_ag(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_ag(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_ag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_ag(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }  // namespace vd

@@ -1,0 +1,171 @@
+// The speed-bias chain eliminated AHEAD of the step kernel, off the iteration's critical path (single GPU).
+//
+// Every entry of S' with a row or a column in the chain part comes from the IMU factors and the prior alone -- visual, LiDAR, ICP and
+// LPS factors never touch a speed-bias block (estimator.cpp:1179-1186, 1189-1242, 1298-1396) -- so the chain does not have to wait for the
+// gather of S'.  The gather and the step kernel are ONE launch (vil_step.hpp: k_step, rs_merged); beside the gather workgroups and the
+// master, one more workgroup
+//   1. gathers the chain part of S' into LDS through a table the host built at upload (destination, up to two IMU-record sources, one
+//      prior source per entry: a fixed summation order, no index arithmetic on the device),
+//   2. runs the two-sided chain elimination of vil_chain.hpp on it (13 us at K = 10) while the gather workgroups sum the partial records
+//      (11 us) and the master judges the candidate and forms its vectors (7 us),
+//   3. leaves W^T (pose rows unscaled: the Jacobi scale of a pose column needs the visual / LiDAR diagonal, which is not known here, and row
+//      scaling commutes with the column elimination), the factored blocks, the chain columns' scales and the chain share of u^T S' u.
+// Further workgroups then contract W W^T on the matrix cores, one 16 x 16 tile each, and the master starts its dense part from
+// M_pp = Sc (S'_pp - W W^T) Sc + mu d^2: the chain (14.6 us) and its Schur contraction (5.3 us) are off the master's critical path.
+// (Measured first inside k_sweep, behind the IMU / prior workgroups' flags: the chain workgroup needs 31 us there -- 8 us of it waiting for
+//  the records -- against 19 us of visual work: the sweep got 12.6 us longer, the step kernel 13.7 us shorter.)
+#pragma once
+#include "vil_chain.hpp"
+
+namespace vd {
+
+// Raw chain entries in LDS, as the chain consumes them:
+//   dg[k][45]  lower triangle of diagonal block k        sub[k][81]  rows of block k+1 x columns of block k (k < K-1)
+//   pb[col][row]  pose rows x chain columns, stride NPs    rhs[9K]
+struct ChainSlab { double* dg; double* sub; double* pb; double* rhs; int NPs; };
+__host__ __device__ inline int chain_slab_nps(int K) { return (6 * K + 7 + 1) & ~1; }
+__host__ __device__ inline size_t chain_slab_doubles(int K) { return even_up(45 * K) + even_up(81 * K) + (size_t)9 * K * chain_slab_nps(K) + even_up(9 * K); }
+__host__ __device__ inline ChainSlab chain_slab(double* p, int K) {
+    ChainSlab S; S.NPs = chain_slab_nps(K);
+    S.dg = p; S.sub = S.dg + even_up(45 * K); S.pb = S.sub + even_up(81 * K); S.rhs = S.pb + (size_t)9 * K * S.NPs;
+    return S;
+}
+// LDS of the chain workgroup (doubles): chain scratch | sc, dc, u of the chain columns | slab
+__host__ __device__ inline size_t prechain_lds_doubles(int K) { return chain_scratch_doubles(K) + 3 * (size_t)even_up(9 * K) + chain_slab_doubles(K) + 8; }
+
+struct ChainSrcSlab {
+    const DevP& P; const ChainSlab& B; const double* scB; const double* dcB; const double* uB; double mu;
+    __device__ __forceinline__ double diag(int k, int i, int j) const { return B.dg[45 * k + (i * (i + 1) >> 1) + j]; }
+    __device__ __forceinline__ double sub(int k, int kn, int q, int c) const { return kn > k ? B.sub[81 * k + q * 9 + c] : B.sub[81 * kn + c * 9 + q]; }
+    __device__ __forceinline__ double prow(int r, int k, int c) const { return B.pb[(size_t)(9 * k + c) * B.NPs + r]; }
+    __device__ __forceinline__ double rhsraw(int j) const { return B.rhs[j - P.NV]; }
+    __device__ __forceinline__ double sc(int j) const { return scB[j - P.NV]; }
+    __device__ __forceinline__ double madd(int j) const { const double d = dcB[j - P.NV]; return mu * d * d; }
+    __device__ __forceinline__ double rowscale(int) const { return 1.0; }
+    __device__ __forceinline__ double u(int j) const { return uB[j - P.NV]; }
+    __device__ __forceinline__ void row_done(int d, int r, double zr, double&) const { st_ag(P.chZ + (size_t)d * (P.NV + 1) + r, zr); }
+    __device__ __forceinline__ void wput(double* p, double v) const { st_ag(p, v); }      // read by the tile workgroups and the master of this launch
+};
+
+// the chain workgroup (all threads of the block enter; dynamic LDS >= prechain_lds_doubles(K)); the IMU / prior records are complete
+// epoch: the launch's flag value; P.chflag[1] is posted as soon as the chain columns' scales are out (the master's vector pass reads them)
+__device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const int jacobi, double* lds, const int epoch) {
+    const int t = threadIdx.x, K = P.K, NP = P.NV, NB = 9 * K, NT = blockDim.x;
+#ifdef VIL_STAMPS
+    #define PSTAMP(k) do { if (t == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[k] = tt_; } } while (0)
+#else
+    #define PSTAMP(k) do {} while (0)
+#endif
+    PSTAMP(12);
+    const ChainLds L = chain_lds(lds, K);
+    double* scB = lds + chain_scratch_doubles(K); double* dcB = scB + even_up(NB); double* uB = dcB + even_up(NB);
+    const ChainSlab B = chain_slab(uB + even_up(NB), K);
+    if (t < 8) L.flag[t] = 0;
+    // the slab is a gather target: entries without a source (pose rows of far frames) stay zero
+    { double* z = B.dg; const int nz = (int)chain_slab_doubles(K); for (int e = t; e < nz; e += NT) z[e] = 0.0; }
+    __syncthreads();
+    // ---- gather: eight table entries per thread and round (one round at K = 10), every load of a round in flight before the first store
+    {
+        const int4* tab = (const int4*)P.chtab;
+        const int n = P.n_chtab;
+        double* slab = B.dg;
+        for (int e0 = t; e0 < n; e0 += 8 * NT) {
+            int4 q[8]; double a[8], b[8], c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = tab[min(e0 + u * NT, n - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = P.ipart[max(q[u].y, 0)]; b[u] = P.ipart[max(q[u].z, 0)];
+                const int cw = q[u].w;
+                c[u] = cw >= 0 ? P.pH[cw] : P.mpart[max(-cw - 2, 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (e0 + u * NT < n) {
+                const double v = (q[u].y >= 0 ? a[u] : 0.0) + (q[u].z >= 0 ? b[u] : 0.0) + (q[u].w != -1 ? c[u] : 0.0);
+                slab[q[u].x] = v;
+            }
+        }
+    }
+    __syncthreads();
+    PSTAMP(13);
+    const ChainSrcSlab src{P, B, scB, dcB, uB, ctl.mu};
+    if (t < NB) {
+        const int j = NP + t;
+        const double dg = src.diag(t / 9, t % 9, t % 9), b = src.rhsraw(j);
+        const double Sc = ctl.first ? (jacobi ? 1.0 / (1.0 + sqrt(dg)) : 1.0) : P.Sc[j];
+        const double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
+        scB[t] = Sc; dcB[t] = d; uB[t] = Sc * (Sc * b / d) / d;
+        st_ag(P.chSc + t, Sc); st_ag(P.chDc + t, d);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (t == 0) st_ag(P.chflag + 1, epoch);
+    PSTAMP(14);
+    double qc = 0.0;
+    chain_eliminate<true>(src, K, NP, P.chain_rs, P.chW, L, qc);
+    PSTAMP(15);
+    if (t < 128) {                                     // the two recursion waves hold the chain x chain share of u^T S' u
+        qc = wave_total(qc);
+        if ((t & 63) == 0) st_ag(P.chQ + (t >> 6), qc);
+    }
+    if (t == 0) st_ag(P.chOk, L.flag[5] ? 0 : 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every thread's W^T / chZ / chQ stores are out ...
+    __syncthreads();
+    if (t == 0) st_ag(P.chflag, epoch);                  // ... W^T is complete: the tile workgroups start
+    // ---- off the critical path (the master needs these for the chain back substitution, 30 us from now): the INVERSES of the factored
+    //      diagonal blocks (one column per lane: x = L^-1 e_c by forward substitution) and the sub-diagonal blocks
+    for (int it = t; it < 9 * K; it += NT) {
+        const int k = it / 9, cc = it - 9 * k;
+        const double* l = L.Ldg + 54 * k; const double* r = l + 45;
+        double x[9];
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            double acc = p == cc ? 1.0 : 0.0;
+#pragma unroll
+            for (int q = 0; q < p; ++q) acc -= l[(p * (p + 1) >> 1) + q] * x[q];
+            x[p] = p < cc ? 0.0 : acc * r[p];
+        }
+#pragma unroll
+        for (int p = 0; p < 9; ++p) if (p >= cc) st_ag(P.chLdg + 54 * k + (p * (p + 1) >> 1) + cc, x[p]);
+    }
+    for (int e = t; e < 82 * K; e += NT) st_ag(P.chLsb + e, L.Lsb[e]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) st_ag(P.chflag + 2, epoch);
+    PSTAMP(16);
+}
+
+// One 16 x 16 tile (I, J), J <= I, of W W^T per workgroup (its first 256 threads: the four waves split the chain columns, their
+// accumulators are added through LDS).  W^T: column j of the chain at chW[j * RS + row], rows = pose part + the right-hand-side row.
+// Output in the tiled lower layout of the step kernel (TILE_RS = 17).
+__device__ __forceinline__ void prechain_ww_tile(const DevP& P, const int tile) {
+    typedef double d4_ __attribute__((ext_vector_type(4)));
+    __shared__ double acc_s[4][256];
+    if (threadIdx.x >= 256) return;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, row = lane & 15, kq = lane >> 4;
+    const int NB = 9 * P.K, RS = P.chain_rs, R = P.NV + 1;
+    int I = 0; while ((I + 1) * (I + 2) / 2 <= tile) ++I;
+    const int J = tile - I * (I + 1) / 2;
+    const bool va = (I << 4) + row < R, vb = (J << 4) + row < R;
+    const double* pa = P.chW + (size_t)kq * RS + (I << 4) + row;
+    const double* pb = P.chW + (size_t)kq * RS + (J << 4) + row;
+    d4_ c4 = {0.0, 0.0, 0.0, 0.0};
+    // k-steps of four chain columns, dealt round-robin to the waves; rows beyond R / columns beyond NB are masked (chW is padded, never read out of bounds)
+    const int nk = (NB + 3) >> 2;
+    for (int ks = wave; ks < nk; ks += 4) {
+        const bool kv = 4 * ks + kq < NB;
+        const double av = ld_ag(pa + (size_t)4 * ks * RS), bv = ld_ag(pb + (size_t)4 * ks * RS);      // written by the chain workgroup of this launch
+        c4 = __builtin_amdgcn_mfma_f64_16x16x4f64((va && kv) ? av : 0.0, (vb && kv) ? bv : 0.0, c4, 0, 0, 0);
+    }
+    // accumulator element g of a lane = (row (lane >> 4) + 4 g, column lane & 15) of the tile
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc_s[wave][(((lane >> 4) + 4 * g) << 4) + (lane & 15)] = c4[g];
+    __syncthreads();
+    {
+        const int r = t >> 4, c = t & 15;
+        const double v = (acc_s[0][t] + acc_s[1][t]) + (acc_s[2][t] + acc_s[3][t]);
+        st_ag(P.chWW + (size_t)tile * (16 * 17) + r * 17 + c, v);
+    }
+}
+
+}  // namespace vd

@@ -192,19 +192,10 @@ template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
 }
 static_assert(VIL_STEP_THREADS == 512, "the tile <-> element mapping above assumes two tiles per 512-thread stride");
 
-// sqrt(x) and 1/sqrt(x) together: hardware rsq seed + two coupled Newton steps (no divide on the pivot chain)
-__device__ __forceinline__ void sqrt_rsqrt(double x, double& sq, double& rs) {
-    // v_rsq_f64 seeds ~2^-26; one coupled Newton step squares that (the pivot chain is latency-bound: every
-    // dependent fp64 op costs ~32 cycles), a residual correction on sqrt keeps it within an ulp or two
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    const double e = fma(-h, g, 0.5);
-    g = fma(g, e, g); h = fma(h, e, h);
-    sq = fma(fma(-g, g, x), h, g); rs = h + h;
-}
 __device__ __forceinline__ int tri_off(int i) { return (i * (i + 1)) >> 1; }
 }  // namespace vd
 #include "vil_chain.hpp"
+#include "vil_prechain.hpp"
 namespace vd {
 
 // ---- tiled lower storage of the (D+1) x (D+1) reduced matrix (last row = right-hand side): 16 x 16 tiles,
@@ -520,6 +511,7 @@ struct ChainSrcStep {                      // the chain's view of the system ins
     __device__ __forceinline__ double rowscale(int r) const { return sc_[r]; }
     __device__ __forceinline__ double rhsraw(int j) const { return gd_[j]; }
     __device__ __forceinline__ void row_done(int, int r, double zr, double& q) const { q += 2.0 * u_[r] * zr; }
+    __device__ __forceinline__ void wput(double* p, double v) const { *p = v; }
 };
 
 template <bool WLDS, class PUB, class SIDE>
@@ -636,12 +628,136 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
     return true;
 }
 
+// ---- chain eliminated ahead by the extra workgroup of k_sweep, W W^T contracted by k_reduce (vil_prechain.hpp): pack the pose tiles as
+//      M_pp = Sc (S'_pp - W W^T) Sc + mu d^2 (the row scaling the chain workgroup deferred is applied here), dense part, chain back
+//      substitution.  Same contract as solve_chain.
+template <class PUB, class SIDE>
+__device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart, PUB pub, SIDE side) {
+    const int t = threadIdx.x;
+    SSTAMP(0);
+    const int K = P.K, D = P.D, NP = P.NV, R = NP + 1, T = (R + 15) >> 4, ntile = (T * (T + 1)) >> 1;
+    const int RS = P.chain_rs, NB = 9 * K, m = K >> 1;
+    double* Tl = lds;
+    const double* Wt = P.chW;
+    double* Ldg = lds + ntile * TILE_SZ; double* Lsb = Ldg + 54 * K; double* tB = Lsb + 82 * K;
+    {   // pose tiles (+ rhs row) from S' alone, their share of u^T S' u -- the chain / tile workgroups of this launch are usually still at work
+        const int NE = ntile << 8;
+        for (int e0 = t; e0 < NE; e0 += 8 * VIL_STEP_THREADS) {
+            double v[8]; int ii[8], jj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(e0 + VIL_STEP_THREADS * u, NE - 1), tile = e >> 8, w = e & 255;
+                ii[u] = (s.tI[tile] << 4) + (w >> 4); jj[u] = (s.tJ[tile] << 4) + (w & 15);
+                v[u] = ld_ag(sb.S + (size_t)min(ii[u], NP - 1) * D + min(jj[u], NP - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + VIL_STEP_THREADS * u;
+                if (e >= NE) break;
+                const int i = ii[u], j = jj[u];
+                double mv = 0.0;
+                if (i < NP && j <= i) {
+                    if (cam) qpart += (i == j ? 1.0 : 2.0) * s.y[i] * v[u] * s.y[j];
+                    mv = s.sc[i] * v[u] * s.sc[j];
+                    if (i == j) mv += mu * s.dcs[i] * s.dcs[i];
+                } else if (i == NP && j < NP) mv = s.sc[j] * s.gd[j];
+                Tl[tl_phys(e)] = mv;
+            }
+        }
+    }
+    {   // the chain workgroup and the W W^T tile workgroups of this launch are done (a tile's flag implies the chain's)
+        const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
+        for (int i = t; i < P.n_ww; i += VIL_STEP_THREADS) while (__hip_atomic_load(P.wwflag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+        __syncthreads();                               // (everything they left is read at agent scope below: no fence)
+    }
+    SSTAMP(1);
+    {   // M_pp -= Sc (W W^T) Sc: each thread on the very elements it packed (same index map: no barrier in between)
+        const int NE = ntile << 8;
+        for (int e0 = t; e0 < NE; e0 += 8 * VIL_STEP_THREADS) {
+            double ww[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ww[u] = ld_ag(P.chWW + tl_phys(min(e0 + VIL_STEP_THREADS * u, NE - 1)));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + VIL_STEP_THREADS * u;
+                if (e >= NE) break;
+                const int tile = e >> 8, w = e & 255, i = (s.tI[tile] << 4) + (w >> 4), j = (s.tJ[tile] << 4) + (w & 15);
+                if (i <= NP && j <= i && j < NP) Tl[tl_phys(e)] -= (i < NP ? s.sc[i] : 1.0) * ww[u] * s.sc[j];
+            }
+        }
+        if (cam) {                                     // chain share of u^T S' u: chain x chain + 2 u_p . (S'_pb u_b)
+            if (t < NP) qpart += 2.0 * s.y[t] * (ld_ag(P.chZ + t) + ld_ag(P.chZ + R + t));
+            if (t == 0) qpart += ld_ag(P.chQ) + ld_ag(P.chQ + 1);
+        }
+        if (t == 0 && !ld_ag(P.chOk)) s.ok = 0;
+    }
+    __syncthreads();
+    SSTAMP(2); SSTAMP(3);
+    if (!s.ok) return false;
+    if (!chol_blocked<true>(Tl, NP, s)) return false;
+    SSTAMP(4);
+    back_subst(Tl, NP, s);
+    pub();
+    SSTAMP(5);
+    {   // the chain workgroup's last act (long done by now): inverses of the factored diagonal blocks, sub-diagonal blocks
+        const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
+        if (t == 0) while (__hip_atomic_load(P.chflag + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+        for (int e = t; e < 54 * K; e += VIL_STEP_THREADS) Ldg[e] = ld_ag(P.chLdg + e);
+        for (int e = t; e < 82 * K; e += VIL_STEP_THREADS) Lsb[e] = ld_ag(P.chLsb + e);
+    }
+    {   // t = y_b - W^T x_p with the deferred row scaling (the right-hand-side row of W^T carries y_b)
+        const int G = (4 * NB <= VIL_STEP_THREADS) ? 4 : 2;
+        const int j = t / G, part = t - j * G;
+        const int jc = min(j, NB - 1);
+        // all of a thread's loads in flight together (W^T comes from the chain workgroup through L2: one round trip, not 17)
+        double acc = 0.0, wv[24];
+        const int nr = (NP - part + G - 1) / G;            // rows part, part + G, ... < NP
+#pragma unroll
+        for (int q = 0; q < 24; ++q) wv[q] = ld_ag(Wt + (size_t)jc * RS + min(part + q * G, NP - 1));
+#pragma unroll
+        for (int q = 0; q < 24; ++q) { const int rr = min(part + q * G, NP - 1); acc += (q < nr ? wv[q] : 0.0) * s.sc[rr] * s.y[rr]; }
+        for (int q = 24; q < nr; ++q) { const int rr = part + q * G; acc += ld_ag(Wt + (size_t)jc * RS + rr) * s.sc[rr] * s.y[rr]; }
+        acc += __shfl_xor(acc, 1, 64);
+        if (G == 4) acc += __shfl_xor(acc, 2, 64);
+        if (j < NB && part == 0) tB[j] = ld_ag(Wt + (size_t)j * RS + NP) - acc;
+    }
+    __syncthreads();
+    // x_k = L_kk^-T (t_k - Ls_k^T x_next) with the INVERSE of L_kk the chain workgroup left (Ldg here holds L^-1, 45 entries per block): two
+    // nine-term dot products per block on nine lanes instead of a 45-step substitution of one lane
+    auto block_back = [&](const double* Li, const double* Ls, double* tk, const double* xn, double* xo) {
+        const int lane = t & 63;
+        if (lane < 9 && Ls) {
+            double v = tk[lane];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) v -= Ls[i * 9 + lane] * xn[i];
+            tk[lane] = v;
+        }
+        CHAIN_FENCE();
+        if (lane < 9) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { const double li = i >= lane ? Li[(i * (i + 1) >> 1) + lane] : 0.0; if (i & 1) a1 += li * tk[i]; else a0 += li * tk[i]; }
+            xo[lane] = a0 + a1;
+        }
+        CHAIN_FENCE();
+    };
+    if (t < 64) block_back(Ldg + 54 * m, nullptr, tB + 9 * m, nullptr, s.y + NP + 9 * m);
+    __syncthreads();
+    if (t < 64) { for (int k = m - 1; k >= 0; --k) block_back(Ldg + 54 * k, Lsb + 82 * k, tB + 9 * k, s.y + NP + 9 * (k + 1), s.y + NP + 9 * k); }
+    else if (t < 128) { for (int k = m + 1; k < K; ++k) block_back(Ldg + 54 * k, Lsb + 82 * k, tB + 9 * k, s.y + NP + 9 * (k - 1), s.y + NP + 9 * k); }
+    else if (t >= VIL_STEP_THREADS - 64) side();
+    __syncthreads();
+    SSTAMP(6);
+    return true;
+}
+
 }  // namespace vd
 
 // The step kernel is the same on one GPU and on N: in the multi-GPU path the whole linear-system set has been all-reduced
 // before it starts (vilsolve.hip: view), so every rank runs it on identical data.
 // CHAIN 0: dense factorisation of all D columns (LDSM: tile array in LDS or global).  CHAIN 1 / 2: vil_chain.hpp, with W^T in
-// LDS / in global memory (tiles always in LDS).
+// LDS / in global memory (tiles always in LDS).  CHAIN 3: the chain was eliminated by the extra workgroup of k_sweep (vil_prechain.hpp).
 //
 // Landmarks never enter the step kernel's serial part: per landmark the pass after the solve leaves the two step directions
 //   la = Sl gradient_l / dl  (Cauchy direction),  lb = Sl gn_l / dl  (Gauss-Newton direction)
@@ -661,9 +777,25 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     // xflag -- the master has published Sc x_p; xstat -- it has given up for this launch (the helpers poll both at once);
     // hflag2[8 k + w] -- wave w of helper k has left the sums of its second pass (no block reduction on that path).
     // Only the master writes Ctl / the camera candidate, after every helper has signalled hflag.
-    const int bid = (int)blockIdx.x;
-    const bool helper = bid > 0;
-    const int nhelp = (int)gridDim.x - 1;
+    // One GPU (P.rs_merged): the gather of the sweep's partial records rides in this launch -- grid = [master | helpers | chain workgroup |
+    // W W^T tile workgroups | gather workgroups]; whoever is done posts the launch epoch in its flag, and master, helpers and tile workgroups
+    // wait for what they read.  The waiting workgroups have the lowest block indices (dispatched first); everything they wait for is finite.
+    const int nhelp = P.n_help;
+    const bool merged = P.rs_merged != 0;
+    // roles by `bid`: 0 master, 1 .. nhelp helpers, then chain, tiles, gather.  The hardware dispatches in blockIdx order and the chain workgroup
+    // is the longest path into the dense part, the gather the next: physical order [chain | gather | master | helpers | tiles]
+    int bid = (int)blockIdx.x;
+    if (merged) {
+        const int pc = P.prechain ? 1 : 0, p0 = (int)blockIdx.x;
+        if (pc && p0 == 0) bid = 1 + nhelp;
+        else if (p0 - pc < P.n_gather) bid = 1 + nhelp + pc + P.n_ww + (p0 - pc);
+        else { const int q = p0 - pc - P.n_gather; bid = q <= nhelp ? q : 1 + nhelp + pc + (q - 1 - nhelp); }
+    }
+#ifdef VIL_STAMPS
+    if (bid == 0 && t == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[30] = tt_; }
+#endif
+    const int b_chain = 1 + nhelp, b_ww = b_chain + ((merged && P.prechain) ? 1 : 0), b_gather = b_ww + (merged ? P.n_ww : 0);
+    const bool helper = bid > 0 && bid <= nhelp;
     {   // Ctl (1.5 kB with its traces) into LDS: one coalesced load per lane, not 190 loads of a lone lane with everybody waiting at the barrier
         const double* src = (const double*)P.ctl; double* dst = (double*)&s.c;
         for (int i = t; i < (int)(sizeof(Ctl) / 8); i += NT) dst[i] = src[i];
@@ -685,6 +817,20 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
 #endif
     if (s.c.done) return;                    // finished in an earlier launch: nobody writes anything
     const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
+    // completion of a whole workgroup: what it leaves for other workgroups of the launch is stored at agent scope (st_ag), so every thread only
+    // waits for its own stores (__syncthreads does not), then one flag; the readers poll relaxed and load at agent scope (ld_ag) -- no fences
+    auto rs_signal = [&](int* f) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (t == 0) __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto rs_wait = [&](const int* f, int n) {
+        for (int i = t; i < n; i += NT) while (__hip_atomic_load(f + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+    };
+    if (merged && bid >= b_ww) {
+        if (t >= VIL_THREADS) return;                  // these two roles are 256-thread roles: the upper waves leave before the first barrier
+        if (bid >= b_gather) { reduce_gather<true>(P, s.c); rs_signal(P.gflag + (bid - b_gather)); return; }
+        rs_wait(P.chflag, 1); prechain_ww_tile(P, bid - b_ww); rs_signal(P.wwflag + (bid - b_ww)); return;
+    }
+    if (merged && P.prechain && bid == b_chain) { prechain_wg(P, s.c, O.jacobi_scaling, Alds, epoch); return; }      // (posts chflag[0 .. 2] itself)
+    if (merged) rs_wait(P.gflag, P.n_gather);          // master and helpers: the candidate's cost, gradient and diagonal (and S') are complete
     // Everything the master and its helpers hand each other inside this launch (hpart, hpart2, stepc) is stored AND loaded with agent-scope
     // atomics, i.e. at the level all XCDs share, so a flag only has to be ordered after the poster's own stores (s_waitcnt).  A release
     // fence would also write back the XCD's L2 and an acquire invalidate the reader's: microseconds on the critical path, for data
@@ -702,14 +848,15 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     };
     // master: every helper has read Ctl (one lane per helper: the polls overlap instead of queueing behind one another)
     bool hseen = false;
-    auto wait_helpers = [&]() { if (!hseen && t < nhelp) wait1(P.hflag + t); hseen = true; };
+    // (... and, gather + step in one launch: the chain / tile workgroups have read Ctl too -- a tile's flag implies the chain's; n_ww <= 45)
+    auto wait_helpers = [&]() { if (!hseen && t < nhelp) wait1(P.hflag + t); if (!hseen && merged && P.prechain && t < P.n_ww) wait1(P.wwflag + t); hseen = true; };
     const bool cam = true;             // (every rank holds the complete system: nothing is counted per rank any more)
     STAMP(0);
     // ---------------- judge the candidate that the sweep just linearised -------------------------
     if (t == 0) {
         Ctl& c = s.c;
         const int cand = 1 - c.cur;
-        const double cand_cost = *P.sys[cand].cost;
+        const double cand_cost = merged ? ld_ag(P.sys[cand].cost) : *P.sys[cand].cost;
         c.cand_cost = cand_cost;
         if (c.first && *P.setup_stat != 0) { c.done = 1; c.term = 6; c.status = *P.setup_stat; }      // k_setup: an IMU covariance is not positive definite (resident window: or its prior is not finite)
         if (c.first || c.resweep) {
@@ -812,7 +959,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         if (!s.c.done && s.need) {
             // camera vectors u = Sc gradient_/d in LDS (nothing global is written here: that is the master's job)
             for (int i = t; i < P.NV; i += NT) {
-                const double dg = sb.diag[i], b = sb.bc[i];
+                const double dg = merged ? ld_ag(sb.diag + i) : sb.diag[i], b = merged ? ld_ag(sb.bc + i) : sb.bc[i];
                 const double Sc = s.was_first ? (O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0) : P.Sc[i];
                 const double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
                 s.y[i] = Sc * (Sc * b / d) / d;
@@ -918,13 +1065,15 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     if (s.need) {
         // ---- camera vectors: Jacobi scaling (first linearisation), dogleg diagonal, gradient_, u = Sc gradient_/d
         double gm = 0;
+        if constexpr (CHAIN == 3) { if (t == 0) wait1(P.chflag + 1); __syncthreads(); }      // the chain workgroup's scales of the chain columns are out
         for (int i = t; i < D; i += NT) {
-            const double dg = sb.diag[i], b = sb.bc[i];
+            const double dg = merged ? ld_ag(sb.diag + i) : sb.diag[i], b = merged ? ld_ag(sb.bc + i) : sb.bc[i];
             double Sc;
-            if (s.was_first) { Sc = O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0; P.Sc[i] = Sc; } else Sc = P.Sc[i];
-            const double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
+            if (s.was_first) { Sc = O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0; if (CHAIN == 3 && i >= P.NV) Sc = ld_ag(P.chSc + (i - P.NV)); P.Sc[i] = Sc; } else Sc = P.Sc[i];
+            double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
+            if (CHAIN == 3 && i >= P.NV) d = ld_ag(P.chDc + (i - P.NV));      // the very numbers the chain workgroup scaled M_bb with
             const double g = Sc * b / d;
-            s.sc[i] = Sc; s.dcs[i] = d; s.gr[i] = g; s.y[i] = Sc * g / d; s.gd[i] = sb.gred[i]; s.rt[i] = Sc / d;
+            s.sc[i] = Sc; s.dcs[i] = d; s.gr[i] = g; s.y[i] = Sc * g / d; s.gd[i] = merged ? ld_ag(sb.gred + i) : sb.gred[i]; s.rt[i] = Sc / d;
             P.dc[i] = d; P.gradc[i] = g;
             if (cam) { g2 += g * g; gm = fmax(gm, fabs(b)); }
         }
@@ -945,7 +1094,8 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                 gather2(h, true);
                 if ((t & 63) == 63) for (int e = 0; e < 9; ++e) s.hs[e] = h[e];
             };
-            ok = solve_chain<CHAIN == 1>(P, sb, s, Alds, mu, cam, q, pub, side);      // packing, chain, Schur update, dense part, back substitution
+            if constexpr (CHAIN == 3) ok = solve_prechain(P, sb, s, Alds, mu, cam, q, pub, side);
+            else ok = solve_chain<CHAIN == 1>(P, sb, s, Alds, mu, cam, q, pub, side);      // packing, chain, Schur update, dense part, back substitution
         } else {
         // tiled storage: element e of the tile array -> (i, j); S entries were prefetched into registers at kernel start
         double* Ag = P.M;
@@ -1013,7 +1163,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         if (!defer && gm <= O.gradient_tolerance) {
             if (!xpub) publish_xp(0);
             if (t == 0) { s.c.done = 1; s.c.term = 2; }
-            if (t < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); store_ctl(); }
+            if (t < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); wait_helpers(); store_ctl(); }
             return;
         }
         if constexpr (CHAIN == 0) { if constexpr (LDSM) ok = chol_blocked<true>(Alds, D, s); else ok = chol_blocked<false>(P.M, D, s, Alds); }      // Alds = staging of the active tile column
@@ -1072,7 +1222,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             }
             if (defer && gm <= O.gradient_tolerance) {          // (the check the other paths make before the factorisation)
                 if (t == 0) { s.c.done = 1; s.c.term = 2; }
-                if (t < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); store_ctl(); }
+                if (t < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); hseen = false; wait_helpers(); store_ctl(); }
                 return;
             }
         }
@@ -1162,5 +1312,5 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     __syncthreads();
     if (s.c.resweep && !s.c.done) { for (int i = t; i < 16 * P.K + 8; i += NT) xc[i] = s.x0[i]; }
     STAMP(7);
-    if (t < 64) { if (nhelp) wait_helpers(); store_ctl(); }      // (no second poll when the sums were already collected)
+    if (t < 64) { wait_helpers(); store_ctl(); }      // (no second poll when the sums were already collected)
 }

@@ -19,6 +19,7 @@
 #include "vil_dev.hpp"
 #include "vil_factors.hpp"
 #include "vil_finish.hpp"
+#include "vil_prechain.hpp"
 
 namespace vd {
 
@@ -489,8 +490,11 @@ __device__ __forceinline__ int imu_local(const DevP& P, int i, int j, int col) {
 //   accumulated with LDS atomics inside a visual workgroup, so two runs agree to rounding, not bit for bit).
 //   The last workgroup handles the vectors and the cost.
 #define RED_EPW 32
+// AG: the results are stored at agent scope (gather + step in one launch: the master reads them in the same launch)
+template <bool AG = false>
 __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl) {
     using namespace vd;
+    auto put = [](double* p, double v) { if (AG) st_ag(p, v); else *p = v; };
     if (threadIdx.x >= VIL_THREADS) return;
     const int cand = 1 - ctl.cur;
     SysBuf sb = P.sys[cand];
@@ -566,9 +570,9 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl) {
         double s = 0.0, dd = 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) { s += part[0][q][el]; dd += part[1][q][el]; }
-        sb.S[(size_t)i * D + j] = s;
-        sb.S[(size_t)j * D + i] = s;
-        if (i == j) sb.diag[i] = s + (i < NV ? dd : 0.0);   // un-reduced diagonal: add back the Schur term of the visual part
+        put(sb.S + (size_t)i * D + j, s);
+        put(sb.S + (size_t)j * D + i, s);
+        if (i == j) put(sb.diag + i, s + (i < NV ? dd : 0.0));   // un-reduced diagonal: add back the Schur term of the visual part
         return;
     }
     // ---- gradient vectors bc / gred: 2D entries, same 8-slice scheme -------------------------------------------------
@@ -601,7 +605,7 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl) {
         double sum = 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) sum += part[0][q][el];
-        (which ? sb.gred : sb.bc)[i] = sum;
+        put((which ? sb.gred : sb.bc) + i, sum);
         return;
     }
     // ---- cost (one workgroup, tree reduction) ---------------------------------------------------------------------
@@ -616,10 +620,11 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl) {
     c = wave_sum(c);                                   // (256 live threads: four waves)
     if ((t & 63) == 0) red[t >> 6] = c;
     __syncthreads();
-    if (t == 0) sb.cost[0] = red[0] + red[1] + red[2] + red[3];
+    if (t == 0) put(sb.cost, red[0] + red[1] + red[2] + red[3]);
 }
 
-// Gather of the sweep's partial records (reduce_gather above): 256 threads, a handful of registers.
+// Gather of the sweep's partial records (reduce_gather above) as a launch of its own: vil_linearize / the marginalisation (no step kernel
+// behind it) and the multi-GPU path (the collective sits between gather and step).  A solve on one GPU gathers inside k_step (rs_merged).
 __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
     const Ctl ctl = *P.ctl;
     if (ctl.done) return;

@@ -116,7 +116,7 @@ struct vil_ctx {
     size_t off_x0 = 0;             // backup of the uploaded state (device)
     double* d_x0 = nullptr;
     std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
-    int n_blocks_sweep = 0, n_blocks_reduce = 0;
+    int n_blocks_sweep = 0, n_blocks_reduce = 0, n_ww = 0;      // n_ww: tiles of W W^T formed by extra workgroups of k_reduce (vil_prechain.hpp)
     size_t lds_sweep = 0, lds_step = 0, lds_reduce = 0;
     size_t span = 0;               // doubles of one linear-system set (SysBuf::ar): the multi-GPU all-reduce message
     bool step_lds = false;
@@ -635,6 +635,50 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     put(nullptr, 8 * (size_t)D, (void**)&P.tmpc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.tmpl);
     put(nullptr, sizeof(Ctl), (void**)&P.ctl);
     put(nullptr, 8 * 64, (void**)&P.dbg);
+    // ---- chain eliminated ahead of the step kernel (vil_prechain.hpp): every IMU factor joins frames (k, k+1), at most one per pair, single GPU.
+    //      The gather table is built here once per upload: the chain workgroup then sums <= 3 sources per entry in a fixed order.
+    bool pre_ok = !sharded && !c->force_split && L >= 0 && K >= 3 && VIL_TUNE_ENV("VIL_NO_PRECHAIN") == nullptr;
+    std::vector<int> as_i(K, -1), as_j(K, -1);
+    for (int f = 0; f < p->n_imu && pre_ok; ++f) {
+        const int i = p->imu_i[f], j = p->imu_j[f];
+        if (j != i + 1 || as_i[i] >= 0 || as_j[j] >= 0) pre_ok = false; else { as_i[i] = f; as_j[j] = f; }
+    }
+    if (pre_ok && 8 * vd::prechain_lds_doubles(K) > 150 * 1024) pre_ok = false;       // the staged slab must fit LDS (K <= 12)
+    {
+        const int rs = vd::chain_rs(K);
+        put(nullptr, 8 * (size_t)vd::chain_wcols(K) * rs, (void**)&P.chW);
+        put(nullptr, 8 * (size_t)54 * K, (void**)&P.chLdg); put(nullptr, 8 * (size_t)82 * K, (void**)&P.chLsb);
+        put(nullptr, 8 * (size_t)9 * K, (void**)&P.chSc); put(nullptr, 8 * (size_t)9 * K, (void**)&P.chDc);
+        put(nullptr, 8 * (size_t)2 * (NV + 1), (void**)&P.chZ); put(nullptr, 8 * 4, (void**)&P.chQ); put(nullptr, 16, (void**)&P.chOk);
+        { const int NLg = (D * (D + 1) / 2 + RED_EPW - 1) / RED_EPW + (2 * D + RED_EPW - 1) / RED_EPW + 1; put(nullptr, 4 * (size_t)(NLg + 8), (void**)&P.gflag); }
+        put(nullptr, 64, (void**)&P.chflag); put(nullptr, 4 * 64, (void**)&P.wwflag);
+        { const size_t Tp = (size_t)(NV + 1 + 15) / 16; put(nullptr, 8 * (size_t)TILE_SZ * (Tp * (Tp + 1) / 2), (void**)&P.chWW); }
+    }
+    if (pre_ok) {
+        const int NPs = vd::chain_slab_nps(K), pn = P.pn;
+        const int o_dg = 0, o_sub = vd::even_up(45 * K), o_pb = o_sub + vd::even_up(81 * K), o_rhs = o_pb + 9 * K * NPs;
+        std::vector<int> tab;
+        auto ip = [&](int f, int la, int lb) { return f < 0 ? -1 : f * 931 + la * 30 + lb; };
+        auto pr = [&](int r, int col) { if (pn <= 0) return -1; const int pi = pinv[r], pj = pinv[col]; return (pi >= 0 && pj >= 0) ? pi * pn + pj : -1; };
+        auto emit = [&](int dst, int a, int b, int cc) { if (a < 0 && b < 0 && cc == -1) return; tab.push_back(dst); tab.push_back(a); tab.push_back(b); tab.push_back(cc); };
+        for (int k = 0; k < K; ++k) {
+            const int fi = as_i[k], fj = as_j[k];
+            for (int i = 0; i < 9; ++i) for (int j = 0; j <= i; ++j) emit(o_dg + 45 * k + i * (i + 1) / 2 + j, ip(fi, 6 + i, 6 + j), ip(fj, 21 + i, 21 + j), pr(NV + 9 * k + i, NV + 9 * k + j));
+            if (k + 1 < K) for (int q = 0; q < 9; ++q) for (int cc = 0; cc < 9; ++cc) emit(o_sub + 81 * k + q * 9 + cc, ip(fi, 21 + q, 6 + cc), -1, pr(NV + 9 * (k + 1) + q, NV + 9 * k + cc));
+            for (int cc = 0; cc < 9; ++cc) {
+                const int pj = pn > 0 ? pinv[NV + 9 * k + cc] : -1;
+                emit(o_rhs + 9 * k + cc, fi < 0 ? -1 : fi * 931 + 900 + 6 + cc, fj < 0 ? -1 : fj * 931 + 900 + 21 + cc, pj >= 0 ? -pj - 2 : -1);
+                for (int r = 0; r < NV; ++r) {
+                    const int fr = r < 6 * K ? r / 6 : -9, lr = r - 6 * fr;
+                    const int a = (fi >= 0 && (fr == k || fr == k + 1)) ? ip(fi, fr == k ? lr : 15 + lr, 6 + cc) : -1;
+                    const int b = (fj >= 0 && (fr == k - 1 || fr == k)) ? ip(fj, fr == k - 1 ? lr : 15 + lr, 21 + cc) : -1;
+                    emit(o_pb + (9 * k + cc) * NPs + r, a, b, pr(r, NV + 9 * k + cc));
+                }
+            }
+        }
+        P.n_chtab = (int)tab.size() / 4;
+        put(tab.data(), 4 * tab.size(), (void**)&P.chtab);
+    }
     if (const char* ev = VIL_TUNE_ENV("VIL_SKIP")) P.skip_mask = atoi(ev);
     // helper workgroups of the step kernel: worth it once every master thread would own more than one landmark
     P.n_help = L >= 2 * VIL_STEP_THREADS ? 7 : (L >= VIL_STEP_THREADS ? 3 : 0);
@@ -714,11 +758,26 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             if (8 * (tiles + wt + scr) + fixed <= 160 * 1024) { P.chain = 1; c->lds_step = 8 * (tiles + wt + scr); }
             else if (8 * (tiles + scr) + fixed <= 160 * 1024) { P.chain = 2; c->lds_step = 8 * (tiles + scr); }
         }
-        c->P.chain = P.chain; c->P.chain_rs = P.chain_rs;
+        // one GPU, chain windows up to K = 12: gather + step in ONE launch with the chain eliminated beside the gather (vil_prechain.hpp).
+        // (Larger windows keep the separate gather: with ~100 kB of dynamic LDS per workgroup their ~1500 gather workgroups would need
+        //  six rounds on 256 compute units; the small gather kernel runs eight workgroups per unit.)
+        const bool merged = !c->split && pre_ok && P.chain != 0 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
+        P.prechain = merged ? 1 : 0;
+        c->n_ww = 0;
+        if (P.prechain) {
+            const size_t Tp = (size_t)(NV + 1 + 15) / 16, tiles = (size_t)TILE_SZ * (Tp * (Tp + 1) / 2);
+            P.chain = 3;
+            c->lds_step = std::max(8 * (tiles + 54 * (size_t)K + 82 * (size_t)K + vd::even_up(9 * K) + 16), 8 * vd::prechain_lds_doubles(K));      // (the chain workgroup is one of this launch's)
+            c->n_ww = (int)(Tp * (Tp + 1) / 2);
+        }
+        c->P.chain = P.chain; c->P.chain_rs = P.chain_rs; c->P.prechain = P.prechain;
+        c->P.rs_merged = merged ? 1 : 0; c->P.n_ww = c->n_ww; c->P.n_gather = merged ? c->n_blocks_reduce : 0;
     }
     if (P.chain) {
         c->step_lds = true;
-        if (P.chain == 1) {
+        if (P.chain == 3) {
+            if ((int)c->lds_step > c->attr_step[4]) { HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step)); c->attr_step[4] = (int)c->lds_step; }
+        } else if (P.chain == 1) {
             if ((int)c->lds_step > c->attr_step[1]) { HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step)); c->attr_step[1] = (int)c->lds_step; }
         } else {
             if ((int)c->lds_step > c->attr_step[2]) { HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step)); c->attr_step[2] = (int)c->lds_step; }
@@ -873,16 +932,19 @@ static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
     return VIL_OK;
 }
 static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr) {
-    hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce), dim3(VIL_THREADS), 0, c->stream, view(c, 0));
+    const bool merged = step && c->P.rs_merged;          // one GPU: the gather rides in the step kernel's launch (vil_step.hpp)
+    if (!merged) hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce), dim3(VIL_THREADS), 0, c->stream, view(c, 0));
     if (ev_mid) hipEventRecord(ev_mid, c->stream);
     if (c->split) {                                    // the one collective of the iteration
         const int st = all_reduce2(c, c->P.sys[0].ar, c->P.sys[1].ar, c->span);
         if (st != VIL_OK) return st;
     }
     if (!step) return VIL_OK;
-    const DevP Ps = view(c, 1);
-    const dim3 g(1 + c->P.n_help), b(VIL_STEP_THREADS);
-    if (c->P.chain == 1) hipLaunchKernelGGL((k_step<true, 1>), g, b, c->lds_step, c->stream, Ps, so);
+    DevP Ps = view(c, 1);
+    if (!merged) { Ps.rs_merged = 0; Ps.n_ww = 0; Ps.n_gather = 0; }
+    const dim3 g(1 + c->P.n_help + (merged ? (c->P.prechain ? 1 : 0) + c->n_ww + c->n_blocks_reduce : 0)), b(VIL_STEP_THREADS);
+    if (c->P.chain == 3) hipLaunchKernelGGL((k_step<true, 3>), g, b, c->lds_step, c->stream, Ps, so);
+    else if (c->P.chain == 1) hipLaunchKernelGGL((k_step<true, 1>), g, b, c->lds_step, c->stream, Ps, so);
     else if (c->P.chain == 2) hipLaunchKernelGGL((k_step<true, 2>), g, b, c->lds_step, c->stream, Ps, so);
     else if (c->step_lds) hipLaunchKernelGGL((k_step<true, 0>), g, b, c->lds_step, c->stream, Ps, so);
     else hipLaunchKernelGGL((k_step<false, 0>), g, b, c->lds_step, c->stream, Ps, so);

@@ -25,9 +25,8 @@ v = np.array(dbg[32:40], dtype=np.int64); print("visual WG0 stamps rel:", (v - v
 print("cholesky cycles (wave 0): diag %d, panel %d, barrier after panel %d, trailing %d, barrier after trailing %d, publish+barrier %d" % (dbg[20], dbg[26], dbg[21], dbg[22], dbg[24], dbg[25]))
 print("packing loop, wave 0 own cycles:", dbg[27], " stamps 10->11:", dbg[11]-dbg[10], " 9->10:", dbg[10]-dbg[9], " 1->9:", dbg[9]-dbg[1], " 11->2:", dbg[2]-dbg[11], " 4->5:", dbg[5]-dbg[4], " 5->6:", dbg[6]-dbg[5])
 c = np.array(dbg[40:47], dtype=np.int64)
-print("chain path (cycles): init %d, chain steps %d, middle %d, schur+dense cholesky %d, dense back-subst %d, chain back-subst %d" % tuple(np.diff(c).tolist()))
-e = np.array(dbg[48:59], dtype=np.int64) - dbg[41]
-print("chain waves, ticks after the start: recursion steps", e[:6].tolist(), "middle done", int(e[6]), "| fwd row wave done", int(e[7]), "| bwd row wave done", int(e[8]), "| pack done", int(e[9]), "| q done", int(e[10]))
-f = np.array(dbg[12:18], dtype=np.int64)
-print("chain workgroup in k_sweep (ticks): wait for IMU/prior %d, stage %d, scales %d, chain (wave 0) %d, write-out %d; visual WG0 ends %d ticks after the chain WG started" % (tuple(np.diff(f).tolist()) + (int(dbg[37] - dbg[12]),)))
-print("visual workgroups: longest entry-to-exit of any of them in any launch since the upload: %d ticks" % dbg[60])
+print("solve path stamps 40..46 (ticks, deltas): entry -> [1] tiles/chain ready -> [2],[3] packed -> [4] dense cholesky -> [5] back-subst -> [6] chain back-subst:", np.diff(c).tolist())
+print("merged launch: kernel entry -> gather flags seen + Ctl loaded (stamp 0): %d ticks; 1 -> 9 (vectors): %d; 9 -> 10: %d; 10 -> solve entry: %d" % (dbg[0] - dbg[30], dbg[9] - dbg[1], dbg[10] - dbg[9], dbg[40] - dbg[10]))
+f = np.array(dbg[12:17], dtype=np.int64)
+print("chain workgroup (ticks): zero + table gather %d, scales %d, chain %d, write-out %d" % tuple(np.diff(f).tolist()))
+print("whole master: entry -> final stamp 7: %d ticks = %.1f us" % (dbg[7] - dbg[30], (dbg[7] - dbg[30]) / 2390.0))
