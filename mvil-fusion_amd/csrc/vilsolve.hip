@@ -540,7 +540,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         };
         int np_tot = p->n_plane, ne_tot = p->n_edge;
         if (res_lidar) {
-            if (sharded || (int)c->slabs.size() > K) return VIL_ERR_UNSUPPORTED;
+            if ((int)c->slabs.size() > K) return VIL_ERR_UNSUPPORTED;
             np_tot = ne_tot = 0;
             for (auto& sl : c->slabs) { np_tot += sl.np; ne_tot += sl.ne; }
         }
@@ -702,6 +702,8 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     if (ws && P.pn) { P.px0 = ws->px0; P.pJ0 = ws->pJ0; P.pr0 = ws->pr0; P.pH = ws->pH; P.pg0 = ws->pg0; P.pc0 = ws->pc0; }      // the device prior slot, contractions included
     {   // what vil_marginalize_resident will need (a few passes over int tables)
         vil_ctx::MargMeta& mm = c->mm;
+        const vil_problem* const lp = p;                  // this rank's shard (LiDAR points of pose 0: any rank's slice of a frame is non-empty when the frame is)
+        if (gp) p = gp;                                    // which blocks the collected factors touch is a property of the WHOLE window, the same on every rank
         mm.has_prior = p->prior.n > 0; mm.prior_kind.clear(); mm.prior_index.clear();
         if (mm.has_prior) { mm.prior_kind.assign(p->prior.blk_kind, p->prior.blk_kind + p->prior.nblk); mm.prior_index.assign(p->prior.blk_index, p->prior.blk_index + p->prior.nblk); }
         mm.obs0.assign(K, 0); mm.n_lm0 = 0; mm.imu01 = false; mm.use_td = p->use_td != 0;
@@ -718,6 +720,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             for (int f = 0; f < p->n_plane && !mm.lidar0; ++f) if (p->plane_pose[f] == 0) mm.lidar0 = true;
             for (int f = 0; f < p->n_edge && !mm.lidar0; ++f) if (p->edge_pose[f] == 0) mm.lidar0 = true;
         }
+        p = lp;
     }
     for (int q = 0; q < 2; ++q) {
         SysBuf& sb = P.sys[q];
@@ -838,8 +841,11 @@ static int upload_sharded(vil_ctx* c, const vil_problem* p, const vil_state* s) 
     int f0 = 0, f1 = 0;
     for (int f = 0; f < p->n_vis; ++f) { if (p->vis_l[f] < lb) f0 = f + 1; if (p->vis_l[f] < le) f1 = f + 1; }
     q.n_vis = f1 - f0; q.vis_i = p->vis_i + f0; q.vis_j = p->vis_j + f0; q.vis_l = p->vis_l + f0; q.vis_const = p->vis_const + (size_t)f0 * 14;
-    q.n_edge = ee - eb; q.edge_pose = p->edge_pose + eb; q.edge_const = p->edge_const + (size_t)eb * 9;
-    q.n_plane = pe - pb; q.plane_pose = p->plane_pose + pb; q.plane_const = p->plane_const + (size_t)pb * 7;
+    if (p->n_plane == VIL_LIDAR_RESIDENT && p->n_edge == VIL_LIDAR_RESIDENT) { /* the slabs of this context already hold this rank's slice of every frame (vil_lidar_push) */ }
+    else {
+        q.n_edge = ee - eb; q.edge_pose = p->edge_pose + eb; q.edge_const = p->edge_const + (size_t)eb * 9;
+        q.n_plane = pe - pb; q.plane_pose = p->plane_pose + pb; q.plane_const = p->plane_const + (size_t)pb * 7;
+    }
     if (c->rank != 0) { q.n_imu = 0; q.n_icp = 0; q.n_lps = 0; q.prior.n = 0; q.prior.nblk = 0; }
     c->lm_b = lb; c->lm_e = le;
     st = comm_agree(c, upload_impl(c, &q, s, true, nullptr, p, f0));       // e.g. rank 0's IMU set-up failed: every rank reports it
@@ -1452,13 +1458,18 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     q.n_lps = (int)lps_ids.size() / 2; q.lps_ids = lps_ids.data(); q.lps_const = lps_c.data();
     q.n_edge = (int)edge_pose.size(); q.edge_pose = edge_pose.data(); q.edge_const = edge_c.data();
     q.n_plane = (int)plane_pose.size(); q.plane_pose = plane_pose.data(); q.plane_const = plane_c.data();
-    int st = upload_impl(c, &q, s, false);
+    // under a communicator the collected factors are sharded like a solve's (visual by landmark owner, LiDAR points in slices, the rest on
+    // rank 0), A and b are all-reduced ONCE and every rank finishes the small dense part redundantly -- the reference's own pattern
+    // (marginalization_factor.cpp:235-264: factors dealt to four threads, private A / b, summed after the join)
+    int st = (c->world > 1 && (c->comm || c->lcomm)) ? upload_sharded(c, &q, s) : upload_impl(c, &q, s, false);
     if (st != VIL_OK) return st;
     const SolveOpts so = to_dev_opts(o);
     st = init_ctl(c, o, 2);
     if (st != VIL_OK) return st;
     launch_sweep(c, so);
-    launch_reduce_step(c, so, false);
+    st = launch_reduce_step(c, so, false);
+    if (st != VIL_OK) return st;
+    c->resident_kind = 2;
     return marg_finish(c, K, old_, drop_pose, pose_t, sb_t, ex_t, td_t, p->use_td != 0, n_lm_elim, s, out);
 }
 
@@ -1517,6 +1528,11 @@ int vil_lidar_drop(vil_ctx* c, int32_t slab) {
 int vil_lidar_push(vil_ctx* c, int32_t n_plane, const double* plane_const, int32_t n_edge, const double* edge_const) {
     if (!c || n_plane < 0 || n_edge < 0 || (n_plane > 0 && !plane_const) || (n_edge > 0 && !edge_const)) return VIL_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(c->device));
+    if (c->world > 1 && (c->comm || c->lcomm)) {       // factor set sharded over ranks: every rank is handed the whole frame and keeps its contiguous slice
+        const int pb = (int)((long long)n_plane * c->rank / c->world), pe = (int)((long long)n_plane * (c->rank + 1) / c->world);
+        const int eb = (int)((long long)n_edge * c->rank / c->world), ee = (int)((long long)n_edge * (c->rank + 1) / c->world);
+        plane_const += (size_t)7 * pb; n_plane = pe - pb; edge_const += (size_t)9 * eb; n_edge = ee - eb;
+    }
     // capacity: points per slab and number of physical slabs only ever grow (the existing slabs are copied once when they do)
     if (n_plane > c->cap_p || n_edge > c->cap_e || c->free_slots.empty()) {
         const int ncp = std::max(c->cap_p, ((n_plane + n_plane / 4 + 255) / 256) * 256), nce = std::max(c->cap_e, ((n_edge + n_edge / 4 + 255) / 256) * 256);
@@ -1564,7 +1580,7 @@ int vil_lidar_push(vil_ctx* c, int32_t n_plane, const double* plane_const, int32
 
 static int marginalize_resident_impl(vil_ctx* c, const vil_state* s, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out, const bool to_slot, vil_win_prior_info* winfo) {
     if (!c || !o || !spec || (!to_slot && (!s || !out)) || !c->uploaded || c->resident_kind != 1) return VIL_ERR_INVALID_ARGUMENT;
-    if (c->sharded) return VIL_ERR_UNSUPPORTED;
+    if (c->sharded && to_slot) return VIL_ERR_UNSUPPORTED;      // (the fully resident window is a single-GPU feature)
     const int K = c->K;
     if (K < 3 || (s && (s->K != K || s->L != c->L))) return VIL_ERR_INVALID_ARGUMENT;
     int none = 0; int& out_n = out ? out->n : none;
@@ -1607,8 +1623,9 @@ static int marginalize_resident_impl(vil_ctx* c, const vil_state* s, const vil_o
     const DevP keep = c->P;
     c->P.marg = old_ ? 1 : 2; c->P.marg_icp = icp_m; c->P.marg_lps = lps_m;
     launch_sweep(c, so);                               // the resident tables at the resident (solved, gauge-fixed) state; masks select the factors
-    launch_reduce_step(c, so, false);
+    st = launch_reduce_step(c, so, false);             // (sharded: A and b of this rank's factors, all-reduced once)
     c->P = keep;
+    if (st != VIL_OK) return st;
     c->resident_kind = 2;                              // the work space now holds the marginalisation's linearisation
     return marg_finish(c, K, old_, drop_pose, pose_t, sb_t, ex_t, td_t, mm.use_td, n_lm_elim, s, out, to_slot, winfo);
 }

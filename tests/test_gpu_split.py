@@ -90,8 +90,71 @@ for world in ((8,) if full else (2, 3)):
             if wo.prior.n:      # (a prior-less window has a 4-dof gauge null space)
                 assert np.abs(ws[r].pose - w1.pose).max() < 1e-9 and np.abs(ws[r].inv_depth - w1.inv_depth).max() < 1e-8
             assert abs(cg - co) <= 1e-11 * co and np.abs(Sg - So).max() <= 1e-9 * np.abs(So).max()
+        # sharded marginalisation (SURVEY 8e last row): the collected factors dealt to the ranks, A / b all-reduced once, the small dense part on
+        # every rank -- equal to the un-sharded marginal of the same (solved) window, bit-identical across ranks
+        if wo.prior.n and not full:
+            be1 = lib.open_vilsolve(); p1 = be1.marginalize(w1, abi.MARGIN_OLD, 0, 0); be1.close()
+            mres = [None] * world
+            def mrun(r):
+                try: mres[r] = ("ok", bes[r].marginalize(ws[r], abi.MARGIN_OLD, 0, 0))
+                except Exception as e: mres[r] = ("err", repr(e))
+            th = [threading.Thread(target=mrun, args=(r,)) for r in range(world)]
+            [t.start() for t in th]; [t.join(300) for t in th]
+            assert all(x is not None and x[0] == "ok" for x in mres), mres
+            A1 = p1.A_matrix(); sc = np.sqrt(np.outer(np.abs(np.diag(A1)) + 1e-300, np.abs(np.diag(A1)) + 1e-300))
+            for r in range(world):
+                pr = mres[r][1]
+                assert pr.c.n == p1.c.n and np.array_equal(pr.blk_kind[:pr.c.nblk], p1.blk_kind[:p1.c.nblk])
+                assert (np.abs(pr.A_matrix() - A1) / sc).max() < 2e-5, (world, cid, r)
+                assert np.array_equal(pr.J0[:pr.c.n ** 2], mres[0][1].J0[:pr.c.n ** 2]) and np.array_equal(pr.r0[:pr.c.n], mres[0][1].r0[:pr.c.n])
     for b in bes: b.close()
 print("SHARD_OK")
+'''
+
+
+RESIDENT_SCRIPT = r'''
+import sys, os, ctypes as C, threading
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import __graft_entry__ as g; g.load_package()
+from mvil_fusion_amd import abi, lib, replay
+kw = dict(K=8, n_frames=24, L=120, n_plane=2400, n_edge=800, seed=31, max_iterations=6, second_new_every=4)
+def chain(bes, n):
+    """the resident-slab chain (vil_lidar_push / vil_solve / vil_marginalize_resident) driven on every rank of `bes` in lockstep"""
+    world = len(bes)
+    rps = [replay.Replay(**kw) for _ in range(world)]
+    out = [[] for _ in range(world)]
+    def run(r):
+        be, rp = bes[r], rps[r]
+        be.set_gauge_fix(True); be.lidar_reset()
+        for k in range(rp.K): be.lidar_push(rp.lidar[k][0], rp.lidar[k][1])
+        for _ in range(n):
+            w = rp.window(with_lidar=False); flag = rp.margin_flag()
+            sm = be.solve(w, rp.opts)
+            pg = be.marginalize_resident(w, flag, w._icp_marg, w._lps_marg, rp.opts)
+            out[r].append((sm.iterations, w.pose.copy(), w.inv_depth.copy(), pg.A_matrix() if pg.c.n > 0 else None))
+            be.lidar_drop(0 if flag == abi.MARGIN_OLD else rp.K - 2)
+            assert rp.absorb(w, pg, flag)
+            be.lidar_push(rp.lidar[rp.K - 1][0], rp.lidar[rp.K - 1][1])
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join(600) for t in th]
+    return out
+one = chain([lib.open_vilsolve()], 10)[0]
+bes = [lib.open_vilsolve() for _ in range(2)]
+arr = (C.c_void_p * 2)(*[b.ctx for b in bes])
+assert bes[0].lib.vil_comm_init_local(arr, 2) == 0
+two = chain(bes, 10)
+assert len(two[0]) == len(two[1]) == len(one) == 10
+for f in range(10):
+    a, b0, b1 = one[f], two[0][f], two[1][f]
+    assert a[0] == b0[0] == b1[0], (f, a[0], b0[0], b1[0])
+    assert np.array_equal(b0[1], b1[1]) and np.array_equal(b0[2], b1[2])                     # ranks agree bit for bit
+    assert np.abs(a[1] - b0[1]).max() < 1e-8 and np.abs(a[2] - b0[2]).max() < 1e-7, (f, np.abs(a[1] - b0[1]).max())
+    assert (a[3] is None) == (b0[3] is None)
+    if a[3] is not None:
+        sc = np.sqrt(np.maximum(np.abs(np.diag(a[3])), 1e-300))
+        assert np.abs((a[3] - b0[3]) / np.outer(sc, sc)).max() < 2e-5 and np.array_equal(b0[3], b1[3])
+print("RESIDENT_SHARD_OK")
 '''
 
 
@@ -109,3 +172,11 @@ def test_sharded_full_size_8_ranks():
     env = dict(os.environ, SHARD_FULL="1")
     out = subprocess.run([sys.executable, "-c", SHARD_SCRIPT % (ROOT, ROOT)], env=env, capture_output=True, text=True, timeout=1500)
     assert "SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_sharded_resident_slabs_and_marginalisation():
+    """Two ranks (in-process communicator, one device): every rank keeps its slice of each LiDAR frame slab, solves its shard of the window and
+    marginalises the RESIDENT shard -- A / b all-reduced once -- over ten images with both marginalisation branches: ranks bit-identical, equal to
+    the single-context chain."""
+    out = subprocess.run([sys.executable, "-c", RESIDENT_SCRIPT % (ROOT, ROOT)], capture_output=True, text=True, timeout=900)
+    assert "RESIDENT_SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
