@@ -261,6 +261,14 @@ int vil_comm_init(vil_ctx* ctx, const void* id128, int rank, int world);
  * same per-iteration reductions as vil_comm_init, summed through device memory instead of RCCL.  Also lets a sharded
  * solve be exercised on a single device (tests). */
 int vil_comm_init_local(vil_ctx** ctxs, int n);
+/* Multi-process exchange WITHOUT RCCL (one process per GPU, or -- tests -- several processes on one GPU): the per-iteration message is
+ * latency-bound, and on the fully connected xGMI mesh "everybody writes its message into everybody's inbox, then sums locally in rank
+ * order" is one hop instead of a ring.  vil_comm_ipc_export allocates this rank's inbox (world x 2 x max_doubles doubles: size it for the
+ * largest window, vil_reduced_dim(K)^2 + 3 D + 4 + 17 L + 6 F doubles) and returns its 64-byte IPC handle; the launcher gathers the
+ * `world` handles in rank order (any transport) and every rank calls vil_comm_ipc_init.  Same sharding, same call sequence and the same
+ * bit-identical results on every rank as with vil_comm_init; the collective is three small launches in stream order. */
+int vil_comm_ipc_export(vil_ctx* ctx, int rank, int world, size_t max_doubles, void* handle64);
+int vil_comm_ipc_init(vil_ctx* ctx, const void* handles /* world x 64 bytes */);
 /* test hook: run the multi-GPU plumbing (partial system in set 0, the collective sums it into set 1, step kernel on set 1) on a
  * single rank, with or without a 1-rank communicator.  Invalidates the resident window. */
 int vil_debug_set_split(vil_ctx* ctx, int32_t on);

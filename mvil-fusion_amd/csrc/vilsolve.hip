@@ -94,6 +94,56 @@ struct LocalComm {
     int agree(int rank, int st) { err[rank] = st; pthread_barrier_wait(&bar); int w = 0; for (int r = 0; r < n; ++r) w = std::min(w, err[r]); pthread_barrier_wait(&bar); return w; }
 };
 struct PeerPtrs { const double* p[8]; int n; };
+
+// Multi-process exchange without RCCL (the per-iteration message is latency-bound; on the fully connected xGMI mesh a one-shot
+// "everybody writes to everybody, then sums locally" beats a ring): every rank owns an INBOX in its device memory -- world x 2 (parity of
+// the collective's sequence number) x cap doubles, then one flag per (source rank, parity), 64 bytes apart -- exported with hipIpcGetMemHandle
+// and opened by every peer.  A collective = k_ipc_push (my message into every inbox, a system-scope fence, then the flags) ->
+// k_ipc_wait (one workgroup spins until every source's flag carries the sequence number) -> k_ipc_sum (rank order: identical bits on every
+// rank).  Everything is in stream order and the sequence number lives in device memory: capturable in a hipGraph, nothing for the host to wait for.
+// Two parities suffice: a peer can only push collective i + 2 after it has summed i + 1, which needs MY push of i + 1, which I do after my sum of i.
+struct IpcComm {
+    int world = 0, rank = 0; size_t cap = 0;
+    char* base = nullptr;                     // my allocation: [inbox | flags | seq | count]
+    void* peer_base[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // opened handles (my own: base)
+    size_t off_flags = 0, off_seq = 0;
+    double* inbox(int r) const { return (double*)peer_base[r]; }
+    int* flags(int r) const { return (int*)((char*)peer_base[r] + off_flags); }
+    int* seq() const { return (int*)(base + off_seq); }
+};
+struct IpcPtrs { double* inbox[8]; int* flags[8]; int world, rank; size_t cap; int* seq; int* count; };
+__global__ void k_ipc_push(const double* send, size_t cnt, IpcPtrs I) {
+    const int sq = *I.seq + 1, par = sq & 1;
+    const size_t off = ((size_t)I.rank * 2 + par) * I.cap;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (size_t)gridDim.x * blockDim.x) {
+        const double v = send[e];
+        for (int r = 0; r < I.world; ++r) I.inbox[r][off + e] = v;
+    }
+    __threadfence_system();                   // this thread's stores have reached every peer ...
+    __syncthreads();
+    __shared__ int last;
+    if (threadIdx.x == 0) last = atomicAdd(I.count, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (last && threadIdx.x == 0) {           // ... all blocks' have: the flags go out, the sequence number advances
+        __threadfence_system();
+        *I.count = 0;
+        for (int r = 0; r < I.world; ++r) __hip_atomic_store(I.flags[r] + 16 * (I.rank * 2 + par), sq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        *I.seq = sq;
+    }
+}
+__global__ void k_ipc_wait(IpcPtrs I) {
+    const int sq = *I.seq, par = sq & 1, t = threadIdx.x;       // (k_ipc_push of this collective has advanced it: same stream)
+    if (t < I.world) while (__hip_atomic_load(I.flags[I.rank] + 16 * (t * 2 + par), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != sq) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void k_ipc_sum(double* out, size_t cnt, IpcPtrs I) {
+    const int par = *I.seq & 1;
+    const double* in = I.inbox[I.rank];
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (size_t)gridDim.x * blockDim.x) {
+        double s = 0;
+        for (int r = 0; r < I.world; ++r) s += __builtin_nontemporal_load(in + ((size_t)r * 2 + par) * I.cap + e);      // written by peers: not through a stale cache line
+        out[e] = s;
+    }
+}
 __global__ void k_sum_peers(double* out, PeerPtrs pp, size_t cnt) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (size_t)gridDim.x * blockDim.x) {
         double s = 0;
@@ -133,12 +183,16 @@ struct vil_ctx {
     std::vector<int> prior_joff;
     ncclComm_t comm = nullptr;     // RCCL communicator over xGMI (world > 1)
     std::shared_ptr<struct LocalComm> lcomm;   // in-process communicator (vil_comm_init_local)
+    std::shared_ptr<struct IpcComm> ipc;       // multi-process peer-buffer exchange (vil_comm_ipc_export / vil_comm_ipc_init)
+    bool has_comm() const { return comm != nullptr || lcomm != nullptr || ipc != nullptr; }
     double* lc_tmp = nullptr; size_t lc_cap = 0;
+    double* ipc_tmp = nullptr;
     bool sharded = false;          // the resident problem is this rank's shard of the factor set
     // hipGraph of a chunk of iterations, reused by repeated solves of one upload (key: chunk length, options)
     struct ChunkGraph { int n; SolveOpts so; hipGraphExec_t exec; };
     std::vector<ChunkGraph> graphs;
-    int use_graph = -1;            // VIL_GRAPH=0 disables
+    int use_graph = -1;            // VIL_GRAPH=0 disables (tuning build)
+    bool graph_failed = false;     // a chunk with a collective could not be captured: direct launches from then on
     int solve_gen = 0;             // generation counter of the helper-workgroup flags (Ctl::gen)
     int solves_since_upload = 0;
     bool split = false;            // sweep + gather fill set 0, the collective sums it into set 1, the step kernel reads set 1
@@ -296,6 +350,8 @@ void vil_destroy(vil_ctx* c) {
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->marg_ws) hipFree(c->marg_ws);
     if (c->lc_tmp) hipFree(c->lc_tmp);
+    if (c->ipc_tmp) hipFree(c->ipc_tmp);
+    if (c->ipc) { for (int r = 0; r < c->ipc->world; ++r) if (r != c->ipc->rank && c->ipc->peer_base[r]) hipIpcCloseMemHandle(c->ipc->peer_base[r]); if (c->ipc->base) hipFree(c->ipc->base); c->ipc.reset(); }
     if (c->d_pl) hipFree(c->d_pl);
     if (c->d_ed) hipFree(c->d_ed);
     if (c->d_lstage) hipFree(c->d_lstage);
@@ -829,6 +885,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
 }
 
 static int comm_agree(vil_ctx* c, int st);
+static int ensure_pin(vil_ctx* c, size_t bytes);
 
 // rank r keeps the visual factors of its landmark range, a contiguous slice of the LiDAR points, and
 // (rank 0 only) the IMU / prior / ICP / LPS factors.  Landmark indices and the state stay global.
@@ -855,7 +912,7 @@ static int upload_sharded(vil_ctx* c, const vil_problem* p, const vil_state* s) 
 
 static int upload_window(vil_ctx* c, const vil_problem* p, const vil_state* s, bool check_setup) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
-    const int st = (c->world > 1 && (c->comm || c->lcomm)) ? upload_sharded(c, p, s)      // a world > 1 context without a communicator works un-sharded
+    const int st = (c->world > 1 && c->has_comm()) ? upload_sharded(c, p, s)      // a world > 1 context without a communicator works un-sharded
                                                            : upload_impl(c, p, s, false, nullptr, nullptr, 0, check_setup);
     if (st == VIL_OK) c->resident_kind = 1;
     return st;
@@ -863,7 +920,20 @@ static int upload_window(vil_ctx* c, const vil_problem* p, const vil_state* s, b
 int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) { return upload_window(c, p, s, true); }
 
 // sum over the ranks of the communicator, in stream order: recv = sum of every rank's send (recv may be send)
+static int ipc_all_reduce(vil_ctx* c, const double* send, double* recv, size_t cnt) {
+    IpcComm* ic = c->ipc.get();
+    if (cnt > ic->cap) return VIL_ERR_UNSUPPORTED;      // the inbox was sized at vil_comm_ipc_export
+    IpcPtrs I; memset(&I, 0, sizeof I);
+    for (int r = 0; r < ic->world; ++r) { I.inbox[r] = ic->inbox(r); I.flags[r] = ic->flags(r); }
+    I.world = ic->world; I.rank = ic->rank; I.cap = ic->cap; I.seq = ic->seq(); I.count = ic->seq() + 16;
+    const unsigned nb = (unsigned)std::min<size_t>(128, (cnt + 255) / 256);
+    hipLaunchKernelGGL(k_ipc_push, dim3(nb), dim3(256), 0, c->stream, send, cnt, I);
+    hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(64), 0, c->stream, I);
+    hipLaunchKernelGGL(k_ipc_sum, dim3(nb), dim3(256), 0, c->stream, recv, cnt, I);
+    return VIL_OK;
+}
 static int all_reduce2(vil_ctx* c, const double* send, double* recv, size_t cnt) {
+    if (c->ipc) return ipc_all_reduce(c, send, recv, cnt);
     if (c->comm) return g_rccl.AllReduce(send, recv, cnt, ncclDouble, ncclSum, c->comm, c->stream) == ncclSuccess ? VIL_OK : VIL_ERR_COMM;
     if (c->lcomm) {
         LocalComm* lc = c->lcomm.get();
@@ -887,6 +957,7 @@ static int all_reduce2(vil_ctx* c, const double* send, double* recv, size_t cnt)
     return VIL_OK;
 }
 static int all_reduce(vil_ctx* c, double* buf, size_t cnt) {
+    if (c->ipc) return ipc_all_reduce(c, buf, buf, cnt);      // (push reads, sum writes: different kernels, stream order)
     if (c->comm) return g_rccl.AllReduce(buf, buf, cnt, ncclDouble, ncclSum, c->comm, c->stream) == ncclSuccess ? VIL_OK : VIL_ERR_COMM;
     if (c->lcomm) {
         // every HIP failure is carried to the next agreement point instead of returning past a barrier the other ranks wait at
@@ -912,6 +983,18 @@ static int all_reduce(vil_ctx* c, double* buf, size_t cnt) {
 // factors whose set-up can fail -- must not leave the other ranks waiting in the first collective of the solve
 static int comm_agree(vil_ctx* c, int st) {
     if (c->lcomm) return c->lcomm->agree(c->rank, st);
+    if (c->ipc) {                                          // every rank's status in its own slot of a world-long message: the worst one wins
+        const int w = c->ipc->world;
+        if (ensure_pin(c, 8 * 64) != VIL_OK) return VIL_ERR_DEVICE;
+        double* h = c->h_pin; for (int r = 0; r < w; ++r) h[r] = r == c->ipc->rank ? (double)st : 0.0;
+        if (!c->ipc_tmp && hipMalloc(&c->ipc_tmp, 8 * 64) != hipSuccess) return VIL_ERR_DEVICE;
+        if (hipMemcpyAsync(c->ipc_tmp, h, 8 * (size_t)w, hipMemcpyHostToDevice, c->stream) != hipSuccess) return VIL_ERR_DEVICE;
+        if (ipc_all_reduce(c, c->ipc_tmp, c->ipc_tmp + 32, (size_t)w) != VIL_OK) return VIL_ERR_COMM;
+        if (hipMemcpyAsync(h + 32, c->ipc_tmp + 32, 8 * (size_t)w, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return VIL_ERR_DEVICE;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return VIL_ERR_DEVICE;
+        int worst = 0; for (int r = 0; r < w; ++r) worst = std::min(worst, (int)h[32 + r]);
+        return worst;
+    }
     if (c->comm) {
         int h = st;
         if (hipMemcpyAsync(c->d_status, &h, sizeof(int), hipMemcpyHostToDevice, c->stream) != hipSuccess) return VIL_ERR_DEVICE;
@@ -1021,22 +1104,34 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
         // ~2 % less inter-kernel gap.  The first solve of an upload launches directly -- capturing costs more than it saves.
         if (c->use_graph < 0) { const char* ev = VIL_TUNE_ENV("VIL_GRAPH"); c->use_graph = ev ? atoi(ev) : 1; }
         const int nthis = std::min(chunk, o->max_iterations + 9 - it);
-        if (c->use_graph && c->solves_since_upload > 0 && !c->profiling && !c->split && nthis > 0) {     // (the local communicator's host barriers cannot be captured)
+        // hipGraph replay: un-sharded solves, and sharded ones whose collective is the library's own kernels (peer-buffer exchange).  RCCL calls are
+        // launched directly (whether a given RCCL build captures correctly is not something this path bets the multi-GPU run on); the in-process
+        // communicator synchronises on the host.  Polling the finished solve's mirror works for everything that is in stream order.
+        const bool no_graph = c->split && !c->ipc;
+        if (c->use_graph && c->solves_since_upload > 0 && !c->profiling && !no_graph && !c->graph_failed && nthis > 0) {
             hipGraphExec_t exec = nullptr;
             for (auto& g : c->graphs) if (g.n == nthis && memcmp(&g.so, &so, sizeof so) == 0) exec = g.exec;
             if (!exec) {
                 hipGraph_t graph = nullptr;
                 HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-                for (int q = 0; q < nthis; ++q) { launch_sweep(c, so); launch_reduce_step(c, so, true, nullptr); }
+                int cst = VIL_OK;
+                for (int q = 0; q < nthis && cst == VIL_OK; ++q) { launch_sweep(c, so); cst = launch_reduce_step(c, so, true, nullptr); }
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(VIL_SWEEP_THREADS), 0, c->stream, view(c, 0), -1);
-                HIPCHK(hipStreamEndCapture(c->stream, &graph));
-                HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-                hipGraphDestroy(graph);
-                c->graphs.push_back({nthis, so, exec});
+                const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+                if (cst != VIL_OK || ce != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+                    // a collective that cannot be captured (the RCCL build at hand decides): this context launches directly from now on.  Nothing has run yet
+                    (void)hipGetLastError();
+                    if (graph) hipGraphDestroy(graph);
+                    exec = nullptr; c->graph_failed = true;
+                    if (!c->split) return VIL_ERR_DEVICE;
+                } else {
+                    hipGraphDestroy(graph);
+                    c->graphs.push_back({nthis, so, exec});
+                }
             }
-            HIPCHK(hipGraphLaunch(exec, c->stream));
-            it += nthis; launched = nthis;
-        } else {
+            if (exec) { HIPCHK(hipGraphLaunch(exec, c->stream)); it += nthis; launched = nthis; }
+        }
+        if (launched == 0) {
             for (int q = 0; q < chunk && it <= o->max_iterations + 8; ++q, ++it, ++launched) {
                 if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q], c->stream));
                 launch_sweep(c, so);
@@ -1051,7 +1146,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
         // synchronising (the no-op tail of the chunk is not waited for, nothing is copied afterwards).  A chunk that runs out without
         // finishing is seen by hipStreamQuery and takes the copy + synchronise route, as do profiling and multi-rank solves.
         bool polled = false;
-        if (c->d_hseq && !c->profiling && !c->split) {
+        if (c->d_hseq && !c->profiling && !(c->split && c->lcomm != nullptr)) {
             volatile int* seq = (volatile int*)(c->h_mirror + sizeof(Ctl));
             const int gen = c->solve_gen;
             const auto tp0 = std::chrono::steady_clock::now();
@@ -1145,7 +1240,7 @@ int vil_solve(vil_ctx* c, const vil_problem* p, vil_state* s, const vil_options*
 int vil_solve_device_lidar(vil_ctx* c, const vil_problem* p, const vil_device_lidar* dl, void* producer_stream, vil_state* s, const vil_options* o, vil_summary* sum) {
     if (!c || !p || !dl || !s || !o || !sum) return VIL_ERR_INVALID_ARGUMENT;
     if ((p->n_plane > 0 && (!dl->plane_soa || dl->plane_stride < p->n_plane)) || (p->n_edge > 0 && (!dl->edge_soa || dl->edge_stride < p->n_edge))) return VIL_ERR_INVALID_ARGUMENT;
-    if (c->world > 1 && (c->comm || c->lcomm)) return VIL_ERR_UNSUPPORTED;
+    if (c->world > 1 && c->has_comm()) return VIL_ERR_UNSUPPORTED;
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(c->device));
     if (producer_stream && (hipStream_t)producer_stream != c->stream) {      // the tables are written by work on another stream: order after it on the device
@@ -1461,7 +1556,7 @@ int vil_marginalize(vil_ctx* c, const vil_problem* p, const vil_state* s, const 
     // under a communicator the collected factors are sharded like a solve's (visual by landmark owner, LiDAR points in slices, the rest on
     // rank 0), A and b are all-reduced ONCE and every rank finishes the small dense part redundantly -- the reference's own pattern
     // (marginalization_factor.cpp:235-264: factors dealt to four threads, private A / b, summed after the join)
-    int st = (c->world > 1 && (c->comm || c->lcomm)) ? upload_sharded(c, &q, s) : upload_impl(c, &q, s, false);
+    int st = (c->world > 1 && c->has_comm()) ? upload_sharded(c, &q, s) : upload_impl(c, &q, s, false);
     if (st != VIL_OK) return st;
     const SolveOpts so = to_dev_opts(o);
     st = init_ctl(c, o, 2);
@@ -1528,7 +1623,7 @@ int vil_lidar_drop(vil_ctx* c, int32_t slab) {
 int vil_lidar_push(vil_ctx* c, int32_t n_plane, const double* plane_const, int32_t n_edge, const double* edge_const) {
     if (!c || n_plane < 0 || n_edge < 0 || (n_plane > 0 && !plane_const) || (n_edge > 0 && !edge_const)) return VIL_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(c->device));
-    if (c->world > 1 && (c->comm || c->lcomm)) {       // factor set sharded over ranks: every rank is handed the whole frame and keeps its contiguous slice
+    if (c->world > 1 && c->has_comm()) {       // factor set sharded over ranks: every rank is handed the whole frame and keeps its contiguous slice
         const int pb = (int)((long long)n_plane * c->rank / c->world), pe = (int)((long long)n_plane * (c->rank + 1) / c->world);
         const int eb = (int)((long long)n_edge * c->rank / c->world), ee = (int)((long long)n_edge * (c->rank + 1) / c->world);
         plane_const += (size_t)7 * pb; n_plane = pe - pb; edge_const += (size_t)9 * eb; n_edge = ee - eb;
@@ -1636,7 +1731,7 @@ int vil_marginalize_resident(vil_ctx* c, const vil_state* s, const vil_options* 
 // ---- the fully resident window (include/vilsolve.h: vil_win_*; device side: vil_window.hpp) ------------------------------------------
 int vil_win_open(vil_ctx* c, const vil_win_cfg* cfg) {
     if (!c || !cfg || cfg->K < 3 || cfg->K > VIL_WIN_MAXK || cfg->max_tracks < 1 || cfg->max_samples < 1) return VIL_ERR_INVALID_ARGUMENT;
-    if (c->world > 1 && (c->comm || c->lcomm)) return VIL_ERR_UNSUPPORTED;
+    if (c->world > 1 && c->has_comm()) return VIL_ERR_UNSUPPORTED;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     auto& w = c->win;
@@ -1848,6 +1943,41 @@ int vil_comm_init(vil_ctx* c, const void* id128, int rank, int world) {
     c->rank = rank; c->world = world; c->uploaded = false; c->lcomm.reset();
     return VIL_OK;
 }
+// multi-process peer-buffer exchange: export the inbox, gather the handles (the launcher's job: torch.distributed / MPI / a pipe), import
+int vil_comm_ipc_export(vil_ctx* c, int rank, int world, size_t max_doubles, void* handle64) {
+    if (!c || !handle64 || world < 1 || world > 8 || rank < 0 || rank >= world || max_doubles < 64) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->ipc) { for (int r = 0; r < c->ipc->world; ++r) if (r != c->ipc->rank && c->ipc->peer_base[r]) hipIpcCloseMemHandle(c->ipc->peer_base[r]); if (c->ipc->base) hipFree(c->ipc->base); c->ipc.reset(); }
+    auto ic = std::make_shared<IpcComm>();
+    ic->world = world; ic->rank = rank; ic->cap = (max_doubles + 31) & ~size_t(31);
+    ic->off_flags = 8 * (size_t)world * 2 * ic->cap; ic->off_seq = ic->off_flags + 64 * (size_t)world * 2;
+    const size_t bytes = ic->off_seq + 256;
+    HIPCHK(hipMalloc((void**)&ic->base, bytes));
+    HIPCHK(hipMemset(ic->base, 0, bytes));
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(hipIpcMemHandle_t) <= 64, "vil_comm_ipc_export hands out 64 bytes");
+    HIPCHK(hipIpcGetMemHandle(&h, ic->base));
+    memset(handle64, 0, 64); memcpy(handle64, &h, sizeof h);
+    ic->peer_base[rank] = ic->base;
+    c->ipc = ic; c->rank = rank; c->world = world; c->uploaded = false; c->lcomm.reset();
+    if (c->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    return VIL_OK;
+}
+int vil_comm_ipc_init(vil_ctx* c, const void* handles) {
+    if (!c || !handles || !c->ipc) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    IpcComm* ic = c->ipc.get();
+    for (int r = 0; r < ic->world; ++r) {
+        if (r == ic->rank) continue;
+        hipIpcMemHandle_t h; memcpy(&h, (const char*)handles + 64 * (size_t)r, sizeof h);
+        void* p = nullptr;
+        if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return VIL_ERR_COMM; }
+        ic->peer_base[r] = p;
+    }
+    return VIL_OK;
+}
+
 int vil_comm_init_local(vil_ctx** ctxs, int n) {
     if (!ctxs || n < 1 || n > 8) return VIL_ERR_INVALID_ARGUMENT;
     for (int r = 0; r < n; ++r) if (!ctxs[r]) return VIL_ERR_INVALID_ARGUMENT;
@@ -1868,7 +1998,7 @@ int vil_comm_init_local(vil_ctx** ctxs, int n) {
     for (int r = 0; r < n; ++r) {
         vil_ctx* c = ctxs[r];
         if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
-        c->lcomm = lc; c->rank = r; c->world = n; c->uploaded = false;
+        c->lcomm = lc; c->rank = r; c->world = n; c->uploaded = false; c->ipc.reset();
     }
     return VIL_OK;
 }

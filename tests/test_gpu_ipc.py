@@ -1,0 +1,84 @@
+"""Multi-PROCESS factor sharding without RCCL (include/vilsolve.h: vil_comm_ipc_export / vil_comm_ipc_init): two processes on ONE device
+exchange the per-iteration linear-system message through each other's IPC-mapped inbox (everybody writes to everybody, local sum in rank
+order).  Both ranks must return the same bits, equal to the oracle and to the un-sharded solve."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import sys, os, ctypes as C, pickle
+root, rank, world, d = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np, time
+import __graft_entry__ as g; g.load_package()
+from mvil_fusion_amd import abi, lib, synth
+import oracle_lib
+orc = oracle_lib.open_oracle()
+be = lib.open_vilsolve(device=0, rank=rank, world=world)
+h = (C.c_char * 64)()
+f = be.lib.vil_comm_ipc_export; f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
+assert f(be.ctx, rank, world, 400000, h) == 0
+open(os.path.join(d, "h%d.tmp" % rank), "wb").write(bytes(h)); os.rename(os.path.join(d, "h%d.tmp" % rank), os.path.join(d, "h%d" % rank))
+t0 = time.time()
+while not all(os.path.exists(os.path.join(d, "h%d" % r)) for r in range(world)):
+    assert time.time() - t0 < 120; time.sleep(0.01)
+allh = b"".join(open(os.path.join(d, "h%d" % r), "rb").read() for r in range(world))
+buf = (C.c_char * len(allh)).from_buffer_copy(allh)
+assert be.lib.vil_comm_ipc_init(be.ctx, buf) == 0
+pf = lambda pre: orc.marginalize(pre).to_prior()
+res = {}
+for cid, kw in ((2, dict(L=150, n_plane=3000, n_edge=800)), (1, {}), (2, {})):
+    w = synth.make_config(cid, prior_fn=pf, **kw); wo = synth.make_config(cid, prior_fn=pf, **kw)
+    lin = be.linearize(w)
+    sg = be.solve(w); so = orc.solve(wo)
+    s2 = be.solve(synth.make_config(cid, prior_fn=pf, **kw))                 # a second solve on the same context: sequence numbers keep running
+    assert sg.iterations == so.iterations == s2.iterations and sg.termination == so.termination, (cid, sg.iterations, so.iterations)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-7 * so.final_cost
+    if wo.prior.n:
+        assert np.abs(w.pose - wo.pose).max() < 1e-6 and np.abs(w.inv_depth - wo.inv_depth).max() < 1e-6
+        pm = be.marginalize(w, abi.MARGIN_OLD, 0, 0)                          # sharded marginalisation through the same exchange
+        po = orc.marginalize(wo, abi.MARGIN_OLD, 0, 0)
+        Ag, Ao = pm.A_matrix(), po.A_matrix(); sc = np.sqrt(np.outer(np.abs(np.diag(Ao)) + 1e-300, np.abs(np.diag(Ao)) + 1e-300))
+        assert pm.c.n == po.c.n and (np.abs(Ag - Ao) / sc).max() < 2e-5
+    if cid == 2 and not kw:                                                  # resident re-solves: the second one replays the captured hipGraph of the chunk, collectives included
+        w3 = synth.make_config(cid, prior_fn=pf, **kw)
+        be.upload(w3)
+        its = []
+        for _ in range(3):
+            be.reset_state(); its.append(be.solve_resident().iterations)
+        assert its == [so.iterations] * 3, its
+        be.download_state(w3)
+        assert np.array_equal(w3.pose, w.pose) and np.array_equal(w3.inv_depth, w.inv_depth)
+    res[(cid, len(kw))] = (w.pose.copy(), w.speedbias.copy(), w.inv_depth.copy(), sg.iterations, lin[0])
+pickle.dump(res, open(os.path.join(d, "res%d" % rank), "wb"))
+be.close()
+print("IPC_RANK_OK", rank)
+'''
+
+
+def test_two_processes_one_device_peer_buffer_exchange(tmp_path):
+    import pickle
+    import numpy as np
+    world = 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", WORKER, ROOT, str(r), str(world), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((o, e))
+    for r, (o, e) in enumerate(outs):
+        assert "IPC_RANK_OK %d" % r in o, o[-2000:] + e[-3000:]
+    res = [pickle.load(open(os.path.join(str(tmp_path), "res%d" % r), "rb")) for r in range(world)]
+    for k in res[0]:
+        for q in range(4):
+            assert np.array_equal(res[0][k][q], res[1][k][q]), (k, q)        # ranks agree bit for bit
