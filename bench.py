@@ -492,6 +492,7 @@ def main():
     ap.add_argument("--preint-intervals", type=int, default=9)
     ap.add_argument("--force-comm", action="store_true", help="test hook: take the multi-GPU code path (process group, communicator, replicas leg) with a single rank")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of sharding one window over RCCL")
+    ap.add_argument("--ipc", action="store_true", help="N>1: the library's peer-buffer exchange (IPC-mapped inboxes over xGMI, vil_comm_ipc_*) instead of RCCL for the per-iteration collective")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -529,7 +530,26 @@ def main():
         return
     sharded = False
     shard_note = None
-    if (world > 1 or args.force_comm) and not args.replicas:
+    if (world > 1 or args.force_comm) and not args.replicas and args.ipc:
+        # peer-buffer exchange instead of RCCL (vil_comm_ipc_*): every rank exports its inbox, the 64-byte handles travel through torch.distributed
+        h = (C.c_char * 64)()
+        fexp = be.lib.vil_comm_ipc_export; fexp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
+        st = fexp(be.ctx, rank, world, 1 << 19, h)
+        mine = torch.frombuffer(bytearray(bytes(h)), dtype=torch.uint8).cuda()
+        allh = [torch.zeros(64, dtype=torch.uint8, device="cuda") for _ in range(world)]
+        dist.all_gather(allh, mine)
+        blob = b"".join(bytes(t.cpu().numpy().tobytes()) for t in allh)
+        if st == 0:
+            st = be.lib.vil_comm_ipc_init(be.ctx, (C.c_char * len(blob)).from_buffer_copy(blob))
+        good = torch.tensor([1 if st == 0 else 0], device="cuda", dtype=torch.int32)
+        dist.all_reduce(good, op=dist.ReduceOp.MIN)
+        if int(good[0]) == 1:
+            sharded = True
+        else:
+            shard_note = "peer-buffer exchange could not be set up (status %d on rank %d): fell back to independent replicas" % (st, rank)
+            be.close()
+            be = lib.open_vilsolve(device=local, rank=0, world=1)
+    elif (world > 1 or args.force_comm) and not args.replicas:
         # one RCCL communicator over xGMI, created inside the library; the 128-byte id travels through torch.distributed.
         # Every rank must agree on the outcome: if any rank cannot join, ALL fall back to independent replicas (reported).
         uid = (C.c_char * 128)()
@@ -692,7 +712,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[%d]: K=%d keyframes, L=%d landmarks, %d visual factors, %d plane + %d edge LiDAR points, %d IMU, %d ICP, %d LPS, prior n=%d (%s)"
                        % (args.config - 1, w.K, w.L, len(w.vis_i), len(w.plane_pose), len(w.edge_pose), len(w.imu_i), len(w.icp_ids), len(w.lps_ids), w.prior.n, prior_kind),
                        "iterations_per_solve": last.iterations, "termination": abi.TERM_NAMES[last.termination], "final_cost": last.final_cost,
-                       "parallelism": "1 GPU" if world == 1 else ("factor set of ONE window sharded over %d GPUs: visual by landmark owner, LiDAR points in contiguous slices, ONE RCCL all-reduce per iteration of the whole linear-system set ([S|g|cost] + the owners' landmark arrays), then the complete step kernel redundantly on every rank" % world if sharded else "%d independent replicas" % world),
+                       "parallelism": "1 GPU" if world == 1 else (("factor set of ONE window sharded over %d GPUs: visual by landmark owner, LiDAR points in contiguous slices, ONE " % world) + ("peer-buffer exchange (IPC inboxes over xGMI)" if args.ipc else "RCCL all-reduce") + " per iteration of the whole linear-system set ([S|g|cost] + the owners' landmark arrays), then the complete step kernel redundantly on every rank; NO N > 1 curve of this code had been measured on hardware before this run (one GPU per build box)" if sharded else "%d independent replicas" % world),
                        "step": "one full window solve, inputs resident in HBM"},
         }
         if shard_note:

@@ -53,7 +53,8 @@ for cid, kw in ((2, dict(L=150, n_plane=3000, n_edge=800)), (1, {}), (2, {})):
             be.reset_state(); its.append(be.solve_resident().iterations)
         assert its == [so.iterations] * 3, its
         be.download_state(w3)
-        assert np.array_equal(w3.pose, w.pose) and np.array_equal(w3.inv_depth, w.inv_depth)
+        assert np.abs(w3.pose - w.pose).max() < 1e-9 and np.abs(w3.inv_depth - w.inv_depth).max() < 1e-8      # (two runs agree to rounding: LDS atomics inside a visual workgroup)
+        res["resident"] = (w3.pose.copy(), w3.speedbias.copy(), w3.inv_depth.copy(), its[-1], 0.0)
     res[(cid, len(kw))] = (w.pose.copy(), w.speedbias.copy(), w.inv_depth.copy(), sg.iterations, lin[0])
 pickle.dump(res, open(os.path.join(d, "res%d" % rank), "wb"))
 be.close()
