@@ -118,7 +118,8 @@ struct DevP {
     // the chain part of S' from the IMU / prior records through a host-built table (chtab: n_chtab x {dst, src a, src b, src c}), eliminates the
     // chain and leaves: W^T with unscaled pose rows (chW), the factored blocks (chLdg, chLsb), the chain columns' scales (chSc, chDc),
     // pieces of u^T S' u (chZ, chQ), status (chOk).  Further workgroups then form W W^T tile by tile (chWW, tiled lower layout).
-    int prechain, n_chtab; const int* chtab;
+    int prechain, n_chtab; const int* chtab; const int* chpq;      // prechain 1: beside the gather in the merged launch; 2: in k_sweep behind the IMU / prior flags (swflag), tiles in k_reduce
+    int* swflag;                   // n_imu + 1 flags: the IMU / prior workgroups of the current sweep have written their records (prechain 2)
     // gather + step in ONE launch (rs_merged): grid = [master | helpers | chain | W W^T tiles (n_ww) | gather (n_gather)]; a workgroup that is
     // done posts the launch epoch in its flag -- gflag[n_gather], chflag, wwflag[n_ww] -- and the master / helpers / tile workgroups wait on them
     int rs_merged, n_ww, n_gather; int* gflag; int* chflag; int* wwflag;

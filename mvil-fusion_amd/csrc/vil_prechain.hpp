@@ -20,14 +20,19 @@
 namespace vd {
 
 // Raw chain entries in LDS, as the chain consumes them:
-//   dg[k][45]  lower triangle of diagonal block k        sub[k][81]  rows of block k+1 x columns of block k (k < K-1)
-//   pb[col][row]  pose rows x chain columns, stride NPs    rhs[9K]
-struct ChainSlab { double* dg; double* sub; double* pb; double* rhs; int NPs; };
+//   dg[k][45]   lower triangle of diagonal block k         sub[k][81]  rows of block k+1 x columns of block k (k < K-1)
+//   pbc[k][3][6][9]  pose rows of frames k-1, k, k+1 x the columns of block k (what the IMU factors touch: compact, 162 per block)
+//   pp[q][row]  every pose / extrinsic / td row x the q-th chain column the PRIOR holds (<= 18: the prior's speed-bias blocks are neighbours), stride NPs
+//   rhs[9K]     pq[9K] (int)  chain column -> its index among the prior's columns, or -1
+#define CHAIN_NPC_MAX 18
+struct ChainSlab { double* dg; double* sub; double* pbc; double* pp; double* rhs; int* pq; int NPs; };
 __host__ __device__ inline int chain_slab_nps(int K) { return (6 * K + 7 + 1) & ~1; }
-__host__ __device__ inline size_t chain_slab_doubles(int K) { return even_up(45 * K) + even_up(81 * K) + (size_t)9 * K * chain_slab_nps(K) + even_up(9 * K); }
+__host__ __device__ inline size_t chain_slab_fp(int K) { return even_up(45 * K) + even_up(81 * K) + (size_t)162 * K + (size_t)CHAIN_NPC_MAX * chain_slab_nps(K) + even_up(9 * K); }      // gather targets (zeroed first)
+__host__ __device__ inline size_t chain_slab_doubles(int K) { return chain_slab_fp(K) + (size_t)even_up(9 * K) / 2 + 2; }
 __host__ __device__ inline ChainSlab chain_slab(double* p, int K) {
     ChainSlab S; S.NPs = chain_slab_nps(K);
-    S.dg = p; S.sub = S.dg + even_up(45 * K); S.pb = S.sub + even_up(81 * K); S.rhs = S.pb + (size_t)9 * K * S.NPs;
+    S.dg = p; S.sub = S.dg + even_up(45 * K); S.pbc = S.sub + even_up(81 * K); S.pp = S.pbc + (size_t)162 * K; S.rhs = S.pp + (size_t)CHAIN_NPC_MAX * S.NPs;
+    S.pq = (int*)(S.rhs + even_up(9 * K));
     return S;
 }
 // LDS of the chain workgroup (doubles): chain scratch | sc, dc, u of the chain columns | slab
@@ -37,7 +42,15 @@ struct ChainSrcSlab {
     const DevP& P; const ChainSlab& B; const double* scB; const double* dcB; const double* uB; double mu;
     __device__ __forceinline__ double diag(int k, int i, int j) const { return B.dg[45 * k + (i * (i + 1) >> 1) + j]; }
     __device__ __forceinline__ double sub(int k, int kn, int q, int c) const { return kn > k ? B.sub[81 * k + q * 9 + c] : B.sub[81 * kn + c * 9 + q]; }
-    __device__ __forceinline__ double prow(int r, int k, int c) const { return B.pb[(size_t)(9 * k + c) * B.NPs + r]; }
+    // unconditional reads (clamped indices) + selects: no per-lane predicated loads
+    __device__ __forceinline__ double prow(int r, int k, int c) const {
+        const int fr = r < 6 * P.K ? r / 6 : 1 << 20, lr = r - 6 * fr, d = fr - (k - 1);
+        const bool in = (unsigned)d <= 2u;
+        const double vi = B.pbc[(size_t)((k * 3 + min(max(d, 0), 2)) * 6 + min(max(lr, 0), 5)) * 9 + c];
+        const int q = B.pq[9 * k + c];
+        const double vp = B.pp[(size_t)max(q, 0) * B.NPs + r];
+        return (in ? vi : 0.0) + (q >= 0 ? vp : 0.0);
+    }
     __device__ __forceinline__ double rhsraw(int j) const { return B.rhs[j - P.NV]; }
     __device__ __forceinline__ double sc(int j) const { return scB[j - P.NV]; }
     __device__ __forceinline__ double madd(int j) const { const double d = dcB[j - P.NV]; return mu * d * d; }
@@ -48,8 +61,10 @@ struct ChainSrcSlab {
 };
 
 // the chain workgroup (all threads of the block enter; dynamic LDS >= prechain_lds_doubles(K)); the IMU / prior records are complete
-// epoch: the launch's flag value; P.chflag[1] is posted as soon as the chain columns' scales are out (the master's vector pass reads them)
-__device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const int jacobi, double* lds, const int epoch) {
+// epoch: the launch's flag value; P.chflag[1] is posted as soon as the chain columns' scales are out (the master's vector pass reads them).
+// wait_records: the workgroup rides in k_sweep (windows too large for the merged launch) and spins until the IMU / prior workgroups of
+// that launch have published their records (swflag).
+__device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const int jacobi, double* lds, const int epoch, const bool wait_records = false) {
     const int t = threadIdx.x, K = P.K, NP = P.NV, NB = 9 * K, NT = blockDim.x;
 #ifdef VIL_STAMPS
     #define PSTAMP(k) do { if (t == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[k] = tt_; } } while (0)
@@ -62,7 +77,12 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     const ChainSlab B = chain_slab(uB + even_up(NB), K);
     if (t < 8) L.flag[t] = 0;
     // the slab is a gather target: entries without a source (pose rows of far frames) stay zero
-    { double* z = B.dg; const int nz = (int)chain_slab_doubles(K); for (int e = t; e < nz; e += NT) z[e] = 0.0; }
+    { double* z = B.dg; const int nz = (int)chain_slab_fp(K); for (int e = t; e < nz; e += NT) z[e] = 0.0; }
+    for (int e = t; e < NB; e += NT) B.pq[e] = P.chpq[e];
+    if (wait_records) {
+        const int ep = (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u);       // (sweep_signal, vil_sweep.hpp)
+        if (t <= P.n_imu && (t < P.n_imu || P.pn > 0)) while (__hip_atomic_load(P.swflag + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ep) __builtin_amdgcn_s_sleep(2);
+    }
     __syncthreads();
     // ---- gather: eight table entries per thread and round (one round at K = 10), every load of a round in flight before the first store
     {

@@ -665,7 +665,7 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
             }
         }
     }
-    {   // the chain workgroup and the W W^T tile workgroups of this launch are done (a tile's flag implies the chain's)
+    if (P.rs_merged) {   // the chain workgroup and the W W^T tile workgroups of this launch are done (a tile's flag implies the chain's)
         const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
         for (int i = t; i < P.n_ww; i += VIL_STEP_THREADS) while (__hip_atomic_load(P.wwflag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
         __syncthreads();                               // (everything they left is read at agent scope below: no fence)
@@ -701,7 +701,7 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
     SSTAMP(5);
     {   // the chain workgroup's last act (long done by now): inverses of the factored diagonal blocks, sub-diagonal blocks
         const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
-        if (t == 0) while (__hip_atomic_load(P.chflag + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+        if (t == 0 && P.rs_merged) while (__hip_atomic_load(P.chflag + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
         __syncthreads();
         for (int e = t; e < 54 * K; e += VIL_STEP_THREADS) Ldg[e] = ld_ag(P.chLdg + e);
         for (int e = t; e < 82 * K; e += VIL_STEP_THREADS) Lsb[e] = ld_ag(P.chLsb + e);
@@ -824,9 +824,13 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         for (int i = t; i < n; i += NT) while (__hip_atomic_load(f + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
         __syncthreads();
     };
+    if (merged && bid >= b_gather) {
+        if (P.rs_merged == 2) reduce_gather<true, VIL_STEP_THREADS / 8>(P, s.c, bid - b_gather);      // 64 entries, all 512 threads
+        else { if (t >= VIL_THREADS) return; reduce_gather<true, RED_EPW>(P, s.c, bid - b_gather); }   // 32 entries on the first four waves
+        rs_signal(P.gflag + (bid - b_gather)); return;
+    }
     if (merged && bid >= b_ww) {
-        if (t >= VIL_THREADS) return;                  // these two roles are 256-thread roles: the upper waves leave before the first barrier
-        if (bid >= b_gather) { reduce_gather<true>(P, s.c); rs_signal(P.gflag + (bid - b_gather)); return; }
+        if (t >= VIL_THREADS) return;                  // a 256-thread role: the upper waves leave before the first barrier
         rs_wait(P.chflag, 1); prechain_ww_tile(P, bid - b_ww); rs_signal(P.wwflag + (bid - b_ww)); return;
     }
     if (merged && P.prechain && bid == b_chain) { prechain_wg(P, s.c, O.jacobi_scaling, Alds, epoch); return; }      // (posts chflag[0 .. 2] itself)
@@ -1065,7 +1069,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     if (s.need) {
         // ---- camera vectors: Jacobi scaling (first linearisation), dogleg diagonal, gradient_, u = Sc gradient_/d
         double gm = 0;
-        if constexpr (CHAIN == 3) { if (t == 0) wait1(P.chflag + 1); __syncthreads(); }      // the chain workgroup's scales of the chain columns are out
+        if constexpr (CHAIN == 3) { if (merged) { if (t == 0) wait1(P.chflag + 1); __syncthreads(); } }      // the chain workgroup's scales of the chain columns are out
         for (int i = t; i < D; i += NT) {
             const double dg = merged ? ld_ag(sb.diag + i) : sb.diag[i], b = merged ? ld_ag(sb.bc + i) : sb.bc[i];
             double Sc;

@@ -491,30 +491,32 @@ __device__ __forceinline__ int imu_local(const DevP& P, int i, int j, int col) {
 //   The last workgroup handles the vectors and the cost.
 #define RED_EPW 32
 // AG: the results are stored at agent scope (gather + step in one launch: the master reads them in the same launch)
-template <bool AG = false>
-__device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl) {
+// EPW: entries per workgroup = blockDim / 8 (32 with 256 threads: the gather kernel; 64 with 512: the gather workgroups of the merged launch,
+// whose register allocation admits one workgroup per compute unit whatever its thread count)
+template <bool AG = false, int EPW = RED_EPW>
+__device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, const int blk /* gather workgroup index */) {
     using namespace vd;
     auto put = [](double* p, double v) { if (AG) st_ag(p, v); else *p = v; };
-    if (threadIdx.x >= VIL_THREADS) return;
+    if ((int)threadIdx.x >= 8 * EPW) return;
     const int cand = 1 - ctl.cur;
     SysBuf sb = P.sys[cand];
     const int D = P.D, NV = P.NV, K = P.K, t = threadIdx.x;
     const int n_rel = P.n_icp + P.n_lps;
     const double* rel0 = P.mpart + (P.pn > 0 ? P.pn + 1 : 0);
     const int NL = (D * (D + 1)) >> 1;
-    const int nSblk = (NL + RED_EPW - 1) / RED_EPW;
-    __shared__ double part[2][8][RED_EPW];
+    const int nSblk = (NL + EPW - 1) / EPW;
+    __shared__ double part[2][8][EPW];
     __shared__ int tab[64 + 48 + 2 * 66];      // imu (i, j) pairs | ICP/LPS pose ids (4 per factor) | LiDAR chunk ranges per pose
     int* t_imu = tab; int* t_rel = tab + 64; int* t_lch = tab + 112;
-    if ((int)blockIdx.x < nSblk) {
+    if (blk < nSblk) {
         if (P.skip_mask & 32) return;
         // stage the small index tables once per workgroup
         if (t < 2 * P.n_imu && t < 64) t_imu[t] = (t & 1) ? P.imu_j[t >> 1] : P.imu_i[t >> 1];
         if (t >= 64 && t < 64 + 4 * n_rel) { const int q = t - 64, f = q >> 2, b = q & 3; t_rel[q] = f < P.n_icp ? P.icp_ids[4 * f + b] : (b < 2 ? P.lps_ids[2 * (f - P.n_icp) + b] : -1); }
         if (t >= 128 && t < 128 + 2 * (K + 1) && t < 128 + 132) t_lch[t - 128] = P.lchunk_pose[t - 128];
         __syncthreads();
-        const int el = t & (RED_EPW - 1), slice = t >> 5;
-        const int idx = blockIdx.x * RED_EPW + el;
+        const int el = t & (EPW - 1), slice = t / EPW;
+        const int idx = blk * EPW + el;
         int i = 0, j = 0;
         const bool ok = idx < NL;
         if (ok) {
@@ -576,15 +578,15 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl) {
         return;
     }
     // ---- gradient vectors bc / gred: 2D entries, same 8-slice scheme -------------------------------------------------
-    const int nVblk = (2 * D + RED_EPW - 1) / RED_EPW;
-    if ((int)blockIdx.x < nSblk + nVblk) {
+    const int nVblk = (2 * D + EPW - 1) / EPW;
+    if (blk < nSblk + nVblk) {
         if (P.skip_mask & 64) return;
         if (t < 2 * P.n_imu && t < 64) t_imu[t] = (t & 1) ? P.imu_j[t >> 1] : P.imu_i[t >> 1];
         if (t >= 64 && t < 64 + 4 * n_rel) { const int q = t - 64, f = q >> 2, b = q & 3; t_rel[q] = f < P.n_icp ? P.icp_ids[4 * f + b] : (b < 2 ? P.lps_ids[2 * (f - P.n_icp) + b] : -1); }
         if (t >= 128 && t < 128 + 2 * (K + 1) && t < 128 + 132) t_lch[t - 128] = P.lchunk_pose[t - 128];
         __syncthreads();
-        const int el = t & (RED_EPW - 1), slice = t >> 5;
-        const int v = ((int)blockIdx.x - nSblk) * RED_EPW + el;
+        const int el = t & (EPW - 1), slice = t / EPW;
+        const int v = (blk - nSblk) * EPW + el;
         const bool ok = v < 2 * D;
         const int which = v >= D ? 1 : 0, i = which ? v - D : v;       // 0: bc, 1: gred
         double acc = 0.0;
@@ -612,42 +614,52 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl) {
     __shared__ double red[8];
     if (P.skip_mask & 64) return;
     double c = 0.0;
-    for (int w = t; w < P.n_vwg; w += VIL_THREADS) c += P.vpart[(size_t)w * P.VP + P.NVT + 3 * NV];
-    for (int q = t; q < P.n_pchunk + P.n_echunk; q += VIL_THREADS) c += P.lpart[(size_t)q * 28 + 27];
-    for (int f = t; f < P.n_imu; f += VIL_THREADS) c += P.ipart[(size_t)f * 931 + 930];
-    for (int f = t; f < n_rel; f += VIL_THREADS) c += rel0[(size_t)f * 601 + 600];
+    for (int w = t; w < P.n_vwg; w += 8 * EPW) c += P.vpart[(size_t)w * P.VP + P.NVT + 3 * NV];
+    for (int q = t; q < P.n_pchunk + P.n_echunk; q += 8 * EPW) c += P.lpart[(size_t)q * 28 + 27];
+    for (int f = t; f < P.n_imu; f += 8 * EPW) c += P.ipart[(size_t)f * 931 + 930];
+    for (int f = t; f < n_rel; f += 8 * EPW) c += rel0[(size_t)f * 601 + 600];
     if (t == 0 && P.pn > 0) c += P.mpart[P.pn];
-    c = wave_sum(c);                                   // (256 live threads: four waves)
+    c = wave_sum(c);
     if ((t & 63) == 0) red[t >> 6] = c;
     __syncthreads();
-    if (t == 0) put(sb.cost, red[0] + red[1] + red[2] + red[3]);
+    if (t == 0) { double tot = 0.0; for (int w = 0; w < EPW / 8; ++w) tot += red[w]; put(sb.cost, tot); }      // (EPW / 8 waves)
 }
 
 // Gather of the sweep's partial records (reduce_gather above) as a launch of its own: vil_linearize / the marginalisation (no step kernel
-// behind it) and the multi-GPU path (the collective sits between gather and step).  A solve on one GPU gathers inside k_step (rs_merged).
-__global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P) {
+// behind it), the multi-GPU path (the collective sits between gather and step) and windows too large for the merged launch (K > 12) -- for
+// those the grid carries one more workgroup per 16 x 16 tile of W W^T (vil_prechain.hpp; n_gather = the gather workgroups).  A solve of a
+// small window on one GPU gathers inside k_step (rs_merged).
+__global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P, int n_gather) {
     const Ctl ctl = *P.ctl;
     if (ctl.done) return;
-    reduce_gather(P, ctl);
+    if ((int)blockIdx.x >= n_gather) { vd::prechain_ww_tile(P, (int)blockIdx.x - n_gather); return; }
+    reduce_gather(P, ctl, (int)blockIdx.x);
 }
 
-// The sweep: grid = n_imu + 2 + n_vwg + ceil(n_pchunk / 2) + ceil(n_echunk / 2) workgroups of VIL_SWEEP_THREADS threads.
-// Workgroup order: [imu x n_imu | prior | rel | visual x n_vwg | plane | edge] (roles: top of this file)
+// the IMU / prior workgroup `slot` of this launch has written its record (read by the chain workgroup of the same launch, prechain 2).
+// Epoch of the flags: solve generation + Ctl::swe, which only the step kernel advances.
+__device__ __forceinline__ void sweep_signal(const DevP& P, const Ctl& ctl, int slot) {
+    __threadfence();                 // every wave's stores of the record (__syncthreads alone does not wait for global stores)
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(P.swflag + slot, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The sweep: grid = n_imu + 2 (+ 1: prechain 2) + n_vwg + ceil(n_pchunk / 2) + ceil(n_echunk / 2) workgroups of VIL_SWEEP_THREADS threads.
+// Workgroup order: [imu x n_imu | prior | rel | (chain) | visual x n_vwg | plane | edge] -- the short roles the chain workgroup waits for
+// come first (roles: top of this file)
 __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O) {
     extern __shared__ double sm[];
     const Ctl ctl = *P.ctl;
-    if (ctl.done) {                                      // the solve has ended: the first launch to see it writes the result out (vil_finish.hpp)
-        if (blockIdx.x == 0 && !ctl.outd && ctl.lin_mode == 0) vd::solve_finish(P, ctl.cur, ctl.status, ctl.gen);
-        return;
-    }
+    if (ctl.done) return;                                // (the result of a finished solve is written out by k_finish, vil_finish.hpp)
     if (blockIdx.x == 0 && threadIdx.x == 0) P.ctl->n_sweeps = ctl.n_sweeps + 1;   // live (not early-exited) launches, for the profiler
     const int cand = 1 - ctl.cur;
     const double* x = P.x[cand];
     SysBuf sb = P.sys[cand];
     int b = blockIdx.x;
-    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm); return; }
+    const bool pre = P.prechain == 2 && ctl.lin_mode == 0;
+    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm); if (pre) sweep_signal(P, ctl, b); return; }
     b -= P.n_imu;
-    if (b == 0) { if (!(P.skip_mask & 16)) vd::sweep_prior(P, x, sm); return; }
+    if (b == 0) { if (!(P.skip_mask & 16)) vd::sweep_prior(P, x, sm); if (pre) sweep_signal(P, ctl, P.n_imu); return; }
     if (b == 1) {
         if (!(P.skip_mask & 16)) vd::sweep_misc(P, O, x, sm);
         if (P.world > 1) {                               // factor set sharded over ranks: the visual workgroups of this rank form the candidate inverse depth of
@@ -659,6 +671,7 @@ __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O
         return;
     }
     b -= 2;
+    if (P.prechain == 2) { if (b == 0) { if (pre) vd::prechain_wg(P, ctl, O.jacobi_scaling, sm, 0, true); return; } b -= 1; }
     // visual workgroups next: the longest-running factor role
     if (b < P.n_vwg) { if (!(P.skip_mask & 1)) vd::sweep_visual(P, O, ctl, b, x, sb, sm); return; }
     b -= P.n_vwg;

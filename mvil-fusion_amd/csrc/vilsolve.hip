@@ -166,7 +166,7 @@ struct vil_ctx {
     size_t off_x0 = 0;             // backup of the uploaded state (device)
     double* d_x0 = nullptr;
     std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
-    int n_blocks_sweep = 0, n_blocks_reduce = 0, n_ww = 0;      // n_ww: tiles of W W^T formed by extra workgroups of k_reduce (vil_prechain.hpp)
+    int n_blocks_sweep = 0, n_blocks_reduce = 0, n_gather_m = 0, n_ww = 0;      // n_ww: tiles of W W^T formed by extra workgroups of k_reduce (vil_prechain.hpp)
     size_t lds_sweep = 0, lds_step = 0, lds_reduce = 0;
     size_t span = 0;               // doubles of one linear-system set (SysBuf::ar): the multi-GPU all-reduce message
     bool step_lds = false;
@@ -192,6 +192,7 @@ struct vil_ctx {
     struct ChunkGraph { int n; SolveOpts so; hipGraphExec_t exec; };
     std::vector<ChunkGraph> graphs;
     int use_graph = -1;            // VIL_GRAPH=0 disables (tuning build)
+    std::vector<int> chtab_key; int* d_chtab = nullptr; int* h_chtab = nullptr; size_t chtab_cap = 0; int chtab_n = 0; hipEvent_t chtab_ev = nullptr; bool chtab_ev_pending = false;      // gather table of the chain workgroup (vil_prechain.hpp)
     bool graph_failed = false;     // a chunk with a collective could not be captured: direct launches from then on
     int solve_gen = 0;             // generation counter of the helper-workgroup flags (Ctl::gen)
     int solves_since_upload = 0;
@@ -350,6 +351,9 @@ void vil_destroy(vil_ctx* c) {
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->marg_ws) hipFree(c->marg_ws);
     if (c->lc_tmp) hipFree(c->lc_tmp);
+    if (c->d_chtab) hipFree(c->d_chtab);
+    if (c->h_chtab) hipHostFree(c->h_chtab);
+    if (c->chtab_ev) hipEventDestroy(c->chtab_ev);
     if (c->ipc_tmp) hipFree(c->ipc_tmp);
     if (c->ipc) { for (int r = 0; r < c->ipc->world; ++r) if (r != c->ipc->rank && c->ipc->peer_base[r]) hipIpcCloseMemHandle(c->ipc->peer_base[r]); if (c->ipc->base) hipFree(c->ipc->base); c->ipc.reset(); }
     if (c->d_pl) hipFree(c->d_pl);
@@ -699,7 +703,6 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         const int i = p->imu_i[f], j = p->imu_j[f];
         if (j != i + 1 || as_i[i] >= 0 || as_j[j] >= 0) pre_ok = false; else { as_i[i] = f; as_j[j] = f; }
     }
-    if (pre_ok && 8 * vd::prechain_lds_doubles(K) > 150 * 1024) pre_ok = false;       // the staged slab must fit LDS (K <= 12)
     {
         const int rs = vd::chain_rs(K);
         put(nullptr, 8 * (size_t)vd::chain_wcols(K) * rs, (void**)&P.chW);
@@ -707,33 +710,61 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         put(nullptr, 8 * (size_t)9 * K, (void**)&P.chSc); put(nullptr, 8 * (size_t)9 * K, (void**)&P.chDc);
         put(nullptr, 8 * (size_t)2 * (NV + 1), (void**)&P.chZ); put(nullptr, 8 * 4, (void**)&P.chQ); put(nullptr, 16, (void**)&P.chOk);
         { const int NLg = (D * (D + 1) / 2 + RED_EPW - 1) / RED_EPW + (2 * D + RED_EPW - 1) / RED_EPW + 1; put(nullptr, 4 * (size_t)(NLg + 8), (void**)&P.gflag); }
-        put(nullptr, 64, (void**)&P.chflag); put(nullptr, 4 * 64, (void**)&P.wwflag);
+        put(nullptr, 64, (void**)&P.chflag); put(nullptr, 4 * 64, (void**)&P.wwflag); put(nullptr, 4 * (size_t)(K + 8), (void**)&P.swflag);
         { const size_t Tp = (size_t)(NV + 1 + 15) / 16; put(nullptr, 8 * (size_t)TILE_SZ * (Tp * (Tp + 1) / 2), (void**)&P.chWW); }
     }
     if (pre_ok) {
-        const int NPs = vd::chain_slab_nps(K), pn = P.pn;
-        const int o_dg = 0, o_sub = vd::even_up(45 * K), o_pb = o_sub + vd::even_up(81 * K), o_rhs = o_pb + 9 * K * NPs;
-        std::vector<int> tab;
-        auto ip = [&](int f, int la, int lb) { return f < 0 ? -1 : f * 931 + la * 30 + lb; };
-        auto pr = [&](int r, int col) { if (pn <= 0) return -1; const int pi = pinv[r], pj = pinv[col]; return (pi >= 0 && pj >= 0) ? pi * pn + pj : -1; };
-        auto emit = [&](int dst, int a, int b, int cc) { if (a < 0 && b < 0 && cc == -1) return; tab.push_back(dst); tab.push_back(a); tab.push_back(b); tab.push_back(cc); };
-        for (int k = 0; k < K; ++k) {
-            const int fi = as_i[k], fj = as_j[k];
-            for (int i = 0; i < 9; ++i) for (int j = 0; j <= i; ++j) emit(o_dg + 45 * k + i * (i + 1) / 2 + j, ip(fi, 6 + i, 6 + j), ip(fj, 21 + i, 21 + j), pr(NV + 9 * k + i, NV + 9 * k + j));
-            if (k + 1 < K) for (int q = 0; q < 9; ++q) for (int cc = 0; cc < 9; ++cc) emit(o_sub + 81 * k + q * 9 + cc, ip(fi, 21 + q, 6 + cc), -1, pr(NV + 9 * (k + 1) + q, NV + 9 * k + cc));
-            for (int cc = 0; cc < 9; ++cc) {
-                const int pj = pn > 0 ? pinv[NV + 9 * k + cc] : -1;
-                emit(o_rhs + 9 * k + cc, fi < 0 ? -1 : fi * 931 + 900 + 6 + cc, fj < 0 ? -1 : fj * 931 + 900 + 21 + cc, pj >= 0 ? -pj - 2 : -1);
-                for (int r = 0; r < NV; ++r) {
-                    const int fr = r < 6 * K ? r / 6 : -9, lr = r - 6 * fr;
-                    const int a = (fi >= 0 && (fr == k || fr == k + 1)) ? ip(fi, fr == k ? lr : 15 + lr, 6 + cc) : -1;
-                    const int b = (fj >= 0 && (fr == k - 1 || fr == k)) ? ip(fj, fr == k - 1 ? lr : 15 + lr, 21 + cc) : -1;
-                    emit(o_pb + (9 * k + cc) * NPs + r, a, b, pr(r, NV + 9 * k + cc));
+        // the table depends on K, the IMU factor layout and the prior's block structure only: consecutive windows of a tracker share it, so it
+        // lives in its own device buffer and is rebuilt (and sent) only when that key changes
+        std::vector<int> key; key.reserve(2 * K + D + 2);
+        key.push_back(K); key.push_back(P.pn); key.insert(key.end(), as_i.begin(), as_i.end()); key.insert(key.end(), as_j.begin(), as_j.end()); key.insert(key.end(), pinv.begin(), pinv.end());
+        if (key != c->chtab_key) {
+            const int NPs = vd::chain_slab_nps(K), pn = P.pn;
+            const int o_dg = 0, o_sub = vd::even_up(45 * K), o_pbc = o_sub + vd::even_up(81 * K), o_pp = o_pbc + 162 * K, o_rhs = o_pp + CHAIN_NPC_MAX * NPs;
+            std::vector<int> tab, pq(9 * K, -1);
+            int npc = 0;
+            for (int jc = 0; jc < 9 * K; ++jc) if (pn > 0 && pinv[NV + jc] >= 0) pq[jc] = npc++;
+            if (npc > CHAIN_NPC_MAX) pre_ok = false;       // (cannot happen: the prior's speed-bias blocks are neighbours -- checked for the chain path)
+            auto ip = [&](int f, int la, int lb) { return f < 0 ? -1 : f * 931 + la * 30 + lb; };
+            auto pr = [&](int r, int col) { if (pn <= 0) return -1; const int pi = pinv[r], pj = pinv[col]; return (pi >= 0 && pj >= 0) ? pi * pn + pj : -1; };
+            auto emit = [&](int dst, int a, int b, int cc) { if (a < 0 && b < 0 && cc == -1) return; tab.push_back(dst); tab.push_back(a); tab.push_back(b); tab.push_back(cc); };
+            for (int k = 0; k < K && pre_ok; ++k) {
+                const int fi = as_i[k], fj = as_j[k];
+                for (int i = 0; i < 9; ++i) for (int j = 0; j <= i; ++j) emit(o_dg + 45 * k + i * (i + 1) / 2 + j, ip(fi, 6 + i, 6 + j), ip(fj, 21 + i, 21 + j), pr(NV + 9 * k + i, NV + 9 * k + j));
+                if (k + 1 < K) for (int q = 0; q < 9; ++q) for (int cc = 0; cc < 9; ++cc) emit(o_sub + 81 * k + q * 9 + cc, ip(fi, 21 + q, 6 + cc), -1, pr(NV + 9 * (k + 1) + q, NV + 9 * k + cc));
+                for (int cc = 0; cc < 9; ++cc) {
+                    const int pj = pn > 0 ? pinv[NV + 9 * k + cc] : -1;
+                    emit(o_rhs + 9 * k + cc, fi < 0 ? -1 : fi * 931 + 900 + 6 + cc, fj < 0 ? -1 : fj * 931 + 900 + 21 + cc, pj >= 0 ? -pj - 2 : -1);
+                    for (int d = 0; d < 3; ++d) {              // pose rows of frames k-1, k, k+1: the IMU factors' share, compact
+                        const int fr = k - 1 + d;
+                        if (fr < 0 || fr >= K) continue;
+                        for (int lr = 0; lr < 6; ++lr) {
+                            const int a = (fi >= 0 && (fr == k || fr == k + 1)) ? ip(fi, fr == k ? lr : 15 + lr, 6 + cc) : -1;
+                            const int b = (fj >= 0 && (fr == k - 1 || fr == k)) ? ip(fj, fr == k - 1 ? lr : 15 + lr, 21 + cc) : -1;
+                            emit(o_pbc + ((k * 3 + d) * 6 + lr) * 9 + cc, a, b, -1);
+                        }
+                    }
+                    if (pq[9 * k + cc] >= 0) for (int r = 0; r < NV; ++r) emit(o_pp + pq[9 * k + cc] * NPs + r, -1, -1, pr(r, NV + 9 * k + cc));      // the prior's share: every row
                 }
             }
+            tab.insert(tab.end(), pq.begin(), pq.end());       // behind the table: the chain column -> prior column map
+            while (tab.size() & 3) tab.push_back(0);
+            const size_t bytes = 4 * tab.size();
+            if (c->chtab_ev_pending) { HIPCHK(hipEventSynchronize(c->chtab_ev)); c->chtab_ev_pending = false; }      // the previous table's DMA has left the pinned copy
+            if (bytes > c->chtab_cap) {
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (c->d_chtab) hipFree(c->d_chtab); if (c->h_chtab) hipHostFree(c->h_chtab);
+                c->d_chtab = nullptr; c->h_chtab = nullptr; c->chtab_cap = 0;
+                HIPCHK(hipMalloc((void**)&c->d_chtab, 2 * bytes)); HIPCHK(hipHostMalloc((void**)&c->h_chtab, 2 * bytes, hipHostMallocDefault));
+                c->chtab_cap = 2 * bytes;
+            }
+            memcpy(c->h_chtab, tab.data(), bytes);
+            HIPCHK(hipMemcpyAsync(c->d_chtab, c->h_chtab, bytes, hipMemcpyHostToDevice, c->stream));
+            if (!c->chtab_ev) HIPCHK(hipEventCreateWithFlags(&c->chtab_ev, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(c->chtab_ev, c->stream)); c->chtab_ev_pending = true;
+            c->chtab_n = ((int)tab.size() - ((9 * K + 3) & ~3)) / 4; c->chtab_key.swap(key);
         }
-        P.n_chtab = (int)tab.size() / 4;
-        put(tab.data(), 4 * tab.size(), (void**)&P.chtab);
+        P.n_chtab = c->chtab_n;
     }
     if (const char* ev = VIL_TUNE_ENV("VIL_SKIP")) P.skip_mask = atoi(ev);
     // helper workgroups of the step kernel: worth it once every master thread would own more than one landmark
@@ -754,6 +785,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     for (const Fix& f : fix) *f.slot = ar.d + (f.scratch ? tables : 0) + f.off;
     if (dl) { P.pl_c = dl->plane_soa; P.pl_stride = dl->plane_stride; P.ed_c = dl->edge_soa; P.ed_stride = dl->edge_stride; }
     if (!gp) { P.glm_start = P.lm_start; P.glm_acol = P.lm_acol; P.gfcol = P.fcol; }
+    if (pre_ok) { P.chtab = c->d_chtab; P.chpq = c->d_chtab + 4 * (size_t)c->chtab_n; }
     if (c->lidar_resident) { P.pl_c = c->d_pl; P.pl_stride = c->nslot * c->cap_p; P.ed_c = c->d_ed; P.ed_stride = c->nslot * c->cap_e; }
     if (ws && P.pn) { P.px0 = ws->px0; P.pJ0 = ws->pJ0; P.pr0 = ws->pr0; P.pH = ws->pH; P.pg0 = ws->pg0; P.pc0 = ws->pc0; }      // the device prior slot, contractions included
     {   // what vil_marginalize_resident will need (a few passes over int tables)
@@ -817,20 +849,33 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             if (8 * (tiles + wt + scr) + fixed <= 160 * 1024) { P.chain = 1; c->lds_step = 8 * (tiles + wt + scr); }
             else if (8 * (tiles + scr) + fixed <= 160 * 1024) { P.chain = 2; c->lds_step = 8 * (tiles + scr); }
         }
-        // one GPU, chain windows up to K = 12: gather + step in ONE launch with the chain eliminated beside the gather (vil_prechain.hpp).
-        // (Larger windows keep the separate gather: with ~100 kB of dynamic LDS per workgroup their ~1500 gather workgroups would need
-        //  six rounds on 256 compute units; the small gather kernel runs eight workgroups per unit.)
-        const bool merged = !c->split && pre_ok && P.chain != 0 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
-        P.prechain = merged ? 1 : 0;
+        // one GPU, chain windows up to K = 12: gather + step in ONE launch with the chain eliminated beside the gather (prechain 1, vil_prechain.hpp).
+        // Larger windows keep the separate gather -- with ~100 kB of dynamic LDS per workgroup their ~1500 gather workgroups would need six
+        // rounds on 256 compute units, the small gather kernel runs eight workgroups per unit -- and eliminate the chain inside k_sweep, behind
+        // the IMU / prior workgroups' flags and under the visual workgroups (42 us at K = 20), with the W W^T tiles on extra workgroups of
+        // k_reduce (prechain 2).
+        const size_t Tp_ = (size_t)(NV + 1 + 15) / 16, tiles_ = (size_t)TILE_SZ * (Tp_ * (Tp_ + 1) / 2);
+        const size_t lds3 = 8 * (tiles_ + 54 * (size_t)K + 82 * (size_t)K + vd::even_up(9 * K) + 16), ldsc = 8 * vd::prechain_lds_doubles(K);
+        const bool can_pre = !c->split && pre_ok && P.chain != 0 && Tp_ * (Tp_ + 1) / 2 <= 64 && lds3 + sizeof(vd::StepShared) + 512 <= 160 * 1024 && ldsc <= 150 * 1024;
+        const bool merged = can_pre && K <= 12 && std::max(lds3, ldsc) <= 80 * 1024 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
+        P.prechain = merged ? 1 : (can_pre ? 2 : 0);
         c->n_ww = 0;
         if (P.prechain) {
-            const size_t Tp = (size_t)(NV + 1 + 15) / 16, tiles = (size_t)TILE_SZ * (Tp * (Tp + 1) / 2);
             P.chain = 3;
-            c->lds_step = std::max(8 * (tiles + 54 * (size_t)K + 82 * (size_t)K + vd::even_up(9 * K) + 16), 8 * vd::prechain_lds_doubles(K));      // (the chain workgroup is one of this launch's)
-            c->n_ww = (int)(Tp * (Tp + 1) / 2);
+            c->n_ww = (int)(Tp_ * (Tp_ + 1) / 2);
+            if (merged) c->lds_step = std::max(lds3, ldsc);       // (the chain workgroup is one of the merged launch's)
+            else {
+                c->lds_step = lds3;
+                c->lds_sweep = std::max(c->lds_sweep, ldsc);      // the chain workgroup rides in k_sweep
+                if ((int)c->lds_sweep > c->attr_sweep) { HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep)); c->attr_sweep = (int)c->lds_sweep; }
+                c->n_blocks_sweep += 1;
+            }
         }
         c->P.chain = P.chain; c->P.chain_rs = P.chain_rs; c->P.prechain = P.prechain;
-        c->P.rs_merged = merged ? 1 : 0; c->P.n_ww = c->n_ww; c->P.n_gather = merged ? c->n_blocks_reduce : 0;
+        // (the merged launch gathers 64 entries per 512-thread workgroup: half as many workgroups as the gather kernel's)
+        const bool g64 = VIL_TUNE_ENV("VIL_GATHER32") == nullptr;
+        c->n_gather_m = g64 ? (D * (D + 1) / 2 + 63) / 64 + (2 * D + 63) / 64 + 1 : c->n_blocks_reduce;
+        c->P.rs_merged = merged ? (g64 ? 2 : 1) : 0; c->P.n_ww = c->n_ww; c->P.n_gather = merged ? c->n_gather_m : 0;
     }
     if (P.chain) {
         c->step_lds = true;
@@ -1022,7 +1067,7 @@ static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
 }
 static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr) {
     const bool merged = step && c->P.rs_merged;          // one GPU: the gather rides in the step kernel's launch (vil_step.hpp)
-    if (!merged) hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce), dim3(VIL_THREADS), 0, c->stream, view(c, 0));
+    if (!merged) hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce + ((step && c->P.prechain == 2) ? c->n_ww : 0)), dim3(VIL_THREADS), 0, c->stream, view(c, 0), c->n_blocks_reduce);
     if (ev_mid) hipEventRecord(ev_mid, c->stream);
     if (c->split) {                                    // the one collective of the iteration
         const int st = all_reduce2(c, c->P.sys[0].ar, c->P.sys[1].ar, c->span);
@@ -1031,7 +1076,7 @@ static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEve
     if (!step) return VIL_OK;
     DevP Ps = view(c, 1);
     if (!merged) { Ps.rs_merged = 0; Ps.n_ww = 0; Ps.n_gather = 0; }
-    const dim3 g(1 + c->P.n_help + (merged ? (c->P.prechain ? 1 : 0) + c->n_ww + c->n_blocks_reduce : 0)), b(VIL_STEP_THREADS);
+    const dim3 g(1 + c->P.n_help + (merged ? (c->P.prechain ? 1 : 0) + c->n_ww + c->n_gather_m : 0)), b(VIL_STEP_THREADS);
     if (c->P.chain == 3) hipLaunchKernelGGL((k_step<true, 3>), g, b, c->lds_step, c->stream, Ps, so);
     else if (c->P.chain == 1) hipLaunchKernelGGL((k_step<true, 1>), g, b, c->lds_step, c->stream, Ps, so);
     else if (c->P.chain == 2) hipLaunchKernelGGL((k_step<true, 2>), g, b, c->lds_step, c->stream, Ps, so);

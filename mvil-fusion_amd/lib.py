@@ -167,31 +167,31 @@ class Backend:
 
     def win_push_frame(self, fr):
         """fr: dict with dt (n), acc (n x 3), gyr (n x 3), acc0, gyr0, lin_ba, lin_bg, obs_track (m), obs (m x 8), plane (p x 7), edge (e x 9)."""
-        f = abi.VilWinFrame()
-        keep = [abi.f64(fr["dt"]), abi.f64(fr["acc"]).reshape(-1, 3), abi.f64(fr["gyr"]).reshape(-1, 3), abi.i32(fr["obs_track"]), abi.f64(fr["obs"]).reshape(-1, abi.VIL_WIN_OBS),
-                abi.f64(fr["plane"]).reshape(-1, 7), abi.f64(fr["edge"]).reshape(-1, 9)]
-        f.n_samples = len(keep[0]); f.dt, f.acc, f.gyr = abi._d(keep[0]), abi._d(keep[1]), abi._d(keep[2])
-        for k in range(3):
-            f.acc0[k], f.gyr0[k], f.lin_ba[k], f.lin_bg[k] = float(fr["acc0"][k]), float(fr["gyr0"][k]), float(fr["lin_ba"][k]), float(fr["lin_bg"][k])
-        f.n_obs = len(keep[3]); f.obs_track, f.obs = abi._d(keep[3]), abi._d(keep[4])
-        f.n_plane = len(keep[5]); f.plane_const = abi._d(keep[5]); f.n_edge = len(keep[6]); f.edge_const = abi._d(keep[6])
+        f = self._wf = getattr(self, "_wf", None) or abi.VilWinFrame()
+        c = np.ascontiguousarray
+        keep = (c(fr["dt"], np.float64), c(fr["acc"], np.float64), c(fr["gyr"], np.float64), c(fr["obs_track"], np.int32), c(fr["obs"], np.float64), c(fr["plane"], np.float64), c(fr["edge"], np.float64))
+        f.n_samples = len(keep[0]); f.dt, f.acc, f.gyr = keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data
+        f.acc0[:] = [float(v) for v in fr["acc0"]]; f.gyr0[:] = [float(v) for v in fr["gyr0"]]; f.lin_ba[:] = [float(v) for v in fr["lin_ba"]]; f.lin_bg[:] = [float(v) for v in fr["lin_bg"]]
+        f.n_obs = len(keep[3]); f.obs_track, f.obs = keep[3].ctypes.data, keep[4].ctypes.data
+        f.n_plane = keep[5].size // 7; f.plane_const = keep[5].ctypes.data; f.n_edge = keep[6].size // 9; f.edge_const = keep[6].ctypes.data
         self._call("win_push_frame", C.byref(f))
 
     def win_drop_frame(self, flag):
         self._call("win_drop_frame", C.c_int32(int(flag)))
 
     def win_solve(self, w, opts=None):
-        """w: a Window whose visual structure is given per landmark (w.lm_track / lm_start / lm_nobs); state in place, like solve()."""
+        """w: a Window whose visual structure is given per landmark (w.lm_track / lm_start / lm_nobs, int32); state in place, like solve()."""
         opts = opts or abi.default_options()
-        w._fix()
-        p = abi.VilWinProblem()
-        keep = [abi.i32(w.lm_track), abi.i32(w.lm_start), abi.i32(w.lm_nobs)]
-        p.L = w.L; p.lm_track, p.lm_start, p.lm_nobs = abi._d(keep[0]), abi._d(keep[1]), abi._d(keep[2])
-        p.lm_const, p.pose_const, p.sb_const = abi._d(w.lm_const), abi._d(w.pose_const), abi._d(w.sb_const)
+        p = self._wp = getattr(self, "_wp", None) or abi.VilWinProblem()
+        d = abi._d
+        p.L = w.L; p.lm_track, p.lm_start, p.lm_nobs = d(w.lm_track), d(w.lm_start), d(w.lm_nobs)
+        p.lm_const, p.pose_const, p.sb_const = d(w.lm_const), d(w.pose_const), d(w.sb_const)
         p.ex_const, p.td_const = int(w.ex_const), int(w.td_const)
-        p.n_icp = len(w.icp_ids); p.icp_ids, p.icp_const = abi._d(w.icp_ids), abi._d(w.icp_const)
-        p.n_lps = len(w.lps_ids); p.lps_ids, p.lps_const = abi._d(w.lps_ids), abi._d(w.lps_const)
-        s = w.c_state()
+        p.n_icp = len(w.icp_ids); p.icp_ids, p.icp_const = d(w.icp_ids), d(w.icp_const)
+        p.n_lps = len(w.lps_ids); p.lps_ids, p.lps_const = d(w.lps_ids), d(w.lps_const)
+        s = abi.VilState()
+        s.K, s.L = w.K, w.L
+        s.pose, s.speedbias, s.ex_pose, s.td, s.inv_depth = d(w.pose), d(w.speedbias), d(w.ex_pose), d(w.td), d(w.inv_depth)
         summ = abi.VilSummary()
         self._call("win_solve", C.byref(p), C.byref(s), C.byref(opts), C.byref(summ))
         return summ

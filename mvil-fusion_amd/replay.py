@@ -388,6 +388,7 @@ class Replay:
     def win_window(self):
         """The window for vil_win_solve: the small tables only -- visual structure per landmark, no factor constants, no LiDAR, no IMU records, no prior."""
         w = self.window(with_lidar=False)
+        w._fix()                                             # (dtypes / contiguity settled here: Backend.win_solve takes the arrays as they are)
         w.lm_track = np.array([tr.slot for tr in w._sel], np.int32)
         w.lm_start = np.array([tr.start for tr in w._sel], np.int32)
         w.lm_nobs = np.array([len(tr.obs) for tr in w._sel], np.int32)

@@ -94,7 +94,7 @@ def test_release_build_has_no_tuning_knobs():
     -DVIL_TUNING build; the shipping library does not even contain their names."""
     blob = open(lib.LIB_PATH, "rb").read()
     for knob in (b"VIL_SKIP", b"VIL_HELP", b"VIL_VWG", b"VIL_VFBAL", b"VIL_DENSE_STEP", b"VIL_MARG_PIVOTED", b"VIL_MARG_DEBUG", b"VIL_GRAPH",
-                 b"VIL_FORCE_SPLIT", b"VIL_PRECHAIN", b"VIL_MAP_FUSED_MAX", b"VGICP_", b"VPRE_TIMING"):
+                 b"VIL_FORCE_SPLIT", b"VIL_PRECHAIN", b"VIL_NO_MERGE", b"VIL_GATHER32", b"VIL_UPLOAD_TRACE", b"VIL_MAP_FUSED_MAX", b"VGICP_", b"VPRE_TIMING"):
         assert knob not in blob, knob
 
 
