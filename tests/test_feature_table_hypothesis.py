@@ -220,7 +220,7 @@ def make_image(n, seed, id_range):
         jit = 0.002 if seed % 6 else 0.2                            # five images in six move little: the parallax test then picks MARGIN_SECOND_NEW
         img.append((fid, (0.6 * np.sin(1.7 * fid) + float(rng.normal(0, jit)), 0.45 * np.cos(2.3 * fid) + float(rng.normal(0, jit)), float(rng.uniform(100, 700)), float(rng.uniform(100, 400)),
                           float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), depth)))
-    scales = [float(v) for v in np.where(rng.uniform(size=80) < 0.15, -1.0, 1.0) * rng.uniform(0.5, 2.0, 80)]      # ~15 % of the solved depths go negative
+    scales = [float(v) for v in np.where(rng.uniform(size=80) < 0.08, -1.0, 1.0) * rng.uniform(0.5, 2.0, 80)]      # ~8 % of the solved depths go negative
     return img, scales
 
 
@@ -233,7 +233,7 @@ def test_feature_table_matches_transcribed_feature_manager(driver, steps):
 def test_feature_table_long_sequence_covers_every_branch(driver):
     """A fixed 80-image sequence: both marginalisation branches, the parallax decision (>= 20 continued tracks), failures removed, pre-window removeBack."""
     rng = np.random.default_rng(7)
-    steps = [(int(rng.integers(25, 41)), int(rng.integers(0, 2 ** 31 - 1)), int(rng.integers(0, 4)) if k < 4 else 1 + int(rng.integers(0, 3)), float(rng.uniform(-0.3, 0.3)), bool(rng.uniform() < 0.15), 45) for k in range(80)]
+    steps = [(int(rng.integers(60, 90)), int(rng.integers(0, 2 ** 31 - 1)), int(rng.integers(0, 4)) if k < 4 else 1 + int(rng.integers(0, 3)), float(rng.uniform(-0.3, 0.3)), bool(rng.uniform() < 0.15), 45) for k in range(80)]
     stats = run_sequence(driver, steps)
     assert stats["old"] >= 5 and stats["new"] >= 5 and stats["parallax_decisions"] >= 10 and stats["failures_removed"] >= 5 and stats["max_landmarks"] >= 10, stats
 
