@@ -129,6 +129,28 @@ public:
     const std::vector<FeatureTrack>& tracks() const { return tracks_; }
     int last_track_num = 0;
 
+    // ---- the fully resident window (vilsolve.h: vil_win_*) ------------------------------------------------------------------------
+    // What vil_win_push_frame takes for window frame `frame`: every track observed in it, by track slot, as [x y z vx vy cur_td row 0]
+    // (row = v - ROW / 2, projection_td_factor.cpp:12-19).  `slots`: feature id -> slot (TrackSlots below).
+    template <class Slots> void win_frame_obs(int frame, double row_half, Slots& slots, std::vector<int32_t>& obs_track, std::vector<double>& obs) const {
+        obs_track.clear(); obs.clear();
+        for (const FeatureTrack& t : tracks_) {
+            const int q = frame - t.start_frame;
+            if (q < 0 || q >= (int)t.obs.size()) continue;
+            const FeatureObs& o = t.obs[q];
+            obs_track.push_back(slots.slot(t.feature_id));
+            const double v[8] = {o.point[0], o.point[1], o.point[2], o.velocity[0], o.velocity[1], o.cur_td, o.uv[1] - row_half, 0.0};
+            obs.insert(obs.end(), v, v + 8);
+        }
+    }
+    // The landmark table of vil_win_problem: the tracks of the problem in table order (= feature_index, estimator.cpp:1192-1194)
+    template <class Slots> void win_landmarks(Slots& slots, std::vector<int32_t>& lm_track, std::vector<int32_t>& lm_start, std::vector<int32_t>& lm_nobs, std::vector<uint8_t>& lm_const) const {
+        lm_track.clear(); lm_start.clear(); lm_nobs.clear(); lm_const.clear();
+        for (const FeatureTrack& t : tracks_) if (in_problem(t)) {
+            lm_track.push_back(slots.slot(t.feature_id)); lm_start.push_back(t.start_frame); lm_nobs.push_back((int32_t)t.obs.size()); lm_const.push_back(t.lidar_depth_flag ? 1 : 0);
+        }
+    }
+
 private:
     FeatureTrack* find(int id) { for (FeatureTrack& t : tracks_) if (t.feature_id == id) return &t; return nullptr; }
     template <class Pred> void erase_if(Pred p) { tracks_.erase(std::remove_if(tracks_.begin(), tracks_.end(), p), tracks_.end()); }
@@ -140,6 +162,29 @@ private:
     }
     int W_; double init_depth_, min_parallax_;
     std::vector<FeatureTrack> tracks_;
+};
+
+// Track slots of the device-resident observation store: one per live feature track, handed out on first use, reusable once the track
+// has left the table (call retain() after every slide).
+class TrackSlots {
+public:
+    explicit TrackSlots(int max_tracks) : id_of_(max_tracks, -1) { for (int q = max_tracks - 1; q >= 0; --q) free_.push_back(q); }
+    int slot(int feature_id) {                        // -1: no slot left (more live tracks than vil_win_cfg.max_tracks)
+        for (size_t q = 0; q < id_of_.size(); ++q) if (id_of_[q] == feature_id) return (int)q;
+        if (free_.empty()) return -1;
+        const int q = free_.back(); free_.pop_back(); id_of_[q] = feature_id;
+        return q;
+    }
+    void retain(const std::vector<FeatureTrack>& live) {
+        for (size_t q = 0; q < id_of_.size(); ++q) {
+            if (id_of_[q] < 0) continue;
+            bool found = false;
+            for (const FeatureTrack& t : live) if (t.feature_id == id_of_[q]) { found = true; break; }
+            if (!found) { id_of_[q] = -1; free_.push_back((int)q); }
+        }
+    }
+private:
+    std::vector<int> id_of_, free_;
 };
 
 // ---- the window's per-frame state and IMU sample buffers (estimator.h:96-130), and its shift -------------------------------

@@ -106,38 +106,44 @@ struct PriorCommit {
     double* pJ0; double* pr0; double* px0; double* pH; double* pg0; double* pc0; int* status;
 };
 __global__ __launch_bounds__(256) void k_prior_commit(PriorCommit A) {
-    const int t = threadIdx.x, b = blockIdx.x, nb = gridDim.x, n = A.n;
-    if (b == 0) {
-        if (t == 0) {
-            int xo = 0;
-            for (int q = 0; q < A.nblk; ++q) {
-                const int kind = A.kind[q], idx = A.index[q];
-                const double* src = kind == VIL_BLK_POSE ? A.x + 7 * idx : (kind == VIL_BLK_SPEEDBIAS ? A.x + 7 * A.K + 9 * idx : (kind == VIL_BLK_EX ? A.x + 16 * A.K : A.x + 16 * A.K + 7));
-                const int gs = (kind == VIL_BLK_POSE || kind == VIL_BLK_EX) ? 7 : (kind == VIL_BLK_SPEEDBIAS ? 9 : 1);
-                for (int k = 0; k < gs; ++k) A.px0[xo + k] = src[k];
-                xo += gs;
-            }
+    extern __shared__ double sJ[];                       // J0 (n x n column-major, column stride n + 1: conflict-free column walks) | r0
+    const int t = threadIdx.x, b = blockIdx.x, nb = gridDim.x, n = A.n, ns = n + 1;
+    double* sr = sJ + (size_t)n * ns;
+    bool bad = false;
+    for (int e = t; e < n * n; e += 256) { const double v = A.J0[e]; if (!(v - v == 0.0)) bad = true; sJ[(e / n) * ns + (e % n)] = v; if (b == 0) A.pJ0[e] = v; }
+    for (int e = t; e < n; e += 256) { const double v = A.r0[e]; if (!(v - v == 0.0)) bad = true; sr[e] = v; if (b == 0) A.pr0[e] = v; }
+    if (bad) atomicExch(A.status, VIL_ERR_NON_FINITE);
+    if (b == 0 && t == 0) {
+        int xo = 0;
+        for (int q = 0; q < A.nblk; ++q) {
+            const int kind = A.kind[q], idx = A.index[q];
+            const double* src = kind == VIL_BLK_POSE ? A.x + 7 * idx : (kind == VIL_BLK_SPEEDBIAS ? A.x + 7 * A.K + 9 * idx : (kind == VIL_BLK_EX ? A.x + 16 * A.K : A.x + 16 * A.K + 7));
+            const int gs = (kind == VIL_BLK_POSE || kind == VIL_BLK_EX) ? 7 : (kind == VIL_BLK_SPEEDBIAS ? 9 : 1);
+            for (int k = 0; k < gs; ++k) A.px0[xo + k] = src[k];
+            xo += gs;
         }
-        bool bad = false;
-        for (int e = t; e < n * n + n; e += 256) { const double v = e < n * n ? A.J0[e] : A.r0[e - n * n]; if (!(v - v == 0.0)) bad = true; if (e < n * n) A.pJ0[e] = v; else A.pr0[e - n * n] = v; }
-        if (bad) atomicExch(A.status, VIL_ERR_NON_FINITE);
     }
-    // contraction from the SOURCE arrays (the copies above may still be in flight in another workgroup)
+    __syncthreads();
+    // the contractions out of LDS (column i of J0 at sJ[i * ns ...]): every workgroup staged the whole matrix (39 kB at n = 70), each computes a slice
     for (int e = b * 256 + t; e < n * n + n + 1; e += nb * 256) {
         if (e < n * n) {
             const int i = e / n, k = e % n;
-            double s = 0;
-            for (int q = 0; q < n; ++q) s += A.J0[(size_t)i * n + q] * A.J0[(size_t)k * n + q];
-            A.pH[e] = s;
+            const double* ci = sJ + (size_t)i * ns; const double* ck = sJ + (size_t)k * ns;
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            int q = 0;
+            for (; q + 3 < n; q += 4) { s0 += ci[q] * ck[q]; s1 += ci[q + 1] * ck[q + 1]; s2 += ci[q + 2] * ck[q + 2]; s3 += ci[q + 3] * ck[q + 3]; }
+            for (; q < n; ++q) s0 += ci[q] * ck[q];
+            A.pH[e] = (s0 + s1) + (s2 + s3);
         } else if (e < n * n + n) {
             const int i = e - n * n;
-            double s = 0;
-            for (int q = 0; q < n; ++q) s += A.J0[(size_t)i * n + q] * A.r0[q];
-            A.pg0[i] = s;
+            const double* ci = sJ + (size_t)i * ns;
+            double s0 = 0, s1 = 0;
+            for (int q = 0; q < n; ++q) { if (q & 1) s1 += ci[q] * sr[q]; else s0 += ci[q] * sr[q]; }
+            A.pg0[i] = s0 + s1;
         } else {
-            double s = 0;
-            for (int q = 0; q < n; ++q) s += A.r0[q] * A.r0[q];
-            A.pc0[0] = s;
+            double s0 = 0;
+            for (int q = 0; q < n; ++q) s0 += sr[q] * sr[q];
+            A.pc0[0] = s0;
         }
     }
 }

@@ -175,7 +175,7 @@ struct vil_ctx {
     char* h_mirror = nullptr; Ctl* d_hctl = nullptr; int* d_hseq = nullptr; double* d_hstate = nullptr; size_t mirror_ns = 0;      // pinned + mapped: Ctl | sequence word | final state, written by solve_finish (vil_finish.hpp)
     bool no_poll = false;          // VIL_NO_POLL=1: copy + synchronise instead of polling the mirror
     bool mirror_state = false;     // the mirror holds the final state of the last solve (vil_download_state needs no device operation)
-    int attr_sweep = 0, attr_step[5] = {0, 0, 0, 0, 0}, attr_marg[2] = {0, 0};      // dynamic-LDS sizes already granted to the kernels (hipFuncSetAttribute is not free)
+    int attr_sweep = 0, attr_step[5] = {0, 0, 0, 0, 0}, attr_marg[2] = {0, 0}, attr_commit = 0;      // dynamic-LDS sizes already granted to the kernels (hipFuncSetAttribute is not free)
     double* h_pin = nullptr;       // pinned scratch
     char* marg_ws = nullptr;       // device work space of vil_marginalize (grow-only)
     size_t marg_ws_bytes = 0;
@@ -1491,7 +1491,11 @@ static int marg_finish(vil_ctx* c, const int K, const bool old_, const int drop_
         pc.n = n; pc.nblk = (int)kinds.size(); pc.J0 = M.J0; pc.r0 = M.r0; pc.x = c->P.x[0]; pc.K = K;
         for (size_t b = 0; b < kinds.size(); ++b) { pc.kind[b] = kinds[b]; pc.index[b] = index[b]; }
         pc.pJ0 = w.pJ0(dst); pc.pr0 = w.pr0(dst); pc.px0 = w.px0(dst); pc.pH = w.pH(dst); pc.pg0 = w.pg0(dst); pc.pc0 = w.pc0(dst); pc.status = w.d_wstat;
-        hipLaunchKernelGGL(k_prior_commit, dim3(32), dim3(256), 0, c->stream, pc);
+        {
+            const size_t pl = 8 * ((size_t)n * (n + 1) + n + 8);
+            if (pl > 48 * 1024 && (int)pl > c->attr_commit) { HIPCHK(hipFuncSetAttribute((const void*)k_prior_commit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl)); c->attr_commit = (int)pl; }
+            hipLaunchKernelGGL(k_prior_commit, dim3(16), dim3(256), pl, c->stream, pc);
+        }
         w.cur = dst; w.pn = n; w.pm = nd + n_lm_elim;
         w.pkind.assign(kinds.begin(), kinds.end()); w.pindex.clear(); w.pcol.clear();
         int col = 0;
@@ -1962,7 +1966,11 @@ int vil_win_prior_set(vil_ctx* c, const vil_prior* pr) {
     PriorCommit pc; memset(&pc, 0, sizeof pc);
     pc.n = pr->n; pc.nblk = 0; pc.J0 = w.pJ0(dst); pc.r0 = w.pr0(dst); pc.x = nullptr; pc.K = w.K;      // nblk = 0: x0 already in place
     pc.pJ0 = w.pJ0(dst); pc.pr0 = w.pr0(dst); pc.px0 = w.px0(dst); pc.pH = w.pH(dst); pc.pg0 = w.pg0(dst); pc.pc0 = w.pc0(dst); pc.status = w.d_wstat;
-    hipLaunchKernelGGL(k_prior_commit, dim3(32), dim3(256), 0, c->stream, pc);
+    {
+        const size_t pl = 8 * (n * (n + 1) + n + 8);
+        if (pl > 48 * 1024 && (int)pl > c->attr_commit) { HIPCHK(hipFuncSetAttribute((const void*)k_prior_commit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl)); c->attr_commit = (int)pl; }
+        hipLaunchKernelGGL(k_prior_commit, dim3(16), dim3(256), pl, c->stream, pc);
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     w.cur = dst; w.pn = pr->n; w.pm = 0;
     w.pkind.assign(pr->blk_kind, pr->blk_kind + pr->nblk); w.pindex.assign(pr->blk_index, pr->blk_index + pr->nblk); w.pcol.assign(pr->blk_col, pr->blk_col + pr->nblk);

@@ -20,7 +20,7 @@ def main():
         dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print("%-44s %6s %10s %6s %10s %10s" % ("kernel", "calls", "avg_us", "live", "live_avg", "live_max"))
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-        thr = 8.0 if k.startswith(("k_sweep", "k_reduce", "void k_step")) else 0.0
+        thr = (8.0 if k.startswith(("k_sweep", "void k_step")) else 5.0) if k.startswith(("k_sweep", "k_reduce", "void k_step")) else 0.0
         live = [x for x in v if x > thr]
         print("%-44s %6d %10.2f %6d %10.2f %10.2f" % (k[:44], len(v), sum(v) / len(v), len(live), sum(live) / max(1, len(live)), max(v)))
     for f in sys.argv[2:4]:

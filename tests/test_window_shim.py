@@ -276,3 +276,62 @@ def test_window_frames_reintegrate_on_device():
     d = os.path.dirname(lib.LIB_PATH)
     exe = _build(FRAMES, [lib.LIB_PATH, "-Wl,-rpath," + d])
     _check_frames([l.split() for l in subprocess.check_output([exe]).decode().strip().split("\n")], 0.0)
+
+
+WINTAB = r'''
+#include <cstdio>
+#include "vilwindow_shim.hpp"
+extern "C" void vil_prior_capacity(int, int*, int*, int*) {}
+extern "C" int vpre_integrate(vpre_ctx*, int32_t, const int32_t*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*) { return -1; }
+int main() {
+    const int W = 6;
+    vil::FeatureTable ft(W, 5.0, 10.0 / 460.0);
+    vil::TrackSlots slots(64);
+    int bad = 0;
+    for (int img = 0; img < 14; ++img) {
+        const int fc = img < W ? img : W;
+        std::vector<int> ids; std::vector<double> obs;
+        for (int id = img / 2; id < img / 2 + 25; ++id) { ids.push_back(id); const double o[8] = {0.01 * id + 0.02 * img, 0.02 * (id % 7), 1.0, 300.0 + id, 200.0 + id % 9, 0.1, -0.1, id % 5 == 0 ? 3.0 : -1.0}; obs.insert(obs.end(), o, o + 8); }
+        ft.add_frame(fc, ids.data(), obs.data(), (int)ids.size(), 0.001 * img);
+        if (fc < W) continue;
+        // the landmark table of the resident window, expanded to factors, is the factor list WindowPacker gets
+        std::vector<int32_t> tr, st, no; std::vector<uint8_t> lc;
+        ft.win_landmarks(slots, tr, st, no, lc);
+        vil::WindowPacker pk(W + 1, ft.count()); ft.pack(pk, 240.0);
+        const vil_problem* p = pk.finish();
+        int f = 0;
+        for (size_t l = 0; l < tr.size(); ++l) for (int q = 1; q < no[l]; ++q, ++f) bad += !(f < p->n_vis && p->vis_i[f] == st[l] && p->vis_j[f] == st[l] + q && p->vis_l[f] == (int)l);
+        bad += f != p->n_vis; bad += (int)tr.size() != p->L;
+        for (size_t l = 0; l < tr.size(); ++l) bad += lc[l] != p->lm_const[l];
+        // the observations of a frame, by slot: what the factor constants are made of
+        for (int k = 0; k <= W; ++k) {
+            std::vector<int32_t> ot; std::vector<double> ob;
+            ft.win_frame_obs(k, 240.0, slots, ot, ob);
+            for (size_t q = 0; q < ot.size(); ++q) bad += ot[q] < 0 || ot[q] >= 64;
+            for (size_t a = 0; a < ot.size(); ++a) for (size_t b2 = a + 1; b2 < ot.size(); ++b2) bad += ot[a] == ot[b2];      // one slot per track
+        }
+        {   // factor 0's constants from the store entries of its landmark
+            std::vector<int32_t> ot; std::vector<double> ob;
+            ft.win_frame_obs(st[0], 240.0, slots, ot, ob);
+            size_t a = 0; while (a < ot.size() && ot[a] != tr[0]) ++a;
+            bad += a == ot.size() || ob[8 * a] != p->vis_const[0] || ob[8 * a + 3] != p->vis_const[6] || ob[8 * a + 5] != p->vis_const[10] || ob[8 * a + 6] != p->vis_const[12];
+        }
+        const double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, P0[3] = {0, 0, 0};
+        if (img % 3) ft.remove_back_shift_depth(R, P0, R, P0); else ft.remove_front(fc);
+        slots.retain(ft.tracks());
+    }
+    std::printf("WINTAB %d\\n", bad);
+    return 0;
+}
+'''
+
+
+def test_resident_window_tables_of_the_shim():
+    """FeatureTable::win_landmarks / win_frame_obs + TrackSlots (the host side of vil_win_*): the landmark table expands to exactly the factor
+    list WindowPacker receives, slots are unique per track and recycled after a slide."""
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "w.cpp"); open(src, "w").write(WINTAB)
+        exe = os.path.join(d, "w")
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        out = subprocess.check_output([exe], text=True)
+    assert "WINTAB 0" in out, out
