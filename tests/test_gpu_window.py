@@ -112,3 +112,67 @@ def test_resident_window_rejects_misuse():
     s = be.win_solve(w, rp.opts)
     assert s.iterations >= 1
     be.close()
+
+
+def test_resident_window_k20_chain_in_sweep(oracle):
+    """K = 20: beyond the merged gather + step launch -- the chain workgroup rides in k_sweep, the W W^T tiles in k_reduce (vil_prechain.hpp)."""
+    K = 20
+    rp = replay.Replay(K=K, n_frames=K + 8, L=260, n_plane=2000, n_edge=600, seed=5, second_new_every=3, max_iterations=10)
+    be = lib.open_vilsolve()
+    _open(be, rp)
+    for step in range(5):
+        flag = rp.margin_flag()
+        w = rp.win_window(); wo = Window.from_dict(rp.window().to_dict())
+        p0 = w.pose[0].copy()
+        sg = be.win_solve(w, rp.opts); so = oracle.solve(wo, rp.opts); oracle.gauge_fix(p0, wo)
+        assert sg.iterations == so.iterations and sg.termination == so.termination, (step, sg.iterations, so.iterations)
+        assert np.abs(w.pose[:, :3] - wo.pose[:, :3]).max() < 1e-6 and np.abs(w.inv_depth - wo.inv_depth).max() < 1e-6, step
+        be.win_marginalize(flag, w._icp_marg, w._lps_marg, rp.opts)
+        pg = be.win_prior_download(K)
+        be.win_drop_frame(flag)
+        assert rp.absorb(w, pg, flag)
+        be.win_push_frame(rp.win_frame(K - 1))
+    be.close()
+
+
+def test_time_cap_ends_the_solve_on_the_host_and_returns_the_accepted_state():
+    """max_solver_time_in_seconds (estimator.cpp:1411): the host checks the clock between two chunks of iterations and ends the solve; k_finish
+    writes the accepted state out.  The result is an iterate of the un-capped solve, never garbage."""
+    from mvil_fusion_amd import synth
+    be = lib.open_vilsolve()                                         # a fresh context enqueues five iterations first
+    full = synth.make_config(1)
+    s_full = be.solve(full, abi.default_options())
+    assert s_full.iterations > 8
+    be.close(); be = lib.open_vilsolve()
+    w = synth.make_config(1)
+    st0 = w.state_copy()
+    s = be.solve(w, abi.default_options(max_time_s=1e-7))            # expired at the first check
+    assert s.termination == abi.TERM_NAMES.index("max_time") and 1 <= s.iterations < s_full.iterations, (s.termination, s.iterations)
+    assert np.isfinite(w.pose).all() and s.final_cost <= s.initial_cost and s.final_cost >= s_full.final_cost * (1 - 1e-9)
+    assert np.abs(w.pose - st0["pose"]).max() > 0                    # it did move: the accepted iterate, not the start
+    tr = np.array(list(s_full.cost_trace)[:s_full.iterations] + [s_full.initial_cost])
+    assert np.abs(tr - s.final_cost).min() <= 1e-6 * s.final_cost      # one of the un-capped solve's iterates (a prior-less window: two runs agree to ~1e-9, its gauge null space amplifies rounding)
+    be.close()
+
+
+def test_resident_window_reports_a_failed_frame_at_the_next_solve():
+    """A frame whose IMU samples make the pre-integrated covariance useless (NaN) is noticed on the device; the NEXT vil_win_solve returns the
+    error and leaves the caller's state untouched, like every failing solve."""
+    rp = replay.Replay(K=8, n_frames=14, L=60, n_plane=800, n_edge=200, seed=3, max_iterations=4)
+    be = lib.open_vilsolve()
+    be.set_gauge_fix(True); be.win_open(**rp.win_open_args())
+    for k in range(rp.K):
+        fr = rp.win_frame(k)
+        if k == rp.K - 1:
+            fr["acc"] = fr["acc"].copy(); fr["acc"][3, 1] = np.nan
+        be.win_push_frame(fr)
+    w = rp.win_window()
+    before = w.pose.copy()
+    with pytest.raises(lib.VilError):
+        be.win_solve(w, rp.opts)
+    assert np.array_equal(w.pose, before)
+    be.win_open(**rp.win_open_args())                                # re-opening clears the sticky status
+    for k in range(rp.K):
+        be.win_push_frame(rp.win_frame(k))
+    assert be.win_solve(w, rp.opts).iterations >= 1
+    be.close()
