@@ -100,3 +100,75 @@ def test_lidar_example_registers_the_synthetic_room():
     assert v[1:3] == ["0", "1"] and np.abs(np.array([float(x) for x in v[4:8]]) - [0.6, -0.4, 0.1, 0.05]).max() < 0.02
     assert m[1:3] == ["0", "2"] and int(m[3]) > 100 and int(m[4]) > 1000
     assert np.abs(np.array([float(x) for x in m[5:9]]) - [0.6, -0.4, 0.1, 0.05]).max() < 0.02
+
+
+def _build_window(d):
+    exe = os.path.join(d, "window_patch")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "window_patch.cpp"),
+                           lib.LIB_PATH, "-Wl,-rpath," + os.path.dirname(lib.LIB_PATH), "-o", exe])
+    return exe
+
+
+def _arr(f, a, dt):
+    a = np.ascontiguousarray(a, dt).ravel()
+    f.write(struct.pack("<q", a.size)); f.write(a.tobytes())
+
+
+def _dump_frame(f, fr):
+    _arr(f, fr["dt"], np.float64); _arr(f, fr["acc"], np.float64); _arr(f, fr["gyr"], np.float64)
+    _arr(f, np.concatenate([fr["acc0"], fr["gyr0"], fr["lin_ba"], fr["lin_bg"]]), np.float64)
+    _arr(f, fr["obs_track"], np.int32); _arr(f, fr["obs"], np.float64); _arr(f, fr["plane"], np.float64); _arr(f, fr["edge"], np.float64)
+
+
+def test_window_example_builds_and_refuses_without_gpu():
+    lib.load_vilsolve()
+    with tempfile.TemporaryDirectory() as d:
+        exe = _build_window(d)
+        import torch
+        if torch.cuda.is_available():
+            return
+        p = os.path.join(d, "s.bin")
+        with open(p, "wb") as f:
+            _arr(f, [8, 64, 64, 1, 0], np.int32); _arr(f, np.zeros(16), np.float64)
+        r = subprocess.run([exe, p], capture_output=True, text=True)
+        assert r.returncode == 3 and "no CPU path" in r.stderr
+
+
+@pytest.mark.gpu
+def test_window_example_reproduces_harness(hip):
+    """examples/window_patch.cpp: the C++ call sequence of INTEGRATION.md section 5b on a dumped 10-image sequence returns what the harness'
+    own resident-window chain returns (the dump is written WHILE the harness runs: both see the same frames, tables and states)."""
+    from mvil_fusion_amd import replay
+    rp = replay.Replay(K=8, n_frames=24, L=120, n_plane=1600, n_edge=480, seed=9, second_new_every=4, max_iterations=6)
+    K, N = rp.K, 10
+    a = rp.win_open_args()
+    hip.set_gauge_fix(True); hip.win_open(**a)
+    ref = []
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "s.bin")
+        with open(p, "wb") as f:
+            _arr(f, [K, a["max_tracks"], a["max_samples"], a["use_td"], N], np.int32)
+            _arr(f, [*a["noise"], *a["G"], a["sqrt_info_px"], a["tr_over_row"], *a["q_lb"], *a["t_lb"]], np.float64)
+            for k in range(K):
+                fr = rp.win_frame(k); hip.win_push_frame(fr); _dump_frame(f, fr)
+            for img in range(N):
+                flag = rp.margin_flag(); w = rp.win_window()
+                _arr(f, [int(flag), w._icp_marg, w._lps_marg, rp.opts.max_iterations], np.int32)
+                _arr(f, w.lm_track, np.int32); _arr(f, w.lm_start, np.int32); _arr(f, w.lm_nobs, np.int32); _arr(f, w.lm_const, np.uint8)
+                _arr(f, w.icp_ids, np.int32); _arr(f, w.icp_const, np.float64); _arr(f, w.lps_ids, np.int32); _arr(f, w.lps_const, np.float64)
+                for arr_ in (w.pose, w.speedbias, w.ex_pose, w.td, w.inv_depth):
+                    _arr(f, arr_, np.float64)
+                s = hip.win_solve(w, rp.opts)
+                info = hip.win_marginalize(flag, w._icp_marg, w._lps_marg, rp.opts)
+                ref.append((s.iterations, s.termination, s.initial_cost, s.final_cost, info.n, w.pose[-1].copy()))
+                hip.win_drop_frame(flag)
+                assert rp.absorb(w, None, flag)
+                fr = rp.win_frame(K - 1); hip.win_push_frame(fr); _dump_frame(f, fr)
+        out = subprocess.check_output([_build_window(d), p], text=True)
+    hip.set_gauge_fix(False)
+    rows = [l.split() for l in out.splitlines() if l.startswith("IMG")]
+    assert len(rows) == N
+    for r, (it, term, c0, c1, n, pose) in zip(rows, ref):
+        assert (int(r[2]), int(r[3]), int(r[6])) == (it, term, n), (r[:7], it, term, n)
+        assert abs(float(r[4]) - c0) <= 1e-9 * c0 and abs(float(r[5]) - c1) <= 1e-8 * c1      # (two runs of a chain agree to rounding)
+        assert np.abs(np.array([float(v) for v in r[7:14]]) - pose).max() < 1e-8
