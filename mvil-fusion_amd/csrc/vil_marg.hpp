@@ -351,7 +351,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_marg_fast(MargDev M) {
         s.gr[i] = rel > 1e-30 ? rel : 1e-30;
     }
     __syncthreads();
-    bool ok = chol_blocked<true>(tl, n, s);
+    bool ok = chol_lookahead(tl, n, s);
     __syncthreads();
     if (ok) {
         for (int i = t; i < n; i += NT) { const double l = 1.0 / s.dinv[i]; if (!(l * l > s.gr[i])) s.ok = 0; }

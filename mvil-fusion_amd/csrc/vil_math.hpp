@@ -199,6 +199,15 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double& sq, double& rs) {
     g = fma(g, e, g); h = fma(h, e, h);
     sq = fma(fma(-g, g, x), h, g); rs = h + h;
 }
+// The same pair with the reciprocal root on the shortest dependent chain -- rsq, y * y, fma, fma (x / 2 forms beside the rsq) -- for pivot
+// chains where the next pivot waits for 1 / sqrt only (chol_lookahead); sqrt follows off the chain with one residual correction.
+__device__ __forceinline__ void rsqrt_sqrt(double x, double& sq, double& rs) {
+    const double y = __builtin_amdgcn_rsq(x), xh = 0.5 * x;
+    const double e = fma(-xh, y * y, 0.5);
+    rs = fma(y, e, y);
+    const double g = x * rs;
+    sq = fma(fma(-g, g, x), 0.5 * rs, g);
+}
 // Data that crosses workgroups INSIDE one launch is stored and loaded at agent scope -- the level the eight XCDs share -- so that a flag only
 // has to be ordered behind the poster's own stores (s_waitcnt vmcnt(0)).  A release fence instead writes the whole XCD's L2 back
 // (buffer_wbl2): measured with 390 gather workgroups doing that in one launch, the launch took 100 us instead of 75.

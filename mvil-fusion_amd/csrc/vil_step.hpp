@@ -38,7 +38,7 @@ struct StepShared {
     double x0[328];                               // camera part of x_cur (16K + 8 doubles), fetched while the system is being solved
     unsigned char cst[48];                        // pose_const[K] | sb_const[K]
     double hs[12];                                // the helpers' sums, gathered by a spare wave during the chain back substitution
-    int need, was_first, ok;
+    int need, was_first, ok, cok;
     long long tacc[6];
 };
 
@@ -410,6 +410,161 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double
     return true;
 }
 
+// The same factorisation with look-ahead, for a matrix whose tiles are register-resident (REGRES above).  The serial chain of a block step --
+// four dependent pivots (~230 cycles each: rsq seed, coupled Newton step, the block's own updates), then the panel's forward substitution --
+// does not need the whole workgroup, and the trailing update does not need to be finished before the next block starts: block k + 1 reads
+// four columns only.  So the LAST wave(s) of the workgroup (the panel group, one wave per 64 panel rows) run that chain, applying panel k to
+// the four columns of block k + 1 themselves (scalar FMAs on the thread's own row, the 4 x 4 block redundantly per thread), while the other
+// waves apply panel k to everything else on the matrix cores: their register tiles, and -- with the stores masked to the columns right of
+// block k + 1 -- the LDS tiles of the tile column block k + 1 lives in.  A tile column goes to LDS one block step before the factorisation
+// enters it.  ONE barrier per block step, and the panel group's chain (~2000 cycles) is the step; chol_blocked needs ~3500 (diagonal block,
+// panel, barrier, trailing update, barrier, everybody in lockstep).
+// On return rows < D hold L, row D holds y = L^-1 rhs, s.dinv[j] = 1 / L_jj.  Returns false (uniformly) on a non-positive pivot.
+template <class PTR, class PRE = NoPre>
+__device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE pre = PRE()) {
+    const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
+    const int R = D + 1;                 // rows including the rhs row
+    const int T = (R + 15) >> 4;         // tile rows
+    const int la = (lane & 15) * TILE_RS + (lane >> 4);     // operand element (row lane&15, k lane>>4) inside a tile
+    const int lc = (lane >> 4) * TILE_RS + (lane & 15);     // accumulator element (row lane>>4 (+4g), col lane&15)
+    const int ntile_all = (T * (T + 1)) >> 1;               // <= NW * CH_SLOTS
+    // panel group: the last npw waves; thread tp of it owns the tp-th row below the block.  The tiles are dealt to the other waves first
+    const int npw = max(1, (R - min(STEP_NB, D) + 63) >> 6);   // the first block has the most panel rows: R - min(NB, D)
+    const int NWT = NW - npw;
+    const int tp = t - 64 * NWT;
+    d4 Creg[CH_SLOTS]; int tIJ[CH_SLOTS];
+#pragma unroll
+    for (int u = 0; u < CH_SLOTS; ++u) {
+        const int g = wave < NWT ? wave + NWT * u : NWT * CH_SLOTS + (wave - NWT) + npw * u;
+        tIJ[u] = -1;
+        if (g < ntile_all) {
+            const int I = s.tI[g], J = s.tJ[g];
+            tIJ[u] = (I << 8) | J;
+            const int cb = tl_base(I, J) + lc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Creg[u][q] = A[cb + q * (4 * TILE_RS)];
+        }
+    }
+    pre(Creg, tIJ);
+    if (t == 0) s.cok = 1;
+    // Panel group: block at column kb -- its 4 x 4 diagonal block (every thread, redundantly) and the rows below it.  UPD: first subtract the
+    // previous panel (columns kb - 4 .. kb - 1, always a full block) from what is read.
+    // FULL: a whole 4 x 4 block (only the last block of the matrix can be shorter) -- no branch anywhere between the loads and the stores, so that
+    // the scheduler can fill the latency shadows of the pivot chain with the panel update and the forward substitution.
+    auto diag_panel = [&](const int kb, auto full_c, auto upd_c) {
+        constexpr bool FULL = decltype(full_c)::value, UPD = decltype(upd_c)::value;
+        const int nb = FULL ? STEP_NB : min(STEP_NB, D - kb), Kt = kb >> 4, ko = kb & 15;
+        const int db = tl_base(Kt, Kt) + ko * TILE_RS + ko;
+        const int i = kb + nb + tp;                          // this thread's panel row
+        const bool row = i < R;
+        const int ic = min(i, R - 1);
+        const int base = tl_base(ic >> 4, Kt) + (ic & 15) * TILE_RS + ko;
+        double d00 = A[db], d10 = 0, d11 = 1, d20 = 0, d21 = 0, d22 = 1, d30 = 0, d31 = 0, d32 = 0, d33 = 1;
+        if (nb > 1) { d10 = A[db + TILE_RS]; d11 = A[db + TILE_RS + 1]; }
+        if (nb > 2) { d20 = A[db + 2 * TILE_RS]; d21 = A[db + 2 * TILE_RS + 1]; d22 = A[db + 2 * TILE_RS + 2]; }
+        if (nb > 3) { d30 = A[db + 3 * TILE_RS]; d31 = A[db + 3 * TILE_RS + 1]; d32 = A[db + 3 * TILE_RS + 2]; d33 = A[db + 3 * TILE_RS + 3]; }
+        double a0 = A[base], a1 = nb > 1 ? A[base + 1] : 0.0, a2 = nb > 2 ? A[base + 2] : 0.0, a3 = nb > 3 ? A[base + 3] : 0.0;
+        if constexpr (UPD) {
+            const int kp = kb - STEP_NB, Kp = kp >> 4, kpo = kp & 15;      // the previous panel: columns kp .. kp + 3 of tile column Kp
+            const int pb = tl_base(Kt, Kp) + ko * TILE_RS + kpo;           // rows kb .. kb + 3 of it (all in tile row Kt)
+            const int pr = tl_base(ic >> 4, Kp) + (ic & 15) * TILE_RS + kpo;
+            double xd[4][4], xr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xd[r][q] = (FULL || r < nb) ? A[pb + r * TILE_RS + q] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xr[q] = A[pr + q];
+            // (rows of a short last block that do not exist: xd = 0, the identity padding stays)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                d00 = fma(-xd[0][q], xd[0][q], d00);
+                d10 = fma(-xd[1][q], xd[0][q], d10); d11 = fma(-xd[1][q], xd[1][q], d11);
+                d20 = fma(-xd[2][q], xd[0][q], d20); d21 = fma(-xd[2][q], xd[1][q], d21); d22 = fma(-xd[2][q], xd[2][q], d22);
+                d30 = fma(-xd[3][q], xd[0][q], d30); d31 = fma(-xd[3][q], xd[1][q], d31); d32 = fma(-xd[3][q], xd[2][q], d32); d33 = fma(-xd[3][q], xd[3][q], d33);
+                a0 = fma(-xr[q], xd[0][q], a0); a1 = fma(-xr[q], xd[1][q], a1); a2 = fma(-xr[q], xd[2][q], a2); a3 = fma(-xr[q], xd[3][q], a3);
+            }
+        }
+        // every pivot waits for the previous reciprocal root, one multiply and one fma; everything else is formed beside the chain
+        double l00, r0_, l11, r1_, l22, r2_, l33, r3_;
+        bool ok = d00 > 0.0 && isfinite(d00);
+        rsqrt_sqrt(d00, l00, r0_);
+        const double l10 = d10 * r0_, l20 = d20 * r0_, l30 = d30 * r0_, x0 = a0 * r0_;
+        d11 = fma(-l10, l10, d11); ok = ok && d11 > 0.0 && isfinite(d11);
+        const double t21 = fma(-l20, l10, d21), t31 = fma(-l30, l10, d31), u22 = fma(-l20, l20, d22), u33a = fma(-l30, l30, d33), v32 = fma(-l30, l20, d32);
+        const double y1 = fma(-x0, l10, a1), y2a = fma(-x0, l20, a2), y3a = fma(-x0, l30, a3);
+        rsqrt_sqrt(d11, l11, r1_);
+        const double l21 = t21 * r1_, l31 = t31 * r1_, x1 = y1 * r1_;
+        d22 = fma(-l21, l21, u22); ok = ok && d22 > 0.0 && isfinite(d22);
+        const double t32 = fma(-l31, l21, v32), u33 = fma(-l31, l31, u33a), y2 = fma(-x1, l21, y2a), y3b = fma(-x1, l31, y3a);
+        rsqrt_sqrt(d22, l22, r2_);
+        const double l32 = t32 * r2_, x2 = y2 * r2_;
+        d33 = fma(-l32, l32, u33); ok = ok && d33 > 0.0 && isfinite(d33);
+        const double y3 = fma(-x2, l32, y3b);
+        rsqrt_sqrt(d33, l33, r3_);
+        const double x3 = y3 * r3_;
+        // (a non-positive pivot: identical data in every thread of the group; what is stored below is not read -- everyone leaves after the barrier)
+        // (a thread without a row stores into the padding doubles of tile (0, 0) -- element 16 of a tile row, never read -- instead of branching: a
+        //  conditional store would let the compiler sink this row's loads, update and substitution behind the pivot chain, into the branch)
+        if constexpr (FULL) { A[row ? base : 16] = x0; A[row ? base + 1 : TILE_RS + 16] = x1; A[row ? base + 2 : 2 * TILE_RS + 16] = x2; A[row ? base + 3 : 3 * TILE_RS + 16] = x3; }
+        else if (row) { A[base] = x0; if (nb > 1) A[base + 1] = x1; if (nb > 2) A[base + 2] = x2; if (nb > 3) A[base + 3] = x3; }
+        if (tp == 0) {                                       // the factored block itself and the reciprocal pivots
+            if (!ok) s.cok = 0;
+            A[db] = l00; s.dinv[kb] = r0_;
+            if (nb > 1) { A[db + TILE_RS] = l10; A[db + TILE_RS + 1] = l11; s.dinv[kb + 1] = r1_; }
+            if (nb > 2) { A[db + 2 * TILE_RS] = l20; A[db + 2 * TILE_RS + 1] = l21; A[db + 2 * TILE_RS + 2] = l22; s.dinv[kb + 2] = r2_; }
+            if (nb > 3) { A[db + 3 * TILE_RS] = l30; A[db + 3 * TILE_RS + 1] = l31; A[db + 3 * TILE_RS + 2] = l32; A[db + 3 * TILE_RS + 3] = l33; s.dinv[kb + 3] = r3_; }
+        }
+    };
+    // tile column 0 to LDS (tile column 1 as well when the matrix has fewer than three blocks in column 0 -- never: a tile column has four), block 0
+#pragma unroll
+    for (int u = 0; u < CH_SLOTS; ++u) if (tIJ[u] >= 0 && (tIJ[u] & 255) == 0) {
+        const int cb = tl_base(tIJ[u] >> 8, 0) + lc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) A[cb + q * (4 * TILE_RS)] = Creg[u][q];
+    }
+    __syncthreads();
+    if (tp >= 0) { if (D >= STEP_NB) diag_panel(0, std::true_type{}, std::false_type{}); else diag_panel(0, std::false_type{}, std::false_type{}); }
+    __syncthreads();
+    if (!s.cok) return false;
+    for (int kb = 0; kb + STEP_NB < D; kb += STEP_NB) {      // panel kb (a full block) is in LDS; the last block has no successor
+        const int Kt = kb >> 4, ko = kb & 15;
+        const int kb1 = kb + STEP_NB, Kn = kb1 >> 4;         // the next block and its tile column (LDS-resident)
+        const int c0 = kb1 + min(STEP_NB, D - kb1);          // first column right of the next block: what the tile waves update in tile column Kn
+        const bool pub = ((kb1 + STEP_NB) & 15) == 0;        // the block after the next opens tile column Kn + 1: publish it after this update
+        if (tp >= 0) { if (kb1 + STEP_NB <= D) diag_panel(kb1, std::true_type{}, std::true_type{}); else diag_panel(kb1, std::false_type{}, std::true_type{}); }
+#pragma unroll
+        for (int u = 0; u < CH_SLOTS; ++u) {
+            const int I = tIJ[u] >> 8, J = tIJ[u] & 255;
+            if (tIJ[u] < 0 || J < Kn) continue;                       // finished (or empty) slot: wave-uniform
+            // unconditional reads (inside the tile for every lane) + select: a per-lane predicated load would compile to an exec-mask branch with its own wait
+            const double a_ = A[tl_base(I, Kt) + la + ko], b_ = A[tl_base(J, Kt) + la + ko];
+            if (J > Kn) {                                            // register tile: rows/cols are beyond the panel
+                Creg[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_, b_, Creg[u], 0, 0, 0);
+                if (pub && J == Kn + 1) {
+                    const int cb = tl_base(I, J) + lc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) A[cb + q * (4 * TILE_RS)] = Creg[u][q];
+                }
+            } else {                                                 // tile of the next block's column: lives in LDS, columns >= c0 are ours
+                const int rr = (I << 4) + (lane & 15), cr = (J << 4) + (lane & 15);
+                const double av = (rr >= kb1 && rr < R) ? a_ : 0.0;
+                const double bv = (cr >= c0 && cr < D) ? b_ : 0.0;
+                d4 z = {0.0, 0.0, 0.0, 0.0};
+                const d4 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, z, 0, 0, 0);
+                const int cb = tl_base(I, J) + lc;
+                if (cr >= c0) {                                      // (the accumulator's column is lane & 15 as well)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) A[cb + g * (4 * TILE_RS)] -= acc[g];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // (a non-positive pivot is looked at once, here: the blocks after it computed garbage nobody uses, and the flag's LDS round trip stays off the chain)
+    return s.cok != 0;
+}
+
 // back substitution L^T x = y (y = row D of A) with 16 x 16 diagonal blocks: 10 dependent stages instead of 40.
 //   (I)  W_t = L_tt^-1 for every diagonal tile at once (one thread per tile column, 16-step forward substitution in
 //        registers); W_t is stored TRANSPOSED into the unused upper triangle of its tile, its diagonal is s.dinv.
@@ -600,7 +755,7 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
             Creg[u] = c4;
         }
     };
-    if (!chol_blocked<true>(Tl, NP, s, nullptr, schur)) return false;
+    if (!chol_lookahead(Tl, NP, s, schur)) return false;
     SSTAMP(4);
     back_subst(Tl, NP, s);                             // x_p in s.y[0 .. NP)
     pub();                                             // the landmark workgroups can start: they only need the pose part
@@ -694,7 +849,7 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
     __syncthreads();
     SSTAMP(2); SSTAMP(3);
     if (!s.ok) return false;
-    if (!chol_blocked<true>(Tl, NP, s)) return false;
+    if (!chol_lookahead(Tl, NP, s)) return false;
     SSTAMP(4);
     back_subst(Tl, NP, s);
     pub();
@@ -1170,7 +1325,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             if (t < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); wait_helpers(); store_ctl(); }
             return;
         }
-        if constexpr (CHAIN == 0) { if constexpr (LDSM) ok = chol_blocked<true>(Alds, D, s); else ok = chol_blocked<false>(P.M, D, s, Alds); }      // Alds = staging of the active tile column
+        if constexpr (CHAIN == 0) { if constexpr (LDSM) ok = chol_lookahead(Alds, D, s); else ok = chol_blocked<false>(P.M, D, s, Alds); }      // Alds = staging of the active tile column
         STAMP(3);
 #ifdef VIL_STAMPS
         if (t == 0) { P.dbg[20] = s.tacc[0]; P.dbg[21] = s.tacc[1]; P.dbg[22] = s.tacc[2]; P.dbg[24] = s.tacc[3]; P.dbg[25] = s.tacc[4]; P.dbg[26] = s.tacc[5]; }
