@@ -76,6 +76,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     double* scB = lds + chain_scratch_doubles(K); double* dcB = scB + even_up(NB); double* uB = dcB + even_up(NB);
     const ChainSlab B = chain_slab(uB + even_up(NB), K);
     if (t < 8) L.flag[t] = 0;
+    const double sc_prev = (t < NB && !ctl.first) ? P.Sc[NP + t] : 0.0;      // (in flight under the gather)
     // the slab is a gather target: entries without a source (pose rows of far frames) stay zero
     { double* z = B.dg; const int nz = (int)chain_slab_fp(K); for (int e = t; e < nz; e += NT) z[e] = 0.0; }
     for (int e = t; e < NB; e += NT) B.pq[e] = P.chpq[e];
@@ -112,17 +113,21 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     if (t < NB) {
         const int j = NP + t;
         const double dg = src.diag(t / 9, t % 9, t % 9), b = src.rhsraw(j);
-        const double Sc = ctl.first ? (jacobi ? 1.0 / (1.0 + sqrt(dg)) : 1.0) : P.Sc[j];
+        const double Sc = ctl.first ? (jacobi ? 1.0 / (1.0 + sqrt(dg)) : 1.0) : sc_prev;
         const double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
         scB[t] = Sc; dcB[t] = d; uB[t] = Sc * (Sc * b / d) / d;
-        st_ag(P.chSc + t, Sc); st_ag(P.chDc + t, d);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (t == 0) st_ag(P.chflag + 1, epoch);
+    // the scales leave for the master on a wave the elimination does not use (chain_eliminate runs on waves 0 .. 5): the round trip of the stores
+    // and the flag behind them stay off the chain's path
+    if (t >= 384 && t < 448) {
+        for (int i = t - 384; i < NB; i += 64) { st_ag(P.chSc + i, scB[i]); st_ag(P.chDc + i, dcB[i]); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t == 384) st_ag(P.chflag + 1, epoch);
+    }
     PSTAMP(14);
     double qc = 0.0;
-    chain_eliminate<true>(src, K, NP, P.chain_rs, P.chW, L, qc);
+    chain_eliminate<true>(src, K, NP, P.chain_rs, P.chW, L, qc, P.dbg);      // (P.dbg: stamps of the VIL_STAMPS build)
     PSTAMP(15);
     if (t < 128) {                                     // the two recursion waves hold the chain x chain share of u^T S' u
         qc = wave_total(qc);

@@ -30,3 +30,5 @@ print("merged launch: kernel entry -> gather flags seen + Ctl loaded (stamp 0): 
 f = np.array(dbg[12:17], dtype=np.int64)
 print("chain workgroup (ticks): zero + table gather %d, scales %d, chain %d, write-out %d" % tuple(np.diff(f).tolist()))
 print("whole master: entry -> final stamp 7: %d ticks = %.1f us" % (dbg[7] - dbg[30], (dbg[7] - dbg[30]) / 2390.0))
+g = np.array([dbg[14]] + [dbg[48 + q] for q in range(7)] + [dbg[15]], dtype=np.int64)
+print("chain workgroup, forward recursion wave (ticks after the scales): block 0..5 published, middle block published, all waves done:", (g[1:] - g[0]).tolist(), " row waves done: forward %d, backward %d" % (dbg[55] - dbg[14], dbg[56] - dbg[14]))
