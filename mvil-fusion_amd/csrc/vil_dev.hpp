@@ -106,6 +106,7 @@ struct DevP {
     const double* xorig;          // the state the solve started from (the gauge fix re-anchors on its frame 0)
     int gauge_on;                 // double2vector()'s yaw / translation gauge fix as part of solve_finish
     const int* setup_stat;        // != 0: k_setup found an IMU covariance that is not positive definite -- the first step kernel ends the solve with it
+    int vis_mf;      // visual workgroups: block outer products on the matrix cores (windows up to K = 12, vil_sweep.hpp)
     int n_help; double* hpart; int* hflag;
     // second landmark pass of the helpers (k_step): the master posts the epoch in xflag (Sc x_p is in stepc) or in xstat (no step
     // this launch); every helper WAVE then leaves its six sums in hpart2[8 * slot ..] and the epoch in hflag2[slot], slot = 8 k + wave

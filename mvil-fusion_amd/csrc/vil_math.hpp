@@ -189,6 +189,8 @@ __device__ __forceinline__ void loss_eval(int kind, double a, double s, double& 
     } else { rho = s; rho1 = 1.0; }
 }
 
+typedef double d4 __attribute__((ext_vector_type(4)));      // accumulator fragment of v_mfma_f64_16x16x4_f64
+
 // sqrt(x) and 1/sqrt(x) together: hardware rsq seed + two coupled Newton steps (no divide on the pivot chain)
 __device__ __forceinline__ void sqrt_rsqrt(double x, double& sq, double& rs) {
     // v_rsq_f64 seeds ~2^-26; one coupled Newton step squares that (the pivot chain is latency-bound: every

@@ -179,7 +179,6 @@ __device__ __forceinline__ void pose_plus(const double* in, const double* d, dou
     o[3] = q.x * n; o[4] = q.y * n; o[5] = q.z * n; o[6] = q.w * n;
 }
 
-typedef double d4 __attribute__((ext_vector_type(4)));
 
 // triangular tile index -> tile row / column as compile-time constants, and a compile-time counted loop: element
 // e = t + u * VIL_STEP_THREADS of the tile array belongs to tile 2u or 2u + 1 (512 threads, 256 elements per tile), so inside a

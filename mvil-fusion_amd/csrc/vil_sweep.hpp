@@ -91,27 +91,41 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
 // ---------------------------------------------------------------------------------------------
 // LDS per factor: [Ji 12 | Jj 12 | Jex 12 | Jt 2 | Jl 2 | r 2 | eO 6] = 48 doubles
 #define VF_STRIDE 49   // odd stride: conflict-free column access
+// Windows up to K = 12 (NV <= 80, chunks of <= VIS_MF factors): the block outer products run on the fp64 matrix cores from dense operand rows in LDS
+#define VIS_MF 32      // factors of a chunk on that path (two operand rows each)
+#define VIS_RS 80      // row stride of the operand rows: five 16-column tiles, = 16 mod 32 (the four rows of an MFMA operand fragment on different banks)
+#define VIS_T_SLOTS 2  // 16 x 16 tiles per wave: 15 upper tiles of a 5 x 5 grid on 8 waves
+__host__ __device__ inline bool vis_mfma(int NV) { return NV <= VIS_RS; }
+__host__ __device__ inline int vis_ntile(int NV) { const int T = (NV + 15) >> 4; return (T * (T + 1)) >> 1; }
 // The candidate inverse depth is formed HERE: lambda_cand = lambda_cur + cg la + cn lb (la, lb: the step directions the step
 // kernel's landmark pass left, cg / cn: the dogleg coefficients in Ctl; first sweep and re-sweeps: cg = cn = 0), and written
 // into the candidate state by the landmark's lane group.
 __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, const Ctl& ctl, int wg, const double* x, SysBuf& sb, double* sm) {
     const int NV = P.NV, NVT = P.NVT;
     const int t = threadIdx.x;
-    double* tri = sm;                                  // NVT packed upper triangle of the visual sub-space
-    double* vbc = tri + NVT;                           // NV
+    const bool mf = P.vis_mf != 0;                     // (wave-uniform: a property of the window)
+    const int VT = (NV + 15) >> 4, nvtile = vis_ntile(NV);
+    double* tri = sm;                                  // NVT packed upper triangle of the visual sub-space -- or, mf: its upper 16 x 16 tiles (I <= J), nvtile x 256
+    double* vbc = tri + (mf ? nvtile * 256 : NVT);     // NV
     double* vgr = vbc + NV;                            // NV
     double* vdg = vgr + NV;                            // NV
     double* Jf = vdg + NV;                             // VIL_VCHUNK_F x VF_STRIDE
     double* lmr = Jf + VIL_VCHUNK_F * VF_STRIDE;       // VIL_VCHUNK_LM x 16: invp, eA[13]
     double* red = lmr + VIL_VCHUNK_LM * 16;
-    int* fj = (int*)(red + 8);                         // VIL_VCHUNK_F observer frames
+    double* Gm = red + 8;                              // mf: 2 VIS_MF x VIS_RS rows of Jc (two per factor) | 16 x VIS_RS rows of e_l | 16 scales -invp_l
+    double* Em = Gm + 2 * VIS_MF * VIS_RS;
+    double* sa = Em + 16 * VIS_RS;
+    int* fj = (int*)(mf ? sa + 16 : red + 8);          // VIL_VCHUNK_F observer frames
     int* lms = fj + VIL_VCHUNK_F;                      // VIL_VCHUNK_LM + 1 chunk-local factor offsets
     int* lanc = lms + VIL_VCHUNK_LM + 1;               // VIL_VCHUNK_LM anchor frames
     int* fl = lanc + VIL_VCHUNK_LM;                    // VIL_VCHUNK_F factor -> chunk-local landmark
 #ifdef VIL_STAMPS
-    #define VSTAMP(k) do { __syncthreads(); if (t == 0 && wg == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[32 + k] = tt_; } } while (0)
+    long long vacc[3] = {0, 0, 0}, vprev = 0;
+    #define VSTAMP(k) do { __syncthreads(); if (t == 0 && wg == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[32 + k] = tt_; if (k >= 2 && k <= 3) vacc[k - 2] += tt_ - vprev; vprev = tt_; } } while (0)
+    #define VSTAMP_SC() do { __syncthreads(); if (t == 0 && wg == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); vacc[2] += tt_ - vprev; vprev = tt_; } } while (0)
 #else
     #define VSTAMP(k) do {} while (0)
+    #define VSTAMP_SC() do {} while (0)
 #endif
     VSTAMP(0);
 #ifdef VIL_STAMPS
@@ -123,7 +137,9 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
     // first sweep of a solve and re-sweeps: cg = cn = 0 and la / lb still hold the PREVIOUS solve's directions -- possibly inf / NaN after a
     // diverged solve, and 0 * inf is NaN: the terms are dropped, not multiplied by zero (same bits whenever la, lb are finite)
     const bool stepped = cg != 0.0 || cn != 0.0;
-    for (int e = t; e < NVT + 3 * NV; e += blockDim.x) tri[e] = 0.0;
+    if (mf) { for (int e = t; e < 3 * NV; e += blockDim.x) vbc[e] = 0.0; }      // (the tiles are carried from chunk to chunk only if there is more than one)
+    else for (int e = t; e < NVT + 3 * NV; e += blockDim.x) tri[e] = 0.0;
+    if (mf) for (int e = t; e < (2 * VIS_MF + 16) * VIS_RS + 16; e += blockDim.x) Gm[e] = 0.0;
     const bool mfree = P.marg != 0;            // marginalisation of the resident window: every block free, factors masked
     const bool exc = !mfree && P.ex_const != 0, tdc = mfree ? !P.use_td : !P.td_free;
     double cost = 0.0;
@@ -158,14 +174,26 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             const double sr = sqrt(rho1);
             const bool ci = !mfree && P.pose_const && P.pose_const[i], cj = !mfree && P.pose_const && P.pose_const[j], cl = !mfree && P.lm_const && P.lm_const[l];
             double* w = Jf + t * VF_STRIDE;
+            if (mf) {                                   // the factor's two rows of Jc, dense (the rows were zeroed at the start / after the previous chunk)
+                double* g0 = Gm + 2 * t * VIS_RS; double* g1 = g0 + VIS_RS;
+                const int ca = col_pose(P, i), co = col_pose(P, j), cx = col_ex(P);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    g0[ca + k] = ci ? 0.0 : sr * o.Ji[k]; g1[ca + k] = ci ? 0.0 : sr * o.Ji[6 + k];
+                    g0[co + k] = cj ? 0.0 : sr * o.Jj[k]; g1[co + k] = cj ? 0.0 : sr * o.Jj[6 + k];
+                    g0[cx + k] = exc ? 0.0 : sr * o.Jex[k]; g1[cx + k] = exc ? 0.0 : sr * o.Jex[6 + k];
+                }
+                g0[col_td(P)] = tdc ? 0.0 : sr * o.Jt[0]; g1[col_td(P)] = tdc ? 0.0 : sr * o.Jt[1];
+            } else {
             for (int k = 0; k < 12; ++k) { w[k] = ci ? 0.0 : sr * o.Ji[k]; w[12 + k] = cj ? 0.0 : sr * o.Jj[k]; w[24 + k] = exc ? 0.0 : sr * o.Jex[k]; }
             w[36] = tdc ? 0.0 : sr * o.Jt[0]; w[37] = tdc ? 0.0 : sr * o.Jt[1];
+            }
             w[38] = cl ? 0.0 : sr * o.Jl[0]; w[39] = cl ? 0.0 : sr * o.Jl[1];
             w[40] = sr * o.r[0]; w[41] = sr * o.r[1];
             fj[t] = j; fl[t] = l - l0;
             // observer-pose pieces that need no landmark-level sum
             for (int k = 0; k < 6; ++k) {
-                const double j0 = w[12 + k], j1 = w[18 + k];
+                const double j0 = cj ? 0.0 : sr * o.Jj[k], j1 = cj ? 0.0 : sr * o.Jj[6 + k];
                 const double eo = j0 * w[38] + j1 * w[39];
                 w[42 + k] = eo;
                 sb.eO[(size_t)(P.vis_f0 + f) * 6 + k] = eo;
@@ -189,10 +217,11 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             double e = 0, g = 0, dg = 0, h = 0, b = 0;
             const int off = k < 6 ? k : (k < 12 ? 24 + (k - 6) : 36);
             const int rs = k < 12 ? 6 : 1;      // row stride inside the 2 x n block
+            const int gcol = k < 6 ? col_pose(P, a) + k : (k < 12 ? col_ex(P) + k - 6 : col_td(P));      // (mf: the lane's column of the dense rows)
             for (int q = fs; q < fe; ++q) {
                 const double* w = Jf + q * VF_STRIDE;
                 const double l0_ = w[38], l1_ = w[39], r0 = w[40], r1 = w[41];
-                if (k < 13) { const double j0 = w[off], j1 = w[off + rs]; e += j0 * l0_ + j1 * l1_; g += j0 * r0 + j1 * r1; dg += j0 * j0 + j1 * j1; }
+                if (k < 13) { const double j0 = mf ? Gm[2 * q * VIS_RS + gcol] : w[off], j1 = mf ? Gm[(2 * q + 1) * VIS_RS + gcol] : w[off + rs]; e += j0 * l0_ + j1 * l1_; g += j0 * r0 + j1 * r1; dg += j0 * j0 + j1 * j1; }
                 else { h += l0_ * l0_ + l1_ * l1_; b += l0_ * r0 + l1_ * r1; }
             }
             // broadcast (h, b) of lane 13 to the 16-lane group
@@ -211,15 +240,16 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             double* lr = lmr + tl * 16;
             // (a landmark without a factor in this workgroup's table -- none at all, or owned by another rank -- leaves the set untouched:
             //  its entries stay zero here and the all-reduce takes them from the owner)
-            if (k == 13) { if (fe > fs) { sb.hll[l] = h; sb.bl[l] = b; sb.invp[l] = invp; sb.sl[l] = Sl; } lr[0] = invp; lr[14] = (double)a; }
+            if (k == 13) { if (fe > fs) { sb.hll[l] = h; sb.bl[l] = b; sb.invp[l] = invp; sb.sl[l] = Sl; } lr[0] = invp; lr[14] = (double)a; if (mf) sa[tl] = -invp; }
             if (k == 14 && fe > fs) xcand[xo_lam(P) + l] = stepped ? xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l] : xcur[xo_lam(P) + l];      // the same expression the factor threads evaluated
             if (k < 13) {
                 lr[1 + k] = e; if (fe > fs) sb.eA[(size_t)l * 13 + k] = e;
                 const int col = k < 6 ? col_pose(P, a) + k : (k < 12 ? col_ex(P) + k - 6 : col_td(P));
+                if (mf) Em[tl * VIS_RS + col] = e;
                 if (g != 0.0 || dg != 0.0) { lds_add(vbc + col, g); lds_add(vgr + col, g - ib * e); lds_add(vdg + col, dg); }
             }
             // observer columns: gred -= invp b eO ; lanes 0..5 of the group walk the factors
-            if (k < 6) for (int q = fs; q < fe; ++q) { const double eo = Jf[q * VF_STRIDE + 42 + k]; if (eo != 0.0) lds_add(vgr + col_pose(P, fj[q]) + k, -ib * eo); }
+            if (k < 6) for (int q = fs; q < fe; ++q) { const double eo = Jf[q * VF_STRIDE + 42 + k]; if (mf) Em[tl * VIS_RS + col_pose(P, fj[q]) + k] = eo; if (eo != 0.0) lds_add(vgr + col_pose(P, fj[q]) + k, -ib * eo); }
         }
         __syncthreads();
         VSTAMP(3);
@@ -228,7 +258,72 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
         //      atomics, so they run side by side: every kind's item range is padded to whole waves and the waves of the workgroup
         //      walk the concatenation -- two or three rounds of latency instead of one or two per kind with barriers in between.
         //      Groups: A = anchor pose, X = extrinsic, T = td (shared by all factors of the landmark), O_f = observing pose of factor f.
-        {
+        // Windows up to K = 12 (mf): the same update as G_A^T G_B on the fp64 matrix cores.  Jc_f (2 x NV) is non-zero on the anchor pose, the observing
+        // pose, the extrinsic and td, e_l on the anchor, the extrinsic, td and the landmark's observers: the factor threads and the landmark lanes above
+        // left them as dense rows (Gm: two per factor, Em: one per landmark), and sum_f Jc^T Jc - sum_l invp_l e_l e_l^T is one v_mfma_f64_16x16x4 per
+        // 16 x 16 tile and four rows, -invp_l applied to the A operand on its way in.  Every wave owns two of the 15 upper tiles; all operand loads of
+        // a batch are in flight before its first MFMA.  Deterministic, and 1.6 k cycles per chunk where the ~1200 atomic work items below take 5 k.
+        if (mf) {
+            const int wave = t >> 6, lane = t & 63;
+            const bool first = chunk == sc0, last = chunk + 1 == sc1, has1 = wave + 8 < nvtile;
+            int tI[VIS_T_SLOTS], tJ[VIS_T_SLOTS]; d4 acc[VIS_T_SLOTS];
+#pragma unroll
+            for (int u = 0; u < VIS_T_SLOTS; ++u) {
+                const int g = min(wave + 8 * u, nvtile - 1);                    // (a wave without a second tile mirrors the last one and stores nothing)
+                int I = 0, rem = g; while (rem >= VT - I) { rem -= VT - I; ++I; }      // upper tiles row by row: (I, I + rem)
+                tI[u] = I; tJ[u] = I + rem;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[u][q] = first ? 0.0 : tri[g * 256 + ((lane >> 4) + 4 * q) * 16 + (lane & 15)];
+            }
+            auto mma = [&](const double* G, auto nk_c, auto scaled_c) {       // acc += G_A^T G over NK * 4 rows; G_A = G, or the rows of G scaled by sa[row]
+                constexpr int NK = decltype(nk_c)::value; constexpr bool SCALED = decltype(scaled_c)::value;
+                const double* p = G + (lane >> 4) * VIS_RS + (lane & 15);
+                double a0[NK], b0[NK], a1[NK], b1[NK];
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) {
+                    a0[ks] = p[ks * 4 * VIS_RS + (tI[0] << 4)]; b0[ks] = p[ks * 4 * VIS_RS + (tJ[0] << 4)];
+                    a1[ks] = p[ks * 4 * VIS_RS + (tI[1] << 4)]; b1[ks] = p[ks * 4 * VIS_RS + (tJ[1] << 4)];
+                }
+                if (has1) {
+#pragma unroll
+                    for (int ks = 0; ks < NK; ++ks) {
+                        const double sc = SCALED ? sa[4 * ks + (lane >> 4)] : 1.0;
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(SCALED ? sc * a0[ks] : a0[ks], b0[ks], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(SCALED ? sc * a1[ks] : a1[ks], b1[ks], acc[1], 0, 0, 0);
+                    }
+                } else {                                                       // (one tile: the matrix core of this SIMD is shared with another wave)
+#pragma unroll
+                    for (int ks = 0; ks < NK; ++ks) {
+                        const double sc = SCALED ? sa[4 * ks + (lane >> 4)] : 1.0;
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(SCALED ? sc * a0[ks] : a0[ks], b0[ks], acc[0], 0, 0, 0);
+                    }
+                }
+            };
+            mma(Gm, std::integral_constant<int, 4>{}, std::false_type{});
+            if (nf > 8) mma(Gm + 16 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
+            if (nf > 16) mma(Gm + 32 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
+            if (nf > 24) mma(Gm + 48 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
+            mma(Em, std::integral_constant<int, 4>{}, std::true_type{});
+            if (last) {                                                        // straight from the accumulators into the packed upper triangle of the record
+                double* out = P.vpart + (size_t)wg * P.VP;
+#pragma unroll
+                for (int u = 0; u < VIS_T_SLOTS; ++u) if (wave + 8 * u < nvtile) {
+                    const int j = (tJ[u] << 4) + (lane & 15);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const int i = (tI[u] << 4) + (lane >> 4) + 4 * q; if (i <= j && j < NV) out[tri_idx(NV, i, j)] = acc[u][q]; }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < VIS_T_SLOTS; ++u) if (wave + 8 * u < nvtile) {
+                    const int g = wave + 8 * u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tri[g * 256 + ((lane >> 4) + 4 * q) * 16 + (lane & 15)] = acc[u][q];
+                }
+                __syncthreads();                                               // every wave is done with the operand rows: zero them for the next chunk
+                for (int e = t; e < 2 * nf * VIS_RS; e += blockDim.x) Gm[e] = 0.0;
+                for (int e = t; e < 16 * VIS_RS; e += blockDim.x) Em[e] = 0.0;
+            }
+        } else {
             // (a) shared x shared blocks: item = (landmark, pair of {A,X,T}, row); inner loop over the landmark's factors
             auto item_a = [&](int it) {
                 const int tl = it / 36, pr = it - 36 * tl, p = pr / 6, r = pr - 6 * p;
@@ -300,10 +395,17 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
                 else { const int i3 = it - pa - pc; if (i3 < nb_) item_b(i3); }
             }
         }
+        VSTAMP_SC();
     }
     VSTAMP(4);
+#ifdef VIL_STAMPS
+    if (t == 0 && wg == 0) { P.dbg[62] = vacc[0]; P.dbg[63] = vacc[1]; P.dbg[47] = vacc[2]; }
+#endif
     cost = block_sum(cost, red);
     double* out = P.vpart + (size_t)wg * P.VP;
+    if (mf) {                                              // (the tiles went out from the accumulators of the last chunk)
+        for (int e = t; e < 3 * NV; e += blockDim.x) out[NVT + e] = vbc[e];
+    } else
     for (int e = t; e < NVT + 3 * NV; e += blockDim.x) out[e] = tri[e];
     if (t == 0) out[NVT + 3 * NV] = cost;
     VSTAMP(5);

@@ -554,10 +554,14 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         // 32 factors: sweep 24.7 -> 22.5 us, reduce 15.0 -> 15.4; K = 20 (65 kB records): sweep 42 -> 60 us -- so only for the small records
         int fbal = NV <= 80 ? VIL_VCHUNK_FBAL : VIL_VCHUNK_F;
         if (const char* ev = VIL_TUNE_ENV("VIL_VFBAL")) fbal = std::max(1, atoi(ev));
+        P.vis_mf = (vd::vis_mfma(NV) && VIL_TUNE_ENV("VIL_NO_VMFMA") == nullptr) ? 1 : 0;
+        const int fcap = P.vis_mf ? VIS_MF : VIL_VCHUNK_F;      // (matrix-core path: the operand rows of a whole chunk sit in LDS)
+        static_assert(VIL_VCHUNK_FBAL <= VIS_MF && VIL_VCHUNK_LM <= 16, "chunk bounds of the matrix-core path");
+        fbal = std::min(fbal, fcap);
         while (l0 < L) {
             int l1 = l0, nf = 0;
-            while (l1 < L && l1 - l0 < VIL_VCHUNK_LM && nf + (lms[l1 + 1] - lms[l1]) <= VIL_VCHUNK_F && (l1 == l0 || nf + (lms[l1 + 1] - lms[l1]) <= fbal)) { nf += lms[l1 + 1] - lms[l1]; ++l1; }
-            if (l1 == l0) return VIL_ERR_UNSUPPORTED;   // a single landmark with > VIL_VCHUNK_F observations
+            while (l1 < L && l1 - l0 < VIL_VCHUNK_LM && nf + (lms[l1 + 1] - lms[l1]) <= fcap && (l1 == l0 || nf + (lms[l1 + 1] - lms[l1]) <= fbal)) { nf += lms[l1 + 1] - lms[l1]; ++l1; }
+            if (l1 == l0) return VIL_ERR_UNSUPPORTED;   // a single landmark with more observations than a chunk holds
             if (nf > 0) { vch.push_back(l0); vch.push_back(l1); }
             l0 = l1;
         }
@@ -827,7 +831,9 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     c->P.hctl = c->d_hctl; c->P.hseq = c->d_hseq; c->P.hstate = c->d_hstate;
     c->P.xorig = c->d_x0; c->P.gauge_on = c->gauge_on ? 1 : 0; c->P.setup_stat = c->d_status;
     { const int per = VIL_SWEEP_THREADS / 256; c->n_blocks_sweep = P.n_imu + P.n_vwg + (P.n_pchunk + per - 1) / per + (P.n_echunk + per - 1) / per + 2; }
-    c->lds_sweep = sizeof(double) * (size_t)(P.NVT + 3 * NV + VIL_VCHUNK_F * VF_STRIDE + VIL_VCHUNK_LM * 16 + 32 + VIL_VCHUNK_F + 8 + VIL_VCHUNK_LM + 8);
+    // visual workgroups: packed triangle (windows up to K = 12: upper 16 x 16 tiles + the dense operand rows of the matrix cores), three vectors, the staged
+    // factors, the landmark records
+    c->lds_sweep = sizeof(double) * (size_t)((P.vis_mf ? vd::vis_ntile(NV) * 256 + (2 * VIS_MF + 16) * VIS_RS + 16 : P.NVT) + 3 * NV + VIL_VCHUNK_F * VF_STRIDE + VIL_VCHUNK_LM * 16 + 32 + VIL_VCHUNK_F + 8 + VIL_VCHUNK_LM + 8);
     if (c->lds_sweep < 8 * 2048) c->lds_sweep = 8 * 2048;
     if (c->lds_sweep > 160 * 1024) return VIL_ERR_UNSUPPORTED;
     if ((int)c->lds_sweep > c->attr_sweep) { HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep)); c->attr_sweep = (int)c->lds_sweep; }

@@ -32,3 +32,4 @@ print("chain workgroup (ticks): zero + table gather %d, scales %d, chain %d, wri
 print("whole master: entry -> final stamp 7: %d ticks = %.1f us" % (dbg[7] - dbg[30], (dbg[7] - dbg[30]) / 2390.0))
 g = np.array([dbg[14]] + [dbg[48 + q] for q in range(7)] + [dbg[15]], dtype=np.int64)
 print("chain workgroup, forward recursion wave (ticks after the scales): block 0..5 published, middle block published, all waves done:", (g[1:] - g[0]).tolist(), " row waves done: forward %d, backward %d" % (dbg[55] - dbg[14], dbg[56] - dbg[14]))
+print("visual WG 0, ticks summed over its chunks: factor evaluation %d, landmark sums %d, outer products %d" % (dbg[62], dbg[63], dbg[47]))
