@@ -57,7 +57,7 @@ struct DevP {
     int n_vis, vis_stride, n_vchunk;
     const double* vis_c; const int* vis_i; const int* vis_j; const int* vis_l;
     const int* lm_start;      // L+1
-    const int* vchunk;        // n_vchunk x 2 landmark ranges
+    const int* vchunk;        // n_vchunk x 4: landmark range, factor range
     const int* lm_acol;       // L   reduced column of the anchor pose (6 * start_frame), -1 if the landmark has no factor
     const int* fcol;          // F   reduced column of the observing pose of each factor (6 * vis_j)
     // the same three tables over the WHOLE window and the offset of this rank's first visual factor in it: with the factor set
@@ -80,7 +80,7 @@ struct DevP {
     SysBuf sys[2];
     // per-workgroup partial results of the sweep (no global atomics); gathered by k_reduce
     int n_vwg, NVT, VP;           // visual workgroups; NV(NV+1)/2; doubles per visual partial = NVT + 3 NV + 1
-    const int* vwg;               // n_vwg x 2 sub-chunk ranges
+    const int* vwg;               // n_vwg x 8: {first sub-chunk, end, -, -} and the first sub-chunk's {l0, l1, f0, f1}
     double* vpart;                // n_vwg x VP  [tri(S') | bc | gred | diag | cost]
     double* lpart;                // (n_pchunk + n_echunk) x 28  [21 upper 6x6 | 6 g | cost]
     const int* lchunk_pose;       // 2 x (K+1): chunk ranges per pose (plane, edge)

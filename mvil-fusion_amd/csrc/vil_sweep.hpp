@@ -143,10 +143,12 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
     const bool mfree = P.marg != 0;            // marginalisation of the resident window: every block free, factors masked
     const bool exc = !mfree && P.ex_const != 0, tdc = mfree ? !P.use_td : !P.td_free;
     double cost = 0.0;
-    const int sc0 = P.vwg[2 * wg], sc1 = P.vwg[2 * wg + 1];
+    const int4 wg0 = ((const int4*)P.vwg)[2 * wg], wg1 = ((const int4*)P.vwg)[2 * wg + 1];      // {first chunk, end, -, -}, the first chunk's {l0, l1, f0, f1}
+    const int sc0 = wg0.x, sc1 = wg0.y;
     for (int chunk = sc0; chunk < sc1; ++chunk) {
-        const int l0 = P.vchunk[2 * chunk], l1 = P.vchunk[2 * chunk + 1];
-        const int f0 = P.lm_start[l0], f1 = P.lm_start[l1];
+        int4 ch = wg1;
+        if (chunk != sc0) ch = ((const int4*)P.vchunk)[chunk];
+        const int l0 = ch.x, l1 = ch.y, f0 = ch.z, f1 = ch.w;
         const int nf = f1 - f0, nl = l1 - l0;
         __syncthreads();
         VSTAMP(1);

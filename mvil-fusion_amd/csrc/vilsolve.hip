@@ -562,17 +562,21 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             int l1 = l0, nf = 0;
             while (l1 < L && l1 - l0 < VIL_VCHUNK_LM && nf + (lms[l1 + 1] - lms[l1]) <= fcap && (l1 == l0 || nf + (lms[l1 + 1] - lms[l1]) <= fbal)) { nf += lms[l1 + 1] - lms[l1]; ++l1; }
             if (l1 == l0) return VIL_ERR_UNSUPPORTED;   // a single landmark with more observations than a chunk holds
-            if (nf > 0) { vch.push_back(l0); vch.push_back(l1); }
+            if (nf > 0) { vch.push_back(l0); vch.push_back(l1); vch.push_back(lms[l0]); vch.push_back(lms[l1]); }      // landmark range, factor range
             l0 = l1;
         }
-        P.n_vchunk = (int)vch.size() / 2;
+        P.n_vchunk = (int)vch.size() / 4;
         put(vch.data(), 4 * vch.size(), (void**)&P.vchunk);
         // group the sub-chunks into visual workgroups (each owns one LDS triangle / one partial record)
         int vwg_max = 256;
         if (const char* ev = VIL_TUNE_ENV("VIL_VWG")) vwg_max = std::max(1, atoi(ev));
         P.n_vwg = std::min(P.n_vchunk, vwg_max);
         std::vector<int> vw;
-        for (int w = 0; w < P.n_vwg; ++w) { vw.push_back((int)((long long)P.n_vchunk * w / P.n_vwg)); vw.push_back((int)((long long)P.n_vchunk * (w + 1) / P.n_vwg)); }
+        for (int w = 0; w < P.n_vwg; ++w) {              // chunk range + the first chunk's ranges: a workgroup starts after ONE table look-up
+            const int s0 = (int)((long long)P.n_vchunk * w / P.n_vwg), s1 = (int)((long long)P.n_vchunk * (w + 1) / P.n_vwg);
+            vw.push_back(s0); vw.push_back(s1); vw.push_back(0); vw.push_back(0);
+            for (int q = 0; q < 4; ++q) vw.push_back(vch[4 * (size_t)s0 + q]);
+        }
         put(vw.data(), 4 * vw.size(), (void**)&P.vwg);
         P.NVT = NV * (NV + 1) / 2; P.VP = P.NVT + 3 * NV + 1;
         put(nullptr, 8 * (size_t)std::max(P.n_vwg, 1) * P.VP, (void**)&P.vpart);
