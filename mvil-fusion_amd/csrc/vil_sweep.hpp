@@ -33,6 +33,9 @@ __device__ __forceinline__ double block_sum(double v, double* red /*>= 4 doubles
     return t;
 }
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }   // ds_add_f64
+// a (wave-uniform) pointer the compiler cannot see through: address arithmetic on it stays where it is written instead of being hoisted to the top of
+// the role and kept in registers across the factor evaluation, the kernel's register peak
+template <class T> __device__ __forceinline__ T* opaque(T* p) { asm volatile("" : "+s"(p)); return p; }
 __device__ __forceinline__ int tri_idx(int NV, int i, int j) { if (i > j) { const int t = i; i = j; j = t; } return i * NV - ((i * (i - 1)) >> 1) + (j - i); }
 
 // ---------------------------------------------------------------------------------------------
@@ -100,25 +103,27 @@ __host__ __device__ inline int vis_ntile(int NV) { const int T = (NV + 15) >> 4;
 // The candidate inverse depth is formed HERE: lambda_cand = lambda_cur + cg la + cn lb (la, lb: the step directions the step
 // kernel's landmark pass left, cg / cn: the dogleg coefficients in Ctl; first sweep and re-sweeps: cg = cn = 0), and written
 // into the candidate state by the landmark's lane group.
+template <bool MF>      // MF: the block outer products on the matrix cores (windows up to K = 12); a kernel of its own per value -- both paths in one kernel spill
 __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, const Ctl& ctl, int wg, const double* x, SysBuf& sb, double* sm) {
     const int NV = P.NV, NVT = P.NVT;
     const int t = threadIdx.x;
-    const bool mf = P.vis_mf != 0;                     // (wave-uniform: a property of the window)
+    constexpr bool mf = MF;                            // (DevP::vis_mf, a property of the window: the host launches k_sweep<vis_mf>)
     const int VT = (NV + 15) >> 4, nvtile = vis_ntile(NV);
-    double* tri = sm;                                  // NVT packed upper triangle of the visual sub-space -- or, mf: its upper 16 x 16 tiles (I <= J), nvtile x 256
+    double* tri_ = sm; double* const tri = tri_;       // NVT packed upper triangle of the visual sub-space -- or, mf: its upper 16 x 16 tiles (I <= J), nvtile x 256
     double* vbc = tri + (mf ? nvtile * 256 : NVT);     // NV
     double* vgr = vbc + NV;                            // NV
     double* vdg = vgr + NV;                            // NV
     double* Jf = vdg + NV;                             // VIL_VCHUNK_F x VF_STRIDE
     double* lmr = Jf + VIL_VCHUNK_F * VF_STRIDE;       // VIL_VCHUNK_LM x 16: invp, eA[13]
     double* red = lmr + VIL_VCHUNK_LM * 16;
-    double* Gm = red + 8;                              // mf: 2 VIS_MF x VIS_RS rows of Jc (two per factor) | 16 x VIS_RS rows of e_l | 16 scales -invp_l
-    double* Em = Gm + 2 * VIS_MF * VIS_RS;
-    double* sa = Em + 16 * VIS_RS;
+    double* Gm_ = red + 8; double* const Gm = Gm_;                              // mf: 2 VIS_MF x VIS_RS rows of Jc (two per factor) | 16 x VIS_RS rows of e_l | 16 scales -invp_l
+    double* Em_ = Gm_ + 2 * VIS_MF * VIS_RS; double* const Em = Em_;
+    double* sa_ = Em_ + 16 * VIS_RS; double* const sa = sa_;
     int* fj = (int*)(mf ? sa + 16 : red + 8);          // VIL_VCHUNK_F observer frames
     int* lms = fj + VIL_VCHUNK_F;                      // VIL_VCHUNK_LM + 1 chunk-local factor offsets
     int* lanc = lms + VIL_VCHUNK_LM + 1;               // VIL_VCHUNK_LM anchor frames
     int* fl = lanc + VIL_VCHUNK_LM;                    // VIL_VCHUNK_F factor -> chunk-local landmark
+    int* fa = fl + VIL_VCHUNK_F;                       // (mf) VIS_MF anchor frames
 #ifdef VIL_STAMPS
     long long vacc[3] = {0, 0, 0}, vprev = 0;
     #define VSTAMP(k) do { __syncthreads(); if (t == 0 && wg == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[32 + k] = tt_; if (k >= 2 && k <= 3) vacc[k - 2] += tt_ - vprev; vprev = tt_; } } while (0)
@@ -176,23 +181,11 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             const double sr = sqrt(rho1);
             const bool ci = !mfree && P.pose_const && P.pose_const[i], cj = !mfree && P.pose_const && P.pose_const[j], cl = !mfree && P.lm_const && P.lm_const[l];
             double* w = Jf + t * VF_STRIDE;
-            if (mf) {                                   // the factor's two rows of Jc, dense (the rows were zeroed at the start / after the previous chunk)
-                double* g0 = Gm + 2 * t * VIS_RS; double* g1 = g0 + VIS_RS;
-                const int ca = col_pose(P, i), co = col_pose(P, j), cx = col_ex(P);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    g0[ca + k] = ci ? 0.0 : sr * o.Ji[k]; g1[ca + k] = ci ? 0.0 : sr * o.Ji[6 + k];
-                    g0[co + k] = cj ? 0.0 : sr * o.Jj[k]; g1[co + k] = cj ? 0.0 : sr * o.Jj[6 + k];
-                    g0[cx + k] = exc ? 0.0 : sr * o.Jex[k]; g1[cx + k] = exc ? 0.0 : sr * o.Jex[6 + k];
-                }
-                g0[col_td(P)] = tdc ? 0.0 : sr * o.Jt[0]; g1[col_td(P)] = tdc ? 0.0 : sr * o.Jt[1];
-            } else {
             for (int k = 0; k < 12; ++k) { w[k] = ci ? 0.0 : sr * o.Ji[k]; w[12 + k] = cj ? 0.0 : sr * o.Jj[k]; w[24 + k] = exc ? 0.0 : sr * o.Jex[k]; }
             w[36] = tdc ? 0.0 : sr * o.Jt[0]; w[37] = tdc ? 0.0 : sr * o.Jt[1];
-            }
             w[38] = cl ? 0.0 : sr * o.Jl[0]; w[39] = cl ? 0.0 : sr * o.Jl[1];
             w[40] = sr * o.r[0]; w[41] = sr * o.r[1];
-            fj[t] = j; fl[t] = l - l0;
+            fj[t] = j; fl[t] = l - l0; if (mf) fa[t] = i;
             // observer-pose pieces that need no landmark-level sum
             for (int k = 0; k < 6; ++k) {
                 const double j0 = cj ? 0.0 : sr * o.Jj[k], j1 = cj ? 0.0 : sr * o.Jj[6 + k];
@@ -219,11 +212,10 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             double e = 0, g = 0, dg = 0, h = 0, b = 0;
             const int off = k < 6 ? k : (k < 12 ? 24 + (k - 6) : 36);
             const int rs = k < 12 ? 6 : 1;      // row stride inside the 2 x n block
-            const int gcol = k < 6 ? col_pose(P, a) + k : (k < 12 ? col_ex(P) + k - 6 : col_td(P));      // (mf: the lane's column of the dense rows)
             for (int q = fs; q < fe; ++q) {
                 const double* w = Jf + q * VF_STRIDE;
                 const double l0_ = w[38], l1_ = w[39], r0 = w[40], r1 = w[41];
-                if (k < 13) { const double j0 = mf ? Gm[2 * q * VIS_RS + gcol] : w[off], j1 = mf ? Gm[(2 * q + 1) * VIS_RS + gcol] : w[off + rs]; e += j0 * l0_ + j1 * l1_; g += j0 * r0 + j1 * r1; dg += j0 * j0 + j1 * j1; }
+                if (k < 13) { const double j0 = w[off], j1 = w[off + rs]; e += j0 * l0_ + j1 * l1_; g += j0 * r0 + j1 * r1; dg += j0 * j0 + j1 * j1; }
                 else { h += l0_ * l0_ + l1_ * l1_; b += l0_ * r0 + l1_ * r1; }
             }
             // broadcast (h, b) of lane 13 to the 16-lane group
@@ -252,6 +244,23 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             }
             // observer columns: gred -= invp b eO ; lanes 0..5 of the group walk the factors
             if (k < 6) for (int q = fs; q < fe; ++q) { const double eo = Jf[q * VF_STRIDE + 42 + k]; if (mf) Em[tl * VIS_RS + col_pose(P, fj[q]) + k] = eo; if (eo != 0.0) lds_add(vgr + col_pose(P, fj[q]) + k, -ib * eo); }
+        } else if (mf) {
+            // the threads the landmarks do not use spread the staged Jacobian blocks into the dense operand rows (two per factor, zeroed before): item =
+            // (factor, residual row, one of the 19 columns); written by the evaluating thread itself the six row / group addresses cost it registers it
+            // does not have (19 VGPRs spilled, 3 MB of scratch traffic per launch)
+            const int t0 = 16 * nl, nt = blockDim.x - t0;
+            double* const Gm = opaque(Gm_);
+            int tq = t; asm volatile("" : "+v"(tq));
+            for (int it = tq - t0; it < nf * 38; it += nt) {
+                const int q = it / 38, e = it - 38 * q, rr = e >= 19 ? 1 : 0, m = e - 19 * rr;
+                const double* w = Jf + q * VF_STRIDE;
+                int col; double v;
+                if (m < 6) { col = col_pose(P, fa[q]) + m; v = w[rr * 6 + m]; }
+                else if (m < 12) { col = col_pose(P, fj[q]) + (m - 6); v = w[12 + rr * 6 + (m - 6)]; }
+                else if (m < 18) { col = col_ex(P) + (m - 12); v = w[24 + rr * 6 + (m - 12)]; }
+                else { col = col_td(P); v = w[36 + rr]; }
+                Gm[(2 * q + rr) * VIS_RS + col] = v;
+            }
         }
         __syncthreads();
         VSTAMP(3);
@@ -265,9 +274,11 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
         // left them as dense rows (Gm: two per factor, Em: one per landmark), and sum_f Jc^T Jc - sum_l invp_l e_l e_l^T is one v_mfma_f64_16x16x4 per
         // 16 x 16 tile and four rows, -invp_l applied to the A operand on its way in.  Every wave owns two of the 15 upper tiles; all operand loads of
         // a batch are in flight before its first MFMA.  Deterministic, and 1.6 k cycles per chunk where the ~1200 atomic work items below take 5 k.
-        if (mf) {
-            const int wave = t >> 6, lane = t & 63;
+        if constexpr (mf) {
+            int tq = t; asm volatile("" : "+v"(tq));      // (opaque: what is derived from it is computed here, not at the top of the role)
+            const int wave = __builtin_amdgcn_readfirstlane(tq >> 6), lane = tq & 63;
             const bool first = chunk == sc0, last = chunk + 1 == sc1, has1 = wave + 8 < nvtile;
+            double* const Gm = opaque(Gm_); double* const Em = opaque(Em_); double* const sa = opaque(sa_); double* const tri = opaque(tri_);
             int tI[VIS_T_SLOTS], tJ[VIS_T_SLOTS]; d4 acc[VIS_T_SLOTS];
 #pragma unroll
             for (int u = 0; u < VIS_T_SLOTS; ++u) {
@@ -306,13 +317,16 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             if (nf > 16) mma(Gm + 32 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
             if (nf > 24) mma(Gm + 48 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
             mma(Em, std::integral_constant<int, 4>{}, std::true_type{});
-            if (last) {                                                        // straight from the accumulators into the packed upper triangle of the record
-                double* out = P.vpart + (size_t)wg * P.VP;
+            if (last) {
+                // the accumulators go into the record's layout -- the packed upper triangle -- in LDS (over the operand rows, which every wave is done
+                // with) and leave with whole-line stores below: written straight from the registers, 16 lanes x 8 bytes per row fragment straddle the
+                // unaligned rows of the triangle and the partial lines doubled the kernel's write traffic (5.8 MB against 2.6)
+                __syncthreads();
 #pragma unroll
                 for (int u = 0; u < VIS_T_SLOTS; ++u) if (wave + 8 * u < nvtile) {
                     const int j = (tJ[u] << 4) + (lane & 15);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { const int i = (tI[u] << 4) + (lane >> 4) + 4 * q; if (i <= j && j < NV) out[tri_idx(NV, i, j)] = acc[u][q]; }
+                    for (int q = 0; q < 4; ++q) { const int i = (tI[u] << 4) + (lane >> 4) + 4 * q; if (i <= j && j < NV) Gm[tri_idx(NV, i, j)] = acc[u][q]; }
                 }
             } else {
 #pragma unroll
@@ -405,7 +419,8 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
 #endif
     cost = block_sum(cost, red);
     double* out = P.vpart + (size_t)wg * P.VP;
-    if (mf) {                                              // (the tiles went out from the accumulators of the last chunk)
+    if (mf) {                                              // (the last chunk left the packed triangle in Gm; block_sum's barriers are behind it)
+        for (int e = t; e < NVT; e += blockDim.x) out[e] = Gm[e];
         for (int e = t; e < 3 * NV; e += blockDim.x) out[NVT + e] = vbc[e];
     } else
     for (int e = t; e < NVT + 3 * NV; e += blockDim.x) out[e] = tri[e];
@@ -751,6 +766,7 @@ __device__ __forceinline__ void sweep_signal(const DevP& P, const Ctl& ctl, int 
 // The sweep: grid = n_imu + 2 (+ 1: prechain 2) + n_vwg + ceil(n_pchunk / 2) + ceil(n_echunk / 2) workgroups of VIL_SWEEP_THREADS threads.
 // Workgroup order: [imu x n_imu | prior | rel | (chain) | visual x n_vwg | plane | edge] -- the short roles the chain workgroup waits for
 // come first (roles: top of this file)
+template <bool MF>
 __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O) {
     extern __shared__ double sm[];
     const Ctl ctl = *P.ctl;
@@ -777,7 +793,7 @@ __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O
     b -= 2;
     if (P.prechain == 2) { if (b == 0) { if (pre) vd::prechain_wg(P, ctl, O.jacobi_scaling, sm, 0, true); return; } b -= 1; }
     // visual workgroups next: the longest-running factor role
-    if (b < P.n_vwg) { if (!(P.skip_mask & 1)) vd::sweep_visual(P, O, ctl, b, x, sb, sm); return; }
+    if (b < P.n_vwg) { if (!(P.skip_mask & 1)) vd::sweep_visual<MF>(P, O, ctl, b, x, sb, sm); return; }
     b -= P.n_vwg;
     const int per = VIL_SWEEP_THREADS / 256, npw = (P.n_pchunk + per - 1) / per;
     if (b < npw) { if (!(P.skip_mask & 4)) vd::sweep_lidar<1>(P, O, b, x, sm); return; }

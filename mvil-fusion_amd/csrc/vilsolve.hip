@@ -175,7 +175,7 @@ struct vil_ctx {
     char* h_mirror = nullptr; Ctl* d_hctl = nullptr; int* d_hseq = nullptr; double* d_hstate = nullptr; size_t mirror_ns = 0;      // pinned + mapped: Ctl | sequence word | final state, written by solve_finish (vil_finish.hpp)
     bool no_poll = false;          // VIL_NO_POLL=1: copy + synchronise instead of polling the mirror
     bool mirror_state = false;     // the mirror holds the final state of the last solve (vil_download_state needs no device operation)
-    int attr_sweep = 0, attr_step[5] = {0, 0, 0, 0, 0}, attr_marg[2] = {0, 0}, attr_commit = 0;      // dynamic-LDS sizes already granted to the kernels (hipFuncSetAttribute is not free)
+    int attr_sweep[2] = {0, 0}, attr_step[5] = {0, 0, 0, 0, 0}, attr_marg[2] = {0, 0}, attr_commit = 0;      // dynamic-LDS sizes already granted to the kernels (hipFuncSetAttribute is not free)
     double* h_pin = nullptr;       // pinned scratch
     char* marg_ws = nullptr;       // device work space of vil_marginalize (grow-only)
     size_t marg_ws_bytes = 0;
@@ -840,7 +840,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     c->lds_sweep = sizeof(double) * (size_t)((P.vis_mf ? vd::vis_ntile(NV) * 256 + (2 * VIS_MF + 16) * VIS_RS + 16 : P.NVT) + 3 * NV + VIL_VCHUNK_F * VF_STRIDE + VIL_VCHUNK_LM * 16 + 32 + VIL_VCHUNK_F + 8 + VIL_VCHUNK_LM + 8);
     if (c->lds_sweep < 8 * 2048) c->lds_sweep = 8 * 2048;
     if (c->lds_sweep > 160 * 1024) return VIL_ERR_UNSUPPORTED;
-    if ((int)c->lds_sweep > c->attr_sweep) { HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep)); c->attr_sweep = (int)c->lds_sweep; }
+    if ((int)c->lds_sweep > c->attr_sweep[P.vis_mf]) { HIPCHK(hipFuncSetAttribute(P.vis_mf ? (const void*)k_sweep<true> : (const void*)k_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep)); c->attr_sweep[P.vis_mf] = (int)c->lds_sweep; }
     c->n_blocks_reduce = (D * (D + 1) / 2 + RED_EPW - 1) / RED_EPW + (2 * D + RED_EPW - 1) / RED_EPW + 1;
     // ---- step kernel variant: the speed-bias part of the reduced matrix is a chain whenever every IMU factor couples (k, k+1)
     //      and the prior's speed-bias blocks are neighbours (VINS: exactly one) -> vil_chain.hpp; anything else: dense path
@@ -877,7 +877,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             else {
                 c->lds_step = lds3;
                 c->lds_sweep = std::max(c->lds_sweep, ldsc);      // the chain workgroup rides in k_sweep
-                if ((int)c->lds_sweep > c->attr_sweep) { HIPCHK(hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep)); c->attr_sweep = (int)c->lds_sweep; }
+                if ((int)c->lds_sweep > c->attr_sweep[P.vis_mf]) { HIPCHK(hipFuncSetAttribute(P.vis_mf ? (const void*)k_sweep<true> : (const void*)k_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep)); c->attr_sweep[P.vis_mf] = (int)c->lds_sweep; }
                 c->n_blocks_sweep += 1;
             }
         }
@@ -1072,7 +1072,8 @@ static DevP view(const vil_ctx* c, int which) {
     return P;
 }
 static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
-    hipLaunchKernelGGL(k_sweep, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, view(c, 0), so);
+    if (c->P.vis_mf) hipLaunchKernelGGL(k_sweep<true>, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, view(c, 0), so);
+    else hipLaunchKernelGGL(k_sweep<false>, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, view(c, 0), so);
     return VIL_OK;
 }
 static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr) {

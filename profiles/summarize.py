@@ -20,7 +20,8 @@ def main():
         dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print("%-44s %6s %10s %6s %10s %10s" % ("kernel", "calls", "avg_us", "live", "live_avg", "live_max"))
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-        thr = (8.0 if k.startswith(("k_sweep", "void k_step")) else 5.0) if k.startswith(("k_sweep", "k_reduce", "void k_step")) else 0.0
+        own = any(f in k for f in ("k_sweep", "k_reduce", "k_step<"))      # (k_sweep is a template since round 3: "void k_sweep<true>(...)")
+        thr = (8.0 if ("k_sweep" in k or "k_step<" in k) else 5.0) if own else 0.0
         live = [x for x in v if x > thr]
         print("%-44s %6d %10.2f %6d %10.2f %10.2f" % (k[:44], len(v), sum(v) / len(v), len(live), sum(live) / max(1, len(live)), max(v)))
     for f in sys.argv[2:4]:
@@ -29,7 +30,7 @@ def main():
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"]].append(float(r["Counter_Value"])); name = r["Counter_Name"]
         for k, v in acc.items():
-            if k.startswith(("k_sweep", "k_reduce", "void k_step")):
+            if any(f in k for f in ("k_sweep", "k_reduce", "k_step<")):
                 live = [x for x in v if x > 0.25 * max(v)]
                 print("%s %-40s live launches %4d  mean %.1f KB" % (name, k[:40], len(live), sum(live) / max(1, len(live))))
     if len(sys.argv) > 4:
