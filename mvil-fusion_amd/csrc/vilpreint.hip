@@ -21,7 +21,7 @@
 #define VP_ERR_INVALID -1
 #define VP_ERR_DEVICE -2
 #define VPCHK(x) do { if ((x) != hipSuccess) return VP_ERR_DEVICE; } while (0)
-#define PRE_B 16
+#define PRE_B 24      // samples per batch: an inter-keyframe interval at 200 Hz / 10 Hz (20 samples) is ONE batch; 24 x 720 doubles = 138 kB of LDS
 #define PRE_THREADS 256
 
 namespace {
