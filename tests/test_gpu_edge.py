@@ -184,3 +184,16 @@ def test_solver_options_parity(hip, oracle, kw):
     assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.final_cost
     hip.gauge_fix(p0, wg); oracle.gauge_fix(p0, wo)
     assert np.abs(wg.pose - wo.pose).max() < 1e-6 and np.abs(wg.inv_depth - wo.inv_depth).max() < 1e-5
+
+
+@pytest.mark.parametrize("K", [4, 7, 11, 12, 13, 16])
+def test_window_sizes_around_the_path_switches(hip, oracle, K):
+    """The solver changes machinery with the window size: K <= 12 -- gather + step in one launch with the chain workgroup beside the gather, visual
+    block outer products on the matrix cores (NV = 6 K + 7 <= 80: K = 12 fills the fifth 16-column tile to 79); K >= 13 -- chain workgroup inside the
+    sweep, tile workgroups in the gather kernel, LDS atomics; K = 4 is the smallest window the synthetic tracks allow.  Same trajectory and
+    solution as the oracle on every side of those switches, linearisation included."""
+    kw = dict(K=K, L=150, n_plane=1200, n_edge=400)
+    pf = lambda pre: oracle.marginalize(pre).to_prior()
+    wg, wo = synth.make_config(2, prior_fn=pf, **kw), synth.make_config(2, prior_fn=pf, **kw)
+    _check_lin(hip, oracle, synth.make_config(2, prior_fn=pf, **kw))
+    _check_solve(hip, oracle, wg, wo)
