@@ -177,10 +177,21 @@ __device__ __forceinline__ void prechain_ww_tile(const DevP& P, const int tile) 
     d4_ c4 = {0.0, 0.0, 0.0, 0.0};
     // k-steps of four chain columns, dealt round-robin to the waves; rows beyond R / columns beyond NB are masked (chW is padded, never read out of bounds)
     const int nk = (NB + 3) >> 2;
-    for (int ks = wave; ks < nk; ks += 4) {
-        const bool kv = 4 * ks + kq < NB;
-        const double av = ld_ag(pa + (size_t)4 * ks * RS), bv = ld_ag(pb + (size_t)4 * ks * RS);      // written by the chain workgroup of this launch
-        c4 = __builtin_amdgcn_mfma_f64_16x16x4f64((va && kv) ? av : 0.0, (vb && kv) ? bv : 0.0, c4, 0, 0, 0);
+    // (eight k-steps per round with all sixteen operand loads in flight before the first MFMA: one L2 round trip per round -- a load, a wait and an
+    //  MFMA per k-step was six round trips in a row at K = 10, on the path between the end of the chain and the start of the dense factorisation)
+    for (int ks0 = wave; ks0 < nk; ks0 += 32) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ks = min(ks0 + 4 * u, nk - 1);
+            av[u] = ld_ag(pa + (size_t)4 * ks * RS); bv[u] = ld_ag(pb + (size_t)4 * ks * RS);      // written by the chain workgroup of this launch
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ks = ks0 + 4 * u;
+            const bool kv = ks < nk && 4 * ks + kq < NB;
+            c4 = __builtin_amdgcn_mfma_f64_16x16x4f64((va && kv) ? av[u] : 0.0, (vb && kv) ? bv[u] : 0.0, c4, 0, 0, 0);
+        }
     }
     // accumulator element g of a lane = (row (lane >> 4) + 4 g, column lane & 15) of the tile
 #pragma unroll
