@@ -857,8 +857,14 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
         const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
         if (t == 0 && P.rs_merged) while (__hip_atomic_load(P.chflag + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
         __syncthreads();
-        for (int e = t; e < 54 * K; e += VIL_STEP_THREADS) Ldg[e] = ld_ag(P.chLdg + e);
-        for (int e = t; e < 82 * K; e += VIL_STEP_THREADS) Lsb[e] = ld_ag(P.chLsb + e);
+        // (all loads of a thread in flight together -- a load, a wait and an LDS store per element is one L2 round trip after the other)
+        double pl[2], ps[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { pl[q] = ld_ag(P.chLdg + min(t + q * VIL_STEP_THREADS, 54 * K - 1)); ps[q] = ld_ag(P.chLsb + min(t + q * VIL_STEP_THREADS, 82 * K - 1)); }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const int e = t + q * VIL_STEP_THREADS; if (e < 54 * K) Ldg[e] = pl[q]; if (e < 82 * K) Lsb[e] = ps[q]; }
+        for (int e = t + 2 * VIL_STEP_THREADS; e < 54 * K; e += VIL_STEP_THREADS) Ldg[e] = ld_ag(P.chLdg + e);      // (K > 18)
+        for (int e = t + 2 * VIL_STEP_THREADS; e < 82 * K; e += VIL_STEP_THREADS) Lsb[e] = ld_ag(P.chLsb + e);      // (K > 12)
     }
     {   // t = y_b - W^T x_p with the deferred row scaling (the right-hand-side row of W^T carries y_b)
         const int G = (4 * NB <= VIL_STEP_THREADS) ? 4 : 2;
