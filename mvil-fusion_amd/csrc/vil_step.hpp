@@ -825,6 +825,9 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
         __syncthreads();                               // (everything they left is read at agent scope below: no fence)
     }
     SSTAMP(1);
+    // (the chain workgroup's last flag -- factors for the chain back substitution, written ~4 us after W -- rides in the round trip of the W W^T loads:
+    //  a thread that sees it posted here needs neither a poll nor a barrier after the dense part)
+    const int f2 = P.rs_merged ? ld_ag(P.chflag + 2) : 0;
     {   // M_pp -= Sc (W W^T) Sc: each thread on the very elements it packed (same index map: no barrier in between)
         const int NE = ntile << 8;
         for (int e0 = t; e0 < NE; e0 += 8 * VIL_STEP_THREADS) {
@@ -853,34 +856,34 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
     back_subst(Tl, NP, s);
     pub();
     SSTAMP(5);
-    {   // the chain workgroup's last act (long done by now): inverses of the factored diagonal blocks, sub-diagonal blocks
-        const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
-        if (t == 0 && P.rs_merged) while (__hip_atomic_load(P.chflag + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
-        __syncthreads();
-        // (all loads of a thread in flight together -- a load, a wait and an LDS store per element is one L2 round trip after the other)
-        double pl[2], ps[2];
+    // ---- chain back substitution.  What it needs from the chain workgroup (inverses of the factored diagonal blocks, sub-diagonal blocks, W^T) in ONE
+    //      round trip: every load of a thread in flight together
+    {
+        const int G = (4 * NB <= VIL_STEP_THREADS) ? 4 : 2;
+        const int j = t / G, part = t - j * G;
+        const int jc = min(j, NB - 1);
+        if (P.rs_merged) {
+            const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
+            if (f2 != epoch) while (__hip_atomic_load(P.chflag + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+        }
+        double acc = 0.0, wv[24], pl[2], ps[2];
+        const int nr = (NP - part + G - 1) / G;            // rows part, part + G, ... < NP
 #pragma unroll
         for (int q = 0; q < 2; ++q) { pl[q] = ld_ag(P.chLdg + min(t + q * VIL_STEP_THREADS, 54 * K - 1)); ps[q] = ld_ag(P.chLsb + min(t + q * VIL_STEP_THREADS, 82 * K - 1)); }
+#pragma unroll
+        for (int q = 0; q < 24; ++q) wv[q] = ld_ag(Wt + (size_t)jc * RS + min(part + q * G, NP - 1));
+        const double wrhs = ld_ag(Wt + (size_t)jc * RS + NP);
 #pragma unroll
         for (int q = 0; q < 2; ++q) { const int e = t + q * VIL_STEP_THREADS; if (e < 54 * K) Ldg[e] = pl[q]; if (e < 82 * K) Lsb[e] = ps[q]; }
         for (int e = t + 2 * VIL_STEP_THREADS; e < 54 * K; e += VIL_STEP_THREADS) Ldg[e] = ld_ag(P.chLdg + e);      // (K > 18)
         for (int e = t + 2 * VIL_STEP_THREADS; e < 82 * K; e += VIL_STEP_THREADS) Lsb[e] = ld_ag(P.chLsb + e);      // (K > 12)
-    }
-    {   // t = y_b - W^T x_p with the deferred row scaling (the right-hand-side row of W^T carries y_b)
-        const int G = (4 * NB <= VIL_STEP_THREADS) ? 4 : 2;
-        const int j = t / G, part = t - j * G;
-        const int jc = min(j, NB - 1);
-        // all of a thread's loads in flight together (W^T comes from the chain workgroup through L2: one round trip, not 17)
-        double acc = 0.0, wv[24];
-        const int nr = (NP - part + G - 1) / G;            // rows part, part + G, ... < NP
-#pragma unroll
-        for (int q = 0; q < 24; ++q) wv[q] = ld_ag(Wt + (size_t)jc * RS + min(part + q * G, NP - 1));
+        // t = y_b - W^T x_p with the deferred row scaling (the right-hand-side row of W^T carries y_b)
 #pragma unroll
         for (int q = 0; q < 24; ++q) { const int rr = min(part + q * G, NP - 1); acc += (q < nr ? wv[q] : 0.0) * s.sc[rr] * s.y[rr]; }
         for (int q = 24; q < nr; ++q) { const int rr = part + q * G; acc += ld_ag(Wt + (size_t)jc * RS + rr) * s.sc[rr] * s.y[rr]; }
         acc += __shfl_xor(acc, 1, 64);
         if (G == 4) acc += __shfl_xor(acc, 2, 64);
-        if (j < NB && part == 0) tB[j] = ld_ag(Wt + (size_t)j * RS + NP) - acc;
+        if (j < NB && part == 0) tB[j] = wrhs - acc;
     }
     __syncthreads();
     // x_k = L_kk^-T (t_k - Ls_k^T x_next) with the INVERSE of L_kk the chain workgroup left (Ldg here holds L^-1, 45 entries per block): two
