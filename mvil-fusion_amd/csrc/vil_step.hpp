@@ -419,22 +419,22 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double
 // enters it.  ONE barrier per block step, and the panel group's chain (~2000 cycles) is the step; chol_blocked needs ~3500 (diagonal block,
 // panel, barrier, trailing update, barrier, everybody in lockstep).
 // On return rows < D hold L, row D holds y = L^-1 rhs, s.dinv[j] = 1 / L_jj.  Returns false (uniformly) on a non-positive pivot.
-template <class PTR, class PRE = NoPre>
+template <int SLOTS = CH_SLOTS, class PTR, class PRE = NoPre>      // SLOTS: register tiles per wave (8 waves x SLOTS >= the tiles of the matrix)
 __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE pre = PRE()) {
     const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
     const int R = D + 1;                 // rows including the rhs row
     const int T = (R + 15) >> 4;         // tile rows
     const int la = (lane & 15) * TILE_RS + (lane >> 4);     // operand element (row lane&15, k lane>>4) inside a tile
     const int lc = (lane >> 4) * TILE_RS + (lane & 15);     // accumulator element (row lane>>4 (+4g), col lane&15)
-    const int ntile_all = (T * (T + 1)) >> 1;               // <= NW * CH_SLOTS
+    const int ntile_all = (T * (T + 1)) >> 1;               // <= NW * SLOTS
     // panel group: the last npw waves; thread tp of it owns the tp-th row below the block.  The tiles are dealt to the other waves first
     const int npw = max(1, (R - min(STEP_NB, D) + 63) >> 6);   // the first block has the most panel rows: R - min(NB, D)
     const int NWT = NW - npw;
     const int tp = t - 64 * NWT;
-    d4 Creg[CH_SLOTS]; int tIJ[CH_SLOTS];
+    d4 Creg[SLOTS]; int tIJ[SLOTS];
 #pragma unroll
-    for (int u = 0; u < CH_SLOTS; ++u) {
-        const int g = wave < NWT ? wave + NWT * u : NWT * CH_SLOTS + (wave - NWT) + npw * u;
+    for (int u = 0; u < SLOTS; ++u) {
+        const int g = wave < NWT ? wave + NWT * u : NWT * SLOTS + (wave - NWT) + npw * u;
         tIJ[u] = -1;
         if (g < ntile_all) {
             const int I = s.tI[g], J = s.tJ[g];
@@ -517,14 +517,14 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
     };
     // tile column 0 to LDS (tile column 1 as well when the matrix has fewer than three blocks in column 0 -- never: a tile column has four), block 0
 #pragma unroll
-    for (int u = 0; u < CH_SLOTS; ++u) if (tIJ[u] >= 0 && (tIJ[u] & 255) == 0) {
+    for (int u = 0; u < SLOTS; ++u) if (tIJ[u] >= 0 && (tIJ[u] & 255) == 0) {
         const int cb = tl_base(tIJ[u] >> 8, 0) + lc;
 #pragma unroll
         for (int q = 0; q < 4; ++q) A[cb + q * (4 * TILE_RS)] = Creg[u][q];
     }
-    __syncthreads();
+    lds_barrier();
     if (tp >= 0) { if (D >= STEP_NB) diag_panel(0, std::true_type{}, std::false_type{}); else diag_panel(0, std::false_type{}, std::false_type{}); }
-    __syncthreads();
+    lds_barrier();
     if (!s.cok) return false;
     for (int kb = 0; kb + STEP_NB < D; kb += STEP_NB) {      // panel kb (a full block) is in LDS; the last block has no successor
         const int Kt = kb >> 4, ko = kb & 15;
@@ -533,7 +533,7 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
         const bool pub = ((kb1 + STEP_NB) & 15) == 0;        // the block after the next opens tile column Kn + 1: publish it after this update
         if (tp >= 0) { if (kb1 + STEP_NB <= D) diag_panel(kb1, std::true_type{}, std::true_type{}); else diag_panel(kb1, std::false_type{}, std::true_type{}); }
 #pragma unroll
-        for (int u = 0; u < CH_SLOTS; ++u) {
+        for (int u = 0; u < SLOTS; ++u) {
             const int I = tIJ[u] >> 8, J = tIJ[u] & 255;
             if (tIJ[u] < 0 || J < Kn) continue;                       // finished (or empty) slot: wave-uniform
             // unconditional reads (inside the tile for every lane) + select: a per-lane predicated load would compile to an exec-mask branch with its own wait
@@ -558,7 +558,7 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     // (a non-positive pivot is looked at once, here: the blocks after it computed garbage nobody uses, and the flag's LDS round trip stays off the chain)
     return s.cok != 0;
@@ -598,7 +598,7 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
             for (int i = 1; i < 16; ++i) if (i > j && i < n_t) A[tb + j * TILE_RS + i] = w[i];      // W_ij at (j, i)
         }
     }
-    __syncthreads();
+    lds_barrier();
 #ifdef VIL_STAMPS
     if (t == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); s.tacc[0] = tt_; }
 #endif
@@ -629,7 +629,7 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
             const double x = dv * yd + ((a0 + a1) + (a2 + a3));
             if (t < n_b) s.xs[kb + t] = x;
         }
-        __syncthreads();
+        lds_barrier();
         for (int c = t; c < kb; c += NT) {                  // y_c -= sum_r L[kb+r][c] x_r
             const int base = tl_base(blk, c >> 4) + (c & 15);
             double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
@@ -642,10 +642,10 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
             }
             s.y[c] -= (v0 + v1) + (v2 + v3);
         }
-        __syncthreads();
+        lds_barrier();
     }
     for (int i = t; i < D; i += NT) s.y[i] = s.xs[i];
-    __syncthreads();
+    lds_barrier();
 }
 
 // ---- chain path (vil_chain.hpp): pack the pose part, eliminate the speed-bias chain from both ends, Schur-update the pose
@@ -851,7 +851,19 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
     __syncthreads();
     SSTAMP(2); SSTAMP(3);
     if (!s.ok) return false;
-    if (!chol_lookahead(Tl, NP, s)) return false;
+    // W^T for the chain back substitution (t = y_b - W^T x_p) does not depend on x_p: its loads are issued here and land under the first block steps of the
+    // factorisation, whose barriers order LDS only (lds_barrier) and do not wait for them
+    const int G = (4 * NB <= VIL_STEP_THREADS) ? 4 : 2;
+    const int j = t / G, part = t - j * G;
+    const int jc = min(j, NB - 1);
+    double wv[24], wrhs = 0.0;
+    const bool small = ntile <= 24;                    // K <= 12: three register tiles per wave in the factorisation instead of seven -- room for the prefetch
+    if (small) {
+#pragma unroll
+        for (int q = 0; q < 24; ++q) wv[q] = ld_ag(Wt + (size_t)jc * RS + min(part + q * G, NP - 1));
+        wrhs = ld_ag(Wt + (size_t)jc * RS + NP);
+        if (!chol_lookahead<3>(Tl, NP, s)) return false;
+    } else if (!chol_lookahead(Tl, NP, s)) return false;
     SSTAMP(4);
     back_subst(Tl, NP, s);
     pub();
@@ -859,20 +871,19 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
     // ---- chain back substitution.  What it needs from the chain workgroup (inverses of the factored diagonal blocks, sub-diagonal blocks, W^T) in ONE
     //      round trip: every load of a thread in flight together
     {
-        const int G = (4 * NB <= VIL_STEP_THREADS) ? 4 : 2;
-        const int j = t / G, part = t - j * G;
-        const int jc = min(j, NB - 1);
         if (P.rs_merged) {
             const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
             if (f2 != epoch) while (__hip_atomic_load(P.chflag + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
         }
-        double acc = 0.0, wv[24], pl[2], ps[2];
+        double acc = 0.0, pl[2], ps[2];
         const int nr = (NP - part + G - 1) / G;            // rows part, part + G, ... < NP
 #pragma unroll
         for (int q = 0; q < 2; ++q) { pl[q] = ld_ag(P.chLdg + min(t + q * VIL_STEP_THREADS, 54 * K - 1)); ps[q] = ld_ag(P.chLsb + min(t + q * VIL_STEP_THREADS, 82 * K - 1)); }
+        if (!small) {
 #pragma unroll
-        for (int q = 0; q < 24; ++q) wv[q] = ld_ag(Wt + (size_t)jc * RS + min(part + q * G, NP - 1));
-        const double wrhs = ld_ag(Wt + (size_t)jc * RS + NP);
+            for (int q = 0; q < 24; ++q) wv[q] = ld_ag(Wt + (size_t)jc * RS + min(part + q * G, NP - 1));
+            wrhs = ld_ag(Wt + (size_t)jc * RS + NP);
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) { const int e = t + q * VIL_STEP_THREADS; if (e < 54 * K) Ldg[e] = pl[q]; if (e < 82 * K) Lsb[e] = ps[q]; }
         for (int e = t + 2 * VIL_STEP_THREADS; e < 54 * K; e += VIL_STEP_THREADS) Ldg[e] = ld_ag(P.chLdg + e);      // (K > 18)
