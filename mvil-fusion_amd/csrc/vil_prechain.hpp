@@ -76,35 +76,45 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     double* scB = lds + chain_scratch_doubles(K); double* dcB = scB + even_up(NB); double* uB = dcB + even_up(NB);
     const ChainSlab B = chain_slab(uB + even_up(NB), K);
     if (t < 8) L.flag[t] = 0;
-    const double sc_prev = (t < NB && !ctl.first) ? P.Sc[NP + t] : 0.0;      // (in flight under the gather)
-    // the slab is a gather target: entries without a source (pose rows of far frames) stay zero
+    // ---- gather of the chain part of S' out of the IMU / prior records through the host-built table: eight entries per thread and round (one round at
+    //      K = 10).  Two dependent round trips -- entries, then their sources -- and NOTHING before them: the zeroing of the slab (a gather target: entries
+    //      without a source, pose rows of far frames, stay zero) and the small copies run while the sources are in flight; only the stores wait for the barrier
+    const int4* tab = (const int4*)P.chtab;
+    const int n = P.n_chtab;
+    double* slab = B.dg;
+    int4 q[8]; double a[8], b[8], c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = tab[min(t + u * NT, n - 1)];
+    const double sc_prev = (t < NB && !ctl.first) ? P.Sc[NP + t] : 0.0;
+    const int pqv = P.chpq[min(t, NB - 1)];
+    auto sources = [&]() {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[u] = P.ipart[max(q[u].y, 0)]; b[u] = P.ipart[max(q[u].z, 0)];
+            const int cw = q[u].w;
+            c[u] = cw >= 0 ? P.pH[cw] : P.mpart[max(-cw - 2, 0)];
+        }
+    };
+    if (!wait_records) sources();
     { double* z = B.dg; const int nz = (int)chain_slab_fp(K); for (int e = t; e < nz; e += NT) z[e] = 0.0; }
-    for (int e = t; e < NB; e += NT) B.pq[e] = P.chpq[e];
+    if (t < NB) B.pq[t] = pqv;
+    for (int e = t + NT; e < NB; e += NT) B.pq[e] = P.chpq[e];
     if (wait_records) {
         const int ep = (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u);       // (sweep_signal, vil_sweep.hpp)
         if (t <= P.n_imu && (t < P.n_imu || P.pn > 0)) while (__hip_atomic_load(P.swflag + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ep) __builtin_amdgcn_s_sleep(2);
     }
     __syncthreads();
-    // ---- gather: eight table entries per thread and round (one round at K = 10), every load of a round in flight before the first store
-    {
-        const int4* tab = (const int4*)P.chtab;
-        const int n = P.n_chtab;
-        double* slab = B.dg;
-        for (int e0 = t; e0 < n; e0 += 8 * NT) {
-            int4 q[8]; double a[8], b[8], c[8];
+    if (wait_records) sources();                           // (inside k_sweep the records are complete only behind the flags)
+    for (int e0 = t; e0 < n; e0 += 8 * NT) {
+        if (e0 != t) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) q[u] = tab[min(e0 + u * NT, n - 1)];
+            sources();
+        }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                a[u] = P.ipart[max(q[u].y, 0)]; b[u] = P.ipart[max(q[u].z, 0)];
-                const int cw = q[u].w;
-                c[u] = cw >= 0 ? P.pH[cw] : P.mpart[max(-cw - 2, 0)];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) if (e0 + u * NT < n) {
-                const double v = (q[u].y >= 0 ? a[u] : 0.0) + (q[u].z >= 0 ? b[u] : 0.0) + (q[u].w != -1 ? c[u] : 0.0);
-                slab[q[u].x] = v;
-            }
+        for (int u = 0; u < 8; ++u) if (e0 + u * NT < n) {
+            const double v = (q[u].y >= 0 ? a[u] : 0.0) + (q[u].z >= 0 ? b[u] : 0.0) + (q[u].w != -1 ? c[u] : 0.0);
+            slab[q[u].x] = v;
         }
     }
     __syncthreads();
