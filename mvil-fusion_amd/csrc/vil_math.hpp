@@ -210,8 +210,10 @@ __device__ __forceinline__ void rsqrt_sqrt(double x, double& sq, double& rs) {
     const double g = x * rs;
     sq = fma(fma(-g, g, x), 0.5 * rs, g);
 }
-// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load of the wave (vmcnt(0)), which would end a
-// prefetch that is meant to land behind the barriers of an LDS-only phase.  (Registers loaded from global memory are waited for at their first use.)
+// Workgroup barrier that orders LDS traffic only and leaves global loads in flight.  hipcc 7.2 lowers __syncthreads() on gfx950 to the same two
+// instructions (a workgroup lives on one CU, so its workgroup-scope fence needs no vmcnt wait -- checked on a test kernel); it is written out where a
+// prefetch RELIES on landing behind the barriers of an LDS-only phase, so that this does not hang on the toolchain's lowering of the fence.
+// (Registers loaded from global memory are waited for at their first use.)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // Data that crosses workgroups INSIDE one launch is stored and loaded at agent scope -- the level the eight XCDs share -- so that a flag only
 // has to be ordered behind the poster's own stores (s_waitcnt vmcnt(0)).  A release fence instead writes the whole XCD's L2 back
