@@ -6,7 +6,7 @@
 
 #define VIL_THREADS 256       // eval / reduce kernels, LiDAR chunk size
 #define VIL_SWEEP_THREADS 512 // sweep workgroups: 8 waves = 2 per SIMD for LDS-latency hiding
-#define VIL_VCHUNK_LM 12      // landmarks per visual sub-chunk
+#define VIL_VCHUNK_LM 12      // landmarks per visual sub-chunk (matrix-core path, wide chunks: VIS_LM = 16, vil_sweep.hpp)
 #define VIL_VCHUNK_F 128      // factors per visual workgroup (LDS staging bound)
 #define VIL_VCHUNK_FBAL 32    // factors at which a chunk is closed when the partial records are small (balance between the visual workgroups)
 #define VIL_STEP_THREADS 512
@@ -107,6 +107,7 @@ struct DevP {
     int gauge_on;                 // double2vector()'s yaw / translation gauge fix as part of solve_finish
     const int* setup_stat;        // != 0: k_setup found an IMU covariance that is not positive definite -- the first step kernel ends the solve with it
     int vis_mf;      // visual workgroups: block outer products on the matrix cores (windows up to K = 12, vil_sweep.hpp)
+    int vis_fmax;    // factors of the largest visual chunk
     int n_help; double* hpart; int* hflag;
     // second landmark pass of the helpers (k_step): the master posts the epoch in xflag (Sc x_p is in stepc) or in xstat (no step
     // this launch); every helper WAVE then leaves its six sums in hpart2[8 * slot ..] and the epoch in hflag2[slot], slot = 8 k + wave

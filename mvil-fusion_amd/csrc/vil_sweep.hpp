@@ -95,7 +95,8 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
 // LDS per factor: [Ji 12 | Jj 12 | Jex 12 | Jt 2 | Jl 2 | r 2 | eO 6] = 48 doubles
 #define VF_STRIDE 49   // odd stride: conflict-free column access
 // Windows up to K = 12 (NV <= 80, chunks of <= VIS_MF factors): the block outer products run on the fp64 matrix cores from dense operand rows in LDS
-#define VIS_MF 32      // factors of a chunk on that path (two operand rows each)
+#define VIS_MF 64      // factors a chunk may hold on that path (two operand rows each); chunks are closed at VIL_VCHUNK_FBAL unless the window has more of them than workgroups
+#define VIS_LM 16      // landmarks a chunk may hold (one operand row each: one MFMA batch)
 #define VIS_RS 80      // row stride of the operand rows: five 16-column tiles, = 16 mod 32 (the four rows of an MFMA operand fragment on different banks)
 #define VIS_T_SLOTS 2  // 16 x 16 tiles per wave: 15 upper tiles of a 5 x 5 grid on 8 waves
 __host__ __device__ inline bool vis_mfma(int NV) { return NV <= VIS_RS; }
@@ -113,16 +114,16 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
     double* vbc = tri + (mf ? nvtile * 256 : NVT);     // NV
     double* vgr = vbc + NV;                            // NV
     double* vdg = vgr + NV;                            // NV
-    double* Jf = vdg + NV;                             // VIL_VCHUNK_F x VF_STRIDE
-    double* lmr = Jf + VIL_VCHUNK_F * VF_STRIDE;       // VIL_VCHUNK_LM x 16: invp, eA[13]
-    double* red = lmr + VIL_VCHUNK_LM * 16;
+    double* Jf = vdg + NV;                             // VIL_VCHUNK_F (mf: VIS_MF) x VF_STRIDE
+    double* lmr = Jf + (mf ? VIS_MF : VIL_VCHUNK_F) * VF_STRIDE;       // VIS_LM x 16: invp, eA[13]
+    double* red = lmr + VIS_LM * 16;
     double* Gm_ = red + 8; double* const Gm = Gm_;                              // mf: 2 VIS_MF x VIS_RS rows of Jc (two per factor) | 16 x VIS_RS rows of e_l | 16 scales -invp_l
     double* Em_ = Gm_ + 2 * VIS_MF * VIS_RS; double* const Em = Em_;
     double* sa_ = Em_ + 16 * VIS_RS; double* const sa = sa_;
     int* fj = (int*)(mf ? sa + 16 : red + 8);          // VIL_VCHUNK_F observer frames
-    int* lms = fj + VIL_VCHUNK_F;                      // VIL_VCHUNK_LM + 1 chunk-local factor offsets
-    int* lanc = lms + VIL_VCHUNK_LM + 1;               // VIL_VCHUNK_LM anchor frames
-    int* fl = lanc + VIL_VCHUNK_LM;                    // VIL_VCHUNK_F factor -> chunk-local landmark
+    int* lms = fj + VIL_VCHUNK_F;                      // VIS_LM + 1 chunk-local factor offsets
+    int* lanc = lms + VIS_LM + 1;                      // VIS_LM anchor frames
+    int* fl = lanc + VIS_LM;                           // VIL_VCHUNK_F factor -> chunk-local landmark
     int* fa = fl + VIL_VCHUNK_F;                       // (mf) VIS_MF anchor frames
 #ifdef VIL_STAMPS
     long long vacc[3] = {0, 0, 0}, vprev = 0;
@@ -144,7 +145,10 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
     const bool stepped = cg != 0.0 || cn != 0.0;
     if (mf) { for (int e = t; e < 3 * NV; e += blockDim.x) vbc[e] = 0.0; }      // (the tiles are carried from chunk to chunk only if there is more than one)
     else for (int e = t; e < NVT + 3 * NV; e += blockDim.x) tri[e] = 0.0;
-    if (mf) for (int e = t; e < (2 * VIS_MF + 16) * VIS_RS + 16; e += blockDim.x) Gm[e] = 0.0;
+    if (mf) {                                          // operand rows: two per factor of the largest chunk, the landmark rows and their scales
+        for (int e = t; e < ((2 * P.vis_fmax + 15) & ~15) * VIS_RS; e += blockDim.x) Gm[e] = 0.0;      // (whole batches of 16 rows are read)
+        for (int e = t; e < 16 * VIS_RS + 16; e += blockDim.x) Em[e] = 0.0;
+    }
     const bool mfree = P.marg != 0;            // marginalisation of the resident window: every block free, factors masked
     const bool exc = !mfree && P.ex_const != 0, tdc = mfree ? !P.use_td : !P.td_free;
     double cost = 0.0;
@@ -316,6 +320,12 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             if (nf > 8) mma(Gm + 16 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
             if (nf > 16) mma(Gm + 32 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
             if (nf > 24) mma(Gm + 48 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
+            if (nf > 32) {                                                     // (wide chunks: windows with more chunks of 32 factors than workgroups)
+                mma(Gm + 64 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
+                if (nf > 40) mma(Gm + 80 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
+                if (nf > 48) mma(Gm + 96 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
+                if (nf > 56) mma(Gm + 112 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
+            }
             mma(Em, std::integral_constant<int, 4>{}, std::true_type{});
             if (last) {
                 // the accumulators go into the record's layout -- the packed upper triangle -- in LDS (over the operand rows, which every wave is done

@@ -557,7 +557,6 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             P.vis_f0 = vis_f0;
         }
         std::vector<int> vch;
-        int l0 = 0;
         // a visual workgroup's time grows with the factors of its chunk (rounds of work items), the kernel's with its slowest workgroup:
         // chunks are closed at VIL_VCHUNK_FBAL factors (old landmarks carry up to K - 1 observations, new ones two), a single landmark may exceed it.
         // Every workgroup also writes one partial record of NV (NV + 1) / 2 doubles that k_reduce reads back: measured K = 10 (20 kB records)
@@ -566,20 +565,28 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         if (const char* ev = VIL_TUNE_ENV("VIL_VFBAL")) fbal = std::max(1, atoi(ev));
         P.vis_mf = (vd::vis_mfma(NV) && VIL_TUNE_ENV("VIL_NO_VMFMA") == nullptr) ? 1 : 0;
         const int fcap = P.vis_mf ? VIS_MF : VIL_VCHUNK_F;      // (matrix-core path: the operand rows of a whole chunk sit in LDS)
-        static_assert(VIL_VCHUNK_FBAL <= VIS_MF && VIL_VCHUNK_LM <= 16, "chunk bounds of the matrix-core path");
-        fbal = std::min(fbal, fcap);
-        while (l0 < L) {
-            int l1 = l0, nf = 0;
-            while (l1 < L && l1 - l0 < VIL_VCHUNK_LM && nf + (lms[l1 + 1] - lms[l1]) <= fcap && (l1 == l0 || nf + (lms[l1 + 1] - lms[l1]) <= fbal)) { nf += lms[l1 + 1] - lms[l1]; ++l1; }
-            if (l1 == l0) return VIL_ERR_UNSUPPORTED;   // a single landmark with more observations than a chunk holds
-            if (nf > 0) { vch.push_back(l0); vch.push_back(l1); vch.push_back(lms[l0]); vch.push_back(lms[l1]); }      // landmark range, factor range
-            l0 = l1;
-        }
+        static_assert(VIL_VCHUNK_FBAL <= VIS_MF && VIL_VCHUNK_LM <= VIS_LM && VIS_LM <= 16 && VIS_MF <= VIL_VCHUNK_F, "chunk bounds of the matrix-core path");
+        int vwg_max = 256;
+        if (const char* ev = VIL_TUNE_ENV("VIL_VWG")) vwg_max = std::max(1, atoi(ev));
+        auto chunks = [&](int fb, int lmcap) -> bool {
+            vch.clear(); P.vis_fmax = 1;
+            for (int l0 = 0; l0 < L;) {
+                int l1 = l0, nf = 0;
+                while (l1 < L && l1 - l0 < lmcap && nf + (lms[l1 + 1] - lms[l1]) <= fcap && (l1 == l0 || nf + (lms[l1 + 1] - lms[l1]) <= fb)) { nf += lms[l1 + 1] - lms[l1]; ++l1; }
+                if (l1 == l0) return false;   // a single landmark with more observations than a chunk holds
+                if (nf > 0) { vch.push_back(l0); vch.push_back(l1); vch.push_back(lms[l0]); vch.push_back(lms[l1]); P.vis_fmax = std::max(P.vis_fmax, nf); }      // landmark range, factor range
+                l0 = l1;
+            }
+            return true;
+        };
+        if (!chunks(std::min(fbal, fcap), VIL_VCHUNK_LM)) return VIL_ERR_UNSUPPORTED;
+        // more chunks than workgroups (configs[2]: 12 k factors): a workgroup would walk two chunks one after the other -- evaluation, operand fill and
+        // matrix-core passes twice, barriers in between; ONE chunk of up to VIS_LM landmarks / VIS_MF factors costs little more than one of 32 (a
+        // thread per factor either way, 24 instead of 12 k-steps per tile): k_sweep at configs[2] 34 -> ? us
+        if (P.vis_mf && (int)vch.size() / 4 > vwg_max && VIL_TUNE_ENV("VIL_NO_WIDE") == nullptr && !chunks(fcap, VIS_LM)) return VIL_ERR_UNSUPPORTED;
         P.n_vchunk = (int)vch.size() / 4;
         put(vch.data(), 4 * vch.size(), (void**)&P.vchunk);
         // group the sub-chunks into visual workgroups (each owns one LDS triangle / one partial record)
-        int vwg_max = 256;
-        if (const char* ev = VIL_TUNE_ENV("VIL_VWG")) vwg_max = std::max(1, atoi(ev));
         P.n_vwg = std::min(P.n_vchunk, vwg_max);
         std::vector<int> vw;
         for (int w = 0; w < P.n_vwg; ++w) {              // chunk range + the first chunk's ranges: a workgroup starts after ONE table look-up
@@ -847,7 +854,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     { const int per = VIL_SWEEP_THREADS / 256; c->n_blocks_sweep = P.n_imu + P.n_vwg + (P.n_pchunk + per - 1) / per + (P.n_echunk + per - 1) / per + 2; }
     // visual workgroups: packed triangle (windows up to K = 12: upper 16 x 16 tiles + the dense operand rows of the matrix cores), three vectors, the staged
     // factors, the landmark records
-    c->lds_sweep = sizeof(double) * (size_t)((P.vis_mf ? vd::vis_ntile(NV) * 256 + (2 * VIS_MF + 16) * VIS_RS + 16 : P.NVT) + 3 * NV + VIL_VCHUNK_F * VF_STRIDE + VIL_VCHUNK_LM * 16 + 32 + VIL_VCHUNK_F + 8 + VIL_VCHUNK_LM + 8);
+    c->lds_sweep = sizeof(double) * (size_t)((P.vis_mf ? vd::vis_ntile(NV) * 256 + (2 * VIS_MF + 16) * VIS_RS + 16 : P.NVT) + 3 * NV + (P.vis_mf ? VIS_MF : VIL_VCHUNK_F) * VF_STRIDE + VIS_LM * 16 + 32 + VIL_VCHUNK_F + 8 + VIS_LM + 8);
     if (c->lds_sweep < 8 * 2048) c->lds_sweep = 8 * 2048;
     if (c->lds_sweep > 160 * 1024) return VIL_ERR_UNSUPPORTED;
     if ((int)c->lds_sweep > c->attr_sweep[P.vis_mf]) { HIPCHK(hipFuncSetAttribute(P.vis_mf ? (const void*)k_sweep<true> : (const void*)k_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep)); c->attr_sweep[P.vis_mf] = (int)c->lds_sweep; }
