@@ -582,8 +582,9 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         if (!chunks(std::min(fbal, fcap), VIL_VCHUNK_LM)) return VIL_ERR_UNSUPPORTED;
         // more chunks than workgroups (configs[2]: 12 k factors): a workgroup would walk two chunks one after the other -- evaluation, operand fill and
         // matrix-core passes twice, barriers in between; ONE chunk of up to VIS_LM landmarks / VIS_MF factors costs little more than one of 32 (a
-        // thread per factor either way, 24 instead of 12 k-steps per tile): k_sweep at configs[2] 34 -> ? us
-        if (P.vis_mf && (int)vch.size() / 4 > vwg_max && VIL_TUNE_ENV("VIL_NO_WIDE") == nullptr && !chunks(fcap, VIS_LM)) return VIL_ERR_UNSUPPORTED;
+        // thread per factor either way, 28 instead of 20 k-steps per tile): k_sweep at configs[2] 34.4 -> 25.8 us, 8.68 k -> 9.79 k it/s on one box; forced on
+        // configs[1] (48 records instead of 96, half the gather traffic): 11.40 k -> 10.92 k it/s -- not worth it where every chunk has its own workgroup
+        if (P.vis_mf && ((int)vch.size() / 4 > vwg_max || VIL_TUNE_ENV("VIL_WIDE") != nullptr) && VIL_TUNE_ENV("VIL_NO_WIDE") == nullptr && !chunks(fcap, VIS_LM)) return VIL_ERR_UNSUPPORTED;
         P.n_vchunk = (int)vch.size() / 4;
         put(vch.data(), 4 * vch.size(), (void**)&P.vchunk);
         // group the sub-chunks into visual workgroups (each owns one LDS triangle / one partial record)
