@@ -49,14 +49,13 @@ __device__ __forceinline__ bool chol9(const double* Dk, L9& o) {
     for (int i = 0; i < 9; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j) a[(i * (i + 1) >> 1) + j] = Dk[i * 9 + j];
-    bool ok = true;
+    double rsum = 0.0;        // (a pivot that is not positive and finite makes its reciprocal root NaN or inf, and every later one with it)
 #pragma unroll
     for (int p = 0; p < 9; ++p) {
         const double dpp = a[(p * (p + 1) >> 1) + p];
-        ok = ok && dpp > 0.0 && isfinite(dpp);
-        double sq, rs;
-        sqrt_rsqrt(dpp, sq, rs);
-        o.l[(p * (p + 1) >> 1) + p] = sq; o.r[p] = rs;
+        const double rs = rsqrt_1(dpp);
+        rsum += rs;
+        o.l[(p * (p + 1) >> 1) + p] = rs; o.r[p] = rs;      // (the diagonal of L is never read: row solves, inverses and back substitutions use r)
 #pragma unroll
         for (int i = p + 1; i < 9; ++i) o.l[(i * (i + 1) >> 1) + p] = a[(i * (i + 1) >> 1) + p] * rs;
 #pragma unroll
@@ -64,7 +63,7 @@ __device__ __forceinline__ bool chol9(const double* Dk, L9& o) {
 #pragma unroll
             for (int i = j; i < 9; ++i) a[(i * (i + 1) >> 1) + j] -= o.l[(i * (i + 1) >> 1) + p] * o.l[(j * (j + 1) >> 1) + p];
     }
-    return ok;
+    return rsum < 1.7976931348623157e308;
 }
 
 #define CHAIN_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")

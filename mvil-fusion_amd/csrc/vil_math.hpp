@@ -210,6 +210,12 @@ __device__ __forceinline__ void rsqrt_sqrt(double x, double& sq, double& rs) {
     const double g = x * rs;
     sq = fma(fma(-g, g, x), 0.5 * rs, g);
 }
+// 1 / sqrt(x) alone (a factor whose diagonal nobody reads -- the solves use the reciprocal pivots): rsq seed, ONE Newton step like rsqrt_sqrt (rsqrt_nr above takes two); five instructions
+// instead of the nine of the pair above (fp64 vector instructions issue at half rate on gfx950: the pivot code is bound by their count)
+__device__ __forceinline__ double rsqrt_1(double x) {
+    const double y = __builtin_amdgcn_rsq(x), xh = 0.5 * x;
+    return fma(y, fma(-xh, y * y, 0.5), y);
+}
 // Workgroup barrier that orders LDS traffic only and leaves global loads in flight.  hipcc 7.2 lowers __syncthreads() on gfx950 to the same two
 // instructions (a workgroup lives on one CU, so its workgroup-scope fence needs no vmcnt wait -- checked on a test kernel); it is written out where a
 // prefetch RELIES on landing behind the barriers of an LDS-only phase, so that this does not hang on the toolchain's lowering of the fence.

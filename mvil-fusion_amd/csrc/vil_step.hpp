@@ -419,7 +419,7 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double
 // enters it.  ONE barrier per block step, and the panel group's chain (~2000 cycles) is the step; chol_blocked needs ~3500 (diagonal block,
 // panel, barrier, trailing update, barrier, everybody in lockstep).
 // On return rows < D hold L, row D holds y = L^-1 rhs, s.dinv[j] = 1 / L_jj.  Returns false (uniformly) on a non-positive pivot.
-template <int SLOTS = CH_SLOTS, class PTR, class PRE = NoPre>      // SLOTS: register tiles per wave (8 waves x SLOTS >= the tiles of the matrix)
+template <int SLOTS = CH_SLOTS, bool DIAG = true, class PTR, class PRE = NoPre>      // SLOTS: register tiles per wave (8 waves x SLOTS >= the tiles of the matrix); DIAG = false: the diagonal of L is not formed (the solves read s.dinv), its slots keep their old values
 __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE pre = PRE()) {
     const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
     const int R = D + 1;                 // rows including the rhs row
@@ -485,23 +485,25 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
             }
         }
         // every pivot waits for the previous reciprocal root, one multiply and one fma; everything else is formed beside the chain
-        double l00, r0_, l11, r1_, l22, r2_, l33, r3_;
-        bool ok = d00 > 0.0 && isfinite(d00);
-        rsqrt_sqrt(d00, l00, r0_);
+        // (a pivot that is not positive and finite turns its reciprocal root into NaN or inf -- rsq of a negative number, 0 x inf or inf x 0 in the Newton
+        //  step -- and that reaches every later root through l and d: ONE comparison of the four roots' sum replaces a compare + class test per pivot)
+        double l00 = 0, r0_, l11 = 0, r1_, l22 = 0, r2_, l33 = 0, r3_;
+        if constexpr (DIAG) rsqrt_sqrt(d00, l00, r0_); else r0_ = rsqrt_1(d00);
         const double l10 = d10 * r0_, l20 = d20 * r0_, l30 = d30 * r0_, x0 = a0 * r0_;
-        d11 = fma(-l10, l10, d11); ok = ok && d11 > 0.0 && isfinite(d11);
+        d11 = fma(-l10, l10, d11);
         const double t21 = fma(-l20, l10, d21), t31 = fma(-l30, l10, d31), u22 = fma(-l20, l20, d22), u33a = fma(-l30, l30, d33), v32 = fma(-l30, l20, d32);
         const double y1 = fma(-x0, l10, a1), y2a = fma(-x0, l20, a2), y3a = fma(-x0, l30, a3);
-        rsqrt_sqrt(d11, l11, r1_);
+        if constexpr (DIAG) rsqrt_sqrt(d11, l11, r1_); else r1_ = rsqrt_1(d11);
         const double l21 = t21 * r1_, l31 = t31 * r1_, x1 = y1 * r1_;
-        d22 = fma(-l21, l21, u22); ok = ok && d22 > 0.0 && isfinite(d22);
+        d22 = fma(-l21, l21, u22);
         const double t32 = fma(-l31, l21, v32), u33 = fma(-l31, l31, u33a), y2 = fma(-x1, l21, y2a), y3b = fma(-x1, l31, y3a);
-        rsqrt_sqrt(d22, l22, r2_);
+        if constexpr (DIAG) rsqrt_sqrt(d22, l22, r2_); else r2_ = rsqrt_1(d22);
         const double l32 = t32 * r2_, x2 = y2 * r2_;
-        d33 = fma(-l32, l32, u33); ok = ok && d33 > 0.0 && isfinite(d33);
+        d33 = fma(-l32, l32, u33);
         const double y3 = fma(-x2, l32, y3b);
-        rsqrt_sqrt(d33, l33, r3_);
+        if constexpr (DIAG) rsqrt_sqrt(d33, l33, r3_); else r3_ = rsqrt_1(d33);
         const double x3 = y3 * r3_;
+        const bool ok = (r0_ + r1_) + (r2_ + r3_) < 1.7976931348623157e308;      // false for NaN and for +inf
         // (a non-positive pivot: identical data in every thread of the group; what is stored below is not read -- everyone leaves after the barrier)
         // (a thread without a row stores into the padding doubles of tile (0, 0) -- element 16 of a tile row, never read -- instead of branching: a
         //  conditional store would let the compiler sink this row's loads, update and substitution behind the pivot chain, into the branch)
@@ -509,10 +511,11 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
         else if (row) { A[base] = x0; if (nb > 1) A[base + 1] = x1; if (nb > 2) A[base + 2] = x2; if (nb > 3) A[base + 3] = x3; }
         if (tp == 0) {                                       // the factored block itself and the reciprocal pivots
             if (!ok) s.cok = 0;
-            A[db] = l00; s.dinv[kb] = r0_;
-            if (nb > 1) { A[db + TILE_RS] = l10; A[db + TILE_RS + 1] = l11; s.dinv[kb + 1] = r1_; }
-            if (nb > 2) { A[db + 2 * TILE_RS] = l20; A[db + 2 * TILE_RS + 1] = l21; A[db + 2 * TILE_RS + 2] = l22; s.dinv[kb + 2] = r2_; }
-            if (nb > 3) { A[db + 3 * TILE_RS] = l30; A[db + 3 * TILE_RS + 1] = l31; A[db + 3 * TILE_RS + 2] = l32; A[db + 3 * TILE_RS + 3] = l33; s.dinv[kb + 3] = r3_; }
+            s.dinv[kb] = r0_;
+            if (nb > 1) { A[db + TILE_RS] = l10; s.dinv[kb + 1] = r1_; }
+            if (nb > 2) { A[db + 2 * TILE_RS] = l20; A[db + 2 * TILE_RS + 1] = l21; s.dinv[kb + 2] = r2_; }
+            if (nb > 3) { A[db + 3 * TILE_RS] = l30; A[db + 3 * TILE_RS + 1] = l31; A[db + 3 * TILE_RS + 2] = l32; s.dinv[kb + 3] = r3_; }
+            if constexpr (DIAG) { A[db] = l00; if (nb > 1) A[db + TILE_RS + 1] = l11; if (nb > 2) A[db + 2 * TILE_RS + 2] = l22; if (nb > 3) A[db + 3 * TILE_RS + 3] = l33; }
         }
     };
     // tile column 0 to LDS (tile column 1 as well when the matrix has fewer than three blocks in column 0 -- never: a tile column has four), block 0
@@ -754,7 +757,7 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
             Creg[u] = c4;
         }
     };
-    if (!chol_lookahead(Tl, NP, s, schur)) return false;
+    if (!chol_lookahead<CH_SLOTS, false>(Tl, NP, s, schur)) return false;
     SSTAMP(4);
     back_subst(Tl, NP, s);                             // x_p in s.y[0 .. NP)
     pub();                                             // the landmark workgroups can start: they only need the pose part
@@ -862,8 +865,8 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
 #pragma unroll
         for (int q = 0; q < 24; ++q) wv[q] = ld_ag(Wt + (size_t)jc * RS + min(part + q * G, NP - 1));
         wrhs = ld_ag(Wt + (size_t)jc * RS + NP);
-        if (!chol_lookahead<3>(Tl, NP, s)) return false;
-    } else if (!chol_lookahead(Tl, NP, s)) return false;
+        if (!chol_lookahead<3, false>(Tl, NP, s)) return false;
+    } else if (!chol_lookahead<CH_SLOTS, false>(Tl, NP, s)) return false;
     SSTAMP(4);
     back_subst(Tl, NP, s);
     pub();
@@ -1344,7 +1347,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             if (t < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); wait_helpers(); store_ctl(); }
             return;
         }
-        if constexpr (CHAIN == 0) { if constexpr (LDSM) ok = chol_lookahead(Alds, D, s); else ok = chol_blocked<false>(P.M, D, s, Alds); }      // Alds = staging of the active tile column
+        if constexpr (CHAIN == 0) { if constexpr (LDSM) ok = chol_lookahead<CH_SLOTS, false>(Alds, D, s); else ok = chol_blocked<false>(P.M, D, s, Alds); }      // Alds = staging of the active tile column
         STAMP(3);
 #ifdef VIL_STAMPS
         if (t == 0) { P.dbg[20] = s.tacc[0]; P.dbg[21] = s.tacc[1]; P.dbg[22] = s.tacc[2]; P.dbg[24] = s.tacc[3]; P.dbg[25] = s.tacc[4]; P.dbg[26] = s.tacc[5]; }
