@@ -148,7 +148,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     __syncthreads();
     if (t == 0) st_ag(P.chflag, epoch);                  // ... W^T is complete: the tile workgroups start
     // ---- off the critical path (the master needs these for the chain back substitution, 30 us from now): the INVERSES of the factored
-    //      diagonal blocks (one column per lane: x = L^-1 e_c by forward substitution) and the sub-diagonal blocks
+    //      diagonal blocks (one column per lane: x = L^-1 e_c by forward substitution) and the products M_k = L_kk^-T Ls_k^T with the sub-diagonal blocks
     for (int it = t; it < 9 * K; it += NT) {
         const int k = it / 9, cc = it - 9 * k;
         const double* l = L.Ldg + 54 * k; const double* r = l + 45;
@@ -162,8 +162,17 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
         }
 #pragma unroll
         for (int p = 0; p < 9; ++p) if (p >= cc) st_ag(P.chLdg + 54 * k + (p * (p + 1) >> 1) + cc, x[p]);
+        // row cc of M_k = L_kk^-T Ls_k^T (this lane holds column cc of the inverse): the master's recursion is x_k = L_kk^-T t_k - M_k x_next, ONE nine-term
+        // product per block instead of two with an LDS round trip in between.  (The middle block has no Ls: its row is never read.)
+        const double* ls = L.Lsb + 82 * k;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int p = 0; p < 9; ++p) { if (p & 1) a1 += x[p] * ls[i * 9 + p]; else a0 += x[p] * ls[i * 9 + p]; }
+            st_ag(P.chLsb + 82 * k + 9 * cc + i, k == (K >> 1) ? 0.0 : a0 + a1);
+        }
     }
-    for (int e = t; e < 82 * K; e += NT) st_ag(P.chLsb + e, L.Lsb[e]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) st_ag(P.chflag + 2, epoch);

@@ -900,29 +900,50 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
         if (j < NB && part == 0) tB[j] = wrhs - acc;
     }
     __syncthreads();
-    // x_k = L_kk^-T (t_k - Ls_k^T x_next) with the INVERSE of L_kk the chain workgroup left (Ldg here holds L^-1, 45 entries per block): two
-    // nine-term dot products per block on nine lanes instead of a 45-step substitution of one lane
-    auto block_back = [&](const double* Li, const double* Ls, double* tk, const double* xn, double* xo) {
-        const int lane = t & 63;
-        if (lane < 9 && Ls) {
-            double v = tk[lane];
+    // x_k = L_kk^-T (t_k - Ls_k^T x_next) = c_k - M_k x_next with what the chain workgroup left: the INVERSE of L_kk (Ldg here holds L^-1, 45 entries per block)
+    // and M_k = L_kk^-T Ls_k^T (Lsb here, row r at 9 r).  c_k for every block at once -- thread 9 k + r, a nine-term product -- into s.y; then the two
+    // directions walk away from the middle block (x_m = c_m) on one wave each: lane r holds component r of the block solved before, the nine components
+    // reach every lane as scalars (v_readlane), row r of the next M_k and c_k are requested a block ahead -- no LDS round trip on the recursion
+    if (t < NB) {
+        const int k = t / 9, r = t - 9 * k;
+        const double* Li = Ldg + 54 * k; const double* tk = tB + 9 * k;
+        double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) v -= Ls[i * 9 + lane] * xn[i];
-            tk[lane] = v;
-        }
-        CHAIN_FENCE();
-        if (lane < 9) {
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) { const double li = i >= lane ? Li[(i * (i + 1) >> 1) + lane] : 0.0; if (i & 1) a1 += li * tk[i]; else a0 += li * tk[i]; }
-            xo[lane] = a0 + a1;
-        }
-        CHAIN_FENCE();
-    };
-    if (t < 64) block_back(Ldg + 54 * m, nullptr, tB + 9 * m, nullptr, s.y + NP + 9 * m);
+        for (int i = 0; i < 9; ++i) { const double li = i >= r ? Li[(i * (i + 1) >> 1) + r] : 0.0; if (i & 1) a1 += li * tk[i]; else a0 += li * tk[i]; }
+        s.y[NP + t] = a0 + a1;
+    }
     __syncthreads();
-    if (t < 64) { for (int k = m - 1; k >= 0; --k) block_back(Ldg + 54 * k, Lsb + 82 * k, tB + 9 * k, s.y + NP + 9 * (k + 1), s.y + NP + 9 * k); }
-    else if (t < 128) { for (int k = m + 1; k < K; ++k) block_back(Ldg + 54 * k, Lsb + 82 * k, tB + 9 * k, s.y + NP + 9 * (k - 1), s.y + NP + 9 * k); }
+    if (t < 128) {
+        const int dir = t >> 6, lane = t & 63, r = min(lane, 8), stp = dir == 0 ? -1 : 1, kend = dir == 0 ? -1 : K;
+        double xn = s.y[NP + 9 * m + r];
+        int k = m + stp;
+        double mrow[9], c = 0.0;
+        auto fetch = [&](int kk, double* mr, double& cc) {
+            const double* Mk = Lsb + 82 * kk + 9 * r;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) mr[i] = Mk[i];
+            cc = s.y[NP + 9 * kk + r];
+        };
+        if (k != kend) fetch(k, mrow, c);
+        for (; k != kend; k += stp) {
+            double mnext[9], cnext = 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) mnext[i] = 0.0;
+            if (k + stp != kend) fetch(k + stp, mnext, cnext);
+            const int xlo = __double2loint(xn), xhi = __double2hiint(xn);
+            double a0 = c, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const double xi = __hiloint2double(__builtin_amdgcn_readlane(xhi, i), __builtin_amdgcn_readlane(xlo, i));
+                if (i % 3 == 0) a0 = fma(-mrow[i], xi, a0); else if (i % 3 == 1) a1 = fma(-mrow[i], xi, a1); else a2 = fma(-mrow[i], xi, a2);
+            }
+            xn = a0 + (a1 + a2);
+            if (lane < 9) s.y[NP + 9 * k + lane] = xn;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) mrow[i] = mnext[i];
+            c = cnext;
+        }
+    }
     else if (t >= VIL_STEP_THREADS - 64) side();
     __syncthreads();
     SSTAMP(6);
