@@ -109,8 +109,8 @@ struct DevP {
     int vis_mf;      // visual workgroups: block outer products on the matrix cores (windows up to K = 12, vil_sweep.hpp)
     int vis_fmax;    // factors of the largest visual chunk
     int n_help; double* hpart; int* hflag;
-    // second landmark pass of the helpers (k_step): the master posts the epoch in xflag (Sc x_p is in stepc) or in xstat (no step
-    // this launch); every helper WAVE then leaves its six sums in hpart2[8 * slot ..] and the epoch in hflag2[slot], slot = 8 k + wave
+    // second landmark pass of the helpers (k_step): the master leaves Sc x_p in stepc as 64-bit words {half of a value, launch epoch} -- or
+    // the epoch in xstat (no step this launch); every helper then leaves its six sums the same way in hpart2[16 * slot ..] (xflag / hflag2: unused)
     double* hpart2; int* hflag2; int* xflag; int* xstat;
     double* la; double* lb;        // L each: step directions of the inverse depths (Cauchy, Gauss-Newton), written by the step kernel's landmark pass
     // structure-exploiting solve (vil_chain.hpp): 0 dense, 1 chain with W^T in LDS, 2 chain with W^T in global memory (P.M)

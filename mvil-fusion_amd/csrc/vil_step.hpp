@@ -1040,6 +1040,10 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     auto post = [&](int* f) { if (t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } };
     auto wait1 = [&](int* f) { while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1); };
     auto put = [&](double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // flag-in-data words: 32 bits of payload + the launch epoch in ONE 64-bit store / load (single-copy atomic); epochs never repeat, so a word of
+    // this epoch is this launch's value whatever the buffer held before
+    auto put_ll = [&](unsigned long long* p, int half) { __hip_atomic_store(p, ((unsigned long long)(unsigned)epoch << 32) | (unsigned)half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto ld_ll = [&](const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     // wave 0 (all 64 lanes call it): Ctl back to device memory, one coalesced store per lane and round instead of a lone lane's 190.  (The host's
     // copy is written by solve_finish, vil_finish.hpp: the next sweep launch finds the solve finished and leaves Ctl + the final state there.)
     auto store_ctl = [&]() {
@@ -1124,11 +1128,13 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     };
     // helper side of the second pass: poll "published" and "given up" together (one round trip), then every wave posts its own
     // sums -- the master's gathering wave adds the <= 8 nhelp slots with a fixed tree, no block reduction on the critical path
-    auto wait_x = [&]() {
-        if (t == 0) {
+    auto wait_x = [&](double* dst) {           // dst[0 .. NV) = Sc x_p as soon as its words carry this launch's epoch; s.ok (1 on entry) = 0 if the master gave up
+        for (int w = t; w < 2 * P.NV; w += NT) {
+            const unsigned long long* p = (const unsigned long long*)P.stepc + w;
             for (;;) {
-                const int a = __hip_atomic_load(P.xflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(P.xstat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a == epoch) { s.ok = 1; break; }
+                const unsigned long long v = ld_ll(p);
+                const int b = __hip_atomic_load(P.xstat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(v >> 32) == (unsigned)epoch) { ((unsigned*)dst)[w] = (unsigned)v; break; }
                 if (b == epoch) { s.ok = 0; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -1138,8 +1144,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     auto post_wave2 = [&](double* sm) {
         bsum6(sm, s);
         const int slot = bid - 1;
-        if (t == 0) { double* hp = P.hpart2 + 8 * slot; for (int e = 0; e < 6; ++e) put(hp + e, sm[e]); }
-        post(P.hflag2 + slot);
+        if (t == 0) { unsigned long long* hp = (unsigned long long*)P.hpart2 + 16 * slot; for (int e = 0; e < 6; ++e) { put_ll(hp + 2 * e, __double2loint(sm[e])); put_ll(hp + 2 * e + 1, __double2hiint(sm[e])); } }
     };
     // master side: one wave gathers the helper waves' sums (h[0..6)) and, when with1, the first pass's three numbers (h[6..9))
     auto gather2 = [&](double* h, bool with1) {
@@ -1147,9 +1152,20 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         for (int e = 0; e < 9; ++e) h[e] = 0.0;
         for (int s0 = 0; s0 < nhelp; s0 += 64) {
             const int slot = s0 + ln;
-            if (slot < nhelp) {
-                wait1(P.hflag2 + slot);
-                for (int e = 0; e < 6; ++e) h[e] += __hip_atomic_load(P.hpart2 + 8 * slot + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (slot < nhelp) {                    // the six sums of a helper: twelve words of this epoch, all requested together
+                const unsigned long long* hp = (const unsigned long long*)P.hpart2 + 16 * slot;
+                unsigned long long w[12];
+                for (;;) {
+                    bool all = true;
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) w[e] = ld_ll(hp + e);
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) all = all && (unsigned)(w[e] >> 32) == (unsigned)epoch;
+                    if (all) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int e = 0; e < 6; ++e) h[e] += __hiloint2double((int)(unsigned)w[2 * e + 1], (int)(unsigned)w[2 * e]);
             }
         }
         if (with1 && ln < nhelp) for (int e = 0; e < 3; ++e) h[6 + e] = __hip_atomic_load(P.hpart + 4 * ln + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1196,10 +1212,8 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                 bsum3<true>(g2, q, gm, s);
                 if (t == 0) { double* hp = P.hpart + 4 * hk; put(hp, q); put(hp + 1, g2); put(hp + 2, gm); }
                 post(P.hflag + hk);
-                wait_x();
+                wait_x(s.gn);
                 if (s.ok) {
-                    for (int i = t; i < P.NV; i += NT) s.gn[i] = __hip_atomic_load(P.stepc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __syncthreads();
                     double sm[6] = {0, 0, 0, 0, 0, 0};
                     double b_ = 0.0;
                     if (have) {
@@ -1222,10 +1236,8 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             if (t == 0) { double* hp = P.hpart + 4 * hk; put(hp, q); put(hp + 1, g2); put(hp + 2, gm); }
             post(P.hflag + hk);
             // second pass once the master has the pose part of the solution
-            wait_x();
+            wait_x(s.y);
             if (s.ok) {
-                for (int i = t; i < P.NV; i += NT) s.y[i] = __hip_atomic_load(P.stepc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
                 double sm[6] = {0, 0, 0, 0, 0, 0};
                 lm_pass2(l0, l1, s.y, sm);
                 post_wave2(sm);
@@ -1239,9 +1251,10 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     bool xpub = false;                                 // the master owes the waiting helpers an xflag on every path through the need branch
     auto publish_xp = [&](int okk) {                   // called by all threads; s.y[0 .. NV) = x_p when okk
         if (nhelp) {
-            if (okk) { for (int i = t; i < P.NV; i += NT) put(P.stepc + i, s.sc[i] * s.y[i]); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // (__syncthreads does not wait for global stores)
-            __syncthreads();
-            post(okk ? P.xflag : P.xstat);
+            // Sc x_p goes out as 64-bit words {half of a value, launch epoch}: a helper that reads a word of this epoch has the value -- no flag
+            // behind the data, no wait for the stores, and on the other side ONE round trip instead of a poll followed by the loads
+            if (okk) { for (int w = t; w < 2 * P.NV; w += NT) { const double v = s.sc[w >> 1] * s.y[w >> 1]; put_ll((unsigned long long*)P.stepc + w, (w & 1) ? __double2hiint(v) : __double2loint(v)); } }
+            else { __syncthreads(); post(P.xstat); }
         }
         xpub = true;
     };
@@ -1387,7 +1400,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             if (t < 64) { wait_helpers(); store_ctl(); }      // (a late helper may still be copying Ctl into its LDS)
             return;
         }
-        if constexpr (CHAIN == 0) { if constexpr (LDSM) back_subst(Alds, D, s); else back_subst(P.M, D, s); publish_xp(1); }
+        if constexpr (CHAIN == 0) { if constexpr (LDSM) back_subst(Alds, D, s); else back_subst(P.M, D, s); publish_xp(1); __syncthreads(); }      // (the publishing threads read s.y across the thread map of the loop below)
         STAMP(4);
 #ifdef VIL_STAMPS
         if (t == 0) P.dbg[23] = s.tacc[0];

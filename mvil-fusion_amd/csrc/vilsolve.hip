@@ -714,7 +714,8 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     c->split = c->sharded || c->force_split;
     put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.Sl); put(nullptr, 8 * (size_t)D, (void**)&P.Sc); put(nullptr, 8 * (size_t)D, (void**)&P.dc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.dl);
     put(nullptr, 8 * (size_t)D, (void**)&P.gradc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gradl); put(nullptr, 8 * (size_t)D, (void**)&P.gnc); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.gnl);
-    { const size_t Tm = (size_t)(D + 16) / 16; put(nullptr, 8 * std::max((size_t)D * D, (size_t)TILE_SZ * (Tm * (Tm + 1) / 2)), (void**)&P.M); } put(nullptr, 8 * (size_t)D, (void**)&P.stepc); put(nullptr, 8 * 4 * 16, (void**)&P.hpart); put(nullptr, 4 * 16, (void**)&P.hflag);
+    { const size_t Tm = (size_t)(D + 16) / 16; put(nullptr, 8 * std::max((size_t)D * D, (size_t)TILE_SZ * (Tm * (Tm + 1) / 2)), (void**)&P.M); } put(nullptr, 16 * (size_t)D, (void**)&P.stepc);      // (two 64-bit words per value: half + launch epoch)
+    put(nullptr, 8 * 4 * 16, (void**)&P.hpart); put(nullptr, 4 * 16, (void**)&P.hflag);
     put(nullptr, 8 * 8 * 16 * 8, (void**)&P.hpart2); put(nullptr, 4 * 16 * 8, (void**)&P.hflag2);      // one slot per helper WAVE
     put(nullptr, 16, (void**)&P.xflag); put(nullptr, 16, (void**)&P.xstat);
     put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.la); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.lb); put(nullptr, 8 * (size_t)std::max(L, 1), (void**)&P.stepl);
