@@ -1303,12 +1303,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         if constexpr (CHAIN != 0) {
             __syncthreads();
             auto pub = [&]() { publish_xp(1); };
-            auto side = [&]() {            // last wave: the helpers' sums of both passes (hflag2 is posted after hflag) -> s.hs
-                if (!nhelp) return;
-                double h[9];
-                gather2(h, true);
-                if ((t & 63) == 63) for (int e = 0; e < 9; ++e) s.hs[e] = h[e];
-            };
+            auto side = [&]() {};          // (the helpers' sums are collected after the step vectors below: their round trip outlasts the chain walks)
             if constexpr (CHAIN == 3) ok = solve_prechain(P, sb, s, Alds, mu, cam, q, pub, side);
             else ok = solve_chain<CHAIN == 1>(P, sb, s, Alds, mu, cam, q, pub, side);      // packing, chain, Schur update, dense part, back substitution
         } else {
@@ -1414,6 +1409,9 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             s.y[i] = s.sc[i] * xi;     // Sc x_c for the landmark back-substitution
         }
         __syncthreads();
+        // chain path with helpers: the last wave collects the helpers' sums of both passes (-> s.hs) HERE -- the helpers received x_p before the chain back
+        // substitution and answer ~5 us later, the master's chain walks take half of that: the step vectors above no longer wait for the answer
+        if (defer && t >= NT - 64) { double h[9]; gather2(h, true); if ((t & 63) == 63) for (int e = 0; e < 9; ++e) s.hs[e] = h[e]; }
         double sm[6] = {0, 0, 0, 0, 0, 0};
         if (!nhelp) lm_pass2(0, L, s.y, sm);
         sm[0] += gn2; sm[1] += gg;
