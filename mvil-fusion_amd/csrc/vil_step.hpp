@@ -569,7 +569,7 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
 
 // back substitution L^T x = y (y = row D of A) with 16 x 16 diagonal blocks: 10 dependent stages instead of 40.
 //   (I)  W_t = L_tt^-1 for every diagonal tile at once (one thread per tile column, 16-step forward substitution in
-//        registers); W_t is stored TRANSPOSED into the unused upper triangle of its tile, its diagonal is s.dinv.
+//        registers); then W_t^T REPLACES the diagonal tile (nothing reads L_tt after this): row j = zeros, 1 / L_jj, W_ij (i > j).
 //   (II) from the last tile up: x_blk = W^T y_blk (16 lanes, one short dot product each), barrier, the threads owning a
 //        column c < kb fold x_blk into y_c (16-term dot product down a tile column), barrier.
 // Result in s.y[0..D).
@@ -580,25 +580,31 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
     const int TD = (D + 15) >> 4;                           // diagonal tiles that hold rows of L
     for (int i = D + t; i < (TD << 4); i += NT) { s.xs[i] = 0.0; s.y[i] = 0.0; }   // padding of the last tile: its products vanish
     // ---- (I) ----------------------------------------------------------------------------------------------------
-    for (int q = t; q < (TD << 4); q += NT) {
-        const int tt = q >> 4, j = q & 15;
-        const int n_t = min(16, D - (tt << 4));
-        if (j < n_t) {
-            const int tb = tl_base(tt, tt);
-            const double* dv = s.dinv + (tt << 4);
-            double w[16];
+    // (one round: at most 20 diagonal tiles = 320 columns on 512 threads.  The whole diagonal tile is overwritten with W^T -- row j: zeros, 1 / L_jj,
+    //  W_ij for i > j -- once every thread has read its column of L_tt: nothing reads L_tt after this, and stage (II) gets a plain 16-term product
+    //  per lane instead of a masked one with a select chain for the diagonal)
+    {
+        const int q = t, tt = q >> 4, j = q & 15;
+        const bool mine = q < (TD << 4);
+        const int ttc = mine ? tt : 0;
+        const int n_t = min(16, D - (ttc << 4));
+        const int tb = tl_base(ttc, ttc);
+        const double* dv = s.dinv + (ttc << 4);
+        double w[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double acc0 = 0.0, acc1 = 0.0;
+        for (int i = 0; i < 16; ++i) {
+            double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-                for (int k = 0; k < i; ++k) {                  // w_k = 0 for k < j: the products vanish, no predicate needed
-                    const double l = A[tb + i * TILE_RS + k];
-                    if (k & 1) acc1 += l * w[k]; else acc0 += l * w[k];
-                }
-                w[i] = i < j ? 0.0 : (i == j ? dv[i] : (i < n_t ? -(acc0 + acc1) * dv[i] : 0.0));
+            for (int k = 0; k < i; ++k) {                  // w_k = 0 for k < j: the products vanish, no predicate needed
+                const double l = A[tb + i * TILE_RS + k];
+                if (k & 1) acc1 += l * w[k]; else acc0 += l * w[k];
             }
+            w[i] = (i < j || i >= n_t || j >= n_t) ? 0.0 : (i == j ? dv[i] : -(acc0 + acc1) * dv[i]);
+        }
+        lds_barrier();
+        if (mine) {
 #pragma unroll
-            for (int i = 1; i < 16; ++i) if (i > j && i < n_t) A[tb + j * TILE_RS + i] = w[i];      // W_ij at (j, i)
+            for (int i = 0; i < 16; ++i) A[tb + j * TILE_RS + i] = w[i];      // W_ij at (j, i)
         }
     }
     lds_barrier();
@@ -609,28 +615,15 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
     for (int blk = TD - 1; blk >= 0; --blk) {
         const int kb = blk << 4, n_b = min(16, D - kb);
         if (t < 64) {                                         // wave 0 (scalar branch); lanes 16..63 mirror lanes 0..15 and do not store
-            // all reads first, unconditionally (addresses stay inside the tile / s.y); the triangular mask is folded in as a
-            // 0/1 factor so that the loop stays straight-line code
             const int tt = t & 15;
             const int tb = tl_base(blk, blk) + tt * TILE_RS;
-            double av[16], yv[16];
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { av[i] = A[tb + i]; yv[i] = s.y[kb + i]; }
-            const double dv = s.dinv[kb + tt];
-            double a0 = dv * yv[0], a1 = 0.0, a2 = 0.0, a3 = 0.0;        // placeholder for lane 0; fixed below
-            a0 = 0.0;
-#pragma unroll
-            for (int i = 1; i < 16; ++i) {
-                const double msk = (double)(int)((i > tt) & (i < n_b));
-                const double p = msk * av[i] * yv[i];
-                if ((i & 3) == 0) a0 += p; else if ((i & 3) == 1) a1 += p; else if ((i & 3) == 2) a2 += p; else a3 += p;
+            for (int i = 0; i < 16; i += 4) {                  // row tt of W^T (zeros left of the diagonal and beyond the matrix) times y_blk
+                a0 = fma(A[tb + i], s.y[kb + i], a0); a1 = fma(A[tb + i + 1], s.y[kb + i + 1], a1);
+                a2 = fma(A[tb + i + 2], s.y[kb + i + 2], a2); a3 = fma(A[tb + i + 3], s.y[kb + i + 3], a3);
             }
-            // diagonal term: y[kb + tt] by shuffle-free select over the already loaded yv
-            double yd = yv[0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) yd = (i == tt) ? yv[i] : yd;
-            const double x = dv * yd + ((a0 + a1) + (a2 + a3));
-            if (t < n_b) s.xs[kb + t] = x;
+            if (t < n_b) s.xs[kb + t] = (a0 + a1) + (a2 + a3);
         }
         lds_barrier();
         for (int c = t; c < kb; c += NT) {                  // y_c -= sum_r L[kb+r][c] x_r
