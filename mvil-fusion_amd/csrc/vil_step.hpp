@@ -578,7 +578,7 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
     const int t = threadIdx.x, NT = blockDim.x;
     for (int i = t; i < D; i += NT) s.y[i] = A[tl_idx(D, i)];
     const int TD = (D + 15) >> 4;                           // diagonal tiles that hold rows of L
-    for (int i = D + t; i < (TD << 4); i += NT) { s.xs[i] = 0.0; s.y[i] = 0.0; }   // padding of the last tile: its products vanish
+    for (int i = D + t; i < (TD << 4); i += NT) s.y[i] = 0.0;                        // padding of the last tile: its products vanish
     // ---- (I) ----------------------------------------------------------------------------------------------------
     // (one round: at most 20 diagonal tiles = 320 columns on 512 threads.  The whole diagonal tile is overwritten with W^T -- row j: zeros, 1 / L_jj,
     //  W_ij for i > j -- once every thread has read its column of L_tt: nothing reads L_tt after this, and stage (II) gets a plain 16-term product
@@ -623,25 +623,23 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
                 a0 = fma(A[tb + i], s.y[kb + i], a0); a1 = fma(A[tb + i + 1], s.y[kb + i + 1], a1);
                 a2 = fma(A[tb + i + 2], s.y[kb + i + 2], a2); a3 = fma(A[tb + i + 3], s.y[kb + i + 3], a3);
             }
-            if (t < n_b) s.xs[kb + t] = (a0 + a1) + (a2 + a3);
+            if (t < n_b) s.y[kb + t] = (a0 + a1) + (a2 + a3);      // x over y_blk, which only this wave reads and has read (its LDS operations execute in order)
         }
         lds_barrier();
         for (int c = t; c < kb; c += NT) {                  // y_c -= sum_r L[kb+r][c] x_r
             const int base = tl_base(blk, c >> 4) + (c & 15);
             double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
 #pragma unroll
-            for (int r = 0; r < 16; r += 4) {                  // rows >= n_b of the last tile: xs is zero there (see below)
-                v0 += A[base + r * TILE_RS] * s.xs[kb + r];
-                v1 += A[base + (r + 1) * TILE_RS] * s.xs[kb + r + 1];
-                v2 += A[base + (r + 2) * TILE_RS] * s.xs[kb + r + 2];
-                v3 += A[base + (r + 3) * TILE_RS] * s.xs[kb + r + 3];
+            for (int r = 0; r < 16; r += 4) {                  // rows >= n_b of the last tile: y is zero there (padding above)
+                v0 += A[base + r * TILE_RS] * s.y[kb + r];
+                v1 += A[base + (r + 1) * TILE_RS] * s.y[kb + r + 1];
+                v2 += A[base + (r + 2) * TILE_RS] * s.y[kb + r + 2];
+                v3 += A[base + (r + 3) * TILE_RS] * s.y[kb + r + 3];
             }
             s.y[c] -= (v0 + v1) + (v2 + v3);
         }
         lds_barrier();
     }
-    for (int i = t; i < D; i += NT) s.y[i] = s.xs[i];
-    lds_barrier();
 }
 
 // ---- chain path (vil_chain.hpp): pack the pose part, eliminate the speed-bias chain from both ends, Schur-update the pose
