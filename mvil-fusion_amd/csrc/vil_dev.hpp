@@ -6,9 +6,7 @@
 
 #define VIL_THREADS 256       // eval / reduce kernels, LiDAR chunk size
 #define VIL_SWEEP_THREADS 512 // sweep workgroups: 8 waves = 2 per SIMD for LDS-latency hiding
-#define VIL_VCHUNK_LM 12      // landmarks per visual sub-chunk (matrix-core path, wide chunks: VIS_LM = 16, vil_sweep.hpp)
-#define VIL_VCHUNK_F 128      // factors per visual workgroup (LDS staging bound)
-#define VIL_VCHUNK_FBAL 32    // factors at which a chunk is closed when the partial records are small (balance between the visual workgroups)
+#define VIL_VCHUNK_FBAL 32    // factors below which a visual chunk is not closed for balance (vilsolve.hip: visual_chunks; its bounds: VIS_MF, VIS_LM, VIS_GM in vil_sweep.hpp)
 #define VIL_STEP_THREADS 512
 
 struct SysBuf {       // one linearisation of the window (double-buffered: current / candidate)
@@ -54,10 +52,9 @@ struct DevP {
     // state double buffer: [pose 7K | sb 9K | ex 7 | td 1 | lam L]
     double* x[2];
     // visual (SoA: component k of factor f at vis_c[k*vis_stride + f])
-    int n_vis, vis_stride, n_vchunk;
+    int n_vis, vis_stride;
     const double* vis_c; const int* vis_i; const int* vis_j; const int* vis_l;
     const int* lm_start;      // L+1
-    const int* vchunk;        // n_vchunk x 4: landmark range, factor range
     const int* lm_acol;       // L   reduced column of the anchor pose (6 * start_frame), -1 if the landmark has no factor
     const int* fcol;          // F   reduced column of the observing pose of each factor (6 * vis_j)
     // the same three tables over the WHOLE window and the offset of this rank's first visual factor in it: with the factor set
@@ -79,9 +76,13 @@ struct DevP {
     // linear system + solver work space
     SysBuf sys[2];
     // per-workgroup partial results of the sweep (no global atomics); gathered by k_reduce
-    int n_vwg, NVT, VP;           // visual workgroups; NV(NV+1)/2; doubles per visual partial = NVT + 3 NV + 1
-    const int* vwg;               // n_vwg x 8: {first sub-chunk, end, -, -} and the first sub-chunk's {l0, l1, f0, f1}
-    double* vpart;                // n_vwg x VP  [tri(S') | bc | gred | diag | cost]
+    // visual workgroups = chunks of the landmark list sorted by (first frame, last frame) (vil_sweep.hpp: sweep_visual; vilsolve.hip: visual_chunks)
+    int n_vwg, vis_ts;            // chunks; accumulator tiles per wave the widest chunk needs (k_sweep<vis_ts>: 2 or 5)
+    const int* vwg;               // n_vwg x 8: {first sorted landmark, landmarks, first sorted factor, factors} {first frame, frames, column tiles T, record offset / 16}
+    const int* vlm;               // sorted landmarks x 4: {landmark, chunk-local first factor, factors, anchor frame}
+    const int* vfac;              // sorted factors x 2: {factor, chunk-local landmark}
+    const int* vrec;              // n_vwg x 4: {record offset / 16, first frame, frames, T} (what the gather needs of vwg)
+    double* vpart;                // the records: per chunk T (T + 1) / 2 upper 16 x 16 tiles of its window | bc 16 T | diag 16 T | cost (+ padding to 16)
     double* lpart;                // (n_pchunk + n_echunk) x 28  [21 upper 6x6 | 6 g | cost]
     const int* lchunk_pose;       // 2 x (K+1): chunk ranges per pose (plane, edge)
     double* ipart;                // n_imu x 931  [30x30 H | 30 g | cost]
@@ -106,8 +107,6 @@ struct DevP {
     const double* xorig;          // the state the solve started from (the gauge fix re-anchors on its frame 0)
     int gauge_on;                 // double2vector()'s yaw / translation gauge fix as part of solve_finish
     const int* setup_stat;        // != 0: k_setup found an IMU covariance that is not positive definite -- the first step kernel ends the solve with it
-    int vis_mf;      // visual workgroups: block outer products on the matrix cores (windows up to K = 12, vil_sweep.hpp)
-    int vis_fmax;    // factors of the largest visual chunk
     int n_help; double* hpart; int* hflag;
     // second landmark pass of the helpers (k_step): the master leaves Sc x_p in stepc as 64-bit words {half of a value, launch epoch} -- or
     // the epoch in xstat (no step this launch); every helper then leaves its six sums the same way in hpart2[16 * slot ..] (xflag / hflag2: unused)

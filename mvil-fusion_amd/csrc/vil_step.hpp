@@ -1014,8 +1014,8 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         __syncthreads();
     };
     if (merged && bid >= b_gather) {
-        if (P.rs_merged == 2) reduce_gather<true, VIL_STEP_THREADS / 8>(P, s.c, bid - b_gather);      // 64 entries, all 512 threads
-        else { if (t >= VIL_THREADS) return; reduce_gather<true, RED_EPW>(P, s.c, bid - b_gather); }   // 32 entries on the first four waves
+        if (P.rs_merged == 2) reduce_gather<true, VIL_STEP_THREADS / 8>(P, s.c, bid - b_gather, (int4*)Alds);      // 64 entries, all 512 threads
+        else { if (t >= VIL_THREADS) return; reduce_gather<true, RED_EPW>(P, s.c, bid - b_gather, (int4*)Alds); }      // (descriptor table in the dynamic LDS this role does not use otherwise)   // 32 entries on the first four waves
         rs_signal(P.gflag + (bid - b_gather)); return;
     }
     if (merged && bid >= b_ww) {

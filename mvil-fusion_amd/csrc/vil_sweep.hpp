@@ -7,10 +7,9 @@
 // Work-group roles by blockIdx (workgroups of VIL_SWEEP_THREADS = 512 threads):
 //   [imu]     one WG per IMU factor: lane 0 forms the raw 15x30 block, the WG whitens with the
 //             pre-factored sqrt-information and contracts to a 30x30 H block
-//   [visual]  one WG per group of landmark sub-chunks (<= VIL_VCHUNK_LM landmarks / VIL_VCHUNK_F factors each):
-//             thread-per-factor evaluation staged in LDS, 16 lanes per landmark for the Schur pivots, then three uniform
-//             passes of block outer products (shared x shared, shared x observer, observer x observer) accumulated
-//             with ds_add_f64 into an LDS-resident packed triangle of the (6K+7)^2 visual sub-space
+//   [visual]  one WG per chunk of (frame-sorted) landmarks, <= VIS_LM landmarks / VIS_MF factors: thread-per-factor evaluation
+//             staged in LDS, 16 lanes per landmark for the Schur pivots, then sum_f Jc^T Jc - sum_l invp e e^T on the fp64 matrix
+//             cores in the chunk's frame-window-local columns; the record is the upper 16 x 16 tiles of that window
 //   [plane]/[edge] 256 threads per <=256 pose-uniform LiDAR points (two chunks per WG): thread-per-point evaluation,
 //             wave64 butterfly reduction of the 6x6 + 6 + cost
 //   [prior]   n x n gemv on the pre-contracted J0^T J0
@@ -32,11 +31,6 @@ __device__ __forceinline__ double block_sum(double v, double* red /*>= 4 doubles
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
     return t;
 }
-__device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }   // ds_add_f64
-// a (wave-uniform) pointer the compiler cannot see through: address arithmetic on it stays where it is written instead of being hoisted to the top of
-// the role and kept in registers across the factor evaluation, the kernel's register peak
-template <class T> __device__ __forceinline__ T* opaque(T* p) { asm volatile("" : "+s"(p)); return p; }
-__device__ __forceinline__ int tri_idx(int NV, int i, int j) { if (i > j) { const int t = i; i = j; j = t; } return i * NV - ((i * (i - 1)) >> 1) + (j - i); }
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int f, const double* x, double* sm) {
@@ -92,350 +86,236 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// [visual] round 4: ONE chunk of landmarks per workgroup, block outer products on the fp64 matrix cores for every window size, columns LOCAL to the
+// chunk's frame window, no LDS atomics anywhere (every sum has a fixed order: bit-reproducible).
+//
+// The host sorts the landmarks by (first frame, last frame) and cuts the sorted list into chunks (vilsolve.hip: visual_chunks): a chunk's factors
+// touch the poses of frames [fa, fa + span) only, so its contribution to S' lives in a (6 span + 7)^2 corner structure -- local columns
+//   pose of frame k -> 6 (k - fa) .. +5 | extrinsic -> 6 span .. +5 | td -> 6 span + 6 | r -> 6 span + 7     (T = ceil((6 span + 8) / 16) column tiles)
+// and the record a workgroup leaves is T (T + 1) / 2 upper 16 x 16 tiles of THAT matrix instead of the packed triangle of the whole (6K + 7)^2 visual
+// sub-space (K = 20: 65 kB per workgroup whatever it touched; 12.5 MB per sweep written and read back by the gather).  With G the dense rows of the
+// corrected Jacobians (two per factor, the residual appended as column r) and E the rows e_l of the landmarks (b_l appended), the record is
+//   sum_f G_f^T G_f - sum_l invp_l E_l^T E_l
+// one v_mfma_f64_16x16x4 per tile and four rows, accumulators in registers from the first row to the store.  Column r of that matrix is the
+// Schur-reduced gradient; the un-reduced gradient and diagonal are read off the accumulators between the factor rows and the landmark rows.
 // LDS per factor: [Ji 12 | Jj 12 | Jex 12 | Jt 2 | Jl 2 | r 2 | eO 6] = 48 doubles
 #define VF_STRIDE 49   // odd stride: conflict-free column access
-// Windows up to K = 12 (NV <= 80, chunks of <= VIS_MF factors): the block outer products run on the fp64 matrix cores from dense operand rows in LDS
-#define VIS_MF 64      // factors a chunk may hold on that path (two operand rows each); chunks are closed at VIL_VCHUNK_FBAL unless the window has more of them than workgroups
+#define VIS_MF 64      // factors a chunk may hold (a thread and two operand rows each)
 #define VIS_LM 16      // landmarks a chunk may hold (one operand row each: one MFMA batch)
-#define VIS_RS 80      // row stride of the operand rows: five 16-column tiles, = 16 mod 32 (the four rows of an MFMA operand fragment on different banks)
-#define VIS_T_SLOTS 2  // 16 x 16 tiles per wave: 15 upper tiles of a 5 x 5 grid on 8 waves
-__host__ __device__ inline bool vis_mfma(int NV) { return NV <= VIS_RS; }
-__host__ __device__ inline int vis_ntile(int NV) { const int T = (NV + 15) >> 4; return (T * (T + 1)) >> 1; }
+#define VIS_GM 16384   // doubles of LDS the operand rows of a chunk may take (factor rows in batches of 16 + 16 landmark rows + 16 scales)
+#define VIS_TMAX 8     // column tiles of the widest window (K = 20: 6 * 20 + 8 = 128 columns)
+__host__ __device__ inline int vis_tiles(int span) { return (6 * span + 8 + 15) >> 4; }
+__host__ __device__ inline int vis_rs(int T) { return 16 * ((T + 1) | 1); }          // row stride: >= 16 T + 16 and = 16 mod 32 (the four rows of an operand fragment on different banks)
+__host__ __device__ inline int vis_ntile(int T) { return (T * (T + 1)) >> 1; }
+__host__ __device__ inline int vis_rows(int nf) { return (2 * nf + 15) & ~15; }      // factor rows, whole batches
+__host__ __device__ inline int vis_gm_doubles(int nf, int T) { return (vis_rows(nf) + 16) * vis_rs(T) + 16; }
+__host__ __device__ inline int vis_rec_doubles(int T) { return vis_ntile(T) * 256 + 32 * T + 16; }      // [tiles | bc 16 T | diag 16 T | cost + padding]: whole 128-byte lines
+__host__ __device__ inline int vis_slots(int T) { return (vis_ntile(T) + 7) >> 3; }  // tiles per wave (8 waves)
+// fixed part of the role's LDS (doubles): red 8 | lmr | Jf | int tables (fj, fl, fa: VIS_MF each; lms VIS_LM + 1; lanc, lid: VIS_LM each)
+#define VIS_LDS_FIXED (8 + VIS_LM * 16 + VIS_MF * VF_STRIDE + (3 * VIS_MF + 3 * VIS_LM + 2 + 1) / 2 + 2)
 // The candidate inverse depth is formed HERE: lambda_cand = lambda_cur + cg la + cn lb (la, lb: the step directions the step
 // kernel's landmark pass left, cg / cn: the dogleg coefficients in Ctl; first sweep and re-sweeps: cg = cn = 0), and written
 // into the candidate state by the landmark's lane group.
-template <bool MF>      // MF: the block outer products on the matrix cores (windows up to K = 12); a kernel of its own per value -- both paths in one kernel spill
+template <int TS>      // accumulator tiles per wave: 2 (windows whose widest chunk has T <= 5 column tiles: K <= 12) or 5 (T <= 8: K <= 20); a kernel per value
 __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, const Ctl& ctl, int wg, const double* x, SysBuf& sb, double* sm) {
-    const int NV = P.NV, NVT = P.NVT;
     const int t = threadIdx.x;
-    constexpr bool mf = MF;                            // (DevP::vis_mf, a property of the window: the host launches k_sweep<vis_mf>)
-    const int VT = (NV + 15) >> 4, nvtile = vis_ntile(NV);
-    double* tri_ = sm; double* const tri = tri_;       // NVT packed upper triangle of the visual sub-space -- or, mf: its upper 16 x 16 tiles (I <= J), nvtile x 256
-    double* vbc = tri + (mf ? nvtile * 256 : NVT);     // NV
-    double* vgr = vbc + NV;                            // NV
-    double* vdg = vgr + NV;                            // NV
-    double* Jf = vdg + NV;                             // VIL_VCHUNK_F (mf: VIS_MF) x VF_STRIDE
-    double* lmr = Jf + (mf ? VIS_MF : VIL_VCHUNK_F) * VF_STRIDE;       // VIS_LM x 16: invp, eA[13]
-    double* red = lmr + VIS_LM * 16;
-    double* Gm_ = red + 8; double* const Gm = Gm_;                              // mf: 2 VIS_MF x VIS_RS rows of Jc (two per factor) | 16 x VIS_RS rows of e_l | 16 scales -invp_l
-    double* Em_ = Gm_ + 2 * VIS_MF * VIS_RS; double* const Em = Em_;
-    double* sa_ = Em_ + 16 * VIS_RS; double* const sa = sa_;
-    int* fj = (int*)(mf ? sa + 16 : red + 8);          // VIL_VCHUNK_F observer frames
-    int* lms = fj + VIL_VCHUNK_F;                      // VIS_LM + 1 chunk-local factor offsets
-    int* lanc = lms + VIS_LM + 1;                      // VIS_LM anchor frames
-    int* fl = lanc + VIS_LM;                           // VIL_VCHUNK_F factor -> chunk-local landmark
-    int* fa = fl + VIL_VCHUNK_F;                       // (mf) VIS_MF anchor frames
+    const int4 d0 = ((const int4*)P.vwg)[2 * wg], d1 = ((const int4*)P.vwg)[2 * wg + 1];      // {first sorted landmark, landmarks, first sorted factor, factors}, {fa, span, T, record offset / 16}
+    const int p0 = d0.x, nl = d0.y, fp0 = d0.z, nf = d0.w, fa0 = d1.x, span = d1.y, T = d1.z;
+    const int RS = vis_rs(T), ntile = vis_ntile(T), nrow = vis_rows(nf);
+    const int cX = 6 * span, cT = cX + 6, cR = cX + 7;                 // local columns of the extrinsic, td and the residual
+    double* red = sm;                                  // 8
+    double* lmr = red + 8;                             // VIS_LM x 16: invp, eA[13], -, -
+    double* Jf = lmr + VIS_LM * 16;                    // VIS_MF x VF_STRIDE
+    int* fj = (int*)(Jf + VIS_MF * VF_STRIDE);         // observer frame of a factor
+    int* fl = fj + VIS_MF;                             // factor -> chunk-local landmark
+    int* fa = fl + VIS_MF;                             // anchor frame of a factor
+    int* lms = fa + VIS_MF;                            // VIS_LM + 1 chunk-local factor offsets
+    int* lanc = lms + VIS_LM + 1;                      // anchor frame of a landmark
+    int* lid = lanc + VIS_LM;                          // landmark id
+    double* Gm_ = sm + VIS_LDS_FIXED; double* const Gm = Gm_;          // nrow x RS rows of [Jc | r] (two per factor) | 16 x RS rows of [e_l | b_l] | 16 scales -invp_l
+    double* const Em = Gm + nrow * RS;
+    double* const sa = Em + 16 * RS;
 #ifdef VIL_STAMPS
-    long long vacc[3] = {0, 0, 0}, vprev = 0;
-    #define VSTAMP(k) do { __syncthreads(); if (t == 0 && wg == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[32 + k] = tt_; if (k >= 2 && k <= 3) vacc[k - 2] += tt_ - vprev; vprev = tt_; } } while (0)
-    #define VSTAMP_SC() do { __syncthreads(); if (t == 0 && wg == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); vacc[2] += tt_ - vprev; vprev = tt_; } } while (0)
+    #define VSTAMP(k) do { __syncthreads(); if (t == 0 && wg == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[32 + k] = tt_; } } while (0)
+    long long vt0 = 0; if (t == 0) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(vt0) :: "memory");
 #else
     #define VSTAMP(k) do {} while (0)
-    #define VSTAMP_SC() do {} while (0)
 #endif
     VSTAMP(0);
-#ifdef VIL_STAMPS
-    long long vt0 = 0; if (t == 0) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(vt0) :: "memory");
-#endif
     const double* xcur = P.x[ctl.cur];
     double* xcand = P.x[1 - ctl.cur];
     const double cg = ctl.cg, cn = ctl.cn;
     // first sweep of a solve and re-sweeps: cg = cn = 0 and la / lb still hold the PREVIOUS solve's directions -- possibly inf / NaN after a
     // diverged solve, and 0 * inf is NaN: the terms are dropped, not multiplied by zero (same bits whenever la, lb are finite)
     const bool stepped = cg != 0.0 || cn != 0.0;
-    if (mf) { for (int e = t; e < 3 * NV; e += blockDim.x) vbc[e] = 0.0; }      // (the tiles are carried from chunk to chunk only if there is more than one)
-    else for (int e = t; e < NVT + 3 * NV; e += blockDim.x) tri[e] = 0.0;
-    if (mf) {                                          // operand rows: two per factor of the largest chunk, the landmark rows and their scales
-        for (int e = t; e < ((2 * P.vis_fmax + 15) & ~15) * VIS_RS; e += blockDim.x) Gm[e] = 0.0;      // (whole batches of 16 rows are read)
-        for (int e = t; e < 16 * VIS_RS + 16; e += blockDim.x) Em[e] = 0.0;
-    }
+    for (int e = t; e < (nrow + 16) * RS + 16; e += blockDim.x) Gm[e] = 0.0;      // operand rows and scales
     const bool mfree = P.marg != 0;            // marginalisation of the resident window: every block free, factors masked
     const bool exc = !mfree && P.ex_const != 0, tdc = mfree ? !P.use_td : !P.td_free;
     double cost = 0.0;
-    const int4 wg0 = ((const int4*)P.vwg)[2 * wg], wg1 = ((const int4*)P.vwg)[2 * wg + 1];      // {first chunk, end, -, -}, the first chunk's {l0, l1, f0, f1}
-    const int sc0 = wg0.x, sc1 = wg0.y;
-    for (int chunk = sc0; chunk < sc1; ++chunk) {
-        int4 ch = wg1;
-        if (chunk != sc0) ch = ((const int4*)P.vchunk)[chunk];
-        const int l0 = ch.x, l1 = ch.y, f0 = ch.z, f1 = ch.w;
-        const int nf = f1 - f0, nl = l1 - l0;
-        __syncthreads();
-        VSTAMP(1);
-        if (t >= 256 && t <= 256 + nl) { const int q = t - 256; lms[q] = P.lm_start[l0 + q] - f0; if (q < nl) lanc[q] = P.vis_i[P.lm_start[l0 + q]]; }
-        if (t < nf) {
-            const int f = f0 + t;
-            double c[14];
-#pragma unroll
-            for (int k = 0; k < 14; ++k) c[k] = P.vis_c[(size_t)k * P.vis_stride + f];
-            const int i = P.vis_i[f], j = P.vis_j[f], l = P.vis_l[f];
-            const double* pi = x + xo_pose(P, i); const double* pj = x + xo_pose(P, j); const double* ex = x + xo_ex(P);
-            VisJ o;
-            const double lam = stepped ? xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l] : xcur[xo_lam(P) + l];
-            if (O.precision)
-                visual_eval_f32(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
-                                lam, x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
-            else
-                visual_eval(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
-                            lam, x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
-            double rho, rho1;
-            loss_eval(O.visual_loss, O.visual_loss_scale, o.r[0] * o.r[0] + o.r[1] * o.r[1], rho, rho1);
-            const bool live = !mfree || (P.marg == 1 && i == 0);      // estimator.cpp:1547-1589: landmarks anchored in frame 0
-            if (!live) { rho = 0.0; rho1 = 0.0; }
-            cost += 0.5 * rho;
-            const double sr = sqrt(rho1);
-            const bool ci = !mfree && P.pose_const && P.pose_const[i], cj = !mfree && P.pose_const && P.pose_const[j], cl = !mfree && P.lm_const && P.lm_const[l];
-            double* w = Jf + t * VF_STRIDE;
-            for (int k = 0; k < 12; ++k) { w[k] = ci ? 0.0 : sr * o.Ji[k]; w[12 + k] = cj ? 0.0 : sr * o.Jj[k]; w[24 + k] = exc ? 0.0 : sr * o.Jex[k]; }
-            w[36] = tdc ? 0.0 : sr * o.Jt[0]; w[37] = tdc ? 0.0 : sr * o.Jt[1];
-            w[38] = cl ? 0.0 : sr * o.Jl[0]; w[39] = cl ? 0.0 : sr * o.Jl[1];
-            w[40] = sr * o.r[0]; w[41] = sr * o.r[1];
-            fj[t] = j; fl[t] = l - l0; if (mf) fa[t] = i;
-            // observer-pose pieces that need no landmark-level sum
-            for (int k = 0; k < 6; ++k) {
-                const double j0 = cj ? 0.0 : sr * o.Jj[k], j1 = cj ? 0.0 : sr * o.Jj[6 + k];
-                const double eo = j0 * w[38] + j1 * w[39];
-                w[42 + k] = eo;
-                sb.eO[(size_t)(P.vis_f0 + f) * 6 + k] = eo;
-                if (!cj) {
-                    const double g = j0 * w[40] + j1 * w[41];
-                    lds_add(vbc + col_pose(P, j) + k, g);
-                    lds_add(vgr + col_pose(P, j) + k, g);
-                    lds_add(vdg + col_pose(P, j) + k, j0 * j0 + j1 * j1);
-                }
-            }
-        }
-        __syncthreads();
-        VSTAMP(2);
-        // ---- per landmark: pivots, e on the shared groups, gradients; 16 lanes per landmark ---------------
-        // lane component k: 0..5 anchor pose, 6..11 extrinsic, 12 td, 13 -> (h, b) pivot pieces
-        if (t < 16 * nl) {
-            const int tl = t >> 4, k = t & 15;
-            const int l = l0 + tl;
-            const int fs = lms[tl], fe = lms[tl + 1];
-            const int a = lanc[tl];
-            double e = 0, g = 0, dg = 0, h = 0, b = 0;
-            const int off = k < 6 ? k : (k < 12 ? 24 + (k - 6) : 36);
-            const int rs = k < 12 ? 6 : 1;      // row stride inside the 2 x n block
-            for (int q = fs; q < fe; ++q) {
-                const double* w = Jf + q * VF_STRIDE;
-                const double l0_ = w[38], l1_ = w[39], r0 = w[40], r1 = w[41];
-                if (k < 13) { const double j0 = w[off], j1 = w[off + rs]; e += j0 * l0_ + j1 * l1_; g += j0 * r0 + j1 * r1; dg += j0 * j0 + j1 * j1; }
-                else { h += l0_ * l0_ + l1_ * l1_; b += l0_ * r0 + l1_ * r1; }
-            }
-            // broadcast (h, b) of lane 13 to the 16-lane group
-            h = __shfl(h, (t & ~15) + 13, 64); b = __shfl(b, (t & ~15) + 13, 64);
-            const bool cl = !mfree && P.lm_const && P.lm_const[l];
-            double Sl = 1.0;
-            if (ctl.first) { Sl = (O.jacobi_scaling && !ctl.lin_mode) ? 1.0 / (1.0 + sqrt(h)) : 1.0; if (k == 13) P.Sl[l] = Sl; }
-            else Sl = P.Sl[l];
-            double dl2 = Sl * Sl * h; dl2 = fmin(fmax(dl2, 1e-6), 1e32);
-            const double p = ctl.lin_mode ? h : h + ctl.mu * dl2 / (Sl * Sl);
-            // lin_mode 2 (marginalisation): MarginalizationInfo's pseudo inverse zeroes every direction of A_mm whose eigenvalue is
-            // <= eps = 1e-8 (marginalization_factor.cpp:277); for a landmark without parallax that direction IS the landmark
-            // (eigenvalue = h_ll to first order), so its pivot is dropped and its factors enter the prior as if it were fixed
-            const double invp = (cl || !(p > (ctl.lin_mode == 2 ? 1e-8 : 0.0))) ? 0.0 : 1.0 / p;
-            const double ib = invp * b;
-            double* lr = lmr + tl * 16;
-            // (a landmark without a factor in this workgroup's table -- none at all, or owned by another rank -- leaves the set untouched:
-            //  its entries stay zero here and the all-reduce takes them from the owner)
-            if (k == 13) { if (fe > fs) { sb.hll[l] = h; sb.bl[l] = b; sb.invp[l] = invp; sb.sl[l] = Sl; } lr[0] = invp; lr[14] = (double)a; if (mf) sa[tl] = -invp; }
-            if (k == 14 && fe > fs) xcand[xo_lam(P) + l] = stepped ? xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l] : xcur[xo_lam(P) + l];      // the same expression the factor threads evaluated
-            if (k < 13) {
-                lr[1 + k] = e; if (fe > fs) sb.eA[(size_t)l * 13 + k] = e;
-                const int col = k < 6 ? col_pose(P, a) + k : (k < 12 ? col_ex(P) + k - 6 : col_td(P));
-                if (mf) Em[tl * VIS_RS + col] = e;
-                if (g != 0.0 || dg != 0.0) { lds_add(vbc + col, g); lds_add(vgr + col, g - ib * e); lds_add(vdg + col, dg); }
-            }
-            // observer columns: gred -= invp b eO ; lanes 0..5 of the group walk the factors
-            if (k < 6) for (int q = fs; q < fe; ++q) { const double eo = Jf[q * VF_STRIDE + 42 + k]; if (mf) Em[tl * VIS_RS + col_pose(P, fj[q]) + k] = eo; if (eo != 0.0) lds_add(vgr + col_pose(P, fj[q]) + k, -ib * eo); }
-        } else if (mf) {
-            // the threads the landmarks do not use spread the staged Jacobian blocks into the dense operand rows (two per factor, zeroed before): item =
-            // (factor, residual row, one of the 19 columns); written by the evaluating thread itself the six row / group addresses cost it registers it
-            // does not have (19 VGPRs spilled, 3 MB of scratch traffic per launch)
-            const int t0 = 16 * nl, nt = blockDim.x - t0;
-            double* const Gm = opaque(Gm_);
-            int tq = t; asm volatile("" : "+v"(tq));
-            for (int it = tq - t0; it < nf * 38; it += nt) {
-                const int q = it / 38, e = it - 38 * q, rr = e >= 19 ? 1 : 0, m = e - 19 * rr;
-                const double* w = Jf + q * VF_STRIDE;
-                int col; double v;
-                if (m < 6) { col = col_pose(P, fa[q]) + m; v = w[rr * 6 + m]; }
-                else if (m < 12) { col = col_pose(P, fj[q]) + (m - 6); v = w[12 + rr * 6 + (m - 6)]; }
-                else if (m < 18) { col = col_ex(P) + (m - 12); v = w[24 + rr * 6 + (m - 12)]; }
-                else { col = col_td(P); v = w[36 + rr]; }
-                Gm[(2 * q + rr) * VIS_RS + col] = v;
-            }
-        }
-        __syncthreads();
-        VSTAMP(3);
-        // ---- tri += sum_f Jc^T Jc - invp e e^T.  Three kinds of work items with (nearly) uniform trip counts inside a wave
-        //      (divergent loops cost the maximum over the lanes); the kinds only read the staged factors and add into tri with LDS
-        //      atomics, so they run side by side: every kind's item range is padded to whole waves and the waves of the workgroup
-        //      walk the concatenation -- two or three rounds of latency instead of one or two per kind with barriers in between.
-        //      Groups: A = anchor pose, X = extrinsic, T = td (shared by all factors of the landmark), O_f = observing pose of factor f.
-        // Windows up to K = 12 (mf): the same update as G_A^T G_B on the fp64 matrix cores.  Jc_f (2 x NV) is non-zero on the anchor pose, the observing
-        // pose, the extrinsic and td, e_l on the anchor, the extrinsic, td and the landmark's observers: the factor threads and the landmark lanes above
-        // left them as dense rows (Gm: two per factor, Em: one per landmark), and sum_f Jc^T Jc - sum_l invp_l e_l e_l^T is one v_mfma_f64_16x16x4 per
-        // 16 x 16 tile and four rows, -invp_l applied to the A operand on its way in.  Every wave owns two of the 15 upper tiles; all operand loads of
-        // a batch are in flight before its first MFMA.  Deterministic, and 1.6 k cycles per chunk where the ~1200 atomic work items below take 5 k.
-        if constexpr (mf) {
-            int tq = t; asm volatile("" : "+v"(tq));      // (opaque: what is derived from it is computed here, not at the top of the role)
-            const int wave = __builtin_amdgcn_readfirstlane(tq >> 6), lane = tq & 63;
-            const bool first = chunk == sc0, last = chunk + 1 == sc1, has1 = wave + 8 < nvtile;
-            double* const Gm = opaque(Gm_); double* const Em = opaque(Em_); double* const sa = opaque(sa_); double* const tri = opaque(tri_);
-            int tI[VIS_T_SLOTS], tJ[VIS_T_SLOTS]; d4 acc[VIS_T_SLOTS];
-#pragma unroll
-            for (int u = 0; u < VIS_T_SLOTS; ++u) {
-                const int g = min(wave + 8 * u, nvtile - 1);                    // (a wave without a second tile mirrors the last one and stores nothing)
-                int I = 0, rem = g; while (rem >= VT - I) { rem -= VT - I; ++I; }      // upper tiles row by row: (I, I + rem)
-                tI[u] = I; tJ[u] = I + rem;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[u][q] = first ? 0.0 : tri[g * 256 + ((lane >> 4) + 4 * q) * 16 + (lane & 15)];
-            }
-            auto mma = [&](const double* G, auto nk_c, auto scaled_c) {       // acc += G_A^T G over NK * 4 rows; G_A = G, or the rows of G scaled by sa[row]
-                constexpr int NK = decltype(nk_c)::value; constexpr bool SCALED = decltype(scaled_c)::value;
-                const double* p = G + (lane >> 4) * VIS_RS + (lane & 15);
-                double a0[NK], b0[NK], a1[NK], b1[NK];
-#pragma unroll
-                for (int ks = 0; ks < NK; ++ks) {
-                    a0[ks] = p[ks * 4 * VIS_RS + (tI[0] << 4)]; b0[ks] = p[ks * 4 * VIS_RS + (tJ[0] << 4)];
-                    a1[ks] = p[ks * 4 * VIS_RS + (tI[1] << 4)]; b1[ks] = p[ks * 4 * VIS_RS + (tJ[1] << 4)];
-                }
-                if (has1) {
-#pragma unroll
-                    for (int ks = 0; ks < NK; ++ks) {
-                        const double sc = SCALED ? sa[4 * ks + (lane >> 4)] : 1.0;
-                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(SCALED ? sc * a0[ks] : a0[ks], b0[ks], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(SCALED ? sc * a1[ks] : a1[ks], b1[ks], acc[1], 0, 0, 0);
-                    }
-                } else {                                                       // (one tile: the matrix core of this SIMD is shared with another wave)
-#pragma unroll
-                    for (int ks = 0; ks < NK; ++ks) {
-                        const double sc = SCALED ? sa[4 * ks + (lane >> 4)] : 1.0;
-                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(SCALED ? sc * a0[ks] : a0[ks], b0[ks], acc[0], 0, 0, 0);
-                    }
-                }
-            };
-            mma(Gm, std::integral_constant<int, 4>{}, std::false_type{});
-            if (nf > 8) mma(Gm + 16 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
-            if (nf > 16) mma(Gm + 32 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
-            if (nf > 24) mma(Gm + 48 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
-            if (nf > 32) {                                                     // (wide chunks: windows with more chunks of 32 factors than workgroups)
-                mma(Gm + 64 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
-                if (nf > 40) mma(Gm + 80 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
-                if (nf > 48) mma(Gm + 96 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
-                if (nf > 56) mma(Gm + 112 * VIS_RS, std::integral_constant<int, 4>{}, std::false_type{});
-            }
-            mma(Em, std::integral_constant<int, 4>{}, std::true_type{});
-            if (last) {
-                // the accumulators go into the record's layout -- the packed upper triangle -- in LDS (over the operand rows, which every wave is done
-                // with) and leave with whole-line stores below: written straight from the registers, 16 lanes x 8 bytes per row fragment straddle the
-                // unaligned rows of the triangle and the partial lines doubled the kernel's write traffic (5.8 MB against 2.6)
-                __syncthreads();
-#pragma unroll
-                for (int u = 0; u < VIS_T_SLOTS; ++u) if (wave + 8 * u < nvtile) {
-                    const int j = (tJ[u] << 4) + (lane & 15);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { const int i = (tI[u] << 4) + (lane >> 4) + 4 * q; if (i <= j && j < NV) Gm[tri_idx(NV, i, j)] = acc[u][q]; }
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < VIS_T_SLOTS; ++u) if (wave + 8 * u < nvtile) {
-                    const int g = wave + 8 * u;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) tri[g * 256 + ((lane >> 4) + 4 * q) * 16 + (lane & 15)] = acc[u][q];
-                }
-                __syncthreads();                                               // every wave is done with the operand rows: zero them for the next chunk
-                for (int e = t; e < 2 * nf * VIS_RS; e += blockDim.x) Gm[e] = 0.0;
-                for (int e = t; e < 16 * VIS_RS; e += blockDim.x) Em[e] = 0.0;
-            }
-        } else {
-            // (a) shared x shared blocks: item = (landmark, pair of {A,X,T}, row); inner loop over the landmark's factors
-            auto item_a = [&](int it) {
-                const int tl = it / 36, pr = it - 36 * tl, p = pr / 6, r = pr - 6 * p;
-                const int g1 = p < 3 ? 0 : (p < 5 ? 1 : 2), g2 = p < 3 ? p : (p < 5 ? p - 2 : 2);
-                const int n1 = g1 == 2 ? 1 : 6, n2 = g2 == 2 ? 1 : 6;
-                if (r >= n1) return;
-                const int fs = lms[tl], fe = lms[tl + 1];
-                const double* lr = lmr + tl * 16;
-                const int a = lanc[tl];
-                const int o1 = g1 == 0 ? 0 : (g1 == 1 ? 24 : 36), o2 = g2 == 0 ? 0 : (g2 == 1 ? 24 : 36);
-                const int c1 = g1 == 0 ? col_pose(P, a) : (g1 == 1 ? col_ex(P) : col_td(P)), c2 = g2 == 0 ? col_pose(P, a) : (g2 == 1 ? col_ex(P) : col_td(P));
-                const double* e1 = lr + 1 + (g1 == 0 ? 0 : (g1 == 1 ? 6 : 12)); const double* e2 = lr + 1 + (g2 == 0 ? 0 : (g2 == 1 ? 6 : 12));
-                const int s1 = n1 == 1 ? 1 : 6, s2 = n2 == 1 ? 1 : 6;
-                const double ie1 = lr[0] * e1[r];
-                double acc[6];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) acc[c] = (c < n2) ? -ie1 * e2[c] : 0.0;
-                for (int q = fs; q < fe; ++q) {
-                    const double* w = Jf + q * VF_STRIDE;
-                    const double w0 = w[o1 + r], w1 = w[o1 + s1 + r];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) if (c < n2) acc[c] += w0 * w[o2 + c] + w1 * w[o2 + s2 + c];
-                }
-#pragma unroll
-                for (int c = 0; c < 6; ++c) if (c < n2 && (g1 != g2 || c >= r) && acc[c] != 0.0) lds_add(tri + tri_idx(NV, c1 + r, c2 + c), acc[c]);
-            };
-            // (b) shared x observer blocks: item = (factor, shared group, row); exactly one factor contributes
-            auto item_b = [&](int it) {
-                const int q = it / 18, rem = it - 18 * q, g1 = rem / 6, r = rem - 6 * g1;
-                if (g1 == 2 && r > 0) return;
-                const int tl = fl[q];
-                const double* lr = lmr + tl * 16;
-                const double* w = Jf + q * VF_STRIDE;
-                const int o1 = g1 == 0 ? 0 : (g1 == 1 ? 24 : 36), s1 = g1 == 2 ? 1 : 6;
-                const int c1 = g1 == 0 ? col_pose(P, lanc[tl]) : (g1 == 1 ? col_ex(P) : col_td(P)), c2 = col_pose(P, fj[q]);
-                const double ie1 = lr[0] * lr[1 + (g1 == 0 ? 0 : (g1 == 1 ? 6 : 12)) + r];
-                const double w0 = w[o1 + r], w1 = w[o1 + s1 + r];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    const double v = w0 * w[12 + c] + w1 * w[18 + c] - ie1 * w[42 + c];
-                    if (v != 0.0) lds_add(tri + tri_idx(NV, c1 + r, c2 + c), v);
-                }
-            };
-            // (c) observer x observer blocks: item = (factor q, row); walks the later factors of the same landmark
-            auto item_c = [&](int it) {
-                const int q = it / 6, r = it - 6 * q;
-                const int tl = fl[q], fe = lms[tl + 1];
-                const double* w = Jf + q * VF_STRIDE;
-                const double ieq = lmr[tl * 16] * w[42 + r];
-                const int c1 = col_pose(P, fj[q]) + r;
-                const double j0 = w[12 + r], j1 = w[18 + r];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) if (c >= r) {          // diagonal block (q, q): upper part
-                    const double v = j0 * w[12 + c] + j1 * w[18 + c] - ieq * w[42 + c];
-                    if (v != 0.0) lds_add(tri + tri_idx(NV, c1, c1 - r + c), v);
-                }
-                for (int f2 = q + 1; f2 < fe; ++f2) {
-                    const double* w2 = Jf + f2 * VF_STRIDE;
-                    const int c2 = col_pose(P, fj[f2]);
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) { const double v = -ieq * w2[42 + c]; if (v != 0.0) lds_add(tri + tri_idx(NV, c1, c2 + c), v); }
-                }
-            };
-            const int na = nl * 36, nb_ = nf * 18, nc_ = nf * 6;
-            const int pa = (na + 63) & ~63, pc = (nc_ + 63) & ~63, pb = (nb_ + 63) & ~63;      // the kinds with inner loops first
-            for (int it = t; it < pa + pc + pb; it += blockDim.x) {
-                if (it < pa) { if (it < na) item_a(it); }
-                else if (it < pa + pc) { const int i2 = it - pa; if (i2 < nc_) item_c(i2); }
-                else { const int i3 = it - pa - pc; if (i3 < nb_) item_b(i3); }
-            }
-        }
-        VSTAMP_SC();
+    if (t >= 256 && t <= 256 + nl) {
+        const int q = t - 256;
+        if (q < nl) { const int4 lm = ((const int4*)P.vlm)[p0 + q]; lid[q] = lm.x; lms[q] = lm.y; lanc[q] = lm.w; }      // {landmark, chunk-local first factor, -, anchor frame}
+        else lms[q] = nf;
     }
-    VSTAMP(4);
-#ifdef VIL_STAMPS
-    if (t == 0 && wg == 0) { P.dbg[62] = vacc[0]; P.dbg[63] = vacc[1]; P.dbg[47] = vacc[2]; }
-#endif
+    if (t < nf) {
+        const int2 fq = ((const int2*)P.vfac)[fp0 + t];                // {factor, chunk-local landmark}
+        const int f = fq.x;
+        double c[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) c[k] = P.vis_c[(size_t)k * P.vis_stride + f];
+        const int i = P.vis_i[f], j = P.vis_j[f], l = P.vis_l[f];
+        const double* pi = x + xo_pose(P, i); const double* pj = x + xo_pose(P, j); const double* ex = x + xo_ex(P);
+        VisJ o;
+        const double lam = stepped ? xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l] : xcur[xo_lam(P) + l];
+        if (O.precision)
+            visual_eval_f32(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
+                            lam, x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
+        else
+            visual_eval(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
+                        lam, x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
+        double rho, rho1;
+        loss_eval(O.visual_loss, O.visual_loss_scale, o.r[0] * o.r[0] + o.r[1] * o.r[1], rho, rho1);
+        const bool live = !mfree || (P.marg == 1 && i == 0);      // estimator.cpp:1547-1589: landmarks anchored in frame 0
+        if (!live) { rho = 0.0; rho1 = 0.0; }
+        cost += 0.5 * rho;
+        const double sr = sqrt(rho1);
+        const bool ci = !mfree && P.pose_const && P.pose_const[i], cj = !mfree && P.pose_const && P.pose_const[j], cl = !mfree && P.lm_const && P.lm_const[l];
+        double* w = Jf + t * VF_STRIDE;
+        for (int k = 0; k < 12; ++k) { w[k] = ci ? 0.0 : sr * o.Ji[k]; w[12 + k] = cj ? 0.0 : sr * o.Jj[k]; w[24 + k] = exc ? 0.0 : sr * o.Jex[k]; }
+        w[36] = tdc ? 0.0 : sr * o.Jt[0]; w[37] = tdc ? 0.0 : sr * o.Jt[1];
+        w[38] = cl ? 0.0 : sr * o.Jl[0]; w[39] = cl ? 0.0 : sr * o.Jl[1];
+        w[40] = sr * o.r[0]; w[41] = sr * o.r[1];
+        fj[t] = j; fl[t] = fq.y; fa[t] = i;
+        // e_l on the observing pose: one factor's product, no landmark-level sum
+        for (int k = 0; k < 6; ++k) {
+            const double j0 = cj ? 0.0 : sr * o.Jj[k], j1 = cj ? 0.0 : sr * o.Jj[6 + k];
+            const double eo = j0 * w[38] + j1 * w[39];
+            w[42 + k] = eo;
+            sb.eO[(size_t)(P.vis_f0 + f) * 6 + k] = eo;
+        }
+    }
+    __syncthreads();
+    VSTAMP(1);
+    // ---- per landmark: pivot, e on the shared groups; 16 lanes per landmark ---------------
+    // lane component k: 0..5 anchor pose, 6..11 extrinsic, 12 td, 13 -> (h, b) pivot pieces
+    if (t < 16 * nl) {
+        const int tl = t >> 4, k = t & 15;
+        const int l = lid[tl];
+        const int fs = lms[tl], fe = lms[tl + 1];
+        const int a = lanc[tl];
+        double e = 0, h = 0, b = 0;
+        const int off = k < 6 ? k : (k < 12 ? 24 + (k - 6) : 36);
+        const int rs = k < 12 ? 6 : 1;      // row stride inside the 2 x n block
+        for (int q = fs; q < fe; ++q) {
+            const double* w = Jf + q * VF_STRIDE;
+            const double l0_ = w[38], l1_ = w[39], r0 = w[40], r1 = w[41];
+            if (k < 13) { const double j0 = w[off], j1 = w[off + rs]; e += j0 * l0_ + j1 * l1_; }
+            else { h += l0_ * l0_ + l1_ * l1_; b += l0_ * r0 + l1_ * r1; }
+        }
+        // broadcast (h, b) of lane 13 to the 16-lane group
+        h = __shfl(h, (t & ~15) + 13, 64); b = __shfl(b, (t & ~15) + 13, 64);
+        const bool cl = !mfree && P.lm_const && P.lm_const[l];
+        double Sl = 1.0;
+        if (ctl.first) { Sl = (O.jacobi_scaling && !ctl.lin_mode) ? 1.0 / (1.0 + sqrt(h)) : 1.0; if (k == 13) P.Sl[l] = Sl; }
+        else Sl = P.Sl[l];
+        double dl2 = Sl * Sl * h; dl2 = fmin(fmax(dl2, 1e-6), 1e32);
+        const double p = ctl.lin_mode ? h : h + ctl.mu * dl2 / (Sl * Sl);
+        // lin_mode 2 (marginalisation): MarginalizationInfo's pseudo inverse zeroes every direction of A_mm whose eigenvalue is
+        // <= eps = 1e-8 (marginalization_factor.cpp:277); for a landmark without parallax that direction IS the landmark
+        // (eigenvalue = h_ll to first order), so its pivot is dropped and its factors enter the prior as if it were fixed
+        const double invp = (cl || !(p > (ctl.lin_mode == 2 ? 1e-8 : 0.0))) ? 0.0 : 1.0 / p;
+        double* lr = lmr + tl * 16;
+        double* er = Em + tl * RS;
+        // (a landmark of another rank's shard is in no chunk of this rank: its entries of the set stay zero here and the all-reduce takes them from the owner)
+        if (k == 13) { sb.hll[l] = h; sb.bl[l] = b; sb.invp[l] = invp; sb.sl[l] = Sl; lr[0] = invp; sa[tl] = -invp; er[cR] = b; }
+        if (k == 14) xcand[xo_lam(P) + l] = stepped ? xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l] : xcur[xo_lam(P) + l];      // the same expression the factor threads evaluated
+        if (k < 13) {
+            lr[1 + k] = e; sb.eA[(size_t)l * 13 + k] = e;
+            er[k < 6 ? 6 * (a - fa0) + k : cX + (k - 6)] = e;
+        }
+        // observer columns of e_l: lanes 0..5 of the group walk the factors
+        if (k < 6) for (int q = fs; q < fe; ++q) er[6 * (fj[q] - fa0) + k] = Jf[q * VF_STRIDE + 42 + k];
+    } else {
+        // the threads the landmarks do not use spread the staged Jacobian blocks into the dense operand rows (two per factor, zeroed before): item =
+        // (factor, residual row, one of the 19 columns or r); written by the evaluating thread itself the six row / group addresses cost it registers it
+        // does not have (19 VGPRs spilled, 3 MB of scratch traffic per launch)
+        const int t0 = 16 * nl, nt = blockDim.x - t0;
+        int tq = t; asm volatile("" : "+v"(tq));
+        for (int it = tq - t0; it < nf * 40; it += nt) {
+            const int q = it / 40, e = it - 40 * q, rr = e >= 20 ? 1 : 0, m = e - 20 * rr;
+            const double* w = Jf + q * VF_STRIDE;
+            int col; double v;
+            if (m < 6) { col = 6 * (fa[q] - fa0) + m; v = w[rr * 6 + m]; }
+            else if (m < 12) { col = 6 * (fj[q] - fa0) + (m - 6); v = w[12 + rr * 6 + (m - 6)]; }
+            else if (m < 18) { col = cX + (m - 12); v = w[24 + rr * 6 + (m - 12)]; }
+            else if (m == 18) { col = cT; v = w[36 + rr]; }
+            else { col = cR; v = w[40 + rr]; }
+            Gm[(2 * q + rr) * RS + col] = v;
+        }
+    }
+    __syncthreads();
+    VSTAMP(2);
+    // ---- record = sum_f G_f^T G_f - sum_l invp_l E_l^T E_l on the matrix cores: tile g = wave + 8 u of the upper tiles (row by row), accumulators in
+    //      registers.  Four rows per MFMA; NK k-steps of operands in flight per batch.
+    double* const rec = P.vpart + (size_t)d1.w * 16;
+    {
+        int tq = t; asm volatile("" : "+v"(tq));      // (opaque: what is derived from it is computed here, not at the top of the role)
+        const int wave = __builtin_amdgcn_readfirstlane(tq >> 6), lane = tq & 63;
+        constexpr int NK = TS > 2 ? 2 : 4;
+        int tI[TS], tJ[TS]; bool on[TS]; d4 acc[TS];
+#pragma unroll
+        for (int u = 0; u < TS; ++u) {
+            const int g = wave + 8 * u;
+            on[u] = g < ntile;
+            int I = 0, rem = on[u] ? g : 0; while (rem >= T - I) { rem -= T - I; ++I; }      // upper tiles row by row: (I, I + rem)
+            tI[u] = I; tJ[u] = I + rem;
+            acc[u] = d4{0.0, 0.0, 0.0, 0.0};
+        }
+        auto mma = [&](const double* G, const double* scl, auto scaled_c) {       // acc += G_A^T G over NK * 4 rows; G_A = G, or the rows of G scaled by scl[row]
+            constexpr bool SCALED = decltype(scaled_c)::value;
+            const double* p = G + (lane >> 4) * RS + (lane & 15);
+            double av[TS][NK], bv[TS][NK];
+#pragma unroll
+            for (int u = 0; u < TS; ++u) if (on[u]) {
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) { av[u][ks] = p[ks * 4 * RS + (tI[u] << 4)]; bv[u][ks] = p[ks * 4 * RS + (tJ[u] << 4)]; }
+            }
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const double sc = SCALED ? scl[4 * ks + (lane >> 4)] : 1.0;
+#pragma unroll
+                for (int u = 0; u < TS; ++u) if (on[u]) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(SCALED ? sc * av[u][ks] : av[u][ks], bv[u][ks], acc[u], 0, 0, 0);
+            }
+        };
+        for (int r0 = 0; r0 < nrow; r0 += 4 * NK) mma(Gm + r0 * RS, sa, std::false_type{});
+        // un-reduced gradient J_c^T r (column r of the factor rows' product) and diagonal of J_c^T J_c: straight from the accumulators into the record
+        {
+            double* const rbc = rec + ntile * 256; double* const rdg = rbc + 16 * T;
+            const int n = lane & 15, m0 = lane >> 4;
+#pragma unroll
+            for (int u = 0; u < TS; ++u) if (on[u]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = m0 + 4 * q;
+                    if (tI[u] == tJ[u] && m == n) rdg[(tI[u] << 4) + m] = acc[u][q];
+                    if (tJ[u] == T - 1 && n == (cR & 15)) rbc[(tI[u] << 4) + m] = acc[u][q];
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4 / NK; ++b) mma(Em + b * 4 * NK * RS, sa + b * 4 * NK, std::true_type{});      // the 16 landmark rows, -invp_l on the A operand
+        // tiles leave row-major, 128-byte rows: whole lines
+#pragma unroll
+        for (int u = 0; u < TS; ++u) if (on[u]) {
+            double* o = rec + (wave + 8 * u) * 256 + (lane >> 4) * 16 + (lane & 15);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q * 64] = acc[u][q];
+        }
+    }
+    VSTAMP(3);
     cost = block_sum(cost, red);
-    double* out = P.vpart + (size_t)wg * P.VP;
-    if (mf) {                                              // (the last chunk left the packed triangle in Gm; block_sum's barriers are behind it)
-        for (int e = t; e < NVT; e += blockDim.x) out[e] = Gm[e];
-        for (int e = t; e < 3 * NV; e += blockDim.x) out[NVT + e] = vbc[e];
-    } else
-    for (int e = t; e < NVT + 3 * NV; e += blockDim.x) out[e] = tri[e];
-    if (t == 0) out[NVT + 3 * NV] = cost;
-    VSTAMP(5);
+    if (t == 0) rec[ntile * 256 + 32 * T] = cost;
+    VSTAMP(4);
 #ifdef VIL_STAMPS
     if (t == 0) { long long vt1; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(vt1) :: "memory"); atomicMax((unsigned long long*)(P.dbg + 60), (unsigned long long)(vt1 - vt0)); atomicAdd((unsigned long long*)(P.dbg + 61), (unsigned long long)(vt1 - vt0)); }
 #endif
@@ -615,15 +495,17 @@ __device__ __forceinline__ int imu_local(const DevP& P, int i, int j, int col) {
 
 // Gather of the sweep's partial records into the dense reduced system of the candidate set:
 //   S' (D x D, both triangles), gred, bc, diag, cost.   32 lower-triangle entries per workgroup, 8 threads per
-//   entry splitting the sum over the visual partials; fixed summation order across workgroups (the partials themselves are
-//   accumulated with LDS atomics inside a visual workgroup, so two runs agree to rounding, not bit for bit).
+//   entry splitting the sum over the visual records; fixed summation order everywhere (the records themselves are matrix-core
+//   contractions in a fixed row order: two runs agree bit for bit).  A visual record holds the upper 16 x 16 tiles of its chunk's
+//   frame window (sweep_visual): an entry (i, j) of S' reads the records whose window covers both columns.
 //   The last workgroup handles the vectors and the cost.
 #define RED_EPW 32
+#define VIS_TAB 512      // visual record descriptors a gather workgroup stages in LDS (8 kB)
 // AG: the results are stored at agent scope (gather + step in one launch: the master reads them in the same launch)
 // EPW: entries per workgroup = blockDim / 8 (32 with 256 threads: the gather kernel; 64 with 512: the gather workgroups of the merged launch,
 // whose register allocation admits one workgroup per compute unit whatever its thread count)
 template <bool AG = false, int EPW = RED_EPW>
-__device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, const int blk /* gather workgroup index */) {
+__device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, const int blk /* gather workgroup index */, int4* const vtab /* LDS, VIS_TAB entries */) {
     using namespace vd;
     auto put = [](double* p, double v) { if (AG) st_ag(p, v); else *p = v; };
     if ((int)threadIdx.x >= 8 * EPW) return;
@@ -636,13 +518,19 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
     const int nSblk = (NL + EPW - 1) / EPW;
     __shared__ double part[2][8][EPW];
     __shared__ int tab[64 + 48 + 2 * 66];      // imu (i, j) pairs | ICP/LPS pose ids (4 per factor) | LiDAR chunk ranges per pose
+    // vtab: the visual records' descriptors {offset / 16, first frame, frames, column tiles}, staged per workgroup (records beyond VIS_TAB: read from memory)
     int* t_imu = tab; int* t_rel = tab + 64; int* t_lch = tab + 112;
+    const int4* const vrec = (const int4*)P.vrec;
+    auto vdesc = [&](int w) -> int4 { return w < VIS_TAB ? vtab[w] : vrec[w]; };
+    // local column of reduced column c (< NV) in a record's window, or -1: pose columns of frames [fa, fa + sp), then extrinsic / td
+    auto vlocal = [&](int c, int fa, int sp) -> int { const int d = c - 6 * fa; return c >= 6 * K ? 6 * sp + (c - 6 * K) : (((unsigned)d < (unsigned)(6 * sp)) ? d : -1); };
     if (blk < nSblk) {
         if (P.skip_mask & 32) return;
         // stage the small index tables once per workgroup
         if (t < 2 * P.n_imu && t < 64) t_imu[t] = (t & 1) ? P.imu_j[t >> 1] : P.imu_i[t >> 1];
         if (t >= 64 && t < 64 + 4 * n_rel) { const int q = t - 64, f = q >> 2, b = q & 3; t_rel[q] = f < P.n_icp ? P.icp_ids[4 * f + b] : (b < 2 ? P.lps_ids[2 * (f - P.n_icp) + b] : -1); }
         if (t >= 128 && t < 128 + 2 * (K + 1) && t < 128 + 132) t_lch[t - 128] = P.lchunk_pose[t - 128];
+        for (int e = t; e < min(P.n_vwg, VIS_TAB); e += 8 * EPW) vtab[e] = vrec[e];
         __syncthreads();
         const int el = t & (EPW - 1), slice = t / EPW;
         const int idx = blk * EPW + el;
@@ -657,17 +545,23 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
         }
         double vs = 0.0, vdg = 0.0;
         if (ok && j < NV) {
-            const int tix = tri_idx(NV, i, j);
-            // eight records per round, every load issued before the first add (clamped record index + select: no predicated loads)
-            const double* vp = P.vpart + tix;
-            const double* vd_ = P.vpart + P.NVT + 2 * NV + i;
+            // eight records per round, every load issued before the first add (clamped record / element + select: no predicated loads)
             const int nw = P.n_vwg, wlast = nw - 1;
             for (int w = slice; w < nw; w += 64) {
                 double a[8], d[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int wc = min(w + 8 * u, wlast); a[u] = vp[(size_t)wc * P.VP]; d[u] = (i == j) ? vd_[(size_t)wc * P.VP] : 0.0; }
+                for (int u = 0; u < 8; ++u) {
+                    const int4 ds = vdesc(min(w + 8 * u, wlast));
+                    const int T = ds.w, il_ = vlocal(i, ds.y, ds.z), jl_ = vlocal(j, ds.y, ds.z);
+                    const bool in = il_ >= 0 && jl_ >= 0 && w + 8 * u < nw;
+                    const int il = in ? il_ : 0, jl = in ? jl_ : 0, I = il >> 4, J = jl >> 4;
+                    const double* r = P.vpart + (size_t)ds.x * 16;
+                    const double va = r[(I * T - ((I * (I - 1)) >> 1) + (J - I)) * 256 + (il & 15) * 16 + (jl & 15)];
+                    const double vd_ = (i == j) ? r[vis_ntile(T) * 256 + 16 * T + il] : 0.0;
+                    a[u] = in ? va : 0.0; d[u] = in ? vd_ : 0.0;
+                }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const bool in = w + 8 * u < nw; vs += in ? a[u] : 0.0; vdg += in ? d[u] : 0.0; }
+                for (int u = 0; u < 8; ++u) { vs += a[u]; vdg += d[u]; }
             }
         }
         // the non-visual contributions are spread over the 8 slices of an entry
@@ -713,6 +607,7 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
         if (t < 2 * P.n_imu && t < 64) t_imu[t] = (t & 1) ? P.imu_j[t >> 1] : P.imu_i[t >> 1];
         if (t >= 64 && t < 64 + 4 * n_rel) { const int q = t - 64, f = q >> 2, b = q & 3; t_rel[q] = f < P.n_icp ? P.icp_ids[4 * f + b] : (b < 2 ? P.lps_ids[2 * (f - P.n_icp) + b] : -1); }
         if (t >= 128 && t < 128 + 2 * (K + 1) && t < 128 + 132) t_lch[t - 128] = P.lchunk_pose[t - 128];
+        for (int e = t; e < min(P.n_vwg, VIS_TAB); e += 8 * EPW) vtab[e] = vrec[e];
         __syncthreads();
         const int el = t & (EPW - 1), slice = t / EPW;
         const int v = (blk - nSblk) * EPW + el;
@@ -720,7 +615,13 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
         const int which = v >= D ? 1 : 0, i = which ? v - D : v;       // 0: bc, 1: gred
         double acc = 0.0;
         if (ok) {
-            if (i < NV) for (int w = slice; w < P.n_vwg; w += 8) acc += P.vpart[(size_t)w * P.VP + P.NVT + which * NV + i];
+            if (i < NV) for (int w = slice; w < P.n_vwg; w += 8) {      // bc: the record's vector; gred: column r of its last tile column
+                const int4 ds = vdesc(w);
+                const int T = ds.w, il_ = vlocal(i, ds.y, ds.z), il = max(il_, 0), I = il >> 4;
+                const double* r = P.vpart + (size_t)ds.x * 16;
+                const double val = which ? r[(I * T - ((I * (I - 1)) >> 1) + (T - 1 - I)) * 256 + (il & 15) * 16 + ((6 * ds.z + 7) & 15)] : r[vis_ntile(T) * 256 + il];
+                acc += il_ >= 0 ? val : 0.0;
+            }
             if (i < 6 * K) {
                 const int k = i / 6, a = i - 6 * k;
                 for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += 8) acc += P.lpart[(size_t)c * 28 + 21 + a];      // (chunk records dealt to the eight slices, as above)
@@ -743,7 +644,7 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
     __shared__ double red[8];
     if (P.skip_mask & 64) return;
     double c = 0.0;
-    for (int w = t; w < P.n_vwg; w += 8 * EPW) c += P.vpart[(size_t)w * P.VP + P.NVT + 3 * NV];
+    for (int w = t; w < P.n_vwg; w += 8 * EPW) { const int4 ds = vrec[w]; c += P.vpart[(size_t)ds.x * 16 + vis_ntile(ds.w) * 256 + 32 * ds.w]; }
     for (int q = t; q < P.n_pchunk + P.n_echunk; q += 8 * EPW) c += P.lpart[(size_t)q * 28 + 27];
     for (int f = t; f < P.n_imu; f += 8 * EPW) c += P.ipart[(size_t)f * 931 + 930];
     for (int f = t; f < n_rel; f += 8 * EPW) c += rel0[(size_t)f * 601 + 600];
@@ -762,7 +663,8 @@ __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P, int n_gather) {
     const Ctl ctl = *P.ctl;
     if (ctl.done) return;
     if ((int)blockIdx.x >= n_gather) { vd::prechain_ww_tile(P, (int)blockIdx.x - n_gather); return; }
-    reduce_gather(P, ctl, (int)blockIdx.x);
+    __shared__ int4 vtab[VIS_TAB];
+    reduce_gather(P, ctl, (int)blockIdx.x, vtab);
 }
 
 // the IMU / prior workgroup `slot` of this launch has written its record (read by the chain workgroup of the same launch, prechain 2).
@@ -776,7 +678,7 @@ __device__ __forceinline__ void sweep_signal(const DevP& P, const Ctl& ctl, int 
 // The sweep: grid = n_imu + 2 (+ 1: prechain 2) + n_vwg + ceil(n_pchunk / 2) + ceil(n_echunk / 2) workgroups of VIL_SWEEP_THREADS threads.
 // Workgroup order: [imu x n_imu | prior | rel | (chain) | visual x n_vwg | plane | edge] -- the short roles the chain workgroup waits for
 // come first (roles: top of this file)
-template <bool MF>
+template <int TS>      // accumulator tiles per wave of the visual role
 __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O) {
     extern __shared__ double sm[];
     const Ctl ctl = *P.ctl;
@@ -803,7 +705,7 @@ __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O
     b -= 2;
     if (P.prechain == 2) { if (b == 0) { if (pre) vd::prechain_wg(P, ctl, O.jacobi_scaling, sm, 0, true); return; } b -= 1; }
     // visual workgroups next: the longest-running factor role
-    if (b < P.n_vwg) { if (!(P.skip_mask & 1)) vd::sweep_visual<MF>(P, O, ctl, b, x, sb, sm); return; }
+    if (b < P.n_vwg) { if (!(P.skip_mask & 1)) vd::sweep_visual<TS>(P, O, ctl, b, x, sb, sm); return; }
     b -= P.n_vwg;
     const int per = VIL_SWEEP_THREADS / 256, npw = (P.n_pchunk + per - 1) / per;
     if (b < npw) { if (!(P.skip_mask & 4)) vd::sweep_lidar<1>(P, O, b, x, sm); return; }

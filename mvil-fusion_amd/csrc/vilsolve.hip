@@ -178,6 +178,7 @@ struct vil_ctx {
     std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
     int n_blocks_sweep = 0, n_blocks_reduce = 0, n_gather_m = 0, n_ww = 0;      // n_ww: tiles of W W^T formed by extra workgroups of k_reduce (vil_prechain.hpp)
     size_t lds_sweep = 0, lds_step = 0, lds_reduce = 0;
+    int vis_gm = 0;                      // doubles of operand rows the largest visual chunk of the uploaded window needs (vil_sweep.hpp)
     size_t span = 0;               // doubles of one linear-system set (SysBuf::ar): the multi-GPU all-reduce message
     bool step_lds = false;
     int* d_status = nullptr;
@@ -556,48 +557,76 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             put(gl.data(), 4 * gl.size(), (void**)&P.glm_start); put(gac.data(), 4 * gac.size(), (void**)&P.glm_acol); put(gfc.data(), 4 * gfc.size(), (void**)&P.gfcol);
             P.vis_f0 = vis_f0;
         }
-        std::vector<int> vch;
-        // a visual workgroup's time grows with the factors of its chunk (rounds of work items), the kernel's with its slowest workgroup:
-        // chunks are closed at VIL_VCHUNK_FBAL factors (old landmarks carry up to K - 1 observations, new ones two), a single landmark may exceed it.
-        // Every workgroup also writes one partial record of NV (NV + 1) / 2 doubles that k_reduce reads back: measured K = 10 (20 kB records)
-        // 32 factors: sweep 24.7 -> 22.5 us, reduce 15.0 -> 15.4; K = 20 (65 kB records): sweep 42 -> 60 us -- so only for the small records
-        int fbal = NV <= 80 ? VIL_VCHUNK_FBAL : VIL_VCHUNK_F;
-        if (const char* ev = VIL_TUNE_ENV("VIL_VFBAL")) fbal = std::max(1, atoi(ev));
-        P.vis_mf = (vd::vis_mfma(NV) && VIL_TUNE_ENV("VIL_NO_VMFMA") == nullptr) ? 1 : 0;
-        const int fcap = P.vis_mf ? VIS_MF : VIL_VCHUNK_F;      // (matrix-core path: the operand rows of a whole chunk sit in LDS)
-        static_assert(VIL_VCHUNK_FBAL <= VIS_MF && VIL_VCHUNK_LM <= VIS_LM && VIS_LM <= 16 && VIS_MF <= VIL_VCHUNK_F, "chunk bounds of the matrix-core path");
-        int vwg_max = 256;
-        if (const char* ev = VIL_TUNE_ENV("VIL_VWG")) vwg_max = std::max(1, atoi(ev));
-        auto chunks = [&](int fb, int lmcap) -> bool {
-            vch.clear(); P.vis_fmax = 1;
-            for (int l0 = 0; l0 < L;) {
-                int l1 = l0, nf = 0;
-                while (l1 < L && l1 - l0 < lmcap && nf + (lms[l1 + 1] - lms[l1]) <= fcap && (l1 == l0 || nf + (lms[l1 + 1] - lms[l1]) <= fb)) { nf += lms[l1 + 1] - lms[l1]; ++l1; }
-                if (l1 == l0) return false;   // a single landmark with more observations than a chunk holds
-                if (nf > 0) { vch.push_back(l0); vch.push_back(l1); vch.push_back(lms[l0]); vch.push_back(lms[l1]); P.vis_fmax = std::max(P.vis_fmax, nf); }      // landmark range, factor range
-                l0 = l1;
+        // ---- chunks of the visual role (vil_sweep.hpp: sweep_visual): landmarks sorted by (first frame, last frame) -- insertion order in a tracker's feature
+        //      list is already close to that -- and cut so that (a) a chunk fits the role's LDS (VIS_LM landmarks, VIS_MF factors, VIS_GM doubles of operand
+        //      rows at the row stride of ITS window), (b) the matrix-core work of a chunk, (rows / 4) x tiles of its window, stays under a cap found by
+        //      bisection: the smallest one that gives every chunk a compute unit of its own in the first round of the launch.  A chunk below
+        //      VIL_VCHUNK_FBAL factors is not closed for balance (a workgroup's fixed cost is ~8 us whatever it holds).
+        {
+            std::vector<int> fmin(std::max(L, 1), K), fmax(std::max(L, 1), -1), anch(std::max(L, 1), 0), order;
+            if (ws) { for (int l = 0; l < L; ++l) { anch[l] = fmin[l] = ws->lm_startf[l]; fmax[l] = ws->lm_startf[l] + ws->lm_nobs[l] - 1; } }
+            else for (int f = 0; f < p->n_vis; ++f) {
+                const int l = p->vis_l[f], lo = std::min(p->vis_i[f], p->vis_j[f]), hi = std::max(p->vis_i[f], p->vis_j[f]);
+                anch[l] = p->vis_i[f]; fmin[l] = std::min(fmin[l], lo); fmax[l] = std::max(fmax[l], hi);
             }
-            return true;
-        };
-        if (!chunks(std::min(fbal, fcap), VIL_VCHUNK_LM)) return VIL_ERR_UNSUPPORTED;
-        // more chunks than workgroups (configs[2]: 12 k factors): a workgroup would walk two chunks one after the other -- evaluation, operand fill and
-        // matrix-core passes twice, barriers in between; ONE chunk of up to VIS_LM landmarks / VIS_MF factors costs little more than one of 32 (a
-        // thread per factor either way, 28 instead of 20 k-steps per tile): k_sweep at configs[2] 34.4 -> 25.8 us, 8.68 k -> 9.79 k it/s on one box; forced on
-        // configs[1] (48 records instead of 96, half the gather traffic): 11.40 k -> 10.92 k it/s -- not worth it where every chunk has its own workgroup
-        if (P.vis_mf && ((int)vch.size() / 4 > vwg_max || VIL_TUNE_ENV("VIL_WIDE") != nullptr) && VIL_TUNE_ENV("VIL_NO_WIDE") == nullptr && !chunks(fcap, VIS_LM)) return VIL_ERR_UNSUPPORTED;
-        P.n_vchunk = (int)vch.size() / 4;
-        put(vch.data(), 4 * vch.size(), (void**)&P.vchunk);
-        // group the sub-chunks into visual workgroups (each owns one LDS triangle / one partial record)
-        P.n_vwg = std::min(P.n_vchunk, vwg_max);
-        std::vector<int> vw;
-        for (int w = 0; w < P.n_vwg; ++w) {              // chunk range + the first chunk's ranges: a workgroup starts after ONE table look-up
-            const int s0 = (int)((long long)P.n_vchunk * w / P.n_vwg), s1 = (int)((long long)P.n_vchunk * (w + 1) / P.n_vwg);
-            vw.push_back(s0); vw.push_back(s1); vw.push_back(0); vw.push_back(0);
-            for (int q = 0; q < 4; ++q) vw.push_back(vch[4 * (size_t)s0 + q]);
+            for (int l = 0; l < L; ++l) if (lms[l + 1] > lms[l]) order.push_back(l);
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return fmin[a] != fmin[b] ? fmin[a] < fmin[b] : (fmax[a] != fmax[b] ? fmax[a] < fmax[b] : a < b); });
+            struct Chunk { int p0, nl, nf, fa, span; };
+            std::vector<Chunk> ch;
+            auto cost = [](int nf, int T) { return (vd::vis_rows(nf) / 4 + 4) * vd::vis_ntile(T); };
+            auto cut = [&](int cap) -> bool {
+                ch.clear();
+                Chunk cc{0, 0, 0, 0, 0}; int wlo = K, whi = -1;
+                for (int q = 0; q < (int)order.size(); ++q) {
+                    const int l = order[q], n = lms[l + 1] - lms[l];
+                    const int lo = std::min(wlo, fmin[l]), hi = std::max(whi, fmax[l]), T = vd::vis_tiles(hi - lo + 1);
+                    const bool fits = cc.nl < VIS_LM && cc.nf + n <= VIS_MF && vd::vis_gm_doubles(cc.nf + n, T) <= VIS_GM;
+                    if (cc.nl > 0 && (!fits || (cc.nf >= VIL_VCHUNK_FBAL && cost(cc.nf + n, T) > cap))) {
+                        cc.fa = wlo; cc.span = whi - wlo + 1; ch.push_back(cc);
+                        cc = Chunk{q, 0, 0, 0, 0}; wlo = K; whi = -1;
+                    }
+                    if (cc.nl == 0 && (n > VIS_MF || vd::vis_gm_doubles(n, vd::vis_tiles(fmax[l] - fmin[l] + 1)) > VIS_GM)) return false;      // a landmark no chunk can hold
+                    cc.nl++; cc.nf += n; wlo = std::min(wlo, fmin[l]); whi = std::max(whi, fmax[l]);
+                }
+                if (cc.nl > 0) { cc.fa = wlo; cc.span = whi - wlo + 1; ch.push_back(cc); }
+                return true;
+            };
+            int npt = std::max(p->n_plane, 0), net = std::max(p->n_edge, 0);           // LiDAR points of this upload (resident slabs: what they hold)
+            if (p->n_plane == VIL_LIDAR_RESIDENT) for (auto& sl : c->slabs) { npt += sl.np; net += sl.ne; }
+            int vwg_max = std::max(64, 256 - (p->n_imu + 3 + (npt + 511) / 512 + (net + 511) / 512));
+            if (const char* ev = VIL_TUNE_ENV("VIL_VWG")) vwg_max = std::max(1, atoi(ev));
+            int lo = cost(VIL_VCHUNK_FBAL, 1), hi = cost(VIS_MF, VIS_TMAX);
+            if (const char* ev = VIL_TUNE_ENV("VIL_VCAP")) lo = hi = std::max(1, atoi(ev));
+            if (!cut(lo)) return VIL_ERR_UNSUPPORTED;
+            if ((int)ch.size() > vwg_max) {
+                while (lo < hi) { const int mid = (lo + hi) / 2; cut(mid); if ((int)ch.size() <= vwg_max) hi = mid; else lo = mid + 1; }
+                cut(hi);
+            }
+            P.n_vwg = (int)ch.size();
+            std::vector<int> vw(8 * (size_t)std::max(P.n_vwg, 1), 0), vr(4 * (size_t)std::max(P.n_vwg, 1), 0), vl(4 * std::max(order.size(), (size_t)1), 0), vf(2 * (size_t)std::max(n_vis, 1), 0);
+            size_t roff = 0; int tmax = 1, gmax = 0, fpos = 0;
+            for (int w = 0; w < P.n_vwg; ++w) {
+                const Chunk& cc = ch[w];
+                const int T = vd::vis_tiles(cc.span);
+                int* d = &vw[8 * (size_t)w];
+                d[0] = cc.p0; d[1] = cc.nl; d[2] = fpos; d[3] = cc.nf; d[4] = cc.fa; d[5] = cc.span; d[6] = T; d[7] = (int)(roff / 16);
+                int* r = &vr[4 * (size_t)w]; r[0] = d[7]; r[1] = cc.fa; r[2] = cc.span; r[3] = T;
+                int floc = 0;
+                for (int q = 0; q < cc.nl; ++q) {
+                    const int l = order[cc.p0 + q], n = lms[l + 1] - lms[l];
+                    int* e = &vl[4 * (size_t)(cc.p0 + q)]; e[0] = l; e[1] = floc; e[2] = n; e[3] = anch[l];
+                    for (int k = 0; k < n; ++k) { vf[2 * (size_t)(fpos + floc + k)] = lms[l] + k; vf[2 * (size_t)(fpos + floc + k) + 1] = q; }
+                    floc += n;
+                }
+                fpos += cc.nf; roff += (size_t)vd::vis_rec_doubles(T);
+                tmax = std::max(tmax, T); gmax = std::max(gmax, vd::vis_gm_doubles(cc.nf, T));
+            }
+            P.vis_ts = vd::vis_slots(tmax) <= 2 ? 2 : 5;
+            c->vis_gm = gmax;
+            put(vw.data(), 4 * vw.size(), (void**)&P.vwg); put(vr.data(), 4 * vr.size(), (void**)&P.vrec);
+            put(vl.data(), 4 * vl.size(), (void**)&P.vlm); put(vf.data(), 4 * vf.size(), (void**)&P.vfac);
+            put(nullptr, 8 * std::max(roff, (size_t)16), (void**)&P.vpart);
         }
-        put(vw.data(), 4 * vw.size(), (void**)&P.vwg);
-        P.NVT = NV * (NV + 1) / 2; P.VP = P.NVT + 3 * NV + 1;
-        put(nullptr, 8 * (size_t)std::max(P.n_vwg, 1) * P.VP, (void**)&P.vpart);
     }
     UPTICK("visual");
     // LiDAR
@@ -854,12 +883,16 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     c->P.hctl = c->d_hctl; c->P.hseq = c->d_hseq; c->P.hstate = c->d_hstate;
     c->P.xorig = c->d_x0; c->P.gauge_on = c->gauge_on ? 1 : 0; c->P.setup_stat = c->d_status;
     { const int per = VIL_SWEEP_THREADS / 256; c->n_blocks_sweep = P.n_imu + P.n_vwg + (P.n_pchunk + per - 1) / per + (P.n_echunk + per - 1) / per + 2; }
-    // visual workgroups: packed triangle (windows up to K = 12: upper 16 x 16 tiles + the dense operand rows of the matrix cores), three vectors, the staged
-    // factors, the landmark records
-    c->lds_sweep = sizeof(double) * (size_t)((P.vis_mf ? vd::vis_ntile(NV) * 256 + (2 * VIS_MF + 16) * VIS_RS + 16 : P.NVT) + 3 * NV + (P.vis_mf ? VIS_MF : VIL_VCHUNK_F) * VF_STRIDE + VIS_LM * 16 + 32 + VIL_VCHUNK_F + 8 + VIS_LM + 8);
+    // visual workgroups: the staged factors, the landmark records, the dense operand rows of the largest chunk
+    c->lds_sweep = sizeof(double) * (size_t)(VIS_LDS_FIXED + c->vis_gm);
     if (c->lds_sweep < 8 * 2048) c->lds_sweep = 8 * 2048;
     if (c->lds_sweep > 160 * 1024) return VIL_ERR_UNSUPPORTED;
-    if ((int)c->lds_sweep > c->attr_sweep[P.vis_mf]) { HIPCHK(hipFuncSetAttribute(P.vis_mf ? (const void*)k_sweep<true> : (const void*)k_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep)); c->attr_sweep[P.vis_mf] = (int)c->lds_sweep; }
+    auto grant_sweep = [&]() -> int {
+        const int v = P.vis_ts == 2 ? 0 : 1;
+        if ((int)c->lds_sweep > c->attr_sweep[v]) { HIPCHK(hipFuncSetAttribute(v ? (const void*)k_sweep<5> : (const void*)k_sweep<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep)); c->attr_sweep[v] = (int)c->lds_sweep; }
+        return VIL_OK;
+    };
+    { const int gs = grant_sweep(); if (gs != VIL_OK) return gs; }
     c->n_blocks_reduce = (D * (D + 1) / 2 + RED_EPW - 1) / RED_EPW + (2 * D + RED_EPW - 1) / RED_EPW + 1;
     // ---- step kernel variant: the speed-bias part of the reduced matrix is a chain whenever every IMU factor couples (k, k+1)
     //      and the prior's speed-bias blocks are neighbours (VINS: exactly one) -> vil_chain.hpp; anything else: dense path
@@ -896,7 +929,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             else {
                 c->lds_step = lds3;
                 c->lds_sweep = std::max(c->lds_sweep, ldsc);      // the chain workgroup rides in k_sweep
-                if ((int)c->lds_sweep > c->attr_sweep[P.vis_mf]) { HIPCHK(hipFuncSetAttribute(P.vis_mf ? (const void*)k_sweep<true> : (const void*)k_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_sweep)); c->attr_sweep[P.vis_mf] = (int)c->lds_sweep; }
+                { const int gs = grant_sweep(); if (gs != VIL_OK) return gs; }
                 c->n_blocks_sweep += 1;
             }
         }
@@ -1091,8 +1124,8 @@ static DevP view(const vil_ctx* c, int which) {
     return P;
 }
 static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
-    if (c->P.vis_mf) hipLaunchKernelGGL(k_sweep<true>, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, view(c, 0), so);
-    else hipLaunchKernelGGL(k_sweep<false>, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, view(c, 0), so);
+    if (c->P.vis_ts == 2) hipLaunchKernelGGL(k_sweep<2>, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, view(c, 0), so);
+    else hipLaunchKernelGGL(k_sweep<5>, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, view(c, 0), so);
     return VIL_OK;
 }
 static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr) {
