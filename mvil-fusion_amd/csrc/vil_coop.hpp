@@ -1,9 +1,12 @@
-// Persistent kernels whose workgroups wait for one another (k_vgicp_align, k_pose_solve, the helper workgroups of k_step) only
-// finish if ALL of their workgroups are resident at once.  Two guards, shared by the three translation units of the library:
+// Persistent kernels whose workgroups wait for one another (k_vgicp_align, k_pose_solve; in k_step the master and its helper workgroups and, in
+// the merged gather + step launch, the W W^T tile workgroups) only finish if ALL of their waiting workgroups are resident at once -- k_step's finite
+// roles (chain, gather) carry the lowest block indices and are dispatched before the workgroups that wait for them.
+// Two guards, shared by the three translation units of the library:
 //   capacity(): how many workgroups of a kernel the device can hold at the same time (occupancy x compute units) -- the grid of a
 //               persistent launch is clamped to it, and a kernel that cannot be resident at all takes its multi-launch fallback;
 //   gate():     a process-wide mutex held from the launch of a spinning kernel until its result has arrived, so that two of them
-//               (two contexts, two host threads) never sit half-resident on the device waiting for CUs the other one holds.
+//               (two contexts, two host threads) never sit half-resident on the device waiting for CUs the other one holds; vil_solve_resident
+//               takes it for the duration of a solve (except the ranks of an in-process communicator, which wait for each other's launches).
 // Every other kernel of the library is finite: it can delay a persistent launch, never starve it.
 #pragma once
 #include <hip/hip_runtime.h>

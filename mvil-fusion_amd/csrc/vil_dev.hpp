@@ -82,6 +82,7 @@ struct DevP {
     const int* vlm;               // sorted landmarks x 4: {landmark, chunk-local first factor, factors, anchor frame}
     const int* vfac;              // sorted factors x 2: {factor, chunk-local landmark}
     const int* vrec;              // n_vwg x 4: {record offset / 16, first frame, frames, T} (what the gather needs of vwg)
+    const int* vwend;             // K: chunks whose first frame is <= f (the chunks are sorted by first frame)
     double* vpart;                // the records: per chunk T (T + 1) / 2 upper 16 x 16 tiles of its window | bc 16 T | diag 16 T | cost (+ padding to 16)
     double* lpart;                // (n_pchunk + n_echunk) x 28  [21 upper 6x6 | 6 g | cost]
     const int* lchunk_pose;       // 2 x (K+1): chunk ranges per pose (plane, edge)
@@ -124,7 +125,7 @@ struct DevP {
     // gather + step in ONE launch (rs_merged): grid = [master | helpers | chain | W W^T tiles (n_ww) | gather (n_gather)]; a workgroup that is
     // done posts the launch epoch in its flag -- gflag[n_gather], chflag, wwflag[n_ww] -- and the master / helpers / tile workgroups wait on them
     int rs_merged, n_ww, n_gather; int* gflag; int* chflag; int* wwflag;
-    double* chW; double* chLdg; double* chLsb; double* chSc; double* chDc; double* chZ; double* chQ; int* chOk; double* chWW;
+    double* chW; double* chLraw; double* chLdg; double* chLsb; double* chSc; double* chDc; double* chZ; double* chQ; int* chOk; double* chWW;
 };
 
 __host__ __device__ inline int xo_pose(const DevP& P, int k) { return 7 * k; }

@@ -21,15 +21,24 @@ __host__ __device__ inline void gauge_R2ypr(const double* R, double* ypr) {
     const double rl = atan2(R[2] * sin(y) - R[5] * cos(y), -R[1] * sin(y) + R[4] * cos(y));
     ypr[0] = y / M_PI * 180.0; ypr[1] = pch / M_PI * 180.0; ypr[2] = rl / M_PI * 180.0;
 }
-__host__ __device__ inline void gauge_R2q(const double* R, double* q /*xyzw*/) {
+__host__ __device__ inline void gauge_R2q(const double* R, double* q /*xyzw*/) {      // Eigen's Quaternion(Matrix3): the three off-trace cases written out (no dynamic register indexing: scratch)
     double t = R[0] + R[4] + R[8];
     if (t > 0) { t = sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t; }
     else {
-        int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > R[4 * i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
-        q[i] = 0.5 * t; t = 0.5 / t;
-        q[3] = (R[3 * k + j] - R[3 * j + k]) * t; q[j] = (R[3 * j + i] + R[3 * i + j]) * t; q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+        int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > (i ? R[4] : R[0])) i = 2;
+        if (i == 0) {          // j = 1, k = 2
+            t = sqrt(R[0] - R[4] - R[8] + 1.0);
+            q[0] = 0.5 * t; t = 0.5 / t;
+            q[3] = (R[7] - R[5]) * t; q[1] = (R[3] + R[1]) * t; q[2] = (R[6] + R[2]) * t;
+        } else if (i == 1) {   // j = 2, k = 0
+            t = sqrt(R[4] - R[8] - R[0] + 1.0);
+            q[1] = 0.5 * t; t = 0.5 / t;
+            q[3] = (R[2] - R[6]) * t; q[2] = (R[7] + R[5]) * t; q[0] = (R[1] + R[3]) * t;
+        } else {               // j = 0, k = 1
+            t = sqrt(R[8] - R[0] - R[4] + 1.0);
+            q[2] = 0.5 * t; t = 0.5 / t;
+            q[3] = (R[3] - R[1]) * t; q[0] = (R[2] + R[6]) * t; q[1] = (R[5] + R[7]) * t;
+        }
     }
 }
 __host__ __device__ inline void gauge_rot(const double* pose0_before, const double* pose0_now, double* rot) {
@@ -69,40 +78,48 @@ __host__ __device__ inline void gauge_fix_core(const double* pose0_before, int K
 
 namespace vd {
 // all threads of ONE workgroup; returns after the sequence word has been stored
-// (cur / status / gen: the scalars of Ctl the caller already holds; the record itself is copied from device memory)
-__device__ __forceinline__ void solve_finish(const DevP& P, const int cur, const int status, const int gen) {
-    const int t = threadIdx.x, NT = blockDim.x, K = P.K, NS = P.NS;
-    const double* xs = P.x[cur];
-    double* x = P.x[0]; double* xb = P.x[1];
-    __shared__ double cam[16 * 20 + 8];                  // camera part of the final state (K <= 20)
+// (cur / status / gen: the scalars of Ctl the caller already holds; the record itself is copied from device memory -- or from `lctl`, the caller's
+//  LDS copy, when the step kernel that ended the solve finishes it itself: its own loads of P.ctl date from the head of the launch)
+// cam: 16 K + 8 + 12 doubles of LDS for the camera part of the final state and the gauge correction
+// (what it needs of DevP travels as scalar arguments: with a reference to the kernel's 1.3 kB parameter block -- or a struct of its fields -- used from
+//  the five exits of the step kernel, the block / the struct landed in scratch memory, which the runtime then provides on every launch: +45 us each)
+__device__ __forceinline__ void solve_finish(double* const x, double* const xb, const double* const xorig, double* const hs, Ctl* const dctl, Ctl* const hctl, int* const hseq,
+                                             const int K, const int NS, const int gauge_on, const int cur, const int status, const int gen, double* const cam, const Ctl* const lctl = nullptr) {
+    const int t = threadIdx.x, NT = blockDim.x;
+    const double* xs = cur ? xb : x;
     const int NC = 16 * K + 8;
+    const int o_ex = 16 * K;                            // (xo_pose(k) = 7 k, xo_sb(k) = 7 K + 9 k, xo_ex = 16 K: vil_dev.hpp)
     for (int i = t; i < NC; i += NT) cam[i] = xs[i];
     __syncthreads();
-    if (P.gauge_on && status == 0) {
-        // one thread per frame (+ one for the extrinsic); every thread derives the yaw correction from frame 0 itself
-        double rot[9], p0[3];
-        gauge_rot(P.xorig + xo_pose(P, 0), cam + xo_pose(P, 0), rot);
-        for (int i = 0; i < 3; ++i) p0[i] = cam[xo_pose(P, 0) + i];
+    if (gauge_on && status == 0) {
+        // the yaw (or, near the singular pitch, the full) correction is derived from frame 0 by ONE lane and handed on through LDS (behind the camera part:
+        // cam has 16 K + 8 + 12 doubles); then one thread per frame (+ one for the extrinsic)
+        double* const gr = cam + NC;
+        if (t == 0) { double rot[9]; gauge_rot(xorig, cam, rot); for (int i = 0; i < 9; ++i) gr[i] = rot[i]; for (int i = 0; i < 3; ++i) gr[9 + i] = cam[i]; }
         __syncthreads();
-        if (t < K) gauge_frame(rot, p0, P.xorig + xo_pose(P, 0), cam + xo_pose(P, t), cam + xo_sb(P, t));
-        else if (t == K) gauge_ex(cam + xo_ex(P));
+        if (t <= K) {
+            double rot[9], p0[3];
+            for (int i = 0; i < 9; ++i) rot[i] = gr[i];
+            for (int i = 0; i < 3; ++i) p0[i] = gr[9 + i];
+            if (t < K) gauge_frame(rot, p0, xorig, cam + 7 * t, cam + 7 * K + 9 * t);
+            else gauge_ex(cam + o_ex);
+        }
         __syncthreads();
     }
-    double* hs = P.hstate;
     for (int i = t; i < NS; i += NT) {
         const double v = i < NC ? cam[i] : xs[i];
         x[i] = v; xb[i] = v;
         if (hs) hs[i] = v;
     }
-    if (P.hctl) {
-        const double* src = (const double*)P.ctl; double* h = (double*)P.hctl;
+    if (hctl) {
+        const double* src = lctl ? (const double*)lctl : (const double*)dctl; double* h = (double*)hctl;
         for (int i = t; i < (int)(sizeof(Ctl) / 8); i += NT) h[i] = src[i];
     }
     __threadfence_system();                              // every thread's stores (device and host) before the barrier: __syncthreads alone does not wait for them
     __syncthreads();
     if (t == 0) {
-        P.ctl->outd = 1;
-        if (P.hseq) __hip_atomic_store(P.hseq, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        dctl->outd = 1;
+        if (hseq) __hip_atomic_store(hseq, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 }  // namespace vd
@@ -112,6 +129,7 @@ __device__ __forceinline__ void solve_finish(const DevP& P, const int cur, const
 // estimator.cpp:1411): mark it done with that termination and write the accepted state out.
 __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_finish(DevP P, int term) {
     __shared__ int sc[4];
+    __shared__ double cam[16 * 20 + 8 + 12];             // camera part of the final state (K <= 20) + the gauge rotation / origin
     if (threadIdx.x == 0) {
         Ctl* c = P.ctl;
         if (!c->done && term >= 0) { c->done = 1; c->term = term; }
@@ -124,5 +142,19 @@ __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_finish(DevP P, int term) 
     }
     __syncthreads();
     if (sc[0]) return;
-    vd::solve_finish(P, sc[1], sc[2], sc[3]);
+    vd::solve_finish(P.x[0], P.x[1], P.xorig, P.hstate, P.ctl, P.hctl, P.hseq, P.K, P.NS, P.gauge_on, sc[1], sc[2], sc[3], cam);
+}
+
+// Start of a solve / linearisation / marginalisation sweep: the trust-region record is written by a kernel from its ARGUMENTS (no pinned staging
+// buffer whose contents a later call could overwrite before an asynchronous copy has read it).  reset: both state buffers are first restored to the
+// state the window was uploaded with (vil_reset_state + vil_solve_resident of a bench loop: one launch).
+__global__ __launch_bounds__(256) void k_solve_init(Ctl* ctl, int gen, double radius, double mu, int lin_mode) {
+    double* w = (double*)ctl;
+    for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += blockDim.x) w[i] = 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) { ctl->gen = gen; ctl->first = 1; ctl->radius = radius; ctl->mu = mu; ctl->lin_mode = lin_mode; }
+}
+__global__ __launch_bounds__(256) void k_state_reset(double* x0, double* x1, const double* src, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const double v = src[i]; x0[i] = v; x1[i] = v; }
 }

@@ -60,6 +60,35 @@ struct ChainSrcSlab {
     __device__ __forceinline__ void wput(double* p, double v) const { st_ag(p, v); }      // read by the tile workgroups and the master of this launch
 };
 
+// Column cc of the INVERSE of the factored diagonal block k (x = L^-1 e_c by forward substitution) and row cc of M_k = L_kk^-T Ls_k^T (the lane that
+// holds column cc of the inverse forms it): the master's back substitution is x_k = L_kk^-T t_k - M_k x_next, ONE nine-term product per block instead of
+// two with an LDS round trip in between.  (The middle block has no Ls: its row is never read.)  Ldg / Lsb: the chain's factors (LDS or global).
+__device__ __forceinline__ void chain_inverse_block(const DevP& P, const double* Ldg, const double* Lsb, const int k, const int cc) {
+    const double* l = Ldg + 54 * k; const double* r = l + 45;
+    double x[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+        double acc = p == cc ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < p; ++q) acc -= l[(p * (p + 1) >> 1) + q] * x[q];
+        x[p] = p < cc ? 0.0 : acc * r[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 9; ++p) if (p >= cc) st_ag(P.chLdg + 54 * k + (p * (p + 1) >> 1) + cc, x[p]);
+    const double* ls = Lsb + 82 * k;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) { if (p & 1) a1 += x[p] * ls[i * 9 + p]; else a0 += x[p] * ls[i * 9 + p]; }
+        st_ag(P.chLsb + 82 * k + 9 * cc + i, k == (P.K >> 1) ? 0.0 : a0 + a1);
+    }
+}
+// the same for every block from the raw factors the in-sweep chain workgroup left (one workgroup of the gather launch, K > 12)
+__device__ __forceinline__ void prechain_inverses(const DevP& P) {
+    for (int it = threadIdx.x; it < 9 * P.K; it += blockDim.x) chain_inverse_block(P, P.chLraw, P.chLraw + 54 * P.K, it / 9, it % 9);
+}
+
 // the chain workgroup (all threads of the block enter; dynamic LDS >= prechain_lds_doubles(K)); the IMU / prior records are complete
 // epoch: the launch's flag value; P.chflag[1] is posted as soon as the chain columns' scales are out (the master's vector pass reads them).
 // wait_records: the workgroup rides in k_sweep (windows too large for the merged launch) and spins until the IMU / prior workgroups of
@@ -77,22 +106,25 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     const ChainSlab B = chain_slab(uB + even_up(NB), K);
     if (t < 8) L.flag[t] = 0;
     // ---- gather of the chain part of S' out of the IMU / prior records through the host-built table: eight entries per thread and round (one round at
-    //      K = 10).  Two dependent round trips -- entries, then their sources -- and NOTHING before them: the zeroing of the slab (a gather target: entries
+    //      K = 10, two at K = 20).  Two dependent round trips -- entries, then their sources -- and NOTHING before them: the zeroing of the slab (a gather target: entries
     //      without a source, pose rows of far frames, stay zero) and the small copies run while the sources are in flight; only the stores wait for the barrier
     const int4* tab = (const int4*)P.chtab;
     const int n = P.n_chtab;
     double* slab = B.dg;
-    int4 q[8]; double a[8], b[8], c[8];
+    constexpr int QN = 8;                              // entries per thread and round (K = 10: one round; K = 20, 6840 entries: two)
+    int4 q[QN], q2[QN]; double a[QN], b[QN], c[QN];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) q[u] = tab[min(t + u * NT, n - 1)];
+    for (int u = 0; u < QN; ++u) { q[u] = tab[min(t + u * NT, n - 1)]; q2[u] = tab[min(t + (QN + u) * NT, n - 1)]; }      // (the second round's entries too: no table round trip behind the flags)
     const double sc_prev = (t < NB && !ctl.first) ? P.Sc[NP + t] : 0.0;
     const int pqv = P.chpq[min(t, NB - 1)];
+    const double* const pHs = P.pn > 0 ? P.pH : P.mpart;
+    // (IMU / prior records: agent-scope loads -- inside k_sweep they were written by workgroups of this launch; unconditional loads + selects)
     auto sources = [&]() {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            a[u] = P.ipart[max(q[u].y, 0)]; b[u] = P.ipart[max(q[u].z, 0)];
+        for (int u = 0; u < QN; ++u) {
+            a[u] = ld_ag(P.ipart + max(q[u].y, 0)); b[u] = ld_ag(P.ipart + max(q[u].z, 0));
             const int cw = q[u].w;
-            c[u] = cw >= 0 ? P.pH[cw] : P.mpart[max(-cw - 2, 0)];
+            c[u] = ld_ag(cw >= 0 ? pHs + cw : P.mpart + max(-cw - 2, 0));      // (no prior: cw is never >= 0)
         }
     };
     if (!wait_records) sources();
@@ -101,18 +133,19 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     for (int e = t + NT; e < NB; e += NT) B.pq[e] = P.chpq[e];
     if (wait_records) {
         const int ep = (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u);       // (sweep_signal, vil_sweep.hpp)
-        if (t <= P.n_imu && (t < P.n_imu || P.pn > 0)) while (__hip_atomic_load(P.swflag + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ep) __builtin_amdgcn_s_sleep(2);
+        if (t <= P.n_imu && (t < P.n_imu || P.pn > 0)) while (ld_ag(P.swflag + t) != ep) __builtin_amdgcn_s_sleep(1);
     }
     __syncthreads();
+    PSTAMP(31);
     if (wait_records) sources();                           // (inside k_sweep the records are complete only behind the flags)
-    for (int e0 = t; e0 < n; e0 += 8 * NT) {
+    for (int e0 = t; e0 < n; e0 += QN * NT) {
         if (e0 != t) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) q[u] = tab[min(e0 + u * NT, n - 1)];
+            for (int u = 0; u < QN; ++u) q[u] = e0 == t + QN * NT ? q2[u] : tab[min(e0 + u * NT, n - 1)];
             sources();
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (e0 + u * NT < n) {
+        for (int u = 0; u < QN; ++u) if (e0 + u * NT < n) {
             const double v = (q[u].y >= 0 ? a[u] : 0.0) + (q[u].z >= 0 ? b[u] : 0.0) + (q[u].w != -1 ? c[u] : 0.0);
             slab[q[u].x] = v;
         }
@@ -136,6 +169,19 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
         if (t == 384) st_ag(P.chflag + 1, epoch);
     }
     PSTAMP(14);
+    // in-sweep chain (K > 12): the factored blocks leave for prechain_inverses (a workgroup of the gather launch) as they are published, on the two waves
+    // the elimination leaves idle -- 54 + 82 doubles per block, three stores per lane; from the recursion wave itself (one lane, 54 stores in a row) they
+    // cost it 1.7 us per block, as a pass after the elimination 5 us at the end of the launch's longest workgroup
+    if (wait_records && t >= 384) {
+        const int d = (t >> 6) - 6, lane = t & 63, m = K >> 1, nd = d == 0 ? m : K - 1 - m;
+        for (int st = 0; st <= nd; ++st) {
+            int k;
+            if (st < nd) { chain_wait(L.flag + d, st + 1); k = d == 0 ? st : K - 1 - st; }
+            else { if (d != 0) break; chain_wait(L.flag + 2, 1); k = m; }           // the middle block: factored last
+            if (lane < 54) st_ag(P.chLraw + 54 * k + lane, L.Ldg[54 * k + lane]);
+            for (int e = lane; e < 82; e += 64) st_ag(P.chLraw + 54 * K + 82 * k + e, L.Lsb[82 * k + e]);
+        }
+    }
     double qc = 0.0;
     chain_eliminate<true>(src, K, NP, P.chain_rs, P.chW, L, qc, P.dbg);      // (P.dbg: stamps of the VIL_STAMPS build)
     PSTAMP(15);
@@ -147,35 +193,17 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every thread's W^T / chZ / chQ stores are out ...
     __syncthreads();
     if (t == 0) st_ag(P.chflag, epoch);                  // ... W^T is complete: the tile workgroups start
-    // ---- off the critical path (the master needs these for the chain back substitution, 30 us from now): the INVERSES of the factored
-    //      diagonal blocks (one column per lane: x = L^-1 e_c by forward substitution) and the products M_k = L_kk^-T Ls_k^T with the sub-diagonal blocks
-    for (int it = t; it < 9 * K; it += NT) {
-        const int k = it / 9, cc = it - 9 * k;
-        const double* l = L.Ldg + 54 * k; const double* r = l + 45;
-        double x[9];
-#pragma unroll
-        for (int p = 0; p < 9; ++p) {
-            double acc = p == cc ? 1.0 : 0.0;
-#pragma unroll
-            for (int q = 0; q < p; ++q) acc -= l[(p * (p + 1) >> 1) + q] * x[q];
-            x[p] = p < cc ? 0.0 : acc * r[p];
-        }
-#pragma unroll
-        for (int p = 0; p < 9; ++p) if (p >= cc) st_ag(P.chLdg + 54 * k + (p * (p + 1) >> 1) + cc, x[p]);
-        // row cc of M_k = L_kk^-T Ls_k^T (this lane holds column cc of the inverse): the master's recursion is x_k = L_kk^-T t_k - M_k x_next, ONE nine-term
-        // product per block instead of two with an LDS round trip in between.  (The middle block has no Ls: its row is never read.)
-        const double* ls = L.Lsb + 82 * k;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int p = 0; p < 9; ++p) { if (p & 1) a1 += x[p] * ls[i * 9 + p]; else a0 += x[p] * ls[i * 9 + p]; }
-            st_ag(P.chLsb + 82 * k + 9 * cc + i, k == (K >> 1) ? 0.0 : a0 + a1);
-        }
+    // ---- off the critical path: what the master needs for the chain BACK substitution, 30 us from now (chain_inverse_block above).  Beside the gather
+    //      (merged launch) the 9 K columns are formed here, one per lane, and are ready long before they are read.  Inside k_sweep (K > 12) this workgroup
+    //      is the launch's longest and 7 us of dependent fp64 chains at its end would be 7 us of the iteration: the raw factors go out instead and a
+    //      workgroup of the gather launch forms the columns (prechain_inverses below).
+    //      (waves 6 / 7 stored them as they were published, above)
+    if (!wait_records) {
+        for (int it = t; it < 9 * K; it += NT) chain_inverse_block(P, L.Ldg, L.Lsb, it / 9, it % 9);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) st_ag(P.chflag + 2, epoch);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t == 0) st_ag(P.chflag + 2, epoch);
     PSTAMP(16);
 }
 

@@ -19,6 +19,7 @@
 
 #include "vil_dev.hpp"
 #include "vil_factors.hpp"
+#include "vil_finish.hpp"
 
 namespace vd {
 
@@ -35,11 +36,12 @@ struct StepShared {
     double sc[320], dcs[320], gr[320], gn[320];   // Sc, dogleg diagonal, gradient_, gauss_newton_step_ (camera part)
     double gd[320];                               // reduced gradient (rhs row of M): staged once, the packing loop must not touch global memory
     double rt[320];                               // Sc / dogleg diagonal: the candidate step is formed without a divide
-    double x0[328];                               // camera part of x_cur (16K + 8 doubles), fetched while the system is being solved
+    double x0[344];                               // camera part of x_cur (16K + 8 doubles), fetched while the system is being solved
     unsigned char cst[48];                        // pose_const[K] | sb_const[K]
     double hs[12];                                // the helpers' sums, gathered by a spare wave during the chain back substitution
     int need, was_first, ok, cok;
     long long tacc[6];
+    struct Fin { double* x0; double* x1; const double* xorig; double* hs; Ctl* ctl; Ctl* hctl; int* hseq; int K, NS, gauge; } fin;      // arguments of solve_finish, parked at the head of the launch
 };
 
 // block-wide sum(a), sum(b) and sum-or-max(c) with one pair of barriers
@@ -953,11 +955,10 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
 // and six sums (|gn_l|^2, gn_l . g_l, |la|^2, la . lb, |lb|^2, |lambda|^2); the candidate inverse depth lambda + cg la + cn lb is
 // formed by the NEXT sweep's visual workgroups from the two dogleg coefficients in Ctl, and its norm follows from the sums.
 // With helper workgroups (grid = 1 + n_help) that pass runs on their CUs while the master back-substitutes the chain.
-template <bool LDSM, int CHAIN = 0>
-__global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) {
+// step_body: everything of the launch; `ended` is set (by every thread of the master) on the exits that may have ended the solve.
+template <bool LDSM, int CHAIN>
+__device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd::StepShared& s, double* const Alds, bool& ended) {
     using namespace vd;
-    __shared__ StepShared s;
-    extern __shared__ double Alds[];
     const int t = threadIdx.x, NT = blockDim.x;
     const int D = P.D, L = P.L;
     // The grid is 1 + P.n_help workgroups: the extra ones run the same judge on their own copy of Ctl and
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     {   // Ctl (1.5 kB with its traces) into LDS: one coalesced load per lane, not 190 loads of a lone lane with everybody waiting at the barrier
         const double* src = (const double*)P.ctl; double* dst = (double*)&s.c;
         for (int i = t; i < (int)(sizeof(Ctl) / 8); i += NT) dst[i] = src[i];
-        if (t == 0) { s.need = 0; s.was_first = 0; s.ok = 1; }
+        if (t == 0) { s.need = 0; s.was_first = 0; s.ok = 1; s.fin = StepShared::Fin{P.x[0], P.x[1], P.xorig, P.hstate, P.ctl, P.hctl, P.hseq, P.K, P.NS, P.gauge_on}; }
     }
     for (int q = t; q < 256; q += NT) {      // triangular tile index -> (tile row, tile col)
         int Ir = (int)((sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
@@ -1236,7 +1237,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         } else post(P.hflag + hk);
         return;
     }
-    if (s.c.done) { if (t < 64) { wait_helpers(); store_ctl(); } return; }
+    if (s.c.done) { if (t < 64) { wait_helpers(); store_ctl(); } ended = true; return; }
     for (int i = t; i < 16 * P.K + 8; i += NT) s.x0[i] = x[i];          // (read after several barriers)
     for (int k = t; k < 2 * P.K; k += NT) s.cst[k] = k < P.K ? (P.pose_const ? P.pose_const[k] : 0) : (P.sb_const ? P.sb_const[k - P.K] : 0);
     bool xpub = false;                                 // the master owes the waiting helpers an xflag on every path through the need branch
@@ -1365,6 +1366,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             if (!xpub) publish_xp(0);
             if (t == 0) { s.c.done = 1; s.c.term = 2; }
             if (t < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); wait_helpers(); store_ctl(); }
+            ended = true;
             return;
         }
         if constexpr (CHAIN == 0) { if constexpr (LDSM) ok = chol_lookahead<CH_SLOTS, false>(Alds, D, s); else ok = chol_blocked<false>(P.M, D, s, Alds); }      // Alds = staging of the active tile column
@@ -1384,6 +1386,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             for (int i = t; i < P.NS; i += NT) xc[i] = x[i];
             __syncthreads();
             if (t < 64) { wait_helpers(); store_ctl(); }      // (a late helper may still be copying Ctl into its LDS)
+            ended = true;
             return;
         }
         if constexpr (CHAIN == 0) { if constexpr (LDSM) back_subst(Alds, D, s); else back_subst(P.M, D, s); publish_xp(1); __syncthreads(); }      // (the publishing threads read s.y across the thread map of the loop below)
@@ -1427,6 +1430,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             if (defer && gm <= O.gradient_tolerance) {          // (the check the other paths make before the factorisation)
                 if (t == 0) { s.c.done = 1; s.c.term = 2; }
                 if (t < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); hseen = false; wait_helpers(); store_ctl(); }
+                ended = true;
                 return;
             }
         }
@@ -1517,4 +1521,27 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     if (s.c.resweep && !s.c.done) { for (int i = t; i < 16 * P.K + 8; i += NT) xc[i] = s.x0[i]; }
     STAMP(7);
     if (t < 64) { wait_helpers(); store_ctl(); }      // (no second poll when the sums were already collected)
+    ended = true;
+}
+
+template <bool LDSM, int CHAIN = 0>
+__global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) {
+    __shared__ vd::StepShared s;
+    extern __shared__ double Alds[];
+    bool ended = false;
+    step_body<LDSM, CHAIN>(P, O, s, Alds, ended);
+    // the master's last act when the solve has ended in this launch (wave 0 has stored Ctl): accepted state -> x[0] / x[1], gauge fix, Ctl + state +
+    // sequence word into the host's mirror (vil_finish.hpp) -- the host waits neither for the chunk's remaining launches (no-ops) nor for k_finish.
+    // ONE call site behind every exit of the body, its arguments parked in LDS at the head of the launch (s.fin): inlined at each exit, or reading the
+    // parameter block here, the step kernel spilled scalar registers to scratch memory -- which the runtime then provides on every launch (+45 us).
+#ifdef VIL_NO_INSTEP_FINISH
+    return;
+#endif
+    if (!ended) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s.c.done && s.c.lin_mode == 0) {
+        const vd::StepShared::Fin f = s.fin;
+        vd::solve_finish(f.x0, f.x1, f.xorig, f.hs, f.ctl, f.hctl, f.hseq, f.K, f.NS, f.gauge, s.c.cur, s.c.status, s.c.gen, s.x0, &s.c);
+    }
 }

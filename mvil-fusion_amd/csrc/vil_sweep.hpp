@@ -42,7 +42,14 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
     double* out = P.ipart + (size_t)f * 931;
     const int t = threadIdx.x;
     const int i = P.imu_i[f], j = P.imu_j[f];
-    if (c[16] > 10.0 || (P.marg && !(P.marg == 1 && i == 0 && j == 1 && c[16] < 10.0))) { for (int e = t; e < 931; e += blockDim.x) out[e] = 0.0; return; }   // estimator.cpp:1182 / :1535
+    // (the record is stored at agent scope: the chain workgroup of the same launch may read it -- sweep_signal, prechain 2)
+    if (c[16] > 10.0 || (P.marg && !(P.marg == 1 && i == 0 && j == 1 && c[16] < 10.0))) { for (int e = t; e < 931; e += blockDim.x) st_ag(out + e, 0.0); return; }   // estimator.cpp:1182 / :1535
+#ifdef VIL_STAMPS
+    #define ISTAMP(k) do { if (t == 0 && f == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[k] = tt_; } } while (0)
+#else
+    #define ISTAMP(k) do {} while (0)
+#endif
+    ISTAMP(17);
     for (int e = t; e < 450; e += blockDim.x) Jraw[e] = 0.0;
     __syncthreads();
     if (t <= IMU_NBLOCKS) {   // lanes 0..16: one 3x3 block each (common terms recomputed per lane); lane 17: residual
@@ -57,6 +64,7 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
         }
     }
     __syncthreads();
+    ISTAMP(18);
     const double* U = P.imu_U + (size_t)f * 225;
     const bool fr = P.marg != 0;             // marginalisation: every block free
     const bool ci = !fr && P.pose_const && P.pose_const[i], cj = !fr && P.pose_const && P.pose_const[j];
@@ -76,13 +84,15 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
         }
     }
     __syncthreads();
+    ISTAMP(19);
     for (int e = t; e < 931; e += blockDim.x) {
         double s = 0;
         if (e < 900) { const int a = e / 30, b = e % 30; for (int k = 0; k < 15; ++k) s += UJ[k * 30 + a] * UJ[k * 30 + b]; }
         else if (e < 930) { const int a = e - 900; for (int k = 0; k < 15; ++k) s += UJ[k * 30 + a] * Ur[k]; }
         else { for (int k = 0; k < 15; ++k) s += Ur[k] * Ur[k]; s *= 0.5; }
-        out[e] = s;
+        st_ag(out + e, s);
     }
+    ISTAMP(28);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -96,7 +106,8 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
 // sub-space (K = 20: 65 kB per workgroup whatever it touched; 12.5 MB per sweep written and read back by the gather).  With G the dense rows of the
 // corrected Jacobians (two per factor, the residual appended as column r) and E the rows e_l of the landmarks (b_l appended), the record is
 //   sum_f G_f^T G_f - sum_l invp_l E_l^T E_l
-// one v_mfma_f64_16x16x4 per tile and four rows, accumulators in registers from the first row to the store.  Column r of that matrix is the
+// one v_mfma_f64_16x16x4 per tile and four rows, accumulators in registers from the first row to the store (every tile is stored TRANSPOSED: the
+// matrix is symmetric, and the gather reads a column's rows with consecutive lanes).  Column r of that matrix is the
 // Schur-reduced gradient; the un-reduced gradient and diagonal are read off the accumulators between the factor rows and the landmark rows.
 // LDS per factor: [Ji 12 | Jj 12 | Jex 12 | Jt 2 | Jl 2 | r 2 | eO 6] = 48 doubles
 #define VF_STRIDE 49   // odd stride: conflict-free column access
@@ -278,7 +289,7 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
 #pragma unroll
             for (int u = 0; u < TS; ++u) if (on[u]) {
 #pragma unroll
-                for (int ks = 0; ks < NK; ++ks) { av[u][ks] = p[ks * 4 * RS + (tI[u] << 4)]; bv[u][ks] = p[ks * 4 * RS + (tJ[u] << 4)]; }
+                for (int ks = 0; ks < NK; ++ks) { av[u][ks] = p[ks * 4 * RS + (tJ[u] << 4)]; bv[u][ks] = p[ks * 4 * RS + (tI[u] << 4)]; }      // (A from column tile J: the accumulator is the tile's TRANSPOSE)
             }
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
@@ -298,13 +309,14 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
                 for (int q = 0; q < 4; ++q) {
                     const int m = m0 + 4 * q;
                     if (tI[u] == tJ[u] && m == n) rdg[(tI[u] << 4) + m] = acc[u][q];
-                    if (tJ[u] == T - 1 && n == (cR & 15)) rbc[(tI[u] << 4) + m] = acc[u][q];
+                    if (tJ[u] == T - 1 && m == (cR & 15)) rbc[(tI[u] << 4) + n] = acc[u][q];      // (accumulator row m = column of tile J, column n = row of tile I)
                 }
             }
         }
 #pragma unroll
         for (int b = 0; b < 4 / NK; ++b) mma(Em + b * 4 * NK * RS, sa + b * 4 * NK, std::true_type{});      // the 16 landmark rows, -invp_l on the A operand
-        // tiles leave row-major, 128-byte rows: whole lines
+        // tiles leave as they sit in the accumulators -- TRANSPOSED (element (r, c) of tile (I, J) at c * 16 + r: the gather's lanes walk the rows r of a
+        // column) --, 128-byte lines whole
 #pragma unroll
         for (int u = 0; u < TS; ++u) if (on[u]) {
             double* o = rec + (wave + 8 * u) * 256 + (lane >> 4) * 16 + (lane & 15);
@@ -392,8 +404,7 @@ __device__ inline const double* prior_block_ptr(const DevP& P, const double* x, 
 }
 
 // [prior] workgroup: r = r0 + J0 dx ;  J0^T J0 = pH, J0^T r0 = pg0, r0^T r0 = pc0 are pre-contracted, so the prior costs
-// one n x n gemv.  8 threads per output column split the k range (loads in flight instead of one dependent chain of n
-// global loads per thread), folded with three xor-shuffles.
+// one n x n gemv (n <= 136: K <= 20).
 __device__ __forceinline__ void sweep_prior(const DevP& P, const double* x, double* sm) {
     const int t = threadIdx.x;
     if (P.pn <= 0) return;
@@ -409,20 +420,36 @@ __device__ __forceinline__ void sweep_prior(const DevP& P, const double* x, doub
         for (int k = 0; k < ls; ++k) dx[P.pblk_col[t] + k] = d[k];
     }
     __syncthreads();
-    double part = 0;
-    for (int i0 = 0; i0 < n; i0 += (int)(blockDim.x >> 3)) {
-        const int i = i0 + (t >> 3), r = t & 7;
-        double s = 0;
-        if (i < n) for (int k = r; k < n; k += 8) s += P.pH[(size_t)k * n + i] * dx[k];
-        s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
-        if (i < n && r == 0) {
-            const double g = P.pg0[i] + s;
-            part += dx[i] * (P.pg0[i] + g);
-            P.mpart[i] = g;
+    // g = pg0 + pH dx.  pH = J0^T J0 is symmetric: lane = column i (consecutive lanes read consecutive doubles of row k), the rows k are dealt to the
+    // eight waves, every load of a thread independent of the others; the eight partial sums of a column meet in LDS in a fixed order.
+    // (Before: eight lanes per column over rows k = r, r + 8, ..: 64 different cache lines per wave-load -- 16 us at n = 130, and the chain workgroup of
+    //  a K > 12 sweep waits for this record.)
+    double* pw = sm + 520;     // 8 x 136
+    {
+        const int wave = t >> 6, lane = t & 63;
+        double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll 6
+        for (int k = wave; k < n; k += 8) {
+            const double dk = dx[k];
+            const double* row = P.pH + (size_t)k * n;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const int i = lane + 64 * c; acc[c] += row[min(i, n - 1)] * dk; }
         }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const int i = lane + 64 * c; if (i < n) pw[wave * 136 + i] = acc[c]; }
+    }
+    __syncthreads();
+    double part = 0;
+    if (t < n) {
+        double s = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += pw[w * 136 + t];
+        const double g = P.pg0[t] + s;
+        part = dx[t] * (P.pg0[t] + g);
+        st_ag(P.mpart + t, g);                         // (agent scope: read by the chain workgroup of the same launch, prechain 2)
     }
     part = block_sum(part, red);
-    if (t == 0) P.mpart[n] = 0.5 * (P.pc0[0] + part);
+    if (t == 0) st_ag(P.mpart + n, 0.5 * (P.pc0[0] + part));
 }
 
 // [rel] workgroup: the scan-to-scan ICP and LPS AutoDiff factors
@@ -504,6 +531,11 @@ __device__ __forceinline__ int imu_local(const DevP& P, int i, int j, int col) {
 // AG: the results are stored at agent scope (gather + step in one launch: the master reads them in the same launch)
 // EPW: entries per workgroup = blockDim / 8 (32 with 256 threads: the gather kernel; 64 with 512: the gather workgroups of the merged launch,
 // whose register allocation admits one workgroup per compute unit whatever its thread count)
+// workgroups of the gather: entries of the visual triangle (32 slices each: EPW / 4 per workgroup), the other entries of the lower triangle (8 slices:
+// EPW per workgroup), the 2 D vector entries (32 slices), the cost
+__host__ __device__ inline int gather_vblocks(int NV, int epw) { return ((NV * (NV + 1)) / 2 + epw / 4 - 1) / (epw / 4); }
+__host__ __device__ inline int gather_sblocks(int D, int NV, int epw) { return gather_vblocks(NV, epw) + ((D * (D + 1)) / 2 - (NV * (NV + 1)) / 2 + epw - 1) / epw; }
+__host__ __device__ inline int gather_blocks(int D, int NV, int epw) { return gather_sblocks(D, NV, epw) + (2 * D + epw / 4 - 1) / (epw / 4) + 1; }
 template <bool AG = false, int EPW = RED_EPW>
 __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, const int blk /* gather workgroup index */, int4* const vtab /* LDS, VIS_TAB entries */) {
     using namespace vd;
@@ -514,64 +546,76 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
     const int D = P.D, NV = P.NV, K = P.K, t = threadIdx.x;
     const int n_rel = P.n_icp + P.n_lps;
     const double* rel0 = P.mpart + (P.pn > 0 ? P.pn + 1 : 0);
-    const int NL = (D * (D + 1)) >> 1;
-    const int nSblk = (NL + EPW - 1) / EPW;
-    __shared__ double part[2][8][EPW];
+    const int NL = (D * (D + 1)) >> 1, NVT = (NV * (NV + 1)) >> 1;
+    constexpr int EPV = EPW / 4;               // entries per workgroup where the visual records are summed: 32 slices per entry, one round of loads
+    const int nVblk = gather_vblocks(NV, EPW), nSblk = gather_sblocks(D, NV, EPW);
+    __shared__ double part[2][8 * EPW];
     __shared__ int tab[64 + 48 + 2 * 66];      // imu (i, j) pairs | ICP/LPS pose ids (4 per factor) | LiDAR chunk ranges per pose
     // vtab: the visual records' descriptors {offset / 16, first frame, frames, column tiles}, staged per workgroup (records beyond VIS_TAB: read from memory)
     int* t_imu = tab; int* t_rel = tab + 64; int* t_lch = tab + 112;
     const int4* const vrec = (const int4*)P.vrec;
-    auto vdesc = [&](int w) -> int4 { return w < VIS_TAB ? vtab[w] : vrec[w]; };
+    // (the hot loops run on the staged descriptors only, a tail loop on those beyond VIS_TAB -- a per-lane choice between the two inside a round would be
+    //  an exec-mask branch with its own wait around every descriptor, which serialises the loads of the round)
     // local column of reduced column c (< NV) in a record's window, or -1: pose columns of frames [fa, fa + sp), then extrinsic / td
     auto vlocal = [&](int c, int fa, int sp) -> int { const int d = c - 6 * fa; return c >= 6 * K ? 6 * sp + (c - 6 * K) : (((unsigned)d < (unsigned)(6 * sp)) ? d : -1); };
-    if (blk < nSblk) {
-        if (P.skip_mask & 32) return;
-        // stage the small index tables once per workgroup
+    auto stage = [&](bool visual) {            // the small index tables, once per workgroup
         if (t < 2 * P.n_imu && t < 64) t_imu[t] = (t & 1) ? P.imu_j[t >> 1] : P.imu_i[t >> 1];
         if (t >= 64 && t < 64 + 4 * n_rel) { const int q = t - 64, f = q >> 2, b = q & 3; t_rel[q] = f < P.n_icp ? P.icp_ids[4 * f + b] : (b < 2 ? P.lps_ids[2 * (f - P.n_icp) + b] : -1); }
         if (t >= 128 && t < 128 + 2 * (K + 1) && t < 128 + 132) t_lch[t - 128] = P.lchunk_pose[t - 128];
-        for (int e = t; e < min(P.n_vwg, VIS_TAB); e += 8 * EPW) vtab[e] = vrec[e];
+        if (visual) for (int e = t; e < min(P.n_vwg, VIS_TAB); e += 8 * EPW) vtab[e] = vrec[e];
         __syncthreads();
-        const int el = t & (EPW - 1), slice = t / EPW;
-        const int idx = blk * EPW + el;
+    };
+    if (blk < nSblk) {
+        if (P.skip_mask & 32) return;
+        const bool vis = blk < nVblk;          // (workgroup-uniform)
+        stage(vis);
+        const int epw = vis ? EPV : EPW, ns = vis ? 32 : 8;
+        const int el = t & (epw - 1), slice = t / epw;
+        const int idx = vis ? blk * EPV + el : NVT + (blk - nVblk) * EPW + el;
         int i = 0, j = 0;
-        const bool ok = idx < NL;
+        const bool ok = idx < (vis ? NVT : NL);
         if (ok) {
-            i = (int)((sqrtf(8.f * (float)idx + 1.f) - 1.f) * 0.5f);      // (the two loops below make it exact; the fp64 square root is a 1 k-cycle chain)
-            while (((i + 1) * (i + 2)) / 2 <= idx) ++i;
-            while ((i * (i + 1)) / 2 > idx) --i;
-            j = idx - (i * (i + 1)) / 2;              // (i, j), j <= i, enumerates a lower triangle row by row ...
-            const int a = i; i = D - 1 - a; j = D - 1 - j;   // ... mirrored to the upper entry (D-1-a, D-1-b): consecutive lanes -> consecutive columns (coalesced partial reads)
+            int a = (int)((sqrtf(8.f * (float)idx + 1.f) - 1.f) * 0.5f);      // (the two loops below make it exact; the fp64 square root is a 1 k-cycle chain)
+            while (((a + 1) * (a + 2)) / 2 <= idx) ++a;
+            while ((a * (a + 1)) / 2 > idx) --a;
+            // row a of the lower triangle, column b <= a: rows below NV are the visual triangle (idx < NVT).  Read as the upper entry (i, j) = (b, a):
+            // consecutive lanes -> consecutive rows i of one column j, which are consecutive addresses in the (transposed) tiles of the visual records
+            j = a; i = idx - (a * (a + 1)) / 2;
         }
         double vs = 0.0, vdg = 0.0;
-        if (ok && j < NV) {
-            // eight records per round, every load issued before the first add (clamped record / element + select: no predicated loads)
-            const int nw = P.n_vwg, wlast = nw - 1;
-            for (int w = slice; w < nw; w += 64) {
-                double a[8], d[8];
+        if (vis && ok) {
+            // eight records per round and thread, every load issued before the first add (clamped record / element + select: no predicated loads); with
+            // 32 slices per entry one round covers 256 records.  The records are sorted by first frame: an entry whose row sits in frame f is covered
+            // by the first vwend[f] of them at most.  A wave that holds a diagonal entry also fetches the records' un-reduced diagonals in the same round
+            constexpr int U = 8;
+            const int nw = i < 6 * K ? P.vwend[i / 6] : P.n_vwg, nws = min(nw, VIS_TAB), wlast = max(nws - 1, 0);
+            const bool wdiag = __ballot(i == j) != 0ull;
+            auto fetch = [&](const int4 ds, const bool live, double& va_, double& vd_) {
+                const int T = ds.w, il_ = vlocal(i, ds.y, ds.z), jl_ = vlocal(j, ds.y, ds.z);
+                const bool in = il_ >= 0 && jl_ >= 0 && live;
+                const int il = in ? il_ : 0, jl = in ? jl_ : 0, I = il >> 4, J = jl >> 4;
+                const double* r = P.vpart + (size_t)ds.x * 16;
+                const double va = r[(I * T - ((I * (I - 1)) >> 1) + (J - I)) * 256 + (jl & 15) * 16 + (il & 15)];      // tile (I, J) holds its transpose
+                va_ = in ? va : 0.0; vd_ = 0.0;
+                if (wdiag) { const double vd = r[vis_ntile(T) * 256 + 16 * T + il]; vd_ = (in && i == j) ? vd : 0.0; }
+            };
+            for (int w = slice; w < nws; w += 32 * U) {
+                double a[U], d[U];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int4 ds = vdesc(min(w + 8 * u, wlast));
-                    const int T = ds.w, il_ = vlocal(i, ds.y, ds.z), jl_ = vlocal(j, ds.y, ds.z);
-                    const bool in = il_ >= 0 && jl_ >= 0 && w + 8 * u < nw;
-                    const int il = in ? il_ : 0, jl = in ? jl_ : 0, I = il >> 4, J = jl >> 4;
-                    const double* r = P.vpart + (size_t)ds.x * 16;
-                    const double va = r[(I * T - ((I * (I - 1)) >> 1) + (J - I)) * 256 + (il & 15) * 16 + (jl & 15)];
-                    const double vd_ = (i == j) ? r[vis_ntile(T) * 256 + 16 * T + il] : 0.0;
-                    a[u] = in ? va : 0.0; d[u] = in ? vd_ : 0.0;
-                }
+                for (int u = 0; u < U; ++u) fetch(vtab[min(w + 32 * u, wlast)], w + 32 * u < nws, a[u], d[u]);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { vs += a[u]; vdg += d[u]; }
+                for (int u = 0; u < U; ++u) { vs += a[u]; vdg += d[u]; }
             }
+            for (int w = VIS_TAB + slice; w < nw; w += 32) { double a, d; fetch(vrec[w], true, a, d); vs += a; vdg += d; }      // (windows with more than VIS_TAB chunks)
         }
-        // the non-visual contributions are spread over the 8 slices of an entry
+        // the non-visual contributions are spread over the slices of an entry
         double ms = 0.0;
         if (ok) {
             if (j < 6 * K && i / 6 == j / 6) {                 // LiDAR plane and edge points: pose-diagonal blocks.  The chunk records of a pose
-                const int k = i / 6, a = i - 6 * k, b = j - 6 * k;   // (one per 256 points: 9 per pose at 24 k points, 37 at 96 k) are dealt to the eight slices
+                const int k = i / 6, a = i - 6 * k, b = j - 6 * k;   // (one per 256 points: 9 per pose at 24 k points, 37 at 96 k) are dealt to the slices
                 const int li = a * 6 - ((a * (a - 1)) >> 1) + (b - a);   // of the entry -- one slice walking them all was the longest chain of this kernel
-                for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += 8) ms += P.lpart[(size_t)c * 28 + li];
-                for (int c = t_lch[K + 1 + k] + slice; c < t_lch[K + 2 + k]; c += 8) ms += P.lpart[(size_t)(P.n_pchunk + c) * 28 + li];
+                for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += ns) ms += P.lpart[(size_t)c * 28 + li];
+                for (int c = t_lch[K + 1 + k] + slice; c < t_lch[K + 2 + k]; c += ns) ms += P.lpart[(size_t)(P.n_pchunk + c) * 28 + li];
             }
             if (slice == 3 && j < 6 * K) {                     // ICP / LPS blocks live on pose columns
                 const int pi = i / 6, pj = j / 6, ri = i - 6 * pi, rj = j - 6 * pj;
@@ -589,54 +633,58 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
             }
             if (slice == 6 && P.pn > 0) { const int pi = P.pinv[i], pj = P.pinv[j]; if (pi >= 0 && pj >= 0) ms += P.pH[(size_t)pi * P.pn + pj]; }
         }
-        part[0][slice][el] = vs + ms; part[1][slice][el] = vdg - vs;     // [1]: un-reduced minus reduced visual diagonal
+        part[0][slice * epw + el] = vs + ms; part[1][slice * epw + el] = vdg - vs;     // [1]: un-reduced minus reduced visual diagonal
         __syncthreads();
         if (slice != 0 || !ok) return;
         double s = 0.0, dd = 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { s += part[0][q][el]; dd += part[1][q][el]; }
+        for (int q = 0; q < ns; ++q) { s += part[0][q * epw + el]; dd += part[1][q * epw + el]; }
         put(sb.S + (size_t)i * D + j, s);
         put(sb.S + (size_t)j * D + i, s);
         if (i == j) put(sb.diag + i, s + (i < NV ? dd : 0.0));   // un-reduced diagonal: add back the Schur term of the visual part
         return;
     }
-    // ---- gradient vectors bc / gred: 2D entries, same 8-slice scheme -------------------------------------------------
-    const int nVblk = (2 * D + EPW - 1) / EPW;
-    if (blk < nSblk + nVblk) {
+    // ---- gradient vectors bc / gred: 2D entries, 32 slices each ----------------------------------------------------------------------
+    const int nVblk2 = (2 * D + EPV - 1) / EPV;
+    if (blk < nSblk + nVblk2) {
         if (P.skip_mask & 64) return;
-        if (t < 2 * P.n_imu && t < 64) t_imu[t] = (t & 1) ? P.imu_j[t >> 1] : P.imu_i[t >> 1];
-        if (t >= 64 && t < 64 + 4 * n_rel) { const int q = t - 64, f = q >> 2, b = q & 3; t_rel[q] = f < P.n_icp ? P.icp_ids[4 * f + b] : (b < 2 ? P.lps_ids[2 * (f - P.n_icp) + b] : -1); }
-        if (t >= 128 && t < 128 + 2 * (K + 1) && t < 128 + 132) t_lch[t - 128] = P.lchunk_pose[t - 128];
-        for (int e = t; e < min(P.n_vwg, VIS_TAB); e += 8 * EPW) vtab[e] = vrec[e];
-        __syncthreads();
-        const int el = t & (EPW - 1), slice = t / EPW;
-        const int v = (blk - nSblk) * EPW + el;
+        stage(true);
+        const int el = t & (EPV - 1), slice = t / EPV;
+        const int v = (blk - nSblk) * EPV + el;
         const bool ok = v < 2 * D;
         const int which = v >= D ? 1 : 0, i = which ? v - D : v;       // 0: bc, 1: gred
         double acc = 0.0;
         if (ok) {
-            if (i < NV) for (int w = slice; w < P.n_vwg; w += 8) {      // bc: the record's vector; gred: column r of its last tile column
-                const int4 ds = vdesc(w);
-                const int T = ds.w, il_ = vlocal(i, ds.y, ds.z), il = max(il_, 0), I = il >> 4;
-                const double* r = P.vpart + (size_t)ds.x * 16;
-                const double val = which ? r[(I * T - ((I * (I - 1)) >> 1) + (T - 1 - I)) * 256 + (il & 15) * 16 + ((6 * ds.z + 7) & 15)] : r[vis_ntile(T) * 256 + il];
-                acc += il_ >= 0 ? val : 0.0;
+            if (i < NV) {                              // bc: the record's vector; gred: column r of its last tile column.  Eight records per round and thread, as above
+                const int nw = i < 6 * K ? P.vwend[i / 6] : P.n_vwg, nws = min(nw, VIS_TAB), wlast = max(nws - 1, 0);
+                auto fetch = [&](const int4 ds, const bool live) -> double {
+                    const int T = ds.w, il_ = vlocal(i, ds.y, ds.z), il = max(il_, 0), I = il >> 4;
+                    const double* r = P.vpart + (size_t)ds.x * 16;
+                    const double val = which ? r[(I * T - ((I * (I - 1)) >> 1) + (T - 1 - I)) * 256 + ((6 * ds.z + 7) & 15) * 16 + (il & 15)] : r[vis_ntile(T) * 256 + il];
+                    return (il_ >= 0 && live) ? val : 0.0;
+                };
+                for (int w = slice; w < nws; w += 256) {
+                    double a[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a[u] = fetch(vtab[min(w + 32 * u, wlast)], w + 32 * u < nws);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += a[u];
+                }
+                for (int w = VIS_TAB + slice; w < nw; w += 32) acc += fetch(vrec[w], true);
             }
             if (i < 6 * K) {
                 const int k = i / 6, a = i - 6 * k;
-                for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += 8) acc += P.lpart[(size_t)c * 28 + 21 + a];      // (chunk records dealt to the eight slices, as above)
-                for (int c = t_lch[K + 1 + k] + slice; c < t_lch[K + 2 + k]; c += 8) acc += P.lpart[(size_t)(P.n_pchunk + c) * 28 + 21 + a];
+                for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += 32) acc += P.lpart[(size_t)c * 28 + 21 + a];      // (chunk records dealt to the slices, as above)
+                for (int c = t_lch[K + 1 + k] + slice; c < t_lch[K + 2 + k]; c += 32) acc += P.lpart[(size_t)(P.n_pchunk + c) * 28 + 21 + a];
                 if (slice == 3) for (int f = 0; f < n_rel; ++f) for (int ba = 0; ba < 4; ++ba) if (t_rel[4 * f + ba] == k) acc += rel0[(size_t)f * 601 + 576 + ba * 6 + a];
             }
             if (slice == 4 || slice == 5) for (int f = slice - 4; f < P.n_imu; f += 2) { const int la = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], i); if (la >= 0) acc += P.ipart[(size_t)f * 931 + 900 + la]; }
             if (slice == 6 && P.pn > 0) { const int pi = P.pinv[i]; if (pi >= 0) acc += P.mpart[pi]; }
         }
-        part[0][slice][el] = acc;
+        part[0][slice * EPV + el] = acc;
         __syncthreads();
         if (slice != 0 || !ok) return;
         double sum = 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) sum += part[0][q][el];
+        for (int q = 0; q < 32; ++q) sum += part[0][q * EPV + el];
         put((which ? sb.gred : sb.bc) + i, sum);
         return;
     }
@@ -662,17 +710,23 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
 __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P, int n_gather) {
     const Ctl ctl = *P.ctl;
     if (ctl.done) return;
-    if ((int)blockIdx.x >= n_gather) { vd::prechain_ww_tile(P, (int)blockIdx.x - n_gather); return; }
+    if ((int)blockIdx.x >= n_gather) {
+        const int q = (int)blockIdx.x - n_gather;
+        if (q < P.n_ww) vd::prechain_ww_tile(P, q); else vd::prechain_inverses(P);
+        return;
+    }
     __shared__ int4 vtab[VIS_TAB];
     reduce_gather(P, ctl, (int)blockIdx.x, vtab);
 }
 
 // the IMU / prior workgroup `slot` of this launch has written its record (read by the chain workgroup of the same launch, prechain 2).
 // Epoch of the flags: solve generation + Ctl::swe, which only the step kernel advances.
+// The record went out with agent-scope stores (the level the XCDs share), so the flag only has to be ordered behind every thread's own stores:
+// no release fence (which writes the whole XCD's L2 back while the visual workgroups are filling it), the reader polls relaxed and loads at agent scope.
 __device__ __forceinline__ void sweep_signal(const DevP& P, const Ctl& ctl, int slot) {
-    __threadfence();                 // every wave's stores of the record (__syncthreads alone does not wait for global stores)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores of the record (__syncthreads alone does not wait for global stores)
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(P.swflag + slot, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) vd::st_ag(P.swflag + slot, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u));
 }
 
 // The sweep: grid = n_imu + 2 (+ 1: prechain 2) + n_vwg + ceil(n_pchunk / 2) + ceil(n_echunk / 2) workgroups of VIL_SWEEP_THREADS threads.

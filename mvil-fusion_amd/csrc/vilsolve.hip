@@ -178,6 +178,7 @@ struct vil_ctx {
     std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
     int n_blocks_sweep = 0, n_blocks_reduce = 0, n_gather_m = 0, n_ww = 0;      // n_ww: tiles of W W^T formed by extra workgroups of k_reduce (vil_prechain.hpp)
     size_t lds_sweep = 0, lds_step = 0, lds_reduce = 0;
+    int cap_step3 = -1;                  // workgroups of the merged gather + step launch the device holds at once (vil_coop.hpp)
     int vis_gm = 0;                      // doubles of operand rows the largest visual chunk of the uploaded window needs (vil_sweep.hpp)
     size_t span = 0;               // doubles of one linear-system set (SysBuf::ar): the multi-GPU all-reduce message
     bool step_lds = false;
@@ -623,6 +624,9 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             }
             P.vis_ts = vd::vis_slots(tmax) <= 2 ? 2 : 5;
             c->vis_gm = gmax;
+            std::vector<int> wend(K, 0);
+            for (int w = 0; w < P.n_vwg; ++w) for (int f = ch[w].fa; f < K; ++f) wend[f]++;
+            put(wend.data(), 4 * wend.size(), (void**)&P.vwend);
             put(vw.data(), 4 * vw.size(), (void**)&P.vwg); put(vr.data(), 4 * vr.size(), (void**)&P.vrec);
             put(vl.data(), 4 * vl.size(), (void**)&P.vlm); put(vf.data(), 4 * vf.size(), (void**)&P.vfac);
             put(nullptr, 8 * std::max(roff, (size_t)16), (void**)&P.vpart);
@@ -762,10 +766,10 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     {
         const int rs = vd::chain_rs(K);
         put(nullptr, 8 * (size_t)vd::chain_wcols(K) * rs, (void**)&P.chW);
-        put(nullptr, 8 * (size_t)54 * K, (void**)&P.chLdg); put(nullptr, 8 * (size_t)82 * K, (void**)&P.chLsb);
+        put(nullptr, 8 * (size_t)54 * K, (void**)&P.chLdg); put(nullptr, 8 * (size_t)82 * K, (void**)&P.chLsb); put(nullptr, 8 * (size_t)136 * K, (void**)&P.chLraw);
         put(nullptr, 8 * (size_t)9 * K, (void**)&P.chSc); put(nullptr, 8 * (size_t)9 * K, (void**)&P.chDc);
         put(nullptr, 8 * (size_t)2 * (NV + 1), (void**)&P.chZ); put(nullptr, 8 * 4, (void**)&P.chQ); put(nullptr, 16, (void**)&P.chOk);
-        { const int NLg = (D * (D + 1) / 2 + RED_EPW - 1) / RED_EPW + (2 * D + RED_EPW - 1) / RED_EPW + 1; put(nullptr, 4 * (size_t)(NLg + 8), (void**)&P.gflag); }
+        put(nullptr, 4 * (size_t)(gather_blocks(D, NV, RED_EPW) + 8), (void**)&P.gflag);      // (one flag per gather workgroup of the merged launch: never more than the gather kernel has)
         put(nullptr, 64, (void**)&P.chflag); put(nullptr, 4 * 64, (void**)&P.wwflag); put(nullptr, 4 * (size_t)(K + 8), (void**)&P.swflag);
         { const size_t Tp = (size_t)(NV + 1 + 15) / 16; put(nullptr, 8 * (size_t)TILE_SZ * (Tp * (Tp + 1) / 2), (void**)&P.chWW); }
     }
@@ -893,7 +897,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         return VIL_OK;
     };
     { const int gs = grant_sweep(); if (gs != VIL_OK) return gs; }
-    c->n_blocks_reduce = (D * (D + 1) / 2 + RED_EPW - 1) / RED_EPW + (2 * D + RED_EPW - 1) / RED_EPW + 1;
+    c->n_blocks_reduce = gather_blocks(D, NV, RED_EPW);
     // ---- step kernel variant: the speed-bias part of the reduced matrix is a chain whenever every IMU factor couples (k, k+1)
     //      and the prior's speed-bias blocks are neighbours (VINS: exactly one) -> vil_chain.hpp; anything else: dense path
     {
@@ -919,7 +923,15 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         const size_t Tp_ = (size_t)(NV + 1 + 15) / 16, tiles_ = (size_t)TILE_SZ * (Tp_ * (Tp_ + 1) / 2);
         const size_t lds3 = 8 * (tiles_ + 54 * (size_t)K + 82 * (size_t)K + vd::even_up(9 * K) + 16), ldsc = 8 * vd::prechain_lds_doubles(K);
         const bool can_pre = !c->split && pre_ok && P.chain != 0 && Tp_ * (Tp_ + 1) / 2 <= 64 && lds3 + sizeof(vd::StepShared) + 512 <= 160 * 1024 && ldsc <= 150 * 1024;
-        const bool merged = can_pre && K <= 12 && std::max(lds3, ldsc) <= 80 * 1024 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
+        bool merged = can_pre && K <= 12 && std::max(lds3, ldsc) <= 80 * 1024 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
+        if (merged) {
+            // the merged launch holds workgroups that spin on flags (master, helpers, one per W W^T tile) next to the finite ones they wait for (chain,
+            // gather: lower block indices, dispatched first).  It is only taken when the device can hold every spinning workgroup AND one more at the
+            // same time -- otherwise the waiters could occupy every slot before the last gather workgroup has found one (vil_coop.hpp)
+            if (c->cap_step3 < 0) c->cap_step3 = vilcoop::capacity((const void*)k_step<true, 3>, VIL_STEP_THREADS, std::max(lds3, ldsc), c->device);
+            const int Tw = (int)(Tp_ * (Tp_ + 1) / 2);
+            if (c->cap_step3 < 1 + P.n_help + Tw + 2) merged = false;
+        }
         P.prechain = merged ? 1 : (can_pre ? 2 : 0);
         c->n_ww = 0;
         if (P.prechain) {
@@ -936,7 +948,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         c->P.chain = P.chain; c->P.chain_rs = P.chain_rs; c->P.prechain = P.prechain;
         // (the merged launch gathers 64 entries per 512-thread workgroup: half as many workgroups as the gather kernel's)
         const bool g64 = VIL_TUNE_ENV("VIL_GATHER32") == nullptr;
-        c->n_gather_m = g64 ? (D * (D + 1) / 2 + 63) / 64 + (2 * D + 63) / 64 + 1 : c->n_blocks_reduce;
+        c->n_gather_m = g64 ? gather_blocks(D, NV, 64) : c->n_blocks_reduce;
         c->P.rs_merged = merged ? (g64 ? 2 : 1) : 0; c->P.n_ww = c->n_ww; c->P.n_gather = merged ? c->n_gather_m : 0;
     }
     if (P.chain) {
@@ -1130,7 +1142,8 @@ static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
 }
 static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr) {
     const bool merged = step && c->P.rs_merged;          // one GPU: the gather rides in the step kernel's launch (vil_step.hpp)
-    if (!merged) hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce + ((step && c->P.prechain == 2) ? c->n_ww : 0)), dim3(VIL_THREADS), 0, c->stream, view(c, 0), c->n_blocks_reduce);
+    // (chain eliminated inside k_sweep: one workgroup per W W^T tile and one for the inverses of the chain's diagonal blocks ride in the gather launch)
+    if (!merged) hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce + ((step && c->P.prechain == 2) ? c->n_ww + 1 : 0)), dim3(VIL_THREADS), 0, c->stream, view(c, 0), c->n_blocks_reduce);
     if (ev_mid) hipEventRecord(ev_mid, c->stream);
     if (c->split) {                                    // the one collective of the iteration
         const int st = all_reduce2(c, c->P.sys[0].ar, c->P.sys[1].ar, c->span, c->D);      // (S' first: its lower triangle travels)
@@ -1149,10 +1162,11 @@ static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEve
 }
 
 static int init_ctl(vil_ctx* c, const vil_options* o, int lin_mode) {
-    Ctl ctl; memset(&ctl, 0, sizeof ctl);
-    ctl.gen = ++c->solve_gen; ctl.cur = 0; ctl.first = 1; ctl.radius = o->initial_radius; ctl.mu = o->min_mu; ctl.lin_mode = lin_mode;
-    *c->h_ctl = ctl;
-    HIPCHK(hipMemcpyAsync(c->P.ctl, c->h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
+    // (a kernel with the values in its arguments: an asynchronous copy out of the one pinned h_ctl could be overtaken by the next call's init --
+    //  vil_win_marginalize / push / drop return without a stream synchronisation)
+    static_assert(sizeof(Ctl) % 8 == 0, "Ctl is cleared as doubles");
+    hipLaunchKernelGGL(k_solve_init, dim3(1), dim3(256), 0, c->stream, c->P.ctl, ++c->solve_gen, o->initial_radius, o->min_mu, lin_mode);
+    memset(c->h_ctl, 0, sizeof(Ctl));
     return VIL_OK;
 }
 
@@ -1179,8 +1193,7 @@ int vil_debug_read(vil_ctx* c, long long* out64) {
 int vil_reset_state(vil_ctx* c) {
     if (!c || !c->uploaded) return VIL_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(c->P.x[0], c->d_x0, 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->P.x[1], c->d_x0, 8 * (size_t)c->NS, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_state_reset, dim3((c->NS + 255) / 256), dim3(256), 0, c->stream, c->P.x[0], c->P.x[1], (const double*)c->d_x0, c->NS);
     c->mirror_state = false;
     return VIL_OK;
 }
@@ -1192,6 +1205,12 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     const auto t0 = std::chrono::steady_clock::now();
     const SolveOpts so = to_dev_opts(o);
     c->mirror_state = false;
+    // the step kernel's master, helpers and (merged launch) tile workgroups wait for one another inside a launch: like the other persistent kernels of
+    // the library a solve holds the process-wide gate until its result has arrived, so that it never shares the device with a half-resident
+    // k_pose_solve / k_vgicp_align of another thread (vil_coop.hpp).  Not taken by the ranks of an in-process communicator: they wait for EACH OTHER's
+    // launches, one host thread per rank.
+    std::unique_lock<std::mutex> coop_lock(vilcoop::gate(), std::defer_lock);
+    if (!(c->split && c->lcomm != nullptr)) coop_lock.lock();
     if ((c->P.gauge_on != 0) != c->gauge_on) {            // vil_set_gauge_fix since the upload: the captured graphs carry the old flag
         c->P.gauge_on = c->gauge_on ? 1 : 0;
         for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);

@@ -33,3 +33,6 @@ print("whole master: entry -> final stamp 7: %d ticks = %.1f us" % (dbg[7] - dbg
 g = np.array([dbg[14]] + [dbg[48 + q] for q in range(7)] + [dbg[15]], dtype=np.int64)
 print("chain workgroup, forward recursion wave (ticks after the scales): block 0..5 published, middle block published, all waves done:", (g[1:] - g[0]).tolist(), " row waves done: forward %d, backward %d" % (dbg[55] - dbg[14], dbg[56] - dbg[14]))
 print("visual WG 0, ticks summed over its chunks: factor evaluation %d, landmark sums %d, outer products %d" % (dbg[62], dbg[63], dbg[47]))
+print("visual workgroups: longest %d ticks = %.1f us, sum %d ticks; WG 0 phases (zero+eval | landmark sums + fill | matrix cores + record | cost):" % (dbg[60], dbg[60] / 2390.0, dbg[61]), np.diff(np.array(dbg[32:37], dtype=np.int64)).tolist())
+im = np.array([dbg[17], dbg[18], dbg[19], dbg[28]], dtype=np.int64)
+print("IMU workgroup 0 (ticks): raw blocks %d, whitening %d, contraction + record %d" % tuple(np.diff(im).tolist()), "| chain workgroup: entry -> IMU / prior flags seen %d, -> gathered %d" % (dbg[31] - dbg[12], dbg[13] - dbg[31]))
