@@ -52,6 +52,49 @@ def pmc_traffic_bytes(files=("r03_pmc_fetch_size.csv", "r03_pmc_write_size.csv")
     return tot
 
 
+def pmc_mfma(file, kernel="k_sweep"):
+    """Counter-based matrix-core figures of `kernel` from the committed rocprofv3 --pmc pass (SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES,
+    SQ_BUSY_CYCLES in ONE pass; profiles/): per live launch the MFMA ops (x 512 = fp64 flop), the cycles the matrix pipes were busy (summed over the
+    SIMDs that ran the kernel) and the launch duration.  None if the CSV is missing."""
+    import collections, csv
+    path = os.path.join(ROOT, "profiles", file)
+    if not os.path.exists(path):
+        return None
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if kernel in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    if not acc.get("SQ_INSTS_VALU_MFMA_MOPS_F64") or not acc.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        return None
+    d = [x[1] for x in acc["SQ_VALU_MFMA_BUSY_CYCLES"]]
+    live = [i for i, x in enumerate(d) if x > 0.5 * max(d)]
+    mean = lambda name: sum(acc[name][i][0] for i in live) / len(live)
+    mops, busy, us = mean("SQ_INSTS_VALU_MFMA_MOPS_F64"), mean("SQ_VALU_MFMA_BUSY_CYCLES"), sum(d[i] for i in live) / len(live) / 1e3
+    sq_busy = mean("SQ_BUSY_CYCLES") if acc.get("SQ_BUSY_CYCLES") else None
+    return {"mops_per_launch": mops, "flop_per_launch": 512.0 * mops, "mfma_busy_cycles_per_launch": busy, "sq_busy_cycles_per_launch": sq_busy, "launch_us_under_pmc": us, "live_launches": len(live)}
+
+
+_NATIVE = {}
+
+
+def native_oracle():
+    """BASELINE.md section 2 asks for `-O3 -march=native`: the shipped oracle/liboracle.so is built in the build container with -march=x86-64-v3 (the
+    box that runs the bench is another machine), so the CPU leg rebuilds the oracle HERE with -march=native (~25 s, once) and times that; falls back to
+    the shipped library -- and says so -- if the host has no compiler."""
+    if "so" in _NATIVE:
+        return _NATIVE["so"], _NATIVE["note"]
+    import subprocess, tempfile
+    srcs = ["oracle_factors.cpp", "oracle_solver.cpp", "oracle_marg.cpp", "oracle_api.cpp", "oracle_vgicp.cpp", "oracle_map.cpp"]
+    out = os.path.join(tempfile.gettempdir(), "liboracle_native_%d.so" % os.getpid())
+    cmd = ["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-pthread", "-shared", "-o", out] + [os.path.join(ROOT, "oracle", f) for f in srcs]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+        _NATIVE["so"], _NATIVE["note"] = out, "oracle rebuilt on this host with g++ -O3 -march=native (BASELINE.md section 2)"
+    except Exception:
+        _NATIVE["so"], _NATIVE["note"] = os.path.join(ROOT, "oracle", "liboracle.so"), "shipped oracle/liboracle.so, built with -O3 -march=x86-64-v3 (no compiler on this host for -march=native)"
+    return _NATIVE["so"], _NATIVE["note"]
+
+
 def cpu_baseline(w, opts, budget_s=10.0):
     """Oracle (CPU restatement, kind 'port') timed on this host: repeated full solves of the same window.
     SURVEY 8(d): warm-up 3, then >= 20 solves; single thread like the reference's ceres::Solve (num_threads is never set,
@@ -59,10 +102,10 @@ def cpu_baseline(w, opts, budget_s=10.0):
     GPU/CPU ratio is not flattered by the single-thread choice."""
     import numpy as np
     from mvil_fusion_amd import lib
-    so_path = os.path.join(ROOT, "oracle", "liboracle.so")
-    if not os.path.exists(so_path):
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
         import subprocess
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    so_path, build_note = native_oracle()
     orc = lib.Backend(C.CDLL(so_path), "orc_")
     st0 = w.state_copy()
 
@@ -101,10 +144,10 @@ def cpu_baseline(w, opts, budget_s=10.0):
                       % (len(ts), its, sum(ts), 1e3 * float(np.median(ts))),
             "all_cores": {"value": mt_rate, "unit": "iterations/s", "cores": nthr,
                           "sample": "%d solves, factor sweep on %d threads = best of the team sizes 4/8/16/32 (Schur complement / Cholesky / dogleg stay serial)" % (mt_n, nthr)},
-            "note": "CPU restatement of the reference algorithm (Ceres unavailable); host has %d usable cores" % ncpu}
+            "note": "CPU restatement of the reference algorithm (Ceres unavailable); %s; host has %d usable cores" % (build_note, ncpu)}
 
 
-def roofline_obj(w, prof, measured_on, pmc_files, pmc_note):
+def roofline_obj(w, prof, measured_on, pmc_files, pmc_note, mfma_file=None):
     """`roofline` of the factor sweep (dominant kernel: the one that touches the factor tables) + the gather-and-step launch next to it."""
     ab = algorithmic_bytes(w)
     us = 1e3 * prof.sweep_ms / prof.sweep_launches
@@ -119,10 +162,24 @@ def roofline_obj(w, prof, measured_on, pmc_files, pmc_note):
     NP, NB = 6 * w.K + 7, 9 * w.K
     step_us = 1e3 * prof.step_ms / max(1, prof.step_launches)
     chol_flop = w.K * (9 ** 3 / 3.0 + 2.0 * 81 * (NP + 1 + 9)) + 1.0 * (NP + 1) ** 2 * NB + NP ** 3 / 3.0 + 2.0 * (NP * NP + NB * (NP + 9))
-    r["critical_path_kernel"] = {"kernel": "k_step (gather workgroups | chain workgroup | W W^T tile workgroups | master + helpers)", "avg_launch_us": step_us,
-                                 "bound": "latency: gather of the partial records (~11 us) beside the two-sided 9x9 chain of %d blocks, then a %d-pivot dense Cholesky and the back substitutions on one workgroup (dependent fp64 chains)" % (w.K, NP),
+    merged = w.K <= 12
+    r["critical_path_kernel"] = {"kernel": "k_step (gather workgroups | chain workgroup | W W^T tile workgroups | master + helpers)" if merged else "k_reduce (gather + W W^T tiles) + k_step (master + helpers + chain inverses); the chain workgroup rides in k_sweep", "avg_launch_us": step_us,
+                                 "bound": ("latency: gather of the visual records beside the two-sided 9x9 chain of %d blocks, then a %d-pivot dense Cholesky and the back substitutions on one workgroup (dependent fp64 chains)" if merged else
+                                           "latency: gather of the visual records, then on one workgroup a %d-pivot dense Cholesky and the back substitutions (dependent fp64 chains; the two-sided 9x9 chain of %d blocks is eliminated inside the sweep launch)") % ((w.K, NP) if merged else (NP, w.K)),
                                  "dense_flop_per_launch": chol_flop, "achieved_gflops": chol_flop / (step_us * 1e-6) / 1e9, "peak_tflops_fp64_matrix": 78.6,
-                                 "frac": chol_flop / (step_us * 1e-6) / 78.6e12, "see": "profiles/r03_summary.txt, DESIGN.md section 4"}
+                                 "frac": chol_flop / (step_us * 1e-6) / 78.6e12, "see": "profiles/r04_summary*.txt, DESIGN.md section 4"}
+    if mfma_file:
+        # the Schur contraction of the landmarks (sum_f Jc^T Jc - sum_l invp e e^T per visual workgroup) runs on the fp64 matrix cores inside k_sweep:
+        # utilisation from the COUNTERS of the committed --pmc pass, against the chip's fp64-matrix peak over the sweep's own duration
+        m = pmc_mfma(mfma_file)
+        if m:
+            us_k = m["launch_us_under_pmc"]
+            r["mfma"] = {"kernel": "k_sweep (visual role: Schur contraction of the landmark block)", "bound": "mfma", "unit": "TFLOP/s", "peak": 78.6,
+                         "achieved": m["flop_per_launch"] / (us_k * 1e-6) / 1e12, "frac": m["flop_per_launch"] / (us_k * 1e-6) / 78.6e12,
+                         "v_mfma_f64_16x16x4_per_launch": m["mops_per_launch"] / 4.0, "flop_per_launch": m["flop_per_launch"],
+                         "mfma_busy_cycles_per_launch": m["mfma_busy_cycles_per_launch"], "sq_busy_cycles_per_launch": m["sq_busy_cycles_per_launch"],
+                         "launch_us": us_k, "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES, one pass; MOPS x 512 flop)" % mfma_file,
+                         "note": "a dense window-local contraction spends ~6x the multiply-adds of the block-sparse form; the launch is bound by its longest workgroup (the speed-bias chain at K > 12), not by the matrix pipes"}
     return r
 
 
@@ -674,34 +731,39 @@ def main():
         pcie_classic = {"value": its_p / elp, "unit": "iterations/s", "ms_per_solve": 1e3 * elp / n_p, "host_to_device_bytes_per_solve": int(8 * (14 * len(w.vis_i) + 7 * len(w.plane_pose) + 9 * len(w.edge_pose) + 287 * len(w.imu_i) + w.prior.n ** 2 + 3 * (16 * w.K + 8 + w.L))),
                         "what": "vil_solve per step: EVERY host table packed and uploaded (2.3 MB), solved, state read back (%d solves); first solve of an upload launches directly (no hipGraph)" % n_p}
         pcie_leg = tracker_leg(lib, abi, local)
-    # BASELINE.json configs[2] (K = 10, L = 4000, 120 k LiDAR points): the window the 8-GPU sharding is specified on -- same protocol, fewer steps
-    cfg3_leg = None
-    if args.config == 2 and not args.no_cfg3:
-        w3 = synth.make_config(3, prior_fn=gpu_prior)
-        be.upload(w3)
+    # BASELINE.json configs[2] (K = 10, L = 4000, 120 k LiDAR points: the window the 8-GPU sharding is specified on) and configs[3] (K = 20, prior active:
+    # the "dense Schur block, MFMA path" window) -- same protocol as the headline, fewer steps; each with its own roofline object
+    def window_leg(cfg_id):
+        wx = synth.make_config(cfg_id, prior_fn=gpu_prior)
+        be.upload(wx)
         for _ in range(2):
             be.reset_state(); be.solve_resident(opts)
         sync()
-        n3 = max(4, args.steps // 4); t3 = time.perf_counter(); it3 = 0
-        for _ in range(n3):
-            be.reset_state(); l3 = be.solve_resident(opts); it3 += l3.iterations
+        nx = max(4, args.steps // 4); tx = time.perf_counter(); itx = 0
+        for _ in range(nx):
+            be.reset_state(); lx = be.solve_resident(opts); itx += lx.iterations
         sync()
-        el3 = time.perf_counter() - t3
+        elx = time.perf_counter() - tx
         if dist is not None:
-            tt3 = torch.tensor([float(it3), el3], device="cuda", dtype=torch.float64)
-            s3 = tt3.clone(); dist.all_reduce(s3, op=dist.ReduceOp.SUM); m3 = tt3.clone(); dist.all_reduce(m3, op=dist.ReduceOp.MAX)
-            it3, el3 = (float(it3) if sharded else float(s3[0])), float(m3[1])
-        prof3 = VilProfile()
+            ttx = torch.tensor([float(itx), elx], device="cuda", dtype=torch.float64)
+            sx = ttx.clone(); dist.all_reduce(sx, op=dist.ReduceOp.SUM); mx = ttx.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            itx, elx = (float(itx) if sharded else float(sx[0])), float(mx[1])
+        profx = VilProfile()
         if not args.no_events:
             be.lib.vil_profile_enable(be.ctx, 1)
             be.reset_state(); be.solve_resident(opts)
-            be.lib.vil_profile_read(be.ctx, C.byref(prof3), 1)
-            for _ in range(n3):
+            be.lib.vil_profile_read(be.ctx, C.byref(profx), 1)
+            for _ in range(nx):
                 be.reset_state(); be.solve_resident(opts)
-            be.lib.vil_profile_read(be.ctx, C.byref(prof3), 1)
+            be.lib.vil_profile_read(be.ctx, C.byref(profx), 1)
             be.lib.vil_profile_enable(be.ctx, 0)
-        cfg3_leg = {"value": it3 / el3, "unit": "iterations/s", "n_gpus": world, "ms_per_step": 1e3 * el3 / n3, "steps": n3, "iterations_per_solve": l3.iterations,
-                    "workload": "BASELINE.json configs[2]: K=%d, L=%d, %d visual factors, %d LiDAR points, %s" % (w3.K, w3.L, len(w3.vis_i), len(w3.plane_pose) + len(w3.edge_pose), "sharded over %d GPUs" % world if sharded else ("1 GPU" if world == 1 else "%d replicas" % world))}
+        leg = {"value": itx / elx, "unit": "iterations/s", "n_gpus": world, "ms_per_step": 1e3 * elx / nx, "steps": nx, "iterations_per_solve": lx.iterations,
+               "workload": "BASELINE.json configs[%d]: K=%d, L=%d, %d visual factors, %d LiDAR points, prior n=%d, %s" % (cfg_id - 1, wx.K, wx.L, len(wx.vis_i), len(wx.plane_pose) + len(wx.edge_pose), wx.prior.n, "sharded over %d GPUs" % world if sharded else ("1 GPU" if world == 1 else "%d replicas" % world))}
+        return leg, wx, profx, nx
+    cfg3_leg = cfg4_leg = None
+    if args.config == 2 and not args.no_cfg3:
+        cfg3_leg, w3, prof3, n3 = window_leg(3)
+        cfg4_leg, w4, prof4, n4 = window_leg(4)
     if rank == 0:
         out = {
             "metric": "sliding-window solve iterations/sec (10 KF, 1k feat, 30k LiDAR pts)",
@@ -722,15 +784,20 @@ def main():
             out["replicas"] = replicas_leg
         if prof.sweep_launches > 0:
             out["roofline"] = roofline_obj(w, prof, "second pass of the same %d steps with HIP events enabled (%.1f ms/step instrumented vs %.1f ms/step in the value region)" % (args.steps, 1e3 * el_events / args.steps, 1e3 * max_el / args.steps),
-                                           ("r03_pmc_fetch_size.csv", "r03_pmc_write_size.csv"), "profiles/r03_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command)")
+                                           ("r04_pmc_fetch_size.csv", "r04_pmc_write_size.csv"), "profiles/r04_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command)", "r04_pmc_mfma.csv")
         if world == 1:
             out["pcie_inclusive"] = pcie_leg
             out["pcie_inclusive_classic"] = pcie_classic
         if cfg3_leg:
             if prof3.sweep_launches > 0:
-                cfg3_leg["roofline"] = roofline_obj(w3, prof3, "a further pass of the same %d steps with HIP events enabled" % n3, ("r03_pmc_fetch_size_c3.csv", "r03_pmc_write_size_c3.csv"),
-                                                    "profiles/r03_pmc_{fetch,write}_size_c3.csv (rocprofv3 --pmc passes of tools/run_configs.py 3)")
+                cfg3_leg["roofline"] = roofline_obj(w3, prof3, "a further pass of the same %d steps with HIP events enabled" % n3, ("r04_pmc_fetch_size_c3.csv", "r04_pmc_write_size_c3.csv"),
+                                                    "profiles/r04_pmc_{fetch,write}_size_c3.csv (rocprofv3 --pmc passes of bench.py --config 3)", "r04_pmc_mfma_c3.csv")
             out["configs2_window"] = cfg3_leg
+        if cfg4_leg:
+            if prof4.sweep_launches > 0:
+                cfg4_leg["roofline"] = roofline_obj(w4, prof4, "a further pass of the same %d steps with HIP events enabled" % n4, ("r04_pmc_fetch_size_c4.csv", "r04_pmc_write_size_c4.csv"),
+                                                    "profiles/r04_pmc_{fetch,write}_size_c4.csv (rocprofv3 --pmc passes of bench.py --config 4)", "r04_pmc_mfma_c4.csv")
+            out["configs3_window"] = cfg4_leg
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(w, opts)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

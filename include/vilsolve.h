@@ -179,7 +179,7 @@ typedef struct vil_problem {
 /* ---- solver options: ceres::Solver::Options as used at estimator.cpp:1400-1411 --------------- */
 typedef struct vil_options {
     int32_t max_iterations;         /* NUM_ITERATIONS (30)                                 */
-    double max_time_s;              /* SOLVER_TIME (0.05); <= 0 disables (parity runs)     */
+    double max_time_s;              /* SOLVER_TIME (0.05); <= 0 disables (parity runs); ignored by sharded (multi-rank) solves */
     double function_tolerance;      /* 1e-6  */
     double gradient_tolerance;      /* 1e-10 */
     double parameter_tolerance;     /* 1e-8  */

@@ -51,7 +51,7 @@ struct DevP {
     int ex_const, td_free, use_td;
     // state double buffer: [pose 7K | sb 9K | ex 7 | td 1 | lam L]
     double* x[2];
-    // visual (SoA: component k of factor f at vis_c[k*vis_stride + f])
+    // visual (SoA: component k of the factor at sorted position p at vis_c[k*vis_stride + p]; sorted = by landmark (first frame, last frame): vfinv / vfac)
     int n_vis, vis_stride;
     const double* vis_c; const int* vis_i; const int* vis_j; const int* vis_l;
     const int* lm_start;      // L+1
@@ -80,7 +80,8 @@ struct DevP {
     int n_vwg, vis_ts;            // chunks; accumulator tiles per wave the widest chunk needs (k_sweep<vis_ts>: 2 or 5)
     const int* vwg;               // n_vwg x 8: {first sorted landmark, landmarks, first sorted factor, factors} {first frame, frames, column tiles T, record offset / 16}
     const int* vlm;               // sorted landmarks x 4: {landmark, chunk-local first factor, factors, anchor frame}
-    const int* vfac;              // sorted factors x 2: {factor, chunk-local landmark}
+    const int* vfac;              // sorted factors x 2: {factor (the caller's index), chunk-local landmark}; vis_c / vis_i / vis_j / vis_l are stored in SORTED order
+    const int* vfinv;             // caller's factor index -> sorted position (vil_eval_factors, k_win_pack)
     const int* vrec;              // n_vwg x 4: {record offset / 16, first frame, frames, T} (what the gather needs of vwg)
     const int* vwend;             // K: chunks whose first frame is <= f (the chunks are sorted by first frame)
     double* vpart;                // the records: per chunk T (T + 1) / 2 upper 16 x 16 tiles of its window | bc 16 T | diag 16 T | cost (+ padding to 16)
@@ -125,6 +126,7 @@ struct DevP {
     // gather + step in ONE launch (rs_merged): grid = [master | helpers | chain | W W^T tiles (n_ww) | gather (n_gather)]; a workgroup that is
     // done posts the launch epoch in its flag -- gflag[n_gather], chflag, wwflag[n_ww] -- and the master / helpers / tile workgroups wait on them
     int rs_merged, n_ww, n_gather; int* gflag; int* chflag; int* wwflag;
+    int gather_pose_only;          // the gather forms S' on the visual sub-space + the diagonal only (a solve on the prechain path: vil_sweep.hpp, reduce_gather)
     double* chW; double* chLraw; double* chLdg; double* chLsb; double* chSc; double* chDc; double* chZ; double* chQ; int* chOk; double* chWW;
 };
 

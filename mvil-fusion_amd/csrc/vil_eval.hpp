@@ -13,9 +13,10 @@ __global__ void k_eval_visual(DevP P, const double* x, double* r, double* J) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= P.n_vis) return;
     double c[14];
+    const int fs = P.vfinv[f];                           // the tables are stored in the sweep's sorted order; the output keeps the caller's factor order
 #pragma unroll
-    for (int k = 0; k < 14; ++k) c[k] = P.vis_c[(size_t)k * P.vis_stride + f];
-    const int i = P.vis_i[f], j = P.vis_j[f], l = P.vis_l[f];
+    for (int k = 0; k < 14; ++k) c[k] = P.vis_c[(size_t)k * P.vis_stride + fs];
+    const int i = P.vis_i[fs], j = P.vis_j[fs], l = P.vis_l[fs];
     const double* pi = x + xo_pose(P, i); const double* pj = x + xo_pose(P, j); const double* ex = x + xo_ex(P);
     VisJ o;
     visual_eval(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},

@@ -174,7 +174,6 @@ __device__ __forceinline__ double rcp_nr(double x) {
     return y;
 }
 
-__device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
 // robust loss: rho(s), rho'(s) for ceres CauchyLoss(a)/HuberLoss(a). Both have rho'' <= 0, so the
 // corrector of marginalization_factor.cpp:37-67 reduces to r <- sqrt(rho') r, J <- sqrt(rho') J.

