@@ -78,6 +78,43 @@ public:
     void clear_depth(const double* inv_depth) { int i = 0; for (FeatureTrack& t : tracks_) if (in_problem(t)) { t.estimated_depth = 1.0 / inv_depth[i++]; t.lidar_depth_flag = false; } }
     void remove_failures() { erase_if([](const FeatureTrack& t) { return t.solve_flag == 2; }); }                  // :170-179
 
+    // triangulate (feature_manager.cpp:214-273): a landmark of the problem without a depth yet gets one from the window's poses -- the null vector of the
+    // stacked projection constraints [f_x P_2 - f_z P_0 ; f_y P_2 - f_z P_1] of its observations (f = point.normalized(), P = [R^T | -R^T t] relative to
+    // the anchor camera), depth = V_2 / V_3; a negative result becomes INIT_DEPTH.  pose: K x [p q(xyzw)] body poses, ex: [tic qic(xyzw)].  The reference
+    // takes the last right singular vector of a JacobiSVD; here: the eigenvector of the smallest eigenvalue of A^T A (4 x 4, cyclic Jacobi) -- the same
+    // direction up to sign, and the quotient does not see the sign.
+    void triangulate(const double* pose, const double* ex) {
+        double Ric[9]; quat_R(ex + 3, Ric);
+        for (FeatureTrack& t : tracks_) {
+            if (!in_problem(t) || t.estimated_depth > 0) continue;
+            double B[16] = {0};
+            double R0[9], t0[3];
+            cam_pose(pose + 7 * t.start_frame, ex, Ric, R0, t0);
+            for (size_t m = 0; m < t.obs.size(); ++m) {
+                double R1[9], t1[3], P[12];
+                cam_pose(pose + 7 * (t.start_frame + (int)m), ex, Ric, R1, t1);
+                // R = R0^T R1, t = R0^T (t1 - t0); P = [R^T | -R^T t] = [R1^T R0 | -R1^T (t1 - t0)]
+                const double d[3] = {t1[0] - t0[0], t1[1] - t0[1], t1[2] - t0[2]};
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c) P[4 * r + c] = R1[r] * R0[c] + R1[3 + r] * R0[3 + c] + R1[6 + r] * R0[6 + c];
+                    P[4 * r + 3] = -(R1[r] * d[0] + R1[3 + r] * d[1] + R1[6 + r] * d[2]);
+                }
+                const FeatureObs& o = t.obs[m];
+                const double n = std::sqrt(o.point[0] * o.point[0] + o.point[1] * o.point[1] + o.point[2] * o.point[2]);
+                const double f[3] = {o.point[0] / n, o.point[1] / n, o.point[2] / n};
+                for (int row = 0; row < 2; ++row) {
+                    double a[4];
+                    for (int c = 0; c < 4; ++c) a[c] = f[row] * P[8 + c] - f[2] * P[4 * row + c];
+                    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) B[4 * i + j] += a[i] * a[j];
+                }
+            }
+            double V[16]; jacobi4(B, V);
+            int kmin = 0; for (int k = 1; k < 4; ++k) if (B[5 * k] < B[5 * kmin]) kmin = k;
+            const double depth = V[4 * 2 + kmin] / V[4 * 3 + kmin];
+            t.estimated_depth = depth < 0 ? init_depth_ : depth;
+        }
+    }
+
     // slideWindowOld with shift_depth (estimator.cpp:1798-1813, feature_manager.cpp:286-346): the oldest frame leaves; tracks
     // anchored in it move their depth into the next frame.  R / P: camera-to-world of the leaving (0) and the new first (1) frame, row-major.
     void remove_back_shift_depth(const double R0[9], const double P0[3], const double R1[9], const double P1[3]) {
@@ -152,6 +189,36 @@ public:
     }
 
 private:
+    static void quat_R(const double* q, double* R) {            // [x y z w] -> row-major rotation
+        const double x = q[0], y = q[1], z = q[2], w = q[3];
+        R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+        R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+        R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+    }
+    static void cam_pose(const double* pose7, const double* ex, const double* Ric, double* Rc, double* tc) {      // R_wc = R_wb R_ic, t_wc = p + R_wb t_ic
+        double Rb[9]; quat_R(pose7 + 3, Rb);
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) Rc[3 * r + c] = Rb[3 * r] * Ric[c] + Rb[3 * r + 1] * Ric[3 + c] + Rb[3 * r + 2] * Ric[6 + c];
+            tc[r] = pose7[r] + Rb[3 * r] * ex[0] + Rb[3 * r + 1] * ex[1] + Rb[3 * r + 2] * ex[2];
+        }
+    }
+    static void jacobi4(double* A /* symmetric 4 x 4, eigenvalues left on the diagonal */, double* V /* eigenvectors in columns */) {
+        for (int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            double off = 0.0;
+            for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) off += A[4 * p + q] * A[4 * p + q];
+            if (off < 1e-300) break;
+            for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) {
+                const double apq = A[4 * p + q];
+                if (apq == 0.0) continue;
+                const double th = (A[5 * q] - A[5 * p]) / (2.0 * apq);
+                const double tt = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0)), cs = 1.0 / std::sqrt(tt * tt + 1.0), sn = tt * cs;
+                for (int k = 0; k < 4; ++k) { const double akp = A[4 * k + p], akq = A[4 * k + q]; A[4 * k + p] = cs * akp - sn * akq; A[4 * k + q] = sn * akp + cs * akq; }
+                for (int k = 0; k < 4; ++k) { const double apk = A[4 * p + k], aqk = A[4 * q + k]; A[4 * p + k] = cs * apk - sn * aqk; A[4 * q + k] = sn * apk + cs * aqk; }
+                for (int k = 0; k < 4; ++k) { const double vkp = V[4 * k + p], vkq = V[4 * k + q]; V[4 * k + p] = cs * vkp - sn * vkq; V[4 * k + q] = sn * vkp + cs * vkq; }
+            }
+        }
+    }
     FeatureTrack* find(int id) { for (FeatureTrack& t : tracks_) if (t.feature_id == id) return &t; return nullptr; }
     template <class Pred> void erase_if(Pred p) { tracks_.erase(std::remove_if(tracks_.begin(), tracks_.end(), p), tracks_.end()); }
     // compensatedParallax2 (:386-417): image-plane distance between the second- and third-newest frames

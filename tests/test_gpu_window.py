@@ -176,3 +176,56 @@ def test_resident_window_reports_a_failed_frame_at_the_next_solve():
         be.win_push_frame(rp.win_frame(k))
     assert be.win_solve(w, rp.opts).iterations >= 1
     be.close()
+
+
+def test_full_size_replay_through_the_resident_window(oracle, capsys):
+    """BASELINE.json configs[4] at FULL size as a driver-run test: 100 images of the K = 10 / ~1000-landmark / 30 k-LiDAR-point synthetic replay through
+    vil_win_* (3indoor.bag is not available offline: SURVEY 8d).  Every 10th image the ORACLE is handed the same input window (host tables rebuilt from
+    the replay's bookkeeping, the prior downloaded from the device slot) and must produce the same solve; on the other images the chain simply has to keep
+    running -- an error anywhere shows up at the next checkpoint, the window carries it forward.  A second pass runs the same sequence with fp32 factor
+    evaluation (vil_options.precision = 1, fp64 accumulation and solve) and RECORDS its deviation from the fp64 chain (reported, not asserted
+    beyond a sanity bound)."""
+    K, N = 10, 100
+    kw = dict(K=K, n_frames=N + K + 2, L=1000, n_plane=24000, n_edge=6000, seed=20240605, max_iterations=8)
+
+    def chain(precision, check):
+        rp = replay.Replay(**kw)
+        rp.opts.precision = precision
+        be = lib.open_vilsolve()
+        _open(be, rp)
+        newest, worst, nchk, sizes = [], dict(dpos=0.0, drot=0.0, dcost=0.0), 0, []
+        for step in range(N):
+            flag = rp.margin_flag()
+            w = rp.win_window()
+            wo = None
+            if check and step % 10 == 0:
+                rp.prior = be.win_prior_download(K).to_prior() or rp.prior
+                wo = Window.from_dict(rp.window().to_dict())
+            p0 = w.pose[0].copy()
+            sg = be.win_solve(w, rp.opts)
+            sizes.append((w.L, sum(int(n) - 1 for n in w.lm_nobs)))
+            if wo is not None:
+                so = oracle.solve(wo, rp.opts); oracle.gauge_fix(p0, wo)
+                assert (sg.iterations, sg.termination) == (so.iterations, so.termination), (step, sg.iterations, so.iterations)
+                dp = np.abs(w.pose[:, :3] - wo.pose[:, :3]).max(); dr = max(_rot_angle(w.pose[k, 3:], wo.pose[k, 3:]) for k in range(K))
+                dc = abs(sg.final_cost - so.final_cost) / max(1.0, abs(so.final_cost))
+                worst = dict(dpos=max(worst["dpos"], dp), drot=max(worst["drot"], dr), dcost=max(worst["dcost"], dc)); nchk += 1
+                assert dp < 1e-6 and dr < 1e-7 and dc < 1e-7, (step, dp, dr, dc)
+                assert np.abs(w.speedbias - wo.speedbias).max() < 1e-6 and np.abs(w.inv_depth - wo.inv_depth).max() < 1e-6
+            be.win_marginalize(flag, w._icp_marg, w._lps_marg, rp.opts)
+            newest.append(w.pose[K - 1].copy())
+            be.win_drop_frame(flag)
+            assert rp.absorb(w, None, flag)
+            be.win_push_frame(rp.win_frame(K - 1))
+        be.close()
+        return np.array(newest), worst, nchk, sizes
+    p64, worst, nchk, sizes = chain(0, True)
+    assert nchk == 10
+    Ls, Fs = [s[0] for s in sizes], [s[1] for s in sizes]
+    assert 800 <= np.mean(Ls) <= 1300 and np.mean(Fs) >= 2500            # configs[1]-shaped windows on every image
+    p32, _, _, _ = chain(1, False)
+    d32 = np.abs(p32[:, :3] - p64[:, :3]).max()
+    with capsys.disabled():
+        print("\n[full-size replay, %d images, L ~ %.0f, ~%.0f visual factors, 30 k LiDAR points] fp64 vs oracle at %d checkpoints: dpos %.2e m, drot %.2e rad, dcost %.2e | "
+              "fp32 evaluation vs fp64 chain: max position deviation %.2e m" % (N, np.mean(Ls), np.mean(Fs), nchk, worst["dpos"], worst["drot"], worst["dcost"], d32))
+    assert d32 < 5e-3                                                     # sanity only (measured ~1e-4 m: the replay of bench.py --replay --precision 1)
