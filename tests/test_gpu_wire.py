@@ -4,7 +4,9 @@ correspondences goes through vil::decode_feature_cloud -> vil::FeatureTable::add
 marginalize / drop_frame on the GPU, and the reference's trajectory log (visualization.cpp:199-212) comes out.  The log is compared, line by line, with
   (a) the HARNESS chain: the same sequence through a Python mirror of the per-image loop (tests/wire_chain.py: the line-by-line transcription of
       FeatureManager, every table packed on the host) on the library's CLASSIC entry points vil_solve / vil_gauge_fix / vil_marginalize, and
-  (b) the ORACLE chain: the same mirror on the CPU restatement.
+  (b) the ORACLE: on every image the CPU restatement is handed the harness chain's input window (same tables, prior and state) and logs its own line --
+      a shadow, not a second chain (a landmark whose solved inverse depth sits at zero is dropped or kept on rounding noise, feature_manager.cpp:150-179,
+      and independent chains then differ by a landmark from that image on).
 Both marginalisation branches occur (the parallax test of addFeatureCheckParallax decides, feature_manager.cpp:82-105)."""
 import os
 import subprocess
@@ -36,8 +38,7 @@ def test_wire_format_replay_end_to_end(hip, oracle, tmp_path):
     rows = [l.split() for l in out.splitlines() if l.startswith("IMG")]
     assert len(rows) == seq["n_images"]
     cpp = formats.parse_trajectory(open(logp).read())
-    text_h, rec_h = wc.run_chain(hip, seq)
-    text_o, rec_o = wc.run_chain(oracle, seq)
+    text_h, rec_h, text_o, rec_o = wc.run_chain(hip, seq, shadow=oracle)
     har, orc = formats.parse_trajectory(text_h), formats.parse_trajectory(text_o)
     assert cpp.shape == har.shape == orc.shape == (seq["n_images"], 8)
     # the structure of every image: marginalisation branch, landmark count, iteration count, size of the new prior

@@ -111,9 +111,12 @@ def _triangulate(fm, pose, ex, W):
         it["estimated_depth"] = INIT_DEPTH if d < 0 else d
 
 
-def run_chain(backend, seq, log_path=None):
+def run_chain(backend, seq, log_path=None, shadow=None):
     """The estimator's per-image loop in Python on the CLASSIC entry points of `backend` (lib.Backend: HIP library or oracle).  Returns the Frontend.txt
-    text and per-image records."""
+    text and per-image records.  shadow: a second backend that is handed a copy of EVERY image's input window (same tables, same prior, same state) and
+    whose results are logged beside the chain's but never fed back -- the comparator of a chain must not run its own: a landmark whose solved inverse
+    depth sits at zero is removed or kept on the sign of rounding noise (setDepth / removeFailures, feature_manager.cpp:150-179), and two independent
+    chains then differ by a landmark from that image on.  With a shadow the return value is (text, records, shadow text, shadow records)."""
     K = seq["K"]; W = K - 1
     tfm.W, tfm.INIT_DEPTH, tfm.MIN_PARALLAX = W, seq["init_depth"], seq["min_parallax"]          # the transcription reads its constants from the module
     fm = tfm.RefFeatureManager()
@@ -161,7 +164,7 @@ def run_chain(backend, seq, log_path=None):
     frames = seq["frames"]
     for k in range(K):
         take(k, frames[k], True)
-    lines, recs = [], []
+    lines, recs, slines, srecs = [], [], [], []
     for img in range(seq["n_images"]):
         flag = abi.MARGIN_OLD if state["kf"] else abi.MARGIN_SECOND_NEW
         _triangulate(fm, pose, ex, W)
@@ -186,6 +189,12 @@ def run_chain(backend, seq, log_path=None):
         w.edge_pose = np.concatenate([np.full(len(lidar[k][1]), k, np.int32) for k in range(K)]); w.edge_const = np.concatenate([lidar[k][1] for k in range(K)])
         w.prior = prior
         p0 = w.pose[0].copy()
+        if shadow is not None:
+            ws = Window.from_dict(w.to_dict()); ws.prior = prior
+            ss = shadow.solve(ws, opts); shadow.gauge_fix(p0, ws)
+            ps = shadow.marginalize(ws, flag, -1, -1, opts)
+            slines.append(formats.format_trajectory_line(stamp[K - 1], ws.pose[K - 1, :3], ws.pose[K - 1, 3:]))
+            srecs.append(dict(flag=int(flag), L=len(sel), iterations=ss.iterations, final_cost=ss.final_cost, n=ps.c.n))
         summ = backend.solve(w, opts); backend.gauge_fix(p0, w)
         pose[:], sb[:], ex[:], td[:] = w.pose, w.speedbias, w.ex_pose, w.td
         fm.setDepth(list(w.inv_depth))
@@ -215,4 +224,6 @@ def run_chain(backend, seq, log_path=None):
     if log_path:
         with open(log_path, "w") as f:
             f.write(text)
+    if shadow is not None:
+        return text, recs, "".join(slines), srecs
     return text, recs
