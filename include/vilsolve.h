@@ -267,6 +267,11 @@ int vil_comm_init_local(vil_ctx** ctxs, int n);
  * largest window, vil_reduced_dim(K)^2 + 3 D + 4 + 17 L + 6 F doubles) and returns its 64-byte IPC handle; the launcher gathers the
  * `world` handles in rank order (any transport) and every rank calls vil_comm_ipc_init.  Same sharding, same call sequence and the same
  * bit-identical results on every rank as with vil_comm_init; the collective is three small launches in stream order. */
+/* What travels per trust-region iteration through these exchanges (and vil_comm_init_local): of the set [S' | g | cost | landmark arrays] the lower
+ * triangle of S', the vectors and THIS RANK's slice of the landmark arrays (a landmark's entries are non-zero on its owner only: the sum over ranks is
+ * the owner's value) -- 103 + 380 / world kB per peer at K = 10 / 1000 landmarks instead of 484 kB.  vil_comm_message_bytes reports it for the
+ * uploaded (sharded) window. */
+int vil_comm_message_bytes(vil_ctx* ctx, int64_t* bytes_per_peer, int64_t* bytes_full_set);
 int vil_comm_ipc_export(vil_ctx* ctx, int rank, int world, size_t max_doubles, void* handle64);
 int vil_comm_ipc_init(vil_ctx* ctx, const void* handles /* world x 64 bytes */);
 /* test hook: run the multi-GPU plumbing (partial system in set 0, the collective sums it into set 1, step kernel on set 1) on a

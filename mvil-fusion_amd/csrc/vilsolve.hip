@@ -120,11 +120,28 @@ __device__ __forceinline__ void sym_store(double* out, size_t e, int sym, double
     out[e] = v;
     if (sym && e < (size_t)sym * sym) { const int i = (int)(e / sym), j = (int)(e - (size_t)i * sym); if (j < i) out[(size_t)j * sym + i] = v; }
 }
-__global__ void k_ipc_push(const double* send, size_t cnt, IpcPtrs I, int sym) {
+// Owned segments of the per-iteration message [camera part | h_ll, b_l, 1/pivot, scale (L each) | e_A (13 L) | e_O (6 F)]: a landmark's entries are
+// non-zero on ONE rank, its owner (contiguous landmark / factor ranges, vil_shard_ranges) -- "sum over the ranks" of that part is "take the owner's value"
+// (x + 0 + ... + 0 = x: the same bits).  The library's own exchanges therefore move the camera part of every rank but only the OWNED slice of the landmark
+// arrays: per peer 103 + 380 / world kB instead of 390 kB at K = 10 / 1000 landmarks (150 kB at world = 8), and the summing kernel reads one inbox for them.
+struct OwnSeg { size_t cam; int Lp, n; int lb[9], fb[9]; };      // n = 0: a plain sum of everything (marginalisation, agreements)
+__device__ __forceinline__ int seg_owner(const OwnSeg& S, size_t e) {          // -1: summed over all ranks
+    if (S.n == 0 || e < S.cam) return -1;
+    const size_t a = e - S.cam, Lp = (size_t)S.Lp;
+    const bool lm = a < 17 * Lp;
+    const int v = a < 4 * Lp ? (int)(a % Lp) : (lm ? (int)((a - 4 * Lp) / 13) : (int)((a - 17 * Lp) / 6));
+    const int* b = lm ? S.lb : S.fb;
+    int r = 0;
+    while (r + 1 < S.n && v >= b[r + 1]) ++r;
+    return r;
+}
+__global__ void k_ipc_push(const double* send, size_t cnt, IpcPtrs I, int sym, OwnSeg S) {
     const int sq = *I.seq + 1, par = sq & 1;
     const size_t off = ((size_t)I.rank * 2 + par) * I.cap;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (size_t)gridDim.x * blockDim.x) {
         if (sym_skip(e, sym)) continue;
+        const int own = seg_owner(S, e);
+        if (own >= 0 && own != I.rank) continue;          // somebody else's landmark: zero here, nothing to send
         const double v = send[e];
         for (int r = 0; r < I.world; ++r) I.inbox[r][off + e] = v;
     }
@@ -144,21 +161,25 @@ __global__ void k_ipc_wait(IpcPtrs I) {
     const int sq = *I.seq, par = sq & 1, t = threadIdx.x;       // (k_ipc_push of this collective has advanced it: same stream)
     if (t < I.world) while (__hip_atomic_load(I.flags[I.rank] + 16 * (t * 2 + par), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != sq) __builtin_amdgcn_s_sleep(8);
 }
-__global__ void k_ipc_sum(double* out, size_t cnt, IpcPtrs I, int sym) {
+__global__ void k_ipc_sum(double* out, size_t cnt, IpcPtrs I, int sym, OwnSeg S) {
     const int par = *I.seq & 1;
     const double* in = I.inbox[I.rank];
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (size_t)gridDim.x * blockDim.x) {
         if (sym_skip(e, sym)) continue;
+        const int own = seg_owner(S, e);
         double s = 0;
-        for (int r = 0; r < I.world; ++r) s += __builtin_nontemporal_load(in + ((size_t)r * 2 + par) * I.cap + e);      // written by peers: not through a stale cache line
+        if (own >= 0) s = __builtin_nontemporal_load(in + ((size_t)own * 2 + par) * I.cap + e);                        // the owner's entry (everybody else's is zero and did not travel)
+        else for (int r = 0; r < I.world; ++r) s += __builtin_nontemporal_load(in + ((size_t)r * 2 + par) * I.cap + e);      // written by peers: not through a stale cache line
         sym_store(out, e, sym, s);
     }
 }
-__global__ void k_sum_peers(double* out, PeerPtrs pp, size_t cnt, int sym) {
+__global__ void k_sum_peers(double* out, PeerPtrs pp, size_t cnt, int sym, OwnSeg S) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (size_t)gridDim.x * blockDim.x) {
         if (sym_skip(e, sym)) continue;
+        const int own = seg_owner(S, e);
         double s = 0;
-        for (int r = 0; r < pp.n; ++r) s += pp.p[r][e];          // rank order: identical bits on every rank
+        if (own >= 0) s = pp.p[own][e];
+        else for (int r = 0; r < pp.n; ++r) s += pp.p[r][e];     // rank order: identical bits on every rank
         sym_store(out, e, sym, s);
     }
 }
@@ -213,6 +234,7 @@ struct vil_ctx {
     bool force_split = false;      // vil_debug_set_split: that plumbing on a single rank
     int last_live = 5;             // live sweep launches of the previous solve (sizes the first launch chunk)
     int lm_b = 0, lm_e = 0;        // owned landmark range
+    OwnSeg own = {0, 0, 0, {0}, {0}};      // every rank's landmark / factor range in the per-iteration message (sharded windows)
     // ---- window residency across frames (vil_lidar_*, vil_set_gauge_fix, vil_marginalize_resident) --------------------------------
     struct Slab { int np, ne, slot; };
     std::vector<Slab> slabs;       // window order: slab i <-> pose K - count + i
@@ -1034,6 +1056,18 @@ static int upload_sharded(vil_ctx* c, const vil_problem* p, const vil_state* s) 
     }
     if (c->rank != 0) { q.n_imu = 0; q.n_icp = 0; q.n_lps = 0; q.prior.n = 0; q.prior.nblk = 0; }
     c->lm_b = lb; c->lm_e = le;
+    {   // who owns which slice of the landmark arrays of the message (the same arithmetic on every rank)
+        OwnSeg& S = c->own; memset(&S, 0, sizeof S);
+        S.n = c->world; S.Lp = std::max(p->L, 1);
+        for (int r = 0; r < c->world; ++r) {
+            int32_t b = 0; vil_shard_ranges(p, r, c->world, &b, nullptr, nullptr, nullptr, nullptr, nullptr);
+            S.lb[r] = b; int fb = 0; for (int f = 0; f < p->n_vis; ++f) if (p->vis_l[f] < b) fb = f + 1;
+            S.fb[r] = fb;
+        }
+        S.lb[c->world] = p->L; S.fb[c->world] = p->n_vis;
+        const int D = 15 * p->K + 7;
+        S.cam = ((size_t)D * D + 3 * (size_t)D + 3 + 1) & ~size_t(1);
+    }
     st = comm_agree(c, upload_impl(c, &q, s, true, nullptr, p, f0));       // e.g. rank 0's IMU set-up failed: every rank reports it
     if (st != VIL_OK) c->uploaded = false;
     return st;
@@ -1050,7 +1084,8 @@ static int upload_window(vil_ctx* c, const vil_problem* p, const vil_state* s, b
 int vil_upload(vil_ctx* c, const vil_problem* p, const vil_state* s) { return upload_window(c, p, s, true); }
 
 // sum over the ranks of the communicator, in stream order: recv = sum of every rank's send (recv may be send)
-static int ipc_all_reduce(vil_ctx* c, const double* send, double* recv, size_t cnt, int sym = 0) {
+static const OwnSeg kNoSeg = {0, 0, 0, {0}, {0}};
+static int ipc_all_reduce(vil_ctx* c, const double* send, double* recv, size_t cnt, int sym = 0, const OwnSeg& seg = kNoSeg) {
     IpcComm* ic = c->ipc.get();
     if (!ic->ready) return VIL_ERR_COMM;                // vil_comm_ipc_export without vil_comm_ipc_init: the peers' inboxes are not mapped yet
     if (cnt > ic->cap) return VIL_ERR_UNSUPPORTED;      // the inbox was sized at vil_comm_ipc_export
@@ -1058,13 +1093,13 @@ static int ipc_all_reduce(vil_ctx* c, const double* send, double* recv, size_t c
     for (int r = 0; r < ic->world; ++r) { I.inbox[r] = ic->inbox(r); I.flags[r] = ic->flags(r); }
     I.world = ic->world; I.rank = ic->rank; I.cap = ic->cap; I.seq = ic->seq(); I.count = ic->seq() + 16;
     const unsigned nb = (unsigned)std::min<size_t>(128, (cnt + 255) / 256);
-    hipLaunchKernelGGL(k_ipc_push, dim3(nb), dim3(256), 0, c->stream, send, cnt, I, sym);
+    hipLaunchKernelGGL(k_ipc_push, dim3(nb), dim3(256), 0, c->stream, send, cnt, I, sym, seg);
     hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(64), 0, c->stream, I);
-    hipLaunchKernelGGL(k_ipc_sum, dim3(nb), dim3(256), 0, c->stream, recv, cnt, I, sym);
+    hipLaunchKernelGGL(k_ipc_sum, dim3(nb), dim3(256), 0, c->stream, recv, cnt, I, sym, seg);
     return VIL_OK;
 }
-static int all_reduce2(vil_ctx* c, const double* send, double* recv, size_t cnt, int sym = 0) {
-    if (c->ipc) return ipc_all_reduce(c, send, recv, cnt, sym);
+static int all_reduce2(vil_ctx* c, const double* send, double* recv, size_t cnt, int sym = 0, const OwnSeg& seg = kNoSeg) {
+    if (c->ipc) return ipc_all_reduce(c, send, recv, cnt, sym, seg);
     if (c->comm) return g_rccl.AllReduce(send, recv, cnt, ncclDouble, ncclSum, c->comm, c->stream) == ncclSuccess ? VIL_OK : VIL_ERR_COMM;
     if (c->lcomm) {
         LocalComm* lc = c->lcomm.get();
@@ -1077,7 +1112,7 @@ static int all_reduce2(vil_ctx* c, const double* send, double* recv, size_t cnt,
         if (st != VIL_OK) return st;
         PeerPtrs pp; pp.n = lc->n;
         for (int r = 0; r < 8; ++r) pp.p[r] = r < lc->n ? lc->ptr[r] : nullptr;
-        hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)std::min<size_t>(256, (cnt + 255) / 256)), dim3(256), 0, c->stream, inplace ? c->lc_tmp : recv, pp, cnt, sym);
+        hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)std::min<size_t>(256, (cnt + 255) / 256)), dim3(256), 0, c->stream, inplace ? c->lc_tmp : recv, pp, cnt, sym, seg);
         if (hipStreamSynchronize(c->stream) != hipSuccess) st = VIL_ERR_DEVICE;
         st = lc->agree(c->rank, st);                          // every rank has read every buffer
         if (st != VIL_OK) return st;
@@ -1101,7 +1136,7 @@ static int all_reduce(vil_ctx* c, double* buf, size_t cnt) {
         if (st != VIL_OK) return st;
         PeerPtrs pp; pp.n = lc->n;
         for (int r = 0; r < 8; ++r) pp.p[r] = r < lc->n ? lc->ptr[r] : nullptr;
-        hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)std::min<size_t>(256, (cnt + 255) / 256)), dim3(256), 0, c->stream, c->lc_tmp, pp, cnt, 0);
+        hipLaunchKernelGGL(k_sum_peers, dim3((unsigned)std::min<size_t>(256, (cnt + 255) / 256)), dim3(256), 0, c->stream, c->lc_tmp, pp, cnt, 0, kNoSeg);
         if (hipStreamSynchronize(c->stream) != hipSuccess) st = VIL_ERR_DEVICE;
         st = lc->agree(c->rank, st);                          // every rank has read every buffer
         if (st != VIL_OK) return st;
@@ -1165,7 +1200,7 @@ static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEve
     }
     if (ev_mid) hipEventRecord(ev_mid, c->stream);
     if (c->split) {                                    // the one collective of the iteration
-        const int st = all_reduce2(c, c->P.sys[0].ar, c->P.sys[1].ar, c->span, c->D);      // (S' first: its lower triangle travels)
+        const int st = all_reduce2(c, c->P.sys[0].ar, c->P.sys[1].ar, c->span, c->D, c->own);      // (S' first: its lower triangle travels; landmark arrays: the owners' slices)
         if (st != VIL_OK) return st;
     }
     if (!step) return VIL_OK;
@@ -1745,6 +1780,20 @@ int vil_shard_ranges(const vil_problem* p, int rank, int world, int32_t* lm_begi
     if (edge_end) *edge_end = (int)((long long)p->n_edge * (rank + 1) / world);
     if (plane_begin) *plane_begin = (int)((long long)p->n_plane * rank / world);
     if (plane_end) *plane_end = (int)((long long)p->n_plane * (rank + 1) / world);
+    return VIL_OK;
+}
+
+// bytes this rank sends to EACH peer per trust-region iteration through the library's own exchanges (peer buffers, in-process communicator): the lower
+// triangle of S' + the vectors + its own slice of the landmark arrays.  (RCCL all-reduces the whole set: vil_comm_init.)
+int vil_comm_message_bytes(vil_ctx* c, int64_t* bytes_per_peer, int64_t* bytes_full_set) {
+    if (!c || !c->uploaded || !c->split) return VIL_ERR_INVALID_ARGUMENT;
+    const OwnSeg& S = c->own;
+    const size_t D = (size_t)c->D, cam_sent = S.cam - D * (D - 1) / 2;
+    size_t own = 0;
+    if (S.n > 0) own = (size_t)17 * (S.lb[c->rank + 1] - S.lb[c->rank]) + (size_t)6 * (S.fb[c->rank + 1] - S.fb[c->rank]);
+    else own = c->span - S.cam;
+    if (bytes_per_peer) *bytes_per_peer = (int64_t)(8 * (cam_sent + own));
+    if (bytes_full_set) *bytes_full_set = (int64_t)(8 * c->span);
     return VIL_OK;
 }
 

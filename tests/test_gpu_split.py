@@ -90,6 +90,13 @@ for world in ((8,) if full else (2, 3)):
             if wo.prior.n:      # (a prior-less window has a 4-dof gauge null space)
                 assert np.abs(ws[r].pose - w1.pose).max() < 1e-9 and np.abs(ws[r].inv_depth - w1.inv_depth).max() < 1e-8
             assert abs(cg - co) <= 1e-11 * co and np.abs(Sg - So).max() <= 1e-9 * np.abs(So).max()
+            # the per-iteration message of this rank to each peer: lower triangle of S' + vectors + its OWN slice of the landmark arrays (SURVEY 8e asks
+            # for ~100 kB: that is the camera part; the landmark arrays are dealt, not replicated)
+            mb, fb = C.c_int64(0), C.c_int64(0)
+            assert bes[r].lib.vil_comm_message_bytes(bes[r].ctx, C.byref(mb), C.byref(fb)) == 0
+            D = 15 * wo.K + 7; cam = 8 * (D * (D + 1) // 2 + 3 * D + 4); lmk = 8 * (17 * wo.L + 6 * len(wo.vis_i))
+            assert cam <= mb.value <= cam + 1.6 * lmk / world + 1024 and fb.value >= 8 * D * D + lmk, (world, r, mb.value, fb.value)
+            if full and cid == 2: assert mb.value <= 160 * 1024, mb.value            # configs[1] on 8 ranks: ~150 kB per peer (484 kB as one all-reduced set)
         # sharded marginalisation (SURVEY 8e last row): the collected factors dealt to the ranks, A / b all-reduced once, the small dense part on
         # every rank -- equal to the un-sharded marginal of the same (solved) window, bit-identical across ranks
         if wo.prior.n and not full:
