@@ -61,7 +61,6 @@ for cid, kw in ((2, dict(L=150, n_plane=3000, n_edge=800)), (1, {}), (2, {})):
         cam = 8 * (D * (D + 1) // 2 + 3 * D + 4)
         assert fb.value >= 8 * (D * D + 17 * w3.L + 6 * len(w3.vis_i))
         assert cam <= mb.value <= cam + 8 * (17 * w3.L + 6 * len(w3.vis_i)) * 0.6, (mb.value, fb.value)      # ~half the landmark arrays at world = 2
-        res["msg"] = (mb.value, fb.value)
         res["resident"] = (w3.pose.copy(), w3.speedbias.copy(), w3.inv_depth.copy(), its[-1], 0.0)
     res[(cid, len(kw))] = (w.pose.copy(), w.speedbias.copy(), w.inv_depth.copy(), sg.iterations, lin[0])
 pickle.dump(res, open(os.path.join(d, "res%d" % rank), "wb"))
