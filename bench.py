@@ -24,7 +24,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 class VilProfile(C.Structure):
-    _fields_ = [("sweep_launches", C.c_int64), ("sweep_ms", C.c_double), ("step_launches", C.c_int64), ("step_ms", C.c_double), ("reduce_ms", C.c_double)]
+    _fields_ = [("sweep_launches", C.c_int64), ("sweep_ms", C.c_double), ("step_launches", C.c_int64), ("step_ms", C.c_double), ("reduce_ms", C.c_double), ("collective_ms", C.c_double)]
 
 
 def algorithmic_bytes(w):
@@ -686,6 +686,16 @@ def main():
         be.lib.vil_profile_enable(be.ctx, 0)
     tot_iters, max_el = iters, el
     region_vals = [i_ / e_ for e_, i_ in regions]
+    # N > 1: where an iteration's time goes on EVERY rank (HIP events of the instrumented pass) -- the curve should explain itself
+    phases = None
+    if dist is not None and prof.sweep_launches > 0:
+        n_it = max(1, prof.step_launches)
+        mine = torch.tensor([1e3 * prof.sweep_ms / max(1, prof.sweep_launches), 1e3 * prof.reduce_ms / n_it, 1e3 * prof.collective_ms / n_it,
+                             1e3 * (prof.step_ms - prof.reduce_ms - prof.collective_ms) / n_it], device="cuda", dtype=torch.float64)
+        allp = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        phases = {"unit": "us per iteration (HIP events on the library's stream, instrumented pass)", "columns": ["sweep", "gather", "collective", "step"],
+                  "per_rank": [[round(float(v), 2) for v in t_.cpu()] for t_ in allp]}
     if dist is not None:
         # every region: MAX over ranks of its time; sharded: all ranks work on the SAME solves (units = its iterations, counted once); replicas: units add up
         tt = torch.tensor([[e_, float(i_)] for e_, i_ in regions], device="cuda", dtype=torch.float64)
@@ -782,6 +792,8 @@ def main():
             out["config"]["note"] = shard_note
         if replicas_leg:
             out["replicas"] = replicas_leg
+        if phases:
+            out["phases_per_rank"] = phases
         if prof.sweep_launches > 0:
             out["roofline"] = roofline_obj(w, prof, "second pass of the same %d steps with HIP events enabled (%.1f ms/step instrumented vs %.1f ms/step in the value region)" % (args.steps, 1e3 * el_events / args.steps, 1e3 * max_el / args.steps),
                                            ("r04_pmc_fetch_size.csv", "r04_pmc_write_size.csv"), "profiles/r04_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command)", "r04_pmc_mfma.csv")

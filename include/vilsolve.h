@@ -301,6 +301,7 @@ typedef struct vil_profile {
     int64_t step_launches;
     double step_ms;                /* sweep end -> next sweep start (reduce + step kernels + boundaries) */
     double reduce_ms;              /* of which: sweep end -> reduce end                         */
+    double collective_ms;          /* of which: reduce end -> end of the iteration's collective (sharded solves; ~0 otherwise) */
 } vil_profile;
 int vil_profile_enable(vil_ctx* ctx, int on);
 int vil_profile_read(vil_ctx* ctx, vil_profile* out, int reset);

@@ -274,7 +274,7 @@ struct vil_ctx {
         size_t prior_doubles() const { return 2 * (size_t)nmax * nmax + 2 * (size_t)nmax + x0max + 8; }
     } win;
     bool profiling = false;
-    std::vector<hipEvent_t> ev, ev_mid;
+    std::vector<hipEvent_t> ev, ev_mid, ev_coll;
     vil_profile prof = {0, 0.0, 0, 0.0, 0.0};
 };
 
@@ -374,6 +374,7 @@ void vil_destroy(vil_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& e : c->ev) hipEventDestroy(e);
     for (auto& e : c->ev_mid) hipEventDestroy(e);
+    for (auto& e : c->ev_coll) hipEventDestroy(e);
     for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->ar.d) hipFree(c->ar.d);
@@ -1187,7 +1188,7 @@ static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
     else hipLaunchKernelGGL(k_sweep<5>, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, view(c, 0), so);
     return VIL_OK;
 }
-static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr) {
+static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr, hipEvent_t ev_coll = nullptr) {
     const bool merged = step && c->P.rs_merged;          // one GPU: the gather rides in the step kernel's launch (vil_step.hpp)
     // (chain eliminated inside k_sweep: one workgroup per W W^T tile rides in the gather launch, one for the inverses of the chain's diagonal blocks in the step launch;
     //  a solve on the prechain path reads S' on the visual sub-space + the diagonal only -- vil_linearize, the marginalisation and sharded solves all of it)
@@ -1203,6 +1204,7 @@ static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEve
         const int st = all_reduce2(c, c->P.sys[0].ar, c->P.sys[1].ar, c->span, c->D, c->own);      // (S' first: its lower triangle travels; landmark arrays: the owners' slices)
         if (st != VIL_OK) return st;
     }
+    if (ev_coll) hipEventRecord(ev_coll, c->stream);
     if (!step) return VIL_OK;
     DevP Ps = view(c, 1);
     if (!merged) { Ps.rs_merged = 0; Ps.n_ww = 0; Ps.n_gather = 0; }
@@ -1228,14 +1230,14 @@ static int init_ctl(vil_ctx* c, const vil_options* o, int lin_mode) {
 int vil_profile_enable(vil_ctx* c, int on) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(c->device));
-    if (on && c->ev.empty()) { c->ev.resize(40); for (auto& e : c->ev) HIPCHK(hipEventCreate(&e)); c->ev_mid.resize(20); for (auto& e : c->ev_mid) HIPCHK(hipEventCreate(&e)); }
+    if (on && c->ev.empty()) { c->ev.resize(40); for (auto& e : c->ev) HIPCHK(hipEventCreate(&e)); c->ev_mid.resize(20); for (auto& e : c->ev_mid) HIPCHK(hipEventCreate(&e)); c->ev_coll.resize(20); for (auto& e : c->ev_coll) HIPCHK(hipEventCreate(&e)); }
     c->profiling = on != 0;
     return VIL_OK;
 }
 int vil_profile_read(vil_ctx* c, vil_profile* out, int reset) {
     if (!c || !out) return VIL_ERR_INVALID_ARGUMENT;
     *out = c->prof;
-    if (reset) c->prof = vil_profile{0, 0.0, 0, 0.0, 0.0};
+    if (reset) c->prof = vil_profile{0, 0.0, 0, 0.0, 0.0, 0.0};
     return VIL_OK;
 }
 
@@ -1318,7 +1320,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
                 if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q], c->stream));
                 launch_sweep(c, so);
                 if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q + 1], c->stream));
-                st = launch_reduce_step(c, so, true, c->profiling ? c->ev_mid[q] : nullptr);
+                st = launch_reduce_step(c, so, true, c->profiling ? c->ev_mid[q] : nullptr, c->profiling ? c->ev_coll[q] : nullptr);
                 if (st != VIL_OK) return st;          // a failed collective fails on every rank (all_reduce): nobody is left waiting
             }
             if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * launched], c->stream));
@@ -1356,6 +1358,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
                 HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * q], c->ev[2 * q + 1])); c->prof.sweep_ms += ms; c->prof.sweep_launches++;
                 HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * q + 1], c->ev[2 * q + 2])); c->prof.step_ms += ms; c->prof.step_launches++;
                 HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * q + 1], c->ev_mid[q])); c->prof.reduce_ms += ms;
+                HIPCHK(hipEventElapsedTime(&ms, c->ev_mid[q], c->ev_coll[q])); c->prof.collective_ms += ms;
             }
         }
         // (sharded solves ignore the host-timed cap: the ranks' clocks disagree, and a rank that stops enqueuing chunks leaves its peers waiting in
