@@ -955,7 +955,10 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         const size_t Tp_ = (size_t)(NV + 1 + 15) / 16, tiles_ = (size_t)TILE_SZ * (Tp_ * (Tp_ + 1) / 2);
         const size_t lds3 = 8 * (tiles_ + 54 * (size_t)K + 82 * (size_t)K + vd::even_up(9 * K) + 16), ldsc = 8 * vd::prechain_lds_doubles(K);
         const bool can_pre = !c->split && pre_ok && P.chain != 0 && Tp_ * (Tp_ + 1) / 2 <= 64 && lds3 + sizeof(vd::StepShared) + 512 <= 160 * 1024 && ldsc <= 150 * 1024;
-        bool merged = can_pre && K <= 12 && std::max(lds3, ldsc) <= 80 * 1024 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
+        // (round 4: every window size -- the gather of a prechain solve forms the visual sub-space only, 551 workgroups at K = 20 instead of 1500)
+        int kmerge = 20;
+        if (const char* ev = VIL_TUNE_ENV("VIL_MERGE_K")) kmerge = atoi(ev);
+        bool merged = can_pre && K <= kmerge && std::max(lds3, ldsc) + 52 * 1024 <= 160 * 1024 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
         if (merged) {
             // the merged launch holds workgroups that spin on flags (master, helpers, one per W W^T tile) next to the finite ones they wait for (chain,
             // gather: lower block indices, dispatched first).  It is only taken when the device can hold every spinning workgroup AND one more at the
