@@ -324,6 +324,17 @@ enum { VIL_LIDAR_EDGE = 0, VIL_LIDAR_PLANE3 = 1, VIL_LIDAR_PLANE_NORM = 2, VIL_L
 int vil_eval_lidar_functors(vil_ctx* ctx, int32_t kind, int32_t n, const double* consts, const double* q_lb, const double* t_lb,
                             const double* pose7, double* residuals, double* jacobians);
 
+/* Plan of the sweep's visual role for a window (host logic, no device needed): the landmarks are sorted by (first frame, last frame), the factor tables
+ * stored in that order and cut into chunks, one per workgroup; a chunk's record is the upper 16 x 16 tiles of ITS frame window.  Diagnostic surface:
+ * chunk count, widest window in column tiles, bytes of all records of one sweep (and what the packed (6K + 7)^2 triangles of rounds 1 - 3 would have been),
+ * dynamic LDS of the sweep; optionally per chunk {first frame, frames, factors, landmarks} and the sorted position of every factor. */
+typedef struct vil_visual_plan_info {
+    int32_t n_chunks, max_tiles, tiles_per_wave, cost_cap;
+    int64_t record_bytes, dense_record_bytes, lds_bytes;
+} vil_visual_plan_info;
+int vil_visual_plan(const vil_problem* problem, vil_visual_plan_info* info, int32_t max_chunks, int32_t* chunk_first_frame, int32_t* chunk_frames,
+                    int32_t* chunk_factors, int32_t* chunk_landmarks, int32_t* factor_position);
+
 /* one linearisation of the whole window: robustified cost and the Schur-reduced normal equations
  * S (D x D row-major, D = vil_reduced_dim(K)), g (D), at `state`, with trust-region damping mu = 0
  * and no Jacobi scaling.  Diagnostic / parity surface of the hot loop's sweep + reduction. */

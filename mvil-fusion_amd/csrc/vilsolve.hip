@@ -468,6 +468,118 @@ static void lidar_chunks(const std::vector<int>& cnt, int K, std::vector<int>& c
     for (int k = 0; k < K; ++k) for (int s = cnt[k]; s < cnt[k + 1]; s += VIL_THREADS) { chunks.push_back(s); chunks.push_back(std::min(VIL_THREADS, cnt[k + 1] - s)); chunks.push_back(k); }
 }
 
+// ---- plan of the visual role (vil_sweep.hpp: sweep_visual), host logic without a device -------------------------------------------------------------
+// The sweep walks the landmarks sorted by (first frame, last frame) -- insertion order in a tracker's feature list is already close to that -- and the
+// factor tables are STORED in that order (sorted position <-> caller's factor: vfac / vfinv), so that a chunk's factors are consecutive rows of the SoA
+// tables.  The sorted list is cut into chunks, one per workgroup, so that (a) a chunk fits the role's LDS (VIS_LM landmarks, VIS_MF factors, VIS_GM doubles of
+// operand rows at the row stride of ITS window), (b) the matrix-core work of a chunk, (rows / 4) x tiles of its window, stays under a cap found by bisection:
+// the smallest one that gives every chunk a compute unit of its own in the first round of the launch (vwg_max).  A chunk below VIL_VCHUNK_FBAL factors is
+// not closed for balance (a workgroup's fixed cost is ~8 us whatever it holds).
+struct VisPlan {
+    std::vector<int> order, fperm, finv;                 // sorted landmarks (those with factors); sorted position -> caller's factor and back
+    std::vector<int> vwg, vrec, vlm, vfac, wend;         // the device tables (vil_dev.hpp)
+    size_t rec_doubles = 0; int n_chunks = 0, tmax = 1, gm = 0, cap = 0;
+};
+static bool plan_visual(const int K, const int L, const int n_vis, const std::vector<int>& lms, const std::vector<int>& fmin, const std::vector<int>& fmax, const std::vector<int>& anch,
+                        const int vwg_max, const int cap_forced, VisPlan& o) {
+    o.order.clear(); o.fperm.assign(std::max(n_vis, 1), 0); o.finv.assign(std::max(n_vis, 1), 0);
+    for (int l = 0; l < L; ++l) if (lms[l + 1] > lms[l]) o.order.push_back(l);
+    std::sort(o.order.begin(), o.order.end(), [&](int a, int b) { return fmin[a] != fmin[b] ? fmin[a] < fmin[b] : (fmax[a] != fmax[b] ? fmax[a] < fmax[b] : a < b); });
+    { int pos = 0; for (int l : o.order) for (int f = lms[l]; f < lms[l + 1]; ++f) { o.fperm[pos] = f; o.finv[f] = pos; ++pos; } }
+    const std::vector<int>& order = o.order;
+    struct Chunk { int p0, nl, nf, fa, span; };
+    std::vector<Chunk> ch;
+    auto cost = [](int nf, int T) { return (vd::vis_rows(nf) / 4 + 4) * vd::vis_ntile(T); };
+    auto cut = [&](int cap) -> bool {
+        ch.clear();
+        Chunk cc{0, 0, 0, 0, 0}; int wlo = K, whi = -1;
+        for (int q = 0; q < (int)order.size(); ++q) {
+            const int l = order[q], n = lms[l + 1] - lms[l];
+            const int lo = std::min(wlo, fmin[l]), hi = std::max(whi, fmax[l]), T = vd::vis_tiles(hi - lo + 1);
+            const bool fits = cc.nl < VIS_LM && cc.nf + n <= VIS_MF && vd::vis_gm_doubles(cc.nf + n, T) <= VIS_GM;
+            if (cc.nl > 0 && (!fits || (cc.nf >= VIL_VCHUNK_FBAL && cost(cc.nf + n, T) > cap))) {
+                cc.fa = wlo; cc.span = whi - wlo + 1; ch.push_back(cc);
+                cc = Chunk{q, 0, 0, 0, 0}; wlo = K; whi = -1;
+            }
+            if (cc.nl == 0 && (n > VIS_MF || vd::vis_gm_doubles(n, vd::vis_tiles(fmax[l] - fmin[l] + 1)) > VIS_GM)) return false;      // a landmark no chunk can hold
+            cc.nl++; cc.nf += n; wlo = std::min(wlo, fmin[l]); whi = std::max(whi, fmax[l]);
+        }
+        if (cc.nl > 0) { cc.fa = wlo; cc.span = whi - wlo + 1; ch.push_back(cc); }
+        return true;
+    };
+    int lo = cost(VIL_VCHUNK_FBAL, 1), hi = cost(VIS_MF, VIS_TMAX);
+    if (cap_forced > 0) lo = hi = cap_forced;
+    if (!cut(lo)) return false;
+    o.cap = lo;
+    if ((int)ch.size() > vwg_max) {
+        while (lo < hi) { const int mid = (lo + hi) / 2; cut(mid); if ((int)ch.size() <= vwg_max) hi = mid; else lo = mid + 1; }
+        cut(hi); o.cap = hi;
+    }
+    const int nw = (int)ch.size();
+    o.n_chunks = nw;
+    o.vwg.assign(8 * (size_t)std::max(nw, 1), 0); o.vrec.assign(4 * (size_t)std::max(nw, 1), 0); o.vlm.assign(4 * std::max(order.size(), (size_t)1), 0); o.vfac.assign(2 * (size_t)std::max(n_vis, 1), 0);
+    size_t roff = 0; int fpos = 0;
+    o.tmax = 1; o.gm = 0;
+    for (int w = 0; w < nw; ++w) {
+        const Chunk& cc = ch[w];
+        const int T = vd::vis_tiles(cc.span);
+        int* d = &o.vwg[8 * (size_t)w];
+        d[0] = cc.p0; d[1] = cc.nl; d[2] = fpos; d[3] = cc.nf; d[4] = cc.fa; d[5] = cc.span; d[6] = T; d[7] = (int)(roff / 16);
+        int* r = &o.vrec[4 * (size_t)w]; r[0] = d[7]; r[1] = cc.fa; r[2] = cc.span; r[3] = T;
+        int floc = 0;
+        for (int q = 0; q < cc.nl; ++q) {
+            const int l = order[cc.p0 + q], n = lms[l + 1] - lms[l];
+            int* e = &o.vlm[4 * (size_t)(cc.p0 + q)]; e[0] = l; e[1] = floc; e[2] = n; e[3] = anch[l];
+            for (int k = 0; k < n; ++k) { o.vfac[2 * (size_t)(fpos + floc + k)] = lms[l] + k; o.vfac[2 * (size_t)(fpos + floc + k) + 1] = q; }
+            floc += n;
+        }
+        fpos += cc.nf; roff += (size_t)vd::vis_rec_doubles(T);
+        o.tmax = std::max(o.tmax, T); o.gm = std::max(o.gm, vd::vis_gm_doubles(cc.nf, T));
+    }
+    o.rec_doubles = roff;
+    o.wend.assign(std::max(K, 1), 0);
+    for (int w = 0; w < nw; ++w) for (int f = ch[w].fa; f < K; ++f) o.wend[f]++;
+    return true;
+}
+// frame range and anchor of every landmark from the caller's factor tables
+static void landmark_frames(const vil_problem* p, std::vector<int>& lms, std::vector<int>& fmin, std::vector<int>& fmax, std::vector<int>& anch) {
+    const int L = p->L, K = p->K;
+    lms.assign(L + 1, 0); fmin.assign(std::max(L, 1), K); fmax.assign(std::max(L, 1), -1); anch.assign(std::max(L, 1), 0);
+    for (int f = 0; f < p->n_vis; ++f) lms[p->vis_l[f] + 1]++;
+    for (int l = 0; l < L; ++l) lms[l + 1] += lms[l];
+    for (int f = 0; f < p->n_vis; ++f) {
+        const int l = p->vis_l[f], lo = std::min(p->vis_i[f], p->vis_j[f]), hi = std::max(p->vis_i[f], p->vis_j[f]);
+        anch[l] = p->vis_i[f]; fmin[l] = std::min(fmin[l], lo); fmax[l] = std::max(fmax[l], hi);
+    }
+}
+static int visual_wg_budget(int n_imu, int n_plane, int n_edge) { return std::max(64, 256 - (n_imu + 3 + (n_plane + 511) / 512 + (n_edge + 511) / 512)); }
+// diagnostic surface of the plan (no device needed: the CPU test suite checks its invariants; DESIGN.md quotes its record sizes)
+int vil_visual_plan(const vil_problem* p, vil_visual_plan_info* info, int32_t max_chunks, int32_t* chunk_first_frame, int32_t* chunk_frames, int32_t* chunk_factors, int32_t* chunk_landmarks,
+                    int32_t* factor_position) {
+    if (!p || !info) return VIL_ERR_INVALID_ARGUMENT;
+    for (int f = 0; f < p->n_vis; ++f) {
+        if (!p->vis_l || !p->vis_i || !p->vis_j || p->vis_l[f] < 0 || p->vis_l[f] >= p->L || p->vis_i[f] < 0 || p->vis_i[f] >= p->K || p->vis_j[f] < 0 || p->vis_j[f] >= p->K) return VIL_ERR_INVALID_ARGUMENT;
+        if (f && p->vis_l[f] < p->vis_l[f - 1]) return VIL_ERR_INVALID_ARGUMENT;
+    }
+    std::vector<int> lms, fmin, fmax, anch;
+    landmark_frames(p, lms, fmin, fmax, anch);
+    VisPlan vp;
+    if (!plan_visual(p->K, p->L, p->n_vis, lms, fmin, fmax, anch, visual_wg_budget(p->n_imu, std::max(p->n_plane, 0), std::max(p->n_edge, 0)), 0, vp)) return VIL_ERR_UNSUPPORTED;
+    memset(info, 0, sizeof *info);
+    info->n_chunks = vp.n_chunks; info->max_tiles = vp.tmax; info->tiles_per_wave = vd::vis_slots(vp.tmax) <= 2 ? 2 : 5; info->cost_cap = vp.cap;
+    info->record_bytes = (int64_t)(8 * vp.rec_doubles); info->lds_bytes = (int64_t)(8 * (size_t)(VIS_LDS_FIXED + vp.gm));
+    info->dense_record_bytes = (int64_t)vp.n_chunks * 8 * ((6 * p->K + 7) * (6 * p->K + 8) / 2 + 3 * (6 * p->K + 7) + 1);
+    for (int w = 0; w < vp.n_chunks && w < max_chunks; ++w) {
+        if (chunk_first_frame) chunk_first_frame[w] = vp.vwg[8 * (size_t)w + 4];
+        if (chunk_frames) chunk_frames[w] = vp.vwg[8 * (size_t)w + 5];
+        if (chunk_factors) chunk_factors[w] = vp.vwg[8 * (size_t)w + 3];
+        if (chunk_landmarks) chunk_landmarks[w] = vp.vwg[8 * (size_t)w + 1];
+    }
+    if (factor_position) for (int f = 0; f < p->n_vis; ++f) factor_position[f] = vp.finv[f];
+    return VIL_OK;
+}
+
+
 // gp / vis_f0 (sharded): the whole window's problem and the index of this rank's first visual factor in it
 // Resident sources of the big tables (vil_win_solve, vil_window.hpp): the visual factor tables are expanded on the device from the landmark
 // list + observation store, IMU records / sqrt-information come from the IMU slots, the prior is the device prior slot.  The vil_problem
@@ -548,18 +660,23 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             for (int f = 0; f < p->n_vis; ++f) lms[p->vis_l[f] + 1]++;
             for (int l = 0; l < L; ++l) lms[l + 1] += lms[l];
         }
-        // the sweep walks the landmarks sorted by (first frame, last frame) -- insertion order in a tracker's feature list is already close to that --
-        // and the factor tables are STORED in that order (sorted position <-> caller's factor: vfac / vfinv), so that a chunk's factors are
-        // consecutive rows of the SoA tables (read through the permutation, a chunk touched twice the cache lines it needed)
-        std::vector<int> fmin(std::max(L, 1), K), fmax(std::max(L, 1), -1), anch(std::max(L, 1), 0), order, fperm(std::max(n_vis, 1), 0), finv(std::max(n_vis, 1), 0);
+        // frame window of every landmark, then the plan of the visual role (plan_visual above: sorted order, chunks, device tables)
+        std::vector<int> fmin(std::max(L, 1), K), fmax(std::max(L, 1), -1), anch(std::max(L, 1), 0);
         if (ws) { for (int l = 0; l < L; ++l) { anch[l] = fmin[l] = ws->lm_startf[l]; fmax[l] = ws->lm_startf[l] + ws->lm_nobs[l] - 1; } }
         else for (int f = 0; f < p->n_vis; ++f) {
             const int l = p->vis_l[f], lo = std::min(p->vis_i[f], p->vis_j[f]), hi = std::max(p->vis_i[f], p->vis_j[f]);
             anch[l] = p->vis_i[f]; fmin[l] = std::min(fmin[l], lo); fmax[l] = std::max(fmax[l], hi);
         }
-        for (int l = 0; l < L; ++l) if (lms[l + 1] > lms[l]) order.push_back(l);
-        std::sort(order.begin(), order.end(), [&](int a, int b) { return fmin[a] != fmin[b] ? fmin[a] < fmin[b] : (fmax[a] != fmax[b] ? fmax[a] < fmax[b] : a < b); });
-        { int pos = 0; for (int l : order) for (int f = lms[l]; f < lms[l + 1]; ++f) { fperm[pos] = f; finv[f] = pos; ++pos; } }
+        VisPlan vp;
+        {
+            int npt = std::max(p->n_plane, 0), net = std::max(p->n_edge, 0);           // LiDAR points of this upload (resident slabs: what they hold)
+            if (p->n_plane == VIL_LIDAR_RESIDENT) for (auto& sl : c->slabs) { npt += sl.np; net += sl.ne; }
+            int vwg_max = visual_wg_budget(p->n_imu, npt, net), cap_forced = 0;
+            if (const char* ev = VIL_TUNE_ENV("VIL_VWG")) vwg_max = std::max(1, atoi(ev));
+            if (const char* ev = VIL_TUNE_ENV("VIL_VCAP")) cap_forced = std::max(1, atoi(ev));
+            if (!plan_visual(K, L, n_vis, lms, fmin, fmax, anch, vwg_max, cap_forced, vp)) return VIL_ERR_UNSUPPORTED;
+        }
+        const std::vector<int>& fperm = vp.fperm; const std::vector<int>& finv = vp.finv;
         put(finv.data(), 4 * finv.size(), (void**)&P.vfinv);
         if (ws) {
             // resident window: the factor tables are device work space, k_win_pack fills them from the observation store
@@ -599,70 +716,13 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             put(gl.data(), 4 * gl.size(), (void**)&P.glm_start); put(gac.data(), 4 * gac.size(), (void**)&P.glm_acol); put(gfc.data(), 4 * gfc.size(), (void**)&P.gfcol);
             P.vis_f0 = vis_f0;
         }
-        // ---- chunks of the visual role (vil_sweep.hpp: sweep_visual): the sorted landmark list is cut so that (a) a chunk fits the role's LDS (VIS_LM landmarks, VIS_MF factors, VIS_GM doubles of operand
-        //      rows at the row stride of ITS window), (b) the matrix-core work of a chunk, (rows / 4) x tiles of its window, stays under a cap found by
-        //      bisection: the smallest one that gives every chunk a compute unit of its own in the first round of the launch.  A chunk below
-        //      VIL_VCHUNK_FBAL factors is not closed for balance (a workgroup's fixed cost is ~8 us whatever it holds).
-        {
-            struct Chunk { int p0, nl, nf, fa, span; };
-            std::vector<Chunk> ch;
-            auto cost = [](int nf, int T) { return (vd::vis_rows(nf) / 4 + 4) * vd::vis_ntile(T); };
-            auto cut = [&](int cap) -> bool {
-                ch.clear();
-                Chunk cc{0, 0, 0, 0, 0}; int wlo = K, whi = -1;
-                for (int q = 0; q < (int)order.size(); ++q) {
-                    const int l = order[q], n = lms[l + 1] - lms[l];
-                    const int lo = std::min(wlo, fmin[l]), hi = std::max(whi, fmax[l]), T = vd::vis_tiles(hi - lo + 1);
-                    const bool fits = cc.nl < VIS_LM && cc.nf + n <= VIS_MF && vd::vis_gm_doubles(cc.nf + n, T) <= VIS_GM;
-                    if (cc.nl > 0 && (!fits || (cc.nf >= VIL_VCHUNK_FBAL && cost(cc.nf + n, T) > cap))) {
-                        cc.fa = wlo; cc.span = whi - wlo + 1; ch.push_back(cc);
-                        cc = Chunk{q, 0, 0, 0, 0}; wlo = K; whi = -1;
-                    }
-                    if (cc.nl == 0 && (n > VIS_MF || vd::vis_gm_doubles(n, vd::vis_tiles(fmax[l] - fmin[l] + 1)) > VIS_GM)) return false;      // a landmark no chunk can hold
-                    cc.nl++; cc.nf += n; wlo = std::min(wlo, fmin[l]); whi = std::max(whi, fmax[l]);
-                }
-                if (cc.nl > 0) { cc.fa = wlo; cc.span = whi - wlo + 1; ch.push_back(cc); }
-                return true;
-            };
-            int npt = std::max(p->n_plane, 0), net = std::max(p->n_edge, 0);           // LiDAR points of this upload (resident slabs: what they hold)
-            if (p->n_plane == VIL_LIDAR_RESIDENT) for (auto& sl : c->slabs) { npt += sl.np; net += sl.ne; }
-            int vwg_max = std::max(64, 256 - (p->n_imu + 3 + (npt + 511) / 512 + (net + 511) / 512));
-            if (const char* ev = VIL_TUNE_ENV("VIL_VWG")) vwg_max = std::max(1, atoi(ev));
-            int lo = cost(VIL_VCHUNK_FBAL, 1), hi = cost(VIS_MF, VIS_TMAX);
-            if (const char* ev = VIL_TUNE_ENV("VIL_VCAP")) lo = hi = std::max(1, atoi(ev));
-            if (!cut(lo)) return VIL_ERR_UNSUPPORTED;
-            if ((int)ch.size() > vwg_max) {
-                while (lo < hi) { const int mid = (lo + hi) / 2; cut(mid); if ((int)ch.size() <= vwg_max) hi = mid; else lo = mid + 1; }
-                cut(hi);
-            }
-            P.n_vwg = (int)ch.size();
-            std::vector<int> vw(8 * (size_t)std::max(P.n_vwg, 1), 0), vr(4 * (size_t)std::max(P.n_vwg, 1), 0), vl(4 * std::max(order.size(), (size_t)1), 0), vf(2 * (size_t)std::max(n_vis, 1), 0);
-            size_t roff = 0; int tmax = 1, gmax = 0, fpos = 0;
-            for (int w = 0; w < P.n_vwg; ++w) {
-                const Chunk& cc = ch[w];
-                const int T = vd::vis_tiles(cc.span);
-                int* d = &vw[8 * (size_t)w];
-                d[0] = cc.p0; d[1] = cc.nl; d[2] = fpos; d[3] = cc.nf; d[4] = cc.fa; d[5] = cc.span; d[6] = T; d[7] = (int)(roff / 16);
-                int* r = &vr[4 * (size_t)w]; r[0] = d[7]; r[1] = cc.fa; r[2] = cc.span; r[3] = T;
-                int floc = 0;
-                for (int q = 0; q < cc.nl; ++q) {
-                    const int l = order[cc.p0 + q], n = lms[l + 1] - lms[l];
-                    int* e = &vl[4 * (size_t)(cc.p0 + q)]; e[0] = l; e[1] = floc; e[2] = n; e[3] = anch[l];
-                    for (int k = 0; k < n; ++k) { vf[2 * (size_t)(fpos + floc + k)] = lms[l] + k; vf[2 * (size_t)(fpos + floc + k) + 1] = q; }
-                    floc += n;
-                }
-                fpos += cc.nf; roff += (size_t)vd::vis_rec_doubles(T);
-                tmax = std::max(tmax, T); gmax = std::max(gmax, vd::vis_gm_doubles(cc.nf, T));
-            }
-            P.vis_ts = vd::vis_slots(tmax) <= 2 ? 2 : 5;
-            c->vis_gm = gmax;
-            std::vector<int> wend(K, 0);
-            for (int w = 0; w < P.n_vwg; ++w) for (int f = ch[w].fa; f < K; ++f) wend[f]++;
-            put(wend.data(), 4 * wend.size(), (void**)&P.vwend);
-            put(vw.data(), 4 * vw.size(), (void**)&P.vwg); put(vr.data(), 4 * vr.size(), (void**)&P.vrec);
-            put(vl.data(), 4 * vl.size(), (void**)&P.vlm); put(vf.data(), 4 * vf.size(), (void**)&P.vfac);
-            put(nullptr, 8 * std::max(roff, (size_t)16), (void**)&P.vpart);
-        }
+        P.n_vwg = vp.n_chunks;
+        P.vis_ts = vd::vis_slots(vp.tmax) <= 2 ? 2 : 5;
+        c->vis_gm = vp.gm;
+        put(vp.wend.data(), 4 * vp.wend.size(), (void**)&P.vwend);
+        put(vp.vwg.data(), 4 * vp.vwg.size(), (void**)&P.vwg); put(vp.vrec.data(), 4 * vp.vrec.size(), (void**)&P.vrec);
+        put(vp.vlm.data(), 4 * vp.vlm.size(), (void**)&P.vlm); put(vp.vfac.data(), 4 * vp.vfac.size(), (void**)&P.vfac);
+        put(nullptr, 8 * std::max(vp.rec_doubles, (size_t)16), (void**)&P.vpart);
     }
     UPTICK("visual");
     // LiDAR
