@@ -78,13 +78,10 @@ __host__ __device__ inline void gauge_fix_core(const double* pose0_before, int K
 
 namespace vd {
 // all threads of ONE workgroup; returns after the sequence word has been stored
-// (cur / status / gen: the scalars of Ctl the caller already holds; the record itself is copied from device memory -- or from `lctl`, the caller's
-//  LDS copy, when the step kernel that ended the solve finishes it itself: its own loads of P.ctl date from the head of the launch)
+// (cur / status / gen: the scalars of Ctl the caller already holds; the record itself is copied from device memory)
 // cam: 16 K + 8 + 12 doubles of LDS for the camera part of the final state and the gauge correction
-// (what it needs of DevP travels as scalar arguments: with a reference to the kernel's 1.3 kB parameter block -- or a struct of its fields -- used from
-//  the five exits of the step kernel, the block / the struct landed in scratch memory, which the runtime then provides on every launch: +45 us each)
 __device__ __forceinline__ void solve_finish(double* const x, double* const xb, const double* const xorig, double* const hs, Ctl* const dctl, Ctl* const hctl, int* const hseq,
-                                             const int K, const int NS, const int gauge_on, const int cur, const int status, const int gen, double* const cam, const Ctl* const lctl = nullptr) {
+                                             const int K, const int NS, const int gauge_on, const int cur, const int status, const int gen, double* const cam) {
     const int t = threadIdx.x, NT = blockDim.x;
     const double* xs = cur ? xb : x;
     const int NC = 16 * K + 8;
@@ -112,7 +109,7 @@ __device__ __forceinline__ void solve_finish(double* const x, double* const xb, 
         if (hs) hs[i] = v;
     }
     if (hctl) {
-        const double* src = lctl ? (const double*)lctl : (const double*)dctl; double* h = (double*)hctl;
+        const double* src = (const double*)dctl; double* h = (double*)hctl;
         for (int i = t; i < (int)(sizeof(Ctl) / 8); i += NT) h[i] = src[i];
     }
     __threadfence_system();                              // every thread's stores (device and host) before the barrier: __syncthreads alone does not wait for them

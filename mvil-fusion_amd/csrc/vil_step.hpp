@@ -36,12 +36,11 @@ struct StepShared {
     double sc[320], dcs[320], gr[320], gn[320];   // Sc, dogleg diagonal, gradient_, gauss_newton_step_ (camera part)
     double gd[320];                               // reduced gradient (rhs row of M): staged once, the packing loop must not touch global memory
     double rt[320];                               // Sc / dogleg diagonal: the candidate step is formed without a divide
-    double x0[344];                               // camera part of x_cur (16K + 8 doubles), fetched while the system is being solved
+    double x0[328];                               // camera part of x_cur (16K + 8 doubles), fetched while the system is being solved
     unsigned char cst[48];                        // pose_const[K] | sb_const[K]
     double hs[12];                                // the helpers' sums, gathered by a spare wave during the chain back substitution
     int need, was_first, ok, cok;
     long long tacc[6];
-    struct Fin { double* x0; double* x1; const double* xorig; double* hs; Ctl* ctl; Ctl* hctl; int* hseq; int K, NS, gauge; } fin;      // arguments of solve_finish, parked at the head of the launch
 };
 
 // block-wide sum(a), sum(b) and sum-or-max(c) with one pair of barriers
@@ -875,22 +874,39 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
         const int nr = (NP - part + G - 1) / G;            // rows part, part + G, ... < NP
 #pragma unroll
         for (int q = 0; q < 2; ++q) { pl[q] = ld_ag(P.chLdg + min(t + q * VIL_STEP_THREADS, 54 * K - 1)); ps[q] = ld_ag(P.chLsb + min(t + q * VIL_STEP_THREADS, 82 * K - 1)); }
-        if (!small) {
-#pragma unroll
-            for (int q = 0; q < 24; ++q) wv[q] = ld_ag(Wt + (size_t)jc * RS + min(part + q * G, NP - 1));
-            wrhs = ld_ag(Wt + (size_t)jc * RS + NP);
-        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) { const int e = t + q * VIL_STEP_THREADS; if (e < 54 * K) Ldg[e] = pl[q]; if (e < 82 * K) Lsb[e] = ps[q]; }
         for (int e = t + 2 * VIL_STEP_THREADS; e < 54 * K; e += VIL_STEP_THREADS) Ldg[e] = ld_ag(P.chLdg + e);      // (K > 18)
         for (int e = t + 2 * VIL_STEP_THREADS; e < 82 * K; e += VIL_STEP_THREADS) Lsb[e] = ld_ag(P.chLsb + e);      // (K > 12)
         // t = y_b - W^T x_p with the deferred row scaling (the right-hand-side row of W^T carries y_b)
+        if (small) {
 #pragma unroll
-        for (int q = 0; q < 24; ++q) { const int rr = min(part + q * G, NP - 1); acc += (q < nr ? wv[q] : 0.0) * s.sc[rr] * s.y[rr]; }
-        for (int q = 24; q < nr; ++q) { const int rr = part + q * G; acc += ld_ag(Wt + (size_t)jc * RS + rr) * s.sc[rr] * s.y[rr]; }
-        acc += __shfl_xor(acc, 1, 64);
-        if (G == 4) acc += __shfl_xor(acc, 2, 64);
-        if (j < NB && part == 0) tB[j] = wrhs - acc;
+            for (int q = 0; q < 24; ++q) { const int rr = min(part + q * G, NP - 1); acc += (q < nr ? wv[q] : 0.0) * s.sc[rr] * s.y[rr]; }
+            for (int q = 24; q < nr; ++q) { const int rr = part + q * G; acc += ld_ag(Wt + (size_t)jc * RS + rr) * s.sc[rr] * s.y[rr]; }
+            acc += __shfl_xor(acc, 1, 64);
+            if (G == 4) acc += __shfl_xor(acc, 2, 64);
+            if (j < NB && part == 0) tB[j] = wrhs - acc;
+        } else {
+            // K > 12 (no room for a prefetch across the factorisation, 64 rows per thread in the thread-per-column map: 40 of them were one dependent L2
+            // round trip each, 10 us of the 11.6 this stage took at K = 20): a WAVE per chain column -- lanes along the rows of a column of W^T (whole
+            // lines; NP <= 127: two rows per lane), eight columns of loads in flight per wave, the column's dot product folded on the DPP crossbar
+            const int wave = t >> 6, lane = t & 63;
+            const int r0 = min(lane, NP - 1), r1 = min(lane + 64, NP - 1);
+            const double x0 = lane < NP ? s.sc[r0] * s.y[r0] : 0.0, x1 = lane + 64 < NP ? s.sc[r1] * s.y[r1] : 0.0;
+            for (int j0 = wave; j0 < NB; j0 += 64) {
+                double w0[8], w1[8], wr[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double* col = Wt + (size_t)min(j0 + 8 * u, NB - 1) * RS;
+                    w0[u] = ld_ag(col + r0); w1[u] = ld_ag(col + r1); wr[u] = ld_ag(col + NP);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double a = wave_total(w0[u] * x0 + w1[u] * x1);
+                    if (lane == 0 && j0 + 8 * u < NB) tB[j0 + 8 * u] = wr[u] - a;
+                }
+            }
+        }
     }
     __syncthreads();
     // x_k = L_kk^-T (t_k - Ls_k^T x_next) = c_k - M_k x_next with what the chain workgroup left: the INVERSE of L_kk (Ldg here holds L^-1, 45 entries per block)
@@ -955,10 +971,11 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
 // and six sums (|gn_l|^2, gn_l . g_l, |la|^2, la . lb, |lb|^2, |lambda|^2); the candidate inverse depth lambda + cg la + cn lb is
 // formed by the NEXT sweep's visual workgroups from the two dogleg coefficients in Ctl, and its norm follows from the sums.
 // With helper workgroups (grid = 1 + n_help) that pass runs on their CUs while the master back-substitutes the chain.
-// step_body: everything of the launch; `ended` is set (by every thread of the master) on the exits that may have ended the solve.
-template <bool LDSM, int CHAIN>
-__device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd::StepShared& s, double* const Alds, bool& ended) {
+template <bool LDSM, int CHAIN = 0>
+__global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) {
     using namespace vd;
+    __shared__ StepShared s;
+    extern __shared__ double Alds[];
     const int t = threadIdx.x, NT = blockDim.x;
     const int D = P.D, L = P.L;
     // The grid is 1 + P.n_help workgroups: the extra ones run the same judge on their own copy of Ctl and
@@ -989,7 +1006,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     {   // Ctl (1.5 kB with its traces) into LDS: one coalesced load per lane, not 190 loads of a lone lane with everybody waiting at the barrier
         const double* src = (const double*)P.ctl; double* dst = (double*)&s.c;
         for (int i = t; i < (int)(sizeof(Ctl) / 8); i += NT) dst[i] = src[i];
-        if (t == 0) { s.need = 0; s.was_first = 0; s.ok = 1; s.fin = StepShared::Fin{P.x[0], P.x[1], P.xorig, P.hstate, P.ctl, P.hctl, P.hseq, P.K, P.NS, P.gauge_on}; }
+        if (t == 0) { s.need = 0; s.was_first = 0; s.ok = 1; }
     }
     for (int q = t; q < 256; q += NT) {      // triangular tile index -> (tile row, tile col)
         int Ir = (int)((sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
@@ -1238,7 +1255,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         } else post(P.hflag + hk);
         return;
     }
-    if (s.c.done) { if (t < 64) { wait_helpers(); store_ctl(); } ended = true; return; }
+    if (s.c.done) { if (t < 64) { wait_helpers(); store_ctl(); } return; }
     for (int i = t; i < 16 * P.K + 8; i += NT) s.x0[i] = x[i];          // (read after several barriers)
     for (int k = t; k < 2 * P.K; k += NT) s.cst[k] = k < P.K ? (P.pose_const ? P.pose_const[k] : 0) : (P.sb_const ? P.sb_const[k - P.K] : 0);
     bool xpub = false;                                 // the master owes the waiting helpers an xflag on every path through the need branch
@@ -1367,7 +1384,6 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
             if (!xpub) publish_xp(0);
             if (t == 0) { s.c.done = 1; s.c.term = 2; }
             if (t < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); wait_helpers(); store_ctl(); }
-            ended = true;
             return;
         }
         if constexpr (CHAIN == 0) { if constexpr (LDSM) ok = chol_lookahead<CH_SLOTS, false>(Alds, D, s); else ok = chol_blocked<false>(P.M, D, s, Alds); }      // Alds = staging of the active tile column
@@ -1387,7 +1403,6 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
             for (int i = t; i < P.NS; i += NT) xc[i] = x[i];
             __syncthreads();
             if (t < 64) { wait_helpers(); store_ctl(); }      // (a late helper may still be copying Ctl into its LDS)
-            ended = true;
             return;
         }
         if constexpr (CHAIN == 0) { if constexpr (LDSM) back_subst(Alds, D, s); else back_subst(P.M, D, s); publish_xp(1); __syncthreads(); }      // (the publishing threads read s.y across the thread map of the loop below)
@@ -1431,7 +1446,6 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
             if (defer && gm <= O.gradient_tolerance) {          // (the check the other paths make before the factorisation)
                 if (t == 0) { s.c.done = 1; s.c.term = 2; }
                 if (t < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); hseen = false; wait_helpers(); store_ctl(); }
-                ended = true;
                 return;
             }
         }
@@ -1522,27 +1536,4 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     if (s.c.resweep && !s.c.done) { for (int i = t; i < 16 * P.K + 8; i += NT) xc[i] = s.x0[i]; }
     STAMP(7);
     if (t < 64) { wait_helpers(); store_ctl(); }      // (no second poll when the sums were already collected)
-    ended = true;
-}
-
-template <bool LDSM, int CHAIN = 0>
-__global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) {
-    __shared__ vd::StepShared s;
-    extern __shared__ double Alds[];
-    bool ended = false;
-    step_body<LDSM, CHAIN>(P, O, s, Alds, ended);
-    // the master's last act when the solve has ended in this launch (wave 0 has stored Ctl): accepted state -> x[0] / x[1], gauge fix, Ctl + state +
-    // sequence word into the host's mirror (vil_finish.hpp) -- the host waits neither for the chunk's remaining launches (no-ops) nor for k_finish.
-    // ONE call site behind every exit of the body, its arguments parked in LDS at the head of the launch (s.fin): inlined at each exit, or reading the
-    // parameter block here, the step kernel spilled scalar registers to scratch memory -- which the runtime then provides on every launch (+45 us).
-#ifdef VIL_NO_INSTEP_FINISH
-    return;
-#endif
-    if (!ended) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (s.c.done && s.c.lin_mode == 0) {
-        const vd::StepShared::Fin f = s.fin;
-        vd::solve_finish(f.x0, f.x1, f.xorig, f.hs, f.ctl, f.hctl, f.hseq, f.K, f.NS, f.gauge, s.c.cur, s.c.status, s.c.gen, s.x0, &s.c);
-    }
 }
