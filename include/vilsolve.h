@@ -399,7 +399,11 @@ int vil_marginalize_resident(vil_ctx* ctx, const vil_state* solved, const vil_op
  * and receives the solved, gauge-fixed state (vil_state) in pinned memory the finishing kernel wrote (no copy, no synchronisation).
  * Track slots are the caller's: one per live feature track (FeaturePerId), < max_tracks, reusable once the track is gone.
  * Observation layout (VIL_WIN_OBS = 8 doubles): [x y z vx vy cur_td row 0], row = v - ROW/2 (projection_td_factor.cpp:12-19).
- * Not combinable with a communicator (the multi-GPU path shards a window handed over through vil_upload). */
+ * Under a communicator (vil_comm_init / _init_local / _ipc_init) every rank makes the SAME calls with the SAME arguments: each is handed
+ * every frame and every landmark list (the observation store and the IMU slots are whole on every rank -- a few kB per image), keeps ITS slice of each
+ * frame's LiDAR points and the visual factors of ITS landmark range (the rule of vil_shard_ranges applied to the landmark list), rank 0 alone the IMU /
+ * prior / ICP / LPS factors; the new prior is formed by every rank from the all-reduced marginalisation system (identical bits) into its own slot.
+ * One collective per trust-region iteration, one per marginalisation, as for a window handed over through vil_upload. */
 #define VIL_WIN_OBS 8
 typedef struct vil_win_cfg {
     int32_t K;                      /* frames in the window */

@@ -590,7 +590,16 @@ struct WinSrc {
     const double* d_store; const int* fslot; const int* islot;          // slots of the window frames (host, K each)
     const double* d_rec; const double* d_U; const double* sum_dt;       // IMU slots (device) and the intervals' durations (host, per physical slot)
     const double* pJ0; const double* pr0; const double* px0; double* pH; double* pg0; double* pc0;     // device prior slot (prior.n > 0)
+    int lb, le, f0, n_vis_all;       // sharded (gp != null): this rank keeps the factors of landmarks [lb, le), the first of which is factor f0 of the n_vis_all of the window
 };
+
+// first landmark whose factor prefix reaches r / world of the total (lms: factor prefix per landmark, L + 1 entries) -- THE sharding rule of the visual factors
+static int shard_cut(const std::vector<int>& lms, int L, int r, int world) {
+    if (r <= 0) return 0;
+    if (r >= world) return L;
+    const long long target = (long long)lms[L] * r / world;
+    return std::min((int)(std::lower_bound(lms.begin(), lms.end(), (int)target) - lms.begin()), L);
+}
 
 // check_setup: wait for k_setup's verdict (an IMU covariance that is not positive definite) and return it; false: nothing is waited for --
 // the first step kernel of the solve ends it with that status (DevP::setup_stat), and the launches of the solve queue up behind the upload
@@ -655,14 +664,15 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     int* wd_track = nullptr; int* wd_startf = nullptr;       // device copies of the landmark table (resident window)
     {
         std::vector<int> lms(L + 1, 0);
-        if (ws) for (int l = 0; l < L; ++l) lms[l + 1] = lms[l] + ws->lm_nobs[l] - 1;
+        const int ws_lb = (ws && gp) ? ws->lb : 0, ws_le = (ws && gp) ? ws->le : L;      // resident window under a communicator: the factors of the owned landmarks only
+        if (ws) for (int l = 0; l < L; ++l) lms[l + 1] = lms[l] + ((l >= ws_lb && l < ws_le) ? ws->lm_nobs[l] - 1 : 0);
         else {
             for (int f = 0; f < p->n_vis; ++f) lms[p->vis_l[f] + 1]++;
             for (int l = 0; l < L; ++l) lms[l + 1] += lms[l];
         }
         // frame window of every landmark, then the plan of the visual role (plan_visual above: sorted order, chunks, device tables)
         std::vector<int> fmin(std::max(L, 1), K), fmax(std::max(L, 1), -1), anch(std::max(L, 1), 0);
-        if (ws) { for (int l = 0; l < L; ++l) { anch[l] = fmin[l] = ws->lm_startf[l]; fmax[l] = ws->lm_startf[l] + ws->lm_nobs[l] - 1; } }
+        if (ws) { for (int l = ws_lb; l < ws_le; ++l) { anch[l] = fmin[l] = ws->lm_startf[l]; fmax[l] = ws->lm_startf[l] + ws->lm_nobs[l] - 1; } }
         else for (int f = 0; f < p->n_vis; ++f) {
             const int l = p->vis_l[f], lo = std::min(p->vis_i[f], p->vis_j[f]), hi = std::max(p->vis_i[f], p->vis_j[f]);
             anch[l] = p->vis_i[f]; fmin[l] = std::min(fmin[l], lo); fmax[l] = std::max(fmax[l], hi);
@@ -709,10 +719,18 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         }
         P.vis_f0 = 0;
         if (gp) {                                        // tables of the whole window for the step kernel (every rank walks every landmark)
-            std::vector<int> gl(L + 1, 0), gac(std::max(L, 1), -1), gfc(std::max(gp->n_vis, 1), 0);
-            for (int f = 0; f < gp->n_vis; ++f) gl[gp->vis_l[f] + 1]++;
-            for (int l = 0; l < L; ++l) gl[l + 1] += gl[l];
-            for (int f = gp->n_vis - 1; f >= 0; --f) { gac[gp->vis_l[f]] = 6 * gp->vis_i[f]; gfc[f] = 6 * gp->vis_j[f]; }
+            const int gnv = ws ? ws->n_vis_all : gp->n_vis;
+            std::vector<int> gl(L + 1, 0), gac(std::max(L, 1), -1), gfc(std::max(gnv, 1), 0);
+            if (ws) {
+                for (int l = 0; l < L; ++l) {
+                    gl[l + 1] = gl[l] + ws->lm_nobs[l] - 1; gac[l] = 6 * ws->lm_startf[l];
+                    for (int q = 1; q < ws->lm_nobs[l]; ++q) gfc[gl[l] + q - 1] = 6 * (ws->lm_startf[l] + q);
+                }
+            } else {
+                for (int f = 0; f < gp->n_vis; ++f) gl[gp->vis_l[f] + 1]++;
+                for (int l = 0; l < L; ++l) gl[l + 1] += gl[l];
+                for (int f = gp->n_vis - 1; f >= 0; --f) { gac[gp->vis_l[f]] = 6 * gp->vis_i[f]; gfc[f] = 6 * gp->vis_j[f]; }
+            }
             put(gl.data(), 4 * gl.size(), (void**)&P.glm_start); put(gac.data(), 4 * gac.size(), (void**)&P.glm_acol); put(gfc.data(), 4 * gfc.size(), (void**)&P.gfcol);
             P.vis_f0 = vis_f0;
         }
@@ -826,7 +844,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     UPTICK("imu+prior");
     // systems + work space (zero-initialised)
     // one contiguous block per set: [S | gred | bc | diag | cost | 2 spare | hll | bl | invp | sl | eA | eO]
-    const size_t Lp = (size_t)std::max(L, 1), Fp = (size_t)std::max(gp ? gp->n_vis : n_vis, 1);
+    const size_t Lp = (size_t)std::max(L, 1), Fp = (size_t)std::max(gp ? (ws ? ws->n_vis_all : gp->n_vis) : n_vis, 1);
     const size_t ar_cam = ((size_t)D * D + 3 * (size_t)D + 3 + 1) & ~size_t(1);
     c->span = ar_cam + 4 * Lp + 13 * Lp + 6 * Fp;
     for (int q = 0; q < 2; ++q) put(nullptr, 8 * c->span, (void**)&P.sys[q].ar);
@@ -1835,13 +1853,8 @@ int vil_shard_ranges(const vil_problem* p, int rank, int world, int32_t* lm_begi
     std::vector<int> lms(p->L + 1, 0);
     for (int f = 0; f < p->n_vis; ++f) lms[p->vis_l[f] + 1]++;
     for (int l = 0; l < p->L; ++l) lms[l + 1] += lms[l];
-    auto cut = [&](int r) {   // first landmark whose factor prefix reaches r/world of the total
-        if (r <= 0) return 0; if (r >= world) return p->L;
-        const long long target = (long long)p->n_vis * r / world;
-        return (int)(std::lower_bound(lms.begin(), lms.end(), (int)target) - lms.begin());
-    };
-    if (lm_begin) *lm_begin = std::min(cut(rank), p->L);
-    if (lm_end) *lm_end = std::min(cut(rank + 1), p->L);
+    if (lm_begin) *lm_begin = shard_cut(lms, p->L, rank, world);
+    if (lm_end) *lm_end = shard_cut(lms, p->L, rank + 1, world);
     if (edge_begin) *edge_begin = (int)((long long)p->n_edge * rank / world);
     if (edge_end) *edge_end = (int)((long long)p->n_edge * (rank + 1) / world);
     if (plane_begin) *plane_begin = (int)((long long)p->n_plane * rank / world);
@@ -1943,7 +1956,6 @@ int vil_lidar_push(vil_ctx* c, int32_t n_plane, const double* plane_const, int32
 
 static int marginalize_resident_impl(vil_ctx* c, const vil_state* s, const vil_options* o, const vil_marg_spec* spec, vil_prior_out* out, const bool to_slot, vil_win_prior_info* winfo) {
     if (!c || !o || !spec || (!to_slot && (!s || !out)) || !c->uploaded || c->resident_kind != 1) return VIL_ERR_INVALID_ARGUMENT;
-    if (c->sharded && to_slot) return VIL_ERR_UNSUPPORTED;      // (the fully resident window is a single-GPU feature)
     const int K = c->K;
     if (K < 3 || (s && (s->K != K || s->L != c->L))) return VIL_ERR_INVALID_ARGUMENT;
     int none = 0; int& out_n = out ? out->n : none;
@@ -1999,7 +2011,7 @@ int vil_marginalize_resident(vil_ctx* c, const vil_state* s, const vil_options* 
 // ---- the fully resident window (include/vilsolve.h: vil_win_*; device side: vil_window.hpp) ------------------------------------------
 int vil_win_open(vil_ctx* c, const vil_win_cfg* cfg) {
     if (!c || !cfg || cfg->K < 3 || cfg->K > VIL_WIN_MAXK || cfg->max_tracks < 1 || cfg->max_samples < 1) return VIL_ERR_INVALID_ARGUMENT;
-    if (c->world > 1 && c->has_comm()) return VIL_ERR_UNSUPPORTED;
+    if (c->ipc && c->world > 1 && !c->ipc->ready) return VIL_ERR_COMM;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     auto& w = c->win;
@@ -2133,10 +2145,29 @@ int vil_win_solve(vil_ctx* c, const vil_win_problem* wp, vil_state* s, const vil
     ws.lm_track = wp->lm_track; ws.lm_startf = wp->lm_start; ws.lm_nobs = wp->lm_nobs; ws.n_vis = n_vis; ws.T = w.T;
     ws.d_store = w.d_store; ws.fslot = w.fslot.data(); ws.islot = w.islot.data(); ws.d_rec = w.d_rec; ws.d_U = w.d_U; ws.sum_dt = w.sum_dt.data();
     ws.pJ0 = w.pJ0(w.cur); ws.pr0 = w.pr0(w.cur); ws.px0 = w.px0(w.cur); ws.pH = w.pH(w.cur); ws.pg0 = w.pg0(w.cur); ws.pc0 = w.pc0(w.cur);
+    ws.lb = 0; ws.le = L; ws.f0 = 0; ws.n_vis_all = n_vis;
     // vil_win_solve returns the gauge-fixed state and vil_win_marginalize linearises at it (double2vector() precedes the marginalisation,
     // estimator.cpp:1419 / :1487): the device gauge fix is part of the resident window whatever vil_set_gauge_fix was left at
     const bool gauge_was = c->gauge_on; c->gauge_on = true;
-    int st = upload_impl(c, &q, s, false, nullptr, nullptr, 0, false, &ws);
+    int st;
+    if (c->world > 1 && c->has_comm()) {
+        // SURVEY 8e on the resident window: every rank was handed every frame (vil_win_push_frame: the observation store and the IMU slots are whole on
+        // every rank, the LiDAR slabs hold the rank's slice) and is handed the same small tables here; it keeps the visual factors of ITS landmark range
+        // -- the rule of vil_shard_ranges on the landmark list -- and rank 0 alone the IMU / prior / ICP / LPS factors.  The prior slot is written by
+        // every rank from the all-reduced marginalisation system (identical bits), read by rank 0.
+        std::vector<int> lms(L + 1, 0);
+        for (int l = 0; l < L; ++l) lms[l + 1] = lms[l] + wp->lm_nobs[l] - 1;
+        OwnSeg& S = c->own; memset(&S, 0, sizeof S);
+        S.n = c->world; S.Lp = std::max(L, 1);
+        for (int r = 0; r <= c->world; ++r) { S.lb[r] = shard_cut(lms, L, r, c->world); S.fb[r] = lms[S.lb[r]]; }
+        S.cam = ((size_t)(15 * K + 7) * (15 * K + 7) + 3 * (size_t)(15 * K + 7) + 3 + 1) & ~size_t(1);
+        ws.lb = S.lb[c->rank]; ws.le = S.lb[c->rank + 1]; ws.f0 = S.fb[c->rank]; ws.n_vis = S.fb[c->rank + 1] - S.fb[c->rank];
+        c->lm_b = ws.lb; c->lm_e = ws.le;
+        vil_problem ql = q;
+        if (c->rank != 0) { ql.n_imu = 0; ql.n_icp = 0; ql.n_lps = 0; ql.prior.n = 0; ql.prior.nblk = 0; }
+        st = comm_agree(c, upload_impl(c, &ql, s, true, nullptr, &q, ws.f0, false, &ws));
+        if (st != VIL_OK) c->uploaded = false;
+    } else st = upload_impl(c, &q, s, false, nullptr, nullptr, 0, false, &ws);
     if (st != VIL_OK) { c->gauge_on = gauge_was; return st; }
     c->resident_kind = 1;
     c->P.setup_stat = w.d_wstat;                       // the window's sticky status word: a failed pre-integration / prior ends the solve with it

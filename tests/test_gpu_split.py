@@ -165,6 +165,78 @@ print("RESIDENT_SHARD_OK")
 '''
 
 
+WINDOW_SCRIPT = r'''
+import sys, os, ctypes as C, threading
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import __graft_entry__ as g; g.load_package()
+from mvil_fusion_amd import abi, lib, replay
+kw = dict(K=10, n_frames=32, L=200, n_plane=4000, n_edge=1200, seed=20240611, max_iterations=8, second_new_every=5)
+N = 16
+def chain(bes):
+    """the fully resident window (vil_win_*) driven on every rank of `bes` in lockstep: every rank is handed every frame and every small table"""
+    world = len(bes)
+    rps = [replay.Replay(**kw) for _ in range(world)]
+    out = [[] for _ in range(world)]
+    err = [None] * world
+    def run(r):
+        try:
+            be, rp = bes[r], rps[r]
+            be.set_gauge_fix(False)                                   # vil_win_solve runs the device gauge fix whatever this is left at
+            be.win_open(**rp.win_open_args())
+            for k in range(rp.K): be.win_push_frame(rp.win_frame(k))
+            for _ in range(N):
+                w = rp.win_window(); flag = rp.margin_flag()
+                sm = be.win_solve(w, rp.opts)
+                info = be.win_marginalize(flag, w._icp_marg, w._lps_marg, rp.opts)
+                pg = be.win_prior_download(rp.K)
+                msg = C.c_int64(0); full = C.c_int64(0)
+                if world > 1: assert be.lib.vil_comm_message_bytes(be.ctx, C.byref(msg), C.byref(full)) == 0
+                out[r].append((sm.iterations, sm.termination, w.pose.copy(), w.inv_depth.copy(), pg.A_matrix() if pg.c.n > 0 else None, int(info.n), flag, msg.value, full.value))
+                be.win_drop_frame(flag)
+                assert rp.absorb(w, None, flag)
+                be.win_push_frame(rp.win_frame(rp.K - 1))
+        except BaseException as e:
+            err[r] = e; raise
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join(900) for t in th]
+    assert all(e is None for e in err), err
+    return out
+one = chain([lib.open_vilsolve()])[0]
+for world in (2, 3):
+    bes = [lib.open_vilsolve() for _ in range(world)]
+    arr = (C.c_void_p * world)(*[b.ctx for b in bes])
+    assert bes[0].lib.vil_comm_init_local(arr, world) == 0
+    many = chain(bes)
+    assert all(len(m) == N for m in many) and len(one) == N
+    flags = set()
+    for f in range(N):
+        a = one[f]; flags.add(a[6])
+        for r in range(world):
+            b = many[r][f]
+            assert (a[0], a[1], a[5]) == (b[0], b[1], b[5]), (world, f, r, a[0], b[0], a[5], b[5])
+            assert np.array_equal(b[2], many[0][f][2]) and np.array_equal(b[3], many[0][f][3])           # ranks agree bit for bit
+            assert np.abs(a[2] - b[2]).max() < 1e-8 and np.abs(a[3] - b[3]).max() < 1e-7, (world, f, np.abs(a[2] - b[2]).max(), np.abs(a[3] - b[3]).max())
+            assert (a[4] is None) == (b[4] is None)
+            if a[4] is not None:
+                sc = np.sqrt(np.maximum(np.abs(np.diag(a[4])), 1e-300))
+                assert np.abs((a[4] - b[4]) / np.outer(sc, sc)).max() < 2e-5 and np.array_equal(b[4], many[0][f][4])
+            assert 0 < b[7] < 0.62 * b[8], (b[7], b[8])                   # lower(S') + vectors + the OWNED slice of the landmark arrays
+    assert flags == {abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW}
+    for b in bes: b.close()
+print("WINDOW_SHARD_OK")
+'''
+
+
+def test_resident_window_under_a_communicator():
+    """vil_win_* on 2 and 3 ranks (in-process communicator, one device): every rank is handed every frame (whole observation store and IMU slots, ITS
+    slice of each LiDAR slab) and the same landmark list, keeps the visual factors of its landmark range, and writes the SAME new prior into its own device
+    slot from the all-reduced marginalisation system.  16 images with both marginalisation branches: ranks bit-identical, iteration counts, termination
+    and prior sizes those of the single-context resident window, states equal to it at summation-order level."""
+    out = subprocess.run([sys.executable, "-c", WINDOW_SCRIPT % (ROOT, ROOT)], capture_output=True, text=True, timeout=1200)
+    assert "WINDOW_SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_sharded_solve_local_communicator():
     """2 and 3 ranks of the factor-sharded solve on ONE device through the in-process communicator: the shard ranges,
     ranks without IMU / prior factors, the split step, the scalar reduction and the landmark merge all run as on N GPUs."""
