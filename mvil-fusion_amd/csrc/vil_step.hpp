@@ -428,14 +428,21 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
     const int la = (lane & 15) * TILE_RS + (lane >> 4);     // operand element (row lane&15, k lane>>4) inside a tile
     const int lc = (lane >> 4) * TILE_RS + (lane & 15);     // accumulator element (row lane>>4 (+4g), col lane&15)
     const int ntile_all = (T * (T + 1)) >> 1;               // <= NW * SLOTS
-    // panel group: the last npw waves; thread tp of it owns the tp-th row below the block.  The tiles are dealt to the other waves first
+    // panel group: the last npw waves; thread tp of it owns row STEP_NB + tp.  The tiles are dealt to the other waves first
     const int npw = max(1, (R - min(STEP_NB, D) + 63) >> 6);   // the first block has the most panel rows: R - min(NB, D)
-    const int NWT = NW - npw;
-    const int tp = t - 64 * NWT;
+    // The tile wave(s) that would share a SIMD with the panel wave(s) (wave w runs on SIMD w & 3 as the workgroup is dispatched) sit the factorisation out
+    // when the other tile waves have slots for every tile (K <= 12): the panel group's fp64 chain has its SIMD's issue port to itself (-3 % per block step
+    // in the stand-alone timing).  A different wave placement only loses that.
+    const int NWP = NW - npw;                              // first panel wave
+    const int n_idle = (ntile_all <= (NWP - npw) * SLOTS && NWP >= 4) ? npw : 0;
+    const int NWT = NWP - n_idle;
+    const bool idle_w = wave < NWP && wave >= NWP - 4 && wave < NWP - 4 + n_idle;
+    const int wr = wave - (wave >= NWP - 4 + n_idle && wave < NWP ? n_idle : 0);       // rank among the tile waves
+    const int tp = t - 64 * NWP;
     d4 Creg[SLOTS]; int tIJ[SLOTS];
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
-        const int g = wave < NWT ? wave + NWT * u : NWT * SLOTS + (wave - NWT) + npw * u;
+        const int g = idle_w ? ntile_all : (wave < NWP ? wr + NWT * u : NWT * SLOTS + (wave - NWP) + npw * u);
         tIJ[u] = -1;
         if (g < ntile_all) {
             const int I = s.tI[g], J = s.tJ[g];
@@ -451,14 +458,16 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
     // previous panel (columns kb - 4 .. kb - 1, always a full block) from what is read.
     // FULL: a whole 4 x 4 block (only the last block of the matrix can be shorter) -- no branch anywhere between the loads and the stores, so that
     // the scheduler can fill the latency shadows of the pivot chain with the panel update and the forward substitution.
+    // (thread tp of the group owns the FIXED row STEP_NB + tp: its LDS offset is formed once -- the tp-th row below the current block moved every step,
+    //  and the integer multiplies of its tile address sat in front of every step's loads)
+    const int prow = STEP_NB + tp, prc = min(max(prow, 0), R - 1);
+    const int rowb = tl_base(prc >> 4, 0) + (prc & 15) * TILE_RS;
     auto diag_panel = [&](const int kb, auto full_c, auto upd_c) {
         constexpr bool FULL = decltype(full_c)::value, UPD = decltype(upd_c)::value;
         const int nb = FULL ? STEP_NB : min(STEP_NB, D - kb), Kt = kb >> 4, ko = kb & 15;
         const int db = tl_base(Kt, Kt) + ko * TILE_RS + ko;
-        const int i = kb + nb + tp;                          // this thread's panel row
-        const bool row = i < R;
-        const int ic = min(i, R - 1);
-        const int base = tl_base(ic >> 4, Kt) + (ic & 15) * TILE_RS + ko;
+        const bool row = prow >= kb + nb && prow < R;         // (a row inside or above the block computes on whatever it reads and stores into padding)
+        const int base = rowb + Kt * TILE_SZ + ko;
         double d00 = A[db], d10 = 0, d11 = 1, d20 = 0, d21 = 0, d22 = 1, d30 = 0, d31 = 0, d32 = 0, d33 = 1;
         if (nb > 1) { d10 = A[db + TILE_RS]; d11 = A[db + TILE_RS + 1]; }
         if (nb > 2) { d20 = A[db + 2 * TILE_RS]; d21 = A[db + 2 * TILE_RS + 1]; d22 = A[db + 2 * TILE_RS + 2]; }
@@ -467,7 +476,7 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
         if constexpr (UPD) {
             const int kp = kb - STEP_NB, Kp = kp >> 4, kpo = kp & 15;      // the previous panel: columns kp .. kp + 3 of tile column Kp
             const int pb = tl_base(Kt, Kp) + ko * TILE_RS + kpo;           // rows kb .. kb + 3 of it (all in tile row Kt)
-            const int pr = tl_base(ic >> 4, Kp) + (ic & 15) * TILE_RS + kpo;
+            const int pr = rowb + Kp * TILE_SZ + kpo;
             double xd[4][4], xr[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -506,9 +515,10 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
         const double x3 = y3 * r3_;
         const bool ok = (r0_ + r1_) + (r2_ + r3_) < 1.7976931348623157e308;      // false for NaN and for +inf
         // (a non-positive pivot: identical data in every thread of the group; what is stored below is not read -- everyone leaves after the barrier)
-        // (a thread without a row stores into the padding doubles of tile (0, 0) -- element 16 of a tile row, never read -- instead of branching: a
-        //  conditional store would let the compiler sink this row's loads, update and substitution behind the pivot chain, into the branch)
-        if constexpr (FULL) { A[row ? base : 16] = x0; A[row ? base + 1 : TILE_RS + 16] = x1; A[row ? base + 2 : 2 * TILE_RS + 16] = x2; A[row ? base + 3 : 3 * TILE_RS + 16] = x3; }
+        // (a thread without a row stores into the padding double of ITS row in tile column 0 -- element 16 of a tile row, never read, a different address
+        //  in every lane -- instead of branching: a conditional store would let the compiler sink this row's loads, update and substitution behind the
+        //  pivot chain, into the branch)
+        if constexpr (FULL) { const int pad = rowb + 16; A[row ? base : pad] = x0; A[row ? base + 1 : pad] = x1; A[row ? base + 2 : pad] = x2; A[row ? base + 3 : pad] = x3; }
         else if (row) { A[base] = x0; if (nb > 1) A[base + 1] = x1; if (nb > 2) A[base + 2] = x2; if (nb > 3) A[base + 3] = x3; }
         if (tp == 0) {                                       // the factored block itself and the reciprocal pivots
             if (!ok) s.cok = 0;
@@ -533,32 +543,27 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
     for (int kb = 0; kb + STEP_NB < D; kb += STEP_NB) {      // panel kb (a full block) is in LDS; the last block has no successor
         const int Kt = kb >> 4, ko = kb & 15;
         const int kb1 = kb + STEP_NB, Kn = kb1 >> 4;         // the next block and its tile column (LDS-resident)
-        const int c0 = kb1 + min(STEP_NB, D - kb1);          // first column right of the next block: what the tile waves update in tile column Kn
-        const bool pub = ((kb1 + STEP_NB) & 15) == 0;        // the block after the next opens tile column Kn + 1: publish it after this update
+        const int c0 = kb1 + min(STEP_NB, D - kb1);          // first column right of the next block: the slice [c0, c0 + 4) is published after this update
         if (tp >= 0) { if (kb1 + STEP_NB <= D) diag_panel(kb1, std::true_type{}, std::true_type{}); else diag_panel(kb1, std::false_type{}, std::true_type{}); }
+        // Every tile stays in its wave's registers for the whole factorisation.  What the panel group reads next step -- the four columns [c0, c0 + 4) of the
+        // block after the next, with the panels up to kb applied (it applies panel kb1 itself) -- is the only thing a step writes to LDS: 16 x 4 values per
+        // tile of that tile column instead of a read-modify-write of the whole tile.  Register entries left of c0 and above the diagonal go stale: dead.
+        // (slot by slot on purpose: with all operand loads hoisted in front of the matrix-core instructions every wave issues 2 x SLOTS loads per step for
+        //  finished slots too, and the step got 10 % LONGER in the stand-alone timing -- the fp64 matrix pipe takes 64 cycles per instruction and SIMD, the
+        //  slice stores wait for it, and the panel group's own LDS traffic queues behind the extra loads)
+        const int Kc = c0 >> 4, cs = c0 & 15;
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) {
             const int I = tIJ[u] >> 8, J = tIJ[u] & 255;
-            if (tIJ[u] < 0 || J < Kn) continue;                       // finished (or empty) slot: wave-uniform
-            // unconditional reads (inside the tile for every lane) + select: a per-lane predicated load would compile to an exec-mask branch with its own wait
+            if (tIJ[u] < 0 || J < Kc) continue;                       // finished (or empty) slot: wave-uniform
             const double a_ = A[tl_base(I, Kt) + la + ko], b_ = A[tl_base(J, Kt) + la + ko];
-            if (J > Kn) {                                            // register tile: rows/cols are beyond the panel
-                Creg[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_, b_, Creg[u], 0, 0, 0);
-                if (pub && J == Kn + 1) {
+            Creg[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_, b_, Creg[u], 0, 0, 0);
+            if (J == Kc && c0 < D) {
+                const int cl = lane & 15;
+                if (cl >= cs && cl < cs + STEP_NB) {
                     const int cb = tl_base(I, J) + lc;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) A[cb + q * (4 * TILE_RS)] = Creg[u][q];
-                }
-            } else {                                                 // tile of the next block's column: lives in LDS, columns >= c0 are ours
-                const int rr = (I << 4) + (lane & 15), cr = (J << 4) + (lane & 15);
-                const double av = (rr >= kb1 && rr < R) ? a_ : 0.0;
-                const double bv = (cr >= c0 && cr < D) ? b_ : 0.0;
-                d4 z = {0.0, 0.0, 0.0, 0.0};
-                const d4 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, z, 0, 0, 0);
-                const int cb = tl_base(I, J) + lc;
-                if (cr >= c0) {                                      // (the accumulator's column is lane & 15 as well)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) A[cb + g * (4 * TILE_RS)] -= acc[g];
                 }
             }
         }

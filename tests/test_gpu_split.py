@@ -216,7 +216,8 @@ for world in (2, 3):
             b = many[r][f]
             assert (a[0], a[1], a[5]) == (b[0], b[1], b[5]), (world, f, r, a[0], b[0], a[5], b[5])
             assert np.array_equal(b[2], many[0][f][2]) and np.array_equal(b[3], many[0][f][3])           # ranks agree bit for bit
-            assert np.abs(a[2] - b[2]).max() < 1e-8 and np.abs(a[3] - b[3]).max() < 1e-7, (world, f, np.abs(a[2] - b[2]).max(), np.abs(a[3] - b[3]).max())
+            # (a CHAIN of 16 images: the summation-order difference of one image's solve reaches the next through the prior -- the tolerances of test_resident_window_equals_classic_entry_points)
+            assert np.abs(a[2] - b[2]).max() < 1e-7 and np.abs(a[3] - b[3]).max() < 1e-6, (world, f, np.abs(a[2] - b[2]).max(), np.abs(a[3] - b[3]).max())
             assert (a[4] is None) == (b[4] is None)
             if a[4] is not None:
                 sc = np.sqrt(np.maximum(np.abs(np.diag(a[4])), 1e-300))
