@@ -152,7 +152,8 @@ def roofline_obj(w, prof, measured_on, pmc_files, pmc_note, mfma_file=None):
     ab = algorithmic_bytes(w)
     us = 1e3 * prof.sweep_ms / prof.sweep_launches
     ach = ab / (us * 1e-6) / 1e9
-    r = {"bound": "hbm", "kernel": "k_sweep", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pmc_files), "traffic_source": pmc_note,
+    kname = "k_sweep<5>" if w.K > 12 else "k_sweep<2>"      # (the visual role's accumulator tiles per wave: csrc/vil_sweep.hpp; the counter files may hold other windows' launches too)
+    r = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pmc_files, kname), "traffic_source": pmc_note,
          "algorithmic_bytes_per_launch": ab, "avg_launch_us": us, "launches_timed": int(prof.sweep_launches),
          "gather_plus_step_avg_us": 1e3 * prof.step_ms / max(1, prof.step_launches),
          "measured_on": measured_on, "variant": "fused sweep (no Jacobian materialisation): read-only bytes, SURVEY 8(d)"}
@@ -171,10 +172,10 @@ def roofline_obj(w, prof, measured_on, pmc_files, pmc_note, mfma_file=None):
     if mfma_file:
         # the Schur contraction of the landmarks (sum_f Jc^T Jc - sum_l invp e e^T per visual workgroup) runs on the fp64 matrix cores inside k_sweep:
         # utilisation from the COUNTERS of the committed --pmc pass, against the chip's fp64-matrix peak over the sweep's own duration
-        m = pmc_mfma(mfma_file)
+        m = pmc_mfma(mfma_file, kname)
         if m:
             us_k = m["launch_us_under_pmc"]
-            r["mfma"] = {"kernel": "k_sweep (visual role: Schur contraction of the landmark block)", "bound": "mfma", "unit": "TFLOP/s", "peak": 78.6,
+            r["mfma"] = {"kernel": kname + " (visual role: Schur contraction of the landmark block)", "bound": "mfma", "unit": "TFLOP/s", "peak": 78.6,
                          "achieved": m["flop_per_launch"] / (us_k * 1e-6) / 1e12, "frac": m["flop_per_launch"] / (us_k * 1e-6) / 78.6e12,
                          "v_mfma_f64_16x16x4_per_launch": m["mops_per_launch"] / 4.0, "flop_per_launch": m["flop_per_launch"],
                          "mfma_busy_cycles_per_launch": m["mfma_busy_cycles_per_launch"], "sq_busy_cycles_per_launch": m["sq_busy_cycles_per_launch"],
@@ -537,6 +538,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--replay", type=int, default=0, help="config 5: run N images of the synthetic replay and report per-frame latency instead of the headline metric")
     ap.add_argument("--no-cfg3", dest="no_cfg3", action="store_true", help="skip the extra configs[2] (K=10, L=4000, 120k points) leg")
+    ap.add_argument("--no-tracker", dest="no_tracker", action="store_true", help="skip the PCIe-inclusive tracker legs (counter passes: their configs[1]-shaped windows launch the same kernels as the window under test)")
     ap.add_argument("--classic", action="store_true", help="replay mode: hand every table over on every image (vil_solve + vil_gauge_fix + vil_marginalize) instead of the resident-window entry points")
     ap.add_argument("--slabs", action="store_true", help="replay mode: round-2 residency (LiDAR frame slabs + vil_marginalize_resident) instead of the fully resident window (vil_win_*)")
     ap.add_argument("--precision", type=int, default=0, help="0 = fp64 (reference arithmetic), 1 = fp32 factor evaluation with fp64 accumulation (replay mode only)")
@@ -728,7 +730,7 @@ def main():
     # what a tracker gets: a fresh upload per image (vil_solve = pack + H2D + set-up + solve + read-back), never a re-solve of a resident
     # upload -- reported beside `value`, never as `value`
     pcie_leg = None
-    if world == 1:
+    if world == 1 and not args.no_tracker:
         saved = w.state_copy()
         for _ in range(2):
             w.set_state(saved); be.solve(w, opts)
@@ -797,7 +799,7 @@ def main():
         if prof.sweep_launches > 0:
             out["roofline"] = roofline_obj(w, prof, "second pass of the same %d steps with HIP events enabled (%.1f ms/step instrumented vs %.1f ms/step in the value region)" % (args.steps, 1e3 * el_events / args.steps, 1e3 * max_el / args.steps),
                                            ("r04_pmc_fetch_size.csv", "r04_pmc_write_size.csv"), "profiles/r04_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command)", "r04_pmc_mfma.csv")
-        if world == 1:
+        if world == 1 and pcie_leg is not None:
             out["pcie_inclusive"] = pcie_leg
             out["pcie_inclusive_classic"] = pcie_classic
         if cfg3_leg:

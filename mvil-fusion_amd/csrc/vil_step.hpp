@@ -573,44 +573,75 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
     return s.cok != 0;
 }
 
-// back substitution L^T x = y (y = row D of A) with 16 x 16 diagonal blocks: 10 dependent stages instead of 40.
-//   (I)  W_t = L_tt^-1 for every diagonal tile at once (one thread per tile column, 16-step forward substitution in
-//        registers); then W_t^T REPLACES the diagonal tile (nothing reads L_tt after this): row j = zeros, 1 / L_jj, W_ij (i > j).
-//   (II) from the last tile up: x_blk = W^T y_blk (16 lanes, one short dot product each), barrier, the threads owning a
-//        column c < kb fold x_blk into y_c (16-term dot product down a tile column), barrier.
+// back substitution L^T x = y (y = row D of A) with 16 x 16 diagonal blocks.
+//   (I)  one WAVE per diagonal tile (no workgroup barrier inside): W_t = L_tt^-1 by the column recurrence with FOUR lanes per column -- lane (j, p) holds
+//        the entries L[i][4m + p] of its quarter (36 loads, one round trip) and the w_k with k = p mod 4, a row's partial sums meet in two DPP quad
+//        steps -- then W_t^T REPLACES the diagonal tile (row j = zeros, 1 / L_jj, W_ij for i > j), and N_t = W_t L_{t,t-1} (four matrix-core
+//        instructions) REPLACES the tile left of it.  (One thread per column, as before: 120 loads and their waits in a row; about the same ~5000 cycles for the stage, but no barrier inside it.)
+//   (II) from the last tile up, ONE barrier per tile: wave 0 completes y_blk (its own share of the folds is a register), shares it through LDS, and forms
+//        from the same sixteen values BOTH x_blk = W^T y_blk and N^T y_blk = L_{blk,blk-1}^T x_blk, what x_blk takes off the NEXT block's y -- the only
+//        fold the next stage waits for.  Behind the barrier the other waves fold x_blk into the columns
+//        left of that block, one column per thread, while wave 0 is already in the next stage; their sums are due one barrier later.
+//        (Before: x, barrier, every thread folds, barrier: 1200 - 1700 cycles per tile against ~1000.  Splitting x and the fold over two groups of lanes
+//        with the fold passed through LDS, operands loaded ahead of the barrier, was slower again: the tile is bound by the LDS traffic of its one wave.)
 // Result in s.y[0..D).
 template <class PTR>
 __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
-    const int t = threadIdx.x, NT = blockDim.x;
+    const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63;
     for (int i = t; i < D; i += NT) s.y[i] = A[tl_idx(D, i)];
     const int TD = (D + 15) >> 4;                           // diagonal tiles that hold rows of L
     for (int i = D + t; i < (TD << 4); i += NT) s.y[i] = 0.0;                        // padding of the last tile: its products vanish
     // ---- (I) ----------------------------------------------------------------------------------------------------
-    // (one round: at most 20 diagonal tiles = 320 columns on 512 threads.  The whole diagonal tile is overwritten with W^T -- row j: zeros, 1 / L_jj,
-    //  W_ij for i > j -- once every thread has read its column of L_tt: nothing reads L_tt after this, and stage (II) gets a plain 16-term product
-    //  per lane instead of a masked one with a select chain for the diagonal)
     {
-        const int q = t, tt = q >> 4, j = q & 15;
-        const bool mine = q < (TD << 4);
-        const int ttc = mine ? tt : 0;
-        const int n_t = min(16, D - (ttc << 4));
-        const int tb = tl_base(ttc, ttc);
-        const double* dv = s.dinv + (ttc << 4);
-        double w[16];
+        const int j = lane >> 2, p = lane & 3;
+        const int lc = (lane >> 4) * TILE_RS + (lane & 15);     // accumulator element (row lane>>4 (+4g), col lane&15)
+        for (int tt = wave; tt < TD; tt += NT >> 6) {           // wave-uniform
+            const int n_t = min(16, D - (tt << 4));
+            const int tb = tl_base(tt, tt);
+            const double* dv = s.dinv + (tt << 4);
+            double dr[16], lq[16][4], wq[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            double acc0 = 0.0, acc1 = 0.0;
+            for (int i = 0; i < 16; ++i) dr[i] = dv[i];     // (beyond the matrix: whatever the array holds -- masked below)
 #pragma unroll
-            for (int k = 0; k < i; ++k) {                  // w_k = 0 for k < j: the products vanish, no predicate needed
-                const double l = A[tb + i * TILE_RS + k];
-                if (k & 1) acc1 += l * w[k]; else acc0 += l * w[k];
+            for (int i = 1; i < 16; ++i)
+#pragma unroll
+                for (int m = 0; m < (i + 3) / 4; ++m) lq[i][m] = A[tb + i * TILE_RS + 4 * m + p];
+#pragma unroll
+            for (int i = 1; i < 16; ++i)
+#pragma unroll
+                for (int m = 0; m < (i + 3) / 4; ++m) { double v = lq[i][m]; asm volatile("" : "+v"(v)); lq[i][m] = (4 * m + p < i) ? v : 0.0; }      // (at or right of the diagonal: not L)
+            const bool col = j < n_t;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int m = 0; m < (i + 3) / 4; ++m) { if (m & 1) a1 = fma(lq[i][m], wq[m], a1); else a0 = fma(lq[i][m], wq[m], a0); }
+                double sum = a0 + a1;
+                if (i > 0) { sum = dpp_add<0xB1, 0xf>(sum); sum = dpp_add<0x4E, 0xf>(sum); }     // quad_perm [1,0,3,2], [2,3,0,1]: the four quarters of the row, the same bits in the four lanes
+                double off = -sum * dr[i], on = dr[i];
+                asm volatile("" : "+v"(off), "+v"(on));        // both arms exist before the selects: nothing for the compiler to sink into a branch
+                const bool live = col && i < n_t;
+                const double wi = (live && i > j) ? off : ((live && i == j) ? on : 0.0);
+                wq[i >> 2] = ((i & 3) == p) ? wi : wq[i >> 2];
             }
-            w[i] = (i < j || i >= n_t || j >= n_t) ? 0.0 : (i == j ? dv[i] : -(acc0 + acc1) * dv[i]);
-        }
-        lds_barrier();
-        if (mine) {
+            // (a wave's LDS operations execute in order and every lane's loads above have been consumed: the tile can be overwritten)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) A[tb + j * TILE_RS + i] = w[i];      // W_ij at (j, i)
+            for (int m = 0; m < 4; ++m) A[tb + j * TILE_RS + 4 * m + p] = wq[m];      // W_ij at (j, i)
+            if (tt > 0) {                                    // N = W L_{t,t-1}: N[i][c] = sum_r W[i][r] L[16 t + r][16 (t - 1) + c]
+                const int nb = tl_base(tt, tt - 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                double av[4], bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int o = (4 * q + (lane >> 4)) * TILE_RS + (lane & 15); av[q] = A[tb + o]; bv[q] = A[nb + o]; }
+                d4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double b_ = bv[q]; asm volatile("" : "+v"(b_));
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], (4 * q + (lane >> 4) < n_t) ? b_ : 0.0, c, 0, 0, 0);      // (rows beyond the matrix: W is zero there, L may be anything)
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) A[nb + lc + g * (4 * TILE_RS)] = c[g];
+            }
         }
     }
     lds_barrier();
@@ -618,34 +649,50 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
     if (t == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); s.tacc[0] = tt_; }
 #endif
     // ---- (II) ---------------------------------------------------------------------------------------------------
+    double crit = 0.0;                                      // wave 0, lane tt: what x of the tile just solved takes off y[kb + tt]
+    const int cz = t - 64;                                  // the column a thread of waves 1 .. folds (D <= 320 < NT - 64)
     for (int blk = TD - 1; blk >= 0; --blk) {
-        const int kb = blk << 4, n_b = min(16, D - kb);
-        if (t < 64) {                                         // wave 0 (scalar branch); lanes 16..63 mirror lanes 0..15 and do not store
+        const int kb = blk << 4;
+        if (t < 64) {                                         // wave 0 (scalar branch); lanes 16..63 mirror lanes 0..15 (sixteen active lanes only: no faster)
             const int tt = t & 15;
             const int tb = tl_base(blk, blk) + tt * TILE_RS;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            const int nb = tl_base(blk, max(blk - 1, 0)) + tt;          // column tt of N (blk = 0: unused)
+            double wr[16], nn[16];
 #pragma unroll
-            for (int i = 0; i < 16; i += 4) {                  // row tt of W^T (zeros left of the diagonal and beyond the matrix) times y_blk
-                a0 = fma(A[tb + i], s.y[kb + i], a0); a1 = fma(A[tb + i + 1], s.y[kb + i + 1], a1);
-                a2 = fma(A[tb + i + 2], s.y[kb + i + 2], a2); a3 = fma(A[tb + i + 3], s.y[kb + i + 3], a3);
+            for (int i = 0; i < 16; ++i) { wr[i] = A[tb + i]; nn[i] = A[nb + i * TILE_RS]; }      // independent of y: in flight during the round trip below
+            const double yo = s.y[kb + tt] - crit;
+            s.y[kb + tt] = yo;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (its LDS operations execute in order: the reads below see every lane's store)
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) {                  // row tt of W^T (zeros left of the diagonal and beyond the matrix) and column tt of N, times y_blk
+                const double y0 = s.y[kb + i], y1 = s.y[kb + i + 1], y2 = s.y[kb + i + 2], y3 = s.y[kb + i + 3];
+                a0 = fma(wr[i], y0, a0); a1 = fma(wr[i + 1], y1, a1); a2 = fma(wr[i + 2], y2, a2); a3 = fma(wr[i + 3], y3, a3);
+                c0 = fma(nn[i], y0, c0); c1 = fma(nn[i + 1], y1, c1); c2 = fma(nn[i + 2], y2, c2); c3 = fma(nn[i + 3], y3, c3);
             }
-            if (t < n_b) s.y[kb + t] = (a0 + a1) + (a2 + a3);      // x over y_blk, which only this wave reads and has read (its LDS operations execute in order)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            s.y[kb + tt] = (a0 + a1) + (a2 + a3);             // x (rows beyond the matrix: W^T is zero there, x = 0)
+            crit = (c0 + c1) + (c2 + c3);
         }
         lds_barrier();
-        for (int c = t; c < kb; c += NT) {                  // y_c -= sum_r L[kb+r][c] x_r
-            const int base = tl_base(blk, c >> 4) + (c & 15);
+        if (t >= 64 && (t & ~63) - 64 < kb - 16) {           // (wave-uniform: a wave whose columns all lie right of the limit stays off the LDS pipe)
+            // columns left of the next block: y_c -= sum_r L[kb + r][c] x_r, due at the NEXT barrier
+            const int lim = kb - 16, cc = min(cz, lim - 1);
+            const int base = tl_base(blk, cc >> 4) + (cc & 15);
             double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
 #pragma unroll
-            for (int r = 0; r < 16; r += 4) {                  // rows >= n_b of the last tile: y is zero there (padding above)
-                v0 += A[base + r * TILE_RS] * s.y[kb + r];
-                v1 += A[base + (r + 1) * TILE_RS] * s.y[kb + r + 1];
-                v2 += A[base + (r + 2) * TILE_RS] * s.y[kb + r + 2];
-                v3 += A[base + (r + 3) * TILE_RS] * s.y[kb + r + 3];
+            for (int r = 0; r < 16; r += 4) {
+                v0 = fma(A[base + r * TILE_RS], s.y[kb + r], v0);
+                v1 = fma(A[base + (r + 1) * TILE_RS], s.y[kb + r + 1], v1);
+                v2 = fma(A[base + (r + 2) * TILE_RS], s.y[kb + r + 2], v2);
+                v3 = fma(A[base + (r + 3) * TILE_RS], s.y[kb + r + 3], v3);
             }
-            s.y[c] -= (v0 + v1) + (v2 + v3);
+            double yn = s.y[cc] - ((v0 + v1) + (v2 + v3));
+            asm volatile("" : "+v"(yn));
+            if (cz < lim) s.y[cc] = yn;
         }
-        lds_barrier();
     }
+    lds_barrier();
 }
 
 // ---- chain path (vil_chain.hpp): pack the pose part, eliminate the speed-bias chain from both ends, Schur-update the pose

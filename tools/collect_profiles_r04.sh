@@ -9,12 +9,12 @@ for cfg in 2 3 4; do
   find /tmp/p_trace -name "*kernel_trace.csv" -exec cp {} $O/r04_kernel_trace$sfx.csv \;
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/p_pmc
-    timeout 300 rocprofv3 --pmc $ctr --output-format csv -d /tmp/p_pmc -- python $R/bench.py --config $cfg --steps 10 --warmup 2 --no-cpu --no-events --no-cfg3 > /dev/null 2>&1
+    timeout 300 rocprofv3 --pmc $ctr --output-format csv -d /tmp/p_pmc -- python $R/bench.py --config $cfg --steps 10 --warmup 2 --no-cpu --no-events --no-cfg3 --no-tracker > /dev/null 2>&1
     lc=$(echo $ctr | tr A-Z a-z)
     find /tmp/p_pmc -name "*counter_collection.csv" -exec cp {} $O/r04_pmc_${lc}$sfx.csv \;
   done
   rm -rf /tmp/p_mfma
-  timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/p_mfma -- python $R/bench.py --config $cfg --steps 10 --warmup 2 --no-cpu --no-events --no-cfg3 > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/p_mfma -- python $R/bench.py --config $cfg --steps 10 --warmup 2 --no-cpu --no-events --no-cfg3 --no-tracker > /dev/null 2>&1
   find /tmp/p_mfma -name "*counter_collection.csv" -exec cp {} $O/r04_pmc_mfma$sfx.csv \;
   python $R/profiles/summarize.py $O/r04_kernel_trace$sfx.csv $O/r04_pmc_fetch_size$sfx.csv $O/r04_pmc_write_size$sfx.csv $O/r04_pmc_mfma$sfx.csv > $O/r04_summary$sfx.txt 2>&1
 done
