@@ -151,6 +151,18 @@ __global__ __launch_bounds__(256) void k_solve_init(Ctl* ctl, int gen, double ra
     __syncthreads();
     if (threadIdx.x == 0) { ctl->gen = gen; ctl->first = 1; ctl->radius = radius; ctl->mu = mu; ctl->lin_mode = lin_mode; }
 }
+// (vil_reset_state is deferred to the next call that touches the state: in front of a solve it rides in the init launch -- one launch and one host
+//  call gap less per solve of a bench / re-solve loop)
+__global__ __launch_bounds__(256) void k_solve_init_reset(Ctl* ctl, int gen, double radius, double mu, int lin_mode, double* x0, double* x1, const double* src, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const double v = src[i]; x0[i] = v; x1[i] = v; }
+    if (blockIdx.x == 0) {
+        double* w = (double*)ctl;
+        for (int q = threadIdx.x; q < (int)(sizeof(Ctl) / 8); q += blockDim.x) w[q] = 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) { ctl->gen = gen; ctl->first = 1; ctl->radius = radius; ctl->mu = mu; ctl->lin_mode = lin_mode; }
+    }
+}
 __global__ __launch_bounds__(256) void k_state_reset(double* x0, double* x1, const double* src, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) { const double v = src[i]; x0[i] = v; x1[i] = v; }

@@ -197,6 +197,7 @@ struct vil_ctx {
     int K = 0, L = 0, D = 0, NS = 0;
     size_t off_x0 = 0;             // backup of the uploaded state (device)
     double* d_x0 = nullptr;
+    bool reset_pending = false;       // vil_reset_state called, the copy not launched yet
     std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
     int n_blocks_sweep = 0, n_blocks_reduce = 0, n_blocks_reduce_po = 0, n_gather_m = 0, n_ww = 0;      // n_ww: tiles of W W^T formed by extra workgroups of k_reduce (vil_prechain.hpp)
     size_t lds_sweep = 0, lds_step = 0, lds_reduce = 0;
@@ -608,7 +609,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     int st = validate(p, s, dl != nullptr, ws != nullptr);
     if (st != VIL_OK) return st;                 // an invalid problem leaves the resident one untouched
     c->uploaded = false;                         // from here on the arena is rewritten: resident only again after a complete upload
-    c->resident_kind = 0;
+    c->resident_kind = 0; c->reset_pending = false;
     HIPCHK(hipSetDevice(c->device));
     const int K = p->K, L = p->L, D = 15 * K + 7, NV = 6 * K + 7, NS = 16 * K + 8 + L;
 #ifdef VIL_TUNING
@@ -1025,11 +1026,10 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             if (8 * (tiles + wt + scr) + fixed <= 160 * 1024) { P.chain = 1; c->lds_step = 8 * (tiles + wt + scr); }
             else if (8 * (tiles + scr) + fixed <= 160 * 1024) { P.chain = 2; c->lds_step = 8 * (tiles + scr); }
         }
-        // one GPU, chain windows up to K = 12: gather + step in ONE launch with the chain eliminated beside the gather (prechain 1, vil_prechain.hpp).
-        // Larger windows keep the separate gather -- with ~100 kB of dynamic LDS per workgroup their ~1500 gather workgroups would need six
-        // rounds on 256 compute units, the small gather kernel runs eight workgroups per unit -- and eliminate the chain inside k_sweep, behind
-        // the IMU / prior workgroups' flags and under the visual workgroups (42 us at K = 20), with the W W^T tiles on extra workgroups of
-        // k_reduce (prechain 2).
+        // one GPU, chain windows: gather + step in ONE launch with the chain eliminated beside the gather (prechain 1, vil_prechain.hpp).
+        // Until round 4 only up to K = 12: with ~100 kB of dynamic LDS per workgroup the ~1500 gather workgroups of a K = 20 window needed six rounds
+        // on 256 compute units.  Windows the launch cannot hold (capacity check below) keep the separate gather and eliminate the chain inside
+        // k_sweep, behind the IMU / prior workgroups' flags, with the W W^T tiles on extra workgroups of k_reduce (prechain 2).
         const size_t Tp_ = (size_t)(NV + 1 + 15) / 16, tiles_ = (size_t)TILE_SZ * (Tp_ * (Tp_ + 1) / 2);
         const size_t lds3 = 8 * (tiles_ + 54 * (size_t)K + 82 * (size_t)K + vd::even_up(9 * K) + 16), ldsc = 8 * vd::prechain_lds_doubles(K);
         const bool can_pre = !c->split && pre_ok && P.chain != 0 && Tp_ * (Tp_ + 1) / 2 <= 64 && lds3 + sizeof(vd::StepShared) + 512 <= 160 * 1024 && ldsc <= 150 * 1024;
@@ -1299,11 +1299,23 @@ static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEve
     return VIL_OK;
 }
 
+// vil_reset_state is deferred: whoever touches the resident state next restores it first (a solve inside its init launch)
+static void flush_reset(vil_ctx* c) {
+    if (!c->reset_pending) return;
+    hipLaunchKernelGGL(k_state_reset, dim3((c->NS + 255) / 256), dim3(256), 0, c->stream, c->P.x[0], c->P.x[1], (const double*)c->d_x0, c->NS);
+    c->reset_pending = false;
+}
 static int init_ctl(vil_ctx* c, const vil_options* o, int lin_mode) {
     // (a kernel with the values in its arguments: an asynchronous copy out of the one pinned h_ctl could be overtaken by the next call's init --
     //  vil_win_marginalize / push / drop return without a stream synchronisation)
     static_assert(sizeof(Ctl) % 8 == 0, "Ctl is cleared as doubles");
-    hipLaunchKernelGGL(k_solve_init, dim3(1), dim3(256), 0, c->stream, c->P.ctl, ++c->solve_gen, o->initial_radius, o->min_mu, lin_mode);
+    if (c->reset_pending && lin_mode == 0) {               // vil_reset_state + vil_solve_resident: the state copy rides in the init launch
+        hipLaunchKernelGGL(k_solve_init_reset, dim3((c->NS + 255) / 256), dim3(256), 0, c->stream, c->P.ctl, ++c->solve_gen, o->initial_radius, o->min_mu, lin_mode, c->P.x[0], c->P.x[1], (const double*)c->d_x0, c->NS);
+        c->reset_pending = false;
+    } else {
+        flush_reset(c);
+        hipLaunchKernelGGL(k_solve_init, dim3(1), dim3(256), 0, c->stream, c->P.ctl, ++c->solve_gen, o->initial_radius, o->min_mu, lin_mode);
+    }
     memset(c->h_ctl, 0, sizeof(Ctl));
     return VIL_OK;
 }
@@ -1331,7 +1343,7 @@ int vil_debug_read(vil_ctx* c, long long* out64) {
 int vil_reset_state(vil_ctx* c) {
     if (!c || !c->uploaded) return VIL_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_state_reset, dim3((c->NS + 255) / 256), dim3(256), 0, c->stream, c->P.x[0], c->P.x[1], (const double*)c->d_x0, c->NS);
+    c->reset_pending = true;                                 // (carried out by the next call that touches the state: flush_reset / init_ctl)
     c->mirror_state = false;
     return VIL_OK;
 }
@@ -1473,6 +1485,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
 int vil_download_state(vil_ctx* c, vil_state* s) {
     if (!c || !s || !c->uploaded || s->K != c->K || s->L != c->L) return VIL_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(c->device));
+    flush_reset(c);
     const double* x = nullptr;
     std::vector<double> xb;
     if (c->mirror_state) x = (const double*)(c->h_mirror + sizeof(Ctl) + 64);      // left there by solve_finish: no device operation

@@ -126,6 +126,26 @@ def test_resident_solve_repeatable(hip):
     assert abs(s1.final_cost - s2.final_cost) <= 1e-9 * s1.final_cost
 
 
+def test_deferred_reset_is_carried_out_by_whoever_touches_the_state_next(hip):
+    """vil_reset_state launches nothing: a following vil_solve_resident restores the state inside its init launch, anything else that reads the
+    resident state (vil_download_state here) restores it first."""
+    w = synth.make_config(2, L=150, n_plane=3000, n_edge=800)
+    start = w.state_copy()
+    hip.upload(w)
+    s1 = hip.solve_resident()
+    hip.download_state(w)
+    assert np.abs(w.pose - start["pose"]).max() > 1e-6              # the solve moved the state
+    hip.reset_state()
+    hip.download_state(w)                                           # no solve in between
+    for k in start:
+        assert np.array_equal(getattr(w, k), start[k]), k
+    s2 = hip.solve_resident()                                       # nothing pending any more: continues from the restored state all the same
+    assert (s2.iterations, s2.termination) == (s1.iterations, s1.termination) and s2.final_cost == s1.final_cost
+    hip.reset_state(); hip.reset_state()                            # idempotent
+    s3 = hip.solve_resident()
+    assert s3.final_cost == s1.final_cost
+
+
 @pytest.mark.parametrize("cid,kw", [(1, dict(L=60)), (2, dict(L=100, n_plane=1500, n_edge=500)), (2, dict(K=7, L=80, n_plane=600, n_edge=200))])
 def test_solve_parity_over_seeds(hip, oracle, cid, kw):
     """Differently seeded scenes of the same shape (tools/fuzz_parity.py runs 1200 of them): the trust-region trajectory --
