@@ -384,8 +384,8 @@ def vgicp_mode(args):
            "roofline": {"bound": "hbm", "kernel": "k_vgicp_lin", "achieved": ab / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ab / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                         "traffic": (pmc_traffic_bytes(("r01_vgicp64_pmc_FETCH_SIZE.csv", "r01_vgicp64_pmc_WRITE_SIZE.csv"), "k_vgicp_lin") if (rings, az) == (64, 2048) else
-                                    (pmc_traffic_bytes(("r03_vgicp16_pmc_FETCH_SIZE.csv", "r03_vgicp16_pmc_WRITE_SIZE.csv"), "k_vgicp_lin") if (rings, az) == (16, 1800) else None)),
-                        "traffic_source": "profiles/r03_vgicp16_pmc_*.csv (16-ring x 1800 pair, tools/collect_profiles_r03.sh) / profiles/r01_vgicp64_pmc_*.csv (64-ring x 2048 pair, tools/collect_pmc_rows.sh)",
+                                    (pmc_traffic_bytes(("r04_vgicp16_pmc_FETCH_SIZE.csv", "r04_vgicp16_pmc_WRITE_SIZE.csv"), "k_vgicp_lin") if (rings, az) == (16, 1800) else None)),
+                        "traffic_source": "profiles/r04_vgicp16_pmc_*.csv (16-ring x 1800 pair, tools/collect_profiles_r04.sh) / profiles/r01_vgicp64_pmc_*.csv (64-ring x 2048 pair, tools/collect_pmc_rows.sh)",
                         "algorithmic_bytes_per_launch": ab, "avg_launch_us": k_us, "launches_timed": int(pn.value),
                         "note": "HIP events on the library's stream around the kernel; a whole vgicp_linearize call is %.1f us of wall time (2 launches + D2H of 29 doubles + stream sync)" % (1e6 * el / args.steps)}}
     if not args.no_cpu:
