@@ -27,6 +27,17 @@ class VilProfile(C.Structure):
     _fields_ = [("sweep_launches", C.c_int64), ("sweep_ms", C.c_double), ("step_launches", C.c_int64), ("step_ms", C.c_double), ("reduce_ms", C.c_double), ("collective_ms", C.c_double)]
 
 
+def emit(out):
+    """The ONE JSON line, and the last thing on stdout: native libraries (RCCL's version banner under a communicator) write through C stdio, which is block-buffered
+    on a pipe and would otherwise be flushed at exit, AFTER Python's line."""
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
 def algorithmic_bytes(w):
     """SURVEY.md 8(d), fused (read-only) variant of the sweep: bytes one launch must read."""
     n = w.prior.n
@@ -331,7 +342,7 @@ def replay_mode(args, be, abi, lib):
                                "note": "CPU restatement on the same input windows; solve single-threaded, marginalisation 4 threads (marginalization_factor.h:13)"}
         out["speedup_vs_cpu_baseline"] = float(np.median(tot_c) / np.median(tot_g))
         out["max_abs_position_difference_m"] = float(max(dpos))
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 def vgicp_mode(args):
@@ -406,7 +417,7 @@ def vgicp_mode(args):
                                "note": "single-threaded restatement of fast_gicp's FastVGICP (the reference runs it with OpenMP NumThreads from the yaml)"}
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         out["max_abs_T_difference"] = float(np.abs(Tg - To).max())
-    print(json.dumps(out), flush=True)
+    emit(out)
     g.close()
 
 
@@ -476,7 +487,7 @@ def mapreg_mode(args):
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         out["max_abs_t_difference_m"] = float(np.abs(tg - to).max())
         o.close()
-    print(json.dumps(out), flush=True)
+    emit(out)
     g.close(); be.close()
 
 
@@ -524,7 +535,7 @@ def preint_mode(args):
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         out["max_rel_covariance_difference"] = float(np.abs(rg[:, 62:] - ro[:, 62:]).max() / np.abs(ro[:, 62:]).max())
         o.close()
-    print(json.dumps(out), flush=True)
+    emit(out)
     g.close()
 
 
@@ -816,7 +827,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w, opts)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["all_cores"]["value"]
-        print(json.dumps(out), flush=True)
+        emit(out)
     be.close()
     if dist is not None:
         dist.destroy_process_group()
