@@ -650,7 +650,6 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
 #endif
     // ---- (II) ---------------------------------------------------------------------------------------------------
     double crit = 0.0;                                      // wave 0, lane tt: what x of the tile just solved takes off y[kb + tt]
-    const int cz = t - 64;                                  // the column a thread of waves 1 .. folds (D <= 320 < NT - 64)
     for (int blk = TD - 1; blk >= 0; --blk) {
         const int kb = blk << 4;
         if (t < 64) {                                         // wave 0 (scalar branch); lanes 16..63 mirror lanes 0..15 (sixteen active lanes only: no faster)
@@ -675,21 +674,25 @@ __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
             crit = (c0 + c1) + (c2 + c3);
         }
         lds_barrier();
-        if (t >= 64 && (t & ~63) - 64 < kb - 16) {           // (wave-uniform: a wave whose columns all lie right of the limit stays off the LDS pipe)
-            // columns left of the next block: y_c -= sum_r L[kb + r][c] x_r, due at the NEXT barrier
-            const int lim = kb - 16, cc = min(cz, lim - 1);
-            const int base = tl_base(blk, cc >> 4) + (cc & 15);
-            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        if (t >= 64) {
+            // columns left of the next block: y_c -= sum_r L[kb + r][c] x_r, due at the NEXT barrier (wave-uniform loop bounds: a wave whose columns all lie
+            // right of the limit stays off the LDS pipe)
+            const int lim = kb - 16;
+            for (int w0 = (t & ~63) - 64; w0 < lim; w0 += NT - 64) {
+                const int c = w0 + (t & 63), cc = min(c, lim - 1);
+                const int base = tl_base(blk, cc >> 4) + (cc & 15);
+                double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
 #pragma unroll
-            for (int r = 0; r < 16; r += 4) {
-                v0 = fma(A[base + r * TILE_RS], s.y[kb + r], v0);
-                v1 = fma(A[base + (r + 1) * TILE_RS], s.y[kb + r + 1], v1);
-                v2 = fma(A[base + (r + 2) * TILE_RS], s.y[kb + r + 2], v2);
-                v3 = fma(A[base + (r + 3) * TILE_RS], s.y[kb + r + 3], v3);
+                for (int r = 0; r < 16; r += 4) {
+                    v0 = fma(A[base + r * TILE_RS], s.y[kb + r], v0);
+                    v1 = fma(A[base + (r + 1) * TILE_RS], s.y[kb + r + 1], v1);
+                    v2 = fma(A[base + (r + 2) * TILE_RS], s.y[kb + r + 2], v2);
+                    v3 = fma(A[base + (r + 3) * TILE_RS], s.y[kb + r + 3], v3);
+                }
+                double yn = s.y[cc] - ((v0 + v1) + (v2 + v3));
+                asm volatile("" : "+v"(yn));
+                if (c < lim) s.y[cc] = yn;
             }
-            double yn = s.y[cc] - ((v0 + v1) + (v2 + v3));
-            asm volatile("" : "+v"(yn));
-            if (cz < lim) s.y[cc] = yn;
         }
     }
     lds_barrier();

@@ -1140,13 +1140,13 @@ static int upload_sharded(vil_ctx* c, const vil_problem* p, const vil_state* s) 
     c->lm_b = lb; c->lm_e = le;
     {   // who owns which slice of the landmark arrays of the message (the same arithmetic on every rank)
         OwnSeg& S = c->own; memset(&S, 0, sizeof S);
-        S.n = c->world; S.Lp = std::max(p->L, 1);
-        for (int r = 0; r < c->world; ++r) {
+        S.n = c->world <= 8 ? c->world : 0; S.Lp = std::max(p->L, 1);      // (more than eight ranks: RCCL only, which sums the whole set -- n = 0)
+        for (int r = 0; r < S.n; ++r) {
             int32_t b = 0; vil_shard_ranges(p, r, c->world, &b, nullptr, nullptr, nullptr, nullptr, nullptr);
             S.lb[r] = b; int fb = 0; for (int f = 0; f < p->n_vis; ++f) if (p->vis_l[f] < b) fb = f + 1;
             S.fb[r] = fb;
         }
-        S.lb[c->world] = p->L; S.fb[c->world] = p->n_vis;
+        S.lb[S.n] = p->L; S.fb[S.n] = p->n_vis;
         const int D = 15 * p->K + 7;
         S.cam = ((size_t)D * D + 3 * (size_t)D + 3 + 1) & ~size_t(1);
     }
@@ -2171,10 +2171,10 @@ int vil_win_solve(vil_ctx* c, const vil_win_problem* wp, vil_state* s, const vil
         std::vector<int> lms(L + 1, 0);
         for (int l = 0; l < L; ++l) lms[l + 1] = lms[l] + wp->lm_nobs[l] - 1;
         OwnSeg& S = c->own; memset(&S, 0, sizeof S);
-        S.n = c->world; S.Lp = std::max(L, 1);
-        for (int r = 0; r <= c->world; ++r) { S.lb[r] = shard_cut(lms, L, r, c->world); S.fb[r] = lms[S.lb[r]]; }
+        S.n = c->world <= 8 ? c->world : 0; S.Lp = std::max(L, 1);          // (more than eight ranks: RCCL only, which sums the whole set -- n = 0)
+        for (int r = 0; r <= S.n; ++r) { S.lb[r] = shard_cut(lms, L, r, c->world); S.fb[r] = lms[S.lb[r]]; }
         S.cam = ((size_t)(15 * K + 7) * (15 * K + 7) + 3 * (size_t)(15 * K + 7) + 3 + 1) & ~size_t(1);
-        ws.lb = S.lb[c->rank]; ws.le = S.lb[c->rank + 1]; ws.f0 = S.fb[c->rank]; ws.n_vis = S.fb[c->rank + 1] - S.fb[c->rank];
+        ws.lb = shard_cut(lms, L, c->rank, c->world); ws.le = shard_cut(lms, L, c->rank + 1, c->world); ws.f0 = lms[ws.lb]; ws.n_vis = lms[ws.le] - lms[ws.lb];
         c->lm_b = ws.lb; c->lm_e = ws.le;
         vil_problem ql = q;
         if (c->rank != 0) { ql.n_imu = 0; ql.n_icp = 0; ql.n_lps = 0; ql.prior.n = 0; ql.prior.nblk = 0; }
