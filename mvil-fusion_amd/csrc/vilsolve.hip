@@ -233,6 +233,7 @@ struct vil_ctx {
     int solves_since_upload = 0;
     bool split = false;            // sweep + gather fill set 0, the collective sums it into set 1, the step kernel reads set 1
     bool force_split = false;      // vil_debug_set_split: that plumbing on a single rank
+    int launch_mode = 0;           // vil_debug_set_launch_mode: 0 = the library's choice, 1 = no merged launch, 2 = no chain workgroup
     int last_live = 5;             // live sweep launches of the previous solve (sizes the first launch chunk)
     int lm_b = 0, lm_e = 0;        // owned landmark range
     OwnSeg own = {0, 0, 0, {0}, {0}};      // every rank's landmark / factor range in the per-iteration message (sharded windows)
@@ -868,7 +869,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     put(nullptr, 8 * 64, (void**)&P.dbg);
     // ---- chain eliminated ahead of the step kernel (vil_prechain.hpp): every IMU factor joins frames (k, k+1), at most one per pair, single GPU.
     //      The gather table is built here once per upload: the chain workgroup then sums <= 3 sources per entry in a fixed order.
-    bool pre_ok = !sharded && !c->force_split && L >= 0 && K >= 3 && VIL_TUNE_ENV("VIL_NO_PRECHAIN") == nullptr;
+    bool pre_ok = !sharded && !c->force_split && c->launch_mode != 2 && L >= 0 && K >= 3 && VIL_TUNE_ENV("VIL_NO_PRECHAIN") == nullptr;
     std::vector<int> as_i(K, -1), as_j(K, -1);
     for (int f = 0; f < p->n_imu && pre_ok; ++f) {
         const int i = p->imu_i[f], j = p->imu_j[f];
@@ -1036,7 +1037,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         // (round 4: every window size -- the gather of a prechain solve forms the visual sub-space only, 551 workgroups at K = 20 instead of 1500)
         int kmerge = 20;
         if (const char* ev = VIL_TUNE_ENV("VIL_MERGE_K")) kmerge = atoi(ev);
-        bool merged = can_pre && K <= kmerge && std::max(lds3, ldsc) + 52 * 1024 <= 160 * 1024 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
+        bool merged = can_pre && c->launch_mode == 0 && K <= kmerge && std::max(lds3, ldsc) + 52 * 1024 <= 160 * 1024 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
         if (merged) {
             // the merged launch holds workgroups that spin on flags (master, helpers, one per W W^T tile) next to the finite ones they wait for (chain,
             // gather: lower block indices, dispatched first).  It is only taken when the device can hold every spinning workgroup AND one more at the
@@ -1890,6 +1891,7 @@ int vil_comm_message_bytes(vil_ctx* c, int64_t* bytes_per_peer, int64_t* bytes_f
 }
 
 // ---- window residency across frames (include/vilsolve.h) ------------------------------------------------------------------------
+int vil_debug_set_launch_mode(vil_ctx* c, int32_t mode) { if (!c || mode < 0 || mode > 2) return VIL_ERR_INVALID_ARGUMENT; c->launch_mode = mode; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
 int vil_debug_set_split(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->force_split = on != 0; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
 int vil_set_gauge_fix(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->gauge_on = on != 0; return VIL_OK; }      // (takes effect in the next solve)
 

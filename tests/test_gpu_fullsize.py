@@ -5,7 +5,7 @@ marginalisation identity J0^T J0 = A on the full-size prior."""
 import numpy as np
 import pytest
 
-from mvil_fusion_amd import abi, synth
+from mvil_fusion_amd import abi, lib, synth
 from test_gpu_parity import compare_states
 
 pytestmark = pytest.mark.gpu
@@ -31,6 +31,33 @@ def test_full_size_solve_and_marginalisation_parity(hip, oracle, cid):
     assert mg.c.n == mo.c.n and np.abs(Ag - Ao).max() <= 1e-8 * np.abs(Ao).max()
     J = np.array(mg.J0[:mg.c.n * mg.c.n]).reshape(mg.c.n, mg.c.n).T          # stored column-major
     assert np.abs(J.T @ J - Ag).max() <= 1e-9 * np.abs(Ag).max()
+
+
+@pytest.mark.parametrize("cid,mode", [(2, 1), (2, 2), (4, 1), (4, 2), (1, 1)])
+def test_fallback_launch_structures_match_the_oracle(oracle, cid, mode):
+    """What a single-GPU solve launches when the gather + step launch cannot be taken (vil_debug_set_launch_mode; never on an MI355X at BASELINE's sizes,
+    so forced here): mode 1 = separate gather launch, the speed-bias chain eliminated by a workgroup of the sweep launch behind the IMU / prior
+    workgroups' flags, its W W^T tiles on workgroups of the gather launch, the inverses of its diagonal blocks on a workgroup of the step launch;
+    mode 2 = the step kernel eliminates the chain itself.  Same trust-region trajectory and solution as the oracle, resident re-solves included."""
+    be = lib.open_vilsolve()
+    assert be.lib.vil_debug_set_launch_mode(be.ctx, mode) == 0
+    wg = synth.make_config(cid, prior_fn=_pf(oracle)); wo = synth.make_config(cid, prior_fn=_pf(oracle))
+    p0 = wg.pose[0].copy()
+    sg, so = be.solve(wg), oracle.solve(wo)
+    assert (sg.iterations, sg.successful_steps, sg.termination) == (so.iterations, so.successful_steps, so.termination)
+    assert abs(sg.final_cost - so.final_cost) <= (1e-8 if wo.prior.n else 1e-5) * so.final_cost
+    be.gauge_fix(p0, wg); oracle.gauge_fix(p0, wo)
+    if wo.prior.n:
+        compare_states(wg, wo)
+    w2 = synth.make_config(cid, prior_fn=_pf(oracle))
+    be.upload(w2)
+    for _ in range(2):                                               # the second one replays the captured graph of the three-launch iteration
+        be.reset_state(); s2 = be.solve_resident()
+        assert (s2.iterations, s2.termination) == (so.iterations, so.termination) and s2.final_cost == sg.final_cost
+    mg, mo = be.marginalize(wg, abi.MARGIN_OLD), oracle.marginalize(wo, abi.MARGIN_OLD)
+    assert mg.c.n == mo.c.n and np.abs(mg.A_matrix() - mo.A_matrix()).max() <= (1e-8 if wo.prior.n else 1e-4) * np.abs(mo.A_matrix()).max()
+    assert be.lib.vil_debug_set_launch_mode(be.ctx, 3) != 0
+    be.close()
 
 
 def test_point_order_does_not_matter(hip, oracle):
