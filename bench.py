@@ -168,13 +168,13 @@ def roofline_obj(w, prof, measured_on, pmc_files, pmc_note, mfma_file=None):
          "algorithmic_bytes_per_launch": ab, "avg_launch_us": us, "launches_timed": int(prof.sweep_launches),
          "gather_plus_step_avg_us": 1e3 * prof.step_ms / max(1, prof.step_launches),
          "measured_on": measured_on, "variant": "fused sweep (no Jacobian materialisation): read-only bytes, SURVEY 8(d)"}
-    # the launch that dominates the iteration's TIME is the trust-region step (one GPU, K <= 12: the gather of the sweep's partial records and the
+    # the launch that dominates the iteration's TIME is the trust-region step (one GPU: the gather of the sweep's partial records and the
     # speed-bias chain ride in the same launch); it is neither HBM- nor MFMA-bound (one master workgroup on dependent fp64 chains), so it is
     # reported next to the sweep rather than as the roofline object
     NP, NB = 6 * w.K + 7, 9 * w.K
     step_us = 1e3 * prof.step_ms / max(1, prof.step_launches)
     chol_flop = w.K * (9 ** 3 / 3.0 + 2.0 * 81 * (NP + 1 + 9)) + 1.0 * (NP + 1) ** 2 * NB + NP ** 3 / 3.0 + 2.0 * (NP * NP + NB * (NP + 9))
-    merged = w.K <= 12
+    merged = True       # (round 4: gather + step are one launch at every BASELINE window size on one GPU; vil_debug_set_launch_mode forces the fallbacks)
     r["critical_path_kernel"] = {"kernel": "k_step (gather workgroups | chain workgroup | W W^T tile workgroups | master + helpers)" if merged else "k_reduce (gather + W W^T tiles) + k_step (master + helpers + chain inverses); the chain workgroup rides in k_sweep", "avg_launch_us": step_us,
                                  "bound": ("latency: gather of the visual records beside the two-sided 9x9 chain of %d blocks, then a %d-pivot dense Cholesky and the back substitutions on one workgroup (dependent fp64 chains)" if merged else
                                            "latency: gather of the visual records, then on one workgroup a %d-pivot dense Cholesky and the back substitutions (dependent fp64 chains; the two-sided 9x9 chain of %d blocks is eliminated inside the sweep launch)") % ((w.K, NP) if merged else (NP, w.K)),
@@ -191,7 +191,7 @@ def roofline_obj(w, prof, measured_on, pmc_files, pmc_note, mfma_file=None):
                          "v_mfma_f64_16x16x4_per_launch": m["mops_per_launch"] / 4.0, "flop_per_launch": m["flop_per_launch"],
                          "mfma_busy_cycles_per_launch": m["mfma_busy_cycles_per_launch"], "sq_busy_cycles_per_launch": m["sq_busy_cycles_per_launch"],
                          "launch_us": us_k, "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES, one pass; MOPS x 512 flop)" % mfma_file,
-                         "note": "a dense window-local contraction spends ~6x the multiply-adds of the block-sparse form; the launch is bound by its longest workgroup (the speed-bias chain at K > 12), not by the matrix pipes"}
+                         "note": "a dense window-local contraction spends ~6x the multiply-adds of the block-sparse form; the launch is bound by its longest visual workgroup (evaluation, sums and record around ~4 us of matrix-core work), not by the matrix pipes"}
     return r
 
 

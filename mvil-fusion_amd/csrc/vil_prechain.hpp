@@ -84,7 +84,7 @@ __device__ __forceinline__ void chain_inverse_block(const DevP& P, const double*
         st_ag(P.chLsb + 82 * k + 9 * cc + i, k == (P.K >> 1) ? 0.0 : a0 + a1);
     }
 }
-// the same for every block from the raw factors the in-sweep chain workgroup left (K > 12): one extra workgroup of the STEP kernel's launch, beside the
+// the same for every block from the raw factors the in-sweep chain workgroup left (windows the merged launch cannot hold): one extra workgroup of the STEP kernel's launch, beside the
 // master -- which reads the result 40 us after its entry, behind chflag[2].  lds: 136 K doubles (the factors are staged with whole-line loads: read in
 // place every lane would walk 135 loads at memory latency).  (As a workgroup of the gather launch it was that launch's longest.)
 __device__ __forceinline__ void prechain_inverses(const DevP& P, double* lds, const int epoch) {
@@ -177,7 +177,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
         if (t == 384) st_ag(P.chflag + 1, epoch);
     }
     PSTAMP(14);
-    // in-sweep chain (K > 12): the factored blocks leave for prechain_inverses (a workgroup of the gather launch) as they are published, on the two waves
+    // in-sweep chain (fallback launch structure): the factored blocks leave for prechain_inverses (a workgroup of the gather launch) as they are published, on the two waves
     // the elimination leaves idle -- 54 + 82 doubles per block, three stores per lane; from the recursion wave itself (one lane, 54 stores in a row) they
     // cost it 1.7 us per block, as a pass after the elimination 5 us at the end of the launch's longest workgroup
     if (wait_records && t >= 384) {
@@ -202,7 +202,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     __syncthreads();
     if (t == 0) st_ag(P.chflag, epoch);                  // ... W^T is complete: the tile workgroups start
     // ---- off the critical path: what the master needs for the chain BACK substitution, 30 us from now (chain_inverse_block above).  Beside the gather
-    //      (merged launch) the 9 K columns are formed here, one per lane, and are ready long before they are read.  Inside k_sweep (K > 12) this workgroup
+    //      (merged launch) the 9 K columns are formed here, one per lane, and are ready long before they are read.  Inside k_sweep (fallback launch structure) this workgroup
     //      is the launch's longest and 7 us of dependent fp64 chains at its end would be 7 us of the iteration: the raw factors go out instead and a
     //      workgroup of the step launch forms the columns (prechain_inverses above).
     //      (waves 6 / 7 stored them as they were published, above)

@@ -423,7 +423,7 @@ __device__ __forceinline__ void sweep_prior(const DevP& P, const double* x, doub
     // g = pg0 + pH dx.  pH = J0^T J0 is symmetric: lane = column i (consecutive lanes read consecutive doubles of row k), the rows k are dealt to the
     // eight waves, every load of a thread independent of the others; the eight partial sums of a column meet in LDS in a fixed order.
     // (Before: eight lanes per column over rows k = r, r + 8, ..: 64 different cache lines per wave-load -- 16 us at n = 130, and the chain workgroup of
-    //  a K > 12 sweep waits for this record.)
+    //  the chain workgroup of a fallback-structure sweep waits for this record.)
     double* pw = sm + 520;     // 8 x 136
     {
         const int wave = t >> 6, lane = t & 63;
@@ -714,7 +714,7 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
 }
 
 // Gather of the sweep's partial records (reduce_gather above) as a launch of its own: vil_linearize / the marginalisation (no step kernel
-// behind it), the multi-GPU path (the collective sits between gather and step) and windows too large for the merged launch (K > 12) -- for
+// behind it), the multi-GPU path (the collective sits between gather and step) and windows too large for the merged launch -- for
 // those the grid carries one more workgroup per 16 x 16 tile of W W^T (vil_prechain.hpp; n_gather = the gather workgroups).  A solve of a
 // small window on one GPU gathers inside k_step (rs_merged).
 __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P, int n_gather) {
