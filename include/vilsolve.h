@@ -272,6 +272,11 @@ int vil_comm_init_local(vil_ctx** ctxs, int n);
  * the owner's value) -- 103 + 380 / world kB per peer at K = 10 / 1000 landmarks instead of 484 kB.  vil_comm_message_bytes reports it for the
  * uploaded (sharded) window. */
 int vil_comm_message_bytes(vil_ctx* ctx, int64_t* bytes_per_peer, int64_t* bytes_full_set);
+/* RCCL (vil_comm_init, world <= 8) moves the same content as ONE ncclAllReduce of the packed camera part [lower(S') | g | b_c | diag | cost] plus ONE ncclAllGather
+ * of the owners' landmark slices (padded to the largest): 103 + 48 kB per rank at K = 10 / 1000 landmarks / world 8; vil_comm_message_bytes reports that sum.
+ * test hook: the pack / unpack kernels of that path over the in-process communicator (two small kernels stand in for the RCCL calls), so that they run on
+ * 2 / 3 / 8 ranks of one device. */
+int vil_debug_set_slim_emul(vil_ctx* ctx, int32_t on);
 int vil_comm_ipc_export(vil_ctx* ctx, int rank, int world, size_t max_doubles, void* handle64);
 int vil_comm_ipc_init(vil_ctx* ctx, const void* handles /* world x 64 bytes */);
 /* test hook: run the multi-GPU plumbing (partial system in set 0, the collective sums it into set 1, step kernel on set 1) on a

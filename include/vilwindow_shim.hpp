@@ -81,13 +81,15 @@ public:
     // triangulate (feature_manager.cpp:214-273): a landmark of the problem without a depth yet gets one from the window's poses -- the null vector of the
     // stacked projection constraints [f_x P_2 - f_z P_0 ; f_y P_2 - f_z P_1] of its observations (f = point.normalized(), P = [R^T | -R^T t] relative to
     // the anchor camera), depth = V_2 / V_3; a negative result becomes INIT_DEPTH.  pose: K x [p q(xyzw)] body poses, ex: [tic qic(xyzw)].  The reference
-    // takes the last right singular vector of a JacobiSVD; here: the eigenvector of the smallest eigenvalue of A^T A (4 x 4, cyclic Jacobi) -- the same
-    // direction up to sign, and the quotient does not see the sign.
+    // takes the last right singular vector of a JacobiSVD of the stacked rows; here: a one-sided (Hestenes) Jacobi SVD of the same 2 m x 4 matrix -- column rotations
+    // until the columns are orthogonal, the column of smallest norm names the singular vector.  Working on A itself (never A^T A, whose condition number is the
+    // square) keeps the null direction of a low-parallax track (sigma_min / sigma_max ~ 1e-8) resolved to the accuracy the reference has; the quotient
+    // V_2 / V_3 does not see the vector's sign.
     void triangulate(const double* pose, const double* ex) {
         double Ric[9]; quat_R(ex + 3, Ric);
         for (FeatureTrack& t : tracks_) {
             if (!in_problem(t) || t.estimated_depth > 0) continue;
-            double B[16] = {0};
+            std::vector<double>& A = svd_rows_; A.clear();
             double R0[9], t0[3];
             cam_pose(pose + 7 * t.start_frame, ex, Ric, R0, t0);
             for (size_t m = 0; m < t.obs.size(); ++m) {
@@ -105,11 +107,11 @@ public:
                 for (int row = 0; row < 2; ++row) {
                     double a[4];
                     for (int c = 0; c < 4; ++c) a[c] = f[row] * P[8 + c] - f[2] * P[4 * row + c];
-                    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) B[4 * i + j] += a[i] * a[j];
+                    A.insert(A.end(), a, a + 4);
                 }
             }
-            double V[16]; jacobi4(B, V);
-            int kmin = 0; for (int k = 1; k < 4; ++k) if (B[5 * k] < B[5 * kmin]) kmin = k;
+            double V[16], nrm[4]; svd4_onesided(A.data(), (int)(A.size() / 4), V, nrm);
+            int kmin = 0; for (int k = 1; k < 4; ++k) if (nrm[k] < nrm[kmin]) kmin = k;
             const double depth = V[4 * 2 + kmin] / V[4 * 3 + kmin];
             t.estimated_depth = depth < 0 ? init_depth_ : depth;
         }
@@ -202,23 +204,26 @@ private:
             tc[r] = pose7[r] + Rb[3 * r] * ex[0] + Rb[3 * r + 1] * ex[1] + Rb[3 * r + 2] * ex[2];
         }
     }
-    static void jacobi4(double* A /* symmetric 4 x 4, eigenvalues left on the diagonal */, double* V /* eigenvectors in columns */) {
+    // one-sided Jacobi SVD of A (rows x 4, row-major, overwritten by U Sigma): V = right singular vectors in columns, nrm = singular values (unsorted)
+    static void svd4_onesided(double* A, int rows, double* V, double* nrm) {
         for (int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
-        for (int sweep = 0; sweep < 30; ++sweep) {
-            double off = 0.0;
-            for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) off += A[4 * p + q] * A[4 * p + q];
-            if (off < 1e-300) break;
+        for (int sweep = 0; sweep < 60; ++sweep) {
+            bool rotated = false;
             for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) {
-                const double apq = A[4 * p + q];
-                if (apq == 0.0) continue;
-                const double th = (A[5 * q] - A[5 * p]) / (2.0 * apq);
+                double app = 0.0, aqq = 0.0, apq = 0.0;
+                for (int r = 0; r < rows; ++r) { const double x = A[4 * r + p], y = A[4 * r + q]; app += x * x; aqq += y * y; apq += x * y; }
+                if (apq == 0.0 || std::fabs(apq) <= 1e-16 * std::sqrt(app * aqq)) continue;      // the pair is orthogonal to working precision
+                rotated = true;
+                const double th = (aqq - app) / (2.0 * apq);
                 const double tt = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0)), cs = 1.0 / std::sqrt(tt * tt + 1.0), sn = tt * cs;
-                for (int k = 0; k < 4; ++k) { const double akp = A[4 * k + p], akq = A[4 * k + q]; A[4 * k + p] = cs * akp - sn * akq; A[4 * k + q] = sn * akp + cs * akq; }
-                for (int k = 0; k < 4; ++k) { const double apk = A[4 * p + k], aqk = A[4 * q + k]; A[4 * p + k] = cs * apk - sn * aqk; A[4 * q + k] = sn * apk + cs * aqk; }
-                for (int k = 0; k < 4; ++k) { const double vkp = V[4 * k + p], vkq = V[4 * k + q]; V[4 * k + p] = cs * vkp - sn * vkq; V[4 * k + q] = sn * vkp + cs * vkq; }
+                for (int r = 0; r < rows; ++r) { const double x = A[4 * r + p], y = A[4 * r + q]; A[4 * r + p] = cs * x - sn * y; A[4 * r + q] = sn * x + cs * y; }
+                for (int k = 0; k < 4; ++k) { const double x = V[4 * k + p], y = V[4 * k + q]; V[4 * k + p] = cs * x - sn * y; V[4 * k + q] = sn * x + cs * y; }
             }
+            if (!rotated) break;
         }
+        for (int k = 0; k < 4; ++k) { double s2 = 0.0; for (int r = 0; r < rows; ++r) s2 += A[4 * r + k] * A[4 * r + k]; nrm[k] = std::sqrt(s2); }
     }
+    std::vector<double> svd_rows_;
     FeatureTrack* find(int id) { for (FeatureTrack& t : tracks_) if (t.feature_id == id) return &t; return nullptr; }
     template <class Pred> void erase_if(Pred p) { tracks_.erase(std::remove_if(tracks_.begin(), tracks_.end(), p), tracks_.end()); }
     // compensatedParallax2 (:386-417): image-plane distance between the second- and third-newest frames

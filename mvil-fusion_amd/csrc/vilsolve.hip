@@ -39,6 +39,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     bool load() {
         if (h) return true;
@@ -49,8 +50,9 @@ struct RcclApi {
         GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
         CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
         AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
+        AllGather = (decltype(AllGather))dlsym(h, "ncclAllGather");
         CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
-        return GetUniqueId && CommInitRank && AllReduce && CommDestroy;
+        return GetUniqueId && CommInitRank && AllReduce && AllGather && CommDestroy;
     }
 };
 RcclApi g_rccl;
@@ -124,7 +126,7 @@ __device__ __forceinline__ void sym_store(double* out, size_t e, int sym, double
 // non-zero on ONE rank, its owner (contiguous landmark / factor ranges, vil_shard_ranges) -- "sum over the ranks" of that part is "take the owner's value"
 // (x + 0 + ... + 0 = x: the same bits).  The library's own exchanges therefore move the camera part of every rank but only the OWNED slice of the landmark
 // arrays: per peer 103 + 380 / world kB instead of 390 kB at K = 10 / 1000 landmarks (150 kB at world = 8), and the summing kernel reads one inbox for them.
-struct OwnSeg { size_t cam; int Lp, n; int lb[9], fb[9]; };      // n = 0: a plain sum of everything (marginalisation, agreements)
+struct OwnSeg { size_t cam; int Lp, n; int lb[9], fb[9]; };      // n = 0: a plain sum of everything (agreements; RCCL beyond eight ranks)
 __device__ __forceinline__ int seg_owner(const OwnSeg& S, size_t e) {          // -1: summed over all ranks
     if (S.n == 0 || e < S.cam) return -1;
     const size_t a = e - S.cam, Lp = (size_t)S.Lp;
@@ -184,6 +186,55 @@ __global__ void k_sum_peers(double* out, PeerPtrs pp, size_t cnt, int sym, OwnSe
     }
 }
 
+// The same slim message for RCCL ("[upper(S), g, cost]", ~100 kB): the per-iteration set is PACKED into M = [lower triangle of S' | g, b_c, diag | cost]
+// (D (D + 1) / 2 + 3 D + 4 doubles, summed by ONE ncclAllReduce) and G = this rank's slice of the landmark arrays [h_ll, b_l, 1/pivot, scale | e_A | e_O], padded
+// to the largest slice (ONE ncclAllGather: a landmark's entries live on its owner only, so the sum over ranks is the owner's value -- nothing to add), and
+// UNPACKED into set 1 with both mirror images of S'.  At K = 10 / 1000 landmarks / world 8 RCCL moves 103 + 48 kB per rank instead of all-reducing 484 kB.
+// staging (doubles): [M camS | G gmax | Msum camS | Gall world x gmax]; pack / unpack do not know the transport -- the tests run them over the in-process
+// communicator with k_slim_emul standing in for the two RCCL calls (vil_debug_set_slim_emul), on 2 / 3 / 8 ranks of one device.
+struct SlimLay { int D, Lp, n, rank; size_t cam, camS, gmax, span; int lb[9], fb[9]; };
+__device__ __forceinline__ size_t slim_tri(int i, int j) { return (size_t)i * (i + 1) / 2 + j; }
+// position of set entry e (e >= cam) inside its owner's slice; *owner receives the rank
+__device__ __forceinline__ size_t slim_slot(const SlimLay& Y, size_t e, int* owner) {
+    const size_t a = e - Y.cam, Lp = (size_t)Y.Lp;
+    const bool lm = a < 17 * Lp;
+    const int v = a < 4 * Lp ? (int)(a % Lp) : (lm ? (int)((a - 4 * Lp) / 13) : (int)((a - 17 * Lp) / 6));
+    const int* b = lm ? Y.lb : Y.fb;
+    int r = 0;
+    while (r + 1 < Y.n && v >= b[r + 1]) ++r;
+    *owner = r;
+    const size_t nL = (size_t)(Y.lb[r + 1] - Y.lb[r]);
+    if (a < 4 * Lp) return (a / Lp) * nL + (size_t)(v - Y.lb[r]);
+    if (lm) return 4 * nL + (a - 4 * Lp) - 13 * (size_t)Y.lb[r];
+    return 17 * nL + (a - 17 * Lp) - 6 * (size_t)Y.fb[r];
+}
+__global__ void k_slim_pack(const double* set0, double* M, double* G, SlimLay Y) {
+    const size_t DD = (size_t)Y.D * Y.D, trin = (size_t)Y.D * (Y.D + 1) / 2;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < Y.span; e += (size_t)gridDim.x * blockDim.x) {
+        if (e < DD) { const int i = (int)(e / Y.D), j = (int)(e - (size_t)i * Y.D); if (j <= i) M[slim_tri(i, j)] = set0[e]; }
+        else if (e < Y.cam) M[trin + (e - DD)] = set0[e];
+        else { int r; const size_t g = slim_slot(Y, e, &r); if (r == Y.rank) G[g] = set0[e]; }
+    }
+}
+__global__ void k_slim_unpack(double* set1, const double* Msum, const double* Gall, SlimLay Y) {
+    const size_t DD = (size_t)Y.D * Y.D, trin = (size_t)Y.D * (Y.D + 1) / 2;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < Y.span; e += (size_t)gridDim.x * blockDim.x) {
+        double v;
+        if (e < DD) { const int i = (int)(e / Y.D), j = (int)(e - (size_t)i * Y.D); v = Msum[slim_tri(max(i, j), min(i, j))]; }
+        else if (e < Y.cam) v = Msum[trin + (e - DD)];
+        else { int r; const size_t g = slim_slot(Y, e, &r); v = Gall[(size_t)r * Y.gmax + g]; }
+        set1[e] = v;
+    }
+}
+// stand-in for ncclAllReduce(M -> Msum) + ncclAllGather(G -> Gall) over the in-process communicator (tests): pp.p[r] = rank r's staging buffer
+__global__ void k_slim_emul(double* Msum, double* Gall, PeerPtrs pp, SlimLay Y) {
+    const size_t tot = Y.camS + (size_t)pp.n * Y.gmax;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        if (e < Y.camS) { double a = 0; for (int r = 0; r < pp.n; ++r) a += pp.p[r][e]; Msum[e] = a; }
+        else { const size_t q = e - Y.camS; const int r = (int)(q / Y.gmax); Gall[q] = pp.p[r][Y.camS + (q - (size_t)r * Y.gmax)]; }
+    }
+}
+
 struct vil_ctx {
     int device = 0, rank = 0, world = 1;
     hipStream_t stream = nullptr;
@@ -201,7 +252,7 @@ struct vil_ctx {
     std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
     int n_blocks_sweep = 0, n_blocks_reduce = 0, n_blocks_reduce_po = 0, n_gather_m = 0, n_ww = 0;      // n_ww: tiles of W W^T formed by extra workgroups of k_reduce (vil_prechain.hpp)
     size_t lds_sweep = 0, lds_step = 0, lds_reduce = 0;
-    int cap_step3 = -1;                  // workgroups of the merged gather + step launch the device holds at once (vil_coop.hpp)
+    int cap_step3 = -1; size_t cap_step3_lds = 0;      // workgroups of the merged gather + step launch the device holds at once AT THAT dynamic-LDS size (vil_coop.hpp)
     int vis_gm = 0;                      // doubles of operand rows the largest visual chunk of the uploaded window needs (vil_sweep.hpp)
     size_t span = 0;               // doubles of one linear-system set (SysBuf::ar): the multi-GPU all-reduce message
     bool step_lds = false;
@@ -222,6 +273,8 @@ struct vil_ctx {
     bool has_comm() const { return comm != nullptr || lcomm != nullptr || ipc != nullptr; }
     double* lc_tmp = nullptr; size_t lc_cap = 0;
     double* ipc_tmp = nullptr;
+    double* slim_buf = nullptr; size_t slim_cap = 0; bool slim_emul = false;      // staging of the packed per-iteration message (RCCL; vil_debug_set_slim_emul)
+    bool slim() const { return own.n > 0 && world > 1 && (comm != nullptr || (slim_emul && lcomm != nullptr)); }
     bool sharded = false;          // the resident problem is this rank's shard of the factor set
     // hipGraph of a chunk of iterations, reused by repeated solves of one upload (key: chunk length, options)
     struct ChunkGraph { int n; SolveOpts so; hipGraphExec_t exec; };
@@ -238,7 +291,7 @@ struct vil_ctx {
     int lm_b = 0, lm_e = 0;        // owned landmark range
     OwnSeg own = {0, 0, 0, {0}, {0}};      // every rank's landmark / factor range in the per-iteration message (sharded windows)
     // ---- window residency across frames (vil_lidar_*, vil_set_gauge_fix, vil_marginalize_resident) --------------------------------
-    struct Slab { int np, ne, slot; };
+    struct Slab { int np, ne, slot; int np_all, ne_all; };      // np_all / ne_all: the frame's points BEFORE a communicator's slicing (the same on every rank)
     std::vector<Slab> slabs;       // window order: slab i <-> pose K - count + i
     std::vector<int> free_slots;
     int cap_p = 0, cap_e = 0, nslot = 0;      // points per slab (capacity), physical slabs
@@ -393,6 +446,7 @@ void vil_destroy(vil_ctx* c) {
     if (c->h_chtab) hipHostFree(c->h_chtab);
     if (c->chtab_ev) hipEventDestroy(c->chtab_ev);
     if (c->ipc_tmp) hipFree(c->ipc_tmp);
+    if (c->slim_buf) hipFree(c->slim_buf);
     if (c->ipc) { for (int r = 0; r < c->ipc->world; ++r) if (r != c->ipc->rank && c->ipc->peer_base[r]) hipIpcCloseMemHandle(c->ipc->peer_base[r]); if (c->ipc->base) hipFree(c->ipc->base); c->ipc.reset(); }
     if (c->d_pl) hipFree(c->d_pl);
     if (c->d_ed) hipFree(c->d_ed);
@@ -796,6 +850,9 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         P.n_edge = ne_tot; P.n_echunk = (int)ch.size() / 3; ranges(ch, K + 1);
         for (size_t q = 0; q < ch.size() / 3; ++q) if (ch[3 * q + 2] == 0) c->mm.lidar0 = true;
         put(ch.data(), 4 * ch.size(), (void**)&P.echunk);
+        // (resident slabs under a communicator: a frame with fewer points than ranks leaves some ranks' slices empty -- whether pose 0 carries LiDAR factors, and with it the
+        //  kept / dropped layout of the marginalisation every rank commits, is decided from the UNSLICED counts)
+        if (res_lidar) c->mm.lidar0 = (int)c->slabs.size() == K && c->slabs[0].np_all + c->slabs[0].ne_all > 0;
         put(nullptr, 8 * (size_t)28 * std::max(P.n_pchunk + P.n_echunk, 1), (void**)&P.lpart);
         put(lcp.data(), 4 * lcp.size(), (void**)&P.lchunk_pose);
     }
@@ -962,7 +1019,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     if (ws && P.pn) { P.px0 = ws->px0; P.pJ0 = ws->pJ0; P.pr0 = ws->pr0; P.pH = ws->pH; P.pg0 = ws->pg0; P.pc0 = ws->pc0; }      // the device prior slot, contractions included
     {   // what vil_marginalize_resident will need (a few passes over int tables)
         vil_ctx::MargMeta& mm = c->mm;
-        const vil_problem* const lp = p;                  // this rank's shard (LiDAR points of pose 0: any rank's slice of a frame is non-empty when the frame is)
+        const vil_problem* const lp = p;                  // this rank's shard (LiDAR points of pose 0 of a resident window: from the unsliced slab counts, above)
         if (gp) p = gp;                                    // which blocks the collected factors touch is a property of the WHOLE window, the same on every rank
         mm.has_prior = p->prior.n > 0; mm.prior_kind.clear(); mm.prior_index.clear();
         if (mm.has_prior) { mm.prior_kind.assign(p->prior.blk_kind, p->prior.blk_kind + p->prior.nblk); mm.prior_index.assign(p->prior.blk_index, p->prior.blk_index + p->prior.nblk); }
@@ -1042,7 +1099,9 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             // the merged launch holds workgroups that spin on flags (master, helpers, one per W W^T tile) next to the finite ones they wait for (chain,
             // gather: lower block indices, dispatched first).  It is only taken when the device can hold every spinning workgroup AND one more at the
             // same time -- otherwise the waiters could occupy every slot before the last gather workgroup has found one (vil_coop.hpp)
-            if (c->cap_step3 < 0) c->cap_step3 = vilcoop::capacity((const void*)k_step<true, 3>, VIL_STEP_THREADS, std::max(lds3, ldsc), c->device);
+            // (keyed by the LDS size: 42 kB at K = 10 is three workgroups per compute unit, 95 kB at K = 20 one -- a context that uploads a small window first must not check a large one against the small one's capacity)
+            const size_t ldsm = std::max(lds3, ldsc);
+            if (c->cap_step3 < 0 || c->cap_step3_lds != ldsm) { c->cap_step3 = vilcoop::capacity((const void*)k_step<true, 3>, VIL_STEP_THREADS, ldsm, c->device); c->cap_step3_lds = ldsm; }
             const int Tw = (int)(Tp_ * (Tp_ + 1) / 2);
             if (c->cap_step3 < 1 + P.n_help + Tw + 2) merged = false;
         }
@@ -1181,8 +1240,53 @@ static int ipc_all_reduce(vil_ctx* c, const double* send, double* recv, size_t c
     hipLaunchKernelGGL(k_ipc_sum, dim3(nb), dim3(256), 0, c->stream, recv, cnt, I, sym, seg);
     return VIL_OK;
 }
+static SlimLay slim_layout(const vil_ctx* c) {
+    SlimLay Y; memset(&Y, 0, sizeof Y);
+    const OwnSeg& S = c->own;
+    Y.D = c->D; Y.Lp = S.Lp; Y.n = S.n; Y.rank = c->rank; Y.cam = S.cam; Y.span = c->span;
+    Y.camS = ((size_t)Y.D * (Y.D + 1) / 2 + (S.cam - (size_t)Y.D * Y.D) + 1) & ~size_t(1);
+    for (int r = 0; r <= S.n; ++r) { Y.lb[r] = S.lb[r]; Y.fb[r] = S.fb[r]; }
+    for (int r = 0; r < S.n; ++r) Y.gmax = std::max(Y.gmax, (size_t)17 * (S.lb[r + 1] - S.lb[r]) + (size_t)6 * (S.fb[r + 1] - S.fb[r]));
+    Y.gmax = (Y.gmax + 2) & ~size_t(1);
+    return Y;
+}
+// the per-iteration collective as a packed message: pack -> all-reduce of M + all-gather of the owners' slices -> unpack (see SlimLay)
+static int slim_all_reduce(vil_ctx* c, const double* send, double* recv) {
+    const SlimLay Y = slim_layout(c);
+    const size_t need = 2 * Y.camS + (size_t)(1 + c->world) * Y.gmax;
+    LocalComm* lc = c->comm ? nullptr : c->lcomm.get();
+    int st = VIL_OK;
+    if (need > c->slim_cap) {
+        if (c->slim_buf) hipFree(c->slim_buf);
+        c->slim_buf = nullptr; c->slim_cap = 0;
+        if (hipMalloc(&c->slim_buf, 8 * need) == hipSuccess) { c->slim_cap = need; if (hipMemsetAsync(c->slim_buf, 0, 8 * need, c->stream) != hipSuccess) st = VIL_ERR_DEVICE; }
+        else st = VIL_ERR_DEVICE;
+        if (st != VIL_OK && !lc) return st;          // (in-process ranks carry a failure to the agreement point below)
+    }
+    double* M = c->slim_buf; double* G = M + Y.camS; double* Msum = G + Y.gmax; double* Gall = Msum + Y.camS;
+    const unsigned nb = (unsigned)std::min<size_t>(256, (Y.span + 255) / 256);
+    if (st == VIL_OK) hipLaunchKernelGGL(k_slim_pack, dim3(nb), dim3(256), 0, c->stream, send, M, G, Y);
+    if (!lc) {
+        if (g_rccl.AllReduce(M, Msum, Y.camS, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return VIL_ERR_COMM;
+        if (g_rccl.AllGather(G, Gall, Y.gmax, ncclDouble, c->comm, c->stream) != ncclSuccess) return VIL_ERR_COMM;
+    } else {
+        if (hipStreamSynchronize(c->stream) != hipSuccess) st = VIL_ERR_DEVICE;
+        lc->ptr[c->rank] = c->slim_buf;
+        st = lc->agree(c->rank, st);                          // every rank's M and G are complete and published
+        if (st != VIL_OK) return st;
+        PeerPtrs pp; pp.n = lc->n;
+        for (int r = 0; r < 8; ++r) pp.p[r] = r < lc->n ? lc->ptr[r] : nullptr;
+        hipLaunchKernelGGL(k_slim_emul, dim3(nb), dim3(256), 0, c->stream, Msum, Gall, pp, Y);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) st = VIL_ERR_DEVICE;
+        st = lc->agree(c->rank, st);                          // every rank has read every staging buffer
+        if (st != VIL_OK) return st;
+    }
+    hipLaunchKernelGGL(k_slim_unpack, dim3(nb), dim3(256), 0, c->stream, recv, (const double*)Msum, (const double*)Gall, Y);
+    return VIL_OK;
+}
 static int all_reduce2(vil_ctx* c, const double* send, double* recv, size_t cnt, int sym = 0, const OwnSeg& seg = kNoSeg) {
     if (c->ipc) return ipc_all_reduce(c, send, recv, cnt, sym, seg);
+    if (seg.n > 0 && sym > 0 && cnt == c->span && c->slim()) return slim_all_reduce(c, send, recv);
     if (c->comm) return g_rccl.AllReduce(send, recv, cnt, ncclDouble, ncclSum, c->comm, c->stream) == ncclSuccess ? VIL_OK : VIL_ERR_COMM;
     if (c->lcomm) {
         LocalComm* lc = c->lcomm.get();
@@ -1357,11 +1461,11 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     const SolveOpts so = to_dev_opts(o);
     c->mirror_state = false;
     // the step kernel's master, helpers and (merged launch) tile workgroups wait for one another inside a launch: like the other persistent kernels of
-    // the library a solve holds the process-wide gate until its result has arrived, so that it never shares the device with a half-resident
-    // k_pose_solve / k_vgicp_align of another thread (vil_coop.hpp).  Not taken by the ranks of an in-process communicator: they wait for EACH OTHER's
-    // launches, one host thread per rank.
-    std::unique_lock<std::mutex> coop_lock(vilcoop::gate(), std::defer_lock);
-    if (!(c->split && c->lcomm != nullptr)) coop_lock.lock();
+    // the library a solve holds its device's gate until its result has arrived, so that it never shares the device with a half-resident
+    // k_pose_solve / k_vgicp_align of another thread (vil_coop.hpp).  Not taken by the ranks of a communicator (in-process, peer buffers, RCCL): they wait
+    // for EACH OTHER's launches inside the per-iteration collective -- two ranks driven from threads of one process would deadlock on it.
+    std::unique_lock<std::mutex> coop_lock(vilcoop::gate(c->device), std::defer_lock);
+    if (!c->split) coop_lock.lock();
     if ((c->P.gauge_on != 0) != c->gauge_on) {            // vil_set_gauge_fix since the upload: the captured graphs carry the old flag
         c->P.gauge_on = c->gauge_on ? 1 : 0;
         for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
@@ -1885,13 +1989,16 @@ int vil_comm_message_bytes(vil_ctx* c, int64_t* bytes_per_peer, int64_t* bytes_f
     size_t own = 0;
     if (S.n > 0) own = (size_t)17 * (S.lb[c->rank + 1] - S.lb[c->rank]) + (size_t)6 * (S.fb[c->rank + 1] - S.fb[c->rank]);
     else own = c->span - S.cam;
-    if (bytes_per_peer) *bytes_per_peer = (int64_t)(8 * (cam_sent + own));
+    if (c->slim()) { const SlimLay Y = slim_layout(c); if (bytes_per_peer) *bytes_per_peer = (int64_t)(8 * (Y.camS + Y.gmax)); }      // RCCL: M all-reduced + this rank's padded slice all-gathered
+    else if (c->comm && c->world > 1) { if (bytes_per_peer) *bytes_per_peer = (int64_t)(8 * c->span); }      // RCCL beyond eight ranks: the whole set is all-reduced
+    else if (bytes_per_peer) *bytes_per_peer = (int64_t)(8 * (cam_sent + own));
     if (bytes_full_set) *bytes_full_set = (int64_t)(8 * c->span);
     return VIL_OK;
 }
 
 // ---- window residency across frames (include/vilsolve.h) ------------------------------------------------------------------------
 int vil_debug_set_launch_mode(vil_ctx* c, int32_t mode) { if (!c || mode < 0 || mode > 2) return VIL_ERR_INVALID_ARGUMENT; c->launch_mode = mode; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
+int vil_debug_set_slim_emul(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->slim_emul = on != 0; return VIL_OK; }
 int vil_debug_set_split(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->force_split = on != 0; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
 int vil_set_gauge_fix(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->gauge_on = on != 0; return VIL_OK; }      // (takes effect in the next solve)
 
@@ -1919,6 +2026,7 @@ int vil_lidar_drop(vil_ctx* c, int32_t slab) {
 int vil_lidar_push(vil_ctx* c, int32_t n_plane, const double* plane_const, int32_t n_edge, const double* edge_const) {
     if (!c || n_plane < 0 || n_edge < 0 || (n_plane > 0 && !plane_const) || (n_edge > 0 && !edge_const)) return VIL_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(c->device));
+    const int np_all = n_plane, ne_all = n_edge;
     if (c->world > 1 && c->has_comm()) {       // factor set sharded over ranks: every rank is handed the whole frame and keeps its contiguous slice
         const int pb = (int)((long long)n_plane * c->rank / c->world), pe = (int)((long long)n_plane * (c->rank + 1) / c->world);
         const int eb = (int)((long long)n_edge * c->rank / c->world), ee = (int)((long long)n_edge * (c->rank + 1) / c->world);
@@ -1964,7 +2072,7 @@ int vil_lidar_push(vil_ctx* c, int32_t n_plane, const double* plane_const, int32
         if (n_plane) hipLaunchKernelGGL(k_aos2soa, dim3((n_plane + 255) / 256), dim3(256), 0, c->stream, c->d_lstage, n_plane, 7, c->d_pl + (size_t)slot * c->cap_p, (size_t)c->nslot * c->cap_p);
         if (n_edge) hipLaunchKernelGGL(k_aos2soa, dim3((n_edge + 255) / 256), dim3(256), 0, c->stream, c->d_lstage + (size_t)7 * n_plane, n_edge, 9, c->d_ed + (size_t)slot * c->cap_e, (size_t)c->nslot * c->cap_e);
     }
-    c->slabs.push_back({n_plane, n_edge, slot});
+    c->slabs.push_back({n_plane, n_edge, slot, np_all, ne_all});
     if (c->lidar_resident) { c->uploaded = false; c->resident_kind = 0; }      // (a recycled slot would feed this frame's points to the old pose)
     return VIL_OK;
 }

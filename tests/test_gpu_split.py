@@ -55,10 +55,25 @@ import oracle_lib
 orc = oracle_lib.open_oracle()
 pf = lambda pre: orc.marginalize(pre).to_prior()
 full = os.environ.get("SHARD_FULL") == "1"
+def shard_bounds(w, world):
+    """(landmark range, factor range) of every rank: vil_shard_ranges through the C-ABI"""
+    be0 = lib.open_vilsolve(); out = []
+    p = w.c_problem()
+    for r in range(world):
+        v = [C.c_int32(0) for _ in range(6)]
+        assert be0.lib.vil_shard_ranges(C.byref(p), r, world, *[C.byref(x) for x in v]) == 0
+        lb0, lb1 = v[0].value, v[1].value
+        f0 = int(np.searchsorted(w.vis_l, lb0, "left")); f1 = int(np.searchsorted(w.vis_l, lb1, "left"))
+        out.append((lb0, lb1, f0, f1))
+    be0.close()
+    return out
 for world in ((8,) if full else (2, 3)):
     bes = [lib.open_vilsolve() for _ in range(world)]
     arr = (C.c_void_p * world)(*[b.ctx for b in bes])
     assert bes[0].lib.vil_comm_init_local(arr, world) == 0
+    slim = os.environ.get("SHARD_SLIM") == "1"          # the RCCL path's pack -> all-reduce + all-gather -> unpack, the two RCCL calls emulated in process
+    if slim:
+        for b in bes: assert b.lib.vil_debug_set_slim_emul(b.ctx, 1) == 0
     for cid, kw in (((3, {}), (2, {})) if full else ((2, dict(L=150, n_plane=3000, n_edge=800)), (1, {}))):
         wo = synth.make_config(cid, prior_fn=pf, **kw)
         if full and cid == 3: assert (wo.K, wo.L, len(wo.plane_pose) + len(wo.edge_pose)) == (10, 4000, 120000)     # BASELINE.json configs[2]
@@ -97,6 +112,9 @@ for world in ((8,) if full else (2, 3)):
             D = 15 * wo.K + 7; cam = 8 * (D * (D + 1) // 2 + 3 * D + 4); lmk = 8 * (17 * wo.L + 6 * len(wo.vis_i))
             assert cam <= mb.value <= cam + 1.6 * lmk / world + 1024 and fb.value >= 8 * D * D + lmk, (world, r, mb.value, fb.value)
             if full and cid == 2: assert mb.value <= 160 * 1024, mb.value            # configs[1] on 8 ranks: ~150 kB per peer (484 kB as one all-reduced set)
+            if slim:      # what RCCL moves per rank: the packed camera part (all-reduce) + the largest owner slice (all-gather)
+                own = [17 * (lb1 - lb0) + 6 * (fb1 - fb0) for (lb0, lb1, fb0, fb1) in shard_bounds(wo, world)]
+                assert mb.value == 8 * (((D * (D + 1) // 2 + 3 * D + 4 + 1) // 2) * 2 + ((max(own) + 2) // 2) * 2), (mb.value, D, max(own))
         # sharded marginalisation (SURVEY 8e last row): the collected factors dealt to the ranks, A / b all-reduced once, the small dense part on
         # every rank -- equal to the un-sharded marginal of the same (solved) window, bit-identical across ranks
         if wo.prior.n and not full:
@@ -238,10 +256,14 @@ def test_resident_window_under_a_communicator():
     assert "WINDOW_SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-def test_sharded_solve_local_communicator():
+@pytest.mark.parametrize("slim", ["0", "1"])
+def test_sharded_solve_local_communicator(slim):
     """2 and 3 ranks of the factor-sharded solve on ONE device through the in-process communicator: the shard ranges,
-    ranks without IMU / prior factors, the split step, the scalar reduction and the landmark merge all run as on N GPUs."""
-    out = subprocess.run([sys.executable, "-c", SHARD_SCRIPT % (ROOT, ROOT)], capture_output=True, text=True, timeout=900)
+    ranks without IMU / prior factors, the split step, the scalar reduction and the landmark merge all run as on N GPUs.
+    slim = 1: the RCCL path's packed message (one all-reduce of [lower(S') | vectors | cost] + one all-gather of the owners' landmark
+    slices; include/vilsolve.h) with the two RCCL calls emulated over the same communicator."""
+    env = dict(os.environ, SHARD_SLIM=slim)
+    out = subprocess.run([sys.executable, "-c", SHARD_SCRIPT % (ROOT, ROOT)], env=env, capture_output=True, text=True, timeout=900)
     assert "SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
@@ -249,7 +271,7 @@ def test_sharded_full_size_8_ranks():
     """BASELINE.json configs[2] (K = 10, L = 4000, 120 k LiDAR points) and configs[1] at FULL size as an 8-rank factor-sharded
     solve -- eight contexts, eight host threads, the in-process communicator on one device: every rank bit-identical, equal to
     the oracle and to the un-sharded solve."""
-    env = dict(os.environ, SHARD_FULL="1")
+    env = dict(os.environ, SHARD_FULL="1", SHARD_SLIM="1")      # (the packed message of the RCCL path; the plain in-process exchange runs at 2 / 3 ranks above)
     out = subprocess.run([sys.executable, "-c", SHARD_SCRIPT % (ROOT, ROOT)], env=env, capture_output=True, text=True, timeout=1500)
     assert "SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 

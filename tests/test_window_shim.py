@@ -335,3 +335,89 @@ def test_resident_window_tables_of_the_shim():
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
         out = subprocess.check_output([exe], text=True)
     assert "WINTAB 0" in out, out
+
+
+TRI = r'''
+#include <cstdio>
+#include "vilwindow_shim.hpp"
+extern "C" void vil_prior_capacity(int, int*, int*, int*) {}
+extern "C" int vpre_integrate(vpre_ctx*, int32_t, const int32_t*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*) { return -1; }
+int main(int argc, char** argv) {
+    // stdin: W n_tracks, poses (W + 1) x 7, ex 7, then per track: start nobs, nobs x [x y z]
+    int W, n; if (std::scanf("%d %d", &W, &n) != 2) return 1;
+    std::vector<double> pose(7 * (W + 1)), ex(7);
+    for (double& v : pose) if (std::scanf("%lf", &v) != 1) return 1;
+    for (double& v : ex) if (std::scanf("%lf", &v) != 1) return 1;
+    std::vector<int> start(n), nobs(n); std::vector<std::vector<double>> pts(n);
+    for (int t = 0; t < n; ++t) { if (std::scanf("%d %d", &start[t], &nobs[t]) != 2) return 1; pts[t].resize(3 * nobs[t]); for (double& v : pts[t]) if (std::scanf("%lf", &v) != 1) return 1; }
+    vil::FeatureTable ft(W, 5.0, 10.0 / 460.0);
+    for (int fc = 0; fc <= W; ++fc) {
+        std::vector<int> ids; std::vector<double> obs;
+        for (int t = 0; t < n; ++t) { const int q = fc - start[t]; if (q < 0 || q >= nobs[t]) continue; ids.push_back(t); const double o[8] = {pts[t][3 * q], pts[t][3 * q + 1], pts[t][3 * q + 2], 0, 0, 0, 0, -1.0}; obs.insert(obs.end(), o, o + 8); }
+        ft.add_frame(fc, ids.data(), obs.data(), (int)ids.size(), 0.0);
+    }
+    ft.triangulate(pose.data(), ex.data());
+    for (const vil::FeatureTrack& t : ft.tracks()) std::printf("%d %.17g\n", t.feature_id, t.estimated_depth);
+    return 0;
+}
+'''
+
+
+def test_triangulate_matches_svd_including_low_parallax_tracks():
+    """FeatureTable::triangulate (feature_manager.cpp:214-273) against numpy's SVD of the same stacked rows: ordinary tracks, tracks whose
+    baseline is 1e-7 of their depth (sigma_min / sigma_max ~ 1e-8: an eigen-decomposition of A^T A loses the null direction there, the one-sided
+    Jacobi SVD of the shim must not) and points behind the anchor camera (negative depth -> INIT_DEPTH)."""
+    rng = np.random.default_rng(5)
+    W, INIT = 8, 5.0
+    def q2R(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    ex = np.concatenate([[0.05, -0.02, 0.1], [0.01, -0.02, 0.015, 1.0]]); ex[3:] /= np.linalg.norm(ex[3:])
+    tracks = []
+    for kind, scale in (("wide", 0.3), ("narrow", 3e-7), ("behind", 0.3)):
+        poses = np.zeros((W + 1, 7))
+        for k in range(W + 1):
+            q = np.concatenate([0.02 * rng.standard_normal(3) * (scale > 1e-3), [1.0]]); q /= np.linalg.norm(q)
+            poses[k] = np.concatenate([scale * np.array([k, 0.3 * np.sin(k), 0.1 * k]) + 0.0, q])
+        tracks.append((kind, poses))
+    # one table per pose set (the poses are per call): run the harness three times
+    for kind, poses in tracks:
+        Ric, tic = q2R(ex[3:]), ex[:3]
+        cam = [(q2R(p[3:]) @ Ric, p[:3] + q2R(p[3:]) @ tic) for p in poses]
+        items, lines = [], ["%d %d" % (W, 24)]
+        lines.append(" ".join("%.17g" % v for v in poses.ravel())); lines.append(" ".join("%.17g" % v for v in ex))
+        for t in range(24):
+            start = int(rng.integers(0, W - 3)); nobs = int(rng.integers(2, W + 1 - start + 1))
+            R0, t0 = cam[start]
+            depth = rng.uniform(2.0, 12.0) * (-1.0 if kind == "behind" and t % 2 else 1.0)
+            Xw = R0 @ (np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3), 1.0]) * depth) + t0
+            obs = []
+            for m in range(nobs):
+                R1, t1 = cam[start + m]
+                pc = R1.T @ (Xw - t1)
+                pc = pc / pc[2] + np.array([1e-9 * rng.standard_normal(), 1e-9 * rng.standard_normal(), 0.0]) * (kind != "narrow")
+                obs.append(pc)
+            items.append((start, obs))
+            lines.append("%d %d " % (start, nobs) + " ".join("%.17g" % v for o in obs for v in o))
+        exe = _build(TRI)
+        out = subprocess.run([exe], input="\n".join(lines), capture_output=True, text=True, check=True).stdout.strip().split("\n")
+        got = {int(l.split()[0]): float(l.split()[1]) for l in out}
+        n_checked = n_init = 0
+        for t, (start, obs) in enumerate(items):
+            if not (len(obs) >= 2 and start < W - 2):
+                assert got[t] == -1.0; continue
+            R0, t0 = cam[start]; rows = []
+            for m, pt in enumerate(obs):
+                R1, t1 = cam[start + m]
+                R = R0.T @ R1; tt = R0.T @ (t1 - t0)
+                P = np.hstack([R.T, (-R.T @ tt)[:, None]]); f = pt / np.linalg.norm(pt)
+                rows.append(f[0] * P[2] - f[2] * P[0]); rows.append(f[1] * P[2] - f[2] * P[1])
+            sv = np.linalg.svd(np.array(rows))
+            V = sv[2][-1]; d = V[2] / V[3]
+            want = INIT if d < 0 else d
+            n_init += want == INIT; n_checked += 1
+            # the null direction is determined to ~eps * sigma_max / (sigma_3 - sigma_4); the depth quotient inherits that
+            tol = 1e-9 if kind != "narrow" else 64 * 2.2e-16 * sv[1][0] / max(sv[1][2] - sv[1][3], 1e-300) * max(1.0, abs(d))
+            assert abs(got[t] - want) <= tol * max(1.0, abs(want)), (kind, t, got[t], want, sv[1])
+        assert n_checked >= 10
+        if kind == "behind": assert n_init >= 3
