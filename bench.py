@@ -20,6 +20,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
+# the reference's solver limits on the replay configuration: config/mynteye_leishen_indoor.yaml:76-77 -> estimator.cpp:1404 (max_num_iterations), :1411 (max_solver_time_in_seconds)
+REF_MAX_ITERATIONS, REF_MAX_TIME_S = 30, 0.05
+
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -203,12 +206,12 @@ def tracker_leg(lib, abi, device, n_images=48, warm=6):
     import torch
     from mvil_fusion_amd import replay
     be = lib.open_vilsolve(device=device)
-    rp = replay.Replay(K=10, n_frames=n_images + warm + 14, L=1000, n_plane=24000, n_edge=6000, seed=20240605, max_iterations=8)
+    rp = replay.Replay(K=10, n_frames=n_images + warm + 14, L=1000, n_plane=24000, n_edge=6000, seed=20240605, max_iterations=REF_MAX_ITERATIONS, max_time_s=REF_MAX_TIME_S)
     K = rp.K
     be.set_gauge_fix(True); be.win_open(**rp.win_open_args())
     for k in range(K):
         be.win_push_frame(rp.win_frame(k))
-    its, el, up_bytes = 0, 0.0, 0
+    its, el, up_bytes, capped = 0, 0.0, 0, 0
     for step in range(n_images + warm):
         flag = rp.margin_flag()
         w = rp.win_window()
@@ -223,13 +226,15 @@ def tracker_leg(lib, abi, device, n_images=48, warm=6):
         t4 = time.perf_counter(); be.win_push_frame(fr); t5 = time.perf_counter()
         if step >= warm:
             its += sg.iterations; el += (t1 - t0) + (t3 - t2) + (t5 - t4)
+            capped += sg.termination in (abi.TERM_NAMES.index("max_iterations"), abi.TERM_NAMES.index("max_time"))
             up_bytes += 8 * (7 * len(fr["dt"]) + 12 + 8 * len(fr["obs"]) + 7 * len(fr["plane"]) + 9 * len(fr["edge"])) + 4 * len(fr["obs_track"]) + 8 * (16 * K + 8 + w.L) + 13 * w.L
     be.close()
     n = max(1, step + 1 - warm)
     return {"value": its / el, "unit": "iterations/s", "ms_per_image": 1e3 * el / n, "images": n, "iterations_per_image": its / n,
+            "share_of_images_ended_by_a_cap": capped / n, "caps": {"max_iterations": REF_MAX_ITERATIONS, "max_time_s": REF_MAX_TIME_S},
             "host_to_device_bytes_per_image": int(up_bytes / n),
             "what": "fully resident window (vil_win_*) on a tracker-driven sequence of configs[1]-shaped windows: per image the new frame (IMU samples, observations, 3000 LiDAR points) and "
-                    "the window's small tables + state go up, the solved state comes back; timed = vil_win_push_frame + vil_win_drop_frame + vil_win_solve, max 8 iterations per image (yaml)"}
+                    "the window's small tables + state go up, the solved state comes back; timed = vil_win_push_frame + vil_win_drop_frame + vil_win_solve; solver limits = the reference's yaml (max_num_iterations 30, max_solver_time 0.05 s)"}
 
 
 def replay_mode(args, be, abi, lib):
@@ -240,13 +245,17 @@ def replay_mode(args, be, abi, lib):
     import torch
     from mvil_fusion_amd import replay
     from mvil_fusion_amd.abi import Window
-    rp = replay.Replay(K=10, n_frames=args.replay + 10, L=1000, n_plane=24000, n_edge=6000, seed=20240605, max_iterations=8)
+    cap_it, cap_t = (8, 0.0) if args.cap8 else (REF_MAX_ITERATIONS, REF_MAX_TIME_S)      # --cap8: the short-cap variant of rounds 1-4 (NOT the reference's configuration)
+    rp = replay.Replay(K=10, n_frames=args.replay + 10, L=1000, n_plane=24000, n_edge=6000, seed=20240605, max_iterations=cap_it, max_time_s=cap_t)
     rp.opts.precision = args.precision
     orc = None
     if not args.no_cpu:
         so_path = os.path.join(ROOT, "oracle", "liboracle.so")
         orc = lib.Backend(C.CDLL(so_path), "orc_")
-    opts_cpu = abi.default_options(max_iterations=8)
+    # CPU leg: the same iteration cap WITHOUT the wall-clock cap, so that it reproduces the device's solve (state difference) -- how many of its solves the
+    # reference's 50 ms cap would have cut short on this host is reported beside it (cpu_solves_over_the_time_cap)
+    opts_cpu = abi.default_options(max_iterations=cap_it)
+    terms = []
     g_solve, g_marg, g_slide, g_period, c_solve, c_marg, dpos, its, Ls, nvis = [], [], [], [], [], [], [], [], [], []
     mode = "classic" if args.classic else ("slabs" if args.slabs else "window")
     K = rp.K
@@ -287,7 +296,7 @@ def replay_mode(args, be, abi, lib):
             p0 = w.pose[0].copy()
             t0 = time.perf_counter(); sg = be.solve(w, rp.opts); be.gauge_fix(p0, w); t1 = time.perf_counter()
             pg = be.marginalize(w, flag, w._icp_marg, w._lps_marg, rp.opts); t2 = time.perf_counter()
-        g_solve.append(1e3 * (t1 - t0)); g_marg.append(1e3 * (t2 - t1)); its.append(sg.iterations); Ls.append(w.L); nvis.append(len(w.vis_i))
+        g_solve.append(1e3 * (t1 - t0)); g_marg.append(1e3 * (t2 - t1)); its.append(sg.iterations); Ls.append(w.L); nvis.append(len(w.vis_i)); terms.append(int(sg.termination))
         if orc is not None:
             t0 = time.perf_counter(); orc.solve(wo, opts_cpu); orc.gauge_fix(p0, wo); t1 = time.perf_counter()
             orc.marginalize(wo, flag, w._icp_marg, w._lps_marg, opts_cpu); t2 = time.perf_counter()
@@ -322,8 +331,11 @@ def replay_mode(args, be, abi, lib):
     out = {"metric": "per-frame backend latency, synthetic replay (solve + gauge fix + marginalisation, host buffers in, host buffers out)",
            "value": float(np.median(tot_g)), "unit": "ms/frame", "higher_is_better": False, "n_gpus": 1, "frames": len(g_solve), "dtype": "f64" if args.precision == 0 else "f32 eval / f64 accumulate",
            "data": "synthetic replay (3indoor.bag unavailable offline)",
-           "config": {"workload": "BASELINE.json configs[4] substitute: K=10, ~%d landmarks / ~%d visual factors per window, 30000 LiDAR points, max 8 iterations, every 5th image a non-keyframe (MARGIN_SECOND_NEW)" % (int(np.mean(Ls)), int(np.mean(nvis))),
-                      "iterations_per_frame": float(np.mean(its))},
+           "config": {"workload": "BASELINE.json configs[4] substitute: K=10, ~%d landmarks / ~%d visual factors per window, 30000 LiDAR points, every 5th image a non-keyframe (MARGIN_SECOND_NEW)" % (int(np.mean(Ls)), int(np.mean(nvis))),
+                      "solver_limits": {"max_iterations": cap_it, "max_time_s": cap_t, "source": "short-cap variant (--cap8), not the reference's configuration" if args.cap8 else "config/mynteye_leishen_indoor.yaml:76-77 (estimator.cpp:1404,1411)"},
+                      "iterations_per_frame": float(np.mean(its)), "iterations_per_frame_max": int(max(its)),
+                      "share_of_frames_ended_by_max_iterations": float(np.mean(np.array(terms) == abi.TERM_NAMES.index("max_iterations"))),
+                      "share_of_frames_ended_by_max_time": float(np.mean(np.array(terms) == abi.TERM_NAMES.index("max_time")))},
            "gpu": {"solve_ms": st(g_solve), "marg_ms": st(g_marg), "total_ms": st(tot_g), "note": "includes H2D upload of the window and D2H of the state / prior (PCIe-inclusive)",
                    "mode": {"window": "fully resident window (vil_win_*): observations, IMU samples / records, LiDAR points and the prior stay in HBM; per image the new frame (IMU samples pre-integrated on the device, observations, LiDAR points: slide_push_ms) and the window's small tables go up, the state comes back through pinned memory; the marginalisation is enqueued (marg_ms = the call) and its prior is written device-to-device -- its GPU time is inside the NEXT image's solve_ms",
                             "slabs": "round-2 residency: LiDAR frame slabs stay in HBM, gauge fix on the device, vil_marginalize_resident; visual / IMU tables, state and prior travel every image",
@@ -339,7 +351,9 @@ def replay_mode(args, be, abi, lib):
     if orc is not None:
         tot_c = np.array(c_solve) + np.array(c_marg)
         out["cpu_baseline"] = {"solve_ms": st(c_solve), "marg_ms": st(c_marg), "total_ms": st(tot_c), "cores": 4, "kind": "port",
-                               "note": "CPU restatement on the same input windows; solve single-threaded, marginalisation 4 threads (marginalization_factor.h:13)"}
+                               "cpu_solves_over_the_time_cap": float(np.mean(np.array(c_solve) > 1e3 * cap_t)) if cap_t > 0 else None,
+                               "note": "CPU restatement on the same input windows, same iteration cap, NO wall-clock cap (it has to reproduce the device's solve for the state difference; "
+                                       "cpu_solves_over_the_time_cap = share of its solves the reference's 0.05 s limit would have ended early on this host); solve single-threaded, marginalisation 4 threads (marginalization_factor.h:13)"}
         out["speedup_vs_cpu_baseline"] = float(np.median(tot_c) / np.median(tot_g))
         out["max_abs_position_difference_m"] = float(max(dpos))
     emit(out)
@@ -550,6 +564,7 @@ def main():
     ap.add_argument("--replay", type=int, default=0, help="config 5: run N images of the synthetic replay and report per-frame latency instead of the headline metric")
     ap.add_argument("--no-cfg3", dest="no_cfg3", action="store_true", help="skip the extra configs[2] (K=10, L=4000, 120k points) leg")
     ap.add_argument("--no-tracker", dest="no_tracker", action="store_true", help="skip the PCIe-inclusive tracker legs (counter passes: their configs[1]-shaped windows launch the same kernels as the window under test)")
+    ap.add_argument("--cap8", action="store_true", help="replay mode: the short-cap variant of earlier rounds (8 iterations, no time cap) instead of the reference's limits (30 iterations / 0.05 s)")
     ap.add_argument("--classic", action="store_true", help="replay mode: hand every table over on every image (vil_solve + vil_gauge_fix + vil_marginalize) instead of the resident-window entry points")
     ap.add_argument("--slabs", action="store_true", help="replay mode: round-2 residency (LiDAR frame slabs + vil_marginalize_resident) instead of the fully resident window (vil_win_*)")
     ap.add_argument("--precision", type=int, default=0, help="0 = fp64 (reference arithmetic), 1 = fp32 factor evaluation with fp64 accumulation (replay mode only)")
@@ -566,14 +581,36 @@ def main():
     ap.add_argument("--ipc", action="store_true", help="N>1: the library's peer-buffer exchange (IPC-mapped inboxes over xGMI, vil_comm_ipc_*) instead of RCCL for the per-iteration collective")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher -- one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1
+        # (what the driver's own `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` command line does)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" in os.environ and args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     import torch
     dist = None
+    cdev = "cuda"          # where the tensors of the harness's own exchanges live (handles, timings)
+    n_dev = torch.cuda.device_count()
+    oversub = world > max(1, n_dev)      # more ranks than devices (the one-device test of the N > 1 path): ranks share devices, RCCL cannot (one rank per GPU) -> gloo + peer buffers
+    local = local % max(1, n_dev)
     if world > 1 or args.force_comm:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if oversub:
+            if not (args.ipc or args.replicas):
+                raise SystemExit("bench.py: %d ranks on %d device(s) needs --ipc or --replicas (RCCL wants one GPU per rank)" % (world, n_dev))
+            cdev = "cpu"
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     graft.load_package()
     from mvil_fusion_amd import abi, lib, synth
     if not os.path.exists(lib.LIB_PATH) or not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
@@ -606,13 +643,13 @@ def main():
         h = (C.c_char * 64)()
         fexp = be.lib.vil_comm_ipc_export; fexp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
         st = fexp(be.ctx, rank, world, 1 << 19, h)
-        mine = torch.frombuffer(bytearray(bytes(h)), dtype=torch.uint8).cuda()
-        allh = [torch.zeros(64, dtype=torch.uint8, device="cuda") for _ in range(world)]
+        mine = torch.frombuffer(bytearray(bytes(h)), dtype=torch.uint8).to(cdev)
+        allh = [torch.zeros(64, dtype=torch.uint8, device=cdev) for _ in range(world)]
         dist.all_gather(allh, mine)
         blob = b"".join(bytes(t.cpu().numpy().tobytes()) for t in allh)
         if st == 0:
             st = be.lib.vil_comm_ipc_init(be.ctx, (C.c_char * len(blob)).from_buffer_copy(blob))
-        good = torch.tensor([1 if st == 0 else 0], device="cuda", dtype=torch.int32)
+        good = torch.tensor([1 if st == 0 else 0], device=cdev, dtype=torch.int32)
         dist.all_reduce(good, op=dist.ReduceOp.MIN)
         if int(good[0]) == 1:
             sharded = True
@@ -644,6 +681,19 @@ def main():
             be.close()
             be = lib.open_vilsolve(device=local, rank=0, world=1)
 
+    # what the LIBRARY's communicator says it spans (not what the launcher hoped for): asserted, and printed in the JSON line
+    comm_info = None
+    if dist is not None:
+        cr, cw, ctp = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+        be.lib.vil_comm_info(be.ctx, C.byref(cr), C.byref(cw), C.byref(ctp))
+        mine = torch.tensor([cr.value, cw.value, ctp.value, local], device=cdev, dtype=torch.int32)
+        alli = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(alli, mine)
+        rows = [[int(v) for v in t_.cpu()] for t_ in alli]
+        if sharded and not all(r_[0] == q and r_[1] == world for q, r_ in enumerate(rows)):
+            raise SystemExit("bench.py: the library's communicator does not span the %d ranks the launcher started: %r" % (world, rows))
+        comm_info = {"columns": ["rank", "world", "transport (0 none, 1 RCCL, 2 in-process, 3 peer buffers)", "device"], "per_rank": rows,
+                     "ranks_seen_by_the_library": rows[0][1] if sharded else 1, "devices_visible": n_dev, "harness_backend": "gloo" if cdev == "cpu" else "nccl"}
     got_prior = {"lib": False}
 
     def gpu_prior(pre):
@@ -704,14 +754,14 @@ def main():
     if dist is not None and prof.sweep_launches > 0:
         n_it = max(1, prof.step_launches)
         mine = torch.tensor([1e3 * prof.sweep_ms / max(1, prof.sweep_launches), 1e3 * prof.reduce_ms / n_it, 1e3 * prof.collective_ms / n_it,
-                             1e3 * (prof.step_ms - prof.reduce_ms - prof.collective_ms) / n_it], device="cuda", dtype=torch.float64)
+                             1e3 * (prof.step_ms - prof.reduce_ms - prof.collective_ms) / n_it], device=cdev, dtype=torch.float64)
         allp = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allp, mine)
         phases = {"unit": "us per iteration (HIP events on the library's stream, instrumented pass)", "columns": ["sweep", "gather", "collective", "step"],
                   "per_rank": [[round(float(v), 2) for v in t_.cpu()] for t_ in allp]}
     if dist is not None:
         # every region: MAX over ranks of its time; sharded: all ranks work on the SAME solves (units = its iterations, counted once); replicas: units add up
-        tt = torch.tensor([[e_, float(i_)] for e_, i_ in regions], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([[e_, float(i_)] for e_, i_ in regions], device=cdev, dtype=torch.float64)
         t_max = tt[:, 0].clone(); dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         i_sum = tt[:, 1].clone(); dist.all_reduce(i_sum, op=dist.ReduceOp.SUM)
         units = tt[:, 1] if sharded else i_sum
@@ -733,7 +783,7 @@ def main():
             be2.reset_state(); its2 += be2.solve_resident(opts).iterations
         sync()
         el2 = time.perf_counter() - t2
-        tt2 = torch.tensor([float(its2), el2], device="cuda", dtype=torch.float64)
+        tt2 = torch.tensor([float(its2), el2], device=cdev, dtype=torch.float64)
         s2 = tt2.clone(); dist.all_reduce(s2, op=dist.ReduceOp.SUM)
         m2 = tt2.clone(); dist.all_reduce(m2, op=dist.ReduceOp.MAX)
         replicas_leg = {"value": float(s2[0]) / float(m2[1]), "unit": "iterations/s", "scaling": "weak", "what": "%d independent replicas of the same window, %d steps each, no collective" % (world, args.steps)}
@@ -768,7 +818,7 @@ def main():
         sync()
         elx = time.perf_counter() - tx
         if dist is not None:
-            ttx = torch.tensor([float(itx), elx], device="cuda", dtype=torch.float64)
+            ttx = torch.tensor([float(itx), elx], device=cdev, dtype=torch.float64)
             sx = ttx.clone(); dist.all_reduce(sx, op=dist.ReduceOp.SUM); mx = ttx.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
             itx, elx = (float(itx) if sharded else float(sx[0])), float(mx[1])
         profx = VilProfile()
@@ -807,6 +857,12 @@ def main():
             out["replicas"] = replicas_leg
         if phases:
             out["phases_per_rank"] = phases
+        if comm_info:
+            out["communicator"] = comm_info
+            if sharded:
+                mbb, fbb = C.c_int64(0), C.c_int64(0)
+                if be.lib.vil_comm_message_bytes(be.ctx, C.byref(mbb), C.byref(fbb)) == 0:
+                    out["communicator"]["message_bytes_per_peer_rank0"] = int(mbb.value); out["communicator"]["full_set_bytes"] = int(fbb.value)
         if prof.sweep_launches > 0:
             out["roofline"] = roofline_obj(w, prof, "second pass of the same %d steps with HIP events enabled (%.1f ms/step instrumented vs %.1f ms/step in the value region)" % (args.steps, 1e3 * el_events / args.steps, 1e3 * max_el / args.steps),
                                            ("r04_pmc_fetch_size.csv", "r04_pmc_write_size.csv"), "profiles/r04_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command)", "r04_pmc_mfma.csv")

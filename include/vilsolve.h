@@ -179,7 +179,9 @@ typedef struct vil_problem {
 /* ---- solver options: ceres::Solver::Options as used at estimator.cpp:1400-1411 --------------- */
 typedef struct vil_options {
     int32_t max_iterations;         /* NUM_ITERATIONS (30)                                 */
-    double max_time_s;              /* SOLVER_TIME (0.05); <= 0 disables (parity runs); ignored by sharded (multi-rank) solves */
+    double max_time_s;              /* SOLVER_TIME (0.05); <= 0 disables (parity runs); ignored by sharded (multi-rank) solves.  The host reads the clock between two
+                                     * chunks of enqueued iterations (3 - 15 of them): the cap takes effect at a chunk boundary, never in the middle of one -- ceres reads
+                                     * it after every iteration.  At ~75 us per iteration the reference's 0.05 s is 600 iterations away; its 30-iteration cap always comes first */
     double function_tolerance;      /* 1e-6  */
     double gradient_tolerance;      /* 1e-10 */
     double parameter_tolerance;     /* 1e-8  */
@@ -272,6 +274,9 @@ int vil_comm_init_local(vil_ctx** ctxs, int n);
  * the owner's value) -- 103 + 380 / world kB per peer at K = 10 / 1000 landmarks instead of 484 kB.  vil_comm_message_bytes reports it for the
  * uploaded (sharded) window. */
 int vil_comm_message_bytes(vil_ctx* ctx, int64_t* bytes_per_peer, int64_t* bytes_full_set);
+/* What the context's communicator is: its rank, the number of ranks it spans and the transport of the per-iteration collective (0: none, 1: RCCL,
+ * 2: in-process, 3: peer buffers; -3: peer buffers exported but not yet initialised).  A launcher asserts world == the ranks it started. */
+int vil_comm_info(vil_ctx* ctx, int32_t* rank, int32_t* world, int32_t* transport);
 /* RCCL (vil_comm_init, world <= 8) moves the same content as ONE ncclAllReduce of the packed camera part [lower(S') | g | b_c | diag | cost] plus ONE ncclAllGather
  * of the owners' landmark slices (padded to the largest): 103 + 48 kB per rank at K = 10 / 1000 landmarks / world 8; vil_comm_message_bytes reports that sum.
  * test hook: the pack / unpack kernels of that path over the in-process communicator (two small kernels stand in for the RCCL calls), so that they run on

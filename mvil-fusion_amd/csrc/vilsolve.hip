@@ -1998,6 +1998,13 @@ int vil_comm_message_bytes(vil_ctx* c, int64_t* bytes_per_peer, int64_t* bytes_f
 
 // ---- window residency across frames (include/vilsolve.h) ------------------------------------------------------------------------
 int vil_debug_set_launch_mode(vil_ctx* c, int32_t mode) { if (!c || mode < 0 || mode > 2) return VIL_ERR_INVALID_ARGUMENT; c->launch_mode = mode; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
+int vil_comm_info(vil_ctx* c, int32_t* rank, int32_t* world, int32_t* transport) {
+    if (!c) return VIL_ERR_INVALID_ARGUMENT;
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    if (transport) *transport = c->comm ? 1 : (c->lcomm ? 2 : (c->ipc ? (c->ipc->ready ? 3 : -3) : 0));
+    return VIL_OK;
+}
 int vil_debug_set_slim_emul(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->slim_emul = on != 0; return VIL_OK; }
 int vil_debug_set_split(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->force_split = on != 0; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
 int vil_set_gauge_fix(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->gauge_on = on != 0; return VIL_OK; }      // (takes effect in the next solve)

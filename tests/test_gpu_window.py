@@ -135,7 +135,7 @@ def test_resident_window_k20_chain_in_sweep(oracle):
     be.close()
 
 
-def test_time_cap_ends_the_solve_on_the_host_and_returns_the_accepted_state():
+def test_time_cap_ends_the_solve_on_the_host_and_returns_the_accepted_state(oracle):
     """max_solver_time_in_seconds (estimator.cpp:1411): the host checks the clock between two chunks of iterations and ends the solve; k_finish
     writes the accepted state out.  The result is an iterate of the un-capped solve, never garbage."""
     from mvil_fusion_amd import synth
@@ -153,6 +153,15 @@ def test_time_cap_ends_the_solve_on_the_host_and_returns_the_accepted_state():
     tr = np.array(list(s_full.cost_trace)[:s_full.iterations] + [s_full.initial_cost])
     assert np.abs(tr - s.final_cost).min() <= 1e-6 * s.final_cost      # one of the un-capped solve's iterates (a prior-less window: two runs agree to ~1e-9, its gauge null space amplifies rounding)
     be.close()
+    # the same cap on the ORACLE (oracle_solver.cpp: the clock is read where ceres reads it, at the top of every iteration): it stops with max_time as well, and what
+    # both return is an iterate of the oracle's un-capped trajectory -- the oracle's zeroth (the expired clock is seen before the first step), the device's a later
+    # one (the host reads the clock between two chunks of enqueued iterations: a cap can only take effect at a chunk boundary, documented in vilsolve.h)
+    wo = synth.make_config(1); so_full = oracle.solve(wo, abi.default_options())
+    wc = synth.make_config(1); so_cap = oracle.solve(wc, abi.default_options(max_time_s=1e-7))
+    assert so_cap.termination == abi.TERM_NAMES.index("max_time") and so_cap.iterations == 0 and so_cap.final_cost == so_cap.initial_cost
+    assert np.array_equal(wc.pose, st0["pose"])
+    otr = np.array([so_full.initial_cost] + list(so_full.cost_trace)[:so_full.iterations])
+    assert abs(otr[0] - s.initial_cost) <= 1e-9 * s.initial_cost and np.abs(otr - s.final_cost).min() <= 1e-6 * s.final_cost
 
 
 def test_resident_window_reports_a_failed_frame_at_the_next_solve():
@@ -186,7 +195,9 @@ def test_full_size_replay_through_the_resident_window(oracle, capsys):
     evaluation (vil_options.precision = 1, fp64 accumulation and solve) and RECORDS its deviation from the fp64 chain (reported, not asserted
     beyond a sanity bound)."""
     K, N = 10, 100
-    kw = dict(K=K, n_frames=N + K + 2, L=1000, n_plane=24000, n_edge=6000, seed=20240605, max_iterations=8)
+    # the reference's solver limits (config/mynteye_leishen_indoor.yaml:76-77): 30 iterations / 0.05 s; the oracle runs WITHOUT the wall-clock cap (opts_parity):
+    # on a CPU it would cut the solve after ~3 iterations, the device never reaches it
+    kw = dict(K=K, n_frames=N + K + 2, L=1000, n_plane=24000, n_edge=6000, seed=20240605, max_iterations=30, max_time_s=0.05)
 
     def chain(precision, check):
         rp = replay.Replay(**kw)
@@ -203,10 +214,11 @@ def test_full_size_replay_through_the_resident_window(oracle, capsys):
                 wo = Window.from_dict(rp.window().to_dict())
             p0 = w.pose[0].copy()
             sg = be.win_solve(w, rp.opts)
-            sizes.append((w.L, sum(int(n) - 1 for n in w.lm_nobs)))
+            sizes.append((w.L, sum(int(n) - 1 for n in w.lm_nobs), sg.iterations))
             if wo is not None:
-                so = oracle.solve(wo, rp.opts); oracle.gauge_fix(p0, wo)
+                so = oracle.solve(wo, rp.opts_parity); oracle.gauge_fix(p0, wo)
                 assert (sg.iterations, sg.termination) == (so.iterations, so.termination), (step, sg.iterations, so.iterations)
+                assert sg.termination != abi.TERM_NAMES.index("max_time")
                 dp = np.abs(w.pose[:, :3] - wo.pose[:, :3]).max(); dr = max(_rot_angle(w.pose[k, 3:], wo.pose[k, 3:]) for k in range(K))
                 dc = abs(sg.final_cost - so.final_cost) / max(1.0, abs(so.final_cost))
                 worst = dict(dpos=max(worst["dpos"], dp), drot=max(worst["drot"], dr), dcost=max(worst["dcost"], dc)); nchk += 1
@@ -221,11 +233,11 @@ def test_full_size_replay_through_the_resident_window(oracle, capsys):
         return np.array(newest), worst, nchk, sizes
     p64, worst, nchk, sizes = chain(0, True)
     assert nchk == 10
-    Ls, Fs = [s[0] for s in sizes], [s[1] for s in sizes]
+    Ls, Fs, Is = [s[0] for s in sizes], [s[1] for s in sizes], [s[2] for s in sizes]
     assert 800 <= np.mean(Ls) <= 1300 and np.mean(Fs) >= 2500            # configs[1]-shaped windows on every image
     p32, _, _, _ = chain(1, False)
     d32 = np.abs(p32[:, :3] - p64[:, :3]).max()
     with capsys.disabled():
-        print("\n[full-size replay, %d images, L ~ %.0f, ~%.0f visual factors, 30 k LiDAR points] fp64 vs oracle at %d checkpoints: dpos %.2e m, drot %.2e rad, dcost %.2e | "
-              "fp32 evaluation vs fp64 chain: max position deviation %.2e m" % (N, np.mean(Ls), np.mean(Fs), nchk, worst["dpos"], worst["drot"], worst["dcost"], d32))
+        print("\n[full-size replay, %d images, L ~ %.0f, ~%.0f visual factors, 30 k LiDAR points, limits 30 it / 0.05 s: %.1f iterations per image, max %d] fp64 vs oracle at %d checkpoints: dpos %.2e m, drot %.2e rad, dcost %.2e | "
+              "fp32 evaluation vs fp64 chain: max position deviation %.2e m" % (N, np.mean(Ls), np.mean(Fs), np.mean(Is), max(Is), nchk, worst["dpos"], worst["drot"], worst["dcost"], d32))
     assert d32 < 5e-3                                                     # sanity only (measured ~1e-4 m: the replay of bench.py --replay --precision 1)
