@@ -287,8 +287,9 @@ int vil_comm_ipc_init(vil_ctx* ctx, const void* handles /* world x 64 bytes */);
 /* test hook: run the multi-GPU plumbing (partial system in set 0, the collective sums it into set 1, step kernel on set 1) on a
  * single rank, with or without a 1-rank communicator.  Invalidates the resident window. */
 int vil_debug_set_split(vil_ctx* ctx, int32_t on);
-/* test hook: which launch structure a single-GPU solve takes.  0 (default): the library's choice -- gather + step in one launch whenever the device holds
- * its workgroups (every BASELINE size on an MI355X); 1: the fallback for devices / windows where it does not: separate gather launch, the speed-bias chain
+/* test hook: which launch structure a single-GPU solve takes.  0 (default): the library's choice -- the whole iteration (sweep, gather, chain elimination, step)
+ * in ONE launch whenever the device holds its waiting workgroups and the roles share one dynamic-LDS size (every BASELINE size on an MI355X), else the next one
+ * down this list; 3: sweep launch + gather / step launch (round 4's structure); 1: the fallback for devices / windows where it does not: separate gather launch, the speed-bias chain
  * eliminated by a workgroup of the SWEEP launch; 2: no chain workgroup at all (the step kernel eliminates the chain itself, the round-2 structure).
  * Same results to rounding in every mode.  Invalidates the resident window. */
 int vil_debug_set_launch_mode(vil_ctx* ctx, int32_t mode);

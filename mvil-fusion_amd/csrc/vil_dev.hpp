@@ -126,6 +126,11 @@ struct DevP {
     // gather + step in ONE launch (rs_merged): grid = [master | helpers | chain | W W^T tiles (n_ww) | gather (n_gather)]; a workgroup that is
     // done posts the launch epoch in its flag -- gflag[n_gather], chflag, wwflag[n_ww] -- and the master / helpers / tile workgroups wait on them
     int rs_merged, n_ww, n_gather; int* gflag; int* chflag; int* wwflag;
+    // ---- the whole iteration in ONE launch (k_iter, vil_iter.hpp): grid = [sweep roles (n_sw workgroups, the order of k_sweep) | chain | gather | master | helpers | W W^T tiles];
+    // every sweep workgroup posts the launch epoch in sflag[its index] once its record is out (agent-scope stores); the gather workgroups wait for all of them,
+    // the chain workgroup for the IMU / prior ones
+    int n_sw; int* sflag;
+    long long* prof;               // != null: wall-clock stamps (s_memrealtime, 100 MHz) of the roles of a one-launch iteration, 8 per launch slot (vil_profile)
     int gather_pose_only;          // the gather forms S' on the visual sub-space + the diagonal only (a solve on the prechain path: vil_sweep.hpp, reduce_gather)
     double* chW; double* chLraw; double* chLdg; double* chLsb; double* chSc; double* chDc; double* chZ; double* chQ; int* chOk; double* chWW;
 };

@@ -227,4 +227,7 @@ __device__ __forceinline__ double ld_ag(const double* p) { return __hip_atomic_l
 __device__ __forceinline__ void st_ag(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ld_ag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_ag(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// AG = true: data another workgroup of the SAME launch wrote / will read (agent scope: the level the XCDs' L2s share); false: across a kernel boundary (plain)
+template <bool AG> __device__ __forceinline__ double ldx(const double* p) { if constexpr (AG) return ld_ag(p); else return *p; }
+template <bool AG> __device__ __forceinline__ void stx(double* p, double v) { if constexpr (AG) st_ag(p, v); else *p = v; }
 }  // namespace vd

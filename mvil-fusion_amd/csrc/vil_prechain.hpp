@@ -101,6 +101,9 @@ __device__ __forceinline__ void prechain_inverses(const DevP& P, double* lds, co
 // epoch: the launch's flag value; P.chflag[1] is posted as soon as the chain columns' scales are out (the master's vector pass reads them).
 // wait_records: the workgroup rides in k_sweep (windows too large for the merged launch) and spins until the IMU / prior workgroups of
 // that launch have published their records (swflag).
+// FUSED: the one-launch iteration (vil_iter.hpp) -- the IMU / prior workgroups are workgroups of THIS launch too (wait_records = true, their flags are P.sflag
+// with the launch epoch), but the launch's longest path is the master's, not this workgroup's: it forms the inverses of its diagonal blocks itself.
+template <bool FUSED = false>
 __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const int jacobi, double* lds, const int epoch, const bool wait_records = false) {
     const int t = threadIdx.x, K = P.K, NP = P.NV, NB = 9 * K, NT = blockDim.x;
 #ifdef VIL_STAMPS
@@ -140,8 +143,9 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     if (t < NB) B.pq[t] = pqv;
     for (int e = t + NT; e < NB; e += NT) B.pq[e] = P.chpq[e];
     if (wait_records) {
-        const int ep = (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u);       // (sweep_signal, vil_sweep.hpp)
-        if (t <= P.n_imu && (t < P.n_imu || P.pn > 0)) while (ld_ag(P.swflag + t) != ep) __builtin_amdgcn_s_sleep(1);
+        const int ep = FUSED ? epoch : (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u);       // (sweep_signal, vil_sweep.hpp)
+        const int* const fl = FUSED ? P.sflag : P.swflag;
+        if (t <= P.n_imu && (t < P.n_imu || P.pn > 0)) while (ld_ag(fl + t) != ep) __builtin_amdgcn_s_sleep(1);
     }
     __syncthreads();
     PSTAMP(31);
@@ -180,7 +184,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     // in-sweep chain (fallback launch structure): the factored blocks leave for prechain_inverses (a workgroup of the gather launch) as they are published, on the two waves
     // the elimination leaves idle -- 54 + 82 doubles per block, three stores per lane; from the recursion wave itself (one lane, 54 stores in a row) they
     // cost it 1.7 us per block, as a pass after the elimination 5 us at the end of the launch's longest workgroup
-    if (wait_records && t >= 384) {
+    if (wait_records && !FUSED && t >= 384) {
         const int d = (t >> 6) - 6, lane = t & 63, m = K >> 1, nd = d == 0 ? m : K - 1 - m;
         for (int st = 0; st <= nd; ++st) {
             int k;
@@ -206,7 +210,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     //      is the launch's longest and 7 us of dependent fp64 chains at its end would be 7 us of the iteration: the raw factors go out instead and a
     //      workgroup of the step launch forms the columns (prechain_inverses above).
     //      (waves 6 / 7 stored them as they were published, above)
-    if (!wait_records) {
+    if (!wait_records || FUSED) {
         for (int it = t; it < 9 * K; it += NT) chain_inverse_block(P, L.Ldg, L.Lsb, it / 9, it % 9);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -218,9 +222,14 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
 // One 16 x 16 tile (I, J), J <= I, of W W^T per workgroup (its first 256 threads: the four waves split the chain columns, their
 // accumulators are added through LDS).  W^T: column j of the chain at chW[j * RS + row], rows = pose part + the right-hand-side row.
 // Output in the tiled lower layout of the step kernel (TILE_RS = 17).
-__device__ __forceinline__ void prechain_ww_tile(const DevP& P, const int tile) {
+// FUSED: the four waves' accumulators meet in the workgroup's DYNAMIC LDS (`lds`, >= 1024 doubles) -- the one-launch iteration carries no static LDS, so
+// that its dynamic size is the larger of the sweep roles' and the step roles' needs, not their sum
+template <bool FUSED = false>
+__device__ __forceinline__ void prechain_ww_tile(const DevP& P, const int tile, double* const lds = nullptr) {
     typedef double d4_ __attribute__((ext_vector_type(4)));
-    __shared__ double acc_s[4][256];
+    double (*acc_s)[256];
+    if constexpr (FUSED) acc_s = reinterpret_cast<double (*)[256]>(lds);
+    else { __shared__ double acc_st[4][256]; acc_s = acc_st; }
     if (threadIdx.x >= 256) return;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, row = lane & 15, kq = lane >> 4;
     const int NB = 9 * P.K, RS = P.chain_rs, R = P.NV + 1;

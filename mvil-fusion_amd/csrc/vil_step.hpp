@@ -106,12 +106,13 @@ __device__ __forceinline__ double bmax(double v, StepShared& s) {
 // all loads in flight together); a helper workgroup keeps that between its two passes, so the second one -- which sits on
 // the step kernel's critical path -- touches no global memory for the usual landmark.
 struct LmRows { double e[13], a[6], b[6], c[6]; double m1, m2; int fs, fe, ac, c0, c1, c2; };
+template <bool AG = false>      // AG: e_A / e_O were written by the visual workgroups of THIS launch (the one-launch iteration, k_iter)
 __device__ __forceinline__ void lm_rows(const DevP& P, const SysBuf& sb, int l, LmRows& r) {
     r.fs = P.glm_start[l]; r.fe = P.glm_start[l + 1]; r.ac = P.glm_acol[l];
     if (r.fe == r.fs) return;
     const double* e = sb.eA + (size_t)l * 13;
 #pragma unroll
-    for (int k = 0; k < 13; ++k) r.e[k] = e[k];
+    for (int k = 0; k < 13; ++k) r.e[k] = ldx<AG>(e + k);
     // observers three at a time: index clamped into the landmark's own range (always a valid address), contribution
     // masked by a select -- the global loads of a group are all in flight together instead of one dependent round trip
     // per factor, and there is no per-lane predicated load (those compile to exec-mask branches with their own waits)
@@ -119,9 +120,10 @@ __device__ __forceinline__ void lm_rows(const DevP& P, const SysBuf& sb, int l, 
     r.c0 = P.gfcol[f]; r.c1 = P.gfcol[f1]; r.c2 = P.gfcol[f2];
     const double* e0 = sb.eO + (size_t)f * 6; const double* e1 = sb.eO + (size_t)f1 * 6; const double* e2 = sb.eO + (size_t)f2 * 6;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { r.a[k] = e0[k]; r.b[k] = e1[k]; r.c[k] = e2[k]; }
+    for (int k = 0; k < 6; ++k) { r.a[k] = ldx<AG>(e0 + k); r.b[k] = ldx<AG>(e1 + k); r.c[k] = ldx<AG>(e2 + k); }
     r.m1 = (f + 1 < r.fe) ? 1.0 : 0.0; r.m2 = (f + 2 < r.fe) ? 1.0 : 0.0;
 }
+template <bool AG = false>
 __device__ __forceinline__ double lm_dot_rows(const DevP& P, const SysBuf& sb, const LmRows& r, const double* vc) {
     if (r.fe == r.fs) return 0.0;
     const double* e = r.e;
@@ -143,7 +145,7 @@ __device__ __forceinline__ double lm_dot_rows(const DevP& P, const SysBuf& sb, c
         const double* e0 = sb.eO + (size_t)f * 6; const double* e1 = sb.eO + (size_t)f1 * 6; const double* e2 = sb.eO + (size_t)f2 * 6;
         double a[6], b[6], c[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { a[k] = e0[k]; b[k] = e1[k]; c[k] = e2[k]; }
+        for (int k = 0; k < 6; ++k) { a[k] = ldx<AG>(e0 + k); b[k] = ldx<AG>(e1 + k); c[k] = ldx<AG>(e2 + k); }
         const double* v0 = vc + c0; const double* v1 = vc + c1; const double* v2 = vc + c2;
         const double m1 = (f + 1 < r.fe) ? 1.0 : 0.0, m2 = (f + 2 < r.fe) ? 1.0 : 0.0;
         s0 += a[0] * v0[0]; s1 += a[1] * v0[1]; s2 += a[2] * v0[2]; s3 += a[3] * v0[3]; s0 += a[4] * v0[4]; s1 += a[5] * v0[5];
@@ -152,9 +154,10 @@ __device__ __forceinline__ double lm_dot_rows(const DevP& P, const SysBuf& sb, c
     }
     return (s0 + s1) + (s2 + s3);
 }
+template <bool AG = false>
 __device__ __forceinline__ double lm_dot(const DevP& P, const SysBuf& sb, int l, const double* vc) {
-    LmRows r; lm_rows(P, sb, l, r);
-    return lm_dot_rows(P, sb, r, vc);
+    LmRows r; lm_rows<AG>(P, sb, l, r);
+    return lm_dot_rows<AG>(P, sb, r, vc);
 }
 
 // v^T H v over all free parameters, H = J^T J of the corrected Jacobian, from the reduced pieces:
@@ -836,7 +839,7 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
 //      M_pp = Sc (S'_pp - W W^T) Sc + mu d^2 (the row scaling the chain workgroup deferred is applied here), dense part, chain back
 //      substitution.  Same contract as solve_chain.
 template <class PUB, class SIDE>
-__device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart, PUB pub, SIDE side) {
+__device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart, const int epoch /* of this launch's flags */, PUB pub, SIDE side) {
     const int t = threadIdx.x;
     SSTAMP(0);
     const int K = P.K, D = P.D, NP = P.NV, R = NP + 1, T = (R + 15) >> 4, ntile = (T * (T + 1)) >> 1;
@@ -870,7 +873,6 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
         }
     }
     if (P.rs_merged) {   // the chain workgroup and the W W^T tile workgroups of this launch are done (a tile's flag implies the chain's)
-        const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
         for (int i = t; i < P.n_ww; i += VIL_STEP_THREADS) while (__hip_atomic_load(P.wwflag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
         __syncthreads();                               // (everything they left is read at agent scope below: no fence)
     }
@@ -922,7 +924,6 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
     //      round trip: every load of a thread in flight together
     {
         if (P.rs_merged || P.prechain == 2) {          // (prechain 2: prechain_inverses, a workgroup of this launch)
-            const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
             if (f2 != epoch) while (__hip_atomic_load(P.chflag + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
         }
         double acc = 0.0, pl[2], ps[2];
@@ -1026,11 +1027,12 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
 // and six sums (|gn_l|^2, gn_l . g_l, |la|^2, la . lb, |lb|^2, |lambda|^2); the candidate inverse depth lambda + cg la + cn lb is
 // formed by the NEXT sweep's visual workgroups from the two dogleg coefficients in Ctl, and its norm follows from the sums.
 // With helper workgroups (grid = 1 + n_help) that pass runs on their CUs while the master back-substitutes the chain.
-template <bool LDSM, int CHAIN = 0>
-__global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) {
+// FUSED: the role runs inside the one-launch iteration (k_iter, vil_iter.hpp) -- the sweep's workgroups are part of the SAME launch: the gather workgroups
+// wait for their flags (P.sflag) and read the records at agent scope, the chain workgroup waits for the IMU / prior workgroups', master and helpers read the
+// landmark arrays at agent scope, and the master counts the launch in Ctl::n_sweeps itself.  p0: the workgroup's index among the step roles.
+template <bool LDSM, int CHAIN, bool FUSED>
+__device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd::StepShared& s, double* const Alds, const int p0) {
     using namespace vd;
-    __shared__ StepShared s;
-    extern __shared__ double Alds[];
     const int t = threadIdx.x, NT = blockDim.x;
     const int D = P.D, L = P.L;
     // The grid is 1 + P.n_help workgroups: the extra ones run the same judge on their own copy of Ctl and
@@ -1043,12 +1045,12 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     // W W^T tile workgroups | gather workgroups]; whoever is done posts the launch epoch in its flag, and master, helpers and tile workgroups
     // wait for what they read.  The waiting workgroups have the lowest block indices (dispatched first); everything they wait for is finite.
     const int nhelp = P.n_help;
-    const bool merged = P.rs_merged != 0;
+    const bool merged = FUSED || P.rs_merged != 0;
     // roles by `bid`: 0 master, 1 .. nhelp helpers, then chain, tiles, gather.  The hardware dispatches in blockIdx order and the chain workgroup
     // is the longest path into the dense part, the gather the next: physical order [chain | gather | master | helpers | tiles]
-    int bid = (int)blockIdx.x;
+    int bid = p0;
     if (merged) {
-        const int pc = P.prechain ? 1 : 0, p0 = (int)blockIdx.x;
+        const int pc = P.prechain ? 1 : 0;
         if (pc && p0 == 0) bid = 1 + nhelp;
         else if (p0 - pc < P.n_gather) bid = 1 + nhelp + pc + P.n_ww + (p0 - pc);
         else { const int q = p0 - pc - P.n_gather; bid = q <= nhelp ? q : 1 + nhelp + pc + (q - 1 - nhelp); }
@@ -1070,7 +1072,10 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         s.tI[q] = (unsigned char)Ir; s.tJ[q] = (unsigned char)(q - (Ir * (Ir + 1)) / 2);
     }
     __syncthreads();
-    if (t == 0) s.c.swe++;                   // (every path that writes Ctl back carries the new swe)
+    // (one-launch iteration: nobody else has counted this launch -- every role forms the epoch from the n_sweeps it READ, the master stores the new count)
+    const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
+    __syncthreads();
+    if (t == 0) { s.c.swe++; if (FUSED) s.c.n_sweeps++; }      // (every path that writes Ctl back carries the new swe)
     __syncthreads();
 #ifdef VIL_STAMPS
     #define STAMP(k) do { __syncthreads(); if (t == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[k] = tt_; } } while (0)
@@ -1078,7 +1083,6 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     #define STAMP(k) do {} while (0)
 #endif
     if (s.c.done) return;                    // finished in an earlier launch: nobody writes anything
-    const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
     // completion of a whole workgroup: what it leaves for other workgroups of the launch is stored at agent scope (st_ag), so every thread only
     // waits for its own stores (__syncthreads does not), then one flag; the readers poll relaxed and load at agent scope (ld_ag) -- no fences
     auto rs_signal = [&](int* f) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (t == 0) __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -1087,15 +1091,16 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
         __syncthreads();
     };
     if (merged && bid >= b_gather) {
-        if (P.rs_merged == 2) reduce_gather<true, VIL_STEP_THREADS / 8>(P, s.c, bid - b_gather, (int4*)Alds);      // 64 entries, all 512 threads
+        if constexpr (FUSED) reduce_gather<true, VIL_STEP_THREADS / 8, true>(P, s.c, bid - b_gather, (int4*)Alds, epoch);      // (waits for the sweep workgroups' flags behind its own table staging)
+        else if (P.rs_merged == 2) reduce_gather<true, VIL_STEP_THREADS / 8>(P, s.c, bid - b_gather, (int4*)Alds);      // 64 entries, all 512 threads
         else { if (t >= VIL_THREADS) return; reduce_gather<true, RED_EPW>(P, s.c, bid - b_gather, (int4*)Alds); }      // (descriptor table in the dynamic LDS this role does not use otherwise)   // 32 entries on the first four waves
         rs_signal(P.gflag + (bid - b_gather)); return;
     }
     if (merged && bid >= b_ww) {
         if (t >= VIL_THREADS) return;                  // a 256-thread role: the upper waves leave before the first barrier
-        rs_wait(P.chflag, 1); prechain_ww_tile(P, bid - b_ww); rs_signal(P.wwflag + (bid - b_ww)); return;
+        rs_wait(P.chflag, 1); prechain_ww_tile<FUSED>(P, bid - b_ww, Alds); rs_signal(P.wwflag + (bid - b_ww)); return;
     }
-    if (merged && P.prechain && bid == b_chain) { prechain_wg(P, s.c, O.jacobi_scaling, Alds, epoch); return; }      // (posts chflag[0 .. 2] itself)
+    if (merged && P.prechain && bid == b_chain) { prechain_wg<FUSED>(P, s.c, O.jacobi_scaling, Alds, epoch, FUSED); return; }      // (posts chflag[0 .. 2] itself; one-launch iteration: behind the IMU / prior workgroups' flags)
     if (!merged && P.prechain == 2 && bid == b_chain) { prechain_inverses(P, Alds, epoch); return; }                 // (chain eliminated inside k_sweep: posts chflag[2])
     if (merged) rs_wait(P.gflag, P.n_gather);          // master and helpers: the candidate's cost, gradient and diagonal (and S') are complete
     // Everything the master and its helpers hand each other inside this launch (hpart, hpart2, stepc) is stored AND loaded with agent-scope
@@ -1162,13 +1167,13 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     // pass 1 (needs u = Sc gradient_/d of the camera part in vc): dl, gradient_l, share of u^T H u, |g|^2, max |b|
     auto lm_pass1 = [&](int l0, int l1, const double* vc, double& q, double& g2, double& gm) {
         for (int l = l0 + t; l < l1; l += NT) {
-            const double ip = sb.invp[l], Sl = sb.sl[l], h = sb.hll[l], b = sb.bl[l];
+            const double ip = ldx<FUSED>(sb.invp + l), Sl = ldx<FUSED>(sb.sl + l), h = ldx<FUSED>(sb.hll + l), b = ldx<FUSED>(sb.bl + l);
             const double d = sqrt(fmin(fmax(Sl * Sl * h, 1e-6), 1e32));
             const double g = ip != 0.0 ? Sl * b / d : 0.0;
             P.dl[l] = d; P.gradl[l] = g;
             if (ip != 0.0) {
                 const double ul = Sl * g / d;
-                const double ev = lm_dot(P, sb, l, vc);
+                const double ev = lm_dot<FUSED>(P, sb, l, vc);
                 q += ip * ev * ev + 2.0 * ul * ev + h * ul * ul;
                 g2 += g * g; gm = fmax(gm, fabs(b));
             }
@@ -1177,18 +1182,18 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     // pass 2 (needs Sc x_c of the pose part in vc): landmark back-substitution, step directions, the six sums
     auto lm_pass2 = [&](int l0, int l1, const double* vc, double* sm /*6*/) {
         for (int l = l0 + t; l < l1; l += NT) {
-            const double ip = sb.invp[l];
+            const double ip = ldx<FUSED>(sb.invp + l);
             double a = 0.0, b = 0.0;
             if (ip != 0.0) {
-                const double Sl = sb.sl[l], dl = P.dl[l], g = P.gradl[l];
-                const double xl = (sb.bl[l] - lm_dot(P, sb, l, vc)) * ip / Sl;
+                const double Sl = ldx<FUSED>(sb.sl + l), dl = P.dl[l], g = P.gradl[l];
+                const double xl = (ldx<FUSED>(sb.bl + l) - lm_dot<FUSED>(P, sb, l, vc)) * ip / Sl;
                 const double gnv = -xl * dl;
                 sm[0] += gnv * gnv; sm[1] += gnv * g;
                 a = Sl * g / dl; b = Sl * gnv / dl;
                 sm[2] += a * a; sm[3] += a * b; sm[4] += b * b;
             }
             P.la[l] = a; P.lb[l] = b;
-            if (!(P.lm_const && P.lm_const[l])) { const double lam = x[xo_lam(P) + l]; sm[5] += lam * lam; }
+            if (!(P.lm_const && P.lm_const[l])) { const double lam = ldx<FUSED>(x + xo_lam(P) + l); sm[5] += lam * lam; }      // (an accepted candidate's inverse depths: the visual workgroups of this launch wrote them)
         }
     };
     // helper side of the second pass: poll "published" and "given up" together (one round trip), then every wave posts its own
@@ -1258,10 +1263,10 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                 LmRows r; r.fs = 0; r.fe = 0;
                 double ip = 0, b = 0, d = 1, g = 0, lam2 = 0, ipS = 0, Sd = 0, a_ = 0;      // ipS = invp / Sl, Sd = Sl / dl, a_ = la
                 if (have) {
-                    lm_rows(P, sb, l, r);
-                    ip = sb.invp[l]; b = sb.bl[l];
-                    const double Sl = sb.sl[l], h = sb.hll[l];
-                    if (!(P.lm_const && P.lm_const[l])) { const double lam = x[xo_lam(P) + l]; lam2 = lam * lam; }
+                    lm_rows<FUSED>(P, sb, l, r);
+                    ip = ldx<FUSED>(sb.invp + l); b = ldx<FUSED>(sb.bl + l);
+                    const double Sl = ldx<FUSED>(sb.sl + l), h = ldx<FUSED>(sb.hll + l);
+                    if (!(P.lm_const && P.lm_const[l])) { const double lam = ldx<FUSED>(x + xo_lam(P) + l); lam2 = lam * lam; }
                     d = sqrt(fmin(fmax(Sl * Sl * h, 1e-6), 1e32));
                     g = ip != 0.0 ? Sl * b / d : 0.0;
                     P.dl[l] = d; P.gradl[l] = g;
@@ -1269,7 +1274,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                         Sd = Sl / d; ipS = ip / Sl;               // the divides of the second pass, done while the master solves
                         const double ul = Sd * g;
                         a_ = ul;
-                        const double ev = lm_dot_rows(P, sb, r, s.y);
+                        const double ev = lm_dot_rows<FUSED>(P, sb, r, s.y);
                         q += ip * ev * ev + 2.0 * ul * ev + h * ul * ul;
                         g2 += g * g; gm = fmax(gm, fabs(b));
                     }
@@ -1283,7 +1288,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                     double b_ = 0.0;
                     if (have) {
                         if (ip != 0.0) {
-                            const double xl = (b - lm_dot_rows(P, sb, r, s.gn)) * ipS;
+                            const double xl = (b - lm_dot_rows<FUSED>(P, sb, r, s.gn)) * ipS;
                             const double gnv = -xl * d;
                             sm[0] = gnv * gnv; sm[1] = gnv * g;
                             b_ = Sd * gnv;
@@ -1369,7 +1374,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
             __syncthreads();
             auto pub = [&]() { publish_xp(1); };
             auto side = [&]() {};          // (the helpers' sums are collected after the step vectors below: their round trip outlasts the chain walks)
-            if constexpr (CHAIN == 3) ok = solve_prechain(P, sb, s, Alds, mu, cam, q, pub, side);
+            if constexpr (CHAIN == 3) ok = solve_prechain(P, sb, s, Alds, mu, cam, q, epoch, pub, side);
             else ok = solve_chain<CHAIN == 1>(P, sb, s, Alds, mu, cam, q, pub, side);      // packing, chain, Schur update, dense part, back substitution
         } else {
         // tiled storage: element e of the tile array -> (i, j); S entries were prefetched into registers at kernel start
@@ -1455,7 +1460,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
                 if (!(c.mu < O.max_mu)) { c.iter++; c.invalid_run++; c.reuse = 0; if (c.invalid_run >= 5) { c.done = 1; c.term = 6; c.status = -4; } }
                 c.resweep = 1; c.cg = 0.0; c.cn = 0.0;
             }
-            for (int i = t; i < P.NS; i += NT) xc[i] = x[i];
+            for (int i = t; i < P.NS; i += NT) xc[i] = i >= xo_lam(P) ? ldx<FUSED>(x + i) : x[i];
             __syncthreads();
             if (t < 64) { wait_helpers(); store_ctl(); }      // (a late helper may still be copying Ctl into its LDS)
             return;
@@ -1591,4 +1596,11 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) 
     if (s.c.resweep && !s.c.done) { for (int i = t; i < 16 * P.K + 8; i += NT) xc[i] = s.x0[i]; }
     STAMP(7);
     if (t < 64) { wait_helpers(); store_ctl(); }      // (no second poll when the sums were already collected)
+}
+
+template <bool LDSM, int CHAIN = 0>
+__global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) {
+    __shared__ vd::StepShared s;
+    extern __shared__ double Alds[];
+    step_body<LDSM, CHAIN, false>(P, O, s, Alds, (int)blockIdx.x);
 }

@@ -127,7 +127,8 @@ __host__ __device__ inline int vis_slots(int T) { return (vis_ntile(T) + 7) >> 3
 // The candidate inverse depth is formed HERE: lambda_cand = lambda_cur + cg la + cn lb (la, lb: the step directions the step
 // kernel's landmark pass left, cg / cn: the dogleg coefficients in Ctl; first sweep and re-sweeps: cg = cn = 0), and written
 // into the candidate state by the landmark's lane group.
-template <int TS>      // accumulator tiles per wave: 2 (windows whose widest chunk has T <= 5 column tiles: K <= 12) or 5 (T <= 8: K <= 20); a kernel per value
+// AG: what the workgroup leaves for other workgroups of the SAME launch (the one-launch iteration, vil_iter.hpp: record, landmark arrays) is stored at agent scope
+template <int TS, bool AG = false>      // accumulator tiles per wave: 2 (windows whose widest chunk has T <= 5 column tiles: K <= 12) or 5 (T <= 8: K <= 20); a kernel per value
 __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, const Ctl& ctl, int wg, const double* x, SysBuf& sb, double* sm) {
     const int t = threadIdx.x;
     const int4 d0 = ((const int4*)P.vwg)[2 * wg], d1 = ((const int4*)P.vwg)[2 * wg + 1];      // {first sorted landmark, landmarks, first sorted factor, factors}, {fa, span, T, record offset / 16}
@@ -202,7 +203,7 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             const double j0 = cj ? 0.0 : sr * o.Jj[k], j1 = cj ? 0.0 : sr * o.Jj[6 + k];
             const double eo = j0 * w[38] + j1 * w[39];
             w[42 + k] = eo;
-            sb.eO[(size_t)(P.vis_f0 + f) * 6 + k] = eo;
+            stx<AG>(sb.eO + (size_t)(P.vis_f0 + f) * 6 + k, eo);
         }
     }
     __syncthreads();
@@ -238,10 +239,10 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
         double* lr = lmr + tl * 16;
         double* er = Em + tl * RS;
         // (a landmark of another rank's shard is in no chunk of this rank: its entries of the set stay zero here and the all-reduce takes them from the owner)
-        if (k == 13) { sb.hll[l] = h; sb.bl[l] = b; sb.invp[l] = invp; sb.sl[l] = Sl; lr[0] = invp; sa[tl] = -invp; er[cR] = b; }
-        if (k == 14) xcand[xo_lam(P) + l] = stepped ? xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l] : xcur[xo_lam(P) + l];      // the same expression the factor threads evaluated
+        if (k == 13) { stx<AG>(sb.hll + l, h); stx<AG>(sb.bl + l, b); stx<AG>(sb.invp + l, invp); stx<AG>(sb.sl + l, Sl); lr[0] = invp; sa[tl] = -invp; er[cR] = b; }
+        if (k == 14) stx<AG>(xcand + xo_lam(P) + l, stepped ? xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l] : xcur[xo_lam(P) + l]);      // the same expression the factor threads evaluated (read by the step roles once the candidate is accepted)
         if (k < 13) {
-            lr[1 + k] = e; sb.eA[(size_t)l * 13 + k] = e;
+            lr[1 + k] = e; stx<AG>(sb.eA + (size_t)l * 13 + k, e);
             er[k < 6 ? 6 * (a - fa0) + k : cX + (k - 6)] = e;
         }
         // observer columns of e_l: lanes 0..5 of the group walk the factors
@@ -308,8 +309,8 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int m = m0 + 4 * q;
-                    if (tI[u] == tJ[u] && m == n) rdg[(tI[u] << 4) + m] = acc[u][q];
-                    if (tJ[u] == T - 1 && m == (cR & 15)) rbc[(tI[u] << 4) + n] = acc[u][q];      // (accumulator row m = column of tile J, column n = row of tile I)
+                    if (tI[u] == tJ[u] && m == n) stx<AG>(rdg + (tI[u] << 4) + m, acc[u][q]);
+                    if (tJ[u] == T - 1 && m == (cR & 15)) stx<AG>(rbc + (tI[u] << 4) + n, acc[u][q]);      // (accumulator row m = column of tile J, column n = row of tile I)
                 }
             }
         }
@@ -321,12 +322,12 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
         for (int u = 0; u < TS; ++u) if (on[u]) {
             double* o = rec + (wave + 8 * u) * 256 + (lane >> 4) * 16 + (lane & 15);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q * 64] = acc[u][q];
+            for (int q = 0; q < 4; ++q) stx<AG>(o + q * 64, acc[u][q]);
         }
     }
     VSTAMP(3);
     cost = block_sum(cost, red);
-    if (t == 0) rec[ntile * 256 + 32 * T] = cost;
+    if (t == 0) stx<AG>(rec + ntile * 256 + 32 * T, cost);
     VSTAMP(4);
 #ifdef VIL_STAMPS
     if (t == 0) { long long vt1; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(vt1) :: "memory"); atomicMax((unsigned long long*)(P.dbg + 60), (unsigned long long)(vt1 - vt0)); atomicAdd((unsigned long long*)(P.dbg + 61), (unsigned long long)(vt1 - vt0)); }
@@ -334,7 +335,7 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NR>
+template <int NR, bool AG = false>
 __device__ __forceinline__ void sweep_lidar(const DevP& P, const SolveOpts& O, int wgc, const double* x, double* sm) {
     const int per = blockDim.x >> 8;                    // 256-point chunks per workgroup
     const int sub = threadIdx.x >> 8;
@@ -394,7 +395,7 @@ __device__ __forceinline__ void sweep_lidar(const DevP& P, const SolveOpts& O, i
     if (lane < 16) { const int q = fold_slot(lane); sm[wave * 28 + q] = f0; if (q + 16 < 28) sm[wave * 28 + q + 16] = f1; }
     __syncthreads();
     const int gchunk = (NR == 1 ? 0 : P.n_pchunk) + chunk;
-    if (have && t < 28) P.lpart[(size_t)gchunk * 28 + t] = sm[t] + sm[28 + t] + sm[56 + t] + sm[84 + t];
+    if (have && t < 28) stx<AG>(P.lpart + (size_t)gchunk * 28 + t, sm[t] + sm[28 + t] + sm[56 + t] + sm[84 + t]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -453,6 +454,7 @@ __device__ __forceinline__ void sweep_prior(const DevP& P, const double* x, doub
 }
 
 // [rel] workgroup: the scan-to-scan ICP and LPS AutoDiff factors
+template <bool AG = false>
 __device__ __forceinline__ void sweep_misc(const DevP& P, const SolveOpts& O, const double* x, double* sm) {
     const int t = threadIdx.x;
     // ---- ICP (4 pose blocks) and LPS (2 pose blocks): thread per (factor, block) ----------------------------
@@ -505,7 +507,7 @@ __device__ __forceinline__ void sweep_misc(const DevP& P, const SolveOpts& O, co
             const double* Ja = Jb + (f * 4 + a / 6) * 21 + a % 6;
             v = rho1 * (Ja[0] * r[0] + Ja[7] * r[1] + Ja[14] * r[2]);
         } else v = 0.5 * rho;
-        out0[e] = v;
+        stx<AG>(out0 + e, v);
     }
 }
 
@@ -538,10 +540,19 @@ __host__ __device__ inline int gather_vblocks(int NV, int epw) { return ((NV * (
 // of the rest (39 k of the 47 k entries at K = 20) the gather then forms just the diagonal (the dogleg scaling)
 __host__ __device__ inline int gather_sblocks(int D, int NV, int epw, bool pose_only) { return gather_vblocks(NV, epw) + ((pose_only ? D - NV : (D * (D + 1)) / 2 - (NV * (NV + 1)) / 2) + epw - 1) / epw; }
 __host__ __device__ inline int gather_blocks(int D, int NV, int epw, bool pose_only) { return gather_sblocks(D, NV, epw, pose_only) + (2 * D + epw / 4 - 1) / (epw / 4) + 1; }
-template <bool AG = false, int EPW = RED_EPW>
-__device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, const int blk /* gather workgroup index */, int4* const vtab /* LDS, VIS_TAB entries */) {
+// FUSED: the sweep's workgroups are workgroups of the SAME launch (the one-launch iteration, vil_iter.hpp): once its own tables are staged the workgroup waits
+// for their flags (P.sflag = epoch, n_sw of them), every record is read at agent scope, and the scratch arrays live in the workgroup's dynamic LDS behind vtab
+template <bool AG = false, int EPW = RED_EPW, bool FUSED = false>
+__device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, const int blk /* gather workgroup index */, int4* const vtab /* LDS, VIS_TAB entries */, const int epoch = 0) {
     using namespace vd;
     auto put = [](double* p, double v) { if (AG) st_ag(p, v); else *p = v; };
+    auto rd = [](const double* p) -> double { return ldx<FUSED>(p); };          // a sweep record
+    auto wait_sweep = [&]() {
+        if constexpr (FUSED) {
+            for (int i = threadIdx.x; i < P.n_sw; i += 8 * EPW) while (ld_ag(P.sflag + i) != epoch) __builtin_amdgcn_s_sleep(1);
+            __syncthreads();
+        }
+    };
     if ((int)threadIdx.x >= 8 * EPW) return;
     const int cand = 1 - ctl.cur;
     SysBuf sb = P.sys[cand];
@@ -552,8 +563,11 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
     constexpr int EPV = EPW / 4;               // entries per workgroup where the visual records are summed: 32 slices per entry, one round of loads
     const bool pose_only = P.gather_pose_only != 0;
     const int nVblk = gather_vblocks(NV, EPW), nSblk = gather_sblocks(D, NV, EPW, pose_only);
-    __shared__ double part[2][8 * EPW];
-    __shared__ int tab[64 + 48 + 2 * 66 + 24]; // imu (i, j) pairs | ICP/LPS pose ids (4 per factor) | LiDAR chunk ranges per pose | visual records whose window starts at or before frame f
+    constexpr int NTAB = 64 + 48 + 2 * 66 + 24;
+    double (*part)[8 * EPW]; int* tab; double* red;
+    if constexpr (FUSED) { part = reinterpret_cast<double (*)[8 * EPW]>(vtab + VIS_TAB); tab = reinterpret_cast<int*>(part + 2); red = reinterpret_cast<double*>(tab + NTAB + (NTAB & 1)); }
+    else { __shared__ double part_st[2][8 * EPW]; __shared__ int tab_st[NTAB]; __shared__ double red_st[8]; part = part_st; tab = tab_st; red = red_st; }
+    // tab: imu (i, j) pairs | ICP/LPS pose ids (4 per factor) | LiDAR chunk ranges per pose | visual records whose window starts at or before frame f
     // vtab: the visual records' descriptors {offset / 16, first frame, frames, column tiles}, staged per workgroup (records beyond VIS_TAB: read from memory)
     int* t_imu = tab; int* t_rel = tab + 64; int* t_lch = tab + 112; int* t_wend = tab + 244;
     const int4* const vrec = (const int4*)P.vrec;
@@ -570,6 +584,7 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
             if (t >= 8 * EPW - 32 && t < 8 * EPW - 32 + K) t_wend[t - (8 * EPW - 32)] = P.vwend[t - (8 * EPW - 32)];      // (K <= 20)
         }
         __syncthreads();
+        wait_sweep();
     };
     if (blk < nSblk) {
         if (P.skip_mask & 32) return;
@@ -605,9 +620,9 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
                 const bool in = il_ >= 0 && jl_ >= 0 && live;
                 const int il = in ? il_ : 0, jl = in ? jl_ : 0, I = il >> 4, J = jl >> 4;
                 const double* r = P.vpart + (size_t)ds.x * 16;
-                const double va = r[(I * T - ((I * (I - 1)) >> 1) + (J - I)) * 256 + (jl & 15) * 16 + (il & 15)];      // tile (I, J) holds its transpose
+                const double va = rd(r + (I * T - ((I * (I - 1)) >> 1) + (J - I)) * 256 + (jl & 15) * 16 + (il & 15));      // tile (I, J) holds its transpose
                 va_ = in ? va : 0.0; vd_ = 0.0;
-                if (wdiag) { const double vd = r[vis_ntile(T) * 256 + 16 * T + il]; vd_ = (in && i == j) ? vd : 0.0; }
+                if (wdiag) { const double vd = rd(r + vis_ntile(T) * 256 + 16 * T + il); vd_ = (in && i == j) ? vd : 0.0; }
             };
             for (int w = slice; w < nws; w += 32 * U) {
                 double a[U], d[U];
@@ -624,21 +639,21 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
             if (j < 6 * K && i / 6 == j / 6) {                 // LiDAR plane and edge points: pose-diagonal blocks.  The chunk records of a pose
                 const int k = i / 6, a = i - 6 * k, b = j - 6 * k;   // (one per 256 points: 9 per pose at 24 k points, 37 at 96 k) are dealt to the slices
                 const int li = a * 6 - ((a * (a - 1)) >> 1) + (b - a);   // of the entry -- one slice walking them all was the longest chain of this kernel
-                for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += ns) ms += P.lpart[(size_t)c * 28 + li];
-                for (int c = t_lch[K + 1 + k] + slice; c < t_lch[K + 2 + k]; c += ns) ms += P.lpart[(size_t)(P.n_pchunk + c) * 28 + li];
+                for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += ns) ms += rd(P.lpart + (size_t)c * 28 + li);
+                for (int c = t_lch[K + 1 + k] + slice; c < t_lch[K + 2 + k]; c += ns) ms += rd(P.lpart + (size_t)(P.n_pchunk + c) * 28 + li);
             }
             if (slice == 3 && j < 6 * K) {                     // ICP / LPS blocks live on pose columns
                 const int pi = i / 6, pj = j / 6, ri = i - 6 * pi, rj = j - 6 * pj;
                 for (int f = 0; f < n_rel; ++f)
                     for (int ba = 0; ba < 4; ++ba) if (t_rel[4 * f + ba] == pi) for (int bb = 0; bb < 4; ++bb) if (t_rel[4 * f + bb] == pj)
-                        ms += rel0[(size_t)f * 601 + (ba * 6 + ri) * 24 + bb * 6 + rj];
+                        ms += rd(rel0 + (size_t)f * 601 + (ba * 6 + ri) * 24 + bb * 6 + rj);
             }
             if (slice == 4 || slice == 5) {                    // IMU blocks, two slices split the factors
                 for (int f = slice - 4; f < P.n_imu; f += 2) {
                     const int la = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], i);
                     if (la < 0) continue;
                     const int lb = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], j);
-                    if (lb >= 0) ms += P.ipart[(size_t)f * 931 + la * 30 + lb];
+                    if (lb >= 0) ms += rd(P.ipart + (size_t)f * 931 + la * 30 + lb);
                 }
             }
             if (slice == 6 && P.pn > 0) { const int pi = P.pinv[i], pj = P.pinv[j]; if (pi >= 0 && pj >= 0) ms += P.pH[(size_t)pi * P.pn + pj]; }
@@ -669,7 +684,7 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
                 auto fetch = [&](const int4 ds, const bool live) -> double {
                     const int T = ds.w, il_ = vlocal(i, ds.y, ds.z), il = max(il_, 0), I = il >> 4;
                     const double* r = P.vpart + (size_t)ds.x * 16;
-                    const double val = which ? r[(I * T - ((I * (I - 1)) >> 1) + (T - 1 - I)) * 256 + ((6 * ds.z + 7) & 15) * 16 + (il & 15)] : r[vis_ntile(T) * 256 + il];
+                    const double val = which ? rd(r + (I * T - ((I * (I - 1)) >> 1) + (T - 1 - I)) * 256 + ((6 * ds.z + 7) & 15) * 16 + (il & 15)) : rd(r + vis_ntile(T) * 256 + il);
                     return (il_ >= 0 && live) ? val : 0.0;
                 };
                 for (int w = slice; w < nws; w += 256) {
@@ -683,12 +698,12 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
             }
             if (i < 6 * K) {
                 const int k = i / 6, a = i - 6 * k;
-                for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += 32) acc += P.lpart[(size_t)c * 28 + 21 + a];      // (chunk records dealt to the slices, as above)
-                for (int c = t_lch[K + 1 + k] + slice; c < t_lch[K + 2 + k]; c += 32) acc += P.lpart[(size_t)(P.n_pchunk + c) * 28 + 21 + a];
-                if (slice == 3) for (int f = 0; f < n_rel; ++f) for (int ba = 0; ba < 4; ++ba) if (t_rel[4 * f + ba] == k) acc += rel0[(size_t)f * 601 + 576 + ba * 6 + a];
+                for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += 32) acc += rd(P.lpart + (size_t)c * 28 + 21 + a);      // (chunk records dealt to the slices, as above)
+                for (int c = t_lch[K + 1 + k] + slice; c < t_lch[K + 2 + k]; c += 32) acc += rd(P.lpart + (size_t)(P.n_pchunk + c) * 28 + 21 + a);
+                if (slice == 3) for (int f = 0; f < n_rel; ++f) for (int ba = 0; ba < 4; ++ba) if (t_rel[4 * f + ba] == k) acc += rd(rel0 + (size_t)f * 601 + 576 + ba * 6 + a);
             }
-            if (slice == 4 || slice == 5) for (int f = slice - 4; f < P.n_imu; f += 2) { const int la = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], i); if (la >= 0) acc += P.ipart[(size_t)f * 931 + 900 + la]; }
-            if (slice == 6 && P.pn > 0) { const int pi = P.pinv[i]; if (pi >= 0) acc += P.mpart[pi]; }
+            if (slice == 4 || slice == 5) for (int f = slice - 4; f < P.n_imu; f += 2) { const int la = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], i); if (la >= 0) acc += rd(P.ipart + (size_t)f * 931 + 900 + la); }
+            if (slice == 6 && P.pn > 0) { const int pi = P.pinv[i]; if (pi >= 0) acc += rd(P.mpart + pi); }
         }
         part[0][slice * EPV + el] = acc;
         __syncthreads();
@@ -699,14 +714,14 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
         return;
     }
     // ---- cost (one workgroup, tree reduction) ---------------------------------------------------------------------
-    __shared__ double red[8];
     if (P.skip_mask & 64) return;
+    wait_sweep();
     double c = 0.0;
-    for (int w = t; w < P.n_vwg; w += 8 * EPW) { const int4 ds = vrec[w]; c += P.vpart[(size_t)ds.x * 16 + vis_ntile(ds.w) * 256 + 32 * ds.w]; }
-    for (int q = t; q < P.n_pchunk + P.n_echunk; q += 8 * EPW) c += P.lpart[(size_t)q * 28 + 27];
-    for (int f = t; f < P.n_imu; f += 8 * EPW) c += P.ipart[(size_t)f * 931 + 930];
-    for (int f = t; f < n_rel; f += 8 * EPW) c += rel0[(size_t)f * 601 + 600];
-    if (t == 0 && P.pn > 0) c += P.mpart[P.pn];
+    for (int w = t; w < P.n_vwg; w += 8 * EPW) { const int4 ds = vrec[w]; c += rd(P.vpart + (size_t)ds.x * 16 + vis_ntile(ds.w) * 256 + 32 * ds.w); }
+    for (int q = t; q < P.n_pchunk + P.n_echunk; q += 8 * EPW) c += rd(P.lpart + (size_t)q * 28 + 27);
+    for (int f = t; f < P.n_imu; f += 8 * EPW) c += rd(P.ipart + (size_t)f * 931 + 930);
+    for (int f = t; f < n_rel; f += 8 * EPW) c += rd(rel0 + (size_t)f * 601 + 600);
+    if (t == 0 && P.pn > 0) c += rd(P.mpart + P.pn);
     c = wave_sum(c);
     if ((t & 63) == 0) red[t >> 6] = c;
     __syncthreads();
@@ -738,37 +753,53 @@ __device__ __forceinline__ void sweep_signal(const DevP& P, const Ctl& ctl, int 
 // The sweep: grid = n_imu + 2 (+ 1: prechain 2) + n_vwg + ceil(n_pchunk / 2) + ceil(n_echunk / 2) workgroups of VIL_SWEEP_THREADS threads.
 // Workgroup order: [imu x n_imu | prior | rel | (chain) | visual x n_vwg | plane | edge] -- the short roles the chain workgroup waits for
 // come first (roles: top of this file)
-template <int TS>      // accumulator tiles per wave of the visual role
-__global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O) {
-    extern __shared__ double sm[];
-    const Ctl ctl = *P.ctl;
-    if (ctl.done) return;                                // (the result of a finished solve is written out by k_finish, vil_finish.hpp)
-    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctl->n_sweeps = ctl.n_sweeps + 1;   // live (not early-exited) launches, for the profiler
+// FUSED: the roles as workgroups of the one-launch iteration (k_iter, vil_iter.hpp): everything another workgroup of the launch reads goes out at agent scope,
+// and every workgroup ends by posting the launch epoch in P.sflag[b] (the gather workgroups wait for all of them, the chain workgroup for the IMU / prior ones)
+template <int TS, bool FUSED>      // TS: accumulator tiles per wave of the visual role
+__device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, const Ctl& ctl, double* const sm, const int blk) {
     const int cand = 1 - ctl.cur;
     const double* x = P.x[cand];
     SysBuf sb = P.sys[cand];
-    int b = blockIdx.x;
-    const bool pre = P.prechain == 2 && ctl.lin_mode == 0;
-    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm); if (pre) sweep_signal(P, ctl, b); return; }
+    int b = blk;
+    const bool pre = !FUSED && P.prechain == 2 && ctl.lin_mode == 0;
+    auto posted = [&]() {
+        if constexpr (FUSED) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores of the record (__syncthreads alone does not wait for global stores)
+            __syncthreads();
+            if (threadIdx.x == 0) vd::st_ag(P.sflag + blk, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u));
+        }
+    };
+    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm); if (pre) sweep_signal(P, ctl, b); posted(); return; }
     b -= P.n_imu;
-    if (b == 0) { if (!(P.skip_mask & 16)) vd::sweep_prior(P, x, sm); if (pre) sweep_signal(P, ctl, P.n_imu); return; }
+    if (b == 0) { if (!(P.skip_mask & 16)) vd::sweep_prior(P, x, sm); if (pre) sweep_signal(P, ctl, P.n_imu); posted(); return; }
     if (b == 1) {
-        if (!(P.skip_mask & 16)) vd::sweep_misc(P, O, x, sm);
+        if (!(P.skip_mask & 16)) vd::sweep_misc<FUSED>(P, O, x, sm);
         if (P.world > 1) {                               // factor set sharded over ranks: the visual workgroups of this rank form the candidate inverse depth of
             const double* xcur = P.x[ctl.cur];           // the landmarks it owns; every rank holds la / lb of ALL landmarks (the step kernel runs on the all-reduced
             double* xcand = P.x[1 - ctl.cur];            // system), so the rest is filled in here and the states stay identical on all ranks
             const bool stepped = ctl.cg != 0.0 || ctl.cn != 0.0;      // (as in sweep_visual: stale la / lb are not multiplied by zero)
             for (int l = threadIdx.x; l < P.L; l += blockDim.x) xcand[xo_lam(P) + l] = stepped ? xcur[xo_lam(P) + l] + ctl.cg * P.la[l] + ctl.cn * P.lb[l] : xcur[xo_lam(P) + l];
         }
+        posted();
         return;
     }
     b -= 2;
-    if (P.prechain == 2) { if (b == 0) { if (pre) vd::prechain_wg(P, ctl, O.jacobi_scaling, sm, 0, true); return; } b -= 1; }
+    if (!FUSED && P.prechain == 2) { if (b == 0) { if (pre) vd::prechain_wg(P, ctl, O.jacobi_scaling, sm, 0, true); return; } b -= 1; }
     // visual workgroups next: the longest-running factor role
-    if (b < P.n_vwg) { if (!(P.skip_mask & 1)) vd::sweep_visual<TS>(P, O, ctl, b, x, sb, sm); return; }
+    if (b < P.n_vwg) { if (!(P.skip_mask & 1)) vd::sweep_visual<TS, FUSED>(P, O, ctl, b, x, sb, sm); posted(); return; }
     b -= P.n_vwg;
     const int per = VIL_SWEEP_THREADS / 256, npw = (P.n_pchunk + per - 1) / per;
-    if (b < npw) { if (!(P.skip_mask & 4)) vd::sweep_lidar<1>(P, O, b, x, sm); return; }
+    if (b < npw) { if (!(P.skip_mask & 4)) vd::sweep_lidar<1, FUSED>(P, O, b, x, sm); posted(); return; }
     b -= npw;
-    if (!(P.skip_mask & 8)) vd::sweep_lidar<3>(P, O, b, x, sm);
+    if (!(P.skip_mask & 8)) vd::sweep_lidar<3, FUSED>(P, O, b, x, sm);
+    posted();
+}
+
+template <int TS>
+__global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O) {
+    extern __shared__ double sm[];
+    const Ctl ctl = *P.ctl;
+    if (ctl.done) return;                                // (the result of a finished solve is written out by k_finish, vil_finish.hpp)
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctl->n_sweeps = ctl.n_sweeps + 1;   // live (not early-exited) launches, for the profiler
+    sweep_body<TS, false>(P, O, ctl, sm, (int)blockIdx.x);
 }

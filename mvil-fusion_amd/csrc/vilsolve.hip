@@ -27,6 +27,7 @@
 #include "vil_sweep.hpp"
 #include "vil_eval.hpp"
 #include "vil_step.hpp"
+#include "vil_iter.hpp"
 #include "vil_marg.hpp"
 #include "vil_window.hpp"
 
@@ -235,6 +236,7 @@ __global__ void k_slim_emul(double* Msum, double* Gall, PeerPtrs pp, SlimLay Y) 
     }
 }
 
+#define VIL_SFLAG_MAX 4096      // sweep workgroups a one-launch iteration may have (configs[2]: ~600)
 struct vil_ctx {
     int device = 0, rank = 0, world = 1;
     hipStream_t stream = nullptr;
@@ -252,6 +254,7 @@ struct vil_ctx {
     std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
     int n_blocks_sweep = 0, n_blocks_reduce = 0, n_blocks_reduce_po = 0, n_gather_m = 0, n_ww = 0;      // n_ww: tiles of W W^T formed by extra workgroups of k_reduce (vil_prechain.hpp)
     size_t lds_sweep = 0, lds_step = 0, lds_reduce = 0;
+    bool fused = false; size_t lds_iter = 0; int cap_iter[2] = {-1, -1}; size_t cap_iter_lds[2] = {0, 0}; int attr_iter[2] = {0, 0};      // the one-launch iteration (k_iter<2 | 5>, vil_iter.hpp)
     int cap_step3 = -1; size_t cap_step3_lds = 0;      // workgroups of the merged gather + step launch the device holds at once AT THAT dynamic-LDS size (vil_coop.hpp)
     int vis_gm = 0;                      // doubles of operand rows the largest visual chunk of the uploaded window needs (vil_sweep.hpp)
     size_t span = 0;               // doubles of one linear-system set (SysBuf::ar): the multi-GPU all-reduce message
@@ -286,7 +289,7 @@ struct vil_ctx {
     int solves_since_upload = 0;
     bool split = false;            // sweep + gather fill set 0, the collective sums it into set 1, the step kernel reads set 1
     bool force_split = false;      // vil_debug_set_split: that plumbing on a single rank
-    int launch_mode = 0;           // vil_debug_set_launch_mode: 0 = the library's choice, 1 = no merged launch, 2 = no chain workgroup
+    int launch_mode = 0;           // vil_debug_set_launch_mode: 0 = the library's choice, 1 = no merged launch, 2 = no chain workgroup, 3 = sweep + merged gather / step launch (no one-launch iteration)
     int last_live = 5;             // live sweep launches of the previous solve (sizes the first launch chunk)
     int lm_b = 0, lm_e = 0;        // owned landmark range
     OwnSeg own = {0, 0, 0, {0}, {0}};      // every rank's landmark / factor range in the per-iteration message (sharded windows)
@@ -940,6 +943,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         put(nullptr, 8 * (size_t)2 * (NV + 1), (void**)&P.chZ); put(nullptr, 8 * 4, (void**)&P.chQ); put(nullptr, 16, (void**)&P.chOk);
         put(nullptr, 4 * (size_t)(gather_blocks(D, NV, RED_EPW, false) + 8), (void**)&P.gflag);      // (one flag per gather workgroup of the merged launch: never more than the gather kernel has)
         put(nullptr, 64, (void**)&P.chflag); put(nullptr, 4 * 64, (void**)&P.wwflag); put(nullptr, 4 * (size_t)(K + 8), (void**)&P.swflag);
+        put(nullptr, 4 * (size_t)VIL_SFLAG_MAX, (void**)&P.sflag);      // one flag per sweep workgroup of a one-launch iteration (taken only when there are fewer: below)
         { const size_t Tp = (size_t)(NV + 1 + 15) / 16; put(nullptr, 8 * (size_t)TILE_SZ * (Tp * (Tp + 1) / 2), (void**)&P.chWW); }
     }
     if (pre_ok) {
@@ -1094,7 +1098,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         // (round 4: every window size -- the gather of a prechain solve forms the visual sub-space only, 551 workgroups at K = 20 instead of 1500)
         int kmerge = 20;
         if (const char* ev = VIL_TUNE_ENV("VIL_MERGE_K")) kmerge = atoi(ev);
-        bool merged = can_pre && c->launch_mode == 0 && K <= kmerge && std::max(lds3, ldsc) + 52 * 1024 <= 160 * 1024 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
+        bool merged = can_pre && (c->launch_mode == 0 || c->launch_mode == 3) && K <= kmerge && std::max(lds3, ldsc) + 52 * 1024 <= 160 * 1024 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
         if (merged) {
             // the merged launch holds workgroups that spin on flags (master, helpers, one per W W^T tile) next to the finite ones they wait for (chain,
             // gather: lower block indices, dispatched first).  It is only taken when the device can hold every spinning workgroup AND one more at the
@@ -1124,6 +1128,23 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         c->n_gather_m = g64 ? gather_blocks(D, NV, 64, true) : gather_blocks(D, NV, RED_EPW, true);
         c->n_blocks_reduce_po = gather_blocks(D, NV, RED_EPW, true);
         c->P.rs_merged = merged ? (g64 ? 2 : 1) : 0; c->P.n_ww = c->n_ww; c->P.n_gather = merged ? c->n_gather_m : 0;
+        // ---- the whole iteration in ONE launch (k_iter, vil_iter.hpp): whenever the merged gather + step launch is taken, the kernel's single dynamic-LDS size
+        //      (the larger of the sweep roles' and the step roles' needs -- StepShared and the gather / tile scratch are carved from it) fits a compute unit, and
+        //      the device holds the workgroups that wait for one another (master, helpers, tiles) at once.  vil_debug_set_launch_mode(3) keeps the two launches.
+        c->fused = false; c->P.n_sw = 0;
+        if (merged && g64 && c->launch_mode == 0 && c->n_blocks_sweep <= VIL_SFLAG_MAX && VIL_TUNE_ENV("VIL_NO_FUSE") == nullptr) {
+            const size_t scratch = 8 * (size_t)(2 * VIS_TAB + 2 * 8 * (VIL_STEP_THREADS / 8) + 160);      // gather role: descriptor table | part[2][512] | index tables | red
+            const size_t step_need = 8 * (size_t)VIL_SS_DOUBLES + std::max(std::max(lds3, ldsc), scratch);
+            const size_t li = std::max(c->lds_sweep, step_need);
+            const int v = P.vis_ts == 2 ? 0 : 1;
+            const void* fn = v ? (const void*)k_iter<5> : (const void*)k_iter<2>;
+            if (li <= 160 * 1024) {
+                if ((int)li > c->attr_iter[v]) { HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)li)); c->attr_iter[v] = (int)li; }
+                if (c->cap_iter[v] < 0 || c->cap_iter_lds[v] != li) { c->cap_iter[v] = vilcoop::capacity(fn, VIL_STEP_THREADS, li, c->device); c->cap_iter_lds[v] = li; }
+                const int Tw = (int)(Tp_ * (Tp_ + 1) / 2);
+                if (c->cap_iter[v] >= 1 + P.n_help + Tw + 2) { c->fused = true; c->lds_iter = li; c->P.n_sw = c->n_blocks_sweep; }
+            }
+        }
     }
     if (P.chain) {
         c->step_lds = true;
@@ -1374,6 +1395,15 @@ static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
     else hipLaunchKernelGGL(k_sweep<5>, dim3(c->n_blocks_sweep), dim3(VIL_SWEEP_THREADS), c->lds_sweep, c->stream, view(c, 0), so);
     return VIL_OK;
 }
+// one trust-region iteration as ONE launch (vil_iter.hpp); only un-sharded solves of a window the upload marked `fused`
+static int launch_iter(vil_ctx* c, const SolveOpts& so) {
+    DevP Pi = c->P;
+    Pi.gather_pose_only = 1;
+    const dim3 g(c->n_blocks_sweep + 1 + c->n_gather_m + 1 + c->P.n_help + c->n_ww), b(VIL_STEP_THREADS);      // [sweep roles | chain | gather | master | helpers | W W^T tiles]
+    if (c->P.vis_ts == 2) hipLaunchKernelGGL(k_iter<2>, g, b, c->lds_iter, c->stream, Pi, so);
+    else hipLaunchKernelGGL(k_iter<5>, g, b, c->lds_iter, c->stream, Pi, so);
+    return VIL_OK;
+}
 static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr, hipEvent_t ev_coll = nullptr) {
     const bool merged = step && c->P.rs_merged;          // one GPU: the gather rides in the step kernel's launch (vil_step.hpp)
     // (chain eliminated inside k_sweep: one workgroup per W W^T tile rides in the gather launch, one for the inverses of the chain's diagonal blocks in the step launch;
@@ -1497,7 +1527,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
                 hipGraph_t graph = nullptr;
                 HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
                 int cst = VIL_OK;
-                for (int q = 0; q < nthis && cst == VIL_OK; ++q) { launch_sweep(c, so); cst = launch_reduce_step(c, so, true, nullptr); }
+                for (int q = 0; q < nthis && cst == VIL_OK; ++q) { if (c->fused) cst = launch_iter(c, so); else { launch_sweep(c, so); cst = launch_reduce_step(c, so, true, nullptr); } }
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(VIL_SWEEP_THREADS), 0, c->stream, view(c, 0), -1);
                 const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
                 if (cst != VIL_OK || ce != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
@@ -1516,6 +1546,13 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
         if (launched == 0) {
             for (int q = 0; q < chunk && it <= o->max_iterations + 8; ++q, ++it, ++launched) {
                 if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q], c->stream));
+                if (c->fused) {
+                    // (one launch: the events bracket the whole iteration; what the sweep roles took inside it comes from the launch's own clock stamps, below)
+                    if (c->profiling) { HIPCHK(hipEventRecord(c->ev[2 * q + 1], c->stream)); HIPCHK(hipEventRecord(c->ev_mid[q], c->stream)); HIPCHK(hipEventRecord(c->ev_coll[q], c->stream)); }
+                    st = launch_iter(c, so);
+                    if (st != VIL_OK) return st;
+                    continue;
+                }
                 launch_sweep(c, so);
                 if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q + 1], c->stream));
                 st = launch_reduce_step(c, so, true, c->profiling ? c->ev_mid[q] : nullptr, c->profiling ? c->ev_coll[q] : nullptr);
@@ -1997,7 +2034,7 @@ int vil_comm_message_bytes(vil_ctx* c, int64_t* bytes_per_peer, int64_t* bytes_f
 }
 
 // ---- window residency across frames (include/vilsolve.h) ------------------------------------------------------------------------
-int vil_debug_set_launch_mode(vil_ctx* c, int32_t mode) { if (!c || mode < 0 || mode > 2) return VIL_ERR_INVALID_ARGUMENT; c->launch_mode = mode; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
+int vil_debug_set_launch_mode(vil_ctx* c, int32_t mode) { if (!c || mode < 0 || mode > 3) return VIL_ERR_INVALID_ARGUMENT; c->launch_mode = mode; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
 int vil_comm_info(vil_ctx* c, int32_t* rank, int32_t* world, int32_t* transport) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
     if (rank) *rank = c->rank;

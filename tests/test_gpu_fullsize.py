@@ -33,10 +33,11 @@ def test_full_size_solve_and_marginalisation_parity(hip, oracle, cid):
     assert np.abs(J.T @ J - Ag).max() <= 1e-9 * np.abs(Ag).max()
 
 
-@pytest.mark.parametrize("cid,mode", [(2, 1), (2, 2), (4, 1), (4, 2), (1, 1)])
+@pytest.mark.parametrize("cid,mode", [(2, 1), (2, 2), (4, 1), (4, 2), (1, 1), (2, 3), (3, 3), (4, 3), (1, 3)])
 def test_fallback_launch_structures_match_the_oracle(oracle, cid, mode):
-    """What a single-GPU solve launches when the gather + step launch cannot be taken (vil_debug_set_launch_mode; never on an MI355X at BASELINE's sizes,
-    so forced here): mode 1 = separate gather launch, the speed-bias chain eliminated by a workgroup of the sweep launch behind the IMU / prior
+    """What a single-GPU solve launches when the one-launch iteration (k_iter) cannot be taken (vil_debug_set_launch_mode; never on an MI355X at BASELINE's sizes,
+    so forced here): mode 3 = the sweep launch followed by the merged gather + step launch (round 4's structure: a device that cannot hold the one launch's
+    waiting workgroups, or a window whose sweep and step roles do not fit one dynamic-LDS size); mode 1 = separate gather launch, the speed-bias chain eliminated by a workgroup of the sweep launch behind the IMU / prior
     workgroups' flags, its W W^T tiles on workgroups of the gather launch, the inverses of its diagonal blocks on a workgroup of the step launch;
     mode 2 = the step kernel eliminates the chain itself.  Same trust-region trajectory and solution as the oracle, resident re-solves included."""
     be = lib.open_vilsolve()
@@ -56,7 +57,7 @@ def test_fallback_launch_structures_match_the_oracle(oracle, cid, mode):
         assert (s2.iterations, s2.termination) == (so.iterations, so.termination) and s2.final_cost == sg.final_cost
     mg, mo = be.marginalize(wg, abi.MARGIN_OLD), oracle.marginalize(wo, abi.MARGIN_OLD)
     assert mg.c.n == mo.c.n and np.abs(mg.A_matrix() - mo.A_matrix()).max() <= (1e-8 if wo.prior.n else 1e-4) * np.abs(mo.A_matrix()).max()
-    assert be.lib.vil_debug_set_launch_mode(be.ctx, 3) != 0
+    assert be.lib.vil_debug_set_launch_mode(be.ctx, 4) != 0
     be.close()
 
 
