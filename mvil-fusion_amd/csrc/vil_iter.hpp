@@ -1,14 +1,15 @@
 // One trust-region iteration in ONE launch (single GPU, chain windows): the factor sweep, the gather of its records, the elimination of the speed-bias chain
 // and the step (judge, dense solve, dogleg, candidate) as roles of a single grid
-//   [ sweep roles: imu x n_imu | prior | rel | visual x n_vwg | plane | edge ]  [ chain | gather x n_gather | master | helpers x n_help | W W^T tiles x n_ww ]
+//   [ sweep roles: imu x n_imu | prior | rel | visual x n_vwg | plane | edge ]  [ chain | master | helpers x n_help | W W^T tiles x n_ww | gather x n_gather ]
 // instead of k_sweep followed by the merged gather + step launch (k_step, rs_merged).  What the second launch could not overlap is what this one buys:
 //   * the chain workgroup starts behind the IMU / prior workgroups' flags (~5 us into the launch) and eliminates the chain UNDER the visual workgroups and
 //     the gather -- in the two-launch structure it was one of the two ~20 us legs the master waited for before its dense factorisation;
 //   * the gather workgroups are resident and staged when the last visual record lands (no launch ramp between them);
 //   * one launch boundary per iteration instead of two.
-// Every workgroup waits only for workgroups with LOWER block indices (the hardware dispatches in index order, so what a resident workgroup waits for is resident
-// or done), except the master / helpers / tile workgroups at the end of the grid, which wait for one another and are dispatched once the sweep roles have
-// left their compute units (vil_coop.hpp: the launch is taken only when the device holds all of them at once).  Everything that crosses workgroups inside
+// The sweep roles and the chain workgroup wait for LOWER block indices only (the hardware dispatches in index order: what a resident workgroup waits for is
+// resident or done).  Master, helpers and tile workgroups wait for one another and for the gather workgroups BEHIND them in the grid: they are few, resident from
+// the start (their prologues run under the sweep), and the launch is only taken when the device holds all of them plus two more workgroups at once
+// (vil_coop.hpp), so the gather workgroups always find compute units to run through.  Everything that crosses workgroups inside
 // the launch is stored and loaded at agent scope (st_ag / ld_ag; template parameters AG / FUSED of the roles), flags carry the launch epoch
 // (solve generation, launches so far) -- no fences, no atomics on data.
 // The kernel has NO static LDS: StepShared and the scratch arrays of the gather / tile roles are carved from the dynamic allocation, whose size is the LARGER

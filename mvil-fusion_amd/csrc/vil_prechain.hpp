@@ -149,6 +149,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     }
     __syncthreads();
     PSTAMP(31);
+    if (FUSED && t == 0) prof_stamp(P, epoch - 1, 3);
     if (wait_records) sources();                           // (inside k_sweep the records are complete only behind the flags)
     for (int e0 = t; e0 < n; e0 += QN * NT) {
         if (e0 != t) {
@@ -164,6 +165,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     }
     __syncthreads();
     PSTAMP(13);
+    if (FUSED && t == 0) prof_stamp(P, epoch - 1, 14);
     const ChainSrcSlab src{P, B, scB, dcB, uB, ctl.mu};
     if (t < NB) {
         const int j = NP + t;
@@ -204,7 +206,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     if (t == 0) st_ag(P.chOk, L.flag[5] ? 0 : 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every thread's W^T / chZ / chQ stores are out ...
     __syncthreads();
-    if (t == 0) st_ag(P.chflag, epoch);                  // ... W^T is complete: the tile workgroups start
+    if (t == 0) { st_ag(P.chflag, epoch); if (FUSED) prof_stamp(P, epoch - 1, 4); }                  // ... W^T is complete: the tile workgroups start
     // ---- off the critical path: what the master needs for the chain BACK substitution, 30 us from now (chain_inverse_block above).  Beside the gather
     //      (merged launch) the 9 K columns are formed here, one per lane, and are ready long before they are read.  Inside k_sweep (fallback launch structure) this workgroup
     //      is the launch's longest and 7 us of dependent fp64 chains at its end would be 7 us of the iteration: the raw factors go out instead and a

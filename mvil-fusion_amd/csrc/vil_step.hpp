@@ -876,6 +876,7 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
         for (int i = t; i < P.n_ww; i += VIL_STEP_THREADS) while (__hip_atomic_load(P.wwflag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
         __syncthreads();                               // (everything they left is read at agent scope below: no fence)
     }
+    if (t == 0) prof_stamp(P, epoch - 1, 9);
     SSTAMP(1);
     // (the chain workgroup's last flag -- factors for the chain back substitution, written ~4 us after W -- rides in the round trip of the W W^T loads:
     //  a thread that sees it posted here needs neither a poll nor a barrier after the dense part)
@@ -917,8 +918,10 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
         if (!chol_lookahead<3, false>(Tl, NP, s)) return false;
     } else if (!chol_lookahead<CH_SLOTS, false>(Tl, NP, s)) return false;
     SSTAMP(4);
+    if (t == 0) prof_stamp(P, epoch - 1, 10);
     back_subst(Tl, NP, s);
     pub();
+    if (t == 0) prof_stamp(P, epoch - 1, 11);
     SSTAMP(5);
     // ---- chain back substitution.  What it needs from the chain workgroup (inverses of the factored diagonal blocks, sub-diagonal blocks, W^T) in ONE
     //      round trip: every load of a thread in flight together
@@ -1052,6 +1055,12 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     if (merged) {
         const int pc = P.prechain ? 1 : 0;
         if (pc && p0 == 0) bid = 1 + nhelp;
+        else if (FUSED) {
+            // one-launch iteration: [chain | master | helpers | tiles | gather] -- the few workgroups that wait for others are resident from the start (their prologues
+            // run under the sweep; the device holds them beside the workgroups they wait for: vilsolve.hip), the many gather workgroups take the slots the sweep roles free
+            const int q = p0 - pc;
+            bid = q <= nhelp ? q : (q - 1 - nhelp < P.n_ww ? 1 + nhelp + pc + (q - 1 - nhelp) : 1 + nhelp + pc + P.n_ww + (q - 1 - nhelp - P.n_ww));
+        }
         else if (p0 - pc < P.n_gather) bid = 1 + nhelp + pc + P.n_ww + (p0 - pc);
         else { const int q = p0 - pc - P.n_gather; bid = q <= nhelp ? q : 1 + nhelp + pc + (q - 1 - nhelp); }
     }
@@ -1074,6 +1083,8 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     __syncthreads();
     // (one-launch iteration: nobody else has counted this launch -- every role forms the epoch from the n_sweeps it READ, the master stores the new count)
     const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps + 1u);
+    const int lidx = epoch - 1;                                      // launch slot of the phase stamps (its low six bits)
+    auto PROF = [&](int k, bool mn = false) { if (FUSED && t == 0) prof_stamp(P, lidx, k, mn); };
     __syncthreads();
     if (t == 0) { s.c.swe++; if (FUSED) s.c.n_sweeps++; }      // (every path that writes Ctl back carries the new swe)
     __syncthreads();
@@ -1094,15 +1105,17 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         if constexpr (FUSED) reduce_gather<true, VIL_STEP_THREADS / 8, true>(P, s.c, bid - b_gather, (int4*)Alds, epoch);      // (waits for the sweep workgroups' flags behind its own table staging)
         else if (P.rs_merged == 2) reduce_gather<true, VIL_STEP_THREADS / 8>(P, s.c, bid - b_gather, (int4*)Alds);      // 64 entries, all 512 threads
         else { if (t >= VIL_THREADS) return; reduce_gather<true, RED_EPW>(P, s.c, bid - b_gather, (int4*)Alds); }      // (descriptor table in the dynamic LDS this role does not use otherwise)   // 32 entries on the first four waves
-        rs_signal(P.gflag + (bid - b_gather)); return;
+        rs_signal(P.gflag + (bid - b_gather)); PROF(5); return;
     }
     if (merged && bid >= b_ww) {
         if (t >= VIL_THREADS) return;                  // a 256-thread role: the upper waves leave before the first barrier
-        rs_wait(P.chflag, 1); prechain_ww_tile<FUSED>(P, bid - b_ww, Alds); rs_signal(P.wwflag + (bid - b_ww)); return;
+        rs_wait(P.chflag, 1); prechain_ww_tile<FUSED>(P, bid - b_ww, Alds); rs_signal(P.wwflag + (bid - b_ww)); PROF(13); return;
     }
     if (merged && P.prechain && bid == b_chain) { prechain_wg<FUSED>(P, s.c, O.jacobi_scaling, Alds, epoch, FUSED); return; }      // (posts chflag[0 .. 2] itself; one-launch iteration: behind the IMU / prior workgroups' flags)
     if (!merged && P.prechain == 2 && bid == b_chain) { prechain_inverses(P, Alds, epoch); return; }                 // (chain eliminated inside k_sweep: posts chflag[2])
+    if (bid == 0) PROF(7);
     if (merged) rs_wait(P.gflag, P.n_gather);          // master and helpers: the candidate's cost, gradient and diagonal (and S') are complete
+    if (bid == 0) PROF(8);
     // Everything the master and its helpers hand each other inside this launch (hpart, hpart2, stepc) is stored AND loaded with agent-scope
     // atomics, i.e. at the level all XCDs share, so a flag only has to be ordered after the poster's own stores (s_waitcnt).  A release
     // fence would also write back the XCD's L2 and an acquire invalidate the reader's: microseconds on the critical path, for data
@@ -1596,6 +1609,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     if (s.c.resweep && !s.c.done) { for (int i = t; i < 16 * P.K + 8; i += NT) xc[i] = s.x0[i]; }
     STAMP(7);
     if (t < 64) { wait_helpers(); store_ctl(); }      // (no second poll when the sums were already collected)
+    PROF(12);
 }
 
 template <bool LDSM, int CHAIN = 0>

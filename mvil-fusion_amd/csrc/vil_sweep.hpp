@@ -547,10 +547,14 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
     using namespace vd;
     auto put = [](double* p, double v) { if (AG) st_ag(p, v); else *p = v; };
     auto rd = [](const double* p) -> double { return ldx<FUSED>(p); };          // a sweep record
-    auto wait_sweep = [&]() {
+    // the visual workgroups are the sweep's longest (15 us against ~9 for everything else): a gather workgroup first waits for the OTHER roles' flags, sums their
+    // records while the visual workgroups are still at work, and only then waits for the visual records -- one round of loads behind the last of them
+    auto wait_sweep = [&](const bool visual) {
         if constexpr (FUSED) {
-            for (int i = threadIdx.x; i < P.n_sw; i += 8 * EPW) while (ld_ag(P.sflag + i) != epoch) __builtin_amdgcn_s_sleep(1);
+            const int v0 = P.n_imu + 2, nv = P.n_vwg, n = visual ? nv : P.n_sw - nv;
+            for (int i = threadIdx.x; i < n; i += 8 * EPW) { const int* f = P.sflag + (visual ? v0 + i : (i < v0 ? i : i + nv)); while (ld_ag(f) != epoch) __builtin_amdgcn_s_sleep(1); }
             __syncthreads();
+            if (visual && threadIdx.x == 0) prof_stamp(P, epoch - 1, 6);
         }
     };
     if ((int)threadIdx.x >= 8 * EPW) return;
@@ -584,7 +588,6 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
             if (t >= 8 * EPW - 32 && t < 8 * EPW - 32 + K) t_wend[t - (8 * EPW - 32)] = P.vwend[t - (8 * EPW - 32)];      // (K <= 20)
         }
         __syncthreads();
-        wait_sweep();
     };
     if (blk < nSblk) {
         if (P.skip_mask & 32) return;
@@ -607,6 +610,33 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
             // consecutive lanes -> consecutive rows i of one column j, which are consecutive addresses in the (transposed) tiles of the visual records
             j = a; i = idx - (a * (a + 1)) / 2;
         }
+        wait_sweep(false);
+        // the non-visual contributions are spread over the slices of an entry
+        double ms = 0.0;
+        if (ok) {
+            if (j < 6 * K && i / 6 == j / 6) {                 // LiDAR plane and edge points: pose-diagonal blocks.  The chunk records of a pose
+                const int k = i / 6, a = i - 6 * k, b = j - 6 * k;   // (one per 256 points: 9 per pose at 24 k points, 37 at 96 k) are dealt to the slices
+                const int li = a * 6 - ((a * (a - 1)) >> 1) + (b - a);   // of the entry -- one slice walking them all was the longest chain of this kernel
+                for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += ns) ms += rd(P.lpart + (size_t)c * 28 + li);
+                for (int c = t_lch[K + 1 + k] + slice; c < t_lch[K + 2 + k]; c += ns) ms += rd(P.lpart + (size_t)(P.n_pchunk + c) * 28 + li);
+            }
+            // ICP / LPS and IMU factors are DEALT to the slices of an entry (factor f of the <= 12 ICP / LPS factors on slice 8 + f, IMU factor f on slice 20 + f, modulo the
+            // entry's slices): every slice issues at most a load or two -- one slice walking all ICP / LPS factors was a chain of up to six dependent round trips
+            // (~1.5 us each at agent scope), the longest path of the gather
+            if (j < 6 * K) {                                   // ICP / LPS blocks live on pose columns
+                const int pi = i / 6, pj = j / 6, ri = i - 6 * pi, rj = j - 6 * pj;
+                for (int f = (slice + ns - (8 % ns)) % ns; f < n_rel; f += ns)
+                    for (int ba = 0; ba < 4; ++ba) if (t_rel[4 * f + ba] == pi) for (int bb = 0; bb < 4; ++bb) if (t_rel[4 * f + bb] == pj)
+                        ms += rd(rel0 + (size_t)f * 601 + (ba * 6 + ri) * 24 + bb * 6 + rj);
+            }
+            for (int f = (slice + ns - (20 % ns)) % ns; f < P.n_imu; f += ns) {
+                const int la = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], i), lb = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], j);
+                const double v = rd(P.ipart + (size_t)f * 931 + max(la, 0) * 30 + max(lb, 0));      // (unconditional load + select)
+                ms += (la >= 0 && lb >= 0) ? v : 0.0;
+            }
+            if (slice == 6 && P.pn > 0) { const int pi = P.pinv[i], pj = P.pinv[j]; if (pi >= 0 && pj >= 0) ms += P.pH[(size_t)pi * P.pn + pj]; }
+        }
+        if (vis) wait_sweep(true);      // (workgroup-uniform; the other entries have no visual part)
         double vs = 0.0, vdg = 0.0;
         if (vis && ok) {
             // eight records per round and thread, every load issued before the first add (clamped record / element + select: no predicated loads); with
@@ -633,31 +663,6 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
             }
             for (int w = VIS_TAB + slice; w < nw; w += 32) { double a, d; fetch(vrec[w], true, a, d); vs += a; vdg += d; }      // (windows with more than VIS_TAB chunks)
         }
-        // the non-visual contributions are spread over the slices of an entry
-        double ms = 0.0;
-        if (ok) {
-            if (j < 6 * K && i / 6 == j / 6) {                 // LiDAR plane and edge points: pose-diagonal blocks.  The chunk records of a pose
-                const int k = i / 6, a = i - 6 * k, b = j - 6 * k;   // (one per 256 points: 9 per pose at 24 k points, 37 at 96 k) are dealt to the slices
-                const int li = a * 6 - ((a * (a - 1)) >> 1) + (b - a);   // of the entry -- one slice walking them all was the longest chain of this kernel
-                for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += ns) ms += rd(P.lpart + (size_t)c * 28 + li);
-                for (int c = t_lch[K + 1 + k] + slice; c < t_lch[K + 2 + k]; c += ns) ms += rd(P.lpart + (size_t)(P.n_pchunk + c) * 28 + li);
-            }
-            if (slice == 3 && j < 6 * K) {                     // ICP / LPS blocks live on pose columns
-                const int pi = i / 6, pj = j / 6, ri = i - 6 * pi, rj = j - 6 * pj;
-                for (int f = 0; f < n_rel; ++f)
-                    for (int ba = 0; ba < 4; ++ba) if (t_rel[4 * f + ba] == pi) for (int bb = 0; bb < 4; ++bb) if (t_rel[4 * f + bb] == pj)
-                        ms += rd(rel0 + (size_t)f * 601 + (ba * 6 + ri) * 24 + bb * 6 + rj);
-            }
-            if (slice == 4 || slice == 5) {                    // IMU blocks, two slices split the factors
-                for (int f = slice - 4; f < P.n_imu; f += 2) {
-                    const int la = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], i);
-                    if (la < 0) continue;
-                    const int lb = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], j);
-                    if (lb >= 0) ms += rd(P.ipart + (size_t)f * 931 + la * 30 + lb);
-                }
-            }
-            if (slice == 6 && P.pn > 0) { const int pi = P.pinv[i], pj = P.pinv[j]; if (pi >= 0 && pj >= 0) ms += P.pH[(size_t)pi * P.pn + pj]; }
-        }
         part[0][slice * epw + el] = vs + ms; part[1][slice * epw + el] = vdg - vs;     // [1]: un-reduced minus reduced visual diagonal
         __syncthreads();
         if (slice != 0 || !ok) return;
@@ -677,7 +682,19 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
         const int v = (blk - nSblk) * EPV + el;
         const bool ok = v < 2 * D;
         const int which = v >= D ? 1 : 0, i = which ? v - D : v;       // 0: bc, 1: gred
-        double acc = 0.0;
+        double acc = 0.0, accv = 0.0;                  // the other roles' records first (their workgroups finish long before the visual ones), then the visual records
+        wait_sweep(false);
+        if (ok) {
+            if (i < 6 * K) {
+                const int k = i / 6, a = i - 6 * k;
+                for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += 32) acc += rd(P.lpart + (size_t)c * 28 + 21 + a);      // (chunk records dealt to the slices, as above)
+                for (int c = t_lch[K + 1 + k] + slice; c < t_lch[K + 2 + k]; c += 32) acc += rd(P.lpart + (size_t)(P.n_pchunk + c) * 28 + 21 + a);
+                for (int f = (slice + 32 - 8) % 32; f < n_rel; f += 32) for (int ba = 0; ba < 4; ++ba) if (t_rel[4 * f + ba] == k) acc += rd(rel0 + (size_t)f * 601 + 576 + ba * 6 + a);      // (factors dealt to the slices, as above)
+            }
+            for (int f = (slice + 32 - 20) % 32; f < P.n_imu; f += 32) { const int la = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], i); const double v = rd(P.ipart + (size_t)f * 931 + 900 + max(la, 0)); acc += la >= 0 ? v : 0.0; }
+            if (slice == 6 && P.pn > 0) { const int pi = P.pinv[i]; if (pi >= 0) acc += rd(P.mpart + pi); }
+        }
+        wait_sweep(true);
         if (ok) {
             if (i < NV) {                              // bc: the record's vector; gred: column r of its last tile column.  Eight records per round and thread, as above
                 const int nw = i < 6 * K ? t_wend[i / 6] : P.n_vwg, nws = min(nw, VIS_TAB), wlast = max(nws - 1, 0);
@@ -692,20 +709,12 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
 #pragma unroll
                     for (int u = 0; u < 8; ++u) a[u] = fetch(vtab[min(w + 32 * u, wlast)], w + 32 * u < nws);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) acc += a[u];
+                    for (int u = 0; u < 8; ++u) accv += a[u];
                 }
-                for (int w = VIS_TAB + slice; w < nw; w += 32) acc += fetch(vrec[w], true);
+                for (int w = VIS_TAB + slice; w < nw; w += 32) accv += fetch(vrec[w], true);
             }
-            if (i < 6 * K) {
-                const int k = i / 6, a = i - 6 * k;
-                for (int c = t_lch[k] + slice; c < t_lch[k + 1]; c += 32) acc += rd(P.lpart + (size_t)c * 28 + 21 + a);      // (chunk records dealt to the slices, as above)
-                for (int c = t_lch[K + 1 + k] + slice; c < t_lch[K + 2 + k]; c += 32) acc += rd(P.lpart + (size_t)(P.n_pchunk + c) * 28 + 21 + a);
-                if (slice == 3) for (int f = 0; f < n_rel; ++f) for (int ba = 0; ba < 4; ++ba) if (t_rel[4 * f + ba] == k) acc += rd(rel0 + (size_t)f * 601 + 576 + ba * 6 + a);
-            }
-            if (slice == 4 || slice == 5) for (int f = slice - 4; f < P.n_imu; f += 2) { const int la = imu_local(P, t_imu[2 * f], t_imu[2 * f + 1], i); if (la >= 0) acc += rd(P.ipart + (size_t)f * 931 + 900 + la); }
-            if (slice == 6 && P.pn > 0) { const int pi = P.pinv[i]; if (pi >= 0) acc += rd(P.mpart + pi); }
         }
-        part[0][slice * EPV + el] = acc;
+        part[0][slice * EPV + el] = accv + acc;
         __syncthreads();
         if (slice != 0 || !ok) return;
         double sum = 0.0;
@@ -715,7 +724,7 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
     }
     // ---- cost (one workgroup, tree reduction) ---------------------------------------------------------------------
     if (P.skip_mask & 64) return;
-    wait_sweep();
+    wait_sweep(false); wait_sweep(true);
     double c = 0.0;
     for (int w = t; w < P.n_vwg; w += 8 * EPW) { const int4 ds = vrec[w]; c += rd(P.vpart + (size_t)ds.x * 16 + vis_ntile(ds.w) * 256 + 32 * ds.w); }
     for (int q = t; q < P.n_pchunk + P.n_echunk; q += 8 * EPW) c += rd(P.lpart + (size_t)q * 28 + 27);
@@ -762,11 +771,12 @@ __device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, co
     SysBuf sb = P.sys[cand];
     int b = blk;
     const bool pre = !FUSED && P.prechain == 2 && ctl.lin_mode == 0;
+    if (FUSED && threadIdx.x == 0) prof_stamp(P, ctl.n_sweeps, 0, true);
     auto posted = [&]() {
         if constexpr (FUSED) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores of the record (__syncthreads alone does not wait for global stores)
             __syncthreads();
-            if (threadIdx.x == 0) vd::st_ag(P.sflag + blk, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u));
+            if (threadIdx.x == 0) { vd::st_ag(P.sflag + blk, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u)); prof_stamp(P, ctl.n_sweeps, blk < P.n_imu ? 2 : (blk == P.n_imu ? 15 : 1)); }
         }
     };
     if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm); if (pre) sweep_signal(P, ctl, b); posted(); return; }

@@ -332,6 +332,7 @@ struct vil_ctx {
         size_t prior_doubles() const { return 2 * (size_t)nmax * nmax + 2 * (size_t)nmax + x0max + 8; }
     } win;
     bool profiling = false;
+    long long* d_prof = nullptr; double phase_us[VIL_PROF_SLOTS] = {0}; long long phase_n = 0;      // phase stamps of the one-launch iterations (vil_profile_phases)
     std::vector<hipEvent_t> ev, ev_mid, ev_coll;
     vil_profile prof = {0, 0.0, 0, 0.0, 0.0};
 };
@@ -450,6 +451,7 @@ void vil_destroy(vil_ctx* c) {
     if (c->chtab_ev) hipEventDestroy(c->chtab_ev);
     if (c->ipc_tmp) hipFree(c->ipc_tmp);
     if (c->slim_buf) hipFree(c->slim_buf);
+    if (c->d_prof) hipFree(c->d_prof);
     if (c->ipc) { for (int r = 0; r < c->ipc->world; ++r) if (r != c->ipc->rank && c->ipc->peer_base[r]) hipIpcCloseMemHandle(c->ipc->peer_base[r]); if (c->ipc->base) hipFree(c->ipc->base); c->ipc.reset(); }
     if (c->d_pl) hipFree(c->d_pl);
     if (c->d_ed) hipFree(c->d_ed);
@@ -1399,7 +1401,8 @@ static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
 static int launch_iter(vil_ctx* c, const SolveOpts& so) {
     DevP Pi = c->P;
     Pi.gather_pose_only = 1;
-    const dim3 g(c->n_blocks_sweep + 1 + c->n_gather_m + 1 + c->P.n_help + c->n_ww), b(VIL_STEP_THREADS);      // [sweep roles | chain | gather | master | helpers | W W^T tiles]
+    Pi.prof = c->profiling ? c->d_prof : nullptr;
+    const dim3 g(c->n_blocks_sweep + 1 + c->n_gather_m + 1 + c->P.n_help + c->n_ww), b(VIL_STEP_THREADS);      // [sweep roles | chain | master | helpers | W W^T tiles | gather]
     if (c->P.vis_ts == 2) hipLaunchKernelGGL(k_iter<2>, g, b, c->lds_iter, c->stream, Pi, so);
     else hipLaunchKernelGGL(k_iter<5>, g, b, c->lds_iter, c->stream, Pi, so);
     return VIL_OK;
@@ -1459,7 +1462,19 @@ int vil_profile_enable(vil_ctx* c, int on) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(c->device));
     if (on && c->ev.empty()) { c->ev.resize(40); for (auto& e : c->ev) HIPCHK(hipEventCreate(&e)); c->ev_mid.resize(20); for (auto& e : c->ev_mid) HIPCHK(hipEventCreate(&e)); c->ev_coll.resize(20); for (auto& e : c->ev_coll) HIPCHK(hipEventCreate(&e)); }
+    if (on && !c->d_prof) HIPCHK(hipMalloc((void**)&c->d_prof, 8 * 64 * VIL_PROF_SLOTS));
     c->profiling = on != 0;
+    return VIL_OK;
+}
+/* average position (us after the launch's first workgroup started) of the phase stamps of the one-launch iterations timed since the last reset:
+ * [0] 0, [1] last visual / LiDAR / ICP-LPS role done, [2] last IMU role done, [3] chain: records seen, [4] chain: W^T complete, [5] last gather workgroup done,
+ * [6] last gather workgroup saw the visual flags, [7] master started, [8] master saw the gather's flags, [9] master saw the W W^T tiles,
+ * [10] dense factorisation done, [11] x_p published, [12] master done, [13] last tile workgroup done, [14] chain: its part of S' gathered, [15] prior role done */
+int vil_profile_phases(vil_ctx* c, double* avg_us, int64_t* launches, int reset) {
+    if (!c || !avg_us) return VIL_ERR_INVALID_ARGUMENT;
+    for (int k = 0; k < VIL_PROF_SLOTS; ++k) avg_us[k] = c->phase_n ? c->phase_us[k] / (double)c->phase_n : 0.0;
+    if (launches) *launches = c->phase_n;
+    if (reset) { for (double& v : c->phase_us) v = 0.0; c->phase_n = 0; }
     return VIL_OK;
 }
 int vil_profile_read(vil_ctx* c, vil_profile* out, int reset) {
@@ -1503,6 +1518,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     }
     int st = init_ctl(c, o, 0);
     if (st != VIL_OK) return st;
+    if (c->profiling && c->fused && c->d_prof) HIPCHK(hipMemsetAsync(c->d_prof, 0, 8 * 64 * VIL_PROF_SLOTS, c->stream));
     // every iteration = sweep + gather + step kernel; `done` turns the tail of a chunk into no-ops, and the first sweep launch that finds
     // the solve finished writes the result out (vil_finish.hpp); k_finish at the end of every chunk covers a solve that ends in its last iteration
     bool finished = false, polled_done = false;
@@ -1610,6 +1626,21 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     c->solves_since_upload++;
     const Ctl& ctl = *c->h_ctl;
     c->last_live = ctl.n_sweeps;
+    if (c->profiling && c->fused && c->d_prof && ctl.n_sweeps <= 64) {
+        // the launches' own clock stamps (100 MHz): the sweep phase of a one-launch iteration = first workgroup started -> last sweep role posted
+        std::vector<unsigned long long> hp((size_t)64 * VIL_PROF_SLOTS);
+        HIPCHK(hipMemcpyAsync(hp.data(), c->d_prof, 8 * hp.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int q = 0; q < ctl.n_sweeps; ++q) {
+            const unsigned long long* r = hp.data() + (size_t)q * VIL_PROF_SLOTS;
+            if (!r[0] || !r[1]) continue;
+            const unsigned long long t0 = ~r[0];
+            for (int k = 1; k < VIL_PROF_SLOTS; ++k) if (r[k] >= t0) c->phase_us[k] += (double)(r[k] - t0) * 0.01;
+            c->phase_n++;
+            const double sweep_us = (double)(r[1] - t0) * 0.01, gather_us = r[5] > r[1] ? (double)(r[5] - r[1]) * 0.01 : 0.0;
+            c->prof.sweep_ms += sweep_us * 1e-3; c->prof.step_ms -= sweep_us * 1e-3; c->prof.reduce_ms += gather_us * 1e-3;      // (the events gave the whole launch to step_ms)
+        }
+    }
     memset(sum, 0, sizeof *sum);
     sum->iterations = ctl.iter; sum->successful_steps = ctl.nsucc; sum->termination = ctl.term;
     sum->initial_cost = ctl.initial_cost; sum->final_cost = ctl.cost_cur;
