@@ -33,3 +33,71 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_iter(DevP P, SolveOpts O) 
     vd::StepShared& s = *reinterpret_cast<vd::StepShared*>(dyn);
     step_body<true, 3, true>(P, O, s, dyn + VIL_SS_DOUBLES, (int)blockIdx.x - P.n_sw);
 }
+
+// ---- The whole SOLVE in one launch -----------------------------------------------------------------------------------------------------------------------------
+// What still separated two one-launch iterations was the launch boundary itself: ~12 us per iteration at configs[1] between the master's last store and the first
+// workgroup of the next launch (kernel teardown, the dispatch of 400 workgroups with 100 kB of LDS each, the graph's node-to-node hand-off) -- a sixth of the
+// iteration.  k_solve keeps every workgroup RESIDENT for the whole solve:
+//   [ chain | master | helpers x n_help | W W^T tiles x n_ww ]   dedicated workgroups, the roles of k_iter, one iteration after the other
+//   [ workers ]                                                     each takes sweep role `w` (then tickets from Ctl-indexed counters while there are more roles than
+//                                                                   workers), then gather item `w` (likewise)
+// and the master ends iteration n by posting the epoch of iteration n + 1 in P.goflag -- behind its own stores, the helpers' la / lb (hdone) and Ctl.  Every flag of
+// the iteration carries that epoch, so nothing is ever reset; everything that crosses workgroups is stored and loaded at agent scope, now including what used to
+// cross a launch boundary (Ctl, the candidate state, la / lb, the Jacobi scales).  Taken when the device holds the dedicated workgroups plus a worker for every
+// sweep role or gather item of the longer phase... or fewer: a worker then walks several (vilsolve.hip).  Every wait is bounded (spin_until_eq): a launch that cannot
+// finish raises P.abortf and ends; the host reports VIL_ERR_DEVICE.
+template <int TS>
+__global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(DevP P, SolveOpts O) {
+    extern __shared__ double dyn[];
+    const int t = threadIdx.x, b = (int)blockIdx.x;
+    const int nded = 2 + P.n_help + P.n_ww, nwk = (int)gridDim.x - nded, w = b - nded;
+    double* const tail = dyn + P.tail_off;                  // [Ctl head 32 | camera part of the candidate 336 | ticket]
+    double* const xs = tail + 32; int* const tick = (int*)(tail + 368);
+    const int gen = vd::ld_ag(&P.ctl->gen);                 // (written by the init launch)
+    constexpr int HEAD = (int)(offsetof(Ctl, cost_trace) / 8);
+    static_assert(offsetof(Ctl, cost_trace) % 8 == 0 && HEAD <= 32, "the workers copy the head of Ctl as doubles");
+    for (int n = 0; n <= O.max_iterations + 24; ++n) {
+        const int epoch = (int)((((unsigned)gen) << 12) + (unsigned)n + 1u);
+        if (t == 0) vd::spin_until_eq(P.goflag, epoch, P.abortf);
+        __syncthreads();
+        if (vd::ld_ag(P.abortf) != 0) return;
+        if (b < nded) {
+            vd::StepShared& s = *reinterpret_cast<vd::StepShared*>(dyn);
+            step_body<true, 3, true>(P, O, s, dyn + VIL_SS_DOUBLES, b);
+            __syncthreads();
+            if (s.done_at_entry) return;
+            continue;
+        }
+        if (t < HEAD) tail[t] = vd::ld_ag((const double*)P.ctl + t);
+        __syncthreads();
+        Ctl ctl;
+        { double* cd = (double*)&ctl; for (int i = 0; i < HEAD; ++i) cd[i] = tail[i]; }
+        if (ctl.done) return;
+        {   // the candidate's camera part (written by the master of the previous iteration) into LDS: the factor roles read poses, speeds / biases, extrinsic and td from there
+            const double* xg = P.x[1 - ctl.cur];
+            for (int i = t; i < 16 * P.K + 8; i += VIL_STEP_THREADS) xs[i] = vd::ld_ag(xg + i);
+        }
+        __syncthreads();
+        const bool qs = P.n_sw > nwk, qg = P.n_gather > nwk;      // more roles than workers: tickets (uniform)
+        for (int item = w; item < P.n_sw;) {
+            sweep_body<TS, true>(P, O, ctl, dyn, item, xs);
+            if (!qs) break;
+            __syncthreads();
+            if (t == 0) *tick = nwk + atomicAdd(P.qsweep + (n & 63), 1);
+            __syncthreads();
+            item = *tick;
+        }
+        __syncthreads();
+        for (int item = w; item < P.n_gather;) {
+            reduce_gather<true, VIL_STEP_THREADS / 8, true>(P, ctl, item, (int4*)dyn, epoch);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) { vd::st_ag(P.gflag + item, epoch); prof_stamp(P, epoch - 1, 5); }
+            if (!qg) break;
+            if (t == 0) *tick = nwk + atomicAdd(P.qgather + (n & 63), 1);
+            __syncthreads();
+            item = *tick;
+        }
+        __syncthreads();
+    }
+}

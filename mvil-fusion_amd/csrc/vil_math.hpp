@@ -227,6 +227,16 @@ __device__ __forceinline__ double ld_ag(const double* p) { return __hip_atomic_l
 __device__ __forceinline__ void st_ag(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ld_ag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_ag(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Wait for a flag another workgroup of the launch posts.  abortf == null: wait as long as it takes (launches whose waiting workgroups the dispatch order protects).
+// abortf != null (the persistent solve kernel: every workgroup waits for others, iteration after iteration): give up after ~0.3 s, or as soon as somebody else
+// has, and say so in *abortf -- every later wait of every workgroup then returns at once, the launch ends, and the host reports VIL_ERR_DEVICE instead of hanging
+__device__ __forceinline__ bool spin_until_eq(const int* f, const int v, int* abortf) {
+    for (int sp = 1; ld_ag(f) != v; ++sp) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((sp & 1023) == 0 && abortf && (sp > (1 << 21) || ld_ag(abortf) != 0)) { st_ag(abortf, 1); return false; }
+    }
+    return true;
+}
 // AG = true: data another workgroup of the SAME launch wrote / will read (agent scope: the level the XCDs' L2s share); false: across a kernel boundary (plain)
 template <bool AG> __device__ __forceinline__ double ldx(const double* p) { if constexpr (AG) return ld_ag(p); else return *p; }
 template <bool AG> __device__ __forceinline__ void stx(double* p, double v) { if constexpr (AG) st_ag(p, v); else *p = v; }

@@ -126,7 +126,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     int4 q[QN], q2[QN]; double a[QN], b[QN], c[QN];
 #pragma unroll
     for (int u = 0; u < QN; ++u) { q[u] = tab[min(t + u * NT, n - 1)]; q2[u] = tab[min(t + (QN + u) * NT, n - 1)]; }      // (the second round's entries too: no table round trip behind the flags)
-    const double sc_prev = (t < NB && !ctl.first) ? P.Sc[NP + t] : 0.0;
+    const double sc_prev = (t < NB && !ctl.first) ? ldx<FUSED>(P.Sc + NP + t) : 0.0;
     const int pqv = P.chpq[min(t, NB - 1)];
     const double* const pHs = P.pn > 0 ? P.pH : P.mpart;
     // (IMU / prior records: agent-scope loads -- inside k_sweep they were written by workgroups of this launch; unconditional loads + selects)
@@ -145,7 +145,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     if (wait_records) {
         const int ep = FUSED ? epoch : (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u);       // (sweep_signal, vil_sweep.hpp)
         const int* const fl = FUSED ? P.sflag : P.swflag;
-        if (t <= P.n_imu && (t < P.n_imu || P.pn > 0)) while (ld_ag(fl + t) != ep) __builtin_amdgcn_s_sleep(1);
+        if (t <= P.n_imu && (t < P.n_imu || P.pn > 0)) spin_until_eq(fl + t, ep, P.abortf);
     }
     __syncthreads();
     PSTAMP(31);
@@ -232,8 +232,9 @@ __device__ __forceinline__ void prechain_ww_tile(const DevP& P, const int tile, 
     double (*acc_s)[256];
     if constexpr (FUSED) acc_s = reinterpret_cast<double (*)[256]>(lds);
     else { __shared__ double acc_st[4][256]; acc_s = acc_st; }
-    if (threadIdx.x >= 256) return;
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, row = lane & 15, kq = lane >> 4;
+    if (!FUSED && threadIdx.x >= 256) return;
+    const bool act = threadIdx.x < 256;                  // (one-launch paths: the upper waves idle through the barrier instead of leaving -- a persistent workgroup has a next iteration)
+    const int t = threadIdx.x & 255, wave = t >> 6, lane = t & 63, row = lane & 15, kq = lane >> 4;
     const int NB = 9 * P.K, RS = P.chain_rs, R = P.NV + 1;
     int I = 0; while ((I + 1) * (I + 2) / 2 <= tile) ++I;
     const int J = tile - I * (I + 1) / 2;
@@ -242,7 +243,7 @@ __device__ __forceinline__ void prechain_ww_tile(const DevP& P, const int tile, 
     const double* pb = P.chW + (size_t)kq * RS + (J << 4) + row;
     d4_ c4 = {0.0, 0.0, 0.0, 0.0};
     // k-steps of four chain columns, dealt round-robin to the waves; rows beyond R / columns beyond NB are masked (chW is padded, never read out of bounds)
-    const int nk = (NB + 3) >> 2;
+    const int nk = act ? (NB + 3) >> 2 : 0;
     // (eight k-steps per round with all sixteen operand loads in flight before the first MFMA: one L2 round trip per round -- a load, a wait and an
     //  MFMA per k-step was six round trips in a row at K = 10, on the path between the end of the chain and the start of the dense factorisation)
     for (int ks0 = wave; ks0 < nk; ks0 += 32) {
@@ -260,10 +261,12 @@ __device__ __forceinline__ void prechain_ww_tile(const DevP& P, const int tile, 
         }
     }
     // accumulator element g of a lane = (row (lane >> 4) + 4 g, column lane & 15) of the tile
+    if (act) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc_s[wave][(((lane >> 4) + 4 * g) << 4) + (lane & 15)] = c4[g];
+        for (int g = 0; g < 4; ++g) acc_s[wave][(((lane >> 4) + 4 * g) << 4) + (lane & 15)] = c4[g];
+    }
     __syncthreads();
-    {
+    if (act) {
         const int r = t >> 4, c = t & 15;
         const double v = (acc_s[0][t] + acc_s[1][t]) + (acc_s[2][t] + acc_s[3][t]);
         st_ag(P.chWW + (size_t)tile * (16 * 17) + r * 17 + c, v);
