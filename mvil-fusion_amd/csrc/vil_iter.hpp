@@ -58,9 +58,10 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(DevP P, SolveOpts O)
     static_assert(offsetof(Ctl, cost_trace) % 8 == 0 && HEAD <= 32, "the workers copy the head of Ctl as doubles");
     for (int n = 0; n <= O.max_iterations + 24; ++n) {
         const int epoch = (int)((((unsigned)gen) << 12) + (unsigned)n + 1u);
-        if (t == 0) vd::spin_until_eq(P.goflag, epoch, P.abortf);
+        if (t == 0) { vd::spin_until_eq(P.goflag, epoch, P.abortf); *tick = vd::ld_ag(P.abortf); }
         __syncthreads();
-        if (vd::ld_ag(P.abortf) != 0) return;
+        if (*tick != 0) return;                               // somebody gave up waiting: the launch ends (uniform: one thread's reading)
+        __syncthreads();
         if (b < nded) {
             vd::StepShared& s = *reinterpret_cast<vd::StepShared*>(dyn);
             step_body<true, 3, true>(P, O, s, dyn + VIL_SS_DOUBLES, b);
