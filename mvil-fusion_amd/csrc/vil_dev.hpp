@@ -130,12 +130,7 @@ struct DevP {
     // every sweep workgroup posts the launch epoch in sflag[its index] once its record is out (agent-scope stores); the gather workgroups wait for all of them,
     // the chain workgroup for the IMU / prior ones
     int n_sw; int* sflag;
-    // ---- the whole SOLVE in one launch (k_solve, vil_iter.hpp): persistent workgroups [chain | master | helpers | tiles | workers]; the master ends iteration n by
-    // posting the epoch of iteration n + 1 in goflag, which every workgroup waits for at the top of its loop; helper k posts hdone[k] once its la / lb are out (the
-    // next iteration's visual roles read them); workers beyond their first item draw tickets from qsweep / qgather[iteration & 63]
-    int persist; int* goflag; int* hdone; int* qsweep; int* qgather; int* abortf;
-    const int* hstop;              // pinned host word: == solve generation once the host's clock has passed max_solver_time (checked by the master once per iteration)
-    int tail_off;                  // doubles: where the persistent kernel keeps [Ctl head | camera part of the candidate state | ticket] in its dynamic LDS
+    int* abortf;                   // one-launch iteration: a wait on another workgroup's flag that lasts ~0.3 s gives up and says so here; every later wait returns at once (vil_math.hpp: spin_until_eq)
     long long* prof;               // != null: wall-clock stamps (s_memrealtime, 100 MHz) of the roles of a one-launch iteration, 8 per launch slot (vil_profile)
     int gather_pose_only;          // the gather forms S' on the visual sub-space + the diagonal only (a solve on the prechain path: vil_sweep.hpp, reduce_gather)
     double* chW; double* chLraw; double* chLdg; double* chLsb; double* chSc; double* chDc; double* chZ; double* chQ; int* chOk; double* chWW;

@@ -145,27 +145,22 @@ __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_finish(DevP P, int term) 
 // Start of a solve / linearisation / marginalisation sweep: the trust-region record is written by a kernel from its ARGUMENTS (no pinned staging
 // buffer whose contents a later call could overwrite before an asynchronous copy has read it).  reset: both state buffers are first restored to the
 // state the window was uploaded with (vil_reset_state + vil_solve_resident of a bench loop: one launch).
-// persist != null: the persistent solve kernel's words [goflag | abortf | 64 sweep tickets | 64 gather tickets] -- the first iteration is released here
-__device__ __forceinline__ void persist_init(int* persist, int gen) {
-    if (!persist) return;
-    for (int i = threadIdx.x; i < 2 + 128; i += blockDim.x) persist[i] = i == 0 ? (int)((((unsigned)gen) << 12) + 1u) : 0;
-}
-__global__ __launch_bounds__(256) void k_solve_init(Ctl* ctl, int gen, double radius, double mu, int lin_mode, int* persist) {
+__global__ __launch_bounds__(256) void k_solve_init(Ctl* ctl, int gen, double radius, double mu, int lin_mode, int* abortf /* cleared: vil_math.hpp, spin_until_eq */) {
     double* w = (double*)ctl;
     for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += blockDim.x) w[i] = 0.0;
-    persist_init(persist, gen);
+    if (abortf && threadIdx.x == 0) *abortf = 0;
     __syncthreads();
     if (threadIdx.x == 0) { ctl->gen = gen; ctl->first = 1; ctl->radius = radius; ctl->mu = mu; ctl->lin_mode = lin_mode; }
 }
 // (vil_reset_state is deferred to the next call that touches the state: in front of a solve it rides in the init launch -- one launch and one host
 //  call gap less per solve of a bench / re-solve loop)
-__global__ __launch_bounds__(256) void k_solve_init_reset(Ctl* ctl, int gen, double radius, double mu, int lin_mode, double* x0, double* x1, const double* src, int n, int* persist) {
+__global__ __launch_bounds__(256) void k_solve_init_reset(Ctl* ctl, int gen, double radius, double mu, int lin_mode, double* x0, double* x1, const double* src, int n, int* abortf) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) { const double v = src[i]; x0[i] = v; x1[i] = v; }
     if (blockIdx.x == 0) {
         double* w = (double*)ctl;
         for (int q = threadIdx.x; q < (int)(sizeof(Ctl) / 8); q += blockDim.x) w[q] = 0.0;
-        persist_init(persist, gen);
+        if (abortf && threadIdx.x == 0) *abortf = 0;
         __syncthreads();
         if (threadIdx.x == 0) { ctl->gen = gen; ctl->first = 1; ctl->radius = radius; ctl->mu = mu; ctl->lin_mode = lin_mode; }
     }

@@ -227,9 +227,9 @@ __device__ __forceinline__ double ld_ag(const double* p) { return __hip_atomic_l
 __device__ __forceinline__ void st_ag(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ld_ag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_ag(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// Wait for a flag another workgroup of the launch posts.  abortf == null: wait as long as it takes (launches whose waiting workgroups the dispatch order protects).
-// abortf != null (the persistent solve kernel: every workgroup waits for others, iteration after iteration): give up after ~0.3 s, or as soon as somebody else
-// has, and say so in *abortf -- every later wait of every workgroup then returns at once, the launch ends, and the host reports VIL_ERR_DEVICE instead of hanging
+// Wait for a flag another workgroup of the launch posts.  abortf == null: wait as long as it takes.  abortf != null (the one-launch iteration, where nearly every
+// workgroup waits for others): give up after ~0.3 s, or as soon as somebody else has, and say so in *abortf -- every later wait of every workgroup then returns at
+// once, the launches end, the solve never reports `done`, and the host returns VIL_ERR_DEVICE instead of hanging with the device
 __device__ __forceinline__ bool spin_until_eq(const int* f, const int v, int* abortf) {
     for (int sp = 1; ld_ag(f) != v; ++sp) {
         __builtin_amdgcn_s_sleep(1);

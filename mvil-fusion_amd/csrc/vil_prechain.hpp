@@ -126,7 +126,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     int4 q[QN], q2[QN]; double a[QN], b[QN], c[QN];
 #pragma unroll
     for (int u = 0; u < QN; ++u) { q[u] = tab[min(t + u * NT, n - 1)]; q2[u] = tab[min(t + (QN + u) * NT, n - 1)]; }      // (the second round's entries too: no table round trip behind the flags)
-    const double sc_prev = (t < NB && !ctl.first) ? ldx<FUSED>(P.Sc + NP + t) : 0.0;
+    const double sc_prev = (t < NB && !ctl.first) ? P.Sc[NP + t] : 0.0;
     const int pqv = P.chpq[min(t, NB - 1)];
     const double* const pHs = P.pn > 0 ? P.pH : P.mpart;
     // (IMU / prior records: agent-scope loads -- inside k_sweep they were written by workgroups of this launch; unconditional loads + selects)
@@ -233,7 +233,7 @@ __device__ __forceinline__ void prechain_ww_tile(const DevP& P, const int tile, 
     if constexpr (FUSED) acc_s = reinterpret_cast<double (*)[256]>(lds);
     else { __shared__ double acc_st[4][256]; acc_s = acc_st; }
     if (!FUSED && threadIdx.x >= 256) return;
-    const bool act = threadIdx.x < 256;                  // (one-launch paths: the upper waves idle through the barrier instead of leaving -- a persistent workgroup has a next iteration)
+    const bool act = threadIdx.x < 256;                  // (one-launch iteration: the upper waves idle through the barrier instead of leaving)
     const int t = threadIdx.x & 255, wave = t >> 6, lane = t & 63, row = lane & 15, kq = lane >> 4;
     const int NB = 9 * P.K, RS = P.chain_rs, R = P.NV + 1;
     int I = 0; while ((I + 1) * (I + 2) / 2 <= tile) ++I;

@@ -40,9 +40,8 @@ struct StepShared {
     unsigned char cst[48];                        // pose_const[K] | sb_const[K]
     double hs[12];                                // the helpers' sums, gathered by a spare wave during the chain back substitution
     int need, was_first, ok, cok;
-    int done_at_entry, pad0_;                     // the solve was already finished when this iteration's Ctl was read (persistent kernel: the workgroup leaves its loop)
+    int done_at_entry, pad0_;                     // the solve was already finished when this launch read Ctl
     long long tacc[6];
-    double xc[328];                               // camera part of the candidate state, formed here and written out in one pass (at agent scope in the one-launch paths)
 };
 
 // block-wide sum(a), sum(b) and sum-or-max(c) with one pair of barriers
@@ -1073,7 +1072,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     const bool helper = bid > 0 && bid <= nhelp;
     {   // Ctl (1.5 kB with its traces) into LDS: one coalesced load per lane, not 190 loads of a lone lane with everybody waiting at the barrier
         const double* src = (const double*)P.ctl; double* dst = (double*)&s.c;
-        for (int i = t; i < (int)(sizeof(Ctl) / 8); i += NT) dst[i] = ldx<FUSED>(src + i);      // (persistent kernel: the master of this launch wrote it)
+        for (int i = t; i < (int)(sizeof(Ctl) / 8); i += NT) dst[i] = src[i];
         if (t == 0) { s.need = 0; s.was_first = 0; s.ok = 1; }
     }
     for (int q = t; q < 256; q += NT) {      // triangular tile index -> (tile row, tile col)
@@ -1110,14 +1109,11 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         rs_signal(P.gflag + (bid - b_gather)); PROF(5); return;
     }
     if (merged && bid >= b_ww) {
-        if (!FUSED && t >= VIL_THREADS) return;        // a 256-thread role: the upper waves leave before the first barrier (one-launch paths: they idle THROUGH the barriers -- a persistent workgroup has a next iteration)
+        if (!FUSED && t >= VIL_THREADS) return;        // a 256-thread role: the upper waves leave before the first barrier (one-launch iteration: they idle THROUGH the barriers)
         rs_wait(P.chflag, 1); prechain_ww_tile<FUSED>(P, bid - b_ww, Alds); rs_signal(P.wwflag + (bid - b_ww)); PROF(13); return;
     }
     if (merged && P.prechain && bid == b_chain) { prechain_wg<FUSED>(P, s.c, O.jacobi_scaling, Alds, epoch, FUSED); return; }      // (posts chflag[0 .. 2] itself; one-launch iteration: behind the IMU / prior workgroups' flags)
     if (!merged && P.prechain == 2 && bid == b_chain) { prechain_inverses(P, Alds, epoch); return; }                 // (chain eliminated inside k_sweep: posts chflag[2])
-    // (persistent kernel: the host's stop word -- max_solver_time passed -- is requested here and looked at by the judge below, its PCIe round trip under the wait for the gather)
-    int hstop_v = 0;
-    if constexpr (FUSED) if (bid == 0 && t == 0 && P.persist && P.hstop) hstop_v = __hip_atomic_load(P.hstop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (bid == 0) PROF(7);
     if (merged) rs_wait(P.gflag, P.n_gather);          // master and helpers: the candidate's cost, gradient and diagonal (and S') are complete
     if (bid == 0) PROF(8);
@@ -1138,24 +1134,14 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         static_assert(sizeof(Ctl) % 8 == 0, "Ctl is copied as doubles");
         const double* src = (const double*)&s.c;
         double* dst = (double*)P.ctl;
-        for (int i = t; i < (int)(sizeof(Ctl) / 8); i += 64) stx<FUSED>(dst + i, src[i]);
+        for (int i = t; i < (int)(sizeof(Ctl) / 8); i += 64) dst[i] = src[i];
     };
     // master: every helper has read Ctl (one lane per helper: the polls overlap instead of queueing behind one another)
     bool hseen = false;
     // (... and, gather + step in one launch: the chain / tile workgroups have read Ctl too -- a tile's flag implies the chain's; n_ww <= 45)
     auto wait_helpers = [&]() { if (!hseen && t < nhelp) wait1(P.hflag + t); if (!hseen && merged && P.prechain && t < P.n_ww) wait1(P.wwflag + t); hseen = true; };
-    // wave 0: the end of the master's iteration on every path -- Ctl goes out; in the persistent kernel the next iteration is then released: every helper's la / lb are
-    // out (hdone), the ticket counters of an iteration 32 ahead are cleared, and goflag takes the next epoch behind this wave's own stores
-    auto end_iter = [&]() {
-        wait_helpers(); store_ctl();
-        if constexpr (FUSED) if (P.persist) {
-            if (t < nhelp) spin_until_eq(P.hdone + t, epoch, P.abortf);
-            if (t == 0) { st_ag(P.qsweep + ((lidx + 32) & 63), 0); st_ag(P.qgather + ((lidx + 32) & 63), 0); }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            if (t == 0) st_ag(P.goflag, epoch + 1);
-        }
-    };
+    // wave 0: the end of the master's iteration on every path -- every helper (and tile workgroup) has read Ctl, then the new one goes out
+    auto end_iter = [&]() { wait_helpers(); store_ctl(); };
     const bool cam = true;             // (every rank holds the complete system: nothing is counted per rank any more)
     STAMP(0);
     // ---------------- judge the candidate that the sweep just linearised -------------------------
@@ -1186,7 +1172,6 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         if (!c.done) {
             if (c.iter >= O.max_iterations) { c.done = 1; c.term = 4; }
             else if (c.radius <= 1e-32) { c.done = 1; c.term = 6; c.status = -4; }
-            else if (FUSED && hstop_v != 0 && hstop_v == c.gen && c.iter >= 1) { c.done = 1; c.term = 5; }      // max_solver_time_in_seconds (estimator.cpp:1411): the host's clock, the accepted state stands
         }
     }
     __syncthreads();
@@ -1223,7 +1208,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
                 a = Sl * g / dl; b = Sl * gnv / dl;
                 sm[2] += a * a; sm[3] += a * b; sm[4] += b * b;
             }
-            stx<FUSED>(P.la + l, a); stx<FUSED>(P.lb + l, b);
+            P.la[l] = a; P.lb[l] = b;
             if (!(P.lm_const && P.lm_const[l])) { const double lam = ldx<FUSED>(x + xo_lam(P) + l); sm[5] += lam * lam; }      // (an accepted candidate's inverse depths: the visual workgroups of this launch wrote them)
         }
     };
@@ -1277,13 +1262,11 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     };
     if (helper) {
         const int hk = bid - 1;
-        // persistent kernel: the next iteration's visual roles read la / lb -- the master releases it only behind every helper's hdone
-        auto helper_done = [&]() { if constexpr (FUSED) if (P.persist) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (t == 0) st_ag(P.hdone + hk, epoch); } };
         if (!s.c.done && s.need) {
             // camera vectors u = Sc gradient_/d in LDS (nothing global is written here: that is the master's job)
             for (int i = t; i < P.NV; i += NT) {
                 const double dg = merged ? ld_ag(sb.diag + i) : sb.diag[i], b = merged ? ld_ag(sb.bc + i) : sb.bc[i];
-                const double Sc = s.was_first ? (O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0) : ldx<FUSED>(P.Sc + i);
+                const double Sc = s.was_first ? (O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0) : P.Sc[i];
                 const double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
                 s.y[i] = Sc * (Sc * b / d) / d;
             }
@@ -1332,9 +1315,8 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
                         sm[5] = lam2;
                     }
                     post_wave2(sm);
-                    if (have) { stx<FUSED>(P.la + l, a_); stx<FUSED>(P.lb + l, b_); }      // (for the next sweep: not part of what the master waits for)
+                    if (have) { P.la[l] = a_; P.lb[l] = b_; }      // (for the next sweep: not part of what the master waits for)
                 }
-                helper_done();
                 return;
             }
             lm_pass1(l0, l1, s.y, q, g2, gm);
@@ -1349,11 +1331,10 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
                 post_wave2(sm);
             }
         } else post(P.hflag + hk);
-        helper_done();
         return;
     }
     if (s.c.done) { if (t < 64) end_iter(); return; }
-    for (int i = t; i < 16 * P.K + 8; i += NT) s.x0[i] = ldx<FUSED>(x + i);          // (read after several barriers)
+    for (int i = t; i < 16 * P.K + 8; i += NT) s.x0[i] = x[i];          // (read after several barriers)
     for (int k = t; k < 2 * P.K; k += NT) s.cst[k] = k < P.K ? (P.pose_const ? P.pose_const[k] : 0) : (P.sb_const ? P.sb_const[k - P.K] : 0);
     bool xpub = false;                                 // the master owes the waiting helpers an xflag on every path through the need branch
     auto publish_xp = [&](int okk) {                   // called by all threads; s.y[0 .. NV) = x_p when okk
@@ -1391,7 +1372,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         for (int i = t; i < D; i += NT) {
             const double dg = merged ? ld_ag(sb.diag + i) : sb.diag[i], b = merged ? ld_ag(sb.bc + i) : sb.bc[i];
             double Sc;
-            if (s.was_first) { Sc = O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0; if (CHAIN == 3 && i >= P.NV) Sc = ld_ag(P.chSc + (i - P.NV)); stx<FUSED>(P.Sc + i, Sc); } else Sc = ldx<FUSED>(P.Sc + i);
+            if (s.was_first) { Sc = O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0; if (CHAIN == 3 && i >= P.NV) Sc = ld_ag(P.chSc + (i - P.NV)); P.Sc[i] = Sc; } else Sc = P.Sc[i];
             double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
             if (CHAIN == 3 && i >= P.NV) d = ld_ag(P.chDc + (i - P.NV));      // the very numbers the chain workgroup scaled M_bb with
             const double g = Sc * b / d;
@@ -1497,8 +1478,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
                 if (!(c.mu < O.max_mu)) { c.iter++; c.invalid_run++; c.reuse = 0; if (c.invalid_run >= 5) { c.done = 1; c.term = 6; c.status = -4; } }
                 c.resweep = 1; c.cg = 0.0; c.cn = 0.0;
             }
-            for (int i = t; i < P.NS; i += NT) stx<FUSED>(xc + i, i >= xo_lam(P) ? ldx<FUSED>(x + i) : s.x0[i]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int i = t; i < P.NS; i += NT) xc[i] = i >= xo_lam(P) ? ldx<FUSED>(x + i) : s.x0[i];
             __syncthreads();
             if (t < 64) end_iter();      // (a late helper may still be copying Ctl into its LDS)
             return;
@@ -1556,7 +1536,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         }
         __syncthreads();
     } else {
-        for (int i = t; i < D; i += NT) { s.sc[i] = ldx<FUSED>(P.Sc + i); s.dcs[i] = P.dc[i]; s.gr[i] = P.gradc[i]; s.gn[i] = P.gnc[i]; s.rt[i] = s.sc[i] / s.dcs[i]; }
+        for (int i = t; i < D; i += NT) { s.sc[i] = P.Sc[i]; s.dcs[i] = P.dc[i]; s.gr[i] = P.gradc[i]; s.gn[i] = P.gnc[i]; s.rt[i] = s.sc[i] / s.dcs[i]; }
         __syncthreads();
     }
     STAMP(5);
@@ -1585,26 +1565,28 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     for (int i = t; i < D; i += NT) s.y[i] = (cg * s.gr[i] + cn * s.gn[i]) * s.rt[i];
     __syncthreads();
     const double* stepc = s.y;
+    double* const xcs = s.gr;                        // the candidate's camera part is formed in LDS (gr | gn: 640 doubles, dead from here on -- P.gradc / P.gnc keep them) and leaves in one pass
+    static_assert(offsetof(StepShared, gn) == offsetof(StepShared, gr) + 320 * sizeof(double), "the candidate spills from gr into gn");
     double xn = 0, sn = 0;
     const int K = P.K;
     for (int k = t; k < 2 * K + 2; k += NT) {
         if (k < K) {
-            const double* in = s.x0 + xo_pose(P, k); double* o = s.xc + xo_pose(P, k);
+            const double* in = s.x0 + xo_pose(P, k); double* o = xcs + xo_pose(P, k);
             if (s.cst[k]) { for (int q = 0; q < 7; ++q) o[q] = in[q]; }
             else { pose_plus(in, stepc + col_pose(P, k), o); if (cam) for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
         } else if (k < 2 * K) {
             const int kk = k - K;
-            const double* in = s.x0 + xo_sb(P, kk); double* o = s.xc + xo_sb(P, kk);
+            const double* in = s.x0 + xo_sb(P, kk); double* o = xcs + xo_sb(P, kk);
             const bool cst = s.cst[K + kk] != 0;
             for (int q = 0; q < 9; ++q) { const double d = cst ? 0.0 : stepc[col_sb(P, kk) + q]; o[q] = in[q] + d; if (!cst && cam) { xn += in[q] * in[q]; sn += d * d; } }
         } else if (k == 2 * K) {
-            const double* in = s.x0 + xo_ex(P); double* o = s.xc + xo_ex(P);
+            const double* in = s.x0 + xo_ex(P); double* o = xcs + xo_ex(P);
             if (P.ex_const) { for (int q = 0; q < 7; ++q) o[q] = in[q]; }
             else { pose_plus(in, stepc + col_ex(P), o); if (cam) for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
         } else {
             const double in = s.x0[xo_td(P)];
             const double d = P.td_free ? stepc[col_td(P)] : 0.0;
-            s.xc[xo_td(P)] = in + d;
+            xcs[xo_td(P)] = in + d;
             if (P.td_free && cam) { xn += in * in; sn += d * d; }
         }
     }
@@ -1633,9 +1615,8 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     __syncthreads();
     {   // the candidate's camera part leaves in one pass (a re-sweep: the current state again)
         const bool back = s.c.resweep && !s.c.done;
-        for (int i = t; i < 16 * P.K + 8; i += NT) stx<FUSED>(xc + i, back ? s.x0[i] : s.xc[i]);
+        for (int i = t; i < 16 * P.K + 8; i += NT) xc[i] = back ? s.x0[i] : xcs[i];
     }
-    if constexpr (FUSED) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }      // (every wave's stores are out before the next iteration is released)
     STAMP(7);
     if (t < 64) end_iter();      // (no second poll when the sums were already collected)
     PROF(12);

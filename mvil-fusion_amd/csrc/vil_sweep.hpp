@@ -178,7 +178,7 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
         const int i = P.vis_i[fs], j = P.vis_j[fs], l = P.vis_l[fs];
         const double* pi = x + xo_pose(P, i); const double* pj = x + xo_pose(P, j); const double* ex = x + xo_ex(P);
         VisJ o;
-        const double lam = stepped ? ldx<AG>(xcur + xo_lam(P) + l) + cg * ldx<AG>(P.la + l) + cn * ldx<AG>(P.lb + l) : ldx<AG>(xcur + xo_lam(P) + l);      // (persistent kernel: written by workgroups of this launch)
+        const double lam = stepped ? xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l] : xcur[xo_lam(P) + l];      // (all three written by EARLIER launches: plain loads, L2 hits)
         if (O.precision)
             visual_eval_f32(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
                             lam, x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
@@ -228,8 +228,8 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
         h = __shfl(h, (t & ~15) + 13, 64); b = __shfl(b, (t & ~15) + 13, 64);
         const bool cl = !mfree && P.lm_const && P.lm_const[l];
         double Sl = 1.0;
-        if (ctl.first) { Sl = (O.jacobi_scaling && !ctl.lin_mode) ? 1.0 / (1.0 + sqrt(h)) : 1.0; if (k == 13) stx<AG>(P.Sl + l, Sl); }
-        else Sl = ldx<AG>(P.Sl + l);
+        if (ctl.first) { Sl = (O.jacobi_scaling && !ctl.lin_mode) ? 1.0 / (1.0 + sqrt(h)) : 1.0; if (k == 13) P.Sl[l] = Sl; }
+        else Sl = P.Sl[l];
         double dl2 = Sl * Sl * h; dl2 = fmin(fmax(dl2, 1e-6), 1e32);
         const double p = ctl.lin_mode ? h : h + ctl.mu * dl2 / (Sl * Sl);
         // lin_mode 2 (marginalisation): MarginalizationInfo's pseudo inverse zeroes every direction of A_mm whose eigenvalue is
@@ -240,7 +240,7 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
         double* er = Em + tl * RS;
         // (a landmark of another rank's shard is in no chunk of this rank: its entries of the set stay zero here and the all-reduce takes them from the owner)
         if (k == 13) { stx<AG>(sb.hll + l, h); stx<AG>(sb.bl + l, b); stx<AG>(sb.invp + l, invp); stx<AG>(sb.sl + l, Sl); lr[0] = invp; sa[tl] = -invp; er[cR] = b; }
-        if (k == 14) stx<AG>(xcand + xo_lam(P) + l, stepped ? ldx<AG>(xcur + xo_lam(P) + l) + cg * ldx<AG>(P.la + l) + cn * ldx<AG>(P.lb + l) : ldx<AG>(xcur + xo_lam(P) + l));      // the same expression the factor threads evaluated (read by the step roles once the candidate is accepted)
+        if (k == 14) stx<AG>(xcand + xo_lam(P) + l, stepped ? xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l] : xcur[xo_lam(P) + l]);      // the same expression the factor threads evaluated (read by the step roles once the candidate is accepted)
         if (k < 13) {
             lr[1 + k] = e; stx<AG>(sb.eA + (size_t)l * 13 + k, e);
             er[k < 6 ? 6 * (a - fa0) + k : cX + (k - 6)] = e;
@@ -765,9 +765,9 @@ __device__ __forceinline__ void sweep_signal(const DevP& P, const Ctl& ctl, int 
 // FUSED: the roles as workgroups of the one-launch iteration (k_iter, vil_iter.hpp): everything another workgroup of the launch reads goes out at agent scope,
 // and every workgroup ends by posting the launch epoch in P.sflag[b] (the gather workgroups wait for all of them, the chain workgroup for the IMU / prior ones)
 template <int TS, bool FUSED>      // TS: accumulator tiles per wave of the visual role
-__device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, const Ctl& ctl, double* const sm, const int blk, const double* const xs = nullptr /* persistent kernel: the candidate's camera part, staged in LDS at agent scope */) {
+__device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, const Ctl& ctl, double* const sm, const int blk) {
     const int cand = 1 - ctl.cur;
-    const double* x = xs ? xs : P.x[cand];
+    const double* x = P.x[cand];
     SysBuf sb = P.sys[cand];
     int b = blk;
     const bool pre = !FUSED && P.prechain == 2 && ctl.lin_mode == 0;

@@ -254,8 +254,6 @@ struct vil_ctx {
     std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
     int n_blocks_sweep = 0, n_blocks_reduce = 0, n_blocks_reduce_po = 0, n_gather_m = 0, n_ww = 0;      // n_ww: tiles of W W^T formed by extra workgroups of k_reduce (vil_prechain.hpp)
     size_t lds_sweep = 0, lds_step = 0, lds_reduce = 0;
-    bool persist = false; size_t lds_solve = 0; int n_workers = 0; int cap_solve[2] = {-1, -1}; size_t cap_solve_lds[2] = {0, 0}; int attr_solve[2] = {0, 0};      // the whole solve as ONE persistent launch (k_solve<2 | 5>)
-    int* h_stop = nullptr; int* d_hstop = nullptr;      // pinned, device-mapped word: the host writes the solve generation there once max_solver_time has passed
     bool fused = false; size_t lds_iter = 0; int cap_iter[2] = {-1, -1}; size_t cap_iter_lds[2] = {0, 0}; int attr_iter[2] = {0, 0};      // the one-launch iteration (k_iter<2 | 5>, vil_iter.hpp)
     int cap_step3 = -1; size_t cap_step3_lds = 0;      // workgroups of the merged gather + step launch the device holds at once AT THAT dynamic-LDS size (vil_coop.hpp)
     int vis_gm = 0;                      // doubles of operand rows the largest visual chunk of the uploaded window needs (vil_sweep.hpp)
@@ -355,6 +353,12 @@ static int ensure_mirror(vil_ctx* c, size_t ns) {
     return VIL_OK;
 }
 
+// static LDS of a kernel as the loaded code object reports it (StepShared is only part of what k_step carries: the gather and tile roles keep scratch arrays there)
+static size_t step_static_lds(const void* fn) {
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, fn) != hipSuccess) { (void)hipGetLastError(); return (size_t)64 * 1024; }
+    return (size_t)fa.sharedSizeBytes;
+}
 static SolveOpts to_dev_opts(const vil_options* o) {
     SolveOpts s;
     memset(&s, 0, sizeof s);            // compared bytewise as the key of the cached iteration graphs
@@ -454,7 +458,6 @@ void vil_destroy(vil_ctx* c) {
     if (c->ipc_tmp) hipFree(c->ipc_tmp);
     if (c->slim_buf) hipFree(c->slim_buf);
     if (c->d_prof) hipFree(c->d_prof);
-    if (c->h_stop) hipHostFree(c->h_stop);
     if (c->ipc) { for (int r = 0; r < c->ipc->world; ++r) if (r != c->ipc->rank && c->ipc->peer_base[r]) hipIpcCloseMemHandle(c->ipc->peer_base[r]); if (c->ipc->base) hipFree(c->ipc->base); c->ipc.reset(); }
     if (c->d_pl) hipFree(c->d_pl);
     if (c->d_ed) hipFree(c->d_ed);
@@ -948,8 +951,8 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         put(nullptr, 8 * (size_t)2 * (NV + 1), (void**)&P.chZ); put(nullptr, 8 * 4, (void**)&P.chQ); put(nullptr, 16, (void**)&P.chOk);
         put(nullptr, 4 * (size_t)(gather_blocks(D, NV, RED_EPW, false) + 8), (void**)&P.gflag);      // (one flag per gather workgroup of the merged launch: never more than the gather kernel has)
         put(nullptr, 64, (void**)&P.chflag); put(nullptr, 4 * 64, (void**)&P.wwflag); put(nullptr, 4 * (size_t)(K + 8), (void**)&P.swflag);
-        put(nullptr, 4 * (size_t)VIL_SFLAG_MAX, (void**)&P.sflag);
-        put(nullptr, 4 * (size_t)(2 + 128), (void**)&P.goflag); put(nullptr, 4 * 16, (void**)&P.hdone);      // persistent solve kernel: [goflag | abortf | sweep tickets 64 | gather tickets 64], helpers' done flags      // one flag per sweep workgroup of a one-launch iteration (taken only when there are fewer: below)
+        put(nullptr, 4 * (size_t)VIL_SFLAG_MAX, (void**)&P.sflag);      // one flag per sweep workgroup of a one-launch iteration (taken only when there are fewer: below)
+        put(nullptr, 64, (void**)&P.abortf);      // (raised by a wait on another workgroup's flag that gives up: vil_math.hpp, spin_until_eq)
         { const size_t Tp = (size_t)(NV + 1 + 15) / 16; put(nullptr, 8 * (size_t)TILE_SZ * (Tp * (Tp + 1) / 2), (void**)&P.chWW); }
     }
     if (pre_ok) {
@@ -1022,7 +1025,6 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     const size_t tables = (ar.hsize + 255) & ~size_t(255), total = tables + ((ar.ssize + 255) & ~size_t(255));
     if (total > ar.cap) { if (ar.d) HIPCHK(hipFree(ar.d)); ar.d = nullptr; ar.cap = 0; HIPCHK(hipMalloc(&ar.d, total + total / 4)); ar.cap = total + total / 4; }
     for (const Fix& f : fix) *f.slot = ar.d + (f.scratch ? tables : 0) + f.off;
-    P.abortf = nullptr; P.qsweep = P.goflag + 2; P.qgather = P.goflag + 66; P.persist = 0; P.hstop = nullptr; P.tail_off = 0;      // (abortf = goflag + 1 in the persistent launch only: everything else waits unbounded)
     if (dl) { P.pl_c = dl->plane_soa; P.pl_stride = dl->plane_stride; P.ed_c = dl->edge_soa; P.ed_stride = dl->edge_stride; }
     if (!gp) { P.glm_start = P.lm_start; P.glm_acol = P.lm_acol; P.gfcol = P.fcol; }
     if (pre_ok) { P.chtab = c->d_chtab; P.chpq = c->d_chtab + 4 * (size_t)c->chtab_n; }
@@ -1091,7 +1093,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         P.chain = 0; P.chain_rs = vd::chain_rs(K);
         if (chain) {
             const size_t Tp = (size_t)(NV + 1 + 15) / 16, tiles = (size_t)TILE_SZ * (Tp * (Tp + 1) / 2), wt = (size_t)vd::chain_wcols(K) * P.chain_rs, scr = vd::chain_scratch_doubles(K);
-            const size_t fixed = sizeof(vd::StepShared) + 512;
+            const size_t fixed = step_static_lds((const void*)k_step<true, 1>) + 256;      // (the kernel's whole static LDS: StepShared + the gather / tile roles' scratch)
             if (8 * (tiles + wt + scr) + fixed <= 160 * 1024) { P.chain = 1; c->lds_step = 8 * (tiles + wt + scr); }
             else if (8 * (tiles + scr) + fixed <= 160 * 1024) { P.chain = 2; c->lds_step = 8 * (tiles + scr); }
         }
@@ -1101,11 +1103,11 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         // k_sweep, behind the IMU / prior workgroups' flags, with the W W^T tiles on extra workgroups of k_reduce (prechain 2).
         const size_t Tp_ = (size_t)(NV + 1 + 15) / 16, tiles_ = (size_t)TILE_SZ * (Tp_ * (Tp_ + 1) / 2);
         const size_t lds3 = 8 * (tiles_ + 54 * (size_t)K + 82 * (size_t)K + vd::even_up(9 * K) + 16), ldsc = 8 * vd::prechain_lds_doubles(K);
-        const bool can_pre = !c->split && pre_ok && P.chain != 0 && Tp_ * (Tp_ + 1) / 2 <= 64 && lds3 + sizeof(vd::StepShared) + 512 <= 160 * 1024 && ldsc <= 150 * 1024;
+        const bool can_pre = !c->split && pre_ok && P.chain != 0 && Tp_ * (Tp_ + 1) / 2 <= 64 && lds3 + step_static_lds((const void*)k_step<true, 3>) + 256 <= 160 * 1024 && ldsc <= 150 * 1024;
         // (round 4: every window size -- the gather of a prechain solve forms the visual sub-space only, 551 workgroups at K = 20 instead of 1500)
         int kmerge = 20;
         if (const char* ev = VIL_TUNE_ENV("VIL_MERGE_K")) kmerge = atoi(ev);
-        bool merged = can_pre && (c->launch_mode == 0 || c->launch_mode == 3 || c->launch_mode == 4) && K <= kmerge && std::max(lds3, ldsc) + 52 * 1024 <= 160 * 1024 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
+        bool merged = can_pre && (c->launch_mode == 0 || c->launch_mode == 3) && K <= kmerge && std::max(lds3, ldsc) + step_static_lds((const void*)k_step<true, 3>) + 256 <= 160 * 1024 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
         if (merged) {
             // the merged launch holds workgroups that spin on flags (master, helpers, one per W W^T tile) next to the finite ones they wait for (chain,
             // gather: lower block indices, dispatched first).  It is only taken when the device can hold every spinning workgroup AND one more at the
@@ -1139,7 +1141,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         //      (the larger of the sweep roles' and the step roles' needs -- StepShared and the gather / tile scratch are carved from it) fits a compute unit, and
         //      the device holds the workgroups that wait for one another (master, helpers, tiles) at once.  vil_debug_set_launch_mode(3) keeps the two launches.
         c->fused = false; c->P.n_sw = 0;
-        if (merged && g64 && (c->launch_mode == 0 || c->launch_mode == 4) && c->n_blocks_sweep <= VIL_SFLAG_MAX && VIL_TUNE_ENV("VIL_NO_FUSE") == nullptr) {
+        if (merged && g64 && c->launch_mode == 0 && c->n_blocks_sweep <= VIL_SFLAG_MAX && VIL_TUNE_ENV("VIL_NO_FUSE") == nullptr) {
             const size_t scratch = 8 * (size_t)(2 * VIS_TAB + 2 * 8 * (VIL_STEP_THREADS / 8) + 160);      // gather role: descriptor table | part[2][512] | index tables | red
             const size_t step_need = 8 * (size_t)VIL_SS_DOUBLES + std::max(std::max(lds3, ldsc), scratch);
             const size_t li = std::max(c->lds_sweep, step_need);
@@ -1150,21 +1152,6 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
                 if (c->cap_iter[v] < 0 || c->cap_iter_lds[v] != li) { c->cap_iter[v] = vilcoop::capacity(fn, VIL_STEP_THREADS, li, c->device); c->cap_iter_lds[v] = li; }
                 const int Tw = (int)(Tp_ * (Tp_ + 1) / 2);
                 if (c->cap_iter[v] >= 1 + P.n_help + Tw + 2) { c->fused = true; c->lds_iter = li; c->P.n_sw = c->n_blocks_sweep; }
-            }
-        }
-        // ---- the whole solve as ONE launch of persistent workgroups (k_solve, vil_iter.hpp): the one-launch iteration's roles, looping; taken when the device holds the
-        //      dedicated workgroups (chain, master, helpers, tiles) and at least 16 workers at the kernel's LDS size.  vil_debug_set_launch_mode(4) keeps one launch per iteration.
-        c->persist = false;
-        if (c->fused && c->launch_mode == 0 && VIL_TUNE_ENV("VIL_NO_PERSIST") == nullptr) {
-            const size_t ls = c->lds_iter + 8 * 384;
-            const int v = P.vis_ts == 2 ? 0 : 1;
-            const void* fn = v ? (const void*)k_solve<5> : (const void*)k_solve<2>;
-            if (ls <= 160 * 1024) {
-                if ((int)ls > c->attr_solve[v]) { HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ls)); c->attr_solve[v] = (int)ls; }
-                if (c->cap_solve[v] < 0 || c->cap_solve_lds[v] != ls) { c->cap_solve[v] = vilcoop::capacity(fn, VIL_STEP_THREADS, ls, c->device); c->cap_solve_lds[v] = ls; }
-                const int nded = 2 + P.n_help + c->n_ww;
-                const int nwk = std::min(c->cap_solve[v] - nded, std::max(c->n_blocks_sweep, c->n_gather_m));
-                if (nwk >= 16) { c->persist = true; c->lds_solve = ls; c->n_workers = nwk; }
             }
         }
     }
@@ -1179,14 +1166,14 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         }
     } else {
     { const size_t T = (size_t)(D + 1 + 15) / 16; c->lds_step = 8 * TILE_SZ * (T * (T + 1) / 2); }   // 16x16-tiled (row stride 17) lower storage incl. the rhs row
-    c->step_lds = c->lds_step + sizeof(vd::StepShared) + 256 <= 160 * 1024;
+    c->step_lds = c->lds_step + step_static_lds((const void*)k_step<true, 0>) + 256 <= 160 * 1024;
     if (c->step_lds) {
         if ((int)c->lds_step > c->attr_step[0]) { HIPCHK(hipFuncSetAttribute((const void*)k_step<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step)); c->attr_step[0] = (int)c->lds_step; }
     } else {
         // tile array in global memory; LDS stages the active tile column of the factorisation (T tiles)
         const size_t T = (size_t)(D + 1 + 15) / 16;
         c->lds_step = 8 * (size_t)TILE_SZ * T;
-        if (c->lds_step + sizeof(vd::StepShared) + 256 > 160 * 1024) return VIL_ERR_UNSUPPORTED;
+        if (c->lds_step + step_static_lds((const void*)k_step<false, 0>) + 256 > 160 * 1024) return VIL_ERR_UNSUPPORTED;
         if ((int)c->lds_step > c->attr_step[3]) { HIPCHK(hipFuncSetAttribute((const void*)k_step<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_step)); c->attr_step[3] = (int)c->lds_step; }
     }
     }
@@ -1427,17 +1414,6 @@ static int launch_iter(vil_ctx* c, const SolveOpts& so) {
     else hipLaunchKernelGGL(k_iter<5>, g, b, c->lds_iter, c->stream, Pi, so);
     return VIL_OK;
 }
-// the whole solve as ONE launch of persistent workgroups (vil_iter.hpp: k_solve)
-static int launch_solve(vil_ctx* c, const SolveOpts& so, bool time_cap) {
-    DevP Pk = c->P;
-    Pk.gather_pose_only = 1; Pk.persist = 1; Pk.abortf = Pk.goflag + 1; Pk.tail_off = (int)(c->lds_iter / 8);
-    Pk.prof = c->profiling ? c->d_prof : nullptr;
-    Pk.hstop = time_cap ? c->d_hstop : nullptr;
-    const dim3 g(2 + c->P.n_help + c->n_ww + c->n_workers), b(VIL_STEP_THREADS);      // [chain | master | helpers | W W^T tiles | workers]
-    if (c->P.vis_ts == 2) hipLaunchKernelGGL(k_solve<2>, g, b, c->lds_solve, c->stream, Pk, so);
-    else hipLaunchKernelGGL(k_solve<5>, g, b, c->lds_solve, c->stream, Pk, so);
-    return VIL_OK;
-}
 static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr, hipEvent_t ev_coll = nullptr) {
     const bool merged = step && c->P.rs_merged;          // one GPU: the gather rides in the step kernel's launch (vil_step.hpp)
     // (chain eliminated inside k_sweep: one workgroup per W W^T tile rides in the gather launch, one for the inverses of the chain's diagonal blocks in the step launch;
@@ -1479,11 +1455,11 @@ static int init_ctl(vil_ctx* c, const vil_options* o, int lin_mode) {
     //  vil_win_marginalize / push / drop return without a stream synchronisation)
     static_assert(sizeof(Ctl) % 8 == 0, "Ctl is cleared as doubles");
     if (c->reset_pending && lin_mode == 0) {               // vil_reset_state + vil_solve_resident: the state copy rides in the init launch
-        hipLaunchKernelGGL(k_solve_init_reset, dim3((c->NS + 255) / 256), dim3(256), 0, c->stream, c->P.ctl, ++c->solve_gen, o->initial_radius, o->min_mu, lin_mode, c->P.x[0], c->P.x[1], (const double*)c->d_x0, c->NS, c->persist ? c->P.goflag : (int*)nullptr);
+        hipLaunchKernelGGL(k_solve_init_reset, dim3((c->NS + 255) / 256), dim3(256), 0, c->stream, c->P.ctl, ++c->solve_gen, o->initial_radius, o->min_mu, lin_mode, c->P.x[0], c->P.x[1], (const double*)c->d_x0, c->NS, c->P.abortf);
         c->reset_pending = false;
     } else {
         flush_reset(c);
-        hipLaunchKernelGGL(k_solve_init, dim3(1), dim3(256), 0, c->stream, c->P.ctl, ++c->solve_gen, o->initial_radius, o->min_mu, lin_mode, (c->persist && lin_mode == 0) ? c->P.goflag : (int*)nullptr);
+        hipLaunchKernelGGL(k_solve_init, dim3(1), dim3(256), 0, c->stream, c->P.ctl, ++c->solve_gen, o->initial_radius, o->min_mu, lin_mode, c->P.abortf);
     }
     memset(c->h_ctl, 0, sizeof(Ctl));
     return VIL_OK;
@@ -1549,59 +1525,14 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     }
     int st = init_ctl(c, o, 0);
     if (st != VIL_OK) return st;
-    if (c->profiling && (c->fused || c->persist) && c->d_prof) HIPCHK(hipMemsetAsync(c->d_prof, 0, 8 * 64 * VIL_PROF_SLOTS, c->stream));
+    if (c->profiling && c->fused && c->d_prof) HIPCHK(hipMemsetAsync(c->d_prof, 0, 8 * 64 * VIL_PROF_SLOTS, c->stream));
     // every iteration = sweep + gather + step kernel; `done` turns the tail of a chunk into no-ops, and the first sweep launch that finds
     // the solve finished writes the result out (vil_finish.hpp); k_finish at the end of every chunk covers a solve that ends in its last iteration
     bool finished = false, polled_done = false;
-    if (c->persist) {
-        // ONE launch for the whole solve, k_finish behind it; the host polls the mirror word and, when the reference's wall-clock cap is set, raises the stop word
-        const bool cap = o->max_time_s > 0;
-        if (cap && !c->h_stop) {
-            HIPCHK(hipHostMalloc((void**)&c->h_stop, 64, hipHostMallocMapped)); *c->h_stop = 0;
-            void* dp = nullptr; HIPCHK(hipHostGetDevicePointer(&dp, c->h_stop, 0)); c->d_hstop = (int*)dp;
-        }
-        if (c->profiling) HIPCHK(hipEventRecord(c->ev[0], c->stream));
-        launch_solve(c, so, cap);
-        if (c->profiling) HIPCHK(hipEventRecord(c->ev[1], c->stream));
-        hipLaunchKernelGGL(k_finish, dim3(1), dim3(VIL_SWEEP_THREADS), 0, c->stream, view(c, 0), -1);
-        bool polled = false, stopped = false;
-        if (c->d_hseq && !c->profiling) {
-            volatile int* seq = (volatile int*)(c->h_mirror + sizeof(Ctl));
-            const int gen = c->solve_gen;
-            const auto tp0 = std::chrono::steady_clock::now();
-            for (long spin = 1;; ++spin) {
-                if (*seq == gen) { polled = true; break; }
-                if ((spin & 0xff) == 0) {
-                    const auto now = std::chrono::steady_clock::now();
-                    if (cap && !stopped && std::chrono::duration<double>(now - t0).count() >= o->max_time_s) { __atomic_store_n(c->h_stop, gen, __ATOMIC_RELEASE); stopped = true; }
-                    if ((spin & 0x3ff) == 0) {
-                        const hipError_t q = hipStreamQuery(c->stream);
-                        if (q == hipSuccess) { polled = *seq == gen; break; }
-                        if (q != hipErrorNotReady) return VIL_ERR_DEVICE;
-                        if (now - tp0 > std::chrono::seconds(4)) break;
-                    }
-                }
-            }
-            if (polled) { std::atomic_thread_fence(std::memory_order_acquire); memcpy(c->h_ctl, c->h_mirror, sizeof(Ctl)); polled_done = true; }
-        }
-        if (!polled) {
-            if (cap && !stopped) {      // (profiling / no mirror: the clock is watched from here as well)
-                while (hipStreamQuery(c->stream) == hipErrorNotReady) if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= o->max_time_s) { __atomic_store_n(c->h_stop, c->solve_gen, __ATOMIC_RELEASE); break; }
-            }
-            HIPCHK(hipMemcpyAsync(c->h_ctl, c->P.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-        }
-        finished = c->h_ctl->done != 0;
-        if (c->profiling) {
-            float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-            c->prof.step_ms += ms; c->prof.sweep_launches += c->h_ctl->n_sweeps; c->prof.step_launches += c->h_ctl->n_sweeps;      // (the sweep phases' share moves to sweep_ms from the launch's own stamps, below)
-        }
-    }
     // iterations are enqueued in chunks without host round trips; the first chunk is sized by the previous solve of
     // this context (consecutive windows of a tracker need similar iteration counts), later chunks are short
     int chunk = std::min(15, std::max(3, c->last_live));
-    for (int it = 0; it <= o->max_iterations + 8 && !finished && !c->persist; chunk = 3) {
+    for (int it = 0; it <= o->max_iterations + 8 && !finished; chunk = 3) {
         int launched = 0;
         const int sweeps_before = (it == 0) ? 0 : c->h_ctl->n_sweeps;
         // Repeated solves of ONE upload (bench, re-solves after a rejected frame) replay a captured hipGraph of the chunk:
@@ -1702,7 +1633,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     c->solves_since_upload++;
     const Ctl& ctl = *c->h_ctl;
     c->last_live = ctl.n_sweeps;
-    if (c->profiling && (c->fused || c->persist) && c->d_prof && ctl.n_sweeps <= 64) {
+    if (c->profiling && c->fused && c->d_prof && ctl.n_sweeps <= 64) {
         // the launches' own clock stamps (100 MHz): the sweep phase of a one-launch iteration = first workgroup started -> last sweep role posted
         std::vector<unsigned long long> hp((size_t)64 * VIL_PROF_SLOTS);
         HIPCHK(hipMemcpyAsync(hp.data(), c->d_prof, 8 * hp.size(), hipMemcpyDeviceToHost, c->stream));
@@ -2141,7 +2072,7 @@ int vil_comm_message_bytes(vil_ctx* c, int64_t* bytes_per_peer, int64_t* bytes_f
 }
 
 // ---- window residency across frames (include/vilsolve.h) ------------------------------------------------------------------------
-int vil_debug_set_launch_mode(vil_ctx* c, int32_t mode) { if (!c || mode < 0 || mode > 4) return VIL_ERR_INVALID_ARGUMENT; c->launch_mode = mode; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
+int vil_debug_set_launch_mode(vil_ctx* c, int32_t mode) { if (!c || mode < 0 || mode > 3) return VIL_ERR_INVALID_ARGUMENT; c->launch_mode = mode; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
 int vil_comm_info(vil_ctx* c, int32_t* rank, int32_t* world, int32_t* transport) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
     if (rank) *rank = c->rank;
