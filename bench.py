@@ -66,7 +66,7 @@ def pmc_traffic_bytes(files=("r03_pmc_fetch_size.csv", "r03_pmc_write_size.csv")
     return tot
 
 
-def pmc_mfma(file, kernel="k_sweep"):
+def pmc_mfma(file, kernel="k_iter"):
     """Counter-based matrix-core figures of `kernel` from the committed rocprofv3 --pmc pass (SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES,
     SQ_BUSY_CYCLES in ONE pass; profiles/): per live launch the MFMA ops (x 512 = fp64 flop), the cycles the matrix pipes were busy (summed over the
     SIMDs that ran the kernel) and the launch duration.  None if the CSV is missing."""
@@ -161,28 +161,59 @@ def cpu_baseline(w, opts, budget_s=10.0):
             "note": "CPU restatement of the reference algorithm (Ceres unavailable); %s; host has %d usable cores" % (build_note, ncpu)}
 
 
-def roofline_obj(w, prof, measured_on, pmc_files, pmc_note, mfma_file=None):
-    """`roofline` of the factor sweep (dominant kernel: the one that touches the factor tables) + the gather-and-step launch next to it."""
+PHASE_NAMES = ["first workgroup started", "last visual / LiDAR / ICP-LPS role done", "last IMU role done", "chain workgroup saw the IMU / prior records", "chain: W^T complete", "last gather workgroup done",
+               "last gather workgroup saw the visual flags", "master started", "master saw the gather's flags", "master saw the W W^T tiles", "dense factorisation done", "x_p published", "master done",
+               "last tile workgroup done", "chain: its part of S' gathered", "prior role done"]
+
+
+def phases_obj(be):
+    """Where a one-launch iteration spends its time: the launch's own 100 MHz wall-clock stamps, averaged over the instrumented pass (vil_profile_phases)."""
+    avg = (C.c_double * 16)(); n = C.c_int64(0)
+    if be.lib.vil_profile_phases(be.ctx, avg, C.byref(n), 1) != 0 or n.value == 0:
+        return None
+    order = sorted(range(1, 16), key=lambda q: avg[q])
+    return {"unit": "us after the launch's first workgroup started", "launches_averaged": int(n.value), "source": "s_memrealtime stamps of the roles (csrc/vil_dev.hpp: prof_stamp); XCD clocks agree to ~1-2 us",
+            "stamps": {PHASE_NAMES[q]: round(float(avg[q]), 2) for q in order}}
+
+
+def roofline_obj(w, prof, measured_on, pmc_files, pmc_note, mfma_file=None, one_launch=True, phases=None, two_launch=None):
+    """`roofline` of the dominant kernel.  One-launch iteration (k_iter): the kernel IS the iteration -- factor sweep, gather, chain elimination and trust-region step as roles of
+    one grid -- so `achieved` = the sweep's algorithmic bytes over the WHOLE launch's duration (HIP events), which prices a latency-bound launch against the HBM roof; the sweep PHASE of
+    the launch (its own clock stamps) and the two-launch structure's k_sweep are reported beside it.  Two / three launches per iteration: the sweep kernel, as in earlier rounds."""
     ab = algorithmic_bytes(w)
-    us = 1e3 * prof.sweep_ms / prof.sweep_launches
-    ach = ab / (us * 1e-6) / 1e9
-    kname = "k_sweep<5>" if w.K > 12 else "k_sweep<2>"      # (the visual role's accumulator tiles per wave: csrc/vil_sweep.hpp; the counter files may hold other windows' launches too)
-    r = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pmc_files, kname), "traffic_source": pmc_note,
-         "algorithmic_bytes_per_launch": ab, "avg_launch_us": us, "launches_timed": int(prof.sweep_launches),
-         "gather_plus_step_avg_us": 1e3 * prof.step_ms / max(1, prof.step_launches),
-         "measured_on": measured_on, "variant": "fused sweep (no Jacobian materialisation): read-only bytes, SURVEY 8(d)"}
-    # the launch that dominates the iteration's TIME is the trust-region step (one GPU: the gather of the sweep's partial records and the
-    # speed-bias chain ride in the same launch); it is neither HBM- nor MFMA-bound (one master workgroup on dependent fp64 chains), so it is
-    # reported next to the sweep rather than as the roofline object
+    sweep_us = 1e3 * prof.sweep_ms / prof.sweep_launches
+    rest_us = 1e3 * prof.step_ms / max(1, prof.step_launches)
+    ts = "5" if w.K > 12 else "2"      # (the visual role's accumulator tiles per wave: csrc/vil_sweep.hpp; the counter files may hold other windows' launches too)
     NP, NB = 6 * w.K + 7, 9 * w.K
-    step_us = 1e3 * prof.step_ms / max(1, prof.step_launches)
     chol_flop = w.K * (9 ** 3 / 3.0 + 2.0 * 81 * (NP + 1 + 9)) + 1.0 * (NP + 1) ** 2 * NB + NP ** 3 / 3.0 + 2.0 * (NP * NP + NB * (NP + 9))
-    merged = True       # (round 4: gather + step are one launch at every BASELINE window size on one GPU; vil_debug_set_launch_mode forces the fallbacks)
-    r["critical_path_kernel"] = {"kernel": "k_step (gather workgroups | chain workgroup | W W^T tile workgroups | master + helpers)" if merged else "k_reduce (gather + W W^T tiles) + k_step (master + helpers + chain inverses); the chain workgroup rides in k_sweep", "avg_launch_us": step_us,
-                                 "bound": ("latency: gather of the visual records beside the two-sided 9x9 chain of %d blocks, then a %d-pivot dense Cholesky and the back substitutions on one workgroup (dependent fp64 chains)" if merged else
-                                           "latency: gather of the visual records, then on one workgroup a %d-pivot dense Cholesky and the back substitutions (dependent fp64 chains; the two-sided 9x9 chain of %d blocks is eliminated inside the sweep launch)") % ((w.K, NP) if merged else (NP, w.K)),
-                                 "dense_flop_per_launch": chol_flop, "achieved_gflops": chol_flop / (step_us * 1e-6) / 1e9, "peak_tflops_fp64_matrix": 78.6,
-                                 "frac": chol_flop / (step_us * 1e-6) / 78.6e12, "see": "profiles/r04_summary*.txt, DESIGN.md section 4"}
+    if one_launch:
+        kname = "k_iter<%s>" % ts
+        us = sweep_us + rest_us
+        ach = ab / (us * 1e-6) / 1e9
+        r = {"bound": "hbm", "kernel": kname + " (one launch per trust-region iteration: sweep roles | chain | gather | master + helpers | W W^T tiles)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "traffic": pmc_traffic_bytes(pmc_files, kname), "traffic_source": pmc_note, "algorithmic_bytes_per_launch": ab, "avg_launch_us": us, "launches_timed": int(prof.sweep_launches),
+             "measured_on": measured_on, "variant": "fused sweep (no Jacobian materialisation): read-only bytes, SURVEY 8(d)",
+             "note": "the launch is latency-bound (flag hand-offs between roles, then one master workgroup on dependent fp64 chains): the sweep's 2.4 MB are read in the first quarter of it -- sweep_phase prices that quarter, "
+                     "critical_path what the remaining three quarters are made of",
+             "sweep_phase": {"us": sweep_us, "achieved": ab / (sweep_us * 1e-6) / 1e9, "frac": ab / (sweep_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
+                             "what": "first workgroup of the launch started -> last sweep role's record out, from the launch's own clock stamps"},
+             "critical_path": {"us_after_the_sweep_phase": rest_us, "bound": "latency: gather of the visual records beside the two-sided 9x9 chain of %d blocks, then a %d-pivot dense Cholesky and the back substitutions on one workgroup (dependent fp64 chains)" % (w.K, NP),
+                               "dense_flop_per_launch": chol_flop, "achieved_gflops": chol_flop / (rest_us * 1e-6) / 1e9, "peak_tflops_fp64_matrix": 78.6, "frac": chol_flop / (rest_us * 1e-6) / 78.6e12}}
+        r["critical_path_kernel"] = {"kernel": kname, "avg_launch_us": us, "frac": ach / HBM_PEAK_GBS, "see": "roofline.critical_path, roofline.phases"}
+        if phases:
+            r["phases"] = phases
+        if two_launch:
+            r["two_launch_structure"] = two_launch
+    else:
+        kname = "k_sweep<%s>" % ts
+        us = sweep_us
+        ach = ab / (us * 1e-6) / 1e9
+        r = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(pmc_files, kname), "traffic_source": pmc_note,
+             "algorithmic_bytes_per_launch": ab, "avg_launch_us": us, "launches_timed": int(prof.sweep_launches), "gather_plus_step_avg_us": rest_us,
+             "measured_on": measured_on, "variant": "fused sweep (no Jacobian materialisation): read-only bytes, SURVEY 8(d)"}
+        r["critical_path_kernel"] = {"kernel": "k_step (gather workgroups | chain workgroup | W W^T tile workgroups | master + helpers)", "avg_launch_us": rest_us,
+                                     "bound": "latency: gather of the visual records beside the two-sided 9x9 chain of %d blocks, then a %d-pivot dense Cholesky and the back substitutions on one workgroup (dependent fp64 chains)" % (w.K, NP),
+                                     "dense_flop_per_launch": chol_flop, "achieved_gflops": chol_flop / (rest_us * 1e-6) / 1e9, "peak_tflops_fp64_matrix": 78.6, "frac": chol_flop / (rest_us * 1e-6) / 78.6e12}
     if mfma_file:
         # the Schur contraction of the landmarks (sum_f Jc^T Jc - sum_l invp e e^T per visual workgroup) runs on the fp64 matrix cores inside k_sweep:
         # utilisation from the COUNTERS of the committed --pmc pass, against the chip's fp64-matrix peak over the sweep's own duration
@@ -194,7 +225,8 @@ def roofline_obj(w, prof, measured_on, pmc_files, pmc_note, mfma_file=None):
                          "v_mfma_f64_16x16x4_per_launch": m["mops_per_launch"] / 4.0, "flop_per_launch": m["flop_per_launch"],
                          "mfma_busy_cycles_per_launch": m["mfma_busy_cycles_per_launch"], "sq_busy_cycles_per_launch": m["sq_busy_cycles_per_launch"],
                          "launch_us": us_k, "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES, one pass; MOPS x 512 flop)" % mfma_file,
-                         "note": "a dense window-local contraction spends ~6x the multiply-adds of the block-sparse form; the launch is bound by its longest visual workgroup (evaluation, sums and record around ~4 us of matrix-core work), not by the matrix pipes"}
+                         "note": "a dense window-local contraction spends ~6x the multiply-adds of the block-sparse form; the sweep phase is bound by its longest visual workgroup (evaluation, sums and record around ~4 us of matrix-core work), not by the matrix pipes; "
+                                 "counted over the whole launch of the counter pass (one-launch iteration: the dense factorisation's and the W W^T tiles' few matrix-core instructions are in the count)"}
     return r
 
 
@@ -736,6 +768,7 @@ def main():
     # launch.  Kept out of the `value` region because three event records per ~170 us iteration perturb this
     # latency-bound pipeline by several percent.
     prof = VilProfile()
+    phases_head = None
     if not args.no_events:
         be.lib.vil_profile_enable(be.ctx, 1)
         run(2)
@@ -746,7 +779,36 @@ def main():
         sync()
         el_events = time.perf_counter() - t1
         be.lib.vil_profile_read(be.ctx, C.byref(prof), 1)
+        phases_head = phases_obj(be)
         be.lib.vil_profile_enable(be.ctx, 0)
+    lpi, one = C.c_int32(0), C.c_int32(0)
+    be.lib.vil_debug_get_launch_structure(be.ctx, C.byref(lpi), C.byref(one))
+    one_launch = one.value == 1
+    # the same window through the TWO-launch structure of round 4 (k_sweep, then gather + step): the sweep kernel in isolation -- its HIP-event average is what a
+    # rocprofv3 --kernel-trace of that structure shows -- and the iteration rate the one-launch iteration is measured against.  Not `value`.
+    two_launch = None
+    if one_launch and world == 1 and not args.no_events:
+        be3 = lib.open_vilsolve(device=local)
+        be3.lib.vil_debug_set_launch_mode(be3.ctx, 3)
+        be3.upload(w)
+        for _ in range(3):
+            be3.reset_state(); be3.solve_resident(opts)
+        torch.cuda.synchronize(); t3 = time.perf_counter(); it3 = 0
+        n3s = max(8, args.steps // 2)
+        for _ in range(n3s):
+            be3.reset_state(); it3 += be3.solve_resident(opts).iterations
+        torch.cuda.synchronize(); el3 = time.perf_counter() - t3
+        p3 = VilProfile()
+        be3.lib.vil_profile_enable(be3.ctx, 1)
+        be3.reset_state(); be3.solve_resident(opts); be3.lib.vil_profile_read(be3.ctx, C.byref(p3), 1)
+        for _ in range(n3s):
+            be3.reset_state(); be3.solve_resident(opts)
+        be3.lib.vil_profile_read(be3.ctx, C.byref(p3), 1)
+        be3.close()
+        ab3 = algorithmic_bytes(w); us3 = 1e3 * p3.sweep_ms / max(1, p3.sweep_launches)
+        two_launch = {"value": it3 / el3, "unit": "iterations/s", "steps": n3s, "what": "vil_debug_set_launch_mode(3): k_sweep, then the merged gather + step launch (round 4's structure), same window, same protocol",
+                      "k_sweep": {"kernel": "k_sweep<%s>" % ("5" if w.K > 12 else "2"), "avg_launch_us": us3, "achieved": ab3 / (us3 * 1e-6) / 1e9, "unit": "GB/s", "frac": ab3 / (us3 * 1e-6) / 1e9 / HBM_PEAK_GBS, "launches_timed": int(p3.sweep_launches)},
+                      "k_step_avg_us": 1e3 * p3.step_ms / max(1, p3.step_launches)}
     tot_iters, max_el = iters, el
     region_vals = [i_ / e_ for e_, i_ in regions]
     # N > 1: where an iteration's time goes on EVERY rank (HIP events of the instrumented pass) -- the curve should explain itself
@@ -806,6 +868,7 @@ def main():
         pcie_leg = tracker_leg(lib, abi, local)
     # BASELINE.json configs[2] (K = 10, L = 4000, 120 k LiDAR points: the window the 8-GPU sharding is specified on) and configs[3] (K = 20, prior active:
     # the "dense Schur block, MFMA path" window) -- same protocol as the headline, fewer steps; each with its own roofline object
+    leg_phases, leg_one = {}, {}
     def window_leg(cfg_id):
         wx = synth.make_config(cfg_id, prior_fn=gpu_prior)
         be.upload(wx)
@@ -829,7 +892,10 @@ def main():
             for _ in range(nx):
                 be.reset_state(); be.solve_resident(opts)
             be.lib.vil_profile_read(be.ctx, C.byref(profx), 1)
+            leg_phases[cfg_id] = phases_obj(be)
             be.lib.vil_profile_enable(be.ctx, 0)
+        lx_, ox_ = C.c_int32(0), C.c_int32(0)
+        be.lib.vil_debug_get_launch_structure(be.ctx, C.byref(lx_), C.byref(ox_)); leg_one[cfg_id] = ox_.value == 1
         leg = {"value": itx / elx, "unit": "iterations/s", "n_gpus": world, "ms_per_step": 1e3 * elx / nx, "steps": nx, "iterations_per_solve": lx.iterations,
                "workload": "BASELINE.json configs[%d]: K=%d, L=%d, %d visual factors, %d LiDAR points, prior n=%d, %s" % (cfg_id - 1, wx.K, wx.L, len(wx.vis_i), len(wx.plane_pose) + len(wx.edge_pose), wx.prior.n, "sharded over %d GPUs" % world if sharded else ("1 GPU" if world == 1 else "%d replicas" % world))}
         return leg, wx, profx, nx
@@ -865,19 +931,21 @@ def main():
                     out["communicator"]["message_bytes_per_peer_rank0"] = int(mbb.value); out["communicator"]["full_set_bytes"] = int(fbb.value)
         if prof.sweep_launches > 0:
             out["roofline"] = roofline_obj(w, prof, "second pass of the same %d steps with HIP events enabled (%.1f ms/step instrumented vs %.1f ms/step in the value region)" % (args.steps, 1e3 * el_events / args.steps, 1e3 * max_el / args.steps),
-                                           ("r04_pmc_fetch_size.csv", "r04_pmc_write_size.csv"), "profiles/r04_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command)", "r04_pmc_mfma.csv")
+                                           ("r05_pmc_fetch_size.csv", "r05_pmc_write_size.csv"), "profiles/r05_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command)", "r05_pmc_mfma.csv",
+                                           one_launch=one_launch, phases=phases_head, two_launch=two_launch)
+            out["launches_per_iteration"] = int(lpi.value)
         if world == 1 and pcie_leg is not None:
             out["pcie_inclusive"] = pcie_leg
             out["pcie_inclusive_classic"] = pcie_classic
         if cfg3_leg:
             if prof3.sweep_launches > 0:
-                cfg3_leg["roofline"] = roofline_obj(w3, prof3, "a further pass of the same %d steps with HIP events enabled" % n3, ("r04_pmc_fetch_size_c3.csv", "r04_pmc_write_size_c3.csv"),
-                                                    "profiles/r04_pmc_{fetch,write}_size_c3.csv (rocprofv3 --pmc passes of bench.py --config 3)", "r04_pmc_mfma_c3.csv")
+                cfg3_leg["roofline"] = roofline_obj(w3, prof3, "a further pass of the same %d steps with HIP events enabled" % n3, ("r05_pmc_fetch_size_c3.csv", "r05_pmc_write_size_c3.csv"),
+                                                    "profiles/r05_pmc_{fetch,write}_size_c3.csv (rocprofv3 --pmc passes of bench.py --config 3)", "r05_pmc_mfma_c3.csv", one_launch=leg_one.get(3, False), phases=leg_phases.get(3))
             out["configs2_window"] = cfg3_leg
         if cfg4_leg:
             if prof4.sweep_launches > 0:
-                cfg4_leg["roofline"] = roofline_obj(w4, prof4, "a further pass of the same %d steps with HIP events enabled" % n4, ("r04_pmc_fetch_size_c4.csv", "r04_pmc_write_size_c4.csv"),
-                                                    "profiles/r04_pmc_{fetch,write}_size_c4.csv (rocprofv3 --pmc passes of bench.py --config 4)", "r04_pmc_mfma_c4.csv")
+                cfg4_leg["roofline"] = roofline_obj(w4, prof4, "a further pass of the same %d steps with HIP events enabled" % n4, ("r05_pmc_fetch_size_c4.csv", "r05_pmc_write_size_c4.csv"),
+                                                    "profiles/r05_pmc_{fetch,write}_size_c4.csv (rocprofv3 --pmc passes of bench.py --config 4)", "r05_pmc_mfma_c4.csv", one_launch=leg_one.get(4, False), phases=leg_phases.get(4))
             out["configs3_window"] = cfg4_leg
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(w, opts)

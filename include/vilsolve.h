@@ -293,6 +293,8 @@ int vil_debug_set_split(vil_ctx* ctx, int32_t on);
  * eliminated by a workgroup of the SWEEP launch; 2: no chain workgroup at all (the step kernel eliminates the chain itself, the round-2 structure).
  * Same results to rounding in every mode.  Invalidates the resident window. */
 int vil_debug_set_launch_mode(vil_ctx* ctx, int32_t mode);
+/* what the uploaded window's solves launch per trust-region iteration: 1 (the one-launch iteration), 2 (sweep + gather / step) or 3 (sweep, gather, step) */
+int vil_debug_get_launch_structure(vil_ctx* ctx, int32_t* launches_per_iteration, int32_t* one_launch);
 
 /* replaces estimator.cpp:1126-1419 (build ceres::Problem ... ceres::Solve): state is updated in
  * place on success and left UNCHANGED on any error. */

@@ -1571,7 +1571,6 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
                 if (c->profiling) HIPCHK(hipEventRecord(c->ev[2 * q], c->stream));
                 if (c->fused) {
                     // (one launch: the events bracket the whole iteration; what the sweep roles took inside it comes from the launch's own clock stamps, below)
-                    if (c->profiling) { HIPCHK(hipEventRecord(c->ev[2 * q + 1], c->stream)); HIPCHK(hipEventRecord(c->ev_mid[q], c->stream)); HIPCHK(hipEventRecord(c->ev_coll[q], c->stream)); }
                     st = launch_iter(c, so);
                     if (st != VIL_OK) return st;
                     continue;
@@ -1613,6 +1612,10 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
             live = std::max(0, std::min(live, launched));
             for (int q = 0; q < live; ++q) {
                 float ms = 0.f;
+                if (c->fused) {      // one launch: the events give its whole duration (to step_ms; the sweep phase's share moves to sweep_ms from the launch's own stamps, below)
+                    HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * q], c->ev[2 * q + 2])); c->prof.step_ms += ms; c->prof.sweep_launches++; c->prof.step_launches++;
+                    continue;
+                }
                 HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * q], c->ev[2 * q + 1])); c->prof.sweep_ms += ms; c->prof.sweep_launches++;
                 HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * q + 1], c->ev[2 * q + 2])); c->prof.step_ms += ms; c->prof.step_launches++;
                 HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * q + 1], c->ev_mid[q])); c->prof.reduce_ms += ms;
@@ -2081,6 +2084,13 @@ int vil_comm_info(vil_ctx* c, int32_t* rank, int32_t* world, int32_t* transport)
     return VIL_OK;
 }
 int vil_debug_set_slim_emul(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->slim_emul = on != 0; return VIL_OK; }
+int vil_debug_get_launch_structure(vil_ctx* c, int32_t* launches_per_iteration, int32_t* one_launch) {
+    if (!c || !c->uploaded) return VIL_ERR_INVALID_ARGUMENT;
+    const bool merged = c->P.rs_merged != 0 && !c->split;
+    if (launches_per_iteration) *launches_per_iteration = (c->fused && !c->split) ? 1 : (merged ? 2 : 3);
+    if (one_launch) *one_launch = (c->fused && !c->split) ? 1 : 0;
+    return VIL_OK;
+}
 int vil_debug_set_split(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->force_split = on != 0; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
 int vil_set_gauge_fix(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->gauge_on = on != 0; return VIL_OK; }      // (takes effect in the next solve)
 
