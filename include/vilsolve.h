@@ -326,8 +326,8 @@ int vil_profile_read(vil_ctx* ctx, vil_profile* out, int reset);
 /* One-launch iterations (the whole trust-region iteration as one kernel launch: sweep, gather, chain elimination, step): the launch stamps its phases with the
  * device's 100 MHz wall clock while profiling is on -- vil_profile.sweep_ms is then the sweep PHASE (first workgroup started -> last sweep role's record out),
  * reduce_ms the gather's tail behind it, step_ms the rest of the launch.  vil_profile_phases returns the average position in microseconds of 16 phase stamps
- * after the launch's first workgroup started (csrc/vilsolve.hip lists them) and the number of launches averaged. */
-int vil_profile_phases(vil_ctx* ctx, double* avg_us16, int64_t* launches, int reset);
+ * after the launch's first workgroup started (24 slots; csrc/vilsolve.hip lists them) and the number of launches averaged. */
+int vil_profile_phases(vil_ctx* ctx, double* avg_us24, int64_t* launches, int reset);
 
 /* replaces ceres::CostFunction::Evaluate for a whole factor class at once: raw (no loss) residuals
  * and row-major global-size Jacobian blocks, factor-major, in the caller's factor order. */

@@ -33,58 +33,86 @@ __device__ __forceinline__ double block_sum(double v, double* red /*>= 4 doubles
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int f, const double* x, double* sm) {
+__device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int f, const double* x, double* sm, const int plaunch = -1) {
+    #define IPROF(k) do { if (plaunch >= 0 && f == 0 && threadIdx.x == 0) prof_stamp(P, plaunch, k); } while (0)
+    IPROF(16);
     double* Jraw = sm;            // 450
     double* rr = sm + 450;        // 15
     double* UJ = sm + 480;        // 450
     double* Ur = sm + 930;        // 15
+    double* cs = sm + 960;        // 287: the factor's constants (pre-integrated deltas, their bias Jacobians, linearisation biases, sum_dt)
+    double* Us = sm + 1248;       // 225: sqrt-information (upper triangular)
+    double* xs = sm + 1480;       // 32: pose i | speed-bias i | pose j | speed-bias j
     const double* c = P.imu_c + (size_t)f * 287;
     double* out = P.ipart + (size_t)f * 931;
     const int t = threadIdx.x;
     const int i = P.imu_i[f], j = P.imu_j[f];
-    // (the record is stored at agent scope: the chain workgroup of the same launch may read it -- sweep_signal, prechain 2)
-    if (c[16] > 10.0 || (P.marg && !(P.marg == 1 && i == 0 && j == 1 && c[16] < 10.0))) { for (int e = t; e < 931; e += blockDim.x) st_ag(out + e, 0.0); return; }   // estimator.cpp:1182 / :1535
+    // everything the role reads from memory in ONE round trip, by different threads: constants, sqrt-information and the four state blocks go to LDS (before: sum_dt, then
+    // the constants of every lane, then U inside the whitening loop -- three dependent round trips on the path the chain workgroup waits for)
+    {
+        double v = 0.0;
+        if (t < 287) v = c[t];
+        else if (t < 512) v = P.imu_U[(size_t)f * 225 + (t - 287)];
+        double xv = 0.0;
+        if (t < 32) { const int q = t < 7 ? xo_pose(P, i) + t : (t < 16 ? xo_sb(P, i) + (t - 7) : (t < 23 ? xo_pose(P, j) + (t - 16) : xo_sb(P, j) + (t - 23))); xv = x[q]; }
+        if (t >= 32 && t < 36 && !P.marg) {      // constancy of the four blocks (pose i, speed-bias i, pose j, speed-bias j): in the same round trip, not in front of the whitening
+            const uint8_t* cp = (t & 1) ? P.sb_const : P.pose_const;
+            xv = (cp && cp[t < 34 ? i : j]) ? 1.0 : 0.0;
+        }
+        for (int e = t; e < 450; e += blockDim.x) Jraw[e] = 0.0;
+        if (t < 287) cs[t] = v; else if (t < 512) Us[t - 287] = v;
+        if (t < 36) xs[t] = xv;      // (xs[32 .. 35]: constancy flags)
+    }
+    __syncthreads();
+    IPROF(17);
+    // (the record is stored at agent scope: the chain workgroup of the same launch may read it -- sweep_signal, prechain 2 / the one-launch iteration)
+    if (cs[16] > 10.0 || (P.marg && !(P.marg == 1 && i == 0 && j == 1 && cs[16] < 10.0))) { for (int e = t; e < 931; e += blockDim.x) st_ag(out + e, 0.0); return; }   // estimator.cpp:1182 / :1535
 #ifdef VIL_STAMPS
     #define ISTAMP(k) do { if (t == 0 && f == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[k] = tt_; } } while (0)
 #else
     #define ISTAMP(k) do {} while (0)
 #endif
     ISTAMP(17);
-    for (int e = t; e < 450; e += blockDim.x) Jraw[e] = 0.0;
-    __syncthreads();
-    if (t <= IMU_NBLOCKS) {   // lanes 0..16: one 3x3 block each (common terms recomputed per lane); lane 17: residual
-        ImuCommon o;
-        imu_common(c, V3{P.G[0], P.G[1], P.G[2]}, x + xo_pose(P, i), x + xo_sb(P, i), x + xo_pose(P, j), x + xo_sb(P, j), o);
-        if (t == IMU_NBLOCKS) imu_resid(o, rr);
-        else {
-            int r0, c0; M3 m; double sc;
-            imu_block(o, c, t, r0, c0, m, sc);
-            put33(Jraw, 30, r0, c0, m, sc);
-            if (t == 16) put33(Jraw, 30, 12, 27, m, sc);
+    if ((t & 63) < 3) {   // the 17 3 x 3 blocks + the residual, dealt to three lanes of each of the eight waves (common terms recomputed per lane): a wave runs the divergent
+        // block cases of ITS lanes one after the other -- eighteen lanes of one wave walked all seventeen cases (2.5 us); two waves share a SIMD: ~5 cases per SIMD now
+        const int item = (t >> 6) + 8 * (t & 63);      // 0 .. 23
+        if (item <= IMU_NBLOCKS) {
+            ImuCommon o;
+            imu_common(cs, V3{P.G[0], P.G[1], P.G[2]}, xs, xs + 7, xs + 16, xs + 23, o);
+            if (item == IMU_NBLOCKS) imu_resid(o, rr);
+            else {
+                int r0, c0; M3 m; double sc;
+                imu_block(o, cs, item, r0, c0, m, sc);
+                put33(Jraw, 30, r0, c0, m, sc);
+                if (item == 16) put33(Jraw, 30, 12, 27, m, sc);
+            }
         }
     }
     __syncthreads();
     ISTAMP(18);
-    const double* U = P.imu_U + (size_t)f * 225;
-    const bool fr = P.marg != 0;             // marginalisation: every block free
-    const bool ci = !fr && P.pose_const && P.pose_const[i], cj = !fr && P.pose_const && P.pose_const[j];
-    const bool si = !fr && P.sb_const && P.sb_const[i], sj = !fr && P.sb_const && P.sb_const[j];
+    IPROF(18);
+    const double* U = Us;
+    const bool ci = xs[32] != 0.0, si = xs[33] != 0.0, cj = xs[34] != 0.0, sj = xs[35] != 0.0;      // (marginalisation: every block free -- the flags are zero)
+    // (U is upper triangular WITH its zeros stored: a fixed fifteen-term sum -- every LDS read in flight at once -- instead of a loop from the row's diagonal; the same bits)
     for (int e = t; e < 465; e += blockDim.x) {
         if (e < 450) {
             const int row = e / 30, col = e % 30;
             const bool cst = col < 6 ? ci : (col < 15 ? si : (col < 21 ? cj : sj));
             double s = 0;
-            if (!cst) for (int k = row; k < 15; ++k) s += U[row * 15 + k] * Jraw[k * 30 + col];
-            UJ[e] = s;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) { const double u = U[row * 15 + k], jv = Jraw[k * 30 + col]; s += k >= row ? u * jv : 0.0; }
+            UJ[e] = cst ? 0.0 : s;
         } else {
             const int row = e - 450;
             double s = 0;
-            for (int k = row; k < 15; ++k) s += U[row * 15 + k] * rr[k];
+#pragma unroll
+            for (int k = 0; k < 15; ++k) { const double u = U[row * 15 + k], rv = rr[k]; s += k >= row ? u * rv : 0.0; }
             Ur[row] = s;
         }
     }
     __syncthreads();
     ISTAMP(19);
+    IPROF(19);
     for (int e = t; e < 931; e += blockDim.x) {
         double s = 0;
         if (e < 900) { const int a = e / 30, b = e % 30; for (int k = 0; k < 15; ++k) s += UJ[k * 30 + a] * UJ[k * 30 + b]; }
@@ -93,6 +121,7 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
         st_ag(out + e, s);
     }
     ISTAMP(28);
+    IPROF(20);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -779,7 +808,7 @@ __device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, co
             if (threadIdx.x == 0) { vd::st_ag(P.sflag + blk, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u)); prof_stamp(P, ctl.n_sweeps, blk < P.n_imu ? 2 : (blk == P.n_imu ? 15 : 1)); }
         }
     };
-    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm); if (pre) sweep_signal(P, ctl, b); posted(); return; }
+    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm, FUSED ? ctl.n_sweeps : -1); if (pre) sweep_signal(P, ctl, b); posted(); return; }
     b -= P.n_imu;
     if (b == 0) { if (!(P.skip_mask & 16)) vd::sweep_prior(P, x, sm); if (pre) sweep_signal(P, ctl, P.n_imu); posted(); return; }
     if (b == 1) {
