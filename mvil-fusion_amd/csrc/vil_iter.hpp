@@ -43,4 +43,13 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_iter(DevP P, SolveOpts O) 
     }
     vd::StepShared& s = *reinterpret_cast<vd::StepShared*>(dyn);
     step_body<true, 3, true>(P, O, s, dyn + VIL_SS_DOUBLES, p0);
+    // The first launch that finds the solve FINISHED writes the result out (accepted state -> x[0], gauge fix, Ctl + state into the host mirror, the sequence word the
+    // host polls): its master workgroup, which has nothing else to do -- every role returned at once.  A chunk of enqueued iterations may then be sized generously:
+    // the host is released behind the first dead launch (~5 us), not behind the chunk's no-op tail and k_finish (which still covers a solve that ends in the last
+    // launch of its chunk).  ONE call site, outside the step roles: inlined at the step's five exits the parameter block went to scratch memory (round 4).
+    if (p0 == 1) {
+        __syncthreads();
+        if (s.done_at_entry && s.c.outd == 0 && s.c.lin_mode == 0)
+            vd::solve_finish(P.x[0], P.x[1], P.xorig, P.hstate, P.ctl, P.hctl, P.hseq, P.K, P.NS, P.gauge_on, s.c.cur, s.c.status, s.c.gen, dyn + VIL_SS_DOUBLES);
+    }
 }

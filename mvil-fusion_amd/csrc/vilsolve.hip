@@ -291,6 +291,7 @@ struct vil_ctx {
     bool force_split = false;      // vil_debug_set_split: that plumbing on a single rank
     int launch_mode = 0;           // vil_debug_set_launch_mode: 0 = the library's choice, 1 = no merged launch, 2 = no chain workgroup, 3 = sweep + merged gather / step launch (no one-launch iteration)
     int last_live = 5;             // live sweep launches of the previous solve (sizes the first launch chunk)
+    int recent_live[8] = {5, 5, 5, 5, 5, 5, 5, 5}; int recent_at = 0;      // ... of the last eight solves: the first solve of an upload (a tracker's image) is sized by their maximum
     int lm_b = 0, lm_e = 0;        // owned landmark range
     OwnSeg own = {0, 0, 0, {0}, {0}};      // every rank's landmark / factor range in the per-iteration message (sharded windows)
     // ---- window residency across frames (vil_lidar_*, vil_set_gauge_fix, vil_marginalize_resident) --------------------------------
@@ -426,6 +427,7 @@ int vil_create(const vil_device_cfg* cfg, vil_ctx** out) {
     c->device = cfg->device; c->rank = cfg->rank; c->world = cfg->world > 0 ? cfg->world : 1;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc(&c->d_status, sizeof(int)));
+    HIPCHK(hipMemset(c->d_status, 0, sizeof(int)));
     HIPCHK(hipHostMalloc(&c->h_ctl, sizeof(Ctl), hipHostMallocDefault));
     c->no_poll = getenv("VIL_NO_POLL") != nullptr;
     memset(&c->P, 0, sizeof c->P);
@@ -550,8 +552,15 @@ struct VisPlan {
 static bool plan_visual(const int K, const int L, const int n_vis, const std::vector<int>& lms, const std::vector<int>& fmin, const std::vector<int>& fmax, const std::vector<int>& anch,
                         const int vwg_max, const int cap_forced, VisPlan& o) {
     o.order.clear(); o.fperm.assign(std::max(n_vis, 1), 0); o.finv.assign(std::max(n_vis, 1), 0);
-    for (int l = 0; l < L; ++l) if (lms[l + 1] > lms[l]) o.order.push_back(l);
-    std::sort(o.order.begin(), o.order.end(), [&](int a, int b) { return fmin[a] != fmin[b] ? fmin[a] < fmin[b] : (fmax[a] != fmax[b] ? fmax[a] < fmax[b] : a < b); });
+    {   // by (first frame, last frame, index): a counting sort over the K^2 frame pairs, stable in the index (a comparison sort of a tracker's ~1000 landmarks was 40 us of
+        // every image's 110 us of host preparation)
+        std::vector<int> cnt((size_t)K * K + 1, 0);
+        int nlive = 0;
+        for (int l = 0; l < L; ++l) if (lms[l + 1] > lms[l]) { ++cnt[(size_t)fmin[l] * K + fmax[l] + 1]; ++nlive; }
+        for (size_t q = 0; q < (size_t)K * K; ++q) cnt[q + 1] += cnt[q];
+        o.order.assign(nlive, 0);
+        for (int l = 0; l < L; ++l) if (lms[l + 1] > lms[l]) o.order[cnt[(size_t)fmin[l] * K + fmax[l]]++] = l;
+    }
     { int pos = 0; for (int l : o.order) for (int f = lms[l]; f < lms[l + 1]; ++f) { o.fperm[pos] = f; o.finv[f] = pos; ++pos; } }
     const std::vector<int>& order = o.order;
     struct Chunk { int p0, nl, nf, fa, span; };
@@ -1179,7 +1188,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     }
     UPTICK("h2d+attrs");
     // one-time set-up: IMU sqrt-information, prior contraction
-    HIPCHK(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
+    if (!ws) HIPCHK(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));      // (resident window: nothing writes it -- its status word is the window's own, vil_win_solve -- and a 4-byte fill is a 5 us launch)
     if (ws) {
         // resident window: expand the landmark table into the factor tables, gather the IMU records, copy the state -- everything k_setup
         // would compute (sqrt-information, prior contractions) already sits next to its source
@@ -1533,6 +1542,11 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     // iterations are enqueued in chunks without host round trips; the first chunk is sized by the previous solve of
     // this context (consecutive windows of a tracker need similar iteration counts), later chunks are short
     int chunk = std::min(15, std::max(3, c->last_live));
+    // One-launch iterations write the result out themselves as soon as a launch finds the solve finished (vil_iter.hpp): a chunk that is too LONG costs the stream
+    // ~5 us per dead launch and the host nothing, one that is too SHORT costs a host round trip (~70 us) and a second chunk.  The first solve of an upload -- what a
+    // tracker runs per image, iteration counts wandering by one or two from image to image -- therefore enqueues the largest count of the last eight solves plus two;
+    // re-solves of one upload (graph replay, the same count again and again) keep the exact size.
+    if (c->fused && c->solves_since_upload == 0) { int mx = 3; for (int v : c->recent_live) mx = std::max(mx, v); chunk = std::min(24, mx + 2); }
     for (int it = 0; it <= o->max_iterations + 8 && !finished; chunk = 3) {
         int launched = 0;
         const int sweeps_before = (it == 0) ? 0 : c->h_ctl->n_sweeps;
@@ -1637,6 +1651,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     c->solves_since_upload++;
     const Ctl& ctl = *c->h_ctl;
     c->last_live = ctl.n_sweeps;
+    c->recent_live[c->recent_at++ & 7] = ctl.n_sweeps;
     if (c->profiling && c->fused && c->d_prof && ctl.n_sweeps <= 64) {
         // the launches' own clock stamps (100 MHz): the sweep phase of a one-launch iteration = first workgroup started -> last sweep role posted
         std::vector<unsigned long long> hp((size_t)64 * VIL_PROF_SLOTS);

@@ -170,10 +170,11 @@ class Backend:
         f = self._wf = getattr(self, "_wf", None) or abi.VilWinFrame()
         c = np.ascontiguousarray
         keep = (c(fr["dt"], np.float64), c(fr["acc"], np.float64), c(fr["gyr"], np.float64), c(fr["obs_track"], np.int32), c(fr["obs"], np.float64), c(fr["plane"], np.float64), c(fr["edge"], np.float64))
-        f.n_samples = len(keep[0]); f.dt, f.acc, f.gyr = keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data
+        ad = lambda a: a.__array_interface__["data"][0]
+        f.n_samples = len(keep[0]); f.dt, f.acc, f.gyr = ad(keep[0]), ad(keep[1]), ad(keep[2])
         f.acc0[:] = [float(v) for v in fr["acc0"]]; f.gyr0[:] = [float(v) for v in fr["gyr0"]]; f.lin_ba[:] = [float(v) for v in fr["lin_ba"]]; f.lin_bg[:] = [float(v) for v in fr["lin_bg"]]
-        f.n_obs = len(keep[3]); f.obs_track, f.obs = keep[3].ctypes.data, keep[4].ctypes.data
-        f.n_plane = keep[5].size // 7; f.plane_const = keep[5].ctypes.data; f.n_edge = keep[6].size // 9; f.edge_const = keep[6].ctypes.data
+        f.n_obs = len(keep[3]); f.obs_track, f.obs = ad(keep[3]), ad(keep[4])
+        f.n_plane = keep[5].size // 7; f.plane_const = ad(keep[5]); f.n_edge = keep[6].size // 9; f.edge_const = ad(keep[6])
         self._call("win_push_frame", C.byref(f))
 
     def win_drop_frame(self, flag):
