@@ -163,7 +163,7 @@ def cpu_baseline(w, opts, budget_s=10.0):
 
 PHASE_NAMES = ["first workgroup started", "last visual / LiDAR / ICP-LPS role done", "last IMU role done", "chain workgroup saw the IMU / prior records", "chain: W^T complete", "last gather workgroup done",
                "last gather workgroup saw the visual flags", "master started", "master saw the gather's flags", "master saw the W W^T tiles", "dense factorisation done", "x_p published", "master done",
-               "last tile workgroup done", "chain: its part of S' gathered", "prior role done", "IMU role 0 entered", "IMU role 0: inputs staged", "IMU role 0: raw blocks done", "IMU role 0: whitened", "IMU role 0: record stores issued", "-", "-", "-"]
+               "last tile workgroup done", "chain: its part of S' gathered", "prior role done", "IMU role 0 entered", "IMU role 0: inputs staged", "IMU role 0: raw blocks done", "IMU role 0: whitened", "IMU role 0: record stores issued", "master: chain back-substituted", "master: step vectors and the helpers' sums in", "master: candidate formed"]
 
 
 def phases_obj(be):
@@ -171,7 +171,7 @@ def phases_obj(be):
     avg = (C.c_double * 24)(); n = C.c_int64(0)
     if be.lib.vil_profile_phases(be.ctx, avg, C.byref(n), 1) != 0 or n.value == 0:
         return None
-    order = sorted([q for q in range(1, 21) if avg[q] > 0], key=lambda q: avg[q])
+    order = sorted([q for q in range(1, 24) if avg[q] > 0], key=lambda q: avg[q])
     return {"unit": "us after the launch's first workgroup started", "launches_averaged": int(n.value), "source": "s_memrealtime stamps of the roles (csrc/vil_dev.hpp: prof_stamp); XCD clocks agree to ~1-2 us",
             "stamps": {PHASE_NAMES[q]: round(float(avg[q]), 2) for q in order}}
 

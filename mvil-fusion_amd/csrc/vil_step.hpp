@@ -1140,8 +1140,14 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     bool hseen = false;
     // (... and, gather + step in one launch: the chain / tile workgroups have read Ctl too -- a tile's flag implies the chain's; n_ww <= 45)
     auto wait_helpers = [&]() { if (!hseen && t < nhelp) wait1(P.hflag + t); if (!hseen && merged && P.prechain && t < P.n_ww) wait1(P.wwflag + t); hseen = true; };
-    // wave 0: the end of the master's iteration on every path -- every helper (and tile workgroup) has read Ctl, then the new one goes out
-    auto end_iter = [&]() { wait_helpers(); store_ctl(); };
+    // wave 0: the end of the master's iteration on every path -- every helper (and tile workgroup) has read Ctl, then the new one goes out.  A wait of this launch
+    // that gave up (vil_math.hpp: spin_until_eq) ends the solve here with a device error instead of letting numbers formed from incomplete data through
+    auto end_iter = [&]() {
+        wait_helpers();
+        if (t == 0 && P.abortf && ld_ag(P.abortf) != 0) { s.c.done = 1; s.c.term = 6; s.c.status = -2; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        store_ctl();
+    };
     const bool cam = true;             // (every rank holds the complete system: nothing is counted per rank any more)
     STAMP(0);
     // ---------------- judge the candidate that the sweep just linearised -------------------------
@@ -1466,6 +1472,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         }
         if constexpr (CHAIN == 0) { if constexpr (LDSM) ok = chol_lookahead<CH_SLOTS, false>(Alds, D, s); else ok = chol_blocked<false>(P.M, D, s, Alds); }      // Alds = staging of the active tile column
         STAMP(3);
+        PROF(21);
 #ifdef VIL_STAMPS
         if (t == 0) { P.dbg[20] = s.tacc[0]; P.dbg[21] = s.tacc[1]; P.dbg[22] = s.tacc[2]; P.dbg[24] = s.tacc[3]; P.dbg[25] = s.tacc[4]; P.dbg[26] = s.tacc[5]; }
 #endif
@@ -1540,6 +1547,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         __syncthreads();
     }
     STAMP(5);
+    PROF(22);
     // ---------------- traditional dogleg in dogleg space (scalars saved with the linearisation) ----------------
     gn2 = s.c.gn2; g2 = s.c.g2; gg = s.c.gg;
     const double radius = s.c.radius, alpha = s.c.alpha, mu_u = s.c.mu_used;
@@ -1595,6 +1603,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     // landmark share of the norms from the sums of the pass
     xn += s.c.xnl; sn += cg * cg * s.c.saa + 2.0 * cg * cn * s.c.sab + cn * cn * s.c.sbb;
     STAMP(6);
+    PROF(23);
     if (t == 0) {
         Ctl& c = s.c;
         c.iter++;

@@ -1486,7 +1486,8 @@ int vil_profile_enable(vil_ctx* c, int on) {
  * [0] 0, [1] last visual / LiDAR / ICP-LPS role done, [2] last IMU role done, [3] chain: records seen, [4] chain: W^T complete, [5] last gather workgroup done,
  * [6] last gather workgroup saw the visual flags, [7] master started, [8] master saw the gather's flags, [9] master saw the W W^T tiles,
  * [10] dense factorisation done, [11] x_p published, [12] master done, [13] last tile workgroup done, [14] chain: its part of S' gathered, [15] prior role done,
- * [16 .. 20] IMU role of factor 0: entered, inputs staged, raw blocks done, whitened, record stores issued; [21 .. 23] unused */
+ * [16 .. 20] IMU role of factor 0: entered, inputs staged, raw blocks done, whitened, record stores issued; [21 .. 23] master: chain back-substituted (solve done),
+ * step vectors + helpers' sums in, candidate formed */
 int vil_profile_phases(vil_ctx* c, double* avg_us, int64_t* launches, int reset) {
     if (!c || !avg_us) return VIL_ERR_INVALID_ARGUMENT;
     for (int k = 0; k < VIL_PROF_SLOTS; ++k) avg_us[k] = c->phase_n ? c->phase_us[k] / (double)c->phase_n : 0.0;

@@ -173,4 +173,4 @@ def test_window_example_reproduces_harness(hip):
         # the window solve is bit-reproducible since round 4 (no unordered sum left); what separates the two runs is the %.17g round trip of the C++ program's
         # print-out and nothing else
         assert abs(float(r[4]) - c0) <= 1e-12 * c0 and abs(float(r[5]) - c1) <= 1e-12 * c1
-        assert np.abs(np.array([float(v) for v in r[7:14]]) - pose).max() < 1e-12
+        assert np.abs(np.array([float(v) for v in r[7:14]]) - pose).max() < 1e-12, (r[1], np.abs(np.array([float(v) for v in r[7:14]]) - pose))

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g; g.load_package()
 from mvil_fusion_amd import abi, lib, synth
 NAMES = ["first wg start", "last visual/lidar/rel role done", "last imu role done", "chain: records seen", "chain: W^T complete", "last gather wg done", "last gather wg saw visual flags", "master started",
-         "master saw gather flags", "master saw tiles", "cholesky done", "x_p published", "master done", "last tile wg done", "chain: slab gathered", "prior role done", "imu0: role entered", "imu0: inputs staged", "imu0: raw blocks done", "imu0: whitened", "imu0: record stores issued", "-", "-", "-"]
+         "master saw gather flags", "master saw tiles", "cholesky done", "x_p published", "master done", "last tile wg done", "chain: slab gathered", "prior role done", "imu0: role entered", "imu0: inputs staged", "imu0: raw blocks done", "imu0: whitened", "imu0: record stores issued", "master: chain back-substituted", "master: step vectors + helpers' sums in", "master: candidate formed"]
 for cfg in [int(v) for v in os.environ.get("CFG", "2").split(",")]:
     be = lib.open_vilsolve()
     mode = int(os.environ.get("MODE", "0"))
