@@ -64,6 +64,7 @@ struct DevP {
     // LiDAR points, sorted by pose; chunk = (start, count, pose)
     int n_plane, pl_stride, n_pchunk; const double* pl_c; const int* pchunk;
     int n_edge, ed_stride, n_echunk; const double* ed_c; const int* echunk;
+    int lidar_rep;                // passes of two 256-point chunks a LiDAR workgroup of the sweep makes (vil_sweep.hpp: sweep_body)
     double Rbl[9], tbl[3];
     // IMU
     int n_imu; const double* imu_c; const double* imu_U; const int* imu_i; const int* imu_j;

@@ -827,10 +827,12 @@ __device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, co
     // visual workgroups next: the longest-running factor role
     if (b < P.n_vwg) { if (!(P.skip_mask & 1)) vd::sweep_visual<TS, FUSED>(P, O, ctl, b, x, sb, sm); posted(); return; }
     b -= P.n_vwg;
-    const int per = VIL_SWEEP_THREADS / 256, npw = (P.n_pchunk + per - 1) / per;
-    if (b < npw) { if (!(P.skip_mask & 4)) vd::sweep_lidar<1, FUSED>(P, O, b, x, sm); posted(); return; }
+    // LiDAR roles: 2 chunks of 256 points per pass, P.lidar_rep passes per workgroup (1 unless the window has more sweep roles than the device has compute units:
+    // configs[2]'s 120 k points are 235 two-chunk workgroups -- with the visual roles two dispatch rounds, and the gather workgroups of a one-launch iteration queue behind them)
+    const int per = VIL_SWEEP_THREADS / 256, R = max(P.lidar_rep, 1), npw = (P.n_pchunk + per * R - 1) / (per * R);
+    if (b < npw) { if (!(P.skip_mask & 4)) for (int r = 0; r < R; ++r) { if (r) __syncthreads(); vd::sweep_lidar<1, FUSED>(P, O, b * R + r, x, sm); } posted(); return; }
     b -= npw;
-    if (!(P.skip_mask & 8)) vd::sweep_lidar<3, FUSED>(P, O, b, x, sm);
+    if (!(P.skip_mask & 8)) for (int r = 0; r < R; ++r) { if (r) __syncthreads(); vd::sweep_lidar<3, FUSED>(P, O, b * R + r, x, sm); }
     posted();
 }
 

@@ -1019,7 +1019,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     }
     if (const char* ev = VIL_TUNE_ENV("VIL_SKIP")) P.skip_mask = atoi(ev);
     // helper workgroups of the step kernel: worth it once every master thread would own more than one landmark
-    P.n_help = L >= 2 * VIL_STEP_THREADS ? 7 : (L >= VIL_STEP_THREADS ? 3 : 0);
+    P.n_help = L > 7 * VIL_STEP_THREADS ? 15 : (L >= 2 * VIL_STEP_THREADS ? 7 : (L >= VIL_STEP_THREADS ? 3 : 0));      // (a helper keeps ITS landmarks' rows in registers between its two passes as long as it has a thread per landmark: configs[2]'s 4000 landmarks on 7 helpers fell off that path)
     if (const char* ev = VIL_TUNE_ENV("VIL_HELP")) P.n_help = std::max(0, std::min(15, atoi(ev)));
     // master and helpers wait for one another inside the launch: all of them must be resident at once (vil_coop.hpp).  With its
     // dynamic LDS a step workgroup owns a compute unit; a device with fewer units than 1 + n_help runs without helpers.
@@ -1077,7 +1077,17 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     if (!c->no_poll) { const int ms = ensure_mirror(c, (size_t)NS); if (ms != VIL_OK) return ms; }
     c->P.hctl = c->d_hctl; c->P.hseq = c->d_hseq; c->P.hstate = c->d_hstate;
     c->P.xorig = c->d_x0; c->P.gauge_on = c->gauge_on ? 1 : 0; c->P.setup_stat = c->d_status;
-    { const int per = VIL_SWEEP_THREADS / 256; c->n_blocks_sweep = P.n_imu + P.n_vwg + (P.n_pchunk + per - 1) / per + (P.n_echunk + per - 1) / per + 2; }
+    {
+        const int per = VIL_SWEEP_THREADS / 256;
+        auto nsw = [&](int R) { return P.n_imu + P.n_vwg + (P.n_pchunk + per * R - 1) / (per * R) + (P.n_echunk + per * R - 1) / (per * R) + 2; };
+        // (LiDAR workgroups can make several passes of two chunks -- fewer, longer workgroups when a window has more sweep roles than the device has compute units.
+        //  Measured at configs[2], 496 sweep roles: 1 pass 1068 us per 13-iteration solve, 2 passes 1085, 4 passes 1120, 8 passes 1282: the dispatcher's second round
+        //  balances better than any static packing.  One pass; the knob stays in the tuning build.)
+        int R = 1;
+        if (const char* ev = VIL_TUNE_ENV("VIL_LIDAR_REP")) R = std::max(1, atoi(ev));
+        P.lidar_rep = R; c->P.lidar_rep = R;
+        c->n_blocks_sweep = nsw(R);
+    }
     // visual workgroups: the staged factors, the landmark records, the dense operand rows of the largest chunk
     c->lds_sweep = sizeof(double) * (size_t)(VIS_LDS_FIXED + c->vis_gm);
     if (c->lds_sweep < 8 * 2048) c->lds_sweep = 8 * 2048;
