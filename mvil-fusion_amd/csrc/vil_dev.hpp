@@ -44,6 +44,21 @@ struct SolveOpts {
     double visual_loss_scale, lidar_loss_scale, rel_loss_scale;
 };
 
+// The 405 of an IMU record's 931 doubles [30x30 H | 30 g | cost] that the chain workgroup gathers (speed-bias blocks of both frames, lower triangles; the block between them;
+// the pose rows against the speed-bias columns; the speed-bias gradient), as one compact record: the chain workgroup is ONE compute unit pulling these across the
+// device, bound by the lines it has in flight -- 405 contiguous doubles instead of 9-double runs in 240-byte rows.  -1: not gathered.  Host (table) and device (IMU role).
+#define VIL_CHAIN_REC 405
+__host__ __device__ inline int chain_rec_index(const int e) {
+    if (e >= 930) return -1;
+    if (e >= 900) { const int c = e - 900; return (c >= 6 && c < 15) ? 387 + c - 6 : c >= 21 ? 396 + c - 21 : -1; }
+    const int r = e / 30, c = e - 30 * r;
+    const bool ci = c >= 6 && c < 15, cj = c >= 21;
+    if (!ci && !cj) return -1;
+    if (r >= 6 && r < 15) return (ci && c <= r) ? (r - 6) * (r - 5) / 2 + c - 6 : -1;
+    if (r >= 21) return ci ? 90 + (r - 21) * 9 + c - 6 : c <= r ? 45 + (r - 21) * (r - 20) / 2 + c - 21 : -1;
+    const int pr = r < 6 ? r : r - 9;
+    return ci ? 171 + pr * 9 + c - 6 : 279 + pr * 9 + c - 21;
+}
 struct DevP {
     int K, L, D, NV, NS;
     // constancy
@@ -89,6 +104,8 @@ struct DevP {
     double* lpart;                // (n_pchunk + n_echunk) x 28  [21 upper 6x6 | 6 g | cost]
     const int* lchunk_pose;       // 2 x (K+1): chunk ranges per pose (plane, edge)
     double* ipart;                // n_imu x 931  [30x30 H | 30 g | cost]
+    double* chc;                  // the prior's constant share (J0^T J0 entries) of the chain workgroup's gather, in table order: written by the first iteration of a solve, read by the later ones
+    double* irec;                 // n_imu x VIL_CHAIN_REC: one-launch iteration -- the part of the IMU records the chain workgroup gathers, compact (chain_rec_index)
     double* mpart;                // prior: [pn g | cost] then n_rel x 601 [24x24 H | 24 g | cost]
     const int* pinv;              // D: reduced column -> prior column or -1
     double* Sl; double* Sc; double* dc; double* dl; double* gradc; double* gradl; double* gnc; double* gnl;

@@ -124,21 +124,45 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     double* slab = B.dg;
     constexpr int QN = 8;                              // entries per thread and round (K = 10: one round; K = 20, 6840 entries: two)
     int4 q[QN], q2[QN]; double a[QN], b[QN], c[QN];
+    // (IMU sources of an entry: index into the 931-double records + 1 in the low half, index into the compact tagged records of a one-launch iteration + 1 in the high half)
+    auto entry = [&](const int e) { int4 v = tab[min(e, n - 1)]; v.y = FUSED ? (v.y >> 16) - 1 : (v.y & 0xffff) - 1; v.z = FUSED ? (v.z >> 16) - 1 : (v.z & 0xffff) - 1; return v; };
 #pragma unroll
-    for (int u = 0; u < QN; ++u) { q[u] = tab[min(t + u * NT, n - 1)]; q2[u] = tab[min(t + (QN + u) * NT, n - 1)]; }      // (the second round's entries too: no table round trip behind the flags)
+    for (int u = 0; u < QN; ++u) { q[u] = entry(t + u * NT); q2[u] = entry(t + (QN + u) * NT); }      // (the second round's entries too: no table round trip behind the flags)
     const double sc_prev = (t < NB && !ctl.first) ? P.Sc[NP + t] : 0.0;
     const int pqv = P.chpq[min(t, NB - 1)];
     const double* const pHs = P.pn > 0 ? P.pH : P.mpart;
     // (IMU / prior records: agent-scope loads -- inside k_sweep they were written by workgroups of this launch; unconditional loads + selects)
-    auto sources = [&]() {
+    auto sources = [&](const int e0) {
+        if constexpr (FUSED) {
+            // one-launch iteration.  This workgroup is ONE compute unit pulling its sources across the device with agent-scope loads, which cost per LANE (measured:
+            // ~5 lanes per ns, whatever the lines they fall into), so
+            //  - only the sources an entry has are loaded (fewer than half of the three are there: the prior's gradient in 9 K entries of ~3000);
+            //  - the prior's constant share (J0^T J0 entries) is read from the matrix by the first iteration of a solve only, which leaves it in table order for the
+            //    later ones -- plain, coalesced loads;
+            //  - the IMU roles leave what is gathered here as compact records (chain_rec_index, vil_dev.hpp) and the table is sorted by source.
+#pragma unroll
+            for (int u = 0; u < QN; ++u) {
+                a[u] = 0.0; b[u] = 0.0; c[u] = 0.0;
+                if (q[u].y >= 0) a[u] = ld_ag(P.irec + q[u].y);
+                if (q[u].z >= 0) b[u] = ld_ag(P.irec + q[u].z);
+                const int cw = q[u].w;
+                if (cw < -1) c[u] = ld_ag(P.mpart - cw - 2);
+                else if (cw >= 0) c[u] = ctl.first ? ld_ag(pHs + cw) : P.chc[min(e0 + u * NT, n - 1)];
+            }
+            if (ctl.first) {
+#pragma unroll
+                for (int u = 0; u < QN; ++u) if (e0 + u * NT < n && q[u].w >= 0) P.chc[e0 + u * NT] = c[u];
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < QN; ++u) {
             a[u] = ld_ag(P.ipart + max(q[u].y, 0)); b[u] = ld_ag(P.ipart + max(q[u].z, 0));
             const int cw = q[u].w;
             c[u] = ld_ag(cw >= 0 ? pHs + cw : P.mpart + max(-cw - 2, 0));      // (no prior: cw is never >= 0)
         }
+        }
     };
-    if (!wait_records) sources();
+    if (!wait_records) sources(t);
     { double* z = B.dg; const int nz = (int)chain_slab_fp(K); for (int e = t; e < nz; e += NT) z[e] = 0.0; }
     if (t < NB) B.pq[t] = pqv;
     for (int e = t + NT; e < NB; e += NT) B.pq[e] = P.chpq[e];
@@ -150,12 +174,12 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     __syncthreads();
     PSTAMP(31);
     if (FUSED && t == 0) prof_stamp(P, epoch - 1, 3);
-    if (wait_records) sources();                           // (inside k_sweep the records are complete only behind the flags)
+    if (wait_records) sources(t);                           // (inside k_sweep the records are complete only behind the flags)
     for (int e0 = t; e0 < n; e0 += QN * NT) {
         if (e0 != t) {
 #pragma unroll
-            for (int u = 0; u < QN; ++u) q[u] = e0 == t + QN * NT ? q2[u] : tab[min(e0 + u * NT, n - 1)];
-            sources();
+            for (int u = 0; u < QN; ++u) q[u] = e0 == t + QN * NT ? q2[u] : entry(e0 + u * NT);
+            sources(e0);
         }
 #pragma unroll
         for (int u = 0; u < QN; ++u) if (e0 + u * NT < n) {

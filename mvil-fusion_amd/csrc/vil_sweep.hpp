@@ -33,7 +33,8 @@ __device__ __forceinline__ double block_sum(double v, double* red /*>= 4 doubles
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int f, const double* x, double* sm, const int plaunch = -1) {
+__device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int f, const double* x, double* sm, const int plaunch = -1, const bool chain_rec = false /* one-launch iteration: what the chain workgroup gathers also leaves as a compact record (chain_rec_index, vil_dev.hpp) */) {
+    double* const outc = chain_rec ? P.irec + (size_t)f * VIL_CHAIN_REC : nullptr;
     #define IPROF(k) do { if (plaunch >= 0 && f == 0 && threadIdx.x == 0) prof_stamp(P, plaunch, k); } while (0)
     IPROF(16);
     double* Jraw = sm;            // 450
@@ -66,7 +67,7 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
     __syncthreads();
     IPROF(17);
     // (the record is stored at agent scope: the chain workgroup of the same launch may read it -- sweep_signal, prechain 2 / the one-launch iteration)
-    if (cs[16] > 10.0 || (P.marg && !(P.marg == 1 && i == 0 && j == 1 && cs[16] < 10.0))) { for (int e = t; e < 931; e += blockDim.x) st_ag(out + e, 0.0); return; }   // estimator.cpp:1182 / :1535
+    if (cs[16] > 10.0 || (P.marg && !(P.marg == 1 && i == 0 && j == 1 && cs[16] < 10.0))) { for (int e = t; e < 931; e += blockDim.x) { st_ag(out + e, 0.0); if (outc) { const int ce = chain_rec_index(e); if (ce >= 0) st_ag(outc + ce, 0.0); } } return; }   // estimator.cpp:1182 / :1535
 #ifdef VIL_STAMPS
     #define ISTAMP(k) do { if (t == 0 && f == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[k] = tt_; } } while (0)
 #else
@@ -119,6 +120,7 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
         else if (e < 930) { const int a = e - 900; for (int k = 0; k < 15; ++k) s += UJ[k * 30 + a] * Ur[k]; }
         else { for (int k = 0; k < 15; ++k) s += Ur[k] * Ur[k]; s *= 0.5; }
         st_ag(out + e, s);
+        if (outc) { const int ce = chain_rec_index(e); if (ce >= 0) st_ag(outc + ce, s); }
     }
     ISTAMP(28);
     IPROF(20);
@@ -808,7 +810,7 @@ __device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, co
             if (threadIdx.x == 0) { vd::st_ag(P.sflag + blk, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u)); prof_stamp(P, ctl.n_sweeps, blk < P.n_imu ? 2 : (blk == P.n_imu ? 15 : 1)); }
         }
     };
-    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm, FUSED ? ctl.n_sweeps : -1); if (pre) sweep_signal(P, ctl, b); posted(); return; }
+    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm, FUSED ? ctl.n_sweeps : -1, FUSED); if (pre) sweep_signal(P, ctl, b); posted(); return; }
     b -= P.n_imu;
     if (b == 0) { if (!(P.skip_mask & 16)) vd::sweep_prior(P, x, sm); if (pre) sweep_signal(P, ctl, P.n_imu); posted(); return; }
     if (b == 1) {

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <array>
 #include <memory>
 #include <pthread.h>
 
@@ -236,6 +237,7 @@ __global__ void k_slim_emul(double* Msum, double* Gall, PeerPtrs pp, SlimLay Y) 
     }
 }
 
+#define VIL_CHC_MAX 16384      // entries of the chain workgroup's gather table (K = 20: ~7000)
 #define VIL_SFLAG_MAX 4096      // sweep workgroups a one-launch iteration may have (configs[2]: ~600)
 struct vil_ctx {
     int device = 0, rank = 0, world = 1;
@@ -884,6 +886,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     put(nullptr, 8 * (size_t)225 * std::max(p->n_imu, 1), (void**)&P.imu_U);
     put(p->imu_i, 4 * (size_t)p->n_imu, (void**)&P.imu_i); put(p->imu_j, 4 * (size_t)p->n_imu, (void**)&P.imu_j);
     put(nullptr, 8 * (size_t)931 * std::max(p->n_imu, 1), (void**)&P.ipart);
+    put(nullptr, 8 * (size_t)VIL_CHAIN_REC * std::max(p->n_imu, 1), (void**)&P.irec);      // (compact IMU records for the chain workgroup of a one-launch iteration)
     // prior
     P.pn = p->prior.n > 0 ? p->prior.n : 0; P.pnblk = P.pn ? p->prior.nblk : 0;
     c->prior_joff.clear();
@@ -963,6 +966,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         put(nullptr, 4 * (size_t)VIL_SFLAG_MAX, (void**)&P.sflag);      // one flag per sweep workgroup of a one-launch iteration (taken only when there are fewer: below)
         put(nullptr, 64, (void**)&P.abortf);      // (raised by a wait on another workgroup's flag that gives up: vil_math.hpp, spin_until_eq)
         { const size_t Tp = (size_t)(NV + 1 + 15) / 16; put(nullptr, 8 * (size_t)TILE_SZ * (Tp * (Tp + 1) / 2), (void**)&P.chWW); }
+        put(nullptr, 8 * (size_t)VIL_CHC_MAX, (void**)&P.chc);
     }
     if (pre_ok) {
         // the table depends on K, the IMU factor layout and the prior's block structure only: consecutive windows of a tracker share it, so it
@@ -978,7 +982,9 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             if (npc > CHAIN_NPC_MAX) pre_ok = false;       // (cannot happen: the prior's speed-bias blocks are neighbours -- checked for the chain path)
             auto ip = [&](int f, int la, int lb) { return f < 0 ? -1 : f * 931 + la * 30 + lb; };
             auto pr = [&](int r, int col) { if (pn <= 0) return -1; const int pi = pinv[r], pj = pinv[col]; return (pi >= 0 && pj >= 0) ? pi * pn + pj : -1; };
-            auto emit = [&](int dst, int a, int b, int cc) { if (a < 0 && b < 0 && cc == -1) return; tab.push_back(dst); tab.push_back(a); tab.push_back(b); tab.push_back(cc); };
+            // (IMU sources carry two indices: (index into the 931-double records + 1) in the low half, (index into the compact records of a one-launch iteration + 1) in the high half; 0: none)
+            auto both = [&](int a) { if (a < 0) return 0; const int f = a / 931, ce = chain_rec_index(a % 931); return (a + 1) | ((f * VIL_CHAIN_REC + ce + 1) << 16); };
+            auto emit = [&](int dst, int a, int b, int cc) { if (a < 0 && b < 0 && cc == -1) return; tab.push_back(dst); tab.push_back(both(a)); tab.push_back(both(b)); tab.push_back(cc); };
             for (int k = 0; k < K && pre_ok; ++k) {
                 const int fi = as_i[k], fj = as_j[k];
                 for (int i = 0; i < 9; ++i) for (int j = 0; j <= i; ++j) emit(o_dg + 45 * k + i * (i + 1) / 2 + j, ip(fi, 6 + i, 6 + j), ip(fj, 21 + i, 21 + j), pr(NV + 9 * k + i, NV + 9 * k + j));
@@ -998,6 +1004,15 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
                     if (pq[9 * k + cc] >= 0) for (int r = 0; r < NV; ++r) emit(o_pp + pq[9 * k + cc] * NPs + r, -1, -1, pr(r, NV + 9 * k + cc));      // the prior's share: every row
                 }
             }
+            {   // the chain workgroup deals consecutive entries to consecutive threads and every entry has its own target: sorted by source address, a wave's loads of
+                // the IMU records (and of the prior) fall into a few cache lines each instead of one line per lane -- the gather is bound by the lines its loads touch
+                const size_t ne = tab.size() / 4;
+                std::vector<std::array<int, 4>> ent(ne);
+                memcpy(ent.data(), tab.data(), 16 * ne);
+                auto skey = [](const std::array<int, 4>& e) -> long long { return e[1] > 0 ? (e[1] >> 16) : e[2] > 0 ? (e[2] >> 16) : (1LL << 40) + (e[3] >= 0 ? (1LL << 32) + e[3] : -e[3]); };
+                std::stable_sort(ent.begin(), ent.end(), [&](const std::array<int, 4>& x, const std::array<int, 4>& y) { return skey(x) < skey(y); });
+                memcpy(tab.data(), ent.data(), 16 * ne);
+            }
             tab.insert(tab.end(), pq.begin(), pq.end());       // behind the table: the chain column -> prior column map
             while (tab.size() & 3) tab.push_back(0);
             const size_t bytes = 4 * tab.size();
@@ -1016,6 +1031,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             c->chtab_n = ((int)tab.size() - ((9 * K + 3) & ~3)) / 4; c->chtab_key.swap(key);
         }
         P.n_chtab = c->chtab_n;
+        if (c->chtab_n > VIL_CHC_MAX) pre_ok = false;
     }
     if (const char* ev = VIL_TUNE_ENV("VIL_SKIP")) P.skip_mask = atoi(ev);
     // helper workgroups of the step kernel: worth it once every master thread would own more than one landmark
