@@ -125,9 +125,9 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     constexpr int QN = 8;                              // entries per thread and round (K = 10: one round; K = 20, 6840 entries: two)
     int4 q[QN], q2[QN]; double a[QN], b[QN], c[QN];
     // (IMU sources of an entry: index into the 931-double records + 1 in the low half, index into the compact tagged records of a one-launch iteration + 1 in the high half)
-    auto entry = [&](const int e) { int4 v = tab[min(e, n - 1)]; v.y = FUSED ? (v.y >> 16) - 1 : (v.y & 0xffff) - 1; v.z = FUSED ? (v.z >> 16) - 1 : (v.z & 0xffff) - 1; return v; };
+    auto isrc = [&](const int v) { return FUSED ? (v >> 16) - 1 : (v & 0xffff) - 1; };      // (decoded where it is used: the entries stay as loaded -- sixteen int4 per thread)
 #pragma unroll
-    for (int u = 0; u < QN; ++u) { q[u] = entry(t + u * NT); q2[u] = entry(t + (QN + u) * NT); }      // (the second round's entries too: no table round trip behind the flags)
+    for (int u = 0; u < QN; ++u) { q[u] = tab[min(t + u * NT, n - 1)]; q2[u] = tab[min(t + (QN + u) * NT, n - 1)]; }      // (the second round's entries too: no table round trip behind the flags)      // (the second round's entries too: no table round trip behind the flags)
     const double sc_prev = (t < NB && !ctl.first) ? P.Sc[NP + t] : 0.0;
     const int pqv = P.chpq[min(t, NB - 1)];
     const double* const pHs = P.pn > 0 ? P.pH : P.mpart;
@@ -143,8 +143,9 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
 #pragma unroll
             for (int u = 0; u < QN; ++u) {
                 a[u] = 0.0; b[u] = 0.0; c[u] = 0.0;
-                if (q[u].y >= 0) a[u] = ld_ag(P.irec + q[u].y);
-                if (q[u].z >= 0) b[u] = ld_ag(P.irec + q[u].z);
+                const int ya = isrc(q[u].y), za = isrc(q[u].z);
+                if (ya >= 0) a[u] = ld_ag(P.irec + ya);
+                if (za >= 0) b[u] = ld_ag(P.irec + za);
                 const int cw = q[u].w;
                 if (cw < -1) c[u] = ld_ag(P.mpart - cw - 2);
                 else if (cw >= 0) c[u] = ctl.first ? ld_ag(pHs + cw) : P.chc[min(e0 + u * NT, n - 1)];
@@ -156,7 +157,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
         } else {
 #pragma unroll
         for (int u = 0; u < QN; ++u) {
-            a[u] = ld_ag(P.ipart + max(q[u].y, 0)); b[u] = ld_ag(P.ipart + max(q[u].z, 0));
+            a[u] = ld_ag(P.ipart + max(isrc(q[u].y), 0)); b[u] = ld_ag(P.ipart + max(isrc(q[u].z), 0));
             const int cw = q[u].w;
             c[u] = ld_ag(cw >= 0 ? pHs + cw : P.mpart + max(-cw - 2, 0));      // (no prior: cw is never >= 0)
         }
@@ -178,12 +179,12 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     for (int e0 = t; e0 < n; e0 += QN * NT) {
         if (e0 != t) {
 #pragma unroll
-            for (int u = 0; u < QN; ++u) q[u] = e0 == t + QN * NT ? q2[u] : entry(e0 + u * NT);
+            for (int u = 0; u < QN; ++u) q[u] = e0 == t + QN * NT ? q2[u] : tab[min(e0 + u * NT, n - 1)];
             sources(e0);
         }
 #pragma unroll
         for (int u = 0; u < QN; ++u) if (e0 + u * NT < n) {
-            const double v = (q[u].y >= 0 ? a[u] : 0.0) + (q[u].z >= 0 ? b[u] : 0.0) + (q[u].w != -1 ? c[u] : 0.0);
+            const double v = (isrc(q[u].y) >= 0 ? a[u] : 0.0) + (isrc(q[u].z) >= 0 ? b[u] : 0.0) + (q[u].w != -1 ? c[u] : 0.0);
             slab[q[u].x] = v;
         }
     }

@@ -577,6 +577,158 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
     return s.cok != 0;
 }
 
+// ---- The dense factorisation for R = D + 1 <= 68 rows (K <= 10 frames): 16-wide panels factored by ONE wave, a matrix row per lane --------------------------
+// chol_lookahead's block step (four pivots) is a serial sequence on its panel wave -- LDS round trip in, 56 fmas applying the previous panel before the first pivot can
+// start, the four pivots, LDS round trip out, barrier: ~1800 ticks, 17 times at D = 67.  Here a whole tile column (16 pivots) is ONE such sequence:
+//   * lane l of the chain wave owns row 16 Kt + l of tile column Kt (the diagonal tile's rows and everything below, the rhs row included) in 16 registers;
+//   * column by column, right looking: l_ik = t_ik r_k, then t_ic -= l_ik l_ck for the columns c > k of the tile column -- l_ck is row c's entry, another LANE's
+//     register, read with v_readlane (a uniform operand of the fma);
+//   * the pivot chain is short: row k + 1's pivot candidate, without its last term, is broadcast a step early (tp); the last term's factor l_{k+1,k} is the ONE
+//     broadcast on the chain, and every lane forms d = tp - l^2, its reciprocal root and its own l_{i,k+1} from it -- readlane, fma, rsq + Newton, multiply per pivot,
+//     everything else (15 - k broadcasts and fmas per step) fills the latency shadows;
+//   * the panels meet the matrix cores once per tile column: barrier, the tile waves subtract X X^T (four v_mfma_f64_16x16x4 per tile, tiles register-resident as in
+//     chol_lookahead), the tiles of the NEXT tile column go to LDS first, barrier, the chain wave goes on while the tile waves finish the columns right of it.
+//   * R = 68 at K = 10 is four rows more than a wave has lanes: tile column 0 starts like chol_lookahead -- EVERY lane factors the leading 4 x 4 block redundantly
+//     (uniform loads, no broadcast) -- and its lanes own rows 4 .. 67; the broadcasts of columns 4 .. 15 come from lanes 0 .. 11.
+// Same contract as chol_lookahead<SLOTS, false>: rows < D hold L below the diagonal (the diagonal slots and the diagonal tiles' upper triangles hold values nobody
+// reads), row D holds y = L^-1 rhs, s.dinv[j] = 1 / L_jj; false (uniformly) on a pivot that is not positive and finite.  Requires 16 <= D, D + 1 <= 68.
+__device__ __forceinline__ double bcast_lane(const double v, const int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+template <bool FIRST, bool FULL, class PTR>      // FULL: sixteen pivots (every tile column but a short last one): no branch in the panel
+__device__ __forceinline__ bool rowwave_panel(PTR A, const int Kt, const int D, const int R, StepShared& s, const int lane) {
+    constexpr int o = FIRST ? 4 : 0;                 // lane l owns row 16 Kt + o + l; the row of column k lives in lane k - o
+    const int c0 = Kt << 4;
+    const int nt = FULL ? 16 : min(16, D - c0);      // pivots of this tile column
+    const int row = c0 + o + lane, rc = min(row, R - 1);
+    const int base = tl_base(rc >> 4, Kt) + (rc & 15) * TILE_RS;
+    double t[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) t[c] = A[base + c];
+    // FIRST: the leading 4 x 4 block, redundantly in every lane (chol_lookahead's diag_panel arithmetic)
+    double l10 = 0, l20 = 0, l21 = 0, l30 = 0, l31 = 0, l32 = 0, r4_[4] = {0, 0, 0, 0};
+    if constexpr (FIRST) {
+        const double d00 = A[0], d10 = A[TILE_RS], d20 = A[2 * TILE_RS], d21 = A[2 * TILE_RS + 1], d30 = A[3 * TILE_RS], d31 = A[3 * TILE_RS + 1], d32 = A[3 * TILE_RS + 2];
+        double d11 = A[TILE_RS + 1], d22 = A[2 * TILE_RS + 2], d33 = A[3 * TILE_RS + 3];
+        r4_[0] = rsqrt_1(d00);
+        l10 = d10 * r4_[0]; l20 = d20 * r4_[0]; l30 = d30 * r4_[0];
+        d11 = fma(-l10, l10, d11);
+        const double t21 = fma(-l20, l10, d21), t31 = fma(-l30, l10, d31), u22 = fma(-l20, l20, d22), u33a = fma(-l30, l30, d33), v32 = fma(-l30, l20, d32);
+        r4_[1] = rsqrt_1(d11);
+        l21 = t21 * r4_[1]; l31 = t31 * r4_[1];
+        d22 = fma(-l21, l21, u22);
+        const double t32 = fma(-l31, l21, v32), u33 = fma(-l31, l31, u33a);
+        r4_[2] = rsqrt_1(d22);
+        l32 = t32 * r4_[2];
+        d33 = fma(-l32, l32, u33);
+        r4_[3] = rsqrt_1(d33);
+        if (lane == 0) { A[TILE_RS] = l10; A[2 * TILE_RS] = l20; A[2 * TILE_RS + 1] = l21; A[3 * TILE_RS] = l30; A[3 * TILE_RS + 1] = l31; A[3 * TILE_RS + 2] = l32; }
+    }
+    // row c's entry in column m < c, final: the leading block's rows are in every lane, the others in lane c - o
+    auto B = [&](const int c, const int m) -> double {
+        if constexpr (FIRST) { if (c < 4) return c == 1 ? l10 : c == 2 ? (m == 0 ? l20 : l21) : (m == 0 ? l30 : m == 1 ? l31 : l32); }
+        return bcast_lane(t[m], c - o);
+    };
+    double rsum = 0.0, rsel = 0.0;
+    double tp = FIRST ? 0.0 : bcast_lane(t[0], 0);       // the next pivot's candidate: row k's diagonal entry with every term but the last
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (FULL || k < nt) {                            // (wave-uniform)
+            double r;
+            if (FIRST && k < 4) {
+                if (k >= 1) t[k] = fma(-t[k - 1], B(k, k - 1), t[k]);
+                r = r4_[k];
+            } else {
+                double d = tp;
+                if (k >= 1) { const double bc = B(k, k - 1); d = fma(-bc, bc, tp); t[k] = fma(-t[k - 1], bc, t[k]); }
+                r = rsqrt_1(d);
+            }
+            if (k + 1 < 16 && (FULL || k + 1 < nt) && !(FIRST && k + 1 < 4)) tp = bcast_lane(t[k + 1], k + 1 - o);      // (t[k + 1] has its terms up to column k - 1)
+            t[k] *= r;
+            rsel = lane == k ? r : rsel; rsum += r;
+#pragma unroll
+            for (int c = k + 2; c < 16; ++c) if (FULL || c < nt) t[c] = fma(-t[k], B(c, k), t[c]);
+        }
+    }
+    if (row < R) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) if (FULL || c < nt) A[base + c] = t[c];
+    }
+    if (lane < nt) s.dinv[c0 + lane] = rsel;
+    return rsum < 1.7976931348623157e308;                // false for NaN and for +inf: a pivot that was not positive and finite reaches every later root
+}
+template <int SLOTS = 3, class PTR, class PRE = NoPre>
+__device__ __forceinline__ bool chol_rowwave(PTR A, int D, StepShared& s, PRE pre = PRE()) {
+    const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
+    const int R = D + 1, T = (R + 15) >> 4, TD = (D + 15) >> 4;
+    const int la = (lane & 15) * TILE_RS + (lane >> 4);     // operand element (row lane&15, k lane>>4) inside a tile
+    const int lc = (lane >> 4) * TILE_RS + (lane & 15);     // accumulator element (row lane>>4 (+4g), col lane&15)
+    const int ntile_all = (T * (T + 1)) >> 1;
+    // the chain wave is the last one; the tiles are dealt to the others exactly as chol_lookahead deals them (`pre` sees the same slots), and the tile wave that
+    // shares a SIMD with the chain wave sits out when the others have slots for every tile
+    const int NWP = NW - 1;
+    const int n_idle = (ntile_all <= (NWP - 1) * SLOTS && NWP >= 4) ? 1 : 0;
+    const int NWT = NWP - n_idle;
+    const bool idle_w = wave < NWP && wave >= NWP - 4 && wave < NWP - 4 + n_idle;
+    const int wr = wave - (wave >= NWP - 4 + n_idle && wave < NWP ? n_idle : 0);
+    d4 Creg[SLOTS]; int tIJ[SLOTS];
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const int g = idle_w ? ntile_all : (wave < NWP ? wr + NWT * u : NWT * SLOTS + (wave - NWP) + u);
+        tIJ[u] = -1;
+        if (g < ntile_all) {
+            const int I = s.tI[g], J = s.tJ[g];
+            tIJ[u] = (I << 8) | J;
+            const int cb = tl_base(I, J) + lc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Creg[u][q] = A[cb + q * (4 * TILE_RS)];
+        }
+    }
+    pre(Creg, tIJ);
+    if (t == 0) s.cok = 1;
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) if (tIJ[u] >= 0 && (tIJ[u] & 255) == 0) {
+        const int cb = tl_base(tIJ[u] >> 8, 0) + lc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) A[cb + q * (4 * TILE_RS)] = Creg[u][q];
+    }
+    lds_barrier();
+    auto update = [&](const int u, const int Kt) {          // tile of slot u -= X_I X_J^T over the 16 columns of tile column Kt
+        const int I = tIJ[u] >> 8, J = tIJ[u] & 255;
+        const int ab = tl_base(I, Kt) + la, bb = tl_base(J, Kt) + la;
+        double a_[4], b_[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a_[q] = A[ab + 4 * q]; b_[q] = A[bb + 4 * q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Creg[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_[q], b_[q], Creg[u], 0, 0, 0);
+    };
+    for (int Kt = 0; Kt < TD; ++Kt) {
+        if (wave == NWP) {
+            const bool ok = Kt == 0 ? rowwave_panel<true, true>(A, 0, D, R, s, lane) : (D - (Kt << 4) >= 16 ? rowwave_panel<false, true>(A, Kt, D, R, s, lane) : rowwave_panel<false, false>(A, Kt, D, R, s, lane));
+            if (!ok && lane == 0) s.cok = 0;
+        }
+        lds_barrier();                                       // tile column Kt is L
+        if (Kt + 1 >= TD) break;
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) if (tIJ[u] >= 0 && (tIJ[u] & 255) == Kt + 1) {       // the next tile column first, and to LDS
+            update(u, Kt);
+            const int cb = tl_base(tIJ[u] >> 8, Kt + 1) + lc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) A[cb + q * (4 * TILE_RS)] = Creg[u][q];
+        }
+        lds_barrier();                                       // the chain wave goes on; the columns right of it are due one barrier later
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) if (tIJ[u] >= 0 && (tIJ[u] & 255) > Kt + 1) update(u, Kt);
+    }
+    return s.cok != 0;
+}
+// K <= 10: the row-per-lane panels; otherwise the look-ahead factorisation
+template <int SLOTS, class PTR, class PRE = NoPre>
+__device__ __forceinline__ bool chol_dense(PTR A, int D, StepShared& s, PRE pre = PRE()) {
+    if (D >= 16 && D + 1 <= 68) return chol_rowwave<SLOTS>(A, D, s, pre);
+    return chol_lookahead<SLOTS, false>(A, D, s, pre);
+}
+
 // back substitution L^T x = y (y = row D of A) with 16 x 16 diagonal blocks.
 //   (I)  one WAVE per diagonal tile (no workgroup barrier inside): W_t = L_tt^-1 by the column recurrence with FOUR lanes per column -- lane (j, p) holds
 //        the entries L[i][4m + p] of its quarter (36 loads, one round trip) and the w_k with k = p mod 4, a row's partial sums meet in two DPP quad
@@ -839,7 +991,7 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
 // ---- chain eliminated ahead by the extra workgroup of k_sweep, W W^T contracted by k_reduce (vil_prechain.hpp): pack the pose tiles as
 //      M_pp = Sc (S'_pp - W W^T) Sc + mu d^2 (the row scaling the chain workgroup deferred is applied here), dense part, chain back
 //      substitution.  Same contract as solve_chain.
-template <class PUB, class SIDE>
+template <bool RW /* the row-per-lane factorisation (chol_rowwave) where it applies: the one-launch iteration */, class PUB, class SIDE>
 __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart, const int epoch /* of this launch's flags */, PUB pub, SIDE side) {
     const int t = threadIdx.x;
     SSTAMP(0);
@@ -916,7 +1068,7 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
 #pragma unroll
         for (int q = 0; q < 24; ++q) wv[q] = ld_ag(Wt + (size_t)jc * RS + min(part + q * G, NP - 1));
         wrhs = ld_ag(Wt + (size_t)jc * RS + NP);
-        if (!chol_lookahead<3, false>(Tl, NP, s)) return false;
+        if (!(RW ? chol_dense<3>(Tl, NP, s) : chol_lookahead<3, false>(Tl, NP, s))) return false;
     } else if (!chol_lookahead<CH_SLOTS, false>(Tl, NP, s)) return false;
     SSTAMP(4);
     if (t == 0) prof_stamp(P, epoch - 1, 10);
@@ -1398,7 +1550,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
             __syncthreads();
             auto pub = [&]() { publish_xp(1); };
             auto side = [&]() {};          // (the helpers' sums are collected after the step vectors below: their round trip outlasts the chain walks)
-            if constexpr (CHAIN == 3) ok = solve_prechain(P, sb, s, Alds, mu, cam, q, epoch, pub, side);
+            if constexpr (CHAIN == 3) ok = solve_prechain<FUSED>(P, sb, s, Alds, mu, cam, q, epoch, pub, side);
             else ok = solve_chain<CHAIN == 1>(P, sb, s, Alds, mu, cam, q, pub, side);      // packing, chain, Schur update, dense part, back substitution
         } else {
         // tiled storage: element e of the tile array -> (i, j); S entries were prefetched into registers at kernel start
