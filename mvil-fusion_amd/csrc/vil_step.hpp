@@ -629,8 +629,7 @@ __device__ __forceinline__ bool rowwave_panel(PTR A, const int Kt, const int D, 
         if constexpr (FIRST) { if (c < 4) return c == 1 ? l10 : c == 2 ? (m == 0 ? l20 : l21) : (m == 0 ? l30 : m == 1 ? l31 : l32); }
         return bcast_lane(t[m], c - o);
     };
-    double rsum = 0.0, rsel = 0.0;
-    double tp = FIRST ? 0.0 : bcast_lane(t[0], 0);       // the next pivot's candidate: row k's diagonal entry with every term but the last
+    double rlast = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         if (FULL || k < nt) {                            // (wave-uniform)
@@ -639,13 +638,12 @@ __device__ __forceinline__ bool rowwave_panel(PTR A, const int Kt, const int D, 
                 if (k >= 1) t[k] = fma(-t[k - 1], B(k, k - 1), t[k]);
                 r = r4_[k];
             } else {
-                double d = tp;
-                if (k >= 1) { const double bc = B(k, k - 1); d = fma(-bc, bc, tp); t[k] = fma(-t[k - 1], bc, t[k]); }
-                r = rsqrt_1(d);
+                if (k >= 1) t[k] = fma(-t[k - 1], B(k, k - 1), t[k]);
+                r = rsqrt_1(bcast_lane(t[k], k - o));
             }
-            if (k + 1 < 16 && (FULL || k + 1 < nt) && !(FIRST && k + 1 < 4)) tp = bcast_lane(t[k + 1], k + 1 - o);      // (t[k + 1] has its terms up to column k - 1)
             t[k] *= r;
-            rsel = lane == k ? r : rsel; rsum += r;
+            s.dinv[c0 + k] = r;                          // (every lane, the same value to the same address: one instruction, no select)
+            rlast = r;
 #pragma unroll
             for (int c = k + 2; c < 16; ++c) if (FULL || c < nt) t[c] = fma(-t[k], B(c, k), t[c]);
         }
@@ -654,8 +652,75 @@ __device__ __forceinline__ bool rowwave_panel(PTR A, const int Kt, const int D, 
 #pragma unroll
         for (int c = 0; c < 16; ++c) if (FULL || c < nt) A[base + c] = t[c];
     }
-    if (lane < nt) s.dinv[c0 + lane] = rsel;
-    return rsum < 1.7976931348623157e308;                // false for NaN and for +inf: a pivot that was not positive and finite reaches every later root
+    return rlast < 1.7976931348623157e308;               // false for NaN and for +inf: a pivot that was not positive and finite reaches every later root (through l and d), the panel's last one included
+}
+// The full panel (sixteen pivots) with most broadcasts through LDS.  A term l_im l_cm costs a v_readlane pair, the wait states behind it and the fma; the panel is bound
+// by its instruction count, and 120 of those per lane is most of it.  Here every lane stores l_im into its tile row as soon as it exists (the panel's result, stored
+// column by column instead of at the end), and the terms that are not urgent read l_cm from the diagonal tile with plain LDS loads of a uniform address, one step late:
+//   term m of column c:  m = c - 1   readlane, at step c (the pivot waits for it)
+//                        m = c - 2   readlane, at step c - 1
+//                        m <= c - 3  LDS: loaded during step m + 1, applied at step m + 2
+// Per column the terms are applied in the order of m, as the readlane-only panel applies them: the same bits.
+// (Lanes past the last row own a copy of row R - 1: the same values to the same addresses, no masks.)
+template <bool FIRST, class PTR>
+__device__ __forceinline__ bool rowwave_panel_full(PTR A, const int Kt, const int R, StepShared& s, const int lane) {
+    constexpr int o = FIRST ? 4 : 0;
+    const int c0 = Kt << 4;
+    const int rc = min(c0 + o + lane, R - 1);
+    const int base = tl_base(rc >> 4, Kt) + (rc & 15) * TILE_RS;
+    const int db = tl_base(Kt, Kt);                  // the diagonal tile: row c of the panel at db + c * TILE_RS
+    double t[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) t[c] = A[base + c];
+    double l10 = 0, l20 = 0, l21 = 0, l30 = 0, l31 = 0, l32 = 0, r4_[4] = {0, 0, 0, 0};
+    if constexpr (FIRST) {
+        const double d00 = A[0], d10 = A[TILE_RS], d20 = A[2 * TILE_RS], d21 = A[2 * TILE_RS + 1], d30 = A[3 * TILE_RS], d31 = A[3 * TILE_RS + 1], d32 = A[3 * TILE_RS + 2];
+        double d11 = A[TILE_RS + 1], d22 = A[2 * TILE_RS + 2], d33 = A[3 * TILE_RS + 3];
+        r4_[0] = rsqrt_1(d00);
+        l10 = d10 * r4_[0]; l20 = d20 * r4_[0]; l30 = d30 * r4_[0];
+        d11 = fma(-l10, l10, d11);
+        const double t21 = fma(-l20, l10, d21), t31 = fma(-l30, l10, d31), u22 = fma(-l20, l20, d22), u33a = fma(-l30, l30, d33), v32 = fma(-l30, l20, d32);
+        r4_[1] = rsqrt_1(d11);
+        l21 = t21 * r4_[1]; l31 = t31 * r4_[1];
+        d22 = fma(-l21, l21, u22);
+        const double t32 = fma(-l31, l21, v32), u33 = fma(-l31, l31, u33a);
+        r4_[2] = rsqrt_1(d22);
+        l32 = t32 * r4_[2];
+        d33 = fma(-l32, l32, u33);
+        r4_[3] = rsqrt_1(d33);
+        if (lane == 0) { A[TILE_RS] = l10; A[2 * TILE_RS] = l20; A[2 * TILE_RS + 1] = l21; A[3 * TILE_RS] = l30; A[3 * TILE_RS + 1] = l31; A[3 * TILE_RS + 2] = l32; }
+    }
+    auto L4 = [&](const int c, const int m) -> double { return c == 1 ? l10 : c == 2 ? (m == 0 ? l20 : l21) : (m == 0 ? l30 : m == 1 ? l31 : l32); };
+    auto Bfast = [&](const int c, const int m) -> double {       // row c's entry in column m, out of the owner's register
+        if constexpr (FIRST) { if (c < 4) return L4(c, m); }
+        return bcast_lane(t[m], c - o);
+    };
+    double bv[16], bn[16];                           // column m = k - 2 of the diagonal tile (rows k + 1 ..), and the next step's
+    double r = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        // (the loads for the NEXT step's terms are issued first and pinned there: left to itself the scheduler sinks them to their uses, and every step then waits
+        //  out an LDS round trip)
+        if (k >= 1 && k + 2 < 16) {                  // column k - 1, rows k + 2 ..: stored at the end of the last step
+#pragma unroll
+            for (int c = k + 2; c < 16; ++c) { if (FIRST && c < 4) bn[c] = L4(c, k - 1); else bn[c] = A[db + c * TILE_RS + (k - 1)]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (k >= 2) {
+#pragma unroll
+            for (int c = k + 1; c < 16; ++c) t[c] = fma(-t[k - 2], bv[c], t[c]);
+        }
+        if (k >= 1 && k + 1 < 16) t[k + 1] = fma(-t[k - 1], Bfast(k + 1, k - 1), t[k + 1]);
+        if (k >= 1) t[k] = fma(-t[k - 1], Bfast(k, k - 1), t[k]);
+        r = (FIRST && k < 4) ? r4_[k] : rsqrt_1(bcast_lane(t[k], k - o));
+        t[k] *= r;
+        s.dinv[c0 + k] = r;                          // (every lane, the same value to the same address: one instruction, no select)
+        A[base + k] = t[k];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) bv[c] = bn[c];
+    }
+    return r < 1.7976931348623157e308;               // false for NaN and for +inf: a pivot that was not positive and finite reaches every later root (through l and d), the panel's last one included
 }
 template <int SLOTS = 3, class PTR, class PRE = NoPre>
 __device__ __forceinline__ bool chol_rowwave(PTR A, int D, StepShared& s, PRE pre = PRE()) {
@@ -699,12 +764,15 @@ __device__ __forceinline__ bool chol_rowwave(PTR A, int D, StepShared& s, PRE pr
         double a_[4], b_[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { a_[q] = A[ab + 4 * q]; b_[q] = A[bb + 4 * q]; }
+        // (two accumulators: the four matrix instructions of a tile are two dependent pairs instead of a chain of four)
+        d4 c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_[0], b_[0], Creg[u], 0, 0, 0), c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_[1], b_[1], d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_[2], b_[2], c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_[3], b_[3], c1, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Creg[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_[q], b_[q], Creg[u], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) Creg[u][q] = c0[q] + c1[q];
     };
     for (int Kt = 0; Kt < TD; ++Kt) {
         if (wave == NWP) {
-            const bool ok = Kt == 0 ? rowwave_panel<true, true>(A, 0, D, R, s, lane) : (D - (Kt << 4) >= 16 ? rowwave_panel<false, true>(A, Kt, D, R, s, lane) : rowwave_panel<false, false>(A, Kt, D, R, s, lane));
+            const bool ok = Kt == 0 ? rowwave_panel_full<true>(A, 0, R, s, lane) : (D - (Kt << 4) >= 16 ? rowwave_panel_full<false>(A, Kt, R, s, lane) : rowwave_panel<false, false>(A, Kt, D, R, s, lane));
             if (!ok && lane == 0) s.cok = 0;
         }
         lds_barrier();                                       // tile column Kt is L
