@@ -797,6 +797,65 @@ __device__ __forceinline__ bool chol_dense(PTR A, int D, StepShared& s, PRE pre 
     return chol_lookahead<SLOTS, false>(A, D, s, pre);
 }
 
+// back substitution L^T x = y, a COLUMN per lane: the counterpart of chol_rowwave's panels.  From the last diagonal tile up, one wave: lane (g, j) owns column j of
+// tile column blk - g -- the diagonal tile's column (g = 0) and the same sixteen rows of the three tiles left of it -- as sixteen registers.  Row by row from the
+// bottom, x_i = y_i / L_ii is lane i's; one v_readlane pair makes it a uniform operand, and ONE fma per lane takes l_ij x_i off the y of all 64 columns: the
+// diagonal block's recurrence and the fold into the three blocks left of it are the same instruction.  No inverse of the diagonal tiles (back_subst spends
+// ~5000 ticks on forming them before its first x), four instructions per row on the chain.  Tiles further left than three (one tile at K = 10) are folded by
+// the other waves behind the block's barrier into a separate accumulator that a column picks up when its own block's turn comes -- never on the chain.
+// A is not modified.  Result in s.y[0 .. D); s.xs is scratch.
+template <class PTR>
+__device__ __forceinline__ void back_subst_cols(PTR A, int D, StepShared& s) {
+    const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63;
+    const int TD = (D + 15) >> 4;
+    for (int i = t; i < (TD << 4); i += NT) { s.y[i] = i < D ? A[tl_idx(D, i)] : 0.0; s.xs[i] = 0.0; }
+    const int g = lane >> 4, j = lane & 15;
+    // a block's columns: loaded, masked (the diagonal tile at or above its diagonal, rows past the matrix: not L) and -- the diagonal block's -- scaled by 1 / L_jj
+    // (entries and y alike: x_i is then lane i's value as it stands, a row of the recurrence is readlane + fma).
+    // (measured and not kept: two rows per broadcast round with the sub-diagonal entry as a uniform operand, 7.6 -> 7.9 k ticks at D = 67; block blk - 1 prepared
+    //  in front of block blk's recurrence, 7.6 -> 8.3 k)
+    auto prepare = [&](const int blk, double* l, double& sc) {
+        const int nb = min(16, D - (blk << 4)), cb = blk - g, ccb = max(cb, 0), col = (ccb << 4) + j;
+        const bool valid = cb >= 0;
+        const int tb = tl_base(blk, ccb) + j;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) l[i] = A[tb + i * TILE_RS];
+        sc = g == 0 ? s.dinv[min(col, D - 1)] : 1.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { double v = l[i]; asm volatile("" : "+v"(v)); l[i] = (valid && i < nb && (g > 0 || i > j)) ? v * sc : 0.0; }
+    };
+    __syncthreads();
+    for (int blk = TD - 1; blk >= 0; --blk) {
+        const int nb = min(16, D - (blk << 4));
+        if (wave == 0) {
+            const int cb = blk - g, col = (max(cb, 0) << 4) + j;
+            double l[16], sc;
+            prepare(blk, l, sc);
+            double yv = s.y[col];
+            if (g == 0) yv = (yv - s.xs[col]) * sc;
+            // (x_j is lane j's own value once the rows below j have been taken off: nothing is stored inside the recurrence -- a store per row would put an
+            //  LDS wait into every step)
+            if (nb == 16) {
+#pragma unroll
+                for (int i = 15; i >= 0; --i) yv = fma(-l[i], bcast_lane(yv, i), yv);
+            } else {
+#pragma unroll
+                for (int i = 15; i >= 0; --i) if (i < nb) yv = fma(-l[i], bcast_lane(yv, i), yv);      // (wave-uniform)
+            }
+            if (cb >= 0) s.y[col] = yv;
+        }
+        __syncthreads();
+        if (wave > 0 && blk >= 4) {                           // tile columns 0 .. blk - 4: a column per thread
+            for (int c = t - 64; c < ((blk - 3) << 4); c += NT - 64) {
+                const int cb = tl_base(blk, c >> 4) + (c & 15);
+                double acc = 0.0;
+                for (int i = 0; i < nb; ++i) acc = fma(A[cb + i * TILE_RS], s.y[(blk << 4) + i], acc);
+                s.xs[c] += acc;
+            }
+        }
+    }
+}
+
 // back substitution L^T x = y (y = row D of A) with 16 x 16 diagonal blocks.
 //   (I)  one WAVE per diagonal tile (no workgroup barrier inside): W_t = L_tt^-1 by the column recurrence with FOUR lanes per column -- lane (j, p) holds
 //        the entries L[i][4m + p] of its quarter (36 loads, one round trip) and the w_k with k = p mod 4, a row's partial sums meet in two DPP quad
@@ -1140,7 +1199,7 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
     } else if (!chol_lookahead<CH_SLOTS, false>(Tl, NP, s)) return false;
     SSTAMP(4);
     if (t == 0) prof_stamp(P, epoch - 1, 10);
-    back_subst(Tl, NP, s);
+    if (RW) back_subst_cols(Tl, NP, s); else back_subst(Tl, NP, s);
     pub();
     if (t == 0) prof_stamp(P, epoch - 1, 11);
     SSTAMP(5);
