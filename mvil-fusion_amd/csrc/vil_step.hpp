@@ -591,7 +591,7 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
 //   * R = 68 at K = 10 is four rows more than a wave has lanes: tile column 0 starts like chol_lookahead -- EVERY lane factors the leading 4 x 4 block redundantly
 //     (uniform loads, no broadcast) -- and its lanes own rows 4 .. 67; the broadcasts of columns 4 .. 15 come from lanes 0 .. 11.
 // Same contract as chol_lookahead<SLOTS, false>: rows < D hold L below the diagonal (the diagonal slots and the diagonal tiles' upper triangles hold values nobody
-// reads), row D holds y = L^-1 rhs, s.dinv[j] = 1 / L_jj; false (uniformly) on a pivot that is not positive and finite.  Requires 16 <= D, D + 1 <= 68.
+// reads), row D holds y = L^-1 rhs, s.dinv[j] = 1 / L_jj; false (uniformly) on a pivot that is not positive and finite.  Requires 16 <= D, D + 1 <= 132 (past 68 rows a second wave takes the rows the chain wave has no lanes for: rowwave_panel_second), eight waves.
 __device__ __forceinline__ double bcast_lane(const double v, const int src) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
@@ -662,7 +662,7 @@ __device__ __forceinline__ bool rowwave_panel(PTR A, const int Kt, const int D, 
 //                        m <= c - 3  LDS: loaded during step m + 1, applied at step m + 2
 // Per column the terms are applied in the order of m, as the readlane-only panel applies them: the same bits.
 // (Lanes past the last row own a copy of row R - 1: the same values to the same addresses, no masks.)
-template <bool FIRST, class PTR>
+template <bool FIRST, bool PROG /* a second panel wave follows: the step count is posted behind every step's stores */, class PTR>
 __device__ __forceinline__ bool rowwave_panel_full(PTR A, const int Kt, const int R, StepShared& s, const int lane) {
     constexpr int o = FIRST ? 4 : 0;
     const int c0 = Kt << 4;
@@ -716,11 +716,48 @@ __device__ __forceinline__ bool rowwave_panel_full(PTR A, const int Kt, const in
         t[k] *= r;
         s.dinv[c0 + k] = r;                          // (every lane, the same value to the same address: one instruction, no select)
         A[base + k] = t[k];
+        if constexpr (PROG) { asm volatile("" ::: "memory"); __hip_atomic_store(&s.pad0_, (Kt << 5) + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }      // (a wave's LDS operations execute in order: whoever reads this count finds the step's stores)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 16; ++c) bv[c] = bn[c];
     }
     return r < 1.7976931348623157e308;               // false for NaN and for +inf: a pivot that was not positive and finite reaches every later root (through l and d), the panel's last one included
+}
+// The rows of a full panel past the chain wave's 64 (K > 10: up to 128 rows): a second wave, a row per lane, LEFT looking and one step behind.  It needs nothing
+// from the chain wave's registers: row k of the diagonal tile and the reciprocal pivot are in LDS once the chain wave has posted step k.  The count is read FIRST
+// and the operands behind it in the same round trip (LDS executes a wave's operations in order; the chain wave's stores of a step precede its count): a count
+// that is too small repeats the round.  Per column k terms, contiguous operands -- about half the chain wave's instructions per step, so it keeps up.
+template <class PTR>
+__device__ __forceinline__ void rowwave_panel_second(PTR A, const int Kt, const int o, const int R, StepShared& s, const int lane) {
+    const int c0 = Kt << 4;
+    const int rc = min(c0 + o + 64 + lane, R - 1);
+    const int base = tl_base(rc >> 4, Kt) + (rc & 15) * TILE_RS;
+    const int db = tl_base(Kt, Kt);
+    double t[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) t[c] = A[base + c];
+    // (one step ahead: the operands of step k + 1 are requested before step k's arithmetic -- behind the chain wave they are there already, and the round trip
+    //  disappears from the step; a count that turns out too small repeats the request where it is needed)
+    // (measured and not kept: the operands of step k + 1 requested a step ahead, with and without partial sums -- 56.3 -> 58.3 / 59.5 k ticks at D = 127: this
+    //  wave is then ahead of the chain wave more often, and every round it repeats is LDS traffic in the chain wave's way)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        double b[16], r;
+        for (;;) {
+            const int pv = __hip_atomic_load(&s.pad0_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (a ds_read: in order with the loads behind it)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int m = 0; m < k; ++m) b[m] = A[db + k * TILE_RS + m];
+            r = s.dinv[c0 + k];
+            asm volatile("" ::: "memory");
+            if (__builtin_amdgcn_readfirstlane(pv) >= (Kt << 5) + k + 1) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int m = 0; m < k; ++m) t[k] = fma(-t[m], b[m], t[k]);
+        t[k] *= r;
+        A[base + k] = t[k];
+    }
 }
 template <int SLOTS = 3, class PTR, class PRE = NoPre>
 __device__ __forceinline__ bool chol_rowwave(PTR A, int D, StepShared& s, PRE pre = PRE()) {
@@ -729,17 +766,18 @@ __device__ __forceinline__ bool chol_rowwave(PTR A, int D, StepShared& s, PRE pr
     const int la = (lane & 15) * TILE_RS + (lane >> 4);     // operand element (row lane&15, k lane>>4) inside a tile
     const int lc = (lane >> 4) * TILE_RS + (lane & 15);     // accumulator element (row lane>>4 (+4g), col lane&15)
     const int ntile_all = (T * (T + 1)) >> 1;
-    // the chain wave is the last one; the tiles are dealt to the others exactly as chol_lookahead deals them (`pre` sees the same slots), and the tile wave that
-    // shares a SIMD with the chain wave sits out when the others have slots for every tile
-    const int NWP = NW - 1;
-    const int n_idle = (ntile_all <= (NWP - 1) * SLOTS && NWP >= 4) ? 1 : 0;
+    // the panel waves are the last ones (one; two when the first panel has more than 64 rows -- K > 10); the tiles are dealt to the others exactly as chol_lookahead
+    // deals them (`pre` sees the same slots), and the tile wave(s) that share a SIMD with the panel wave(s) sit out when the others have slots for every tile
+    const int npw = R - 4 > 64 ? 2 : 1;
+    const int NWP = NW - npw;                              // the chain wave; NWP + 1: the second panel wave
+    const int n_idle = (ntile_all <= (NWP - npw) * SLOTS && NWP >= 4) ? npw : 0;
     const int NWT = NWP - n_idle;
     const bool idle_w = wave < NWP && wave >= NWP - 4 && wave < NWP - 4 + n_idle;
     const int wr = wave - (wave >= NWP - 4 + n_idle && wave < NWP ? n_idle : 0);
     d4 Creg[SLOTS]; int tIJ[SLOTS];
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
-        const int g = idle_w ? ntile_all : (wave < NWP ? wr + NWT * u : NWT * SLOTS + (wave - NWP) + u);
+        const int g = idle_w ? ntile_all : (wave < NWP ? wr + NWT * u : NWT * SLOTS + (wave - NWP) + npw * u);
         tIJ[u] = -1;
         if (g < ntile_all) {
             const int I = s.tI[g], J = s.tJ[g];
@@ -750,7 +788,7 @@ __device__ __forceinline__ bool chol_rowwave(PTR A, int D, StepShared& s, PRE pr
         }
     }
     pre(Creg, tIJ);
-    if (t == 0) s.cok = 1;
+    if (t == 0) { s.cok = 1; s.pad0_ = 0; }
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) if (tIJ[u] >= 0 && (tIJ[u] & 255) == 0) {
         const int cb = tl_base(tIJ[u] >> 8, 0) + lc;
@@ -771,10 +809,14 @@ __device__ __forceinline__ bool chol_rowwave(PTR A, int D, StepShared& s, PRE pr
         for (int q = 0; q < 4; ++q) Creg[u][q] = c0[q] + c1[q];
     };
     for (int Kt = 0; Kt < TD; ++Kt) {
+        const int o = Kt == 0 ? 4 : 0;
+        const bool two = R - (Kt << 4) - o > 64;             // (more rows than the chain wave has lanes: only in full panels)
         if (wave == NWP) {
-            const bool ok = Kt == 0 ? rowwave_panel_full<true>(A, 0, R, s, lane) : (D - (Kt << 4) >= 16 ? rowwave_panel_full<false>(A, Kt, R, s, lane) : rowwave_panel<false, false>(A, Kt, D, R, s, lane));
+            bool ok;
+            if (two) ok = Kt == 0 ? rowwave_panel_full<true, true>(A, 0, R, s, lane) : rowwave_panel_full<false, true>(A, Kt, R, s, lane);
+            else ok = Kt == 0 ? rowwave_panel_full<true, false>(A, 0, R, s, lane) : (D - (Kt << 4) >= 16 ? rowwave_panel_full<false, false>(A, Kt, R, s, lane) : rowwave_panel<false, false>(A, Kt, D, R, s, lane));
             if (!ok && lane == 0) s.cok = 0;
-        }
+        } else if (two && wave == NWP + 1) rowwave_panel_second(A, Kt, o, R, s, lane);
         lds_barrier();                                       // tile column Kt is L
         if (Kt + 1 >= TD) break;
 #pragma unroll
@@ -790,10 +832,10 @@ __device__ __forceinline__ bool chol_rowwave(PTR A, int D, StepShared& s, PRE pr
     }
     return s.cok != 0;
 }
-// K <= 10: the row-per-lane panels; otherwise the look-ahead factorisation
+// K <= 20: the row-per-lane panels; otherwise the look-ahead factorisation
 template <int SLOTS, class PTR, class PRE = NoPre>
 __device__ __forceinline__ bool chol_dense(PTR A, int D, StepShared& s, PRE pre = PRE()) {
-    if (D >= 16 && D + 1 <= 68) return chol_rowwave<SLOTS>(A, D, s, pre);
+    if (D >= 16 && D + 1 <= 132 && (blockDim.x >> 6) >= 8) return chol_rowwave<SLOTS>(A, D, s, pre);
     return chol_lookahead<SLOTS, false>(A, D, s, pre);
 }
 
@@ -1196,7 +1238,7 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
         for (int q = 0; q < 24; ++q) wv[q] = ld_ag(Wt + (size_t)jc * RS + min(part + q * G, NP - 1));
         wrhs = ld_ag(Wt + (size_t)jc * RS + NP);
         if (!(RW ? chol_dense<3>(Tl, NP, s) : chol_lookahead<3, false>(Tl, NP, s))) return false;
-    } else if (!chol_lookahead<CH_SLOTS, false>(Tl, NP, s)) return false;
+    } else if (!(RW ? chol_dense<CH_SLOTS>(Tl, NP, s) : chol_lookahead<CH_SLOTS, false>(Tl, NP, s))) return false;
     SSTAMP(4);
     if (t == 0) prof_stamp(P, epoch - 1, 10);
     if (RW) back_subst_cols(Tl, NP, s); else back_subst(Tl, NP, s);

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_chol(const double* Ain, do
     for (int e = t; e < D; e += blockDim.x) xout[e] = s.y[e];
 }
 int main(int argc, char** argv) {
-    const int Ds[] = {67, 67, 127, 127, 79, 79, 40, 40, 64, 64, 19, 31, 48, 55};
+    const int Ds[] = {67, 67, 127, 127, 79, 79, 40, 40, 64, 64, 19, 31, 48, 55, 97, 97, 131, 131, 68, 68};
     int prevD = -1;
     for (int D : Ds) {
         const bool rw = D == prevD || D == 19 || D == 31 || D == 48 || D == 55; prevD = D;      // a size listed twice: the second run takes chol_dense (row-per-lane panels for D <= 67)
