@@ -293,6 +293,11 @@ int vil_debug_set_split(vil_ctx* ctx, int32_t on);
  * eliminated by a workgroup of the SWEEP launch; 2: no chain workgroup at all (the step kernel eliminates the chain itself, the round-2 structure).
  * Same results to rounding in every mode.  Invalidates the resident window. */
 int vil_debug_set_launch_mode(vil_ctx* ctx, int32_t mode);
+/* test hook: the step's dense solve on a matrix of the caller's -- A is (D + 1) x (D + 1) row major, its lower triangle the SPD matrix, its last row the right-hand
+ * side (D <= 159).  L receives the Cholesky factor (lower, row major, last row = L^-1 rhs), x the solution, *ok 0 when a pivot was not positive.  variant 1: what the
+ * one-launch iteration runs (16-wide panels factored a matrix row per lane, back substitution a column per lane: vil_step.hpp chol_rowwave / back_subst_cols);
+ * variant 0: the look-ahead factorisation (4-wide panels) and the back substitution through inverted diagonal tiles that the other launch structures run. */
+int vil_debug_dense_solve(vil_ctx* ctx, int32_t D, const double* A, double* L, double* x, int32_t* ok, int32_t variant);
 /* what the uploaded window's solves launch per trust-region iteration: 1 (the one-launch iteration), 2 (sweep + gather / step) or 3 (sweep, gather, step) */
 int vil_debug_get_launch_structure(vil_ctx* ctx, int32_t* launches_per_iteration, int32_t* one_launch);
 

@@ -381,6 +381,28 @@ static void quat_to_R_host(const double* q, double* R) {
     R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
 }
 
+// test hook (vil_debug_dense_solve): the step's dense factorisation + back substitution on a matrix of the caller's -- one workgroup, the tiled LDS layout of vil_step.hpp.
+// RW: what the one-launch iteration runs (chol_dense / back_subst_cols); otherwise the look-ahead factorisation and the back substitution with inverted diagonal tiles.
+template <int SLOTS, bool RW>
+__global__ __launch_bounds__(VIL_STEP_THREADS) void k_debug_dense(const double* Ain /* (D+1) x (D+1) row major: lower triangle, last row = right-hand side */, double* Lout, double* xout, int* okout, int D) {
+    extern __shared__ double dbgA[];
+    __shared__ vd::StepShared s;
+    const int t = threadIdx.x, R = D + 1, T = (R + 15) >> 4, NTL = ((T * (T + 1)) >> 1) * TILE_SZ;
+    if (t == 0) { int g = 0; for (int I = 0; I < T; ++I) for (int J = 0; J <= I; ++J) { s.tI[g] = (unsigned char)I; s.tJ[g] = (unsigned char)J; ++g; } }
+    for (int e = t; e < NTL; e += blockDim.x) dbgA[e] = 0.0;
+    __syncthreads();
+    for (int e = t; e < R * R; e += blockDim.x) { const int i = e / R, j = e - i * R; if (j <= i && j < D) dbgA[vd::tl_idx(i, j)] = Ain[e]; }
+    __syncthreads();
+    bool ok;
+    if constexpr (RW) ok = vd::chol_dense<SLOTS>(dbgA, D, s); else ok = vd::chol_lookahead<SLOTS, false>(dbgA, D, s);
+    __syncthreads();
+    for (int e = t; e < R * R; e += blockDim.x) { const int i = e / R, j = e - i * R; Lout[e] = (j < i && j < D) ? dbgA[vd::tl_idx(i, j)] : ((j == i && i < D) ? 1.0 / s.dinv[i] : 0.0); }
+    __syncthreads();
+    if (ok) { if constexpr (RW) vd::back_subst_cols(dbgA, D, s); else vd::back_subst(dbgA, D, s); }
+    __syncthreads();
+    for (int e = t; e < D; e += blockDim.x) xout[e] = ok ? s.y[e] : 0.0;
+    if (t == 0) okout[0] = ok ? 1 : 0;
+}
 __global__ void k_aos2soa(const double* aos, int n, int ncomp, double* dst, size_t stride) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f < n) for (int q = 0; q < ncomp; ++q) dst[(size_t)q * stride + f] = aos[(size_t)f * ncomp + q];
@@ -2124,6 +2146,26 @@ int vil_comm_info(vil_ctx* c, int32_t* rank, int32_t* world, int32_t* transport)
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
     if (transport) *transport = c->comm ? 1 : (c->lcomm ? 2 : (c->ipc ? (c->ipc->ready ? 3 : -3) : 0));
+    return VIL_OK;
+}
+int vil_debug_dense_solve(vil_ctx* c, int32_t D, const double* A, double* L, double* x, int32_t* ok, int32_t variant) {
+    if (!c || !A || !L || !x || !ok || D < 1 || D > 159 || variant < 0 || variant > 1) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    const int R = D + 1, T = (R + 15) / 16, nt = T * (T + 1) / 2;
+    const size_t lds = 8 * (size_t)TILE_SZ * nt, nb = 8 * (size_t)R * R;
+    double *dA = nullptr, *dL = nullptr, *dx = nullptr; int* dok = nullptr;
+    HIPCHK(hipMalloc((void**)&dA, nb)); HIPCHK(hipMalloc((void**)&dL, nb)); HIPCHK(hipMalloc((void**)&dx, 8 * (size_t)R)); HIPCHK(hipMalloc((void**)&dok, 64));
+    HIPCHK(hipMemcpy(dA, A, nb, hipMemcpyHostToDevice));
+    const bool small = nt <= 18;                         // (three register tiles per tile wave are enough -- what the step takes at K <= 10)
+    const void* fn = variant ? (small ? (const void*)k_debug_dense<3, true> : (const void*)k_debug_dense<CH_SLOTS, true>) : (small ? (const void*)k_debug_dense<3, false> : (const void*)k_debug_dense<CH_SLOTS, false>);
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* args[] = {(void*)&dA, (void*)&dL, (void*)&dx, (void*)&dok, (void*)&D};
+    HIPCHK(hipLaunchKernel(fn, dim3(1), dim3(VIL_STEP_THREADS), args, lds, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int hok = 0;
+    HIPCHK(hipMemcpy(L, dL, nb, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(x, dx, 8 * (size_t)D, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hok, dok, 4, hipMemcpyDeviceToHost));
+    *ok = hok;
+    hipFree(dA); hipFree(dL); hipFree(dx); hipFree(dok);
     return VIL_OK;
 }
 int vil_debug_set_slim_emul(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->slim_emul = on != 0; return VIL_OK; }
