@@ -170,7 +170,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     if (wait_records) {
         const int ep = FUSED ? epoch : (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u);       // (sweep_signal, vil_sweep.hpp)
         const int* const fl = FUSED ? P.sflag : P.swflag;
-        if (t <= P.n_imu && (t < P.n_imu || P.pn > 0)) spin_until_eq(fl + t, ep, P.abortf);
+        if (t <= P.n_imu && (t < P.n_imu || P.pn > 0)) spin_until_eq((FUSED && t < P.n_imu) ? P.cflag + t : fl + t, ep, P.abortf);      // (one-launch iteration: the IMU roles' compact records have their own, earlier flag)
     }
     __syncthreads();
     PSTAMP(31);

@@ -595,11 +595,11 @@ __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE 
 __device__ __forceinline__ double bcast_lane(const double v, const int src) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
-template <bool FIRST, bool FULL, class PTR>      // FULL: sixteen pivots (every tile column but a short last one): no branch in the panel
+template <bool FIRST, bool FULL, int NTC = 0, class PTR>      // FULL: sixteen pivots; NTC > 0: the pivot count of a short last panel as a constant (3 at K = 10, 15 at K = 20) -- no branch in the panel either way
 __device__ __forceinline__ bool rowwave_panel(PTR A, const int Kt, const int D, const int R, StepShared& s, const int lane) {
     constexpr int o = FIRST ? 4 : 0;                 // lane l owns row 16 Kt + o + l; the row of column k lives in lane k - o
     const int c0 = Kt << 4;
-    const int nt = FULL ? 16 : min(16, D - c0);      // pivots of this tile column
+    const int nt = FULL ? 16 : NTC > 0 ? NTC : min(16, D - c0);      // pivots of this tile column
     const int row = c0 + o + lane, rc = min(row, R - 1);
     const int base = tl_base(rc >> 4, Kt) + (rc & 15) * TILE_RS;
     double t[16];
@@ -814,7 +814,7 @@ __device__ __forceinline__ bool chol_rowwave(PTR A, int D, StepShared& s, PRE pr
         if (wave == NWP) {
             bool ok;
             if (two) ok = Kt == 0 ? rowwave_panel_full<true, true>(A, 0, R, s, lane) : rowwave_panel_full<false, true>(A, Kt, R, s, lane);
-            else ok = Kt == 0 ? rowwave_panel_full<true, false>(A, 0, R, s, lane) : (D - (Kt << 4) >= 16 ? rowwave_panel_full<false, false>(A, Kt, R, s, lane) : rowwave_panel<false, false>(A, Kt, D, R, s, lane));
+            else ok = Kt == 0 ? rowwave_panel_full<true, false>(A, 0, R, s, lane) : (D - (Kt << 4) >= 16 ? rowwave_panel_full<false, false>(A, Kt, R, s, lane) : D - (Kt << 4) == 3 ? rowwave_panel<false, false, 3>(A, Kt, D, R, s, lane) : D - (Kt << 4) == 15 ? rowwave_panel<false, false, 15>(A, Kt, D, R, s, lane) : rowwave_panel<false, false>(A, Kt, D, R, s, lane));
             if (!ok && lane == 0) s.cok = 0;
         } else if (two && wave == NWP + 1) rowwave_panel_second(A, Kt, o, R, s, lane);
         lds_barrier();                                       // tile column Kt is L

@@ -33,7 +33,7 @@ __device__ __forceinline__ double block_sum(double v, double* red /*>= 4 doubles
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int f, const double* x, double* sm, const int plaunch = -1, const bool chain_rec = false /* one-launch iteration: what the chain workgroup gathers also leaves as a compact record (chain_rec_index, vil_dev.hpp) */) {
+__device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int f, const double* x, double* sm, const int plaunch = -1, const bool chain_rec = false /* one-launch iteration: what the chain workgroup gathers also leaves as a compact record (chain_rec_index, vil_dev.hpp) */, const int chain_epoch = 0) {
     double* const outc = chain_rec ? P.irec + (size_t)f * VIL_CHAIN_REC : nullptr;
     #define IPROF(k) do { if (plaunch >= 0 && f == 0 && threadIdx.x == 0) prof_stamp(P, plaunch, k); } while (0)
     IPROF(16);
@@ -114,11 +114,31 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
     __syncthreads();
     ISTAMP(19);
     IPROF(19);
-    for (int e = t; e < 931; e += blockDim.x) {
+    auto entry = [&](const int e) {
         double s = 0;
         if (e < 900) { const int a = e / 30, b = e % 30; for (int k = 0; k < 15; ++k) s += UJ[k * 30 + a] * UJ[k * 30 + b]; }
         else if (e < 930) { const int a = e - 900; for (int k = 0; k < 15; ++k) s += UJ[k * 30 + a] * Ur[k]; }
         else { for (int k = 0; k < 15; ++k) s += Ur[k] * Ur[k]; s *= 0.5; }
+        return s;
+    };
+    if (chain_rec && blockDim.x >= 512) {
+        // one-launch iteration: the 405 entries the chain workgroup gathers are formed and stored FIRST (P.imu_perm: they lead the order), and the role's chain flag
+        // goes up behind THEIR stores -- the other 526 entries are formed while those stores travel and leave afterwards (the gather workgroups wait for the
+        // role's ordinary flag, and have slack: DESIGN.md 0d).  The chain leg of the iteration starts ~0.8 us earlier.
+        const int eA = P.imu_perm[t], eB = P.imu_perm[min(t + 512, 930)];
+        const double sA = entry(eA);
+        st_ag(out + eA, sA);
+        if (t < VIL_CHAIN_REC) st_ag(outc + t, sA);
+        const double sB = entry(eB);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) { st_ag(P.cflag + f, chain_epoch); IPROF(20); }
+        if (t + 512 < 931) st_ag(out + eB, sB);
+        ISTAMP(28);
+        return;
+    }
+    for (int e = t; e < 931; e += blockDim.x) {
+        const double s = entry(e);
         st_ag(out + e, s);
         if (outc) { const int ce = chain_rec_index(e); if (ce >= 0) st_ag(outc + ce, s); }
     }
@@ -807,10 +827,10 @@ __device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, co
         if constexpr (FUSED) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores of the record (__syncthreads alone does not wait for global stores)
             __syncthreads();
-            if (threadIdx.x == 0) { vd::st_ag(P.sflag + blk, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u)); prof_stamp(P, ctl.n_sweeps, blk < P.n_imu ? 2 : (blk == P.n_imu ? 15 : 1)); }
+            if (threadIdx.x == 0) { const int ep = (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u); vd::st_ag(P.sflag + blk, ep); if (blk < P.n_imu) vd::st_ag(P.cflag + blk, ep); prof_stamp(P, ctl.n_sweeps, blk < P.n_imu ? 2 : (blk == P.n_imu ? 15 : 1)); }      // (an IMU role's chain flag: up already unless the role left early)
         }
     };
-    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm, FUSED ? ctl.n_sweeps : -1, FUSED); if (pre) sweep_signal(P, ctl, b); posted(); return; }
+    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm, FUSED ? ctl.n_sweeps : -1, FUSED, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u)); if (pre) sweep_signal(P, ctl, b); posted(); return; }
     b -= P.n_imu;
     if (b == 0) { if (!(P.skip_mask & 16)) vd::sweep_prior(P, x, sm); if (pre) sweep_signal(P, ctl, P.n_imu); posted(); return; }
     if (b == 1) {

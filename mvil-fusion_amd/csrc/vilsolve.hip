@@ -285,6 +285,7 @@ struct vil_ctx {
     struct ChunkGraph { int n; SolveOpts so; hipGraphExec_t exec; };
     std::vector<ChunkGraph> graphs;
     int use_graph = -1;            // VIL_GRAPH=0 disables (tuning build)
+    int* d_imu_perm = nullptr;      // (vil_sweep.hpp, sweep_imu: entry order of the IMU roles)
     std::vector<int> chtab_key; int* d_chtab = nullptr; int* h_chtab = nullptr; size_t chtab_cap = 0; int chtab_n = 0; hipEvent_t chtab_ev = nullptr; bool chtab_ev_pending = false;      // gather table of the chain workgroup (vil_prechain.hpp)
     bool graph_failed = false;     // a chunk with a collective could not be captured: direct launches from then on
     int solve_gen = 0;             // generation counter of the helper-workgroup flags (Ctl::gen)
@@ -478,6 +479,7 @@ void vil_destroy(vil_ctx* c) {
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->marg_ws) hipFree(c->marg_ws);
     if (c->lc_tmp) hipFree(c->lc_tmp);
+    if (c->d_imu_perm) hipFree(c->d_imu_perm);
     if (c->d_chtab) hipFree(c->d_chtab);
     if (c->h_chtab) hipHostFree(c->h_chtab);
     if (c->chtab_ev) hipEventDestroy(c->chtab_ev);
@@ -908,6 +910,15 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     put(nullptr, 8 * (size_t)225 * std::max(p->n_imu, 1), (void**)&P.imu_U);
     put(p->imu_i, 4 * (size_t)p->n_imu, (void**)&P.imu_i); put(p->imu_j, 4 * (size_t)p->n_imu, (void**)&P.imu_j);
     put(nullptr, 8 * (size_t)931 * std::max(p->n_imu, 1), (void**)&P.ipart);
+    if (!c->d_imu_perm) {   // the order of an IMU role's record entries in a one-launch iteration: what the chain workgroup gathers first.  Constant: one device copy per context
+        int perm[1024]; int n = VIL_CHAIN_REC;
+        for (int e = 0; e < 931; ++e) { const int ce = chain_rec_index(e); if (ce >= 0) perm[ce] = e; else perm[n++] = e; }
+        for (int e = 931; e < 1024; ++e) perm[e] = 930;
+        HIPCHK(hipMalloc((void**)&c->d_imu_perm, sizeof(perm)));
+        HIPCHK(hipMemcpy(c->d_imu_perm, perm, sizeof(perm), hipMemcpyHostToDevice));
+    }
+    P.imu_perm = c->d_imu_perm;
+    put(nullptr, 4 * (size_t)(std::max(p->n_imu, 1) + 8), (void**)&P.cflag);
     put(nullptr, 8 * (size_t)VIL_CHAIN_REC * std::max(p->n_imu, 1), (void**)&P.irec);      // (compact IMU records for the chain workgroup of a one-launch iteration)
     // prior
     P.pn = p->prior.n > 0 ? p->prior.n : 0; P.pnblk = P.pn ? p->prior.nblk : 0;
