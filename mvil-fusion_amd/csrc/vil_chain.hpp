@@ -67,8 +67,12 @@ __device__ __forceinline__ bool chol9(const double* Dk, L9& o) {
 }
 
 #define CHAIN_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-__device__ __forceinline__ void chain_wait(volatile int* f, int v) { while (*f < v) __builtin_amdgcn_s_sleep(1); CHAIN_FENCE(); }
-__device__ __forceinline__ void chain_post(volatile int* f, int v) { CHAIN_FENCE(); if ((threadIdx.x & 63) == 0) *f = v; }   // LDS operations of a wave execute in order
+// (relaxed workgroup-scope atomics, not volatile accesses: the address-space inference skips volatile loads and stores, and these flags then travel as FLAT
+//  instructions -- each poll behind an s_waitcnt vmcnt(0) lgkmcnt(0), i.e. behind the completion of the row waves' own global stores of W^T, a microsecond per block)
+__device__ __forceinline__ int chain_flag_get(volatile int* f) { return __hip_atomic_load(const_cast<int*>(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void chain_flag_set(volatile int* f, int v) { __hip_atomic_store(const_cast<int*>(f), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void chain_wait(volatile int* f, int v) { while (__hip_atomic_load(const_cast<int*>(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(1); CHAIN_FENCE(); }
+__device__ __forceinline__ void chain_post(volatile int* f, int v) { CHAIN_FENCE(); if ((threadIdx.x & 63) == 0) __hip_atomic_store(const_cast<int*>(f), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // LDS operations of a wave execute in order
 
 // solve one panel row against the factored 9 x 9 block: w = a L^-T
 __device__ __forceinline__ void row_solve9(const double* l, const double* r, const double* a, double* w) {
@@ -193,7 +197,7 @@ __device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, con
             chain_post(L.flag + 2, 1);
             CSTMP(54);
         }
-        if (!ok) L.flag[5] = 1;
+        if (!ok) chain_flag_set(L.flag + 5, 1);
         return;
     }
     // ---------------- row waves: pose-part row r (r == NP: right-hand side) of direction d -------------------------------------

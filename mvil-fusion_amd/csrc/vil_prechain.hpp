@@ -115,7 +115,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     const ChainLds L = chain_lds(lds, K);
     double* scB = lds + chain_scratch_doubles(K); double* dcB = scB + even_up(NB); double* uB = dcB + even_up(NB);
     const ChainSlab B = chain_slab(uB + even_up(NB), K);
-    if (t < 8) L.flag[t] = 0;
+    if (t < 8) chain_flag_set(L.flag + t, 0);
     // ---- gather of the chain part of S' out of the IMU / prior records through the host-built table: eight entries per thread and round (one round at
     //      K = 10, two at K = 20).  Two dependent round trips -- entries, then their sources -- and NOTHING before them: the zeroing of the slab (a gather target: entries
     //      without a source, pose rows of far frames, stay zero) and the small copies run while the sources are in flight; only the stores wait for the barrier
@@ -228,7 +228,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
         qc = wave_total(qc);
         if ((t & 63) == 0) st_ag(P.chQ + (t >> 6), qc);
     }
-    if (t == 0) st_ag(P.chOk, L.flag[5] ? 0 : 1);
+    if (t == 0) st_ag(P.chOk, chain_flag_get(L.flag + 5) ? 0 : 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every thread's W^T / chZ / chQ stores are out ...
     __syncthreads();
     if (t == 0) { st_ag(P.chflag, epoch); if (FUSED) prof_stamp(P, epoch - 1, 4); }                  // ... W^T is complete: the tile workgroups start

@@ -1057,7 +1057,7 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
     double* Tl = lds;
     double* Wt = WLDS ? lds + ntile * TILE_SZ : P.M;                       // W^T: column j of the chain at Wt[j * RS + row]
     const ChainLds L = chain_lds(lds + ntile * TILE_SZ + (WLDS ? (size_t)chain_wcols(K) * RS : 0), K);
-    if (t < 8) L.flag[t] = 0;
+    if (t < 8) chain_flag_set(L.flag + t, 0);
     __syncthreads();
     SSTAMP(1);
     if (t < 384) {
@@ -1097,7 +1097,7 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
     }
     __syncthreads();
     SSTAMP(2);
-    if (L.flag[5]) return false;
+    if (chain_flag_get(L.flag + 5)) return false;
     SSTAMP(3);
     // ---- S_pp -= W W^T on the matrix cores, straight into the accumulators of the blocked Cholesky; dense part -------------
     auto schur = [&](d4* Creg, const int* tIJ) {
