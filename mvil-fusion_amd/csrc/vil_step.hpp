@@ -106,7 +106,7 @@ __device__ __forceinline__ double bmax(double v, StepShared& s) {
 // chained index loads.  The landmark's rows are first fetched into an LmRows (anchor/ex/td row + the first three observers:
 // all loads in flight together); a helper workgroup keeps that between its two passes, so the second one -- which sits on
 // the step kernel's critical path -- touches no global memory for the usual landmark.
-struct LmRows { double e[13], a[6], b[6], c[6]; double m1, m2; int fs, fe, ac, c0, c1, c2; };
+struct LmRows { double e[13], a[6], b[6], c[6]; double m1, m2; int fs, fe, ac, c0, c1, c2, stride = 3; };      // stride: observers between this lane's groups of three (3: the lane has them all; 12: a quad shares a landmark)
 template <bool AG = false>      // AG: e_A / e_O were written by the visual workgroups of THIS launch (the one-launch iteration, k_iter)
 __device__ __forceinline__ void lm_rows(const DevP& P, const SysBuf& sb, int l, LmRows& r) {
     r.fs = P.glm_start[l]; r.fe = P.glm_start[l + 1]; r.ac = P.glm_acol[l];
@@ -124,6 +124,28 @@ __device__ __forceinline__ void lm_rows(const DevP& P, const SysBuf& sb, int l, 
     for (int k = 0; k < 6; ++k) { r.a[k] = ldx<AG>(e0 + k); r.b[k] = ldx<AG>(e1 + k); r.c[k] = ldx<AG>(e2 + k); }
     r.m1 = (f + 1 < r.fe) ? 1.0 : 0.0; r.m2 = (f + 2 < r.fe) ? 1.0 : 0.0;
 }
+// A landmark shared by the four lanes of a quad: lane qd takes the observers [3 qd, 3 qd + 3) (and every twelfth group of three behind them), lane 0 the anchor /
+// extrinsic / td row as well.  The lanes' dot products add up to lm_dot_rows' of the whole landmark (quad_total): up to TWELVE observers without a load in the second
+// pass -- with one lane per landmark everything past the third observer was a dependent round trip to memory inside the pass the master waits for (configs[1]:
+// a third of the landmarks have four to nine observers, so every helper paid two of them).
+template <bool AG = false>
+__device__ __forceinline__ void lm_rows_quad(const DevP& P, const SysBuf& sb, int l, int qd, LmRows& r) {
+    const int fs0 = P.glm_start[l], fe = P.glm_start[l + 1];
+    r.ac = qd == 0 ? P.glm_acol[l] : 0; r.stride = 12;
+    r.fs = min(fs0 + 3 * qd, fe); r.fe = fe;
+    if (fe == fs0) { r.fs = fe; return; }                  // (no observer: the landmark takes no part, anchor row included -- as lm_rows)
+    const double* e = sb.eA + (size_t)l * 13;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) { const double v = ldx<AG>(e + k); r.e[k] = qd == 0 ? v : 0.0; }
+    const int f = min(fs0 + 3 * qd, fe - 1), f1 = min(f + 1, fe - 1), f2 = min(f + 2, fe - 1);
+    r.c0 = P.gfcol[f]; r.c1 = P.gfcol[f1]; r.c2 = P.gfcol[f2];
+    const double* e0 = sb.eO + (size_t)f * 6; const double* e1 = sb.eO + (size_t)f1 * 6; const double* e2 = sb.eO + (size_t)f2 * 6;
+    const bool m0 = fs0 + 3 * qd < fe;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const double va = ldx<AG>(e0 + k); r.a[k] = m0 ? va : 0.0; r.b[k] = ldx<AG>(e1 + k); r.c[k] = ldx<AG>(e2 + k); }
+    r.m1 = (fs0 + 3 * qd + 1 < fe) ? 1.0 : 0.0; r.m2 = (fs0 + 3 * qd + 2 < fe) ? 1.0 : 0.0;
+}
+__device__ __forceinline__ double quad_total(double v) { v = dpp_add<0xB1, 0xf>(v); return dpp_add<0x4E, 0xf>(v); }      // quad_perm [1,0,3,2], [2,3,0,1]: the same bits in the four lanes
 template <bool AG = false>
 __device__ __forceinline__ double lm_dot_rows(const DevP& P, const SysBuf& sb, const LmRows& r, const double* vc) {
     if (r.fe == r.fs) return 0.0;
@@ -140,7 +162,7 @@ __device__ __forceinline__ double lm_dot_rows(const DevP& P, const SysBuf& sb, c
         s2 += r.m1 * (b[0] * v1[0] + b[1] * v1[1] + b[2] * v1[2]); s3 += r.m1 * (b[3] * v1[3] + b[4] * v1[4] + b[5] * v1[5]);
         s0 += r.m2 * (c[0] * v2[0] + c[1] * v2[1] + c[2] * v2[2]); s1 += r.m2 * (c[3] * v2[3] + c[4] * v2[4] + c[5] * v2[5]);
     }
-    for (int f = r.fs + 3; f < r.fe; f += 3) {          // landmarks seen from more than three frames: the rest from memory
+    for (int f = r.fs + r.stride; f < r.fe; f += r.stride) {          // landmarks seen from more frames than the lane(s) hold: the rest from memory
         const int f1 = min(f + 1, r.fe - 1), f2 = min(f + 2, r.fe - 1);
         const int c0 = P.gfcol[f], c1 = P.gfcol[f1], c2 = P.gfcol[f2];
         const double* e0 = sb.eO + (size_t)f * 6; const double* e1 = sb.eO + (size_t)f1 * 6; const double* e2 = sb.eO + (size_t)f2 * 6;
@@ -1603,24 +1625,30 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
             if (per <= NT) {
                 // one landmark per thread: its rows and scalars stay in registers between the two passes, the second pass
                 // (which the master waits for) reads only Sc x_p
-                const int l = l0 + t;
-                const bool have = l < l1;
+                // (a QUAD per landmark while the helper has four threads for each -- lm_rows_quad: up to twelve observers in registers; the quad's lanes hold the same
+                //  scalars, its lane 0 owns the landmark's sums and stores)
+                const bool quad = 4 * per <= NT;
+                const int qd = quad ? (t & 3) : 0;
+                const int l = l0 + (quad ? (t >> 2) : t);
+                const bool have = l < l1, lead = have && qd == 0;
                 LmRows r; r.fs = 0; r.fe = 0;
-                double ip = 0, b = 0, d = 1, g = 0, lam2 = 0, ipS = 0, Sd = 0, a_ = 0;      // ipS = invp / Sl, Sd = Sl / dl, a_ = la
+                double ip = 0, b = 0, d = 1, g = 0, lam2 = 0, ipS = 0, Sd = 0, a_ = 0, h_ = 0;      // ipS = invp / Sl, Sd = Sl / dl, a_ = la
                 if (have) {
-                    lm_rows<FUSED>(P, sb, l, r);
+                    if (quad) lm_rows_quad<FUSED>(P, sb, l, qd, r); else lm_rows<FUSED>(P, sb, l, r);
                     ip = ldx<FUSED>(sb.invp + l); b = ldx<FUSED>(sb.bl + l);
                     const double Sl = ldx<FUSED>(sb.sl + l), h = ldx<FUSED>(sb.hll + l);
+                    h_ = h;
                     if (!(P.lm_const && P.lm_const[l])) { const double lam = ldx<FUSED>(x + xo_lam(P) + l); lam2 = lam * lam; }
                     d = sqrt(fmin(fmax(Sl * Sl * h, 1e-6), 1e32));
                     g = ip != 0.0 ? Sl * b / d : 0.0;
-                    P.dl[l] = d; P.gradl[l] = g;
-                    if (ip != 0.0) {
-                        Sd = Sl / d; ipS = ip / Sl;               // the divides of the second pass, done while the master solves
-                        const double ul = Sd * g;
-                        a_ = ul;
-                        const double ev = lm_dot_rows<FUSED>(P, sb, r, s.y);
-                        q += ip * ev * ev + 2.0 * ul * ev + h * ul * ul;
+                    if (lead) { P.dl[l] = d; P.gradl[l] = g; }
+                    if (ip != 0.0) { Sd = Sl / d; ipS = ip / Sl; a_ = Sd * g; }               // the divides of the second pass, done while the master solves
+                }
+                {
+                    double ev = (have && ip != 0.0) ? lm_dot_rows<FUSED>(P, sb, r, s.y) : 0.0;
+                    if (quad) ev = quad_total(ev);
+                    if (lead && ip != 0.0) {
+                        q += ip * ev * ev + 2.0 * a_ * ev + h_ * a_ * a_;
                         g2 += g * g; gm = fmax(gm, fabs(b));
                     }
                 }
@@ -1631,9 +1659,11 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
                 if (s.ok) {
                     double sm[6] = {0, 0, 0, 0, 0, 0};
                     double b_ = 0.0;
-                    if (have) {
+                    double ev2 = (have && ip != 0.0) ? lm_dot_rows<FUSED>(P, sb, r, s.gn) : 0.0;
+                    if (quad) ev2 = quad_total(ev2);
+                    if (lead) {
                         if (ip != 0.0) {
-                            const double xl = (b - lm_dot_rows<FUSED>(P, sb, r, s.gn)) * ipS;
+                            const double xl = (b - ev2) * ipS;
                             const double gnv = -xl * d;
                             sm[0] = gnv * gnv; sm[1] = gnv * g;
                             b_ = Sd * gnv;
@@ -1642,7 +1672,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
                         sm[5] = lam2;
                     }
                     post_wave2(sm);
-                    if (have) { P.la[l] = a_; P.lb[l] = b_; }      // (for the next sweep: not part of what the master waits for)
+                    if (lead) { P.la[l] = a_; P.lb[l] = b_; }      // (for the next sweep: not part of what the master waits for)
                 }
                 return;
             }
@@ -1718,7 +1748,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         if constexpr (CHAIN != 0) {
             __syncthreads();
             auto pub = [&]() { publish_xp(1); };
-            auto side = [&]() {};          // (the helpers' sums are collected after the step vectors below: their round trip outlasts the chain walks)
+            auto side = [&]() {};          // (the helpers' sums are collected after the step vectors below: their round trip outlasts the chain walks -- also with a quad of threads per landmark: fetched by the spare wave beside the walks, the walks' barrier waits for the answer instead, 46.2 -> 47.2 us, and the sums are in at the same 49.4)
             if constexpr (CHAIN == 3) ok = solve_prechain<FUSED>(P, sb, s, Alds, mu, cam, q, epoch, pub, side);
             else ok = solve_chain<CHAIN == 1>(P, sb, s, Alds, mu, cam, q, pub, side);      // packing, chain, Schur update, dense part, back substitution
         } else {
