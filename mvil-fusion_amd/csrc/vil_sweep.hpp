@@ -586,7 +586,11 @@ __device__ __forceinline__ int imu_local(const DevP& P, int i, int j, int col) {
 // whose register allocation admits one workgroup per compute unit whatever its thread count)
 // workgroups of the gather: entries of the visual triangle (32 slices each: EPW / 4 per workgroup), the other entries of the lower triangle (8 slices:
 // EPW per workgroup), the 2 D vector entries (32 slices), the cost
-__host__ __device__ inline int gather_vblocks(int NV, int epw) { return ((NV * (NV + 1)) / 2 + epw / 4 - 1) / (epw / 4); }
+// entries of the visual triangle per gather workgroup: a quarter of EPW (32 slices per entry: one round of loads covers 256 records) -- but EPW (8 slices) for
+// the large windows (K > 16): at K = 20 the quarter made 508 workgroups of ~6 us each for the ~210 compute units the waiting roles leave free -- the launch's
+// dynamic LDS allows one workgroup per unit -- i.e. three rounds, and the last gather workgroup saw the visual flags 21 us after the last visual record
+__host__ __device__ inline int gather_epv(int NV, int epw) { return NV > 100 ? epw : epw / 4; }
+__host__ __device__ inline int gather_vblocks(int NV, int epw) { const int epv = gather_epv(NV, epw); return ((NV * (NV + 1)) / 2 + epv - 1) / epv; }
 // pose_only: a solve whose speed-bias chain is eliminated from the IMU / prior records directly (vil_prechain.hpp) reads S' on the visual sub-space only;
 // of the rest (39 k of the 47 k entries at K = 20) the gather then forms just the diagonal (the dogleg scaling)
 __host__ __device__ inline int gather_sblocks(int D, int NV, int epw, bool pose_only) { return gather_vblocks(NV, epw) + ((pose_only ? D - NV : (D * (D + 1)) / 2 - (NV * (NV + 1)) / 2) + epw - 1) / epw; }
@@ -644,9 +648,10 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
         if (P.skip_mask & 32) return;
         const bool vis = blk < nVblk;          // (workgroup-uniform)
         stage(vis);
-        const int epw = vis ? EPV : EPW, ns = vis ? 32 : 8;
+        const int epvb = gather_epv(NV, EPW);
+        const int epw = vis ? epvb : EPW, ns = (8 * EPW) / epw;
         const int el = t & (epw - 1), slice = t / epw;
-        int idx = vis ? blk * EPV + el : NVT + (blk - nVblk) * EPW + el;
+        int idx = vis ? blk * epvb + el : NVT + (blk - nVblk) * EPW + el;
         int i = 0, j = 0;
         bool ok = idx < (vis ? NVT : NL);
         if (!vis && pose_only) {               // only the diagonal of the non-visual part
@@ -701,18 +706,19 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
                 const bool in = il_ >= 0 && jl_ >= 0 && live;
                 const int il = in ? il_ : 0, jl = in ? jl_ : 0, I = il >> 4, J = jl >> 4;
                 const double* r = P.vpart + (size_t)ds.x * 16;
-                const double va = rd(r + (I * T - ((I * (I - 1)) >> 1) + (J - I)) * 256 + (jl & 15) * 16 + (il & 15));      // tile (I, J) holds its transpose
-                va_ = in ? va : 0.0; vd_ = 0.0;
-                if (wdiag) { const double vd = rd(r + vis_ntile(T) * 256 + 16 * T + il); vd_ = (in && i == j) ? vd : 0.0; }
+                // (only the records that cover the entry are loaded: agent-scope loads cost per lane, and at K = 20 two records in three do not)
+                va_ = 0.0; vd_ = 0.0;
+                if (in) va_ = rd(r + (I * T - ((I * (I - 1)) >> 1) + (J - I)) * 256 + (jl & 15) * 16 + (il & 15));      // tile (I, J) holds its transpose
+                if (wdiag && in && i == j) vd_ = rd(r + vis_ntile(T) * 256 + 16 * T + il);
             };
-            for (int w = slice; w < nws; w += 32 * U) {
+            for (int w = slice; w < nws; w += ns * U) {
                 double a[U], d[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) fetch(vtab[min(w + 32 * u, wlast)], w + 32 * u < nws, a[u], d[u]);
+                for (int u = 0; u < U; ++u) fetch(vtab[min(w + ns * u, wlast)], w + ns * u < nws, a[u], d[u]);
 #pragma unroll
                 for (int u = 0; u < U; ++u) { vs += a[u]; vdg += d[u]; }
             }
-            for (int w = VIS_TAB + slice; w < nw; w += 32) { double a, d; fetch(vrec[w], true, a, d); vs += a; vdg += d; }      // (windows with more than VIS_TAB chunks)
+            for (int w = VIS_TAB + slice; w < nw; w += ns) { double a, d; fetch(vrec[w], true, a, d); vs += a; vdg += d; }      // (windows with more than VIS_TAB chunks)
         }
         part[0][slice * epw + el] = vs + ms; part[1][slice * epw + el] = vdg - vs;     // [1]: un-reduced minus reduced visual diagonal
         __syncthreads();
