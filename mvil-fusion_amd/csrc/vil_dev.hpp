@@ -106,6 +106,7 @@ struct DevP {
     double* ipart;                // n_imu x 931  [30x30 H | 30 g | cost]
     double* chc;                  // the prior's constant share (J0^T J0 entries) of the chain workgroup's gather, in table order: written by the first iteration of a solve, read by the later ones
     const int* imu_perm;          // the order an IMU role of a one-launch iteration forms its 931 record entries in: the VIL_CHAIN_REC the chain workgroup gathers first (in the compact record's order)
+    int* sall;                    // one-launch iteration: [16] / [32] = launch epoch once every non-visual / visual sweep role has posted -- published by the master workgroup, which polls the roles' flags ONCE for all gather workgroups
     int* cflag;                   // n_imu: an IMU role's compact record is complete (launch epoch; P.sflag[role] follows when the whole record is)
     double* irec;                 // n_imu x VIL_CHAIN_REC: one-launch iteration -- the part of the IMU records the chain workgroup gathers, compact (chain_rec_index)
     double* mpart;                // prior: [pn g | cost] then n_rel x 601 [24x24 H | 24 g | cost]

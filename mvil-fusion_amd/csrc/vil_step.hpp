@@ -1458,6 +1458,17 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     if (merged && P.prechain && bid == b_chain) { prechain_wg<FUSED>(P, s.c, O.jacobi_scaling, Alds, epoch, FUSED); return; }      // (posts chflag[0 .. 2] itself; one-launch iteration: behind the IMU / prior workgroups' flags)
     if (!merged && P.prechain == 2 && bid == b_chain) { prechain_inverses(P, Alds, epoch); return; }                 // (chain eliminated inside k_sweep: posts chflag[2])
     if (bid == 0) PROF(7);
+    if constexpr (FUSED) {
+        if (bid == 0) {      // the master collects the sweep roles' flags for the gather workgroups: the other roles first (they finish early), then the visual ones
+            const int v0 = P.n_imu + 2, nv = P.n_vwg, n1 = P.n_sw - nv;
+            for (int i = t; i < n1; i += NT) spin_until_eq(P.sflag + (i < v0 ? i : i + nv), epoch, P.abortf);
+            __syncthreads();
+            if (t == 0) st_ag(P.sall + 16, epoch);
+            for (int i = t; i < nv; i += NT) spin_until_eq(P.sflag + v0 + i, epoch, P.abortf);
+            __syncthreads();
+            if (t == 0) st_ag(P.sall + 32, epoch);
+        }
+    }
     if (merged) rs_wait(P.gflag, P.n_gather);          // master and helpers: the candidate's cost, gradient and diagonal (and S') are complete
     if (bid == 0) PROF(8);
     // Everything the master and its helpers hand each other inside this launch (hpart, hpart2, stepc) is stored AND loaded with agent-scope

@@ -606,8 +606,10 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
     // records while the visual workgroups are still at work, and only then waits for the visual records -- one round of loads behind the last of them
     auto wait_sweep = [&](const bool visual) {
         if constexpr (FUSED) {
-            const int v0 = P.n_imu + 2, nv = P.n_vwg, n = visual ? nv : P.n_sw - nv;
-            for (int i = threadIdx.x; i < n; i += 8 * EPW) { const int* f = P.sflag + (visual ? v0 + i : (i < v0 ? i : i + nv)); spin_until_eq(f, epoch, P.abortf); }
+            // (ONE word per group of roles, published by the master workgroup -- vil_step.hpp: it polls the roles' flags once for everybody.  Every gather workgroup
+            //  polling every role's flag was n_gather x n_sweep lanes on a few dozen cache lines: 166 x 1700 at configs[2], where the gather saw the visual flags
+            //  4.3 us after the last visual record)
+            if (threadIdx.x == 0) spin_until_eq(P.sall + (visual ? 32 : 16), epoch, P.abortf);
             __syncthreads();
             if (visual && threadIdx.x == 0) prof_stamp(P, epoch - 1, 6);
         }

@@ -996,6 +996,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         put(nullptr, 8 * (size_t)2 * (NV + 1), (void**)&P.chZ); put(nullptr, 8 * 4, (void**)&P.chQ); put(nullptr, 16, (void**)&P.chOk);
         put(nullptr, 4 * (size_t)(gather_blocks(D, NV, RED_EPW, false) + 8), (void**)&P.gflag);      // (one flag per gather workgroup of the merged launch: never more than the gather kernel has)
         put(nullptr, 64, (void**)&P.chflag); put(nullptr, 4 * 64, (void**)&P.wwflag); put(nullptr, 4 * (size_t)(K + 8), (void**)&P.swflag);
+        put(nullptr, 4 * 64, (void**)&P.sall);
         put(nullptr, 4 * (size_t)VIL_SFLAG_MAX, (void**)&P.sflag);      // one flag per sweep workgroup of a one-launch iteration (taken only when there are fewer: below)
         put(nullptr, 64, (void**)&P.abortf);      // (raised by a wait on another workgroup's flag that gives up: vil_math.hpp, spin_until_eq)
         { const size_t Tp = (size_t)(NV + 1 + 15) / 16; put(nullptr, 8 * (size_t)TILE_SZ * (Tp * (Tp + 1) / 2), (void**)&P.chWW); }
