@@ -1469,7 +1469,10 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
             if (t == 0) st_ag(P.sall + 32, epoch);
         }
     }
-    if (merged) rs_wait(P.gflag, P.n_gather);          // master and helpers: the candidate's cost, gradient and diagonal (and S') are complete
+    // master and helpers: the candidate's cost, gradient and diagonal (and S') are complete.  One-launch iteration: the master polls the gather workgroups' flags
+    // and passes one word on to the helpers (their first pass is not on the critical path: a hop more, n_help x n_gather polling lanes fewer)
+    if (FUSED && merged && bid > 0) { if (t == 0) spin_until_eq(P.sall + 48, epoch, P.abortf); __syncthreads(); }
+    else if (merged) { rs_wait(P.gflag, P.n_gather); if (FUSED && t == 0) st_ag(P.sall + 48, epoch); }
     if (bid == 0) PROF(8);
     // Everything the master and its helpers hand each other inside this launch (hpart, hpart2, stepc) is stored AND loaded with agent-scope
     // atomics, i.e. at the level all XCDs share, so a flag only has to be ordered after the poster's own stores (s_waitcnt).  A release
