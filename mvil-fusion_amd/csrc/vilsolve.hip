@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <mutex>
 #include <array>
 #include <memory>
 #include <pthread.h>
@@ -286,7 +287,9 @@ struct vil_ctx {
     std::vector<ChunkGraph> graphs;
     int use_graph = -1;            // VIL_GRAPH=0 disables (tuning build)
     int* d_imu_perm = nullptr;      // (vil_sweep.hpp, sweep_imu: entry order of the IMU roles)
-    std::vector<int> chtab_key; int* d_chtab = nullptr; int* h_chtab = nullptr; size_t chtab_cap = 0; int chtab_n = 0; hipEvent_t chtab_ev = nullptr; bool chtab_ev_pending = false;      // gather table of the chain workgroup (vil_prechain.hpp)
+    // (a few tables by key: a tracker alternates between the prior structures of its two marginalisation kinds, and a rebuild -- entries, sort, copy -- is ~80 us of host time)
+    struct ChTab { std::vector<int> key; int* d = nullptr; int* h = nullptr; size_t cap = 0; int n = 0; hipEvent_t ev = nullptr; bool ev_pending = false; unsigned long long used = 0; };
+    ChTab chtabs[4]; int chtab_cur = 0; unsigned long long chtab_clock = 0;      // gather table of the chain workgroup (vil_prechain.hpp)
     bool graph_failed = false;     // a chunk with a collective could not be captured: direct launches from then on
     int solve_gen = 0;             // generation counter of the helper-workgroup flags (Ctl::gen)
     int solves_since_upload = 0;
@@ -359,8 +362,14 @@ static int ensure_mirror(vil_ctx* c, size_t ns) {
 
 // static LDS of a kernel as the loaded code object reports it (StepShared is only part of what k_step carries: the gather and tile roles keep scratch arrays there)
 static size_t step_static_lds(const void* fn) {
+    // (a property of the code object: asked once per kernel and process -- hipFuncGetAttributes is a few microseconds of driver time, and every upload, i.e. every
+    //  image of a tracker, asked five times)
+    static std::mutex mu; static std::vector<std::pair<const void*, size_t>> known;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto& e : known) if (e.first == fn) return e.second;
     hipFuncAttributes fa;
     if (hipFuncGetAttributes(&fa, fn) != hipSuccess) { (void)hipGetLastError(); return (size_t)64 * 1024; }
+    known.emplace_back(fn, (size_t)fa.sharedSizeBytes);
     return (size_t)fa.sharedSizeBytes;
 }
 static SolveOpts to_dev_opts(const vil_options* o) {
@@ -480,9 +489,7 @@ void vil_destroy(vil_ctx* c) {
     if (c->marg_ws) hipFree(c->marg_ws);
     if (c->lc_tmp) hipFree(c->lc_tmp);
     if (c->d_imu_perm) hipFree(c->d_imu_perm);
-    if (c->d_chtab) hipFree(c->d_chtab);
-    if (c->h_chtab) hipHostFree(c->h_chtab);
-    if (c->chtab_ev) hipEventDestroy(c->chtab_ev);
+    for (auto& ct : c->chtabs) { if (ct.d) hipFree(ct.d); if (ct.h) hipHostFree(ct.h); if (ct.ev) hipEventDestroy(ct.ev); }
     if (c->ipc_tmp) hipFree(c->ipc_tmp);
     if (c->slim_buf) hipFree(c->slim_buf);
     if (c->d_prof) hipFree(c->d_prof);
@@ -1002,12 +1009,19 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         { const size_t Tp = (size_t)(NV + 1 + 15) / 16; put(nullptr, 8 * (size_t)TILE_SZ * (Tp * (Tp + 1) / 2), (void**)&P.chWW); }
         put(nullptr, 8 * (size_t)VIL_CHC_MAX, (void**)&P.chc);
     }
+    UPTICK("ws-puts");
     if (pre_ok) {
         // the table depends on K, the IMU factor layout and the prior's block structure only: consecutive windows of a tracker share it, so it
         // lives in its own device buffer and is rebuilt (and sent) only when that key changes
         std::vector<int> key; key.reserve(2 * K + D + 2);
         key.push_back(K); key.push_back(P.pn); key.insert(key.end(), as_i.begin(), as_i.end()); key.insert(key.end(), as_j.begin(), as_j.end()); key.insert(key.end(), pinv.begin(), pinv.end());
-        if (key != c->chtab_key) {
+        int cs = -1;
+        for (int q = 0; q < 4; ++q) if (c->chtabs[q].d && c->chtabs[q].key == key) cs = q;
+        const bool ct_hit = cs >= 0;
+        if (!ct_hit) { cs = 0; for (int q = 1; q < 4; ++q) if (c->chtabs[q].used < c->chtabs[cs].used) cs = q; }      // (least recently used)
+        vil_ctx::ChTab& ct = c->chtabs[cs];
+        ct.used = ++c->chtab_clock; c->chtab_cur = cs;
+        if (!ct_hit) {
             const int NPs = vd::chain_slab_nps(K), pn = P.pn;
             const int o_dg = 0, o_sub = vd::even_up(45 * K), o_pbc = o_sub + vd::even_up(81 * K), o_pp = o_pbc + 162 * K, o_rhs = o_pp + CHAIN_NPC_MAX * NPs;
             std::vector<int> tab, pq(9 * K, -1);
@@ -1050,22 +1064,23 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             tab.insert(tab.end(), pq.begin(), pq.end());       // behind the table: the chain column -> prior column map
             while (tab.size() & 3) tab.push_back(0);
             const size_t bytes = 4 * tab.size();
-            if (c->chtab_ev_pending) { HIPCHK(hipEventSynchronize(c->chtab_ev)); c->chtab_ev_pending = false; }      // the previous table's DMA has left the pinned copy
-            if (bytes > c->chtab_cap) {
-                HIPCHK(hipStreamSynchronize(c->stream));
-                if (c->d_chtab) hipFree(c->d_chtab); if (c->h_chtab) hipHostFree(c->h_chtab);
-                c->d_chtab = nullptr; c->h_chtab = nullptr; c->chtab_cap = 0;
-                HIPCHK(hipMalloc((void**)&c->d_chtab, 2 * bytes)); HIPCHK(hipHostMalloc((void**)&c->h_chtab, 2 * bytes, hipHostMallocDefault));
-                c->chtab_cap = 2 * bytes;
+            if (ct.ev_pending) { HIPCHK(hipEventSynchronize(ct.ev)); ct.ev_pending = false; }      // the previous table's DMA has left the pinned copy
+            if (bytes > ct.cap) {
+                HIPCHK(hipStreamSynchronize(c->stream));      // (nobody reads the old one)
+                if (ct.d) hipFree(ct.d); if (ct.h) hipHostFree(ct.h);
+                ct.d = nullptr; ct.h = nullptr; ct.cap = 0;
+                HIPCHK(hipMalloc((void**)&ct.d, 2 * bytes)); HIPCHK(hipHostMalloc((void**)&ct.h, 2 * bytes, hipHostMallocDefault));
+                ct.cap = 2 * bytes;
             }
-            memcpy(c->h_chtab, tab.data(), bytes);
-            HIPCHK(hipMemcpyAsync(c->d_chtab, c->h_chtab, bytes, hipMemcpyHostToDevice, c->stream));
-            if (!c->chtab_ev) HIPCHK(hipEventCreateWithFlags(&c->chtab_ev, hipEventDisableTiming));
-            HIPCHK(hipEventRecord(c->chtab_ev, c->stream)); c->chtab_ev_pending = true;
-            c->chtab_n = ((int)tab.size() - ((9 * K + 3) & ~3)) / 4; c->chtab_key.swap(key);
+            memcpy(ct.h, tab.data(), bytes);
+            HIPCHK(hipMemcpyAsync(ct.d, ct.h, bytes, hipMemcpyHostToDevice, c->stream));
+            if (!ct.ev) HIPCHK(hipEventCreateWithFlags(&ct.ev, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(ct.ev, c->stream)); ct.ev_pending = true;
+            ct.n = ((int)tab.size() - ((9 * K + 3) & ~3)) / 4; ct.key.swap(key);
+            UPTICK("chtab-new");
         }
-        P.n_chtab = c->chtab_n;
-        if (c->chtab_n > VIL_CHC_MAX) pre_ok = false;
+        P.n_chtab = ct.n;
+        if (ct.n > VIL_CHC_MAX) pre_ok = false;
     }
     if (const char* ev = VIL_TUNE_ENV("VIL_SKIP")) P.skip_mask = atoi(ev);
     // helper workgroups of the step kernel: worth it once every master thread would own more than one landmark
@@ -1086,7 +1101,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     for (const Fix& f : fix) *f.slot = ar.d + (f.scratch ? tables : 0) + f.off;
     if (dl) { P.pl_c = dl->plane_soa; P.pl_stride = dl->plane_stride; P.ed_c = dl->edge_soa; P.ed_stride = dl->edge_stride; }
     if (!gp) { P.glm_start = P.lm_start; P.glm_acol = P.lm_acol; P.gfcol = P.fcol; }
-    if (pre_ok) { P.chtab = c->d_chtab; P.chpq = c->d_chtab + 4 * (size_t)c->chtab_n; }
+    if (pre_ok) { const vil_ctx::ChTab& ct = c->chtabs[c->chtab_cur]; P.chtab = ct.d; P.chpq = ct.d + 4 * (size_t)ct.n; }
     if (c->lidar_resident) { P.pl_c = c->d_pl; P.pl_stride = c->nslot * c->cap_p; P.ed_c = c->d_ed; P.ed_stride = c->nslot * c->cap_e; }
     if (ws && P.pn) { P.px0 = ws->px0; P.pJ0 = ws->pJ0; P.pr0 = ws->pr0; P.pH = ws->pH; P.pg0 = ws->pg0; P.pc0 = ws->pc0; }      // the device prior slot, contractions included
     {   // what vil_marginalize_resident will need (a few passes over int tables)
