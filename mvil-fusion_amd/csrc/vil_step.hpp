@@ -129,9 +129,9 @@ __device__ __forceinline__ void lm_rows(const DevP& P, const SysBuf& sb, int l, 
 // pass -- with one lane per landmark everything past the third observer was a dependent round trip to memory inside the pass the master waits for (configs[1]:
 // a third of the landmarks have four to nine observers, so every helper paid two of them).
 template <bool AG = false>
-__device__ __forceinline__ void lm_rows_quad(const DevP& P, const SysBuf& sb, int l, int qd, LmRows& r) {
+__device__ __forceinline__ void lm_rows_quad(const DevP& P, const SysBuf& sb, int l, int qd, LmRows& r, const int G = 4 /* lanes that share the landmark: 4 (a quad) or 2 (a pair: six observers in registers) */) {
     const int fs0 = P.glm_start[l], fe = P.glm_start[l + 1];
-    r.ac = qd == 0 ? P.glm_acol[l] : 0; r.stride = 12;
+    r.ac = qd == 0 ? P.glm_acol[l] : 0; r.stride = 3 * G;
     r.fs = min(fs0 + 3 * qd, fe); r.fe = fe;
     if (fe == fs0) { r.fs = fe; return; }                  // (no observer: the landmark takes no part, anchor row included -- as lm_rows)
     const double* e = sb.eA + (size_t)l * 13;
@@ -146,6 +146,7 @@ __device__ __forceinline__ void lm_rows_quad(const DevP& P, const SysBuf& sb, in
     r.m1 = (fs0 + 3 * qd + 1 < fe) ? 1.0 : 0.0; r.m2 = (fs0 + 3 * qd + 2 < fe) ? 1.0 : 0.0;
 }
 __device__ __forceinline__ double quad_total(double v) { v = dpp_add<0xB1, 0xf>(v); return dpp_add<0x4E, 0xf>(v); }      // quad_perm [1,0,3,2], [2,3,0,1]: the same bits in the four lanes
+__device__ __forceinline__ double pair_total(double v) { return dpp_add<0xB1, 0xf>(v); }      // quad_perm [1,0,3,2]: lanes 2 m and 2 m + 1
 template <bool AG = false>
 __device__ __forceinline__ double lm_dot_rows(const DevP& P, const SysBuf& sb, const LmRows& r, const double* vc) {
     if (r.fe == r.fs) return 0.0;
@@ -1641,14 +1642,15 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
                 // (which the master waits for) reads only Sc x_p
                 // (a QUAD per landmark while the helper has four threads for each -- lm_rows_quad: up to twelve observers in registers; the quad's lanes hold the same
                 //  scalars, its lane 0 owns the landmark's sums and stores)
-                const bool quad = 4 * per <= NT;
-                const int qd = quad ? (t & 3) : 0;
-                const int l = l0 + (quad ? (t >> 2) : t);
+                const bool quad = 2 * per <= NT;                  // (lanes per landmark: four while the helper has them, else two, else one)
+                const int G = 4 * per <= NT ? 4 : (quad ? 2 : 1);
+                const int qd = t & (G - 1);
+                const int l = l0 + (G == 4 ? (t >> 2) : G == 2 ? (t >> 1) : t);
                 const bool have = l < l1, lead = have && qd == 0;
                 LmRows r; r.fs = 0; r.fe = 0;
                 double ip = 0, b = 0, d = 1, g = 0, lam2 = 0, ipS = 0, Sd = 0, a_ = 0, h_ = 0;      // ipS = invp / Sl, Sd = Sl / dl, a_ = la
                 if (have) {
-                    if (quad) lm_rows_quad<FUSED>(P, sb, l, qd, r); else lm_rows<FUSED>(P, sb, l, r);
+                    if (quad) lm_rows_quad<FUSED>(P, sb, l, qd, r, G); else lm_rows<FUSED>(P, sb, l, r);
                     ip = ldx<FUSED>(sb.invp + l); b = ldx<FUSED>(sb.bl + l);
                     const double Sl = ldx<FUSED>(sb.sl + l), h = ldx<FUSED>(sb.hll + l);
                     h_ = h;
@@ -1660,7 +1662,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
                 }
                 {
                     double ev = (have && ip != 0.0) ? lm_dot_rows<FUSED>(P, sb, r, s.y) : 0.0;
-                    if (quad) ev = quad_total(ev);
+                    if (G == 4) ev = quad_total(ev); else if (G == 2) ev = pair_total(ev);
                     if (lead && ip != 0.0) {
                         q += ip * ev * ev + 2.0 * a_ * ev + h_ * a_ * a_;
                         g2 += g * g; gm = fmax(gm, fabs(b));
@@ -1674,7 +1676,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
                     double sm[6] = {0, 0, 0, 0, 0, 0};
                     double b_ = 0.0;
                     double ev2 = (have && ip != 0.0) ? lm_dot_rows<FUSED>(P, sb, r, s.gn) : 0.0;
-                    if (quad) ev2 = quad_total(ev2);
+                    if (G == 4) ev2 = quad_total(ev2); else if (G == 2) ev2 = pair_total(ev2);
                     if (lead) {
                         if (ip != 0.0) {
                             const double xl = (b - ev2) * ipS;

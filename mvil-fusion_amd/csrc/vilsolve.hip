@@ -1084,7 +1084,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     }
     if (const char* ev = VIL_TUNE_ENV("VIL_SKIP")) P.skip_mask = atoi(ev);
     // helper workgroups of the step kernel: worth it once every master thread would own more than one landmark
-    P.n_help = L > 7 * VIL_STEP_THREADS ? 15 : (L > 15 * (VIL_STEP_THREADS / 4) ? 7 : (L >= VIL_STEP_THREADS ? std::min(15, (L + VIL_STEP_THREADS / 4 - 1) / (VIL_STEP_THREADS / 4)) : 0));      // (up to 1920 landmarks: a QUAD of threads per landmark -- vil_step.hpp, lm_rows_quad -- i.e. 128 landmarks per helper)      // (a helper keeps ITS landmarks' rows in registers between its two passes as long as it has a thread per landmark: configs[2]'s 4000 landmarks on 7 helpers fell off that path)
+    P.n_help = L > 7 * VIL_STEP_THREADS ? 15 : (L > 15 * (VIL_STEP_THREADS / 2) ? 7 : (L > 15 * (VIL_STEP_THREADS / 4) ? std::min(15, (L + VIL_STEP_THREADS / 2 - 1) / (VIL_STEP_THREADS / 2)) : (L >= VIL_STEP_THREADS ? std::min(15, (L + VIL_STEP_THREADS / 4 - 1) / (VIL_STEP_THREADS / 4)) : 0)));      // (up to 1920 landmarks: a QUAD of threads per landmark -- vil_step.hpp, lm_rows_quad -- i.e. 128 landmarks per helper; up to 3840: a pair, 256 per helper)      // (a helper keeps ITS landmarks' rows in registers between its two passes as long as it has a thread per landmark: configs[2]'s 4000 landmarks on 7 helpers fell off that path)
     if (const char* ev = VIL_TUNE_ENV("VIL_HELP")) P.n_help = std::max(0, std::min(15, atoi(ev)));
     // master and helpers wait for one another inside the launch: all of them must be resident at once (vil_coop.hpp).  With its
     // dynamic LDS a step workgroup owns a compute unit; a device with fewer units than 1 + n_help runs without helpers.
