@@ -293,6 +293,11 @@ int vil_debug_set_split(vil_ctx* ctx, int32_t on);
  * eliminated by a workgroup of the SWEEP launch; 2: no chain workgroup at all (the step kernel eliminates the chain itself, the round-2 structure).
  * Same results to rounding in every mode.  Invalidates the resident window. */
 int vil_debug_set_launch_mode(vil_ctx* ctx, int32_t mode);
+/* profiling (with vil_profile_enable(ctx, 1), one-launch iterations): times == NULL arms it -- from now on every workgroup of launch `launch` (0-based) of a solve
+ * leaves its entry and exit time (100 MHz device clock) --; with times != NULL the pairs {entry, exit} of the first max_workgroups (<= 4096) workgroups of the last
+ * recorded launch are copied out, in block-index order = the launch's grid order [imu | prior | rel][chain][visual | plane | edge][master | helpers | tiles][gather]
+ * (zeros: a workgroup that did not run).  tools/probe_workgroups.py prints them by role. */
+int vil_profile_workgroups(vil_ctx* ctx, int32_t launch, uint64_t* times, int32_t max_workgroups);
 /* test hook: the step's dense solve on a matrix of the caller's -- A is (D + 1) x (D + 1) row major, its lower triangle the SPD matrix, its last row the right-hand
  * side (D <= 159).  L receives the Cholesky factor (lower, row major, last row = L^-1 rhs), x the solution, *ok 0 when a pivot was not positive.  variant 1: what the
  * one-launch iteration runs (16-wide panels factored a matrix row per lane, back substitution a column per lane: vil_step.hpp chol_rowwave / back_subst_cols);

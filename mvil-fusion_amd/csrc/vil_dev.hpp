@@ -106,6 +106,7 @@ struct DevP {
     double* ipart;                // n_imu x 931  [30x30 H | 30 g | cost]
     double* chc;                  // the prior's constant share (J0^T J0 entries) of the chain workgroup's gather, in table order: written by the first iteration of a solve, read by the later ones
     const int* imu_perm;          // the order an IMU role of a one-launch iteration forms its 931 record entries in: the VIL_CHAIN_REC the chain workgroup gathers first (in the compact record's order)
+    int wg_launch;                // profiling: the launch (0-based, of the solve) whose workgroups leave their entry / exit times behind the phase stamps in P.prof (vil_profile_workgroups); -1: none
     int* sall;                    // one-launch iteration: [16] / [32] = launch epoch once every non-visual / visual sweep role has posted -- published by the master workgroup, which polls the roles' flags ONCE for all gather workgroups
     int* cflag;                   // n_imu: an IMU role's compact record is complete (launch epoch; P.sflag[role] follows when the whole record is)
     double* irec;                 // n_imu x VIL_CHAIN_REC: one-launch iteration -- the part of the IMU records the chain workgroup gathers, compact (chain_rec_index)
@@ -160,6 +161,7 @@ struct DevP {
 // Phase stamps of a one-launch iteration (vil_profile_phases): slot k of launch `launch` keeps the LATEST (or, want_min, the EARLIEST: stored inverted) wall-clock
 // reading any workgroup posted for it -- s_memrealtime, the 100 MHz counter every XCD shares; one atomic per workgroup and slot, nothing when P.prof is null
 #define VIL_PROF_SLOTS 24
+#define VIL_PROF_WGS 4096      // workgroups of one launch whose entry / exit times fit behind the phase stamps (vil_profile_workgroups)
 #if defined(__HIPCC__)
 __device__ __forceinline__ void prof_stamp(const DevP& P, int launch, int k, bool want_min = false) {
     if (P.prof) { const unsigned long long t = wall_clock64(); atomicMax((unsigned long long*)P.prof + VIL_PROF_SLOTS * (launch & 63) + k, want_min ? ~t : t); }

@@ -28,6 +28,15 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_iter(DevP P, SolveOpts O) 
     // roles on 256 compute units: its records were seen at 20 us instead of 10).  Master, helpers and tiles stay BEHIND the sweep roles: 24 - 45 waiting workgroups
     // ahead of them cost the visual roles a second dispatch round at K = 20 (sweep phase 26 -> 35 us, measured); ahead of the gather workgroups their prologues
     // still run under the sweep.  sweep role index (= its flag in P.sflag): the order of k_sweep
+    // profiling (vil_profile_workgroups): every workgroup of ONE chosen launch leaves its entry and exit time -- when a role is dispatched and how long it stays is
+    // what the phase stamps cannot say (it found the gather workgroups of K = 20 queueing in three rounds behind the launch's LDS footprint)
+    const unsigned long long wg_t_in = P.prof ? wall_clock64() : 0ull;
+    auto wg_times = [&](const int launch) {
+        if (P.prof && launch == P.wg_launch && threadIdx.x == 0 && blockIdx.x < VIL_PROF_WGS) {
+            unsigned long long* d = (unsigned long long*)P.prof + 64 * VIL_PROF_SLOTS + 2 * blockIdx.x;
+            d[0] = wg_t_in; d[1] = wall_clock64();
+        }
+    };
     const int b = (int)blockIdx.x, n_early = P.n_imu + 2, n_wait = 1 + P.n_help + P.n_ww;
     int sw = -1, p0 = -1;
     if (b < n_early) sw = b;
@@ -39,10 +48,12 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_iter(DevP P, SolveOpts O) 
         const Ctl ctl = *P.ctl;
         if (ctl.done) return;
         sweep_body<TS, true>(P, O, ctl, dyn, sw);
+        wg_times(ctl.n_sweeps);
         return;
     }
     vd::StepShared& s = *reinterpret_cast<vd::StepShared*>(dyn);
     step_body<true, 3, true>(P, O, s, dyn + VIL_SS_DOUBLES, p0);
+    wg_times(s.c.n_sweeps - 1);      // (the step roles have counted this launch already)
     // The first launch that finds the solve FINISHED writes the result out (accepted state -> x[0], gauge fix, Ctl + state into the host mirror, the sequence word the
     // host polls): its master workgroup, which has nothing else to do -- every role returned at once.  A chunk of enqueued iterations may then be sized generously:
     // the host is released behind the first dead launch (~5 us), not behind the chunk's no-op tail and k_finish (which still covers a solve that ends in the last

@@ -339,6 +339,7 @@ struct vil_ctx {
         size_t prior_doubles() const { return 2 * (size_t)nmax * nmax + 2 * (size_t)nmax + x0max + 8; }
     } win;
     bool profiling = false;
+    int wg_launch = -1;      // (vil_profile_workgroups)
     long long* d_prof = nullptr; double phase_us[VIL_PROF_SLOTS] = {0}; long long phase_n = 0;      // phase stamps of the one-launch iterations (vil_profile_phases)
     std::vector<hipEvent_t> ev, ev_mid, ev_coll;
     vil_profile prof = {0, 0.0, 0, 0.0, 0.0};
@@ -1492,7 +1493,7 @@ static int launch_sweep(vil_ctx* c, const SolveOpts& so) {
 static int launch_iter(vil_ctx* c, const SolveOpts& so) {
     DevP Pi = c->P;
     Pi.gather_pose_only = 1;
-    Pi.prof = c->profiling ? c->d_prof : nullptr;
+    Pi.prof = c->profiling ? c->d_prof : nullptr; Pi.wg_launch = c->profiling ? c->wg_launch : -1;
     const dim3 g(c->n_blocks_sweep + 1 + c->n_gather_m + 1 + c->P.n_help + c->n_ww), b(VIL_STEP_THREADS);      // [sweep roles | chain | master | helpers | W W^T tiles | gather]
     if (c->P.vis_ts == 2) hipLaunchKernelGGL(k_iter<2>, g, b, c->lds_iter, c->stream, Pi, so);
     else hipLaunchKernelGGL(k_iter<5>, g, b, c->lds_iter, c->stream, Pi, so);
@@ -1553,7 +1554,7 @@ int vil_profile_enable(vil_ctx* c, int on) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(c->device));
     if (on && c->ev.empty()) { c->ev.resize(40); for (auto& e : c->ev) HIPCHK(hipEventCreate(&e)); c->ev_mid.resize(20); for (auto& e : c->ev_mid) HIPCHK(hipEventCreate(&e)); c->ev_coll.resize(20); for (auto& e : c->ev_coll) HIPCHK(hipEventCreate(&e)); }
-    if (on && !c->d_prof) HIPCHK(hipMalloc((void**)&c->d_prof, 8 * 64 * VIL_PROF_SLOTS));
+    if (on && !c->d_prof) { HIPCHK(hipMalloc((void**)&c->d_prof, 8 * (64 * VIL_PROF_SLOTS + 2 * VIL_PROF_WGS))); HIPCHK(hipMemset(c->d_prof, 0, 8 * (64 * VIL_PROF_SLOTS + 2 * VIL_PROF_WGS))); }
     c->profiling = on != 0;
     return VIL_OK;
 }
@@ -2193,6 +2194,19 @@ int vil_debug_dense_solve(vil_ctx* c, int32_t D, const double* A, double* L, dou
     HIPCHK(hipMemcpy(L, dL, nb, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(x, dx, 8 * (size_t)D, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hok, dok, 4, hipMemcpyDeviceToHost));
     *ok = hok;
     hipFree(dA); hipFree(dL); hipFree(dx); hipFree(dok);
+    return VIL_OK;
+}
+int vil_profile_workgroups(vil_ctx* c, int32_t launch, uint64_t* times, int32_t max_workgroups) {
+    if (!c) return VIL_ERR_INVALID_ARGUMENT;
+    if (!times) {                                         // arm: the solves from now on record launch `launch` (< 0: none)
+        c->wg_launch = launch;
+        if (c->d_prof) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipMemset((char*)c->d_prof + 8 * 64 * VIL_PROF_SLOTS, 0, 8 * 2 * VIL_PROF_WGS)); }
+        return VIL_OK;
+    }
+    if (!c->d_prof || max_workgroups < 0) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int n = std::min<int>(max_workgroups, VIL_PROF_WGS);
+    HIPCHK(hipMemcpy(times, (char*)c->d_prof + 8 * 64 * VIL_PROF_SLOTS, 8 * 2 * (size_t)n, hipMemcpyDeviceToHost));
     return VIL_OK;
 }
 int vil_debug_set_slim_emul(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INVALID_ARGUMENT; c->slim_emul = on != 0; return VIL_OK; }
