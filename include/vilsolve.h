@@ -293,6 +293,9 @@ int vil_debug_set_split(vil_ctx* ctx, int32_t on);
  * eliminated by a workgroup of the SWEEP launch; 2: no chain workgroup at all (the step kernel eliminates the chain itself, the round-2 structure).
  * Same results to rounding in every mode.  Invalidates the resident window. */
 int vil_debug_set_launch_mode(vil_ctx* ctx, int32_t mode);
+/* test hook: the next n hipGraph captures of this context's solves are treated as failed (as a driver that cannot capture or instantiate the chunk would make them).
+ * A failed capture is not an error: nothing has run yet, the solve at hand and every later solve of the context launch directly.  n = 0 re-arms graph replay. */
+int vil_debug_fail_graph_capture(vil_ctx* ctx, int32_t n);
 /* profiling (with vil_profile_enable(ctx, 1), one-launch iterations): times == NULL arms it -- from now on every workgroup of launch `launch` (0-based) of a solve
  * leaves its entry and exit time (100 MHz device clock) --; with times != NULL the pairs {entry, exit} of the first max_workgroups (<= 4096) workgroups of the last
  * recorded launch are copied out, in block-index order = the launch's grid order [imu | prior | rel][chain][visual | plane | edge][master | helpers | tiles][gather]

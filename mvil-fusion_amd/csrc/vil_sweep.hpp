@@ -48,6 +48,11 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
     double* out = P.ipart + (size_t)f * 931;
     const int t = threadIdx.x;
     const int i = P.imu_i[f], j = P.imu_j[f];
+    // (one-launch iteration: the order in which the record's entries are formed, P.imu_perm, is asked for HERE -- behind the whitening's barrier it was a dependent
+    //  round trip to memory on the path the chain workgroup waits for)
+    const bool perm_order = chain_rec && blockDim.x >= 512;
+    int eA = 0, eB = 0;
+    if (perm_order) { eA = P.imu_perm[t]; eB = P.imu_perm[min(t + 512, 930)]; }
     // everything the role reads from memory in ONE round trip, by different threads: constants, sqrt-information and the four state blocks go to LDS (before: sum_dt, then
     // the constants of every lane, then U inside the whitening loop -- three dependent round trips on the path the chain workgroup waits for)
     {
@@ -121,11 +126,10 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
         else { for (int k = 0; k < 15; ++k) s += Ur[k] * Ur[k]; s *= 0.5; }
         return s;
     };
-    if (chain_rec && blockDim.x >= 512) {
+    if (perm_order) {
         // one-launch iteration: the 405 entries the chain workgroup gathers are formed and stored FIRST (P.imu_perm: they lead the order), and the role's chain flag
         // goes up behind THEIR stores -- the other 526 entries are formed while those stores travel and leave afterwards (the gather workgroups wait for the
         // role's ordinary flag, and have slack: DESIGN.md 0d).  The chain leg of the iteration starts ~0.8 us earlier.
-        const int eA = P.imu_perm[t], eB = P.imu_perm[min(t + 512, 930)];
         const double sA = entry(eA);
         st_ag(out + eA, sA);
         if (t < VIL_CHAIN_REC) st_ag(outc + t, sA);

@@ -290,7 +290,8 @@ struct vil_ctx {
     // (a few tables by key: a tracker alternates between the prior structures of its two marginalisation kinds, and a rebuild -- entries, sort, copy -- is ~80 us of host time)
     struct ChTab { std::vector<int> key; int* d = nullptr; int* h = nullptr; size_t cap = 0; int n = 0; hipEvent_t ev = nullptr; bool ev_pending = false; unsigned long long used = 0; };
     ChTab chtabs[4]; int chtab_cur = 0; unsigned long long chtab_clock = 0;      // gather table of the chain workgroup (vil_prechain.hpp)
-    bool graph_failed = false;     // a chunk with a collective could not be captured: direct launches from then on
+    bool graph_failed = false;     // a chunk could not be captured / instantiated: direct launches from then on
+    int fail_capture = 0;          // vil_debug_fail_graph_capture: that many captures are treated as failed
     int solve_gen = 0;             // generation counter of the helper-workgroup flags (Ctl::gen)
     int solves_since_upload = 0;
     bool split = false;            // sweep + gather fill set 0, the collective sums it into set 1, the step kernel reads set 1
@@ -1645,12 +1646,14 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
                 for (int q = 0; q < nthis && cst == VIL_OK; ++q) { if (c->fused) cst = launch_iter(c, so); else { launch_sweep(c, so); cst = launch_reduce_step(c, so, true, nullptr); } }
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(VIL_SWEEP_THREADS), 0, c->stream, view(c, 0), -1);
                 const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
-                if (cst != VIL_OK || ce != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-                    // a collective that cannot be captured (the RCCL build at hand decides): this context launches directly from now on.  Nothing has run yet
+                const bool forced = c->fail_capture > 0;
+                if (forced) --c->fail_capture;
+                if (cst != VIL_OK || ce != hipSuccess || forced || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+                    // a chunk that cannot be captured or instantiated (a collective the RCCL build at hand does not capture, a driver out of graph memory): nothing has
+                    // run yet, so THIS solve and every later one of the context take the direct launches right below -- the caller (optimization()) has no retry
                     (void)hipGetLastError();
                     if (graph) hipGraphDestroy(graph);
                     exec = nullptr; c->graph_failed = true;
-                    if (!c->split) return VIL_ERR_DEVICE;
                 } else {
                     hipGraphDestroy(graph);
                     c->graphs.push_back({nthis, so, exec});
@@ -2168,6 +2171,7 @@ int vil_comm_message_bytes(vil_ctx* c, int64_t* bytes_per_peer, int64_t* bytes_f
 }
 
 // ---- window residency across frames (include/vilsolve.h) ------------------------------------------------------------------------
+int vil_debug_fail_graph_capture(vil_ctx* c, int32_t n) { if (!c || n < 0) return VIL_ERR_INVALID_ARGUMENT; c->fail_capture = n; c->graph_failed = false; return VIL_OK; }
 int vil_debug_set_launch_mode(vil_ctx* c, int32_t mode) { if (!c || mode < 0 || mode > 3) return VIL_ERR_INVALID_ARGUMENT; c->launch_mode = mode; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
 int vil_comm_info(vil_ctx* c, int32_t* rank, int32_t* world, int32_t* transport) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;

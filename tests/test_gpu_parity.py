@@ -116,6 +116,27 @@ def test_solve_leaves_state_unchanged_on_error(hip):
         assert np.array_equal(before[k], after[k], equal_nan=True)
 
 
+def test_failed_graph_capture_falls_back_to_direct_launches(hip):
+    """Re-solves of one upload replay a captured hipGraph of the chunk.  A capture / instantiation that fails is NOT an error of the solve: nothing has run yet,
+    the solve at hand and the later ones launch directly (vil_debug_fail_graph_capture stands in for the driver), with the results of the replayed graph."""
+    w = synth.make_config(2, L=150, n_plane=3000, n_edge=800)
+    hip.upload(w)
+    ref = []
+    for _ in range(3):                                   # direct launches (first solve of the upload), then capture + replay
+        hip.reset_state(); s = hip.solve_resident(); ref.append((s.iterations, s.termination, float(s.final_cost).hex()))
+    assert len(set(ref)) == 1
+    hip.upload(w)
+    hip.reset_state(); hip.solve_resident()
+    assert hip.lib.vil_debug_fail_graph_capture(hip.ctx, 1) == 0
+    for _ in range(3):                                   # the capture fails: this solve and the next ones are direct launches, and succeed
+        hip.reset_state(); s = hip.solve_resident()
+        assert (s.iterations, s.termination, float(s.final_cost).hex()) == ref[0]
+    assert hip.lib.vil_debug_fail_graph_capture(hip.ctx, 0) == 0      # re-armed: capture + replay again
+    hip.reset_state(); s = hip.solve_resident()
+    assert (s.iterations, s.termination, float(s.final_cost).hex()) == ref[0]
+    assert hip.lib.vil_debug_fail_graph_capture(hip.ctx, -1) != 0
+
+
 def test_resident_solve_repeatable(hip):
     w = synth.make_config(2, L=150, n_plane=3000, n_edge=800)
     hip.upload(w)
