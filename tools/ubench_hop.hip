@@ -5,17 +5,22 @@
 //   hipcc -O3 --offload-arch=gfx950 -o /tmp/ubench_hop tools/ubench_hop.hip && /tmp/ubench_hop
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 __device__ __forceinline__ unsigned long long wall() { unsigned long long t; asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
 template <int V> __device__ __forceinline__ int ld(const int* p) {
     int v;
     if (V == 0) asm volatile("global_load_dword %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     else if (V == 1) asm volatile("buffer_inv sc0\n global_load_dword %0, %1, off sc0\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    else asm volatile("global_load_dword %0, %1, off sc0\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    else if (V == 2) asm volatile("global_load_dword %0, %1, off sc0\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    else if (V == 3) asm volatile("buffer_inv sc1\n global_load_dword %0, %1, off sc0\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    else if (V == 5) asm volatile("global_load_dword %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    else asm volatile("global_atomic_or %0, %1, %2, off sc0\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p), "v"(0) : "memory");      // V == 4: a returning read-modify-write (performed where atomics are performed)
     return v;
 }
 template <int V> __device__ __forceinline__ void st(int* p, int v) {
-    if (V == 0) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+    if (V == 0 || V == 5) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+    else if (V == 4) asm volatile("global_atomic_swap %0, %1, off" :: "v"(p), "v"(v) : "memory");
     else asm volatile("global_store_dword %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
 }
 template <int V> __device__ __forceinline__ bool wait_eq(const int* p, int v, int* ab) {
@@ -34,13 +39,13 @@ template <int V> __global__ __launch_bounds__(64) void k_hop(int* flags, double*
     bool ok = true;
     for (int r = 1; r <= rounds && ok; ++r) {
         if (blk == a) {
-            for (int q = 0; q < nd; ++q) { const double v = r + q; if (V == 0) asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(data + q * 64 + t), "v"(v) : "memory"); else asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(data + q * 64 + t), "v"(v) : "memory"); }
+            for (int q = 0; q < nd; ++q) { const double v = r + q; if (V == 0) asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(data + q * 64 + t), "v"(v) : "memory"); else if (V == 5) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(data + q * 64 + t), "v"(v) : "memory"); else asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(data + q * 64 + t), "v"(v) : "memory"); }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (t == 0) st<V>(fa, r);
             ok = wait_eq<V>(fb, r, ab);
         } else {
             ok = wait_eq<V>(fa, r, ab);
-            for (int q = 0; q < nd; ++q) { double v; if (V == 0) asm volatile("global_load_dwordx2 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(data + q * 64 + t) : "memory"); else asm volatile("global_load_dwordx2 %0, %1, off sc0\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(data + q * 64 + t) : "memory"); acc += v - (r + q); }
+            for (int q = 0; q < nd; ++q) { double v; if (V == 0 || V == 5) asm volatile("global_load_dwordx2 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(data + q * 64 + t) : "memory"); else asm volatile("global_load_dwordx2 %0, %1, off sc0\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(data + q * 64 + t) : "memory"); acc += v - (r + q); }
             if (t == 0) st<V>(fb, r);
         }
     }
@@ -48,20 +53,25 @@ template <int V> __global__ __launch_bounds__(64) void k_hop(int* flags, double*
     if (t == 0 && blk == a) { out[0] = ok ? (long long)(t1 - t0) : -1; }
     if (blk == b && acc != 0.0 && t == 0) out[1] = 1;      // stale payload seen
 }
-int main() {
+int main(int argc, char** argv) {
+    // argv[1]: offset (kB) of the flags / payload inside a 64 MB buffer -- where the lines' home channel lies relative to the XCDs differs with the address
     int* flags; double* data; long long* out; int* xcc; int* ab;
-    hipMalloc(&flags, 4096); hipMalloc(&data, 8 * 64 * 64); hipMalloc(&out, 64); hipMalloc(&xcc, 4 * 256); hipMalloc(&ab, 4);
+    const size_t off = argc > 1 ? (size_t)atol(argv[1]) * 1024 : 0;
+    char* big; hipMalloc(&big, 64u << 20); flags = (int*)(big + off); data = (double*)(big + off + 4096); printf("offset %zu kB\n", off >> 10); hipMalloc(&out, 64); hipMalloc(&xcc, 4 * 256); hipMalloc(&ab, 4);
     const int rounds = 400;
     std::vector<int> hx(256);
     const int pairs[4][2] = {{0, 8}, {0, 1}, {0, 4}, {8, 16}};
-    for (int nd : {0, 4}) for (int v = 0; v < 3; ++v) for (auto& pr : pairs) {
+    for (int nd : {0, 4}) for (int v : {0, 3, 5}) for (auto& pr : pairs) {
         hipMemset(flags, 0, 4096); hipMemset(out, 0, 64); hipMemset(ab, 0, 4); hipMemset(data, 0, 8 * 64 * 64);
         if (v == 0) hipLaunchKernelGGL(k_hop<0>, dim3(64), dim3(64), 0, 0, flags, data, pr[0], pr[1], rounds, nd, out, xcc, ab);
         if (v == 1) hipLaunchKernelGGL(k_hop<1>, dim3(64), dim3(64), 0, 0, flags, data, pr[0], pr[1], rounds, nd, out, xcc, ab);
+        if (v == 3) hipLaunchKernelGGL(k_hop<3>, dim3(64), dim3(64), 0, 0, flags, data, pr[0], pr[1], rounds, nd, out, xcc, ab);
+        if (v == 5) hipLaunchKernelGGL(k_hop<5>, dim3(64), dim3(64), 0, 0, flags, data, pr[0], pr[1], rounds, nd, out, xcc, ab);
+        if (v == 4) hipLaunchKernelGGL(k_hop<4>, dim3(64), dim3(64), 0, 0, flags, data, pr[0], pr[1], rounds, nd, out, xcc, ab);
         if (v == 2) hipLaunchKernelGGL(k_hop<2>, dim3(64), dim3(64), 0, 0, flags, data, pr[0], pr[1], rounds, nd, out, xcc, ab);
         if (hipDeviceSynchronize() != hipSuccess) { printf("device error\n"); return 1; }
         long long ho[2]; hipMemcpy(ho, out, 16, hipMemcpyDeviceToHost); hipMemcpy(hx.data(), xcc, 4 * 64, hipMemcpyDeviceToHost);
-        printf("payload %d doubles/lane  variant %d (%s)  blocks (%d, %d) on XCDs (%d, %d): %s", nd, v, v == 0 ? "agent scope sc1" : (v == 1 ? "sc0 + buffer_inv sc0 per poll" : "sc0, no invalidate"),
+        printf("payload %d doubles/lane  variant %d (%s)  blocks (%d, %d) on XCDs (%d, %d): %s", nd, v, v == 0 ? "agent scope sc1" : (v == 1 ? "sc0 + buffer_inv sc0 per poll" : (v == 2 ? "sc0, no invalidate" : (v == 3 ? "sc0 + buffer_inv sc1 per poll" : (v == 5 ? "plain payload stores, sc1 flag and loads" : "flag by atomic or / swap, payload sc0")))),
                pr[0], pr[1], hx[pr[0]], hx[pr[1]], ho[0] < 0 ? "NOT coherent (gave up)" : "");
         if (ho[0] >= 0) printf("%.0f ns per round trip (two hand-offs)%s", 10.0 * ho[0] / rounds, ho[1] ? "  STALE PAYLOAD" : "");
         printf("\n");
