@@ -1738,6 +1738,36 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     }
     STAMP(1);
     double gn2 = 0, g2 = 0, gg = 0;
+    // The candidate x_cur (+) step for the FULL Gauss-Newton step (cg = 0, cn = 1: what the dogleg takes whenever the step fits the trust region -- every iteration after the
+    // first few) is formed SPECULATIVELY by wave 0 while the last wave collects the helpers' sums: the 2 K + 2 camera blocks are 2 K + 2 lanes of ONE wave, which forms the
+    // step entries of its own block itself (no step vector in LDS, no barrier) and whose wave total IS the block sum of the norms (the other waves contribute zeros).  When the
+    // dogleg then does take the full step, the ordinary path's step loop, barrier, pose_plus and block sum are skipped; (0 * gradient + 1 * gn) * rt has the value gn * rt.
+    bool spec = false;
+    double* const xcs_spec = Alds; double* const sums_spec = Alds + 336;      // (the factor's tiles: dead once the back substitutions are through)
+    auto cand_blocks = [&](auto&& stepf, double* xcs, double& xn, double& sn) {
+        const int K = P.K;
+        for (int k = t; k < 2 * K + 2; k += NT) {
+            if (k < K) {
+                const double* in = s.x0 + xo_pose(P, k); double* o = xcs + xo_pose(P, k);
+                if (s.cst[k]) { for (int q = 0; q < 7; ++q) o[q] = in[q]; }
+                else { double st[6]; for (int q = 0; q < 6; ++q) st[q] = stepf(col_pose(P, k) + q); pose_plus(in, st, o); for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
+            } else if (k < 2 * K) {
+                const int kk = k - K;
+                const double* in = s.x0 + xo_sb(P, kk); double* o = xcs + xo_sb(P, kk);
+                const bool cst = s.cst[K + kk] != 0;
+                for (int q = 0; q < 9; ++q) { const double d = cst ? 0.0 : stepf(col_sb(P, kk) + q); o[q] = in[q] + d; if (!cst) { xn += in[q] * in[q]; sn += d * d; } }
+            } else if (k == 2 * K) {
+                const double* in = s.x0 + xo_ex(P); double* o = xcs + xo_ex(P);
+                if (P.ex_const) { for (int q = 0; q < 7; ++q) o[q] = in[q]; }
+                else { double st[6]; for (int q = 0; q < 6; ++q) st[q] = stepf(col_ex(P) + q); pose_plus(in, st, o); for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
+            } else {
+                const double in = s.x0[xo_td(P)];
+                const double d = P.td_free ? stepf(col_td(P)) : 0.0;
+                xcs[xo_td(P)] = in + d;
+                if (P.td_free) { xn += in * in; sn += d * d; }
+            }
+        }
+    };
     if (s.need) {
         // ---- camera vectors: Jacobi scaling (first linearisation), dogleg diagonal, gradient_, u = Sc gradient_/d
         double gm = 0;
@@ -1873,6 +1903,15 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         __syncthreads();
         // chain path with helpers: the last wave collects the helpers' sums of both passes (-> s.hs) HERE -- the helpers received x_p before the chain back
         // substitution and answer ~5 us later, the master's chain walks take half of that: the step vectors above no longer wait for the answer
+        if (defer && LDSM && NT >= 128 && 2 * P.K + 2 <= 64) {
+            if (t < 64) {
+                double xs_ = 0, ss_ = 0;
+                cand_blocks([&](const int i) { return (0.0 * s.gr[i] + 1.0 * s.gn[i]) * s.rt[i]; }, xcs_spec, xs_, ss_);
+                xs_ = wave_total_l63(xs_); ss_ = wave_total_l63(ss_);
+                if (t == 63) { sums_spec[0] = xs_; sums_spec[1] = ss_; }
+            }
+            spec = true;      // (what wave 0 wrote is read behind the barriers of the block sums below)
+        }
         if (defer && t >= NT - 64) { double h[9]; gather2(h, true); if ((t & 63) == 63) for (int e = 0; e < 9; ++e) s.hs[e] = h[e]; }
         double sm[6] = {0, 0, 0, 0, 0, 0};
         if (!nhelp) lm_pass2(0, L, s.y, sm);
@@ -1937,36 +1976,17 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     const double gd = cg * g2 + cn * gg;
     const double model_change = -(0.5 * qd + gd);
     // ---------------- candidate state x_cur (+) step: camera blocks here, inverse depths in the next sweep ----------------------
-    for (int i = t; i < D; i += NT) s.y[i] = (cg * s.gr[i] + cn * s.gn[i]) * s.rt[i];
-    __syncthreads();
-    const double* stepc = s.y;
-    double* const xcs = s.gr;                        // the candidate's camera part is formed in LDS (gr | gn: 640 doubles, dead from here on -- P.gradc / P.gnc keep them) and leaves in one pass
+    double* xcs = s.gr;                              // the candidate's camera part is formed in LDS (gr | gn: 640 doubles, dead from here on -- P.gradc / P.gnc keep them) and leaves in one pass
     static_assert(offsetof(StepShared, gn) == offsetof(StepShared, gr) + 320 * sizeof(double), "the candidate spills from gr into gn");
     double xn = 0, sn = 0;
-    const int K = P.K;
-    for (int k = t; k < 2 * K + 2; k += NT) {
-        if (k < K) {
-            const double* in = s.x0 + xo_pose(P, k); double* o = xcs + xo_pose(P, k);
-            if (s.cst[k]) { for (int q = 0; q < 7; ++q) o[q] = in[q]; }
-            else { pose_plus(in, stepc + col_pose(P, k), o); if (cam) for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
-        } else if (k < 2 * K) {
-            const int kk = k - K;
-            const double* in = s.x0 + xo_sb(P, kk); double* o = xcs + xo_sb(P, kk);
-            const bool cst = s.cst[K + kk] != 0;
-            for (int q = 0; q < 9; ++q) { const double d = cst ? 0.0 : stepc[col_sb(P, kk) + q]; o[q] = in[q] + d; if (!cst && cam) { xn += in[q] * in[q]; sn += d * d; } }
-        } else if (k == 2 * K) {
-            const double* in = s.x0 + xo_ex(P); double* o = xcs + xo_ex(P);
-            if (P.ex_const) { for (int q = 0; q < 7; ++q) o[q] = in[q]; }
-            else { pose_plus(in, stepc + col_ex(P), o); if (cam) for (int q = 0; q < 7; ++q) { xn += in[q] * in[q]; sn += (in[q] - o[q]) * (in[q] - o[q]); } }
-        } else {
-            const double in = s.x0[xo_td(P)];
-            const double d = P.td_free ? stepc[col_td(P)] : 0.0;
-            xcs[xo_td(P)] = in + d;
-            if (P.td_free && cam) { xn += in * in; sn += d * d; }
-        }
+    if (spec && cg == 0.0 && cn == 1.0) { xcs = xcs_spec; xn = sums_spec[0]; sn = sums_spec[1]; }      // (uniform: every thread computed the same scalars)
+    else {
+        for (int i = t; i < D; i += NT) s.y[i] = (cg * s.gr[i] + cn * s.gn[i]) * s.rt[i];
+        __syncthreads();
+        cand_blocks([&](const int i) { return s.y[i]; }, xcs, xn, sn);
+        double dummy2 = 0;
+        bsum3(xn, sn, dummy2, s);
     }
-    double dummy2 = 0;
-    bsum3(xn, sn, dummy2, s);
     // landmark share of the norms from the sums of the pass
     xn += s.c.xnl; sn += cg * cg * s.c.saa + 2.0 * cg * cn * s.c.sab + cn * cn * s.c.sbb;
     STAMP(6);
