@@ -1500,9 +1500,10 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     auto wait_helpers = [&]() { if (!hseen && t < nhelp) wait1(P.hflag + t); if (!hseen && merged && P.prechain && t < P.n_ww) wait1(P.wwflag + t); hseen = true; };
     // wave 0: the end of the master's iteration on every path -- every helper (and tile workgroup) has read Ctl, then the new one goes out.  A wait of this launch
     // that gave up (vil_math.hpp: spin_until_eq) ends the solve here with a device error instead of letting numbers formed from incomplete data through
+    int abort_pre = -1;            // the abort word as thread 0 read it when the helpers' sums came in (below): the load's round trip runs under the dogleg's scalars instead of at the launch's very end
     auto end_iter = [&]() {
         wait_helpers();
-        if (t == 0 && P.abortf && ld_ag(P.abortf) != 0) { s.c.done = 1; s.c.term = 6; s.c.status = -2; }
+        if (t == 0 && P.abortf && (abort_pre >= 0 ? abort_pre : ld_ag(P.abortf)) != 0) { s.c.done = 1; s.c.term = 6; s.c.status = -2; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         store_ctl();
     };
@@ -1954,6 +1955,8 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     }
     STAMP(5);
     PROF(22);
+    // (every wait of the master is behind it here: a workgroup that gives up later than this is a helper waiting for the master, and the next launch's waits see its word)
+    if (t == 0 && P.abortf) abort_pre = ld_ag(P.abortf);
     // ---------------- traditional dogleg in dogleg space (scalars saved with the linearisation) ----------------
     gn2 = s.c.gn2; g2 = s.c.g2; gg = s.c.gg;
     const double radius = s.c.radius, alpha = s.c.alpha, mu_u = s.c.mu_used;
