@@ -296,6 +296,17 @@ int vil_debug_set_launch_mode(vil_ctx* ctx, int32_t mode);
 /* test hook: the next n hipGraph captures of this context's solves are treated as failed (as a driver that cannot capture or instantiate the chunk would make them).
  * A failed capture is not an error: nothing has run yet, the solve at hand and every later solve of the context launch directly.  n = 0 re-arms graph replay. */
 int vil_debug_fail_graph_capture(vil_ctx* ctx, int32_t n);
+/* Recovery of a one-launch solve whose workgroups could not all run together.  The one-launch iteration's roles wait for one another inside the launch; every such
+ * wait is bounded by TIME (0.25 s of the device's 100 MHz wall clock).  A wait that gives up ends the launches at once; vil_solve_resident / vil_solve / vil_win_solve
+ * then put the resident state back to what the solve started from and run the SAME solve again with two launches per iteration (sweep, then gather + step: mode 3 of
+ * vil_debug_set_launch_mode -- same results to rounding), and return its result.  Only if that attempt gives up too is VIL_ERR_DEVICE returned -- with the resident
+ * state (and the caller's vil_state) as the solve found them.  The next solve takes the one-launch structure again.
+ * vil_recovery_counts: solves of this context that were re-run that way / that failed on both structures.
+ * test hook vil_debug_drop_flag: in launch `launch` (0-based) of the NEXT solve, sweep role `role` (workgroup index in the sweep's order [imu | prior | rel | visual |
+ * plane | edge]; -2 - g: gather workgroup g) does not post its completion flag -- what a workgroup that never became resident looks like to the ones waiting for it.
+ * launch | 0x10000: a gather workgroup's flag is lost in the retry as well (a solve that fails on both structures). */
+int vil_debug_drop_flag(vil_ctx* ctx, int32_t role, int32_t launch);
+int vil_recovery_counts(vil_ctx* ctx, int64_t* recovered, int64_t* failed);
 /* profiling (with vil_profile_enable(ctx, 1), one-launch iterations): times == NULL arms it -- from now on every workgroup of launch `launch` (0-based) of a solve
  * leaves its entry and exit time (100 MHz device clock) --; with times != NULL the pairs {entry, exit} of the first max_workgroups (<= 4096) workgroups of the last
  * recorded launch are copied out, in block-index order = the launch's grid order [imu | prior | rel][chain][visual | plane | edge][master | helpers | tiles][gather]

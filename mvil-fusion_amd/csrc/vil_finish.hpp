@@ -6,6 +6,7 @@
 #pragma once
 #include <math.h>
 #include "vil_dev.hpp"
+#include "vil_math.hpp"
 
 // estimator.cpp:960-1011 double2vector(): yaw + translation gauge fix.  One arithmetic for the host entry point (vil_gauge_fix)
 // and the device kernel (vil_set_gauge_fix): pose K x 7 [p q(xyzw)], speed-bias K x 9, ex 7.
@@ -80,13 +81,15 @@ namespace vd {
 // all threads of ONE workgroup; returns after the sequence word has been stored
 // (cur / status / gen: the scalars of Ctl the caller already holds; the record itself is copied from device memory)
 // cam: 16 K + 8 + 12 doubles of LDS for the camera part of the final state and the gauge correction
+// AG (the persistent solve, k_solve): the accepted state and Ctl were written by workgroups of THIS launch -- read at agent scope, Ctl from the caller's copy `lctl`
+template <bool AG = false>
 __device__ __forceinline__ void solve_finish(double* const x, double* const xb, const double* const xorig, double* const hs, Ctl* const dctl, Ctl* const hctl, int* const hseq,
-                                             const int K, const int NS, const int gauge_on, const int cur, const int status, const int gen, double* const cam) {
+                                             const int K, const int NS, const int gauge_on, const int cur, const int status, const int gen, double* const cam, const Ctl* const lctl = nullptr) {
     const int t = threadIdx.x, NT = blockDim.x;
     const double* xs = cur ? xb : x;
     const int NC = 16 * K + 8;
     const int o_ex = 16 * K;                            // (xo_pose(k) = 7 k, xo_sb(k) = 7 K + 9 k, xo_ex = 16 K: vil_dev.hpp)
-    for (int i = t; i < NC; i += NT) cam[i] = xs[i];
+    for (int i = t; i < NC; i += NT) cam[i] = vd::ldx<AG>(xs + i);
     __syncthreads();
     if (gauge_on && status == 0) {
         // the yaw (or, near the singular pitch, the full) correction is derived from frame 0 by ONE lane and handed on through LDS (behind the camera part:
@@ -104,12 +107,12 @@ __device__ __forceinline__ void solve_finish(double* const x, double* const xb, 
         __syncthreads();
     }
     for (int i = t; i < NS; i += NT) {
-        const double v = i < NC ? cam[i] : xs[i];
+        const double v = i < NC ? cam[i] : vd::ldx<AG>(xs + i);
         x[i] = v; xb[i] = v;
         if (hs) hs[i] = v;
     }
     if (hctl) {
-        const double* src = (const double*)dctl; double* h = (double*)hctl;
+        const double* src = lctl ? (const double*)lctl : (const double*)dctl; double* h = (double*)hctl;
         for (int i = t; i < (int)(sizeof(Ctl) / 8); i += NT) h[i] = src[i];
     }
     __threadfence_system();                              // every thread's stores (device and host) before the barrier: __syncthreads alone does not wait for them
@@ -145,7 +148,11 @@ __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_finish(DevP P, int term) 
 // Start of a solve / linearisation / marginalisation sweep: the trust-region record is written by a kernel from its ARGUMENTS (no pinned staging
 // buffer whose contents a later call could overwrite before an asynchronous copy has read it).  reset: both state buffers are first restored to the
 // state the window was uploaded with (vil_reset_state + vil_solve_resident of a bench loop: one launch).
-__global__ __launch_bounds__(256) void k_solve_init(Ctl* ctl, int gen, double radius, double mu, int lin_mode, int* abortf /* cleared: vil_math.hpp, spin_until_eq */) {
+// xsave != null (a solve): the state the solve starts from (x0 = x1 here) is kept aside -- a one-launch solve whose wait gave up is re-run from it with the
+// multi-launch structure, and a solve that fails altogether leaves the resident state as it found it (vilsolve.hip, vil_solve_resident)
+__global__ __launch_bounds__(256) void k_solve_init(Ctl* ctl, int gen, double radius, double mu, int lin_mode, int* abortf /* cleared: vil_math.hpp, spin_until_eq */, const double* x0, double* xsave, int n) {
+    if (xsave) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) xsave[i] = x0[i]; }
+    if (blockIdx.x != 0) return;
     double* w = (double*)ctl;
     for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += blockDim.x) w[i] = 0.0;
     if (abortf && threadIdx.x == 0) *abortf = 0;
@@ -154,9 +161,9 @@ __global__ __launch_bounds__(256) void k_solve_init(Ctl* ctl, int gen, double ra
 }
 // (vil_reset_state is deferred to the next call that touches the state: in front of a solve it rides in the init launch -- one launch and one host
 //  call gap less per solve of a bench / re-solve loop)
-__global__ __launch_bounds__(256) void k_solve_init_reset(Ctl* ctl, int gen, double radius, double mu, int lin_mode, double* x0, double* x1, const double* src, int n, int* abortf) {
+__global__ __launch_bounds__(256) void k_solve_init_reset(Ctl* ctl, int gen, double radius, double mu, int lin_mode, double* x0, double* x1, const double* src, int n, int* abortf, double* xsave) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) { const double v = src[i]; x0[i] = v; x1[i] = v; }
+    if (i < n) { const double v = src[i]; x0[i] = v; x1[i] = v; if (xsave) xsave[i] = v; }
     if (blockIdx.x == 0) {
         double* w = (double*)ctl;
         for (int q = threadIdx.x; q < (int)(sizeof(Ctl) / 8); q += blockDim.x) w[q] = 0.0;

@@ -17,6 +17,7 @@
 #include "vil_sweep.hpp"
 #include "vil_step.hpp"
 
+#define VIL_LC_DOUBLES 160      // k_solve: a sweep role's copy of Ctl at the front of its dynamic LDS
 #define VIL_SS_DOUBLES ((sizeof(vd::StepShared) + 15) / 16 * 2)      // StepShared at the front of the step roles' dynamic LDS (16-byte granules)
 static_assert(VIL_SWEEP_THREADS == VIL_STEP_THREADS, "one block size for every role of k_iter");
 
@@ -62,5 +63,108 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_iter(DevP P, SolveOpts O) 
         __syncthreads();
         if (s.done_at_entry && s.c.outd == 0 && s.c.lin_mode == 0)
             vd::solve_finish(P.x[0], P.x[1], P.xorig, P.hstate, P.ctl, P.hctl, P.hseq, P.K, P.NS, P.gauge_on, s.c.cur, s.c.status, s.c.gen, dyn + VIL_SS_DOUBLES);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------------
+// The WHOLE SOLVE in one launch (round 6): the roles of k_iter as a RESIDENT grid that loops over the trust-region iterations.  What a launch boundary cost per
+// iteration -- the dispatch ramp, the end-of-kernel write-back, the gap to the next dispatch: ~10 us of 61 at configs[1], measured as (host clock per iteration) -
+// (first workgroup in .. master done) -- becomes one flag: the master posts the iteration's epoch in P.sall[0] behind its Ctl / candidate stores, every other
+// workgroup waits for it and reads Ctl again.
+//   grid = [imu x n_imu | prior | rel] [chain] [visual x n_vwg | plane | edge] [master | helpers x n_help | W W^T tiles x n_ww]        (no gather workgroups)
+// * EVERY workgroup must be resident at once (a workgroup that is not never runs: nobody leaves before the solve ends): the launch is only taken when the grid is
+//   smaller than what the device holds (vilsolve.hip: c->persist), i.e. configs[1]-sized windows (186 workgroups) -- K = 20 and configs[2] keep k_iter.
+// * The gather items are therefore DUTIES of workgroups that would otherwise idle: tile workgroups (idle until the chain is eliminated), helpers (idle until the
+//   gather is complete), then the sweep roles once their own record is out -- the short roles (IMU, prior, ICP / LPS, LiDAR) before the visual ones; one item each,
+//   so no item queues behind another (the launch is not taken when there are more items than such workgroups).
+// * What crosses from one iteration to the next crosses at agent scope (the FUSED loads / stores of the roles: Ctl, the candidate's camera part, la / lb, Sc);
+//   flags carry the epoch (generation, iteration) and are never reset, as in k_iter.
+// * Time cap (ceres max_solver_time_in_seconds, estimator.cpp:1411): the MASTER reads the device's wall clock at the end of an iteration -- where ceres reads its own,
+//   at the top of the next -- and ends the solve with the accepted state; the step it has just formed is not counted.
+// * A wait that gives up (vil_math.hpp) ends every role's loop; the host re-runs the solve with one launch per iteration (vil_solve_resident).
+template <int TS>
+__global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(DevP P, SolveOpts O, long long budget_ticks /* 100 MHz; <= 0: no time cap */) {
+    extern __shared__ double dyn[];
+    const int b = (int)blockIdx.x, t = (int)threadIdx.x, n_early = P.n_imu + 2;
+    const unsigned long long t_start = wall_clock64();
+    int sw = -1, p0 = -1;
+    if (b < n_early) sw = b;
+    else if (b == n_early) p0 = 0;                                  // chain
+    else if (b <= P.n_sw) sw = b - 1;                               // visual | plane | edge
+    else p0 = b - P.n_sw;                                           // 1: master; 2 .. 1 + n_help: helpers; then the tile workgroups
+    // gather duty of this workgroup (-1: none): candidates in the order [tiles | helpers | short sweep roles | visual roles]
+    const int n_nv = P.n_sw - P.n_vwg;
+    int ci = -1;
+    if (sw >= 0) ci = P.n_ww + P.n_help + (sw < n_early ? sw : (sw >= n_early + P.n_vwg ? sw - P.n_vwg : n_nv + (sw - n_early)));
+    else if (p0 >= 2 + P.n_help) ci = p0 - 2 - P.n_help;
+    else if (p0 >= 2) ci = P.n_ww + (p0 - 2);
+    const int item = (ci >= 0 && ci < P.n_gather) ? ci : -1;
+    Ctl* const lc = reinterpret_cast<Ctl*>(dyn);                    // a sweep role's copy of Ctl (the step roles keep theirs in StepShared, at the same place)
+    static_assert(sizeof(Ctl) % 8 == 0 && sizeof(Ctl) / 8 <= VIL_LC_DOUBLES, "Ctl copy of the sweep roles");
+    auto gather_item = [&](const Ctl& ctl, const int epoch, int4* const scratch) {
+        reduce_gather<true, VIL_STEP_THREADS / 8, true>(P, ctl, item, scratch, epoch);
+        if (P.drop_role == -2 - item && ctl.n_sweeps == P.drop_launch) return;      // (test hook: vil_debug_drop_flag)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+        if (t == 0) { st_ag(P.gflag + item, epoch); prof_stamp(P, epoch - 1, 5); }
+    };
+    if (sw >= 0) {
+        for (;;) {
+            __syncthreads();                                        // (the previous iteration's readers of lc)
+            { const double* src = (const double*)P.ctl; double* dst = (double*)lc; for (int i = t; i < (int)(sizeof(Ctl) / 8); i += VIL_STEP_THREADS) dst[i] = ld_ag(src + i); }
+            __syncthreads();
+            const Ctl& ctl = *lc;
+            if (ctl.done) return;
+            const int epoch = (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u);
+            sweep_body<TS, true>(P, O, ctl, dyn + VIL_LC_DOUBLES, sw);
+            if (item >= 0) { __syncthreads(); gather_item(ctl, epoch, (int4*)(dyn + VIL_LC_DOUBLES)); }
+            __syncthreads();
+            if (t == 0) spin_until_eq(P.sall, epoch, P.abortf);     // the master has written Ctl and the candidate of the next iteration (or the end of the solve)
+            __syncthreads();
+            if (ld_ag(P.abortf) != 0) return;
+        }
+    }
+    vd::StepShared& s = *reinterpret_cast<vd::StepShared*>(dyn);
+    double* const Alds = dyn + VIL_SS_DOUBLES;
+    auto duty = [&](const int epoch, int, int) { if (item >= 0) { gather_item(s.c, epoch, (int4*)Alds); __syncthreads(); } };
+    for (;;) {
+        __syncthreads();
+        step_body<true, 3, true>(P, O, s, Alds, p0, duty);
+        __syncthreads();
+        if (s.done_at_entry) return;                                // (chain, helpers, tiles: the master has ended the solve -- it does not come back here itself)
+        const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps);      // (step_body has counted this iteration in the workgroup's copy of Ctl)
+        if (p0 >= 2 && p0 < 2 + P.n_help) {                        // helper: its la / lb stores are out (the visual roles of the next iteration read them)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+            if (t == 0) st_ag(P.hflag2 + (p0 - 2), epoch);
+        }
+        if (p0 == 1) {
+            // master: Ctl and the candidate are out (end_iter's stores: waited for here).  Time cap, then either the end of the solve -- written out at once -- or the next iteration
+            if (t < P.n_help) spin_until_eq(P.hflag2 + t, epoch, P.abortf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+            if (t == 0 && !s.c.done) {
+                const bool gave_up = ld_ag(P.abortf) != 0;
+                if (gave_up) { s.c.done = 1; s.c.term = 6; s.c.status = -2; }
+                else if (budget_ticks > 0 && (long long)(wall_clock64() - t_start) > budget_ticks) { s.c.done = 1; s.c.term = 5; if (s.c.iter > 0 && !s.c.resweep) s.c.iter--; }      // (the step just formed was never judged: not an iteration of the summary)
+                if (s.c.done) s.red[0] = 1.0; else s.red[0] = 0.0;
+            } else if (t == 0) s.red[0] = 0.0;
+            __syncthreads();
+            if (s.red[0] != 0.0) {                                  // ended by the clock / a wait that gave up: Ctl goes out again
+                if (t < 64) { const double* src = (const double*)&s.c; double* dst = (double*)P.ctl; for (int i = t; i < (int)(sizeof(Ctl) / 8); i += 64) st_ag(dst + i, src[i]); }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+            }
+            if (s.c.done) {
+                if (s.c.lin_mode == 0) {
+                    if (t == 0) s.c.outd = 1;
+                    __syncthreads();
+                    vd::solve_finish<true>(P.x[0], P.x[1], P.xorig, P.hstate, P.ctl, P.hctl, P.hseq, P.K, P.NS, P.gauge_on, s.c.cur, s.c.status, s.c.gen, Alds, &s.c);
+                }
+                if (t == 0) st_ag(P.sall, epoch);                  // everybody reads `done` and leaves
+                return;
+            }
+            if (t == 0) st_ag(P.sall, epoch);
+            continue;
+        }
+        if (t == 0) spin_until_eq(P.sall, epoch, P.abortf);
+        __syncthreads();
+        if (ld_ag(P.abortf) != 0) return;
     }
 }

@@ -228,12 +228,23 @@ __device__ __forceinline__ void st_ag(double* p, double v) { __hip_atomic_store(
 __device__ __forceinline__ int ld_ag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_ag(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // Wait for a flag another workgroup of the launch posts.  abortf == null: wait as long as it takes.  abortf != null (the one-launch iteration, where nearly every
-// workgroup waits for others): give up after ~0.3 s, or as soon as somebody else has, and say so in *abortf -- every later wait of every workgroup then returns at
-// once, the launches end, the solve never reports `done`, and the host returns VIL_ERR_DEVICE instead of hanging with the device
+// workgroup waits for others): give up after VIL_WAIT_TICKS of the 100 MHz wall clock (0.25 s -- TIME, not poll rounds: a poll is an L2 / fabric round trip whose
+// length depends on what else the device is doing), or as soon as somebody else has, and say so in *abortf -- every later wait of every workgroup then returns at
+// once, the launches end, the master marks the solve `done` with status -2, and the host re-runs the solve with the multi-launch structure (vilsolve.hip,
+// vil_solve_resident).  The host's own poll window (2 s) is longer than this bound.
+#define VIL_WAIT_TICKS 25000000ull
+// every 1024th poll round of a bounded wait: has somebody given up, or has this wait lasted too long?  (t0 = 0 on the first call: the clock starts 1024 rounds in)
+__device__ __forceinline__ bool wait_expired(unsigned long long& t0, int* abortf) {
+    if (ld_ag(abortf) != 0) return true;
+    const unsigned long long now = wall_clock64();
+    if (t0 == 0) { t0 = now; return false; }
+    return now - t0 > VIL_WAIT_TICKS;
+}
 __device__ __forceinline__ bool spin_until_eq(const int* f, const int v, int* abortf) {
+    unsigned long long t0 = 0;
     for (int sp = 1; ld_ag(f) != v; ++sp) {
         __builtin_amdgcn_s_sleep(1);
-        if ((sp & 1023) == 0 && abortf && (sp > (1 << 21) || ld_ag(abortf) != 0)) { st_ag(abortf, 1); return false; }
+        if ((sp & 1023) == 0 && abortf && wait_expired(t0, abortf)) { st_ag(abortf, 1); return false; }
     }
     return true;
 }

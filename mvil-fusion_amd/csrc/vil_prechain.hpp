@@ -128,7 +128,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     auto isrc = [&](const int v) { return FUSED ? (v >> 16) - 1 : (v & 0xffff) - 1; };      // (decoded where it is used: the entries stay as loaded -- sixteen int4 per thread)
 #pragma unroll
     for (int u = 0; u < QN; ++u) { q[u] = tab[min(t + u * NT, n - 1)]; q2[u] = tab[min(t + (QN + u) * NT, n - 1)]; }      // (the second round's entries too: no table round trip behind the flags)      // (the second round's entries too: no table round trip behind the flags)
-    const double sc_prev = (t < NB && !ctl.first) ? P.Sc[NP + t] : 0.0;
+    const double sc_prev = (t < NB && !ctl.first) ? ldx<FUSED>(P.Sc + NP + t) : 0.0;      // (written by the master workgroup of an earlier iteration)
     const int pqv = P.chpq[min(t, NB - 1)];
     const double* const pHs = P.pn > 0 ? P.pH : P.mpart;
     // (IMU / prior records: agent-scope loads -- inside k_sweep they were written by workgroups of this launch; unconditional loads + selects)

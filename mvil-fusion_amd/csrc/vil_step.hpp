@@ -1378,8 +1378,11 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
 // FUSED: the role runs inside the one-launch iteration (k_iter, vil_iter.hpp) -- the sweep's workgroups are part of the SAME launch: the gather workgroups
 // wait for their flags (P.sflag) and read the records at agent scope, the chain workgroup waits for the IMU / prior workgroups', master and helpers read the
 // landmark arrays at agent scope, and the master counts the launch in Ctl::n_sweeps itself.  p0: the workgroup's index among the step roles.
-template <bool LDSM, int CHAIN, bool FUSED>
-__device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd::StepShared& s, double* const Alds, const int p0) {
+struct NoDuty { __device__ __forceinline__ void operator()(int, int, int) const {} };
+// DUTY (the persistent solve, k_solve): called by the helper and tile workgroups of a live iteration once they hold Ctl and the epoch, BEFORE their own waits -- they
+// have nothing to do until the gather is complete / the chain is eliminated, and take one gather item each meanwhile: duty(epoch, kind 0 tile | 1 helper, index)
+template <bool LDSM, int CHAIN, bool FUSED, class DUTY = NoDuty>
+__device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd::StepShared& s, double* const Alds, const int p0, DUTY duty = DUTY()) {
     using namespace vd;
     const int t = threadIdx.x, NT = blockDim.x;
     const int D = P.D, L = P.L;
@@ -1416,7 +1419,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     const bool helper = bid > 0 && bid <= nhelp;
     {   // Ctl (1.5 kB with its traces) into LDS: one coalesced load per lane, not 190 loads of a lone lane with everybody waiting at the barrier
         const double* src = (const double*)P.ctl; double* dst = (double*)&s.c;
-        for (int i = t; i < (int)(sizeof(Ctl) / 8); i += NT) dst[i] = src[i];
+        for (int i = t; i < (int)(sizeof(Ctl) / 8); i += NT) dst[i] = ldx<FUSED>(src + i);      // (FUSED: whatever the roles hand from one iteration to the next crosses at agent scope -- the persistent solve, k_solve, has no launch boundary between them)
         if (t == 0) { s.need = 0; s.was_first = 0; s.ok = 1; }
     }
     for (int q = t; q < 256; q += NT) {      // triangular tile index -> (tile row, tile col)
@@ -1450,9 +1453,11 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         if constexpr (FUSED) reduce_gather<true, VIL_STEP_THREADS / 8, true>(P, s.c, bid - b_gather, (int4*)Alds, epoch);      // (waits for the sweep workgroups' flags behind its own table staging)
         else if (P.rs_merged == 2) reduce_gather<true, VIL_STEP_THREADS / 8>(P, s.c, bid - b_gather, (int4*)Alds);      // 64 entries, all 512 threads
         else { if (t >= VIL_THREADS) return; reduce_gather<true, RED_EPW>(P, s.c, bid - b_gather, (int4*)Alds); }      // (descriptor table in the dynamic LDS this role does not use otherwise)   // 32 entries on the first four waves
+        if (P.drop_role == -2 - (bid - b_gather) && s.c.n_sweeps - 1 == P.drop_launch) return;      // (test hook, vil_debug_drop_flag: this gather workgroup loses its flag in that launch of the solve)
         rs_signal(P.gflag + (bid - b_gather)); PROF(5); return;
     }
     if (merged && bid >= b_ww) {
+        if constexpr (FUSED) duty(epoch, 0, bid - b_ww);
         if (!FUSED && t >= VIL_THREADS) return;        // a 256-thread role: the upper waves leave before the first barrier (one-launch iteration: they idle THROUGH the barriers)
         rs_wait(P.chflag, 1); prechain_ww_tile<FUSED>(P, bid - b_ww, Alds); rs_signal(P.wwflag + (bid - b_ww)); PROF(13); return;
     }
@@ -1472,7 +1477,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     }
     // master and helpers: the candidate's cost, gradient and diagonal (and S') are complete.  One-launch iteration: the master polls the gather workgroups' flags
     // and passes one word on to the helpers (their first pass is not on the critical path: a hop more, n_help x n_gather polling lanes fewer)
-    if (FUSED && merged && bid > 0) { if (t == 0) spin_until_eq(P.sall + 48, epoch, P.abortf); __syncthreads(); }
+    if (FUSED && merged && bid > 0) { duty(epoch, 1, bid - 1); if (t == 0) spin_until_eq(P.sall + 48, epoch, P.abortf); __syncthreads(); }
     else if (merged) { rs_wait(P.gflag, P.n_gather); if (FUSED && t == 0) st_ag(P.sall + 48, epoch); }
     if (bid == 0) PROF(8);
     // Everything the master and its helpers hand each other inside this launch (hpart, hpart2, stepc) is stored AND loaded with agent-scope
@@ -1492,7 +1497,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         static_assert(sizeof(Ctl) % 8 == 0, "Ctl is copied as doubles");
         const double* src = (const double*)&s.c;
         double* dst = (double*)P.ctl;
-        for (int i = t; i < (int)(sizeof(Ctl) / 8); i += 64) dst[i] = src[i];
+        for (int i = t; i < (int)(sizeof(Ctl) / 8); i += 64) stx<FUSED>(dst + i, src[i]);
     };
     // master: every helper has read Ctl (one lane per helper: the polls overlap instead of queueing behind one another)
     bool hseen = false;
@@ -1573,7 +1578,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
                 a = Sl * g / dl; b = Sl * gnv / dl;
                 sm[2] += a * a; sm[3] += a * b; sm[4] += b * b;
             }
-            P.la[l] = a; P.lb[l] = b;
+            stx<FUSED>(P.la + l, a); stx<FUSED>(P.lb + l, b);
             if (!(P.lm_const && P.lm_const[l])) { const double lam = ldx<FUSED>(x + xo_lam(P) + l); sm[5] += lam * lam; }      // (an accepted candidate's inverse depths: the visual workgroups of this launch wrote them)
         }
     };
@@ -1582,13 +1587,14 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     auto wait_x = [&](double* dst) {           // dst[0 .. NV) = Sc x_p as soon as its words carry this launch's epoch; s.ok (1 on entry) = 0 if the master gave up
         for (int w = t; w < 2 * P.NV; w += NT) {
             const unsigned long long* p = (const unsigned long long*)P.stepc + w;
+            unsigned long long tw0 = 0;
             for (int sp = 0;;) {
                 const unsigned long long v = ld_ll(p);
                 const int b = __hip_atomic_load(P.xstat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(v >> 32) == (unsigned)epoch) { ((unsigned*)dst)[w] = (unsigned)v; break; }
                 if (b == epoch) { s.ok = 0; break; }
                 __builtin_amdgcn_s_sleep(1);
-                if ((++sp & 1023) == 0 && P.abortf && (sp > (1 << 21) || ld_ag(P.abortf) != 0)) { st_ag(P.abortf, 1); s.ok = 0; break; }
+                if ((++sp & 1023) == 0 && P.abortf && wait_expired(tw0, P.abortf)) { st_ag(P.abortf, 1); s.ok = 0; break; }
             }
         }
         __syncthreads();
@@ -1607,6 +1613,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
             if (slot < nhelp) {                    // the six sums of a helper: twelve words of this epoch, all requested together
                 const unsigned long long* hp = (const unsigned long long*)P.hpart2 + 16 * slot;
                 unsigned long long w[12];
+                unsigned long long tw0 = 0;
                 for (int sp = 0;;) {
                     bool all = true;
 #pragma unroll
@@ -1615,7 +1622,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
                     for (int e = 0; e < 12; ++e) all = all && (unsigned)(w[e] >> 32) == (unsigned)epoch;
                     if (all) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if ((++sp & 1023) == 0 && P.abortf && (sp > (1 << 21) || ld_ag(P.abortf) != 0)) { st_ag(P.abortf, 1); break; }
+                    if ((++sp & 1023) == 0 && P.abortf && wait_expired(tw0, P.abortf)) { st_ag(P.abortf, 1); break; }
                 }
 #pragma unroll
                 for (int e = 0; e < 6; ++e) h[e] += __hiloint2double((int)(unsigned)w[2 * e + 1], (int)(unsigned)w[2 * e]);
@@ -1631,7 +1638,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
             // camera vectors u = Sc gradient_/d in LDS (nothing global is written here: that is the master's job)
             for (int i = t; i < P.NV; i += NT) {
                 const double dg = merged ? ld_ag(sb.diag + i) : sb.diag[i], b = merged ? ld_ag(sb.bc + i) : sb.bc[i];
-                const double Sc = s.was_first ? (O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0) : P.Sc[i];
+                const double Sc = s.was_first ? (O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0) : ldx<FUSED>(P.Sc + i);
                 const double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
                 s.y[i] = Sc * (Sc * b / d) / d;
             }
@@ -1689,7 +1696,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
                         sm[5] = lam2;
                     }
                     post_wave2(sm);
-                    if (lead) { P.la[l] = a_; P.lb[l] = b_; }      // (for the next sweep: not part of what the master waits for)
+                    if (lead) { stx<FUSED>(P.la + l, a_); stx<FUSED>(P.lb + l, b_); }      // (for the next sweep: not part of what the master waits for -- k_solve's helpers post hflag2 behind these stores, its master collects that flag before it opens the next iteration)
                 }
                 return;
             }
@@ -1708,7 +1715,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         return;
     }
     if (s.c.done) { if (t < 64) end_iter(); return; }
-    for (int i = t; i < 16 * P.K + 8; i += NT) s.x0[i] = x[i];          // (read after several barriers)
+    for (int i = t; i < 16 * P.K + 8; i += NT) s.x0[i] = ldx<FUSED>(x + i);          // (read after several barriers)
     for (int k = t; k < 2 * P.K; k += NT) s.cst[k] = k < P.K ? (P.pose_const ? P.pose_const[k] : 0) : (P.sb_const ? P.sb_const[k - P.K] : 0);
     bool xpub = false;                                 // the master owes the waiting helpers an xflag on every path through the need branch
     auto publish_xp = [&](int okk) {                   // called by all threads; s.y[0 .. NV) = x_p when okk
@@ -1776,7 +1783,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         for (int i = t; i < D; i += NT) {
             const double dg = merged ? ld_ag(sb.diag + i) : sb.diag[i], b = merged ? ld_ag(sb.bc + i) : sb.bc[i];
             double Sc;
-            if (s.was_first) { Sc = O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0; if (CHAIN == 3 && i >= P.NV) Sc = ld_ag(P.chSc + (i - P.NV)); P.Sc[i] = Sc; } else Sc = P.Sc[i];
+            if (s.was_first) { Sc = O.jacobi_scaling ? 1.0 / (1.0 + sqrt(dg)) : 1.0; if (CHAIN == 3 && i >= P.NV) Sc = ld_ag(P.chSc + (i - P.NV)); stx<FUSED>(P.Sc + i, Sc); } else Sc = ldx<FUSED>(P.Sc + i);
             double d = sqrt(fmin(fmax(Sc * Sc * dg, 1e-6), 1e32));
             if (CHAIN == 3 && i >= P.NV) d = ld_ag(P.chDc + (i - P.NV));      // the very numbers the chain workgroup scaled M_bb with
             const double g = Sc * b / d;
@@ -1883,7 +1890,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
                 if (!(c.mu < O.max_mu)) { c.iter++; c.invalid_run++; c.reuse = 0; if (c.invalid_run >= 5) { c.done = 1; c.term = 6; c.status = -4; } }
                 c.resweep = 1; c.cg = 0.0; c.cn = 0.0;
             }
-            for (int i = t; i < P.NS; i += NT) xc[i] = i >= xo_lam(P) ? ldx<FUSED>(x + i) : s.x0[i];
+            for (int i = t; i < P.NS; i += NT) stx<FUSED>(xc + i, i >= xo_lam(P) ? ldx<FUSED>(x + i) : s.x0[i]);
             __syncthreads();
             if (t < 64) end_iter();      // (a late helper may still be copying Ctl into its LDS)
             return;
@@ -1950,7 +1957,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         }
         __syncthreads();
     } else {
-        for (int i = t; i < D; i += NT) { s.sc[i] = P.Sc[i]; s.dcs[i] = P.dc[i]; s.gr[i] = P.gradc[i]; s.gn[i] = P.gnc[i]; s.rt[i] = s.sc[i] / s.dcs[i]; }
+        for (int i = t; i < D; i += NT) { s.sc[i] = ldx<FUSED>(P.Sc + i); s.dcs[i] = P.dc[i]; s.gr[i] = P.gradc[i]; s.gn[i] = P.gnc[i]; s.rt[i] = s.sc[i] / s.dcs[i]; }
         __syncthreads();
     }
     STAMP(5);
@@ -2014,7 +2021,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     __syncthreads();
     {   // the candidate's camera part leaves in one pass (a re-sweep: the current state again)
         const bool back = s.c.resweep && !s.c.done;
-        for (int i = t; i < 16 * P.K + 8; i += NT) xc[i] = back ? s.x0[i] : xcs[i];
+        for (int i = t; i < 16 * P.K + 8; i += NT) stx<FUSED>(xc + i, back ? s.x0[i] : xcs[i]);
     }
     STAMP(7);
     if (t < 64) end_iter();      // (no second poll when the sums were already collected)

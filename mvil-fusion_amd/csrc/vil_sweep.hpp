@@ -60,7 +60,7 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
         if (t < 287) v = c[t];
         else if (t < 512) v = P.imu_U[(size_t)f * 225 + (t - 287)];
         double xv = 0.0;
-        if (t < 32) { const int q = t < 7 ? xo_pose(P, i) + t : (t < 16 ? xo_sb(P, i) + (t - 7) : (t < 23 ? xo_pose(P, j) + (t - 16) : xo_sb(P, j) + (t - 23))); xv = x[q]; }
+        if (t < 32) { const int q = t < 7 ? xo_pose(P, i) + t : (t < 16 ? xo_sb(P, i) + (t - 7) : (t < 23 ? xo_pose(P, j) + (t - 16) : xo_sb(P, j) + (t - 23))); xv = chain_rec ? ld_ag(x + q) : x[q]; }      // (one-launch iteration / persistent solve: the candidate crosses from the master workgroup at agent scope)
         if (t >= 32 && t < 36 && !P.marg) {      // constancy of the four blocks (pose i, speed-bias i, pose j, speed-bias j): in the same round trip, not in front of the whitening
             const uint8_t* cp = (t & 1) ? P.sb_const : P.pose_const;
             xv = (cp && cp[t < 34 ? i : j]) ? 1.0 : 0.0;
@@ -231,15 +231,20 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
 #pragma unroll
         for (int k = 0; k < 14; ++k) c[k] = P.vis_c[(size_t)k * P.vis_stride + fs];
         const int i = P.vis_i[fs], j = P.vis_j[fs], l = P.vis_l[fs];
-        const double* pi = x + xo_pose(P, i); const double* pj = x + xo_pose(P, j); const double* ex = x + xo_ex(P);
+        // (AG -- the one-launch iteration and the persistent solve: the camera part of the candidate was written by the master workgroup, la / lb by the helpers, the
+        //  current inverse depths by a visual workgroup of an earlier iteration: all cross at agent scope; the other launch structures read them behind a launch boundary)
+        double pi[7], pj[7], ex[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { pi[k] = ldx<AG>(x + xo_pose(P, i) + k); pj[k] = ldx<AG>(x + xo_pose(P, j) + k); ex[k] = ldx<AG>(x + xo_ex(P) + k); }
+        const double tdv = ldx<AG>(x + xo_td(P));
         VisJ o;
-        const double lam = stepped ? xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l] : xcur[xo_lam(P) + l];      // (all three written by EARLIER launches: plain loads, L2 hits)
+        const double lam = stepped ? ldx<AG>(xcur + xo_lam(P) + l) + cg * ldx<AG>(P.la + l) + cn * ldx<AG>(P.lb + l) : ldx<AG>(xcur + xo_lam(P) + l);
         if (O.precision)
             visual_eval_f32(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
-                            lam, x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
+                            lam, tdv, P.sqrt_info, P.k_tr, P.use_td, o);
         else
             visual_eval(c, quatR(pi + 3), V3{pi[0], pi[1], pi[2]}, quatR(pj + 3), V3{pj[0], pj[1], pj[2]}, quatR(ex + 3), V3{ex[0], ex[1], ex[2]},
-                        lam, x[xo_td(P)], P.sqrt_info, P.k_tr, P.use_td, o);
+                        lam, tdv, P.sqrt_info, P.k_tr, P.use_td, o);
         double rho, rho1;
         loss_eval(O.visual_loss, O.visual_loss_scale, o.r[0] * o.r[0] + o.r[1] * o.r[1], rho, rho1);
         const bool live = !mfree || (P.marg == 1 && i == 0);      // estimator.cpp:1547-1589: landmarks anchored in frame 0
@@ -295,7 +300,7 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
         double* er = Em + tl * RS;
         // (a landmark of another rank's shard is in no chunk of this rank: its entries of the set stay zero here and the all-reduce takes them from the owner)
         if (k == 13) { stx<AG>(sb.hll + l, h); stx<AG>(sb.bl + l, b); stx<AG>(sb.invp + l, invp); stx<AG>(sb.sl + l, Sl); lr[0] = invp; sa[tl] = -invp; er[cR] = b; }
-        if (k == 14) stx<AG>(xcand + xo_lam(P) + l, stepped ? xcur[xo_lam(P) + l] + cg * P.la[l] + cn * P.lb[l] : xcur[xo_lam(P) + l]);      // the same expression the factor threads evaluated (read by the step roles once the candidate is accepted)
+        if (k == 14) stx<AG>(xcand + xo_lam(P) + l, stepped ? ldx<AG>(xcur + xo_lam(P) + l) + cg * ldx<AG>(P.la + l) + cn * ldx<AG>(P.lb + l) : ldx<AG>(xcur + xo_lam(P) + l));      // the same expression the factor threads evaluated (read by the step roles once the candidate is accepted)
         if (k < 13) {
             lr[1 + k] = e; stx<AG>(sb.eA + (size_t)l * 13 + k, e);
             er[k < 6 ? 6 * (a - fa0) + k : cX + (k - 6)] = e;
@@ -827,6 +832,7 @@ __device__ __forceinline__ void sweep_signal(const DevP& P, const Ctl& ctl, int 
 // come first (roles: top of this file)
 // FUSED: the roles as workgroups of the one-launch iteration (k_iter, vil_iter.hpp): everything another workgroup of the launch reads goes out at agent scope,
 // and every workgroup ends by posting the launch epoch in P.sflag[b] (the gather workgroups wait for all of them, the chain workgroup for the IMU / prior ones)
+#define VIL_XSTAGE 2048      // doubles into a sweep role's dynamic LDS where a one-launch role keeps its copy of the state's camera part (16 K + 8 <= 328 doubles)
 template <int TS, bool FUSED>      // TS: accumulator tiles per wave of the visual role
 __device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, const Ctl& ctl, double* const sm, const int blk) {
     const int cand = 1 - ctl.cur;
@@ -839,14 +845,25 @@ __device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, co
         if constexpr (FUSED) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores of the record (__syncthreads alone does not wait for global stores)
             __syncthreads();
-            if (threadIdx.x == 0) { const int ep = (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u); vd::st_ag(P.sflag + blk, ep); if (blk < P.n_imu) vd::st_ag(P.cflag + blk, ep); prof_stamp(P, ctl.n_sweeps, blk < P.n_imu ? 2 : (blk == P.n_imu ? 15 : 1)); }      // (an IMU role's chain flag: up already unless the role left early)
+            if (threadIdx.x == 0 && !(blk == P.drop_role && ctl.n_sweeps == P.drop_launch)) { const int ep = (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u); vd::st_ag(P.sflag + blk, ep); if (blk < P.n_imu) vd::st_ag(P.cflag + blk, ep); prof_stamp(P, ctl.n_sweeps, blk < P.n_imu ? 2 : (blk == P.n_imu ? 15 : 1)); }      // (an IMU role's chain flag: up already unless the role left early)
+        }
+    };
+    // FUSED: the prior, ICP / LPS and LiDAR roles hand pointers into the state to the factor code -- they read the camera part from a copy in LDS, fetched at agent scope
+    // (sm + VIL_XSTAGE: past what any of these roles uses, inside what every one-launch workgroup owns)
+    auto xstage = [&]() -> const double* {
+        if constexpr (!FUSED) return x;
+        else {
+            double* xl = sm + VIL_XSTAGE;
+            for (int e = threadIdx.x; e < 16 * P.K + 8; e += blockDim.x) xl[e] = vd::ld_ag(x + e);
+            __syncthreads();
+            return xl;
         }
     };
     if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm, FUSED ? ctl.n_sweeps : -1, FUSED, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u)); if (pre) sweep_signal(P, ctl, b); posted(); return; }
     b -= P.n_imu;
-    if (b == 0) { if (!(P.skip_mask & 16)) vd::sweep_prior(P, x, sm); if (pre) sweep_signal(P, ctl, P.n_imu); posted(); return; }
+    if (b == 0) { if (!(P.skip_mask & 16)) vd::sweep_prior(P, xstage(), sm); if (pre) sweep_signal(P, ctl, P.n_imu); posted(); return; }
     if (b == 1) {
-        if (!(P.skip_mask & 16)) vd::sweep_misc<FUSED>(P, O, x, sm);
+        if (!(P.skip_mask & 16)) vd::sweep_misc<FUSED>(P, O, xstage(), sm);
         if (P.world > 1) {                               // factor set sharded over ranks: the visual workgroups of this rank form the candidate inverse depth of
             const double* xcur = P.x[ctl.cur];           // the landmarks it owns; every rank holds la / lb of ALL landmarks (the step kernel runs on the all-reduced
             double* xcand = P.x[1 - ctl.cur];            // system), so the rest is filled in here and the states stay identical on all ranks
@@ -864,9 +881,10 @@ __device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, co
     // LiDAR roles: 2 chunks of 256 points per pass, P.lidar_rep passes per workgroup (1 unless the window has more sweep roles than the device has compute units:
     // configs[2]'s 120 k points are 235 two-chunk workgroups -- with the visual roles two dispatch rounds, and the gather workgroups of a one-launch iteration queue behind them)
     const int per = VIL_SWEEP_THREADS / 256, R = max(P.lidar_rep, 1), npw = (P.n_pchunk + per * R - 1) / (per * R);
-    if (b < npw) { if (!(P.skip_mask & 4)) for (int r = 0; r < R; ++r) { if (r) __syncthreads(); vd::sweep_lidar<1, FUSED>(P, O, b * R + r, x, sm); } posted(); return; }
+    const double* const xl = (FUSED && (P.skip_mask & 12) != 12) ? xstage() : x;
+    if (b < npw) { if (!(P.skip_mask & 4)) for (int r = 0; r < R; ++r) { if (r) __syncthreads(); vd::sweep_lidar<1, FUSED>(P, O, b * R + r, xl, sm); } posted(); return; }
     b -= npw;
-    if (!(P.skip_mask & 8)) for (int r = 0; r < R; ++r) { if (r) __syncthreads(); vd::sweep_lidar<3, FUSED>(P, O, b * R + r, x, sm); }
+    if (!(P.skip_mask & 8)) for (int r = 0; r < R; ++r) { if (r) __syncthreads(); vd::sweep_lidar<3, FUSED>(P, O, b * R + r, xl, sm); }
     posted();
 }
 
