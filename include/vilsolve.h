@@ -291,6 +291,8 @@ int vil_debug_set_split(vil_ctx* ctx, int32_t on);
  * in ONE launch whenever the device holds its waiting workgroups and the roles share one dynamic-LDS size (every BASELINE size on an MI355X), else the next one
  * down this list; 3: sweep launch + gather / step launch (round 4's structure); 1: the fallback for devices / windows where it does not: separate gather launch, the speed-bias chain
  * eliminated by a workgroup of the SWEEP launch; 2: no chain workgroup at all (the step kernel eliminates the chain itself, the round-2 structure).
+ * 4: one launch per ITERATION (k_iter) also where the whole solve could run as one resident launch (k_solve: the default for windows whose every role fits the
+ * device at once -- configs[1]; same bits as mode 4).
  * Same results to rounding in every mode.  Invalidates the resident window. */
 int vil_debug_set_launch_mode(vil_ctx* ctx, int32_t mode);
 /* test hook: the next n hipGraph captures of this context's solves are treated as failed (as a driver that cannot capture or instantiate the chunk would make them).
@@ -317,7 +319,8 @@ int vil_profile_workgroups(vil_ctx* ctx, int32_t launch, uint64_t* times, int32_
  * one-launch iteration runs (16-wide panels factored a matrix row per lane, back substitution a column per lane: vil_step.hpp chol_rowwave / back_subst_cols);
  * variant 0: the look-ahead factorisation (4-wide panels) and the back substitution through inverted diagonal tiles that the other launch structures run. */
 int vil_debug_dense_solve(vil_ctx* ctx, int32_t D, const double* A, double* L, double* x, int32_t* ok, int32_t variant);
-/* what the uploaded window's solves launch per trust-region iteration: 1 (the one-launch iteration), 2 (sweep + gather / step) or 3 (sweep, gather, step) */
+/* what the uploaded window's solves launch per trust-region iteration: 0 (nothing: the whole solve is ONE resident launch, k_solve -- windows whose roles all fit the
+ * device at once; *one_launch = 1 as well), 1 (the one-launch iteration), 2 (sweep + gather / step) or 3 (sweep, gather, step) */
 int vil_debug_get_launch_structure(vil_ctx* ctx, int32_t* launches_per_iteration, int32_t* one_launch);
 
 /* replaces estimator.cpp:1126-1419 (build ceres::Problem ... ceres::Solve): state is updated in

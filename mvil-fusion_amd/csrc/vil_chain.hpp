@@ -72,7 +72,7 @@ __device__ __forceinline__ bool chol9(const double* Dk, L9& o) {
 __device__ __forceinline__ int chain_flag_get(volatile int* f) { return __hip_atomic_load(const_cast<int*>(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void chain_flag_set(volatile int* f, int v) { __hip_atomic_store(const_cast<int*>(f), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void chain_wait(volatile int* f, int v) { while (__hip_atomic_load(const_cast<int*>(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(1); CHAIN_FENCE(); }
-__device__ __forceinline__ void chain_post(volatile int* f, int v) { CHAIN_FENCE(); if ((threadIdx.x & 63) == 0) __hip_atomic_store(const_cast<int*>(f), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // LDS operations of a wave execute in order
+__device__ __forceinline__ void chain_post(volatile int* f, int v) { CHAIN_FENCE(); if ((vil_tid() & 63) == 0) __hip_atomic_store(const_cast<int*>(f), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // LDS operations of a wave execute in order
 
 // solve one panel row against the factored 9 x 9 block: w = a L^-T
 __device__ __forceinline__ void row_solve9(const double* l, const double* r, const double* a, double* w) {
@@ -101,7 +101,7 @@ __device__ __forceinline__ void row_solve9(const double* l, const double* r, con
 // the recursion waves).
 template <bool WITHQ, class SRC>
 __device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, const int NP, const int RS, double* Wt, const ChainLds& L, double& qacc, long long* dbg = nullptr) {
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int t = vil_tid(), wave = t >> 6, lane = t & 63;
 #ifdef VIL_STAMPS
     #define CSTMP(k) do { if (lane == 0 && dbg) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); dbg[k] = tt_; } } while (0)
 #else
@@ -294,7 +294,7 @@ __device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, con
 // Ldg: 45 + 9 doubles of block k; Lsb: its sub-diagonal block (rows of the neighbouring block that was eliminated after it)
 // or nullptr for the middle block; tk / xn / xo: LDS.  Lanes 0..8 form the right-hand side, lane 0 solves.
 __device__ __forceinline__ void chain_block_back(const double* Ldg, const double* Lsb, double* tk, const double* xn, double* xo) {
-    const int lane = threadIdx.x & 63;
+    const int lane = vil_tid() & 63;
     if (lane < 9 && Lsb) {
         double v = tk[lane];
 #pragma unroll

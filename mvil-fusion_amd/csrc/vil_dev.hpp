@@ -152,6 +152,9 @@ struct DevP {
     // every sweep workgroup posts the launch epoch in sflag[its index] once its record is out (agent-scope stores); the gather workgroups wait for all of them,
     // the chain workgroup for the IMU / prior ones
     int n_sw; int* sflag;
+    int persist;                   // 1: this launch is the persistent solve (k_solve): Ctl leaves through its tail, the helpers post hflag2 behind their la / lb stores
+    unsigned long long* xtag;      // persistent solve: the candidate's camera part as 2 (16 K + 8) tagged words {half of a value, epoch}, written by the master, polled by the sweep roles
+    unsigned long long* ihdr;      // persistent solve (k_solve): the 64-byte hand-over line between two iterations (vil_iter.hpp)
     int drop_role, drop_launch;    // test hook (vil_debug_drop_flag): sweep role `drop_role` (its workgroup index in k_sweep's order; -2 - g: gather workgroup g) does not post its flag in launch `drop_launch` (0-based) of the solve; -1: off
     int* abortf;                   // one-launch iteration: a wait on another workgroup's flag that lasts 0.25 s gives up and says so here; every later wait returns at once (vil_math.hpp: spin_until_eq)
     long long* prof;               // != null: wall-clock stamps (s_memrealtime, 100 MHz) of the roles of a one-launch iteration, 8 per launch slot (vil_profile)

@@ -85,7 +85,7 @@ namespace vd {
 template <bool AG = false>
 __device__ __forceinline__ void solve_finish(double* const x, double* const xb, const double* const xorig, double* const hs, Ctl* const dctl, Ctl* const hctl, int* const hseq,
                                              const int K, const int NS, const int gauge_on, const int cur, const int status, const int gen, double* const cam, const Ctl* const lctl = nullptr) {
-    const int t = threadIdx.x, NT = blockDim.x;
+    const int t = vil_tid(), NT = blockDim.x;
     const double* xs = cur ? xb : x;
     const int NC = 16 * K + 8;
     const int o_ex = 16 * K;                            // (xo_pose(k) = 7 k, xo_sb(k) = 7 K + 9 k, xo_ex = 16 K: vil_dev.hpp)
@@ -124,13 +124,14 @@ __device__ __forceinline__ void solve_finish(double* const x, double* const xb, 
 }
 }  // namespace vd
 
+#ifndef VIL_PERSIST_TU
 // term < 0: the last launch of every chunk of iterations -- writes the result out if the solve ended in the chunk's last iteration (no
 // sweep launch behind it to do so), a no-op otherwise.  term >= 0: the host ended the solve (max_solver_time_in_seconds,
 // estimator.cpp:1411): mark it done with that termination and write the accepted state out.
 __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_finish(DevP P, int term) {
     __shared__ int sc[4];
     __shared__ double cam[16 * 20 + 8 + 12];             // camera part of the final state (K <= 20) + the gauge rotation / origin
-    if (threadIdx.x == 0) {
+    if (vil_tid() == 0) {
         Ctl* c = P.ctl;
         if (!c->done && term >= 0) { c->done = 1; c->term = term; }
         if (!c->done) c = nullptr;
@@ -151,28 +152,29 @@ __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_finish(DevP P, int term) 
 // xsave != null (a solve): the state the solve starts from (x0 = x1 here) is kept aside -- a one-launch solve whose wait gave up is re-run from it with the
 // multi-launch structure, and a solve that fails altogether leaves the resident state as it found it (vilsolve.hip, vil_solve_resident)
 __global__ __launch_bounds__(256) void k_solve_init(Ctl* ctl, int gen, double radius, double mu, int lin_mode, int* abortf /* cleared: vil_math.hpp, spin_until_eq */, const double* x0, double* xsave, int n) {
-    if (xsave) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) xsave[i] = x0[i]; }
+    if (xsave) { const int i = blockIdx.x * 256 + vil_tid(); if (i < n) xsave[i] = x0[i]; }
     if (blockIdx.x != 0) return;
     double* w = (double*)ctl;
-    for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += blockDim.x) w[i] = 0.0;
-    if (abortf && threadIdx.x == 0) *abortf = 0;
+    for (int i = vil_tid(); i < (int)(sizeof(Ctl) / 8); i += blockDim.x) w[i] = 0.0;
+    if (abortf && vil_tid() == 0) *abortf = 0;
     __syncthreads();
-    if (threadIdx.x == 0) { ctl->gen = gen; ctl->first = 1; ctl->radius = radius; ctl->mu = mu; ctl->lin_mode = lin_mode; }
+    if (vil_tid() == 0) { ctl->gen = gen; ctl->first = 1; ctl->radius = radius; ctl->mu = mu; ctl->lin_mode = lin_mode; }
 }
 // (vil_reset_state is deferred to the next call that touches the state: in front of a solve it rides in the init launch -- one launch and one host
 //  call gap less per solve of a bench / re-solve loop)
 __global__ __launch_bounds__(256) void k_solve_init_reset(Ctl* ctl, int gen, double radius, double mu, int lin_mode, double* x0, double* x1, const double* src, int n, int* abortf, double* xsave) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 256 + vil_tid();
     if (i < n) { const double v = src[i]; x0[i] = v; x1[i] = v; if (xsave) xsave[i] = v; }
     if (blockIdx.x == 0) {
         double* w = (double*)ctl;
-        for (int q = threadIdx.x; q < (int)(sizeof(Ctl) / 8); q += blockDim.x) w[q] = 0.0;
-        if (abortf && threadIdx.x == 0) *abortf = 0;
+        for (int q = vil_tid(); q < (int)(sizeof(Ctl) / 8); q += blockDim.x) w[q] = 0.0;
+        if (abortf && vil_tid() == 0) *abortf = 0;
         __syncthreads();
-        if (threadIdx.x == 0) { ctl->gen = gen; ctl->first = 1; ctl->radius = radius; ctl->mu = mu; ctl->lin_mode = lin_mode; }
+        if (vil_tid() == 0) { ctl->gen = gen; ctl->first = 1; ctl->radius = radius; ctl->mu = mu; ctl->lin_mode = lin_mode; }
     }
 }
 __global__ __launch_bounds__(256) void k_state_reset(double* x0, double* x1, const double* src, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 256 + vil_tid();
     if (i < n) { const double v = src[i]; x0[i] = v; x1[i] = v; }
 }
+#endif

@@ -18,9 +18,11 @@
 #include "vil_step.hpp"
 
 #define VIL_LC_DOUBLES 160      // k_solve: a sweep role's copy of Ctl at the front of its dynamic LDS
+#define VIL_XL_DOUBLES 352      // ... and its copy of the state's camera part behind it (16 K + 8 doubles, K <= 15: one polling thread per 32-bit half)
 #define VIL_SS_DOUBLES ((sizeof(vd::StepShared) + 15) / 16 * 2)      // StepShared at the front of the step roles' dynamic LDS (16-byte granules)
 static_assert(VIL_SWEEP_THREADS == VIL_STEP_THREADS, "one block size for every role of k_iter");
 
+#ifndef VIL_PERSIST_TU
 template <int TS>      // accumulator tiles per wave of the visual role (k_sweep<TS>)
 __global__ __launch_bounds__(VIL_STEP_THREADS) void k_iter(DevP P, SolveOpts O) {
     extern __shared__ double dyn[];
@@ -66,11 +68,13 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_iter(DevP P, SolveOpts O) 
     }
 }
 
+#endif
+#ifdef VIL_PERSIST_TU
 // ---------------------------------------------------------------------------------------------------------------------------------------------------------------
 // The WHOLE SOLVE in one launch (round 6): the roles of k_iter as a RESIDENT grid that loops over the trust-region iterations.  What a launch boundary cost per
 // iteration -- the dispatch ramp, the end-of-kernel write-back, the gap to the next dispatch: ~10 us of 61 at configs[1], measured as (host clock per iteration) -
-// (first workgroup in .. master done) -- becomes one flag: the master posts the iteration's epoch in P.sall[0] behind its Ctl / candidate stores, every other
-// workgroup waits for it and reads Ctl again.
+// (first workgroup in .. master done) -- becomes one 64-byte line: the master posts what a sweep role reads of Ctl, tagged with the iteration's epoch, behind its Ctl /
+// candidate stores (P.ihdr); every other workgroup polls it.
 //   grid = [imu x n_imu | prior | rel] [chain] [visual x n_vwg | plane | edge] [master | helpers x n_help | W W^T tiles x n_ww]        (no gather workgroups)
 // * EVERY workgroup must be resident at once (a workgroup that is not never runs: nobody leaves before the solve ends): the launch is only taken when the grid is
 //   smaller than what the device holds (vilsolve.hip: c->persist), i.e. configs[1]-sized windows (186 workgroups) -- K = 20 and configs[2] keep k_iter.
@@ -82,9 +86,22 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_iter(DevP P, SolveOpts O) 
 // * Time cap (ceres max_solver_time_in_seconds, estimator.cpp:1411): the MASTER reads the device's wall clock at the end of an iteration -- where ceres reads its own,
 //   at the top of the next -- and ends the solve with the accepted state; the step it has just formed is not counted.
 // * A wait that gives up (vil_math.hpp) ends every role's loop; the host re-runs the solve with one launch per iteration (vil_solve_resident).
+// * The parameter block is read through an OPAQUE pointer to the kernarg segment, renewed every iteration (as the thread index is, vil_math.hpp): nothing a role derives
+//   from it can be hoisted in front of the iteration loop -- with the by-value block LLVM hoisted every address of every role and the allocator spilled them.
+struct KSolveArgs { DevP P; SolveOpts O; long long budget_ticks; /* 100 MHz; <= 0: no time cap */ };
+__device__ __forceinline__ const KSolveArgs& ksolve_args() {
+    typedef const __attribute__((address_space(4))) KSolveArgs* KP;
+    KP kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return *(const KSolveArgs*)kp;
+}
 template <int TS>
-__global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(DevP P, SolveOpts O, long long budget_ticks /* 100 MHz; <= 0: no time cap */) {
+__global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(KSolveArgs kernarg_block /* read through ksolve_args() */) {
+    using vd::ld_ag; using vd::st_ag; using vd::spin_until_eq;
     extern __shared__ double dyn[];
+    const KSolveArgs& A0 = ksolve_args();
+    const DevP& P = A0.P;
+    const long long budget_ticks = A0.budget_ticks;
     const int b = (int)blockIdx.x, t = (int)threadIdx.x, n_early = P.n_imu + 2;
     const unsigned long long t_start = wall_clock64();
     int sw = -1, p0 = -1;
@@ -101,34 +118,67 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(DevP P, SolveOpts O,
     const int item = (ci >= 0 && ci < P.n_gather) ? ci : -1;
     Ctl* const lc = reinterpret_cast<Ctl*>(dyn);                    // a sweep role's copy of Ctl (the step roles keep theirs in StepShared, at the same place)
     static_assert(sizeof(Ctl) % 8 == 0 && sizeof(Ctl) / 8 <= VIL_LC_DOUBLES, "Ctl copy of the sweep roles");
-    auto gather_item = [&](const Ctl& ctl, const int epoch, int4* const scratch) {
-        reduce_gather<true, VIL_STEP_THREADS / 8, true>(P, ctl, item, scratch, epoch);
-        if (P.drop_role == -2 - item && ctl.n_sweeps == P.drop_launch) return;      // (test hook: vil_debug_drop_flag)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
-        if (t == 0) { st_ag(P.gflag + item, epoch); prof_stamp(P, epoch - 1, 5); }
-    };
+    // ---- the hand-over between two iterations: ONE 64-byte line of seven tagged words {payload 32 bits, epoch of the iteration that ended} -- what a sweep role reads of
+    //      Ctl (cur / done / first / lin_mode, mu, cg, cn; gen and the iteration count are the epoch itself).  The master writes it behind its Ctl and candidate
+    //      stores; a sweep role polls it with seven lanes and is in its next iteration one round trip after the master's store -- no flag followed by a load of Ctl.
+    //      The step roles poll word 0 and then read Ctl itself (they have slack: none of them is the start of an iteration's longest path).
+    auto hdr_ld = [&](const int k) { return __hip_atomic_load(P.ihdr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     if (sw >= 0) {
+        // a sweep role's dynamic LDS: [its copy of Ctl | its copy of the state's camera part | the role's own arrays (IMU roles: + the gather duty's scratch behind them)]
+        double* const xl = dyn + VIL_LC_DOUBLES; double* const sm = xl + VIL_XL_DOUBLES;
+        const int NC = 16 * A0.P.K + 8;
+        { const double* src = (const double*)P.ctl; double* dst = (double*)lc; for (int i = t; i < (int)(sizeof(Ctl) / 8); i += VIL_STEP_THREADS) dst[i] = ld_ag(src + i); }      // (the first iteration: as the init launch left them)
+        __syncthreads();
+        { const double* x0 = A0.P.x[1 - lc->cur]; for (int i = t; i < NC; i += VIL_STEP_THREADS) xl[i] = ld_ag(x0 + i); }
+        __syncthreads();
+        bool resident = false;                                      // IMU roles: constants, sqrt-information and constancy flags stay in LDS from the first iteration on
         for (;;) {
-            __syncthreads();                                        // (the previous iteration's readers of lc)
-            { const double* src = (const double*)P.ctl; double* dst = (double*)lc; for (int i = t; i < (int)(sizeof(Ctl) / 8); i += VIL_STEP_THREADS) dst[i] = ld_ag(src + i); }
-            __syncthreads();
+            const KSolveArgs& A = ksolve_args();
+            const DevP& P = A.P; const SolveOpts& O = A.O;
             const Ctl& ctl = *lc;
             if (ctl.done) return;
             const int epoch = (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u);
-            sweep_body<TS, true>(P, O, ctl, dyn + VIL_LC_DOUBLES, sw);
-            if (item >= 0) { __syncthreads(); gather_item(ctl, epoch, (int4*)(dyn + VIL_LC_DOUBLES)); }
+            sweep_body<TS, true>(P, O, ctl, sm, sw, xl, resident);
+            resident = true;
+            if (item >= 0) {
+                int4* const scratch = (int4*)(sm + (sw < P.n_imu ? 2048 : 0));
+                __syncthreads();
+                reduce_gather<true, VIL_STEP_THREADS / 8, true>(P, ctl, item, scratch, epoch);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+                if (t == 0 && !(P.drop_role == -2 - item && ctl.n_sweeps == P.drop_launch)) { st_ag(P.gflag + item, epoch); prof_stamp(P, epoch - 1, 5); }      // (drop: test hook, vil_debug_drop_flag)
+            }
+            __syncthreads();                                        // every reader of lc / xl is through
+            // the hand-over: lanes 0 .. 6 poll the header words, threads 8 .. 8 + 2 NC the candidate's tagged halves -- ONE round trip behind the master's stores brings
+            // the flag AND the data (a `done` header releases the threads whose words will never come)
+            if (t < 7 || (t >= 8 && t < 8 + 2 * NC)) {
+                const unsigned long long* const wp = t < 7 ? P.ihdr + t : P.xtag + (t - 8);
+                unsigned long long w = 0, tw0 = 0; bool ok = true, have = false;
+                for (int sp = 1;; ++sp) {
+                    w = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long h0 = t < 7 ? w : hdr_ld(0);
+                    if ((unsigned)(w >> 32) == (unsigned)epoch) { have = true; break; }
+                    if ((unsigned)(h0 >> 32) == (unsigned)epoch && ((unsigned)h0 & 2u)) break;      // the solve has ended
+                    __builtin_amdgcn_s_sleep(4);
+                    if ((sp & 1023) == 0 && vd::wait_expired(tw0, P.abortf)) { st_ag(P.abortf, 1); ok = false; break; }
+                }
+                const unsigned pl = (unsigned)w;
+                if (!ok) lc->pad_ = 1;
+                else if (!have) {}
+                else if (t == 0) { lc->cur = pl & 1; lc->done = (pl >> 1) & 1; lc->first = (pl >> 2) & 1; lc->lin_mode = (pl >> 3) & 3; lc->n_sweeps = (int)((unsigned)epoch & 0xfffu); }
+                else if (t < 7) { unsigned* d = (unsigned*)(t <= 2 ? &lc->mu : (t <= 4 ? &lc->cg : &lc->cn)); d[(t - 1) & 1] = pl; }      // (little endian: low half first)
+                else ((unsigned*)xl)[t - 8] = pl;
+            }
             __syncthreads();
-            if (t == 0) spin_until_eq(P.sall, epoch, P.abortf);     // the master has written Ctl and the candidate of the next iteration (or the end of the solve)
-            __syncthreads();
-            if (ld_ag(P.abortf) != 0) return;
+            if (lc->pad_) return;                                   // a wait gave up: the host re-runs the solve (vil_solve_resident)
         }
     }
     vd::StepShared& s = *reinterpret_cast<vd::StepShared*>(dyn);
     double* const Alds = dyn + VIL_SS_DOUBLES;
-    auto duty = [&](const int epoch, int, int) { if (item >= 0) { gather_item(s.c, epoch, (int4*)Alds); __syncthreads(); } };
     for (;;) {
+        const KSolveArgs& A = ksolve_args();
+        const DevP& P = A.P; const SolveOpts& O = A.O;
         __syncthreads();
-        step_body<true, 3, true>(P, O, s, Alds, p0, duty);
+        step_body<true, 3, true>(P, O, s, Alds, p0, item);
         __syncthreads();
         if (s.done_at_entry) return;                                // (chain, helpers, tiles: the master has ended the solve -- it does not come back here itself)
         const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps);      // (step_body has counted this iteration in the workgroup's copy of Ctl)
@@ -137,34 +187,46 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(DevP P, SolveOpts O,
             if (t == 0) st_ag(P.hflag2 + (p0 - 2), epoch);
         }
         if (p0 == 1) {
-            // master: Ctl and the candidate are out (end_iter's stores: waited for here).  Time cap, then either the end of the solve -- written out at once -- or the next iteration
-            if (t < P.n_help) spin_until_eq(P.hflag2 + t, epoch, P.abortf);
+            // master.  The candidate is out (waited for here); Ctl is still in LDS only (step_body's end_iter leaves it to this tail).  Order: time cap -> the hand-over line
+            // of the sweep roles (they read nothing else of Ctl) -> Ctl itself -> word 8 of the line, which the step roles (and nobody on an iteration's longest path) wait for.
+            // On paths where the helpers ran no second pass the spare wave's poll inside step_body did not happen: collected here (a helper posts hflag2 on every path).
+            if (s.pad0_ != epoch && t < P.n_help) spin_until_eq(P.hflag2 + t, epoch, P.abortf);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
-            if (t == 0 && !s.c.done) {
-                const bool gave_up = ld_ag(P.abortf) != 0;
-                if (gave_up) { s.c.done = 1; s.c.term = 6; s.c.status = -2; }
-                else if (budget_ticks > 0 && (long long)(wall_clock64() - t_start) > budget_ticks) { s.c.done = 1; s.c.term = 5; if (s.c.iter > 0 && !s.c.resweep) s.c.iter--; }      // (the step just formed was never judged: not an iteration of the summary)
-                if (s.c.done) s.red[0] = 1.0; else s.red[0] = 0.0;
-            } else if (t == 0) s.red[0] = 0.0;
+            if (t == 0 && !s.c.done && budget_ticks > 0 && (long long)(wall_clock64() - t_start) > budget_ticks) { s.c.done = 1; s.c.term = 5; if (s.c.iter > 0 && !s.c.resweep) s.c.iter--; }      // (the step just formed was never judged: not an iteration of the summary)
             __syncthreads();
-            if (s.red[0] != 0.0) {                                  // ended by the clock / a wait that gave up: Ctl goes out again
-                if (t < 64) { const double* src = (const double*)&s.c; double* dst = (double*)P.ctl; for (int i = t; i < (int)(sizeof(Ctl) / 8); i += 64) st_ag(dst + i, src[i]); }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
-            }
-            if (s.c.done) {
-                if (s.c.lin_mode == 0) {
-                    if (t == 0) s.c.outd = 1;
-                    __syncthreads();
-                    vd::solve_finish<true>(P.x[0], P.x[1], P.xorig, P.hstate, P.ctl, P.hctl, P.hseq, P.K, P.NS, P.gauge_on, s.c.cur, s.c.status, s.c.gen, Alds, &s.c);
+            const bool done = s.c.done != 0;
+            auto post_hdr = [&]() {
+                if (t < 7) {
+                    const Ctl& c = s.c;
+                    const double dv = t <= 2 ? c.mu : (t <= 4 ? c.cg : c.cn);
+                    const unsigned pl = t == 0 ? (unsigned)((c.cur & 1) | ((c.done ? 1 : 0) << 1) | ((c.first ? 1 : 0) << 2) | ((c.lin_mode & 3) << 3)) : (unsigned)(((t - 1) & 1) ? __double2hiint(dv) : __double2loint(dv));
+                    __hip_atomic_store(P.ihdr + t, ((unsigned long long)(unsigned)epoch << 32) | pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (t == 0) st_ag(P.sall, epoch);                  // everybody reads `done` and leaves
+            };
+            if (!done) post_hdr();                                 // the next iteration's sweep roles start from this
+            if (done && s.c.lin_mode == 0 && t == 0) s.c.outd = 1;
+            __syncthreads();
+            if (t < 64) { const double* src = (const double*)&s.c; double* dst = (double*)P.ctl; for (int i = t; i < (int)(sizeof(Ctl) / 8); i += 64) st_ag(dst + i, src[i]); }
+            if (done) {
+                if (s.c.lin_mode == 0) vd::solve_finish<true>(P.x[0], P.x[1], P.xorig, P.hstate, P.ctl, P.hctl, P.hseq, P.K, P.NS, P.gauge_on, s.c.cur, s.c.status, s.c.gen, Alds, &s.c);      // (the host is released here)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+                post_hdr();                                        // everybody reads `done` and leaves
+                if (t == 0) __hip_atomic_store(P.ihdr + 8, (unsigned long long)(unsigned)epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
             }
-            if (t == 0) st_ag(P.sall, epoch);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+            if (t == 0) __hip_atomic_store(P.ihdr + 8, (unsigned long long)(unsigned)epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             continue;
         }
-        if (t == 0) spin_until_eq(P.sall, epoch, P.abortf);
+        if (t == 0) {
+            unsigned long long tw0 = 0; s.red[1] = 0.0;
+            for (int sp = 1; (unsigned)(hdr_ld(8) >> 32) != (unsigned)epoch; ++sp) {      // (word 8: Ctl is complete)
+                __builtin_amdgcn_s_sleep(8);
+                if ((sp & 1023) == 0 && vd::wait_expired(tw0, P.abortf)) { st_ag(P.abortf, 1); s.red[1] = 1.0; break; }
+            }
+        }
         __syncthreads();
-        if (ld_ag(P.abortf) != 0) return;
+        if (s.red[1] != 0.0) return;
     }
 }
+#endif

@@ -5,6 +5,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// The thread index of the roles.  VIL_OPAQUE_TID (the translation unit of the persistent solve, vilpersist.hip): an OPAQUE value -- what a role derives from it is
+// computed where the role runs.  The roles are inlined into k_solve's iteration loop; from a plain threadIdx.x LLVM's loop-invariant code motion hoists every
+// per-thread address of every role in front of the loop and the register allocator spills them (470 dwords per lane, measured; 20 with the opaque index).
+// The other kernels keep the plain index (k_iter with the opaque one: 9 dwords of scratch, from none).
+#ifdef VIL_OPAQUE_TID
+__device__ __forceinline__ int vil_tid() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+#else
+__device__ __forceinline__ int vil_tid() { return (int)threadIdx.x; }
+#endif
 namespace vd {
 
 // T = double everywhere on the reference path; T = float only for the fp32-evaluation mode of the bulk factor classes

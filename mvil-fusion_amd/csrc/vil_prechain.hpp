@@ -89,12 +89,12 @@ __device__ __forceinline__ void chain_inverse_block(const DevP& P, const double*
 // place every lane would walk 135 loads at memory latency).  (As a workgroup of the gather launch it was that launch's longest.)
 __device__ __forceinline__ void prechain_inverses(const DevP& P, double* lds, const int epoch) {
     const int n = 136 * P.K;
-    for (int e = threadIdx.x; e < n; e += blockDim.x) lds[e] = P.chLraw[e];
+    for (int e = vil_tid(); e < n; e += blockDim.x) lds[e] = P.chLraw[e];
     __syncthreads();
-    for (int it = threadIdx.x; it < 9 * P.K; it += blockDim.x) chain_inverse_block(P, lds, lds + 54 * P.K, it / 9, it % 9);
+    for (int it = vil_tid(); it < 9 * P.K; it += blockDim.x) chain_inverse_block(P, lds, lds + 54 * P.K, it / 9, it % 9);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) st_ag(P.chflag + 2, epoch);
+    if (vil_tid() == 0) st_ag(P.chflag + 2, epoch);
 }
 
 // the chain workgroup (all threads of the block enter; dynamic LDS >= prechain_lds_doubles(K)); the IMU / prior records are complete
@@ -105,7 +105,7 @@ __device__ __forceinline__ void prechain_inverses(const DevP& P, double* lds, co
 // with the launch epoch), but the launch's longest path is the master's, not this workgroup's: it forms the inverses of its diagonal blocks itself.
 template <bool FUSED = false>
 __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const int jacobi, double* lds, const int epoch, const bool wait_records = false) {
-    const int t = threadIdx.x, K = P.K, NP = P.NV, NB = 9 * K, NT = blockDim.x;
+    const int t = vil_tid(), K = P.K, NP = P.NV, NB = 9 * K, NT = blockDim.x;
 #ifdef VIL_STAMPS
     #define PSTAMP(k) do { if (t == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[k] = tt_; } } while (0)
 #else
@@ -257,9 +257,9 @@ __device__ __forceinline__ void prechain_ww_tile(const DevP& P, const int tile, 
     double (*acc_s)[256];
     if constexpr (FUSED) acc_s = reinterpret_cast<double (*)[256]>(lds);
     else { __shared__ double acc_st[4][256]; acc_s = acc_st; }
-    if (!FUSED && threadIdx.x >= 256) return;
-    const bool act = threadIdx.x < 256;                  // (one-launch iteration: the upper waves idle through the barrier instead of leaving)
-    const int t = threadIdx.x & 255, wave = t >> 6, lane = t & 63, row = lane & 15, kq = lane >> 4;
+    if (!FUSED && vil_tid() >= 256) return;
+    const bool act = vil_tid() < 256;                  // (one-launch iteration: the upper waves idle through the barrier instead of leaving)
+    const int t = vil_tid() & 255, wave = t >> 6, lane = t & 63, row = lane & 15, kq = lane >> 4;
     const int NB = 9 * P.K, RS = P.chain_rs, R = P.NV + 1;
     int I = 0; while ((I + 1) * (I + 2) / 2 <= tile) ++I;
     const int J = tile - I * (I + 1) / 2;

@@ -50,8 +50,8 @@ __device__ __forceinline__ void bsum3(double& a, double& b, double& c, StepShare
     a = wave_total_l63(a); b = wave_total_l63(b);          // DPP folds: the wave totals land in lane 63
     c = CMAX ? wave_max_l63(c) : wave_total_l63(c);
     __syncthreads();
-    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if ((threadIdx.x & 63) == 63) { s.red[w] = a; s.red[8 + w] = b; s.red[16 + w] = c; }
+    const int w = vil_tid() >> 6, nw = blockDim.x >> 6;
+    if ((vil_tid() & 63) == 63) { s.red[w] = a; s.red[8 + w] = b; s.red[16 + w] = c; }
     __syncthreads();
     a = 0; b = 0; c = 0;
     for (int q = 0; q < nw; ++q) { a += s.red[q]; b += s.red[8 + q]; c = CMAX ? fmax(c, s.red[16 + q]) : c + s.red[16 + q]; }
@@ -61,8 +61,8 @@ __device__ __forceinline__ void bsum3(double& a, double& b, double& c, StepShare
 __device__ __forceinline__ void bsum5(double& a, double& b, double& c, double& d, double& e, StepShared& s) {
     a = wave_total_l63(a); b = wave_total_l63(b); c = wave_max_l63(c); d = wave_total_l63(d); e = wave_total_l63(e);
     __syncthreads();
-    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if ((threadIdx.x & 63) == 63) { s.red[w] = a; s.red[8 + w] = b; s.red[16 + w] = c; s.red[24 + w] = d; s.red[32 + w] = e; }
+    const int w = vil_tid() >> 6, nw = blockDim.x >> 6;
+    if ((vil_tid() & 63) == 63) { s.red[w] = a; s.red[8 + w] = b; s.red[16 + w] = c; s.red[24 + w] = d; s.red[32 + w] = e; }
     __syncthreads();
     a = 0; b = 0; c = 0; d = 0; e = 0;
     for (int q = 0; q < nw; ++q) { a += s.red[q]; b += s.red[8 + q]; c = fmax(c, s.red[16 + q]); d += s.red[24 + q]; e += s.red[32 + q]; }
@@ -73,8 +73,8 @@ __device__ __forceinline__ void bsum6(double* v, StepShared& s) {
 #pragma unroll
     for (int e = 0; e < 6; ++e) v[e] = wave_total_l63(v[e]);
     __syncthreads();
-    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if ((threadIdx.x & 63) == 63) { for (int e = 0; e < 6; ++e) s.red[8 * e + w] = v[e]; }
+    const int w = vil_tid() >> 6, nw = blockDim.x >> 6;
+    if ((vil_tid() & 63) == 63) { for (int e = 0; e < 6; ++e) s.red[8 * e + w] = v[e]; }
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 6; ++e) { double a = 0; for (int q = 0; q < nw; ++q) a += s.red[8 * e + q]; v[e] = a; }
@@ -83,7 +83,7 @@ __device__ __forceinline__ void bsum6(double* v, StepShared& s) {
 __device__ __forceinline__ double bsum(double v, StepShared& s) {
     v = wave_total_l63(v);
     __syncthreads();
-    if ((threadIdx.x & 63) == 63) s.red[threadIdx.x >> 6] = v;
+    if ((vil_tid() & 63) == 63) s.red[vil_tid() >> 6] = v;
     __syncthreads();
     double t = 0;
     const int nw = blockDim.x >> 6;
@@ -93,7 +93,7 @@ __device__ __forceinline__ double bsum(double v, StepShared& s) {
 __device__ __forceinline__ double bmax(double v, StepShared& s) {
     v = wave_max_l63(v);
     __syncthreads();
-    if ((threadIdx.x & 63) == 63) s.red[threadIdx.x >> 6] = v;
+    if ((vil_tid() & 63) == 63) s.red[vil_tid() >> 6] = v;
     __syncthreads();
     double t = 0;
     const int nw = blockDim.x >> 6;
@@ -188,7 +188,7 @@ __device__ __forceinline__ double lm_dot(const DevP& P, const SysBuf& sb, int l,
 //   v_c^T H_cc v_c = v_c^T S' v_c + sum_l invp (e_l.v_c)^2     (S' = H_cc - sum_l invp e e^T)
 // vc must be readable by every thread (LDS or global).
 __device__ __forceinline__ double quad_form(const DevP& P, const SysBuf& sb, const double* vc, const double* vl, StepShared& s) {
-    const int D = P.D, L = P.L, t = threadIdx.x, NT = blockDim.x;
+    const int D = P.D, L = P.L, t = vil_tid(), NT = blockDim.x;
     double part = 0;
     for (int e = t; e < D * D; e += NT) { const int i = e / D, j = e - i * D; part += vc[i] * sb.S[e] * vc[j]; }
     for (int l = t; l < L; l += NT) {
@@ -250,7 +250,7 @@ struct NoPre { template <class C> __device__ __forceinline__ void operator()(C*,
 // PRE: called once with the freshly loaded register tiles (REGRES) -- the chain path subtracts W W^T there
 template <bool REGRES, class PTR, class PRE = NoPre>
 __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double* Acol = nullptr, PRE pre = PRE()) {
-    const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
+    const int t = vil_tid(), NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
     const int R = D + 1;                 // rows including the rhs row
     const int T = (R + 15) >> 4;         // tile rows
     const int la = (lane & 15) * TILE_RS + (lane >> 4);     // operand element (row lane&15, k lane>>4) inside a tile
@@ -432,7 +432,7 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double
         CSTAMP(3);
     }
 #ifdef VIL_STAMPS
-    if (threadIdx.x == 0) { for (int q = 0; q < 6; ++q) s.tacc[q] = tacc[q]; }
+    if (vil_tid() == 0) { for (int q = 0; q < 6; ++q) s.tacc[q] = tacc[q]; }
 #endif
     return true;
 }
@@ -449,7 +449,7 @@ __device__ __forceinline__ bool chol_blocked(PTR A, int D, StepShared& s, double
 // On return rows < D hold L, row D holds y = L^-1 rhs, s.dinv[j] = 1 / L_jj.  Returns false (uniformly) on a non-positive pivot.
 template <int SLOTS = CH_SLOTS, bool DIAG = true, class PTR, class PRE = NoPre>      // SLOTS: register tiles per wave (8 waves x SLOTS >= the tiles of the matrix); DIAG = false: the diagonal of L is not formed (the solves read s.dinv), its slots keep their old values
 __device__ __forceinline__ bool chol_lookahead(PTR A, int D, StepShared& s, PRE pre = PRE()) {
-    const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
+    const int t = vil_tid(), NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
     const int R = D + 1;                 // rows including the rhs row
     const int T = (R + 15) >> 4;         // tile rows
     const int la = (lane & 15) * TILE_RS + (lane >> 4);     // operand element (row lane&15, k lane>>4) inside a tile
@@ -784,7 +784,7 @@ __device__ __forceinline__ void rowwave_panel_second(PTR A, const int Kt, const 
 }
 template <int SLOTS = 3, class PTR, class PRE = NoPre>
 __device__ __forceinline__ bool chol_rowwave(PTR A, int D, StepShared& s, PRE pre = PRE()) {
-    const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
+    const int t = vil_tid(), NT = blockDim.x, wave = t >> 6, lane = t & 63, NW = NT >> 6;
     const int R = D + 1, T = (R + 15) >> 4, TD = (D + 15) >> 4;
     const int la = (lane & 15) * TILE_RS + (lane >> 4);     // operand element (row lane&15, k lane>>4) inside a tile
     const int lc = (lane >> 4) * TILE_RS + (lane & 15);     // accumulator element (row lane>>4 (+4g), col lane&15)
@@ -871,7 +871,7 @@ __device__ __forceinline__ bool chol_dense(PTR A, int D, StepShared& s, PRE pre 
 // A is not modified.  Result in s.y[0 .. D); s.xs is scratch.
 template <class PTR>
 __device__ __forceinline__ void back_subst_cols(PTR A, int D, StepShared& s) {
-    const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63;
+    const int t = vil_tid(), NT = blockDim.x, wave = t >> 6, lane = t & 63;
     const int TD = (D + 15) >> 4;
     for (int i = t; i < (TD << 4); i += NT) { s.y[i] = i < D ? A[tl_idx(D, i)] : 0.0; s.xs[i] = 0.0; }
     const int g = lane >> 4, j = lane & 15;
@@ -935,7 +935,7 @@ __device__ __forceinline__ void back_subst_cols(PTR A, int D, StepShared& s) {
 // Result in s.y[0..D).
 template <class PTR>
 __device__ __forceinline__ void back_subst(PTR A, int D, StepShared& s) {
-    const int t = threadIdx.x, NT = blockDim.x, wave = t >> 6, lane = t & 63;
+    const int t = vil_tid(), NT = blockDim.x, wave = t >> 6, lane = t & 63;
     for (int i = t; i < D; i += NT) s.y[i] = A[tl_idx(D, i)];
     const int TD = (D + 15) >> 4;                           // diagonal tiles that hold rows of L
     for (int i = D + t; i < (TD << 4); i += NT) s.y[i] = 0.0;                        // padding of the last tile: its products vanish
@@ -1068,7 +1068,7 @@ struct ChainSrcStep {                      // the chain's view of the system ins
 
 template <bool WLDS, class PUB, class SIDE>
 __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart, PUB pub, SIDE side) {
-    const int t = threadIdx.x;
+    const int t = vil_tid();
 #ifdef VIL_STAMPS
     #define SSTAMP(k) do { if (t == 0) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); P.dbg[40 + k] = tt_; } } while (0)
 #else
@@ -1185,7 +1185,7 @@ __device__ __forceinline__ bool solve_chain(const DevP& P, const SysBuf& sb, Ste
 //      substitution.  Same contract as solve_chain.
 template <bool RW /* the row-per-lane factorisation (chol_rowwave) where it applies: the one-launch iteration */, class PUB, class SIDE>
 __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, StepShared& s, double* lds, const double mu, const bool cam, double& qpart, const int epoch /* of this launch's flags */, PUB pub, SIDE side) {
-    const int t = threadIdx.x;
+    const int t = vil_tid();
     SSTAMP(0);
     const int K = P.K, D = P.D, NP = P.NV, R = NP + 1, T = (R + 15) >> 4, ntile = (T * (T + 1)) >> 1;
     const int RS = P.chain_rs, NB = 9 * K, m = K >> 1;
@@ -1378,13 +1378,12 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
 // FUSED: the role runs inside the one-launch iteration (k_iter, vil_iter.hpp) -- the sweep's workgroups are part of the SAME launch: the gather workgroups
 // wait for their flags (P.sflag) and read the records at agent scope, the chain workgroup waits for the IMU / prior workgroups', master and helpers read the
 // landmark arrays at agent scope, and the master counts the launch in Ctl::n_sweeps itself.  p0: the workgroup's index among the step roles.
-struct NoDuty { __device__ __forceinline__ void operator()(int, int, int) const {} };
-// DUTY (the persistent solve, k_solve): called by the helper and tile workgroups of a live iteration once they hold Ctl and the epoch, BEFORE their own waits -- they
-// have nothing to do until the gather is complete / the chain is eliminated, and take one gather item each meanwhile: duty(epoch, kind 0 tile | 1 helper, index)
-template <bool LDSM, int CHAIN, bool FUSED, class DUTY = NoDuty>
-__device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd::StepShared& s, double* const Alds, const int p0, DUTY duty = DUTY()) {
+// duty_item >= 0 (the persistent solve, k_solve): the gather item a helper or tile workgroup of a live iteration takes once it holds Ctl and the epoch, BEFORE its own
+// waits -- it has nothing to do until the gather is complete / the chain is eliminated
+template <bool LDSM, int CHAIN, bool FUSED>
+__device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd::StepShared& s, double* const Alds, const int p0, const int duty_item = -1) {
     using namespace vd;
-    const int t = threadIdx.x, NT = blockDim.x;
+    const int t = vil_tid(), NT = blockDim.x;
     const int D = P.D, L = P.L;
     // The grid is 1 + P.n_help workgroups: the extra ones run the same judge on their own copy of Ctl and
     // do the two landmark passes of their slice on their own CU (those passes are bound by what ONE CU can pull out of L2).
@@ -1456,8 +1455,16 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         if (P.drop_role == -2 - (bid - b_gather) && s.c.n_sweeps - 1 == P.drop_launch) return;      // (test hook, vil_debug_drop_flag: this gather workgroup loses its flag in that launch of the solve)
         rs_signal(P.gflag + (bid - b_gather)); PROF(5); return;
     }
+    auto duty = [&]() {
+        if constexpr (FUSED) if (duty_item >= 0) {
+            reduce_gather<true, VIL_STEP_THREADS / 8, true>(P, s.c, duty_item, (int4*)Alds, epoch);
+            if (!(P.drop_role == -2 - duty_item && s.c.n_sweeps - 1 == P.drop_launch)) rs_signal(P.gflag + duty_item);
+            PROF(5);
+            __syncthreads();
+        }
+    };
     if (merged && bid >= b_ww) {
-        if constexpr (FUSED) duty(epoch, 0, bid - b_ww);
+        duty();
         if (!FUSED && t >= VIL_THREADS) return;        // a 256-thread role: the upper waves leave before the first barrier (one-launch iteration: they idle THROUGH the barriers)
         rs_wait(P.chflag, 1); prechain_ww_tile<FUSED>(P, bid - b_ww, Alds); rs_signal(P.wwflag + (bid - b_ww)); PROF(13); return;
     }
@@ -1477,7 +1484,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     }
     // master and helpers: the candidate's cost, gradient and diagonal (and S') are complete.  One-launch iteration: the master polls the gather workgroups' flags
     // and passes one word on to the helpers (their first pass is not on the critical path: a hop more, n_help x n_gather polling lanes fewer)
-    if (FUSED && merged && bid > 0) { duty(epoch, 1, bid - 1); if (t == 0) spin_until_eq(P.sall + 48, epoch, P.abortf); __syncthreads(); }
+    if (FUSED && merged && bid > 0) { duty(); if (t == 0) spin_until_eq(P.sall + 48, epoch, P.abortf); __syncthreads(); }
     else if (merged) { rs_wait(P.gflag, P.n_gather); if (FUSED && t == 0) st_ag(P.sall + 48, epoch); }
     if (bid == 0) PROF(8);
     // Everything the master and its helpers hand each other inside this launch (hpart, hpart2, stepc) is stored AND loaded with agent-scope
@@ -1510,7 +1517,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         wait_helpers();
         if (t == 0 && P.abortf && (abort_pre >= 0 ? abort_pre : ld_ag(P.abortf)) != 0) { s.c.done = 1; s.c.term = 6; s.c.status = -2; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-        store_ctl();
+        if (!(FUSED && P.persist)) store_ctl();      // (the persistent solve: Ctl leaves through k_solve's tail, BEHIND the hand-over line of the next iteration's sweep roles)
     };
     const bool cam = true;             // (every rank holds the complete system: nothing is counted per rank any more)
     STAMP(0);
@@ -1891,6 +1898,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
                 c.resweep = 1; c.cg = 0.0; c.cn = 0.0;
             }
             for (int i = t; i < P.NS; i += NT) stx<FUSED>(xc + i, i >= xo_lam(P) ? ldx<FUSED>(x + i) : s.x0[i]);
+            if (FUSED && P.persist) for (int w = t; w < 2 * (16 * P.K + 8); w += NT) put_ll(P.xtag + w, (w & 1) ? __double2hiint(s.x0[w >> 1]) : __double2loint(s.x0[w >> 1]));      // (the sweep roles of a persistent solve poll these)
             __syncthreads();
             if (t < 64) end_iter();      // (a late helper may still be copying Ctl into its LDS)
             return;
@@ -1964,6 +1972,8 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     PROF(22);
     // (every wait of the master is behind it here: a workgroup that gives up later than this is a helper waiting for the master, and the next launch's waits see its word)
     if (t == 0 && P.abortf) abort_pre = ld_ag(P.abortf);
+    // persistent solve: the helpers' la / lb (read by the visual roles of the NEXT iteration) are out -- their flags are collected by the spare wave under the dogleg's scalars
+    if (FUSED && P.persist && t >= NT - 64) { if ((t & 63) < nhelp) spin_until_eq(P.hflag2 + (t & 63), epoch, P.abortf); __builtin_amdgcn_wave_barrier(); if (t == NT - 64) s.pad0_ = epoch; }
     // ---------------- traditional dogleg in dogleg space (scalars saved with the linearisation) ----------------
     gn2 = s.c.gn2; g2 = s.c.g2; gg = s.c.gg;
     const double radius = s.c.radius, alpha = s.c.alpha, mu_u = s.c.mu_used;
@@ -2022,15 +2032,19 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     {   // the candidate's camera part leaves in one pass (a re-sweep: the current state again)
         const bool back = s.c.resweep && !s.c.done;
         for (int i = t; i < 16 * P.K + 8; i += NT) stx<FUSED>(xc + i, back ? s.x0[i] : xcs[i]);
+        // persistent solve: the same values as 64-bit words {half of a value, epoch} -- the sweep roles of the next iteration poll THEM (data and flag in one round trip)
+        if (FUSED && P.persist) for (int w = t; w < 2 * (16 * P.K + 8); w += NT) { const double v = back ? s.x0[w >> 1] : xcs[w >> 1]; put_ll(P.xtag + w, (w & 1) ? __double2hiint(v) : __double2loint(v)); }
     }
     STAMP(7);
     if (t < 64) end_iter();      // (no second poll when the sums were already collected)
     PROF(12);
 }
 
+#ifndef VIL_PERSIST_TU
 template <bool LDSM, int CHAIN = 0>
 __global__ __launch_bounds__(VIL_STEP_THREADS) void k_step(DevP P, SolveOpts O) {
     __shared__ vd::StepShared s;
     extern __shared__ double Alds[];
     step_body<LDSM, CHAIN, false>(P, O, s, Alds, (int)blockIdx.x);
 }
+#endif

@@ -15,6 +15,11 @@
 //   [prior]   n x n gemv on the pre-contracted J0^T J0
 //   [rel]     ICP and LPS AutoDiff factors (scalar forward-mode duals, thread = (factor, block, coordinate))
 #pragma once
+#ifdef VIL_PERSIST_TU
+#define VIL_X_IN_LDS true       // this translation unit's one-launch roles are k_solve's: the camera part of the state comes as the workgroup's LDS copy
+#else
+#define VIL_X_IN_LDS false
+#endif
 #include "vil_dev.hpp"
 #include "vil_factors.hpp"
 #include "vil_finish.hpp"
@@ -25,7 +30,7 @@ namespace vd {
 __device__ __forceinline__ double block_sum(double v, double* red /*>= 4 doubles*/) {
     v = wave_sum(v);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    if ((vil_tid() & 63) == 0) red[vil_tid() >> 6] = v;
     __syncthreads();
     double t = 0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
@@ -33,9 +38,10 @@ __device__ __forceinline__ double block_sum(double v, double* red /*>= 4 doubles
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int f, const double* x, double* sm, const int plaunch = -1, const bool chain_rec = false /* one-launch iteration: what the chain workgroup gathers also leaves as a compact record (chain_rec_index, vil_dev.hpp) */, const int chain_epoch = 0) {
+__device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int f, const double* x, double* sm, const int plaunch = -1, const bool chain_rec = false /* one-launch iteration: what the chain workgroup gathers also leaves as a compact record (chain_rec_index, vil_dev.hpp) */, const int chain_epoch = 0,
+                                          const bool x_lds = false /* persistent solve: x is the workgroup's copy in LDS */, const bool resident = false /* ... and the factor's constants, sqrt-information and constancy flags are in LDS since the solve's first iteration */) {
     double* const outc = chain_rec ? P.irec + (size_t)f * VIL_CHAIN_REC : nullptr;
-    #define IPROF(k) do { if (plaunch >= 0 && f == 0 && threadIdx.x == 0) prof_stamp(P, plaunch, k); } while (0)
+    #define IPROF(k) do { if (plaunch >= 0 && f == 0 && vil_tid() == 0) prof_stamp(P, plaunch, k); } while (0)
     IPROF(16);
     double* Jraw = sm;            // 450
     double* rr = sm + 450;        // 15
@@ -46,7 +52,7 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
     double* xs = sm + 1480;       // 32: pose i | speed-bias i | pose j | speed-bias j
     const double* c = P.imu_c + (size_t)f * 287;
     double* out = P.ipart + (size_t)f * 931;
-    const int t = threadIdx.x;
+    const int t = vil_tid();
     const int i = P.imu_i[f], j = P.imu_j[f];
     // (one-launch iteration: the order in which the record's entries are formed, P.imu_perm, is asked for HERE -- behind the whitening's barrier it was a dependent
     //  round trip to memory on the path the chain workgroup waits for)
@@ -57,17 +63,16 @@ __device__ __forceinline__ void sweep_imu(const DevP& P, const SolveOpts& O, int
     // the constants of every lane, then U inside the whitening loop -- three dependent round trips on the path the chain workgroup waits for)
     {
         double v = 0.0;
-        if (t < 287) v = c[t];
-        else if (t < 512) v = P.imu_U[(size_t)f * 225 + (t - 287)];
+        if (!resident) { if (t < 287) v = c[t]; else if (t < 512) v = P.imu_U[(size_t)f * 225 + (t - 287)]; }
         double xv = 0.0;
-        if (t < 32) { const int q = t < 7 ? xo_pose(P, i) + t : (t < 16 ? xo_sb(P, i) + (t - 7) : (t < 23 ? xo_pose(P, j) + (t - 16) : xo_sb(P, j) + (t - 23))); xv = chain_rec ? ld_ag(x + q) : x[q]; }      // (one-launch iteration / persistent solve: the candidate crosses from the master workgroup at agent scope)
-        if (t >= 32 && t < 36 && !P.marg) {      // constancy of the four blocks (pose i, speed-bias i, pose j, speed-bias j): in the same round trip, not in front of the whitening
+        if (t < 32) { const int q = t < 7 ? xo_pose(P, i) + t : (t < 16 ? xo_sb(P, i) + (t - 7) : (t < 23 ? xo_pose(P, j) + (t - 16) : xo_sb(P, j) + (t - 23))); xv = (chain_rec && !x_lds) ? ld_ag(x + q) : x[q]; }      // (one-launch iteration: the candidate crosses from the master workgroup at agent scope)
+        if (t >= 32 && t < 36 && !P.marg && !resident) {      // constancy of the four blocks (pose i, speed-bias i, pose j, speed-bias j): in the same round trip, not in front of the whitening
             const uint8_t* cp = (t & 1) ? P.sb_const : P.pose_const;
             xv = (cp && cp[t < 34 ? i : j]) ? 1.0 : 0.0;
         }
         for (int e = t; e < 450; e += blockDim.x) Jraw[e] = 0.0;
-        if (t < 287) cs[t] = v; else if (t < 512) Us[t - 287] = v;
-        if (t < 36) xs[t] = xv;      // (xs[32 .. 35]: constancy flags)
+        if (!resident) { if (t < 287) cs[t] = v; else if (t < 512) Us[t - 287] = v; }
+        if (t < (resident ? 32 : 36)) xs[t] = xv;      // (xs[32 .. 35]: constancy flags)
     }
     __syncthreads();
     IPROF(17);
@@ -185,7 +190,7 @@ __host__ __device__ inline int vis_slots(int T) { return (vis_ntile(T) + 7) >> 3
 // AG: what the workgroup leaves for other workgroups of the SAME launch (the one-launch iteration, vil_iter.hpp: record, landmark arrays) is stored at agent scope
 template <int TS, bool AG = false>      // accumulator tiles per wave: 2 (windows whose widest chunk has T <= 5 column tiles: K <= 12) or 5 (T <= 8: K <= 20); a kernel per value
 __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, const Ctl& ctl, int wg, const double* x, SysBuf& sb, double* sm) {
-    const int t = threadIdx.x;
+    const int t = vil_tid();
     const int4 d0 = ((const int4*)P.vwg)[2 * wg], d1 = ((const int4*)P.vwg)[2 * wg + 1];      // {first sorted landmark, landmarks, first sorted factor, factors}, {fa, span, T, record offset / 16}
     const int p0 = d0.x, nl = d0.y, fp0 = d0.z, nf = d0.w, fa0 = d1.x, span = d1.y, T = d1.z;
     const int RS = vis_rs(T), ntile = vis_ntile(T), nrow = vis_rows(nf);
@@ -235,8 +240,8 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
         //  current inverse depths by a visual workgroup of an earlier iteration: all cross at agent scope; the other launch structures read them behind a launch boundary)
         double pi[7], pj[7], ex[7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) { pi[k] = ldx<AG>(x + xo_pose(P, i) + k); pj[k] = ldx<AG>(x + xo_pose(P, j) + k); ex[k] = ldx<AG>(x + xo_ex(P) + k); }
-        const double tdv = ldx<AG>(x + xo_td(P));
+        for (int k = 0; k < 7; ++k) { pi[k] = ldx<AG && !VIL_X_IN_LDS>(x + xo_pose(P, i) + k); pj[k] = ldx<AG && !VIL_X_IN_LDS>(x + xo_pose(P, j) + k); ex[k] = ldx<AG && !VIL_X_IN_LDS>(x + xo_ex(P) + k); }      // (VIL_X_IN_LDS: the persistent solve hands its roles the workgroup's copy of the camera part in LDS)
+        const double tdv = ldx<AG && !VIL_X_IN_LDS>(x + xo_td(P));
         VisJ o;
         const double lam = stepped ? ldx<AG>(xcur + xo_lam(P) + l) + cg * ldx<AG>(P.la + l) + cn * ldx<AG>(P.lb + l) : ldx<AG>(xcur + xo_lam(P) + l);
         if (O.precision)
@@ -398,13 +403,13 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
 template <int NR, bool AG = false>
 __device__ __forceinline__ void sweep_lidar(const DevP& P, const SolveOpts& O, int wgc, const double* x, double* sm) {
     const int per = blockDim.x >> 8;                    // 256-point chunks per workgroup
-    const int sub = threadIdx.x >> 8;
+    const int sub = vil_tid() >> 8;
     const int nchunk = NR == 1 ? P.n_pchunk : P.n_echunk;
     const int chunk = wgc * per + sub;
     const bool have = chunk < nchunk;
     const int* ch = (NR == 1 ? P.pchunk : P.echunk) + 3 * (have ? chunk : 0);
     const int start = ch[0], cnt = have ? ch[1] : 0, k = ch[2];
-    const int t = threadIdx.x & 255;
+    const int t = vil_tid() & 255;
     sm += sub * 128;
     const double* pose = x + xo_pose(P, k);
     const bool cst = !P.marg && P.pose_const && P.pose_const[k];
@@ -467,7 +472,7 @@ __device__ inline const double* prior_block_ptr(const DevP& P, const double* x, 
 // [prior] workgroup: r = r0 + J0 dx ;  J0^T J0 = pH, J0^T r0 = pg0, r0^T r0 = pc0 are pre-contracted, so the prior costs
 // one n x n gemv (n <= 136: K <= 20).
 __device__ __forceinline__ void sweep_prior(const DevP& P, const double* x, double* sm) {
-    const int t = threadIdx.x;
+    const int t = vil_tid();
     if (P.pn <= 0) return;
     const int n = P.pn;
     double* dx = sm;           // n
@@ -516,7 +521,7 @@ __device__ __forceinline__ void sweep_prior(const DevP& P, const double* x, doub
 // [rel] workgroup: the scan-to-scan ICP and LPS AutoDiff factors
 template <bool AG = false>
 __device__ __forceinline__ void sweep_misc(const DevP& P, const SolveOpts& O, const double* x, double* sm) {
-    const int t = threadIdx.x;
+    const int t = vil_tid();
     // ---- ICP (4 pose blocks) and LPS (2 pose blocks): thread per (factor, block) ----------------------------
     double* Jb = sm;              // up to 12 factors x 4 blocks x 21
     double* rb = sm + 12 * 84;    // 12 x 3
@@ -618,15 +623,15 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
             // (ONE word per group of roles, published by the master workgroup -- vil_step.hpp: it polls the roles' flags once for everybody.  Every gather workgroup
             //  polling every role's flag was n_gather x n_sweep lanes on a few dozen cache lines: 166 x 1700 at configs[2], where the gather saw the visual flags
             //  4.3 us after the last visual record)
-            if (threadIdx.x == 0) spin_until_eq(P.sall + (visual ? 32 : 16), epoch, P.abortf);
+            if (vil_tid() == 0) spin_until_eq(P.sall + (visual ? 32 : 16), epoch, P.abortf);
             __syncthreads();
-            if (visual && threadIdx.x == 0) prof_stamp(P, epoch - 1, 6);
+            if (visual && vil_tid() == 0) prof_stamp(P, epoch - 1, 6);
         }
     };
-    if ((int)threadIdx.x >= 8 * EPW) return;
+    if (vil_tid() >= 8 * EPW) return;
     const int cand = 1 - ctl.cur;
     SysBuf sb = P.sys[cand];
-    const int D = P.D, NV = P.NV, K = P.K, t = threadIdx.x;
+    const int D = P.D, NV = P.NV, K = P.K, t = vil_tid();
     const int n_rel = P.n_icp + P.n_lps;
     const double* rel0 = P.mpart + (P.pn > 0 ? P.pn + 1 : 0);
     const int NL = (D * (D + 1)) >> 1, NVT = (NV * (NV + 1)) >> 1;
@@ -805,6 +810,7 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
     if (t == 0) { double tot = 0.0; for (int w = 0; w < EPW / 8; ++w) tot += red[w]; put(sb.cost, tot); }      // (EPW / 8 waves)
 }
 
+#ifndef VIL_PERSIST_TU
 // Gather of the sweep's partial records (reduce_gather above) as a launch of its own: vil_linearize / the marginalisation (no step kernel
 // behind it), the multi-GPU path (the collective sits between gather and step) and windows too large for the merged launch -- for
 // those the grid carries one more workgroup per 16 x 16 tile of W W^T (vil_prechain.hpp; n_gather = the gather workgroups).  A solve of a
@@ -816,6 +822,7 @@ __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P, int n_gather) {
     __shared__ int4 vtab[VIS_TAB];
     reduce_gather(P, ctl, (int)blockIdx.x, vtab);
 }
+#endif
 
 // the IMU / prior workgroup `slot` of this launch has written its record (read by the chain workgroup of the same launch, prechain 2).
 // Epoch of the flags: solve generation + Ctl::swe, which only the step kernel advances.
@@ -824,7 +831,7 @@ __global__ __launch_bounds__(VIL_THREADS) void k_reduce(DevP P, int n_gather) {
 __device__ __forceinline__ void sweep_signal(const DevP& P, const Ctl& ctl, int slot) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores of the record (__syncthreads alone does not wait for global stores)
     __syncthreads();
-    if (threadIdx.x == 0) vd::st_ag(P.swflag + slot, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u));
+    if (vil_tid() == 0) vd::st_ag(P.swflag + slot, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.swe + 1u));
 }
 
 // The sweep: grid = n_imu + 2 (+ 1: prechain 2) + n_vwg + ceil(n_pchunk / 2) + ceil(n_echunk / 2) workgroups of VIL_SWEEP_THREADS threads.
@@ -834,32 +841,32 @@ __device__ __forceinline__ void sweep_signal(const DevP& P, const Ctl& ctl, int 
 // and every workgroup ends by posting the launch epoch in P.sflag[b] (the gather workgroups wait for all of them, the chain workgroup for the IMU / prior ones)
 #define VIL_XSTAGE 2048      // doubles into a sweep role's dynamic LDS where a one-launch role keeps its copy of the state's camera part (16 K + 8 <= 328 doubles)
 template <int TS, bool FUSED>      // TS: accumulator tiles per wave of the visual role
-__device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, const Ctl& ctl, double* const sm, const int blk) {
+__device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, const Ctl& ctl, double* const sm, const int blk, const double* const xlds = nullptr, const bool imu_resident = false) {
     const int cand = 1 - ctl.cur;
-    const double* x = P.x[cand];
+    const double* x = (FUSED && VIL_X_IN_LDS) ? xlds : P.x[cand];
     SysBuf sb = P.sys[cand];
     int b = blk;
     const bool pre = !FUSED && P.prechain == 2 && ctl.lin_mode == 0;
-    if (FUSED && threadIdx.x == 0) prof_stamp(P, ctl.n_sweeps, 0, true);
+    if (FUSED && vil_tid() == 0) prof_stamp(P, ctl.n_sweeps, 0, true);
     auto posted = [&]() {
         if constexpr (FUSED) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores of the record (__syncthreads alone does not wait for global stores)
             __syncthreads();
-            if (threadIdx.x == 0 && !(blk == P.drop_role && ctl.n_sweeps == P.drop_launch)) { const int ep = (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u); vd::st_ag(P.sflag + blk, ep); if (blk < P.n_imu) vd::st_ag(P.cflag + blk, ep); prof_stamp(P, ctl.n_sweeps, blk < P.n_imu ? 2 : (blk == P.n_imu ? 15 : 1)); }      // (an IMU role's chain flag: up already unless the role left early)
+            if (vil_tid() == 0 && !(blk == P.drop_role && ctl.n_sweeps == P.drop_launch)) { const int ep = (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u); vd::st_ag(P.sflag + blk, ep); if (blk < P.n_imu) vd::st_ag(P.cflag + blk, ep); prof_stamp(P, ctl.n_sweeps, blk < P.n_imu ? 2 : (blk == P.n_imu ? 15 : 1)); }      // (an IMU role's chain flag: up already unless the role left early)
         }
     };
     // FUSED: the prior, ICP / LPS and LiDAR roles hand pointers into the state to the factor code -- they read the camera part from a copy in LDS, fetched at agent scope
     // (sm + VIL_XSTAGE: past what any of these roles uses, inside what every one-launch workgroup owns)
     auto xstage = [&]() -> const double* {
-        if constexpr (!FUSED) return x;
+        if constexpr (!FUSED || VIL_X_IN_LDS) return x;
         else {
             double* xl = sm + VIL_XSTAGE;
-            for (int e = threadIdx.x; e < 16 * P.K + 8; e += blockDim.x) xl[e] = vd::ld_ag(x + e);
+            for (int e = vil_tid(); e < 16 * P.K + 8; e += blockDim.x) xl[e] = vd::ld_ag(x + e);
             __syncthreads();
             return xl;
         }
     };
-    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm, FUSED ? ctl.n_sweeps : -1, FUSED, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u)); if (pre) sweep_signal(P, ctl, b); posted(); return; }
+    if (b < P.n_imu) { if (!(P.skip_mask & 2)) vd::sweep_imu(P, O, b, x, sm, FUSED ? ctl.n_sweeps : -1, FUSED, (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u), FUSED && VIL_X_IN_LDS, imu_resident); if (pre) sweep_signal(P, ctl, b); posted(); return; }
     b -= P.n_imu;
     if (b == 0) { if (!(P.skip_mask & 16)) vd::sweep_prior(P, xstage(), sm); if (pre) sweep_signal(P, ctl, P.n_imu); posted(); return; }
     if (b == 1) {
@@ -868,7 +875,7 @@ __device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, co
             const double* xcur = P.x[ctl.cur];           // the landmarks it owns; every rank holds la / lb of ALL landmarks (the step kernel runs on the all-reduced
             double* xcand = P.x[1 - ctl.cur];            // system), so the rest is filled in here and the states stay identical on all ranks
             const bool stepped = ctl.cg != 0.0 || ctl.cn != 0.0;      // (as in sweep_visual: stale la / lb are not multiplied by zero)
-            for (int l = threadIdx.x; l < P.L; l += blockDim.x) xcand[xo_lam(P) + l] = stepped ? xcur[xo_lam(P) + l] + ctl.cg * P.la[l] + ctl.cn * P.lb[l] : xcur[xo_lam(P) + l];
+            for (int l = vil_tid(); l < P.L; l += blockDim.x) xcand[xo_lam(P) + l] = stepped ? xcur[xo_lam(P) + l] + ctl.cg * P.la[l] + ctl.cn * P.lb[l] : xcur[xo_lam(P) + l];
         }
         posted();
         return;
@@ -888,11 +895,13 @@ __device__ __forceinline__ void sweep_body(const DevP& P, const SolveOpts& O, co
     posted();
 }
 
+#ifndef VIL_PERSIST_TU
 template <int TS>
 __global__ __launch_bounds__(VIL_SWEEP_THREADS) void k_sweep(DevP P, SolveOpts O) {
     extern __shared__ double sm[];
     const Ctl ctl = *P.ctl;
     if (ctl.done) return;                                // (the result of a finished solve is written out by k_finish, vil_finish.hpp)
-    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctl->n_sweeps = ctl.n_sweeps + 1;   // live (not early-exited) launches, for the profiler
+    if (blockIdx.x == 0 && vil_tid() == 0) P.ctl->n_sweeps = ctl.n_sweeps + 1;   // live (not early-exited) launches, for the profiler
     sweep_body<TS, false>(P, O, ctl, sm, (int)blockIdx.x);
 }
+#endif

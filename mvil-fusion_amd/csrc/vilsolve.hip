@@ -33,6 +33,10 @@
 #include "vil_marg.hpp"
 #include "vil_window.hpp"
 
+// vilpersist.hip: the persistent solve kernel k_solve<2 | 5> (compiled in its own translation unit: vil_math.hpp, VIL_OPAQUE_TID)
+const void* vil_k_solve_fn(int vis_ts);
+void vil_k_solve_launch(int vis_ts, unsigned grid, size_t lds, hipStream_t stream, const DevP& P, const SolveOpts& O, long long budget_ticks);
+
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[vilsolve] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return VIL_ERR_DEVICE; } } while (0)
 
 namespace {
@@ -262,6 +266,7 @@ struct vil_ctx {
     std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
     int n_blocks_sweep = 0, n_blocks_reduce = 0, n_blocks_reduce_po = 0, n_gather_m = 0, n_ww = 0;      // n_ww: tiles of W W^T formed by extra workgroups of k_reduce (vil_prechain.hpp)
     size_t lds_sweep = 0, lds_step = 0, lds_reduce = 0;
+    bool persist = false; size_t lds_solve = 0; int cap_solve[2] = {-1, -1}; size_t cap_solve_lds[2] = {0, 0}; int attr_solve[2] = {0, 0};      // the whole solve in one resident launch (k_solve<2 | 5>, vil_iter.hpp)
     bool fused = false; size_t lds_iter = 0; int cap_iter[2] = {-1, -1}; size_t cap_iter_lds[2] = {0, 0}; int attr_iter[2] = {0, 0};      // the one-launch iteration (k_iter<2 | 5>, vil_iter.hpp)
     int cap_step3 = -1; size_t cap_step3_lds = 0;      // workgroups of the merged gather + step launch the device holds at once AT THAT dynamic-LDS size (vil_coop.hpp)
     int vis_gm = 0;                      // doubles of operand rows the largest visual chunk of the uploaded window needs (vil_sweep.hpp)
@@ -344,7 +349,7 @@ struct vil_ctx {
         double* pc0(int w) const { return pg0(w) + nmax; }
         size_t prior_doubles() const { return 2 * (size_t)nmax * nmax + 2 * (size_t)nmax + x0max + 8; }
     } win;
-    bool profiling = false;
+    bool profiling = false, stamps = false; long long period_n = 0;
     int wg_launch = -1;      // (vil_profile_workgroups)
     long long* d_prof = nullptr; double phase_us[VIL_PROF_SLOTS] = {0}; long long phase_n = 0;      // phase stamps of the one-launch iterations (vil_profile_phases)
     std::vector<hipEvent_t> ev, ev_mid, ev_coll;
@@ -1020,6 +1025,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         put(nullptr, 64, (void**)&P.chflag); put(nullptr, 4 * 64, (void**)&P.wwflag); put(nullptr, 4 * (size_t)(K + 8), (void**)&P.swflag);
         put(nullptr, 4 * 64, (void**)&P.sall);
         put(nullptr, 4 * (size_t)VIL_SFLAG_MAX, (void**)&P.sflag);      // one flag per sweep workgroup of a one-launch iteration (taken only when there are fewer: below)
+        put(nullptr, 256, (void**)&P.ihdr); put(nullptr, 8 * 2 * (size_t)(16 * K + 8), (void**)&P.xtag);
         put(nullptr, 64, (void**)&P.abortf);      // (raised by a wait on another workgroup's flag that gives up: vil_math.hpp, spin_until_eq)
         { const size_t Tp = (size_t)(NV + 1 + 15) / 16; put(nullptr, 8 * (size_t)TILE_SZ * (Tp * (Tp + 1) / 2), (void**)&P.chWW); }
         put(nullptr, 8 * (size_t)VIL_CHC_MAX, (void**)&P.chc);
@@ -1210,7 +1216,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         // (round 4: every window size -- the gather of a prechain solve forms the visual sub-space only, 551 workgroups at K = 20 instead of 1500)
         int kmerge = 20;
         if (const char* ev = VIL_TUNE_ENV("VIL_MERGE_K")) kmerge = atoi(ev);
-        bool merged = can_pre && (c->launch_mode == 0 || c->launch_mode == 3) && K <= kmerge && std::max(lds3, ldsc) + step_static_lds((const void*)k_step<true, 3>) + 256 <= 160 * 1024 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
+        bool merged = can_pre && (c->launch_mode == 0 || c->launch_mode == 3 || c->launch_mode == 4) && K <= kmerge && std::max(lds3, ldsc) + step_static_lds((const void*)k_step<true, 3>) + 256 <= 160 * 1024 && VIL_TUNE_ENV("VIL_NO_MERGE") == nullptr;
         if (merged) {
             // the merged launch holds workgroups that spin on flags (master, helpers, one per W W^T tile) next to the finite ones they wait for (chain,
             // gather: lower block indices, dispatched first).  It is only taken when the device can hold every spinning workgroup AND one more at the
@@ -1243,8 +1249,8 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         // ---- the whole iteration in ONE launch (k_iter, vil_iter.hpp): whenever the merged gather + step launch is taken, the kernel's single dynamic-LDS size
         //      (the larger of the sweep roles' and the step roles' needs -- StepShared and the gather / tile scratch are carved from it) fits a compute unit, and
         //      the device holds the workgroups that wait for one another (master, helpers, tiles) at once.  vil_debug_set_launch_mode(3) keeps the two launches.
-        c->fused = false; c->P.n_sw = 0;
-        if (merged && g64 && c->launch_mode == 0 && c->n_blocks_sweep <= VIL_SFLAG_MAX && VIL_TUNE_ENV("VIL_NO_FUSE") == nullptr) {
+        c->fused = false; c->persist = false; c->P.n_sw = 0;
+        if (merged && g64 && (c->launch_mode == 0 || c->launch_mode == 4) && c->n_blocks_sweep <= VIL_SFLAG_MAX && VIL_TUNE_ENV("VIL_NO_FUSE") == nullptr) {
             const size_t scratch = 8 * (size_t)(2 * VIS_TAB + 2 * 8 * (VIL_STEP_THREADS / 8) + 160);      // gather role: descriptor table | part[2][512] | index tables | red
             const size_t step_need = 8 * (size_t)VIL_SS_DOUBLES + std::max(std::max(lds3, ldsc), scratch);
             const size_t li = std::max(c->lds_sweep, step_need);
@@ -1255,6 +1261,20 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
                 if (c->cap_iter[v] < 0 || c->cap_iter_lds[v] != li) { c->cap_iter[v] = vilcoop::capacity(fn, VIL_STEP_THREADS, li, c->device); c->cap_iter_lds[v] = li; }
                 const int Tw = (int)(Tp_ * (Tp_ + 1) / 2);
                 if (c->cap_iter[v] >= 1 + P.n_help + Tw + 2) { c->fused = true; c->lds_iter = li; c->P.n_sw = c->n_blocks_sweep; }
+                // ---- the whole SOLVE in one resident launch (k_solve): the grid [sweep roles | chain | master | helpers | tiles] must fit the device at once with two
+                //      workgroups to spare, and every gather item must find a workgroup that takes it as a duty (tiles, helpers, sweep roles): configs[1]-sized
+                //      windows.  Everything else keeps one launch per iteration.  vil_debug_set_launch_mode(4) keeps k_iter.
+                if (c->fused && c->launch_mode == 0 && VIL_TUNE_ENV("VIL_NO_PERSIST") == nullptr) {
+                    const size_t sweep_need = 8 * (size_t)(VIL_LC_DOUBLES + VIL_XL_DOUBLES) + std::max(c->lds_sweep, 8 * (size_t)2048 + scratch);      // [Ctl copy | state copy | role arrays (IMU roles: gather scratch behind them)]
+                    const size_t ls = std::max(sweep_need, step_need);
+                    const void* fs = vil_k_solve_fn(P.vis_ts);
+                    if (ls <= 160 * 1024 && K <= 15) {
+                        if ((int)ls > c->attr_solve[v]) { HIPCHK(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ls)); c->attr_solve[v] = (int)ls; }
+                        if (c->cap_solve[v] < 0 || c->cap_solve_lds[v] != ls) { c->cap_solve[v] = vilcoop::capacity(fs, VIL_STEP_THREADS, ls, c->device); c->cap_solve_lds[v] = ls; }
+                        const int grid = c->n_blocks_sweep + 2 + P.n_help + Tw, n_cap = c->n_blocks_sweep + P.n_help + Tw;
+                        if (grid + 2 <= c->cap_solve[v] && c->n_gather_m <= n_cap) { c->persist = true; c->lds_solve = ls; }
+                    }
+                }
             }
         }
     }
@@ -1517,6 +1537,13 @@ static int launch_iter(vil_ctx* c, const SolveOpts& so) {
     else hipLaunchKernelGGL(k_iter<5>, g, b, c->lds_iter, c->stream, Pi, so);
     return VIL_OK;
 }
+// the whole solve as ONE resident launch (vil_iter.hpp, k_solve); budget_ticks: what is left of max_time_s on the device's 100 MHz clock (0: no cap)
+static int launch_solve(vil_ctx* c, const SolveOpts& so, long long budget_ticks) {
+    DevP Pi = c->P;
+    Pi.gather_pose_only = 1; Pi.prof = c->stamps ? c->d_prof : nullptr; Pi.wg_launch = -1; Pi.persist = 1;
+    vil_k_solve_launch(c->P.vis_ts, (unsigned)(c->n_blocks_sweep + 2 + c->P.n_help + c->n_ww), c->lds_solve, c->stream, Pi, so, budget_ticks);      // [sweep roles | chain | master | helpers | W W^T tiles]
+    return VIL_OK;
+}
 static int launch_reduce_step(vil_ctx* c, const SolveOpts& so, bool step, hipEvent_t ev_mid = nullptr, hipEvent_t ev_coll = nullptr) {
     const bool merged = step && c->P.rs_merged;          // one GPU: the gather rides in the step kernel's launch (vil_step.hpp)
     // (chain eliminated inside k_sweep: one workgroup per W W^T tile rides in the gather launch, one for the inverses of the chain's diagonal blocks in the step launch;
@@ -1574,7 +1601,8 @@ int vil_profile_enable(vil_ctx* c, int on) {
     HIPCHK(hipSetDevice(c->device));
     if (on && c->ev.empty()) { c->ev.resize(2 * VIL_MAX_CHUNK + 2); for (auto& e : c->ev) HIPCHK(hipEventCreate(&e)); c->ev_mid.resize(VIL_MAX_CHUNK + 1); for (auto& e : c->ev_mid) HIPCHK(hipEventCreate(&e)); c->ev_coll.resize(VIL_MAX_CHUNK + 1); for (auto& e : c->ev_coll) HIPCHK(hipEventCreate(&e)); }
     if (on && !c->d_prof) { HIPCHK(hipMalloc((void**)&c->d_prof, 8 * (64 * VIL_PROF_SLOTS + 2 * VIL_PROF_WGS))); HIPCHK(hipMemset(c->d_prof, 0, 8 * (64 * VIL_PROF_SLOTS + 2 * VIL_PROF_WGS))); }
-    c->profiling = on != 0;
+    c->profiling = on == 1;
+    c->stamps = on == 2;          // 2: the phase stamps alone -- the launch structure stays the library's choice (the persistent solve keeps its one launch; no events)
     return VIL_OK;
 }
 /* average position (us after the launch's first workgroup started) of the phase stamps of the one-launch iterations timed since the last reset:
@@ -1586,8 +1614,9 @@ int vil_profile_enable(vil_ctx* c, int on) {
 int vil_profile_phases(vil_ctx* c, double* avg_us, int64_t* launches, int reset) {
     if (!c || !avg_us) return VIL_ERR_INVALID_ARGUMENT;
     for (int k = 0; k < VIL_PROF_SLOTS; ++k) avg_us[k] = c->phase_n ? c->phase_us[k] / (double)c->phase_n : 0.0;
+    avg_us[0] = c->period_n ? c->phase_us[0] / (double)c->period_n : 0.0;      // [0]: average iteration period inside a persistent solve (0: launches)
     if (launches) *launches = c->phase_n;
-    if (reset) { for (double& v : c->phase_us) v = 0.0; c->phase_n = 0; }
+    if (reset) { for (double& v : c->phase_us) v = 0.0; c->phase_n = 0; c->period_n = 0; }
     return VIL_OK;
 }
 int vil_profile_read(vil_ctx* c, vil_profile* out, int reset) {
@@ -1617,9 +1646,10 @@ static int solve_attempt(vil_ctx* c, const vil_options* o, vil_summary* sum, con
     const SolveOpts so = to_dev_opts(o);
     c->mirror_state = false;
     *gave_up = false;
+    const bool persist = c->persist && c->fused && !c->split && !c->profiling;      // (the phase stamps and the per-launch events belong to the one-launch iteration)
     int st = init_ctl(c, o, 0);
     if (st != VIL_OK) return st;
-    if (c->profiling && c->fused && c->d_prof) HIPCHK(hipMemsetAsync(c->d_prof, 0, 8 * 64 * VIL_PROF_SLOTS, c->stream));
+    if ((c->profiling || (c->stamps && persist)) && c->fused && c->d_prof) HIPCHK(hipMemsetAsync(c->d_prof, 0, 8 * 64 * VIL_PROF_SLOTS, c->stream));
     // every iteration = sweep + gather + step kernel; `done` turns the tail of a chunk into no-ops, and the first sweep launch that finds
     // the solve finished writes the result out (vil_finish.hpp); k_finish at the end of every chunk covers a solve that ends in its last iteration
     bool finished = false, polled_done = false;
@@ -1643,7 +1673,7 @@ static int solve_attempt(vil_ctx* c, const vil_options* o, vil_summary* sum, con
         // launched directly (whether a given RCCL build captures correctly is not something this path bets the multi-GPU run on); the in-process
         // communicator synchronises on the host.  Polling the finished solve's mirror works for everything that is in stream order.
         const bool no_graph = c->split && !c->ipc;
-        if (c->use_graph && c->solves_since_upload > 0 && !c->profiling && !no_graph && !c->graph_failed && !direct && nthis > 0) {      // (direct: a retry, or a solve with a debug hook in its parameter block)
+        if (c->use_graph && c->solves_since_upload > 0 && !c->profiling && !no_graph && !c->graph_failed && !direct && !persist && nthis > 0) {      // (direct: a retry, or a solve with a debug hook in its parameter block)
             hipGraphExec_t exec = nullptr;
             for (auto& g : c->graphs) if (g.n == nthis && memcmp(&g.so, &so, sizeof so) == 0) exec = g.exec;
             if (!exec) {
@@ -1671,6 +1701,14 @@ static int solve_attempt(vil_ctx* c, const vil_options* o, vil_summary* sum, con
                 }
             }
             if (exec) { HIPCHK(hipGraphLaunch(exec, c->stream)); it += nthis; launched = nthis; }
+        }
+        if (launched == 0 && persist) {
+            // ONE launch runs every iteration and writes the result out; the time cap travels with it (the master reads the device clock where ceres reads its own)
+            long long ticks = 0;
+            if (o->max_time_s > 0) ticks = std::max(1LL, (long long)((o->max_time_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()) * 1e8));
+            st = launch_solve(c, so, ticks);
+            if (st != VIL_OK) return st;
+            launched = 1; it = o->max_iterations + 9;
         }
         if (launched == 0) {
             for (int q = 0; q < chunk && it <= o->max_iterations + 8; ++q, ++it, ++launched) {
@@ -1745,7 +1783,7 @@ static int solve_attempt(vil_ctx* c, const vil_options* o, vil_summary* sum, con
     c->solves_since_upload++;
     c->last_live = ctl.n_sweeps;
     c->recent_live[c->recent_at++ & 7] = ctl.n_sweeps;
-    if (c->profiling && c->fused && c->d_prof && ctl.n_sweeps <= 64) {
+    if ((c->profiling || (c->stamps && persist)) && c->fused && c->d_prof && ctl.n_sweeps <= 64) {
         // the launches' own clock stamps (100 MHz): the sweep phase of a one-launch iteration = first workgroup started -> last sweep role posted
         std::vector<unsigned long long> hp((size_t)64 * VIL_PROF_SLOTS);
         HIPCHK(hipMemcpyAsync(hp.data(), c->d_prof, 8 * hp.size(), hipMemcpyDeviceToHost, c->stream));
@@ -1756,6 +1794,7 @@ static int solve_attempt(vil_ctx* c, const vil_options* o, vil_summary* sum, con
             const unsigned long long t0 = ~r[0];
             for (int k = 1; k < VIL_PROF_SLOTS; ++k) if (r[k] >= t0) c->phase_us[k] += (double)(r[k] - t0) * 0.01;
             c->phase_n++;
+            if (q + 1 < ctl.n_sweeps && r[VIL_PROF_SLOTS]) { c->phase_us[0] += (double)(~r[VIL_PROF_SLOTS] - t0) * 0.01; c->period_n++; }      // (persistent solve: first role of this iteration -> first role of the next)
             const double sweep_us = (double)(r[1] - t0) * 0.01, gather_us = r[5] > r[1] ? (double)(r[5] - r[1]) * 0.01 : 0.0;
             c->prof.sweep_ms += sweep_us * 1e-3; c->prof.step_ms -= sweep_us * 1e-3; c->prof.reduce_ms += gather_us * 1e-3;      // (the events gave the whole launch to step_ms)
         }
@@ -1811,10 +1850,20 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     };
     st = restore();
     if (st != VIL_OK) return st;
-    if (c->fused && !c->split) {
-        c->fused = false;                              // (the upload prepared the merged gather + step launch as well: the one-launch iteration is only taken where that one is)
+    if (c->persist && c->fused && !c->split && !c->profiling) {
+        // the resident solve needs EVERY workgroup of its grid on the device at once; one launch per iteration only the handful that wait for one another
+        c->persist = false;
         st = solve_attempt(c, o, sum, t0, true, &gave_up);
-        c->fused = true;                               // the next solve is a one-launch solve again
+        c->persist = true;
+        if (!gave_up) { c->P.drop_role = -1; c->P.drop_launch = -1; c->n_recovered++; return st; }
+        st = restore();
+        if (st != VIL_OK) return st;
+    }
+    if (c->fused && !c->split) {
+        const bool pz = c->persist;
+        c->fused = false; c->persist = false;          // (the upload prepared the merged gather + step launch as well: the one-launch iteration is only taken where that one is)
+        st = solve_attempt(c, o, sum, t0, true, &gave_up);
+        c->fused = true; c->persist = pz;              // the next solve takes the library's first choice again
         c->P.drop_role = -1; c->P.drop_launch = -1;
         if (!gave_up) { c->n_recovered++; return st; }
         st = restore();
@@ -2248,7 +2297,7 @@ int vil_comm_message_bytes(vil_ctx* c, int64_t* bytes_per_peer, int64_t* bytes_f
 
 // ---- window residency across frames (include/vilsolve.h) ------------------------------------------------------------------------
 int vil_debug_fail_graph_capture(vil_ctx* c, int32_t n) { if (!c || n < 0) return VIL_ERR_INVALID_ARGUMENT; c->fail_capture = n; c->graph_failed = false; return VIL_OK; }
-int vil_debug_set_launch_mode(vil_ctx* c, int32_t mode) { if (!c || mode < 0 || mode > 3) return VIL_ERR_INVALID_ARGUMENT; c->launch_mode = mode; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
+int vil_debug_set_launch_mode(vil_ctx* c, int32_t mode) { if (!c || mode < 0 || mode > 4) return VIL_ERR_INVALID_ARGUMENT; c->launch_mode = mode; c->uploaded = false; c->resident_kind = 0; return VIL_OK; }
 int vil_comm_info(vil_ctx* c, int32_t* rank, int32_t* world, int32_t* transport) {
     if (!c) return VIL_ERR_INVALID_ARGUMENT;
     if (rank) *rank = c->rank;
@@ -2293,7 +2342,7 @@ int vil_debug_set_slim_emul(vil_ctx* c, int32_t on) { if (!c) return VIL_ERR_INV
 int vil_debug_get_launch_structure(vil_ctx* c, int32_t* launches_per_iteration, int32_t* one_launch) {
     if (!c || !c->uploaded) return VIL_ERR_INVALID_ARGUMENT;
     const bool merged = c->P.rs_merged != 0 && !c->split;
-    if (launches_per_iteration) *launches_per_iteration = (c->fused && !c->split) ? 1 : (merged ? 2 : 3);
+    if (launches_per_iteration) *launches_per_iteration = (c->fused && !c->split) ? ((c->persist && !c->profiling) ? 0 : 1) : (merged ? 2 : 3);      // 0: the whole solve is one resident launch (k_solve)
     if (one_launch) *one_launch = (c->fused && !c->split) ? 1 : 0;
     return VIL_OK;
 }

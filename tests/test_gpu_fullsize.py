@@ -57,7 +57,7 @@ def test_fallback_launch_structures_match_the_oracle(oracle, cid, mode):
         assert (s2.iterations, s2.termination) == (so.iterations, so.termination) and s2.final_cost == sg.final_cost
     mg, mo = be.marginalize(wg, abi.MARGIN_OLD), oracle.marginalize(wo, abi.MARGIN_OLD)
     assert mg.c.n == mo.c.n and np.abs(mg.A_matrix() - mo.A_matrix()).max() <= (1e-8 if wo.prior.n else 1e-4) * np.abs(mo.A_matrix()).max()
-    assert be.lib.vil_debug_set_launch_mode(be.ctx, 4) != 0
+    assert be.lib.vil_debug_set_launch_mode(be.ctx, 5) != 0
     be.close()
 
 

@@ -18,12 +18,12 @@ for cfg in [int(v) for v in os.environ.get("CFG", "2").split(",")]:
     for _ in range(20): be.reset_state(); its += be.solve_resident(opts).iterations
     el = time.perf_counter() - t0
     print("cfg %d mode %d: %.0f it/s (%.1f us per iteration, host clock, graph replay)" % (cfg, mode, its / el, 1e6 * el / its))
-    if mode == 0:
-        be.lib.vil_profile_enable(be.ctx, 1)
+    if mode in (0, 4):
+        be.lib.vil_profile_enable(be.ctx, int(os.environ.get("PROF", "2" if mode == 0 else "1")))      # 2: stamps alone (the persistent solve keeps its launch)
         for _ in range(5): be.reset_state(); be.solve_resident(opts)
         avg = (C.c_double * 24)(); n = C.c_int64(0)
         be.lib.vil_profile_phases(be.ctx, avg, C.byref(n), 1)
         be.lib.vil_profile_enable(be.ctx, 0)
-        print("  %d launches averaged; us after the launch's first workgroup started:" % n.value)
+        print("  %d launches averaged; iteration period inside a persistent solve %.2f us; us after the launch's / iteration's first workgroup started:" % (n.value, avg[0]))
         for k in sorted([q for q in range(1, 24) if avg[q] > 0], key=lambda q: avg[q]): print("    %6.2f  %s" % (avg[k], NAMES[k]))
     be.close()
