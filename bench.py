@@ -168,7 +168,7 @@ PHASE_NAMES = ["first workgroup started", "last visual / LiDAR / ICP-LPS role do
 
 def phases_obj(be):
     """Where a one-launch iteration spends its time: the launch's own 100 MHz wall-clock stamps, averaged over the instrumented pass (vil_profile_phases)."""
-    avg = (C.c_double * 24)(); n = C.c_int64(0)
+    avg = (C.c_double * 32)(); n = C.c_int64(0)
     if be.lib.vil_profile_phases(be.ctx, avg, C.byref(n), 1) != 0 or n.value == 0:
         return None
     order = sorted([q for q in range(1, 24) if avg[q] > 0], key=lambda q: avg[q])

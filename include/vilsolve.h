@@ -354,7 +354,9 @@ int vil_profile_read(vil_ctx* ctx, vil_profile* out, int reset);
  * device's 100 MHz wall clock while profiling is on -- vil_profile.sweep_ms is then the sweep PHASE (first workgroup started -> last sweep role's record out),
  * reduce_ms the gather's tail behind it, step_ms the rest of the launch.  vil_profile_phases returns the average position in microseconds of 16 phase stamps
  * after the launch's first workgroup started (24 slots; csrc/vilsolve.hip lists them) and the number of launches averaged. */
-int vil_profile_phases(vil_ctx* ctx, double* avg_us24, int64_t* launches, int reset);
+int vil_profile_phases(vil_ctx* ctx, double* avg_us32, int64_t* launches, int reset);
+/* the raw stamps (100 MHz device clock; 32 per launch / iteration, slot 0 stored inverted; 0: not stamped) of the last profiled solve: returns the launches copied */
+int vil_debug_read_stamps(vil_ctx* ctx, uint64_t* out, int32_t max_launches);
 
 /* replaces ceres::CostFunction::Evaluate for a whole factor class at once: raw (no loss) residuals
  * and row-major global-size Jacobian blocks, factor-major, in the caller's factor order. */

@@ -164,7 +164,7 @@ struct DevP {
 
 // Phase stamps of a one-launch iteration (vil_profile_phases): slot k of launch `launch` keeps the LATEST (or, want_min, the EARLIEST: stored inverted) wall-clock
 // reading any workgroup posted for it -- s_memrealtime, the 100 MHz counter every XCD shares; one atomic per workgroup and slot, nothing when P.prof is null
-#define VIL_PROF_SLOTS 24
+#define VIL_PROF_SLOTS 32
 #define VIL_PROF_WGS 4096      // workgroups of one launch whose entry / exit times fit behind the phase stamps (vil_profile_workgroups)
 #if defined(__HIPCC__)
 __device__ __forceinline__ void prof_stamp(const DevP& P, int launch, int k, bool want_min = false) {

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(KSolveArgs kernarg_b
             const Ctl& ctl = *lc;
             if (ctl.done) return;
             const int epoch = (int)((((unsigned)ctl.gen) << 12) + (unsigned)ctl.n_sweeps + 1u);
-            sweep_body<TS, true>(P, O, ctl, sm, sw, xl, resident);
+            sweep_body<TS, true>(P, O, ctl, sm, sw, xl, resident && !(P.skip_mask & 256));
             resident = true;
             if (item >= 0) {
                 int4* const scratch = (int4*)(sm + (sw < P.n_imu ? 2048 : 0));
@@ -168,8 +168,11 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(KSolveArgs kernarg_b
                 else if (t < 7) { unsigned* d = (unsigned*)(t <= 2 ? &lc->mu : (t <= 4 ? &lc->cg : &lc->cn)); d[(t - 1) & 1] = pl; }      // (little endian: low half first)
                 else ((unsigned*)xl)[t - 8] = pl;
             }
+            if (sw == 0 && t == 0) prof_stamp(P, epoch - 1, 27);
             __syncthreads();
+            if (sw == 0 && t == 0) prof_stamp(P, epoch - 1, 28);
             if (lc->pad_) return;                                   // a wait gave up: the host re-runs the solve (vil_solve_resident)
+            if (P.skip_mask & 512) { const double* xg = P.x[1 - lc->cur]; for (int i = t; i < NC; i += VIL_STEP_THREADS) xl[i] = ld_ag(xg + i); __syncthreads(); }      // (debug: the candidate from memory)
         }
     }
     vd::StepShared& s = *reinterpret_cast<vd::StepShared*>(dyn);
@@ -191,7 +194,8 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(KSolveArgs kernarg_b
             // of the sweep roles (they read nothing else of Ctl) -> Ctl itself -> word 8 of the line, which the step roles (and nobody on an iteration's longest path) wait for.
             // On paths where the helpers ran no second pass the spare wave's poll inside step_body did not happen: collected here (a helper posts hflag2 on every path).
             if (s.pad0_ != epoch && t < P.n_help) spin_until_eq(P.hflag2 + t, epoch, P.abortf);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+            __syncthreads();                                        // (no wait for the candidate's stores: the sweep roles take it from the tagged words, P.xtag)
+            if (t == 0) prof_stamp(P, epoch - 1, 24);
             if (t == 0 && !s.c.done && budget_ticks > 0 && (long long)(wall_clock64() - t_start) > budget_ticks) { s.c.done = 1; s.c.term = 5; if (s.c.iter > 0 && !s.c.resweep) s.c.iter--; }      // (the step just formed was never judged: not an iteration of the summary)
             __syncthreads();
             const bool done = s.c.done != 0;
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(KSolveArgs kernarg_b
                     __hip_atomic_store(P.ihdr + t, ((unsigned long long)(unsigned)epoch << 32) | pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             };
-            if (!done) post_hdr();                                 // the next iteration's sweep roles start from this
+            if (!done) { post_hdr(); if (t == 0) prof_stamp(P, epoch - 1, 25); }      // the next iteration's sweep roles start from this
             if (done && s.c.lin_mode == 0 && t == 0) s.c.outd = 1;
             __syncthreads();
             if (t < 64) { const double* src = (const double*)&s.c; double* dst = (double*)P.ctl; for (int i = t; i < (int)(sizeof(Ctl) / 8); i += 64) st_ag(dst + i, src[i]); }
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(KSolveArgs kernarg_b
                 return;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
-            if (t == 0) __hip_atomic_store(P.ihdr + 8, (unsigned long long)(unsigned)epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 0) { __hip_atomic_store(P.ihdr + 8, (unsigned long long)(unsigned)epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); prof_stamp(P, epoch - 1, 26); }
             continue;
         }
         if (t == 0) {

@@ -350,6 +350,7 @@ struct vil_ctx {
         size_t prior_doubles() const { return 2 * (size_t)nmax * nmax + 2 * (size_t)nmax + x0max + 8; }
     } win;
     bool profiling = false, stamps = false; long long period_n = 0;
+    std::vector<unsigned long long> last_stamps;      // raw stamps of the last profiled solve (vil_debug_read_stamps)
     int wg_launch = -1;      // (vil_profile_workgroups)
     long long* d_prof = nullptr; double phase_us[VIL_PROF_SLOTS] = {0}; long long phase_n = 0;      // phase stamps of the one-launch iterations (vil_profile_phases)
     std::vector<hipEvent_t> ev, ev_mid, ev_coll;
@@ -1626,6 +1627,12 @@ int vil_profile_read(vil_ctx* c, vil_profile* out, int reset) {
     return VIL_OK;
 }
 
+int vil_debug_read_stamps(vil_ctx* c, uint64_t* out, int32_t max_launches) {
+    if (!c || !out || max_launches < 0) return VIL_ERR_INVALID_ARGUMENT;
+    const size_t n = std::min((size_t)max_launches * VIL_PROF_SLOTS, c->last_stamps.size());
+    for (size_t i = 0; i < n; ++i) out[i] = c->last_stamps[i];
+    return (int)(n / VIL_PROF_SLOTS);
+}
 int vil_debug_read(vil_ctx* c, long long* out64) {
     if (!c || !c->uploaded) return VIL_ERR_INVALID_ARGUMENT;
     HIPCHK(hipMemcpy(out64, c->P.dbg, 8 * 64, hipMemcpyDeviceToHost));
@@ -1785,7 +1792,7 @@ static int solve_attempt(vil_ctx* c, const vil_options* o, vil_summary* sum, con
     c->recent_live[c->recent_at++ & 7] = ctl.n_sweeps;
     if ((c->profiling || (c->stamps && persist)) && c->fused && c->d_prof && ctl.n_sweeps <= 64) {
         // the launches' own clock stamps (100 MHz): the sweep phase of a one-launch iteration = first workgroup started -> last sweep role posted
-        std::vector<unsigned long long> hp((size_t)64 * VIL_PROF_SLOTS);
+        std::vector<unsigned long long>& hp = c->last_stamps; hp.assign((size_t)64 * VIL_PROF_SLOTS, 0ull);
         HIPCHK(hipMemcpyAsync(hp.data(), c->d_prof, 8 * hp.size(), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         for (int q = 0; q < ctl.n_sweeps; ++q) {

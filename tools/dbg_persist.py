@@ -17,7 +17,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     import time
     for rep in range(3):
         be.reset_state(); t0 = time.perf_counter(); s = be.solve_resident(); dt = time.perf_counter() - t0
-        print("mode %d cfg %d launches/iter %d: it %d succ %d term %d cost %.12g -> %.15g  %.3f ms" % (mode, cid, n.value, s.iterations, s.successful_steps, s.termination, s.initial_cost, s.final_cost, dt * 1e3), flush=True)
+        print("mode %d cfg %d launches/iter %d: it %d succ %d term %d cost %.12g -> %.15g  %.3f ms" % (mode, cid, n.value, s.iterations, s.successful_steps, s.termination, s.initial_cost, s.final_cost, dt * 1e3), float(s.final_cost).hex(), flush=True)
     sys.exit(0)
 cid = int(os.environ.get("CFG", "2"))
 extra = os.environ.get("KW", "{}")

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g; g.load_package()
 from mvil_fusion_amd import abi, lib, synth
 NAMES = ["first wg start", "last visual/lidar/rel role done", "last imu role done", "chain: records seen", "chain: W^T complete", "last gather wg done", "last gather wg saw visual flags", "master started",
-         "master saw gather flags", "master saw tiles", "cholesky done", "x_p published", "master done", "last tile wg done", "chain: slab gathered", "prior role done", "imu0: role entered", "imu0: inputs staged", "imu0: raw blocks done", "imu0: whitened", "imu0: record stores issued", "master: chain back-substituted", "master: step vectors + helpers' sums in", "master: candidate formed"]
+         "master saw gather flags", "master saw tiles", "cholesky done", "x_p published", "master done", "last tile wg done", "chain: slab gathered", "prior role done", "imu0: role entered", "imu0: inputs staged", "imu0: raw blocks done", "imu0: whitened", "imu0: record stores issued", "master: chain back-substituted", "master: step vectors + helpers' sums in", "master: candidate formed", "tail: hflag2 + candidate stores in", "tail: header posted", "tail: Ctl out, word 8 posted", "sweep role 0: header seen", "sweep role 0: next iteration entered", "", "", ""]
 for cfg in [int(v) for v in os.environ.get("CFG", "2").split(",")]:
     be = lib.open_vilsolve()
     mode = int(os.environ.get("MODE", "0"))
@@ -21,9 +21,9 @@ for cfg in [int(v) for v in os.environ.get("CFG", "2").split(",")]:
     if mode in (0, 4):
         be.lib.vil_profile_enable(be.ctx, int(os.environ.get("PROF", "2" if mode == 0 else "1")))      # 2: stamps alone (the persistent solve keeps its launch)
         for _ in range(5): be.reset_state(); be.solve_resident(opts)
-        avg = (C.c_double * 24)(); n = C.c_int64(0)
+        avg = (C.c_double * 32)(); n = C.c_int64(0)
         be.lib.vil_profile_phases(be.ctx, avg, C.byref(n), 1)
         be.lib.vil_profile_enable(be.ctx, 0)
         print("  %d launches averaged; iteration period inside a persistent solve %.2f us; us after the launch's / iteration's first workgroup started:" % (n.value, avg[0]))
-        for k in sorted([q for q in range(1, 24) if avg[q] > 0], key=lambda q: avg[q]): print("    %6.2f  %s" % (avg[k], NAMES[k]))
+        for k in sorted([q for q in range(1, 32) if avg[q] > 0], key=lambda q: avg[q]): print("    %6.2f  %s" % (avg[k], NAMES[k]))
     be.close()
