@@ -199,20 +199,15 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(KSolveArgs kernarg_b
             if (t == 0 && !s.c.done && budget_ticks > 0 && (long long)(wall_clock64() - t_start) > budget_ticks) { s.c.done = 1; s.c.term = 5; if (s.c.iter > 0 && !s.c.resweep) s.c.iter--; }      // (the step just formed was never judged: not an iteration of the summary)
             __syncthreads();
             const bool done = s.c.done != 0;
-            auto post_hdr = [&]() {
-                if (t < 7) {
-                    const Ctl& c = s.c;
-                    const double dv = t <= 2 ? c.mu : (t <= 4 ? c.cg : c.cn);
-                    const unsigned pl = t == 0 ? (unsigned)((c.cur & 1) | ((c.done ? 1 : 0) << 1) | ((c.first ? 1 : 0) << 2) | ((c.lin_mode & 3) << 3)) : (unsigned)(((t - 1) & 1) ? __double2hiint(dv) : __double2loint(dv));
-                    __hip_atomic_store(P.ihdr + t, ((unsigned long long)(unsigned)epoch << 32) | pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            };
+            auto post_hdr = [&]() { post_iter_header(P, s.c, epoch); };
             if (!done) { post_hdr(); if (t == 0) prof_stamp(P, epoch - 1, 25); }      // the next iteration's sweep roles start from this
+            const bool written = s.c.outd != 0;                    // (cost first: the master wrote the result out inside step_body)
+            __syncthreads();
             if (done && s.c.lin_mode == 0 && t == 0) s.c.outd = 1;
             __syncthreads();
             if (t < 64) { const double* src = (const double*)&s.c; double* dst = (double*)P.ctl; for (int i = t; i < (int)(sizeof(Ctl) / 8); i += 64) st_ag(dst + i, src[i]); }
             if (done) {
-                if (s.c.lin_mode == 0) vd::solve_finish<true>(P.x[0], P.x[1], P.xorig, P.hstate, P.ctl, P.hctl, P.hseq, P.K, P.NS, P.gauge_on, s.c.cur, s.c.status, s.c.gen, Alds, &s.c);      // (the host is released here)
+                if (s.c.lin_mode == 0 && !written) vd::solve_finish<true>(P.x[0], P.x[1], P.xorig, P.hstate, P.ctl, P.hctl, P.hseq, P.K, P.NS, P.gauge_on, s.c.cur, s.c.status, s.c.gen, Alds, &s.c);      // (the host is released here)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
                 post_hdr();                                        // everybody reads `done` and leaves
                 if (t == 0) __hip_atomic_store(P.ihdr + 8, (unsigned long long)(unsigned)epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

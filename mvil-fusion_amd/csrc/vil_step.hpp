@@ -40,6 +40,7 @@ struct StepShared {
     unsigned char cst[48];                        // pose_const[K] | sb_const[K]
     double hs[12];                                // the helpers' sums, gathered by a spare wave during the chain back substitution
     int need, was_first, ok, cok;
+    int early, judged;                            // persistent solve, master: the candidate's cost alone ended the solve (judged from the sweep's cost partials, before the gather) / the judge has run
     int done_at_entry, pad0_;                     // the solve was already finished when this launch read Ctl
     long long tacc[6];
 };
@@ -1378,6 +1379,46 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
 // FUSED: the role runs inside the one-launch iteration (k_iter, vil_iter.hpp) -- the sweep's workgroups are part of the SAME launch: the gather workgroups
 // wait for their flags (P.sflag) and read the records at agent scope, the chain workgroup waits for the IMU / prior workgroups', master and helpers read the
 // landmark arrays at agent scope, and the master counts the launch in Ctl::n_sweeps itself.  p0: the workgroup's index among the step roles.
+// The judge of a candidate that is a STEP (not the first linearisation, not a re-sweep): function tolerance, relative decrease, radius update (trust_region_minimizer.cc;
+// SURVEY Appendix B).  One function for the ordinary place (behind the gather) and the persistent solve's cost-first judgement (behind the sweep roles' cost partials).
+__device__ __forceinline__ void judge_step(Ctl& c, const double cand_cost, const SolveOpts& O, int& need) {
+    const int cand = 1 - c.cur;
+    if (fabs(c.cost_cur - cand_cost) <= O.function_tolerance * c.cost_cur) { c.done = 1; c.term = 1; }
+    else {
+        const double rel = (c.cost_cur - cand_cost) / c.model_change;
+        if (isfinite(cand_cost) && rel > O.min_relative_decrease) {
+            c.cur = cand; c.cost_cur = cand_cost; c.nsucc++;
+            if (rel < 0.25) c.radius *= 0.5;
+            if (rel > 0.75) c.radius = fmax(c.radius, 3.0 * c.dogleg_norm);
+            c.radius = fmin(O.max_radius, c.radius);
+            c.reuse = 0; need = 1;
+        } else { c.radius *= 0.5; c.reuse = 1; need = 0; }
+    }
+    if (c.iter >= 1 && c.iter <= 64) c.cost_trace[c.iter - 1] = c.cost_cur;
+}
+__device__ __forceinline__ void judge_caps(Ctl& c, const SolveOpts& O) {
+    if (!c.done) {
+        if (c.iter >= O.max_iterations) { c.done = 1; c.term = 4; }
+        else if (c.radius <= 1e-32) { c.done = 1; c.term = 6; c.status = -4; }
+    }
+}
+// would judge_step + judge_caps END the solve?  (no side effects: the persistent solve asks before the gather is complete)
+__device__ __forceinline__ bool judge_would_end(const Ctl& c, const double cand_cost, const SolveOpts& O) {
+    if (fabs(c.cost_cur - cand_cost) <= O.function_tolerance * c.cost_cur) return true;
+    if (c.iter >= O.max_iterations) return true;
+    const double rel = (c.cost_cur - cand_cost) / c.model_change;
+    const bool accepted = isfinite(cand_cost) && rel > O.min_relative_decrease;
+    return !accepted && c.radius * 0.5 <= 1e-32;
+}
+// the hand-over line of a persistent solve (vil_iter.hpp): what a sweep role reads of Ctl, as seven words {payload, epoch}; lanes 0 .. 6 of the caller
+__device__ __forceinline__ void post_iter_header(const DevP& P, const Ctl& c, const int epoch) {
+    const int t = vil_tid();
+    if (t < 7) {
+        const double dv = t <= 2 ? c.mu : (t <= 4 ? c.cg : c.cn);
+        const unsigned pl = t == 0 ? (unsigned)((c.cur & 1) | ((c.done ? 1 : 0) << 1) | ((c.first ? 1 : 0) << 2) | ((c.lin_mode & 3) << 3)) : (unsigned)(((t - 1) & 1) ? __double2hiint(dv) : __double2loint(dv));
+        __hip_atomic_store(P.ihdr + t, ((unsigned long long)(unsigned)epoch << 32) | pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 // duty_item >= 0 (the persistent solve, k_solve): the gather item a helper or tile workgroup of a live iteration takes once it holds Ctl and the epoch, BEFORE its own
 // waits -- it has nothing to do until the gather is complete / the chain is eliminated
 template <bool LDSM, int CHAIN, bool FUSED>
@@ -1419,7 +1460,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     {   // Ctl (1.5 kB with its traces) into LDS: one coalesced load per lane, not 190 loads of a lone lane with everybody waiting at the barrier
         const double* src = (const double*)P.ctl; double* dst = (double*)&s.c;
         for (int i = t; i < (int)(sizeof(Ctl) / 8); i += NT) dst[i] = ldx<FUSED>(src + i);      // (FUSED: whatever the roles hand from one iteration to the next crosses at agent scope -- the persistent solve, k_solve, has no launch boundary between them)
-        if (t == 0) { s.need = 0; s.was_first = 0; s.ok = 1; }
+        if (t == 0) { s.need = 0; s.was_first = 0; s.ok = 1; s.early = 0; s.judged = 0; }
     }
     for (int q = t; q < 256; q += NT) {      // triangular tile index -> (tile row, tile col)
         int Ir = (int)((sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
@@ -1480,12 +1521,37 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
             for (int i = t; i < nv; i += NT) spin_until_eq(P.sflag + v0 + i, epoch, P.abortf);
             __syncthreads();
             if (t == 0) st_ag(P.sall + 32, epoch);
+            // ---- persistent solve, COST FIRST: every sweep role's cost partial is out.  The master has nothing to do until the gather is complete (~6 us from here): it
+            //      adds the partials itself -- the gather's own code and order, the same bits -- and asks whether the judgement will end the solve (function tolerance,
+            //      iteration cap, radius underflow).  If so the solve ends HERE: judge, write-out (the host is released), the `done` hand-over line; the gather
+            //      workgroups, the helpers and the tile workgroups drain behind it.  What is swept into Jacobians in a solve's last iteration is then never waited for.
+            if (P.persist && !s.c.first && !s.c.resweep && s.c.lin_mode == 0) {
+                const double cc = gather_cost<VIL_STEP_THREADS / 8, true>(P, s.red);      // (valid in thread 0)
+                if (t == 0) s.early = judge_would_end(s.c, cc, O) ? 1 : 0;
+                __syncthreads();
+                if (s.early) {
+                    if (t == 0) { Ctl& c = s.c; c.cand_cost = cc; judge_step(c, cc, O, s.need); judge_caps(c, O); c.outd = 1; s.judged = 1; }
+                    __syncthreads();
+                    vd::solve_finish<true>(P.x[0], P.x[1], P.xorig, P.hstate, P.ctl, P.hctl, P.hseq, P.K, P.NS, P.gauge_on, s.c.cur, s.c.status, s.c.gen, Alds, &s.c);
+                    post_iter_header(P, s.c, epoch);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+                    if (t == 0) st_ag(P.sall + 48, epoch);      // the helpers wake up, read the line and leave
+                }
+            }
         }
     }
     // master and helpers: the candidate's cost, gradient and diagonal (and S') are complete.  One-launch iteration: the master polls the gather workgroups' flags
     // and passes one word on to the helpers (their first pass is not on the critical path: a hop more, n_help x n_gather polling lanes fewer)
-    if (FUSED && merged && bid > 0) { duty(); if (t == 0) spin_until_eq(P.sall + 48, epoch, P.abortf); __syncthreads(); }
-    else if (merged) { rs_wait(P.gflag, P.n_gather); if (FUSED && t == 0) st_ag(P.sall + 48, epoch); }
+    if (FUSED && merged && bid > 0) {
+        duty();
+        if (t == 0) {
+            spin_until_eq(P.sall + 48, epoch, P.abortf);
+            if (P.persist) { const unsigned long long h0 = __hip_atomic_load(P.ihdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s.early = ((unsigned)(h0 >> 32) == (unsigned)epoch && ((unsigned)h0 & 2u)) ? 1 : 0; }      // cost first: the master has ended the solve
+        }
+        __syncthreads();
+        if (s.early) { if (t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __hip_atomic_store(P.hflag + (bid - 1), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
+    }
+    else if (merged && !s.early) { rs_wait(P.gflag, P.n_gather); if (FUSED && t == 0) st_ag(P.sall + 48, epoch); }
     if (bid == 0) PROF(8);
     // Everything the master and its helpers hand each other inside this launch (hpart, hpart2, stepc) is stored AND loaded with agent-scope
     // atomics, i.e. at the level all XCDs share, so a flag only has to be ordered after the poster's own stores (s_waitcnt).  A release
@@ -1522,7 +1588,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     const bool cam = true;             // (every rank holds the complete system: nothing is counted per rank any more)
     STAMP(0);
     // ---------------- judge the candidate that the sweep just linearised -------------------------
-    if (t == 0) {
+    if (t == 0 && !s.judged) {
         Ctl& c = s.c;
         const int cand = 1 - c.cur;
         const double cand_cost = merged ? ld_ag(P.sys[cand].cost) : *P.sys[cand].cost;
@@ -1532,24 +1598,8 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
             if (c.first) { c.initial_cost = cand_cost; s.was_first = 1; }
             if (!isfinite(cand_cost)) { c.done = 1; c.term = 6; c.status = -3; }
             c.cur = cand; c.cost_cur = cand_cost; c.first = 0; c.resweep = 0; s.need = 1;
-        } else {
-            if (fabs(c.cost_cur - cand_cost) <= O.function_tolerance * c.cost_cur) { c.done = 1; c.term = 1; }
-            else {
-                const double rel = (c.cost_cur - cand_cost) / c.model_change;
-                if (isfinite(cand_cost) && rel > O.min_relative_decrease) {
-                    c.cur = cand; c.cost_cur = cand_cost; c.nsucc++;
-                    if (rel < 0.25) c.radius *= 0.5;
-                    if (rel > 0.75) c.radius = fmax(c.radius, 3.0 * c.dogleg_norm);
-                    c.radius = fmin(O.max_radius, c.radius);
-                    c.reuse = 0; s.need = 1;
-                } else { c.radius *= 0.5; c.reuse = 1; s.need = 0; }
-            }
-            if (c.iter >= 1 && c.iter <= 64) c.cost_trace[c.iter - 1] = c.cost_cur;
-        }
-        if (!c.done) {
-            if (c.iter >= O.max_iterations) { c.done = 1; c.term = 4; }
-            else if (c.radius <= 1e-32) { c.done = 1; c.term = 6; c.status = -4; }
-        }
+        } else judge_step(c, cand_cost, O, s.need);
+        judge_caps(c, O);
     }
     __syncthreads();
     const int cur = s.c.cur;

@@ -611,6 +611,30 @@ __host__ __device__ inline int gather_sblocks(int D, int NV, int epw, bool pose_
 __host__ __device__ inline int gather_blocks(int D, int NV, int epw, bool pose_only) { return gather_sblocks(D, NV, epw, pose_only) + (2 * D + epw / 4 - 1) / (epw / 4) + 1; }
 // FUSED: the sweep's workgroups are workgroups of the SAME launch (the one-launch iteration, vil_iter.hpp): once its own tables are staged the workgroup waits
 // for their flags (P.sflag = epoch, n_sw of them), every record is read at agent scope, and the scratch arrays live in the workgroup's dynamic LDS behind vtab
+// the candidate's cost from the sweep roles' partials: 8 EPW threads, a fixed order (per-thread strided sums, wave sums, the waves in order) -- the gather's cost item and
+// the persistent solve's cost-first judgement (vil_step.hpp) call THIS, so that both see the same bits.  The total is valid in thread 0; red: >= EPW / 8 doubles of LDS.
+template <int EPW, bool FUSED>
+__device__ __forceinline__ double gather_cost(const DevP& P, double* const red) {
+    using namespace vd;
+    const int t = vil_tid();
+    auto rd = [](const double* p) -> double { return ldx<FUSED>(p); };
+    const int4* const vrec = (const int4*)P.vrec;
+    const int n_rel = P.n_icp + P.n_lps;
+    const double* rel0 = P.mpart + (P.pn > 0 ? P.pn + 1 : 0);
+    double c = 0.0;
+    for (int w = t; w < P.n_vwg; w += 8 * EPW) { const int4 ds = vrec[w]; c += rd(P.vpart + (size_t)ds.x * 16 + vis_ntile(ds.w) * 256 + 32 * ds.w); }
+    for (int q = t; q < P.n_pchunk + P.n_echunk; q += 8 * EPW) c += rd(P.lpart + (size_t)q * 28 + 27);
+    for (int f = t; f < P.n_imu; f += 8 * EPW) c += rd(P.ipart + (size_t)f * 931 + 930);
+    for (int f = t; f < n_rel; f += 8 * EPW) c += rd(rel0 + (size_t)f * 601 + 600);
+    if (t == 0 && P.pn > 0) c += rd(P.mpart + P.pn);
+    c = wave_sum(c);
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = c;
+    __syncthreads();
+    double tot = 0.0;
+    if (t == 0) for (int w = 0; w < EPW / 8; ++w) tot += red[w];      // (EPW / 8 waves)
+    return tot;
+}
 template <bool AG = false, int EPW = RED_EPW, bool FUSED = false>
 __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, const int blk /* gather workgroup index */, int4* const vtab /* LDS, VIS_TAB entries */, const int epoch = 0) {
     using namespace vd;
@@ -798,16 +822,8 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
     // ---- cost (one workgroup, tree reduction) ---------------------------------------------------------------------
     if (P.skip_mask & 64) return;
     wait_sweep(false); wait_sweep(true);
-    double c = 0.0;
-    for (int w = t; w < P.n_vwg; w += 8 * EPW) { const int4 ds = vrec[w]; c += rd(P.vpart + (size_t)ds.x * 16 + vis_ntile(ds.w) * 256 + 32 * ds.w); }
-    for (int q = t; q < P.n_pchunk + P.n_echunk; q += 8 * EPW) c += rd(P.lpart + (size_t)q * 28 + 27);
-    for (int f = t; f < P.n_imu; f += 8 * EPW) c += rd(P.ipart + (size_t)f * 931 + 930);
-    for (int f = t; f < n_rel; f += 8 * EPW) c += rd(rel0 + (size_t)f * 601 + 600);
-    if (t == 0 && P.pn > 0) c += rd(P.mpart + P.pn);
-    c = wave_sum(c);
-    if ((t & 63) == 0) red[t >> 6] = c;
-    __syncthreads();
-    if (t == 0) { double tot = 0.0; for (int w = 0; w < EPW / 8; ++w) tot += red[w]; put(sb.cost, tot); }      // (EPW / 8 waves)
+    const double tot = gather_cost<EPW, FUSED>(P, red);
+    if (t == 0) put(sb.cost, tot);
 }
 
 #ifndef VIL_PERSIST_TU
