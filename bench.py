@@ -176,7 +176,7 @@ def phases_obj(be):
             "stamps": {PHASE_NAMES[q]: round(float(avg[q]), 2) for q in order}}
 
 
-def roofline_obj(w, prof, measured_on, pmc_files, pmc_note, mfma_file=None, one_launch=True, phases=None, two_launch=None):
+def roofline_obj(w, prof, measured_on, pmc_files, pmc_note, mfma_file=None, one_launch=True, phases=None, two_launch=None, persistent=False):
     """`roofline` of the dominant kernel.  One-launch iteration (k_iter): the kernel IS the iteration -- factor sweep, gather, chain elimination and trust-region step as roles of
     one grid -- so `achieved` = the sweep's algorithmic bytes over the WHOLE launch's duration (HIP events), which prices a latency-bound launch against the HBM roof; the sweep PHASE of
     the launch (its own clock stamps) and the two-launch structure's k_sweep are reported beside it.  Two / three launches per iteration: the sweep kernel, as in earlier rounds."""
@@ -186,18 +186,27 @@ def roofline_obj(w, prof, measured_on, pmc_files, pmc_note, mfma_file=None, one_
     ts = "5" if w.K > 12 else "2"      # (the visual role's accumulator tiles per wave: csrc/vil_sweep.hpp; the counter files may hold other windows' launches too)
     NP, NB = 6 * w.K + 7, 9 * w.K
     chol_flop = w.K * (9 ** 3 / 3.0 + 2.0 * 81 * (NP + 1 + 9)) + 1.0 * (NP + 1) ** 2 * NB + NP ** 3 / 3.0 + 2.0 * (NP * NP + NB * (NP + 9))
+    units = 1.0
+    if one_launch and persistent:
+        # the persistent solve: ONE launch per solve runs every iteration (k_solve, csrc/vil_iter.hpp).  A launch processes `units` sweeps: achieved = units x the sweep's
+        # algorithmic bytes over the launch's duration (HIP events around the launch).  Per iteration: the launch's own clock stamps.
+        units = prof.sweep_launches / max(1, prof.step_launches)
+        launch_us = 1e3 * (prof.step_ms + prof.sweep_ms) / max(1, prof.step_launches)
+        rest_us = launch_us / units - sweep_us
     if one_launch:
-        kname = "k_iter<%s>" % ts
-        us = sweep_us + rest_us
+        kname = ("k_solve<%s>" if persistent else "k_iter<%s>") % ts
+        us = (sweep_us + rest_us) * units
+        ab1, ab = ab, ab * units           # per sweep / per launch
         ach = ab / (us * 1e-6) / 1e9
-        r = {"bound": "hbm", "kernel": kname + " (one launch per trust-region iteration: sweep roles | chain | gather | master + helpers | W W^T tiles)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-             "traffic": pmc_traffic_bytes(pmc_files, kname), "traffic_source": pmc_note, "algorithmic_bytes_per_launch": ab, "avg_launch_us": us, "launches_timed": int(prof.sweep_launches),
+        r = {"bound": "hbm", "kernel": kname + (" (ONE resident launch per SOLVE: the roles below loop over the trust-region iterations; per iteration: sweep roles | chain | gather duties | master + helpers | W W^T tiles)" if persistent else " (one launch per trust-region iteration: sweep roles | chain | gather | master + helpers | W W^T tiles)"), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "traffic": pmc_traffic_bytes(pmc_files, kname), "traffic_source": pmc_note, "algorithmic_bytes_per_launch": ab, "avg_launch_us": us, "launches_timed": int(prof.step_launches if persistent else prof.sweep_launches),
+             "sweeps_per_launch": units, "avg_iteration_us": us / units,
              "measured_on": measured_on, "variant": "fused sweep (no Jacobian materialisation): read-only bytes, SURVEY 8(d)",
              "note": "the launch is latency-bound (flag hand-offs between roles, then one master workgroup on dependent fp64 chains): the sweep's 2.4 MB are read in the first quarter of it -- sweep_phase prices that quarter, "
                      "critical_path what the remaining three quarters are made of",
-             "sweep_phase": {"us": sweep_us, "achieved": ab / (sweep_us * 1e-6) / 1e9, "frac": ab / (sweep_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
-                             "what": "first workgroup of the launch started -> last sweep role's record out, from the launch's own clock stamps"},
-             "critical_path": {"us_after_the_sweep_phase": rest_us, "bound": "latency: gather of the visual records beside the two-sided 9x9 chain of %d blocks, then a %d-pivot dense Cholesky and the back substitutions on one workgroup (dependent fp64 chains)" % (w.K, NP),
+             "sweep_phase": {"us": sweep_us, "achieved": ab1 / (sweep_us * 1e-6) / 1e9, "frac": ab1 / (sweep_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
+                             "what": "first workgroup of the launch (persistent solve: of the iteration) started -> last sweep role's record out, from the launch's own clock stamps"},
+             "critical_path": {"us_after_the_sweep_phase": rest_us, "per": "iteration", "bound": "latency: gather of the visual records beside the two-sided 9x9 chain of %d blocks, then a %d-pivot dense Cholesky and the back substitutions on one workgroup (dependent fp64 chains)" % (w.K, NP),
                                "dense_flop_per_launch": chol_flop, "achieved_gflops": chol_flop / (rest_us * 1e-6) / 1e9, "peak_tflops_fp64_matrix": 78.6, "frac": chol_flop / (rest_us * 1e-6) / 78.6e12}}
         r["critical_path_kernel"] = {"kernel": kname, "avg_launch_us": us, "frac": ach / HBM_PEAK_GBS, "see": "roofline.critical_path, roofline.phases"}
         if phases:
@@ -769,8 +778,11 @@ def main():
     # latency-bound pipeline by several percent.
     prof = VilProfile()
     phases_head = None
+    lpi0, one0 = C.c_int32(0), C.c_int32(0)
+    be.lib.vil_debug_get_launch_structure(be.ctx, C.byref(lpi0), C.byref(one0))
+    persistent = one0.value == 1 and lpi0.value == 0      # the whole solve is one resident launch (k_solve): events around THAT launch + its own stamps (profile mode 2 keeps the launch structure)
     if not args.no_events:
-        be.lib.vil_profile_enable(be.ctx, 1)
+        be.lib.vil_profile_enable(be.ctx, 2 if persistent else 1)
         run(2)
         be.lib.vil_profile_read(be.ctx, C.byref(prof), 1)
         sync()
@@ -931,21 +943,21 @@ def main():
                     out["communicator"]["message_bytes_per_peer_rank0"] = int(mbb.value); out["communicator"]["full_set_bytes"] = int(fbb.value)
         if prof.sweep_launches > 0:
             out["roofline"] = roofline_obj(w, prof, "second pass of the same %d steps with HIP events enabled (%.1f ms/step instrumented vs %.1f ms/step in the value region)" % (args.steps, 1e3 * el_events / args.steps, 1e3 * max_el / args.steps),
-                                           ("r05_pmc_fetch_size.csv", "r05_pmc_write_size.csv"), "profiles/r05_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command)", "r05_pmc_mfma.csv",
-                                           one_launch=one_launch, phases=phases_head, two_launch=two_launch)
+                                           ("r06_pmc_fetch_size.csv", "r06_pmc_write_size.csv"), "profiles/r06_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command)", "r06_pmc_mfma.csv",
+                                           one_launch=one_launch, phases=phases_head, two_launch=two_launch, persistent=persistent)
             out["launches_per_iteration"] = int(lpi.value)
         if world == 1 and pcie_leg is not None:
             out["pcie_inclusive"] = pcie_leg
             out["pcie_inclusive_classic"] = pcie_classic
         if cfg3_leg:
             if prof3.sweep_launches > 0:
-                cfg3_leg["roofline"] = roofline_obj(w3, prof3, "a further pass of the same %d steps with HIP events enabled" % n3, ("r05_pmc_fetch_size_c3.csv", "r05_pmc_write_size_c3.csv"),
-                                                    "profiles/r05_pmc_{fetch,write}_size_c3.csv (rocprofv3 --pmc passes of bench.py --config 3)", "r05_pmc_mfma_c3.csv", one_launch=leg_one.get(3, False), phases=leg_phases.get(3))
+                cfg3_leg["roofline"] = roofline_obj(w3, prof3, "a further pass of the same %d steps with HIP events enabled" % n3, ("r06_pmc_fetch_size_c3.csv", "r06_pmc_write_size_c3.csv"),
+                                                    "profiles/r06_pmc_{fetch,write}_size_c3.csv (rocprofv3 --pmc passes of bench.py --config 3)", "r06_pmc_mfma_c3.csv", one_launch=leg_one.get(3, False), phases=leg_phases.get(3))
             out["configs2_window"] = cfg3_leg
         if cfg4_leg:
             if prof4.sweep_launches > 0:
-                cfg4_leg["roofline"] = roofline_obj(w4, prof4, "a further pass of the same %d steps with HIP events enabled" % n4, ("r05_pmc_fetch_size_c4.csv", "r05_pmc_write_size_c4.csv"),
-                                                    "profiles/r05_pmc_{fetch,write}_size_c4.csv (rocprofv3 --pmc passes of bench.py --config 4)", "r05_pmc_mfma_c4.csv", one_launch=leg_one.get(4, False), phases=leg_phases.get(4))
+                cfg4_leg["roofline"] = roofline_obj(w4, prof4, "a further pass of the same %d steps with HIP events enabled" % n4, ("r06_pmc_fetch_size_c4.csv", "r06_pmc_write_size_c4.csv"),
+                                                    "profiles/r06_pmc_{fetch,write}_size_c4.csv (rocprofv3 --pmc passes of bench.py --config 4)", "r06_pmc_mfma_c4.csv", one_launch=leg_one.get(4, False), phases=leg_phases.get(4))
             out["configs3_window"] = cfg4_leg
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(w, opts)

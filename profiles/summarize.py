@@ -20,8 +20,9 @@ def main():
         dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print("%-44s %6s %10s %6s %10s %10s" % ("kernel", "calls", "avg_us", "live", "live_avg", "live_max"))
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-        own = any(f in k for f in ("k_sweep", "k_reduce", "k_step<", "k_iter<"))      # (k_sweep is a template since round 3: "void k_sweep<true>(...)"; k_iter: round 5, the one-launch iteration)
-        thr = (8.0 if ("k_sweep" in k or "k_step<" in k or "k_iter<" in k) else 5.0) if own else 0.0
+        own = any(f in k for f in ("k_sweep", "k_reduce", "k_step<", "k_iter<", "k_solve<"))      # (k_solve: round 6, the whole solve as one resident launch)
+        own_dummy = 0      # (k_sweep is a template since round 3: "void k_sweep<true>(...)"; k_iter: round 5, the one-launch iteration)
+        thr = (8.0 if ("k_sweep" in k or "k_step<" in k or "k_iter<" in k or "k_solve<" in k) else 5.0) if own else 0.0
         live = [x for x in v if x > thr]
         print("%-44s %6d %10.2f %6d %10.2f %10.2f" % (k[:44], len(v), sum(v) / len(v), len(live), sum(live) / max(1, len(live)), max(v)))
         if "k_iter<" in k and live:
@@ -34,7 +35,7 @@ def main():
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"]].append(float(r["Counter_Value"])); name = r["Counter_Name"]
         for k, v in acc.items():
-            if any(f in k for f in ("k_sweep", "k_reduce", "k_step<", "k_iter<")):
+            if any(f in k for f in ("k_sweep", "k_reduce", "k_step<", "k_iter<", "k_solve<")):
                 live = [x for x in v if x > 0.25 * max(v)]
                 print("%s %-40s live launches %4d  mean %.1f KB" % (name, k[:40], len(live), sum(live) / max(1, len(live))))
     if len(sys.argv) > 4:
@@ -42,7 +43,7 @@ def main():
         for r in csv.DictReader(open(sys.argv[4])):
             acc[r["Kernel_Name"]][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         for k, v in acc.items():
-            if ("k_sweep" in k or "k_iter<" in k) and v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            if ("k_sweep" in k or "k_iter<" in k or "k_solve<" in k) and v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
                 # the Schur contraction of the landmark block: every visual workgroup of the sweep (one per compute unit) on the fp64 matrix cores
                 d = [x[1] for x in v["SQ_VALU_MFMA_BUSY_CYCLES"]]
                 live = [i for i, x in enumerate(d) if x > 0.5 * max(d)]
