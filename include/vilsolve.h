@@ -299,7 +299,7 @@ int vil_debug_set_launch_mode(vil_ctx* ctx, int32_t mode);
  * A failed capture is not an error: nothing has run yet, the solve at hand and every later solve of the context launch directly.  n = 0 re-arms graph replay. */
 int vil_debug_fail_graph_capture(vil_ctx* ctx, int32_t n);
 /* Recovery of a one-launch solve whose workgroups could not all run together.  The one-launch iteration's roles wait for one another inside the launch; every such
- * wait is bounded by TIME (0.25 s of the device's 100 MHz wall clock).  A wait that gives up ends the launches at once; vil_solve_resident / vil_solve / vil_win_solve
+ * wait is bounded by TIME (50 ms of the device's 100 MHz wall clock).  A wait that gives up ends the launches at once; vil_solve_resident / vil_solve / vil_win_solve
  * then put the resident state back to what the solve started from and run the SAME solve again with two launches per iteration (sweep, then gather + step: mode 3 of
  * vil_debug_set_launch_mode -- same results to rounding), and return its result.  Only if that attempt gives up too is VIL_ERR_DEVICE returned -- with the resident
  * state (and the caller's vil_state) as the solve found them.  The next solve takes the one-launch structure again.

@@ -156,7 +156,7 @@ struct DevP {
     unsigned long long* xtag;      // persistent solve: the candidate's camera part as 2 (16 K + 8) tagged words {half of a value, epoch}, written by the master, polled by the sweep roles
     unsigned long long* ihdr;      // persistent solve (k_solve): the 64-byte hand-over line between two iterations (vil_iter.hpp)
     int drop_role, drop_launch;    // test hook (vil_debug_drop_flag): sweep role `drop_role` (its workgroup index in k_sweep's order; -2 - g: gather workgroup g) does not post its flag in launch `drop_launch` (0-based) of the solve; -1: off
-    int* abortf;                   // one-launch iteration: a wait on another workgroup's flag that lasts 0.25 s gives up and says so here; every later wait returns at once (vil_math.hpp: spin_until_eq)
+    int* abortf;                   // one-launch iteration: a wait on another workgroup's flag that lasts 50 ms gives up and says so here; every later wait returns at once (vil_math.hpp: spin_until_eq)
     long long* prof;               // != null: wall-clock stamps (s_memrealtime, 100 MHz) of the roles of a one-launch iteration, 8 per launch slot (vil_profile)
     int gather_pose_only;          // the gather forms S' on the visual sub-space + the diagonal only (a solve on the prechain path: vil_sweep.hpp, reduce_gather)
     double* chW; double* chLraw; double* chLdg; double* chLsb; double* chSc; double* chDc; double* chZ; double* chQ; int* chOk; double* chWW;

@@ -237,11 +237,11 @@ __device__ __forceinline__ void st_ag(double* p, double v) { __hip_atomic_store(
 __device__ __forceinline__ int ld_ag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_ag(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // Wait for a flag another workgroup of the launch posts.  abortf == null: wait as long as it takes.  abortf != null (the one-launch iteration, where nearly every
-// workgroup waits for others): give up after VIL_WAIT_TICKS of the 100 MHz wall clock (0.25 s -- TIME, not poll rounds: a poll is an L2 / fabric round trip whose
+// workgroup waits for others): give up after VIL_WAIT_TICKS of the 100 MHz wall clock (50 ms -- TIME, not poll rounds: a poll is an L2 / fabric round trip whose
 // length depends on what else the device is doing), or as soon as somebody else has, and say so in *abortf -- every later wait of every workgroup then returns at
 // once, the launches end, the master marks the solve `done` with status -2, and the host re-runs the solve with the multi-launch structure (vilsolve.hip,
 // vil_solve_resident).  The host's own poll window (2 s) is longer than this bound.
-#define VIL_WAIT_TICKS 25000000ull
+#define VIL_WAIT_TICKS 5000000ull
 // every 1024th poll round of a bounded wait: has somebody given up, or has this wait lasted too long?  (t0 = 0 on the first call: the clock starts 1024 rounds in)
 __device__ __forceinline__ bool wait_expired(unsigned long long& t0, int* abortf) {
     if (ld_ag(abortf) != 0) return true;

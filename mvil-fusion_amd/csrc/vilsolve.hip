@@ -261,6 +261,7 @@ struct vil_ctx {
     double* d_x0 = nullptr;
     double* d_xsave = nullptr;        // the state the solve at hand started from (written by its init launch)
     int drop_role = -1, drop_launch = -1;      // vil_debug_drop_flag: armed for the next solve
+    int rung_fail_run[2] = {0, 0}, rung_cooldown[2] = {0, 0};      // launch-structure ladder (vil_solve_resident): consecutive give-ups of the persistent solve / the one-launch iteration, solves they sit out
     int64_t n_recovered = 0, n_aborted = 0;    // solves whose one-launch attempt gave up and were re-run with two launches per iteration / that failed on both
     bool reset_pending = false;       // vil_reset_state called, the copy not launched yet
     std::vector<int> plane_perm, edge_perm;   // sorted index -> caller index
@@ -681,6 +682,10 @@ static int vil_helpers_for(int L) {
     if (L <= 15 * quad) return std::min(15, (L + quad - 1) / quad);
     return std::min(15, (L + pair - 1) / pair);
 }
+// Co-residency is decided per XCD: the dispatcher deals the workgroups of a grid round-robin to the eight XCDs, each of which places ITS share on ITS compute units.
+// n consecutive workgroups that wait for others therefore need ceil(n / 8) slots on every XCD, and one more for the workgroups they wait for to run through
+// (measured under a 32-unit mask, 4 units per XCD: 25 waiting workgroups fit the device's 32 slots and still starved the gather workgroups of one XCD).
+static bool fits_per_xcd(int n_resident, int capacity) { return (n_resident + 7) / 8 + 1 <= capacity / 8; }
 static int visual_wg_budget(int n_imu, int n_plane, int n_edge) { return std::max(64, 256 - (n_imu + 3 + (n_plane + 511) / 512 + (n_edge + 511) / 512)); }
 // diagnostic surface of the plan (no device needed: the CPU test suite checks its invariants; DESIGN.md quotes its record sizes)
 int vil_visual_plan(const vil_problem* p, vil_visual_plan_info* info, int32_t max_chunks, int32_t* chunk_first_frame, int32_t* chunk_frames, int32_t* chunk_factors, int32_t* chunk_landmarks,
@@ -1115,7 +1120,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     // dynamic LDS a step workgroup owns a compute unit; a device with fewer units than 1 + n_help runs without helpers.
     {
         int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) cus = 0;
+        cus = vilcoop::compute_units(c->device);      // (what this process really has: a CU mask is not in the device attribute)
         if (1 + P.n_help > cus / 2) P.n_help = 0;
     }
     UPTICK("workspace");
@@ -1226,7 +1231,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
             const size_t ldsm = std::max(lds3, ldsc);
             if (c->cap_step3 < 0 || c->cap_step3_lds != ldsm) { c->cap_step3 = vilcoop::capacity((const void*)k_step<true, 3>, VIL_STEP_THREADS, ldsm, c->device); c->cap_step3_lds = ldsm; }
             const int Tw = (int)(Tp_ * (Tp_ + 1) / 2);
-            if (c->cap_step3 < 1 + P.n_help + Tw + 2) merged = false;
+            if (!fits_per_xcd(1 + P.n_help + Tw + 1, c->cap_step3)) merged = false;
         }
         P.prechain = merged ? 1 : (can_pre ? 2 : 0);
         c->n_ww = 0;
@@ -1261,7 +1266,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
                 if ((int)li > c->attr_iter[v]) { HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)li)); c->attr_iter[v] = (int)li; }
                 if (c->cap_iter[v] < 0 || c->cap_iter_lds[v] != li) { c->cap_iter[v] = vilcoop::capacity(fn, VIL_STEP_THREADS, li, c->device); c->cap_iter_lds[v] = li; }
                 const int Tw = (int)(Tp_ * (Tp_ + 1) / 2);
-                if (c->cap_iter[v] >= 1 + P.n_help + Tw + 2) { c->fused = true; c->lds_iter = li; c->P.n_sw = c->n_blocks_sweep; }
+                if (fits_per_xcd(1 + P.n_help + Tw + 1, c->cap_iter[v])) { c->fused = true; c->lds_iter = li; c->P.n_sw = c->n_blocks_sweep; }      // (+ the chain workgroup)
                 // ---- the whole SOLVE in one resident launch (k_solve): the grid [sweep roles | chain | master | helpers | tiles] must fit the device at once with two
                 //      workgroups to spare, and every gather item must find a workgroup that takes it as a duty (tiles, helpers, sweep roles): configs[1]-sized
                 //      windows.  Everything else keeps one launch per iteration.  vil_debug_set_launch_mode(4) keeps k_iter.
@@ -1273,7 +1278,7 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
                         if ((int)ls > c->attr_solve[v]) { HIPCHK(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ls)); c->attr_solve[v] = (int)ls; }
                         if (c->cap_solve[v] < 0 || c->cap_solve_lds[v] != ls) { c->cap_solve[v] = vilcoop::capacity(fs, VIL_STEP_THREADS, ls, c->device); c->cap_solve_lds[v] = ls; }
                         const int grid = c->n_blocks_sweep + 2 + P.n_help + Tw, n_cap = c->n_blocks_sweep + P.n_help + Tw;
-                        if (grid + 2 <= c->cap_solve[v] && c->n_gather_m <= n_cap) { c->persist = true; c->lds_solve = ls; }
+                        if (fits_per_xcd(grid, c->cap_solve[v]) && c->n_gather_m <= n_cap) { c->persist = true; c->lds_solve = ls; }
                     }
                 }
             }
@@ -1852,42 +1857,42 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     const bool hook_sticky = hook && (c->drop_launch & 0x10000) != 0;      // (... and for the retry as well: the test of a solve that fails on both structures)
     c->P.drop_role = c->drop_role; c->P.drop_launch = c->drop_launch & 0xffff;
     c->drop_role = -1; c->drop_launch = -1;
-    bool gave_up = false;
-    int st = solve_attempt(c, o, sum, t0, hook, &gave_up);
-    if (!hook_sticky) { c->P.drop_role = -1; c->P.drop_launch = -1; }
-    if (!gave_up) return st;
-    // ---- a wait inside a launch gave up: the gate of the library is process-local and co-residency is a property of the whole device (another process's persistent
-    // kernel, a CU mask the occupancy query does not see), so the one-launch iteration carries this way out instead of a hang.  The state goes back to what the
-    // solve started from (the judge may have accepted a candidate whose cost was formed from incomplete sums) and the SAME solve runs again with the two-launch
-    // structure -- sweep launch, then gather + step launch, whose waiting workgroups only wait for workgroups dispatched BEFORE them or for the handful of
-    // master / helper / tile workgroups (mode 3 of vil_debug_set_launch_mode; same results to rounding).  The caller (optimization(), estimator.cpp:1400-1414) has no retry of its own.
+    // The ladder of launch structures: the persistent solve (EVERY role resident at once), one launch per iteration (the handful of waiting workgroups resident at
+    // once), two launches per iteration.  A wait inside a launch that gives up (vil_math.hpp: 50 ms of the device clock) moves the SAME solve one rung down, from the
+    // state it started from -- co-residency is a property of the whole device (another process's persistent kernel, a CU mask the occupancy query does not see) and the
+    // library's gate is process-local, so this is the way out instead of a hang; the caller (optimization(), estimator.cpp:1400-1414) has no retry of its own.
+    // A rung that gives up in two consecutive solves is left out for the next 256 solves of the context (a masked device must not pay the wait per image).
+    const bool cfg_persist = c->persist, cfg_fused = c->fused;
     auto restore = [&]() -> int {
         HIPCHK(hipStreamSynchronize(c->stream));      // the drained launches of the attempt (every wait returns at once behind the abort word)
         hipLaunchKernelGGL(k_state_reset, dim3((c->NS + 255) / 256), dim3(256), 0, c->stream, c->P.x[0], c->P.x[1], (const double*)c->d_xsave, c->NS);
         c->reset_pending = false; c->mirror_state = false;
         return VIL_OK;
     };
-    st = restore();
-    if (st != VIL_OK) return st;
-    if (c->persist && c->fused && !c->split && !c->profiling) {
-        // the resident solve needs EVERY workgroup of its grid on the device at once; one launch per iteration only the handful that wait for one another
-        c->persist = false;
-        st = solve_attempt(c, o, sum, t0, true, &gave_up);
-        c->persist = true;
-        if (!gave_up) { c->P.drop_role = -1; c->P.drop_launch = -1; c->n_recovered++; return st; }
-        st = restore();
-        if (st != VIL_OK) return st;
+    for (int q = 0; q < 2; ++q) if (c->rung_cooldown[q] > 0) c->rung_cooldown[q]--;
+    const bool can_persist = cfg_persist && cfg_fused && !c->split && !c->profiling, can_fused = cfg_fused && !c->split;
+    int first = can_persist && c->rung_cooldown[0] == 0 ? 0 : (can_fused && c->rung_cooldown[1] == 0 ? 1 : 2);
+    if (!can_fused) first = 2;
+    bool gave_up = false, retried = false;
+    int st = VIL_ERR_DEVICE;
+    for (int rung = first; rung <= 2; ++rung) {
+        if (rung == 1 && !can_fused) continue;
+        c->persist = rung == 0; c->fused = cfg_fused && rung <= 1;
+        st = solve_attempt(c, o, sum, t0, hook || retried, &gave_up);
+        c->persist = cfg_persist; c->fused = cfg_fused;
+        if (!hook_sticky) { c->P.drop_role = -1; c->P.drop_launch = -1; }
+        if (!gave_up) {
+            if (rung < 2) c->rung_fail_run[rung] = 0;
+            if (retried) c->n_recovered++;
+            c->P.drop_role = -1; c->P.drop_launch = -1;
+            return st;
+        }
+        if (rung < 2 && ++c->rung_fail_run[rung] >= 2) { c->rung_cooldown[rung] = 256; c->rung_fail_run[rung] = 0; }
+        const int rs = restore();
+        if (rs != VIL_OK) return rs;
+        retried = true;
     }
-    if (c->fused && !c->split) {
-        const bool pz = c->persist;
-        c->fused = false; c->persist = false;          // (the upload prepared the merged gather + step launch as well: the one-launch iteration is only taken where that one is)
-        st = solve_attempt(c, o, sum, t0, true, &gave_up);
-        c->fused = true; c->persist = pz;              // the next solve takes the library's first choice again
-        c->P.drop_role = -1; c->P.drop_launch = -1;
-        if (!gave_up) { c->n_recovered++; return st; }
-        st = restore();
-        if (st != VIL_OK) return st;
-    }
+    c->P.drop_role = -1; c->P.drop_launch = -1;
     c->n_aborted++;
     HIPCHK(hipStreamSynchronize(c->stream));
     return VIL_ERR_DEVICE;                             // the resident state is the one the solve started from

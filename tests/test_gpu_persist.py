@@ -119,7 +119,7 @@ def test_a_lost_flag_in_the_persistent_solve_falls_back_to_one_launch_per_iterat
     be.reset_state()
     t0 = time.perf_counter(); s = be.solve_resident(); dt = time.perf_counter() - t0
     assert bits(s) == ref4 and np.array_equal(state_of(be, w2), x4)      # re-run as one launch per iteration: that structure's bits
-    assert 0.2 < dt < 3.0, dt
+    assert 0.04 < dt < 3.0, dt
     assert counts(be) == (before[0] + 1, before[1])
     be.reset_state()
     t0 = time.perf_counter(); s = be.solve_resident(); dt = time.perf_counter() - t0

@@ -1,6 +1,6 @@
 """The one-launch iteration's way out: a wait inside the launch that gives up must not end the caller's solve with an error.
 
-The roles of k_iter wait for one another's flags; every wait is bounded by the device's wall clock (0.25 s).  When one gives up, vil_solve_resident restores the
+The roles of k_iter wait for one another's flags; every wait is bounded by the device's wall clock (50 ms).  When one gives up, vil_solve_resident restores the
 state the solve started from and re-runs the SAME solve with two launches per iteration (mode 3 of vil_debug_set_launch_mode), returns that result, and the next
 solve is a one-launch solve again.  vil_debug_drop_flag stands in for a workgroup that never became resident."""
 import copy
@@ -69,7 +69,7 @@ def test_lost_flag_is_recovered_by_the_two_launch_structure(oracle, window, role
         dt = time.perf_counter() - t0
         assert bits(s) == ref3, (bits(s), ref3)                   # ... with the two-launch structure: that structure's bits
         assert np.array_equal(state_of(be, copy.deepcopy(w)), x3)
-        assert 0.2 < dt < 3.0, dt                                  # one bounded wait (0.25 s), not a hang and not the host's 2 s poll window twice
+        assert 0.04 < dt < 3.0, dt                                  # one bounded wait (50 ms), not a hang and not the host's 2 s poll window twice
         after = counts(be)
         assert after[0] == before[0] + 1 and after[1] == before[1]
         # the abort word is cleared and the next solve is a one-launch solve again: its bits, at its speed
