@@ -594,6 +594,110 @@ def preint_mode(args):
     g.close()
 
 
+def solve_batch(bes, opts, abi):
+    n = len(bes)
+    ctxs = (C.c_void_p * n)(*[b.ctx for b in bes])
+    sums = (abi.VilSummary * n)(); st = (C.c_int32 * n)()
+    f = bes[0].lib.vil_solve_batch; f.restype = C.c_int
+    rc = f(ctxs, C.c_int32(n), C.byref(opts), sums, st)
+    if rc != 0:
+        raise RuntimeError("vil_solve_batch: status %d" % rc)
+    return sum(s.iterations for s in sums)
+
+
+def concurrent_windows(lib, abi, w, opts, steps, device=0, Bs=(1, 2, 4, 8)):
+    """B contexts of the SAME window solved concurrently (vil_solve_batch: a stream + a host thread each, one launch per iteration): aggregate iterations/s.
+    One window keeps one master workgroup busy for two thirds of an iteration -- this is what the device does with the rest; the single-GPU form of `replicas`."""
+    import torch
+    ab = algorithmic_bytes(w)
+    bes = [lib.open_vilsolve(device=device) for _ in range(max(Bs))]
+    for be in bes:
+        be.upload(w)
+    rows = []
+    for B in Bs:
+        grp = bes[:B]
+        for _ in range(3):
+            for be in grp: be.reset_state()
+            solve_batch(grp, opts, abi)
+        torch.cuda.synchronize(); t0 = time.perf_counter(); its = 0
+        for _ in range(steps):
+            for be in grp: be.reset_state()
+            its += solve_batch(grp, opts, abi)
+        torch.cuda.synchronize(); el = time.perf_counter() - t0
+        rows.append({"B": B, "aggregate_it_per_s": its / el, "ms_per_batch": 1e3 * el / steps, "hbm_frac_of_the_sweeps": (its + B * steps) * ab / el / 1e9 / HBM_PEAK_GBS})
+    for be in bes:
+        be.close()
+    base = rows[0]["aggregate_it_per_s"]
+    for r in rows:
+        r["speedup_vs_B1"] = r["aggregate_it_per_s"] / base
+    return {"what": "vil_solve_batch: B resident contexts of the configs[1] window, one launch per trust-region iteration each (k_iter), a stream and a host thread per context; every window's result is bit-equal to its solo solve (tests/test_gpu_batch.py)",
+            "steps_per_B": steps, "rows": rows, "note": "B = 1 here is one launch per iteration through the batch entry point (a thread per call); the headline `value` is the persistent solve of ONE window"}
+
+
+def batch_mode(args):
+    import torch
+    graft.load_package()
+    from mvil_fusion_amd import abi, lib, synth
+    be0 = lib.open_vilsolve()
+    def gpu_prior(pre):
+        return be0.marginalize(pre).to_prior()
+    w = synth.make_config(2, prior_fn=gpu_prior)
+    be0.close()
+    out = {"metric": "concurrent windows on one GPU: aggregate solve iterations/sec (10 KF, 1k feat, 30k LiDAR pts per window)", "unit": "iterations/s", "n_gpus": 1, "dtype": "f64", "data": "synthetic", "higher_is_better": True}
+    out["concurrent_windows"] = concurrent_windows(lib, abi, w, abi.default_options(), args.steps)
+    out["value"] = max(r["aggregate_it_per_s"] for r in out["concurrent_windows"]["rows"])
+    emit(out)
+
+
+def scale_sweep_mode(args):
+    """What the kernels do when there IS work: the configs[1] shape with s x the landmarks and LiDAR points, K = 10.  Per size: the sweep phase of the
+    iteration (the launch's own clock stamps / the sweep launch's HIP events) against the HBM roof, the whole iteration, and which launch structure the library took.
+    The --pmc passes of this command (tools/collect_profiles_r06.sh) add FETCH / WRITE / MFMA per size to profiles/r06_scale_sweep.txt."""
+    import torch
+    graft.load_package()
+    from mvil_fusion_amd import abi, lib, synth
+    opts = abi.default_options()
+    rows = []
+    for sc in [int(v) for v in args.scales.split(",")]:
+        w = synth.make_config(2, L=1000 * sc, n_plane=24000 * sc, n_edge=6000 * sc)      # (no marginalisation prior: the generator's synthetic one)
+        be = lib.open_vilsolve()
+        if args.launch_mode:
+            be.lib.vil_debug_set_launch_mode(be.ctx, args.launch_mode)
+        try:
+            be.upload(w)
+        except lib.VilError as e:
+            rows.append({"scale": sc, "error": "upload status %d" % e.status}); be.close(); continue
+        lpi, one = C.c_int32(0), C.c_int32(0)
+        be.lib.vil_debug_get_launch_structure(be.ctx, C.byref(lpi), C.byref(one))
+        n = max(3, args.steps // max(1, sc))
+        for _ in range(2):
+            be.reset_state(); be.solve_resident(opts)
+        torch.cuda.synchronize(); t0 = time.perf_counter(); its = 0
+        for _ in range(n):
+            be.reset_state(); its += be.solve_resident(opts).iterations
+        torch.cuda.synchronize(); el = time.perf_counter() - t0
+        row = {"scale": sc, "landmarks": w.L, "visual_factors": int(len(w.vis_i)), "lidar_points": int(len(w.plane_pose) + len(w.edge_pose)), "launches_per_iteration": int(lpi.value),
+               "iterations_per_s": its / el, "us_per_iteration": 1e6 * el / its, "algorithmic_bytes_per_sweep": algorithmic_bytes(w)}
+        if not args.no_events:
+            prof = VilProfile()
+            be.lib.vil_profile_enable(be.ctx, 2 if lpi.value == 0 else 1)
+            be.reset_state(); be.solve_resident(opts); be.lib.vil_profile_read(be.ctx, C.byref(prof), 1)
+            for _ in range(n):
+                be.reset_state(); be.solve_resident(opts)
+            be.lib.vil_profile_read(be.ctx, C.byref(prof), 1)
+            be.lib.vil_profile_enable(be.ctx, 0)
+            if prof.sweep_launches > 0:
+                sweep_us = 1e3 * prof.sweep_ms / prof.sweep_launches
+                row["sweep_phase_us"] = sweep_us
+                row["sweep_phase_GBps"] = row["algorithmic_bytes_per_sweep"] / (sweep_us * 1e-6) / 1e9
+                row["sweep_phase_frac_of_hbm_peak"] = row["sweep_phase_GBps"] / HBM_PEAK_GBS
+        rows.append(row)
+        be.close()
+    emit({"metric": "factor sweep against the HBM roof as the window grows (K = 10)", "unit": "GB/s", "value": max([r.get("sweep_phase_GBps", 0.0) for r in rows] + [0.0]), "n_gpus": 1, "dtype": "f64", "data": "synthetic",
+          "higher_is_better": True, "peak": HBM_PEAK_GBS, "scale_sweep": rows,
+          "what": "configs[1] shape x scale: the sweep phase = first workgroup started -> last sweep role's record out (one-launch structures: the launch's own 100 MHz stamps; otherwise HIP events around k_sweep)"})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -617,6 +721,10 @@ def main():
     ap.add_argument("--scan-surf", type=int, default=6000); ap.add_argument("--scan-corner", type=int, default=800)
     ap.add_argument("--preint", action="store_true", help="SURVEY 8(f) row 3: bench the IMU pre-integration instead of the headline metric")
     ap.add_argument("--preint-intervals", type=int, default=9)
+    ap.add_argument("--batch", action="store_true", help="concurrent windows on one GPU (vil_solve_batch): aggregate iterations/s for B = 1, 2, 4, 8 contexts of the configs[1] window")
+    ap.add_argument("--scale-sweep", dest="scale_sweep", action="store_true", help="the configs[1] shape at 1x, 4x, 16x, 64x landmarks and LiDAR points (K = 10): what the sweep does when it has work")
+    ap.add_argument("--scales", type=str, default="1,4,16,64")
+    ap.add_argument("--launch-mode", dest="launch_mode", type=int, default=0, help="scale sweep: vil_debug_set_launch_mode (4 = one launch per iteration also where the persistent solve would be taken: the counter passes)")
     ap.add_argument("--force-comm", action="store_true", help="test hook: take the multi-GPU code path (process group, communicator, replicas leg) with a single rank")
     ap.add_argument("--replicas", action="store_true", help="N>1: independent replicas instead of sharding one window over RCCL")
     ap.add_argument("--ipc", action="store_true", help="N>1: the library's peer-buffer exchange (IPC-mapped inboxes over xGMI, vil_comm_ipc_*) instead of RCCL for the per-iteration collective")
@@ -659,6 +767,10 @@ def main():
             graft.build()              # a checkout without built artefacts (the .so files are git-ignored): compile, do not fall back
         if dist is not None:
             dist.barrier()
+    if args.batch:
+        return batch_mode(args)
+    if args.scale_sweep:
+        return scale_sweep_mode(args)
     if args.vgicp:
         vgicp_mode(args)
         return

@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <shared_mutex>
 #include <algorithm>
 
 namespace vilcoop {
@@ -55,7 +56,9 @@ inline int compute_units(int device) {
     cache[d] = got; have[d] = true;
     return got;
 }
-inline std::mutex& gate(int device) { static std::mutex m[64]; return m[(unsigned)device & 63u]; }          // (inline function: one instance per shared object)
+// gate(dev): EXCLUSIVE (std::unique_lock) for a launch whose whole grid must be resident (k_solve, k_pose_solve, k_vgicp_align); SHARED (std::shared_lock) for the
+// solves of a vil_solve_batch -- one-launch iterations, a handful of waiting workgroups each, whose sum the batch checks against the device (vilsolve.hip)
+inline std::shared_mutex& gate(int device) { static std::shared_mutex m[64]; return m[(unsigned)device & 63u]; }          // (inline function: one instance per shared object)
 inline int capacity(const void* func, int threads, size_t dyn_lds, int device) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, func, threads, dyn_lds) != hipSuccess) { (void)hipGetLastError(); return 0; }

@@ -357,7 +357,7 @@ int align_fused(vmap_ctx* c, int n_corner, int n_surf, double* q, double* t, con
             if (hipHostGetDevicePointer(&c->d_res, c->h_res, 0) != hipSuccess) { hipHostFree(c->h_res); c->h_res = nullptr; c->d_res = nullptr; }
         } else c->h_res = nullptr;
     }
-    std::lock_guard<std::mutex> coop_lock(vilcoop::gate(c->device));                     // k_pose_solve's workgroups wait for one another (vil_coop.hpp)
+    std::unique_lock<std::shared_mutex> coop_lock(vilcoop::gate(c->device));                     // k_pose_solve's workgroups wait for one another (vil_coop.hpp)
     const int G = std::min(std::min(VP1_MAXG, c->coop_cap), std::max(1, (nq + VP1_THREADS - 1) / VP1_THREADS));
     double* edge_soa = c->d_soa; double* plane_soa = c->d_soa + (size_t)9 * es;
     double* h_pose = (double*)(c->h_reg + REG_POSE);

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <vector>
 #include <mutex>
+#include <thread>
 #include <array>
 #include <memory>
 #include <pthread.h>
@@ -261,6 +262,7 @@ struct vil_ctx {
     double* d_x0 = nullptr;
     double* d_xsave = nullptr;        // the state the solve at hand started from (written by its init launch)
     int drop_role = -1, drop_launch = -1;      // vil_debug_drop_flag: armed for the next solve
+    bool in_batch = false;         // this solve is one of a vil_solve_batch (shared gate, no persistent solve)
     int rung_fail_run[2] = {0, 0}, rung_cooldown[2] = {0, 0};      // launch-structure ladder (vil_solve_resident): consecutive give-ups of the persistent solve / the one-launch iteration, solves they sit out
     int64_t n_recovered = 0, n_aborted = 0;    // solves whose one-launch attempt gave up and were re-run with two launches per iteration / that failed on both
     bool reset_pending = false;       // vil_reset_state called, the copy not launched yet
@@ -1845,8 +1847,10 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     // the library a solve holds its device's gate until its result has arrived, so that it never shares the device with a half-resident
     // k_pose_solve / k_vgicp_align of another thread (vil_coop.hpp).  Not taken by the ranks of a communicator (in-process, peer buffers, RCCL): they wait
     // for EACH OTHER's launches inside the per-iteration collective -- two ranks driven from threads of one process would deadlock on it.
-    std::unique_lock<std::mutex> coop_lock(vilcoop::gate(c->device), std::defer_lock);
-    if (!c->split) coop_lock.lock();
+    // (the solves of a vil_solve_batch share the gate: one launch per iteration each, never the persistent solve -- the batch has checked that their waiting workgroups fit together)
+    std::unique_lock<std::shared_mutex> coop_lock(vilcoop::gate(c->device), std::defer_lock);
+    std::shared_lock<std::shared_mutex> coop_shared(vilcoop::gate(c->device), std::defer_lock);
+    if (!c->split) { if (c->in_batch) coop_shared.lock(); else coop_lock.lock(); }
     if ((c->P.gauge_on != 0) != c->gauge_on) {            // vil_set_gauge_fix since the upload: the captured graphs carry the old flag
         c->P.gauge_on = c->gauge_on ? 1 : 0;
         for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
@@ -1870,7 +1874,7 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
         return VIL_OK;
     };
     for (int q = 0; q < 2; ++q) if (c->rung_cooldown[q] > 0) c->rung_cooldown[q]--;
-    const bool can_persist = cfg_persist && cfg_fused && !c->split && !c->profiling, can_fused = cfg_fused && !c->split;
+    const bool can_persist = cfg_persist && cfg_fused && !c->split && !c->profiling && !c->in_batch, can_fused = cfg_fused && !c->split;
     int first = can_persist && c->rung_cooldown[0] == 0 ? 0 : (can_fused && c->rung_cooldown[1] == 0 ? 1 : 2);
     if (!can_fused) first = 2;
     bool gave_up = false, retried = false;
@@ -1896,6 +1900,35 @@ int vil_solve_resident(vil_ctx* c, const vil_options* o, vil_summary* sum) {
     c->n_aborted++;
     HIPCHK(hipStreamSynchronize(c->stream));
     return VIL_ERR_DEVICE;                             // the resident state is the one the solve started from
+}
+
+// B windows solved CONCURRENTLY on one device: every context on its own stream, one launch per trust-region iteration each (k_iter), driven by a host thread per
+// context.  A single window leaves most of the device idle behind its sweep phase (one master workgroup on dependent fp64 chains); B of them interleave -- the
+// single-GPU form of the `replicas` leg of a multi-GPU run.  Each window's result is bit-equal to its solo solve with one launch per iteration.
+int vil_solve_batch(vil_ctx** ctxs, int32_t n, const vil_options* o, vil_summary* sums, int32_t* statuses) {
+    if (!ctxs || n < 1 || n > 16 || !o || !sums || !statuses) return VIL_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || !ctxs[i]->uploaded || ctxs[i]->resident_kind != 1 || ctxs[i]->split || ctxs[i]->device != ctxs[0]->device) return VIL_ERR_INVALID_ARGUMENT;
+        for (int j = 0; j < i; ++j) if (ctxs[j] == ctxs[i]) return VIL_ERR_INVALID_ARGUMENT;
+    }
+    // how many of them may wait inside their launches at once: the waiting workgroups of all (master, helpers, tiles, chain) must fit the device per XCD
+    int group = n;
+    {
+        int waiting = 0, cap = 1 << 30;
+        for (int i = 0; i < n; ++i) { const vil_ctx* c = ctxs[i]; waiting = std::max(waiting, 2 + c->P.n_help + c->n_ww); const int v = c->P.vis_ts == 2 ? 0 : 1; if (c->fused && c->cap_iter[v] > 0) cap = std::min(cap, c->cap_iter[v]); }
+        while (group > 1 && !fits_per_xcd(group * waiting, cap)) --group;
+    }
+    for (int i0 = 0; i0 < n; i0 += group) {
+        const int m = std::min(group, n - i0);
+        std::vector<std::thread> th;
+        for (int k = 0; k < m; ++k) {
+            vil_ctx* c = ctxs[i0 + k];
+            th.emplace_back([c, o, sums, statuses, i0, k]() { c->in_batch = true; statuses[i0 + k] = vil_solve_resident(c, o, &sums[i0 + k]); c->in_batch = false; });
+        }
+        for (auto& t : th) t.join();
+    }
+    for (int i = 0; i < n; ++i) if (statuses[i] != VIL_OK) return statuses[i];
+    return VIL_OK;
 }
 
 int vil_debug_drop_flag(vil_ctx* c, int32_t role, int32_t launch) {

@@ -823,7 +823,7 @@ int vgicp_align(vgicp_ctx* c, const double* guess, const vgicp_options* o, doubl
     VgGuess gs; std::memcpy(gs.m, guess, sizeof gs.m);
     if (c->coop_cap < 0) c->coop_cap = vilcoop::capacity((const void*)k_vgicp_align, VGA_THREADS, 0, c->device);
     if (c->coop_cap < 1) return vgicp_align_host(c, guess, o, T_out, out);      // the kernel cannot be resident on this device: one launch per pass instead
-    std::lock_guard<std::mutex> coop_lock(vilcoop::gate(c->device));                     // held until the result record has arrived (vil_coop.hpp)
+    std::unique_lock<std::shared_mutex> coop_lock(vilcoop::gate(c->device));                     // held until the result record has arrived (vil_coop.hpp)
     int G = std::min(std::min(nblk, VG_MAXG), c->coop_cap);     // all workgroups resident: they wait for each other.  A pass is bound by the slots per thread (each a chain of dependent gathers), so as many workgroups as there are 256-slot blocks, up to 128 (VGICP_G sweeps it)
     if (const char* ev = VIL_TUNE_ENV("VGICP_G")) G = std::max(1, std::min(VG_MAXG, atoi(ev)));
     const int epoch_of_call = c->coop_epoch;

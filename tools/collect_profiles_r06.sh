@@ -37,6 +37,23 @@ timeout 300 python bench.py --vgicp --vgicp-rings 64 --vgicp-az 2048 > $O/r06_vg
 timeout 300 python bench.py --mapreg > $O/r06_mapreg.json 2>/dev/null
 timeout 300 python bench.py --preint > $O/r06_preint.json 2>/dev/null
 fi
+# scale sweep: the bench leg + counter passes per size (one launch per iteration everywhere: the counters are then per iteration at every size)
+timeout 600 python bench.py --scale-sweep --steps 20 > $O/r06_scale_sweep.json 2>/dev/null
+mkdir -p $O/scale
+for sc in 1 4 16 64; do
+  timeout 300 python bench.py --scale-sweep --scales $sc --launch-mode 4 --steps 12 > $O/scale/scale_$sc.json 2>/dev/null
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/p_sc; (cd /tmp; timeout 300 rocprofv3 --pmc $ctr --output-format csv -d /tmp/p_sc -- python $R/bench.py --scale-sweep --scales $sc --launch-mode 4 --steps 8 --no-events > /dev/null 2>&1)
+    lc=$(echo $ctr | tr A-Z a-z | sed s/_size//); find /tmp/p_sc -name "*counter_collection.csv" -exec cp {} $O/scale/scale_${sc}_$lc.csv \;
+  done
+  rm -rf /tmp/p_sc; (cd /tmp; timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d /tmp/p_sc -- python $R/bench.py --scale-sweep --scales $sc --launch-mode 4 --steps 8 --no-events > /dev/null 2>&1)
+  find /tmp/p_sc -name "*counter_collection.csv" -exec cp {} $O/scale/scale_${sc}_mfma.csv \;
+done
+python profiles/scale_summary.py $O/scale > $O/r06_scale_sweep.txt 2>&1
+rm -f $O/scale/*.csv
+timeout 300 python bench.py --batch --steps 30 > $O/r06_concurrent_windows.json 2>/dev/null
+GPU_MAX_HW_QUEUES=8 timeout 300 python bench.py --batch --steps 30 > $O/r06_concurrent_windows_8queues.json 2>/dev/null
+for c in 2; do MODE=0 CFG=$c timeout 120 python tools/probe_timeline.py; MODE=4 CFG=$c timeout 120 python tools/probe_timeline.py; done > $O/r06_timeline.txt 2>&1
 timeout 900 python tools/run_configs.py > $O/r06_configs.txt 2>&1
 for c in 2 3 4; do CFG=$c timeout 120 python tools/probe_phases.py; done > $O/r06_phases.txt 2>&1
 timeout 200 python tools/probe_tracker.py > $O/r06_tracker_breakdown.txt 2>&1

@@ -19,7 +19,8 @@ for cfg in [int(v) for v in os.environ.get("CFG", "2").split(",")]:
     el = time.perf_counter() - t0
     print("cfg %d mode %d: %.0f it/s (%.1f us per iteration, host clock, graph replay)" % (cfg, mode, its / el, 1e6 * el / its))
     if mode in (0, 4):
-        be.lib.vil_profile_enable(be.ctx, int(os.environ.get("PROF", "2" if mode == 0 else "1")))      # 2: stamps alone (the persistent solve keeps its launch)
+        lpi_, one_ = C.c_int32(0), C.c_int32(0); be.lib.vil_debug_get_launch_structure(be.ctx, C.byref(lpi_), C.byref(one_))
+        be.lib.vil_profile_enable(be.ctx, int(os.environ.get("PROF", "2" if lpi_.value == 0 else "1")))      # 2: stamps alone (the persistent solve keeps its launch)
         for _ in range(5): be.reset_state(); be.solve_resident(opts)
         avg = (C.c_double * 32)(); n = C.c_int64(0)
         be.lib.vil_profile_phases(be.ctx, avg, C.byref(n), 1)

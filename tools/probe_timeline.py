@@ -11,7 +11,8 @@ be = lib.open_vilsolve()
 if mode: assert be.lib.vil_debug_set_launch_mode(be.ctx, mode) == 0
 w = synth.make_config(cfg); be.upload(w)
 for _ in range(3): be.reset_state(); be.solve_resident()
-be.lib.vil_profile_enable(be.ctx, int(os.environ.get("PROF", "2" if mode == 0 else "1")))
+lpi_, one_ = C.c_int32(0), C.c_int32(0); be.lib.vil_debug_get_launch_structure(be.ctx, C.byref(lpi_), C.byref(one_))
+be.lib.vil_profile_enable(be.ctx, int(os.environ.get("PROF", "2" if lpi_.value == 0 else "1")))
 be.reset_state(); s = be.solve_resident()
 buf = (C.c_uint64 * (32 * 64))()
 n = be.lib.vil_debug_read_stamps(be.ctx, buf, 64)
