@@ -363,6 +363,10 @@ int vil_profile_read(vil_ctx* ctx, vil_profile* out, int reset);
 int vil_profile_phases(vil_ctx* ctx, double* avg_us32, int64_t* launches, int reset);
 /* the raw stamps (100 MHz device clock; 32 per launch / iteration, slot 0 stored inverted; 0: not stamped) of the last profiled solve: returns the launches copied */
 int vil_debug_read_stamps(vil_ctx* ctx, uint64_t* out, int32_t max_launches);
+/* the 16 wall-clock stamps (100 MHz) the kernels of the context's LAST marginalisation left: k_marg [0] entered, [1] dropped block gathered, [2] its Cholesky inverse
+ * done, [3] kept x dropped blocks staged, [4] T = A_kd A_dd^-1, [5] A = A_kk - T A_dk and b, [6] symmetrised copies out; k_marg_fast [7] entered, [8] tiles loaded,
+ * [9] n x n factorisation done, [10] J0 / r0 out; k_marg (pivoted square root, only when the un-pivoted one was refused) [11] entered, [12] done */
+int vil_debug_marg_stamps(vil_ctx* ctx, uint64_t* out16);
 
 /* replaces ceres::CostFunction::Evaluate for a whole factor class at once: raw (no loss) residuals
  * and row-major global-size Jacobian blocks, factor-major, in the caller's factor order. */

@@ -31,7 +31,9 @@ struct MargDev {
     double* J0; double* r0;     // n x n column-major, n
     double eps;
     int* stat;                  // [0] stages of the small eigen problem, [1] stages of the n x n one (diagnostic)
+    unsigned long long* ts;     // 16 wall-clock stamps (100 MHz) of the phases of the three launches (vil_debug_marg_stamps): k_marg 0 .. 6, k_marg_fast 7 .. 10, k_marg phase 1 11 .. 12
 };
+#define MSTAMP(k) do { if (threadIdx.x == 0 && M.ts) M.ts[k] = wall_clock64(); } while (0)
 
 namespace vd {
 
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M, int phase) {
     const int t = threadIdx.x, NT = blockDim.x;
     const int D = M.D, nd = M.nd, n = M.n;
     if (phase == 1) {
+        MSTAMP(11);
         if (M.stat[2] == 1) return;                      // the un-pivoted factorisation went through
         for (int e = t; e < n * n; e += NT) mlds[e] = M.J0[e];
         if (t < n) bsh[t] = M.b[t];
@@ -185,8 +188,10 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M, int phase) {
             const int j = e / n, k = e - j * n;                   // column-major element (k, j): J0[j*n + k]
             M.J0[e] = mlds[k * n + j];
         }
+        MSTAMP(12);
         return;
     }
+    MSTAMP(0);
     // ---- dropped block, symmetrised (marginalization_factor.cpp:273), eigen pseudo inverse ------------
     for (int e = t; e < nd * nd; e += NT) {
         const int i = e / nd, j = e - i * nd;
@@ -197,22 +202,32 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M, int phase) {
     // marginalization_factor.cpp:277 IS the inverse, and a 15 x 15 Cholesky inverse costs a few microseconds where the
     // eigen-decomposition (one-sided Jacobi, a workgroup barrier per rotation stage) costs ~100.  Certificate:
     // lambda_min = 1 / lambda_max(A_dd^-1) >= 1 / ||A_dd^-1||_F.  Anything else takes the eigen route below.
+    MSTAMP(1);
     __shared__ int fast_ok;
     double* W = sm; double* Li = sm + 225; double* Wr = sm + 450;      // nd <= 15: factor, its inverse, reciprocal pivots (sm holds 3 * 136 + 64 doubles)
     if (t == 0) fast_ok = nd <= 15 ? 1 : 0;
     for (int e = t; e < nd * nd; e += NT) W[e] = mlds[e];
     __syncthreads();
-    for (int p = 0; p < nd && fast_ok; ++p) {
-        const double d = W[p * nd + p];
-        if (!(d > 0.0) || !isfinite(d)) { __syncthreads(); if (t == 0) fast_ok = 0; __syncthreads(); break; }
-        const double r = rsqrt_nr(d);
-        __syncthreads();
-        if (t == 0) Wr[p] = r;
-        if (t >= p && t < nd) W[t * nd + p] *= r;
-        __syncthreads();
-        for (int e = t; e < nd * nd; e += NT) { const int i = e / nd, j = e - i * nd; if (j > p && i >= j) W[e] -= W[i * nd + p] * W[j * nd + p]; }
-        __syncthreads();
+    // (ONE wave factors the block, wave-synchronously -- LDS operations of a wave execute in order, a wait for them is all a step needs: 15 pivots in ~3 us.  With the
+    //  whole workgroup, three barriers of 1024 threads per pivot, the same loop took 14.7 us of every marginalisation: profiles/r06_marg_phases.txt)
+    if (t < 64 && fast_ok) {
+        bool okw = true;
+        for (int p = 0; p < nd; ++p) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const double d = W[p * nd + p];
+            if (!(d > 0.0) || !isfinite(d)) { okw = false; break; }      // (uniform: every lane read the same entry)
+            const double r = rsqrt_nr(d);
+            if (t == 0) Wr[p] = r;
+            if (t >= p && t < nd) W[t * nd + p] *= r;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            for (int e = t; e < nd * nd; e += 64) { const int i = e / nd, j = e - i * nd; if (j > p && i >= j) W[e] -= W[i * nd + p] * W[j * nd + p]; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!okw && t == 0) fast_ok = 0;
     }
+    __syncthreads();
     if (fast_ok) {
         if (t < nd) {                                    // column t of L^-1 by forward substitution
             const int j = t;
@@ -240,6 +255,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M, int phase) {
     // staged = the products below run out of LDS: the kept x dropped blocks of S, A_dd^-1 and T are gathered once, with every load of a
     // thread independent of the others -- the direct loops chase index -> S entry -> product nd times in a row per output element
     // (n = 70: some 75 dependent L2 round trips per thread, most of this kernel's time)
+    MSTAMP(2);
     const bool staged = fast_ok && (size_t)n * n >= 3 * (size_t)n * nd;
     double* Skd = mlds; double* Sdk = mlds + (size_t)n * nd; double* Tl = mlds + 2 * (size_t)n * nd;
     if (staged) {
@@ -251,6 +267,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M, int phase) {
             Sdk[(size_t)q * n + i] = M.S[(size_t)M.drop_cols[q] * D + M.keep_cols[i]];
         }
         __syncthreads();
+        MSTAMP(3);
         for (int e = t; e < n * nd; e += NT) {           // T = A_kd A_dd^-1
             const int i = e / nd, j = e - i * nd;
             double acc = 0.0;
@@ -289,6 +306,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M, int phase) {
     }
     __syncthreads();
     }
+    MSTAMP(4);
     // A = A_kk - T A_dk ; b = b_k - T b_d      (marginalization_factor.cpp:289-290)
     for (int e = t; e < n * n + n; e += NT) {
         if (e < n * n) {
@@ -305,12 +323,14 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(MargDev M, int phase) {
         }
     }
     __syncthreads();
+    MSTAMP(5);
     // Eigen's SelfAdjointEigenSolver reads the lower triangle only
     for (int e = t; e < n * n; e += NT) { const int i = e / n, j = e - i * n; M.J0[e] = i >= j ? M.V[e] : M.V[(size_t)j * n + i]; }
     __syncthreads();
     for (int e = t; e < n * n; e += NT) { M.A[e] = M.V[e]; }
     __syncthreads();
     if (t == 0) M.stat[2] = 0;
+    MSTAMP(6);
     // linearized_jacobians / linearized_residuals (marginalization_factor.cpp:301-309) are ANY pair with J0^T J0 = A and
     // J0^T r0 = b: the reference takes sqrt(S) V^T from an eigen-decomposition, whose basis is implementation-defined
     // (SURVEY App. C #12).  Here J0 = G^T from a Cholesky A = G G^T and r0 = G^-1 b: the prior residual r0 + J0 dx is the
@@ -326,6 +346,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_marg_fast(MargDev M) {
     __shared__ StepShared s;
     extern __shared__ double tl[];
     const int t = threadIdx.x, NT = blockDim.x, n = M.n;
+    MSTAMP(7);
     for (int q = t; q < 256; q += NT) {
         int Ir = (int)((sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
         if (((Ir + 1) * (Ir + 2)) / 2 <= q) ++Ir;
@@ -351,8 +372,10 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_marg_fast(MargDev M) {
         s.gr[i] = rel > 1e-30 ? rel : 1e-30;
     }
     __syncthreads();
+    MSTAMP(8);
     bool ok = chol_lookahead(tl, n, s);
     __syncthreads();
+    MSTAMP(9);
     if (ok) {
         for (int i = t; i < n; i += NT) { const double l = 1.0 / s.dinv[i]; if (!(l * l > s.gr[i])) s.ok = 0; }
         __syncthreads();
@@ -365,4 +388,5 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_marg_fast(MargDev M) {
     }
     for (int i = t; i < n; i += NT) M.r0[i] = tl[tl_idx(n, i)];
     if (t == 0) { M.stat[2] = 1; M.stat[1] = 0; }
+    MSTAMP(10);
 }

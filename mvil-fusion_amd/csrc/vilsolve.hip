@@ -277,12 +277,14 @@ struct vil_ctx {
     bool step_lds = false;
     int* d_status = nullptr;
     Ctl* h_ctl = nullptr;          // pinned
+    int* h_word = nullptr;         // pinned: status words read back from the device
     char* h_mirror = nullptr; Ctl* d_hctl = nullptr; int* d_hseq = nullptr; double* d_hstate = nullptr; size_t mirror_ns = 0;      // pinned + mapped: Ctl | sequence word | final state, written by solve_finish (vil_finish.hpp)
     bool no_poll = false;          // VIL_NO_POLL=1: copy + synchronise instead of polling the mirror
     bool mirror_state = false;     // the mirror holds the final state of the last solve (vil_download_state needs no device operation)
     int attr_sweep[2] = {0, 0}, attr_step[5] = {0, 0, 0, 0, 0}, attr_marg[2] = {0, 0}, attr_commit = 0;      // dynamic-LDS sizes already granted to the kernels (hipFuncSetAttribute is not free)
     double* h_pin = nullptr;       // pinned scratch
     char* marg_ws = nullptr;       // device work space of vil_marginalize (grow-only)
+    unsigned long long* d_marg_ts = nullptr;      // phase stamps of the last marginalisation's kernels (vil_debug_marg_stamps)
     size_t marg_ws_bytes = 0;
     size_t h_pin_bytes = 0;
     std::vector<int> prior_joff;
@@ -479,6 +481,7 @@ int vil_create(const vil_device_cfg* cfg, vil_ctx** out) {
     HIPCHK(hipMalloc(&c->d_status, sizeof(int)));
     HIPCHK(hipMemset(c->d_status, 0, sizeof(int)));
     HIPCHK(hipHostMalloc(&c->h_ctl, sizeof(Ctl), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->h_word, 64, hipHostMallocDefault));      // small status reads land in PINNED memory: the first asynchronous copy into pageable memory of a process makes the runtime build its staging buffers (7 ms, measured: the "first vil_marginalize costs 9 ms" of rounds 3 - 5)
     c->no_poll = getenv("VIL_NO_POLL") != nullptr;
     memset(&c->P, 0, sizeof c->P);
     *out = c;
@@ -500,6 +503,7 @@ void vil_destroy(vil_ctx* c) {
     if (c->dep_ev) hipEventDestroy(c->dep_ev);
     if (c->d_status) hipFree(c->d_status);
     if (c->h_ctl) hipHostFree(c->h_ctl);
+    if (c->h_word) hipHostFree(c->h_word);
     if (c->h_mirror) hipHostFree(c->h_mirror);
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->marg_ws) hipFree(c->marg_ws);
@@ -1327,11 +1331,11 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
     const int nb_setup = ws ? 0 : P.n_imu + (P.pn ? 64 : 0);
     if (nb_setup > 0) hipLaunchKernelGGL(k_setup, dim3(nb_setup), dim3(VIL_THREADS), 0, c->stream, P, const_cast<double*>(P.imu_U), c->d_status);
     if (check_setup) {
-        int hstat = 0;
-        HIPCHK(hipMemcpyAsync(&hstat, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        c->h_word[0] = 0;
+        HIPCHK(hipMemcpyAsync(c->h_word, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipGetLastError());
-        if (hstat != 0) return VIL_ERR_NOT_POSITIVE_DEFINITE;
+        if (c->h_word[0] != 0) return VIL_ERR_NOT_POSITIVE_DEFINITE;
     }
     UPTICK("setup");
     c->uploaded = true; c->resident_kind = 2;    // vil_upload / vil_solve promote it to 1
@@ -1510,12 +1514,12 @@ static int comm_agree(vil_ctx* c, int st) {
         return worst;
     }
     if (c->comm) {
-        int h = st;
-        if (hipMemcpyAsync(c->d_status, &h, sizeof(int), hipMemcpyHostToDevice, c->stream) != hipSuccess) return VIL_ERR_DEVICE;
+        int* h = c->h_word + 4; *h = st;
+        if (hipMemcpyAsync(c->d_status, h, sizeof(int), hipMemcpyHostToDevice, c->stream) != hipSuccess) return VIL_ERR_DEVICE;
         if (g_rccl.AllReduce(c->d_status, c->d_status, 1, ncclInt, ncclMin, c->comm, c->stream) != ncclSuccess) return VIL_ERR_COMM;
-        if (hipMemcpyAsync(&h, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return VIL_ERR_DEVICE;
+        if (hipMemcpyAsync(h, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return VIL_ERR_DEVICE;
         if (hipStreamSynchronize(c->stream) != hipSuccess) return VIL_ERR_DEVICE;
-        return h;
+        return *h;
     }
     return st;
 }
@@ -1639,6 +1643,13 @@ int vil_debug_read_stamps(vil_ctx* c, uint64_t* out, int32_t max_launches) {
     const size_t n = std::min((size_t)max_launches * VIL_PROF_SLOTS, c->last_stamps.size());
     for (size_t i = 0; i < n; ++i) out[i] = c->last_stamps[i];
     return (int)(n / VIL_PROF_SLOTS);
+}
+int vil_debug_marg_stamps(vil_ctx* c, uint64_t* out16) {
+    if (!c || !out16 || !c->d_marg_ts) return VIL_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out16, c->d_marg_ts, 8 * 16, hipMemcpyDeviceToHost));
+    return VIL_OK;
 }
 int vil_debug_read(vil_ctx* c, long long* out64) {
     if (!c || !c->uploaded) return VIL_ERR_INVALID_ARGUMENT;
@@ -2134,7 +2145,7 @@ static int marg_finish(vil_ctx* c, const int K, const bool old_, const int drop_
     if (n > n_max || n > 136 || nd > 15 || (int)kinds.size() > nblk_max || n <= 0 || nd <= 0) return VIL_ERR_UNSUPPORTED;
     // ---- device work space + kernel ------------------------------------------------------------------------------
     const size_t nn = (size_t)n * n;
-    const size_t bytes = 8 * ((size_t)nd * nd * 2 + nd + nn * 5 + (size_t)n * 3) + 4 * (size_t)(nd + n) + 8192;
+    const size_t bytes = 8 * ((size_t)nd * nd * 2 + nd + nn * 5 + (size_t)n * 3) + 4 * (size_t)(nd + n) + 8192 + 256;
     if (bytes > c->marg_ws_bytes) {          // grow-only work space: no allocation on the per-frame path once warm
         if (c->marg_ws) hipFree(c->marg_ws);
         c->marg_ws = nullptr; c->marg_ws_bytes = 0;
@@ -2154,6 +2165,7 @@ static int marg_finish(vil_ctx* c, const int K, const bool old_, const int drop_
     M.V = (double*)take(8 * nn); M.w = (double*)take(8 * (size_t)n);
     M.J0 = (double*)take(8 * (2 * nn + 2 * (size_t)n)); M.A = M.J0 + nn; M.r0 = M.A + nn; M.b = M.r0 + n;      // what goes back to the host: one block, one copy
     M.stat = (int*)take(32);
+    M.ts = (unsigned long long*)take(8 * 16); c->d_marg_ts = M.ts;
     if (off > bytes) return VIL_ERR_DEVICE;
     // the column table travels through pinned memory: the copy is asynchronous and the resident window never waits for it (the next use
     // of this staging area is a whole solve away)
@@ -2718,7 +2730,7 @@ int vil_win_prior_download(vil_ctx* c, vil_prior_out* out) {
     if (!c || !out || !c->win.open) return VIL_ERR_INVALID_ARGUMENT;
     auto& w = c->win;
     HIPCHK(hipSetDevice(c->device));
-    int wst = 0;
+    int& wst = c->h_word[8]; wst = 0;
     HIPCHK(hipMemcpyAsync(&wst, w.d_wstat, 4, hipMemcpyDeviceToHost, c->stream));
     out->n = w.pn; out->nblk = (int)w.pkind.size(); out->m = w.pm;
     if (w.pn > 0) {
