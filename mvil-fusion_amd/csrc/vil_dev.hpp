@@ -152,6 +152,7 @@ struct DevP {
     // every sweep workgroup posts the launch epoch in sflag[its index] once its record is out (agent-scope stores); the gather workgroups wait for all of them,
     // the chain workgroup for the IMU / prior ones
     int n_sw; int* sflag;
+    long long vmirror;             // doubles from a visual record to its mirror (timing experiment VIL_SKIP=1024: every tile written twice, gathered twice)
     int persist;                   // 1: this launch is the persistent solve (k_solve): Ctl leaves through its tail, the helpers post hflag2 behind their la / lb stores
     unsigned long long* xtag;      // persistent solve: the candidate's camera part as 2 (16 K + 8) tagged words {half of a value, epoch}, written by the master, polled by the sweep roles
     unsigned long long* ihdr;      // persistent solve (k_solve): the 64-byte hand-over line between two iterations (vil_iter.hpp)

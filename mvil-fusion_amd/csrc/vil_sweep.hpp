@@ -388,6 +388,14 @@ __device__ __forceinline__ void sweep_visual(const DevP& P, const SolveOpts& O, 
             double* o = rec + (wave + 8 * u) * 256 + (lane >> 4) * 16 + (lane & 15);
 #pragma unroll
             for (int q = 0; q < 4; ++q) stx<AG>(o + q * 64, acc[u][q]);
+            // (timing experiment, tuning build, VIL_SKIP=1024: every tile is written a SECOND time, into the mirror, and the gather reads both -- twice the record traffic
+            //  with the results intact; DESIGN.md "record traffic at K = 20")
+#ifdef VIL_TUNING
+            if (P.skip_mask & 1024) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) stx<AG>(o + P.vmirror + q * 64, acc[u][q]);
+            }
+#endif
         }
     }
     VSTAMP(3);
@@ -749,6 +757,9 @@ __device__ __forceinline__ void reduce_gather(const DevP& P, const Ctl& ctl, con
                 // (only the records that cover the entry are loaded: agent-scope loads cost per lane, and at K = 20 two records in three do not)
                 va_ = 0.0; vd_ = 0.0;
                 if (in) va_ = rd(r + (I * T - ((I * (I - 1)) >> 1) + (J - I)) * 256 + (jl & 15) * 16 + (il & 15));      // tile (I, J) holds its transpose
+#ifdef VIL_TUNING
+                if (in && (P.skip_mask & 1024)) { const double m2 = rd(r + P.vmirror + (I * T - ((I * (I - 1)) >> 1) + (J - I)) * 256 + (jl & 15) * 16 + (il & 15)); va_ = 0.5 * va_ + 0.5 * m2; }      // (the mirror: the same value)
+#endif
                 if (wdiag && in && i == j) vd_ = rd(r + vis_ntile(T) * 256 + 16 * T + il);
             };
             for (int w = slice; w < nws; w += ns * U) {

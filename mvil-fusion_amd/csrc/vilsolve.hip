@@ -481,7 +481,7 @@ int vil_create(const vil_device_cfg* cfg, vil_ctx** out) {
     HIPCHK(hipMalloc(&c->d_status, sizeof(int)));
     HIPCHK(hipMemset(c->d_status, 0, sizeof(int)));
     HIPCHK(hipHostMalloc(&c->h_ctl, sizeof(Ctl), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&c->h_word, 64, hipHostMallocDefault));      // small status reads land in PINNED memory: the first asynchronous copy into pageable memory of a process makes the runtime build its staging buffers (7 ms, measured: the "first vil_marginalize costs 9 ms" of rounds 3 - 5)
+    HIPCHK(hipHostMalloc((void**)&c->h_word, 64, hipHostMallocDefault));      // small status reads land in PINNED memory (an asynchronous copy into pageable memory goes through the runtime's staging path)
     c->no_poll = getenv("VIL_NO_POLL") != nullptr;
     memset(&c->P, 0, sizeof c->P);
     *out = c;
@@ -881,7 +881,12 @@ static int upload_impl(vil_ctx* c, const vil_problem* p, const vil_state* s, boo
         put(vp.wend.data(), 4 * vp.wend.size(), (void**)&P.vwend);
         put(vp.vwg.data(), 4 * vp.vwg.size(), (void**)&P.vwg); put(vp.vrec.data(), 4 * vp.vrec.size(), (void**)&P.vrec);
         put(vp.vlm.data(), 4 * vp.vlm.size(), (void**)&P.vlm); put(vp.vfac.data(), 4 * vp.vfac.size(), (void**)&P.vfac);
+#ifdef VIL_TUNING
+        put(nullptr, 8 * 2 * std::max(vp.rec_doubles, (size_t)16), (void**)&P.vpart);      // (x 2: the second half is the mirror of the record-traffic experiment, VIL_SKIP=1024 -- tuning build only)
+        P.vmirror = (long long)std::max(vp.rec_doubles, (size_t)16);
+#else
         put(nullptr, 8 * std::max(vp.rec_doubles, (size_t)16), (void**)&P.vpart);
+#endif
     }
     UPTICK("visual");
     // LiDAR

@@ -10,16 +10,23 @@ cfg = int(os.environ.get("CFG", "2")); mode = int(os.environ.get("MODE", "0"))
 be = lib.open_vilsolve()
 if mode: assert be.lib.vil_debug_set_launch_mode(be.ctx, mode) == 0
 w = synth.make_config(cfg); be.upload(w)
-for _ in range(3): be.reset_state(); be.solve_resident()
+TOL = os.environ.get("TOLERATE") is not None      # (timing experiments with wrong results: a failing solve still leaves its stamps)
+def solve():
+    try: return be.solve_resident()
+    except lib.VilError as e:
+        if not TOL: raise
+        return None
+for _ in range(3): be.reset_state(); solve()
 lpi_, one_ = C.c_int32(0), C.c_int32(0); be.lib.vil_debug_get_launch_structure(be.ctx, C.byref(lpi_), C.byref(one_))
 be.lib.vil_profile_enable(be.ctx, int(os.environ.get("PROF", "2" if lpi_.value == 0 else "1")))
-be.reset_state(); s = be.solve_resident()
+be.reset_state(); s = solve()
+its = s.iterations if s is not None else 2
 buf = (C.c_uint64 * (32 * 64))()
 n = be.lib.vil_debug_read_stamps(be.ctx, buf, 64)
 M = 0xFFFFFFFFFFFFFFFF
 t00 = None
-print("iterations %d; columns: " % s.iterations + " | ".join(nm for _, nm in SHOW))
-for q in range(min(n, s.iterations + 2)):
+print("iterations %d; columns: " % its + " | ".join(nm for _, nm in SHOW))
+for q in range(min(n, its + 2)):
     r = buf[32 * q: 32 * q + 32]
     if not r[0]: continue
     t0 = (~r[0]) & M
