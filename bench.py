@@ -1045,6 +1045,18 @@ def main():
             out["config"]["note"] = shard_note
         if replicas_leg:
             out["replicas"] = replicas_leg
+            if phases and phases.get("per_rank"):
+                # the first N > 1 record explains itself: what sharding ONE window can and cannot divide (Amdahl), from this very run's numbers
+                pr = phases["per_rank"]
+                sweep = max(r[0] for r in pr); gather = max(r[1] for r in pr); coll = max(r[2] for r in pr); step = max(r[3] for r in pr)
+                one_gpu = replicas_leg["value"] / world
+                out["sharding_explained"] = {
+                    "one_gpu_it_per_s_in_this_run": one_gpu, "one_gpu_us_per_iteration": 1e6 / one_gpu,
+                    "sharded_us_per_iteration_from_the_phases": sweep + gather + coll + step,
+                    "divided_by_sharding_us": sweep, "not_divided_us": {"gather": gather, "collective": coll, "step (dense solve, redundant on every rank)": step},
+                    "amdahl_bound_it_per_s_at_infinite_ranks": 1e6 / max(1e-9, gather + coll + step),
+                    "note": "sharding one window divides the factor sweep only; gather, the one collective and the complete trust-region step repeat on every rank, and a sharded solve runs three launches per "
+                            "iteration instead of the single-GPU structure's one resident launch per solve -- `replicas` (and bench.py --batch on one GPU) is the leg that scales"}
         if phases:
             out["phases_per_rank"] = phases
         if comm_info:

@@ -53,7 +53,9 @@ python profiles/scale_summary.py $O/scale > $O/r06_scale_sweep.txt 2>&1
 rm -f $O/scale/*.csv
 timeout 300 python bench.py --batch --steps 30 > $O/r06_concurrent_windows.json 2>/dev/null
 GPU_MAX_HW_QUEUES=8 timeout 300 python bench.py --batch --steps 30 > $O/r06_concurrent_windows_8queues.json 2>/dev/null
-for c in 2; do MODE=0 CFG=$c timeout 120 python tools/probe_timeline.py; MODE=4 CFG=$c timeout 120 python tools/probe_timeline.py; done > $O/r06_timeline.txt 2>&1
+(for c in 2; do echo "== configs[1], the library's choice (persistent solve)"; MODE=0 CFG=$c timeout 120 python tools/probe_timeline.py; echo "== configs[1], one launch per iteration (mode 4)"; MODE=4 CFG=$c timeout 120 python tools/probe_timeline.py; done; echo "== configs[2] (K = 10, 4000 landmarks)"; MODE=0 CFG=3 timeout 120 python tools/probe_timeline.py; echo "== configs[3] (K = 20)"; MODE=0 CFG=4 timeout 120 python tools/probe_timeline.py) 2>&1 | grep -v amdgpu.ids > $O/r06_timeline.txt
+timeout 200 python tools/probe_marg.py 2>&1 | grep -v amdgpu.ids > $O/r06_marg_phases.txt
+timeout 100 python tools/probe_marg_first.py 2>&1 | grep -v amdgpu.ids >> $O/r06_marg_phases.txt
 timeout 900 python tools/run_configs.py > $O/r06_configs.txt 2>&1
 for c in 2 3 4; do CFG=$c timeout 120 python tools/probe_phases.py; done > $O/r06_phases.txt 2>&1
 timeout 200 python tools/probe_tracker.py > $O/r06_tracker_breakdown.txt 2>&1
