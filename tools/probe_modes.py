@@ -1,4 +1,4 @@
-"""Debug aid: one configs[cid] solve per launch structure, each in its own process (a device fault ends that process only).  usage: CFG=2 python tools/dbg_persist.py [modes...]"""
+"""Debug aid: one configs[cid] solve per launch structure, each in its own process (a device fault ends that process only).  usage: CFG=2 python tools/probe_modes.py [modes...]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
