@@ -63,15 +63,20 @@ struct ChainSrcSlab {
 // Column cc of the INVERSE of the factored diagonal block k (x = L^-1 e_c by forward substitution) and row cc of M_k = L_kk^-T Ls_k^T (the lane that
 // holds column cc of the inverse forms it): the master's back substitution is x_k = L_kk^-T t_k - M_k x_next, ONE nine-term product per block instead of
 // two with an LDS round trip in between.  (The middle block has no Ls: its row is never read.)  Ldg / Lsb: the chain's factors (LDS or global).
-__device__ __forceinline__ void chain_inverse_block(const DevP& P, const double* Ldg, const double* Lsb, const int k, const int cc) {
+__device__ __forceinline__ void chain_inverse_block(const DevP& P, const double* Ldg, const double* Lsb, const int k, const int cc, const double* LI = nullptr /* the inverses are there already (chain_eliminate with factor waves: ChainLds::LI) */) {
     const double* l = Ldg + 54 * k; const double* r = l + 45;
     double x[9];
+    if (LI) {
+#pragma unroll
+        for (int p = 0; p < 9; ++p) x[p] = LI[82 * k + 9 * p + cc];
+    } else {
 #pragma unroll
     for (int p = 0; p < 9; ++p) {
         double acc = p == cc ? 1.0 : 0.0;
 #pragma unroll
         for (int q = 0; q < p; ++q) acc -= l[(p * (p + 1) >> 1) + q] * x[q];
         x[p] = p < cc ? 0.0 : acc * r[p];
+    }
     }
 #pragma unroll
     for (int p = 0; p < 9; ++p) if (p >= cc) st_ag(P.chLdg + 54 * k + (p * (p + 1) >> 1) + cc, x[p]);
@@ -202,10 +207,12 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     __syncthreads();
     // the scales leave for the master on a wave the elimination does not use (chain_eliminate runs on waves 0 .. 5): the round trip of the stores
     // and the flag behind them stay off the chain's path
-    if (t >= 384 && t < 448) {
-        for (int i = t - 384; i < NB; i += 64) { st_ag(P.chSc + i, scB[i]); st_ag(P.chDc + i, dcB[i]); }
+    const bool fw = (FUSED || !wait_records) && 6 * K + 8 <= 128 && !(P.skip_mask & 2048);      // (rows of the elimination on the matrix cores, waves 2, 3, 6, 7: up to eight row tiles; waves 6 / 7 are free unless this workgroup rides in k_sweep, where they carry the raw factors out, below)
+    const int tsc = fw ? 256 : 384;                     // a wave the elimination does not use
+    if (t >= tsc && t < tsc + 64) {
+        for (int i = t - tsc; i < NB; i += 64) { st_ag(P.chSc + i, scB[i]); st_ag(P.chDc + i, dcB[i]); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (t == 384) st_ag(P.chflag + 1, epoch);
+        if (t == tsc) st_ag(P.chflag + 1, epoch);
     }
     PSTAMP(14);
     // in-sweep chain (fallback launch structure): the factored blocks leave for prechain_inverses (a workgroup of the gather launch) as they are published, on the two waves
@@ -222,7 +229,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
         }
     }
     double qc = 0.0;
-    chain_eliminate<true>(src, K, NP, P.chain_rs, P.chW, L, qc, P.dbg);      // (P.dbg: stamps of the VIL_STAMPS build)
+    chain_eliminate<true>(src, K, NP, P.chain_rs, P.chW, L, qc, P.dbg, fw);      // (P.dbg: stamps of the VIL_STAMPS build)
     PSTAMP(15);
     if (t < 128) {                                     // the two recursion waves hold the chain x chain share of u^T S' u
         qc = wave_total(qc);
@@ -238,7 +245,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     //      workgroup of the step launch forms the columns (prechain_inverses above).
     //      (waves 6 / 7 stored them as they were published, above)
     if (!wait_records || FUSED) {
-        for (int it = t; it < 9 * K; it += NT) chain_inverse_block(P, L.Ldg, L.Lsb, it / 9, it % 9);
+        for (int it = t; it < 9 * K; it += NT) chain_inverse_block(P, L.Ldg, L.Lsb, it / 9, it % 9, fw ? L.LI : nullptr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) st_ag(P.chflag + 2, epoch);
