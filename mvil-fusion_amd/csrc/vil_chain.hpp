@@ -26,17 +26,19 @@ __host__ __device__ inline int even_up(int v) { return (v + 1) & ~1; }
 __host__ __device__ inline int chain_wcols(int K) { return (9 * K + 31) & ~31; }     // columns of W^T incl. padding: the Schur contraction reads 32 at a time
 // Chain scratch in LDS behind the tile array (and W^T), in doubles:
 //   Dk 2 x 82 | L_kk (45 + 9 reciprocal pivots) per block | sub-diagonal block per block (82 each) | carry of the backward
-//   direction R x 9 | t (9K) | the diagonal blocks as they are factored (packed lower triangles, 46 per block) | the inverses of their factors (82 per block, entry (p, c) at 9 p + c) | 8 ints of flags
+//   direction R x 9 | t (9K) | 8 ints of flags.  The diagonal block a recursion wave factors sits where its factor will (Ldg: a packed lower triangle, read before the factor is
+//   stored); the inverses of the factors (fw: entry (p, c) of block k at LI[LIs k + 9 p + c]) live in memory of the CALLER'S that is dead by then (prechain_wg: the slab's
+//   sub-diagonal blocks) -- at K = 20 the workgroup has no LDS to spare
 struct ChainLds {
-    double* Dk; double* Ldg; double* Lsb; double* cB; double* tB; double* Dq; double* LI;
+    double* Dk; double* Ldg; double* Lsb; double* cB; double* tB; double* LI; int LIs;
     volatile int* flag;       // [0], [1]: blocks published by the recursion wave of direction d; [2]: middle factor published;
                               // [3], [4]: carry of the backward direction published by its two row waves; [5]: a pivot was not positive;
                               // [6], [7]: spare
 };
-__host__ __device__ inline size_t chain_scratch_doubles(int K) { const int R = 6 * K + 8; return 164 + (size_t)54 * K + (size_t)82 * K + (size_t)9 * R + even_up(9 * K) + (size_t)46 * K + (size_t)82 * K + 8; }
+__host__ __device__ inline size_t chain_scratch_doubles(int K) { const int R = 6 * K + 8; return 164 + (size_t)54 * K + (size_t)82 * K + (size_t)9 * R + even_up(9 * K) + 8; }
 __device__ __forceinline__ ChainLds chain_lds(double* cs, int K) {
     ChainLds L; const int R = 6 * K + 8;
-    L.Dk = cs; L.Ldg = cs + 164; L.Lsb = L.Ldg + 54 * K; L.cB = L.Lsb + 82 * K; L.tB = L.cB + 9 * R; L.Dq = L.tB + even_up(9 * K); L.LI = L.Dq + 46 * K; L.flag = (volatile int*)(L.LI + 82 * K);
+    L.Dk = cs; L.Ldg = cs + 164; L.Lsb = L.Ldg + 54 * K; L.cB = L.Lsb + 82 * K; L.tB = L.cB + 9 * R; L.LI = nullptr; L.LIs = 0; L.flag = (volatile int*)(L.tB + even_up(9 * K));
     return L;
 }
 
@@ -114,7 +116,7 @@ __device__ __forceinline__ void row_solve9(const double* l, const double* r, con
 // raw entry passes through exactly one lane here: pose row x chain block in the row waves, diagonal and sub-diagonal blocks in
 // the recursion waves).
 // The row waves of chain_eliminate on the matrix cores (see there).  MT: tiles of 16 rows a wave carries -- tiles half, half + 2, .. of its direction; a tile past the
-// last one (K = 10: the third of wave `half` = 1) is computed on clamped rows and never stored.  Straight-line code: every load is unconditional from a clamped address and
+// last one (K = 10: the third of wave `half` = 1) is skipped by a scalar branch.  Otherwise straight-line code: every load is unconditional from a clamped address and
 // selected afterwards (a per-lane predicated load is an exec-mask branch with its own wait: the first version of this function spent 57 waits per block on them).
 template <bool WITHQ, int MT, class SRC>
 __device__ __forceinline__ void chain_rows_mfma(const SRC& src, const int K, const int NP, const int RS, double* Wt, const ChainLds& L, double& qacc, long long* dbg, const int d, const int half) {
@@ -137,6 +139,7 @@ __device__ __forceinline__ void chain_rows_mfma(const SRC& src, const int K, con
         const double g0 = src.rhsraw(NP + 9 * k + c0), g1 = src.rhsraw(NP + 9 * k + c1), g2 = src.rhsraw(NP + 9 * k + c2);
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
+            if (!act[u]) continue;                       // (wave-uniform: a scalar branch; the tile's entries stay zero)
             const double v0 = src.prow(rcl[u], k, c0), v1 = src.prow(rcl[u], k, c1), v2 = src.prow(rcl[u], k, c2);
             x[u][0] = isrhs[u] ? g0 : v0; x[u][1] = isrhs[u] ? g1 : v1; x[u][2] = h2 ? (isrhs[u] ? g2 : v2) : 0.0;
         }
@@ -165,9 +168,9 @@ __device__ __forceinline__ void chain_rows_mfma(const SRC& src, const int K, con
     // W_k^T = L_kk^-1 A'^T of one tile, its columns out (rows past R - 1 of the last tile land in the padding of W^T's columns: RS = 16 ntile)
     auto solve_store = [&](const int k, const int u, const double* li, const double* ax) {
         d4v acc = d4v{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(li[q], ax[q], acc, 0, 0, 0);
         if (act[u]) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(li[q], ax[q], acc, 0, 0, 0);
             double* const col = Wt + (size_t)(9 * k) * RS + rr[u];
             src.wput(col + (size_t)c0 * RS, acc[0]);
             src.wput(col + (size_t)c1 * RS, acc[1]);
@@ -183,10 +186,11 @@ __device__ __forceinline__ void chain_rows_mfma(const SRC& src, const int K, con
         fetch(k2, an);
         chain_wait(fflag, st + 1);
         double li[3], l1[3];
-        operand(L.LI + 82 * k, li);
+        operand(L.LI + L.LIs * k, li);
         operand(L.Lsb + 82 * k, l1);
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
+            if (!act[u]) continue;
             const d4v w = solve_store(k, u, li, ax[u]);
             d4v acc = d4v{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -234,7 +238,7 @@ __device__ __forceinline__ void chain_rows_mfma(const SRC& src, const int K, con
                 ax[u][0] -= b0; ax[u][1] -= b1; ax[u][2] -= h2 ? b2 : 0.0;
             }
         }
-        operand(L.LI + 82 * m, li);
+        operand(L.LI + L.LIs * m, li);
 #pragma unroll
         for (int u = 0; u < MT; ++u) solve_store(m, u, li, ax[u]);
     }
@@ -296,7 +300,7 @@ __device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, con
             if (st > 0) { const double* Lp = L.Lsb + 82 * kp;
 #pragma unroll
                 for (int c = 0; c < 9; ++c) v -= Lp[di * 9 + c] * Lp[dj * 9 + c]; }
-            L.Dq[46 * k + dq] = v;
+            L.Ldg[54 * k + dq] = v;
             double a[9];
 #pragma unroll
             for (int c = 0; c < 9; ++c) a[c] = as_[c];
@@ -308,7 +312,7 @@ __device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, con
             sub_rows(k2, kn2, an);
             CHAIN_FENCE();
             L9 Lf;
-            ok = chol9<true>(L.Dq + 46 * k, Lf) && ok;
+            ok = chol9<true>(L.Ldg + 54 * k, Lf) && ok;
             double w[9];
             row_solve9(Lf.l, Lf.r, a, w);
 #pragma unroll
@@ -319,7 +323,7 @@ __device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, con
                 double x[9];
                 inv9_col(Lf, ql, x);
 #pragma unroll
-                for (int p = 0; p < 9; ++p) L.LI[82 * k + 9 * p + ql] = x[p];      // (lanes past 8: column 8 again, the same values to the same addresses)
+                for (int p = 0; p < 9; ++p) L.LI[L.LIs * k + 9 * p + ql] = x[p];      // (lanes past 8: column 8 again, the same values to the same addresses)
             } else {
 #pragma unroll
                 for (int e = 0; e < 45; ++e) L.Ldg[54 * k + e] = Lf.l[e];
@@ -343,17 +347,17 @@ __device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, con
                 if (nb > 0) { const double* Lp = L.Lsb + 82 * (m + 1);
 #pragma unroll
                     for (int c = 0; c < 9; ++c) v -= Lp[di * 9 + c] * Lp[dj * 9 + c]; }
-                L.Dq[46 * m + dq] = v;
+                L.Ldg[54 * m + dq] = v;
             }
             CHAIN_FENCE();
             L9 Lf;
-            ok = chol9<true>(L.Dq + 46 * m, Lf) && ok;
+            ok = chol9<true>(L.Ldg + 54 * m, Lf) && ok;
             if (fw) {
                 const int cc = min(lane, 8);
                 double x[9];
                 inv9_col(Lf, cc, x);
 #pragma unroll
-                for (int p = 0; p < 9; ++p) L.LI[82 * m + 9 * p + cc] = x[p];
+                for (int p = 0; p < 9; ++p) L.LI[L.LIs * m + 9 * p + cc] = x[p];
             } else {
 #pragma unroll
                 for (int e = 0; e < 45; ++e) L.Ldg[54 * m + e] = Lf.l[e];

@@ -63,12 +63,12 @@ struct ChainSrcSlab {
 // Column cc of the INVERSE of the factored diagonal block k (x = L^-1 e_c by forward substitution) and row cc of M_k = L_kk^-T Ls_k^T (the lane that
 // holds column cc of the inverse forms it): the master's back substitution is x_k = L_kk^-T t_k - M_k x_next, ONE nine-term product per block instead of
 // two with an LDS round trip in between.  (The middle block has no Ls: its row is never read.)  Ldg / Lsb: the chain's factors (LDS or global).
-__device__ __forceinline__ void chain_inverse_block(const DevP& P, const double* Ldg, const double* Lsb, const int k, const int cc, const double* LI = nullptr /* the inverses are there already (chain_eliminate with factor waves: ChainLds::LI) */) {
+__device__ __forceinline__ void chain_inverse_block(const DevP& P, const double* Ldg, const double* Lsb, const int k, const int cc, const double* LI = nullptr /* the inverses are there already (chain_eliminate, fw: ChainLds::LI) */, const int LIs = 0) {
     const double* l = Ldg + 54 * k; const double* r = l + 45;
     double x[9];
     if (LI) {
 #pragma unroll
-        for (int p = 0; p < 9; ++p) x[p] = LI[82 * k + 9 * p + cc];
+        for (int p = 0; p < 9; ++p) x[p] = LI[LIs * k + 9 * p + cc];
     } else {
 #pragma unroll
     for (int p = 0; p < 9; ++p) {
@@ -117,9 +117,12 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     #define PSTAMP(k) do {} while (0)
 #endif
     PSTAMP(12);
-    const ChainLds L = chain_lds(lds, K);
+    ChainLds L = chain_lds(lds, K);
     double* scB = lds + chain_scratch_doubles(K); double* dcB = scB + even_up(NB); double* uB = dcB + even_up(NB);
     const ChainSlab B = chain_slab(uB + even_up(NB), K);
+    L.LI = B.sub; L.LIs = 81;                          // the inverses of the factored blocks take the place of the raw sub-diagonal blocks: block k's is written when the
+                                                       // elimination of block k ends, its raw sub-diagonal block (k, k + 1) was read a step before (forwards: by that very
+                                                       // step's look-ahead; backwards: when block k + 1 was eliminated)
     if (t < 8) chain_flag_set(L.flag + t, 0);
     // ---- gather of the chain part of S' out of the IMU / prior records through the host-built table: eight entries per thread and round (one round at
     //      K = 10, two at K = 20).  Two dependent round trips -- entries, then their sources -- and NOTHING before them: the zeroing of the slab (a gather target: entries
@@ -245,7 +248,7 @@ __device__ __forceinline__ void prechain_wg(const DevP& P, const Ctl& ctl, const
     //      workgroup of the step launch forms the columns (prechain_inverses above).
     //      (waves 6 / 7 stored them as they were published, above)
     if (!wait_records || FUSED) {
-        for (int it = t; it < 9 * K; it += NT) chain_inverse_block(P, L.Ldg, L.Lsb, it / 9, it % 9, fw ? L.LI : nullptr);
+        for (int it = t; it < 9 * K; it += NT) chain_inverse_block(P, L.Ldg, L.Lsb, it / 9, it % 9, fw ? L.LI : nullptr, L.LIs);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) st_ag(P.chflag + 2, epoch);
