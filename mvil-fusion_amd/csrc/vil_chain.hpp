@@ -119,7 +119,8 @@ __device__ __forceinline__ void row_solve9(const double* l, const double* r, con
 // last one (K = 10: the third of wave `half` = 1) is skipped by a scalar branch.  Otherwise straight-line code: every load is unconditional from a clamped address and
 // selected afterwards (a per-lane predicated load is an exec-mask branch with its own wait: the first version of this function spent 57 waits per block on them).
 template <bool WITHQ, int MT, class SRC>
-__device__ __forceinline__ void chain_rows_mfma(const SRC& src, const int K, const int NP, const int RS, double* Wt, const ChainLds& L, double& qacc, long long* dbg, const int d, const int half) {
+__device__ __forceinline__ void chain_rows_mfma(const SRC& src, const int K, const int NP, const int RS, double* Wt, const ChainLds& L, double& qacc, long long* dbg, const int d, const int half,
+                                                const int t0, const int ntl /* this wave's tiles: t0, t0 + 2, .. (ntl of them, those below the direction's tile count) */) {
     typedef double d4v __attribute__((ext_vector_type(4)));
     const int lane = vil_tid() & 63;
     const int R = NP + 1, m = K >> 1, nf = m, nb = K - 1 - m, nd = d == 0 ? nf : nb, ntile = (R + 15) >> 4;
@@ -128,8 +129,8 @@ __device__ __forceinline__ void chain_rows_mfma(const SRC& src, const int K, con
     int rr[MT], rcl[MT]; double rsc[MT]; bool act[MT], isrhs[MT];
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
-        const int T = half + 2 * u;
-        act[u] = T < ntile;                              // (wave-uniform)
+        const int T = t0 + 2 * u;
+        act[u] = u < ntl && T < ntile;                   // (wave-uniform)
         rr[u] = 16 * T + rl; rcl[u] = min(rr[u], NP - 1); isrhs[u] = rr[u] >= NP;
         rsc[u] = src.rowscale(rcl[u]); if (isrhs[u]) rsc[u] = 1.0;
     }
@@ -243,7 +244,7 @@ __device__ __forceinline__ void chain_rows_mfma(const SRC& src, const int K, con
         for (int u = 0; u < MT; ++u) solve_store(m, u, li, ax[u]);
     }
     row_sums();
-    if (half == 0) RSTMP(55);
+    if (half == 0 && t0 == 0) RSTMP(55);
 }
 
 template <bool WITHQ, class SRC>
@@ -254,7 +255,7 @@ __device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, con
 #else
     #define CSTMP(k) do {} while (0)
 #endif
-    if (fw ? (wave == 4 || wave == 5) : wave >= 6) return;      // (fw: row waves 2, 3 forwards and 6, 7 backwards -- SIMDs 2 and 3; the recursion waves keep SIMDs 0 and 1 to themselves)
+    if (fw ? wave == 4 : wave >= 6) return;      // (fw: row waves 2, 3 forwards and 6, 7 backwards -- SIMDs 2 and 3; the recursion waves keep SIMDs 0 and 1 to themselves)
     const int R = NP + 1, m = K >> 1, nf = m, nb = K - 1 - m;
     if (wave < 2) {
         // ---------------- recursion wave of direction d ----------------------------------------------------------------------
@@ -387,10 +388,20 @@ __device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, con
         const int ntile = (R + 15) >> 4;
         // waves 2, 3: forwards; 6, 7: backwards, with the halves swapped -- an odd number of tiles (five at K = 10) then loads SIMDs 2 and 3 alike (3 + 2 tiles each);
         // the forward direction has a block more and ends the elimination: its waves issue first
+        // Up to six tiles the forward waves carry two each and wave 5 the rest (K = 10: the fifth tile, four rows): it shares SIMD 1 with the BACKWARD recursion wave, which
+        // has a block less to do -- a forward row step must not be longer than a recursion step (3750 ticks), or the rows end that much later, block after block.
+        const bool small = ntile <= 6;
+        if (wave == 5) {
+            if (!small || ntile <= 4) return;
+            __builtin_amdgcn_s_setprio(2);
+            chain_rows_mfma<WITHQ, 3>(src, K, NP, RS, Wt, L, qacc, dbg, 0, 1, 4, 1);      // tile 4
+            __builtin_amdgcn_s_setprio(0);
+            return;
+        }
         const int rd = wave >> 2, rh = rd == 0 ? (wave & 1) : 1 - (wave & 1);
         if (rd == 0) __builtin_amdgcn_s_setprio(2);
-        if (ntile <= 6) chain_rows_mfma<WITHQ, 3>(src, K, NP, RS, Wt, L, qacc, dbg, rd, rh);
-        else chain_rows_mfma<WITHQ, 4>(src, K, NP, RS, Wt, L, qacc, dbg, rd, rh);
+        if (small) chain_rows_mfma<WITHQ, 3>(src, K, NP, RS, Wt, L, qacc, dbg, rd, rh, rh, (rd == 0 && rh == 0) ? 2 : 3);      // (forwards: tiles 0, 2 | 1, 3, (5) | wave 5: 4)
+        else chain_rows_mfma<WITHQ, 4>(src, K, NP, RS, Wt, L, qacc, dbg, rd, rh, rh, 4);
         __builtin_amdgcn_s_setprio(0);
         return;
     }
