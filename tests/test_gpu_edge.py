@@ -186,12 +186,14 @@ def test_solver_options_parity(hip, oracle, kw):
     assert np.abs(wg.pose - wo.pose).max() < 1e-6 and np.abs(wg.inv_depth - wo.inv_depth).max() < 1e-5
 
 
-@pytest.mark.parametrize("K", [4, 7, 11, 12, 13, 16])
+@pytest.mark.parametrize("K", [4, 5, 7, 9, 11, 12, 13, 14, 15, 16, 18])
 def test_window_sizes_around_the_path_switches(hip, oracle, K):
     """The solver changes machinery with the window size: K <= 12 -- gather + step in one launch with the chain workgroup beside the gather, visual
     block outer products on the matrix cores (NV = 6 K + 7 <= 80: K = 12 fills the fifth 16-column tile to 79); K >= 13 -- chain workgroup inside the
     sweep, tile workgroups in the gather kernel, LDS atomics; K = 4 is the smallest window the synthetic tracks allow.  Same trajectory and
-    solution as the oracle on every side of those switches, linearisation included."""
+    solution as the oracle on every side of those switches, linearisation included.  (Round 6: the chain workgroup's row waves work on 16-row tiles of the 6 K + 8 pose
+    rows -- 2 tiles at K = 4, 3 at K = 5, 4 at K = 7 / 9, 5 at K = 11 / 12 with the fifth on its own wave, 6 at K = 13 / 14, 7 at K = 15 / 16, 8 at K = 18: every
+    assignment of tiles to waves is on this list.)"""
     kw = dict(K=K, L=150, n_plane=1200, n_edge=400)
     pf = lambda pre: oracle.marginalize(pre).to_prior()
     wg, wo = synth.make_config(2, prior_fn=pf, **kw), synth.make_config(2, prior_fn=pf, **kw)
