@@ -104,8 +104,8 @@ __device__ __forceinline__ void row_solve9(const double* l, const double* r, con
 // forward / backward direction (D_k -> L_kk -> L_{k+-1,k} -> D_{k+-1}) and publish every factored block through LDS + a flag;
 // waves 2,3 / 4,5 own the pose-part rows (incl. the right-hand side) of the forward / backward direction and follow the flags:
 // row solve against L_kk, W^T column block to Wt, fill carried into the next block.  Wave 0 finally factors the middle block,
-// waves 2,3 finish its rows.  fw: waves 6 / 7 re-factor the diagonal blocks the recursion waves leave in LDS and publish the factors to the row waves (below);
-// otherwise the recursion waves publish them themselves.  Other waves return at once (the caller gives them the tile packing).  The caller zeroes the flags
+// waves 2,3 finish its rows.  fw (the caller's waves 5 .. 7 are free and L.LI is set): the recursion waves publish the INVERSE of every factored block and the rows are
+// carried by chain_rows_mfma on the matrix cores (waves 2, 3, 5 forwards, 6, 7 backwards); otherwise a row per lane on waves 2 .. 5 against the published factors.  Other waves return at once (the caller gives them the tile packing).  The caller zeroes the flags
 // before and puts a workgroup barrier after.
 // SRC: raw S' entries -- diag(k, i, j): entry (i, j <= i) of diagonal block k; sub(k, kn, q, c): row q of block kn = k +- 1, column c
 // of block k; prow(r, k, c): pose row r, column c of block k --; sc(j) scale of reduced column j; madd(j) = mu dc_j^2; rowscale(r) scale applied to pose row r
@@ -248,7 +248,7 @@ __device__ __forceinline__ void chain_rows_mfma(const SRC& src, const int K, con
 }
 
 template <bool WITHQ, class SRC>
-__device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, const int NP, const int RS, double* Wt, const ChainLds& L, double& qacc, long long* dbg = nullptr, const bool fw = false /* waves 6 / 7 of the block are free to be factor waves */) {
+__device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, const int NP, const int RS, double* Wt, const ChainLds& L, double& qacc, long long* dbg = nullptr, const bool fw = false /* rows on the matrix cores (chain_rows_mfma): the caller's waves 5 .. 7 are free, L.LI is set */) {
     const int t = vil_tid(), wave = t >> 6, lane = t & 63;
 #ifdef VIL_STAMPS
     #define CSTMP(k) do { if (lane == 0 && dbg) { long long tt_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt_) :: "memory"); dbg[k] = tt_; } } while (0)
@@ -375,8 +375,8 @@ __device__ __forceinline__ void chain_eliminate(const SRC& src, const int K, con
     if (fw) {
         // ---------------- row waves on the matrix cores (fw) --------------------------------------------------------------------------------------------------------
         // A row per lane costs every row wave ~150 fp64 instructions, ~180 LDS reads (the factor and the sub-diagonal block, broadcast) and ~150 integer instructions per
-        // block, four waves of them -- with the recursion and factor waves that SATURATES the compute unit (2600 vector instructions per block step on four SIMDs, one LDS
-        // pipe), and the row waves end 8 k ticks behind a recursion that got 5 k ticks shorter.  Here the rows of a block are two small matrix products on
+        // block, four waves of them -- with the recursion waves that SATURATES the compute unit (2600 vector instructions per block step on four SIMDs, one LDS
+        // pipe): with the factor's store off the recursion wave the recursion got 5 k ticks shorter and the row waves ended where they had before.  Here the rows of a block are two small matrix products on
         // v_mfma_f64_16x16x4, sixteen rows per tile:   W_k^T = L_kk^-1 A'_k^T   and   carry^T = L_{kn,k} W_k^T   (A' = scaled rows - carry of the block before)
         // with the 9 x 9 matrices as the A operand (one load of three values per lane and block, whatever the number of tiles) and the rows as the B operand.  A lane
         // holds element (row lane & 15, column 4 s + (lane >> 4)), s = 0 .. 2, of a tile -- the layout the instruction wants for B and ALSO the layout it returns the
