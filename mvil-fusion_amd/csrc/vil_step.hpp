@@ -1258,9 +1258,16 @@ __device__ __forceinline__ bool solve_prechain(const DevP& P, const SysBuf& sb, 
     double wv[24], wrhs = 0.0;
     const bool small = ntile <= 24;                    // K <= 12: three register tiles per wave in the factorisation instead of seven -- room for the prefetch
     if (small) {
+        // (waves whose threads all sit past the last chain column -- the last two at K = 10, the panel wave of the factorisation among them -- ask for nothing: their 25
+        //  requests per lane queued in front of the factorisation's first panel at the compute unit's 5 lanes per ns)
+        const bool wave_has_columns = __builtin_amdgcn_readfirstlane(((t >> 6) << 6) / G) < NB;      // (a scalar branch)
 #pragma unroll
-        for (int q = 0; q < 24; ++q) wv[q] = ld_ag(Wt + (size_t)jc * RS + min(part + q * G, NP - 1));
-        wrhs = ld_ag(Wt + (size_t)jc * RS + NP);
+        for (int q = 0; q < 24; ++q) wv[q] = 0.0;
+        if (wave_has_columns) {
+#pragma unroll
+            for (int q = 0; q < 24; ++q) wv[q] = ld_ag(Wt + (size_t)jc * RS + min(part + q * G, NP - 1));
+            wrhs = ld_ag(Wt + (size_t)jc * RS + NP);
+        }
         if (!(RW ? chol_dense<3>(Tl, NP, s) : chol_lookahead<3, false>(Tl, NP, s))) return false;
     } else if (!(RW ? chol_dense<CH_SLOTS>(Tl, NP, s) : chol_lookahead<CH_SLOTS, false>(Tl, NP, s))) return false;
     SSTAMP(4);
