@@ -1811,8 +1811,8 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     STAMP(1);
     double gn2 = 0, g2 = 0, gg = 0;
     // The candidate x_cur (+) step for the FULL Gauss-Newton step (cg = 0, cn = 1: what the dogleg takes whenever the step fits the trust region -- every iteration after the
-    // first few) is formed SPECULATIVELY by wave 0 while the last wave collects the helpers' sums: the 2 K + 2 camera blocks are 2 K + 2 lanes of ONE wave, which forms the
-    // step entries of its own block itself (no step vector in LDS, no barrier) and whose wave total IS the block sum of the norms (the other waves contribute zeros).  When the
+    // first few) is formed SPECULATIVELY by waves 0 and 1 while the last wave collects the helpers' sums: a camera block is a lane, which forms the
+    // step entries of its own block itself (no step vector in LDS, no barrier); the two waves' totals are the block sum of the norms.  When the
     // dogleg then does take the full step, the ordinary path's step loop, barrier, pose_plus and block sum are skipped; (0 * gradient + 1 * gn) * rt has the value gn * rt.
     bool spec = false;
     double* const xcs_spec = Alds; double* const sums_spec = Alds + 336;      // (the factor's tiles: dead once the back substitutions are through)
@@ -1976,14 +1976,43 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
         __syncthreads();
         // chain path with helpers: the last wave collects the helpers' sums of both passes (-> s.hs) HERE -- the helpers received x_p before the chain back
         // substitution and answer ~5 us later, the master's chain walks take half of that: the step vectors above no longer wait for the answer
-        if (defer && LDSM && NT >= 128 && 2 * P.K + 2 <= 64) {
+        if (defer && LDSM && NT >= 192 && P.K + 1 <= 64) {
+            // TWO waves, one code path each (the blocks of one kind in one wave: 2 K + 2 lanes of one wave walked four divergent paths one after the other, 2.3 us -- the
+            // longest item between the chain's back substitution and the dogleg): wave 0 the K poses and the extrinsic, wave 1 the K speed-bias blocks and td
+            auto stepf = [&](const int i) { return (0.0 * s.gr[i] + 1.0 * s.gn[i]) * s.rt[i]; };
+            const int K = P.K;
+            double xs_ = 0, ss_ = 0;
             if (t < 64) {
-                double xs_ = 0, ss_ = 0;
-                cand_blocks([&](const int i) { return (0.0 * s.gr[i] + 1.0 * s.gn[i]) * s.rt[i]; }, xcs_spec, xs_, ss_);
-                xs_ = wave_total_l63(xs_); ss_ = wave_total_l63(ss_);
-                if (t == 63) { sums_spec[0] = xs_; sums_spec[1] = ss_; }
+                if (t <= K) {
+                    const bool isex = t == K;
+                    const int xo = isex ? xo_ex(P) : xo_pose(P, t), col = isex ? col_ex(P) : col_pose(P, t);
+                    const bool cst = isex ? P.ex_const != 0 : s.cst[min(t, K - 1)] != 0;
+                    const double* in = s.x0 + xo; double* o = xcs_spec + xo;
+                    double st[6], ov[7];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) st[q] = stepf(col + q);
+                    pose_plus(in, st, ov);
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) { const double iv = in[q]; o[q] = cst ? iv : ov[q]; if (!cst) { xs_ += iv * iv; ss_ += (iv - ov[q]) * (iv - ov[q]); } }
+                }
+            } else if (t < 128) {
+                const int l = t - 64;
+                if (l < K) {
+                    const double* in = s.x0 + xo_sb(P, l); double* o = xcs_spec + xo_sb(P, l);
+                    const bool cst = s.cst[K + l] != 0;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) { const double iv = in[q], d = cst ? 0.0 : stepf(col_sb(P, l) + q); o[q] = iv + d; if (!cst) { xs_ += iv * iv; ss_ += d * d; } }
+                } else if (l == K) {
+                    const double iv = s.x0[xo_td(P)], d = P.td_free ? stepf(col_td(P)) : 0.0;
+                    xcs_spec[xo_td(P)] = iv + d;
+                    if (P.td_free) { xs_ += iv * iv; ss_ += d * d; }
+                }
             }
-            spec = true;      // (what wave 0 wrote is read behind the barriers of the block sums below)
+            if (t < 128) {
+                xs_ = wave_total_l63(xs_); ss_ = wave_total_l63(ss_);
+                if ((t & 63) == 63) { sums_spec[2 * (t >> 6)] = xs_; sums_spec[2 * (t >> 6) + 1] = ss_; }
+            }
+            spec = true;      // (what waves 0 and 1 wrote is read behind the barriers of the block sums below)
         }
         if (defer && t >= NT - 64) { double h[9]; gather2(h, true); if ((t & 63) == 63) for (int e = 0; e < 9; ++e) s.hs[e] = h[e]; }
         double sm[6] = {0, 0, 0, 0, 0, 0};
@@ -2056,7 +2085,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     double* xcs = s.gr;                              // the candidate's camera part is formed in LDS (gr | gn: 640 doubles, dead from here on -- P.gradc / P.gnc keep them) and leaves in one pass
     static_assert(offsetof(StepShared, gn) == offsetof(StepShared, gr) + 320 * sizeof(double), "the candidate spills from gr into gn");
     double xn = 0, sn = 0;
-    if (spec && cg == 0.0 && cn == 1.0) { xcs = xcs_spec; xn = sums_spec[0]; sn = sums_spec[1]; }      // (uniform: every thread computed the same scalars)
+    if (spec && cg == 0.0 && cn == 1.0) { xcs = xcs_spec; xn = sums_spec[0] + sums_spec[2]; sn = sums_spec[1] + sums_spec[3]; }      // (uniform: every thread computed the same scalars)
     else {
         for (int i = t; i < D; i += NT) s.y[i] = (cg * s.gr[i] + cn * s.gn[i]) * s.rt[i];
         __syncthreads();
