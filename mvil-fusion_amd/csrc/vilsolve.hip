@@ -1933,6 +1933,14 @@ int vil_solve_batch(vil_ctx** ctxs, int32_t n, const vil_options* o, vil_summary
         int waiting = 0, cap = 1 << 30;
         for (int i = 0; i < n; ++i) { const vil_ctx* c = ctxs[i]; waiting = std::max(waiting, 2 + c->P.n_help + c->n_ww); const int v = c->P.vis_ts == 2 ? 0 : 1; if (c->fused && c->cap_iter[v] > 0) cap = std::min(cap, c->cap_iter[v]); }
         while (group > 1 && !fits_per_xcd(group * waiting, cap)) --group;
+        // ... and at most half of the device may wait: the workgroups the waiting ones wait for need the other half.  How many launches really run at once is the
+        // runtime's number of hardware queues (four unless GPU_MAX_HW_QUEUES says otherwise): with eight queues eight windows of configs[1] waited on 208 of 256
+        // compute units and the batch took 14 ms instead of 2 (profiles/r06_concurrent_windows_8queues.json, before this rule)
+        {
+            const char* qe = getenv("GPU_MAX_HW_QUEUES");
+            const int hwq = qe && atoi(qe) > 0 ? atoi(qe) : 4;
+            while (group > 1 && std::min(group, hwq) * waiting > cap / 2) --group;
+        }
     }
     for (int i0 = 0; i0 < n; i0 += group) {
         const int m = std::min(group, n - i0);
