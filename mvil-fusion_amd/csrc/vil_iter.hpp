@@ -181,7 +181,7 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(KSolveArgs kernarg_b
         const KSolveArgs& A = ksolve_args();
         const DevP& P = A.P; const SolveOpts& O = A.O;
         __syncthreads();
-        step_body<true, 3, true>(P, O, s, Alds, p0, item);
+        step_body<true, 3, true>(P, O, s, Alds, p0, item, budget_ticks > 0 ? (long long)t_start + budget_ticks : 0ll);
         __syncthreads();
         if (s.done_at_entry) return;                                // (chain, helpers, tiles: the master has ended the solve -- it does not come back here itself)
         const int epoch = (int)((((unsigned)s.c.gen) << 12) + (unsigned)s.c.n_sweeps);      // (step_body has counted this iteration in the workgroup's copy of Ctl)
@@ -196,11 +196,11 @@ __global__ __launch_bounds__(VIL_STEP_THREADS) void k_solve(KSolveArgs kernarg_b
             if (s.pad0_ != epoch && t < P.n_help) spin_until_eq(P.hflag2 + t, epoch, P.abortf);
             __syncthreads();                                        // (no wait for the candidate's stores: the sweep roles take it from the tagged words, P.xtag)
             if (t == 0) prof_stamp(P, epoch - 1, 24);
-            if (t == 0 && !s.c.done && budget_ticks > 0 && (long long)(wall_clock64() - t_start) > budget_ticks) { s.c.done = 1; s.c.term = 5; if (s.c.iter > 0 && !s.c.resweep) s.c.iter--; }      // (the step just formed was never judged: not an iteration of the summary)
+            if (t == 0 && !s.c.done && !s.hdr_posted && budget_ticks > 0 && (long long)(wall_clock64() - t_start) > budget_ticks) { s.c.done = 1; s.c.term = 5; if (s.c.iter > 0 && !s.c.resweep) s.c.iter--; }      // (the step just formed was never judged: not an iteration of the summary)
             __syncthreads();
             const bool done = s.c.done != 0;
             auto post_hdr = [&]() { post_iter_header(P, s.c, epoch); };
-            if (!done) { post_hdr(); if (t == 0) prof_stamp(P, epoch - 1, 25); }      // the next iteration's sweep roles start from this
+            if (!done && s.hdr_posted != 1) { post_hdr(); if (t == 0) prof_stamp(P, epoch - 1, 25); }      // the next iteration's sweep roles start from this (unless step_body has posted it with the candidate)
             const bool written = s.c.outd != 0;                    // (cost first: the master wrote the result out inside step_body)
             __syncthreads();
             if (done && s.c.lin_mode == 0 && t == 0) s.c.outd = 1;

@@ -40,6 +40,7 @@ struct StepShared {
     unsigned char cst[48];                        // pose_const[K] | sb_const[K]
     double hs[12];                                // the helpers' sums, gathered by a spare wave during the chain back substitution
     int need, was_first, ok, cok;
+    int hdr_posted, hdr_pad_;                     // persistent solve, master: the next iteration's hand-over line went out inside step_body (below)
     int early, judged;                            // persistent solve, master: the candidate's cost alone ended the solve (judged from the sweep's cost partials, before the gather) / the judge has run
     int done_at_entry, pad0_;                     // the solve was already finished when this launch read Ctl
     long long tacc[6];
@@ -1429,7 +1430,7 @@ __device__ __forceinline__ void post_iter_header(const DevP& P, const Ctl& c, co
 // duty_item >= 0 (the persistent solve, k_solve): the gather item a helper or tile workgroup of a live iteration takes once it holds Ctl and the epoch, BEFORE its own
 // waits -- it has nothing to do until the gather is complete / the chain is eliminated
 template <bool LDSM, int CHAIN, bool FUSED>
-__device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd::StepShared& s, double* const Alds, const int p0, const int duty_item = -1) {
+__device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd::StepShared& s, double* const Alds, const int p0, const int duty_item = -1, const long long deadline_tick = 0 /* persistent solve: the device's wall clock at which max_solver_time ends (0: no cap) */) {
     using namespace vd;
     const int t = vil_tid(), NT = blockDim.x;
     const int D = P.D, L = P.L;
@@ -1467,7 +1468,7 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
     {   // Ctl (1.5 kB with its traces) into LDS: one coalesced load per lane, not 190 loads of a lone lane with everybody waiting at the barrier
         const double* src = (const double*)P.ctl; double* dst = (double*)&s.c;
         for (int i = t; i < (int)(sizeof(Ctl) / 8); i += NT) dst[i] = ldx<FUSED>(src + i);      // (FUSED: whatever the roles hand from one iteration to the next crosses at agent scope -- the persistent solve, k_solve, has no launch boundary between them)
-        if (t == 0) { s.need = 0; s.was_first = 0; s.ok = 1; s.early = 0; s.judged = 0; }
+        if (t == 0) { s.need = 0; s.was_first = 0; s.ok = 1; s.early = 0; s.judged = 0; s.hdr_posted = 0; }
     }
     for (int q = t; q < 256; q += NT) {      // triangular tile index -> (tile row, tile col)
         int Ir = (int)((sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
@@ -2113,8 +2114,20 @@ __device__ __forceinline__ void step_body(const DevP& P, const SolveOpts& O, vd:
             c.invalid_run = 0;
             if (sqrt(sn) <= O.parameter_tolerance * (sqrt(xn) + O.parameter_tolerance)) { c.done = 1; c.term = 3; }
         }
+        // persistent solve: the time cap is looked at HERE (k_solve's tail looked at it a microsecond later), so that what the next iteration's sweep roles wait for can
+        // leave with the candidate: the step just formed was never judged -- not an iteration of the summary
+        if (FUSED && deadline_tick > 0 && !c.done && (long long)wall_clock64() > deadline_tick) { c.done = 1; c.term = 5; if (c.iter > 0 && !c.resweep) c.iter--; s.hdr_posted = 2; }
     }
     __syncthreads();
+    // persistent solve: the hand-over line of the next iteration's sweep roles goes out with (in front of) the candidate's tagged words -- they are all a sweep role reads of this
+    // iteration (Ctl itself, and the word the step roles wait for, still leave through k_solve's tail) -- once the helpers' la / lb are known to be out (s.pad0_: their
+    // flags were collected under the dogleg's scalars; otherwise the tail collects them and posts the line as before).  1.5 us earlier than behind the tail's barriers.
+    if constexpr (FUSED) {
+        if (P.persist && bid == 0 && !s.c.done && s.pad0_ == epoch) {
+            post_iter_header(P, s.c, epoch);
+            if (t == 0) { s.hdr_posted = 1; prof_stamp(P, lidx, 25); }
+        }
+    }
     {   // the candidate's camera part leaves in one pass (a re-sweep: the current state again)
         const bool back = s.c.resweep && !s.c.done;
         for (int i = t; i < 16 * P.K + 8; i += NT) stx<FUSED>(xc + i, back ? s.x0[i] : xcs[i]);
