@@ -302,7 +302,8 @@ int vil_debug_fail_graph_capture(vil_ctx* ctx, int32_t n);
  * launch per trust-region iteration each.  One window keeps a single master workgroup busy for two thirds of an iteration; n of them interleave on the device -- what a
  * server that tracks several sessions on one GPU runs, and the single-GPU form of the `replicas` leg of bench.py --gpus N.  statuses[i] / summaries[i]: as
  * vil_solve_resident of context i; every window's result is bit-equal to its solo solve under vil_debug_set_launch_mode(4).  More windows than the device holds
- * waiting workgroups for are solved in groups.  Returns the first non-zero status. */
+ * waiting workgroups for are solved in groups: the waiting workgroups of a group fit the device per XCD and take at most half of it, counting the launches the runtime
+ * runs together (its hardware queues: four, or GPU_MAX_HW_QUEUES).  Returns the first non-zero status. */
 int vil_solve_batch(vil_ctx** ctxs, int32_t n, const vil_options* options, vil_summary* summaries, int32_t* statuses);
 /* Recovery of a one-launch solve whose workgroups could not all run together.  The one-launch iteration's roles wait for one another inside the launch; every such
  * wait is bounded by TIME (50 ms of the device's 100 MHz wall clock).  A wait that gives up ends the launches at once; vil_solve_resident / vil_solve / vil_win_solve
